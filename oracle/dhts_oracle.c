@@ -1,0 +1,635 @@
+/*
+ * dhts_oracle.c -- CPU restatement of the reference's hot path.  TEST INFRASTRUCTURE ONLY
+ * (see dhts_oracle.h).  Build: gcc -O2 -ffp-contract=off -fPIC -shared (oracle/Makefile).
+ *
+ * Every function cites the reference file:line it restates.  Arithmetic follows the reference's
+ * evaluation order operation by operation: the reference runs the step in Python floats (IEEE double,
+ * `**`/pow = libm pow) on float32-valued inputs, rounds state and Jacobian entries to float32 on store,
+ * and multiplies 2x2 blocks / applies the adjoint in float32 (NumPy).  -ffp-contract=off keeps the
+ * compiler from fusing a*b+c, which neither CPython nor NumPy's 2x2 matmul does.
+ */
+#include "dhts_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define GAMMA 0.5      /* model/macro/_arz.py:1 */
+#define EPSILON 1e-5   /* model/macro/_arz.py:2 */
+
+/* Python's max(a, b): b if b > a else a */
+static inline double py_max(double a, double b) { return (b > a) ? b : a; }
+
+/* ------------------------------------------------------------------------------------------------
+ * ARZ helpers in double (Python floats).  model/macro/_arz.py:121-149
+ * ---------------------------------------------------------------------------------------------- */
+static double arz_u_eq(double r, double u_max) {           /* compute_u_eq :133-138 */
+    r = py_max(r, 0.);
+    return u_max * (1. - pow(r + EPSILON, GAMMA));
+}
+static double arz_u_eq_prime(double r, double u_max) {     /* compute_u_eq_prime :146-149 */
+    r = py_max(r, EPSILON);
+    return -u_max * GAMMA * pow(r, GAMMA - 1);
+}
+static double arz_y(double r, double u, double u_max) {    /* compute_y :121-124 */
+    double u_eq = arz_u_eq(r, u_max);
+    return r * (u - u_eq);
+}
+static double arz_u(double r, double y, double u_max) {    /* compute_u :126-131 */
+    r = py_max(r, EPSILON);
+    double u_eq = arz_u_eq(r, u_max);
+    return (y / r) + u_eq;
+}
+
+typedef struct { double r, y, u, ueq; } fullq;
+
+static double lambda_0(const fullq *q, double u_max) {     /* FullQ.lambda_0 :103-104 */
+    return q->u + q->r * arz_u_eq_prime(q->r, u_max);
+}
+
+static fullq compute_Ql(const fullq *QL, double u_max) {   /* :155-165 (set_r_y on floats :88-92) */
+    fullq n;
+    n.u = arz_u(QL->r, QL->y, u_max);
+    n.r = QL->r;
+    n.y = QL->y;
+    n.ueq = arz_u_eq(QL->r, u_max);
+    return n;
+}
+static fullq compute_Qc(const fullq *QL, double u_max) {   /* :167-182 */
+    const double g = GAMMA;
+    fullq c;
+    c.r = pow((QL->u + u_max * pow(QL->r, g)) / ((g + 1) * u_max), 1.0 / g);
+    c.u = (g / (g + 1)) * (QL->u + u_max * pow(QL->r, g));
+    c.y = arz_y(c.r, c.u, u_max);
+    c.ueq = arz_u_eq(c.r, u_max);
+    return c;
+}
+static fullq compute_Qm(const fullq *QL, const fullq *QR, double u_max) {  /* :184-199 */
+    const double g = GAMMA;
+    fullq m;
+    m.r = pow(pow(QL->r, g) + ((QL->u - QR->u) / u_max), 1.0 / g);
+    m.u = QR->u;
+    m.y = arz_y(m.r, m.u, u_max);
+    m.ueq = arz_u_eq(m.r, u_max);
+    return m;
+}
+
+/* model/macro/_arz.py:212-332 */
+static void riemann(const fullq *QL, const fullq *QR, double u_max, int *case_ind, fullq *Q0, double *s0, double *s1) {
+    int ci;
+    double speed0, speed1;
+    if (QL->r < EPSILON) {                                 /* :225-230 */
+        speed0 = 0.0;
+        speed1 = QL->u;
+        ci = 0;
+    } else if (QR->r < EPSILON) {                          /* :233-249 */
+        double qm_u = u_max + QL->u - QL->ueq;             /* FullQ.from_r_u(0, ., u_max).u */
+        double l0l = lambda_0(QL, u_max);
+        double l0m = qm_u;
+        speed0 = (l0l + l0m) * 0.5;
+        speed1 = speed0;
+        ci = (l0l >= 0.0) ? 0 : 2;
+    } else if (fabs(QL->u - QR->u) < EPSILON) {            /* :252-257 */
+        speed0 = 0.0;
+        speed1 = QR->u;
+        ci = 0;
+    } else if (QL->u > QR->u) {                            /* :260-274 */
+        fullq Qm = compute_Qm(QL, QR, u_max);
+        double flux_r_diff = Qm.r * Qm.u - QL->r * QL->u;
+        speed0 = flux_r_diff / py_max(Qm.r - QL->r, EPSILON);
+        speed1 = QR->u;
+        ci = (speed0 >= 0.0) ? 0 : 1;
+    } else if (u_max + QL->u - QL->ueq > QR->u) {          /* :277-296 */
+        fullq Qm = compute_Qm(QL, QR, u_max);
+        double l0l = lambda_0(QL, u_max);
+        double l0m = lambda_0(&Qm, u_max);
+        speed0 = (l0l + l0m) * 0.5;
+        speed1 = QR->u;
+        if (l0l >= 0) ci = 0;
+        else if (l0m <= 0) ci = 1;
+        else ci = 2;
+    } else {                                               /* :299-314 */
+        double qm_u = u_max + QL->u - QL->ueq;
+        double l0l = lambda_0(QL, u_max);
+        double l0m = qm_u;
+        speed0 = (l0l + l0m) * 0.5;
+        speed1 = QR->u;
+        ci = (l0l >= 0.0) ? 0 : 2;
+    }
+    if (ci == 0) *Q0 = compute_Ql(QL, u_max);              /* :316-326 */
+    else if (ci == 1) *Q0 = compute_Qm(QL, QR, u_max);
+    else *Q0 = compute_Qc(QL, u_max);
+    *case_ind = ci;
+    *s0 = speed0;
+    *s1 = speed1;
+}
+
+void oracle_arz_riemann(const double L[4], const double R[4], double u_max, int *case_ind, double q0[4], double speed[2]) {
+    fullq QL = {L[0], L[1], L[2], L[3]}, QR = {R[0], R[1], R[2], R[3]}, Q0;
+    riemann(&QL, &QR, u_max, case_ind, &Q0, &speed[0], &speed[1]);
+    q0[0] = Q0.r; q0[1] = Q0.y; q0[2] = Q0.u; q0[3] = Q0.ueq;
+}
+
+/* model/macro/darz.py:12-33 */
+static void compute_dL(float dL[4], float dR[4]) {
+    dL[0] = 1.f; dL[1] = 0.f; dL[2] = 0.f; dL[3] = 1.f;
+    dR[0] = dR[1] = dR[2] = dR[3] = 0.f;
+}
+/* model/macro/darz.py:35-122 */
+static void compute_dM(const fullq *Qm, const fullq *QL, const fullq *QR, double u_max, float dL[4], float dR[4]) {
+    const double gamma = GAMMA;
+    double r_L = py_max(QL->r, EPSILON);
+    double r_R = py_max(QR->r, EPSILON);
+    double y_L = QL->y, y_R = QR->y;
+    double r_M = Qm->r, u_M = Qm->u, ueq_M = Qm->ueq;
+    double ueq_prime_M = arz_u_eq_prime(r_M, u_max);
+
+    double duL_drL = -y_L / pow(r_L, 2) + arz_u_eq_prime(r_L, u_max);
+    double duL_dyL = 1.0 / r_L;
+    double duR_drR = -y_R / pow(r_R, 2) + arz_u_eq_prime(r_R, u_max);
+    double duR_dyR = 1.0 / r_R;
+
+    double a = (1.0 / gamma) * pow(r_M, 1.0 - gamma);
+    double b = gamma * pow(r_L, gamma - 1.0);
+    double c = (1.0 / u_max) * (duL_drL);
+    double drM_drL = a * (b + c);
+    double d = (1.0 / u_max) * (duL_dyL);
+    double drM_dyL = a * d;
+    double e = u_M - ueq_M;
+    double dyM_drL = drM_drL * e + r_M * (-ueq_prime_M * drM_drL);
+    double dyM_dyL = drM_dyL * e + r_M * (-ueq_prime_M * drM_dyL);
+
+    double f = (-1.0 / u_max) * duR_drR;
+    double drM_drR = a * f;
+    double g = (-1.0 / u_max) * duR_dyR;
+    double drM_dyR = a * g;
+    double dyM_drR = drM_drR * e + r_M * (duR_drR - ueq_prime_M * drM_drR);
+    double dyM_dyR = drM_dyR * e + r_M * (duR_dyR - ueq_prime_M * drM_dyR);
+
+    dL[0] = (float)drM_drL; dL[1] = (float)drM_dyL; dL[2] = (float)dyM_drL; dL[3] = (float)dyM_dyL;
+    dR[0] = (float)drM_drR; dR[1] = (float)drM_dyR; dR[2] = (float)dyM_drR; dR[3] = (float)dyM_dyR;
+}
+/* model/macro/darz.py:124-192 */
+static void compute_dC(const fullq *Qc, const fullq *QL, double u_max, float dL[4], float dR[4]) {
+    const double gamma = GAMMA;
+    double r_L = py_max(QL->r, EPSILON);
+    double y_L = QL->y;
+    double ueq_prime_L = arz_u_eq_prime(r_L, u_max);
+    double r_C = Qc->r, u_C = Qc->u, ueq_C = Qc->ueq;
+    double ueq_prime_C = arz_u_eq_prime(r_C, u_max);
+
+    double duL_drL = -y_L / pow(r_L, 2) + ueq_prime_L;
+    double duL_dyL = 1.0 / (r_L);
+    double f = u_max * gamma * pow(r_L, gamma - 1.0);
+    double duC_drL = (gamma / (gamma + 1)) * (duL_drL + f);
+    double duC_dyL = (gamma / (gamma + 1)) * duL_dyL;
+
+    double b = (gamma + 1) * u_max;
+    double c = pow(r_C, 1.0 - gamma);
+    double d = c / gamma;
+    double e = d / b;
+    double drC_drL = e * (duL_drL + f);
+    double drC_dyL = e * (duL_dyL);
+    double g = u_C - ueq_C;
+    double dyC_drL = drC_drL * g + r_C * (duC_drL - ueq_prime_C * drC_drL);
+    double dyC_dyL = drC_dyL * g + r_C * (duC_dyL - ueq_prime_C * drC_dyL);
+
+    dL[0] = (float)drC_drL; dL[1] = (float)drC_dyL; dL[2] = (float)dyC_drL; dL[3] = (float)dyC_dyL;
+    dR[0] = dR[1] = dR[2] = dR[3] = 0.f;
+}
+static void dLdR(int ci, const fullq *Q0, const fullq *QL, const fullq *QR, double u_max, float dL[4], float dR[4]) {
+    if (ci == 0) compute_dL(dL, dR);                       /* darz.py:194-215 */
+    else if (ci == 1) compute_dM(Q0, QL, QR, u_max, dL, dR);
+    else compute_dC(Q0, QL, u_max, dL, dR);
+}
+/* model/macro/darz.py:217-233 */
+static void flux_prime(const fullq *q, double u_max, float fp[4]) {
+    double r = py_max(q->r, EPSILON);
+    double y = q->y;
+    double ueq = q->ueq;
+    double ueq_prime = arz_u_eq_prime(r, u_max);
+    fp[0] = (float)(ueq + r * ueq_prime);
+    fp[1] = 1.f;
+    fp[2] = (float)(y * ueq_prime - pow(y / r, 2));
+    fp[3] = (float)((2.0 * y) / r + ueq);
+}
+
+void oracle_arz_dLdR(int ci, const double q0[4], const double L[4], const double R[4], double u_max, float dL[4], float dR[4]) {
+    fullq Q0 = {q0[0], q0[1], q0[2], q0[3]}, QL = {L[0], L[1], L[2], L[3]}, QR = {R[0], R[1], R[2], R[3]};
+    dLdR(ci, &Q0, &QL, &QR, u_max, dL, dR);
+}
+void oracle_arz_flux_prime(const double q0[4], double u_max, float fp[4]) {
+    fullq Q0 = {q0[0], q0[1], q0[2], q0[3]};
+    flux_prime(&Q0, u_max, fp);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * float32 glue: the same helpers evaluated on 0-dim float32 torch tensors (every op rounded to
+ * float32, Python scalars cast to float32; torch.pow(x, 0.5) == sqrt on the reference's build).
+ * model/macro/_arz.py:82-92 with :121-138
+ * ---------------------------------------------------------------------------------------------- */
+static float glue_u_eq(float r, float u_max) {
+    if (0.f > r) {
+        /* max(r, 0.) picked the Python float 0. -> the rest is double, cast where it meets a tensor */
+        return (float)((double)u_max * (1. - pow(0. + EPSILON, GAMMA)));
+    }
+    float t = r + (float)EPSILON;
+    t = sqrtf(t);
+    t = 1.f - t;
+    return u_max * t;
+}
+void oracle_arz_from_r_u(float r, float u, float u_max, float *y, float *u_eq) {
+    float ueq = glue_u_eq(r, u_max);
+    *y = r * (u - ueq);
+    *u_eq = ueq;
+}
+void oracle_arz_from_r_y(float r, float y, float u_max, float *u, float *u_eq) {
+    if (r < (float)EPSILON) {
+        /* max(r, EPSILON) picked the Python float: u_eq(1e-5) in double, then float32 tensor ops */
+        double ueq_c = (double)u_max * (1. - pow(EPSILON + EPSILON, GAMMA));
+        *u = y / (float)EPSILON + (float)ueq_c;
+    } else {
+        *u = y / r + glue_u_eq(r, u_max);
+    }
+    *u_eq = glue_u_eq(r, u_max);
+}
+
+/* backward of the glue as torch autograd evaluates it (float32):
+ *   u = y / rc + u_max * (1 - (rc + eps)^0.5),  rc = r if r >= eps else const          */
+static void glue_u_bwd(float r, float y, float u_max, float g_u, float *g_r, float *g_y) {
+    if (r < (float)EPSILON) {
+        *g_y += g_u / (float)EPSILON;
+        return;
+    }
+    *g_y += g_u / r;
+    float gd = -g_u * ((y / r) / r);                         /* div backward wrt divisor */
+    float gp = 0.f;
+    if (!(0.f > r)) {
+        float t = r + (float)EPSILON;
+        float gm = g_u * u_max;                            /* mul by u_max */
+        float gs = -gm;                                    /* 1 - x */
+        gp = gs * (0.5f * powf(t, -0.5f));                 /* pow backward: g * (e * x^(e-1)) */
+    }
+    *g_r += gd + gp;
+}
+/* y = r * (u - u_eq(r)) */
+static void glue_y_bwd(float r, float u, float u_max, float g_y, float *g_r, float *g_u) {
+    float ueq = glue_u_eq(r, u_max);
+    float diff = u - ueq;
+    float g_diff = g_y * r;
+    *g_u += g_diff;
+    float acc = g_y * diff;
+    if (!(0.f > r)) {
+        float t = r + (float)EPSILON;
+        float g_ueq = -g_diff;
+        float gm = g_ueq * u_max;
+        float gs = -gm;
+        acc += gs * (0.5f * powf(t, -0.5f));
+    }
+    *g_r += acc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * one lane step.  road/lane/_macro_lane.py:83-146 + road/lane/dmacro_lane.py:96-132,236-275
+ * ---------------------------------------------------------------------------------------------- */
+/* np.matmul on float32 2x2 blocks (dmacro_lane.py:126-129).  NumPy's float32 matmul (OpenBLAS sgemm on an
+ * FMA machine) accumulates acc = a0*b0 (rounded), acc = fma(a1, b1, acc): measured bit-for-bit on 20 000 random
+ * 2x2 pairs in the build container, for the stacked (N,3,2,2)@(N,1,2,1) form of the backward as well. */
+static inline float dot2(float a0, float b0, float a1, float b1) { return fmaf(a1, b1, a0 * b0); }
+static void matmul22(const float a[4], const float b[4], float o[4]) {
+    o[0] = dot2(a[0], b[0], a[1], b[2]);
+    o[1] = dot2(a[0], b[1], a[1], b[3]);
+    o[2] = dot2(a[2], b[0], a[3], b[2]);
+    o[3] = dot2(a[2], b[1], a[3], b[3]);
+}
+
+int oracle_macro_step(int N, const float *r, const float *y, const float *u, const float *ueq,
+                      double dt, double dx, double u_max,
+                      float *nr, float *ny, float *nu, float *nueq, float *dqs,
+                      int *case_out, double *speed_out, int *err_index) {
+    int rc = ORACLE_OK;
+    int nI = N + 1;
+    fullq *Q0 = (fullq *)malloc(sizeof(fullq) * nI);
+    int *ci = (int *)malloc(sizeof(int) * nI);
+    for (int i = 0; i < nI; i++) {                         /* _solve_riemann :116-146 */
+        fullq QL = {r[i], y[i], u[i], ueq[i]};
+        fullq QR = {r[i + 1], y[i + 1], u[i + 1], ueq[i + 1]};
+        double s0, s1;
+        riemann(&QL, &QR, u_max, &ci[i], &Q0[i], &s0, &s1);
+        if (case_out) case_out[i] = ci[i];
+        if (speed_out) { speed_out[2 * i] = s0; speed_out[2 * i + 1] = s1; }
+        double a0 = py_max(fabs(s0), 1e-5), a1 = py_max(fabs(s1), 1e-5);
+        if (!((dt < dx / a0) && (dt < dx / a1)) && rc == ORACLE_OK) {
+            rc = ORACLE_ERR_CFL;
+            if (err_index) *err_index = i;
+        }
+    }
+    double c = dt / dx;                                    /* update_coefficient :99 */
+    float cf = (float)c, ncf = (float)(-c);
+    for (int k = 0; k < N; k++) {
+        const fullq *qL = &Q0[k], *qR = &Q0[k + 1];
+        /* :109-112  curr.q + (F(Q0_L) - F(Q0_R)) * c */
+        double fr = (qL->r * qL->u - qR->r * qR->u) * c;
+        double fy = (qL->y * qL->u - qR->y * qR->u) * c;
+        float nrk = (float)((double)r[k + 1] + fr);        /* float32 store: get_next_state_vector :327-334 */
+        float nyk = (float)((double)y[k + 1] + fy);
+        nr[k] = nrk;
+        ny[k] = nyk;
+        if (nu && nueq) oracle_arz_from_r_y(nrk, nyk, (float)u_max, &nu[k], &nueq[k]);   /* set_next_state_vector_y */
+        if (dqs) {                                         /* dMacroLane._backward :96-132 */
+            fullq cl = {r[k], y[k], u[k], ueq[k]};
+            fullq ct = {r[k + 1], y[k + 1], u[k + 1], ueq[k + 1]};
+            fullq cr = {r[k + 2], y[k + 2], u[k + 2], ueq[k + 2]};
+            float LdL[4], LdR[4], RdL[4], RdR[4], fpL[4], fpR[4], m[4], m2[4];
+            dLdR(ci[k], qL, &cl, &ct, u_max, LdL, LdR);
+            dLdR(ci[k + 1], qR, &ct, &cr, u_max, RdL, RdR);
+            flux_prime(qL, u_max, fpL);
+            flux_prime(qR, u_max, fpR);
+            float *d = dqs + (size_t)k * 12;
+            matmul22(fpL, LdL, m);                         /* dqs[ci,0] = -c * (-(fp_L @ rs_L_dL)) */
+            for (int j = 0; j < 4; j++) d[j] = ncf * (-m[j]);
+            matmul22(fpR, RdR, m);                         /* dqs[ci,2] = -c * (fp_R @ rs_R_dR) */
+            for (int j = 0; j < 4; j++) d[8 + j] = ncf * m[j];
+            matmul22(fpR, RdL, m);                         /* dqs[ci,1] = I - c * (fp_R@rs_R_dL - fp_L@rs_L_dR) */
+            matmul22(fpL, LdR, m2);
+            for (int j = 0; j < 4; j++) {
+                float eye = (j == 0 || j == 3) ? 1.f : 0.f;
+                d[4 + j] = eye - cf * (m[j] - m2[j]);
+            }
+        }
+    }
+    free(Q0);
+    free(ci);
+    return rc;
+}
+
+/* road/lane/dmacro_lane.py:277-309 */
+void oracle_macro_step_bwd(int N, const float *dqs, const float *g_nr, const float *g_ny, float *g_r, float *g_y) {
+    /* grad_cell[a][k] = dqs[a][k]^T @ (g_nr[a], g_ny[a]) */
+    float *gc = (float *)malloc(sizeof(float) * (size_t)N * 6);
+    for (int a = 0; a < N; a++)
+        for (int k = 0; k < 3; k++) {
+            const float *d = dqs + (size_t)a * 12 + k * 4;
+            gc[a * 6 + k * 2 + 0] = dot2(d[0], g_nr[a], d[2], g_ny[a]);
+            gc[a * 6 + k * 2 + 1] = dot2(d[1], g_nr[a], d[3], g_ny[a]);
+        }
+    for (int c = 0; c < 2; c++) {
+        float *g = c ? g_y : g_r;
+        for (int i = 0; i < N + 2; i++) g[i] = 0.f;
+        for (int a = 0; a < N; a++) g[a + 1] = gc[a * 6 + 2 + c];                 /* grad_ry[1:-1] = k=1 */
+        for (int a = 0; a + 1 < N; a++) g[a + 2] += gc[a * 6 + 4 + c];            /* grad_ry[2:-1] += k=2 of a */
+        for (int a = 1; a < N; a++) g[a] += gc[a * 6 + 0 + c];                    /* grad_ry[1:-2] += k=0 of a */
+        g[0] = gc[0 + c];                                                          /* boundaries */
+        g[N + 1] = gc[(N - 1) * 6 + 4 + c];
+    }
+    free(gc);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * batched straight-lane rollout: per lane what RoadNetwork.forward does for one dMacroLane without
+ * neighbours (road/network/road_network.py:79-111, 299-387): ghosts re-derived from their (r, u)
+ * every step (float32 from_r_u), lane step, commit.
+ * ---------------------------------------------------------------------------------------------- */
+int oracle_macro_rollout_fwd(int L, int N, int T, double dt, double dx, double u_max,
+                             const float *r0, const float *u0, const float *ghost_r, const float *ghost_u,
+                             float *rT, float *yT, float *uT, float *tape,
+                             float *hist_r, float *hist_y, float *hist_u) {
+    int rc = ORACLE_OK;
+    size_t P = (size_t)N + 2;
+    float *buf = (float *)malloc(sizeof(float) * P * 8);
+    float *r = buf, *y = buf + P, *u = buf + 2 * P, *q = buf + 3 * P;
+    float *nr = buf + 4 * P, *ny = buf + 5 * P, *nu = buf + 6 * P, *nq = buf + 7 * P;
+    for (int l = 0; l < L; l++) {
+        for (int i = 0; i < N; i++) {                      /* set_state_vector_u :246-263 */
+            r[i + 1] = r0[(size_t)l * N + i];
+            u[i + 1] = u0[(size_t)l * N + i];
+            oracle_arz_from_r_u(r[i + 1], u[i + 1], (float)u_max, &y[i + 1], &q[i + 1]);
+        }
+        r[0] = ghost_r[l * 2]; u[0] = ghost_u[l * 2];
+        r[N + 1] = ghost_r[l * 2 + 1]; u[N + 1] = ghost_u[l * 2 + 1];
+        oracle_arz_from_r_u(r[0], u[0], (float)u_max, &y[0], &q[0]);
+        oracle_arz_from_r_u(r[N + 1], u[N + 1], (float)u_max, &y[N + 1], &q[N + 1]);
+        for (int t = 0; t < T; t++) {
+            float *d = tape ? tape + ((size_t)t * L + l) * N * 12 : NULL;
+            int e = oracle_macro_step(N, r, y, u, q, dt, dx, u_max, nr, ny, nu, nq, d, NULL, NULL, NULL);
+            if (e && !rc) rc = e;
+            memcpy(r + 1, nr, sizeof(float) * N);          /* update_state :202-213 */
+            memcpy(y + 1, ny, sizeof(float) * N);
+            memcpy(u + 1, nu, sizeof(float) * N);
+            memcpy(q + 1, nq, sizeof(float) * N);
+            size_t ho = ((size_t)t * L + l) * N;
+            if (hist_r) memcpy(hist_r + ho, nr, sizeof(float) * N);
+            if (hist_y) memcpy(hist_y + ho, ny, sizeof(float) * N);
+            if (hist_u) memcpy(hist_u + ho, nu, sizeof(float) * N);
+        }
+        memcpy(rT + (size_t)l * N, r + 1, sizeof(float) * N);
+        memcpy(yT + (size_t)l * N, y + 1, sizeof(float) * N);
+        memcpy(uT + (size_t)l * N, u + 1, sizeof(float) * N);
+    }
+    free(buf);
+    return rc;
+}
+
+void oracle_macro_rollout_bwd(int L, int N, int T, double u_max,
+                              const float *tape, const float *r0, const float *u0,
+                              const float *ghost_r, const float *ghost_u,
+                              const float *rT, const float *yT,
+                              const float *g_rT, const float *g_yT, const float *g_uT,
+                              const float *hist_r, const float *hist_y,
+                              const float *gh_r, const float *gh_y, const float *gh_u,
+                              float *g_r0, float *g_u0, float *g_ghost_r, float *g_ghost_u) {
+    size_t P = (size_t)N + 2;
+    float *buf = (float *)malloc(sizeof(float) * P * 4);
+    float *gr = buf, *gy = buf + P, *ngr = buf + 2 * P, *ngy = buf + 3 * P;
+    float um = (float)u_max;
+    for (int l = 0; l < L; l++) {
+        size_t lo = (size_t)l * N;
+        double ggl[2] = {0., 0.}, ggr[2] = {0., 0.};   /* cotangent on ghost (r, y), left / right */
+        for (int i = 0; i < N; i++) {                      /* loss taps on the final (r, y, u) */
+            gr[i] = g_rT ? g_rT[lo + i] : 0.f;
+            gy[i] = g_yT ? g_yT[lo + i] : 0.f;
+            if (g_uT) glue_u_bwd(rT[lo + i], yT[lo + i], um, g_uT[lo + i], &gr[i], &gy[i]);
+        }
+        for (int t = T - 1; t >= 0; t--) {
+            size_t ho = ((size_t)t * L + l) * N;
+            /* per-step taps on the state after step t (at t = T-1 they add to the final taps) */
+            for (int i = 0; i < N; i++) {
+                if (gh_r) gr[i] += gh_r[ho + i];
+                if (gh_y) gy[i] += gh_y[ho + i];
+                if (gh_u) glue_u_bwd(hist_r[ho + i], hist_y[ho + i], um, gh_u[ho + i], &gr[i], &gy[i]);
+            }
+            oracle_macro_step_bwd(N, tape + ho * 12, gr, gy, ngr, ngy);
+            /* ghost (r, y) cotangents of this step.  In the reference they flow through FullQ.from_r_u's float32
+             * graph to the ghost (r, u) leaves and are summed by autograd in engine order (road_network.py:372-387).
+             * The sum is ill-conditioned (terms cancel ~40:1 over a rollout), so its float32 value depends on that
+             * order; the restatement accumulates in double, which lands within the order noise of the reference. */
+            ggl[0] += ngr[0]; ggl[1] += ngy[0];
+            ggr[0] += ngr[N + 1]; ggr[1] += ngy[N + 1];
+            memcpy(gr, ngr + 1, sizeof(float) * N);
+            memcpy(gy, ngy + 1, sizeof(float) * N);
+        }
+        for (int i = 0; i < N; i++) {                      /* initial (r0, u0) -> (r0, y0) glue */
+            float a = gr[i], b = 0.f;
+            glue_y_bwd(r0[lo + i], u0[lo + i], um, gy[i], &a, &b);
+            g_r0[lo + i] = a;
+            g_u0[lo + i] = b;
+        }
+        for (int s = 0; s < 2; s++) {                      /* y = r * (u - u_eq(r)) in double */
+            double gr_ = s ? ggr[0] : ggl[0], gy_ = s ? ggr[1] : ggl[1];
+            double rr = ghost_r[l * 2 + s], uu = ghost_u[l * 2 + s];
+            double ueq = (double)glue_u_eq((float)rr, um);
+            double dueq = (0. > rr) ? 0. : -u_max * 0.5 / sqrt(rr + EPSILON);
+            g_ghost_r[l * 2 + s] = (float)(gr_ + gy_ * ((uu - ueq) - rr * dueq));
+            g_ghost_u[l * 2 + s] = (float)(gy_ * rr);
+        }
+    }
+    free(buf);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * IDM.  model/micro/_idm.py:6-50, model/micro/didm.py:13-103
+ * ---------------------------------------------------------------------------------------------- */
+#define IDM_DELTA 4.0
+
+double oracle_idm_acc(double a_max, double a_pref, double v, double v_target, double dp, double dv,
+                      double min_space, double time_pref, double dt, double *sstar, int flags[2]) {
+    double s = (min_space + v * time_pref + ((v * dv) / (2 * pow(a_max * a_pref, 0.5))));
+    int clipped_s = (s < 0.0);
+    s = py_max(s, 0);
+    double acc = a_max * (1.0 - pow(v / v_target, IDM_DELTA) - pow((s / dp), 2.0));
+    int clipped_a = (acc < -v / dt);
+    acc = py_max(acc, -v / dt);
+    *sstar = s;
+    flags[0] = clipped_a;
+    flags[1] = clipped_s;
+    return acc;
+}
+
+void oracle_idm_jac(double a_max, double a_pref, double v, double v_target, double dp, double dv,
+                    double min_space, double time_pref, double s, double dt, const int flags[2],
+                    float dE[4], float dLd[4]) {
+    (void)min_space;
+    dE[0] = 1.f; dE[1] = (float)dt; dE[2] = 0.f; dE[3] = 0.f;
+    dLd[0] = dLd[1] = dLd[2] = dLd[3] = 0.f;
+    if (!flags[0]) {
+        dE[2] = (float)(dt * (-2 * a_max * (pow(s, 2) / pow(dp, 3))));
+        if (flags[1])
+            dE[3] = (float)(1 + dt * a_max * (-IDM_DELTA * (pow(v, (IDM_DELTA - 1)) / pow(v_target, IDM_DELTA))));
+        else
+            dE[3] = (float)(1 + dt * a_max * (-IDM_DELTA * (pow(v, (IDM_DELTA - 1)) / pow(v_target, IDM_DELTA))
+                                             - 2 * (s / pow(dp, 2)) * (time_pref + ((v + dv) / (2 * sqrt(a_max * a_pref))))));
+        dLd[2] = (float)(dt * (2 * a_max * (pow(s, 2) / pow(dp, 3))));
+        if (flags[1])
+            dLd[3] = (float)(dt * a_max * (-2 * (s / pow(dp, 2))));
+        else
+            dLd[3] = (float)(dt * a_max * (-2 * (s / pow(dp, 2)) * (-v / (2 * sqrt(a_max * a_pref)))));
+    }
+}
+
+/* road/lane/_micro_lane.py:131-214 + road/lane/dmicro_lane.py:87-127 */
+int oracle_micro_step(int V, const float *p, const float *v, const double *params,
+                      double head_dp, double head_dv, double dt,
+                      float *np_, float *nv_, float *dqs, int *err_index) {
+    int rc = ORACLE_OK;
+    for (int i = 0; i < V; i++) {
+        const double *pr = params + (size_t)i * 6;
+        double dp, dv;
+        if (i == V - 1) {                                  /* compute_state_delta :195-214 */
+            dp = head_dp;
+            dv = head_dv;
+        } else {
+            const double *pl = params + (size_t)(i + 1) * 6;
+            dp = fabs((double)p[i + 1] - (double)p[i]) - ((pl[5] + pr[5]) * 0.5);
+            dv = (double)v[i] - (double)v[i + 1];
+        }
+        double dp_raw = dp, dv_raw = dv;
+        if (dp < 0) {                                      /* :151-162: printed, deltas zeroed */
+            if (rc == ORACLE_OK) { rc = ORACLE_ERR_COLLISION; if (err_index) *err_index = i; }
+            dp = 0; dv = 0;
+        }
+        double dpc = py_max(dp, 1e-5);                     /* :166 */
+        double s; int fl[2];
+        double acc = oracle_idm_acc(pr[0], pr[1], v[i], pr[2], dpc, dv, pr[3], pr[4], dt, &s, fl);
+        np_[i] = (float)((double)p[i] + dt * (double)v[i]);     /* :182-183, float32 store :280-285 */
+        nv_[i] = (float)((double)v[i] + dt * acc);
+        if (dqs)                                           /* _backward uses the un-clamped deltas: dmicro_lane.py:97 */
+            oracle_idm_jac(pr[0], pr[1], v[i], pr[2], dp_raw, dv_raw, pr[3], pr[4], s, dt, fl,
+                           dqs + (size_t)i * 8, dqs + (size_t)i * 8 + 4);
+    }
+    return rc;
+}
+
+/* road/lane/dmicro_lane.py:271-298 */
+void oracle_micro_step_bwd(int V, const float *dqs, const float *g_np, const float *g_nv, float *g_p, float *g_v) {
+    for (int i = 0; i <= V; i++) g_p[i] = g_v[i] = 0.f;
+    for (int a = 0; a < V; a++) {                          /* grad_ps[:-1] = k=0 */
+        const float *d = dqs + (size_t)a * 8;
+        g_p[a] = dot2(d[0], g_np[a], d[2], g_nv[a]);
+        g_v[a] = dot2(d[1], g_np[a], d[3], g_nv[a]);
+    }
+    for (int a = 0; a < V; a++) {                          /* grad_ps[1:] += k=1 */
+        const float *d = dqs + (size_t)a * 8 + 4;
+        g_p[a + 1] += dot2(d[0], g_np[a], d[2], g_nv[a]);
+        g_v[a + 1] += dot2(d[1], g_np[a], d[3], g_nv[a]);
+    }
+}
+
+int oracle_micro_rollout_fwd(int L, int V, int T, double dt, const float *p0, const float *v0,
+                             const double *params, double head_dp, double head_dv,
+                             float *pT, float *vT, float *tape, float *hist_p, float *hist_v) {
+    int rc = ORACLE_OK;
+    float *buf = (float *)malloc(sizeof(float) * (size_t)V * 4);
+    float *p = buf, *v = buf + V, *np_ = buf + 2 * V, *nv_ = buf + 3 * V;
+    for (int l = 0; l < L; l++) {
+        memcpy(p, p0 + (size_t)l * V, sizeof(float) * V);
+        memcpy(v, v0 + (size_t)l * V, sizeof(float) * V);
+        for (int t = 0; t < T; t++) {
+            size_t ho = ((size_t)t * L + l) * V;
+            int e = oracle_micro_step(V, p, v, params + (size_t)l * V * 6, head_dp, head_dv, dt, np_, nv_,
+                                      tape ? tape + ho * 8 : NULL, NULL);
+            if (e && !rc) rc = e;
+            memcpy(p, np_, sizeof(float) * V);             /* update_state :216-225 */
+            memcpy(v, nv_, sizeof(float) * V);
+            if (hist_p) memcpy(hist_p + ho, p, sizeof(float) * V);
+            if (hist_v) memcpy(hist_v + ho, v, sizeof(float) * V);
+        }
+        memcpy(pT + (size_t)l * V, p, sizeof(float) * V);
+        memcpy(vT + (size_t)l * V, v, sizeof(float) * V);
+    }
+    free(buf);
+    return rc;
+}
+
+void oracle_micro_rollout_bwd(int L, int V, int T, const float *tape,
+                              const float *g_pT, const float *g_vT, const float *gh_p, const float *gh_v,
+                              float *g_p0, float *g_v0, float *g_head) {
+    float *buf = (float *)malloc(sizeof(float) * (size_t)(V + 1) * 4);
+    float *gp = buf, *gv = buf + (V + 1), *ngp = buf + 2 * (V + 1), *ngv = buf + 3 * (V + 1);
+    for (int l = 0; l < L; l++) {
+        size_t lo = (size_t)l * V;
+        float gh[2] = {0.f, 0.f};
+        for (int i = 0; i < V; i++) {
+            gp[i] = g_pT ? g_pT[lo + i] : 0.f;
+            gv[i] = g_vT ? g_vT[lo + i] : 0.f;
+        }
+        for (int t = T - 1; t >= 0; t--) {
+            size_t ho = ((size_t)t * L + l) * V;
+            for (int i = 0; i < V; i++) {
+                if (gh_p) gp[i] += gh_p[ho + i];
+                if (gh_v) gv[i] += gh_v[ho + i];
+            }
+            oracle_micro_step_bwd(V, tape + ho * 8, gp, gv, ngp, ngv);
+            /* virtual leader slot = (p_head + head_dp, v_head - head_dv): dmicro_lane.py:142-151 */
+            gh[0] += ngp[V];
+            gh[1] -= ngv[V];
+            ngp[V - 1] += ngp[V];
+            ngv[V - 1] += ngv[V];
+            memcpy(gp, ngp, sizeof(float) * V);
+            memcpy(gv, ngv, sizeof(float) * V);
+        }
+        memcpy(g_p0 + lo, gp, sizeof(float) * V);
+        memcpy(g_v0 + lo, gv, sizeof(float) * V);
+        if (g_head) { g_head[l * 2] = gh[0]; g_head[l * 2 + 1] = gh[1]; }
+    }
+    free(buf);
+}

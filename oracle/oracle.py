@@ -1,0 +1,209 @@
+"""ctypes front-end of oracle/libdhts_oracle.so (plain-C restatement, see dhts_oracle.h).
+
+TEST INFRASTRUCTURE ONLY.  Builds the shared object with gcc on first use.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libdhts_oracle.so")
+_lib = None
+
+OK, ERR_CFL, ERR_COLLISION = 0, 1, 2
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "dhts_oracle.c")
+    hdr = os.path.join(_HERE, "dhts_oracle.h")
+    if (not force and os.path.exists(_SO)
+            and os.path.getmtime(_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _SO
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libdhts_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.oracle_idm_acc.restype = C.c_double
+        _lib.oracle_idm_acc.argtypes = [C.c_double] * 9 + [C.c_void_p, C.c_void_p]
+        _lib.oracle_idm_jac.argtypes = [C.c_double] * 10 + [C.c_void_p] * 3
+        _lib.oracle_arz_riemann.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.oracle_arz_dLdR.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+        _lib.oracle_arz_flux_prime.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
+        _lib.oracle_arz_from_r_u.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        _lib.oracle_arz_from_r_y.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        _lib.oracle_macro_step.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_double] * 3 + [C.c_void_p] * 8
+        _lib.oracle_macro_step_bwd.argtypes = [C.c_int] + [C.c_void_p] * 5
+        _lib.oracle_macro_rollout_fwd.argtypes = [C.c_int] * 3 + [C.c_double] * 3 + [C.c_void_p] * 11
+        _lib.oracle_macro_rollout_bwd.argtypes = [C.c_int] * 3 + [C.c_double] + [C.c_void_p] * 19
+        _lib.oracle_micro_step.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_double] * 3 + [C.c_void_p] * 4
+        _lib.oracle_micro_step_bwd.argtypes = [C.c_int] + [C.c_void_p] * 5
+        _lib.oracle_micro_rollout_fwd.argtypes = [C.c_int] * 3 + [C.c_double] + [C.c_void_p] * 3 + [C.c_double] * 2 + [C.c_void_p] * 5
+        _lib.oracle_micro_rollout_bwd.argtypes = [C.c_int] * 3 + [C.c_void_p] * 8
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# ---- ARZ interface ---------------------------------------------------------------------------------
+def arz_riemann(L, R, u_max):
+    L, R = _f64(L), _f64(R)
+    case = C.c_int(0)
+    q0 = np.zeros(4)
+    sp = np.zeros(2)
+    lib().oracle_arz_riemann(_p(L), _p(R), float(u_max), C.addressof(case), _p(q0), _p(sp))
+    return case.value, q0, sp
+
+
+def arz_dLdR(case, q0, L, R, u_max):
+    dL = np.zeros((2, 2), np.float32)
+    dR = np.zeros((2, 2), np.float32)
+    lib().oracle_arz_dLdR(int(case), _p(_f64(q0)), _p(_f64(L)), _p(_f64(R)), float(u_max), _p(dL), _p(dR))
+    return dL, dR
+
+
+def arz_flux_prime(q0, u_max):
+    fp = np.zeros((2, 2), np.float32)
+    lib().oracle_arz_flux_prime(_p(_f64(q0)), float(u_max), _p(fp))
+    return fp
+
+
+def arz_from_r_u(r, u, u_max):
+    y, q = C.c_float(0), C.c_float(0)
+    lib().oracle_arz_from_r_u(float(r), float(u), float(u_max), C.addressof(y), C.addressof(q))
+    return np.float32(y.value), np.float32(q.value)
+
+
+def arz_from_r_y(r, y, u_max):
+    u, q = C.c_float(0), C.c_float(0)
+    lib().oracle_arz_from_r_y(float(r), float(y), float(u_max), C.addressof(u), C.addressof(q))
+    return np.float32(u.value), np.float32(q.value)
+
+
+# ---- macro lane ------------------------------------------------------------------------------------
+def macro_step(state, dt, dx, u_max, want_tape=True):
+    """state: float32 [4][N+2] = (r, y, u, u_eq) with ghosts.  Returns dict."""
+    st = _f32(state)
+    N = st.shape[1] - 2
+    nr, ny, nu, nq = (np.zeros(N, np.float32) for _ in range(4))
+    dqs = np.zeros((N, 3, 2, 2), np.float32) if want_tape else None
+    case = np.zeros(N + 1, np.int32)
+    speed = np.zeros((N + 1, 2), np.float64)
+    ei = C.c_int(-1)
+    rc = lib().oracle_macro_step(N, _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), float(dt), float(dx), float(u_max),
+                                 _p(nr), _p(ny), _p(nu), _p(nq), _p(dqs), _p(case), _p(speed), C.addressof(ei))
+    return dict(rc=rc, nr=nr, ny=ny, nu=nu, nueq=nq, dqs=dqs, case=case, speed=speed, err_index=ei.value)
+
+
+def macro_step_bwd(dqs, g_nr, g_ny):
+    dqs, g_nr, g_ny = _f32(dqs), _f32(g_nr), _f32(g_ny)
+    N = g_nr.shape[0]
+    g_r, g_y = np.zeros(N + 2, np.float32), np.zeros(N + 2, np.float32)
+    lib().oracle_macro_step_bwd(N, _p(dqs), _p(g_nr), _p(g_ny), _p(g_r), _p(g_y))
+    return g_r, g_y
+
+
+def macro_rollout_fwd(r0, u0, ghost_r, ghost_u, T, dt, dx, u_max, want_tape=True, want_hist=False):
+    r0, u0, ghost_r, ghost_u = _f32(r0), _f32(u0), _f32(ghost_r), _f32(ghost_u)
+    r0 = r0.reshape(-1, r0.shape[-1])
+    u0 = u0.reshape(r0.shape)
+    L, N = r0.shape
+    ghost_r, ghost_u = ghost_r.reshape(L, 2), ghost_u.reshape(L, 2)
+    rT, yT, uT = (np.zeros((L, N), np.float32) for _ in range(3))
+    tape = np.zeros((T, L, N, 3, 2, 2), np.float32) if want_tape else None
+    hr = hy = hu = None
+    if want_hist:
+        hr, hy, hu = (np.zeros((T, L, N), np.float32) for _ in range(3))
+    rc = lib().oracle_macro_rollout_fwd(L, N, T, float(dt), float(dx), float(u_max), _p(r0), _p(u0), _p(ghost_r),
+                                        _p(ghost_u), _p(rT), _p(yT), _p(uT), _p(tape), _p(hr), _p(hy), _p(hu))
+    return dict(rc=rc, rT=rT, yT=yT, uT=uT, tape=tape, hist_r=hr, hist_y=hy, hist_u=hu,
+                r0=r0, u0=u0, ghost_r=ghost_r, ghost_u=ghost_u, T=T, u_max=u_max)
+
+
+def macro_rollout_bwd(fwd, g_rT=None, g_yT=None, g_uT=None, gh_r=None, gh_y=None, gh_u=None):
+    L, N = fwd["r0"].shape
+    T = fwd["T"]
+    g_rT, g_yT, g_uT, gh_r, gh_y, gh_u = map(_f32, (g_rT, g_yT, g_uT, gh_r, gh_y, gh_u))
+    g_r0, g_u0 = np.zeros((L, N), np.float32), np.zeros((L, N), np.float32)
+    g_gr, g_gu = np.zeros((L, 2), np.float32), np.zeros((L, 2), np.float32)
+    lib().oracle_macro_rollout_bwd(L, N, T, float(fwd["u_max"]), _p(fwd["tape"]), _p(fwd["r0"]), _p(fwd["u0"]),
+                                   _p(fwd["ghost_r"]), _p(fwd["ghost_u"]), _p(fwd["rT"]), _p(fwd["yT"]),
+                                   _p(g_rT), _p(g_yT), _p(g_uT), _p(fwd["hist_r"]), _p(fwd["hist_y"]),
+                                   _p(gh_r), _p(gh_y), _p(gh_u), _p(g_r0), _p(g_u0), _p(g_gr), _p(g_gu))
+    return dict(g_r0=g_r0, g_u0=g_u0, g_ghost_r=g_gr, g_ghost_u=g_gu)
+
+
+# ---- IDM / micro lane ------------------------------------------------------------------------------
+def idm_acc(a_max, a_pref, v, v_t, dp, dv, s0, Tp, dt):
+    s = C.c_double(0)
+    fl = (C.c_int * 2)()
+    acc = lib().oracle_idm_acc(a_max, a_pref, v, v_t, dp, dv, s0, Tp, dt, C.addressof(s), C.addressof(fl))
+    return acc, s.value, (fl[0], fl[1])
+
+
+def idm_jac(a_max, a_pref, v, v_t, dp, dv, s0, Tp, sstar, dt, flags):
+    fl = (C.c_int * 2)(int(flags[0]), int(flags[1]))
+    dE, dLd = np.zeros((2, 2), np.float32), np.zeros((2, 2), np.float32)
+    lib().oracle_idm_jac(a_max, a_pref, v, v_t, dp, dv, s0, Tp, sstar, dt, C.addressof(fl), _p(dE), _p(dLd))
+    return dE, dLd
+
+
+def micro_step(p, v, params, head_dp, head_dv, dt, want_tape=True):
+    p, v, params = _f32(p), _f32(v), _f64(params)
+    V = p.shape[0]
+    np_, nv_ = np.zeros(V, np.float32), np.zeros(V, np.float32)
+    dqs = np.zeros((V, 2, 2, 2), np.float32) if want_tape else None
+    ei = C.c_int(-1)
+    rc = lib().oracle_micro_step(V, _p(p), _p(v), _p(params), float(head_dp), float(head_dv), float(dt),
+                                 _p(np_), _p(nv_), _p(dqs), C.addressof(ei))
+    return dict(rc=rc, np=np_, nv=nv_, dqs=dqs, err_index=ei.value)
+
+
+def micro_step_bwd(dqs, g_np, g_nv):
+    dqs, g_np, g_nv = _f32(dqs), _f32(g_np), _f32(g_nv)
+    V = g_np.shape[0]
+    g_p, g_v = np.zeros(V + 1, np.float32), np.zeros(V + 1, np.float32)
+    lib().oracle_micro_step_bwd(V, _p(dqs), _p(g_np), _p(g_nv), _p(g_p), _p(g_v))
+    return g_p, g_v
+
+
+def micro_rollout_fwd(p0, v0, params, T, dt, head_dp=1000.0, head_dv=0.0, want_tape=True, want_hist=False):
+    p0, v0, params = _f32(p0), _f32(v0), _f64(params)
+    p0 = p0.reshape(-1, p0.shape[-1])
+    v0 = v0.reshape(p0.shape)
+    L, V = p0.shape
+    params = params.reshape(L, V, 6)
+    pT, vT = np.zeros((L, V), np.float32), np.zeros((L, V), np.float32)
+    tape = np.zeros((T, L, V, 2, 2, 2), np.float32) if want_tape else None
+    hp = hv = None
+    if want_hist:
+        hp, hv = np.zeros((T, L, V), np.float32), np.zeros((T, L, V), np.float32)
+    rc = lib().oracle_micro_rollout_fwd(L, V, T, float(dt), _p(p0), _p(v0), _p(params), float(head_dp), float(head_dv),
+                                        _p(pT), _p(vT), _p(tape), _p(hp), _p(hv))
+    return dict(rc=rc, pT=pT, vT=vT, tape=tape, hist_p=hp, hist_v=hv, T=T, shape=(L, V))
+
+
+def micro_rollout_bwd(fwd, g_pT=None, g_vT=None, gh_p=None, gh_v=None):
+    L, V = fwd["shape"]
+    g_pT, g_vT, gh_p, gh_v = map(_f32, (g_pT, g_vT, gh_p, gh_v))
+    g_p0, g_v0 = np.zeros((L, V), np.float32), np.zeros((L, V), np.float32)
+    g_head = np.zeros((L, 2), np.float32)
+    lib().oracle_micro_rollout_bwd(L, V, fwd["T"], _p(fwd["tape"]), _p(g_pT), _p(g_vT), _p(gh_p), _p(gh_v),
+                                   _p(g_p0), _p(g_v0), _p(g_head))
+    return dict(g_p0=g_p0, g_v0=g_v0, g_head=g_head)

@@ -1,0 +1,483 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by IMPORTING the reference in this container.
+
+Test tooling only.  Run here (the reference does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/gen_goldens.py [--only G1,G4 ...]
+
+It imports the reference's own implementation of the hot path from /root/reference
+(model.macro._arz / darz, model.micro._idm / didm, road.lane.dmacro_lane / dmicro_lane,
+road.network.road_network) and records, as plain arrays in tests/golden/*.npz, the inputs
+it fed and the outputs the reference produced.  Nothing from the reference's source text
+is stored: the fixtures hold data only.  Seeds and library versions are stored in each
+file under the key `meta`.
+
+Golden sets:
+  G1/G2  riemann_kat.npz     ARZ.riemann_solve + dARZ.compute_dLdR + dARZ.flux_prime per interface
+  G3     macro_step.npz      one dMacroLane step: next state, Jacobian tape dqs, backward of cotangents
+  G4     macro_rollout_*.npz T-step rollouts through RoadNetwork.forward with loss and gradients
+  G5     idm_kat.npz         IDM.compute_acceleration + dIDM.compute_dEgo/dLeading
+  G6     micro_rollout_*.npz dMicroLane rollouts with loss and gradients
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+REFERENCE = "/root/reference"
+sys.path.insert(0, REFERENCE)
+
+import numpy as np  # noqa: E402
+import torch as th  # noqa: E402
+
+from model.macro._arz import ARZ, EPSILON  # noqa: E402
+from model.macro.darz import dARZ  # noqa: E402
+from model.micro._idm import IDM  # noqa: E402
+from model.micro.didm import dIDM  # noqa: E402
+from road.lane.dmacro_lane import dMacroLane, dMacroForwardLayer  # noqa: E402
+from road.lane.dmicro_lane import dMicroLane  # noqa: E402
+from road.network.road_network import RoadNetwork  # noqa: E402
+from road.network.route import MicroRoute  # noqa: E402
+from road.vehicle.micro_vehicle import MicroVehicle  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def meta(**kw):
+    d = dict(torch=th.__version__, numpy=np.__version__, python=sys.version.split()[0],
+             generator="tools/gen_goldens.py", reference="SonSang/diff-hybrid-traffic-sim @ /root/reference")
+    d.update(kw)
+    return np.array(json.dumps(d))
+
+
+# ----------------------------------------------------------------------------------------------
+# G1/G2: interface KATs
+# ----------------------------------------------------------------------------------------------
+
+def fullq_from_r_u_f32(r, u, u_max):
+    """Build a cell state the way lanes do for initial/ghost cells: float32 torch glue
+    (FullQ.from_r_u on 0-dim tensors) then detach to Python floats (dMacroLane.decell)."""
+    fq = ARZ.FullQ.from_r_u(th.tensor(r, dtype=th.float32), th.tensor(u, dtype=th.float32), u_max)
+    return detach(fq, u_max)
+
+
+def fullq_from_r_y_f32(r, y, u_max):
+    """Interior cells after a step: FullQ.set_r_y on 0-dim float32 tensors, then detach."""
+    fq = ARZ.FullQ(u_max)
+    fq.set_r_y(th.tensor(r, dtype=th.float32), th.tensor(y, dtype=th.float32), u_max)
+    return detach(fq, u_max)
+
+
+def detach(fq, u_max):
+    out = ARZ.FullQ(u_max)
+    out.q.r = float(fq.q.r)
+    out.q.y = float(fq.q.y)
+    out.u = float(fq.u)
+    out.u_eq = float(fq.u_eq)
+    return out
+
+
+def branch_of(QL, QR, u_max):
+    """Which of the six branches of the solver the pair takes (numbering of SURVEY 8a A3)."""
+    if QL.q.r < EPSILON:
+        return 1
+    if QR.q.r < EPSILON:
+        return 2
+    if abs(QL.u - QR.u) < EPSILON:
+        return 3
+    if QL.u > QR.u:
+        return 4
+    if u_max + QL.u - QL.u_eq > QR.u:
+        return 5
+    return 6
+
+
+def gen_riemann_kat(seed=20261002):
+    rng = np.random.default_rng(seed)
+    pairs = []  # (QL, QR, u_max)
+
+    def add(QL, QR, um):
+        pairs.append((QL, QR, um))
+
+    for um in (30.0, 13.5, 20.0):
+        # generic random pairs built from (r, u)
+        for _ in range(260):
+            rl, rr = rng.uniform(0.0, 1.0, 2)
+            ul, ur = rng.uniform(0.0, um, 2)
+            add(fullq_from_r_u_f32(rl, ul, um), fullq_from_r_u_f32(rr, ur, um), um)
+        # interior-like cells built from (r, y), including r > 1 and negative y
+        for _ in range(120):
+            rl, rr = rng.uniform(0.0, 1.3, 2)
+            yl, yr = rng.uniform(-6.0, 6.0, 2)
+            add(fullq_from_r_y_f32(rl, yl, um), fullq_from_r_y_f32(rr, yr, um), um)
+        # near-equilibrium pairs (u = u_eq(r)): small y
+        for _ in range(40):
+            rl, rr = rng.uniform(0.02, 0.98, 2)
+            ul = float(ARZ.compute_u_eq(rl, um))
+            ur = float(ARZ.compute_u_eq(rr, um))
+            add(fullq_from_r_u_f32(rl, ul, um), fullq_from_r_u_f32(rr, ur, um), um)
+        # vacuum on the left / right / both
+        for rv in (0.0, 1e-6, 5e-6, 9.9e-6):
+            for _ in range(6):
+                r2 = rng.uniform(0.05, 1.0)
+                u1, u2 = rng.uniform(0.0, um, 2)
+                add(fullq_from_r_u_f32(rv, u1, um), fullq_from_r_u_f32(r2, u2, um), um)
+                add(fullq_from_r_u_f32(r2, u2, um), fullq_from_r_u_f32(rv, u1, um), um)
+            add(fullq_from_r_u_f32(rv, um, um), fullq_from_r_u_f32(rv, um, um), um)
+        # right vacuum with negative lambda_0 on the left (dense, slow left state) -> case 2
+        for _ in range(20):
+            rl = rng.uniform(0.5, 1.0)
+            ul = rng.uniform(0.0, 0.3 * um)
+            add(fullq_from_r_u_f32(rl, ul, um), fullq_from_r_u_f32(0.0, um, um), um)
+        # equal speeds (branch 3): same u on both sides, and |du| just under/over epsilon
+        for _ in range(20):
+            rl, rr = rng.uniform(0.05, 1.0, 2)
+            u = float(np.float32(rng.uniform(0.0, um)))
+            add(fullq_from_r_u_f32(rl, u, um), fullq_from_r_u_f32(rr, u, um), um)
+        # slow dense right state: shocks with negative speed (branch 4 case 1)
+        for _ in range(60):
+            rl = rng.uniform(0.3, 1.0)
+            rr = rng.uniform(0.6, 1.0)
+            ul = rng.uniform(0.2 * um, um)
+            ur = rng.uniform(0.0, 0.2 * um)
+            add(fullq_from_r_u_f32(rl, ul, um), fullq_from_r_u_f32(rr, ur, um), um)
+        # rarefactions: dense slow left, faster right (branch 5 all cases, branch 6)
+        for _ in range(120):
+            rl = rng.uniform(0.2, 1.0)
+            ul = rng.uniform(0.0, 0.5 * um)
+            rr = rng.uniform(0.01, 1.0)
+            ur = ul + rng.uniform(0.0, 1.2 * um)
+            add(fullq_from_r_u_f32(rl, ul, um), fullq_from_r_u_f32(rr, ur, um), um)
+
+    n = len(pairs)
+    inp = np.zeros((n, 9), dtype=np.float64)  # rL yL uL ueqL rR yR uR ueqR u_max
+    case = np.zeros(n, dtype=np.int32)
+    branch = np.zeros(n, dtype=np.int32)
+    q0 = np.zeros((n, 4), dtype=np.float64)   # r y u u_eq of Q_0
+    speed = np.zeros((n, 2), dtype=np.float64)
+    dL = np.zeros((n, 2, 2), dtype=np.float32)
+    dR = np.zeros((n, 2, 2), dtype=np.float32)
+    fp = np.zeros((n, 2, 2), dtype=np.float32)
+    for i, (QL, QR, um) in enumerate(pairs):
+        inp[i] = (QL.q.r, QL.q.y, QL.u, QL.u_eq, QR.q.r, QR.q.y, QR.u, QR.u_eq, um)
+        rs = ARZ.riemann_solve(QL, QR, um)
+        case[i] = rs.case_ind
+        branch[i] = branch_of(QL, QR, um)
+        q0[i] = (rs.Q_0.q.r, rs.Q_0.q.y, rs.Q_0.u, rs.Q_0.u_eq)
+        speed[i] = (rs.speed0, rs.speed1)
+        a, b = dARZ.compute_dLdR(rs, QL, QR, um)
+        dL[i], dR[i] = a, b
+        fp[i] = dARZ.flux_prime(rs.Q_0)
+    combos = sorted(set(zip(branch.tolist(), case.tolist())))
+    print("G1/G2: %d pairs, (branch,case) combos hit: %s" % (n, combos))
+    assert np.all(np.isfinite(q0)) and np.all(np.isfinite(dL)) and np.all(np.isfinite(dR))
+    np.savez_compressed(os.path.join(OUT, "riemann_kat.npz"), inp=inp, case=case, branch=branch, q0=q0,
+                        speed=speed, dL=dL, dR=dR, fp=fp, meta=meta(seed=seed, combos=combos))
+
+
+# ----------------------------------------------------------------------------------------------
+# G3: one dMacroLane step
+# ----------------------------------------------------------------------------------------------
+
+def lane_padded_state(lane):
+    """(r, y, u, u_eq)[N+2] as float32 values: ghosts at both ends."""
+    cells = [lane.leftmost_cell] + list(lane.curr_cell) + [lane.rightmost_cell]
+    out = np.zeros((4, len(cells)), dtype=np.float32)
+    for i, c in enumerate(cells):
+        out[0, i] = float(c.state.q.r)
+        out[1, i] = float(c.state.q.y)
+        out[2, i] = float(c.state.u)
+        out[3, i] = float(c.state.u_eq)
+    return out
+
+
+def gen_macro_step(seed=7):
+    th.manual_seed(seed)
+    cases = {}
+    configs = [
+        # name, N, dx, dt, u_max, kind
+        ("rand64", 64, 5.0, 0.01, 30.0, "rand"),
+        ("sanity100", 100, 100.0, 0.03, 30.0, "sanity"),
+        ("vacuum9", 9, 5.0, 0.01, 30.0, "vacuum"),
+        ("single1", 1, 5.0, 0.01, 30.0, "rand"),
+        ("jam33", 33, 4.0, 0.02, 20.0, "jam"),
+    ]
+    for name, N, dx, dt, um, kind in configs:
+        if kind == "rand":
+            r = th.rand(N + 2)
+            u = th.rand(N + 2) * um
+        elif kind == "sanity":
+            r = th.rand(N + 2)
+            u = th.lerp(th.tensor([0.4 * um]), th.tensor([0.7 * um]), th.rand(N + 2))
+        elif kind == "vacuum":
+            r = th.tensor([0.3, 0.0, 0.0, 0.5, 1e-6, 0.7, 0.0, 0.2, 0.9, 0.0, 0.4])
+            u = th.tensor([10.0, 30.0, 30.0, 5.0, 30.0, 2.0, 30.0, 25.0, 1.0, 30.0, 12.0])
+        elif kind == "jam":
+            r = th.cat([th.rand(17) * 0.3, 0.7 + th.rand(N + 2 - 17) * 0.3])
+            u = th.cat([15 + th.rand(17) * 5.0, th.rand(N + 2 - 17) * 2.0])
+        r = r.to(th.float32)
+        u = u.to(th.float32)
+        lane = dMacroLane(0, N * dx, um, dx)
+        lane.set_state_vector_u(r[1:-1], u[1:-1])
+        lane.set_leftmost_cell(r[0], u[0])
+        lane.set_rightmost_cell(r[-1], u[-1])
+        state = lane_padded_state(lane)
+        cr, cy = lane.vectorize_input()
+        cr = cr.detach().clone().requires_grad_(True)
+        cy = cy.detach().clone().requires_grad_(True)
+        nr, ny = dMacroForwardLayer.apply(lane, cr, cy, dt)
+        dqs = lane.d_lane[-1].dqs.copy()
+        rs = lane.riemann_solution
+        case = np.array([s.case_ind for s in rs], dtype=np.int32)
+        speeds = np.array([[s.speed0, s.speed1] for s in rs], dtype=np.float64)
+        # the float32 glue for the next step's u, u_eq (set_next_state_vector_y)
+        lane.set_next_state_vector_y(nr.detach(), ny.detach())
+        nu = np.array([float(c.state.u) for c in lane.next_cell], dtype=np.float32)
+        nueq = np.array([float(c.state.u_eq) for c in lane.next_cell], dtype=np.float32)
+        g_nr = th.randn(N)
+        g_ny = th.randn(N)
+        (nr * g_nr + ny * g_ny).sum().backward()
+        cases[name] = dict(N=N, dx=dx, dt=dt, u_max=um)
+        pre = name + "_"
+        cases[pre + "state"] = state
+        cases[pre + "nr"] = nr.detach().numpy().copy()
+        cases[pre + "ny"] = ny.detach().numpy().copy()
+        cases[pre + "nu"] = nu
+        cases[pre + "nueq"] = nueq
+        cases[pre + "dqs"] = dqs
+        cases[pre + "case"] = case
+        cases[pre + "speed"] = speeds
+        cases[pre + "g_nr"] = g_nr.numpy().copy()
+        cases[pre + "g_ny"] = g_ny.numpy().copy()
+        cases[pre + "g_r"] = cr.grad.numpy().copy()
+        cases[pre + "g_y"] = cy.grad.numpy().copy()
+        print("G3 %-10s N=%3d cases=%s" % (name, N, np.bincount(case, minlength=3).tolist()))
+    cfg = {k: v for k, v in cases.items() if isinstance(v, dict)}
+    arrays = {k: v for k, v in cases.items() if not isinstance(v, dict)}
+    np.savez_compressed(os.path.join(OUT, "macro_step.npz"), meta=meta(seed=seed, configs=cfg), **arrays)
+
+
+# ----------------------------------------------------------------------------------------------
+# G4: macro rollouts through RoadNetwork.forward
+# ----------------------------------------------------------------------------------------------
+
+def macro_rollout(name, N, T, dx, dt, um, seed, init="uniform", tap="final_sq", record_steps=0):
+    """One straight dMacroLane in a RoadNetwork (example/inverse/macro.py:34-68 construction),
+    T x RoadNetwork.forward(dt, True), loss on (r_T, u_T), backward to r0, u0 and ghost (r, u)."""
+    th.manual_seed(seed)
+    if init == "uniform":       # section 8d C1: r0 = rand, u0 = rand * u_max, ghosts likewise
+        r0 = th.rand(N)
+        u0 = th.rand(N) * um
+        gr = th.rand(2)
+        gu = th.rand(2) * um
+    elif init == "bench":       # section 8d C2 regime: r0 in [0.05, 0.95]
+        r0 = 0.05 + 0.9 * th.rand(N)
+        u0 = th.rand(N) * um
+        gr = 0.05 + 0.9 * th.rand(2)
+        gu = th.rand(2) * um
+    elif init == "sanity":      # example/sanity/macro.py regime
+        r0 = th.rand(N)
+        u0 = th.lerp(th.tensor([0.4 * um]), th.tensor([0.7 * um]), th.rand(N))
+        gr = th.rand(2)
+        gu = th.lerp(th.tensor([0.4 * um]), th.tensor([0.7 * um]), th.rand(2))
+    r0 = r0.to(th.float32).requires_grad_(True)
+    u0 = u0.to(th.float32).requires_grad_(True)
+    gr = gr.to(th.float32).requires_grad_(True)
+    gu = gu.to(th.float32).requires_grad_(True)
+
+    lane = dMacroLane(0, N * dx, um, dx)
+    lane.set_state_vector_u(r0, u0)
+    lane.set_leftmost_cell(gr[0], gu[0])
+    lane.set_rightmost_cell(gr[1], gu[1])
+    net = RoadNetwork(um)
+    net.add_lane(lane)
+
+    steps_r, steps_y, steps_u = [], [], []
+    loss = 0
+    t0 = time.time()
+    for t in range(T):
+        net.forward(dt, True)
+        if tap == "every_sum":      # sanity script: sum of r, y, u after every step
+            r, y, u = lane.get_state_vector()
+            loss = loss + r.sum() + y.sum() + u.sum()
+        if t < record_steps:
+            r, y, u = lane.get_state_vector()
+            steps_r.append(r.detach().numpy().copy())
+            steps_y.append(y.detach().numpy().copy())
+            steps_u.append(u.detach().numpy().copy())
+    rT, yT, uT = lane.get_state_vector()
+    if tap == "final_sq":
+        loss = (rT ** 2).sum() + (uT ** 2).sum()
+    t1 = time.time()
+    loss.backward()
+    t2 = time.time()
+    case_hist = np.zeros(3, dtype=np.int64)
+    print("G4 %-12s N=%d T=%d loss=%.6f fwd %.1fs bwd %.1fs" % (name, N, T, float(loss), t1 - t0, t2 - t1))
+    np.savez_compressed(
+        os.path.join(OUT, "macro_rollout_%s.npz" % name),
+        r0=r0.detach().numpy(), u0=u0.detach().numpy(), ghost_r=gr.detach().numpy(), ghost_u=gu.detach().numpy(),
+        rT=rT.detach().numpy(), yT=yT.detach().numpy(), uT=uT.detach().numpy(),
+        loss=np.float64(float(loss)),
+        g_r0=r0.grad.numpy(), g_u0=u0.grad.numpy(), g_ghost_r=gr.grad.numpy(), g_ghost_u=gu.grad.numpy(),
+        steps_r=np.array(steps_r, dtype=np.float32), steps_y=np.array(steps_y, dtype=np.float32),
+        steps_u=np.array(steps_u, dtype=np.float32),
+        meta=meta(seed=seed, N=N, T=T, dx=dx, dt=dt, u_max=um, init=init, tap=tap,
+                  ref_seconds_fwd=t1 - t0, ref_seconds_bwd=t2 - t1))
+
+
+def gen_macro_rollouts(which):
+    if "c1" in which:        # BASELINE config #1: 1 lane x 100 cells x 200 steps
+        macro_rollout("c1", 100, 200, 5.0, 0.01, 30.0, seed=1, init="uniform", tap="final_sq", record_steps=8)
+    if "sanity" in which:    # example/sanity/macro.py regime: 100 cells x 10 steps, dx=100, dt=0.03
+        macro_rollout("sanity", 100, 10, 100.0, 0.03, 30.0, seed=0, init="sanity", tap="every_sum", record_steps=10)
+    if "small" in which:     # quick: 24 cells x 40 steps
+        macro_rollout("small", 24, 40, 5.0, 0.01, 30.0, seed=3, init="uniform", tap="final_sq", record_steps=40)
+    if "bench64" in which:   # C2 regime at oracle-checkable size: 64 cells x 300 steps
+        macro_rollout("bench64", 64, 300, 5.0, 0.01, 30.0, seed=2026, init="bench", tap="final_sq", record_steps=4)
+    if "long" in which:      # error growth check at T = 1000
+        macro_rollout("long", 48, 1000, 5.0, 0.01, 30.0, seed=11, init="bench", tap="final_sq", record_steps=0)
+
+
+# ----------------------------------------------------------------------------------------------
+# G5: IDM KATs
+# ----------------------------------------------------------------------------------------------
+
+def gen_idm_kat(seed=5):
+    rng = np.random.default_rng(seed)
+    rows = []
+    for _ in range(600):
+        sl = rng.choice([30.0, 20.0, 13.5])
+        a_max = sl * rng.uniform(0.5, 1.5)
+        a_pref = sl * rng.uniform(0.5, 1.5)
+        v_t = sl * rng.uniform(0.8, 1.2)
+        s0 = rng.uniform(0.5, 5.0)
+        T = rng.uniform(0.1, 3.0)
+        v = float(np.float32(rng.uniform(0.0, 1.2 * sl)))
+        dp = float(np.float32(rng.choice([rng.uniform(0.5, 50.0), rng.uniform(1e-5, 0.5), 1000.0])))
+        dv = float(np.float32(rng.uniform(-sl, sl)))
+        dt = rng.choice([0.01, 1.0 / 30.0, 0.1])
+        rows.append((a_max, a_pref, v, v_t, dp, dv, s0, T, dt))
+    # force negative optimal spacing (leader much faster) and acceleration clipping (tiny gap)
+    for _ in range(60):
+        rows.append((30.0, 24.0, float(np.float32(rng.uniform(5, 30))), 27.0, float(np.float32(rng.uniform(5, 100))),
+                     float(np.float32(-rng.uniform(20, 60))), 0.5, 0.1, 0.01))
+        rows.append((30.0, 24.0, float(np.float32(rng.uniform(0.0, 3.0))), 27.0, float(np.float32(rng.uniform(1e-5, 0.2))),
+                     float(np.float32(rng.uniform(0, 5))), 0.5, 0.1, 0.01))
+    # default vehicle (road/vehicle/micro_vehicle.py:31-72) at speed limit 30
+    for _ in range(80):
+        rows.append((30.0 * 1.0, 30.0 * 0.8, float(np.float32(rng.uniform(0, 30))), 30.0 * 0.9,
+                     float(np.float32(rng.uniform(0.1, 60))), float(np.float32(rng.uniform(-10, 10))), 5.0 * 0.1, 0.1, 0.01))
+    inp = np.array(rows, dtype=np.float64)
+    n = len(rows)
+    acc = np.zeros(n)
+    sstar = np.zeros(n)
+    flags = np.zeros((n, 2), dtype=np.int32)
+    dE = np.zeros((n, 2, 2), dtype=np.float32)
+    dLd = np.zeros((n, 2, 2), dtype=np.float32)
+    for i, (a_max, a_pref, v, v_t, dp, dv, s0, T, dt) in enumerate(rows):
+        a, s, ca, cs = IDM.compute_acceleration(a_max, a_pref, v, v_t, dp, dv, s0, T, dt)
+        acc[i], sstar[i] = a, s
+        flags[i] = (int(ca), int(cs))
+        dE[i] = dIDM.compute_dEgo(a_max, a_pref, v, v_t, dp, dv, s0, T, s, dt, ca, cs).numpy()
+        dLd[i] = dIDM.compute_dLeading(a_max, a_pref, v, v_t, dp, dv, s0, T, s, dt, ca, cs).numpy()
+    print("G5: %d rows; clipped_acc %d, clipped_spacing %d" % (n, flags[:, 0].sum(), flags[:, 1].sum()))
+    np.savez_compressed(os.path.join(OUT, "idm_kat.npz"), inp=inp, acc=acc, sstar=sstar, flags=flags,
+                        dEgo=dE, dLeading=dLd, meta=meta(seed=seed, columns="a_max a_pref v v_target dp dv min_space time_pref dt"))
+
+
+# ----------------------------------------------------------------------------------------------
+# G6: dMicroLane rollouts through RoadNetwork.forward
+# ----------------------------------------------------------------------------------------------
+
+def micro_rollout(name, V, T, dt, sl, seed, params="default", tap="final_sq", head=(1000, 0), record_steps=0,
+                  spacing=4.0, jitter=2.0, vlo=0.3, vhi=0.7):
+    th.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    vlen = 5.0
+    p0 = th.arange(0, V) * spacing * vlen + th.rand(V) * jitter * vlen       # example/inverse/micro.py:78-80
+    v0 = th.lerp(th.tensor([vlo * sl]), th.tensor([vhi * sl]), th.rand(V))
+    p0 = p0.to(th.float32).requires_grad_(True)
+    v0 = v0.to(th.float32).requires_grad_(True)
+    lane = dMicroLane(0, 1e10, sl)
+    net = RoadNetwork(sl)
+    net.add_lane(lane)
+    par = np.zeros((V, 6), dtype=np.float64)  # a_max a_pref v_target min_space time_pref length
+    for i in range(V):
+        mv = MicroVehicle.default_micro_vehicle(sl)
+        if params == "random":
+            mv.accel_max = float(sl * rng.uniform(0.8, 1.5))
+            mv.accel_pref = float(sl * rng.uniform(0.6, 1.5))
+            mv.target_speed = float(sl * rng.uniform(0.8, 1.2))
+            mv.min_space = float(vlen * rng.uniform(0.1, 1.0))
+            mv.time_pref = float(rng.uniform(0.1, 1.5))
+        mv.position = p0[i]
+        mv.speed = v0[i]
+        par[i] = (mv.accel_max, mv.accel_pref, mv.target_speed, mv.min_space, mv.time_pref, mv.length)
+        net.add_vehicle(mv, MicroRoute([0]))
+    lane.set_state_vector(p0, v0)
+    steps_p, steps_v = [], []
+    loss = 0
+    t0 = time.time()
+    for t in range(T):
+        net.forward(dt, True)
+        assert lane.head_position_delta == head[0] and lane.head_speed_delta == head[1]
+        if tap == "every_sum":
+            p, v = lane.get_state_vector()
+            loss = loss + p.sum() + v.sum()
+        if t < record_steps:
+            p, v = lane.get_state_vector()
+            steps_p.append(p.detach().numpy().copy())
+            steps_v.append(v.detach().numpy().copy())
+    pT, vT = lane.get_state_vector()
+    if tap == "final_sq":
+        loss = 1e-4 * (pT ** 2).sum() + (vT ** 2).sum()      # section 8d C3 loss taps
+    t1 = time.time()
+    loss.backward()
+    t2 = time.time()
+    print("G6 %-10s V=%d T=%d loss=%.6f fwd %.1fs bwd %.1fs" % (name, V, T, float(loss), t1 - t0, t2 - t1))
+    np.savez_compressed(
+        os.path.join(OUT, "micro_rollout_%s.npz" % name),
+        p0=p0.detach().numpy(), v0=v0.detach().numpy(), params=par, pT=pT.detach().numpy(), vT=vT.detach().numpy(),
+        loss=np.float64(float(loss)), g_p0=p0.grad.numpy(), g_v0=v0.grad.numpy(),
+        steps_p=np.array(steps_p, dtype=np.float32), steps_v=np.array(steps_v, dtype=np.float32),
+        meta=meta(seed=seed, V=V, T=T, dt=dt, speed_limit=sl, params=params, tap=tap, head=list(head),
+                  ref_seconds_fwd=t1 - t0, ref_seconds_bwd=t2 - t1))
+
+
+def gen_micro_rollouts(which):
+    if "inv10" in which:     # example/inverse/micro.py defaults: 10 vehicles, dt 0.01; T=200
+        micro_rollout("inv10", 10, 200, 0.01, 30.0, seed=1, params="default", tap="final_sq", record_steps=8)
+    if "rand24" in which:    # random per-vehicle parameters, loss tapped every step
+        micro_rollout("rand24", 24, 150, 1.0 / 30.0, 20.0, seed=4, params="random", tap="every_sum", record_steps=8)
+    if "dense16" in which:   # C3 regime: 20 m spacing + U[0,10), v in [9,21], speed limit 30
+        micro_rollout("dense16", 16, 400, 0.01, 30.0, seed=9, params="default", tap="final_sq", record_steps=4,
+                      spacing=4.0, jitter=2.0, vlo=0.3, vhi=0.7)
+    if "long" in which:      # T = 1000
+        micro_rollout("long", 12, 1000, 0.01, 30.0, seed=12, params="default", tap="final_sq", record_steps=0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="G1,G3,G4,G5,G6")
+    ap.add_argument("--g4", default="c1,sanity,small,bench64,long")
+    ap.add_argument("--g6", default="inv10,rand24,dense16,long")
+    args = ap.parse_args()
+    only = set(args.only.split(","))
+    os.makedirs(OUT, exist_ok=True)
+    if "G1" in only:
+        gen_riemann_kat()
+    if "G3" in only:
+        gen_macro_step()
+    if "G4" in only:
+        gen_macro_rollouts(set(args.g4.split(",")))
+    if "G5" in only:
+        gen_idm_kat()
+    if "G6" in only:
+        gen_micro_rollouts(set(args.g6.split(",")))
+
+
+if __name__ == "__main__":
+    main()
