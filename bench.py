@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py -- differentiable cell-steps/s (forward + adjoint) of the time-fused HIP stepper.
+
+    python bench.py --gpus N --steps K --warmup W [--workload macro|micro]
+
+One "step" = one pass of the hot path over one batch of synthetic input: a full differentiable rollout
+(forward sweep writing the Jacobian tape + reverse sweep reading it back) of BASELINE.json configs[1]
+(macro: 1024 lanes x 512 ARZ cells x 1000 time steps) or, with --workload micro,
+configs[2] (4096 lanes x 256 IDM vehicles x 1000 time steps; C3), inputs resident in HBM.
+For N > 1 the driver launches one process per GPU (torch.distributed.run); every rank owns its own shard of
+independent lanes (weak scaling: the per-GPU batch is the configuration above), there is no data-path
+collective, and the scalar loss is all-reduced over RCCL once per pass.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "diff-hybrid-traffic-sim_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured-achievable copy rate
+MACRO_TAPE_B = 48           # float32 [3][2][2] per cell-step   (road/lane/dmacro_lane.py:56)
+MICRO_TAPE_B = 32           # float32 [2][2][2] per vehicle-step (road/lane/dmicro_lane.py:54)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["macro", "micro"], default="macro")
+    ap.add_argument("--lanes", type=int, default=0, help="override lanes per GPU")
+    ap.add_argument("--cells", type=int, default=0, help="override cells / vehicles per lane")
+    ap.add_argument("--time-steps", type=int, default=0, help="override simulated time steps per rollout")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+class MacroWorkload:
+    """r0 ~ U[0.05, 0.95], u0 ~ U[0, u_max], fixed random ghosts, dx = 5, dt = 0.01, u_max = 30,
+    loss = sum r_T^2 + sum u_T^2."""
+    name = "macro_straight_1024x512x1000"
+    unit_bytes = MACRO_TAPE_B
+
+    def __init__(self, dev, rank, L, N, T):
+        from dhts import ops
+        self.ops, self.L, self.N, self.T = ops, L, N, T
+        self.dt, self.dx, self.um = 0.01, 5.0, 30.0
+        gen = torch.Generator(device="cpu").manual_seed(2026 + rank)
+        self.r0 = (0.05 + 0.9 * torch.rand(L, N, generator=gen)).to(dev)
+        self.u0 = (self.um * torch.rand(L, N, generator=gen)).to(dev)
+        gr = (0.05 + 0.9 * torch.rand(L, 2, generator=gen)).to(dev)
+        gu = (self.um * torch.rand(L, 2, generator=gen)).to(dev)
+        gy, gq = ops.macro_state_from_ru(gr, gu, self.um)
+        self.ghost = torch.stack([gr, gy, gu, gq], dim=-1).contiguous()
+        self.desc = ops.macro_desc(L, N, self.dt, self.dx, self.um)
+        self.tape = torch.empty(ops.macro_tape_numel(self.desc, T), dtype=torch.float32, device=dev)
+        self.err = ops.new_error_record(dev)
+        self.out = tuple(torch.empty(L, N, device=dev) for _ in range(4))
+        self.gout = (torch.empty(L, N, device=dev), torch.empty(L, N, device=dev))
+        self.g_ghost = torch.zeros(L, 2, 2, dtype=torch.float64, device=dev)
+        self.units = L * N * T                       # cell-steps per pass
+        self.ev = []
+
+    def one_pass(self, record=False):
+        ops = self.ops
+        y0, q0 = ops.macro_state_from_ru(self.r0, self.u0, self.um)
+        if record:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e[0].record()
+        rT, yT, uT, _ = ops.macro_rollout_fwd(self.desc, self.T, self.r0, y0, self.u0, q0, self.ghost,
+                                              tape=self.tape, err=self.err, out=self.out)
+        if record:
+            e[1].record()
+        loss = (rT * rT).sum() + (uT * uT).sum()
+        g_r, g_y = 2.0 * rT, torch.zeros_like(rT)
+        ops.macro_u_tap_bwd(rT, yT, 2.0 * uT, g_r, g_y, self.um)
+        if record:
+            e[2].record()
+        g_r0, g_y0, _ = ops.macro_rollout_bwd(self.desc, self.T, self.tape, g_r, g_y, err=self.err, out=self.gout,
+                                              g_ghost=self.g_ghost)
+        if record:
+            e[3].record()
+            self.ev.append(e)
+        g_u0 = ops.macro_state_from_ru_bwd(self.r0, self.u0, g_y0, g_r0, self.um)
+        return loss, g_r0, g_u0
+
+    def cpu_baseline(self):
+        """The C oracle (a port of the reference's algorithm) on the host cores: bounded sample of the same
+        workload -- 2 lanes per core x 512 cells x 250 steps, repeated for >= 10 s."""
+        import numpy as np
+        from oracle import oracle as O
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+        Lc, N, T = 2 * cores, self.N, 250
+        rng = np.random.default_rng(2026)
+        r0 = rng.uniform(0.05, 0.95, (Lc, N)).astype(np.float32)
+        u0 = rng.uniform(0.0, self.um, (Lc, N)).astype(np.float32)
+        gr = rng.uniform(0.05, 0.95, (Lc, 2)).astype(np.float32)
+        gu = rng.uniform(0.0, self.um, (Lc, 2)).astype(np.float32)
+        O.macro_rollout_fwd(r0[:2], u0[:2], gr[:2], gu[:2], 2, self.dt, self.dx, self.um)   # load + warm
+        done, t0 = 0, time.perf_counter()
+        while True:
+            f = O.macro_rollout_fwd(r0, u0, gr, gu, T, self.dt, self.dx, self.um)
+            O.macro_rollout_bwd(f, g_rT=2 * f["rT"], g_uT=2 * f["uT"])
+            done += Lc * N * T
+            el = time.perf_counter() - t0
+            if el >= 10.0:
+                break
+        return {"value": done / el, "unit": "cell-steps/s", "cores": cores, "kind": "port",
+                "sample": "%d lanes x %d cells x %d steps fwd+bwd, repeated %.1f s (OpenMP over lanes)" % (Lc, N, T, el)}
+
+
+class MicroWorkload:
+    """256 default_micro_vehicle(30) per lane, p_i = 20 i + U[0, 10), v ~ U[9, 21], head gap 1000 / 0,
+    dt = 0.01, loss = sum 1e-4 p_T^2 + sum v_T^2."""
+    name = "micro_idm_4096x256x1000"
+    unit_bytes = MICRO_TAPE_B
+
+    def __init__(self, dev, rank, L, V, T):
+        from dhts import ops
+        self.ops, self.L, self.V, self.T = ops, L, V, T
+        self.dt = 0.01
+        gen = torch.Generator(device="cpu").manual_seed(3026 + rank)
+        self.p0 = (torch.arange(V)[None, :] * 20.0 + 10.0 * torch.rand(L, V, generator=gen)).to(dev)
+        self.v0 = (9.0 + 12.0 * torch.rand(L, V, generator=gen)).to(dev)
+        par = torch.tensor([30.0 * 1.0, 30.0 * 0.8, 30.0 * 0.9, 5.0 * 0.1, 0.1, 5.0], dtype=torch.float64, device=dev)
+        self.params = par[:, None, None].expand(6, L, V).contiguous()
+        self.head = torch.tensor([[1000.0, 0.0]], dtype=torch.float64, device=dev).expand(L, 2).contiguous()
+        self.desc = ops.micro_desc(L, V, self.dt)
+        self.tape = torch.empty(ops.micro_tape_numel(self.desc, T), dtype=torch.float32, device=dev)
+        self.err = ops.new_error_record(dev)
+        self.out = (torch.empty(L, V, device=dev), torch.empty(L, V, device=dev))
+        self.gout = (torch.empty(L, V, device=dev), torch.empty(L, V, device=dev))
+        self.g_head = torch.zeros(L, 2, dtype=torch.float64, device=dev)
+        self.units = L * V * T
+        self.ev = []
+
+    def one_pass(self, record=False):
+        ops = self.ops
+        if record:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e[0].record()
+        pT, vT = ops.micro_rollout_fwd(self.desc, self.T, self.p0, self.v0, self.params, self.head, tape=self.tape,
+                                       err=self.err, out=self.out)
+        if record:
+            e[1].record()
+        loss = 1e-4 * (pT * pT).sum() + (vT * vT).sum()
+        g_p, g_v = 2e-4 * pT, 2.0 * vT
+        if record:
+            e[2].record()
+        g_p0, g_v0, _ = ops.micro_rollout_bwd(self.desc, self.T, self.tape, g_p, g_v, err=self.err, out=self.gout,
+                                              g_head=self.g_head)
+        if record:
+            e[3].record()
+            self.ev.append(e)
+        return loss, g_p0, g_v0
+
+    def cpu_baseline(self):
+        import numpy as np
+        from oracle import oracle as O
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+        Lc, V, T = 4 * cores, self.V, 250
+        rng = np.random.default_rng(3026)
+        p0 = (np.arange(V)[None, :] * 20.0 + rng.uniform(0, 10, (Lc, V))).astype(np.float32)
+        v0 = rng.uniform(9, 21, (Lc, V)).astype(np.float32)
+        par = np.tile(np.array([30.0, 24.0, 27.0, 0.5, 0.1, 5.0]), (Lc, V, 1))
+        O.micro_rollout_fwd(p0[:2], v0[:2], par[:2], 2, self.dt)
+        done, t0 = 0, time.perf_counter()
+        while True:
+            f = O.micro_rollout_fwd(p0, v0, par, T, self.dt)
+            O.micro_rollout_bwd(f, g_pT=2e-4 * f["pT"], g_vT=2 * f["vT"])
+            done += Lc * V * T
+            el = time.perf_counter() - t0
+            if el >= 10.0:
+                break
+        return {"value": done / el, "unit": "cell-steps/s", "cores": cores, "kind": "port",
+                "sample": "%d lanes x %d vehicles x %d steps fwd+bwd, repeated %.1f s (OpenMP over lanes)" % (Lc, V, T, el)}
+
+
+def main():
+    args = parse()
+    from dhts import dist as D
+    rank, world, local = D.init()
+    if world != args.gpus:
+        if rank == 0 and world > 1:
+            print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    if args.workload == "macro":
+        L, N, T = args.lanes or 1024, args.cells or 512, args.time_steps or 1000
+        w = MacroWorkload(dev, rank, L, N, T)
+    else:
+        L, N, T = args.lanes or 4096, args.cells or 256, args.time_steps or 1000
+        w = MicroWorkload(dev, rank, L, N, T)
+
+    flat = torch.zeros(1, dtype=torch.float32, device=dev)        # [loss] -- the per-pass RCCL all-reduce
+    for _ in range(args.warmup):
+        loss, _, _ = w.one_pass()
+        flat[0] = loss
+        D.allreduce_sum_(flat)
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, g_a, g_b = w.one_pass(record=True)
+        flat[0] = loss
+        D.allreduce_sum_(flat)
+    D.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(elapsed, dev)
+
+    from dhts import ops
+    fault = w.err.tolist()
+    assert fault[0] in (0, 2), "simulation fault during the bench: %s" % (fault,)
+    assert torch.isfinite(g_a).all() and torch.isfinite(g_b).all() and bool(torch.isfinite(flat).all())
+
+    if rank == 0:
+        fwd_ms = [e[0].elapsed_time(e[1]) for e in w.ev]
+        bwd_ms = [e[2].elapsed_time(e[3]) for e in w.ev]
+        fwd_avg, bwd_avg = sum(fwd_ms) / len(fwd_ms), sum(bwd_ms) / len(bwd_ms)
+        per_launch_bytes = w.units * w.unit_bytes          # tape bytes one launch writes (fwd) / reads (bwd)
+        kernels = {
+            "rollout_fwd": {"ms": fwd_avg, "algorithmic_GB": per_launch_bytes / 1e9, "GBps": per_launch_bytes / fwd_avg / 1e6},
+            "rollout_bwd": {"ms": bwd_avg, "algorithmic_GB": per_launch_bytes / 1e9, "GBps": per_launch_bytes / bwd_avg / 1e6},
+        }
+        dom = "rollout_fwd" if fwd_avg >= bwd_avg else "rollout_bwd"
+        achieved = kernels[dom]["GBps"]
+        value = w.units * args.steps * world / elapsed
+        out = {
+            "metric": "differentiable cell-steps/s (fwd+bwd)",
+            "value": value,
+            "unit": "cell-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64 step on f32 state, f32 tape/adjoint",
+            "data": "synthetic",
+            "config": {"workload": w.name, "lanes_per_gpu": L, "units_per_lane": N, "time_steps": T,
+                       "parallelism": "lanes sharded over %d GPU(s), no data-path collective" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+            "whole_path": {"algorithmic_GBps": w.units * 2 * w.unit_bytes * args.steps / elapsed / 1e9,
+                           "frac_of_peak": w.units * 2 * w.unit_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
+            "kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = w.cpu_baseline()
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

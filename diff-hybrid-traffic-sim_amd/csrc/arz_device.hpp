@@ -1,0 +1,238 @@
+// arz_device.hpp -- device math of the ARZ cell stencil (gfx950).
+//
+// Implements, per cell interface, what the reference computes in model/macro/_arz.py:212-332 (exact Riemann
+// solver), model/macro/darz.py:12-233 (analytic Jacobians of Q_0 and of the flux) and the 2x2 products of
+// road/lane/dmacro_lane.py:115-129 -- and, per cell, the float32 state glue of _arz.py:82-92.
+//
+// Precision ladder (SURVEY.md 8a Note P): inputs are float32 state widened to double, the solve and every
+// Jacobian entry are double, entries are rounded to float32, 2x2 products and the adjoint are float32 with
+// NumPy's accumulation form acc = a0*b0; acc = fma(a1, b1, acc).  The translation unit is compiled with
+// -ffp-contract=off so nothing else is fused.  gamma = 0.5 is a compile-time constant: x**gamma is sqrt(x),
+// x**(1/gamma) is x*x, x**(gamma-1) is 1/sqrt(x) (the reference's only exponents).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dhts {
+
+constexpr double kEps = 1e-5;             // EPSILON, _arz.py:2
+constexpr float kEpsF = 1e-5f;            // the same constant cast to float32 where it meets a tensor
+constexpr double kG = 0.5;                // GAMMA, _arz.py:1
+constexpr double kG1 = kG + 1.0;          // gamma + 1
+constexpr double kGoG1 = kG / (kG + 1.0); // gamma / (gamma + 1)
+
+// Python's max(a, b): b if b > a else a
+__device__ __forceinline__ double pymax(double a, double b) { return (b > a) ? b : a; }
+
+// compute_u_eq, _arz.py:133-138
+__device__ __forceinline__ double u_eq_d(double r, double um) {
+    r = pymax(r, 0.);
+    return um * (1. - sqrt(r + kEps));
+}
+// compute_u_eq_prime, _arz.py:146-149
+__device__ __forceinline__ double u_eq_prime_d(double r, double um) {
+    r = pymax(r, kEps);
+    return -um * kG * (1.0 / sqrt(r));
+}
+
+// ---- float32 glue (0-dim torch tensors in the reference) ---------------------------------------------
+__device__ __forceinline__ float glue_u_eq(float r, float um) {
+    if (0.f > r) return (float)((double)um * (1. - sqrt(0. + kEps)));   // max(r, 0.) picked the Python float
+    float t = r + kEpsF;
+    t = __fsqrt_rn(t);
+    t = 1.f - t;
+    return um * t;
+}
+// FullQ.set_r_u / from_r_u, _arz.py:73-86
+__device__ __forceinline__ void glue_from_r_u(float r, float u, float um, float &y, float &ueq) {
+    ueq = glue_u_eq(r, um);
+    y = r * (u - ueq);
+}
+// FullQ.set_r_y, _arz.py:88-92
+__device__ __forceinline__ void glue_from_r_y(float r, float y, float um, float &u, float &ueq) {
+    ueq = glue_u_eq(r, um);
+    if (r < kEpsF) {
+        double ueq_c = (double)um * (1. - sqrt(kEps + kEps));       // u_eq(1e-5) in Python floats
+        u = __fdiv_rn(y, kEpsF) + (float)ueq_c;
+    } else {
+        u = __fdiv_rn(y, r) + ueq;
+    }
+}
+// adjoint of u = y / rc + u_eq(rc) as torch autograd evaluates it (float32)
+__device__ __forceinline__ void glue_u_bwd(float r, float y, float um, float g_u, float &g_r, float &g_y) {
+    if (r < kEpsF) {
+        g_y += __fdiv_rn(g_u, kEpsF);
+        return;
+    }
+    g_y += __fdiv_rn(g_u, r);
+    float gd = -g_u * __fdiv_rn(__fdiv_rn(y, r), r);
+    float gp = 0.f;
+    if (!(0.f > r)) {
+        float t = r + kEpsF;
+        float gs = -(g_u * um);
+        gp = gs * (0.5f * __fdiv_rn(1.f, __fsqrt_rn(t)));
+    }
+    g_r += gd + gp;
+}
+// adjoint of y = r * (u - u_eq(r))
+__device__ __forceinline__ void glue_y_bwd(float r, float u, float um, float g_y, float &g_r, float &g_u) {
+    float ueq = glue_u_eq(r, um);
+    float diff = u - ueq;
+    float g_diff = g_y * r;
+    g_u = g_diff;
+    float acc = g_y * diff;
+    if (!(0.f > r)) {
+        float t = r + kEpsF;
+        float gs = -((-g_diff) * um);
+        acc += gs * (0.5f * __fdiv_rn(1.f, __fsqrt_rn(t)));
+    }
+    g_r += acc;
+}
+
+// float32 2-term dot the way NumPy's matmul accumulates it
+__device__ __forceinline__ float dot2(float a0, float b0, float a1, float b1) { return __fmaf_rn(a1, b1, a0 * b0); }
+
+struct Iface {
+    double Fr, Fy;   // flux of Q_0: (r*u, y*u)                                  (_arz.py:94-101)
+    float A[4];      // fp(Q_0) @ dQ_0/dQ_L   row-major 2x2, float32             (dmacro_lane.py:126-129)
+    float B[4];      // fp(Q_0) @ dQ_0/dQ_R
+    double smax;     // max(|speed0|, |speed1|) for the CFL check               (_macro_lane.py:141-146)
+};
+
+// One interface: left state (rL, yL, uL, qL = u_eq), right state, speed limit.
+__device__ __forceinline__ void arz_interface(double rL, double yL, double uL, double qL,
+                                              double rR, double yR, double uR, double qR,
+                                              double um, Iface &o) {
+    // ---- Riemann solve: case index and speeds (_arz.py:222-314) ----
+    int ci;
+    double s0, s1;
+    double rm = 0., l0m_u = 0.;
+    const double sqrt_rL = sqrt(rL);                       // r_L ** gamma
+    const double ueqp_L = u_eq_prime_d(rL, um);
+    if (rL < kEps) {
+        s0 = 0.0; s1 = uL; ci = 0;
+    } else if (rR < kEps) {
+        double qm_u = um + uL - qL;
+        double l0l = uL + rL * ueqp_L;
+        s0 = (l0l + qm_u) * 0.5; s1 = s0;
+        ci = (l0l >= 0.0) ? 0 : 2;
+    } else if (fabs(uL - uR) < kEps) {
+        s0 = 0.0; s1 = uR; ci = 0;
+    } else if (uL > uR) {
+        double b = sqrt_rL + ((uL - uR) / um);
+        rm = b * b;                                        // compute_Qm :194
+        double diff = rm * uR - rL * uL;
+        s0 = diff / pymax(rm - rL, kEps); s1 = uR;
+        ci = (s0 >= 0.0) ? 0 : 1;
+    } else if (um + uL - qL > uR) {
+        double b = sqrt_rL + ((uL - uR) / um);
+        rm = b * b;
+        double l0l = uL + rL * ueqp_L;
+        double l0m = uR + rm * u_eq_prime_d(rm, um);
+        s0 = (l0l + l0m) * 0.5; s1 = uR;
+        ci = (l0l >= 0) ? 0 : ((l0m <= 0) ? 1 : 2);
+    } else {
+        double qm_u = um + uL - qL;
+        double l0l = uL + rL * ueqp_L;
+        s0 = (l0l + qm_u) * 0.5; s1 = uR;
+        ci = (l0l >= 0.0) ? 0 : 2;
+    }
+    (void)l0m_u;
+    o.smax = fmax(fabs(s0), fabs(s1));
+
+    // ---- Q_0 (_arz.py:155-199, 316-326), its Jacobians (darz.py:12-192) ----
+    double r0, y0, u0, q0;
+    float dL[4], dR[4];
+    const double rLc = pymax(rL, kEps);
+    if (ci == 0) {
+        // compute_Ql: set_r_y on Python floats
+        r0 = rL; y0 = yL;
+        u0 = (yL / rLc) + u_eq_d(rLc, um);
+        q0 = u_eq_d(rL, um);
+    } else if (ci == 1) {
+        r0 = rm; u0 = uR;
+        q0 = u_eq_d(rm, um);
+        y0 = rm * (uR - q0);
+        // compute_dM, darz.py:35-122
+        const double rRc = pymax(rR, kEps);
+        const double ueqp_M = u_eq_prime_d(rm, um);
+        const double duL_drL = -yL / (rLc * rLc) + ueqp_L;
+        const double duL_dyL = 1.0 / rLc;
+        const double duR_drR = -yR / (rRc * rRc) + u_eq_prime_d(rRc, um);
+        const double duR_dyR = 1.0 / rRc;
+        const double a = (1.0 / kG) * sqrt(rm);
+        const double b = kG * (1.0 / sqrt(rLc));
+        const double c = (1.0 / um) * duL_drL;
+        const double drM_drL = a * (b + c);
+        const double d = (1.0 / um) * duL_dyL;
+        const double drM_dyL = a * d;
+        const double e = u0 - q0;
+        const double dyM_drL = drM_drL * e + rm * (-ueqp_M * drM_drL);
+        const double dyM_dyL = drM_dyL * e + rm * (-ueqp_M * drM_dyL);
+        const double f = (-1.0 / um) * duR_drR;
+        const double drM_drR = a * f;
+        const double g = (-1.0 / um) * duR_dyR;
+        const double drM_dyR = a * g;
+        const double dyM_drR = drM_drR * e + rm * (duR_drR - ueqp_M * drM_drR);
+        const double dyM_dyR = drM_dyR * e + rm * (duR_dyR - ueqp_M * drM_dyR);
+        dL[0] = (float)drM_drL; dL[1] = (float)drM_dyL; dL[2] = (float)dyM_drL; dL[3] = (float)dyM_dyL;
+        dR[0] = (float)drM_drR; dR[1] = (float)drM_dyR; dR[2] = (float)dyM_drR; dR[3] = (float)dyM_dyR;
+    } else {
+        // compute_Qc, _arz.py:167-182
+        const double base = uL + um * sqrt_rL;
+        const double t = base / (kG1 * um);
+        r0 = t * t;
+        u0 = kGoG1 * base;
+        q0 = u_eq_d(r0, um);
+        y0 = r0 * (u0 - q0);
+        // compute_dC, darz.py:124-192
+        const double ueqp_C = u_eq_prime_d(r0, um);
+        const double duL_drL = -yL / (rLc * rLc) + ueqp_L;
+        const double duL_dyL = 1.0 / rLc;
+        const double f = um * kG * (1.0 / sqrt(rLc));
+        const double duC_drL = kGoG1 * (duL_drL + f);
+        const double duC_dyL = kGoG1 * duL_dyL;
+        const double b = kG1 * um;
+        const double c = sqrt(r0);
+        const double d = c / kG;
+        const double e = d / b;
+        const double drC_drL = e * (duL_drL + f);
+        const double drC_dyL = e * duL_dyL;
+        const double g = u0 - q0;
+        const double dyC_drL = drC_drL * g + r0 * (duC_drL - ueqp_C * drC_drL);
+        const double dyC_dyL = drC_dyL * g + r0 * (duC_dyL - ueqp_C * drC_dyL);
+        dL[0] = (float)drC_drL; dL[1] = (float)drC_dyL; dL[2] = (float)dyC_drL; dL[3] = (float)dyC_dyL;
+    }
+    o.Fr = r0 * u0;
+    o.Fy = y0 * u0;
+
+    // ---- flux Jacobian at Q_0 (darz.py:217-233), float32 entries ----
+    const double r0c = pymax(r0, kEps);
+    const double ueqp_0 = u_eq_prime_d(r0c, um);
+    const double yor = y0 / r0c;
+    float fp[4];
+    fp[0] = (float)(q0 + r0c * ueqp_0);
+    fp[1] = 1.f;
+    fp[2] = (float)(y0 * ueqp_0 - yor * yor);
+    fp[3] = (float)((2.0 * y0) / r0c + q0);
+
+    // ---- fp @ dL, fp @ dR in float32 (np.matmul) ----
+    if (ci == 0) {          // dL = I, dR = 0: the products are fp and 0 exactly
+        o.A[0] = fp[0]; o.A[1] = fp[1]; o.A[2] = fp[2]; o.A[3] = fp[3];
+        o.B[0] = o.B[1] = o.B[2] = o.B[3] = 0.f;
+    } else {
+        o.A[0] = dot2(fp[0], dL[0], fp[1], dL[2]);
+        o.A[1] = dot2(fp[0], dL[1], fp[1], dL[3]);
+        o.A[2] = dot2(fp[2], dL[0], fp[3], dL[2]);
+        o.A[3] = dot2(fp[2], dL[1], fp[3], dL[3]);
+        if (ci == 1) {
+            o.B[0] = dot2(fp[0], dR[0], fp[1], dR[2]);
+            o.B[1] = dot2(fp[0], dR[1], fp[1], dR[3]);
+            o.B[2] = dot2(fp[2], dR[0], fp[3], dR[2]);
+            o.B[3] = dot2(fp[2], dR[1], fp[3], dR[3]);
+        } else {
+            o.B[0] = o.B[1] = o.B[2] = o.B[3] = 0.f;
+        }
+    }
+}
+
+}  // namespace dhts

@@ -1,0 +1,70 @@
+// idm_device.hpp -- device math of the IDM car-following step (gfx950).
+//
+// Implements model/micro/_idm.py:6-50 (acceleration with the two clips) and model/micro/didm.py:13-103
+// (2x2 Jacobians wrt the ego and the leading vehicle) for one vehicle, in double on float32 state, with the
+// Jacobian entries rounded to float32 (the reference assembles them in th.zeros((2, 2))).
+// Powers are the reference's integer ones: x**2, x**3, x**4 by multiplication, x**0.5 = sqrt.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dhts {
+
+struct IdmParams {      // road/vehicle/micro_vehicle.py:21-28, kept as doubles like the reference's Python floats
+    double a_max, a_pref, v_target, min_space, time_pref, length;
+};
+
+struct IdmStep {
+    float np, nv;       // next position / speed, float32 store (_micro_lane.py:182-183, :280-285)
+    float dE[4];        // d(p', v')/d(p, v) of the ego vehicle, row-major
+    float dLd[4];       // d(p', v')/d(p, v) of the leading vehicle
+    bool collided;      // raw gap < 0 (_micro_lane.py:188-192)
+};
+
+// p, v: ego state; dp_raw, dv_raw: gap and speed difference to the leader as compute_state_delta returns them
+// (_micro_lane.py:195-214).
+__device__ __forceinline__ void idm_step(double p, double v, double dp_raw, double dv_raw, const IdmParams &m,
+                                         double dt, IdmStep &o) {
+    double dp = dp_raw, dv = dv_raw;
+    o.collided = dp < 0;
+    if (o.collided) { dp = 0; dv = 0; }                    // :151-160 "Set deltas to 0"
+    const double dpc = (1e-5 > dp) ? 1e-5 : dp;            // :166 max(position_delta, POSITION_DELTA_EPS)
+
+    // IDM.compute_acceleration, _idm.py:30-50
+    const double two_sqrt_ab = 2 * sqrt(m.a_max * m.a_pref);
+    double s = (m.min_space + v * m.time_pref + ((v * dv) / two_sqrt_ab));
+    const bool clipped_s = (s < 0.0);
+    s = (0. > s) ? 0. : s;
+    const double vr = v / m.v_target;
+    const double vr2 = vr * vr;
+    const double sr = s / dpc;
+    double acc = m.a_max * (1.0 - vr2 * vr2 - sr * sr);
+    const double floor_acc = -v / dt;
+    const bool clipped_a = (acc < floor_acc);
+    acc = (floor_acc > acc) ? floor_acc : acc;
+
+    o.np = (float)(p + dt * v);
+    o.nv = (float)(v + dt * acc);
+
+    // dIDM.compute_dEgo / compute_dLeading, didm.py:38-103, with the UN-clamped deltas (dmicro_lane.py:97)
+    o.dE[0] = 1.f; o.dE[1] = (float)dt; o.dE[2] = 0.f; o.dE[3] = 0.f;
+    o.dLd[0] = o.dLd[1] = o.dLd[2] = o.dLd[3] = 0.f;
+    if (!clipped_a) {
+        const double dp2 = dp_raw * dp_raw;
+        const double dp3 = dp2 * dp_raw;
+        const double s2_dp3 = (s * s) / dp3;
+        const double vt2 = m.v_target * m.v_target;
+        const double free_term = -4.0 * ((v * v * v) / (vt2 * vt2));
+        const double s_dp2 = s / dp2;
+        o.dE[2] = (float)(dt * (-2 * m.a_max * s2_dp3));
+        o.dLd[2] = (float)(dt * (2 * m.a_max * s2_dp3));
+        if (clipped_s) {
+            o.dE[3] = (float)(1 + dt * m.a_max * free_term);
+            o.dLd[3] = (float)(dt * m.a_max * (-2 * s_dp2));
+        } else {
+            o.dE[3] = (float)(1 + dt * m.a_max * (free_term - 2 * s_dp2 * (m.time_pref + ((v + dv_raw) / two_sqrt_ab))));
+            o.dLd[3] = (float)(dt * m.a_max * (-2 * s_dp2 * (-v / two_sqrt_ab)));
+        }
+    }
+}
+
+}  // namespace dhts

@@ -1,0 +1,317 @@
+// macro_kernels.hip -- time-fused forward and reverse sweeps of the ARZ cell stencil on gfx950.
+//
+// Forward (macro_rollout_fwd_kernel): ONE 64-lane wavefront owns one traffic lane for the whole rollout.
+//   The lane's state (r, y, u, u_eq; float32, N cells + 2 ghosts) lives in LDS for all T steps; HBM sees only
+//   the initial load, the final store and the Jacobian tape (48 B per cell-step, written as three coalesced
+//   16-B-per-lane streams).  A step walks the lane in 64-cell passes from the downstream end to the upstream
+//   end: thread t of pass j solves interface i = 64 j + t (between cells i-1 and i) once, hands the result to
+//   thread t-1 through a wave shuffle (the cell left of an interface needs it as ITS right interface), and
+//   thread 63 takes the first interface of the previous pass from scalar registers.  Walking downstream ->
+//   upstream lets the update be done in place: a pass only writes cells >= 64 j that no later pass reads.
+//   No barrier, no second wave, no inter-workgroup traffic.
+// Reverse (macro_rollout_bwd_kernel): one workgroup per lane, cotangent (g_r, g_y) in LDS, tape read back as the
+//   same three streams, newest step first; g' = J^T g with the reference's float32 accumulation order.
+//
+// Reference: road/lane/_macro_lane.py:83-146, road/lane/dmacro_lane.py:96-132 and :277-309.
+#include <hip/hip_runtime.h>
+
+#include "../../include/dhts.h"
+#include "arz_device.hpp"
+
+namespace dhts {
+
+__device__ __forceinline__ double shfl_down1(double x) { return __shfl_down(x, 1, 64); }
+__device__ __forceinline__ float shfl_down1(float x) { return __shfl_down(x, 1, 64); }
+__device__ __forceinline__ float bcast0(float x) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
+}
+__device__ __forceinline__ double bcast0(double x) {
+    long long b = __double_as_longlong(x);
+    int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
+    int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ void raise_fault(dhts_error *err, int code, int step, int lane, int index) {
+    if (err == nullptr) return;
+    if (atomicCAS(&err->code, 0, code) == 0) {
+        err->step = step;
+        err->lane = lane;
+        err->index = index;
+    }
+}
+
+// grid = L workgroups of 64 threads; dynamic LDS = 4 * (N + 2) floats
+__global__ __launch_bounds__(64) void macro_rollout_fwd_kernel(
+    int L, int N, int T, double dt, double dx, double um,
+    const float *__restrict__ r_in, const float *__restrict__ y_in, const float *__restrict__ u_in,
+    const float *__restrict__ q_in, const float *__restrict__ ghost,
+    float *__restrict__ r_out, float *__restrict__ y_out, float *__restrict__ u_out, float *__restrict__ q_out,
+    float4 *__restrict__ tape, float *__restrict__ hist, dhts_error *err) {
+    extern __shared__ float lds[];
+    const int lane = blockIdx.x;
+    const int t = threadIdx.x;
+    const int P = N + 2;
+    float *Sr = lds, *Sy = lds + P, *Su = lds + 2 * P, *Sq = lds + 3 * P;
+    const size_t base = (size_t)lane * N;
+
+    for (int k = t; k < N; k += 64) {
+        Sr[k + 1] = r_in[base + k];
+        Sy[k + 1] = y_in[base + k];
+        Su[k + 1] = u_in[base + k];
+        Sq[k + 1] = q_in[base + k];
+    }
+    if (t < 2) {
+        const float *g = ghost + (size_t)lane * 8 + t * 4;
+        const int p = t ? N + 1 : 0;
+        Sr[p] = g[0]; Sy[p] = g[1]; Su[p] = g[2]; Sq[p] = g[3];
+    }
+    __syncthreads();
+
+    const int K = (N + 1 + 63) >> 6;           // passes per step: N + 1 interfaces
+    const int Np = (N + 63) & ~63;
+    const double c = dt / dx;                  // update_coefficient, _macro_lane.py:99
+    const float cf = (float)c, ncf = (float)(-c);
+    const float umf = (float)um;
+    int fault_step = -1, fault_index = 0;
+
+    for (int step = 0; step < T; ++step) {
+        // first interface of the pass above (j + 1), broadcast from its thread 0
+        double cFr = 0., cFy = 0.;
+        float cA0 = 0.f, cA1 = 0.f, cA2 = 0.f, cA3 = 0.f, cB0 = 0.f, cB1 = 0.f, cB2 = 0.f, cB3 = 0.f;
+        float4 *tp = tape ? tape + ((size_t)step * L + lane) * 3 * Np : nullptr;
+        float *hp = hist ? hist + ((size_t)step * L + lane) * 3 * N : nullptr;
+        for (int j = K - 1; j >= 0; --j) {
+            const int i = (j << 6) + t;        // interface i, and cell i to its right
+            const bool vi = i <= N;
+            const bool vc = i < N;
+            const int ii = vi ? i : N;
+            const double rL = Sr[ii], yL = Sy[ii], uL = Su[ii], qL = Sq[ii];
+            const float rCf = Sr[ii + 1], yCf = Sy[ii + 1];
+            const double rR = rCf, yR = yCf, uR = Su[ii + 1], qR = Sq[ii + 1];
+            Iface f;
+            arz_interface(rL, yL, uL, qL, rR, yR, uR, qR, um, f);
+            // CFL: dt < dx / max(|speed|, 1e-5) for both speeds (_macro_lane.py:141-146), tested as a product
+            if (vi && fault_step < 0 && !(dt * pymax(f.smax, 1e-5) < dx)) { fault_step = step; fault_index = i; }
+
+            // right interface of cell i = interface i + 1: thread t + 1, or the carried one for thread 63
+            double Fr_R = shfl_down1(f.Fr), Fy_R = shfl_down1(f.Fy);
+            float A0 = shfl_down1(f.A[0]), A1 = shfl_down1(f.A[1]), A2 = shfl_down1(f.A[2]), A3 = shfl_down1(f.A[3]);
+            float B0 = shfl_down1(f.B[0]), B1 = shfl_down1(f.B[1]), B2 = shfl_down1(f.B[2]), B3 = shfl_down1(f.B[3]);
+            if (t == 63) {
+                Fr_R = cFr; Fy_R = cFy;
+                A0 = cA0; A1 = cA1; A2 = cA2; A3 = cA3;
+                B0 = cB0; B1 = cB1; B2 = cB2; B3 = cB3;
+            }
+            cFr = bcast0(f.Fr); cFy = bcast0(f.Fy);
+            cA0 = bcast0(f.A[0]); cA1 = bcast0(f.A[1]); cA2 = bcast0(f.A[2]); cA3 = bcast0(f.A[3]);
+            cB0 = bcast0(f.B[0]); cB1 = bcast0(f.B[1]); cB2 = bcast0(f.B[2]); cB3 = bcast0(f.B[3]);
+
+            if (vc) {
+                // Godunov update, _macro_lane.py:109-112, float32 store :327-334
+                const float nr = (float)(rR + (f.Fr - Fr_R) * c);
+                const float ny = (float)(yR + (f.Fy - Fy_R) * c);
+                float nu, nq;
+                glue_from_r_y(nr, ny, umf, nu, nq);      // set_next_state_vector_y, :282-299
+                Sr[i + 1] = nr; Sy[i + 1] = ny; Su[i + 1] = nu; Sq[i + 1] = nq;
+                if (tp) {
+                    // dMacroLane._backward, dmacro_lane.py:126-129
+                    float4 d0, d1, d2;
+                    d0.x = ncf * (-f.A[0]); d0.y = ncf * (-f.A[1]); d0.z = ncf * (-f.A[2]); d0.w = ncf * (-f.A[3]);
+                    d2.x = ncf * B0; d2.y = ncf * B1; d2.z = ncf * B2; d2.w = ncf * B3;
+                    d1.x = 1.f - cf * (A0 - f.B[0]); d1.y = 0.f - cf * (A1 - f.B[1]);
+                    d1.z = 0.f - cf * (A2 - f.B[2]); d1.w = 1.f - cf * (A3 - f.B[3]);
+                    tp[i] = d0;
+                    tp[Np + i] = d1;
+                    tp[2 * Np + i] = d2;
+                }
+                if (hp) { hp[i] = nr; hp[N + i] = ny; hp[2 * N + i] = nu; }
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = t; k < N; k += 64) {
+        r_out[base + k] = Sr[k + 1];
+        y_out[base + k] = Sy[k + 1];
+        u_out[base + k] = Su[k + 1];
+        q_out[base + k] = Sq[k + 1];
+    }
+    if (fault_step >= 0) raise_fault(err, DHTS_FAULT_CFL, fault_step, lane, fault_index);
+}
+
+// grid = L workgroups of `blockDim.x` threads (multiple of 64); dynamic LDS = 6 * (N + 2) floats.
+// g' = J^T g per step: grad_cell[a][k] = dqs[a][k]^T g[a]; g'[b] = (c1[b] + c2[b-1]) + c0[b+1]   (dmacro_lane.py:283-303)
+__global__ void macro_rollout_bwd_kernel(
+    int L, int N, int T, const float4 *__restrict__ tape,
+    const float *__restrict__ g_r_in, const float *__restrict__ g_y_in, const float *__restrict__ g_hist,
+    float *__restrict__ g_r_out, float *__restrict__ g_y_out, double *__restrict__ g_ghost, dhts_error *err) {
+    extern __shared__ float lds[];
+    const int lane = blockIdx.x;
+    const int t = threadIdx.x;
+    const int B = blockDim.x;
+    const int P = N + 2;
+    // index k + 1 holds cell k; slots 0 and N + 1 stay zero for c2 / c0 so edge cells add 0
+    float *Gr = lds, *Gy = lds + P, *C0r = lds + 2 * P, *C0y = lds + 3 * P, *C2r = lds + 4 * P, *C2y = lds + 5 * P;
+    const size_t base = (size_t)lane * N;
+    const int Np = (N + 63) & ~63;
+
+    for (int k = t; k < P; k += B) { C0r[k] = 0.f; C0y[k] = 0.f; C2r[k] = 0.f; C2y[k] = 0.f; Gr[k] = 0.f; Gy[k] = 0.f; }
+    __syncthreads();
+    for (int k = t; k < N; k += B) { Gr[k + 1] = g_r_in[base + k]; Gy[k + 1] = g_y_in[base + k]; }
+    __syncthreads();
+
+    double ghl_r = 0., ghl_y = 0., ghr_r = 0., ghr_y = 0.;   // ghost cotangent sums (thread 0 / thread of cell N-1)
+    bool bad = false;
+    for (int step = T - 1; step >= 0; --step) {
+        const float4 *tp = tape + ((size_t)step * L + lane) * 3 * Np;
+        const float *gh = g_hist ? g_hist + ((size_t)step * L + lane) * 2 * N : nullptr;
+        for (int k = t; k < N; k += B) {
+            const float4 d0 = tp[k], d1 = tp[Np + k], d2 = tp[2 * Np + k];
+            float gr = Gr[k + 1], gy = Gy[k + 1];
+            if (gh) { gr += gh[k]; gy += gh[N + k]; }
+            const float c0r = dot2(d0.x, gr, d0.z, gy), c0y = dot2(d0.y, gr, d0.w, gy);
+            const float c1r = dot2(d1.x, gr, d1.z, gy), c1y = dot2(d1.y, gr, d1.w, gy);
+            const float c2r = dot2(d2.x, gr, d2.z, gy), c2y = dot2(d2.y, gr, d2.w, gy);
+            // c0 of cell k goes to cell k-1 (slot k), c2 of cell k goes to cell k+1 (slot k+2)
+            C0r[k] = c0r; C0y[k] = c0y;
+            C2r[k + 2] = c2r; C2y[k + 2] = c2y;
+            Gr[k + 1] = c1r; Gy[k + 1] = c1y;
+            if (k == 0) { ghl_r += (double)c0r; ghl_y += (double)c0y; }
+            if (k == N - 1) { ghr_r += (double)c2r; ghr_y += (double)c2y; }
+        }
+        __syncthreads();
+        for (int k = t; k < N; k += B) {
+            // slot k+1 of C2 = c2 of cell k-1 (0 for k = 0); slot k+1 of C0 = c0 of cell k+1 (0 for k = N-1)
+            const float c2lr = (k > 0) ? C2r[k + 1] : 0.f, c2ly = (k > 0) ? C2y[k + 1] : 0.f;
+            const float c0rr = (k < N - 1) ? C0r[k + 1] : 0.f, c0ry = (k < N - 1) ? C0y[k + 1] : 0.f;
+            const float nr = (Gr[k + 1] + c2lr) + c0rr;
+            const float ny = (Gy[k + 1] + c2ly) + c0ry;
+            Gr[k + 1] = nr; Gy[k + 1] = ny;
+            bad |= !(isfinite(nr) && isfinite(ny));
+        }
+        __syncthreads();
+    }
+    for (int k = t; k < N; k += B) { g_r_out[base + k] = Gr[k + 1]; g_y_out[base + k] = Gy[k + 1]; }
+    if (g_ghost) {
+        if (t == 0) { g_ghost[(size_t)lane * 4 + 0] = ghl_r; g_ghost[(size_t)lane * 4 + 1] = ghl_y; }
+        if (t == (N - 1) % B) { g_ghost[(size_t)lane * 4 + 2] = ghr_r; g_ghost[(size_t)lane * 4 + 3] = ghr_y; }
+    }
+    if (bad) raise_fault(err, DHTS_FAULT_NAN, 0, lane, t);
+}
+
+// ---- elementwise float32 glue ------------------------------------------------------------------------
+__global__ void macro_state_from_ru_kernel(int64_t n, float um, const float *__restrict__ r, const float *__restrict__ u,
+                                           float *__restrict__ y, float *__restrict__ q) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float yy, qq;
+        glue_from_r_u(r[i], u[i], um, yy, qq);
+        y[i] = yy;
+        q[i] = qq;
+    }
+}
+__global__ void macro_state_from_ru_bwd_kernel(int64_t n, float um, const float *__restrict__ r, const float *__restrict__ u,
+                                               const float *__restrict__ g_y, float *__restrict__ g_r, float *__restrict__ g_u) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gr = g_r[i], gu = 0.f;
+        glue_y_bwd(r[i], u[i], um, g_y[i], gr, gu);
+        g_r[i] = gr;
+        g_u[i] = gu;
+    }
+}
+__global__ void macro_u_tap_bwd_kernel(int64_t n, float um, const float *__restrict__ r, const float *__restrict__ y,
+                                       const float *__restrict__ g_u, float *__restrict__ g_r, float *__restrict__ g_y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gr = g_r[i], gy = g_y[i];
+        glue_u_bwd(r[i], y[i], um, g_u[i], gr, gy);
+        g_r[i] = gr;
+        g_y[i] = gy;
+    }
+}
+
+}  // namespace dhts
+
+// ---- C ABI -----------------------------------------------------------------------------------------------
+using namespace dhts;
+
+static inline bool macro_desc_ok(const dhts_macro_desc *d) {
+    return d && d->n_lanes > 0 && d->n_cells > 0 && d->n_cells <= DHTS_MACRO_MAX_CELLS && d->dt > 0 && d->dx > 0 && d->u_max > 0;
+}
+static inline int launch_status() { return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH; }
+static inline int grid_1d(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+extern "C" {
+
+int dhts_padded(int n) { return (n + 63) & ~63; }
+
+size_t dhts_macro_tape_bytes(const dhts_macro_desc *d, int T) {
+    if (!macro_desc_ok(d) || T < 0) return 0;
+    return (size_t)T * d->n_lanes * 3 * dhts_padded(d->n_cells) * sizeof(float4);
+}
+
+int dhts_macro_state_from_ru(int64_t n, double u_max, const float *r, const float *u, float *y, float *ueq, void *stream) {
+    if (n < 0 || !r || !u || !y || !ueq) return DHTS_E_INVALID;
+    if (n == 0) return DHTS_OK;
+    macro_state_from_ru_kernel<<<grid_1d(n), 256, 0, (hipStream_t)stream>>>(n, (float)u_max, r, u, y, ueq);
+    return launch_status();
+}
+int dhts_macro_state_from_ru_bwd(int64_t n, double u_max, const float *r, const float *u, const float *g_y,
+                                 float *g_r, float *g_u, void *stream) {
+    if (n < 0 || !r || !u || !g_y || !g_r || !g_u) return DHTS_E_INVALID;
+    if (n == 0) return DHTS_OK;
+    macro_state_from_ru_bwd_kernel<<<grid_1d(n), 256, 0, (hipStream_t)stream>>>(n, (float)u_max, r, u, g_y, g_r, g_u);
+    return launch_status();
+}
+int dhts_macro_u_tap_bwd(int64_t n, double u_max, const float *r, const float *y, const float *g_u,
+                         float *g_r, float *g_y, void *stream) {
+    if (n < 0 || !r || !y || !g_u || !g_r || !g_y) return DHTS_E_INVALID;
+    if (n == 0) return DHTS_OK;
+    macro_u_tap_bwd_kernel<<<grid_1d(n), 256, 0, (hipStream_t)stream>>>(n, (float)u_max, r, y, g_u, g_r, g_y);
+    return launch_status();
+}
+
+int dhts_macro_rollout_fwd(const dhts_macro_desc *d, int T,
+                           const float *r, const float *y, const float *u, const float *ueq, const float *ghost,
+                           float *r_out, float *y_out, float *u_out, float *ueq_out,
+                           float *tape, float *hist, dhts_error *err, void *stream) {
+    if (!macro_desc_ok(d) || T < 0 || !r || !y || !u || !ueq || !ghost || !r_out || !y_out || !u_out || !ueq_out)
+        return DHTS_E_INVALID;
+    const size_t lds = sizeof(float) * 4 * (size_t)(d->n_cells + 2);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)macro_rollout_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DHTS_E_LAUNCH;
+    macro_rollout_fwd_kernel<<<d->n_lanes, 64, lds, (hipStream_t)stream>>>(
+        d->n_lanes, d->n_cells, T, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out,
+        reinterpret_cast<float4 *>(tape), hist, err);
+    return launch_status();
+}
+
+int dhts_macro_rollout_bwd(const dhts_macro_desc *d, int T, const float *tape,
+                           const float *g_r, const float *g_y, const float *g_hist,
+                           float *g_r_out, float *g_y_out, double *g_ghost, dhts_error *err, void *stream) {
+    if (!macro_desc_ok(d) || T < 0 || (T > 0 && !tape) || !g_r || !g_y || !g_r_out || !g_y_out) return DHTS_E_INVALID;
+    const size_t lds = sizeof(float) * 6 * (size_t)(d->n_cells + 2);
+    int B = dhts_padded(d->n_cells);
+    if (B > 512) B = 512;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)macro_rollout_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DHTS_E_LAUNCH;
+    macro_rollout_bwd_kernel<<<d->n_lanes, B, lds, (hipStream_t)stream>>>(
+        d->n_lanes, d->n_cells, T, reinterpret_cast<const float4 *>(tape), g_r, g_y, g_hist, g_r_out, g_y_out, g_ghost, err);
+    return launch_status();
+}
+
+int dhts_macro_step_fwd(const dhts_macro_desc *d,
+                        const float *r, const float *y, const float *u, const float *ueq, const float *ghost,
+                        float *r_out, float *y_out, float *u_out, float *ueq_out,
+                        float *tape, dhts_error *err, void *stream) {
+    return dhts_macro_rollout_fwd(d, 1, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, tape, nullptr, err, stream);
+}
+int dhts_macro_step_bwd(const dhts_macro_desc *d, const float *tape, const float *g_r, const float *g_y,
+                        float *g_r_out, float *g_y_out, double *g_ghost, dhts_error *err, void *stream) {
+    return dhts_macro_rollout_bwd(d, 1, tape, g_r, g_y, nullptr, g_r_out, g_y_out, g_ghost, err, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,226 @@
+// micro_kernels.hip -- time-fused forward and reverse sweeps of the IDM car-following ODE on gfx950.
+//
+// Forward (micro_rollout_fwd_kernel<K>): one 64-lane wavefront owns one traffic lane for the whole rollout.
+//   Vehicle slot i follows slot i + 1 (MicroLane.curr_vehicle order), so the leader of a vehicle is simply the
+//   next slot: positions and speeds (float32) live in LDS, thread t of pass j owns slot 64 j + t, its six
+//   double parameters stay in registers for all T steps (K = passes is a template parameter so they do), and
+//   passes run tail -> head so that a pass reads its leaders' OLD state before the next pass overwrites it.
+//   HBM sees the initial load, the final store and the Jacobian tape (32 B per vehicle-step, two coalesced
+//   16-B-per-lane streams).  The head vehicle uses the lane's (head_position_delta, head_speed_delta).
+// Reverse (micro_rollout_bwd_kernel): one workgroup per lane, cotangent in LDS, newest step first:
+//   g'[i] = dEgo[i]^T g[i] + dLeading[i-1]^T g[i-1]; the virtual-leader slot's cotangent returns to the head
+//   vehicle and to the head gap (dmicro_lane.py:130-153, 271-298).
+//
+// Reference: road/lane/_micro_lane.py:131-214, road/lane/dmicro_lane.py:87-127 and :271-298.
+#include <hip/hip_runtime.h>
+
+#include "../../include/dhts.h"
+#include "arz_device.hpp"   // dot2
+#include "idm_device.hpp"
+
+namespace dhts {
+
+__device__ __forceinline__ void raise_fault_m(dhts_error *err, int code, int step, int lane, int index) {
+    if (err == nullptr) return;
+    if (atomicCAS(&err->code, 0, code) == 0) {
+        err->step = step;
+        err->lane = lane;
+        err->index = index;
+    }
+}
+
+// grid = L workgroups of 64 threads; dynamic LDS = 2 * (V + 1) floats
+template <int K>
+__global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
+    int L, int V, int T, double dt,
+    const float *__restrict__ p_in, const float *__restrict__ v_in, const int32_t *__restrict__ count,
+    const double *__restrict__ params, const double *__restrict__ head,
+    float *__restrict__ p_out, float *__restrict__ v_out, float4 *__restrict__ tape, float *__restrict__ hist,
+    dhts_error *err) {
+    extern __shared__ float lds[];
+    const int lane = blockIdx.x;
+    const int t = threadIdx.x;
+    float *Sp = lds, *Sv = lds + (V + 1);
+    const size_t base = (size_t)lane * V;
+    const int n = count ? count[lane] : V;
+    const int Vp = (V + 63) & ~63;
+    const size_t plane = (size_t)L * V;
+
+    IdmParams prm[K];
+    double len_lead[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int i = (j << 6) + t;
+        const int ic = i < V ? i : V - 1;
+        const int il = (i + 1) < V ? (i + 1) : V - 1;
+        prm[j].a_max = params[0 * plane + base + ic];
+        prm[j].a_pref = params[1 * plane + base + ic];
+        prm[j].v_target = params[2 * plane + base + ic];
+        prm[j].min_space = params[3 * plane + base + ic];
+        prm[j].time_pref = params[4 * plane + base + ic];
+        prm[j].length = params[5 * plane + base + ic];
+        len_lead[j] = params[5 * plane + base + il];
+    }
+    for (int k = t; k < V; k += 64) { Sp[k] = p_in[base + k]; Sv[k] = v_in[base + k]; }
+    if (t == 0) { Sp[V] = 0.f; Sv[V] = 0.f; }
+    __syncthreads();
+    const double head_dp = head[(size_t)lane * 2], head_dv = head[(size_t)lane * 2 + 1];
+    int fault_step = -1, fault_index = 0;
+
+    for (int step = 0; step < T; ++step) {
+        float4 *tp = tape ? tape + ((size_t)step * L + lane) * 2 * Vp : nullptr;
+        float *hp = hist ? hist + ((size_t)step * L + lane) * 2 * V : nullptr;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int i = (j << 6) + t;
+            const bool valid = i < n;
+            const int ic = valid ? i : 0;
+            const double p = Sp[ic], v = Sv[ic];
+            const double pl = Sp[ic + 1], vl = Sv[ic + 1];
+            double dp, dv;
+            if (i == n - 1) {                         // compute_state_delta, _micro_lane.py:201-204
+                dp = head_dp; dv = head_dv;
+            } else {                                  // :206-212
+                dp = fabs(pl - p) - ((len_lead[j] + prm[j].length) * 0.5);
+                dv = v - vl;
+            }
+            IdmStep o;
+            idm_step(p, v, dp, dv, prm[j], dt, o);
+            if (valid) {
+                if (o.collided && fault_step < 0) { fault_step = step; fault_index = i; }
+                Sp[i] = o.np; Sv[i] = o.nv;
+                if (tp) {
+                    tp[i] = make_float4(o.dE[0], o.dE[1], o.dE[2], o.dE[3]);
+                    tp[Vp + i] = make_float4(o.dLd[0], o.dLd[1], o.dLd[2], o.dLd[3]);
+                }
+                if (hp) { hp[i] = o.np; hp[V + i] = o.nv; }
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = t; k < V; k += 64) { p_out[base + k] = Sp[k]; v_out[base + k] = Sv[k]; }
+    if (fault_step >= 0) raise_fault_m(err, DHTS_FAULT_COLLISION, fault_step, lane, fault_index);
+}
+
+// grid = L workgroups of blockDim.x threads; dynamic LDS = 4 * (V + 2) floats
+__global__ void micro_rollout_bwd_kernel(
+    int L, int V, int T, const float4 *__restrict__ tape, const int32_t *__restrict__ count,
+    const float *__restrict__ g_p_in, const float *__restrict__ g_v_in, const float *__restrict__ g_hist,
+    float *__restrict__ g_p_out, float *__restrict__ g_v_out, double *__restrict__ g_head, dhts_error *err) {
+    extern __shared__ float lds[];
+    const int lane = blockIdx.x;
+    const int t = threadIdx.x;
+    const int B = blockDim.x;
+    const int P = V + 2;
+    float *Gp = lds, *Gv = lds + P, *C1p = lds + 2 * P, *C1v = lds + 3 * P;   // C1[i + 1] = dLeading[i]^T g[i]
+    const size_t base = (size_t)lane * V;
+    const int n = count ? count[lane] : V;
+    const int Vp = (V + 63) & ~63;
+
+    for (int k = t; k < P; k += B) { Gp[k] = 0.f; Gv[k] = 0.f; C1p[k] = 0.f; C1v[k] = 0.f; }
+    __syncthreads();
+    for (int k = t; k < n; k += B) { Gp[k] = g_p_in[base + k]; Gv[k] = g_v_in[base + k]; }
+    __syncthreads();
+
+    double gh_p = 0., gh_v = 0.;       // held by the thread that owns the head vehicle
+    for (int step = T - 1; step >= 0; --step) {
+        const float4 *tp = tape + ((size_t)step * L + lane) * 2 * Vp;
+        const float *gh = g_hist ? g_hist + ((size_t)step * L + lane) * 2 * V : nullptr;
+        for (int k = t; k < n; k += B) {
+            const float4 dE = tp[k], dLd = tp[Vp + k];
+            float gp = Gp[k], gv = Gv[k];
+            if (gh) { gp += gh[k]; gv += gh[V + k]; }
+            Gp[k] = dot2(dE.x, gp, dE.z, gv);          // grad_ps[:-1] = dqs[:, 0]^T g
+            Gv[k] = dot2(dE.y, gp, dE.w, gv);
+            C1p[k + 1] = dot2(dLd.x, gp, dLd.z, gv);   // grad_ps[1:] += dqs[:, 1]^T g
+            C1v[k + 1] = dot2(dLd.y, gp, dLd.w, gv);
+        }
+        __syncthreads();
+        for (int k = t; k < n; k += B) {
+            float np_ = Gp[k], nv_ = Gv[k];
+            if (k > 0) { np_ += C1p[k]; nv_ += C1v[k]; }
+            if (k == n - 1) {
+                // virtual leader = (p_head + head_dp, v_head - head_dv): its cotangent C1[n] returns to the head
+                const float vp = C1p[n], vv = C1v[n];
+                gh_p += (double)vp;
+                gh_v -= (double)vv;
+                np_ += vp; nv_ += vv;
+            }
+            Gp[k] = np_; Gv[k] = nv_;
+        }
+        __syncthreads();
+    }
+    for (int k = t; k < V; k += B) {
+        g_p_out[base + k] = (k < n) ? Gp[k] : 0.f;
+        g_v_out[base + k] = (k < n) ? Gv[k] : 0.f;
+    }
+    if (g_head) {
+        if (n == 0) { if (t == 0) { g_head[(size_t)lane * 2] = 0.; g_head[(size_t)lane * 2 + 1] = 0.; } }
+        else if (t == (n - 1) % B) { g_head[(size_t)lane * 2] = gh_p; g_head[(size_t)lane * 2 + 1] = gh_v; }
+    }
+    (void)err;
+}
+
+}  // namespace dhts
+
+using namespace dhts;
+
+static inline bool micro_desc_ok(const dhts_micro_desc *d) {
+    return d && d->n_lanes > 0 && d->capacity > 0 && d->capacity <= DHTS_MICRO_MAX_VEHICLES && d->dt > 0;
+}
+static inline int launch_status_m() { return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH; }
+
+template <int K>
+static void launch_micro_fwd(const dhts_micro_desc *d, int T, const float *p, const float *v, const int32_t *count,
+                             const double *params, const double *head, float *p_out, float *v_out, float *tape,
+                             float *hist, dhts_error *err, hipStream_t s) {
+    const size_t lds = sizeof(float) * 2 * (size_t)(d->capacity + 1);
+    micro_rollout_fwd_kernel<K><<<d->n_lanes, 64, lds, s>>>(d->n_lanes, d->capacity, T, d->dt, p, v, count, params, head,
+                                                           p_out, v_out, reinterpret_cast<float4 *>(tape), hist, err);
+}
+
+extern "C" {
+
+size_t dhts_micro_tape_bytes(const dhts_micro_desc *d, int T) {
+    if (!micro_desc_ok(d) || T < 0) return 0;
+    return (size_t)T * d->n_lanes * 2 * ((d->capacity + 63) & ~63) * sizeof(float4);
+}
+
+int dhts_micro_rollout_fwd(const dhts_micro_desc *d, int T,
+                           const float *p, const float *v, const int32_t *count, const double *params, const double *head,
+                           float *p_out, float *v_out, float *tape, float *hist, dhts_error *err, void *stream) {
+    if (!micro_desc_ok(d) || T < 0 || !p || !v || !params || !head || !p_out || !v_out) return DHTS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int K = (d->capacity + 63) >> 6;
+    if (K <= 1) launch_micro_fwd<1>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    else if (K <= 2) launch_micro_fwd<2>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    else if (K <= 4) launch_micro_fwd<4>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    else if (K <= 8) launch_micro_fwd<8>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    else launch_micro_fwd<16>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    return launch_status_m();
+}
+
+int dhts_micro_rollout_bwd(const dhts_micro_desc *d, int T, const float *tape, const int32_t *count,
+                           const float *g_p, const float *g_v, const float *g_hist,
+                           float *g_p_out, float *g_v_out, double *g_head, dhts_error *err, void *stream) {
+    if (!micro_desc_ok(d) || T < 0 || (T > 0 && !tape) || !g_p || !g_v || !g_p_out || !g_v_out) return DHTS_E_INVALID;
+    const size_t lds = sizeof(float) * 4 * (size_t)(d->capacity + 2);
+    int B = (d->capacity + 63) & ~63;
+    if (B > 256) B = 256;
+    micro_rollout_bwd_kernel<<<d->n_lanes, B, lds, (hipStream_t)stream>>>(
+        d->n_lanes, d->capacity, T, reinterpret_cast<const float4 *>(tape), count, g_p, g_v, g_hist, g_p_out, g_v_out, g_head, err);
+    return launch_status_m();
+}
+
+int dhts_micro_step_fwd(const dhts_micro_desc *d,
+                        const float *p, const float *v, const int32_t *count, const double *params, const double *head,
+                        float *p_out, float *v_out, float *tape, dhts_error *err, void *stream) {
+    return dhts_micro_rollout_fwd(d, 1, p, v, count, params, head, p_out, v_out, tape, nullptr, err, stream);
+}
+int dhts_micro_step_bwd(const dhts_micro_desc *d, const float *tape, const int32_t *count,
+                        const float *g_p, const float *g_v,
+                        float *g_p_out, float *g_v_out, double *g_head, dhts_error *err, void *stream) {
+    return dhts_micro_rollout_bwd(d, 1, tape, count, g_p, g_v, nullptr, g_p_out, g_v_out, g_head, err, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+"""ctypes binding of libdhts.so (C ABI: include/dhts.h).
+
+The shared object is built in-tree by `diff-hybrid-traffic-sim_amd/csrc/Makefile` (driven by
+`__graft_entry__.build()`).  There is NO fallback: if the library is missing or a call fails, an exception
+is raised -- the product path never routes through a CPU implementation.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+SO_PATH = os.path.join(CSRC, "libdhts.so")
+
+OK, E_INVALID, E_LAUNCH, E_NO_DEVICE = 0, -1, -2, -3
+FAULT_NONE, FAULT_CFL, FAULT_COLLISION, FAULT_NAN = 0, 1, 2, 3
+MACRO_MAX_CELLS = 4000
+MICRO_MAX_VEHICLES = 1024
+
+
+class MacroDesc(C.Structure):
+    _fields_ = [("n_lanes", C.c_int32), ("n_cells", C.c_int32), ("dt", C.c_double), ("dx", C.c_double),
+                ("u_max", C.c_double)]
+
+
+class MicroDesc(C.Structure):
+    _fields_ = [("n_lanes", C.c_int32), ("capacity", C.c_int32), ("dt", C.c_double)]
+
+
+# name -> (restype, argtypes); every symbol include/dhts.h declares
+_P = C.c_void_p
+SIGNATURES = {
+    "dhts_version": (C.c_int, []),
+    "dhts_device_count": (C.c_int, []),
+    "dhts_padded": (C.c_int, [C.c_int]),
+    "dhts_macro_tape_bytes": (C.c_size_t, [C.POINTER(MacroDesc), C.c_int]),
+    "dhts_macro_state_from_ru": (C.c_int, [C.c_int64, C.c_double, _P, _P, _P, _P, _P]),
+    "dhts_macro_state_from_ru_bwd": (C.c_int, [C.c_int64, C.c_double, _P, _P, _P, _P, _P, _P]),
+    "dhts_macro_u_tap_bwd": (C.c_int, [C.c_int64, C.c_double, _P, _P, _P, _P, _P, _P]),
+    "dhts_macro_rollout_fwd": (C.c_int, [C.POINTER(MacroDesc), C.c_int] + [_P] * 13),
+    "dhts_macro_rollout_bwd": (C.c_int, [C.POINTER(MacroDesc), C.c_int] + [_P] * 9),
+    "dhts_macro_step_fwd": (C.c_int, [C.POINTER(MacroDesc)] + [_P] * 12),
+    "dhts_macro_step_bwd": (C.c_int, [C.POINTER(MacroDesc)] + [_P] * 8),
+    "dhts_micro_tape_bytes": (C.c_size_t, [C.POINTER(MicroDesc), C.c_int]),
+    "dhts_micro_rollout_fwd": (C.c_int, [C.POINTER(MicroDesc), C.c_int] + [_P] * 11),
+    "dhts_micro_rollout_bwd": (C.c_int, [C.POINTER(MicroDesc), C.c_int] + [_P] * 10),
+    "dhts_micro_step_fwd": (C.c_int, [C.POINTER(MicroDesc)] + [_P] * 10),
+    "dhts_micro_step_bwd": (C.c_int, [C.POINTER(MicroDesc)] + [_P] * 9),
+}
+
+_lib = None
+
+
+class DhtsError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libdhts.so; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise DhtsError(
+                "libdhts.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C diff-hybrid-traffic-sim_amd/csrc`). There is no CPU fallback." % SO_PATH)
+        handle = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)       # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != OK:
+        names = {E_INVALID: "DHTS_E_INVALID (bad argument)", E_LAUNCH: "DHTS_E_LAUNCH (HIP launch failed)",
+                 E_NO_DEVICE: "DHTS_E_NO_DEVICE"}
+        raise DhtsError("%s failed: %s" % (what, names.get(status, status)))

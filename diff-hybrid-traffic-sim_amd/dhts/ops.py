@@ -1,0 +1,266 @@
+"""Device-side operators over libdhts.so: raw calls on torch CUDA tensors + torch.autograd.Functions.
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping, the optimiser outside); every
+per-step computation of the hot path is a hand-written HIP kernel behind the C ABI (include/dhts.h).
+
+Mirrors the reference operators
+    dMacroForwardLayer  road/lane/dmacro_lane.py:234-309
+    dMicroForwardLayer  road/lane/dmicro_lane.py:228-298
+batched over lanes and fused over time steps.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import MacroDesc, MicroDesc, check
+
+EPS = 1e-5  # model/macro/_arz.py:2
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise TypeError("%s must be a float32 CUDA tensor (got %s on %s)" % (name, t.dtype, t.device))
+    return t.contiguous()
+
+
+def new_error_record(device):
+    """Device-side sticky fault record (dhts_error): int32 [code, step, lane, index]."""
+    return torch.zeros(4, dtype=torch.int32, device=device)
+
+
+def raise_on_fault(err):
+    """Read the record back (synchronises) and raise the way the reference asserts."""
+    code, step, lane, index = err.tolist()
+    if code == _lib.FAULT_CFL:
+        # road/lane/_macro_lane.py:145-146
+        raise AssertionError("Time step size does not meet CFL condition. Please try smaller delta_time. "
+                             "(step %d, lane %d, interface %d)" % (step, lane, index))
+    if code == _lib.FAULT_NAN:
+        raise AssertionError("non-finite gradient in the reverse sweep (lane %d)" % lane)   # dmacro_lane.py:308
+    return code   # FAULT_COLLISION is printed-and-tolerated in the reference (_micro_lane.py:155-160)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# macro
+# ---------------------------------------------------------------------------------------------------------
+def macro_desc(L, N, dt, dx, u_max):
+    if not (1 <= N <= _lib.MACRO_MAX_CELLS):
+        raise ValueError("cells per lane must be in 1..%d" % _lib.MACRO_MAX_CELLS)
+    return MacroDesc(int(L), int(N), float(dt), float(dx), float(u_max))
+
+
+def macro_tape_numel(desc, T):
+    return _lib.lib().dhts_macro_tape_bytes(C.byref(desc), int(T)) // 4
+
+
+def macro_state_from_ru(r, u, u_max):
+    r, u = _f32c(r, "r"), _f32c(u, "u")
+    y, q = torch.empty_like(r), torch.empty_like(r)
+    check(_lib.lib().dhts_macro_state_from_ru(r.numel(), float(u_max), _ptr(r), _ptr(u), _ptr(y), _ptr(q), _stream()),
+          "dhts_macro_state_from_ru")
+    return y, q
+
+
+def macro_state_from_ru_bwd(r, u, g_y, g_r, u_max):
+    """g_r is updated in place; returns g_u."""
+    g_u = torch.empty_like(r)
+    check(_lib.lib().dhts_macro_state_from_ru_bwd(r.numel(), float(u_max), _ptr(r), _ptr(u), _ptr(g_y), _ptr(g_r),
+                                                  _ptr(g_u), _stream()), "dhts_macro_state_from_ru_bwd")
+    return g_u
+
+
+def macro_u_tap_bwd(r, y, g_u, g_r, g_y, u_max):
+    """g_r, g_y updated in place."""
+    check(_lib.lib().dhts_macro_u_tap_bwd(r.numel(), float(u_max), _ptr(r), _ptr(y), _ptr(g_u), _ptr(g_r), _ptr(g_y),
+                                          _stream()), "dhts_macro_u_tap_bwd")
+
+
+def macro_rollout_fwd(desc, T, r, y, u, ueq, ghost, tape=None, hist=None, err=None, out=None):
+    """state planes [L][N]; ghost [L][2][4]; returns (r, y, u, ueq) after T steps."""
+    L, N = desc.n_lanes, desc.n_cells
+    for name, t in (("r", r), ("y", y), ("u", u), ("ueq", ueq)):
+        if tuple(t.shape) != (L, N):
+            raise ValueError("%s must have shape (%d, %d)" % (name, L, N))
+    if tuple(ghost.shape) != (L, 2, 4):
+        raise ValueError("ghost must have shape (%d, 2, 4)" % L)
+    r, y, u, ueq, ghost = (_f32c(t, n) for t, n in ((r, "r"), (y, "y"), (u, "u"), (ueq, "ueq"), (ghost, "ghost")))
+    if out is None:
+        out = tuple(torch.empty_like(r) for _ in range(4))
+    check(_lib.lib().dhts_macro_rollout_fwd(C.byref(desc), int(T), _ptr(r), _ptr(y), _ptr(u), _ptr(ueq), _ptr(ghost),
+                                            _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]),
+                                            _ptr(tape), _ptr(hist), _ptr(err), _stream()), "dhts_macro_rollout_fwd")
+    return out
+
+
+def macro_rollout_bwd(desc, T, tape, g_r, g_y, g_hist=None, err=None, out=None, g_ghost=None):
+    """returns (g_r0, g_y0, g_ghost[L][2][2] float64)."""
+    g_r, g_y = _f32c(g_r, "g_r"), _f32c(g_y, "g_y")
+    if out is None:
+        out = (torch.empty_like(g_r), torch.empty_like(g_y))
+    if g_ghost is None:
+        g_ghost = torch.zeros(desc.n_lanes, 2, 2, dtype=torch.float64, device=g_r.device)
+    check(_lib.lib().dhts_macro_rollout_bwd(C.byref(desc), int(T), _ptr(tape), _ptr(g_r), _ptr(g_y), _ptr(g_hist),
+                                            _ptr(out[0]), _ptr(out[1]), _ptr(g_ghost), _ptr(err), _stream()),
+          "dhts_macro_rollout_bwd")
+    return out[0], out[1], g_ghost
+
+
+class MacroRollout(torch.autograd.Function):
+    """T fused differentiable steps of L independent straight ARZ lanes.
+
+    (r0, u0 [L][N], ghost_r, ghost_u [L][2]) -> (rT, yT, uT [L][N]) (+ hist [T][L][3][N] when asked).
+    What example/inverse/macro.py does with one dMacroLane in a RoadNetwork (macro.py:34-68,
+    _inverse.py:91-99), for L lanes at once: state set by set_state_vector_u, ghosts by
+    set_leftmost_cell / set_rightmost_cell, T x RoadNetwork.forward, state read by get_state_vector.
+    """
+
+    @staticmethod
+    def forward(ctx, r0, u0, ghost_r, ghost_u, T, dt, dx, u_max, want_hist=False, check_faults=True):
+        L, N = r0.shape
+        desc = macro_desc(L, N, dt, dx, u_max)
+        r0c, u0c = _f32c(r0.detach(), "r0"), _f32c(u0.detach(), "u0")
+        gr, gu = _f32c(ghost_r.detach(), "ghost_r"), _f32c(ghost_u.detach(), "ghost_u")
+        y0, q0 = macro_state_from_ru(r0c, u0c, u_max)
+        gy, gq = macro_state_from_ru(gr, gu, u_max)
+        ghost = torch.stack([gr, gy, gu, gq], dim=-1).contiguous()            # [L][2][4]
+        need_grad = any(t.requires_grad for t in (r0, u0, ghost_r, ghost_u))
+        tape = torch.empty(macro_tape_numel(desc, T), dtype=torch.float32, device=r0.device) if need_grad else None
+        hist = torch.empty(T, L, 3, N, dtype=torch.float32, device=r0.device) if want_hist else None
+        err = new_error_record(r0.device)
+        rT, yT, uT, qT = macro_rollout_fwd(desc, T, r0c, y0, u0c, q0, ghost, tape=tape, hist=hist, err=err)
+        if check_faults:
+            raise_on_fault(err)
+        ctx.desc, ctx.T, ctx.u_max, ctx.tape, ctx.want_hist = desc, T, u_max, tape, want_hist
+        ctx.save_for_backward(r0c, u0c, gr, gu, gq, rT, yT, hist)
+        ctx.mark_non_differentiable(qT)
+        if want_hist:
+            return rT, yT, uT, qT, hist
+        return rT, yT, uT, qT
+
+    @staticmethod
+    def backward(ctx, g_rT, g_yT, g_uT, _g_qT, g_hist=None):
+        r0, u0, gr, gu, gq, rT, yT, hist = ctx.saved_tensors
+        desc, T, um = ctx.desc, ctx.T, ctx.u_max
+        L, N = desc.n_lanes, desc.n_cells
+        dev = r0.device
+        g_r = g_rT.contiguous().clone() if g_rT is not None else torch.zeros(L, N, device=dev)
+        g_y = g_yT.contiguous().clone() if g_yT is not None else torch.zeros(L, N, device=dev)
+        if g_uT is not None:
+            macro_u_tap_bwd(rT, yT, g_uT.contiguous(), g_r, g_y, um)
+        gh = None
+        if ctx.want_hist and g_hist is not None:
+            # per-step taps: (r, y) cotangents directly, u cotangent through the float32 glue of that step's state
+            hr, hy = hist[:, :, 0].contiguous(), hist[:, :, 1].contiguous()
+            ghr, ghy = g_hist[:, :, 0].contiguous().clone(), g_hist[:, :, 1].contiguous().clone()
+            macro_u_tap_bwd(hr, hy, g_hist[:, :, 2].contiguous(), ghr, ghy, um)
+            gh = torch.stack([ghr, ghy], dim=2).contiguous()                   # [T][L][2][N]
+        err = new_error_record(dev)
+        g_r0, g_y0, g_ghost = macro_rollout_bwd(desc, T, ctx.tape, g_r, g_y, g_hist=gh, err=err)
+        raise_on_fault(err)
+        g_u0 = macro_state_from_ru_bwd(r0, u0, g_y0, g_r0, um)
+        # ghost (r, y) cotangent sums -> ghost (r, u) leaves, in double (the sum is ill-conditioned)
+        rr, uu, qq = gr.double(), gu.double(), gq.double()
+        dueq = torch.where(rr < 0, torch.zeros_like(rr), -um * 0.5 / torch.sqrt(rr.clamp_min(0) + EPS))
+        g_gr = (g_ghost[..., 0] + g_ghost[..., 1] * ((uu - qq) - rr * dueq)).float()
+        g_gu = (g_ghost[..., 1] * rr).float()
+        return g_r0, g_u0, g_gr, g_gu, None, None, None, None, None, None
+
+
+def macro_rollout(r0, u0, ghost_r, ghost_u, T, dt, dx, u_max, want_hist=False, check_faults=True):
+    return MacroRollout.apply(r0, u0, ghost_r, ghost_u, int(T), float(dt), float(dx), float(u_max), want_hist,
+                              check_faults)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# micro
+# ---------------------------------------------------------------------------------------------------------
+def micro_desc(L, V, dt):
+    if not (1 <= V <= _lib.MICRO_MAX_VEHICLES):
+        raise ValueError("vehicle slots per lane must be in 1..%d" % _lib.MICRO_MAX_VEHICLES)
+    return MicroDesc(int(L), int(V), float(dt))
+
+
+def micro_tape_numel(desc, T):
+    return _lib.lib().dhts_micro_tape_bytes(C.byref(desc), int(T)) // 4
+
+
+def micro_rollout_fwd(desc, T, p, v, params, head, count=None, tape=None, hist=None, err=None, out=None):
+    """p, v [L][V] float32; params [6][L][V] float64; head [L][2] float64; count [L] int32 or None."""
+    L, V = desc.n_lanes, desc.capacity
+    p, v = _f32c(p, "p"), _f32c(v, "v")
+    if tuple(p.shape) != (L, V) or tuple(v.shape) != (L, V):
+        raise ValueError("p, v must have shape (%d, %d)" % (L, V))
+    if params.dtype != torch.float64 or tuple(params.shape) != (6, L, V):
+        raise ValueError("params must be float64 [6][L][V]")
+    if head.dtype != torch.float64 or tuple(head.shape) != (L, 2):
+        raise ValueError("head must be float64 [L][2]")
+    if count is not None and (count.dtype != torch.int32 or tuple(count.shape) != (L,)):
+        raise ValueError("count must be int32 [L]")
+    params, head = params.contiguous(), head.contiguous()
+    if out is None:
+        out = (torch.empty_like(p), torch.empty_like(v))
+    check(_lib.lib().dhts_micro_rollout_fwd(C.byref(desc), int(T), _ptr(p), _ptr(v), _ptr(count), _ptr(params), _ptr(head),
+                                            _ptr(out[0]), _ptr(out[1]), _ptr(tape), _ptr(hist), _ptr(err), _stream()),
+          "dhts_micro_rollout_fwd")
+    return out
+
+
+def micro_rollout_bwd(desc, T, tape, g_p, g_v, count=None, g_hist=None, err=None, out=None, g_head=None):
+    g_p, g_v = _f32c(g_p, "g_p"), _f32c(g_v, "g_v")
+    if out is None:
+        out = (torch.empty_like(g_p), torch.empty_like(g_v))
+    if g_head is None:
+        g_head = torch.zeros(desc.n_lanes, 2, dtype=torch.float64, device=g_p.device)
+    check(_lib.lib().dhts_micro_rollout_bwd(C.byref(desc), int(T), _ptr(tape), _ptr(count), _ptr(g_p), _ptr(g_v),
+                                            _ptr(g_hist), _ptr(out[0]), _ptr(out[1]), _ptr(g_head), _ptr(err), _stream()),
+          "dhts_micro_rollout_bwd")
+    return out[0], out[1], g_head
+
+
+class MicroRollout(torch.autograd.Function):
+    """T fused differentiable IDM steps of L independent lanes with a fixed head gap.
+
+    (p0, v0 [L][V]) -> (pT, vT) (+ hist [T][L][2][V]).  What example/inverse/micro.py does with one dMicroLane
+    (micro.py:36-118): vehicles ordered tail -> head, head gap = lane defaults (1000, 0).
+    The head gap is differentiable: `head` [L][2] float64 receives the cotangent of
+    (head_position_delta, head_speed_delta).
+    """
+
+    @staticmethod
+    def forward(ctx, p0, v0, params, head, count, T, dt, want_hist=False):
+        L, V = p0.shape
+        desc = micro_desc(L, V, dt)
+        p0c, v0c = _f32c(p0.detach(), "p0"), _f32c(v0.detach(), "v0")
+        need_grad = p0.requires_grad or v0.requires_grad or head.requires_grad
+        tape = torch.empty(micro_tape_numel(desc, T), dtype=torch.float32, device=p0.device) if need_grad else None
+        hist = torch.empty(T, L, 2, V, dtype=torch.float32, device=p0.device) if want_hist else None
+        err = new_error_record(p0.device)
+        pT, vT = micro_rollout_fwd(desc, T, p0c, v0c, params, head.detach(), count=count, tape=tape, hist=hist, err=err)
+        ctx.desc, ctx.T, ctx.tape, ctx.count, ctx.want_hist, ctx.err = desc, T, tape, count, want_hist, err
+        if want_hist:
+            return pT, vT, hist
+        return pT, vT
+
+    @staticmethod
+    def backward(ctx, g_pT, g_vT, g_hist=None):
+        desc, T = ctx.desc, ctx.T
+        dev = ctx.tape.device
+        L, V = desc.n_lanes, desc.capacity
+        g_p = g_pT.contiguous() if g_pT is not None else torch.zeros(L, V, device=dev)
+        g_v = g_vT.contiguous() if g_vT is not None else torch.zeros(L, V, device=dev)
+        gh = g_hist.contiguous() if (ctx.want_hist and g_hist is not None) else None
+        g_p0, g_v0, g_head = micro_rollout_bwd(desc, T, ctx.tape, g_p, g_v, count=ctx.count, g_hist=gh)
+        return g_p0, g_v0, None, g_head, None, None, None, None
+
+
+def micro_rollout(p0, v0, params, head, T, dt, count=None, want_hist=False):
+    return MicroRollout.apply(p0, v0, params, head, count, int(T), float(dt), want_hist)

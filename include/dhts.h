@@ -1,0 +1,169 @@
+/*
+ * dhts.h -- C ABI of libdhts.so: the MI355X (gfx950) differentiable traffic stepper.
+ *
+ * The reference (SonSang/diff-hybrid-traffic-sim) has NO FFI: its hot path sits behind two Python
+ * torch.autograd.Function operators,
+ *     dMacroForwardLayer   road/lane/dmacro_lane.py:234-309   (ARZ cell stencil, forward + Jacobian tape)
+ *     dMicroForwardLayer   road/lane/dmicro_lane.py:228-298   (IDM car-following ODE, forward + tape)
+ * each called once per lane per step from RoadNetwork.forward (road/network/road_network.py:99-101).
+ * This header is the boundary a maintainer binds instead (ctypes stub in INTEGRATION.md): plain
+ * pointers and sizes, no torch types.  Every entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *   - All array pointers are DEVICE pointers owned by the caller (hipMalloc / torch CUDA tensors),
+ *     float32 unless stated.  Nothing is allocated, freed or synchronised inside a call; work is
+ *     enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *   - Return value: DHTS_OK, or a negative DHTS_E_* for a host-side failure (bad argument, launch
+ *     error).  Simulation faults the reference reports with `assert` (CFL violation
+ *     _macro_lane.py:141-146, vehicle collision _micro_lane.py:151-162) are written to the optional
+ *     device-side sticky record `dhts_error*` (first fault wins) and read back by the caller after the
+ *     rollout; the rollout itself continues the way the reference's arithmetic would.
+ *   - Layouts: state planes are [lane][cell] (cell fastest).  The Jacobian tape is internal to this
+ *     library but documented so it can be inspected:
+ *         macro: [step][lane][3][Np][4] float32, Np = dhts_padded(N) (multiple of 64); plane k = 0/1/2 holds
+ *                d(next cell a)/d(cell a-1 / a / a+1) as row-major 2x2 in (r, y) -- the reference's
+ *                dqs[a][k] (dmacro_lane.py:50-56) with the cell index moved inside for coalescing.
+ *         micro: [step][lane][2][Vp][4] float32; plane 0 = dEgo, plane 1 = dLeading (dmicro_lane.py:48-54).
+ */
+#ifndef DHTS_H
+#define DHTS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DHTS_VERSION 100 /* 0.1.0 */
+
+#define DHTS_OK 0
+#define DHTS_E_INVALID (-1)   /* bad argument (NULL where required, non-positive size, unsupported size) */
+#define DHTS_E_LAUNCH (-2)    /* HIP launch / runtime error */
+#define DHTS_E_NO_DEVICE (-3) /* no gfx950 device visible */
+
+/* fault codes in dhts_error.code */
+#define DHTS_FAULT_NONE 0
+#define DHTS_FAULT_CFL 1       /* dt >= dx / max(|speed|, 1e-5) at an interface  (_macro_lane.py:141-146) */
+#define DHTS_FAULT_COLLISION 2 /* gap to the leader < 0                           (_micro_lane.py:151-162) */
+#define DHTS_FAULT_NAN 3       /* non-finite cotangent in the reverse sweep       (dmacro_lane.py:308)     */
+
+typedef struct dhts_error {
+    int32_t code;  /* DHTS_FAULT_*; 0 = no fault.  Caller zeroes it before the first call. */
+    int32_t step;  /* step index within the rollout */
+    int32_t lane;  /* lane index */
+    int32_t index; /* interface / vehicle index within the lane */
+} dhts_error;
+
+/* ---- macro (ARZ) ------------------------------------------------------------------------------- */
+typedef struct dhts_macro_desc {
+    int32_t n_lanes;  /* L: independent lanes in the batch */
+    int32_t n_cells;  /* N: cells per lane (1 .. DHTS_MACRO_MAX_CELLS) */
+    double dt;        /* delta_time */
+    double dx;        /* cell_length (MacroLane.cell_length, _macro_lane.py:44) */
+    double u_max;     /* speed_limit */
+} dhts_macro_desc;
+
+#define DHTS_MACRO_MAX_CELLS 4000
+
+int dhts_version(void);
+/* number of visible gfx950 devices, or DHTS_E_NO_DEVICE */
+int dhts_device_count(void);
+/* cells / vehicle slots rounded up to the tape's padded width (multiple of 64) */
+int dhts_padded(int n);
+/* bytes of Jacobian tape for T steps */
+size_t dhts_macro_tape_bytes(const dhts_macro_desc *d, int T);
+
+/* float32 glue of FullQ.set_r_u / FullQ.from_r_u (model/macro/_arz.py:73-86 with :121-138):
+ * y = r * (u - u_eq(r)), u_eq = u_max * (1 - sqrt(max(r, 0) + 1e-5)); n elements. */
+int dhts_macro_state_from_ru(int64_t n, double u_max, const float *r, const float *u, float *y, float *ueq, void *stream);
+/* its adjoint as torch autograd evaluates it: g_r += g_y * d y/d r, g_u = g_y * r   (g_r in/out, g_u out) */
+int dhts_macro_state_from_ru_bwd(int64_t n, double u_max, const float *r, const float *u, const float *g_y,
+                                 float *g_r, float *g_u, void *stream);
+/* adjoint of the speed tap u = y / max(r, eps) + u_eq(max(r, eps)) of FullQ.set_r_y (_arz.py:88-92,126-131):
+ * g_r += g_u * d u/d r, g_y += g_u * d u/d y   (both in/out) */
+int dhts_macro_u_tap_bwd(int64_t n, double u_max, const float *r, const float *y, const float *g_u,
+                         float *g_r, float *g_y, void *stream);
+
+/*
+ * T fused steps of L independent lanes: replaces T x L calls of dMacroForwardLayer.forward
+ * (dmacro_lane.py:236-275 = MacroLane.forward _macro_lane.py:83-146 + dMacroLane._backward :96-132 +
+ * the float32 u/u_eq glue of set_next_state_vector_y _macro_lane.py:282-299).
+ *   in : r, y, u, ueq [L][N]; ghost [L][2][4] = per lane (left, right) x (r, y, u, ueq), constant over the
+ *        rollout (RoadNetwork.setup_macro_boundary for a lane without neighbours, road_network.py:299-387)
+ *   out: r_out, y_out, u_out, ueq_out [L][N] (may alias the inputs);
+ *        tape (dhts_macro_tape_bytes) or NULL for a non-differentiable run;
+ *        hist [T][L][3][N] = (r, y, u) after every step, or NULL
+ */
+int dhts_macro_rollout_fwd(const dhts_macro_desc *d, int T,
+                           const float *r, const float *y, const float *u, const float *ueq, const float *ghost,
+                           float *r_out, float *y_out, float *u_out, float *ueq_out,
+                           float *tape, float *hist, dhts_error *err, void *stream);
+/*
+ * Reverse sweep over the tape: replaces T x L calls of dMacroForwardLayer.backward (dmacro_lane.py:277-309).
+ *   in : g_r, g_y [L][N] cotangent of the final (r, y); g_hist [T][L][2][N] optional cotangent of the
+ *        (r, y) after every step (NULL = none)
+ *   out: g_r_out, g_y_out [L][N] cotangent of the initial (r, y) (may alias the inputs);
+ *        g_ghost [L][2][2] DOUBLE = per lane (left, right) x (r, y): sum over steps of the cotangent that
+ *        reaches the ghost cells (grad_ry[0], grad_ry[-1] of dmacro_lane.py:302-303)
+ */
+int dhts_macro_rollout_bwd(const dhts_macro_desc *d, int T, const float *tape,
+                           const float *g_r, const float *g_y, const float *g_hist,
+                           float *g_r_out, float *g_y_out, double *g_ghost, dhts_error *err, void *stream);
+
+/* One step = the drop-in for a batch of dMacroForwardLayer.forward / .backward calls (T = 1 of the above;
+ * tape is one step's worth). */
+int dhts_macro_step_fwd(const dhts_macro_desc *d,
+                        const float *r, const float *y, const float *u, const float *ueq, const float *ghost,
+                        float *r_out, float *y_out, float *u_out, float *ueq_out,
+                        float *tape, dhts_error *err, void *stream);
+int dhts_macro_step_bwd(const dhts_macro_desc *d, const float *tape, const float *g_r, const float *g_y,
+                        float *g_r_out, float *g_y_out, double *g_ghost, dhts_error *err, void *stream);
+
+/* ---- micro (IDM) ------------------------------------------------------------------------------- */
+typedef struct dhts_micro_desc {
+    int32_t n_lanes;   /* L */
+    int32_t capacity;  /* V: vehicle slots per lane (1 .. DHTS_MICRO_MAX_VEHICLES); slot i follows slot i+1,
+                          head = slot count-1 (MicroLane.curr_vehicle order, _micro_lane.py:31-34) */
+    double dt;
+} dhts_micro_desc;
+
+#define DHTS_MICRO_MAX_VEHICLES 1024
+#define DHTS_MICRO_NPARAM 6 /* accel_max, accel_pref, target_speed, min_space, time_pref, length (micro_vehicle.py:21-28) */
+
+size_t dhts_micro_tape_bytes(const dhts_micro_desc *d, int T);
+
+/*
+ * T fused steps of L independent lanes: replaces T x L calls of dMicroForwardLayer.forward
+ * (dmicro_lane.py:230-269 = MicroLane.forward _micro_lane.py:131-214 + dMicroLane._backward :87-127).
+ *   in : p, v [L][V]; count [L] int32 vehicles per lane or NULL (= V everywhere);
+ *        params [6][L][V] DOUBLE (the reference keeps them as Python floats);
+ *        head [L][2] DOUBLE = (head_position_delta, head_speed_delta) per lane, constant over the rollout
+ *        (defaults 1000 / 0, _micro_lane.py:14-15)
+ *   out: p_out, v_out [L][V]; tape or NULL; hist [T][L][2][V] = (p, v) after every step, or NULL
+ */
+int dhts_micro_rollout_fwd(const dhts_micro_desc *d, int T,
+                           const float *p, const float *v, const int32_t *count, const double *params, const double *head,
+                           float *p_out, float *v_out, float *tape, float *hist, dhts_error *err, void *stream);
+/*
+ * Reverse sweep: replaces T x L calls of dMicroForwardLayer.backward (dmicro_lane.py:271-298), including the
+ * virtual-leader slot of dMicroLane.vectorize_input (:130-153) whose cotangent returns to the head vehicle and
+ * to (head_position_delta, head_speed_delta).
+ *   in : g_p, g_v [L][V]; g_hist [T][L][2][V] optional
+ *   out: g_p_out, g_v_out [L][V]; g_head [L][2] DOUBLE = cotangent of (head_position_delta, head_speed_delta)
+ */
+int dhts_micro_rollout_bwd(const dhts_micro_desc *d, int T, const float *tape, const int32_t *count,
+                           const float *g_p, const float *g_v, const float *g_hist,
+                           float *g_p_out, float *g_v_out, double *g_head, dhts_error *err, void *stream);
+
+int dhts_micro_step_fwd(const dhts_micro_desc *d,
+                        const float *p, const float *v, const int32_t *count, const double *params, const double *head,
+                        float *p_out, float *v_out, float *tape, dhts_error *err, void *stream);
+int dhts_micro_step_bwd(const dhts_micro_desc *d, const float *tape, const int32_t *count,
+                        const float *g_p, const float *g_v,
+                        float *g_p_out, float *g_v_out, double *g_head, dhts_error *err, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DHTS_H */

@@ -396,10 +396,12 @@ int oracle_macro_rollout_fwd(int L, int N, int T, double dt, double dx, double u
                              float *hist_r, float *hist_y, float *hist_u) {
     int rc = ORACLE_OK;
     size_t P = (size_t)N + 2;
-    float *buf = (float *)malloc(sizeof(float) * P * 8);
-    float *r = buf, *y = buf + P, *u = buf + 2 * P, *q = buf + 3 * P;
-    float *nr = buf + 4 * P, *ny = buf + 5 * P, *nu = buf + 6 * P, *nq = buf + 7 * P;
+    /* lanes are independent: OpenMP over lanes (bench.py's cpu_baseline uses all host cores) */
+#pragma omp parallel for schedule(dynamic, 1)
     for (int l = 0; l < L; l++) {
+        float *buf = (float *)malloc(sizeof(float) * P * 8);
+        float *r = buf, *y = buf + P, *u = buf + 2 * P, *q = buf + 3 * P;
+        float *nr = buf + 4 * P, *ny = buf + 5 * P, *nu = buf + 6 * P, *nq = buf + 7 * P;
         for (int i = 0; i < N; i++) {                      /* set_state_vector_u :246-263 */
             r[i + 1] = r0[(size_t)l * N + i];
             u[i + 1] = u0[(size_t)l * N + i];
@@ -412,7 +414,10 @@ int oracle_macro_rollout_fwd(int L, int N, int T, double dt, double dx, double u
         for (int t = 0; t < T; t++) {
             float *d = tape ? tape + ((size_t)t * L + l) * N * 12 : NULL;
             int e = oracle_macro_step(N, r, y, u, q, dt, dx, u_max, nr, ny, nu, nq, d, NULL, NULL, NULL);
-            if (e && !rc) rc = e;
+            if (e) {
+#pragma omp critical
+                if (!rc) rc = e;
+            }
             memcpy(r + 1, nr, sizeof(float) * N);          /* update_state :202-213 */
             memcpy(y + 1, ny, sizeof(float) * N);
             memcpy(u + 1, nu, sizeof(float) * N);
@@ -425,8 +430,8 @@ int oracle_macro_rollout_fwd(int L, int N, int T, double dt, double dx, double u
         memcpy(rT + (size_t)l * N, r + 1, sizeof(float) * N);
         memcpy(yT + (size_t)l * N, y + 1, sizeof(float) * N);
         memcpy(uT + (size_t)l * N, u + 1, sizeof(float) * N);
+        free(buf);
     }
-    free(buf);
     return rc;
 }
 
@@ -439,10 +444,11 @@ void oracle_macro_rollout_bwd(int L, int N, int T, double u_max,
                               const float *gh_r, const float *gh_y, const float *gh_u,
                               float *g_r0, float *g_u0, float *g_ghost_r, float *g_ghost_u) {
     size_t P = (size_t)N + 2;
-    float *buf = (float *)malloc(sizeof(float) * P * 4);
-    float *gr = buf, *gy = buf + P, *ngr = buf + 2 * P, *ngy = buf + 3 * P;
     float um = (float)u_max;
+#pragma omp parallel for schedule(dynamic, 1)
     for (int l = 0; l < L; l++) {
+        float *buf = (float *)malloc(sizeof(float) * P * 4);
+        float *gr = buf, *gy = buf + P, *ngr = buf + 2 * P, *ngy = buf + 3 * P;
         size_t lo = (size_t)l * N;
         double ggl[2] = {0., 0.}, ggr[2] = {0., 0.};   /* cotangent on ghost (r, y), left / right */
         for (int i = 0; i < N; i++) {                      /* loss taps on the final (r, y, u) */
@@ -482,8 +488,8 @@ void oracle_macro_rollout_bwd(int L, int N, int T, double u_max,
             g_ghost_r[l * 2 + s] = (float)(gr_ + gy_ * ((uu - ueq) - rr * dueq));
             g_ghost_u[l * 2 + s] = (float)(gy_ * rr);
         }
+        free(buf);
     }
-    free(buf);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -578,16 +584,20 @@ int oracle_micro_rollout_fwd(int L, int V, int T, double dt, const float *p0, co
                              const double *params, double head_dp, double head_dv,
                              float *pT, float *vT, float *tape, float *hist_p, float *hist_v) {
     int rc = ORACLE_OK;
-    float *buf = (float *)malloc(sizeof(float) * (size_t)V * 4);
-    float *p = buf, *v = buf + V, *np_ = buf + 2 * V, *nv_ = buf + 3 * V;
+#pragma omp parallel for schedule(dynamic, 1)
     for (int l = 0; l < L; l++) {
+        float *buf = (float *)malloc(sizeof(float) * (size_t)V * 4);
+        float *p = buf, *v = buf + V, *np_ = buf + 2 * V, *nv_ = buf + 3 * V;
         memcpy(p, p0 + (size_t)l * V, sizeof(float) * V);
         memcpy(v, v0 + (size_t)l * V, sizeof(float) * V);
         for (int t = 0; t < T; t++) {
             size_t ho = ((size_t)t * L + l) * V;
             int e = oracle_micro_step(V, p, v, params + (size_t)l * V * 6, head_dp, head_dv, dt, np_, nv_,
                                       tape ? tape + ho * 8 : NULL, NULL);
-            if (e && !rc) rc = e;
+            if (e) {
+#pragma omp critical
+                if (!rc) rc = e;
+            }
             memcpy(p, np_, sizeof(float) * V);             /* update_state :216-225 */
             memcpy(v, nv_, sizeof(float) * V);
             if (hist_p) memcpy(hist_p + ho, p, sizeof(float) * V);
@@ -595,17 +605,18 @@ int oracle_micro_rollout_fwd(int L, int V, int T, double dt, const float *p0, co
         }
         memcpy(pT + (size_t)l * V, p, sizeof(float) * V);
         memcpy(vT + (size_t)l * V, v, sizeof(float) * V);
+        free(buf);
     }
-    free(buf);
     return rc;
 }
 
 void oracle_micro_rollout_bwd(int L, int V, int T, const float *tape,
                               const float *g_pT, const float *g_vT, const float *gh_p, const float *gh_v,
                               float *g_p0, float *g_v0, float *g_head) {
-    float *buf = (float *)malloc(sizeof(float) * (size_t)(V + 1) * 4);
-    float *gp = buf, *gv = buf + (V + 1), *ngp = buf + 2 * (V + 1), *ngv = buf + 3 * (V + 1);
+#pragma omp parallel for schedule(dynamic, 1)
     for (int l = 0; l < L; l++) {
+        float *buf = (float *)malloc(sizeof(float) * (size_t)(V + 1) * 4);
+        float *gp = buf, *gv = buf + (V + 1), *ngp = buf + 2 * (V + 1), *ngv = buf + 3 * (V + 1);
         size_t lo = (size_t)l * V;
         float gh[2] = {0.f, 0.f};
         for (int i = 0; i < V; i++) {
@@ -630,6 +641,6 @@ void oracle_micro_rollout_bwd(int L, int V, int T, const float *tape,
         memcpy(g_p0 + lo, gp, sizeof(float) * V);
         memcpy(g_v0 + lo, gv, sizeof(float) * V);
         if (g_head) { g_head[l * 2] = gh[0]; g_head[l * 2 + 1] = gh[1]; }
+        free(buf);
     }
-    free(buf);
 }

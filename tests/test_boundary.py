@@ -1,0 +1,83 @@
+"""The drop-in boundary: libdhts.so loads and exports every symbol include/dhts.h declares; host-side argument
+checks; the product never touches the oracle.  No GPU needed (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import PKG, ROOT
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "dhts.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dhts_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dhts import _lib
+    lib = _lib.lib()
+    names = header_functions()
+    assert len(names) >= 16
+    for n in names:
+        assert hasattr(lib, n), "libdhts.so does not export %s" % n
+    # and the binding table covers the header exactly
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_version_and_padding():
+    from dhts import _lib
+    lib = _lib.lib()
+    assert lib.dhts_version() == 100
+    assert [lib.dhts_padded(n) for n in (1, 64, 65, 512)] == [64, 64, 128, 512]
+
+
+def test_tape_bytes_match_documented_layout():
+    from dhts import _lib
+    lib = _lib.lib()
+    d = _lib.MacroDesc(1024, 512, 0.01, 5.0, 30.0)
+    assert lib.dhts_macro_tape_bytes(C.byref(d), 1000) == 1000 * 1024 * 3 * 512 * 16    # 48 B per cell-step
+    m = _lib.MicroDesc(4096, 256, 0.01)
+    assert lib.dhts_micro_tape_bytes(C.byref(m), 1000) == 1000 * 4096 * 2 * 256 * 16    # 32 B per vehicle-step
+    bad = _lib.MacroDesc(0, 512, 0.01, 5.0, 30.0)
+    assert lib.dhts_macro_tape_bytes(C.byref(bad), 10) == 0
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    from dhts import _lib
+    lib = _lib.lib()
+    d = _lib.MacroDesc(4, 0, 0.01, 5.0, 30.0)           # zero cells
+    assert lib.dhts_macro_rollout_fwd(C.byref(d), 1, *([None] * 13)) == _lib.E_INVALID
+    d = _lib.MacroDesc(4, 16, 0.01, 5.0, 30.0)          # NULL state pointers
+    assert lib.dhts_macro_rollout_fwd(C.byref(d), 1, *([None] * 13)) == _lib.E_INVALID
+    assert lib.dhts_macro_rollout_bwd(C.byref(d), 1, *([None] * 9)) == _lib.E_INVALID
+    m = _lib.MicroDesc(4, 5000, 0.01)                   # over capacity
+    assert lib.dhts_micro_rollout_fwd(C.byref(m), 1, *([None] * 11)) == _lib.E_INVALID
+    assert lib.dhts_macro_state_from_ru(8, 30.0, None, None, None, None, None) == _lib.E_INVALID
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from dhts import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "SO_PATH", os.path.join(PKG, "csrc", "does_not_exist.so"))
+    with pytest.raises(_lib.DhtsError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_product_does_not_touch_oracle():
+    """Nothing under the product package imports, links or mentions the oracle."""
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in txt.lower(), os.path.join(dirpath, f)
+    txt = open(os.path.join(ROOT, "include", "dhts.h")).read()
+    assert "oracle" not in txt.lower()
+
+
+def test_cpu_tensors_are_rejected():
+    import torch
+    from dhts import ops
+    with pytest.raises(TypeError, match="CUDA"):
+        ops.macro_state_from_ru(torch.zeros(4), torch.zeros(4), 30.0)

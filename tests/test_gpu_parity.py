@@ -1,0 +1,379 @@
+"""Parity of the HIP path (through the C ABI, libdhts.so) against the CPU oracle and the golden vectors.
+Needs a real MI355X:  python -m pytest tests -m gpu"""
+import os
+
+import numpy as np
+import pytest
+
+from util import TOL_GRAD, TOL_STATE, meta_of, rel_max, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+
+def T_(x, dev, dtype=None, grad=False):
+    import torch
+    t = torch.tensor(np.ascontiguousarray(x), device=dev, dtype=dtype)
+    if grad:
+        t.requires_grad_(True)
+    return t
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def tape_to_dqs(tape, T, L, N, planes=3):
+    """[T][L][planes][Np][4] -> the reference's dqs [T][L][N][planes][2][2]."""
+    Np = (N + 63) // 64 * 64
+    t = tape.cpu().numpy().reshape(T, L, planes, Np, 4)[:, :, :, :N, :]
+    return np.ascontiguousarray(t.transpose(0, 1, 3, 2, 4)).reshape(T, L, N, planes, 2, 2)
+
+
+def dqs_to_tape(dqs, planes=3):
+    T, L, N = dqs.shape[:3]
+    Np = (N + 63) // 64 * 64
+    out = np.zeros((T, L, planes, Np, 4), np.float32)
+    out[:, :, :, :N, :] = dqs.reshape(T, L, N, planes, 4).transpose(0, 1, 3, 2, 4)
+    return out
+
+
+# =================================================================================================================
+# macro
+# =================================================================================================================
+@pytest.mark.parametrize("name", ["rand64", "sanity100", "vacuum9", "single1", "jam33"])
+def test_macro_step_vs_golden_and_oracle(cuda, oracle, golden_dir, name):
+    """dhts_macro_step_fwd / _bwd against the reference's own single-step outputs (G3)."""
+    import torch
+    from dhts import ops
+    g = load(golden_dir, "macro_step.npz")
+    c = meta_of(g)["configs"][name]
+    st = g[name + "_state"]
+    N = c["N"]
+    desc = ops.macro_desc(1, N, c["dt"], c["dx"], c["u_max"])
+    planes = [T_(st[k, 1:-1][None], cuda) for k in range(4)]
+    ghost = T_(np.stack([st[:, 0], st[:, -1]])[None], cuda)           # [1][2][4]
+    tape = torch.zeros(ops.macro_tape_numel(desc, 1), device=cuda)
+    err = ops.new_error_record(cuda)
+    nr, ny, nu, nq = ops.macro_rollout_fwd(desc, 1, *planes, ghost, tape=tape, err=err)
+    assert ops.raise_on_fault(err) == 0
+    dqs = tape_to_dqs(tape, 1, 1, N)[0, 0]
+    o = oracle.macro_step(st, c["dt"], c["dx"], c["u_max"])
+    # device double arithmetic follows the oracle's operation order; only pow() vs sqrt()/mul differs
+    assert ulp_diff(nr.cpu().numpy()[0], o["nr"]).max() <= 1
+    assert ulp_diff(ny.cpu().numpy()[0], o["ny"]).max() <= 1
+    assert ulp_diff(nu.cpu().numpy()[0], o["nu"]).max() <= 2
+    assert ulp_diff(nq.cpu().numpy()[0], o["nueq"]).max() <= 1
+    assert rel_max(dqs, o["dqs"]) <= 1e-6
+    assert np.mean(dqs != o["dqs"]) <= 0.02
+    # and against the reference's own numbers
+    assert rel_max(nr.cpu().numpy()[0], g[name + "_nr"]) <= 2e-7
+    assert rel_max(ny.cpu().numpy()[0], g[name + "_ny"]) <= 2e-7
+    assert rel_max(dqs, g[name + "_dqs"]) <= 1e-6
+    # backward on the reference's tape and cotangents
+    tape_ref = T_(dqs_to_tape(g[name + "_dqs"][None, None]).reshape(-1), cuda)
+    g_r0, g_y0, g_ghost = ops.macro_rollout_bwd(desc, 1, tape_ref, T_(g[name + "_g_nr"][None], cuda), T_(g[name + "_g_ny"][None], cuda))
+    ref_r, ref_y = g[name + "_g_r"], g[name + "_g_y"]
+    assert np.array_equal(g_r0.cpu().numpy()[0], ref_r[1:-1]) and np.array_equal(g_y0.cpu().numpy()[0], ref_y[1:-1])
+    gg = g_ghost.cpu().numpy()[0]
+    assert np.allclose(gg[0], [ref_r[0], ref_y[0]], rtol=1e-6, atol=1e-7) and np.allclose(gg[1], [ref_r[-1], ref_y[-1]], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["small", "c1", "sanity", "bench64", "long"])
+def test_macro_rollout_vs_golden(cuda, golden_dir, name):
+    """Autograd-level drop-in (dhts.macro_rollout) against the reference's rollouts and gradients (G4)."""
+    import torch
+    import dhts
+    g = load(golden_dir, "macro_rollout_%s.npz" % name)
+    m = meta_of(g)
+    r0, u0 = T_(g["r0"][None], cuda, grad=True), T_(g["u0"][None], cuda, grad=True)
+    gr, gu = T_(g["ghost_r"][None], cuda, grad=True), T_(g["ghost_u"][None], cuda, grad=True)
+    every = m["tap"] == "every_sum"
+    out = dhts.macro_rollout(r0, u0, gr, gu, m["T"], m["dt"], m["dx"], m["u_max"], want_hist=True)
+    rT, yT, uT, _, hist = out
+    if every:
+        loss = hist.sum()
+    else:
+        loss = (rT ** 2).sum() + (uT ** 2).sum()
+    loss.backward()
+    assert rel_max(rT.detach().cpu().numpy()[0], g["rT"]) <= TOL_STATE
+    assert rel_max(yT.detach().cpu().numpy()[0], g["yT"]) <= TOL_STATE
+    assert rel_max(uT.detach().cpu().numpy()[0], g["uT"]) <= TOL_STATE
+    h = hist.detach().cpu().numpy()
+    for t in range(len(g["steps_r"])):
+        assert rel_max(h[t, 0, 0], g["steps_r"][t]) <= TOL_STATE
+        assert rel_max(h[t, 0, 1], g["steps_y"][t]) <= TOL_STATE
+        assert rel_max(h[t, 0, 2], g["steps_u"][t]) <= TOL_STATE
+    assert abs(float(loss) - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+    assert rel_max(r0.grad.cpu().numpy()[0], g["g_r0"]) <= TOL_GRAD
+    assert rel_max(u0.grad.cpu().numpy()[0], g["g_u0"]) <= TOL_GRAD
+    assert rel_max(gr.grad.cpu().numpy()[0], g["g_ghost_r"]) <= TOL_GRAD
+    assert rel_max(gu.grad.cpu().numpy()[0], g["g_ghost_u"]) <= TOL_GRAD
+
+
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 100, 127, 128, 129, 512, 1000])
+def test_macro_rollout_vs_oracle_sizes(cuda, oracle, N):
+    """Lane lengths around the 64-cell pass boundaries, several lanes, against the oracle."""
+    import torch
+    import dhts
+    rng = np.random.default_rng(100 + N)
+    L, T, dt, dx, um = 5, 25, 0.01, 5.0, 30.0
+    r0 = rng.uniform(0.0, 1.0, (L, N)).astype(np.float32)
+    u0 = rng.uniform(0.0, um, (L, N)).astype(np.float32)
+    if N > 8:
+        r0[0, 3:6] = 0.0          # vacuum cells
+        r0[1, N // 2] = 1e-6
+    gr = rng.uniform(0.0, 1.0, (L, 2)).astype(np.float32)
+    gu = rng.uniform(0.0, um, (L, 2)).astype(np.float32)
+    f = oracle.macro_rollout_fwd(r0, u0, gr, gu, T, dt, dx, um)
+    assert f["rc"] == 0
+    w_r = rng.standard_normal((L, N)).astype(np.float32)
+    w_u = rng.standard_normal((L, N)).astype(np.float32)
+    b = oracle.macro_rollout_bwd(f, g_rT=w_r, g_uT=w_u)
+    tr0, tu0 = T_(r0, cuda, grad=True), T_(u0, cuda, grad=True)
+    tgr, tgu = T_(gr, cuda, grad=True), T_(gu, cuda, grad=True)
+    rT, yT, uT, _ = dhts.macro_rollout(tr0, tu0, tgr, tgu, T, dt, dx, um)
+    ((rT * T_(w_r, cuda)).sum() + (uT * T_(w_u, cuda)).sum()).backward()
+    assert rel_max(rT.detach().cpu().numpy(), f["rT"]) <= TOL_STATE
+    assert rel_max(yT.detach().cpu().numpy(), f["yT"]) <= TOL_STATE
+    assert rel_max(uT.detach().cpu().numpy(), f["uT"]) <= TOL_STATE
+    assert rel_max(tr0.grad.cpu().numpy(), b["g_r0"]) <= TOL_GRAD
+    assert rel_max(tu0.grad.cpu().numpy(), b["g_u0"]) <= TOL_GRAD
+    assert rel_max(tgr.grad.cpu().numpy(), b["g_ghost_r"]) <= TOL_GRAD
+    assert rel_max(tgu.grad.cpu().numpy(), b["g_ghost_u"]) <= TOL_GRAD
+
+
+def test_macro_tape_matches_oracle_over_rollout(cuda, oracle):
+    """The whole Jacobian tape of a rollout, entry by entry."""
+    import torch
+    from dhts import ops
+    rng = np.random.default_rng(5)
+    L, N, T, dt, dx, um = 3, 150, 12, 0.01, 5.0, 30.0
+    r0 = rng.uniform(0.05, 0.95, (L, N)).astype(np.float32)
+    u0 = rng.uniform(0.0, um, (L, N)).astype(np.float32)
+    gr = rng.uniform(0.05, 0.95, (L, 2)).astype(np.float32)
+    gu = rng.uniform(0.0, um, (L, 2)).astype(np.float32)
+    f = oracle.macro_rollout_fwd(r0, u0, gr, gu, T, dt, dx, um)
+    desc = ops.macro_desc(L, N, dt, dx, um)
+    r, u = T_(r0, cuda), T_(u0, cuda)
+    y, q = ops.macro_state_from_ru(r, u, um)
+    tgr, tgu = T_(gr, cuda), T_(gu, cuda)
+    gy, gq = ops.macro_state_from_ru(tgr, tgu, um)
+    ghost = torch.stack([tgr, gy, tgu, gq], dim=-1).contiguous()
+    tape = torch.zeros(ops.macro_tape_numel(desc, T), device=cuda)
+    ops.macro_rollout_fwd(desc, T, r, y, u, q, ghost, tape=tape)
+    dqs = tape_to_dqs(tape, T, L, N)
+    assert rel_max(dqs, f["tape"]) <= 2e-6
+    assert np.mean(dqs != f["tape"]) <= 0.02
+
+
+def test_macro_cfl_fault(cuda):
+    """dt * speed >= dx: the reference asserts (_macro_lane.py:141-146); the drop-in raises the same way."""
+    import dhts
+    L, N = 2, 70
+    r0 = T_(np.full((L, N), 0.3, np.float32), cuda)
+    u0 = T_(np.full((L, N), 20.0, np.float32), cuda)
+    gr = T_(np.full((L, 2), 0.3, np.float32), cuda)
+    gu = T_(np.full((L, 2), 20.0, np.float32), cuda)
+    with pytest.raises(AssertionError, match="CFL"):
+        dhts.macro_rollout(r0, u0, gr, gu, 3, 1.0, 5.0, 30.0)
+    dhts.macro_rollout(r0, u0, gr, gu, 3, 0.01, 5.0, 30.0)
+
+
+def test_macro_full_size_properties(cuda):
+    """BASELINE config 2 (1024 lanes x 512 cells x 1000 steps) through size-independent properties:
+    bitwise repeatability, replica consistency (identical lanes -> identical results), lane independence
+    (a lane's result does not depend on its neighbours in the batch), and exact homogeneity of the adjoint."""
+    import torch
+    from dhts import ops
+    L, N, T, dt, dx, um = 1024, 512, 1000, 0.01, 5.0, 30.0
+    gen = torch.Generator(device="cpu").manual_seed(2026)
+    r0 = (0.05 + 0.9 * torch.rand(L, N, generator=gen)).to(cuda)
+    u0 = (um * torch.rand(L, N, generator=gen)).to(cuda)
+    gr = (0.05 + 0.9 * torch.rand(L, 2, generator=gen)).to(cuda)
+    gu = (um * torch.rand(L, 2, generator=gen)).to(cuda)
+    # lanes 1 and 2 are copies of lane 0; lane 3 is lane 700's copy
+    for dst, src in ((1, 0), (2, 0), (3, 700)):
+        r0[dst], u0[dst], gr[dst], gu[dst] = r0[src], u0[src], gr[src], gu[src]
+    desc = ops.macro_desc(L, N, dt, dx, um)
+    y0, q0 = ops.macro_state_from_ru(r0, u0, um)
+    gy, gq = ops.macro_state_from_ru(gr, gu, um)
+    ghost = torch.stack([gr, gy, gu, gq], dim=-1).contiguous()
+    tape = torch.empty(ops.macro_tape_numel(desc, T), device=cuda)
+    err = ops.new_error_record(cuda)
+    out1 = ops.macro_rollout_fwd(desc, T, r0, y0, u0, q0, ghost, tape=tape, err=err)
+    assert ops.raise_on_fault(err) == 0
+    rT, yT, uT, qT = out1
+    assert torch.isfinite(rT).all() and torch.isfinite(uT).all()
+    g_r, g_y = 2 * rT, torch.zeros_like(rT)
+    ops.macro_u_tap_bwd(rT, yT, 2 * uT, g_r, g_y, um)
+    b1 = ops.macro_rollout_bwd(desc, T, tape, g_r, g_y)
+    # replica consistency
+    for dst, src in ((1, 0), (2, 0), (3, 700)):
+        assert torch.equal(rT[dst], rT[src]) and torch.equal(uT[dst], uT[src])
+        assert torch.equal(b1[0][dst], b1[0][src]) and torch.equal(b1[1][dst], b1[1][src])
+    # exact homogeneity: J^T (2 g) == 2 J^T g bit for bit (power-of-two scaling is exact in float32)
+    b2 = ops.macro_rollout_bwd(desc, T, tape, 2 * g_r, 2 * g_y)
+    assert torch.equal(b2[0], 2 * b1[0]) and torch.equal(b2[1], 2 * b1[1])
+    # bitwise repeatability of forward + tape
+    tape2 = torch.empty_like(tape)
+    out2 = ops.macro_rollout_fwd(desc, T, r0, y0, u0, q0, ghost, tape=tape2)
+    assert all(torch.equal(a, b) for a, b in zip(out1, out2))
+    assert torch.equal(tape, tape2)
+    del tape2
+    # lane independence: a 16-lane sub-batch reproduces the same lanes of the full batch
+    sel = slice(690, 706)
+    d16 = ops.macro_desc(16, N, dt, dx, um)
+    tape16 = torch.empty(ops.macro_tape_numel(d16, T), device=cuda)
+    o16 = ops.macro_rollout_fwd(d16, T, r0[sel].contiguous(), y0[sel].contiguous(), u0[sel].contiguous(), q0[sel].contiguous(),
+                                ghost[sel].contiguous(), tape=tape16)
+    assert torch.equal(o16[0], rT[sel]) and torch.equal(o16[2], uT[sel])
+
+
+# =================================================================================================================
+# micro
+# =================================================================================================================
+def micro_inputs(g, cuda):
+    import torch
+    par = g["params"]                                        # [V][6]
+    params = T_(np.ascontiguousarray(par.T[:, None, :]), cuda, dtype=torch.float64)    # [6][1][V]
+    return params
+
+
+@pytest.mark.parametrize("name", ["inv10", "rand24", "dense16", "long"])
+def test_micro_rollout_vs_golden(cuda, golden_dir, name):
+    import torch
+    import dhts
+    g = load(golden_dir, "micro_rollout_%s.npz" % name)
+    m = meta_of(g)
+    p0, v0 = T_(g["p0"][None], cuda, grad=True), T_(g["v0"][None], cuda, grad=True)
+    head = T_(np.array([m["head"]], dtype=np.float64), cuda)
+    out = dhts.micro_rollout(p0, v0, micro_inputs(g, cuda), head, m["T"], m["dt"], want_hist=True)
+    pT, vT, hist = out
+    if m["tap"] == "every_sum":
+        loss = hist.sum()
+    else:
+        loss = 1e-4 * (pT ** 2).sum() + (vT ** 2).sum()
+    loss.backward()
+    assert rel_max(pT.detach().cpu().numpy()[0], g["pT"]) <= 1e-6
+    assert rel_max(vT.detach().cpu().numpy()[0], g["vT"]) <= 1e-6
+    h = hist.detach().cpu().numpy()
+    for t in range(len(g["steps_p"])):
+        assert ulp_diff(h[t, 0, 0], g["steps_p"][t]).max() <= 1
+        assert ulp_diff(h[t, 0, 1], g["steps_v"][t]).max() <= 1
+    assert rel_max(p0.grad.cpu().numpy()[0], g["g_p0"]) <= 1e-5
+    assert rel_max(v0.grad.cpu().numpy()[0], g["g_v0"]) <= 1e-5
+
+
+@pytest.mark.parametrize("V", [1, 2, 63, 64, 65, 128, 200, 256, 300, 600, 1024])
+def test_micro_rollout_vs_oracle_sizes(cuda, oracle, V):
+    import torch
+    import dhts
+    rng = np.random.default_rng(200 + V)
+    L, T, dt = 4, 30, 0.01
+    p0 = (np.arange(V)[None, :] * 20.0 + rng.uniform(0, 10, (L, V))).astype(np.float32)
+    v0 = rng.uniform(9, 21, (L, V)).astype(np.float32)
+    par = np.empty((L, V, 6))
+    par[..., 0] = 30.0 * rng.uniform(0.8, 1.5, (L, V))
+    par[..., 1] = 30.0 * rng.uniform(0.6, 1.5, (L, V))
+    par[..., 2] = 30.0 * rng.uniform(0.8, 1.2, (L, V))
+    par[..., 3] = rng.uniform(0.5, 5.0, (L, V))
+    par[..., 4] = rng.uniform(0.1, 1.5, (L, V))
+    par[..., 5] = 5.0
+    f = oracle.micro_rollout_fwd(p0, v0, par, T, dt, 37.5, 1.25)
+    w_p = rng.standard_normal((L, V)).astype(np.float32)
+    w_v = rng.standard_normal((L, V)).astype(np.float32)
+    b = oracle.micro_rollout_bwd(f, g_pT=w_p, g_vT=w_v)
+    tp0, tv0 = T_(p0, cuda, grad=True), T_(v0, cuda, grad=True)
+    head = T_(np.tile([37.5, 1.25], (L, 1)), cuda, dtype=torch.float64, grad=True)
+    params = T_(par.transpose(2, 0, 1), cuda, dtype=torch.float64)
+    pT, vT = dhts.micro_rollout(tp0, tv0, params, head, T, dt)
+    ((pT * T_(w_p, cuda)).sum() + (vT * T_(w_v, cuda)).sum()).backward()
+    assert rel_max(pT.detach().cpu().numpy(), f["pT"]) <= 1e-6
+    assert rel_max(vT.detach().cpu().numpy(), f["vT"]) <= 1e-6
+    assert rel_max(tp0.grad.cpu().numpy(), b["g_p0"]) <= 1e-5
+    assert rel_max(tv0.grad.cpu().numpy(), b["g_v0"]) <= 1e-5
+    assert rel_max(head.grad.cpu().numpy(), b["g_head"]) <= 1e-4
+
+
+def test_micro_ragged_and_empty_lanes(cuda, oracle):
+    """Per-lane vehicle counts: empty lane, single vehicle, partly filled, full."""
+    import torch
+    from dhts import ops
+    rng = np.random.default_rng(9)
+    V, T, dt = 100, 20, 0.01
+    counts = [0, 1, 37, 64, 65, 100]
+    L = len(counts)
+    p0 = (np.arange(V)[None, :] * 20.0 + rng.uniform(0, 10, (L, V))).astype(np.float32)
+    v0 = rng.uniform(9, 21, (L, V)).astype(np.float32)
+    par = np.tile(np.array([30.0, 24.0, 27.0, 0.5, 0.1, 5.0]), (L, V, 1))
+    desc = ops.micro_desc(L, V, dt)
+    tape = torch.zeros(ops.micro_tape_numel(desc, T), device=cuda)
+    head = T_(np.tile([1000.0, 0.0], (L, 1)), cuda, dtype=torch.float64)
+    params = T_(par.transpose(2, 0, 1), cuda, dtype=torch.float64)
+    count = T_(np.array(counts, np.int32), cuda)
+    pT, vT = ops.micro_rollout_fwd(desc, T, T_(p0, cuda), T_(v0, cuda), params, head, count=count, tape=tape)
+    w = rng.standard_normal((2, L, V)).astype(np.float32)
+    g_p0, g_v0, g_head = ops.micro_rollout_bwd(desc, T, tape, T_(w[0], cuda), T_(w[1], cuda), count=count)
+    for l, n in enumerate(counts):
+        if n == 0:
+            assert torch.equal(pT[l].cpu(), torch.tensor(p0[l])) and torch.equal(vT[l].cpu(), torch.tensor(v0[l]))
+            assert float(g_p0[l].abs().max()) == 0.0
+            continue
+        f = oracle.micro_rollout_fwd(p0[l:l + 1, :n], v0[l:l + 1, :n], par[l:l + 1, :n], T, dt)
+        b = oracle.micro_rollout_bwd(f, g_pT=w[0, l:l + 1, :n], g_vT=w[1, l:l + 1, :n])
+        assert rel_max(pT[l, :n].cpu().numpy(), f["pT"][0]) <= 1e-6
+        assert rel_max(vT[l, :n].cpu().numpy(), f["vT"][0]) <= 1e-6
+        assert torch.equal(pT[l, n:].cpu(), torch.tensor(p0[l, n:]))      # untouched slots pass through
+        assert rel_max(g_p0[l, :n].cpu().numpy(), b["g_p0"][0]) <= 1e-5
+        assert rel_max(g_v0[l, :n].cpu().numpy(), b["g_v0"][0]) <= 1e-5
+        assert float(g_p0[l, n:].abs().max()) == 0.0 if n < V else True
+
+
+def test_micro_collision_is_recorded_and_tolerated(cuda, oracle):
+    """gap < 0: the reference prints, zeroes the deltas and carries on (_micro_lane.py:151-162)."""
+    import torch
+    from dhts import ops
+    par = np.tile(np.array([30.0, 24.0, 27.0, 0.5, 0.1, 5.0]), (1, 2, 1))
+    p0 = np.array([[0.0, 3.0]], np.float32)
+    v0 = np.array([[10.0, 1.0]], np.float32)
+    desc = ops.micro_desc(1, 2, 0.01)
+    err = ops.new_error_record(cuda)
+    tape = torch.zeros(ops.micro_tape_numel(desc, 1), device=cuda)
+    head = T_(np.array([[1000.0, 0.0]]), cuda, dtype=torch.float64)
+    pT, vT = ops.micro_rollout_fwd(desc, 1, T_(p0, cuda), T_(v0, cuda), T_(par.transpose(2, 0, 1), cuda, dtype=torch.float64),
+                                   head, tape=tape, err=err)
+    code, step, lane, index = err.tolist()
+    assert (code, step, lane, index) == (2, 0, 0, 0)
+    o = oracle.micro_step(p0[0], v0[0], par[0], 1000.0, 0.0, 0.01)
+    assert rel_max(pT.cpu().numpy()[0], o["np"]) <= 1e-6 and rel_max(vT.cpu().numpy()[0], o["nv"]) <= 1e-6
+    dqs = tape_to_dqs(tape, 1, 1, 2, planes=2)[0, 0]
+    assert rel_max(dqs, o["dqs"]) <= 1e-5
+
+
+def test_micro_full_size_properties(cuda):
+    """BASELINE config 3 (4096 lanes x 256 vehicles = 2^20, 1000 steps): repeatability, replica consistency,
+    exact homogeneity of the adjoint, and ordering (no vehicle overtakes its leader)."""
+    import torch
+    from dhts import ops
+    L, V, T, dt = 4096, 256, 1000, 0.01
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    p0 = (torch.arange(V)[None, :] * 20.0 + 10.0 * torch.rand(L, V, generator=gen)).to(cuda)
+    v0 = (9.0 + 12.0 * torch.rand(L, V, generator=gen)).to(cuda)
+    p0[1], v0[1] = p0[0], v0[0]
+    params = torch.tensor([30.0, 24.0, 27.0, 0.5, 0.1, 5.0], dtype=torch.float64, device=cuda)[:, None, None].expand(6, L, V).contiguous()
+    head = torch.tensor([[1000.0, 0.0]], dtype=torch.float64, device=cuda).expand(L, 2).contiguous()
+    desc = ops.micro_desc(L, V, dt)
+    tape = torch.empty(ops.micro_tape_numel(desc, T), device=cuda)
+    err = ops.new_error_record(cuda)
+    pT, vT = ops.micro_rollout_fwd(desc, T, p0, v0, params, head, tape=tape, err=err)
+    assert err.tolist()[0] == 0
+    assert torch.isfinite(pT).all() and torch.isfinite(vT).all() and (vT >= 0).all()
+    assert (pT[:, 1:] - pT[:, :-1] > 5.0).all()           # gaps stay larger than a vehicle length
+    assert torch.equal(pT[1], pT[0]) and torch.equal(vT[1], vT[0])
+    g1 = ops.micro_rollout_bwd(desc, T, tape, 2e-4 * pT, 2 * vT)
+    g2 = ops.micro_rollout_bwd(desc, T, tape, 4e-4 * pT, 4 * vT)
+    assert torch.equal(g2[0], 2 * g1[0]) and torch.equal(g2[1], 2 * g1[1])
+    assert torch.equal(g1[0][1], g1[0][0])
+    tape2 = torch.empty_like(tape)
+    pT2, vT2 = ops.micro_rollout_fwd(desc, T, p0, v0, params, head, tape=tape2)
+    assert torch.equal(pT, pT2) and torch.equal(vT, vT2) and torch.equal(tape, tape2)
