@@ -38,7 +38,7 @@ __device__ __forceinline__ double u_eq_prime_d(double r, double um) {
 __device__ __forceinline__ float glue_u_eq(float r, float um) {
     if (0.f > r) return (float)((double)um * (1. - sqrt(0. + kEps)));   // max(r, 0.) picked the Python float
     float t = r + kEpsF;
-    t = __fsqrt_rn(t);
+    t = sqrtf(t);
     t = 1.f - t;
     return um * t;
 }
@@ -52,24 +52,24 @@ __device__ __forceinline__ void glue_from_r_y(float r, float y, float um, float 
     ueq = glue_u_eq(r, um);
     if (r < kEpsF) {
         double ueq_c = (double)um * (1. - sqrt(kEps + kEps));       // u_eq(1e-5) in Python floats
-        u = __fdiv_rn(y, kEpsF) + (float)ueq_c;
+        u = ((y) / (kEpsF)) + (float)ueq_c;
     } else {
-        u = __fdiv_rn(y, r) + ueq;
+        u = ((y) / (r)) + ueq;
     }
 }
 // adjoint of u = y / rc + u_eq(rc) as torch autograd evaluates it (float32)
 __device__ __forceinline__ void glue_u_bwd(float r, float y, float um, float g_u, float &g_r, float &g_y) {
     if (r < kEpsF) {
-        g_y += __fdiv_rn(g_u, kEpsF);
+        g_y += ((g_u) / (kEpsF));
         return;
     }
-    g_y += __fdiv_rn(g_u, r);
-    float gd = -g_u * __fdiv_rn(__fdiv_rn(y, r), r);
+    g_y += ((g_u) / (r));
+    float gd = -g_u * ((((y) / (r))) / (r));
     float gp = 0.f;
     if (!(0.f > r)) {
         float t = r + kEpsF;
         float gs = -(g_u * um);
-        gp = gs * (0.5f * __fdiv_rn(1.f, __fsqrt_rn(t)));
+        gp = gs * (0.5f * ((1.f) / (sqrtf(t))));
     }
     g_r += gd + gp;
 }
@@ -83,7 +83,7 @@ __device__ __forceinline__ void glue_y_bwd(float r, float u, float um, float g_y
     if (!(0.f > r)) {
         float t = r + kEpsF;
         float gs = -((-g_diff) * um);
-        acc += gs * (0.5f * __fdiv_rn(1.f, __fsqrt_rn(t)));
+        acc += gs * (0.5f * ((1.f) / (sqrtf(t))));
     }
     g_r += acc;
 }
