@@ -95,13 +95,19 @@ struct Iface {
     double Fr, Fy;   // flux of Q_0: (r*u, y*u)                                  (_arz.py:94-101)
     float A[4];      // fp(Q_0) @ dQ_0/dQ_L   row-major 2x2, float32             (dmacro_lane.py:126-129)
     float B[4];      // fp(Q_0) @ dQ_0/dQ_R
-    double smax;     // max(|speed0|, |speed1|) for the CFL check               (_macro_lane.py:141-146)
+    bool cfl_bad;    // dt >= dx / max(|speed|, 1e-5) for speed0 or speed1       (_macro_lane.py:141-146)
 };
 
-// One interface: left state (rL, yL, uL, qL = u_eq), right state, speed limit.
-__device__ __forceinline__ void arz_interface(double rL, double yL, double uL, double qL,
-                                              double rR, double yR, double uR, double qR,
-                                              double um, Iface &o) {
+struct IfaceConst {  // per-launch constants
+    double um, inv_um, inv_15um, dt, dx;
+};
+
+// Reference-order version: IEEE double division and square root exactly where the reference divides and takes
+// powers.  Selected with -DDHTS_IEEE_DIV_SQRT (validation builds); the default build uses arz_interface_fast.
+__device__ __forceinline__ void arz_interface_ieee(double rL, double yL, double uL, double qL,
+                                                   double rR, double yR, double uR, double qR,
+                                                   const IfaceConst &k, Iface &o) {
+    const double um = k.um;
     // ---- Riemann solve: case index and speeds (_arz.py:222-314) ----
     int ci;
     double s0, s1;
@@ -137,7 +143,7 @@ __device__ __forceinline__ void arz_interface(double rL, double yL, double uL, d
         ci = (l0l >= 0.0) ? 0 : 2;
     }
     (void)l0m_u;
-    o.smax = fmax(fabs(s0), fabs(s1));
+    o.cfl_bad = !(k.dt * pymax(fmax(fabs(s0), fabs(s1)), 1e-5) < k.dx);
 
     // ---- Q_0 (_arz.py:155-199, 316-326), its Jacobians (darz.py:12-192) ----
     double r0, y0, u0, q0;
@@ -233,6 +239,218 @@ __device__ __forceinline__ void arz_interface(double rL, double yL, double uL, d
             o.B[0] = o.B[1] = o.B[2] = o.B[3] = 0.f;
         }
     }
+}
+
+// ---- fast double helpers ---------------------------------------------------------------------------------
+// s = sqrt(x), h = 0.5 / sqrt(x) for x in the normal range (callers pass x >= 1e-5): v_rsq_f64 seed (2^-23),
+// one Goldschmidt step, two residual corrections of s (the sequence LLVM uses for a correctly rounded f64 sqrt,
+// without its denormal scaling) and one of h.  Both results are within ~1 ulp.
+__device__ __forceinline__ void sqrt_hrsqrt(double x, double &s, double &h) {
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    s = __builtin_fma(d, h, g);
+    r = __builtin_fma(-h, s, 0.5);
+    h = __builtin_fma(h + h, r, h);
+}
+__device__ __forceinline__ double fast_sqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+
+// Production version of the interface solve.  Same formulas and branch structure as arz_interface_ieee, with
+//   * every 1/sqrt(x), 1/x and sqrt(x) of one argument taken from ONE rsq + Newton sequence,
+//   * divisions by launch constants turned into multiplications by their reciprocals,
+//   * the shock speed's division removed (only its sign and its CFL bound are used),
+//   * a*b+c contracted to fma.
+// Results differ from the reference-order version by a few double ulps, i.e. by < 1e-8 of a float32 ulp
+// before the float32 stores (tests/test_gpu_parity.py compares both against the oracle).
+__device__ __forceinline__ void arz_interface_fast(double rL, double yL, double uL, double qL,
+                                                   double rR, double yR, double uR, double qR,
+                                                   const IfaceConst &k, Iface &o) {
+#pragma clang fp contract(fast)
+    const double um = k.um, inv_um = k.inv_um;
+    const double rLc = pymax(rL, kEps);
+    double sL, hL;
+    sqrt_hrsqrt(rLc, sL, hL);                              // sL = sqrt(rLc); 2 hL = rLc^-1/2
+    const double rsL = hL + hL;
+    const double inv_rLc = rsL * rsL;                      // 1 / rLc
+    const double ueqp_L = -um * hL;                        // u_eq'(rL) = -um * gamma * rLc^(gamma-1)
+    const double sLe = fast_sqrt(pymax(rL, 0.) + kEps);    // sqrt(rL + eps) of u_eq(rL)
+
+    // ---- Riemann solve: case index, CFL flag (_arz.py:222-314) ----
+    int ci;
+    bool bad;
+    double rm = 0., sm = 0., hm = 0.;
+    const bool vacL = rL < kEps;
+    const bool vacR = rR < kEps;
+    const bool same = fabs(uL - uR) < kEps;
+    const bool wave_m = !(vacL || vacR || same);           // branches 4, 5, 6
+    const bool b4 = wave_m && (uL > uR);
+    const bool b5 = wave_m && !b4 && (um + uL - qL > uR);
+    if (b4 || b5) {
+        const double b = sL + (uL - uR) * inv_um;          // sqrt(rL) = sL here (rL >= eps)
+        rm = b * b;                                        // compute_Qm :194
+    }
+    const double l0l = uL + rL * ueqp_L;
+    double diff = 0.;
+    if (b4) diff = rm * uR - rL * uL;
+    const bool need_m = b5 || (b4 && diff < 0.);
+    if (need_m) sqrt_hrsqrt(pymax(rm, kEps), sm, hm);
+    if (vacL) {
+        ci = 0;
+        bad = !(k.dt * pymax(fabs(uL), 1e-5) < k.dx);
+    } else if (vacR) {
+        const double s0 = (l0l + (um + uL - qL)) * 0.5;
+        ci = (l0l >= 0.0) ? 0 : 2;
+        bad = !(k.dt * pymax(fabs(s0), 1e-5) < k.dx);
+    } else if (same) {
+        ci = 0;
+        bad = !(k.dt * pymax(fabs(uR), 1e-5) < k.dx);
+    } else if (b4) {
+        const double den = pymax(rm - rL, kEps);
+        ci = (diff >= 0.0) ? 0 : 1;                        // sign of speed0 = diff / den
+        // dt * max(|diff| / den, 1e-5) < dx  without the division
+        bad = !(k.dt * fabs(diff) < k.dx * den) || !(k.dt * pymax(fabs(uR), 1e-5) < k.dx);
+    } else if (b5) {
+        const double l0m = uR + rm * (-um * hm);
+        const double s0 = (l0l + l0m) * 0.5;
+        ci = (l0l >= 0) ? 0 : ((l0m <= 0) ? 1 : 2);
+        bad = !(k.dt * pymax(fmax(fabs(s0), fabs(uR)), 1e-5) < k.dx);
+    } else {
+        const double s0 = (l0l + (um + uL - qL)) * 0.5;
+        ci = (l0l >= 0.0) ? 0 : 2;
+        bad = !(k.dt * pymax(fmax(fabs(s0), fabs(uR)), 1e-5) < k.dx);
+    }
+    o.cfl_bad = bad;
+
+    // ---- Q_0 (_arz.py:155-199, 316-326), its Jacobians (darz.py:12-192) ----
+    double r0, y0, u0, q0, r0c, h0, inv_r0c;
+    float dL[4], dR[4];
+    if (ci == 0) {
+        const double sLce = vacL ? sqrt(kEps + kEps) : sLe;       // sqrt(rLc + eps)
+        r0 = rL; y0 = yL;
+        u0 = yL * inv_rLc + um * (1. - sLce);
+        q0 = um * (1. - sLe);
+        r0c = rLc; h0 = hL; inv_r0c = inv_rLc;
+    } else if (ci == 1) {
+        r0 = rm; u0 = uR;
+        q0 = um * (1. - fast_sqrt(pymax(rm, 0.) + kEps));
+        y0 = rm * (uR - q0);
+        r0c = pymax(rm, kEps); h0 = hm;
+        const double rsm = hm + hm;
+        inv_r0c = rsm * rsm;
+        // compute_dM, darz.py:35-122
+        const double rRc = pymax(rR, kEps);
+        double sR, hR;
+        sqrt_hrsqrt(rRc, sR, hR);
+        const double rsR = hR + hR;
+        const double inv_rRc = rsR * rsR;
+        const double ueqp_M = -um * hm;
+        const double duL_drL = -yL * (inv_rLc * inv_rLc) + ueqp_L;
+        const double duL_dyL = inv_rLc;
+        const double duR_drR = -yR * (inv_rRc * inv_rRc) + (-um * hR);
+        const double duR_dyR = inv_rRc;
+        const double sqrt_rm = (rm >= kEps) ? sm : sqrt(rm);
+        const double a = 2.0 * sqrt_rm;                    // (1 / gamma) * r_M ** (1 - gamma)
+        const double b = hL;                               // gamma * r_L ** (gamma - 1)
+        const double c = inv_um * duL_drL;
+        const double drM_drL = a * (b + c);
+        const double d = inv_um * duL_dyL;
+        const double drM_dyL = a * d;
+        const double e = u0 - q0;
+        const double dyM_drL = drM_drL * e + rm * (-ueqp_M * drM_drL);
+        const double dyM_dyL = drM_dyL * e + rm * (-ueqp_M * drM_dyL);
+        const double f = -inv_um * duR_drR;
+        const double drM_drR = a * f;
+        const double g = -inv_um * duR_dyR;
+        const double drM_dyR = a * g;
+        const double dyM_drR = drM_drR * e + rm * (duR_drR - ueqp_M * drM_drR);
+        const double dyM_dyR = drM_dyR * e + rm * (duR_dyR - ueqp_M * drM_dyR);
+        dL[0] = (float)drM_drL; dL[1] = (float)drM_dyL; dL[2] = (float)dyM_drL; dL[3] = (float)dyM_dyL;
+        dR[0] = (float)drM_drR; dR[1] = (float)drM_dyR; dR[2] = (float)dyM_drR; dR[3] = (float)dyM_dyR;
+    } else {
+        // compute_Qc, _arz.py:167-182
+        const double base = uL + um * sL;
+        const double t = base * k.inv_15um;
+        r0 = t * t;
+        u0 = kGoG1 * base;
+        q0 = um * (1. - fast_sqrt(pymax(r0, 0.) + kEps));
+        y0 = r0 * (u0 - q0);
+        r0c = pymax(r0, kEps);
+        double s0c;
+        sqrt_hrsqrt(r0c, s0c, h0);
+        const double rs0 = h0 + h0;
+        inv_r0c = rs0 * rs0;
+        // compute_dC, darz.py:124-192
+        const double ueqp_C = -um * h0;
+        const double duL_drL = -yL * (inv_rLc * inv_rLc) + ueqp_L;
+        const double duL_dyL = inv_rLc;
+        const double f = um * hL;                          // u_max * gamma * r_L ** (gamma - 1)
+        const double duC_drL = kGoG1 * (duL_drL + f);
+        const double duC_dyL = kGoG1 * duL_dyL;
+        const double e = (fabs(t) * 2.0) * k.inv_15um;     // ((r_C ** (1 - gamma)) / gamma) / ((gamma + 1) u_max)
+        const double drC_drL = e * (duL_drL + f);
+        const double drC_dyL = e * duL_dyL;
+        const double g = u0 - q0;
+        const double dyC_drL = drC_drL * g + r0 * (duC_drL - ueqp_C * drC_drL);
+        const double dyC_dyL = drC_dyL * g + r0 * (duC_dyL - ueqp_C * drC_dyL);
+        dL[0] = (float)drC_drL; dL[1] = (float)drC_dyL; dL[2] = (float)dyC_drL; dL[3] = (float)dyC_dyL;
+    }
+    o.Fr = r0 * u0;
+    o.Fy = y0 * u0;
+
+    // ---- flux Jacobian at Q_0 (darz.py:217-233), float32 entries ----
+    const double ueqp_0 = -um * h0;
+    const double yor = y0 * inv_r0c;
+    float fp[4];
+    fp[0] = (float)(q0 + r0c * ueqp_0);
+    fp[1] = 1.f;
+    fp[2] = (float)(y0 * ueqp_0 - yor * yor);
+    fp[3] = (float)((2.0 * y0) * inv_r0c + q0);
+
+    // ---- fp @ dL, fp @ dR in float32 (np.matmul) ----
+    if (ci == 0) {          // dL = I, dR = 0: the products are fp and 0 exactly
+        o.A[0] = fp[0]; o.A[1] = fp[1]; o.A[2] = fp[2]; o.A[3] = fp[3];
+        o.B[0] = o.B[1] = o.B[2] = o.B[3] = 0.f;
+    } else {
+        o.A[0] = dot2(fp[0], dL[0], fp[1], dL[2]);
+        o.A[1] = dot2(fp[0], dL[1], fp[1], dL[3]);
+        o.A[2] = dot2(fp[2], dL[0], fp[3], dL[2]);
+        o.A[3] = dot2(fp[2], dL[1], fp[3], dL[3]);
+        if (ci == 1) {
+            o.B[0] = dot2(fp[0], dR[0], fp[1], dR[2]);
+            o.B[1] = dot2(fp[0], dR[1], fp[1], dR[3]);
+            o.B[2] = dot2(fp[2], dR[0], fp[3], dR[2]);
+            o.B[3] = dot2(fp[2], dR[1], fp[3], dR[3]);
+        } else {
+            o.B[0] = o.B[1] = o.B[2] = o.B[3] = 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void arz_interface(double rL, double yL, double uL, double qL,
+                                              double rR, double yR, double uR, double qR,
+                                              const IfaceConst &k, Iface &o) {
+#ifdef DHTS_IEEE_DIV_SQRT
+    arz_interface_ieee(rL, yL, uL, qL, rR, yR, uR, qR, k, o);
+#else
+    arz_interface_fast(rL, yL, uL, qL, rR, yR, uR, qR, k, o);
+#endif
 }
 
 }  // namespace dhts

@@ -20,8 +20,18 @@
 
 namespace dhts {
 
-__device__ __forceinline__ double shfl_down1(double x) { return __shfl_down(x, 1, 64); }
-__device__ __forceinline__ float shfl_down1(float x) { return __shfl_down(x, 1, 64); }
+// wave_shl:1 DPP move: lane t receives lane t+1's value; lane 63 (no source) keeps `carry`.
+// One v_mov_b32_dpp per dword -- no LDS round trip.
+constexpr int kDppWaveShl1 = 0x130;
+__device__ __forceinline__ float take_right(float x, float carry) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(carry), __float_as_int(x), kDppWaveShl1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double take_right(double x, double carry) {
+    const long long xb = __double_as_longlong(x), cb = __double_as_longlong(carry);
+    const int lo = __builtin_amdgcn_update_dpp((int)(cb & 0xffffffffll), (int)(xb & 0xffffffffll), kDppWaveShl1, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(cb >> 32), (int)(xb >> 32), kDppWaveShl1, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ float bcast0(float x) {
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
 }
@@ -73,6 +83,8 @@ __global__ __launch_bounds__(64) void macro_rollout_fwd_kernel(
     const double c = dt / dx;                  // update_coefficient, _macro_lane.py:99
     const float cf = (float)c, ncf = (float)(-c);
     const float umf = (float)um;
+    IfaceConst kc;
+    kc.um = um; kc.inv_um = 1.0 / um; kc.inv_15um = 1.0 / (kG1 * um); kc.dt = dt; kc.dx = dx;
     int fault_step = -1, fault_index = 0;
 
     for (int step = 0; step < T; ++step) {
@@ -81,28 +93,34 @@ __global__ __launch_bounds__(64) void macro_rollout_fwd_kernel(
         float cA0 = 0.f, cA1 = 0.f, cA2 = 0.f, cA3 = 0.f, cB0 = 0.f, cB1 = 0.f, cB2 = 0.f, cB3 = 0.f;
         float4 *tp = tape ? tape + ((size_t)step * L + lane) * 3 * Np : nullptr;
         float *hp = hist ? hist + ((size_t)step * L + lane) * 3 * N : nullptr;
+        // state of the pass about to run, read one pass ahead (a pass only writes cells >= 64 j, which no later
+        // pass of the step reads, so the reads of pass j - 1 can be issued before pass j computes)
+        int ip = ((K - 1) << 6) + t;
+        ip = ip <= N ? ip : N;
+        float pL0 = Sr[ip], pL1 = Sy[ip], pL2 = Su[ip], pL3 = Sq[ip];
+        float pR0 = Sr[ip + 1], pR1 = Sy[ip + 1], pR2 = Su[ip + 1], pR3 = Sq[ip + 1];
         for (int j = K - 1; j >= 0; --j) {
             const int i = (j << 6) + t;        // interface i, and cell i to its right
             const bool vi = i <= N;
             const bool vc = i < N;
-            const int ii = vi ? i : N;
-            const double rL = Sr[ii], yL = Sy[ii], uL = Su[ii], qL = Sq[ii];
-            const float rCf = Sr[ii + 1], yCf = Sy[ii + 1];
-            const double rR = rCf, yR = yCf, uR = Su[ii + 1], qR = Sq[ii + 1];
+            const double rL = pL0, yL = pL1, uL = pL2, qL = pL3;
+            const double rR = pR0, yR = pR1, uR = pR2, qR = pR3;
+            if (j > 0) {
+                const int in = i - 64;         // always <= N
+                pL0 = Sr[in]; pL1 = Sy[in]; pL2 = Su[in]; pL3 = Sq[in];
+                pR0 = Sr[in + 1]; pR1 = Sy[in + 1]; pR2 = Su[in + 1]; pR3 = Sq[in + 1];
+            }
             Iface f;
-            arz_interface(rL, yL, uL, qL, rR, yR, uR, qR, um, f);
+            arz_interface(rL, yL, uL, qL, rR, yR, uR, qR, kc, f);
             // CFL: dt < dx / max(|speed|, 1e-5) for both speeds (_macro_lane.py:141-146), tested as a product
-            if (vi && fault_step < 0 && !(dt * pymax(f.smax, 1e-5) < dx)) { fault_step = step; fault_index = i; }
+            if (vi && fault_step < 0 && f.cfl_bad) { fault_step = step; fault_index = i; }
 
             // right interface of cell i = interface i + 1: thread t + 1, or the carried one for thread 63
-            double Fr_R = shfl_down1(f.Fr), Fy_R = shfl_down1(f.Fy);
-            float A0 = shfl_down1(f.A[0]), A1 = shfl_down1(f.A[1]), A2 = shfl_down1(f.A[2]), A3 = shfl_down1(f.A[3]);
-            float B0 = shfl_down1(f.B[0]), B1 = shfl_down1(f.B[1]), B2 = shfl_down1(f.B[2]), B3 = shfl_down1(f.B[3]);
-            if (t == 63) {
-                Fr_R = cFr; Fy_R = cFy;
-                A0 = cA0; A1 = cA1; A2 = cA2; A3 = cA3;
-                B0 = cB0; B1 = cB1; B2 = cB2; B3 = cB3;
-            }
+            const double Fr_R = take_right(f.Fr, cFr), Fy_R = take_right(f.Fy, cFy);
+            const float A0 = take_right(f.A[0], cA0), A1 = take_right(f.A[1], cA1);
+            const float A2 = take_right(f.A[2], cA2), A3 = take_right(f.A[3], cA3);
+            const float B0 = take_right(f.B[0], cB0), B1 = take_right(f.B[1], cB1);
+            const float B2 = take_right(f.B[2], cB2), B3 = take_right(f.B[3], cB3);
             cFr = bcast0(f.Fr); cFy = bcast0(f.Fy);
             cA0 = bcast0(f.A[0]); cA1 = bcast0(f.A[1]); cA2 = bcast0(f.A[2]); cA3 = bcast0(f.A[3]);
             cB0 = bcast0(f.B[0]); cB1 = bcast0(f.B[1]); cB2 = bcast0(f.B[2]); cB3 = bcast0(f.B[3]);
