@@ -1,14 +1,13 @@
 // macro_kernels.hip -- time-fused forward and reverse sweeps of the ARZ cell stencil on gfx950.
 //
-// Forward (macro_rollout_fwd_kernel): ONE 64-lane wavefront owns one traffic lane for the whole rollout.
-//   The lane's state (r, y, u, u_eq; float32, N cells + 2 ghosts) lives in LDS for all T steps; HBM sees only
-//   the initial load, the final store and the Jacobian tape (48 B per cell-step, written as three coalesced
-//   16-B-per-lane streams).  A step walks the lane in 64-cell passes from the downstream end to the upstream
-//   end: thread t of pass j solves interface i = 64 j + t (between cells i-1 and i) once, hands the result to
-//   thread t-1 through a wave shuffle (the cell left of an interface needs it as ITS right interface), and
-//   thread 63 takes the first interface of the previous pass from scalar registers.  Walking downstream ->
-//   upstream lets the update be done in place: a pass only writes cells >= 64 j that no later pass reads.
-//   No barrier, no second wave, no inter-workgroup traffic.
+// Forward (macro_rollout_fwd_kernel): one workgroup of W wavefronts owns one traffic lane for the whole rollout.
+//   The lane's state (r, y, u, u_eq; float32, N cells + 2 ghosts) lives in LDS (ping-pong) for all T steps; HBM
+//   sees only the initial load, the final store and the Jacobian tape (48 B per cell-step, written as three
+//   coalesced 16-B-per-lane streams).  Each wave owns a contiguous chunk of cells and walks it in 64-interface
+//   passes: thread t of a pass solves ONE interface (between cells i-1 and i) once, hands the result to thread
+//   t-1 with a DPP wave shift (the cell left of an interface needs it as ITS right interface), and thread 63
+//   takes the first interface of the previous pass from scalar registers.  One workgroup barrier per time
+//   step; no inter-workgroup traffic.
 // Reverse (macro_rollout_bwd_kernel): one workgroup per lane, cotangent (g_r, g_y) in LDS, tape read back as the
 //   same three streams, newest step first; g' = J^T g with the reference's float32 accumulation order.
 //
@@ -51,36 +50,43 @@ __device__ __forceinline__ void raise_fault(dhts_error *err, int code, int step,
     }
 }
 
-// grid = L workgroups of 64 threads; dynamic LDS = 4 * (N + 2) floats
-__global__ __launch_bounds__(64) void macro_rollout_fwd_kernel(
-    int L, int N, int T, double dt, double dx, double um,
+// grid = L workgroups (one traffic lane each) of W = blockDim.x / 64 wavefronts; dynamic LDS = 2 * 4 * (N + 2) floats.
+// Wave w owns the cells [w C, min(N, (w + 1) C)) with C = 64 p - 1, i.e. at most 64 p interfaces = p passes, so no
+// wave ever needs a pass for a single left-over interface; the state is ping-pong buffered in LDS and the only
+// synchronisation is one workgroup barrier per time step.
+__global__ __launch_bounds__(512) void macro_rollout_fwd_kernel(
+    int L, int N, int T, int p, double dt, double dx, double um,
     const float *__restrict__ r_in, const float *__restrict__ y_in, const float *__restrict__ u_in,
     const float *__restrict__ q_in, const float *__restrict__ ghost,
     float *__restrict__ r_out, float *__restrict__ y_out, float *__restrict__ u_out, float *__restrict__ q_out,
     float4 *__restrict__ tape, float *__restrict__ hist, dhts_error *err) {
     extern __shared__ float lds[];
     const int lane = blockIdx.x;
-    const int t = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int t = tid & 63;
+    const int wv = tid >> 6;
     const int P = N + 2;
-    float *Sr = lds, *Sy = lds + P, *Su = lds + 2 * P, *Sq = lds + 3 * P;
     const size_t base = (size_t)lane * N;
 
-    for (int k = t; k < N; k += 64) {
-        Sr[k + 1] = r_in[base + k];
-        Sy[k + 1] = y_in[base + k];
-        Su[k + 1] = u_in[base + k];
-        Sq[k + 1] = q_in[base + k];
+    // buffer b, plane k (r, y, u, u_eq) at lds + (b * 4 + k) * P; index c + 1 holds cell c, 0 and N + 1 the ghosts
+    for (int k = tid; k < N; k += blockDim.x) {
+        lds[0 * P + k + 1] = r_in[base + k];
+        lds[1 * P + k + 1] = y_in[base + k];
+        lds[2 * P + k + 1] = u_in[base + k];
+        lds[3 * P + k + 1] = q_in[base + k];
     }
-    if (t < 2) {
-        const float *g = ghost + (size_t)lane * 8 + t * 4;
-        const int p = t ? N + 1 : 0;
-        Sr[p] = g[0]; Sy[p] = g[1]; Su[p] = g[2]; Sq[p] = g[3];
+    if (tid < 16) {
+        const int b = tid >> 3, side = (tid >> 2) & 1, k = tid & 3;
+        lds[(b * 4 + k) * P + (side ? N + 1 : 0)] = ghost[(size_t)lane * 8 + side * 4 + k];
     }
     __syncthreads();
 
-    const int K = (N + 1 + 63) >> 6;           // passes per step: N + 1 interfaces
+    const int C = 64 * p - 1;
+    const int lo = wv * C;                           // first cell / first interface of this wave
+    const int hi = (lo + C < N) ? lo + C : N;        // one past its last cell = its last interface
+    const int K = (lo < N) ? ((hi - lo + 1 + 63) >> 6) : 0;
     const int Np = (N + 63) & ~63;
-    const double c = dt / dx;                  // update_coefficient, _macro_lane.py:99
+    const double c = dt / dx;                        // update_coefficient, _macro_lane.py:99
     const float cf = (float)c, ncf = (float)(-c);
     const float umf = (float)um;
     IfaceConst kc;
@@ -88,71 +94,76 @@ __global__ __launch_bounds__(64) void macro_rollout_fwd_kernel(
     int fault_step = -1, fault_index = 0;
 
     for (int step = 0; step < T; ++step) {
+        const float *cur = lds + (step & 1) * 4 * P;
+        float *nxt = lds + ((step & 1) ^ 1) * 4 * P;
+        const float *Sr = cur, *Sy = cur + P, *Su = cur + 2 * P, *Sq = cur + 3 * P;
         // first interface of the pass above (j + 1), broadcast from its thread 0
         double cFr = 0., cFy = 0.;
         float cA0 = 0.f, cA1 = 0.f, cA2 = 0.f, cA3 = 0.f, cB0 = 0.f, cB1 = 0.f, cB2 = 0.f, cB3 = 0.f;
         float4 *tp = tape ? tape + ((size_t)step * L + lane) * 3 * Np : nullptr;
         float *hp = hist ? hist + ((size_t)step * L + lane) * 3 * N : nullptr;
-        // state of the pass about to run, read one pass ahead (a pass only writes cells >= 64 j, which no later
-        // pass of the step reads, so the reads of pass j - 1 can be issued before pass j computes)
-        int ip = ((K - 1) << 6) + t;
-        ip = ip <= N ? ip : N;
-        float pL0 = Sr[ip], pL1 = Sy[ip], pL2 = Su[ip], pL3 = Sq[ip];
-        float pR0 = Sr[ip + 1], pR1 = Sy[ip + 1], pR2 = Su[ip + 1], pR3 = Sq[ip + 1];
-        for (int j = K - 1; j >= 0; --j) {
-            const int i = (j << 6) + t;        // interface i, and cell i to its right
-            const bool vi = i <= N;
-            const bool vc = i < N;
-            const double rL = pL0, yL = pL1, uL = pL2, qL = pL3;
-            const double rR = pR0, yR = pR1, uR = pR2, qR = pR3;
-            if (j > 0) {
-                const int in = i - 64;         // always <= N
-                pL0 = Sr[in]; pL1 = Sy[in]; pL2 = Su[in]; pL3 = Sq[in];
-                pR0 = Sr[in + 1]; pR1 = Sy[in + 1]; pR2 = Su[in + 1]; pR3 = Sq[in + 1];
-            }
-            Iface f;
-            arz_interface(rL, yL, uL, qL, rR, yR, uR, qR, kc, f);
-            // CFL: dt < dx / max(|speed|, 1e-5) for both speeds (_macro_lane.py:141-146), tested as a product
-            if (vi && fault_step < 0 && f.cfl_bad) { fault_step = step; fault_index = i; }
-
-            // right interface of cell i = interface i + 1: thread t + 1, or the carried one for thread 63
-            const double Fr_R = take_right(f.Fr, cFr), Fy_R = take_right(f.Fy, cFy);
-            const float A0 = take_right(f.A[0], cA0), A1 = take_right(f.A[1], cA1);
-            const float A2 = take_right(f.A[2], cA2), A3 = take_right(f.A[3], cA3);
-            const float B0 = take_right(f.B[0], cB0), B1 = take_right(f.B[1], cB1);
-            const float B2 = take_right(f.B[2], cB2), B3 = take_right(f.B[3], cB3);
-            cFr = bcast0(f.Fr); cFy = bcast0(f.Fy);
-            cA0 = bcast0(f.A[0]); cA1 = bcast0(f.A[1]); cA2 = bcast0(f.A[2]); cA3 = bcast0(f.A[3]);
-            cB0 = bcast0(f.B[0]); cB1 = bcast0(f.B[1]); cB2 = bcast0(f.B[2]); cB3 = bcast0(f.B[3]);
-
-            if (vc) {
-                // Godunov update, _macro_lane.py:109-112, float32 store :327-334
-                const float nr = (float)(rR + (f.Fr - Fr_R) * c);
-                const float ny = (float)(yR + (f.Fy - Fy_R) * c);
-                float nu, nq;
-                glue_from_r_y(nr, ny, umf, nu, nq);      // set_next_state_vector_y, :282-299
-                Sr[i + 1] = nr; Sy[i + 1] = ny; Su[i + 1] = nu; Sq[i + 1] = nq;
-                if (tp) {
-                    // dMacroLane._backward, dmacro_lane.py:126-129
-                    float4 d0, d1, d2;
-                    d0.x = ncf * (-f.A[0]); d0.y = ncf * (-f.A[1]); d0.z = ncf * (-f.A[2]); d0.w = ncf * (-f.A[3]);
-                    d2.x = ncf * B0; d2.y = ncf * B1; d2.z = ncf * B2; d2.w = ncf * B3;
-                    d1.x = 1.f - cf * (A0 - f.B[0]); d1.y = 0.f - cf * (A1 - f.B[1]);
-                    d1.z = 0.f - cf * (A2 - f.B[2]); d1.w = 1.f - cf * (A3 - f.B[3]);
-                    tp[i] = d0;
-                    tp[Np + i] = d1;
-                    tp[2 * Np + i] = d2;
+        if (K > 0) {
+            // state of the pass about to run, read one pass ahead
+            int ip = lo + ((K - 1) << 6) + t;
+            ip = ip <= hi ? ip : hi;
+            float pL0 = Sr[ip], pL1 = Sy[ip], pL2 = Su[ip], pL3 = Sq[ip];
+            float pR0 = Sr[ip + 1], pR1 = Sy[ip + 1], pR2 = Su[ip + 1], pR3 = Sq[ip + 1];
+            for (int j = K - 1; j >= 0; --j) {
+                const int i = lo + (j << 6) + t;   // interface i, and cell i to its right
+                const bool vi = i <= hi;
+                const bool vc = i < hi;
+                const double rL = pL0, yL = pL1, uL = pL2, qL = pL3;
+                const double rR = pR0, yR = pR1, uR = pR2, qR = pR3;
+                if (j > 0) {
+                    const int in = i - 64;         // always <= hi
+                    pL0 = Sr[in]; pL1 = Sy[in]; pL2 = Su[in]; pL3 = Sq[in];
+                    pR0 = Sr[in + 1]; pR1 = Sy[in + 1]; pR2 = Su[in + 1]; pR3 = Sq[in + 1];
                 }
-                if (hp) { hp[i] = nr; hp[N + i] = ny; hp[2 * N + i] = nu; }
+                Iface f;
+                arz_interface(rL, yL, uL, qL, rR, yR, uR, qR, kc, f);
+                // CFL: dt < dx / max(|speed|, 1e-5) for both speeds (_macro_lane.py:141-146)
+                if (vi && fault_step < 0 && f.cfl_bad) { fault_step = step; fault_index = i; }
+
+                // right interface of cell i = interface i + 1: thread t + 1, or the carried one for thread 63
+                const double Fr_R = take_right(f.Fr, cFr), Fy_R = take_right(f.Fy, cFy);
+                const float A0 = take_right(f.A[0], cA0), A1 = take_right(f.A[1], cA1);
+                const float A2 = take_right(f.A[2], cA2), A3 = take_right(f.A[3], cA3);
+                const float B0 = take_right(f.B[0], cB0), B1 = take_right(f.B[1], cB1);
+                const float B2 = take_right(f.B[2], cB2), B3 = take_right(f.B[3], cB3);
+                cFr = bcast0(f.Fr); cFy = bcast0(f.Fy);
+                cA0 = bcast0(f.A[0]); cA1 = bcast0(f.A[1]); cA2 = bcast0(f.A[2]); cA3 = bcast0(f.A[3]);
+                cB0 = bcast0(f.B[0]); cB1 = bcast0(f.B[1]); cB2 = bcast0(f.B[2]); cB3 = bcast0(f.B[3]);
+
+                if (vc) {
+                    // Godunov update, _macro_lane.py:109-112, float32 store :327-334
+                    const float nr = (float)(rR + (f.Fr - Fr_R) * c);
+                    const float ny = (float)(yR + (f.Fy - Fy_R) * c);
+                    float nu, nq;
+                    glue_from_r_y(nr, ny, umf, nu, nq);      // set_next_state_vector_y, :282-299
+                    nxt[i + 1] = nr; nxt[P + i + 1] = ny; nxt[2 * P + i + 1] = nu; nxt[3 * P + i + 1] = nq;
+                    if (tp) {
+                        // dMacroLane._backward, dmacro_lane.py:126-129
+                        float4 d0, d1, d2;
+                        d0.x = ncf * (-f.A[0]); d0.y = ncf * (-f.A[1]); d0.z = ncf * (-f.A[2]); d0.w = ncf * (-f.A[3]);
+                        d2.x = ncf * B0; d2.y = ncf * B1; d2.z = ncf * B2; d2.w = ncf * B3;
+                        d1.x = 1.f - cf * (A0 - f.B[0]); d1.y = 0.f - cf * (A1 - f.B[1]);
+                        d1.z = 0.f - cf * (A2 - f.B[2]); d1.w = 1.f - cf * (A3 - f.B[3]);
+                        tp[i] = d0;
+                        tp[Np + i] = d1;
+                        tp[2 * Np + i] = d2;
+                    }
+                    if (hp) { hp[i] = nr; hp[N + i] = ny; hp[2 * N + i] = nu; }
+                }
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int k = t; k < N; k += 64) {
-        r_out[base + k] = Sr[k + 1];
-        y_out[base + k] = Sy[k + 1];
-        u_out[base + k] = Su[k + 1];
-        q_out[base + k] = Sq[k + 1];
+    const float *fin = lds + (T & 1) * 4 * P;
+    for (int k = tid; k < N; k += blockDim.x) {
+        r_out[base + k] = fin[k + 1];
+        y_out[base + k] = fin[P + k + 1];
+        u_out[base + k] = fin[2 * P + k + 1];
+        q_out[base + k] = fin[3 * P + k + 1];
     }
     if (fault_step >= 0) raise_fault(err, DHTS_FAULT_CFL, fault_step, lane, fault_index);
 }
@@ -260,7 +271,18 @@ static inline int grid_1d(int64_t n) {
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 
+// test / tuning hook: force the number of wavefronts per lane of the forward kernel (0 = heuristic)
+static int dhts_fwd_waves_override = 0;
+
 extern "C" {
+
+int dhts_set_option(int option, int value) {
+    if (option == DHTS_OPT_MACRO_FWD_WAVES && value >= 0 && value <= 8) {
+        dhts_fwd_waves_override = value;
+        return DHTS_OK;
+    }
+    return DHTS_E_INVALID;
+}
 
 int dhts_padded(int n) { return (n + 63) & ~63; }
 
@@ -296,12 +318,22 @@ int dhts_macro_rollout_fwd(const dhts_macro_desc *d, int T,
                            float *tape, float *hist, dhts_error *err, void *stream) {
     if (!macro_desc_ok(d) || T < 0 || !r || !y || !u || !ueq || !ghost || !r_out || !y_out || !u_out || !ueq_out)
         return DHTS_E_INVALID;
-    const size_t lds = sizeof(float) * 4 * (size_t)(d->n_cells + 2);
+    const int N = d->n_cells;
+    const size_t lds = sizeof(float) * 8 * (size_t)(N + 2);
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)macro_rollout_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_LAUNCH;
-    macro_rollout_fwd_kernel<<<d->n_lanes, 64, lds, (hipStream_t)stream>>>(
-        d->n_lanes, d->n_cells, T, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out,
+    // Waves per lane: enough wavefronts to put ~2 on every SIMD of the chip (256 CUs x 4 SIMDs; measured best on
+    // 1024 lanes x 512 cells: 1 -> 11.9 ms, 2 -> 9.2, 3 -> 9.6, 4 -> 9.8, 5 -> 11.9), at most 8 per lane, and never
+    // more than the lane has 63-cell chunks.  p = passes per wave, chunk = 64 p - 1 cells.
+    int W = dhts_fwd_waves_override > 0 ? dhts_fwd_waves_override : (int)((2 * 1024 + d->n_lanes - 1) / d->n_lanes);
+    if (W > 8) W = 8;
+    if (W < 1) W = 1;
+    int p = 1;
+    while ((N + (64 * p - 1) - 1) / (64 * p - 1) > W) ++p;
+    W = (N + (64 * p - 1) - 1) / (64 * p - 1);
+    macro_rollout_fwd_kernel<<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(
+        d->n_lanes, N, T, p, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out,
         reinterpret_cast<float4 *>(tape), hist, err);
     return launch_status();
 }

@@ -13,6 +13,7 @@ SO_PATH = os.path.join(CSRC, "libdhts.so")
 
 OK, E_INVALID, E_LAUNCH, E_NO_DEVICE = 0, -1, -2, -3
 FAULT_NONE, FAULT_CFL, FAULT_COLLISION, FAULT_NAN = 0, 1, 2, 3
+OPT_MACRO_FWD_WAVES = 1
 MACRO_MAX_CELLS = 4000
 MICRO_MAX_VEHICLES = 1024
 
@@ -31,6 +32,7 @@ _P = C.c_void_p
 SIGNATURES = {
     "dhts_version": (C.c_int, []),
     "dhts_device_count": (C.c_int, []),
+    "dhts_set_option": (C.c_int, [C.c_int, C.c_int]),
     "dhts_padded": (C.c_int, [C.c_int]),
     "dhts_macro_tape_bytes": (C.c_size_t, [C.POINTER(MacroDesc), C.c_int]),
     "dhts_macro_state_from_ru": (C.c_int, [C.c_int64, C.c_double, _P, _P, _P, _P, _P]),

@@ -69,6 +69,10 @@ typedef struct dhts_macro_desc {
 int dhts_version(void);
 /* number of visible gfx950 devices, or DHTS_E_NO_DEVICE */
 int dhts_device_count(void);
+/* tuning knobs (process-wide, not part of the numerical contract).
+ * DHTS_OPT_MACRO_FWD_WAVES: wavefronts per traffic lane in the macro forward kernel, 1..8; 0 = heuristic. */
+#define DHTS_OPT_MACRO_FWD_WAVES 1
+int dhts_set_option(int option, int value);
 /* cells / vehicle slots rounded up to the tape's padded width (multiple of 64) */
 int dhts_padded(int n);
 /* bytes of Jacobian tape for T steps */

@@ -148,6 +148,35 @@ def test_macro_rollout_vs_oracle_sizes(cuda, oracle, N):
     assert rel_max(tgu.grad.cpu().numpy(), b["g_ghost_u"]) <= TOL_GRAD
 
 
+@pytest.mark.parametrize("waves", [1, 2, 3, 5, 8])
+def test_macro_forward_is_independent_of_wave_split(cuda, waves):
+    """The forward kernel splits a lane over 1..8 wavefronts; state and tape must not depend on the split."""
+    import torch
+    from dhts import _lib, ops
+    rng = np.random.default_rng(77)
+    L, N, T, dt, dx, um = 6, 517, 40, 0.01, 5.0, 30.0
+    r = T_(rng.uniform(0.0, 1.0, (L, N)).astype(np.float32), cuda)
+    u = T_(rng.uniform(0.0, um, (L, N)).astype(np.float32), cuda)
+    y, q = ops.macro_state_from_ru(r, u, um)
+    gr = T_(rng.uniform(0.0, 1.0, (L, 2)).astype(np.float32), cuda)
+    gu = T_(rng.uniform(0.0, um, (L, 2)).astype(np.float32), cuda)
+    gy, gq = ops.macro_state_from_ru(gr, gu, um)
+    ghost = torch.stack([gr, gy, gu, gq], dim=-1).contiguous()
+    desc = ops.macro_desc(L, N, dt, dx, um)
+    res = []
+    try:
+        for w in (1, waves):
+            assert _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_WAVES, w) == 0
+            tape = torch.zeros(ops.macro_tape_numel(desc, T), device=cuda)
+            out = ops.macro_rollout_fwd(desc, T, r, y, u, q, ghost, tape=tape)
+            res.append((out, tape))
+    finally:
+        _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_WAVES, 0)
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[0][1], res[1][1])
+
+
 def test_macro_tape_matches_oracle_over_rollout(cuda, oracle):
     """The whole Jacobian tape of a rollout, entry by entry."""
     import torch
