@@ -278,7 +278,7 @@ __device__ __forceinline__ double fast_sqrt(double x) {
 //   * the shock speed's division removed (only its sign and its CFL bound are used),
 //   * a*b+c contracted to fma.
 // Results differ from the reference-order version by a few double ulps, i.e. by < 1e-8 of a float32 ulp
-// before the float32 stores (tests/test_gpu_parity.py compares both against the oracle).
+// before the float32 stores (tests/test_gpu_parity.py checks the result against the golden vectors).
 __device__ __forceinline__ void arz_interface_fast(double rL, double yL, double uL, double qL,
                                                    double rR, double yR, double uR, double qR,
                                                    const IfaceConst &k, Iface &o) {
