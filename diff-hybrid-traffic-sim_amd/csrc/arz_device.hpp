@@ -98,6 +98,12 @@ struct Iface {
     bool cfl_bad;    // dt >= dx / max(|speed|, 1e-5) for speed0 or speed1       (_macro_lane.py:141-146)
 };
 
+struct IfaceDebug {  // intermediate results exported only by the known-answer entry point (dhts_arz_interface_batch)
+    int ci;          // case_ind: 0 = Q_L, 1 = Q_M, 2 = Q_C
+    double q0[4];    // Q_0 = (r, y, u, u_eq)
+    float dL[4], dR[4], fp[4];
+};
+
 struct IfaceConst {  // per-launch constants
     double um, inv_um, inv_15um, dt, dx;
 };
@@ -106,7 +112,7 @@ struct IfaceConst {  // per-launch constants
 // powers.  Selected with -DDHTS_IEEE_DIV_SQRT (validation builds); the default build uses arz_interface_fast.
 __device__ __forceinline__ void arz_interface_ieee(double rL, double yL, double uL, double qL,
                                                    double rR, double yR, double uR, double qR,
-                                                   const IfaceConst &k, Iface &o) {
+                                                   const IfaceConst &k, Iface &o, IfaceDebug *dbg = nullptr) {
     const double um = k.um;
     // ---- Riemann solve: case index and speeds (_arz.py:222-314) ----
     int ci;
@@ -221,6 +227,15 @@ __device__ __forceinline__ void arz_interface_ieee(double rL, double yL, double 
     fp[2] = (float)(y0 * ueqp_0 - yor * yor);
     fp[3] = (float)((2.0 * y0) / r0c + q0);
 
+    if (dbg) {
+        dbg->ci = ci;
+        dbg->q0[0] = r0; dbg->q0[1] = y0; dbg->q0[2] = u0; dbg->q0[3] = q0;
+        for (int j = 0; j < 4; ++j) {
+            dbg->fp[j] = fp[j];
+            dbg->dL[j] = (ci == 0) ? ((j == 0 || j == 3) ? 1.f : 0.f) : dL[j];
+            dbg->dR[j] = (ci == 1) ? dR[j] : 0.f;
+        }
+    }
     // ---- fp @ dL, fp @ dR in float32 (np.matmul) ----
     if (ci == 0) {          // dL = I, dR = 0: the products are fp and 0 exactly
         o.A[0] = fp[0]; o.A[1] = fp[1]; o.A[2] = fp[2]; o.A[3] = fp[3];
@@ -281,7 +296,7 @@ __device__ __forceinline__ double fast_sqrt(double x) {
 // before the float32 stores (tests/test_gpu_parity.py checks the result against the golden vectors).
 __device__ __forceinline__ void arz_interface_fast(double rL, double yL, double uL, double qL,
                                                    double rR, double yR, double uR, double qR,
-                                                   const IfaceConst &k, Iface &o) {
+                                                   const IfaceConst &k, Iface &o, IfaceDebug *dbg = nullptr) {
 #pragma clang fp contract(fast)
     const double um = k.um, inv_um = k.inv_um;
     const double rLc = pymax(rL, kEps);
@@ -423,6 +438,15 @@ __device__ __forceinline__ void arz_interface_fast(double rL, double yL, double 
     fp[2] = (float)(y0 * ueqp_0 - yor * yor);
     fp[3] = (float)((2.0 * y0) * inv_r0c + q0);
 
+    if (dbg) {
+        dbg->ci = ci;
+        dbg->q0[0] = r0; dbg->q0[1] = y0; dbg->q0[2] = u0; dbg->q0[3] = q0;
+        for (int j = 0; j < 4; ++j) {
+            dbg->fp[j] = fp[j];
+            dbg->dL[j] = (ci == 0) ? ((j == 0 || j == 3) ? 1.f : 0.f) : dL[j];
+            dbg->dR[j] = (ci == 1) ? dR[j] : 0.f;
+        }
+    }
     // ---- fp @ dL, fp @ dR in float32 (np.matmul) ----
     if (ci == 0) {          // dL = I, dR = 0: the products are fp and 0 exactly
         o.A[0] = fp[0]; o.A[1] = fp[1]; o.A[2] = fp[2]; o.A[3] = fp[3];
@@ -445,11 +469,11 @@ __device__ __forceinline__ void arz_interface_fast(double rL, double yL, double 
 
 __device__ __forceinline__ void arz_interface(double rL, double yL, double uL, double qL,
                                               double rR, double yR, double uR, double qR,
-                                              const IfaceConst &k, Iface &o) {
+                                              const IfaceConst &k, Iface &o, IfaceDebug *dbg = nullptr) {
 #ifdef DHTS_IEEE_DIV_SQRT
-    arz_interface_ieee(rL, yL, uL, qL, rR, yR, uR, qR, k, o);
+    arz_interface_ieee(rL, yL, uL, qL, rR, yR, uR, qR, k, o, dbg);
 #else
-    arz_interface_fast(rL, yL, uL, qL, rR, yR, uR, qR, k, o);
+    arz_interface_fast(rL, yL, uL, qL, rR, yR, uR, qR, k, o, dbg);
 #endif
 }
 

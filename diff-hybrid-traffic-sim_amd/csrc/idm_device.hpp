@@ -18,6 +18,9 @@ struct IdmStep {
     float dE[4];        // d(p', v')/d(p, v) of the ego vehicle, row-major
     float dLd[4];       // d(p', v')/d(p, v) of the leading vehicle
     bool collided;      // raw gap < 0 (_micro_lane.py:188-192)
+    // exported by the known-answer entry point only (dead code in the rollout kernel)
+    double acc, sstar;
+    bool clipped_acc, clipped_spacing;
 };
 
 // p, v: ego state; dp_raw, dv_raw: gap and speed difference to the leader as compute_state_delta returns them
@@ -44,6 +47,7 @@ __device__ __forceinline__ void idm_step(double p, double v, double dp_raw, doub
 
     o.np = (float)(p + dt * v);
     o.nv = (float)(v + dt * acc);
+    o.acc = acc; o.sstar = s; o.clipped_acc = clipped_a; o.clipped_spacing = clipped_s;
 
     // dIDM.compute_dEgo / compute_dLeading, didm.py:38-103, with the UN-clamped deltas (dmicro_lane.py:97)
     o.dE[0] = 1.f; o.dE[1] = (float)dt; o.dE[2] = 0.f; o.dE[3] = 0.f;

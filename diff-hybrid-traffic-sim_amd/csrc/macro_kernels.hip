@@ -228,6 +228,34 @@ __global__ void macro_rollout_bwd_kernel(
     if (bad) raise_fault(err, DHTS_FAULT_NAN, 0, lane, t);
 }
 
+// ---- known-answer entry: n independent interfaces, both solver variants ---------------------------------
+// in [9][n] double = rL yL uL ueqL rR yR uR ueqR u_max (SoA); variant 0 = production, 1 = reference-order IEEE
+__global__ void arz_interface_batch_kernel(int64_t n, int variant, const double *__restrict__ in, double dt, double dx,
+                                           int32_t *__restrict__ ci, double *__restrict__ q0, double *__restrict__ flux,
+                                           float *__restrict__ dL, float *__restrict__ dR, float *__restrict__ fp,
+                                           float *__restrict__ A, float *__restrict__ B, int32_t *__restrict__ cfl_bad) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        IfaceConst kc;
+        kc.um = in[8 * n + i]; kc.inv_um = 1.0 / kc.um; kc.inv_15um = 1.0 / (kG1 * kc.um); kc.dt = dt; kc.dx = dx;
+        Iface f;
+        IfaceDebug dbg;
+        if (variant == 1)
+            arz_interface_ieee(in[i], in[n + i], in[2 * n + i], in[3 * n + i], in[4 * n + i], in[5 * n + i], in[6 * n + i],
+                               in[7 * n + i], kc, f, &dbg);
+        else
+            arz_interface_fast(in[i], in[n + i], in[2 * n + i], in[3 * n + i], in[4 * n + i], in[5 * n + i], in[6 * n + i],
+                               in[7 * n + i], kc, f, &dbg);
+        ci[i] = dbg.ci;
+        flux[i] = f.Fr; flux[n + i] = f.Fy;
+        cfl_bad[i] = f.cfl_bad ? 1 : 0;
+        for (int j = 0; j < 4; ++j) {
+            q0[j * n + i] = dbg.q0[j];
+            dL[j * n + i] = dbg.dL[j]; dR[j * n + i] = dbg.dR[j]; fp[j * n + i] = dbg.fp[j];
+            A[j * n + i] = f.A[j]; B[j * n + i] = f.B[j];
+        }
+    }
+}
+
 // ---- elementwise float32 glue ------------------------------------------------------------------------
 __global__ void macro_state_from_ru_kernel(int64_t n, float um, const float *__restrict__ r, const float *__restrict__ u,
                                            float *__restrict__ y, float *__restrict__ q) {
@@ -289,6 +317,16 @@ int dhts_padded(int n) { return (n + 63) & ~63; }
 size_t dhts_macro_tape_bytes(const dhts_macro_desc *d, int T) {
     if (!macro_desc_ok(d) || T < 0) return 0;
     return (size_t)T * d->n_lanes * 3 * dhts_padded(d->n_cells) * sizeof(float4);
+}
+
+int dhts_arz_interface_batch(int64_t n, int variant, const double *in, double dt, double dx, int32_t *case_ind, double *q0,
+                             double *flux, float *dL, float *dR, float *fp, float *A, float *B, int32_t *cfl_bad, void *stream) {
+    if (n < 0 || (variant != 0 && variant != 1) || !in || !case_ind || !q0 || !flux || !dL || !dR || !fp || !A || !B || !cfl_bad)
+        return DHTS_E_INVALID;
+    if (n == 0) return DHTS_OK;
+    arz_interface_batch_kernel<<<grid_1d(n), 256, 0, (hipStream_t)stream>>>(n, variant, in, dt, dx, case_ind, q0, flux, dL, dR, fp,
+                                                                          A, B, cfl_bad);
+    return launch_status();
 }
 
 int dhts_macro_state_from_ru(int64_t n, double u_max, const float *r, const float *u, float *y, float *ueq, void *stream) {

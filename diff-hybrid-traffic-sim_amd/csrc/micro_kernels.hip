@@ -102,11 +102,29 @@ __global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
     if (fault_step >= 0) raise_fault_m(err, DHTS_FAULT_COLLISION, fault_step, lane, fault_index);
 }
 
+// known-answer entry: n independent vehicles.  in [9][n] double = a_max a_pref v v_target dp dv min_space time_pref dt
+__global__ void idm_batch_kernel(int64_t n, const double *__restrict__ in, double *__restrict__ next_pv,
+                                 float *__restrict__ dE, float *__restrict__ dLd, int32_t *__restrict__ collided,
+                                 double *__restrict__ acc_s, int32_t *__restrict__ clips) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        IdmParams m;
+        m.a_max = in[i]; m.a_pref = in[n + i]; m.v_target = in[3 * n + i]; m.min_space = in[6 * n + i];
+        m.time_pref = in[7 * n + i]; m.length = 0.;
+        IdmStep o;
+        idm_step(0.0, in[2 * n + i], in[4 * n + i], in[5 * n + i], m, in[8 * n + i], o);
+        next_pv[i] = o.np; next_pv[n + i] = o.nv;
+        collided[i] = o.collided ? 1 : 0;
+        acc_s[i] = o.acc; acc_s[n + i] = o.sstar;
+        clips[i] = o.clipped_acc ? 1 : 0; clips[n + i] = o.clipped_spacing ? 1 : 0;
+        for (int j = 0; j < 4; ++j) { dE[j * n + i] = o.dE[j]; dLd[j * n + i] = o.dLd[j]; }
+    }
+}
+
 // grid = L workgroups of blockDim.x threads; dynamic LDS = 4 * (V + 2) floats
 __global__ void micro_rollout_bwd_kernel(
     int L, int V, int T, const float4 *__restrict__ tape, const int32_t *__restrict__ count,
     const float *__restrict__ g_p_in, const float *__restrict__ g_v_in, const float *__restrict__ g_hist,
-    float *__restrict__ g_p_out, float *__restrict__ g_v_out, double *__restrict__ g_head, dhts_error *err) {
+    float *__restrict__ g_p_out, float *__restrict__ g_v_out, double *__restrict__ g_head, int fold, dhts_error *err) {
     extern __shared__ float lds[];
     const int lane = blockIdx.x;
     const int t = threadIdx.x;
@@ -142,9 +160,14 @@ __global__ void micro_rollout_bwd_kernel(
             if (k == n - 1) {
                 // virtual leader = (p_head + head_dp, v_head - head_dv): its cotangent C1[n] returns to the head
                 const float vp = C1p[n], vv = C1v[n];
-                gh_p += (double)vp;
-                gh_v -= (double)vv;
-                np_ += vp; nv_ += vv;
+                if (fold) {
+                    gh_p += (double)vp;
+                    gh_v -= (double)vv;
+                    np_ += vp; nv_ += vv;
+                } else {                   // single-step operator form: hand the raw slot cotangent back
+                    gh_p = (double)vp;
+                    gh_v = (double)vv;
+                }
             }
             Gp[k] = np_; Gv[k] = nv_;
         }
@@ -181,6 +204,15 @@ static void launch_micro_fwd(const dhts_micro_desc *d, int T, const float *p, co
 
 extern "C" {
 
+int dhts_idm_batch(int64_t n, const double *in, double *next_pv, float *dEgo, float *dLeading, int32_t *collided,
+                   double *acc_sstar, int32_t *clips, void *stream) {
+    if (n < 0 || !in || !next_pv || !dEgo || !dLeading || !collided || !acc_sstar || !clips) return DHTS_E_INVALID;
+    if (n == 0) return DHTS_OK;
+    int64_t g = (n + 255) / 256;
+    idm_batch_kernel<<<(int)(g > 2048 ? 2048 : g), 256, 0, (hipStream_t)stream>>>(n, in, next_pv, dEgo, dLeading, collided, acc_sstar, clips);
+    return launch_status_m();
+}
+
 size_t dhts_micro_tape_bytes(const dhts_micro_desc *d, int T) {
     if (!micro_desc_ok(d) || T < 0) return 0;
     return (size_t)T * d->n_lanes * 2 * ((d->capacity + 63) & ~63) * sizeof(float4);
@@ -200,16 +232,22 @@ int dhts_micro_rollout_fwd(const dhts_micro_desc *d, int T,
     return launch_status_m();
 }
 
-int dhts_micro_rollout_bwd(const dhts_micro_desc *d, int T, const float *tape, const int32_t *count,
-                           const float *g_p, const float *g_v, const float *g_hist,
-                           float *g_p_out, float *g_v_out, double *g_head, dhts_error *err, void *stream) {
+static int micro_bwd_launch(const dhts_micro_desc *d, int T, const float *tape, const int32_t *count,
+                            const float *g_p, const float *g_v, const float *g_hist,
+                            float *g_p_out, float *g_v_out, double *g_head, int fold, dhts_error *err, void *stream) {
     if (!micro_desc_ok(d) || T < 0 || (T > 0 && !tape) || !g_p || !g_v || !g_p_out || !g_v_out) return DHTS_E_INVALID;
     const size_t lds = sizeof(float) * 4 * (size_t)(d->capacity + 2);
     int B = (d->capacity + 63) & ~63;
     if (B > 256) B = 256;
     micro_rollout_bwd_kernel<<<d->n_lanes, B, lds, (hipStream_t)stream>>>(
-        d->n_lanes, d->capacity, T, reinterpret_cast<const float4 *>(tape), count, g_p, g_v, g_hist, g_p_out, g_v_out, g_head, err);
+        d->n_lanes, d->capacity, T, reinterpret_cast<const float4 *>(tape), count, g_p, g_v, g_hist, g_p_out, g_v_out, g_head, fold, err);
     return launch_status_m();
+}
+
+int dhts_micro_rollout_bwd(const dhts_micro_desc *d, int T, const float *tape, const int32_t *count,
+                                      const float *g_p, const float *g_v, const float *g_hist,
+                                      float *g_p_out, float *g_v_out, double *g_head, dhts_error *err, void *stream) {
+    return micro_bwd_launch(d, T, tape, count, g_p, g_v, g_hist, g_p_out, g_v_out, g_head, 1, err, stream);
 }
 
 int dhts_micro_step_fwd(const dhts_micro_desc *d,
@@ -220,7 +258,7 @@ int dhts_micro_step_fwd(const dhts_micro_desc *d,
 int dhts_micro_step_bwd(const dhts_micro_desc *d, const float *tape, const int32_t *count,
                         const float *g_p, const float *g_v,
                         float *g_p_out, float *g_v_out, double *g_head, dhts_error *err, void *stream) {
-    return dhts_micro_rollout_bwd(d, 1, tape, count, g_p, g_v, nullptr, g_p_out, g_v_out, g_head, err, stream);
+    return micro_bwd_launch(d, 1, tape, count, g_p, g_v, nullptr, g_p_out, g_v_out, g_head, 0, err, stream);
 }
 
 }  // extern "C"

@@ -226,6 +226,17 @@ def micro_rollout_bwd(desc, T, tape, g_p, g_v, count=None, g_hist=None, err=None
     return out[0], out[1], g_head
 
 
+def micro_step_bwd(desc, tape, g_p, g_v, count=None):
+    """dMicroForwardLayer.backward for a batch of lanes: returns (g_p[L][V], g_v[L][V], g_virtual[L][2] float64),
+    g_virtual = raw cotangent of the virtual leader slot (not folded into the head vehicle)."""
+    g_p, g_v = _f32c(g_p, "g_p"), _f32c(g_v, "g_v")
+    out = (torch.empty_like(g_p), torch.empty_like(g_v))
+    g_virtual = torch.zeros(desc.n_lanes, 2, dtype=torch.float64, device=g_p.device)
+    check(_lib.lib().dhts_micro_step_bwd(C.byref(desc), _ptr(tape), _ptr(count), _ptr(g_p), _ptr(g_v), _ptr(out[0]), _ptr(out[1]),
+                                         _ptr(g_virtual), None, _stream()), "dhts_micro_step_bwd")
+    return out[0], out[1], g_virtual
+
+
 class MicroRollout(torch.autograd.Function):
     """T fused differentiable IDM steps of L independent lanes with a fixed head gap.
 
@@ -264,3 +275,44 @@ class MicroRollout(torch.autograd.Function):
 
 def micro_rollout(p0, v0, params, head, T, dt, count=None, want_hist=False):
     return MicroRollout.apply(p0, v0, params, head, count, int(T), float(dt), want_hist)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# known-answer / scalar-surface entry points (model.macro._arz, model.macro.darz, model.micro._idm mirrors)
+# ---------------------------------------------------------------------------------------------------------
+def arz_interface_batch(inp, dt=0.01, dx=5.0, variant=0):
+    """inp: float64 [n][9] = rL yL uL ueqL rR yR uR ueqR u_max (CUDA).  Returns a dict of CUDA tensors:
+    case [n] int32, q0 [n][4] f64, flux [n][2] f64, dL/dR/fp/A/B [n][2][2] f32, cfl_bad [n] bool."""
+    if inp.dtype != torch.float64 or not inp.is_cuda or inp.dim() != 2 or inp.shape[1] != 9:
+        raise TypeError("inp must be a float64 CUDA tensor of shape [n][9]")
+    n, dev = inp.shape[0], inp.device
+    soa = inp.t().contiguous()
+    case = torch.empty(n, dtype=torch.int32, device=dev)
+    q0 = torch.empty(4, n, dtype=torch.float64, device=dev)
+    flux = torch.empty(2, n, dtype=torch.float64, device=dev)
+    f32 = [torch.empty(4, n, dtype=torch.float32, device=dev) for _ in range(5)]
+    bad = torch.empty(n, dtype=torch.int32, device=dev)
+    check(_lib.lib().dhts_arz_interface_batch(n, int(variant), _ptr(soa), float(dt), float(dx), _ptr(case), _ptr(q0), _ptr(flux),
+                                              *[_ptr(t) for t in f32], _ptr(bad), _stream()), "dhts_arz_interface_batch")
+    m = [t.t().reshape(n, 2, 2) for t in f32]
+    return dict(case=case, q0=q0.t().contiguous(), flux=flux.t().contiguous(), dL=m[0], dR=m[1], fp=m[2], A=m[3], B=m[4],
+                cfl_bad=bad.bool())
+
+
+def idm_batch(inp):
+    """inp: float64 [n][9] = a_max a_pref v v_target dp dv min_space time_pref dt (CUDA).
+    Returns next_v (float32-rounded v + dt acc, as f64), acc, dEgo, dLeading [n][2][2] f32, collided [n] bool."""
+    if inp.dtype != torch.float64 or not inp.is_cuda or inp.dim() != 2 or inp.shape[1] != 9:
+        raise TypeError("inp must be a float64 CUDA tensor of shape [n][9]")
+    n, dev = inp.shape[0], inp.device
+    soa = inp.t().contiguous()
+    nxt = torch.empty(2, n, dtype=torch.float64, device=dev)
+    dE = torch.empty(4, n, dtype=torch.float32, device=dev)
+    dLd = torch.empty(4, n, dtype=torch.float32, device=dev)
+    col = torch.empty(n, dtype=torch.int32, device=dev)
+    acs = torch.empty(2, n, dtype=torch.float64, device=dev)
+    clips = torch.empty(2, n, dtype=torch.int32, device=dev)
+    check(_lib.lib().dhts_idm_batch(n, _ptr(soa), _ptr(nxt), _ptr(dE), _ptr(dLd), _ptr(col), _ptr(acs), _ptr(clips), _stream()),
+          "dhts_idm_batch")
+    return dict(next_p=nxt[0], next_v=nxt[1], dEgo=dE.t().reshape(n, 2, 2), dLeading=dLd.t().reshape(n, 2, 2),
+                collided=col.bool(), acc=acs[0], sstar=acs[1], clipped_acc=clips[0].bool(), clipped_spacing=clips[1].bool())

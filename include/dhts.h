@@ -78,6 +78,19 @@ int dhts_padded(int n);
 /* bytes of Jacobian tape for T steps */
 size_t dhts_macro_tape_bytes(const dhts_macro_desc *d, int T);
 
+/*
+ * n independent cell interfaces: ARZ.riemann_solve (model/macro/_arz.py:212-332) + dARZ.compute_dLdR and
+ * dARZ.flux_prime (model/macro/darz.py:194-233) + the two 2x2 products of dMacroLane._backward
+ * (road/lane/dmacro_lane.py:126-129), exactly as the rollout kernel evaluates them per interface.
+ *   in  [9][n] DOUBLE (SoA): rL yL uL ueqL rR yR uR ueqR u_max  (float32-valued state widened to double)
+ *   variant 0 = production arithmetic, 1 = reference-order IEEE division / square root
+ *   out case_ind [n] int32 (0 = Q_L, 1 = Q_M, 2 = Q_C); q0 [4][n] DOUBLE (r, y, u, u_eq of Q_0);
+ *       flux [2][n] DOUBLE (r u, y u of Q_0); dL, dR, fp [4][n] float32 row-major 2x2; A = fp @ dL, B = fp @ dR [4][n];
+ *       cfl_bad [n] int32 = the CFL assert of _macro_lane.py:141-146 would fire for (dt, dx)
+ */
+int dhts_arz_interface_batch(int64_t n, int variant, const double *in, double dt, double dx, int32_t *case_ind, double *q0,
+                             double *flux, float *dL, float *dR, float *fp, float *A, float *B, int32_t *cfl_bad, void *stream);
+
 /* float32 glue of FullQ.set_r_u / FullQ.from_r_u (model/macro/_arz.py:73-86 with :121-138):
  * y = r * (u - u_eq(r)), u_eq = u_max * (1 - sqrt(max(r, 0) + 1e-5)); n elements. */
 int dhts_macro_state_from_ru(int64_t n, double u_max, const float *r, const float *u, float *y, float *ueq, void *stream);
@@ -138,6 +151,17 @@ typedef struct dhts_micro_desc {
 size_t dhts_micro_tape_bytes(const dhts_micro_desc *d, int T);
 
 /*
+ * n independent vehicles: IDM.compute_acceleration (model/micro/_idm.py:6-50) + one explicit-Euler step
+ * (_micro_lane.py:182-183) + dIDM.compute_dEgo / compute_dLeading (model/micro/didm.py:13-103).
+ *   in  [9][n] DOUBLE (SoA): a_max a_pref v v_target position_delta speed_delta min_space time_pref delta_time
+ *   out next_pv [2][n] DOUBLE: (0 + dt v, v + dt acc) rounded to float32; dEgo, dLeading [4][n] float32;
+ *       collided [n] int32 (position_delta < 0); acc_sstar [2][n] DOUBLE = (acceleration, clipped optimal spacing);
+ *       clips [2][n] int32 = (clipped_acceleration, clipped_optimal_spacing)
+ */
+int dhts_idm_batch(int64_t n, const double *in, double *next_pv, float *dEgo, float *dLeading, int32_t *collided,
+                   double *acc_sstar, int32_t *clips, void *stream);
+
+/*
  * T fused steps of L independent lanes: replaces T x L calls of dMicroForwardLayer.forward
  * (dmicro_lane.py:230-269 = MicroLane.forward _micro_lane.py:131-214 + dMicroLane._backward :87-127).
  *   in : p, v [L][V]; count [L] int32 vehicles per lane or NULL (= V everywhere);
@@ -163,6 +187,8 @@ int dhts_micro_rollout_bwd(const dhts_micro_desc *d, int T, const float *tape, c
 int dhts_micro_step_fwd(const dhts_micro_desc *d,
                         const float *p, const float *v, const int32_t *count, const double *params, const double *head,
                         float *p_out, float *v_out, float *tape, dhts_error *err, void *stream);
+/* The single-step reverse keeps the operator form of dMicroForwardLayer.backward: the cotangent of the virtual
+ * leader slot is NOT folded back into the head vehicle; g_head [L][2] DOUBLE returns it raw as (g_p[V], g_s[V]). */
 int dhts_micro_step_bwd(const dhts_micro_desc *d, const float *tape, const int32_t *count,
                         const float *g_p, const float *g_v,
                         float *g_p_out, float *g_v_out, double *g_head, dhts_error *err, void *stream);

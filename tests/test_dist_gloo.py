@@ -1,0 +1,89 @@
+"""The N > 1 path on CPU: world_size-2 gloo processes shard independent lanes with dhts.dist.shard_range and
+all-reduce the flat [d loss / d theta_shared || loss] buffer.  The per-shard numbers come from the
+CPU oracle here (test infrastructure); on the GPU box the same host logic drives the HIP kernels (bench.py)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from conftest import PKG, ROOT
+
+WORKER = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(pkg)r)
+import numpy as np, torch
+from dhts import dist as D
+from oracle import oracle as O
+
+rank, world, local = D.init(backend="gloo")
+assert world == 2
+L, N, T, dt, dx, um = 7, 40, 30, 0.01, 5.0, 30.0          # 7 lanes over 2 ranks: ragged shards 4 + 3
+rng = np.random.default_rng(123)
+r0 = rng.uniform(0.05, 0.95, (L, N)).astype(np.float32)
+u0 = rng.uniform(0.0, um, (L, N)).astype(np.float32)
+theta = np.array([0.4, 12.0, 0.6, 7.0], np.float32)       # shared parameters: the ghost (r, u) of every lane
+b, e = D.shard_range(L, rank, world)
+gr = np.tile(theta[[0, 2]], (e - b, 1)); gu = np.tile(theta[[1, 3]], (e - b, 1))
+f = O.macro_rollout_fwd(r0[b:e], u0[b:e], gr, gu, T, dt, dx, um)
+g = O.macro_rollout_bwd(f, g_rT=2 * f["rT"], g_uT=2 * f["uT"])
+loss = float(np.sum(f["rT"].astype(np.float64) ** 2) + np.sum(f["uT"].astype(np.float64) ** 2))
+flat = torch.tensor([g["g_ghost_r"][:, 0].sum(), g["g_ghost_u"][:, 0].sum(), g["g_ghost_r"][:, 1].sum(),
+                     g["g_ghost_u"][:, 1].sum(), loss], dtype=torch.float32)
+D.allreduce_sum_(flat)
+D.barrier()
+tmax = D.max_over_ranks(1.0 + rank, torch.device("cpu"))
+if rank == 0:
+    print("RESULT " + json.dumps({"flat": flat.tolist(), "tmax": tmax, "shard": [b, e]}))
+'''
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_shard_range_covers_all_units():
+    from dhts import dist as D
+    for n in (0, 1, 7, 8, 1024, 2048):
+        for world in (1, 2, 3, 8):
+            spans = [D.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_gloo_allreduce_matches_single_process(oracle, tmp_path):
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "pkg": PKG})
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT ")][0]
+    res = json.loads(line[len("RESULT "):])
+    assert res["tmax"] == 2.0 and res["shard"] == [0, 4]
+    # single-process reference over all 7 lanes
+    L, N, T, dt, dx, um = 7, 40, 30, 0.01, 5.0, 30.0
+    rng = np.random.default_rng(123)
+    r0 = rng.uniform(0.05, 0.95, (L, N)).astype(np.float32)
+    u0 = rng.uniform(0.0, um, (L, N)).astype(np.float32)
+    theta = np.array([0.4, 12.0, 0.6, 7.0], np.float32)
+    gr = np.tile(theta[[0, 2]], (L, 1))
+    gu = np.tile(theta[[1, 3]], (L, 1))
+    f = oracle.macro_rollout_fwd(r0, u0, gr, gu, T, dt, dx, um)
+    g = oracle.macro_rollout_bwd(f, g_rT=2 * f["rT"], g_uT=2 * f["uT"])
+    loss = float(np.sum(f["rT"].astype(np.float64) ** 2) + np.sum(f["uT"].astype(np.float64) ** 2))
+    ref = [g["g_ghost_r"][:, 0].sum(), g["g_ghost_u"][:, 0].sum(), g["g_ghost_r"][:, 1].sum(), g["g_ghost_u"][:, 1].sum(), loss]
+    assert np.allclose(res["flat"], ref, rtol=2e-6)

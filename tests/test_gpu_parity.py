@@ -38,6 +38,75 @@ def dqs_to_tape(dqs, planes=3):
 
 
 # =================================================================================================================
+# known-answer vectors straight through the device math
+# =================================================================================================================
+@pytest.mark.parametrize("variant", [0, 1])
+def test_device_interface_solver_vs_reference_kat(cuda, golden_dir, variant):
+    """G1/G2 on the device: every (branch, case) pair of the Riemann solver, Q_0, Jacobians, flux Jacobian and
+    the 2x2 products, for the production arithmetic (0) and the reference-order IEEE build (1)."""
+    import torch
+    from dhts import ops
+    g = load(golden_dir, "riemann_kat.npz")
+    out = ops.arz_interface_batch(T_(g["inp"], cuda), variant=variant)
+    case = out["case"].cpu().numpy()
+    assert np.array_equal(case, g["case"])                     # all 2076 branch decisions
+    assert set(zip(g["branch"].tolist(), case.tolist())) == {(1, 0), (2, 0), (2, 2), (3, 0), (4, 0), (4, 1), (5, 0),
+                                                             (5, 1), (5, 2), (6, 0), (6, 2)}
+    q0 = out["q0"].cpu().numpy()
+    tol = 1e-13 if variant == 1 else 1e-11                     # double results: a few ulps (x cancellation in u = y / r + u_eq)
+    assert np.max(np.abs(q0 - g["q0"]) / np.maximum(np.abs(g["q0"]), 1e-3)) <= tol
+    flux_ref = np.stack([g["q0"][:, 0] * g["q0"][:, 2], g["q0"][:, 1] * g["q0"][:, 2]], 1)
+    assert np.max(np.abs(out["flux"].cpu().numpy() - flux_ref) / np.maximum(np.abs(flux_ref), 1e-3)) <= tol
+    for key in ("dL", "dR", "fp"):
+        # float32 entries: almost all bit-exact; an entry that is a near-cancellation of two O(1) terms may differ
+        # in its last double ulps, so the bound is one float32 ulp of the matrix' largest entry
+        got, ref = out[key].cpu().numpy(), g[key]
+        scale = np.abs(ref).reshape(-1, 4).max(1).reshape(-1, 1, 1)
+        assert np.all(np.abs(got - ref) <= 1.2e-7 * np.maximum(scale, 1e-30)), key
+        assert np.mean(got != ref) <= 2e-3, key
+    # products as np.matmul forms them (acc = a0*b0; acc = fma(a1, b1, acc)) from the reference's own factors
+    def mm(a, b):
+        a, b = a.astype(np.float64), b.astype(np.float64)
+        o = np.empty_like(a)
+        for i in range(2):
+            for j in range(2):
+                p0 = (a[:, i, 0] * b[:, 0, j]).astype(np.float32).astype(np.float64)
+                o[:, i, j] = p0 + a[:, i, 1] * b[:, 1, j]
+        return o.astype(np.float32)
+    same = np.all((out["dL"].cpu().numpy() == g["dL"]) & (out["dR"].cpu().numpy() == g["dR"]) &
+                  (out["fp"].cpu().numpy() == g["fp"]), axis=(1, 2))
+    assert same.mean() >= 0.99
+    A_ref, B_ref = mm(g["fp"], g["dL"]), mm(g["fp"], g["dR"])
+    assert np.array_equal(out["A"].cpu().numpy()[same], A_ref[same])
+    assert np.array_equal(out["B"].cpu().numpy()[same], B_ref[same])
+    # the CFL assert of _macro_lane.py:141-146 evaluated on the reference's own wave speeds (dt = 0.01, dx = 5)
+    sp = np.maximum(np.abs(g["speed"]), 1e-5)
+    cfl_ref = ~((0.01 < 5.0 / sp[:, 0]) & (0.01 < 5.0 / sp[:, 1]))
+    assert np.array_equal(out["cfl_bad"].cpu().numpy(), cfl_ref) and cfl_ref.any() and not cfl_ref.all()
+
+
+def test_device_idm_vs_reference_kat(cuda, golden_dir):
+    """G5 on the device: acceleration with both clips, Euler step, dEgo / dLeading."""
+    from dhts import ops
+    g = load(golden_dir, "idm_kat.npz")
+    inp = g["inp"]
+    out = ops.idm_batch(T_(inp, cuda))
+    v, dt = inp[:, 2], inp[:, 8]
+    assert np.array_equal(out["clipped_acc"].cpu().numpy(), g["flags"][:, 0].astype(bool))
+    assert np.array_equal(out["clipped_spacing"].cpu().numpy(), g["flags"][:, 1].astype(bool))
+    assert np.max(np.abs(out["acc"].cpu().numpy() - g["acc"]) / np.maximum(np.abs(g["acc"]), 1e-3)) <= 1e-12
+    assert np.max(np.abs(out["sstar"].cpu().numpy() - g["sstar"])) <= 1e-12
+    nv_ref = (v + dt * g["acc"]).astype(np.float32)
+    assert ulp_diff(out["next_v"].cpu().numpy().astype(np.float32), nv_ref).max() <= 1
+    for key in ("dEgo", "dLeading"):
+        got, ref = out[key].cpu().numpy(), g[key]
+        assert rel_max(got, ref) <= 1e-6
+        d = ulp_diff(got, ref)
+        assert d.max() <= 2 and np.mean(d > 0) <= 0.01, key
+    assert not out["collided"].any()
+
+
+# =================================================================================================================
 # macro
 # =================================================================================================================
 @pytest.mark.parametrize("name", ["rand64", "sanity100", "vacuum9", "single1", "jam33"])
