@@ -236,6 +236,15 @@ def main():
         }
         dom = "rollout_fwd" if fwd_avg >= bwd_avg else "rollout_bwd"
         achieved = kernels[dom]["GBps"]
+        # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE
+        # and --pmc WRITE_SIZE, gfx950 FETCH correction applied); only quoted for the configuration they were taken on
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if w.name in pmc and (L, N, T) in ((1024, 512, 1000), (4096, 256, 1000)):
+                traffic = pmc[w.name][dom]["hbm_bytes"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         value = w.units * args.steps * world / elapsed
         out = {
             "metric": "differentiable cell-steps/s (fwd+bwd)",
@@ -253,7 +262,8 @@ def main():
             "config": {"workload": w.name, "lanes_per_gpu": L, "units_per_lane": N, "time_steps": T,
                        "parallelism": "lanes sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (PMC)",
+                         "algorithmic_bytes_per_launch": per_launch_bytes},
             "whole_path": {"algorithmic_GBps": w.units * 2 * w.unit_bytes * args.steps / elapsed / 1e9,
                            "frac_of_peak": w.units * 2 * w.unit_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
             "kernels": kernels,
