@@ -12,6 +12,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "fast_math.hpp"
+
 namespace dhts {
 
 constexpr double kEps = 1e-5;             // EPSILON, _arz.py:2
@@ -19,6 +21,7 @@ constexpr float kEpsF = 1e-5f;            // the same constant cast to float32 w
 constexpr double kG = 0.5;                // GAMMA, _arz.py:1
 constexpr double kG1 = kG + 1.0;          // gamma + 1
 constexpr double kGoG1 = kG / (kG + 1.0); // gamma / (gamma + 1)
+constexpr double kHalfRsqrtEps = 158.11388300841895;   // 0.5 / sqrt(1e-5) = gamma * EPSILON ** (gamma - 1)
 
 // Python's max(a, b): b if b > a else a
 __device__ __forceinline__ double pymax(double a, double b) { return (b > a) ? b : a; }
@@ -256,37 +259,6 @@ __device__ __forceinline__ void arz_interface_ieee(double rL, double yL, double 
     }
 }
 
-// ---- fast double helpers ---------------------------------------------------------------------------------
-// s = sqrt(x), h = 0.5 / sqrt(x) for x in the normal range (callers pass x >= 1e-5): v_rsq_f64 seed (2^-23),
-// one Goldschmidt step, two residual corrections of s (the sequence LLVM uses for a correctly rounded f64 sqrt,
-// without its denormal scaling) and one of h.  Both results are within ~1 ulp.
-__device__ __forceinline__ void sqrt_hrsqrt(double x, double &s, double &h) {
-    double y = __builtin_amdgcn_rsq(x);
-    double g = x * y;
-    h = 0.5 * y;
-    double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    double d = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d, h, g);
-    d = __builtin_fma(-g, g, x);
-    s = __builtin_fma(d, h, g);
-    r = __builtin_fma(-h, s, 0.5);
-    h = __builtin_fma(h + h, r, h);
-}
-__device__ __forceinline__ double fast_sqrt(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    double g = x * y;
-    double h = 0.5 * y;
-    double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    double d = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d, h, g);
-    d = __builtin_fma(-g, g, x);
-    return __builtin_fma(d, h, g);
-}
-
 // Production version of the interface solve.  Same formulas and branch structure as arz_interface_ieee, with
 //   * every 1/sqrt(x), 1/x and sqrt(x) of one argument taken from ONE rsq + Newton sequence,
 //   * divisions by launch constants turned into multiplications by their reciprocals,
@@ -310,22 +282,20 @@ __device__ __forceinline__ void arz_interface_fast(double rL, double yL, double 
     // ---- Riemann solve: case index, CFL flag (_arz.py:222-314) ----
     int ci;
     bool bad;
-    double rm = 0., sm = 0., hm = 0.;
+    double rm = 0.;
     const bool vacL = rL < kEps;
     const bool vacR = rR < kEps;
     const bool same = fabs(uL - uR) < kEps;
     const bool wave_m = !(vacL || vacR || same);           // branches 4, 5, 6
     const bool b4 = wave_m && (uL > uR);
     const bool b5 = wave_m && !b4 && (um + uL - qL > uR);
+    double bm = 0.;                                        // sqrt(rm) up to sign: rm = bm^2
     if (b4 || b5) {
-        const double b = sL + (uL - uR) * inv_um;          // sqrt(rL) = sL here (rL >= eps)
-        rm = b * b;                                        // compute_Qm :194
+        bm = sL + (uL - uR) * inv_um;                      // sqrt(rL) = sL here (rL >= eps)
+        rm = bm * bm;                                      // compute_Qm :194
     }
+    const double abm = fabs(bm);
     const double l0l = uL + rL * ueqp_L;
-    double diff = 0.;
-    if (b4) diff = rm * uR - rL * uL;
-    const bool need_m = b5 || (b4 && diff < 0.);
-    if (need_m) sqrt_hrsqrt(pymax(rm, kEps), sm, hm);
     if (vacL) {
         ci = 0;
         bad = !(k.dt * pymax(fabs(uL), 1e-5) < k.dx);
@@ -337,12 +307,15 @@ __device__ __forceinline__ void arz_interface_fast(double rL, double yL, double 
         ci = 0;
         bad = !(k.dt * pymax(fabs(uR), 1e-5) < k.dx);
     } else if (b4) {
+        const double diff = rm * uR - rL * uL;
         const double den = pymax(rm - rL, kEps);
         ci = (diff >= 0.0) ? 0 : 1;                        // sign of speed0 = diff / den
         // dt * max(|diff| / den, 1e-5) < dx  without the division
         bad = !(k.dt * fabs(diff) < k.dx * den) || !(k.dt * pymax(fabs(uR), 1e-5) < k.dx);
     } else if (b5) {
-        const double l0m = uR + rm * (-um * hm);
+        // lambda_0(Q_m) = u_R + r_m u_eq'(r_m) = u_R - gamma u_max r_m^gamma = u_R - u_max |b| / 2   (r_m >= eps),
+        // and u_R + r_m (-u_max gamma eps^(gamma-1)) below eps: no square root needed
+        const double l0m = (rm >= kEps) ? (uR - (0.5 * um) * abm) : (uR + rm * (-um * kHalfRsqrtEps));
         const double s0 = (l0l + l0m) * 0.5;
         ci = (l0l >= 0) ? 0 : ((l0m <= 0) ? 1 : 2);
         bad = !(k.dt * pymax(fmax(fabs(s0), fabs(uR)), 1e-5) < k.dx);
@@ -366,65 +339,51 @@ __device__ __forceinline__ void arz_interface_fast(double rL, double yL, double 
         r0 = rm; u0 = uR;
         q0 = um * (1. - fast_sqrt(pymax(rm, 0.) + kEps));
         y0 = rm * (uR - q0);
-        r0c = pymax(rm, kEps); h0 = hm;
-        const double rsm = hm + hm;
+        r0c = pymax(rm, kEps);
+        h0 = (rm >= kEps) ? 0.5 * fast_rcp(abm) : kHalfRsqrtEps;        // 0.5 / sqrt(r0c), sqrt(rm) = |b|
+        const double rsm = h0 + h0;
         inv_r0c = rsm * rsm;
-        // compute_dM, darz.py:35-122
+        // compute_dM, darz.py:35-122 (same quantities, common factors pulled out)
         const double rRc = pymax(rR, kEps);
         double sR, hR;
         sqrt_hrsqrt(rRc, sR, hR);
         const double rsR = hR + hR;
         const double inv_rRc = rsR * rsR;
-        const double ueqp_M = -um * hm;
+        const double ueqp_M = -um * h0;
         const double duL_drL = -yL * (inv_rLc * inv_rLc) + ueqp_L;
-        const double duL_dyL = inv_rLc;
         const double duR_drR = -yR * (inv_rRc * inv_rRc) + (-um * hR);
-        const double duR_dyR = inv_rRc;
-        const double sqrt_rm = (rm >= kEps) ? sm : sqrt(rm);
-        const double a = 2.0 * sqrt_rm;                    // (1 / gamma) * r_M ** (1 - gamma)
-        const double b = hL;                               // gamma * r_L ** (gamma - 1)
-        const double c = inv_um * duL_drL;
-        const double drM_drL = a * (b + c);
-        const double d = inv_um * duL_dyL;
-        const double drM_dyL = a * d;
-        const double e = u0 - q0;
-        const double dyM_drL = drM_drL * e + rm * (-ueqp_M * drM_drL);
-        const double dyM_dyL = drM_dyL * e + rm * (-ueqp_M * drM_dyL);
-        const double f = -inv_um * duR_drR;
-        const double drM_drR = a * f;
-        const double g = -inv_um * duR_dyR;
-        const double drM_dyR = a * g;
-        const double dyM_drR = drM_drR * e + rm * (duR_drR - ueqp_M * drM_drR);
-        const double dyM_dyR = drM_dyR * e + rm * (duR_dyR - ueqp_M * drM_dyR);
-        dL[0] = (float)drM_drL; dL[1] = (float)drM_dyL; dL[2] = (float)dyM_drL; dL[3] = (float)dyM_dyL;
-        dR[0] = (float)drM_drR; dR[1] = (float)drM_dyR; dR[2] = (float)dyM_drR; dR[3] = (float)dyM_dyR;
+        const double a = 2.0 * abm;                        // (1 / gamma) * r_M ** (1 - gamma)
+        const double ai = a * inv_um;
+        const double k1 = (u0 - q0) - rm * ueqp_M;         // d y_M = k1 d r_M + r_M d u_R
+        const double drM_drL = a * hL + ai * duL_drL;      // gamma * r_L ** (gamma - 1) = hL
+        const double drM_dyL = ai * inv_rLc;
+        const double drM_drR = -ai * duR_drR;
+        const double drM_dyR = -ai * inv_rRc;
+        dL[0] = (float)drM_drL; dL[1] = (float)drM_dyL; dL[2] = (float)(drM_drL * k1); dL[3] = (float)(drM_dyL * k1);
+        dR[0] = (float)drM_drR; dR[1] = (float)drM_dyR;
+        dR[2] = (float)(drM_drR * k1 + rm * duR_drR); dR[3] = (float)(drM_dyR * k1 + rm * inv_rRc);
     } else {
         // compute_Qc, _arz.py:167-182
         const double base = uL + um * sL;
         const double t = base * k.inv_15um;
+        const double at = fabs(t);                         // sqrt(r_C)
         r0 = t * t;
         u0 = kGoG1 * base;
         q0 = um * (1. - fast_sqrt(pymax(r0, 0.) + kEps));
         y0 = r0 * (u0 - q0);
         r0c = pymax(r0, kEps);
-        double s0c;
-        sqrt_hrsqrt(r0c, s0c, h0);
+        h0 = (r0 >= kEps) ? 0.5 * fast_rcp(at) : kHalfRsqrtEps;
         const double rs0 = h0 + h0;
         inv_r0c = rs0 * rs0;
-        // compute_dC, darz.py:124-192
+        // compute_dC, darz.py:124-192 (same quantities, common factors pulled out)
         const double ueqp_C = -um * h0;
-        const double duL_drL = -yL * (inv_rLc * inv_rLc) + ueqp_L;
-        const double duL_dyL = inv_rLc;
-        const double f = um * hL;                          // u_max * gamma * r_L ** (gamma - 1)
-        const double duC_drL = kGoG1 * (duL_drL + f);
-        const double duC_dyL = kGoG1 * duL_dyL;
-        const double e = (fabs(t) * 2.0) * k.inv_15um;     // ((r_C ** (1 - gamma)) / gamma) / ((gamma + 1) u_max)
-        const double drC_drL = e * (duL_drL + f);
-        const double drC_dyL = e * duL_dyL;
-        const double g = u0 - q0;
-        const double dyC_drL = drC_drL * g + r0 * (duC_drL - ueqp_C * drC_drL);
-        const double dyC_dyL = drC_dyL * g + r0 * (duC_dyL - ueqp_C * drC_dyL);
-        dL[0] = (float)drC_drL; dL[1] = (float)drC_dyL; dL[2] = (float)dyC_drL; dL[3] = (float)dyC_dyL;
+        const double w = (-yL * (inv_rLc * inv_rLc) + ueqp_L) + um * hL;    // duL_drL + u_max gamma r_L ** (gamma - 1)
+        const double e = (at * 2.0) * k.inv_15um;          // ((r_C ** (1 - gamma)) / gamma) / ((gamma + 1) u_max)
+        const double k2 = (u0 - q0) - r0 * ueqp_C;         // d y_C = k2 d r_C + r_C d u_C
+        const double drC_drL = e * w;
+        const double drC_dyL = e * inv_rLc;
+        dL[0] = (float)drC_drL; dL[1] = (float)drC_dyL;
+        dL[2] = (float)(drC_drL * k2 + r0 * (kGoG1 * w)); dL[3] = (float)(drC_dyL * k2 + r0 * (kGoG1 * inv_rLc));
     }
     o.Fr = r0 * u0;
     o.Fy = y0 * u0;

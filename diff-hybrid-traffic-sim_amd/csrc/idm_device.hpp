@@ -7,6 +7,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "fast_math.hpp"
+
 namespace dhts {
 
 struct IdmParams {      // road/vehicle/micro_vehicle.py:21-28, kept as doubles like the reference's Python floats
@@ -23,10 +25,12 @@ struct IdmStep {
     bool clipped_acc, clipped_spacing;
 };
 
+// Reference-order version: IEEE double division / square root exactly where the reference divides and takes powers
+// (validation; dhts_idm_batch variant 1).
 // p, v: ego state; dp_raw, dv_raw: gap and speed difference to the leader as compute_state_delta returns them
 // (_micro_lane.py:195-214).
-__device__ __forceinline__ void idm_step(double p, double v, double dp_raw, double dv_raw, const IdmParams &m,
-                                         double dt, IdmStep &o) {
+__device__ __forceinline__ void idm_step_ieee(double p, double v, double dp_raw, double dv_raw, const IdmParams &m,
+                                              double dt, IdmStep &o) {
     double dp = dp_raw, dv = dv_raw;
     o.collided = dp < 0;
     if (o.collided) { dp = 0; dv = 0; }                    // :151-160 "Set deltas to 0"
@@ -67,6 +71,69 @@ __device__ __forceinline__ void idm_step(double p, double v, double dp_raw, doub
         } else {
             o.dE[3] = (float)(1 + dt * m.a_max * (free_term - 2 * s_dp2 * (m.time_pref + ((v + dv_raw) / two_sqrt_ab))));
             o.dLd[3] = (float)(dt * m.a_max * (-2 * s_dp2 * (-v / two_sqrt_ab)));
+        }
+    }
+}
+
+// ---- production version -------------------------------------------------------------------------------------
+// Per-vehicle constants evaluated once per rollout (IEEE operations), so that the time loop has no division by a
+// constant and no square root: 1 / (2 sqrt(a_max a_pref)), 1 / v_target, 1 / v_target^4.
+struct IdmDerived {
+    double a_max, min_space, time_pref, length;
+    double inv_2sab, inv_vt, inv_vt4;
+};
+__device__ __forceinline__ IdmDerived idm_derive(const IdmParams &m) {
+    IdmDerived d;
+    d.a_max = m.a_max; d.min_space = m.min_space; d.time_pref = m.time_pref; d.length = m.length;
+    d.inv_2sab = 1.0 / (2 * sqrt(m.a_max * m.a_pref));
+    d.inv_vt = 1.0 / m.v_target;
+    const double vt2 = m.v_target * m.v_target;
+    d.inv_vt4 = 1.0 / (vt2 * vt2);
+    return d;
+}
+// Same formulas and clip logic as idm_step_ieee; the only division left is ONE reciprocal of the gap.  Results differ
+// from the reference-order version by a few double ulps (< 1e-8 of a float32 ulp before the float32 stores).
+__device__ __forceinline__ void idm_step(double p, double v, double dp_raw, double dv_raw, const IdmDerived &m,
+                                         double dt, double inv_dt, IdmStep &o) {
+#pragma clang fp contract(fast)
+    double dp = dp_raw, dv = dv_raw;
+    o.collided = dp < 0;
+    if (o.collided) { dp = 0; dv = 0; }
+    const double dpc = (1e-5 > dp) ? 1e-5 : dp;
+    const double rdp = fast_rcp(dpc);
+
+    double s = (m.min_space + v * m.time_pref + ((v * dv) * m.inv_2sab));
+    const bool clipped_s = (s < 0.0);
+    s = (0. > s) ? 0. : s;
+    const double vr = v * m.inv_vt;
+    const double vr2 = vr * vr;
+    const double sr = s * rdp;
+    double acc = m.a_max * (1.0 - vr2 * vr2 - sr * sr);
+    const double floor_acc = -v * inv_dt;
+    const bool clipped_a = (acc < floor_acc);
+    acc = (floor_acc > acc) ? floor_acc : acc;
+
+    o.np = (float)(p + dt * v);
+    o.nv = (float)(v + dt * acc);
+    o.acc = acc; o.sstar = s; o.clipped_acc = clipped_a; o.clipped_spacing = clipped_s;
+
+    o.dE[0] = 1.f; o.dE[1] = (float)dt; o.dE[2] = 0.f; o.dE[3] = 0.f;
+    o.dLd[0] = o.dLd[1] = o.dLd[2] = o.dLd[3] = 0.f;
+    if (!clipped_a) {
+        // the Jacobians use the UN-clamped gap (dmicro_lane.py:97); it equals the clamped one unless gap < 1e-5
+        const double rdr = (dp_raw >= 1e-5) ? rdp : 1.0 / dp_raw;
+        const double rdr2 = rdr * rdr;
+        const double s2_dp3 = (s * s) * (rdr2 * rdr);
+        const double free_term = -4.0 * ((v * v * v) * m.inv_vt4);
+        const double s_dp2 = s * rdr2;
+        o.dE[2] = (float)(dt * (-2 * m.a_max * s2_dp3));
+        o.dLd[2] = (float)(dt * (2 * m.a_max * s2_dp3));
+        if (clipped_s) {
+            o.dE[3] = (float)(1 + dt * m.a_max * free_term);
+            o.dLd[3] = (float)(dt * m.a_max * (-2 * s_dp2));
+        } else {
+            o.dE[3] = (float)(1 + dt * m.a_max * (free_term - 2 * s_dp2 * (m.time_pref + ((v + dv_raw) * m.inv_2sab))));
+            o.dLd[3] = (float)(dt * m.a_max * (-2 * s_dp2 * (-v * m.inv_2sab)));
         }
     }
 }

@@ -46,19 +46,22 @@ __global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
     const int Vp = (V + 63) & ~63;
     const size_t plane = (size_t)L * V;
 
-    IdmParams prm[K];
+    IdmDerived prm[K];
     double len_lead[K];
+    const double inv_dt = 1.0 / dt;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const int i = (j << 6) + t;
         const int ic = i < V ? i : V - 1;
         const int il = (i + 1) < V ? (i + 1) : V - 1;
-        prm[j].a_max = params[0 * plane + base + ic];
-        prm[j].a_pref = params[1 * plane + base + ic];
-        prm[j].v_target = params[2 * plane + base + ic];
-        prm[j].min_space = params[3 * plane + base + ic];
-        prm[j].time_pref = params[4 * plane + base + ic];
-        prm[j].length = params[5 * plane + base + ic];
+        IdmParams raw;
+        raw.a_max = params[0 * plane + base + ic];
+        raw.a_pref = params[1 * plane + base + ic];
+        raw.v_target = params[2 * plane + base + ic];
+        raw.min_space = params[3 * plane + base + ic];
+        raw.time_pref = params[4 * plane + base + ic];
+        raw.length = params[5 * plane + base + ic];
+        prm[j] = idm_derive(raw);
         len_lead[j] = params[5 * plane + base + il];
     }
     for (int k = t; k < V; k += 64) { Sp[k] = p_in[base + k]; Sv[k] = v_in[base + k]; }
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
                 dv = v - vl;
             }
             IdmStep o;
-            idm_step(p, v, dp, dv, prm[j], dt, o);
+            idm_step(p, v, dp, dv, prm[j], dt, inv_dt, o);
             if (valid) {
                 if (o.collided && fault_step < 0) { fault_step = step; fault_index = i; }
                 Sp[i] = o.np; Sv[i] = o.nv;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
 }
 
 // known-answer entry: n independent vehicles.  in [9][n] double = a_max a_pref v v_target dp dv min_space time_pref dt
-__global__ void idm_batch_kernel(int64_t n, const double *__restrict__ in, double *__restrict__ next_pv,
+__global__ void idm_batch_kernel(int64_t n, int variant, const double *__restrict__ in, double *__restrict__ next_pv,
                                  float *__restrict__ dE, float *__restrict__ dLd, int32_t *__restrict__ collided,
                                  double *__restrict__ acc_s, int32_t *__restrict__ clips) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -111,7 +114,9 @@ __global__ void idm_batch_kernel(int64_t n, const double *__restrict__ in, doubl
         m.a_max = in[i]; m.a_pref = in[n + i]; m.v_target = in[3 * n + i]; m.min_space = in[6 * n + i];
         m.time_pref = in[7 * n + i]; m.length = 0.;
         IdmStep o;
-        idm_step(0.0, in[2 * n + i], in[4 * n + i], in[5 * n + i], m, in[8 * n + i], o);
+        const double dt = in[8 * n + i];
+        if (variant == 1) idm_step_ieee(0.0, in[2 * n + i], in[4 * n + i], in[5 * n + i], m, dt, o);
+        else idm_step(0.0, in[2 * n + i], in[4 * n + i], in[5 * n + i], idm_derive(m), dt, 1.0 / dt, o);
         next_pv[i] = o.np; next_pv[n + i] = o.nv;
         collided[i] = o.collided ? 1 : 0;
         acc_s[i] = o.acc; acc_s[n + i] = o.sstar;
@@ -204,12 +209,12 @@ static void launch_micro_fwd(const dhts_micro_desc *d, int T, const float *p, co
 
 extern "C" {
 
-int dhts_idm_batch(int64_t n, const double *in, double *next_pv, float *dEgo, float *dLeading, int32_t *collided,
+int dhts_idm_batch(int64_t n, int variant, const double *in, double *next_pv, float *dEgo, float *dLeading, int32_t *collided,
                    double *acc_sstar, int32_t *clips, void *stream) {
-    if (n < 0 || !in || !next_pv || !dEgo || !dLeading || !collided || !acc_sstar || !clips) return DHTS_E_INVALID;
+    if (n < 0 || (variant != 0 && variant != 1) || !in || !next_pv || !dEgo || !dLeading || !collided || !acc_sstar || !clips) return DHTS_E_INVALID;
     if (n == 0) return DHTS_OK;
     int64_t g = (n + 255) / 256;
-    idm_batch_kernel<<<(int)(g > 2048 ? 2048 : g), 256, 0, (hipStream_t)stream>>>(n, in, next_pv, dEgo, dLeading, collided, acc_sstar, clips);
+    idm_batch_kernel<<<(int)(g > 2048 ? 2048 : g), 256, 0, (hipStream_t)stream>>>(n, variant, in, next_pv, dEgo, dLeading, collided, acc_sstar, clips);
     return launch_status_m();
 }
 

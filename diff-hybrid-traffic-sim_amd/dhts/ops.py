@@ -299,7 +299,7 @@ def arz_interface_batch(inp, dt=0.01, dx=5.0, variant=0):
                 cfl_bad=bad.bool())
 
 
-def idm_batch(inp):
+def idm_batch(inp, variant=0):
     """inp: float64 [n][9] = a_max a_pref v v_target dp dv min_space time_pref dt (CUDA).
     Returns next_v (float32-rounded v + dt acc, as f64), acc, dEgo, dLeading [n][2][2] f32, collided [n] bool."""
     if inp.dtype != torch.float64 or not inp.is_cuda or inp.dim() != 2 or inp.shape[1] != 9:
@@ -312,7 +312,7 @@ def idm_batch(inp):
     col = torch.empty(n, dtype=torch.int32, device=dev)
     acs = torch.empty(2, n, dtype=torch.float64, device=dev)
     clips = torch.empty(2, n, dtype=torch.int32, device=dev)
-    check(_lib.lib().dhts_idm_batch(n, _ptr(soa), _ptr(nxt), _ptr(dE), _ptr(dLd), _ptr(col), _ptr(acs), _ptr(clips), _stream()),
+    check(_lib.lib().dhts_idm_batch(n, int(variant), _ptr(soa), _ptr(nxt), _ptr(dE), _ptr(dLd), _ptr(col), _ptr(acs), _ptr(clips), _stream()),
           "dhts_idm_batch")
     return dict(next_p=nxt[0], next_v=nxt[1], dEgo=dE.t().reshape(n, 2, 2), dLeading=dLd.t().reshape(n, 2, 2),
                 collided=col.bool(), acc=acs[0], sstar=acs[1], clipped_acc=clips[0].bool(), clipped_spacing=clips[1].bool())

@@ -153,12 +153,13 @@ size_t dhts_micro_tape_bytes(const dhts_micro_desc *d, int T);
 /*
  * n independent vehicles: IDM.compute_acceleration (model/micro/_idm.py:6-50) + one explicit-Euler step
  * (_micro_lane.py:182-183) + dIDM.compute_dEgo / compute_dLeading (model/micro/didm.py:13-103).
+ *   variant 0 = production arithmetic, 1 = reference-order IEEE division / square root
  *   in  [9][n] DOUBLE (SoA): a_max a_pref v v_target position_delta speed_delta min_space time_pref delta_time
  *   out next_pv [2][n] DOUBLE: (0 + dt v, v + dt acc) rounded to float32; dEgo, dLeading [4][n] float32;
  *       collided [n] int32 (position_delta < 0); acc_sstar [2][n] DOUBLE = (acceleration, clipped optimal spacing);
  *       clips [2][n] int32 = (clipped_acceleration, clipped_optimal_spacing)
  */
-int dhts_idm_batch(int64_t n, const double *in, double *next_pv, float *dEgo, float *dLeading, int32_t *collided,
+int dhts_idm_batch(int64_t n, int variant, const double *in, double *next_pv, float *dEgo, float *dLeading, int32_t *collided,
                    double *acc_sstar, int32_t *clips, void *stream);
 
 /*

@@ -63,7 +63,7 @@ def test_device_interface_solver_vs_reference_kat(cuda, golden_dir, variant):
         got, ref = out[key].cpu().numpy(), g[key]
         scale = np.abs(ref).reshape(-1, 4).max(1).reshape(-1, 1, 1)
         assert np.all(np.abs(got - ref) <= 1.2e-7 * np.maximum(scale, 1e-30)), key
-        assert np.mean(got != ref) <= 2e-3, key
+        assert np.mean(got != ref) <= (2e-3 if variant == 1 else 2e-2), key
     # products as np.matmul forms them (acc = a0*b0; acc = fma(a1, b1, acc)) from the reference's own factors
     def mm(a, b):
         a, b = a.astype(np.float64), b.astype(np.float64)
@@ -75,7 +75,7 @@ def test_device_interface_solver_vs_reference_kat(cuda, golden_dir, variant):
         return o.astype(np.float32)
     same = np.all((out["dL"].cpu().numpy() == g["dL"]) & (out["dR"].cpu().numpy() == g["dR"]) &
                   (out["fp"].cpu().numpy() == g["fp"]), axis=(1, 2))
-    assert same.mean() >= 0.99
+    assert same.mean() >= (0.99 if variant == 1 else 0.95)
     A_ref, B_ref = mm(g["fp"], g["dL"]), mm(g["fp"], g["dR"])
     assert np.array_equal(out["A"].cpu().numpy()[same], A_ref[same])
     assert np.array_equal(out["B"].cpu().numpy()[same], B_ref[same])
@@ -85,12 +85,14 @@ def test_device_interface_solver_vs_reference_kat(cuda, golden_dir, variant):
     assert np.array_equal(out["cfl_bad"].cpu().numpy(), cfl_ref) and cfl_ref.any() and not cfl_ref.all()
 
 
-def test_device_idm_vs_reference_kat(cuda, golden_dir):
-    """G5 on the device: acceleration with both clips, Euler step, dEgo / dLeading."""
+@pytest.mark.parametrize("variant", [0, 1])
+def test_device_idm_vs_reference_kat(cuda, golden_dir, variant):
+    """G5 on the device: acceleration with both clips, Euler step, dEgo / dLeading, for the production arithmetic (0)
+    and the reference-order IEEE version (1)."""
     from dhts import ops
     g = load(golden_dir, "idm_kat.npz")
     inp = g["inp"]
-    out = ops.idm_batch(T_(inp, cuda))
+    out = ops.idm_batch(T_(inp, cuda), variant=variant)
     v, dt = inp[:, 2], inp[:, 8]
     assert np.array_equal(out["clipped_acc"].cpu().numpy(), g["flags"][:, 0].astype(bool))
     assert np.array_equal(out["clipped_spacing"].cpu().numpy(), g["flags"][:, 1].astype(bool))
