@@ -5,42 +5,30 @@
 
 namespace dhts {
 
-// s = sqrt(x), h = 0.5 / sqrt(x) for x in the normal range (callers pass x >= 1e-5): v_rsq_f64 seed (2^-23),
-// one Goldschmidt step, two residual corrections of s (the sequence LLVM uses for a correctly rounded f64 sqrt,
-// without its denormal scaling) and one of h.  Both results are within ~1 ulp.
+// s = sqrt(x), h = 0.5 / sqrt(x): v_rsq_f64 seed (relative error <= 2^-23) + ONE coupled Goldschmidt step, which squares
+// the error: both results are good to ~2e-14 relative.  That is 6 orders below half a float32 ulp, so a float32 value
+// rounded from an expression built on them differs from the exactly rounded one with probability ~1e-6; the exact
+// IEEE sequences (13 / 10 dependent double operations instead of 6) are kept in the *_ieee reference-order variants.
 __device__ __forceinline__ void sqrt_hrsqrt(double x, double &s, double &h) {
-    double y = __builtin_amdgcn_rsq(x);
-    double g = x * y;
-    h = 0.5 * y;
-    double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    double d = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d, h, g);
-    d = __builtin_fma(-g, g, x);
-    s = __builtin_fma(d, h, g);
-    r = __builtin_fma(-h, s, 0.5);
-    h = __builtin_fma(h + h, r, h);
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g = x * y;
+    const double h0 = 0.5 * y;
+    const double r = __builtin_fma(-h0, g, 0.5);
+    s = __builtin_fma(g, r, g);
+    h = __builtin_fma(h0, r, h0);
 }
 __device__ __forceinline__ double fast_sqrt(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    double g = x * y;
-    double h = 0.5 * y;
-    double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    double d = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d, h, g);
-    d = __builtin_fma(-g, g, x);
-    return __builtin_fma(d, h, g);
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g = x * y;
+    const double h0 = 0.5 * y;
+    const double r = __builtin_fma(-h0, g, 0.5);
+    return __builtin_fma(g, r, g);
 }
 
-// 1 / x: v_rcp_f64 seed + two Newton steps (~1 ulp)
+// 1 / x: v_rcp_f64 seed (<= 2^-23) + one Newton step (~1e-14 relative)
 __device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
 }
 
 }  // namespace dhts
