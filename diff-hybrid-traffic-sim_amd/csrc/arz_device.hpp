@@ -271,59 +271,43 @@ __device__ __forceinline__ void arz_interface_fast(double rL, double yL, double 
                                                    const IfaceConst &k, Iface &o, IfaceDebug *dbg = nullptr) {
 #pragma clang fp contract(fast)
     const double um = k.um, inv_um = k.inv_um;
-    const double rLc = pymax(rL, kEps);
+    const double rLc = fmax(rL, kEps);
     double sL, hL;
     sqrt_hrsqrt(rLc, sL, hL);                              // sL = sqrt(rLc); 2 hL = rLc^-1/2
     const double rsL = hL + hL;
     const double inv_rLc = rsL * rsL;                      // 1 / rLc
     const double ueqp_L = -um * hL;                        // u_eq'(rL) = -um * gamma * rLc^(gamma-1)
-    const double sLe = fast_sqrt(pymax(rL, 0.) + kEps);    // sqrt(rL + eps) of u_eq(rL)
+    const double sLe = fast_sqrt(fmax(rL, 0.) + kEps);     // sqrt(rL + eps) of u_eq(rL)
 
-    // ---- Riemann solve: case index, CFL flag (_arz.py:222-314) ----
-    int ci;
-    bool bad;
-    double rm = 0.;
+    // ---- Riemann solve: case index, CFL flag (_arz.py:222-314), evaluated branch-free: the six branches only
+    //      differ in a handful of cheap candidates, which are all computed and then selected ----
     const bool vacL = rL < kEps;
     const bool vacR = rR < kEps;
     const bool same = fabs(uL - uR) < kEps;
     const bool wave_m = !(vacL || vacR || same);           // branches 4, 5, 6
     const bool b4 = wave_m && (uL > uR);
-    const bool b5 = wave_m && !b4 && (um + uL - qL > uR);
-    double bm = 0.;                                        // sqrt(rm) up to sign: rm = bm^2
-    if (b4 || b5) {
-        bm = sL + (uL - uR) * inv_um;                      // sqrt(rL) = sL here (rL >= eps)
-        rm = bm * bm;                                      // compute_Qm :194
-    }
+    const double qm_u = um + uL - qL;                      // u of Q_m = (0, .) next to vacuum (:235, :301)
+    const bool b5 = wave_m && !b4 && (qm_u > uR);
+    const double bm = sL + (uL - uR) * inv_um;             // sqrt(r_m) up to sign (sqrt(rL) = sL when rL >= eps)
+    const double rm = bm * bm;                             // compute_Qm :194 (used by branches 4 and 5 only)
     const double abm = fabs(bm);
     const double l0l = uL + rL * ueqp_L;
-    if (vacL) {
-        ci = 0;
-        bad = !(k.dt * pymax(fabs(uL), 1e-5) < k.dx);
-    } else if (vacR) {
-        const double s0 = (l0l + (um + uL - qL)) * 0.5;
-        ci = (l0l >= 0.0) ? 0 : 2;
-        bad = !(k.dt * pymax(fabs(s0), 1e-5) < k.dx);
-    } else if (same) {
-        ci = 0;
-        bad = !(k.dt * pymax(fabs(uR), 1e-5) < k.dx);
-    } else if (b4) {
-        const double diff = rm * uR - rL * uL;
-        const double den = pymax(rm - rL, kEps);
-        ci = (diff >= 0.0) ? 0 : 1;                        // sign of speed0 = diff / den
-        // dt * max(|diff| / den, 1e-5) < dx  without the division
-        bad = !(k.dt * fabs(diff) < k.dx * den) || !(k.dt * pymax(fabs(uR), 1e-5) < k.dx);
-    } else if (b5) {
-        // lambda_0(Q_m) = u_R + r_m u_eq'(r_m) = u_R - gamma u_max r_m^gamma = u_R - u_max |b| / 2   (r_m >= eps),
-        // and u_R + r_m (-u_max gamma eps^(gamma-1)) below eps: no square root needed
-        const double l0m = (rm >= kEps) ? (uR - (0.5 * um) * abm) : (uR + rm * (-um * kHalfRsqrtEps));
-        const double s0 = (l0l + l0m) * 0.5;
-        ci = (l0l >= 0) ? 0 : ((l0m <= 0) ? 1 : 2);
-        bad = !(k.dt * pymax(fmax(fabs(s0), fabs(uR)), 1e-5) < k.dx);
-    } else {
-        const double s0 = (l0l + (um + uL - qL)) * 0.5;
-        ci = (l0l >= 0.0) ? 0 : 2;
-        bad = !(k.dt * pymax(fmax(fabs(s0), fabs(uR)), 1e-5) < k.dx);
-    }
+    const double diff = rm * uR - rL * uL;                 // numerator of the shock speed (:263-265)
+    const double den = fmax(rm - rL, kEps);
+    // lambda_0(Q_m) = u_R + r_m u_eq'(r_m) = u_R - gamma u_max r_m^gamma = u_R - u_max |b| / 2   (r_m >= eps),
+    // and u_R + r_m (-u_max gamma eps^(gamma-1)) below eps: no square root needed
+    const double l0m = (rm >= kEps) ? (uR - (0.5 * um) * abm) : (uR + rm * (-um * kHalfRsqrtEps));
+    const bool l0l_ok = l0l >= 0.0;
+    const int ci_vac = l0l_ok ? 0 : 2;                     // branches 2 and 6
+    const int ci_b4 = (diff >= 0.0) ? 0 : 1;               // sign of speed0 = diff / den
+    const int ci_b5 = l0l_ok ? 0 : ((l0m <= 0) ? 1 : 2);
+    const int ci = (vacL || (same && !vacR)) ? 0 : (b4 ? ci_b4 : (b5 ? ci_b5 : ci_vac));
+    // CFL: dt * max(|speed|, 1e-5) < dx for speed0 and speed1; speed0 = n0 / d0 with d0 > 0 (no division)
+    const double s0_avg = (l0l + (b5 ? l0m : qm_u)) * 0.5; // branches 2, 5, 6
+    const double n0 = (vacL || (same && !vacR)) ? 0.0 : (b4 ? fabs(diff) : fabs(s0_avg));
+    const double d0 = b4 ? den : 1.0;
+    const double s1 = vacL ? fabs(uL) : ((vacR) ? fabs(s0_avg) : fabs(uR));
+    const bool bad = !(k.dt * fmax(n0, 1e-5 * d0) < k.dx * d0) || !(k.dt * fmax(s1, 1e-5) < k.dx);
     o.cfl_bad = bad;
 
     // ---- Q_0 (_arz.py:155-199, 316-326), its Jacobians (darz.py:12-192) ----
@@ -337,14 +321,14 @@ __device__ __forceinline__ void arz_interface_fast(double rL, double yL, double 
         r0c = rLc; h0 = hL; inv_r0c = inv_rLc;
     } else if (ci == 1) {
         r0 = rm; u0 = uR;
-        q0 = um * (1. - fast_sqrt(pymax(rm, 0.) + kEps));
+        q0 = um * (1. - fast_sqrt(fmax(rm, 0.) + kEps));
         y0 = rm * (uR - q0);
-        r0c = pymax(rm, kEps);
+        r0c = fmax(rm, kEps);
         h0 = (rm >= kEps) ? 0.5 * fast_rcp(abm) : kHalfRsqrtEps;        // 0.5 / sqrt(r0c), sqrt(rm) = |b|
         const double rsm = h0 + h0;
         inv_r0c = rsm * rsm;
         // compute_dM, darz.py:35-122 (same quantities, common factors pulled out)
-        const double rRc = pymax(rR, kEps);
+        const double rRc = fmax(rR, kEps);
         double sR, hR;
         sqrt_hrsqrt(rRc, sR, hR);
         const double rsR = hR + hR;
@@ -369,9 +353,9 @@ __device__ __forceinline__ void arz_interface_fast(double rL, double yL, double 
         const double at = fabs(t);                         // sqrt(r_C)
         r0 = t * t;
         u0 = kGoG1 * base;
-        q0 = um * (1. - fast_sqrt(pymax(r0, 0.) + kEps));
+        q0 = um * (1. - fast_sqrt(fmax(r0, 0.) + kEps));
         y0 = r0 * (u0 - q0);
-        r0c = pymax(r0, kEps);
+        r0c = fmax(r0, kEps);
         h0 = (r0 >= kEps) ? 0.5 * fast_rcp(at) : kHalfRsqrtEps;
         const double rs0 = h0 + h0;
         inv_r0c = rs0 * rs0;
