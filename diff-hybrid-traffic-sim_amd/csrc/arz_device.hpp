@@ -319,55 +319,43 @@ __device__ __forceinline__ void arz_interface_fast(double rL, double yL, double 
         u0 = yL * inv_rLc + um * (1. - sLce);
         q0 = um * (1. - sLe);
         r0c = rLc; h0 = hL; inv_r0c = inv_rLc;
-    } else if (ci == 1) {
-        r0 = rm; u0 = uR;
-        q0 = um * (1. - fast_sqrt(fmax(rm, 0.) + kEps));
-        y0 = rm * (uR - q0);
-        r0c = fmax(rm, kEps);
-        h0 = (rm >= kEps) ? 0.5 * fast_rcp(abm) : kHalfRsqrtEps;        // 0.5 / sqrt(r0c), sqrt(rm) = |b|
-        const double rsm = h0 + h0;
-        inv_r0c = rsm * rsm;
-        // compute_dM, darz.py:35-122 (same quantities, common factors pulled out)
-        const double rRc = fmax(rR, kEps);
-        double sR, hR;
-        sqrt_hrsqrt(rRc, sR, hR);
-        const double rsR = hR + hR;
-        const double inv_rRc = rsR * rsR;
-        const double ueqp_M = -um * h0;
-        const double duL_drL = -yL * (inv_rLc * inv_rLc) + ueqp_L;
-        const double duR_drR = -yR * (inv_rRc * inv_rRc) + (-um * hR);
-        const double a = 2.0 * abm;                        // (1 / gamma) * r_M ** (1 - gamma)
-        const double ai = a * inv_um;
-        const double k1 = (u0 - q0) - rm * ueqp_M;         // d y_M = k1 d r_M + r_M d u_R
-        const double drM_drL = a * hL + ai * duL_drL;      // gamma * r_L ** (gamma - 1) = hL
-        const double drM_dyL = ai * inv_rLc;
-        const double drM_drR = -ai * duR_drR;
-        const double drM_dyR = -ai * inv_rRc;
-        dL[0] = (float)drM_drL; dL[1] = (float)drM_dyL; dL[2] = (float)(drM_drL * k1); dL[3] = (float)(drM_dyL * k1);
-        dR[0] = (float)drM_drR; dR[1] = (float)drM_dyR;
-        dR[2] = (float)(drM_drR * k1 + rm * duR_drR); dR[3] = (float)(drM_dyR * k1 + rm * inv_rRc);
     } else {
-        // compute_Qc, _arz.py:167-182
+        // Q_M (case 1, compute_Qm _arz.py:184-199 + compute_dM darz.py:35-122) and Q_C (case 2, compute_Qc :167-182 +
+        // compute_dC darz.py:124-192) share one form: r_0 = b0^2 with b0 = sqrt(r_L) + (u_L - u_R) / u_max   (Q_M)
+        //                                                              or (u_L + u_max sqrt(r_L)) / ((gamma+1) u_max) (Q_C),
+        // and d b0 / d(r_L, y_L) = sc * (du_L/dr_L + u_max gamma r_L^(gamma-1), du_L/dy_L), sc = 1/u_max or 1/((gamma+1) u_max).
+        const bool c1 = (ci == 1);
         const double base = uL + um * sL;
-        const double t = base * k.inv_15um;
-        const double at = fabs(t);                         // sqrt(r_C)
-        r0 = t * t;
-        u0 = kGoG1 * base;
+        const double b0 = c1 ? bm : base * k.inv_15um;
+        const double ab0 = fabs(b0);                       // sqrt(r_0) = r_0 ** (1 - gamma)
+        r0 = b0 * b0;
+        u0 = c1 ? uR : kGoG1 * base;
         q0 = um * (1. - fast_sqrt(fmax(r0, 0.) + kEps));
         y0 = r0 * (u0 - q0);
         r0c = fmax(r0, kEps);
-        h0 = (r0 >= kEps) ? 0.5 * fast_rcp(at) : kHalfRsqrtEps;
+        h0 = (r0 >= kEps) ? 0.5 * fast_rcp(ab0) : kHalfRsqrtEps;          // 0.5 / sqrt(r0c)
         const double rs0 = h0 + h0;
         inv_r0c = rs0 * rs0;
-        // compute_dC, darz.py:124-192 (same quantities, common factors pulled out)
-        const double ueqp_C = -um * h0;
-        const double w = (-yL * (inv_rLc * inv_rLc) + ueqp_L) + um * hL;    // duL_drL + u_max gamma r_L ** (gamma - 1)
-        const double e = (at * 2.0) * k.inv_15um;          // ((r_C ** (1 - gamma)) / gamma) / ((gamma + 1) u_max)
-        const double k2 = (u0 - q0) - r0 * ueqp_C;         // d y_C = k2 d r_C + r_C d u_C
-        const double drC_drL = e * w;
-        const double drC_dyL = e * inv_rLc;
-        dL[0] = (float)drC_drL; dL[1] = (float)drC_dyL;
-        dL[2] = (float)(drC_drL * k2 + r0 * (kGoG1 * w)); dL[3] = (float)(drC_dyL * k2 + r0 * (kGoG1 * inv_rLc));
+        const double w = (-yL * (inv_rLc * inv_rLc) + ueqp_L) + um * hL;  // du_L/dr_L + u_max gamma r_L^(gamma-1)
+        const double a2sc = (2.0 * ab0) * (c1 ? inv_um : k.inv_15um);
+        const double k1 = (u0 - q0) - r0 * (-um * h0);     // d y_0 = k1 d r_0 + r_0 d u_0
+        const double gL = c1 ? 0.0 : kGoG1;                // d u_0 / d u_L
+        const double dr_drL = a2sc * w;
+        const double dr_dyL = a2sc * inv_rLc;
+        dL[0] = (float)dr_drL; dL[1] = (float)dr_dyL;
+        dL[2] = (float)(dr_drL * k1 + r0 * (gL * w)); dL[3] = (float)(dr_dyL * k1 + r0 * (gL * inv_rLc));
+        if (c1) {
+            const double rRc = fmax(rR, kEps);
+            double sR, hR;
+            sqrt_hrsqrt(rRc, sR, hR);
+            const double rsR = hR + hR;
+            const double inv_rRc = rsR * rsR;
+            const double duR_drR = -yR * (inv_rRc * inv_rRc) + (-um * hR);
+            const double dr_drR = -a2sc * duR_drR;
+            const double dr_dyR = -a2sc * inv_rRc;
+            dR[0] = (float)dr_drR; dR[1] = (float)dr_dyR;
+            dR[2] = (float)(dr_drR * k1 + r0 * duR_drR); dR[3] = (float)(dr_dyR * k1 + r0 * inv_rRc);
+        }
     }
     o.Fr = r0 * u0;
     o.Fy = y0 * u0;
