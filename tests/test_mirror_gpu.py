@@ -196,3 +196,23 @@ def test_two_connected_macro_lanes_exchange_ghosts(cuda):
     ra, _, ua = a.get_state_vector()
     rb, _, ub = b.get_state_vector()
     assert torch.equal(torch.cat([ra, rb]), rw) and torch.equal(torch.cat([ua, ub]), uw)
+
+
+def test_inverse_examples_reduce_the_error(cuda, tmp_path):
+    """examples/inverse_macro.py and inverse_micro.py (the harness counterparts of example/inverse/*.py): Adam on the
+    HIP path drives the end error down and writes the reference's "{beg} {end}" log lines."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    for script, extra in (("inverse_macro.py", ["--n_cell", "100", "--n_timestep", "200"]),
+                          ("inverse_micro.py", ["--n_vehicle", "10", "--n_timestep", "200"])):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script), "--n_episode", "30", "--n_lane", "3",
+                              "--seed", "1", "--run_name", "t"] + extra, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        kind = script.split("_")[1].split(".")[0]
+        lines = open(tmp_path / "result" / "inverse" / "t" / "gd" / "trial_0.txt").read().split("\n")
+        lines = [l.split() for l in lines if l]
+        assert len(lines) == 30 and all(len(l) == 2 for l in lines)
+        assert float(lines[-1][1]) < 0.7 * float(lines[0][1]), (kind, lines[0], lines[-1])
+        import shutil
+        shutil.rmtree(tmp_path / "result")
