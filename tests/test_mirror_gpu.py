@@ -216,3 +216,57 @@ def test_inverse_examples_reduce_the_error(cuda, tmp_path):
         assert float(lines[-1][1]) < 0.7 * float(lines[0][1]), (kind, lines[0], lines[-1])
         import shutil
         shutil.rmtree(tmp_path / "result")
+
+
+def test_hybrid_three_lane_network_like_example(cuda, golden_dir):
+    """example/inverse/hybrid.py's network macro(0) -> micro(1) -> macro(2) through the mirror (G7): flux-capacitor
+    spawning, micro -> macro hand-off with the ancillary variable `a`, same event times, states and gradients."""
+    import torch
+    from road.lane.dmacro_lane import dMacroLane
+    from road.lane.dmicro_lane import dMicroLane
+    from road.network.road_network import RoadNetwork
+    g = load(golden_dir, "hybrid_hybrid3.npz")
+    m = meta_of(g)
+    N, T, dx, dt, um = m["N"], m["T"], m["dx"], m["dt"], m["u_max"]
+    np.random.seed(m["seed"])
+    r0, u0 = tt(g["r0"], cuda, True), tt(g["u0"], cuda, True)
+    bd_r, bd_u = tt(g["bd_r"], cuda), tt(g["bd_u"], cuda)
+    net = RoadNetwork(um)
+    a = dMacroLane(0, N * dx, um, dx)
+    a.set_leftmost_cell(bd_r[0], bd_u[0])
+    a.set_rightmost_cell(bd_r[1], bd_u[1])
+    net.add_lane(a)
+    a.set_state_vector_u(r0, u0)
+    b = dMicroLane(1, N * dx, um)
+    net.add_lane(b)
+    c = dMacroLane(2, N * dx, um, dx)
+    c.set_leftmost_cell(bd_r[2], bd_u[2])
+    c.set_rightmost_cell(bd_r[3], bd_u[3])
+    net.add_lane(c)
+    net.connect_lane(0, 1)
+    net.connect_lane(1, 2)
+    net.macro_route = net.create_random_macro_route()
+    assert sorted(net.macro_route.next_lane_dict.items()) == [tuple(x) for x in g["macro_next"].tolist()]
+    events, nveh = [], []
+    for t in range(T):
+        before, spawned = b.num_vehicle(), net.num_vehicle
+        net.forward(dt, True)
+        if net.num_vehicle > spawned:
+            events.append((t, 0, float(b.curr_vehicle[0].speed)))
+        if b.num_vehicle() < before + (net.num_vehicle - spawned):
+            events.append((t, 1, float(c.curr_cell[0].state.q.r)))
+        nveh.append(b.num_vehicle())
+    ref_ev = g["events"]
+    assert [(e[0], e[1]) for e in events] == [(int(e[0]), int(e[1])) for e in ref_ev]
+    assert np.allclose([e[2] for e in events], ref_ev[:, 2], rtol=1e-5, atol=1e-6)
+    assert nveh == g["nveh"].tolist()
+    rA, yA, uA = a.get_state_vector()
+    rC, yC, uC = c.get_state_vector()
+    pB, vB = b.get_state_vector()
+    loss = (rC ** 2).sum() + (uC ** 2).sum() + (rA ** 2).sum() + (uA ** 2).sum() + 1e-4 * (pB ** 2).sum() + (vB ** 2).sum()
+    loss.backward()
+    for got, key in ((rA, "rA"), (uA, "uA"), (rC, "rC"), (uC, "uC"), (pB, "pB"), (vB, "vB")):
+        assert rel_max(got.detach().cpu().numpy(), g[key]) <= TOL_STATE, key
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    assert rel_max(r0.grad.cpu().numpy(), g["g_r0"]) <= TOL_GRAD
+    assert rel_max(u0.grad.cpu().numpy(), g["g_u0"]) <= TOL_GRAD

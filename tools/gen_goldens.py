@@ -18,6 +18,7 @@ Golden sets:
   G4     macro_rollout_*.npz T-step rollouts through RoadNetwork.forward with loss and gradients
   G5     idm_kat.npz         IDM.compute_acceleration + dIDM.compute_dEgo/dLeading
   G6     micro_rollout_*.npz dMicroLane rollouts with loss and gradients
+  G7     hybrid_hybrid3.npz  macro -> micro -> macro network with spawn / hand-off events, loss and gradients
 """
 import argparse
 import json
@@ -459,6 +460,66 @@ def gen_micro_rollouts(which):
         micro_rollout("long", 12, 1000, 0.01, 30.0, seed=12, params="default", tap="final_sq", record_steps=0)
 
 
+# ----------------------------------------------------------------------------------------------
+# G7: 3-lane hybrid network macro(0) -> micro(1) -> macro(2)  (example/inverse/hybrid.py:37-82)
+# ----------------------------------------------------------------------------------------------
+
+def gen_hybrid(name="hybrid3", N=10, T=500, dx=5.0, dt=0.01, um=30.0, seed=21):
+    th.manual_seed(seed)
+    np.random.seed(seed)
+    L = N * dx
+    bd_r = th.rand(4)
+    bd_u = th.rand(4) * um
+    r0 = (0.3 + 0.6 * th.rand(N)).requires_grad_(True)          # dense enough to emit vehicles
+    u0 = (0.3 * um + 0.5 * um * th.rand(N)).requires_grad_(True)
+    net = RoadNetwork(um)
+    a = dMacroLane(0, L, um, dx)
+    a.set_leftmost_cell(bd_r[0], bd_u[0])
+    a.set_rightmost_cell(bd_r[1], bd_u[1])
+    net.add_lane(a)
+    a.set_state_vector_u(r0, u0)
+    b = dMicroLane(1, L, um)
+    net.add_lane(b)
+    c = dMacroLane(2, L, um, dx)
+    c.set_leftmost_cell(bd_r[2], bd_u[2])
+    c.set_rightmost_cell(bd_r[3], bd_u[3])
+    net.add_lane(c)
+    net.connect_lane(0, 1)
+    net.connect_lane(1, 2)
+    net.macro_route = net.create_random_macro_route()
+    events = []          # (step, kind, value): kind 0 = spawn on lane 1, 1 = hand-off to lane 2
+    nveh = []
+    t0 = time.time()
+    for t in range(T):
+        before, spawned = b.num_vehicle(), net.num_vehicle
+        net.forward(dt, True)
+        if net.num_vehicle > spawned:
+            events.append((t, 0, float(b.curr_vehicle[0].speed)))
+        if b.num_vehicle() < before + (net.num_vehicle - spawned):
+            events.append((t, 1, float(c.curr_cell[0].state.q.r)))
+        nveh.append(b.num_vehicle())
+    rA, yA, uA = a.get_state_vector()
+    rC, yC, uC = c.get_state_vector()
+    pB, vB = b.get_state_vector()
+    loss = (rC ** 2).sum() + (uC ** 2).sum() + (rA ** 2).sum() + (uA ** 2).sum()
+    if len(pB):
+        loss = loss + 1e-4 * (pB ** 2).sum() + (vB ** 2).sum()
+    t1 = time.time()
+    loss.backward()
+    print("G7 %s: %d events, %d vehicles at the end, loss %.6f, fwd %.1fs bwd %.1fs" % (
+        name, len(events), b.num_vehicle(), float(loss), t1 - t0, time.time() - t1))
+    np.savez_compressed(
+        os.path.join(OUT, "hybrid_%s.npz" % name),
+        r0=r0.detach().numpy(), u0=u0.detach().numpy(), bd_r=bd_r.numpy(), bd_u=bd_u.numpy(),
+        rA=rA.detach().numpy(), yA=yA.detach().numpy(), uA=uA.detach().numpy(),
+        rC=rC.detach().numpy(), yC=yC.detach().numpy(), uC=uC.detach().numpy(),
+        pB=pB.detach().numpy(), vB=vB.detach().numpy(), events=np.array(events, dtype=np.float64),
+        nveh=np.array(nveh, dtype=np.int32), loss=np.float64(float(loss)),
+        g_r0=r0.grad.numpy(), g_u0=u0.grad.numpy(),
+        macro_next=np.array(sorted(net.macro_route.next_lane_dict.items()), dtype=np.int32),
+        meta=meta(seed=seed, N=N, T=T, dx=dx, dt=dt, u_max=um))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="G1,G3,G4,G5,G6")
@@ -477,6 +538,8 @@ def main():
         gen_idm_kat()
     if "G6" in only:
         gen_micro_rollouts(set(args.g6.split(",")))
+    if "G7" in only:
+        gen_hybrid()
 
 
 if __name__ == "__main__":
