@@ -1,0 +1,289 @@
+"""ItscpEnv on the reference's import path (example.control.itscp._env; reference _env.py:24-962) without the
+highway-env / gym / pygame dependencies: grid-of-intersections topology, inflow schedules, differentiable signal phases,
+per-step queue-length loss.  Rendering is out of scope.
+
+Topology (reference _env.py:221-439): every intersection (row, col) has, per side (south / west / north / east) and per
+lane index, one approaching and one leaving lane of `lane_length`; inside the intersection each approaching lane gets a
+straight connector to the opposite leaving lane and (right-most lane only) a right-turn connector; left turns are disabled.
+Neighbouring intersections are joined leaving -> approaching.  Lane geometry is only used for lane LENGTHS; it is
+reproduced with the same floating-point construction so that ceil(length / cell_length) gives the same cell counts.
+"""
+import numpy as np
+import torch as th
+
+from dmath.operation import sigmoid
+from example.common.rms import RunningMean
+from example.control.itscp._env_config import default_config
+from example.control.itscp._simulator import ItscpRoadNetwork as SimRoadNetwork
+from road.lane.dmacro_lane import MacroLane, dMacroLane
+from road.lane.dmicro_lane import MicroLane, dMicroLane
+
+LANE_WIDTH = 4          # highway-env AbstractLane.DEFAULT_WIDTH
+
+
+class LaneID:
+    """(row, col) of the intersection, side `loc` ('south' / 'west' / 'north' / 'east' / 'mid'), for connectors the side
+    they come from (`ploc`), direction and lane index (reference _env.py:24-60)."""
+
+    def __init__(self, row, col, loc, ploc, approaching, lane_id):
+        self.row, self.col, self.loc, self.ploc, self.approaching, self.lane_id = row, col, loc, ploc, approaching, lane_id
+
+    def __str__(self):
+        return "{}_{}_{}_{}_{}_{}".format(self.row, self.col, self.loc, self.ploc,
+                                          "approaching" if self.approaching else "leaving", self.lane_id)
+
+    def __eq__(self, o):
+        return str(self) == str(o)
+
+    def __hash__(self):
+        return hash(str(self))
+
+
+class _Segment:
+    def __init__(self, start, end):
+        self.start, self.end = np.array(start, dtype=float), np.array(end, dtype=float)
+        self.length = float(np.linalg.norm(self.end - self.start))
+        self.direction = (self.end - self.start) / self.length
+
+    def position(self, s):
+        return self.start + s * self.direction
+
+
+class _Lane:
+    def __init__(self, seg, sim_lane):
+        self.env_lane, self.sim_lane = seg, sim_lane
+
+
+def itscp_random_schedule(lane_id, num_timestep):
+    """Five sessions of constant random inflow per lane (reference _env.py:62-92)."""
+    per = num_timestep // 5
+    schedule = {}
+    for id in lane_id:
+        cur = []
+        for _ in range(5):
+            r = np.random.random((1)).item()
+            cur.extend([r] * per)
+            cur = cur[:num_timestep]
+        schedule[id] = cur
+    return schedule
+
+
+SIDE_OF_CORNER = (("south", "east"), ("west", "south"), ("north", "west"), ("east", "north"))   # (approaching, leaving)
+STRAIGHT = {"north": "south", "west": "east", "east": "west", "south": "north"}
+RIGHT = {"north": "west", "west": "south", "east": "north", "south": "east"}
+
+
+class ItscpEnv:
+
+    def __init__(self, schedule_callback=itscp_random_schedule):
+        self.schedule_callback = schedule_callback
+        self.config = dict(default_config)
+        self.simulator = None
+        self.lane = {}
+        self.schedule = {}
+        self.macro_route_schedule = []
+        self.queue_length = {}
+        self.flux = {}
+        self.avg_speed = []
+        self.is_static_rms = RunningMean(100_000)
+        self.render_eval = False
+        self.route_provider = None          # optional callable(lane_id) -> MicroRoute replacing create_random_route
+        self.time = self.steps = 0
+
+    def action_size(self):
+        length = self.config["policy_length"] * self.config["duration"]
+        return int(length / self.config["signal_length"]) * (self.num_intersection ** 2)
+
+    def reset(self):
+        if self.config["random_seed"] > 0:
+            np.random.seed(self.config["random_seed"])
+        self.num_intersection = self.config["num_intersection"]
+        self.num_lane = self.config["num_lane"]
+        self.num_timestep = self.config["policy_length"] * self.config["duration"] * self.config["simulation_frequency"]
+        self._make_road()
+        self.schedule = self.schedule_callback(list(self.lane.keys()), self.num_timestep)
+        self.time = self.steps = 0
+        self.reward_queue_c = -1.0
+        self.macro_route_schedule = [self.simulator.create_random_macro_route() for _ in range(self.num_timestep)]
+        self._make_micro_route()
+        return self.observe()
+
+    def _make_micro_route(self):
+        sim = self.simulator
+        sim.lane_waiting_micro_vehicle.clear()
+        sim.lane_waiting_micro_route.clear()
+        for lid in sim.lane.keys():
+            pairs = [sim.create_default_vehicle_with_random_route(lid) for _ in range(self.config["max_num_micro_vehicle_per_lane"])]
+            sim.lane_waiting_micro_vehicle[lid] = [p[0] for p in pairs]
+            sim.lane_waiting_micro_route[lid] = [p[1] for p in pairs]
+
+    # ---- topology --------------------------------------------------------------------------------------------------
+    def _make_road(self):
+        n_int, n_lane = self.config["num_intersection"], self.config["num_lane"]
+        outer = (LANE_WIDTH + 10) + LANE_WIDTH * (n_lane - 3 + 0.5)
+        access = self.config["lane_length"]
+        self.simulator = SimRoadNetwork(self.config["speed_limit"])
+        if self.route_provider is not None:
+            self.simulator.create_random_route = self.route_provider
+        self.lane.clear()
+        for row in range(n_int):
+            for col in range(n_int):
+                center = np.array([col * (outer + access), row * (outer + access)]) * 2.0
+                approaching_ids = []
+                for corner in range(4):
+                    ang = np.radians(90 * corner)
+                    rot = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+                    for approaching in (True, False):
+                        loc = SIDE_OF_CORNER[corner][0 if approaching else 1]
+                        for k in range(n_lane):
+                            lid = LaneID(row, col, loc, None, approaching, k)
+                            a = np.array([LANE_WIDTH * (k + 0.5), access + outer])
+                            b = np.array([LANE_WIDTH * (k + 0.5), outer])
+                            if not approaching:
+                                a, b = np.flip(a, axis=0), np.flip(b, axis=0)
+                            self._make_lane(lid, center + rot @ a, center + rot @ b)
+                            if approaching:
+                                approaching_ids.append(lid)
+                idx = 0
+                for lid in approaching_ids:
+                    seg = self.lane[lid].env_lane
+                    for turn in ("straight", "right"):
+                        if turn == "right" and lid.lane_id != n_lane - 1:
+                            continue
+                        n_loc = (RIGHT if turn == "right" else STRAIGHT)[lid.loc]
+                        nid = LaneID(row, col, n_loc, None, False, lid.lane_id)
+                        nseg = self.lane[nid].env_lane
+                        mid = LaneID(row, col, "mid", lid.loc, True, idx)
+                        idx += 1
+                        self._make_lane(mid, seg.position(seg.length), nseg.position(nseg.length))
+                        self._connect(lid, mid)
+                        self._connect(mid, nid)
+        for row in range(n_int):
+            for col in range(n_int):
+                for side, other, dr, dc in (("north", "south", -1, 0), ("west", "east", 0, -1)):
+                    if (side == "north" and row == 0) or (side == "west" and col == 0):
+                        continue
+                    for approaching in (True, False):
+                        for k in range(n_lane):
+                            cur = LaneID(row, col, side, None, approaching, k)
+                            con = LaneID(row + dr, col + dc, other, None, not approaching, k)
+                            if approaching:
+                                self._connect(con, cur)
+                            else:
+                                self._connect(cur, con)
+
+    def _make_lane(self, lid, start, end):
+        seg = _Segment(start, end)
+        n_int, sl, dx, mode = self.config["num_intersection"], self.config["speed_limit"], self.config["cell_length"], self.config["mode"]
+        sid = len(self.simulator.lane)
+        if mode == "macro":
+            sim_lane = dMacroLane(sid, seg.length, sl, dx)
+        elif mode == "micro":
+            sim_lane = MicroLane(sid, seg.length, sl)
+        else:       # hybrid: intersections on the border of the grid are macro, interior ones micro
+            border = lid.row in (0, n_int - 1) or lid.col in (0, n_int - 1)
+            sim_lane = dMacroLane(sid, seg.length, sl, dx) if border else dMicroLane(sid, seg.length, sl)
+        self.simulator.add_lane(sim_lane)
+        self.lane[lid] = _Lane(seg, sim_lane)
+
+    def _connect(self, a, b):
+        self.simulator.connect_lane(self.lane[a].sim_lane.id, self.lane[b].sim_lane.id)
+
+    # ---- observation / step ------------------------------------------------------------------------------------------
+    def observe(self):
+        n_obs = self.config["num_schedule_obs"]
+        obs = []
+        for lid in self.lane.keys():
+            sc = self.schedule[lid]
+            t = len(sc) // n_obs
+            for k in range(n_obs):
+                if len(self.lane[lid].sim_lane.prev_lane) == 0:
+                    t0, t1 = int(t * k), min(int(t * k + t), len(sc))
+                    obs.append(sum(sc[t0:t1]) / (t1 - t0))
+                else:
+                    obs.append(0)
+        return np.array(obs).astype(np.float32)
+
+    def step(self, action, differentiable):
+        self.steps += 1
+        self.queue_length.clear()
+        self.flux.clear()
+        self._simulate(action, differentiable)
+        obs = self.observe()
+        reward = self._reward(action)
+        info = {"img": []}
+        return obs, reward, self.steps >= self.config["duration"], info
+
+    def _simulate(self, action, differentiable):
+        self.time = 0
+        for _ in range(self.num_timestep):
+            self._simulate_step(action, differentiable)
+        return []
+
+    def _is_static(self, speed, differentiable):
+        """sigmoid(k (static_speed - speed)), k = 16 / |running mean of all (static_speed - speed) seen so far|, one
+        sample at a time in visiting order (reference _env.py:586-618); `speed` is a 1-D tensor of one lane."""
+        s0 = self.config["static_speed"]
+        if not differentiable:
+            return (speed < s0).float()
+        with th.no_grad():
+            means = self.is_static_rms.prefix_means((s0 - speed).detach().cpu().numpy())
+            k = th.as_tensor(16.0 / np.abs(means), dtype=th.float32, device=speed.device)
+        return th.sigmoid(th.clamp((s0 - speed) * k, -16.0, 16.0))
+
+    def _simulate_step(self, action, differentiable):
+        frame = self.time
+        sim = self.simulator
+        for lid in self.lane.keys():
+            sl = self.lane[lid].sim_lane
+            sim.lane_incoming[sl.id] = self.schedule[lid][frame] if len(sl.prev_lane) == 0 else -1
+            sim.lane_signal[sl.id] = self.lane_signal_info(lid, action, frame, differentiable)[1]
+        sim.macro_route = self.macro_route_schedule[frame]
+        dt = 1.0 / self.config["simulation_frequency"]
+        sim.forward(dt, differentiable)
+        self.time += 1
+        for lid in self.lane.keys():
+            sl = self.lane[lid].sim_lane
+            q = 0
+            if isinstance(sl, MacroLane):
+                r, _, u = sl.get_state_vector()
+                q = (self._is_static(u, differentiable) * (r * sl.cell_length / sim.vehicle_length)).sum()
+            elif isinstance(sl, MicroLane):
+                if sl.num_vehicle():
+                    _, v = sl.get_state_vector()
+                    q = self._is_static(v, differentiable).sum()
+            else:
+                raise ValueError()
+            self.queue_length.setdefault(lid, []).append((q ** 2.0) * dt)
+            self.flux.setdefault(lid, [])
+
+    def _reward(self, action):
+        reward = 0
+        for lid in self.lane.keys():
+            for x in self.queue_length[lid]:
+                reward = reward + self.reward_queue_c * x
+        return reward
+
+    # ---- signals -----------------------------------------------------------------------------------------------------
+    def lane_signal_info(self, lane_id, action, curr_frame, differentiable):
+        """(prev_signal, next_signal) of a lane (reference _env.py:885-962): within each signal phase the action value a
+        of the lane's intersection splits the phase: west-east green while progress < a, north-south green afterwards."""
+        frames = self.config["simulation_frequency"] * self.config["signal_length"]
+        sq = self.num_intersection ** 2
+        phase = min(curr_frame // frames, len(action) // sq - 1)
+        a = action[phase * sq + lane_id.row * self.num_intersection + lane_id.col]
+        if not isinstance(a, th.Tensor):
+            a = th.tensor(a)
+        progress = min((curr_frame % frames) / frames, 1.0)
+
+        def we():
+            return sigmoid(a - progress, constant=32) if differentiable else float(a > progress)
+
+        def ns():
+            return sigmoid(progress - a, constant=32) if differentiable else float(progress > a)
+
+        if lane_id.loc == "mid":
+            return (we() if lane_id.ploc in ("west", "east") else ns()), 1.0
+        if not lane_id.approaching:
+            return 1.0, 1.0
+        return 1.0, (we() if lane_id.loc in ("west", "east") else ns())

@@ -1,0 +1,81 @@
+"""The itscp environment (differentiable traffic-signal control) through the mirror classes on the GPU, against the
+reference's own runs (G8, tools/gen_goldens.py): lane table, schedules, reward, d reward / d action, per-step queues."""
+import os
+
+import numpy as np
+import pytest
+
+from util import TOL_GRAD, meta_of, rel_max
+
+pytestmark = pytest.mark.gpu
+
+
+def build_env(g, m):
+    from example.control.itscp._env import ItscpEnv
+    from example.control.itscp.problem import problem_1
+    from road.network.route import MacroRoute, MicroRoute
+    env = ItscpEnv()
+    env.schedule_callback = problem_1
+    for k, v in dict(num_intersection=m["num_intersection"], lane_length=m["lane_length"], num_lane=m["num_lane"],
+                     policy_length=m["policy_length"], signal_length=m["signal_length"], mode=m["mode"],
+                     speed_limit=m["speed_limit"], random_seed=m["seed"]).items():
+        env.config[k] = v
+    spawn = [MicroRoute([int(x) for x in r if x >= 0]) for r in g["spawn_routes"]]
+    cursor = {"i": 0}
+
+    def provider(lane_id):
+        # routes drawn at spawn time come from the recorded table; the ones drawn at reset are discarded by the reference
+        # as well (waiting vehicles only exist for source micro lanes)
+        if env.time == 0 and not getattr(env, "_armed", False):
+            return MicroRoute([lane_id])
+        r = spawn[cursor["i"]]
+        cursor["i"] += 1
+        return r
+    env.route_provider = provider
+    env.reset()
+    env._armed = True
+    return env
+
+
+@pytest.mark.parametrize("name", ["macro_small", "macro", "hybrid"])
+def test_itscp_rollout_matches_reference(cuda, golden_dir, name):
+    import torch
+    path = os.path.join(golden_dir, "itscp_%s.npz" % name)
+    if not os.path.exists(path):
+        pytest.skip("golden not generated")
+    if name == "hybrid" and not os.environ.get("DHTS_SLOW"):
+        pytest.skip("144 lanes x 600 steps through per-lane operator calls takes minutes; set DHTS_SLOW=1")
+    g = np.load(path)
+    m = meta_of(g)
+    env = build_env(g, m)
+    keys = list(env.lane.keys())
+    tab = g["lane_tab"]
+    # topology: same lanes in the same order with the same lengths, cell counts and connectivity
+    assert len(keys) == len(tab) and env.num_timestep == m["T"]
+    for i, k in enumerate(keys):
+        sl = env.lane[k].sim_lane
+        assert sl.id == i and float(sl.is_macro()) == tab[i, 1]
+        assert abs(sl.length - tab[i, 2]) <= 1e-12 * max(1.0, tab[i, 2])
+        assert getattr(sl, "num_cell", 0) == int(tab[i, 3])
+        assert "%s|%s|%d" % (k.loc, k.ploc, int(k.approaching)) == str(g["lane_str"][i])
+        assert (k.row, k.col, k.lane_id) == tuple(int(x) for x in tab[i, 5:8])
+    edges = sorted((a, b) for a in env.simulator.lane for b in env.simulator.lane[a].next_lane.keys())
+    assert edges == sorted(tuple(e) for e in g["edges"].tolist())
+    # host RNG parity: the schedule and the per-step macro routes are drawn in the reference's order
+    sched = np.array([env.schedule[k] for k in keys])
+    assert np.array_equal(sched, g["schedule"])
+    mr = -np.ones_like(g["macro_route"])
+    for t, r in enumerate(env.macro_route_schedule):
+        for a, b in r.next_lane_dict.items():
+            mr[t, a] = b
+    assert np.array_equal(mr, g["macro_route"])
+    # rollout
+    action = torch.tensor(g["action"], device=cuda, requires_grad=True)
+    env._simulate(action, True)
+    reward = env._reward(action)
+    reward.backward()
+    queue = np.array([[float(x) for x in env.queue_length[k]] for k in keys])
+    assert env.simulator.num_vehicle == m["n_vehicle_spawned"]
+    assert rel_max(queue, g["queue"]) <= 1e-4
+    assert abs(float(reward) - float(g["reward"])) <= 1e-4 * abs(float(g["reward"]))
+    assert rel_max(action.grad.cpu().numpy(), g["g_action"]) <= 5 * TOL_GRAD

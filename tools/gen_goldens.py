@@ -19,6 +19,8 @@ Golden sets:
   G5     idm_kat.npz         IDM.compute_acceleration + dIDM.compute_dEgo/dLeading
   G6     micro_rollout_*.npz dMicroLane rollouts with loss and gradients
   G7     hybrid_hybrid3.npz  macro -> micro -> macro network with spawn / hand-off events, loss and gradients
+  G8     itscp_*.npz         itscp environment (needs tools/ref_stubs for highway_env / gym / pygame): lane table,
+                             schedules, per-step macro routes, action -> reward, d reward / d action, per-step queues
 """
 import argparse
 import json
@@ -520,11 +522,86 @@ def gen_hybrid(name="hybrid3", N=10, T=500, dx=5.0, dt=0.01, um=30.0, seed=21):
         meta=meta(seed=seed, N=N, T=T, dx=dx, dt=dt, u_max=um))
 
 
+# ----------------------------------------------------------------------------------------------
+# G8: itscp environment (example/control/itscp): lane table, schedules, routes, reward and d reward / d action
+# ----------------------------------------------------------------------------------------------
+
+def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, action_kind):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_stubs"))
+    from example.control.itscp._env import ItscpEnv
+    from example.control.itscp.problem import problem_1
+    env = ItscpEnv()
+    env.schedule_callback = problem_1
+    env.render_eval = False
+    for k, v in dict(num_intersection=n_int, lane_length=lane_length, num_lane=n_lane, render=False, policy_length=sim_len,
+                     signal_length=sig_len, mode=mode, speed_limit=60.0, random_seed=seed).items():
+        env.config[k] = v
+    env.reset()
+    sim = env.simulator
+    keys = list(env.lane.keys())
+    nl = len(keys)
+    T = env.num_timestep
+    lane_tab = np.zeros((nl, 8), dtype=np.float64)      # sim id, is_macro, length, num_cell, cell_length, row, col, lane_id
+    lane_str = []
+    for i, k in enumerate(keys):
+        sl = env.lane[k].sim_lane
+        assert sl.id == i
+        lane_tab[i] = (sl.id, float(sl.is_macro()), sl.length, getattr(sl, "num_cell", 0), getattr(sl, "cell_length", 0.0),
+                       k.row, k.col, k.lane_id)
+        lane_str.append("%s|%s|%d" % (k.loc, k.ploc, int(k.approaching)))
+    edges = np.array([(a, b) for a in sim.lane for b in sim.lane[a].next_lane.keys()], dtype=np.int32)
+    sched = np.array([env.schedule[k] for k in keys], dtype=np.float64)
+    mroute = -np.ones((T, nl), dtype=np.int32)
+    for t, r in enumerate(env.macro_route_schedule):
+        for a, b in r.next_lane_dict.items():
+            mroute[t, a] = b
+    # routes drawn at spawn time, in call order
+    spawn_routes = []
+    orig = sim.create_random_route
+
+    def logged(lane_id):
+        r = orig(lane_id)
+        spawn_routes.append(list(r.route))
+        return r
+    sim.create_random_route = logged
+    A = env.action_size()
+    rng = np.random.default_rng(seed)
+    if action_kind == "half":
+        a0 = np.full(A, 0.5, dtype=np.float32)
+    else:
+        a0 = rng.uniform(0.1, 0.9, A).astype(np.float32)
+    action = th.tensor(a0, requires_grad=True)
+    t0 = time.time()
+    env.queue_length.clear()
+    env._simulate(action, True)
+    queue = np.array([[float(x) for x in env.queue_length[k]] for k in keys], dtype=np.float64)   # [lanes][T]
+    reward = env._reward(action)
+    t1 = time.time()
+    reward.backward()
+    t2 = time.time()
+    nveh = sim.num_vehicle
+    print("G8 %s: %d lanes, %d cells, T=%d, %d actions, %d vehicles spawned, reward %.6f, fwd %.0fs bwd %.0fs" % (
+        name, nl, int(lane_tab[:, 3].sum()), T, A, nveh, float(reward), t1 - t0, t2 - t1))
+    maxlen = max([len(r) for r in spawn_routes], default=1)
+    sr = -np.ones((len(spawn_routes), maxlen), dtype=np.int32)
+    for i, r in enumerate(spawn_routes):
+        sr[i, :len(r)] = r
+    np.savez_compressed(
+        os.path.join(OUT, "itscp_%s.npz" % name),
+        lane_tab=lane_tab, lane_str=np.array(lane_str), edges=edges, schedule=sched, macro_route=mroute, spawn_routes=sr,
+        action=a0, reward=np.float64(float(reward)), g_action=action.grad.numpy(), queue=queue,
+        meta=meta(seed=seed, mode=mode, num_intersection=n_int, num_lane=n_lane, lane_length=lane_length,
+                  policy_length=sim_len, signal_length=sig_len, speed_limit=60.0, cell_length=5.0, simulation_frequency=30,
+                  static_speed=0.2, vehicle_length=5.0, T=T, n_vehicle_spawned=nveh,
+                  ref_seconds_fwd=t1 - t0, ref_seconds_bwd=t2 - t1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="G1,G3,G4,G5,G6")
     ap.add_argument("--g4", default="c1,sanity,small,bench64,long")
     ap.add_argument("--g6", default="inv10,rand24,dense16,long")
+    ap.add_argument("--g8", default="macro_small,macro,hybrid")
     args = ap.parse_args()
     only = set(args.only.split(","))
     os.makedirs(OUT, exist_ok=True)
@@ -540,6 +617,14 @@ def main():
         gen_micro_rollouts(set(args.g6.split(",")))
     if "G7" in only:
         gen_hybrid()
+    if "G8" in only:                 # run_itscp_macro.sh / run_itscp_hybrid.sh flag sets (+ a small macro case)
+        which = set(args.g8.split(","))
+        if "macro_small" in which:
+            gen_itscp("macro_small", "macro", 1, 1, 10.0, 2, 1, seed=5, action_kind="rand")
+        if "macro" in which:
+            gen_itscp("macro", "macro", 1, 3, 30.0, 10, 2, seed=7, action_kind="rand")
+        if "hybrid" in which:
+            gen_itscp("hybrid", "hybrid", 3, 1, 5.0, 20, 4, seed=9, action_kind="rand")
 
 
 if __name__ == "__main__":
