@@ -1,0 +1,75 @@
+"""Flat tables describing a macro road network with signals (the itscp environment in `macro` mode) for the fused
+network kernels: lane geometry, per-lane signal kind, and per time step which neighbour feeds each ghost cell.
+
+Built on the host from plain arrays (lane cell counts / lengths, directed lane edges, per-step macro-route matching,
+inflow schedules); semantics follow ItscpRoadNetwork.setup_macro_boundary (reference example/control/itscp/
+_simulator.py:56-137) and RoadNetwork.get_macro_boundary (road/network/road_network.py:299-362).
+"""
+import numpy as np
+
+SIG_ALWAYS, SIG_WE, SIG_NS = 0, 1, 2
+
+
+class MacroNetworkTables:
+    def __init__(self, lane_ncell, lane_length, edges, sig_kind, inter, macro_route, schedule):
+        """lane_ncell [L] int, lane_length [L] float, edges [(a, b)] lane a feeds lane b, sig_kind / inter [L] int,
+        macro_route [T][L] int (successor chosen for lane l at step t, -1 = none), schedule [L][T] float."""
+        self.lane_ncell = np.asarray(lane_ncell, dtype=np.int32)
+        L = len(self.lane_ncell)
+        self.n_lanes = L
+        self.lane_off = np.concatenate([[0], np.cumsum(self.lane_ncell)[:-1]]).astype(np.int32)
+        self.n_cells = int(self.lane_ncell.sum())
+        self.lane_dx = (np.asarray(lane_length, dtype=np.float64) / self.lane_ncell).astype(np.float64)
+        self.sig_kind = np.asarray(sig_kind, dtype=np.int32)
+        self.inter = np.asarray(inter, dtype=np.int32)
+        macro_route = np.asarray(macro_route, dtype=np.int32)
+        T = macro_route.shape[0]
+        self.T = T
+        prev = [[] for _ in range(L)]
+        nxt = [[] for _ in range(L)]
+        for a, b in np.asarray(edges, dtype=np.int64).tolist():
+            nxt[a].append(b)
+            prev[b].append(a)
+        route_prev = -np.ones((T, L), dtype=np.int32)
+        tt, aa = np.nonzero(macro_route >= 0)
+        route_prev[tt, macro_route[tt, aa]] = aa
+        self.left_src = np.empty((T, L), dtype=np.int32)
+        self.left_gate = np.empty((T, L), dtype=np.int32)
+        self.right_src = np.empty((T, L), dtype=np.int32)
+        for l in range(L):
+            if len(prev[l]) == 0:
+                self.left_src[:, l] = -1                 # source lane: inflow schedule, always open
+                self.left_gate[:, l] = -2
+            else:
+                self.left_src[:, l] = prev[l][0] if len(prev[l]) == 1 else route_prev[:, l]
+                self.left_gate[:, l] = route_prev[:, l]  # -1: nobody routed into this lane at this step = red
+            if len(nxt[l]) == 0:
+                self.right_src[:, l] = -1                # sink lane: its own stored ghost
+            else:
+                self.right_src[:, l] = nxt[l][0] if len(nxt[l]) == 1 else macro_route[:, l]
+        assert (self.left_src[:, [len(p) > 0 for p in prev]] >= 0).all(), "a lane with several upstream lanes was left unmatched"
+        assert (self.right_src[:, [len(n) > 0 for n in nxt]] >= 0).all(), "a lane with several downstream lanes was left unmatched"
+        self.schedule = np.ascontiguousarray(np.asarray(schedule, dtype=np.float64).T)      # [T][L]
+        self.is_source = np.array([len(p) == 0 for p in prev])
+
+    @staticmethod
+    def from_env(env):
+        """From an example.control.itscp._env.ItscpEnv (after reset) in `macro` mode."""
+        keys = list(env.lane.keys())
+        lanes = [env.lane[k].sim_lane for k in keys]
+        assert all(sl.is_macro() for sl in lanes), "macro mode only"
+        kinds = []
+        for k in keys:
+            if k.loc == "mid" or not k.approaching:
+                kinds.append(SIG_ALWAYS)
+            else:
+                kinds.append(SIG_WE if k.loc in ("west", "east") else SIG_NS)
+        edges = [(a, b) for a in env.simulator.lane for b in env.simulator.lane[a].next_lane.keys()]
+        T, L = env.num_timestep, len(keys)
+        mr = -np.ones((T, L), dtype=np.int32)
+        for t, r in enumerate(env.macro_route_schedule):
+            for a, b in r.next_lane_dict.items():
+                mr[t, a] = b
+        return MacroNetworkTables([sl.num_cell for sl in lanes], [sl.length for sl in lanes], edges, kinds,
+                                  [k.row * env.num_intersection + k.col for k in keys], mr,
+                                  [env.schedule[k] for k in keys])

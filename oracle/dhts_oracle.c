@@ -644,3 +644,252 @@ void oracle_micro_rollout_bwd(int L, int V, int T, const float *tape,
         free(buf);
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * macro road network with differentiable signals (itscp `macro` mode)
+ * ---------------------------------------------------------------------------------------------- */
+static float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+/* dmath/operation.py:3-30: sigmoid(clamp(value * constant, -16, 16)), float32 */
+static float soft_switch(float value, float constant) {
+    float z = value * constant;
+    z = z < -16.f ? -16.f : (z > 16.f ? 16.f : z);
+    return sigmoid_f(z);
+}
+/* d soft_switch / d value (0 outside the clamp) */
+static float soft_switch_grad(float value, float constant) {
+    float z = value * constant;
+    if (z < -16.f || z > 16.f) return 0.f;
+    float s = sigmoid_f(z);
+    return s * (1.f - s) * constant;
+}
+
+typedef struct {            /* per step: phase signals of every intersection and their inputs */
+    float we, ns, a, prog;
+    int a_index;
+} net_signal;
+
+static void net_signals(const oracle_net_desc *d, const float *action, int t, net_signal *sg) {
+    /* ItscpEnv.lane_signal_info, _env.py:885-962 */
+    int F = d->frames_per_phase, sq = d->n_inter_sq;
+    int phase = t / F;
+    int last = d->n_action / sq - 1;
+    if (phase > last) phase = last;
+    double pr = (double)(t % F) / (double)F;
+    if (pr > 1.0) pr = 1.0;
+    for (int k = 0; k < sq; k++) {
+        net_signal *s = &sg[k];
+        s->a_index = phase * sq + k;
+        s->a = action[s->a_index];
+        s->prog = (float)pr;
+        s->we = soft_switch(s->a - s->prog, 32.f);
+        s->ns = soft_switch(s->prog - s->a, 32.f);
+    }
+}
+static float lane_signal(const net_signal *sg, int kind, int inter) {
+    return kind == 0 ? 1.f : (kind == 1 ? sg[inter].we : sg[inter].ns);
+}
+
+int oracle_net_macro_fwd(const oracle_net_desc *d, const int *lane_ncell, const int *lane_off, const double *lane_dx,
+                         const int *sig_kind, const int *inter, const int *left_src, const int *left_gate,
+                         const int *right_src, const double *schedule, const float *action,
+                         float *hist, float *tape, float *kc, float *queue, double *reward) {
+    const int L = d->n_lanes, C = d->n_cells, T = d->T;
+    const float um = (float)d->u_max;
+    int rc = ORACLE_OK;
+    int maxn = 0;
+    for (int l = 0; l < L; l++) if (lane_ncell[l] > maxn) maxn = lane_ncell[l];
+    float *pad = (float *)malloc(sizeof(float) * 8 * (size_t)(maxn + 2));
+    float *own_r = (float *)malloc(sizeof(float) * 2 * (size_t)L);      /* stored downstream ghost (r, u) of sink lanes */
+    net_signal *sg = (net_signal *)malloc(sizeof(net_signal) * (size_t)d->n_inter_sq);
+    double *samples = (double *)malloc(sizeof(double) * ((size_t)T * C + 1));   /* RunningMean data */
+    size_t n_samples = 0;
+    double csum_all = 0.;                 /* sum of all samples; window handled with the stored history */
+    const size_t window = 100000;
+    /* initial state: FullQ(speed_limit): r = y = 0, u = u_eq = u_max */
+    for (int c = 0; c < C; c++) { hist[0 * C + c] = 0.f; hist[1 * C + c] = 0.f; hist[2 * C + c] = um; hist[3 * C + c] = um; }
+    for (int l = 0; l < L; l++) { own_r[2 * l] = 0.f; own_r[2 * l + 1] = um; }
+    for (int t = 0; t < T; t++) {
+        const float *cur = hist + (size_t)t * 4 * C;
+        float *nxt = hist + (size_t)(t + 1) * 4 * C;
+        net_signals(d, action, t, sg);
+        for (int l = 0; l < L; l++) {
+            const int n = lane_ncell[l], off = lane_off[l];
+            float *r = pad, *y = pad + (n + 2), *u = pad + 2 * (n + 2), *q = pad + 3 * (n + 2);
+            float *nr = pad + 4 * (n + 2), *ny = nr + n, *nu = ny + n, *nq = nu + n;
+            for (int i = 0; i < n; i++) { r[i + 1] = cur[off + i]; y[i + 1] = cur[C + off + i]; u[i + 1] = cur[2 * C + off + i]; q[i + 1] = cur[3 * C + off + i]; }
+            /* upstream ghost, _simulator.py:56-108 */
+            const int ls = left_src[(size_t)t * L + l], lg = left_gate[(size_t)t * L + l];
+            if (ls < 0) {               /* source lane: Python floats all the way (r = schedule, u = u_eq(r), signal 1.0) */
+                double gr = schedule[(size_t)t * L + l];
+                double gu = arz_u_eq(gr, d->u_max);
+                double fr = gr * 1.0 + 0 * (1.0 - 1.0), fu = gu * 1.0 + d->u_max * (1.0 - 1.0);
+                r[0] = (float)fr; u[0] = (float)fu;
+                y[0] = (float)arz_y(fr, fu, d->u_max); q[0] = (float)arz_u_eq(fr, d->u_max);
+            } else {
+                const int sl = ls, last = lane_off[sl] + lane_ncell[sl] - 1;
+                float gr = cur[last], gu = cur[2 * C + last];
+                float s = (lg == -1) ? 0.f : ((lg == -2) ? 1.f : lane_signal(sg, sig_kind[lg], inter[lg]));
+                float fr = gr * s + 0.f * (1.0f - s);
+                float fu = gu * s + um * (1.0f - s);
+                r[0] = fr; u[0] = fu;
+                oracle_arz_from_r_u(fr, fu, um, &y[0], &q[0]);
+            }
+            /* downstream ghost, _simulator.py:110-137 */
+            {
+                const int rs = right_src[(size_t)t * L + l];
+                float gr, gu;
+                if (rs < 0) { gr = own_r[2 * l]; gu = own_r[2 * l + 1]; }
+                else { gr = cur[lane_off[rs]]; gu = cur[2 * C + lane_off[rs]]; }
+                float s2 = soft_switch(lane_signal(sg, sig_kind[l], inter[l]) - 0.5f, 32.f);
+                float fr = s2 * gr + (1.0f - s2) * 1.0f;
+                float fu = s2 * gu + (1.0f - s2) * 0.0f;
+                r[n + 1] = fr; u[n + 1] = fu;
+                oracle_arz_from_r_u(fr, fu, um, &y[n + 1], &q[n + 1]);
+                own_r[2 * l] = fr; own_r[2 * l + 1] = fu;      /* set_rightmost_cell overwrites the stored ghost */
+            }
+            int e = oracle_macro_step(n, r, y, u, q, d->dt, lane_dx[l], d->u_max, nr, ny, nu, nq,
+                                      tape + ((size_t)t * C + off) * 12, NULL, NULL, NULL);
+            if (e && !rc) rc = e;
+            for (int i = 0; i < n; i++) { nxt[off + i] = nr[i]; nxt[C + off + i] = ny[i]; nxt[2 * C + off + i] = nu[i]; nxt[3 * C + off + i] = nq[i]; }
+        }
+        /* queue-length loss on the committed state, _env.py:664-742 with :586-618 */
+        for (int l = 0; l < L; l++) {
+            const int n = lane_ncell[l], off = lane_off[l];
+            float qlen = 0.f;
+            for (int i = 0; i < n; i++) {
+                const float rr = nxt[off + i], uu = nxt[2 * C + off + i];
+                const float x = (float)d->static_speed - uu;
+                samples[n_samples++] = (double)x;
+                csum_all += (double)x;
+                double mean;
+                if (n_samples <= window) mean = csum_all / (double)n_samples;
+                else {
+                    /* sum of the last `window` samples */
+                    double s = 0.;
+                    for (size_t j = n_samples - window; j < n_samples; j++) s += samples[j];
+                    mean = s / (double)window;
+                }
+                const float k = 16.f / fabsf((float)mean);
+                kc[(size_t)t * C + off + i] = k;
+                const float is_static = soft_switch(x, k);
+                const float nveh = rr * (float)lane_dx[l] / (float)d->vehicle_length;
+                qlen = qlen + is_static * nveh;
+            }
+            queue[(size_t)t * L + l] = (qlen * qlen) * (float)d->dt;
+        }
+    }
+    /* _reward, _env.py:770-797: lanes outer, steps inner, float32 accumulation */
+    float rew = 0.f;
+    for (int l = 0; l < L; l++)
+        for (int t = 0; t < T; t++) rew = rew + (-1.0f) * queue[(size_t)t * L + l];
+    *reward = (double)rew;
+    free(pad); free(own_r); free(sg); free(samples);
+    return rc;
+}
+
+void oracle_net_macro_bwd(const oracle_net_desc *d, const int *lane_ncell, const int *lane_off, const double *lane_dx,
+                          const int *sig_kind, const int *inter, const int *left_src, const int *left_gate,
+                          const int *right_src, const double *schedule, const float *action,
+                          const float *hist, const float *tape, const float *kc, const float *queue, float *g_action) {
+    (void)schedule; (void)queue;
+    const int L = d->n_lanes, C = d->n_cells, T = d->T;
+    const float um = (float)d->u_max;
+    int maxn = 0;
+    for (int l = 0; l < L; l++) if (lane_ncell[l] > maxn) maxn = lane_ncell[l];
+    float *g = (float *)calloc((size_t)2 * C, sizeof(float));          /* cotangent of (r, y) of the state at time t+1 */
+    float *gp = (float *)calloc((size_t)2 * C, sizeof(float));         /* ... at time t */
+    float *buf = (float *)malloc(sizeof(float) * 4 * (size_t)(maxn + 2));
+    float *own_r = (float *)malloc(sizeof(float) * 2 * (size_t)L * (size_t)(T + 1));   /* stored sink ghosts per step */
+    net_signal *sg = (net_signal *)malloc(sizeof(net_signal) * (size_t)d->n_inter_sq);
+    double *ga = (double *)calloc((size_t)d->n_action, sizeof(double));
+    /* replay the stored downstream ghosts of sink lanes (they only depend on themselves) */
+    for (int l = 0; l < L; l++) { own_r[2 * l] = 0.f; own_r[2 * l + 1] = um; }
+    for (int t = 0; t < T; t++) {
+        net_signals(d, action, t, sg);
+        for (int l = 0; l < L; l++) {
+            const int rs = right_src[(size_t)t * L + l];
+            float *o = own_r + (size_t)t * 2 * L, *on = own_r + (size_t)(t + 1) * 2 * L;
+            const float *cur = hist + (size_t)t * 4 * C;
+            float gr = rs < 0 ? o[2 * l] : cur[lane_off[rs]], gu = rs < 0 ? o[2 * l + 1] : cur[2 * C + lane_off[rs]];
+            float s2 = soft_switch(lane_signal(sg, sig_kind[l], inter[l]) - 0.5f, 32.f);
+            on[2 * l] = s2 * gr + (1.0f - s2) * 1.0f;
+            on[2 * l + 1] = s2 * gu + (1.0f - s2) * 0.0f;
+        }
+    }
+    for (int t = T - 1; t >= 0; t--) {
+        const float *cur = hist + (size_t)t * 4 * C, *nxt = hist + (size_t)(t + 1) * 4 * C;
+        net_signals(d, action, t, sg);
+        /* (a) loss taps on the state after step t: reward = - sum_l q_l^2 dt */
+        for (int l = 0; l < L; l++) {
+            const int n = lane_ncell[l], off = lane_off[l];
+            float qlen = 0.f;
+            for (int i = 0; i < n; i++) {
+                const float x = (float)d->static_speed - nxt[2 * C + off + i];
+                qlen += soft_switch(x, kc[(size_t)t * C + off + i]) * (nxt[off + i] * (float)lane_dx[l] / (float)d->vehicle_length);
+            }
+            const float g_q = -1.0f * (float)d->dt * 2.f * qlen;
+            for (int i = 0; i < n; i++) {
+                const float rr = nxt[off + i], yy = nxt[C + off + i], uu = nxt[2 * C + off + i];
+                const float k = kc[(size_t)t * C + off + i];
+                const float x = (float)d->static_speed - uu;
+                const float is_static = soft_switch(x, k);
+                const float nveh = rr * (float)lane_dx[l] / (float)d->vehicle_length;
+                g[off + i] += g_q * is_static * ((float)lane_dx[l] / (float)d->vehicle_length);
+                const float g_u = g_q * nveh * (-soft_switch_grad(x, k));
+                glue_u_bwd(rr, yy, um, g_u, &g[off + i], &g[C + off + i]);
+            }
+        }
+        /* (b) lane steps backwards, (c) ghost cotangents to neighbours / signals / action */
+        memset(gp, 0, sizeof(float) * 2 * (size_t)C);
+        for (int l = 0; l < L; l++) {
+            const int n = lane_ncell[l], off = lane_off[l];
+            float *gr_ = buf, *gy_ = buf + (n + 2);
+            oracle_macro_step_bwd(n, tape + ((size_t)t * C + off) * 12, g + off, g + C + off, gr_, gy_);
+            for (int i = 0; i < n; i++) { gp[off + i] += gr_[i + 1]; gp[C + off + i] += gy_[i + 1]; }
+            /* upstream ghost */
+            const int ls = left_src[(size_t)t * L + l], lg = left_gate[(size_t)t * L + l];
+            if (ls >= 0) {
+                const int last = lane_off[ls] + lane_ncell[ls] - 1;
+                const float grn_r = cur[last], grn_u = cur[2 * C + last];
+                const float s = (lg == -1) ? 0.f : ((lg == -2) ? 1.f : lane_signal(sg, sig_kind[lg], inter[lg]));
+                const float fr = grn_r * s + 0.f * (1.0f - s), fu = grn_u * s + um * (1.0f - s);
+                float g_fr = gr_[0], g_fu = 0.f;
+                glue_y_bwd(fr, fu, um, gy_[0], &g_fr, &g_fu);
+                gp[last] += g_fr * s;
+                glue_u_bwd(cur[last], cur[C + last], um, g_fu * s, &gp[last], &gp[C + last]);
+                if (lg >= 0 && sig_kind[lg] != 0) {
+                    const float g_s = g_fr * grn_r + g_fu * (grn_u - um);
+                    const net_signal *q = &sg[inter[lg]];
+                    const float dsig = sig_kind[lg] == 1 ? soft_switch_grad(q->a - q->prog, 32.f) : -soft_switch_grad(q->prog - q->a, 32.f);
+                    ga[q->a_index] += (double)(g_s * dsig);
+                }
+            }
+            /* downstream ghost */
+            {
+                const int rs = right_src[(size_t)t * L + l];
+                const float *o = own_r + (size_t)t * 2 * L;
+                const float grn_r = rs < 0 ? o[2 * l] : cur[lane_off[rs]], grn_u = rs < 0 ? o[2 * l + 1] : cur[2 * C + lane_off[rs]];
+                const float sig = lane_signal(sg, sig_kind[l], inter[l]);
+                const float s2 = soft_switch(sig - 0.5f, 32.f);
+                const float fr = s2 * grn_r + (1.0f - s2) * 1.0f, fu = s2 * grn_u + (1.0f - s2) * 0.0f;
+                float g_fr = gr_[n + 1], g_fu = 0.f;
+                glue_y_bwd(fr, fu, um, gy_[n + 1], &g_fr, &g_fu);
+                if (rs >= 0) {
+                    const int first = lane_off[rs];
+                    gp[first] += g_fr * s2;
+                    glue_u_bwd(cur[first], cur[C + first], um, g_fu * s2, &gp[first], &gp[C + first]);
+                }
+                if (sig_kind[l] != 0) {
+                    const float g_s2 = g_fr * (grn_r - 1.0f) + g_fu * grn_u;
+                    const float g_sig = g_s2 * soft_switch_grad(sig - 0.5f, 32.f);
+                    const net_signal *q = &sg[inter[l]];
+                    const float dsig = sig_kind[l] == 1 ? soft_switch_grad(q->a - q->prog, 32.f) : -soft_switch_grad(q->prog - q->a, 32.f);
+                    ga[q->a_index] += (double)(g_sig * dsig);
+                }
+            }
+        }
+        float *tmp = g; g = gp; gp = tmp;
+    }
+    for (int k = 0; k < d->n_action; k++) g_action[k] = (float)ga[k];
+    free(g); free(gp); free(buf); free(own_r); free(sg); free(ga);
+}

@@ -109,6 +109,38 @@ void oracle_micro_rollout_bwd(int L, int V, int T, const float *tape,
                               const float *g_pT, const float *g_vT, const float *gh_p, const float *gh_v,
                               float *g_p0, float *g_v0, float *g_head);
 
+
+/* ---- macro road NETWORK with differentiable signals (itscp `macro` mode) ----------------------------------------
+ * Restates what ItscpEnv._simulate + ItscpRoadNetwork.forward do for a network of dMacroLanes
+ * (example/control/itscp/_env.py:620-768, 885-962; _simulator.py:56-137; road/network/road_network.py:79-111,299-387):
+ * per step  signals from the action -> ghost cells of every lane from the time-n state of its neighbours (Jacobi),
+ * blended between green and red values -> one ARZ step per lane -> queue-length loss with the running-mean-scaled
+ * sigmoid (_env.py:586-618, example/common/rms.py).
+ * Topology and schedules come as tables (built by the caller from the environment):
+ *   lane_ncell, lane_off [L] (cells and first-cell offset), lane_dx [L] double, sig_kind [L] (0 = always green,
+ *   1 = west-east phase, 2 = north-south phase), inter [L] (intersection index), per step t and lane l:
+ *   left_src  (lane whose LAST cell is the green upstream ghost; -1 = source lane: r = schedule, u = u_eq(r)),
+ *   left_gate (lane whose signal gates the upstream ghost; -1 = red (0.0); -2 = always 1.0),
+ *   right_src (lane whose FIRST cell is the green downstream ghost; -1 = the lane's own stored ghost),
+ *   schedule [T][L] double (inflow density of source lanes).
+ * All lanes start empty (r = 0, y = 0, u = u_eq = u_max).  Work arrays are caller-allocated:
+ *   hist [T+1][4][C] float (r, y, u, u_eq after t steps), tape [T][C][12], kc [T][C] float (sigmoid constants),
+ *   queue [T][L] float (per-lane loss terms q^2 dt).  Returns reward = - sum queue in *reward (float32 accumulation
+ *   order of the reference: lanes outer, steps inner).  rc = ORACLE_OK / ORACLE_ERR_CFL. */
+typedef struct oracle_net_desc {
+    int n_lanes, n_cells, T, n_inter_sq, frames_per_phase, n_action;
+    double dt, u_max, static_speed, vehicle_length;
+} oracle_net_desc;
+int oracle_net_macro_fwd(const oracle_net_desc *d, const int *lane_ncell, const int *lane_off, const double *lane_dx,
+                         const int *sig_kind, const int *inter, const int *left_src, const int *left_gate,
+                         const int *right_src, const double *schedule, const float *action,
+                         float *hist, float *tape, float *kc, float *queue, double *reward);
+/* d reward / d action [n_action] */
+void oracle_net_macro_bwd(const oracle_net_desc *d, const int *lane_ncell, const int *lane_off, const double *lane_dx,
+                          const int *sig_kind, const int *inter, const int *left_src, const int *left_gate,
+                          const int *right_src, const double *schedule, const float *action,
+                          const float *hist, const float *tape, const float *kc, const float *queue, float *g_action);
+
 #ifdef __cplusplus
 }
 #endif

@@ -207,3 +207,38 @@ def micro_rollout_bwd(fwd, g_pT=None, g_vT=None, gh_p=None, gh_v=None):
     lib().oracle_micro_rollout_bwd(L, V, fwd["T"], _p(fwd["tape"]), _p(g_pT), _p(g_vT), _p(gh_p), _p(gh_v),
                                    _p(g_p0), _p(g_v0), _p(g_head))
     return dict(g_p0=g_p0, g_v0=g_v0, g_head=g_head)
+
+
+# ---- macro road network with signals (itscp `macro` mode) ---------------------------------------------------
+class NetDesc(C.Structure):
+    _fields_ = [("n_lanes", C.c_int), ("n_cells", C.c_int), ("T", C.c_int), ("n_inter_sq", C.c_int),
+                ("frames_per_phase", C.c_int), ("n_action", C.c_int), ("dt", C.c_double), ("u_max", C.c_double),
+                ("static_speed", C.c_double), ("vehicle_length", C.c_double)]
+
+
+def net_macro(tab, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0, want_grad=True):
+    """tab: dhts.network.MacroNetworkTables (plain numpy tables).  Returns reward, queue [T][L], hist, g_action."""
+    l = lib()
+    l.oracle_net_macro_fwd.argtypes = [C.POINTER(NetDesc)] + [C.c_void_p] * 15
+    l.oracle_net_macro_bwd.argtypes = [C.POINTER(NetDesc)] + [C.c_void_p] * 15
+    action = _f32(action)
+    T, L, Cn = tab.T, tab.n_lanes, tab.n_cells
+    d = NetDesc(L, Cn, T, int(n_inter_sq), int(frames_per_phase), len(action), float(dt), float(u_max), float(static_speed),
+                float(vehicle_length))
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)     # noqa: E731
+    ncell, off, dx = i32(tab.lane_ncell), i32(tab.lane_off), _f64(tab.lane_dx)
+    kind, inter = i32(tab.sig_kind), i32(tab.inter)
+    ls, lg, rs, sched = i32(tab.left_src), i32(tab.left_gate), i32(tab.right_src), _f64(tab.schedule)
+    hist = np.zeros((T + 1, 4, Cn), np.float32)
+    tape = np.zeros((T, Cn, 12), np.float32)
+    kc = np.zeros((T, Cn), np.float32)
+    queue = np.zeros((T, L), np.float32)
+    reward = C.c_double(0)
+    args = [_p(ncell), _p(off), _p(dx), _p(kind), _p(inter), _p(ls), _p(lg), _p(rs), _p(sched), _p(action)]
+    rc = l.oracle_net_macro_fwd(C.byref(d), *args, _p(hist), _p(tape), _p(kc), _p(queue), C.addressof(reward))
+    out = dict(rc=rc, reward=reward.value, queue=queue, hist=hist, kc=kc)
+    if want_grad:
+        g = np.zeros(len(action), np.float32)
+        l.oracle_net_macro_bwd(C.byref(d), *args, _p(hist), _p(tape), _p(kc), _p(queue), _p(g))
+        out["g_action"] = g
+    return out

@@ -129,3 +129,28 @@ def test_collision_reported(oracle):
     o = oracle.micro_step(np.array([0.0, 3.0], np.float32), np.array([10.0, 1.0], np.float32), par, 1000.0, 0.0, 0.01)
     assert o["rc"] == oracle.ERR_COLLISION and o["err_index"] == 0
     assert np.all(np.isfinite(o["np"])) and np.all(np.isfinite(o["nv"]))
+
+
+# ---- G8: macro road network with signals (itscp `macro` mode) ---------------------------------------------------------
+def itscp_tables(g):
+    from dhts.network import SIG_ALWAYS, SIG_NS, SIG_WE, MacroNetworkTables
+    m = meta_of(g)
+    tab = g["lane_tab"]
+    kinds = []
+    for s in g["lane_str"]:
+        loc, _, app = str(s).split("|")
+        kinds.append(SIG_ALWAYS if (loc == "mid" or app == "0") else (SIG_WE if loc in ("west", "east") else SIG_NS))
+    inter = (tab[:, 5] * m["num_intersection"] + tab[:, 6]).astype(int)
+    return MacroNetworkTables(tab[:, 3].astype(int), tab[:, 2], g["edges"], kinds, inter, g["macro_route"], g["schedule"]), m
+
+
+@pytest.mark.parametrize("name", ["macro_small", "macro"])
+def test_itscp_macro_network(oracle, golden_dir, name):
+    g = load(golden_dir, "itscp_%s.npz" % name)
+    t, m = itscp_tables(g)
+    o = oracle.net_macro(t, g["action"], m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"],
+                         1.0 / m["simulation_frequency"], m["speed_limit"], m["static_speed"], m["vehicle_length"])
+    assert o["rc"] == 0
+    assert rel_max(o["queue"].T, g["queue"]) <= TOL_STATE
+    assert abs(o["reward"] - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+    assert rel_max(o["g_action"], g["g_action"]) <= TOL_GRAD
