@@ -23,6 +23,18 @@ class MacroDesc(C.Structure):
                 ("u_max", C.c_double)]
 
 
+class NetDesc(C.Structure):
+    _fields_ = [("n_replicas", C.c_int32), ("n_lanes", C.c_int32), ("n_cells", C.c_int32), ("n_steps", C.c_int32),
+                ("n_inter_sq", C.c_int32), ("frames_per_phase", C.c_int32), ("n_action", C.c_int32),
+                ("dt", C.c_double), ("u_max", C.c_double), ("static_speed", C.c_double), ("vehicle_length", C.c_double)]
+
+
+class NetTables(C.Structure):
+    _fields_ = [("lane_ncell", C.c_void_p), ("lane_off", C.c_void_p), ("sig_kind", C.c_void_p), ("inter", C.c_void_p),
+                ("lane_dx", C.c_void_p), ("left_src", C.c_void_p), ("left_gate", C.c_void_p), ("right_src", C.c_void_p),
+                ("schedule", C.c_void_p), ("replica_stride", C.c_int64)]
+
+
 class MicroDesc(C.Structure):
     _fields_ = [("n_lanes", C.c_int32), ("capacity", C.c_int32), ("dt", C.c_double)]
 
@@ -44,6 +56,10 @@ SIGNATURES = {
     "dhts_macro_rollout_bwd": (C.c_int, [C.POINTER(MacroDesc), C.c_int] + [_P] * 9),
     "dhts_macro_step_fwd": (C.c_int, [C.POINTER(MacroDesc)] + [_P] * 12),
     "dhts_macro_step_bwd": (C.c_int, [C.POINTER(MacroDesc)] + [_P] * 8),
+    "dhts_net_macro_hist_bytes": (C.c_size_t, [C.POINTER(NetDesc)]),
+    "dhts_net_macro_tape_bytes": (C.c_size_t, [C.POINTER(NetDesc)]),
+    "dhts_net_macro_rollout_fwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetTables)] + [_P] * 8),
+    "dhts_net_macro_rollout_bwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetTables)] + [_P] * 9),
     "dhts_micro_tape_bytes": (C.c_size_t, [C.POINTER(MicroDesc), C.c_int]),
     "dhts_micro_rollout_fwd": (C.c_int, [C.POINTER(MicroDesc), C.c_int] + [_P] * 11),
     "dhts_micro_rollout_bwd": (C.c_int, [C.POINTER(MicroDesc), C.c_int] + [_P] * 10),

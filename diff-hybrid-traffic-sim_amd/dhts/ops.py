@@ -316,3 +316,79 @@ def idm_batch(inp, variant=0):
           "dhts_idm_batch")
     return dict(next_p=nxt[0], next_v=nxt[1], dEgo=dE.t().reshape(n, 2, 2), dLeading=dLd.t().reshape(n, 2, 2),
                 collided=col.bool(), acc=acs[0], sstar=acs[1], clipped_acc=clips[0].bool(), clipped_spacing=clips[1].bool())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# macro road network with differentiable signals (itscp `macro` mode), replica batch
+# ---------------------------------------------------------------------------------------------------------
+class DeviceNetTables:
+    """dhts.network.MacroNetworkTables uploaded once; `tables` may be one MacroNetworkTables (shared by all replicas)
+    or a list of them (one per replica: same topology, own schedules / per-step routes)."""
+
+    def __init__(self, tables, device):
+        import numpy as np
+        many = isinstance(tables, (list, tuple))
+        first = tables[0] if many else tables
+        self.n_lanes, self.n_cells, self.T = first.n_lanes, first.n_cells, first.T
+        self.n_replica_tables = len(tables) if many else 0
+        up = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=device)    # noqa: E731
+        self.lane_ncell, self.lane_off = up(first.lane_ncell, torch.int32), up(first.lane_off, torch.int32)
+        self.sig_kind, self.inter = up(first.sig_kind, torch.int32), up(first.inter, torch.int32)
+        self.lane_dx = up(first.lane_dx, torch.float64)
+        stack = (lambda name: np.stack([getattr(t, name) for t in tables])) if many else (lambda name: getattr(first, name))
+        self.left_src, self.left_gate = up(stack("left_src"), torch.int32), up(stack("left_gate"), torch.int32)
+        self.right_src, self.schedule = up(stack("right_src"), torch.int32), up(stack("schedule"), torch.float64)
+        self.c = _lib.NetTables(self.lane_ncell.data_ptr(), self.lane_off.data_ptr(), self.sig_kind.data_ptr(),
+                                self.inter.data_ptr(), self.lane_dx.data_ptr(), self.left_src.data_ptr(),
+                                self.left_gate.data_ptr(), self.right_src.data_ptr(), self.schedule.data_ptr(),
+                                self.T * self.n_lanes if many else 0)
+
+
+class NetMacroRollout(torch.autograd.Function):
+    """action [R][A] -> reward [R] of R replicas of a signalised macro network (ItscpEnv.step(action, True) of the
+    reference in `macro` mode, reward = - sum of squared queue lengths); also returns the per-step queue terms."""
+
+    @staticmethod
+    def forward(ctx, action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed, vehicle_length):
+        a = _f32c(action.detach(), "action")
+        R, A = a.shape
+        if dev_tables.n_replica_tables not in (0, R):
+            raise ValueError("per-replica tables must match the number of replicas")
+        d = _lib.NetDesc(R, dev_tables.n_lanes, dev_tables.n_cells, dev_tables.T, int(n_inter_sq), int(frames_per_phase), A,
+                         float(dt), float(u_max), float(static_speed), float(vehicle_length))
+        lib = _lib.lib()
+        hist_n, tape_n = lib.dhts_net_macro_hist_bytes(C.byref(d)) // 4, lib.dhts_net_macro_tape_bytes(C.byref(d)) // 4
+        if hist_n == 0:
+            raise ValueError("unsupported network size (need steps * cells <= 100000)")
+        dev = a.device
+        hist = torch.empty(hist_n, dtype=torch.float32, device=dev)
+        tape = torch.empty(tape_n, dtype=torch.float32, device=dev)
+        kc = torch.empty(R, dev_tables.T, dev_tables.n_cells, dtype=torch.float32, device=dev)
+        queue = torch.empty(R, dev_tables.T, dev_tables.n_lanes, dtype=torch.float32, device=dev)
+        reward = torch.empty(R, dtype=torch.float32, device=dev)
+        err = new_error_record(dev)
+        check(lib.dhts_net_macro_rollout_fwd(C.byref(d), C.byref(dev_tables.c), _ptr(a), _ptr(hist), _ptr(tape), _ptr(kc),
+                                             _ptr(queue), _ptr(reward), _ptr(err), _stream()), "dhts_net_macro_rollout_fwd")
+        raise_on_fault(err)
+        ctx.d, ctx.tables = d, dev_tables
+        ctx.save_for_backward(a, hist, tape, kc)
+        ctx.mark_non_differentiable(queue)
+        return reward, queue
+
+    @staticmethod
+    def backward(ctx, g_reward, _g_queue):
+        a, hist, tape, kc = ctx.saved_tensors
+        d = ctx.d
+        g_action = torch.empty_like(a)
+        ws = torch.empty(d.n_replicas * (d.n_steps + 1) * 2 * d.n_lanes, dtype=torch.float32, device=a.device)
+        err = new_error_record(a.device)
+        check(_lib.lib().dhts_net_macro_rollout_bwd(C.byref(d), C.byref(ctx.tables.c), _ptr(a), _ptr(hist), _ptr(tape), _ptr(kc),
+                                                    _ptr(g_reward.contiguous().float()), _ptr(g_action), _ptr(ws), _ptr(err),
+                                                    _stream()), "dhts_net_macro_rollout_bwd")
+        raise_on_fault(err)
+        return g_action, None, None, None, None, None, None, None
+
+
+def net_macro_rollout(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0):
+    return NetMacroRollout.apply(action, dev_tables, int(n_inter_sq), int(frames_per_phase), float(dt), float(u_max),
+                                 float(static_speed), float(vehicle_length))

@@ -194,6 +194,40 @@ int dhts_micro_step_bwd(const dhts_micro_desc *d, const float *tape, const int32
                         const float *g_p, const float *g_v,
                         float *g_p_out, float *g_v_out, double *g_head, dhts_error *err, void *stream);
 
+
+/* ---- macro road network with differentiable signals (itscp `macro` mode) -------------------------------------------
+ * One fused rollout of R independent replicas of a signalised network of ARZ lanes: replaces, per replica, what
+ * ItscpEnv._simulate does with ItscpRoadNetwork.forward (example/control/itscp/_env.py:620-768, 885-962;
+ * _simulator.py:56-137; road/network/road_network.py:79-111, 299-387) and ItscpEnv._reward (_env.py:770-797):
+ * per step  signals from the action -> ghost cells of every lane from its neighbours' time-n edge cells, blended between
+ * green and red values -> one ARZ step per lane -> queue-length loss (running-mean-scaled sigmoid, _env.py:586-618).
+ * Lanes start empty.  Tables (device pointers) are built on the host (dhts/network.py):
+ *   lane_ncell, lane_off, sig_kind (0 always green, 1 west-east phase, 2 north-south phase), inter [L] int32; lane_dx [L]
+ *   DOUBLE; left_src / left_gate / right_src [T][L] int32 and schedule [T][L] DOUBLE, per replica when replica_stride
+ *   (elements between replicas) is non-zero, else shared.  Limits: T * n_cells <= 100000 (the loss' running-mean window).
+ */
+typedef struct dhts_net_desc {
+    int32_t n_replicas, n_lanes, n_cells, n_steps, n_inter_sq, frames_per_phase, n_action;
+    double dt, u_max, static_speed, vehicle_length;
+} dhts_net_desc;
+typedef struct dhts_net_tables {
+    const int32_t *lane_ncell, *lane_off, *sig_kind, *inter;
+    const double *lane_dx;
+    const int32_t *left_src, *left_gate, *right_src;
+    const double *schedule;
+    int64_t replica_stride;
+} dhts_net_tables;
+size_t dhts_net_macro_hist_bytes(const dhts_net_desc *d);   /* state history [R][T+1][4][C] float32 */
+size_t dhts_net_macro_tape_bytes(const dhts_net_desc *d);   /* Jacobian tape [R][T][3][Cp][4] float32 */
+/* action [R][n_action]; out: hist, tape, kc [R][T][C] (loss sigmoid constants), queue [R][T][L] (loss terms q^2 dt),
+ * reward [R] float32 = - sum of the queue terms */
+int dhts_net_macro_rollout_fwd(const dhts_net_desc *d, const dhts_net_tables *t, const float *action, float *hist, float *tape,
+                               float *kc, float *queue, float *reward, dhts_error *err, void *stream);
+/* g_reward [R] (NULL = ones) -> g_action [R][n_action]; workspace: (T+1) * 2 * L floats per replica */
+int dhts_net_macro_rollout_bwd(const dhts_net_desc *d, const dhts_net_tables *t, const float *action, const float *hist,
+                               const float *tape, const float *kc, const float *g_reward, float *g_action, float *workspace,
+                               dhts_error *err, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

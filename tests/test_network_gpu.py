@@ -1,0 +1,77 @@
+"""The fused macro-network rollout kernel (signals, ghost exchange, queue loss, action gradient; one workgroup per
+replica) against the reference's itscp runs (G8) and against the CPU oracle on randomised actions / replica batches."""
+import os
+
+import numpy as np
+import pytest
+
+from test_oracle_golden import itscp_tables
+from util import TOL_GRAD, TOL_STATE, rel_max
+
+pytestmark = pytest.mark.gpu
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize("name", ["macro_small", "macro"])
+def test_network_rollout_vs_reference(cuda, golden_dir, name):
+    import torch
+    from dhts import ops
+    g = load(golden_dir, "itscp_%s.npz" % name)
+    tab, m = itscp_tables(g)
+    dt = 1.0 / m["simulation_frequency"]
+    dtab = ops.DeviceNetTables(tab, cuda)
+    action = torch.tensor(g["action"][None], device=cuda, requires_grad=True)
+    reward, queue = ops.net_macro_rollout(action, dtab, m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"],
+                                          dt, m["speed_limit"], m["static_speed"], m["vehicle_length"])
+    reward.sum().backward()
+    assert rel_max(queue[0].cpu().numpy().T, g["queue"]) <= TOL_STATE
+    assert abs(float(reward[0]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+    assert rel_max(action.grad[0].cpu().numpy(), g["g_action"]) <= TOL_GRAD
+
+
+def test_network_replica_batch_vs_oracle(cuda, oracle, golden_dir):
+    """64 replicas with their own actions (shared tables) and 3 replicas with their own schedules: every replica equals
+    the oracle's single-network run; results are bitwise repeatable."""
+    import torch
+    from dhts import ops
+    from dhts.network import MacroNetworkTables
+    g = load(golden_dir, "itscp_macro_small.npz")
+    tab, m = itscp_tables(g)
+    dt, um = 1.0 / m["simulation_frequency"], m["speed_limit"]
+    sq, F = m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"]
+    rng = np.random.default_rng(4)
+    R, A = 64, len(g["action"])
+    acts = rng.uniform(0.1, 0.9, (R, A)).astype(np.float32)
+    dtab = ops.DeviceNetTables(tab, cuda)
+    a = torch.tensor(acts, device=cuda, requires_grad=True)
+    w = torch.tensor(rng.uniform(0.5, 2.0, R).astype(np.float32), device=cuda)
+    reward, queue = ops.net_macro_rollout(a, dtab, sq, F, dt, um)
+    (reward * w).sum().backward()
+    for r in (0, 17, 63):
+        o = oracle.net_macro(tab, acts[r], sq, F, dt, um)
+        assert rel_max(queue[r].cpu().numpy(), o["queue"]) <= TOL_STATE
+        assert abs(float(reward[r]) - o["reward"]) <= 1e-5 * abs(o["reward"])
+        assert rel_max(a.grad[r].cpu().numpy() / float(w[r]), o["g_action"]) <= TOL_GRAD
+    a2 = torch.tensor(acts, device=cuda, requires_grad=True)
+    reward2, queue2 = ops.net_macro_rollout(a2, dtab, sq, F, dt, um)
+    (reward2 * w).sum().backward()
+    assert torch.equal(reward, reward2) and torch.equal(queue, queue2) and torch.equal(a.grad, a2.grad)
+    # per-replica schedules
+    tabs = []
+    for r in range(3):
+        sched = tab.schedule.T * (0.5 + 0.25 * r)
+        t = MacroNetworkTables.__new__(MacroNetworkTables)
+        t.__dict__.update(tab.__dict__)
+        t.schedule = np.ascontiguousarray(sched.T)
+        tabs.append(t)
+    dt3 = ops.DeviceNetTables(tabs, cuda)
+    a3 = torch.tensor(acts[:3], device=cuda, requires_grad=True)
+    reward3, _ = ops.net_macro_rollout(a3, dt3, sq, F, dt, um)
+    reward3.sum().backward()
+    for r in range(3):
+        o = oracle.net_macro(tabs[r], acts[r], sq, F, dt, um)
+        assert abs(float(reward3[r]) - o["reward"]) <= 1e-5 * max(abs(o["reward"]), 1e-6)
+        assert rel_max(a3.grad[r].cpu().numpy(), o["g_action"]) <= TOL_GRAD
