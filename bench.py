@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["macro", "micro"], default="macro")
+    ap.add_argument("--workload", choices=["macro", "micro", "itscp_macro"], default="macro")
     ap.add_argument("--lanes", type=int, default=0, help="override lanes per GPU")
     ap.add_argument("--cells", type=int, default=0, help="override cells / vehicles per lane")
     ap.add_argument("--time-steps", type=int, default=0, help="override simulated time steps per rollout")
@@ -185,6 +185,66 @@ class MicroWorkload:
                 "sample": "%d lanes x %d vehicles x %d steps fwd+bwd, repeated %.1f s (OpenMP over lanes)" % (Lc, V, T, el)}
 
 
+class ItscpMacroWorkload:
+    """run_itscp_macro.sh's network (1 intersection, 3 lanes, 30 m, 10 s, signal 2 s: 40 lanes, 236 cells, 300 steps, 5
+    actions) x 256 replicas with per-replica problem_1 schedules and actions U[0.1, 0.9]: reward and d reward / d action
+    of every replica in one fused launch each way (a stepping stone to BASELINE config 4, which adds micro lanes)."""
+    name = "itscp_macro_256x(40 lanes, 236 cells)x300"
+    unit_bytes = MACRO_TAPE_B
+
+    def __init__(self, dev, rank, R, _n, _t):
+        import numpy as np
+        from dhts import ops
+        from dhts.network import MacroNetworkTables
+        from example.control.itscp._env import ItscpEnv
+        from example.control.itscp.problem import problem_1
+        self.ops, self.R = ops, R
+        np.random.seed(1000 * rank + 1)
+        env = ItscpEnv()
+        env.schedule_callback = problem_1
+        for k, v in dict(num_intersection=1, lane_length=30.0, num_lane=3, policy_length=10, signal_length=2, mode="macro",
+                         speed_limit=60.0).items():
+            env.config[k] = v
+        env.reset()
+        base = MacroNetworkTables.from_env(env)
+        tabs = [base]
+        keys = list(env.lane.keys())
+        for r in range(1, R):       # same topology and per-step routes, a fresh problem_1 inflow schedule per replica
+            sched = env.schedule_callback(keys, env.num_timestep)
+            t = MacroNetworkTables.__new__(MacroNetworkTables)
+            t.__dict__.update(base.__dict__)
+            t.schedule = np.ascontiguousarray(np.array([sched[k] for k in keys], dtype=np.float64).T)
+            tabs.append(t)
+        self.tab = ops.DeviceNetTables(tabs, dev)
+        self.sq, self.F, self.dt, self.um = 1, 60, 1.0 / 30.0, 60.0
+        gen = torch.Generator(device="cpu").manual_seed(77 + rank)
+        self.action = (0.1 + 0.8 * torch.rand(R, env.action_size(), generator=gen)).to(dev).requires_grad_(True)
+        self.units = R * tabs[0].n_cells * tabs[0].T
+        self.L, self.N, self.T = R, tabs[0].n_cells, tabs[0].T
+        self.err = ops.new_error_record(dev)
+        self.ev = []
+
+    def one_pass(self, record=False):
+        self.action.grad = None
+        if record:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e[0].record()
+        reward, _ = self.ops.net_macro_rollout(self.action, self.tab, self.sq, self.F, self.dt, self.um)
+        if record:
+            e[1].record()
+        loss = -reward.sum()
+        if record:
+            e[2].record()
+        loss.backward()
+        if record:
+            e[3].record()
+            self.ev.append(e)
+        return loss.detach(), self.action.grad, self.action.grad
+
+    def cpu_baseline(self):
+        return {"value": None, "unit": "cell-steps/s", "cores": 0, "kind": "port", "sample": "not timed for this workload"}
+
+
 def main():
     args = parse()
     from dhts import dist as D
@@ -199,9 +259,12 @@ def main():
     if args.workload == "macro":
         L, N, T = args.lanes or 1024, args.cells or 512, args.time_steps or 1000
         w = MacroWorkload(dev, rank, L, N, T)
-    else:
+    elif args.workload == "micro":
         L, N, T = args.lanes or 4096, args.cells or 256, args.time_steps or 1000
         w = MicroWorkload(dev, rank, L, N, T)
+    else:
+        w = ItscpMacroWorkload(dev, rank, args.lanes or 256, 0, 0)
+        L, N, T = w.L, w.N, w.T
 
     flat = torch.zeros(1, dtype=torch.float32, device=dev)        # [loss] -- the per-pass RCCL all-reduce
     for _ in range(args.warmup):
