@@ -577,6 +577,19 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
     queue = np.array([[float(x) for x in env.queue_length[k]] for k in keys], dtype=np.float64)   # [lanes][T]
     reward = env._reward(action)
     t1 = time.time()
+    # split of the gradient by lane type (bisecting aid): reward restricted to macro / micro lanes
+    parts = {}
+    for tag, want_macro in (("macro", True), ("micro", False)):
+        part = 0
+        for k in keys:
+            if env.lane[k].sim_lane.is_macro() == want_macro:
+                for x in env.queue_length[k]:
+                    part = part + (-1.0) * x
+        if isinstance(part, th.Tensor) and part.requires_grad:
+            parts[tag] = th.autograd.grad(part, action, retain_graph=True, allow_unused=True)[0]
+            parts[tag] = np.zeros(len(a0), np.float32) if parts[tag] is None else parts[tag].numpy()
+        else:
+            parts[tag] = np.zeros(len(a0), np.float32)
     reward.backward()
     t2 = time.time()
     nveh = sim.num_vehicle
@@ -590,6 +603,7 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
         os.path.join(OUT, "itscp_%s.npz" % name),
         lane_tab=lane_tab, lane_str=np.array(lane_str), edges=edges, schedule=sched, macro_route=mroute, spawn_routes=sr,
         action=a0, reward=np.float64(float(reward)), g_action=action.grad.numpy(), queue=queue,
+        g_action_macro_lanes=parts["macro"], g_action_micro_lanes=parts["micro"],
         meta=meta(seed=seed, mode=mode, num_intersection=n_int, num_lane=n_lane, lane_length=lane_length,
                   policy_length=sim_len, signal_length=sig_len, speed_limit=60.0, cell_length=5.0, simulation_frequency=30,
                   static_speed=0.2, vehicle_length=5.0, T=T, n_vehicle_spawned=nveh,
@@ -625,6 +639,8 @@ def main():
             gen_itscp("macro", "macro", 1, 3, 30.0, 10, 2, seed=7, action_kind="rand")
         if "hybrid" in which:
             gen_itscp("hybrid", "hybrid", 3, 1, 5.0, 20, 4, seed=9, action_kind="rand")
+        if "hybrid_short" in which:      # 8 s: enough for the first vehicles to cross the interior intersection
+            gen_itscp("hybrid_short", "hybrid", 3, 1, 5.0, 8, 2, seed=9, action_kind="rand")
 
 
 if __name__ == "__main__":
