@@ -78,7 +78,8 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
     // carve LDS: doubles first (alignment)
     double *Fq = lds_d;                                  // [NI][2] flux of Q_0
     double *scan = Fq + 2 * NI;                          // [B] partial sums for the prefix mean
-    float *fl = reinterpret_cast<float *>(scan + B);
+    double *dxd = scan + B;                              // lane cell length [L] (double)
+    float *fl = reinterpret_cast<float *>(dxd + L);
     float *S0 = fl;                                      // state buffer 0: [4][C]
     float *S1 = S0 + 4 * C;
     float *G = S1 + 4 * C;                               // ghosts [L][2][4]
@@ -86,6 +87,13 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
     float *sig = AB + 8 * NI;                            // [sq][2]
     float *own = sig + 2 * sq;                           // stored downstream ghost (r, u) of sink lanes [L][2]
     float *ql = own + 2 * L;                             // per-lane queue of this step [L]
+    float *dxl_s = ql + L;                               // lane cell length [L]
+    int *off_s = reinterpret_cast<int *>(dxl_s + L);     // lane_off [L]
+    int *ncl_s = off_s + L;                              // lane_ncell [L]
+    int *knd_s = ncl_s + L;                              // sig_kind [L]
+    int *int_s = knd_s + L;                              // inter [L]
+    int *cell_lane = int_s + L;                          // [C]
+    int *iface_lane = cell_lane + C;                     // [NI]
     const float um = (float)um_d;
     const float *act = action + (size_t)rep * n_action;
     const size_t toff = (size_t)rep * tb.table_stride;
@@ -97,6 +105,12 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
     IfaceConst kconst;
     kconst.um = um_d; kconst.inv_um = 1.0 / um_d; kconst.inv_15um = 1.0 / (kG1 * um_d); kconst.dt = dt; kconst.dx = 1.0;
 
+    for (int l = tid; l < L; l += B) {
+        off_s[l] = tb.lane_off[l]; ncl_s[l] = tb.lane_ncell[l]; knd_s[l] = tb.sig_kind[l]; int_s[l] = tb.inter[l];
+        dxl_s[l] = (float)tb.lane_dx[l]; dxd[l] = tb.lane_dx[l];
+        for (int i = 0; i < tb.lane_ncell[l]; ++i) cell_lane[tb.lane_off[l] + i] = l;
+        for (int k = 0; k <= tb.lane_ncell[l]; ++k) iface_lane[tb.lane_off[l] + l + k] = l;
+    }
     // initial state: empty lanes (FullQ(speed_limit): r = y = 0, u = u_eq = u_max)
     for (int c = tid; c < C; c += B) {
         S0[c] = 0.f; S0[C + c] = 0.f; S0[2 * C + c] = um; S0[3 * C + c] = um;
@@ -135,12 +149,12 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
                     fr = (float)gr; fu = (float)gu;
                     fy = (float)(gr * (gu - gu)); fq = (float)gu;      // y = r (u - u_eq(r)) = 0 for u = u_eq(r)
                 } else {
-                    const int last = tb.lane_off[ls] + tb.lane_ncell[ls] - 1;
+                    const int last = off_s[ls] + ncl_s[ls] - 1;
                     const float gr = cur[last], gu = cur[2 * C + last];
                     float s;
                     if (lg == -1) s = 0.f;
                     else if (lg == -2) s = 1.f;
-                    else { const int kd = tb.sig_kind[lg]; s = kd == 0 ? 1.f : sig[2 * tb.inter[lg] + (kd == 1 ? 0 : 1)]; }
+                    else { const int kd = knd_s[lg]; s = kd == 0 ? 1.f : sig[2 * int_s[lg] + (kd == 1 ? 0 : 1)]; }
                     fr = gr * s + 0.f * (1.0f - s);
                     fu = gu * s + um * (1.0f - s);
                     glue_from_r_u(fr, fu, um, fy, fq);
@@ -149,9 +163,9 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
                 const int rs = rs_t[l];
                 float gr, gu;
                 if (rs < 0) { gr = own[2 * l]; gu = own[2 * l + 1]; }
-                else { const int first = tb.lane_off[rs]; gr = cur[first]; gu = cur[2 * C + first]; }
-                const int kd = tb.sig_kind[l];
-                const float sg = kd == 0 ? 1.f : sig[2 * tb.inter[l] + (kd == 1 ? 0 : 1)];
+                else { const int first = off_s[rs]; gr = cur[first]; gu = cur[2 * C + first]; }
+                const int kd = knd_s[l];
+                const float sg = kd == 0 ? 1.f : sig[2 * int_s[l] + (kd == 1 ? 0 : 1)];
                 const float s2 = soft_switch(sg - 0.5f, kSigK);
                 fr = s2 * gr + (1.0f - s2) * 1.0f;
                 fu = s2 * gu + (1.0f - s2) * 0.0f;
@@ -164,17 +178,8 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
         __syncthreads();
         // ---- interface solves: interface id = cell offset + lane index + k, k = 0 .. ncell
         for (int i = tid; i < NI; i += B) {
-            // locate the lane of interface i: lane l owns interfaces [off_l + l, off_l + l + ncell_l]
-            int l = 0;
-            {
-                int lo = 0, hi = L - 1;
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (tb.lane_off[mid] + mid <= i) lo = mid; else hi = mid - 1;
-                }
-                l = lo;
-            }
-            const int off = tb.lane_off[l], n = tb.lane_ncell[l];
+            const int l = iface_lane[i];                   // lane l owns interfaces [off_l + l, off_l + l + ncell_l]
+            const int off = off_s[l], n = ncl_s[l];
             const int k = i - off - l;                     // 0 .. n
             const float *gl = G + (size_t)(2 * l) * 4, *gr_ = G + (size_t)(2 * l + 1) * 4;
             double rL, yL, uL, qL, rR, yR, uR, qR;
@@ -182,7 +187,7 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
             else { const int c = off + k - 1; rL = cur[c]; yL = cur[C + c]; uL = cur[2 * C + c]; qL = cur[3 * C + c]; }
             if (k == n) { rR = gr_[0]; yR = gr_[1]; uR = gr_[2]; qR = gr_[3]; }
             else { const int c = off + k; rR = cur[c]; yR = cur[C + c]; uR = cur[2 * C + c]; qR = cur[3 * C + c]; }
-            kconst.dx = tb.lane_dx[l];
+            kconst.dx = dxd[l];
             Iface f;
             arz_interface(rL, yL, uL, qL, rR, yR, uR, qR, kconst, f);
             if (f.cfl_bad && fault_step < 0) { fault_step = t; fault_lane = l; fault_index = k; }
@@ -196,16 +201,8 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
         float *hn = hist_r + (size_t)(t + 1) * 4 * C;
         float4 *tp = tape_r + (size_t)t * 3 * Cp;
         for (int c = tid; c < C; c += B) {
-            int l;
-            {
-                int lo = 0, hi = L - 1;
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (tb.lane_off[mid] <= c) lo = mid; else hi = mid - 1;
-                }
-                l = lo;
-            }
-            const double cc = dt / tb.lane_dx[l];
+            const int l = cell_lane[c];
+            const double cc = dt / dxd[l];
             const float cf = (float)cc, ncf = (float)(-cc);
             const int iL = c + l, iR = c + l + 1;
             const float nr = (float)((double)cur[c] + (Fq[2 * iL] - Fq[2 * iR]) * cc);
@@ -229,34 +226,34 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
         const int c0 = tid * chunk, c1 = min(C, c0 + chunk);
         double part = 0.;
         for (int c = c0; c < c1; ++c) part += (double)((float)static_speed - nxt[2 * C + c]);
-        scan[tid] = part;
-        __syncthreads();
-        if (tid == 0) {
-            double acc = 0.;
-            for (int k = 0; k < B; ++k) { const double v = scan[k]; scan[k] = acc; acc += v; }   // exclusive
+        // exclusive scan of the per-thread partial sums: inclusive scan inside each wave by shuffles, then the wave
+        // totals (at most 16) are combined through LDS
+        double incl = part;
+        for (int d = 1; d < 64; d <<= 1) {
+            const double up = __shfl_up(incl, d, 64);
+            if ((tid & 63) >= d) incl += up;
         }
+        const int wv = tid >> 6, nw = B >> 6;
+        if ((tid & 63) == 63) scan[wv] = incl;                 // wave totals
         __syncthreads();
+        double wave_base = 0., step_total = 0.;
+        for (int k = 0; k < nw; ++k) { const double v = scan[k]; if (k < wv) wave_base += v; step_total += v; }
+        const double excl = wave_base + (incl - part);
         {
-            double acc = run_sum + scan[tid];
+            double acc = run_sum + excl;
             for (int c = c0; c < c1; ++c) {
                 acc += (double)((float)static_speed - nxt[2 * C + c]);
                 const double mean = acc / (double)(run_cnt + c + 1);
                 kc_r[(size_t)t * C + c] = 16.f / fabsf((float)mean);
             }
         }
-        // total of this step for the running sum (same value in every thread)
-        double step_total = scan[B - 1];
-        {
-            const int lc0 = (B - 1) * chunk, lc1 = min(C, lc0 + chunk);
-            for (int c = lc0; c < lc1; ++c) step_total += (double)((float)static_speed - nxt[2 * C + c]);
-        }
         run_sum += step_total;
         run_cnt += C;
         __syncthreads();
         // ---- lane queues: q = sum_cells is_static * r dx / len_veh, loss term q^2 dt   (_env.py:664-742)
         for (int l = tid; l < L; l += B) {
-            const int off = tb.lane_off[l], n = tb.lane_ncell[l];
-            const float dxl = (float)tb.lane_dx[l];
+            const int off = off_s[l], n = ncl_s[l];
+            const float dxl = dxl_s[l];
             float q = 0.f;
             for (int i = 0; i < n; ++i) {
                 const int c = off + i;
@@ -307,6 +304,12 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
     float *gq = sig + 5 * sq;            // per-lane d reward / d queue [L]
     float *cell_add = gq + L;            // per (lane, side): cotangent for the neighbour's edge cell (r, y) + target  [2L][3]
     float *act_add = cell_add + 6 * L;   // per (lane, side): (value, a_index)  [2L][2]
+    float *dxl_s = act_add + 4 * L;      // lane cell length [L]
+    int *off_s = reinterpret_cast<int *>(dxl_s + L);
+    int *ncl_s = off_s + L;
+    int *knd_s = ncl_s + L;
+    int *int_s = knd_s + L;
+    int *cell_lane = int_s + L;          // [C]
     const float um = (float)um_d;
     const float *act = action + (size_t)rep * n_action;
     const size_t toff = (size_t)rep * tb.table_stride;
@@ -316,6 +319,11 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
     float *own_r = own_hist + (size_t)rep * (T + 1) * 2 * L;
     const float gscale = g_reward ? g_reward[rep] : 1.f;
 
+    for (int l = tid; l < L; l += B) {
+        off_s[l] = tb.lane_off[l]; ncl_s[l] = tb.lane_ncell[l]; knd_s[l] = tb.sig_kind[l]; int_s[l] = tb.inter[l];
+        dxl_s[l] = (float)tb.lane_dx[l];
+        for (int i = 0; i < tb.lane_ncell[l]; ++i) cell_lane[tb.lane_off[l] + i] = l;
+    }
     // replay the stored downstream ghosts of sink lanes (they depend on themselves and on constants only)
     for (int l = tid; l < L; l += B) { own_r[2 * l] = 0.f; own_r[2 * l + 1] = um; }
     __syncthreads();
@@ -326,12 +334,12 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
             const int rs = rs_t[l];
             const float *o = own_r + (size_t)t * 2 * L;
             float *on = own_r + (size_t)(t + 1) * 2 * L;
-            const float gr = rs < 0 ? o[2 * l] : cur[tb.lane_off[rs]];
-            const float gu = rs < 0 ? o[2 * l + 1] : cur[2 * C + tb.lane_off[rs]];
+            const float gr = rs < 0 ? o[2 * l] : cur[off_s[rs]];
+            const float gu = rs < 0 ? o[2 * l + 1] : cur[2 * C + off_s[rs]];
             float we, ns, a, pr; int ai;
-            const int kd = tb.sig_kind[l];
+            const int kd = knd_s[l];
             float sg = 1.f;
-            if (kd != 0) { phase_signal(act, n_action, sq, F, t, tb.inter[l], we, ns, a, pr, ai); sg = kd == 1 ? we : ns; }
+            if (kd != 0) { phase_signal(act, n_action, sq, F, t, int_s[l], we, ns, a, pr, ai); sg = kd == 1 ? we : ns; }
             const float s2 = soft_switch(sg - 0.5f, kSigK);
             on[2 * l] = s2 * gr + (1.0f - s2) * 1.0f;
             on[2 * l + 1] = s2 * gu + (1.0f - s2) * 0.0f;
@@ -355,8 +363,8 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
         }
         // ---- (a) loss taps on the state after step t: d reward / d q_l = -2 q_l dt
         for (int l = tid; l < L; l += B) {
-            const int off = tb.lane_off[l], n = tb.lane_ncell[l];
-            const float dxl = (float)tb.lane_dx[l];
+            const int off = off_s[l], n = ncl_s[l];
+            const float dxl = dxl_s[l];
             float q = 0.f;
             for (int i = 0; i < n; ++i) {
                 const int c = off + i;
@@ -367,13 +375,8 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
         }
         __syncthreads();
         for (int c = tid; c < C; c += B) {
-            int l;
-            {
-                int lo = 0, hi = L - 1;
-                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tb.lane_off[mid] <= c) lo = mid; else hi = mid - 1; }
-                l = lo;
-            }
-            const float dxl = (float)tb.lane_dx[l];
+            const int l = cell_lane[c];
+            const float dxl = dxl_s[l];
             const float rr = nxt[c], yy = nxt[C + c], uu = nxt[2 * C + c];
             const float k = kc_r[(size_t)t * C + c];
             const float x = (float)static_speed - uu;
@@ -392,13 +395,8 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
         __syncthreads();
         // ---- (c1) gather inside each lane: g'[b] = (c1[b] + c2[b-1]) + c0[b+1]   (dmacro_lane.py:296-299)
         for (int c = tid; c < C; c += B) {
-            int l;
-            {
-                int lo = 0, hi = L - 1;
-                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tb.lane_off[mid] <= c) lo = mid; else hi = mid - 1; }
-                l = lo;
-            }
-            const int off = tb.lane_off[l], n = tb.lane_ncell[l];
+            const int l = cell_lane[c];
+            const int off = off_s[l], n = ncl_s[l];
             float vr = gp[c], vy = gp[C + c];
             if (c > off) { vr += c2[c - 1]; vy += c2[C + c - 1]; }
             if (c < off + n - 1) { vr += c0[c + 1]; vy += c0[C + c + 1]; }
@@ -408,16 +406,16 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
         // ---- (c2) ghost adjoints: thread -> (lane, side)
         for (int j = tid; j < 2 * L; j += B) {
             const int l = j >> 1, side = j & 1;
-            const int off = tb.lane_off[l], n = tb.lane_ncell[l];
+            const int off = off_s[l], n = ncl_s[l];
             float tgt = -1.f, add_r = 0.f, add_y = 0.f, a_val = 0.f, a_idx = -1.f;
             if (side == 0) {
                 const int ls = ls_t[l], lg = lg_t[l];
                 if (ls >= 0) {
-                    const int last = tb.lane_off[ls] + tb.lane_ncell[ls] - 1;
+                    const int last = off_s[ls] + ncl_s[ls] - 1;
                     const float grn_r = cur[last], grn_u = cur[2 * C + last];
                     float s = 1.f; int kd = 0, it = 0;
                     if (lg == -1) s = 0.f;
-                    else if (lg >= 0) { kd = tb.sig_kind[lg]; it = tb.inter[lg]; s = kd == 0 ? 1.f : sig[5 * it + (kd == 1 ? 0 : 1)]; }
+                    else if (lg >= 0) { kd = knd_s[lg]; it = int_s[lg]; s = kd == 0 ? 1.f : sig[5 * it + (kd == 1 ? 0 : 1)]; }
                     const float fr = grn_r * s + 0.f * (1.0f - s), fu = grn_u * s + um * (1.0f - s);
                     float g_fr = c0[off], g_fu = 0.f;
                     glue_y_bwd(fr, fu, um, c0[C + off], g_fr, g_fu);
@@ -434,9 +432,9 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
             } else {
                 const int rs = rs_t[l];
                 const float *o = own_r + (size_t)t * 2 * L;
-                const float grn_r = rs < 0 ? o[2 * l] : cur[tb.lane_off[rs]];
-                const float grn_u = rs < 0 ? o[2 * l + 1] : cur[2 * C + tb.lane_off[rs]];
-                const int kd = tb.sig_kind[l], it = tb.inter[l];
+                const float grn_r = rs < 0 ? o[2 * l] : cur[off_s[rs]];
+                const float grn_u = rs < 0 ? o[2 * l + 1] : cur[2 * C + off_s[rs]];
+                const int kd = knd_s[l], it = int_s[l];
                 const float sg = kd == 0 ? 1.f : sig[5 * it + (kd == 1 ? 0 : 1)];
                 const float s2 = soft_switch(sg - 0.5f, kSigK);
                 const float fr = s2 * grn_r + (1.0f - s2) * 1.0f, fu = s2 * grn_u + (1.0f - s2) * 0.0f;
@@ -444,7 +442,7 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
                 float g_fr = c2[lastc], g_fu = 0.f;
                 glue_y_bwd(fr, fu, um, c2[C + lastc], g_fr, g_fu);
                 if (rs >= 0) {
-                    const int first = tb.lane_off[rs];
+                    const int first = off_s[rs];
                     add_r = g_fr * s2;
                     glue_u_bwd(cur[first], cur[C + first], um, g_fu * s2, add_r, add_y);
                     tgt = (float)first;
@@ -465,12 +463,8 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
         for (int c = tid; c < C; c += B) {
             float vr = g[c], vy = g[C + c];
             // only edge cells of lanes can be targets; scanning 2L entries is cheap and keeps the order fixed
-            bool edge = false;
-            {
-                int lo = 0, hi = L - 1;
-                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tb.lane_off[mid] <= c) lo = mid; else hi = mid - 1; }
-                edge = (c == tb.lane_off[lo]) || (c == tb.lane_off[lo] + tb.lane_ncell[lo] - 1);
-            }
+            const int lc = cell_lane[c];
+            const bool edge = (c == off_s[lc]) || (c == off_s[lc] + ncl_s[lc] - 1);
             if (edge) {
                 for (int j = 0; j < 2 * L; ++j)
                     if (cell_add[3 * j] == (float)c) { vr += cell_add[3 * j + 1]; vy += cell_add[3 * j + 2]; }
@@ -530,8 +524,9 @@ int dhts_net_macro_rollout_fwd(const dhts_net_desc *d, const dhts_net_tables *t,
                                float *kc, float *queue, float *reward, dhts_error *err, void *stream) {
     if (!net_desc_ok(d) || !net_tables_ok(t) || !action || !hist || !tape || !kc || !queue || !reward) return DHTS_E_INVALID;
     const int B = net_block(d), L = d->n_lanes, C = d->n_cells, NI = C + L;
-    const size_t lds = sizeof(double) * (2 * (size_t)NI + B) +
-                       sizeof(float) * (8 * (size_t)C + 8 * L + 8 * (size_t)NI + 2 * d->n_inter_sq + 2 * L + L);
+    const size_t lds = sizeof(double) * (2 * (size_t)NI + B + L) +
+                       sizeof(float) * (8 * (size_t)C + 8 * L + 8 * (size_t)NI + 2 * d->n_inter_sq + 2 * L + L + L) +
+                       sizeof(int) * (4 * (size_t)L + C + NI);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)net_macro_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -547,7 +542,7 @@ int dhts_net_macro_rollout_bwd(const dhts_net_desc *d, const dhts_net_tables *t,
                                dhts_error *err, void *stream) {
     if (!net_desc_ok(d) || !net_tables_ok(t) || !action || !hist || !tape || !kc || !g_action || !workspace) return DHTS_E_INVALID;
     const int B = net_block(d), L = d->n_lanes, C = d->n_cells;
-    const size_t lds = sizeof(float) * (8 * (size_t)C + 5 * d->n_inter_sq + L + 6 * L + 4 * L) + 64;
+    const size_t lds = sizeof(float) * (8 * (size_t)C + 5 * d->n_inter_sq + L + 6 * L + 4 * L + L) + sizeof(int) * (4 * (size_t)L + C) + 64;
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)net_macro_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
