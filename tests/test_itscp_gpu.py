@@ -37,7 +37,7 @@ def build_env(g, m):
     return env
 
 
-@pytest.mark.parametrize("name", ["macro_small", "macro", "hybrid"])
+@pytest.mark.parametrize("name", ["macro_small", "macro", "hybrid_short", "hybrid"])
 def test_itscp_rollout_matches_reference(cuda, golden_dir, name):
     import torch
     path = os.path.join(golden_dir, "itscp_%s.npz" % name)

@@ -590,6 +590,16 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
             parts[tag] = np.zeros(len(a0), np.float32) if parts[tag] is None else parts[tag].numpy()
         else:
             parts[tag] = np.zeros(len(a0), np.float32)
+    # gradient of the reward restricted to the first t0 steps (bisecting aid)
+    cuts = [T // 4, T // 2, (3 * T) // 4]
+    g_cut = []
+    for t0_ in cuts:
+        part = 0
+        for k in keys:
+            for x in env.queue_length[k][:t0_]:
+                part = part + (-1.0) * x
+        gc = th.autograd.grad(part, action, retain_graph=True, allow_unused=True)[0]
+        g_cut.append(np.zeros(len(a0), np.float32) if gc is None else gc.numpy())
     reward.backward()
     t2 = time.time()
     nveh = sim.num_vehicle
@@ -604,6 +614,7 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
         lane_tab=lane_tab, lane_str=np.array(lane_str), edges=edges, schedule=sched, macro_route=mroute, spawn_routes=sr,
         action=a0, reward=np.float64(float(reward)), g_action=action.grad.numpy(), queue=queue,
         g_action_macro_lanes=parts["macro"], g_action_micro_lanes=parts["micro"],
+        g_action_cut_steps=np.array(cuts, dtype=np.int32), g_action_cut=np.array(g_cut, dtype=np.float32),
         meta=meta(seed=seed, mode=mode, num_intersection=n_int, num_lane=n_lane, lane_length=lane_length,
                   policy_length=sim_len, signal_length=sig_len, speed_limit=60.0, cell_length=5.0, simulation_frequency=30,
                   static_speed=0.2, vehicle_length=5.0, T=T, n_vehicle_spawned=nveh,
