@@ -58,8 +58,8 @@ SIGNATURES = {
     "dhts_macro_step_bwd": (C.c_int, [C.POINTER(MacroDesc)] + [_P] * 8),
     "dhts_net_macro_hist_bytes": (C.c_size_t, [C.POINTER(NetDesc)]),
     "dhts_net_macro_tape_bytes": (C.c_size_t, [C.POINTER(NetDesc)]),
-    "dhts_net_macro_rollout_fwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetTables)] + [_P] * 8),
-    "dhts_net_macro_rollout_bwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetTables)] + [_P] * 9),
+    "dhts_net_macro_rollout_fwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetTables)] + [_P] * 9),
+    "dhts_net_macro_rollout_bwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetTables)] + [_P] * 10),
     "dhts_micro_tape_bytes": (C.c_size_t, [C.POINTER(MicroDesc), C.c_int]),
     "dhts_micro_rollout_fwd": (C.c_int, [C.POINTER(MicroDesc), C.c_int] + [_P] * 11),
     "dhts_micro_rollout_bwd": (C.c_int, [C.POINTER(MicroDesc), C.c_int] + [_P] * 10),

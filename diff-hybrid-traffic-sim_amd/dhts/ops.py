@@ -366,24 +366,25 @@ class NetMacroRollout(torch.autograd.Function):
         kc = torch.empty(R, dev_tables.T, dev_tables.n_cells, dtype=torch.float32, device=dev)
         queue = torch.empty(R, dev_tables.T, dev_tables.n_lanes, dtype=torch.float32, device=dev)
         reward = torch.empty(R, dtype=torch.float32, device=dev)
+        ws = torch.zeros(R * dev_tables.T * 2 * dev_tables.n_lanes, dtype=torch.float32, device=dev)
         err = new_error_record(dev)
         check(lib.dhts_net_macro_rollout_fwd(C.byref(d), C.byref(dev_tables.c), _ptr(a), _ptr(hist), _ptr(tape), _ptr(kc),
-                                             _ptr(queue), _ptr(reward), _ptr(err), _stream()), "dhts_net_macro_rollout_fwd")
+                                             _ptr(queue), _ptr(reward), _ptr(ws), _ptr(err), _stream()),
+              "dhts_net_macro_rollout_fwd")
         raise_on_fault(err)
         ctx.d, ctx.tables = d, dev_tables
-        ctx.save_for_backward(a, hist, tape, kc)
+        ctx.save_for_backward(a, hist, tape, kc, queue, ws)
         ctx.mark_non_differentiable(queue)
         return reward, queue
 
     @staticmethod
     def backward(ctx, g_reward, _g_queue):
-        a, hist, tape, kc = ctx.saved_tensors
+        a, hist, tape, kc, queue, ws = ctx.saved_tensors
         d = ctx.d
         g_action = torch.empty_like(a)
-        ws = torch.empty(d.n_replicas * (d.n_steps + 1) * 2 * d.n_lanes, dtype=torch.float32, device=a.device)
         err = new_error_record(a.device)
         check(_lib.lib().dhts_net_macro_rollout_bwd(C.byref(d), C.byref(ctx.tables.c), _ptr(a), _ptr(hist), _ptr(tape), _ptr(kc),
-                                                    _ptr(g_reward.contiguous().float()), _ptr(g_action), _ptr(ws), _ptr(err),
+                                                    _ptr(queue), _ptr(g_reward.contiguous().float()), _ptr(g_action), _ptr(ws), _ptr(err),
                                                     _stream()), "dhts_net_macro_rollout_bwd")
         raise_on_fault(err)
         return g_action, None, None, None, None, None, None, None

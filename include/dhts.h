@@ -204,7 +204,8 @@ int dhts_micro_step_bwd(const dhts_micro_desc *d, const float *tape, const int32
  * Lanes start empty.  Tables (device pointers) are built on the host (dhts/network.py):
  *   lane_ncell, lane_off, sig_kind (0 always green, 1 west-east phase, 2 north-south phase), inter [L] int32; lane_dx [L]
  *   DOUBLE; left_src / left_gate / right_src [T][L] int32 and schedule [T][L] DOUBLE, per replica when replica_stride
- *   (elements between replicas) is non-zero, else shared.  Limits: T * n_cells <= 100000 (the loss' running-mean window).
+ *   (elements between replicas) is non-zero, else shared.  Limits: T * n_cells <= 100000 (the loss' running-mean window),
+ *   n_cells + n_lanes <= 1024 (one workgroup per replica), n_action <= 1024.
  */
 typedef struct dhts_net_desc {
     int32_t n_replicas, n_lanes, n_cells, n_steps, n_inter_sq, frames_per_phase, n_action;
@@ -220,13 +221,13 @@ typedef struct dhts_net_tables {
 size_t dhts_net_macro_hist_bytes(const dhts_net_desc *d);   /* state history [R][T+1][4][C] float32 */
 size_t dhts_net_macro_tape_bytes(const dhts_net_desc *d);   /* Jacobian tape [R][T][3][Cp][4] float32 */
 /* action [R][n_action]; out: hist, tape, kc [R][T][C] (loss sigmoid constants), queue [R][T][L] (loss terms q^2 dt),
- * reward [R] float32 = - sum of the queue terms */
+ * reward [R] float32 = - sum of the queue terms; workspace [R][T][2 L] float32 (kept for the reverse sweep) */
 int dhts_net_macro_rollout_fwd(const dhts_net_desc *d, const dhts_net_tables *t, const float *action, float *hist, float *tape,
-                               float *kc, float *queue, float *reward, dhts_error *err, void *stream);
-/* g_reward [R] (NULL = ones) -> g_action [R][n_action]; workspace: (T+1) * 2 * L floats per replica */
+                               float *kc, float *queue, float *reward, float *workspace, dhts_error *err, void *stream);
+/* hist, tape, kc, queue, workspace from the forward; g_reward [R] (NULL = ones) -> g_action [R][n_action] */
 int dhts_net_macro_rollout_bwd(const dhts_net_desc *d, const dhts_net_tables *t, const float *action, const float *hist,
-                               const float *tape, const float *kc, const float *g_reward, float *g_action, float *workspace,
-                               dhts_error *err, void *stream);
+                               const float *tape, const float *kc, const float *queue, const float *g_reward, float *g_action,
+                               const float *workspace, dhts_error *err, void *stream);
 
 #ifdef __cplusplus
 }

@@ -591,7 +591,7 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
         else:
             parts[tag] = np.zeros(len(a0), np.float32)
     # gradient of the reward restricted to the first t0 steps (bisecting aid)
-    cuts = [T // 4, T // 2, (3 * T) // 4]
+    cuts = [T // 4, T // 2, (3 * T) // 4] if os.environ.get("DHTS_FINE_CUTS") is None else [int(x) for x in os.environ["DHTS_FINE_CUTS"].split(",")]
     g_cut = []
     for t0_ in cuts:
         part = 0
@@ -600,6 +600,17 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
                 part = part + (-1.0) * x
         gc = th.autograd.grad(part, action, retain_graph=True, allow_unused=True)[0]
         g_cut.append(np.zeros(len(a0), np.float32) if gc is None else gc.numpy())
+    # per-lane late contributions (bisecting aid): gradient of each macro lane's loss over the last quarter
+    g_lane_late = {}
+    if os.environ.get("DHTS_LANE_LATE"):
+        want = [int(x) for x in os.environ["DHTS_LANE_LATE"].split(",")]
+        for i, k in enumerate(keys):
+            if i in want:
+                part = 0
+                for x in env.queue_length[k][(3 * T) // 4:]:
+                    part = part + (-1.0) * x
+                gc = th.autograd.grad(part, action, retain_graph=True, allow_unused=True)[0] if (isinstance(part, th.Tensor) and part.requires_grad) else None
+                g_lane_late[i] = np.zeros(len(a0), np.float32) if gc is None else gc.numpy()
     reward.backward()
     t2 = time.time()
     nveh = sim.num_vehicle
@@ -615,6 +626,8 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
         action=a0, reward=np.float64(float(reward)), g_action=action.grad.numpy(), queue=queue,
         g_action_macro_lanes=parts["macro"], g_action_micro_lanes=parts["micro"],
         g_action_cut_steps=np.array(cuts, dtype=np.int32), g_action_cut=np.array(g_cut, dtype=np.float32),
+        g_lane_late_ids=np.array(sorted(g_lane_late), dtype=np.int32),
+        g_lane_late=np.array([g_lane_late[i] for i in sorted(g_lane_late)], dtype=np.float32).reshape(len(g_lane_late), len(a0)),
         meta=meta(seed=seed, mode=mode, num_intersection=n_int, num_lane=n_lane, lane_length=lane_length,
                   policy_length=sim_len, signal_length=sig_len, speed_limit=60.0, cell_length=5.0, simulation_frequency=30,
                   static_speed=0.2, vehicle_length=5.0, T=T, n_vehicle_spawned=nveh,
@@ -649,7 +662,7 @@ def main():
         if "macro" in which:
             gen_itscp("macro", "macro", 1, 3, 30.0, 10, 2, seed=7, action_kind="rand")
         if "hybrid" in which:
-            gen_itscp("hybrid", "hybrid", 3, 1, 5.0, 20, 4, seed=9, action_kind="rand")
+            gen_itscp(os.environ.get("DHTS_HYBRID_NAME", "hybrid"), "hybrid", 3, 1, 5.0, 20, 4, seed=9, action_kind="rand")
         if "hybrid_short" in which:      # 8 s: enough for the first vehicles to cross the interior intersection
             gen_itscp("hybrid_short", "hybrid", 3, 1, 5.0, 8, 2, seed=9, action_kind="rand")
 
