@@ -57,6 +57,36 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.dhts_macro_state_from_ru(8, 30.0, None, None, None, None, None) == _lib.E_INVALID
 
 
+def test_network_entry_points_reject_bad_sizes():
+    from dhts import _lib
+    lib = _lib.lib()
+    ok = _lib.NetDesc(4, 40, 236, 300, 1, 60, 5, 1 / 30, 60.0, 0.2, 5.0)
+    assert lib.dhts_net_macro_hist_bytes(C.byref(ok)) == 4 * 301 * 4 * 236 * 4
+    assert lib.dhts_net_macro_tape_bytes(C.byref(ok)) == 4 * 300 * 3 * 256 * 16
+    too_long = _lib.NetDesc(4, 40, 236, 600, 1, 60, 5, 1 / 30, 60.0, 0.2, 5.0)       # 600 * 236 > 100000 samples
+    assert lib.dhts_net_macro_hist_bytes(C.byref(too_long)) == 0
+    too_wide = _lib.NetDesc(4, 300, 900, 10, 1, 60, 5, 1 / 30, 60.0, 0.2, 5.0)        # cells + lanes > 1024
+    assert lib.dhts_net_macro_tape_bytes(C.byref(too_wide)) == 0
+    tabs = _lib.NetTables()
+    assert lib.dhts_net_macro_rollout_fwd(C.byref(ok), C.byref(tabs), *([None] * 9)) == _lib.E_INVALID
+    assert lib.dhts_net_macro_rollout_bwd(C.byref(ok), C.byref(tabs), *([None] * 10)) == _lib.E_INVALID
+
+
+def test_network_tables_builder():
+    """dhts.network.MacroNetworkTables: ghost-source tables of a 3-lane chain with a fork."""
+    import numpy as np
+    from dhts.network import MacroNetworkTables
+    # lane 0 -> {1, 2}; per-step route picks 1 (t = 0) then 2 (t = 1); lane 3 is isolated
+    mr = np.array([[1, -1, -1, -1], [2, -1, -1, -1]])
+    t = MacroNetworkTables([2, 3, 1, 4], [10.0, 15.0, 5.0, 20.0], [(0, 1), (0, 2)], [1, 0, 0, 2], [0, 0, 0, 0], mr,
+                           np.ones((4, 2)))
+    assert t.n_cells == 10 and t.lane_off.tolist() == [0, 2, 5, 6] and np.allclose(t.lane_dx, 5.0)
+    assert t.left_src.tolist() == [[-1, 0, 0, -1], [-1, 0, 0, -1]]          # single upstream lane: always that lane
+    assert t.left_gate.tolist() == [[-2, 0, -1, -2], [-2, -1, 0, -2]]        # gated by the route's choice (-1 = red)
+    assert t.right_src.tolist() == [[1, -1, -1, -1], [2, -1, -1, -1]]        # fork follows the route; sinks keep their own ghost
+    assert t.is_source.tolist() == [True, False, False, True]
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from dhts import _lib
     monkeypatch.setattr(_lib, "_lib", None)
