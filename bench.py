@@ -66,6 +66,7 @@ class MacroWorkload:
         self.gout = (torch.empty(L, N, device=dev), torch.empty(L, N, device=dev))
         self.g_ghost = torch.zeros(L, 2, 2, dtype=torch.float64, device=dev)
         self.units = L * N * T                       # cell-steps per pass
+        self.name = "macro_straight_%dx%dx%d" % (L, N, T)
         self.ev = []
 
     def one_pass(self, record=False):
@@ -140,6 +141,7 @@ class MicroWorkload:
         self.gout = (torch.empty(L, V, device=dev), torch.empty(L, V, device=dev))
         self.g_head = torch.zeros(L, 2, dtype=torch.float64, device=dev)
         self.units = L * V * T
+        self.name = "micro_idm_%dx%dx%d" % (L, V, T)
         self.ev = []
 
     def one_pass(self, record=False):
@@ -253,6 +255,7 @@ def main():
         if rank == 0 and world > 1:
             print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    local = local % torch.cuda.device_count()      # one GPU per rank on a full node; wraps only in single-GPU smoke tests
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -17,7 +17,8 @@ def init(backend=None):
     rank, world, local = env_rank_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # DHTS_DIST_BACKEND=gloo lets two ranks share one GPU in a smoke test; the default on GPUs is RCCL ("nccl")
+            backend = os.environ.get("DHTS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
