@@ -323,7 +323,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64 step on f32 state, f32 tape/adjoint",
+            "dtype": "f64",
+            "dtype_detail": "float32 state widened to double for the step, Jacobian tape and adjoint in float32 (the reference's ladder)",
             "data": "synthetic",
             "config": {"workload": w.name, "lanes_per_gpu": L, "units_per_lane": N, "time_steps": T,
                        "parallelism": "lanes sharded over %d GPU(s), no data-path collective" % world},

@@ -46,6 +46,8 @@ struct NetTables {
     const int32_t *left_src, *left_gate, *right_src;            // [T][L] (per replica when table_stride != 0)
     const double *schedule;                                     // [T][L]
     size_t table_stride;                                        // elements between replicas in the [T][L] tables (0 = shared)
+    const int32_t *nxt_ptr, *nxt_idx, *prv_ptr, *prv_idx;       // static adjacency, CSR, ascending ids
+    int n_edges;
 };
 
 __device__ __forceinline__ void net_fault(dhts_error *err, int code, int step, int lane, int index) {
@@ -285,7 +287,8 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
 
 // reverse: three barriers per step, global reads (history rows, loss constants, tape, queue terms, tables) fetched one step
 // ahead into registers.
-// LDS floats: H0, H1 [3][C] (history rows r, y, u; ping-pong) | c0, c2 [2][C] | gq [L] | cell_add [2L][3] | act_add [2L][2]
+// LDS floats: H0, H1 [3][C] (history rows r, y, u; ping-pong) | c0, c2 [2][C] | gq [L] | inL, inF [E][2] | doubles red [16][sq]
+// Limits (checked on the host side of the Python layer): a lane has at most 4 upstream and 4 downstream neighbours.
 __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
                                      double static_speed, double veh_len, NetTables tb, const float *__restrict__ action,
                                      const float *__restrict__ hist, const float4 *__restrict__ tape,
@@ -295,13 +298,16 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
     extern __shared__ double lds_d[];
     const int rep = blockIdx.x, tid = threadIdx.x;
     const int Cp = (C + 63) & ~63;
+    const int E = tb.n_edges > 0 ? tb.n_edges : 1;
+    const int red_off = (10 * C + L + 4 * E + C + 1) / 2 + 1;     // doubles after the float / int region
     float *fl = reinterpret_cast<float *>(lds_d);
     float *H0 = fl, *H1 = H0 + 3 * C;
     float *c0 = H1 + 3 * C, *c2 = c0 + 2 * C;
     float *gq = c2 + 2 * C;
-    float *cell_add = gq + L;
-    float *act_add = cell_add + 6 * L;
-    int *cell_lane_s = reinterpret_cast<int *>(act_add + 4 * L);
+    float *inL = gq + L;                 // [E][2] cotangent for the LAST cell of lane s from the upstream ghost of its k-th next lane
+    float *inF = inL + 2 * E;            // [E][2] cotangent for the FIRST cell of lane s from the downstream ghost of its k-th prev lane
+    int *cell_lane_s = reinterpret_cast<int *>(inF + 2 * E);
+    double *red = lds_d + red_off;       // [16][sq] per-wave partial sums of the action cotangent
     const float um = (float)um_d, s0f = (float)static_speed;
     const float *act = action + (size_t)rep * n_action;
     const size_t toff = (size_t)rep * tb.table_stride;
@@ -317,6 +323,7 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
         const int off = tb.lane_off[tid], n = tb.lane_ncell[tid];
         for (int i = 0; i < n; ++i) cell_lane_s[off + i] = tid;
     }
+    for (int k = tid; k < 2 * E; k += blockDim.x) { inL[k] = 0.f; inF[k] = 0.f; }
     __syncthreads();
     int c_lane = 0, c_first = 0, c_last = 0; float c_dxv = 0.f;
     if (is_cell) {
@@ -326,6 +333,43 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
     const int g_lane = tid >> 1, g_side = tid & 1;
     int g_kind = 0, g_inter = 0, g_off = 0, g_n = 0;
     if (is_ghost) { g_kind = tb.sig_kind[g_lane]; g_inter = tb.inter[g_lane]; g_off = tb.lane_off[g_lane]; g_n = tb.lane_ncell[g_lane]; }
+
+    // ghost thread: inbox position for each possible source lane (the source of a step is one of the lane's static
+    // neighbours): upstream ghost of lane n sourced from s in prev(n) -> entry (index of n in next(s)) of inL, likewise inF
+    constexpr int kMaxCand = 4, kMaxEnt = 8;
+    int cand_src[kMaxCand], cand_pos[kMaxCand], n_cand = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxCand; ++i) { cand_src[i] = -1; cand_pos[i] = 0; }
+    if (is_ghost) {
+        const int32_t *my_ptr = g_side == 0 ? tb.prv_ptr : tb.nxt_ptr, *my_idx = g_side == 0 ? tb.prv_idx : tb.nxt_idx;
+        const int32_t *o_ptr = g_side == 0 ? tb.nxt_ptr : tb.prv_ptr, *o_idx = g_side == 0 ? tb.nxt_idx : tb.prv_idx;
+        for (int e = my_ptr[g_lane]; e < my_ptr[g_lane + 1] && n_cand < kMaxCand; ++e) {
+            const int s_lane = my_idx[e];
+            int k = o_ptr[s_lane];
+            while (o_idx[k] != g_lane) ++k;
+#pragma unroll
+            for (int i = 0; i < kMaxCand; ++i) if (i == n_cand) { cand_src[i] = s_lane; cand_pos[i] = k; }
+            ++n_cand;
+        }
+    }
+    // edge-cell thread: its inbox entries in ascending slot order (2 n for inL entries, 2 m + 1 for inF entries);
+    // entry code = inbox index * 2 + (1 for inF)
+    int ent[kMaxEnt], n_ent = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxEnt; ++i) ent[i] = -1;
+    if (is_cell && (tid == c_first || tid == c_last)) {
+        int a = tb.nxt_ptr[c_lane], a_end = (tid == c_last) ? tb.nxt_ptr[c_lane + 1] : a;
+        int b = tb.prv_ptr[c_lane], b_end = (tid == c_first) ? tb.prv_ptr[c_lane + 1] : b;
+        while ((a < a_end || b < b_end) && n_ent < kMaxEnt) {
+            const int sa = a < a_end ? 2 * tb.nxt_idx[a] : 0x7fffffff;
+            const int sb = b < b_end ? 2 * tb.prv_idx[b] + 1 : 0x7fffffff;
+            const int code = sa < sb ? 2 * a : 2 * b + 1;
+            if (sa < sb) ++a; else ++b;
+#pragma unroll
+            for (int i = 0; i < kMaxEnt; ++i) if (i == n_ent) ent[i] = code;
+            ++n_ent;
+        }
+    }
 
     // ---- prefetch registers (data of step t, fetched during step t+1)
     float p_hr = 0.f, p_hy = 0.f, p_hu = 0.f, p_kc = 0.f, p_q = 0.f, p_own_r = 0.f, p_own_u = 0.f;
@@ -356,8 +400,11 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
     __syncthreads();
     fetch(T - 1);
     float g_r = 0.f, g_y = 0.f;          // cotangent of this thread's cell at time t+1
-    double ga = 0.;                      // thread k < n_action: d reward / d action[k]
+    double ga = 0.;                      // thread q < sq: d reward / d action[cur_phase * sq + q], flushed when the phase changes
+    int cur_phase = -1;
     bool bad = false;
+    // actions of phases the rollout never reaches get a zero gradient (thread q owns the entries of intersection q)
+    if (tid < sq) for (int k = tid; k < n_action; k += sq) g_action[(size_t)rep * n_action + k] = 0.f;
 
     for (int t = T - 1; t >= 0; --t) {
         float *Hc = (t & 1) ? H1 : H0;           // row t   (state before step t)
@@ -394,6 +441,7 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
             if (c > c_first) { v_r += c2[c - 1]; v_y += c2[C + c - 1]; }
             if (c < c_last) { v_r += c0[c + 1]; v_y += c0[C + c + 1]; }
         }
+        float my_aval = 0.f; int my_akey = -1;
         if (is_ghost) {
             float tgt = -1.f, add_r = 0.f, add_y = 0.f, a_val = 0.f, a_idx = -1.f;
             if (g_side == 0) {
@@ -441,28 +489,49 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
                     a_val = g_sig * dsig; a_idx = (float)ai;
                 }
             }
-            cell_add[3 * tid] = tgt; cell_add[3 * tid + 1] = add_r; cell_add[3 * tid + 2] = add_y;
-            act_add[2 * tid] = a_val; act_add[2 * tid + 1] = a_idx;
+            // route the cell cotangent to the inbox entry of (source lane, this lane)
+            if (tgt >= 0.f) {
+                float *box = g_side == 0 ? inL : inF;
+#pragma unroll
+                for (int i = 0; i < kMaxCand; ++i)
+                    if (cand_src[i] == src) { box[2 * cand_pos[i]] = add_r; box[2 * cand_pos[i] + 1] = add_y; }
+            }
+            my_aval = a_val; my_akey = a_idx < 0.f ? -1 : ((int)a_idx) % sq;
+        }
+        // action cotangent: per intersection, fixed-shape reduction (wave butterfly in double, then the wave partials)
+        for (int q = 0; q < sq; ++q) {
+            double v = (my_akey == q) ? (double)my_aval : 0.0;
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            if ((tid & 63) == 0) red[(tid >> 6) * sq + q] = v;
         }
         lds_barrier();
-        // ---- phase D: ordered accumulation (lane id ascending, upstream before downstream): edge cells and the action
+        // ---- phase D: edge cells take their inbox entries in ascending slot order (lane id ascending, upstream ghost of
+        //      lane n = slot 2n before downstream ghost of lane m = slot 2m+1), then clear them; action partials are summed
         if (is_cell) {
-            const int c = tid;
-            if (c == c_first || c == c_last) {
-                for (int j = 0; j < 2 * L; ++j)
-                    if (cell_add[3 * j] == (float)c) { v_r += cell_add[3 * j + 1]; v_y += cell_add[3 * j + 2]; }
+#pragma unroll
+            for (int i = 0; i < kMaxEnt; ++i) {
+                if (ent[i] >= 0) {
+                    float *box = (ent[i] & 1) ? inF : inL;
+                    const int k = ent[i] >> 1;
+                    v_r += box[2 * k]; v_y += box[2 * k + 1];
+                    box[2 * k] = 0.f; box[2 * k + 1] = 0.f;
+                }
             }
             g_r = v_r; g_y = v_y;
             bad |= !(isfinite(v_r) && isfinite(v_y));
         }
-        if (tid < n_action) {
-            for (int j = 0; j < 2 * L; ++j)
-                if (act_add[2 * j + 1] == (float)tid) ga += (double)act_add[2 * j];
+        if (tid < sq) {
+            double v = 0.;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += red[w * sq + tid];
+            // all contributions of step t belong to the phase of step t
+            int phase = t / F; const int lastp = n_action / sq - 1; phase = phase > lastp ? lastp : phase;
+            if (phase != cur_phase) { if (cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + tid] = (float)ga; ga = 0.; cur_phase = phase; }
+            ga += v;
         }
-        // no barrier here: the next step's first phase only writes rows / gq that nobody reads before its own barrier,
-        // and cell_add / act_add are rewritten two barriers later
+        // no barrier here: the next step's first phase only writes rows / gq that nobody reads before its own barrier;
+        // inbox entries and the reduction scratch are rewritten two barriers later
     }
-    if (tid < n_action) g_action[(size_t)rep * n_action + tid] = (float)ga;
+    if (tid < sq && cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + tid] = (float)ga;
     if (bad) net_fault(err, DHTS_FAULT_NAN, 0, 0, tid);
 }
 
@@ -486,11 +555,13 @@ static inline NetTables net_tables(const dhts_net_tables *t) {
     n.lane_ncell = t->lane_ncell; n.lane_off = t->lane_off; n.sig_kind = t->sig_kind; n.inter = t->inter; n.lane_dx = t->lane_dx;
     n.left_src = t->left_src; n.left_gate = t->left_gate; n.right_src = t->right_src; n.schedule = t->schedule;
     n.table_stride = (size_t)t->replica_stride;
+    n.nxt_ptr = t->nxt_ptr; n.nxt_idx = t->nxt_idx; n.prv_ptr = t->prv_ptr; n.prv_idx = t->prv_idx; n.n_edges = t->n_edges;
     return n;
 }
 static inline bool net_tables_ok(const dhts_net_tables *t) {
     return t && t->lane_ncell && t->lane_off && t->sig_kind && t->inter && t->lane_dx && t->left_src && t->left_gate &&
-           t->right_src && t->schedule && t->replica_stride >= 0;
+           t->right_src && t->schedule && t->replica_stride >= 0 && t->nxt_ptr && t->nxt_idx && t->prv_ptr && t->prv_idx &&
+           t->n_edges >= 0;
 }
 
 extern "C" {
@@ -525,7 +596,8 @@ int dhts_net_macro_rollout_bwd(const dhts_net_desc *d, const dhts_net_tables *t,
     if (!net_desc_ok(d) || !net_tables_ok(t) || !action || !hist || !tape || !kc || !queue || !g_action || !workspace)
         return DHTS_E_INVALID;
     const int B = net_block(d), L = d->n_lanes, C = d->n_cells;
-    const size_t lds = sizeof(float) * (10 * (size_t)C + L + 6 * L + 4 * L) + sizeof(int) * (size_t)C + 64;
+    const int E = t->n_edges > 0 ? t->n_edges : 1;
+    const size_t lds = sizeof(double) * (((10 * (size_t)C + L + 4 * E + C + 1) / 2 + 1) + 16 * (size_t)d->n_inter_sq) + 64;
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)net_macro_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -32,7 +32,8 @@ class NetDesc(C.Structure):
 class NetTables(C.Structure):
     _fields_ = [("lane_ncell", C.c_void_p), ("lane_off", C.c_void_p), ("sig_kind", C.c_void_p), ("inter", C.c_void_p),
                 ("lane_dx", C.c_void_p), ("left_src", C.c_void_p), ("left_gate", C.c_void_p), ("right_src", C.c_void_p),
-                ("schedule", C.c_void_p), ("replica_stride", C.c_int64)]
+                ("schedule", C.c_void_p), ("replica_stride", C.c_int64), ("nxt_ptr", C.c_void_p), ("nxt_idx", C.c_void_p),
+                ("prv_ptr", C.c_void_p), ("prv_idx", C.c_void_p), ("n_edges", C.c_int32)]
 
 
 class MicroDesc(C.Structure):

@@ -30,6 +30,14 @@ class MacroNetworkTables:
         for a, b in np.asarray(edges, dtype=np.int64).tolist():
             nxt[a].append(b)
             prev[b].append(a)
+        # static adjacency (CSR, ascending ids)
+        self.nxt_ptr = np.concatenate([[0], np.cumsum([len(n) for n in nxt])]).astype(np.int32)
+        self.nxt_idx = np.array([b for n in nxt for b in sorted(n)], dtype=np.int32)
+        self.prv_ptr = np.concatenate([[0], np.cumsum([len(p_) for p_ in prev])]).astype(np.int32)
+        self.prv_idx = np.array([a for p_ in prev for a in sorted(p_)], dtype=np.int32)
+        self.n_edges = int(len(self.nxt_idx))
+        if max([len(n) for n in nxt] + [len(p_) for p_ in prev]) > 4:
+            raise ValueError("the network kernels support at most 4 upstream and 4 downstream lanes per lane")
         route_prev = -np.ones((T, L), dtype=np.int32)
         tt, aa = np.nonzero(macro_route >= 0)
         route_prev[tt, macro_route[tt, aa]] = aa

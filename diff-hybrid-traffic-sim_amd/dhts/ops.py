@@ -338,10 +338,14 @@ class DeviceNetTables:
         stack = (lambda name: np.stack([getattr(t, name) for t in tables])) if many else (lambda name: getattr(first, name))
         self.left_src, self.left_gate = up(stack("left_src"), torch.int32), up(stack("left_gate"), torch.int32)
         self.right_src, self.schedule = up(stack("right_src"), torch.int32), up(stack("schedule"), torch.float64)
+        pad1 = lambda a: a if len(a) else np.zeros(1, dtype=np.int32)      # noqa: E731  (never pass a NULL pointer)
+        self.nxt_ptr, self.nxt_idx = up(first.nxt_ptr, torch.int32), up(pad1(first.nxt_idx), torch.int32)
+        self.prv_ptr, self.prv_idx = up(first.prv_ptr, torch.int32), up(pad1(first.prv_idx), torch.int32)
         self.c = _lib.NetTables(self.lane_ncell.data_ptr(), self.lane_off.data_ptr(), self.sig_kind.data_ptr(),
                                 self.inter.data_ptr(), self.lane_dx.data_ptr(), self.left_src.data_ptr(),
                                 self.left_gate.data_ptr(), self.right_src.data_ptr(), self.schedule.data_ptr(),
-                                self.T * self.n_lanes if many else 0)
+                                self.T * self.n_lanes if many else 0, self.nxt_ptr.data_ptr(), self.nxt_idx.data_ptr(),
+                                self.prv_ptr.data_ptr(), self.prv_idx.data_ptr(), first.n_edges)
 
 
 class NetMacroRollout(torch.autograd.Function):

@@ -205,7 +205,7 @@ int dhts_micro_step_bwd(const dhts_micro_desc *d, const float *tape, const int32
  *   lane_ncell, lane_off, sig_kind (0 always green, 1 west-east phase, 2 north-south phase), inter [L] int32; lane_dx [L]
  *   DOUBLE; left_src / left_gate / right_src [T][L] int32 and schedule [T][L] DOUBLE, per replica when replica_stride
  *   (elements between replicas) is non-zero, else shared.  Limits: T * n_cells <= 100000 (the loss' running-mean window),
- *   n_cells + n_lanes <= 1024 (one workgroup per replica), n_action <= 1024.
+ *   n_cells + n_lanes <= 1024 (one workgroup per replica), n_action <= 1024, at most 4 upstream / 4 downstream lanes per lane.
  */
 typedef struct dhts_net_desc {
     int32_t n_replicas, n_lanes, n_cells, n_steps, n_inter_sq, frames_per_phase, n_action;
@@ -217,6 +217,10 @@ typedef struct dhts_net_tables {
     const int32_t *left_src, *left_gate, *right_src;
     const double *schedule;
     int64_t replica_stride;
+    /* static adjacency in CSR form, neighbour ids ascending: next lanes of lane l = nxt_idx[nxt_ptr[l] .. nxt_ptr[l+1]),
+     * previous lanes likewise (used by the reverse sweep to route ghost cotangents without searching) */
+    const int32_t *nxt_ptr, *nxt_idx, *prv_ptr, *prv_idx;
+    int32_t n_edges;
 } dhts_net_tables;
 size_t dhts_net_macro_hist_bytes(const dhts_net_desc *d);   /* state history [R][T+1][4][C] float32 */
 size_t dhts_net_macro_tape_bytes(const dhts_net_desc *d);   /* Jacobian tape [R][T][3][Cp][4] float32 */
