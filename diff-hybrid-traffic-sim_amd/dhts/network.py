@@ -1,4 +1,4 @@
-"""Flat tables describing a macro road network with signals (the itscp environment in `macro` mode) for the fused
+"""Flat tables describing a road network with signals (the itscp environment in `macro` / `hybrid` mode) for the fused
 network kernels: lane geometry, per-lane signal kind, and per time step which neighbour feeds each ghost cell.
 
 Built on the host from plain arrays (lane cell counts / lengths, directed lane edges, per-step macro-route matching,
@@ -81,3 +81,67 @@ class MacroNetworkTables:
         return MacroNetworkTables([sl.num_cell for sl in lanes], [sl.length for sl in lanes], edges, kinds,
                                   [k.row * env.num_intersection + k.col for k in keys], mr,
                                   [env.schedule[k] for k in keys])
+
+
+class HybridNetworkTables:
+    """Tables of a network mixing macro lanes (ARZ cells) and micro lanes (IDM vehicles): the itscp environment in
+    `hybrid` mode (reference _env.py:489-498: the lanes of interior intersections are micro).  Ghost sources follow
+    RoadNetwork.get_macro_boundary (road_network.py:299-362): a micro neighbour never feeds a ghost cell, the lane's
+    own stored ghost does; hand-off targets follow RoadNetwork.conversion (road_network.py:113-170)."""
+
+    def __init__(self, lane_macro, lane_ncell, lane_length, edges, sig_kind, inter, macro_route, schedule):
+        self.lane_macro = np.asarray(lane_macro, dtype=np.int32)
+        self.lane_ncell = np.where(self.lane_macro == 1, np.asarray(lane_ncell, dtype=np.int32), 0).astype(np.int32)
+        self.lane_length = np.asarray(lane_length, dtype=np.float64)
+        L = len(self.lane_ncell)
+        self.n_lanes = L
+        self.lane_off = np.concatenate([[0], np.cumsum(self.lane_ncell)[:-1]]).astype(np.int32)
+        self.n_cells = int(self.lane_ncell.sum())
+        self.lane_dx = np.where(self.lane_ncell > 0, self.lane_length / np.maximum(self.lane_ncell, 1), 0.0).astype(np.float64)
+        self.sig_kind = np.asarray(sig_kind, dtype=np.int32)
+        self.inter = np.asarray(inter, dtype=np.int32)
+        macro_route = np.asarray(macro_route, dtype=np.int32)
+        T = macro_route.shape[0]
+        self.T = T
+        prev = [[] for _ in range(L)]
+        nxt = [[] for _ in range(L)]
+        for a, b in np.asarray(edges, dtype=np.int64).tolist():
+            nxt[a].append(b)
+            prev[b].append(a)
+        self.next_lanes, self.prev_lanes = nxt, prev
+        is_macro = self.lane_macro == 1
+        route_prev = -np.ones((T, L), dtype=np.int32)
+        tt, aa = np.nonzero(macro_route >= 0)
+        route_prev[tt, macro_route[tt, aa]] = aa
+        self.left_src = -np.ones((T, L), dtype=np.int32)
+        self.left_gate = -np.ones((T, L), dtype=np.int32)
+        self.right_src = -np.ones((T, L), dtype=np.int32)
+        for l in range(L):
+            if not is_macro[l]:
+                continue
+            if len(prev[l]) == 0:
+                self.left_src[:, l] = -1
+                self.left_gate[:, l] = -2
+            elif len(prev[l]) == 1:
+                self.left_src[:, l] = prev[l][0] if is_macro[prev[l][0]] else -3
+                self.left_gate[:, l] = route_prev[:, l]
+            else:
+                if not all(is_macro[a] for a in prev[l]):
+                    raise ValueError("a macro lane with several upstream lanes needs all of them macro")
+                self.left_src[:, l] = route_prev[:, l]
+                self.left_gate[:, l] = route_prev[:, l]
+                if (route_prev[:, l] < 0).any():
+                    raise ValueError("a lane with several upstream lanes was left unmatched")
+            if len(nxt[l]) == 1:
+                self.right_src[:, l] = nxt[l][0] if is_macro[nxt[l][0]] else -1
+            elif len(nxt[l]) > 1:
+                if not all(is_macro[b] for b in nxt[l]):
+                    raise ValueError("a macro lane with several downstream lanes needs all of them macro")
+                self.right_src[:, l] = macro_route[:, l]
+                if (macro_route[:, l] < 0).any():
+                    raise ValueError("a lane with several downstream lanes was left unmatched")
+        for l in range(L):
+            if not is_macro[l] and len(prev[l]) == 0:
+                raise ValueError("micro source lanes (stochastic inflow, _simulator.py:153-174) are not supported")
+        self.conv_next = np.where(is_macro[None, :], macro_route, -1).astype(np.int32)
+        self.schedule = np.ascontiguousarray(np.asarray(schedule, dtype=np.float64).T)      # [T][L]

@@ -893,3 +893,5 @@ void oracle_net_macro_bwd(const oracle_net_desc *d, const int *lane_ncell, const
     for (int k = 0; k < d->n_action; k++) g_action[k] = (float)ga[k];
     free(g); free(gp); free(buf); free(own_r); free(sg); free(ga);
 }
+
+#include "dhts_oracle_hybrid.inc"

@@ -26,6 +26,7 @@ extern "C" {
 #define ORACLE_OK 0
 #define ORACLE_ERR_CFL 1
 #define ORACLE_ERR_COLLISION 2
+#define ORACLE_ERR_ROUTE 3        /* hybrid network: spawn without a matching pre-drawn route / lane over capacity */
 
 /* ---- ARZ: one interface -------------------------------------------------------------------- */
 /* L, R: (r, y, u, u_eq) of the left / right cell as doubles holding float32 values.
@@ -140,6 +141,26 @@ void oracle_net_macro_bwd(const oracle_net_desc *d, const int *lane_ncell, const
                           const int *sig_kind, const int *inter, const int *left_src, const int *left_gate,
                           const int *right_src, const double *schedule, const float *action,
                           const float *hist, const float *tape, const float *kc, const float *queue, float *g_action);
+
+/* ---- HYBRID road network (itscp `hybrid` mode): macro lanes + micro lanes + hand-offs ------------------------------
+ * As oracle_net_macro_* plus, per lane: lane_macro [L] (1 = ARZ cells, 0 = IDM vehicles; micro lanes have 0 cells),
+ * lane_len [L] double, and
+ *   left_src   additionally -3 = the lane's own stored upstream ghost (its single upstream lane is micro; with
+ *              left_gate -1 the blended ghost is the red value (0, u_max)),
+ *   right_src  -1 also for a macro lane whose single downstream lane is micro (own stored ghost, _simulator.py:116),
+ *   conv_next  [T][L] the step's macro-route successor of a macro lane (conversion target, road_network.py:113-130),
+ *   routes     [n_routes][route_stride] lane ids (-1 padded): the route of the k-th vehicle spawned (the reference
+ *              draws them with np.random at spawn time, road_network.py:604-646; the caller pre-draws / replays them).
+ * Forward and reverse sweep in one call: queue [T][L], *reward (all steps), *reward_cut and g_action
+ * (d reward_cut / d action, NULL = forward only) for the reward restricted to steps < t_cut; *n_spawned, *n_deposits;
+ * hist_out [T+1][4][C] optional.  rc = ORACLE_OK / ORACLE_ERR_CFL / ORACLE_ERR_ROUTE. */
+int oracle_net_hybrid(const oracle_net_desc *d, const int *lane_macro, const double *lane_len,
+                      const int *lane_ncell, const int *lane_off, const double *lane_dx,
+                      const int *sig_kind, const int *inter, const int *left_src, const int *left_gate,
+                      const int *right_src, const int *conv_next, const double *schedule,
+                      const int *routes, int n_routes, int route_stride, const float *action, int t_cut,
+                      float *queue, double *reward, double *reward_cut, float *g_action, int *n_spawned,
+                      int *n_deposits, float *hist_out);
 
 #ifdef __cplusplus
 }

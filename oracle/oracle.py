@@ -242,3 +242,30 @@ def net_macro(tab, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed
         l.oracle_net_macro_bwd(C.byref(d), *args, _p(hist), _p(tape), _p(kc), _p(queue), _p(g))
         out["g_action"] = g
     return out
+
+
+def net_hybrid(tab, routes, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0,
+               t_cut=None, want_grad=True, want_hist=False):
+    """tab: dhts.network.HybridNetworkTables; routes [n][stride] int (-1 padded) in spawn order."""
+    l = lib()
+    l.oracle_net_hybrid.argtypes = ([C.POINTER(NetDesc)] + [C.c_void_p] * 13 + [C.c_int, C.c_int, C.c_void_p, C.c_int]
+                                    + [C.c_void_p] * 7)
+    action = _f32(action)
+    T, L, Cn = tab.T, tab.n_lanes, tab.n_cells
+    d = NetDesc(L, Cn, T, int(n_inter_sq), int(frames_per_phase), len(action), float(dt), float(u_max), float(static_speed),
+                float(vehicle_length))
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)     # noqa: E731
+    routes = i32(routes)
+    args = [_p(i32(tab.lane_macro)), _p(_f64(tab.lane_length)), _p(i32(tab.lane_ncell)), _p(i32(tab.lane_off)), _p(_f64(tab.lane_dx)),
+            _p(i32(tab.sig_kind)), _p(i32(tab.inter)), _p(i32(tab.left_src)), _p(i32(tab.left_gate)), _p(i32(tab.right_src)),
+            _p(i32(tab.conv_next)), _p(_f64(tab.schedule)), _p(routes)]
+    queue = np.zeros((T, L), np.float32)
+    reward, reward_cut = C.c_double(0), C.c_double(0)
+    g = np.zeros(len(action), np.float32)
+    nsp, ndep = C.c_int(0), C.c_int(0)
+    hist = np.zeros((T + 1, 4, Cn), np.float32) if want_hist else None
+    rc = l.oracle_net_hybrid(C.byref(d), *args, routes.shape[0], routes.shape[1], _p(action), T if t_cut is None else int(t_cut),
+                             _p(queue), C.addressof(reward), C.addressof(reward_cut), _p(g) if want_grad else None,
+                             C.addressof(nsp), C.addressof(ndep), _p(hist) if want_hist else None)
+    return dict(rc=rc, reward=reward.value, reward_cut=reward_cut.value, queue=queue, g_action=g if want_grad else None,
+                n_spawned=nsp.value, n_deposits=ndep.value, hist=hist)

@@ -86,6 +86,23 @@ def test_device_interface_solver_vs_reference_kat(cuda, golden_dir, variant):
 
 
 @pytest.mark.parametrize("variant", [0, 1])
+def test_device_interface_solver_on_deposited_cells(cuda, golden_dir, variant):
+    """Cells rewritten by Conversion.micro_to_macro carry u, y of the deposited vehicle but the u_eq of the density
+    before the deposit (conversion.py:158-166): the solver must read each of r, y, u, u_eq where the reference does."""
+    from dhts import ops
+    g = load(golden_dir, "riemann_kat_stale.npz")
+    out = ops.arz_interface_batch(T_(g["inp"], cuda), variant=variant)
+    assert np.array_equal(out["case"].cpu().numpy(), g["case"])
+    tol = 1e-13 if variant == 1 else 2e-10
+    q0 = out["q0"].cpu().numpy()
+    assert np.max(np.abs(q0 - g["q0"]) / np.maximum(np.abs(g["q0"]), 1e-3)) <= tol
+    for key in ("dL", "dR", "fp"):
+        got, ref = out[key].cpu().numpy(), g[key]
+        scale = np.abs(ref).reshape(-1, 4).max(1).reshape(-1, 1, 1)
+        assert np.all(np.abs(got - ref) <= 1.2e-7 * np.maximum(scale, 1e-30)), key
+
+
+@pytest.mark.parametrize("variant", [0, 1])
 def test_device_idm_vs_reference_kat(cuda, golden_dir, variant):
     """G5 on the device: acceleration with both clips, Euler step, dEgo / dLeading, for the production arithmetic (0)
     and the reference-order IEEE version (1)."""

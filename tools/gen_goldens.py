@@ -181,6 +181,57 @@ def gen_riemann_kat(seed=20261002):
                         speed=speed, dL=dL, dR=dR, fp=fp, meta=meta(seed=seed, combos=combos))
 
 
+def gen_riemann_kat_stale(seed=20261003):
+    """Interface KATs on states as Conversion.micro_to_macro leaves them (conversion.py:124-166): r, u, y rewritten
+    from the deposited vehicle while the cell's u_eq still belongs to the density before the deposit."""
+    rng = np.random.default_rng(seed)
+    pairs = []
+
+    def deposited(um):
+        r_old = float(rng.choice([0.0, 1e-6, rng.uniform(0.0, 0.4), rng.uniform(0.0, 1.0)]))
+        fq = fullq_from_r_u_f32(r_old, rng.uniform(0.0, um), um)
+        n_r = th.tensor(min(max(r_old + rng.uniform(0.0, 1.0), 1e-5), 1.0 - 1e-5), dtype=th.float32)
+        speed = th.tensor(rng.uniform(0.0, um), dtype=th.float32)
+        fq.q.r = float(n_r)
+        fq.u = float(speed)
+        fq.q.y = float(ARZ.compute_y(n_r, speed, um))
+        return fq
+
+    def plain(um):
+        if rng.uniform() < 0.5:
+            return fullq_from_r_u_f32(rng.uniform(0.0, 1.0), rng.uniform(0.0, um), um)
+        return fullq_from_r_y_f32(rng.uniform(0.0, 1.2), rng.uniform(-4.0, 4.0), um)
+
+    for um in (60.0, 30.0, 13.5):
+        for _ in range(200):
+            pairs.append((deposited(um), plain(um), um))
+            pairs.append((plain(um), deposited(um), um))
+            pairs.append((deposited(um), deposited(um), um))
+    n = len(pairs)
+    inp = np.zeros((n, 9), dtype=np.float64)
+    case = np.zeros(n, dtype=np.int32)
+    branch = np.zeros(n, dtype=np.int32)
+    q0 = np.zeros((n, 4), dtype=np.float64)
+    speed = np.zeros((n, 2), dtype=np.float64)
+    dL = np.zeros((n, 2, 2), dtype=np.float32)
+    dR = np.zeros((n, 2, 2), dtype=np.float32)
+    fp = np.zeros((n, 2, 2), dtype=np.float32)
+    for i, (QL, QR, um) in enumerate(pairs):
+        inp[i] = (QL.q.r, QL.q.y, QL.u, QL.u_eq, QR.q.r, QR.q.y, QR.u, QR.u_eq, um)
+        rs = ARZ.riemann_solve(QL, QR, um)
+        case[i] = rs.case_ind
+        branch[i] = branch_of(QL, QR, um)
+        q0[i] = (rs.Q_0.q.r, rs.Q_0.q.y, rs.Q_0.u, rs.Q_0.u_eq)
+        speed[i] = (rs.speed0, rs.speed1)
+        a, b = dARZ.compute_dLdR(rs, QL, QR, um)
+        dL[i], dR[i] = a, b
+        fp[i] = dARZ.flux_prime(rs.Q_0)
+    combos = sorted(set(zip(branch.tolist(), case.tolist())))
+    print("G1s: %d stale-u_eq pairs, combos %s" % (n, combos))
+    np.savez_compressed(os.path.join(OUT, "riemann_kat_stale.npz"), inp=inp, case=case, branch=branch, q0=q0,
+                        speed=speed, dL=dL, dR=dR, fp=fp, meta=meta(seed=seed, combos=combos))
+
+
 # ----------------------------------------------------------------------------------------------
 # G3: one dMacroLane step
 # ----------------------------------------------------------------------------------------------
@@ -645,6 +696,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if "G1" in only:
         gen_riemann_kat()
+    if "G1s" in only:
+        gen_riemann_kat_stale()
     if "G3" in only:
         gen_macro_step()
     if "G4" in only:
@@ -662,9 +715,15 @@ def main():
         if "macro" in which:
             gen_itscp("macro", "macro", 1, 3, 30.0, 10, 2, seed=7, action_kind="rand")
         if "hybrid" in which:
+            # bisecting aids recorded with this case: gradients of the reward restricted to its first t0 steps and
+            # of the last-quarter loss of the lanes vehicles are deposited into (see tests/test_itscp_gpu.py)
+            os.environ.setdefault("DHTS_FINE_CUTS", "150,300,450,480,510,540,570")
+            os.environ.setdefault("DHTS_LANE_LATE", "16,54,82,116")
             gen_itscp(os.environ.get("DHTS_HYBRID_NAME", "hybrid"), "hybrid", 3, 1, 5.0, 20, 4, seed=9, action_kind="rand")
         if "hybrid_short" in which:      # 8 s: enough for the first vehicles to cross the interior intersection
             gen_itscp("hybrid_short", "hybrid", 3, 1, 5.0, 8, 2, seed=9, action_kind="rand")
+        if "hybrid_one" in which:        # one intersection: spawns and deposits (micro -> macro) within 8 s
+            gen_itscp("hybrid_one", "hybrid", 1, 1, 5.0, 8, 2, seed=11, action_kind="rand")
 
 
 if __name__ == "__main__":
