@@ -1,0 +1,1031 @@
+// hybrid_kernels.hip -- time-fused forward and reverse sweeps of a HYBRID road network (itscp `hybrid` mode): ARZ cell
+// lanes, IDM vehicle lanes and the hand-offs between them, one workgroup per network replica, on gfx950.
+//
+// Reference per step (example/control/itscp/_env.py:620-768; _simulator.py:56-276; road/network/road_network.py:79-170,
+// 429-580; road/network/conversion.py:11-215): signals -> boundaries of every lane (macro: blended ghost cells, micro: head
+// gap of the head vehicle) -> one step per lane -> commit -> hand-offs in lane-id order -> queue-length loss.
+//
+// Work split inside the workgroup: the macro side runs one item per thread exactly like network_kernels.hip (ghosts,
+// interface solves, cell updates, ordered prefix mean).  The micro side is a handful of vehicles: ONE lane of an extra
+// wavefront (the "micro thread") walks them serially, with all of its state in LDS, and writes every float32 operation it
+// performs -- with the partial derivatives -- to a per-replica record stream in HBM.  The reverse kernel replays that
+// stream backwards (the same thing torch autograd does for the reference) in step with the hand-written macro adjoint; the
+// two sides meet at the hand-off records (capacitor reads, deposits) and at the signals.
+//
+// Ids on the record stream: [0, 3V) = persistent slots of the vehicles (position, speed, ancillary a), [3V, 3V + 16) =
+// flux capacitors, above that the step's temporaries, renumbered from the same base every step; COMMIT records copy
+// temporaries into the slots at the end of a step, so the reverse kernel needs adjoint storage for one step only.
+#include <hip/hip_runtime.h>
+
+#include "../../include/dhts.h"
+#include "arz_device.hpp"
+#include "idm_device.hpp"
+#include "net_device.hpp"
+
+namespace dhts {
+
+constexpr int kMaxMicro = 64;        // micro lanes per network
+constexpr int kMaxCaps = 16;         // macro lanes with a micro successor
+constexpr int kLaneCap = 16;         // vehicles per micro lane
+constexpr int kMaxVeh = 128;         // vehicles per replica and episode
+constexpr int kRouteStride = 32;     // MAX_ROUTE_LENGTH, road_network.py:17
+constexpr int kMaxLocals = 2048;     // temporaries per step
+constexpr int kMaxStepRecords = 1024;
+constexpr int kWindow = 100000;      // RunningMean(100_000), _env.py:122
+
+enum { K_NODE = 1, K_COMMIT = 2, K_DEPOSIT = 3, K_CELLREAD = 4, K_SIGNAL = 5, K_SEED = 6, K_MARK = 7 };
+
+struct HybTables {
+    NetTables net;
+    const int32_t *lane_macro; const double *lane_len; const int32_t *conv_next; const int32_t *routes;
+    int n_routes, route_stride, loss_steps;
+};
+
+// workspace layout of one replica (bytes, all 16-byte aligned)
+struct HybWs {
+    size_t own_hist, rec_k, rec_i, rec_w, step_off, mark_off, xs, per_replica;
+    int rec_cap, V;
+};
+__host__ __device__ inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
+__host__ __device__ inline HybWs hyb_ws(int L, int C, int T, int n_routes, int records_per_step) {
+    HybWs w;
+    w.V = n_routes < kMaxVeh ? n_routes : kMaxVeh;
+    const int rps = records_per_step > 0 ? records_per_step : 512;
+    w.rec_cap = T * rps + 64;
+    size_t o = 0;
+    w.own_hist = o; o += up16(sizeof(float) * (size_t)T * 2 * L);
+    w.rec_k = o; o += up16(sizeof(int) * (size_t)w.rec_cap);
+    w.rec_i = o; o += up16(sizeof(int4) * (size_t)w.rec_cap);
+    w.rec_w = o; o += up16(sizeof(float4) * (size_t)w.rec_cap);
+    w.step_off = o; o += up16(sizeof(int) * (size_t)(T + 1));
+    w.mark_off = o; o += up16(sizeof(int) * (size_t)(T + 1));
+    w.xs = o; o += up16(sizeof(float) * (size_t)T * (size_t)(C + kMaxVeh));
+    w.per_replica = o;
+    return w;
+}
+
+struct Tv { float val; int id; };
+__device__ __forceinline__ Tv tv_c(float v) { Tv x; x.val = v; x.id = -1; return x; }
+
+struct Rec {               // the micro thread's handle on the record stream
+    int *k; int4 *i; float4 *w;
+    int n, cap, next_local, base_local;
+    bool over;
+};
+__device__ __forceinline__ void rec_push(Rec &R, int kind, int out, int4 in, float4 w) {
+    if (R.n >= R.cap) { R.over = true; return; }
+    R.k[R.n] = (kind << 24) | (out & 0xffffff); R.i[R.n] = in; R.w[R.n] = w; ++R.n;
+}
+__device__ __forceinline__ Tv tv_leaf(Rec &R, float v) { Tv x; x.val = v; x.id = R.next_local++; return x; }
+__device__ __forceinline__ Tv tv_node4(Rec &R, float v, Tv a, float wa, Tv b, float wb, Tv c, float wc, Tv d, float wd) {
+    if (a.id < 0 && b.id < 0 && c.id < 0 && d.id < 0) return tv_c(v);
+    Tv x; x.val = v; x.id = R.next_local++;
+    rec_push(R, K_NODE, x.id, make_int4(a.id, b.id, c.id, d.id), make_float4(wa, wb, wc, wd));
+    return x;
+}
+__device__ __forceinline__ Tv tv_node2(Rec &R, float v, Tv a, float wa, Tv b, float wb) {
+    return tv_node4(R, v, a, wa, b, wb, tv_c(0.f), 0.f, tv_c(0.f), 0.f);
+}
+__device__ __forceinline__ Tv tv_add(Rec &R, Tv a, Tv b) { return tv_node2(R, a.val + b.val, a, 1.f, b, 1.f); }
+__device__ __forceinline__ Tv tv_sub(Rec &R, Tv a, Tv b) { return tv_node2(R, a.val - b.val, a, 1.f, b, -1.f); }
+__device__ __forceinline__ Tv tv_mul(Rec &R, Tv a, Tv b) { return tv_node2(R, a.val * b.val, a, b.val, b, a.val); }
+__device__ __forceinline__ Tv tv_div(Rec &R, Tv a, Tv b) {
+    return tv_node2(R, a.val / b.val, a, 1.f / b.val, b, -((a.val / b.val) / b.val));
+}
+__device__ __forceinline__ Tv tv_soft(Rec &R, Tv a, float k) {
+    return tv_node2(R, soft_switch(a.val, k), a, soft_switch_grad(a.val, k), tv_c(0.f), 0.f);
+}
+__device__ __forceinline__ Tv tv_pos_or_zero(Tv a) { return a.val > 0.f ? a : tv_c(0.f); }
+
+// sample `idx - kWindow` of the loss' running-mean stream (written hundreds of steps earlier by another thread of this
+// workgroup: read around the vector L1)
+__device__ __forceinline__ float stream_load(const float *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// LDS carve-up shared by both kernels' host wrappers
+struct HybLds {
+    size_t fq, scanw, incl, vsp, vep, s0, s1, g, ab, contrib, ql, sig, lanelen, vp, vv, va, vxold, hdpv, hdvv, capv, qmicro,
+        cell_lane, iface_lane, cnext, vidp, vidv, vida, vcur, vrlen, vroute, lane_n, lane_veh, hdpi, hdvi, vcp, capi, mslot,
+        capof, mlane, cbefore, convlist, linfo, caplast, total;
+};
+__host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V) {
+    HybLds o; size_t p = 0; const int NI = C + L;
+    auto D = [&](size_t n) { size_t r = p; p += 8 * n; return r; };
+    auto F = [&](size_t n) { size_t r = p; p += 4 * ((n + 1) & ~(size_t)1); return r; };
+    o.fq = D(2 * (size_t)NI); o.scanw = D(32); o.incl = D(2 * (size_t)C); o.vsp = D(kMaxMicro + 1); o.vep = D(kMaxMicro + 1);
+    o.s0 = F(4 * (size_t)C); o.s1 = F(4 * (size_t)C); o.g = F(8 * (size_t)L); o.ab = F(8 * (size_t)NI); o.contrib = F(C); o.ql = F(L);
+    o.sig = F(2 * (size_t)sq); o.lanelen = F(L); o.vp = F(V); o.vv = F(V); o.va = F(V); o.vxold = F(V);
+    o.hdpv = F(kMaxMicro); o.hdvv = F(kMaxMicro); o.capv = F(kMaxCaps); o.qmicro = F(kMaxMicro);
+    o.cell_lane = F(C); o.iface_lane = F(NI); o.cnext = F(L); o.vidp = F(V); o.vidv = F(V); o.vida = F(V); o.vcur = F(V);
+    o.vrlen = F(V); o.vroute = F((size_t)V * kRouteStride); o.lane_n = F(kMaxMicro); o.lane_veh = F(kMaxMicro * kLaneCap);
+    o.hdpi = F(kMaxMicro); o.hdvi = F(kMaxMicro); o.vcp = F(kMaxMicro + 1); o.capi = F(kMaxCaps); o.mslot = F(L); o.capof = F(L);
+    o.mlane = F(kMaxMicro); o.cbefore = F(kMaxMicro + 1); o.convlist = F(L); o.linfo = F(L); o.caplast = F(kMaxCaps);
+    o.total = p;
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
+                                      double static_speed, double veh_len, HybTables tb, const float *__restrict__ action,
+                                      float *__restrict__ hist, float4 *__restrict__ tape, float *__restrict__ kc,
+                                      float *__restrict__ queue, float *__restrict__ reward, int *__restrict__ counts,
+                                      char *__restrict__ workspace, int records_per_step, dhts_error *err) {
+    extern __shared__ double lds_d[];
+    char *lds = reinterpret_cast<char *>(lds_d);
+    const int rep = blockIdx.x, tid = threadIdx.x, B = blockDim.x;
+    const int NI = C + L, Cp = (C + 63) & ~63;
+    const HybWs ws = hyb_ws(L, C, T, tb.n_routes, records_per_step);
+    const int V = ws.V;
+    const HybLds lo = hyb_lds(L, C, sq, V);
+    double *Fq = reinterpret_cast<double *>(lds + lo.fq), *scanw = reinterpret_cast<double *>(lds + lo.scanw);
+    double *incl = reinterpret_cast<double *>(lds + lo.incl), *vsp = reinterpret_cast<double *>(lds + lo.vsp), *vep = reinterpret_cast<double *>(lds + lo.vep);
+#define LF(name) reinterpret_cast<float *>(lds + lo.name)
+#define LI(name) reinterpret_cast<int *>(lds + lo.name)
+    float *S0 = LF(s0), *S1 = LF(s1), *G = LF(g), *AB = LF(ab), *contrib = LF(contrib), *ql = LF(ql), *sig = LF(sig), *lanelen = LF(lanelen);
+    float *vp = LF(vp), *vv = LF(vv), *va = LF(va), *vxold = LF(vxold), *hdpv = LF(hdpv), *hdvv = LF(hdvv), *capv = LF(capv), *qmicro = LF(qmicro);
+    int *cell_lane_s = LI(cell_lane), *iface_lane_s = LI(iface_lane), *cnext = LI(cnext), *vidp = LI(vidp), *vidv = LI(vidv), *vida = LI(vida);
+    int *vcur = LI(vcur), *vrlen = LI(vrlen), *vroute = LI(vroute), *lane_n = LI(lane_n), *lane_veh = LI(lane_veh), *hdpi = LI(hdpi), *hdvi = LI(hdvi);
+    int *vcp = LI(vcp), *capi = LI(capi), *mslot = LI(mslot), *capof = LI(capof), *mlane = LI(mlane), *cbefore = LI(cbefore), *convlist = LI(convlist), *linfo = LI(linfo), *caplast = LI(caplast);
+    const float um = (float)um_d, s0f = (float)static_speed, vlen = (float)veh_len, dtf = (float)dt;
+    const float *act = action + (size_t)rep * n_action;
+    const size_t toff = (size_t)rep * tb.net.table_stride;
+    float *hist_r = hist + (size_t)rep * (T + 1) * 4 * C;
+    float4 *tape_r = tape + (size_t)rep * T * 3 * Cp;
+    float *kc_r = kc + (size_t)rep * T * C;
+    float *queue_r = queue + (size_t)rep * T * L;
+    char *wsr = workspace + (size_t)rep * ws.per_replica;
+    float *own_w = reinterpret_cast<float *>(wsr + ws.own_hist);
+    int *step_off = reinterpret_cast<int *>(wsr + ws.step_off), *mark_off = reinterpret_cast<int *>(wsr + ws.mark_off);
+    float *xs = reinterpret_cast<float *>(wsr + ws.xs);
+    const bool is_mt = (tid == B - 64);            // the micro thread: lane 0 of the extra wavefront
+    const int loss_steps = tb.loss_steps > 0 ? tb.loss_steps : T;
+
+    // ---- setup: maps, static lists
+    if (tid < L) {
+        const int off = tb.net.lane_off[tid], n = tb.net.lane_ncell[tid];
+        for (int i = 0; i < n; ++i) cell_lane_s[off + i] = tid;
+        lanelen[tid] = (float)tb.lane_len[tid];
+        linfo[tid] = tb.net.sig_kind[tid] | (tb.net.inter[tid] << 2);
+        ql[tid] = 0.f;
+    }
+    if (tid < C) {
+        S0[tid] = 0.f; S0[C + tid] = 0.f; S0[2 * C + tid] = um; S0[3 * C + tid] = um;
+        hist_r[tid] = 0.f; hist_r[C + tid] = 0.f; hist_r[2 * C + tid] = um; hist_r[3 * C + tid] = um;
+    }
+    __syncthreads();
+    int n_micro = 0, n_caps = 0, n_conv = 0, n_macro = 0;
+    if (tid == 0) {
+        // interface numbering: lane l (macro) owns interfaces [off + (macro lanes before l), ... + n]
+        int mac = 0, nm = 0, nc = 0, nv = 0, cells = 0;
+        for (int l = 0; l < L; ++l) {
+            mslot[l] = -1; capof[l] = -1;
+            if (tb.lane_macro[l]) {
+                const int off = tb.net.lane_off[l], n = tb.net.lane_ncell[l];
+                for (int k = 0; k <= n; ++k) iface_lane_s[off + mac + k] = l;
+                ++mac; cells += n;
+                bool spawns = false;
+                for (int e = tb.net.nxt_ptr[l]; e < tb.net.nxt_ptr[l + 1]; ++e) spawns |= !tb.lane_macro[tb.net.nxt_idx[e]];
+                if (spawns) { if (nc < kMaxCaps) { capof[l] = nc; caplast[nc] = off + n - 1; } ++nc; convlist[nv++] = l; }
+            } else {
+                if (nm < kMaxMicro) { mslot[l] = nm; mlane[nm] = l; cbefore[nm] = cells; lane_n[nm] = 0; }
+                ++nm; convlist[nv++] = l;
+            }
+        }
+        cbefore[nm < kMaxMicro ? nm : kMaxMicro] = cells;
+        scanw[0] = (double)mac; scanw[1] = (double)nm; scanw[2] = (double)nc; scanw[3] = (double)nv;
+    }
+    __syncthreads();
+    n_macro = (int)scanw[0]; n_micro = (int)scanw[1]; n_caps = (int)scanw[2]; n_conv = (int)scanw[3];
+    const int NIm = C + n_macro;                     // interfaces that exist
+    if (n_micro > kMaxMicro || n_caps > kMaxCaps) { if (tid == 0) net_fault(err, DHTS_FAULT_CAPACITY, -1, 0, n_micro); return; }
+    __syncthreads();
+    (void)NI;
+    // ---- per-thread roles
+    const bool is_if = tid < NIm, is_cell = tid < C, is_ghost = tid < 2 * L, is_lane = tid < L;
+    int i_lane = 0, i_k = 0, i_n = 0, i_off = 0, i_mb = 0;
+    IfaceConst kconst;
+    kconst.um = um_d; kconst.inv_um = 1.0 / um_d; kconst.inv_15um = 1.0 / (kG1 * um_d); kconst.dt = dt; kconst.dx = 1.0;
+    int c_lane = 0, c_mb = 0, c_macb = 0; double c_cc = 0.; float c_dxv = 0.f;
+    if (is_cell) {
+        c_lane = cell_lane_s[tid]; c_cc = dt / tb.net.lane_dx[c_lane]; c_dxv = (float)tb.net.lane_dx[c_lane] / vlen;
+        for (int l = 0; l < c_lane; ++l) { if (tb.lane_macro[l]) ++c_macb; else ++c_mb; }
+    }
+    if (is_if) {
+        i_lane = iface_lane_s[tid]; i_off = tb.net.lane_off[i_lane]; i_n = tb.net.lane_ncell[i_lane];
+        for (int l = 0; l < i_lane; ++l) if (tb.lane_macro[l]) ++i_mb;
+        i_k = tid - i_off - i_mb;
+        kconst.dx = tb.net.lane_dx[i_lane];
+    }
+    const int g_lane = tid >> 1, g_side = tid & 1;
+    int g_kind = 0, g_inter = 0; bool g_macro = false;
+    float own_r = 0.f, own_u = um;
+    if (is_ghost) { g_kind = tb.net.sig_kind[g_lane]; g_inter = tb.net.inter[g_lane]; g_macro = tb.lane_macro[g_lane] != 0; }
+    int l_off = 0, l_n = 0, l_ms = -1; bool l_macro = false;
+    if (is_lane) { l_off = tb.net.lane_off[tid]; l_n = tb.net.lane_ncell[tid]; l_ms = mslot[tid]; l_macro = tb.lane_macro[tid] != 0; }
+    // signals of step 0
+    if (tid < sq) { float we, ns, a, pr; int ai; phase_signal(act, n_action, sq, F, 0, tid, we, ns, a, pr, ai); sig[2 * tid] = we; sig[2 * tid + 1] = ns; }
+
+    // ---- micro thread state
+    Rec rec;
+    rec.k = reinterpret_cast<int *>(wsr + ws.rec_k); rec.i = reinterpret_cast<int4 *>(wsr + ws.rec_i);
+    rec.w = reinterpret_cast<float4 *>(wsr + ws.rec_w);
+    rec.n = 0; rec.cap = ws.rec_cap; rec.base_local = 3 * V + kMaxCaps; rec.next_local = rec.base_local; rec.over = false;
+    int spawned = 0, deposits = 0; bool cap_fault = false;
+    IdmParams idm;
+    idm.a_max = um_d * 1.0; idm.a_pref = um_d * 0.8; idm.v_target = um_d * 0.9; idm.min_space = veh_len * 0.1; idm.time_pref = 0.1; idm.length = veh_len;
+    double sig_sum = 0.; long long sig_cnt = 0;          // signal_rms (never reaches its window in one episode)
+    if (is_mt) for (int j = 0; j < kMaxCaps; ++j) { capv[j] = 0.f; capi[j] = -1; }
+    __syncthreads();
+
+    double run_in = 0., run_out = 0.; long long run_cnt = 0;
+    float lane_total = 0.f;
+    int fault_step = -1, fault_index = 0;
+
+    for (int t = 0; t < T; ++t) {
+        const float *cur = (t & 1) ? S1 : S0;
+        float *nxt = (t & 1) ? S0 : S1;
+        // ================= P1: boundaries =================
+        if (is_lane) cnext[tid] = tb.conv_next[toff + (size_t)t * L + tid];
+        if (is_ghost && g_macro) {
+            float fr, fu, fy, fq;
+            const size_t o = toff + (size_t)t * L + g_lane;
+            if (g_side == 0) {
+                const int src = tb.net.left_src[o], gate = tb.net.left_gate[o];
+                if (src == -1) {
+                    const double sched = tb.net.schedule[o];
+                    const double gu = um_d * (1. - sqrt(fmax(sched, 0.) + kEps));
+                    fr = (float)sched; fu = (float)gu; fy = 0.f; fq = (float)gu;
+                } else {
+                    float gr = 0.f, gu = um;             // src == -3: own stored ghost behind a red gate
+                    if (src >= 0) { const int last = tb.net.lane_off[src] + tb.net.lane_ncell[src] - 1; gr = cur[last]; gu = cur[2 * C + last]; }
+                    float s = 1.f;
+                    if (gate == -1) s = 0.f;
+                    else if (gate >= 0) { const int kd = tb.net.sig_kind[gate]; if (kd != 0) s = sig[2 * tb.net.inter[gate] + (kd - 1)]; }
+                    fr = gr * s + 0.f * (1.0f - s);
+                    fu = gu * s + um * (1.0f - s);
+                    glue_from_r_u(fr, fu, um, fy, fq);
+                }
+            } else {
+                const int src = tb.net.right_src[o];
+                float gr = own_r, gu = own_u;
+                if (src >= 0) { const int first = tb.net.lane_off[src]; gr = cur[first]; gu = cur[2 * C + first]; }
+                own_w[(size_t)t * 2 * L + 2 * g_lane] = own_r; own_w[(size_t)t * 2 * L + 2 * g_lane + 1] = own_u;
+                const float sg = g_kind != 0 ? sig[2 * g_inter + (g_kind - 1)] : 1.f;
+                const float s2 = soft_switch(sg - 0.5f, kSigK);
+                fr = s2 * gr + (1.0f - s2) * 1.0f;
+                fu = s2 * gu + (1.0f - s2) * 0.0f;
+                glue_from_r_u(fr, fu, um, fy, fq);
+                own_r = fr; own_u = fu;
+            }
+            float *g = G + (size_t)tid * 4;
+            g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
+        }
+        if (is_mt) {
+            step_off[t] = rec.n;
+            rec.next_local = rec.base_local;
+            for (int k = 0; k < n_micro; ++k) {
+                hdpv[k] = 1000.f; hdvv[k] = 0.f; hdpi[k] = -1; hdvi[k] = -1;
+                const int nv = lane_n[k];
+                if (nv == 0) continue;
+                const int l = mlane[k];
+                const int hv = lane_veh[k * kLaneCap + nv - 1];
+                const int *route = vroute + hv * kRouteStride;
+                const int rlen = vrlen[hv], cursor = vcur[hv];
+                Tv hp; hp.val = vp[hv]; hp.id = vidp[hv];
+                Tv hs; hs.val = vv[hv]; hs.id = vidv[hv];
+                const Tv Lc = tv_c(lanelen[l]), half = tv_c(vlen * 0.5f);
+                Tv reach = tv_sub(rec, tv_sub(rec, Lc, hp), half);
+                Tv green_dp = tv_c(1000.f), green_dv = tv_c(0.f);
+                for (int j = cursor; j < rlen - 1; ++j) {
+                    const int there = route[j + 1];
+                    const int ms = mslot[there];
+                    if (ms < 0) break;                       // macro successor: defaults
+                    if (lane_n[ms]) {
+                        const int lv = lane_veh[ms * kLaneCap + 0];
+                        Tv lp; lp.val = vp[lv]; lp.id = vidp[lv];
+                        Tv lsp; lsp.val = vv[lv]; lsp.id = vidv[lv];
+                        green_dp = tv_pos_or_zero(tv_add(rec, reach, tv_sub(rec, lp, half)));
+                        green_dv = tv_sub(rec, hs, lsp);
+                        break;
+                    }
+                    reach = tv_add(rec, reach, tv_c(lanelen[there]));
+                }
+                Tv red_dp = tv_pos_or_zero(tv_sub(rec, tv_sub(rec, Lc, hp), half));
+                const bool prev_exist = cursor > 0, next_exist = cursor < rlen - 1;
+                Tv prev_s = tv_c(0.f), next_s = tv_c(0.f);
+                if (prev_exist) prev_s = tv_soft(rec, tv_sub(rec, tv_c(0.f), hp), 16.f);
+                Tv curr_s = tv_mul(rec, tv_soft(rec, hp, 16.f), tv_soft(rec, tv_sub(rec, Lc, hp), 16.f));
+                if (next_exist) next_s = tv_soft(rec, tv_sub(rec, hp, Lc), 16.f);
+                Tv total = tv_add(rec, tv_add(rec, prev_s, curr_s), next_s);
+                Tv fin = tv_c(0.f);
+                for (int w = 0; w < 3; ++w) {
+                    if ((w == 0 && !prev_exist) || (w == 2 && !next_exist)) continue;
+                    const int lid = route[cursor + w - 1];
+                    const Tv sc = w == 0 ? prev_s : (w == 1 ? curr_s : next_s);
+                    Tv sv = tv_c(1.f);
+                    const int kd = linfo[lid] & 3;
+                    if (kd != 0) {
+                        const int it = linfo[lid] >> 2;
+                        sv = tv_leaf(rec, sig[2 * it + (kd - 1)]);
+                        rec_push(rec, K_SIGNAL, 0, make_int4(sv.id, it, kd, 0), make_float4(0.f, 0.f, 0.f, 0.f));
+                    }
+                    fin = tv_add(rec, fin, tv_mul(rec, tv_div(rec, sc, total), sv));
+                }
+                sig_sum += (double)fin.val; ++sig_cnt;
+                const float k2 = 32.f / fabsf((float)(sig_sum / (double)sig_cnt));
+                Tv fs = tv_soft(rec, tv_sub(rec, fin, tv_c(0.5f)), k2);
+                Tv one_m = tv_sub(rec, tv_c(1.f), fs);
+                Tv dp_ = tv_add(rec, tv_mul(rec, green_dp, fs), tv_mul(rec, red_dp, one_m));
+                Tv dv_ = tv_add(rec, tv_mul(rec, green_dv, fs), tv_mul(rec, tv_c(0.f), one_m));
+                hdpv[k] = dp_.val; hdpi[k] = dp_.id; hdvv[k] = dv_.val; hdvi[k] = dv_.id;
+            }
+        }
+        lds_barrier();
+        // ================= P2: interface solves | IDM steps =================
+        if (is_if) {
+            const float *gl = G + (size_t)(2 * i_lane) * 4, *gr_ = G + (size_t)(2 * i_lane + 1) * 4;
+            double rL, yL, uL, qL, rR, yR, uR, qR;
+            if (i_k == 0) { rL = gl[0]; yL = gl[1]; uL = gl[2]; qL = gl[3]; }
+            else { const int c = i_off + i_k - 1; rL = cur[c]; yL = cur[C + c]; uL = cur[2 * C + c]; qL = cur[3 * C + c]; }
+            if (i_k == i_n) { rR = gr_[0]; yR = gr_[1]; uR = gr_[2]; qR = gr_[3]; }
+            else { const int c = i_off + i_k; rR = cur[c]; yR = cur[C + c]; uR = cur[2 * C + c]; qR = cur[3 * C + c]; }
+            Iface f;
+            arz_interface(rL, yL, uL, qL, rR, yR, uR, qR, kconst, f);
+            if (f.cfl_bad && fault_step < 0) { fault_step = t; fault_index = i_k; }
+            Fq[2 * tid] = f.Fr; Fq[2 * tid + 1] = f.Fy;
+            float *ab = AB + (size_t)tid * 8;
+            ab[0] = f.A[0]; ab[1] = f.A[1]; ab[2] = f.A[2]; ab[3] = f.A[3];
+            ab[4] = f.B[0]; ab[5] = f.B[1]; ab[6] = f.B[2]; ab[7] = f.B[3];
+        }
+        if (is_mt) {
+            for (int k = 0; k < n_micro; ++k) {
+                const int nv = lane_n[k];
+                if (nv == 0) continue;
+                Tv newp[kLaneCap], newv[kLaneCap];
+                Tv hd_p; hd_p.val = hdpv[k]; hd_p.id = hdpi[k];
+                Tv hd_v; hd_v.val = hdvv[k]; hd_v.id = hdvi[k];
+                for (int i = 0; i < nv; ++i) {
+                    const int vi = lane_veh[k * kLaneCap + i];
+                    Tv p_; p_.val = vp[vi]; p_.id = vidp[vi];
+                    Tv v_; v_.val = vv[vi]; v_.id = vidv[vi];
+                    IdmStep o;
+                    if (i == nv - 1) {
+                        idm_step_ieee((double)p_.val, (double)v_.val, (double)hd_p.val, (double)hd_v.val, idm, dt, o);
+                        newp[i] = tv_node4(rec, o.np, p_, o.dE[0] + o.dLd[0], v_, o.dE[1] + o.dLd[1], hd_p, o.dLd[0], hd_v, -o.dLd[1]);
+                        newv[i] = tv_node4(rec, o.nv, p_, o.dE[2] + o.dLd[2], v_, o.dE[3] + o.dLd[3], hd_p, o.dLd[2], hd_v, -o.dLd[3]);
+                    } else {
+                        const int vj = lane_veh[k * kLaneCap + i + 1];
+                        Tv pl; pl.val = vp[vj]; pl.id = vidp[vj];
+                        Tv vl; vl.val = vv[vj]; vl.id = vidv[vj];
+                        const double dp = fabs((double)pl.val - (double)p_.val) - ((veh_len + veh_len) * 0.5);
+                        const double dv = (double)v_.val - (double)vl.val;
+                        idm_step_ieee((double)p_.val, (double)v_.val, dp, dv, idm, dt, o);
+                        newp[i] = tv_node4(rec, o.np, p_, o.dE[0], v_, o.dE[1], pl, o.dLd[0], vl, o.dLd[1]);
+                        newv[i] = tv_node4(rec, o.nv, p_, o.dE[2], v_, o.dE[3], pl, o.dLd[2], vl, o.dLd[3]);
+                    }
+                    if (newp[i].id < 0) newp[i] = tv_leaf(rec, o.np);
+                    if (newv[i].id < 0) newv[i] = tv_leaf(rec, o.nv);
+                }
+                for (int i = 0; i < nv; ++i) {
+                    const int vi = lane_veh[k * kLaneCap + i];
+                    vp[vi] = newp[i].val; vidp[vi] = newp[i].id; vv[vi] = newv[i].val; vidv[vi] = newv[i].id;
+                }
+            }
+        }
+        lds_barrier();
+        // ================= P3: cell updates + tape | next step's signals =================
+        if (is_cell) {
+            const int c = tid;
+            const float cf = (float)c_cc, ncf = (float)(-c_cc);
+            const int iL = c + c_macb, iR = iL + 1;
+            const float nr = (float)((double)cur[c] + (Fq[2 * iL] - Fq[2 * iR]) * c_cc);
+            const float ny = (float)((double)cur[C + c] + (Fq[2 * iL + 1] - Fq[2 * iR + 1]) * c_cc);
+            float nu, nq;
+            glue_from_r_y(nr, ny, um, nu, nq);
+            nxt[c] = nr; nxt[C + c] = ny; nxt[2 * C + c] = nu; nxt[3 * C + c] = nq;
+            const float *aL = AB + (size_t)iL * 8, *aR = AB + (size_t)iR * 8;
+            float4 d0, d1, d2;
+            d0.x = ncf * (-aL[0]); d0.y = ncf * (-aL[1]); d0.z = ncf * (-aL[2]); d0.w = ncf * (-aL[3]);
+            d2.x = ncf * aR[4]; d2.y = ncf * aR[5]; d2.z = ncf * aR[6]; d2.w = ncf * aR[7];
+            d1.x = 1.f - cf * (aR[0] - aL[4]); d1.y = 0.f - cf * (aR[1] - aL[5]);
+            d1.z = 0.f - cf * (aR[2] - aL[6]); d1.w = 1.f - cf * (aR[3] - aL[7]);
+            float4 *tp = tape_r + (size_t)t * 3 * Cp;
+            tp[c] = d0; tp[Cp + c] = d1; tp[2 * Cp + c] = d2;
+        }
+        if (tid < sq && t + 1 < T) { float we, ns, a, pr; int ai; phase_signal(act, n_action, sq, F, t + 1, tid, we, ns, a, pr, ai); sig[2 * tid] = we; sig[2 * tid + 1] = ns; }
+        lds_barrier();
+        // ================= P4: hand-offs in lane-id order (micro thread) =================
+        if (is_mt) {
+            mark_off[t] = rec.n;
+            rec_push(rec, K_MARK, 0, make_int4(0, 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f));
+            for (int ci = 0; ci < n_conv; ++ci) {
+                const int l = convlist[ci];
+                if (capof[l] >= 0) {
+                    const int m = cnext[l];
+                    if (m < 0 || mslot[m] < 0) continue;
+                    const int j = capof[l], ms = mslot[m];
+                    const int last = caplast[j];
+                    const float rl = nxt[last], ul = nxt[2 * C + last];
+                    Tv lr = tv_leaf(rec, rl), lu = tv_leaf(rec, ul);
+                    rec_push(rec, K_CELLREAD, 0, make_int4(lr.id, lu.id, last, 0), make_float4(0.f, 0.f, 0.f, 0.f));
+                    Tv cp; cp.val = capv[j]; cp.id = capi[j];
+                    cp = tv_add(rec, cp, tv_mul(rec, tv_mul(rec, lr, lu), tv_c(dtf)));
+                    capv[j] = cp.val; capi[j] = cp.id;
+                    const float level = cp.val;
+                    float space = lanelen[m];
+                    if (lane_n[ms]) space = vp[lane_veh[ms * kLaneCap + 0]] - 0.5f * vlen;
+                    if (level >= vlen && space >= vlen * 1.0f) {
+                        if (spawned >= V || lane_n[ms] >= kLaneCap || tb.routes[(size_t)spawned * tb.route_stride] != m) { cap_fault = true; continue; }
+                        const int vi = spawned;
+                        vp[vi] = 0.f; vidp[vi] = -1; vv[vi] = ul; vidv[vi] = lu.id;
+                        va[vi] = cp.val - (float)((double)level - veh_len); vida[vi] = cp.id;
+                        vcur[vi] = 0;
+                        int rl_ = 0;
+                        for (int q = 0; q < kRouteStride; ++q) {
+                            const int lid = q < tb.route_stride ? tb.routes[(size_t)spawned * tb.route_stride + q] : -1;
+                            vroute[vi * kRouteStride + q] = lid;
+                            if (lid >= 0 && rl_ == q) rl_ = q + 1;
+                        }
+                        vrlen[vi] = rl_;
+                        capv[j] = (float)((double)level - veh_len); capi[j] = -1;
+                        for (int q = lane_n[ms]; q > 0; --q) lane_veh[ms * kLaneCap + q] = lane_veh[ms * kLaneCap + q - 1];
+                        lane_veh[ms * kLaneCap + 0] = vi;
+                        ++lane_n[ms];
+                        ++spawned;
+                    }
+                    continue;
+                }
+                const int k = mslot[l];
+                const int nv = lane_n[k];
+                if (nv == 0) continue;
+                const int vi = lane_veh[k * kLaneCap + nv - 1];
+                const int cursor = vcur[vi], rlen = vrlen[vi];
+                const int nid = cursor < rlen - 1 ? vroute[vi * kRouteStride + cursor + 1] : -1;
+                const float Lf = lanelen[l];
+                if (nid == -1) {
+                    if (vp[vi] >= Lf) --lane_n[k];
+                } else if (mslot[nid] >= 0) {
+                    if (vp[vi] >= Lf) {
+                        const int ms = mslot[nid];
+                        if (lane_n[ms] >= kLaneCap) { cap_fault = true; continue; }
+                        --lane_n[k];
+                        Tv p_; p_.val = vp[vi]; p_.id = vidp[vi];
+                        p_ = tv_sub(rec, p_, tv_c(Lf));
+                        vp[vi] = p_.val; vidp[vi] = p_.id;
+                        for (int q = lane_n[ms]; q > 0; --q) lane_veh[ms * kLaneCap + q] = lane_veh[ms * kLaneCap + q - 1];
+                        lane_veh[ms * kLaneCap + 0] = vi;
+                        ++lane_n[ms];
+                        ++vcur[vi];
+                    }
+                } else if (vp[vi] > Lf + 1.0f * vlen) {
+                    --lane_n[k];
+                    ++deposits;
+                    const float front = vp[vi] - Lf, rear = front - vlen;
+                    const double dxd = tb.net.lane_dx[nid];
+                    const float dx = (float)dxd;
+                    const int ncell = tb.net.lane_ncell[nid], off = tb.net.lane_off[nid];
+                    for (int q = 0; q < ncell; ++q) {
+                        const double c_lo = dxd * q, c_hi = dxd * (q + 1);
+                        if (!(c_hi > (double)rear && c_lo < (double)front)) break;
+                        const bool hi_is_front = (double)front > c_hi, lo_is_rear = (double)rear < c_lo;
+                        const float hi = hi_is_front ? front : (float)c_hi, lo = lo_is_rear ? rear : (float)c_lo;
+                        const float overlap = dx + vlen - (hi - lo);
+                        const int cell = off + q;
+                        float n_r = nxt[cell] + (va[vi] / vlen) * (overlap / dx);
+                        if (n_r > 1.0f - 1e-5f) n_r = n_r - (float)((double)n_r - (1.0 - 1e-5));
+                        else if (n_r < 1e-5f) n_r = n_r - (float)((double)n_r - 1e-5);
+                        rec_push(rec, K_DEPOSIT, nid, make_int4(vida[vi], vidp[vi], vidv[vi], cell),
+                                 make_float4(overlap, (float)(-(int)hi_is_front + (int)lo_is_rear), n_r, va[vi]));
+                        float yy, qq;
+                        glue_from_r_u(n_r, vv[vi], um, yy, qq);
+                        nxt[cell] = n_r; nxt[C + cell] = yy; nxt[2 * C + cell] = vv[vi];     // u_eq keeps its pre-deposit value
+                    }
+                }
+            }
+            // vehicle samples of the loss' running mean, per micro lane in id order
+            int cnt = 0; double ssum = 0., esum = 0.;
+            for (int k = 0; k < n_micro; ++k) {
+                vcp[k] = cnt; vsp[k] = ssum; vep[k] = esum;
+                for (int i = 0; i < lane_n[k]; ++i) {
+                    const int vi = lane_veh[k * kLaneCap + i];
+                    const long long idx = run_cnt + cbefore[k] + cnt;
+                    const float x = s0f - vv[vi];
+                    float xo = 0.f;
+                    if (idx >= kWindow) xo = stream_load(xs + (idx - kWindow));
+                    xs[idx] = x; vxold[vi] = xo;
+                    ssum += (double)x; esum += (double)xo; ++cnt;
+                }
+            }
+            vcp[n_micro] = cnt; vsp[n_micro] = ssum; vep[n_micro] = esum;
+        }
+        __syncthreads();
+        // ================= P5a: ordered scans over the cells (new samples and the ones leaving the window) ==========
+        float x_new = 0.f;
+        {
+            double a = 0., b = 0.;
+            if (is_cell) {
+                x_new = s0f - nxt[2 * C + tid];
+                const long long idx = run_cnt + tid + vcp[c_mb];
+                a = (double)x_new;
+                if (idx >= kWindow) b = (double)stream_load(xs + (idx - kWindow));
+                xs[idx] = x_new;
+            }
+            double ia = a, ib = b;
+            for (int d = 1; d < 64; d <<= 1) {
+                const double ua = __shfl_up(ia, d, 64), ub = __shfl_up(ib, d, 64);
+                if ((tid & 63) >= d) { ia += ua; ib += ub; }
+            }
+            if (is_cell) { incl[tid] = ia; incl[C + tid] = ib; }
+            if ((tid & 63) == 63) { scanw[tid >> 6] = ia; scanw[16 + (tid >> 6)] = ib; }
+        }
+        lds_barrier();
+        // ================= P5b: loss constants, history | vehicle loss terms and commits =================
+        {
+            const int nwc = (C + 63) >> 6;
+            double tot_a = 0., tot_b = 0.;
+            for (int w = 0; w < nwc; ++w) { tot_a += scanw[w]; tot_b += scanw[16 + w]; }
+            if (is_cell) {
+                const int wv = tid >> 6;
+                double base_a = 0., base_b = 0.;
+                for (int w = 0; w < wv; ++w) { base_a += scanw[w]; base_b += scanw[16 + w]; }
+                const long long n = run_cnt + tid + vcp[c_mb] + 1;
+                const double pin = run_in + base_a + incl[tid] + vsp[c_mb];
+                const double pout = run_out + base_b + incl[C + tid] + vep[c_mb];
+                const double mean = n > kWindow ? (pin - pout) / (double)kWindow : pin / (double)n;
+                const float kk = 16.f / fabsf((float)mean);
+                kc_r[(size_t)t * C + tid] = kk;
+                contrib[tid] = soft_switch(x_new, kk) * (nxt[tid] * c_dxv);
+                float *hn = hist_r + (size_t)(t + 1) * 4 * C;
+                hn[tid] = nxt[tid]; hn[C + tid] = nxt[C + tid]; hn[2 * C + tid] = nxt[2 * C + tid]; hn[3 * C + tid] = nxt[3 * C + tid];
+            }
+            if (is_mt) {
+                for (int k = 0; k < n_micro; ++k) {
+                    qmicro[k] = 0.f;
+                    const int nv = lane_n[k];
+                    if (nv == 0) continue;
+                    const int cb = cbefore[k];
+                    double pa = run_in + vsp[k], pb = run_out + vep[k];
+                    if (cb > 0) {
+                        const int c = cb - 1;
+                        for (int w = 0; w < (c >> 6); ++w) { pa += scanw[w]; pb += scanw[16 + w]; }
+                        pa += incl[c]; pb += incl[C + c];
+                    }
+                    long long n = run_cnt + cb + vcp[k];
+                    Tv qlen = tv_c(0.f);
+                    for (int i = 0; i < nv; ++i) {
+                        const int vi = lane_veh[k * kLaneCap + i];
+                        Tv v_; v_.val = vv[vi]; v_.id = vidv[vi];
+                        Tv xs_ = tv_sub(rec, tv_c(s0f), v_);
+                        pa += (double)xs_.val; pb += (double)vxold[vi]; ++n;
+                        const double mean = n > kWindow ? (pa - pb) / (double)kWindow : pa / (double)n;
+                        const float kk = 16.f / fabsf((float)mean);
+                        qlen = tv_add(rec, qlen, tv_soft(rec, xs_, kk));
+                    }
+                    qmicro[k] = (qlen.val * qlen.val) * dtf;
+                    if (qlen.id >= 0 && t < loss_steps)
+                        rec_push(rec, K_SEED, 0, make_int4(qlen.id, 0, 0, 0), make_float4(-1.0f * dtf * 2.f * qlen.val, 0.f, 0.f, 0.f));
+                }
+                // commit temporaries into the persistent slots
+                for (int k = 0; k < n_micro; ++k)
+                    for (int i = 0; i < lane_n[k]; ++i) {
+                        const int vi = lane_veh[k * kLaneCap + i];
+                        if (vidp[vi] != 3 * vi) { rec_push(rec, K_COMMIT, 3 * vi, make_int4(vidp[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vidp[vi] = 3 * vi; }
+                        if (vidv[vi] != 3 * vi + 1) { rec_push(rec, K_COMMIT, 3 * vi + 1, make_int4(vidv[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vidv[vi] = 3 * vi + 1; }
+                        if (vida[vi] != 3 * vi + 2) { rec_push(rec, K_COMMIT, 3 * vi + 2, make_int4(vida[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vida[vi] = 3 * vi + 2; }
+                    }
+                for (int j = 0; j < n_caps; ++j)
+                    if (capi[j] != 3 * V + j && capi[j] >= 0) { rec_push(rec, K_COMMIT, 3 * V + j, make_int4(capi[j], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); capi[j] = 3 * V + j; }
+                if (rec.next_local - rec.base_local > kMaxLocals || rec.n - step_off[t] > kMaxStepRecords) cap_fault = true;
+            }
+            run_in += tot_a + vsp[n_micro]; run_out += tot_b + vep[n_micro]; run_cnt += C + vcp[n_micro];
+        }
+        lds_barrier();
+        // ================= P5c: lane queue terms =================
+        if (is_lane) {
+            float term;
+            if (l_macro) {
+                float q = 0.f;
+                for (int i = 0; i < l_n; ++i) q = q + contrib[l_off + i];
+                term = (q * q) * dtf;
+            } else term = l_ms >= 0 ? qmicro[l_ms] : 0.f;
+            queue_r[(size_t)t * L + tid] = term;
+            lane_total = lane_total + (-1.0f) * term;
+        }
+        lds_barrier();
+    }
+    if (is_mt) {
+        step_off[T] = rec.n; mark_off[T] = rec.n;
+        counts[4 * rep + 0] = spawned; counts[4 * rep + 1] = deposits; counts[4 * rep + 2] = rec.n; counts[4 * rep + 3] = 0;
+        if (rec.over || cap_fault) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, rec.n);
+    }
+    if (is_lane) ql[tid] = lane_total;
+    __syncthreads();
+    if (tid == 0) {
+        float rew = 0.f;
+        for (int l = 0; l < L; ++l) rew = rew + ql[l];
+        reward[rep] = rew;
+    }
+    if (fault_step >= 0) net_fault(err, DHTS_FAULT_CFL, fault_step, i_lane, fault_index);
+#undef LF
+#undef LI
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// reverse
+// ---------------------------------------------------------------------------------------------------------------------
+struct HybLdsB {
+    size_t red, h0, h1, gl, c0, c2, gq, inl, inf, sg, adj, gam, rk, ri, rw, cell_lane, total;
+};
+__host__ __device__ inline HybLdsB hyb_lds_b(int L, int C, int sq, int V, int E) {
+    HybLdsB o; size_t p = 0;
+    auto D = [&](size_t n) { size_t r = p; p += 8 * n; return r; };
+    auto F = [&](size_t n) { size_t r = p; p += 4 * ((n + 3) & ~(size_t)3); return r; };
+    o.red = D(16 * (size_t)sq);
+    o.h0 = F(3 * (size_t)C); o.h1 = F(3 * (size_t)C); o.gl = F(3 * (size_t)C); o.c0 = F(2 * (size_t)C); o.c2 = F(2 * (size_t)C);
+    o.gq = F(L); o.inl = F(3 * (size_t)E); o.inf = F(3 * (size_t)E); o.sg = F(6 * (size_t)sq);
+    o.adj = F(3 * (size_t)V + kMaxCaps + kMaxLocals); o.gam = F(sq);
+    o.rk = F(kMaxStepRecords); o.ri = F(4 * (size_t)kMaxStepRecords); o.rw = F(4 * (size_t)kMaxStepRecords);
+    o.cell_lane = F(C);
+    o.total = p;
+    return o;
+}
+
+// Phases per step (five barriers): loss taps into the cell cotangents -> micro records of the hand-off / loss part,
+// newest first (deposits and capacitor reads exchange cotangents with the cells) -> J^T g per cell | the rest of the step's
+// micro records -> gather inside the lanes, ghost cotangents to inbox slots, signals -> edge cells take their inboxes.
+__global__ void net_hybrid_bwd_kernel(int R_, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
+                                      double static_speed, double veh_len, HybTables tb, const float *__restrict__ action,
+                                      const float *__restrict__ hist, const float4 *__restrict__ tape,
+                                      const float *__restrict__ kc, const float *__restrict__ queue,
+                                      const float *__restrict__ g_reward, float *__restrict__ g_action,
+                                      const char *__restrict__ workspace, int records_per_step, dhts_error *err) {
+    extern __shared__ double lds_d[];
+    char *lds = reinterpret_cast<char *>(lds_d);
+    const int rep = blockIdx.x, tid = threadIdx.x, B = blockDim.x;
+    const int Cp = (C + 63) & ~63;
+    const int E = tb.net.n_edges > 0 ? tb.net.n_edges : 1;
+    const HybWs ws = hyb_ws(L, C, T, tb.n_routes, records_per_step);
+    const int V = ws.V;
+    const HybLdsB lo = hyb_lds_b(L, C, sq, V, E);
+#define LF(name) reinterpret_cast<float *>(lds + lo.name)
+    double *red = reinterpret_cast<double *>(lds + lo.red);
+    float *H0 = LF(h0), *H1 = LF(h1), *gL = LF(gl), *c0 = LF(c0), *c2 = LF(c2), *gq = LF(gq), *inL = LF(inl), *inF = LF(inf);
+    float *sg = LF(sg), *adj = LF(adj), *gam = LF(gam), *rw = LF(rw);
+    int *rk = reinterpret_cast<int *>(lds + lo.rk), *ri = reinterpret_cast<int *>(lds + lo.ri);
+    int *cell_lane_s = reinterpret_cast<int *>(lds + lo.cell_lane);
+    const float um = (float)um_d, s0f = (float)static_speed, vlen = (float)veh_len;
+    const float *act = action + (size_t)rep * n_action;
+    const size_t toff = (size_t)rep * tb.net.table_stride;
+    const float *hist_r = hist + (size_t)rep * (T + 1) * 4 * C;
+    const float4 *tape_r = tape + (size_t)rep * T * 3 * Cp;
+    const float *kc_r = kc + (size_t)rep * T * C;
+    const float *queue_r = queue + (size_t)rep * T * L;
+    const char *wsr = workspace + (size_t)rep * ws.per_replica;
+    const float *own_r = reinterpret_cast<const float *>(wsr + ws.own_hist);
+    const int *step_off = reinterpret_cast<const int *>(wsr + ws.step_off), *mark_off = reinterpret_cast<const int *>(wsr + ws.mark_off);
+    const int *grk = reinterpret_cast<const int *>(wsr + ws.rec_k);
+    const int4 *gri = reinterpret_cast<const int4 *>(wsr + ws.rec_i);
+    const float4 *grw = reinterpret_cast<const float4 *>(wsr + ws.rec_w);
+    const float gscale = g_reward ? g_reward[rep] : 1.f;
+    const int loss_steps = tb.loss_steps > 0 ? tb.loss_steps : T;
+    const bool is_cell = tid < C, is_ghost = tid < 2 * L, is_lane = tid < L;
+    const bool in_mw = tid >= B - 64, is_mt = (tid == B - 64);
+    const int mw_lane = tid - (B - 64);
+    const int n_adj = 3 * V + kMaxCaps + kMaxLocals, base_local = 3 * V + kMaxCaps;
+
+    if (is_lane) {
+        const int off = tb.net.lane_off[tid], n = tb.net.lane_ncell[tid];
+        for (int i = 0; i < n; ++i) cell_lane_s[off + i] = tid;
+    }
+    for (int k = tid; k < 3 * E; k += B) { inL[k] = 0.f; inF[k] = 0.f; }
+    for (int k = tid; k < n_adj; k += B) adj[k] = 0.f;
+    if (tid < sq) gam[tid] = 0.f;
+    if (is_cell) { gL[tid] = 0.f; gL[C + tid] = 0.f; gL[2 * C + tid] = 0.f; }
+    __syncthreads();
+    int c_lane = 0, c_first = 0, c_last = 0; float c_dxv = 0.f;
+    if (is_cell) {
+        c_lane = cell_lane_s[tid]; c_first = tb.net.lane_off[c_lane]; c_last = c_first + tb.net.lane_ncell[c_lane] - 1;
+        c_dxv = (float)tb.net.lane_dx[c_lane] / vlen;
+    }
+    const int g_lane = tid >> 1, g_side = tid & 1;
+    int g_kind = 0, g_inter = 0, g_off = 0, g_n = 0; bool g_macro = false;
+    if (is_ghost) {
+        g_kind = tb.net.sig_kind[g_lane]; g_inter = tb.net.inter[g_lane]; g_off = tb.net.lane_off[g_lane]; g_n = tb.net.lane_ncell[g_lane];
+        g_macro = tb.lane_macro[g_lane] != 0;
+    }
+    bool l_macro = false;
+    if (is_lane) l_macro = tb.lane_macro[tid] != 0;
+    // static inbox routing (see network_kernels.hip)
+    constexpr int kMaxCand = 4, kMaxEnt = 8;
+    int cand_src[kMaxCand], cand_pos[kMaxCand], n_cand = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxCand; ++i) { cand_src[i] = -1; cand_pos[i] = 0; }
+    if (is_ghost && g_macro) {
+        const int32_t *my_ptr = g_side == 0 ? tb.net.prv_ptr : tb.net.nxt_ptr, *my_idx = g_side == 0 ? tb.net.prv_idx : tb.net.nxt_idx;
+        const int32_t *o_ptr = g_side == 0 ? tb.net.nxt_ptr : tb.net.prv_ptr, *o_idx = g_side == 0 ? tb.net.nxt_idx : tb.net.prv_idx;
+        for (int e = my_ptr[g_lane]; e < my_ptr[g_lane + 1] && n_cand < kMaxCand; ++e) {
+            const int s_lane = my_idx[e];
+            int k = o_ptr[s_lane];
+            while (o_idx[k] != g_lane) ++k;
+#pragma unroll
+            for (int i = 0; i < kMaxCand; ++i) if (i == n_cand) { cand_src[i] = s_lane; cand_pos[i] = k; }
+            ++n_cand;
+        }
+    }
+    int ent[kMaxEnt], n_ent = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxEnt; ++i) ent[i] = -1;
+    if (is_cell && (tid == c_first || tid == c_last)) {
+        int a = tb.net.nxt_ptr[c_lane], a_end = (tid == c_last) ? tb.net.nxt_ptr[c_lane + 1] : a;
+        int b = tb.net.prv_ptr[c_lane], b_end = (tid == c_first) ? tb.net.prv_ptr[c_lane + 1] : b;
+        while ((a < a_end || b < b_end) && n_ent < kMaxEnt) {
+            const int sa = a < a_end ? 2 * tb.net.nxt_idx[a] : 0x7fffffff;
+            const int sb = b < b_end ? 2 * tb.net.prv_idx[b] + 1 : 0x7fffffff;
+            const int code = sa < sb ? 2 * a : 2 * b + 1;
+            if (sa < sb) ++a; else ++b;
+#pragma unroll
+            for (int i = 0; i < kMaxEnt; ++i) if (i == n_ent) ent[i] = code;
+            ++n_ent;
+        }
+    }
+    // final state's history row
+    if (is_cell) {
+        const float *h = hist_r + (size_t)T * 4 * C;
+        float *Hn = (T & 1) ? H1 : H0;
+        Hn[tid] = h[tid]; Hn[C + tid] = h[C + tid]; Hn[2 * C + tid] = h[2 * C + tid];
+    }
+    float gown_r = 0.f, gown_u = 0.f;    // cotangent of the stored downstream ghost (side-1 ghost thread)
+    double ga = 0.; int cur_phase = -1;
+    bool bad = false, over = false;
+    if (tid < sq) for (int k = tid; k < n_action; k += sq) g_action[(size_t)rep * n_action + k] = 0.f;
+    __syncthreads();
+
+    for (int t = T - 1; t >= 0; --t) {
+        float *Hc = (t & 1) ? H1 : H0;           // row t
+        const float *Hn = (t & 1) ? H0 : H1;     // row t+1
+        // ================= R0: this step's data =================
+        float w_kc = 0.f; float4 d0 = make_float4(0, 0, 0, 0), d1 = d0, d2 = d0;
+        int src = 0, gate = 0; float w_own_r = 0.f, w_own_u = 0.f;
+        if (is_cell) {
+            const float *h = hist_r + (size_t)t * 4 * C;
+            Hc[tid] = h[tid]; Hc[C + tid] = h[C + tid]; Hc[2 * C + tid] = h[2 * C + tid];
+            w_kc = kc_r[(size_t)t * C + tid];
+            const float4 *tp = tape_r + (size_t)t * 3 * Cp;
+            d0 = tp[tid]; d1 = tp[Cp + tid]; d2 = tp[2 * Cp + tid];
+        }
+        if (is_lane) {
+            const float w_q = queue_r[(size_t)t * L + tid];
+            gq[tid] = (l_macro && t < loss_steps) ? gscale * (-1.0f) * (float)dt * 2.f * sqrtf(w_q / (float)dt) : 0.f;
+        }
+        if (is_ghost && g_macro) {
+            const size_t o = toff + (size_t)t * L + g_lane;
+            if (g_side == 0) { src = tb.net.left_src[o]; gate = tb.net.left_gate[o]; }
+            else { src = tb.net.right_src[o]; w_own_r = own_r[(size_t)t * 2 * L + 2 * g_lane]; w_own_u = own_r[(size_t)t * 2 * L + 2 * g_lane + 1]; }
+        }
+        if (tid < sq) {
+            float we, ns, a, pr; int ai;
+            phase_signal(act, n_action, sq, F, t, tid, we, ns, a, pr, ai);
+            sg[6 * tid] = we; sg[6 * tid + 1] = ns;
+            sg[6 * tid + 2] = soft_switch_grad(a - pr, kSigK); sg[6 * tid + 3] = -soft_switch_grad(pr - a, kSigK);
+        }
+        const int r_lo = step_off[t], r_hi = step_off[t + 1], r_mark = mark_off[t];
+        const int n_rec = r_hi - r_lo;
+        if (in_mw) {
+            if (n_rec > kMaxStepRecords) over = true;
+            else for (int k = mw_lane; k < n_rec; k += 64) {
+                rk[k] = grk[r_lo + k];
+                const int4 a = gri[r_lo + k]; const float4 b = grw[r_lo + k];
+                ri[4 * k] = a.x; ri[4 * k + 1] = a.y; ri[4 * k + 2] = a.z; ri[4 * k + 3] = a.w;
+                rw[4 * k] = b.x; rw[4 * k + 1] = b.y; rw[4 * k + 2] = b.z; rw[4 * k + 3] = b.w;
+            }
+            for (int k = mw_lane; k < kMaxLocals; k += 64) adj[base_local + k] = 0.f;
+        }
+        lds_barrier();
+        // ================= R1: loss taps on the state after step t =================
+        if (is_cell) {
+            const int c = tid;
+            const float rr = Hn[c], uu = Hn[2 * C + c];
+            const float x = s0f - uu;
+            const float gql = gq[c_lane];
+            gL[c] += gql * soft_switch(x, w_kc) * c_dxv;
+            gL[2 * C + c] += gql * (rr * c_dxv) * (-soft_switch_grad(x, w_kc));
+        }
+        lds_barrier();
+        // ================= R2: micro records of the loss / hand-off part, newest first =================
+        auto replay = [&](int hi, int lo_) {
+            for (int k = hi - 1; k >= lo_; --k) {
+                const int kind = rk[k] >> 24, out = rk[k] & 0xffffff;
+                const int *in = ri + 4 * k; const float *w = rw + 4 * k;
+                if (kind == K_NODE) {
+                    const float a = adj[out];
+                    if (a != 0.f) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (in[q] >= 0) adj[in[q]] += a * w[q];
+                    }
+                } else if (kind == K_COMMIT) {
+                    if (in[0] >= 0) adj[in[0]] += adj[out];
+                    adj[out] = 0.f;
+                } else if (kind == K_SEED) {
+                    adj[in[0]] += gscale * w[0];
+                } else if (kind == K_DEPOSIT) {
+                    const int c = in[3];
+                    const float n_r = w[2], speed = Hn[2 * C + c];
+                    float g_nr = gL[c], g_speed = gL[2 * C + c];
+                    glue_y_bwd(n_r, speed, um, gL[C + c], g_nr, g_speed);
+                    const float dx = (float)tb.net.lane_dx[out];
+                    if (in[0] >= 0) adj[in[0]] += g_nr * ((w[0] / dx) / vlen);
+                    if (in[1] >= 0) adj[in[1]] += g_nr * ((w[3] / vlen) / dx) * w[1];
+                    if (in[2] >= 0) adj[in[2]] += g_speed;
+                    gL[c] = g_nr; gL[C + c] = 0.f; gL[2 * C + c] = 0.f;
+                } else if (kind == K_CELLREAD) {
+                    gL[in[2]] += adj[in[0]];
+                    gL[2 * C + in[2]] += adj[in[1]];
+                } else if (kind == K_SIGNAL) {
+                    gam[in[1]] += adj[in[0]] * sg[6 * in[1] + 2 + (in[2] - 1)];
+                }
+            }
+        };
+        if (is_mt && !over) replay(n_rec, r_mark - r_lo + 1);
+        lds_barrier();
+        // ================= R3: speed cotangents into (r, y); J^T g per cell | rest of the micro records =================
+        float v_r = 0.f, v_y = 0.f;
+        if (is_cell) {
+            const int c = tid;
+            float gr = gL[c], gy = gL[C + c];
+            glue_u_bwd(Hn[c], Hn[C + c], um, gL[2 * C + c], gr, gy);
+            c0[c] = dot2(d0.x, gr, d0.z, gy); c0[C + c] = dot2(d0.y, gr, d0.w, gy);
+            c2[c] = dot2(d2.x, gr, d2.z, gy); c2[C + c] = dot2(d2.y, gr, d2.w, gy);
+            v_r = dot2(d1.x, gr, d1.z, gy); v_y = dot2(d1.y, gr, d1.w, gy);
+        }
+        if (is_mt && !over) replay(r_mark - r_lo, 0);
+        lds_barrier();
+        // ================= R4: gather inside the lane; ghost cotangents =================
+        if (is_cell) {
+            const int c = tid;
+            if (c > c_first) { v_r += c2[c - 1]; v_y += c2[C + c - 1]; }
+            if (c < c_last) { v_r += c0[c + 1]; v_y += c0[C + c + 1]; }
+        }
+        float my_aval = 0.f; int my_akey = -1;
+        if (is_ghost && g_macro) {
+            float tgt = -1.f, add_r = 0.f, add_u = 0.f, a_val = 0.f; int a_key = -1;
+            if (g_side == 0) {
+                if (src >= 0) {
+                    const int last = tb.net.lane_off[src] + tb.net.lane_ncell[src] - 1;
+                    const float grn_r = Hc[last], grn_u = Hc[2 * C + last];
+                    float s = 1.f; int kd = 0, it = 0;
+                    if (gate == -1) s = 0.f;
+                    else if (gate >= 0) { kd = tb.net.sig_kind[gate]; it = tb.net.inter[gate]; if (kd != 0) s = sg[6 * it + (kd - 1)]; }
+                    const float fr = grn_r * s + 0.f * (1.0f - s), fu = grn_u * s + um * (1.0f - s);
+                    float g_fr = c0[g_off], g_fu = 0.f;
+                    glue_y_bwd(fr, fu, um, c0[C + g_off], g_fr, g_fu);
+                    add_r = g_fr * s; add_u = g_fu * s;
+                    tgt = (float)last;
+                    if (kd != 0) { a_val = (g_fr * grn_r + g_fu * (grn_u - um)) * sg[6 * it + 2 + (kd - 1)]; a_key = it; }
+                }
+            } else {
+                const float grn_r = src < 0 ? w_own_r : Hc[tb.net.lane_off[src]];
+                const float grn_u = src < 0 ? w_own_u : Hc[2 * C + tb.net.lane_off[src]];
+                const float sgl = g_kind != 0 ? sg[6 * g_inter + (g_kind - 1)] : 1.f;
+                const float s2 = soft_switch(sgl - 0.5f, kSigK);
+                const float fr = s2 * grn_r + (1.0f - s2) * 1.0f, fu = s2 * grn_u + (1.0f - s2) * 0.0f;
+                const int lastc = g_off + g_n - 1;
+                float g_fr = c2[lastc] + gown_r, g_fu = gown_u;      // the blended ghost is also the stored one
+                glue_y_bwd(fr, fu, um, c2[C + lastc], g_fr, g_fu);
+                if (src >= 0) { add_r = g_fr * s2; add_u = g_fu * s2; tgt = (float)tb.net.lane_off[src]; gown_r = 0.f; gown_u = 0.f; }
+                else { gown_r = g_fr * s2; gown_u = g_fu * s2; }
+                if (g_kind != 0) {
+                    const float g_s2 = g_fr * (grn_r - 1.0f) + g_fu * grn_u;
+                    a_val = g_s2 * soft_switch_grad(sgl - 0.5f, kSigK) * sg[6 * g_inter + 2 + (g_kind - 1)]; a_key = g_inter;
+                }
+            }
+            if (tgt >= 0.f) {
+                float *box = g_side == 0 ? inL : inF;
+#pragma unroll
+                for (int i = 0; i < kMaxCand; ++i)
+                    if (cand_src[i] == src) { box[3 * cand_pos[i]] = add_r; box[3 * cand_pos[i] + 1] = 0.f; box[3 * cand_pos[i] + 2] = add_u; }
+            }
+            my_aval = a_val; my_akey = a_key;
+        }
+        for (int q = 0; q < sq; ++q) {
+            double v = (my_akey == q) ? (double)my_aval : 0.0;
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            if ((tid & 63) == 0) red[(tid >> 6) * sq + q] = v;
+        }
+        lds_barrier();
+        // ================= R5: edge cells take their inboxes; action partials =================
+        if (is_cell) {
+            float v_u = 0.f;
+#pragma unroll
+            for (int i = 0; i < kMaxEnt; ++i) {
+                if (ent[i] >= 0) {
+                    float *box = (ent[i] & 1) ? inF : inL;
+                    const int k = ent[i] >> 1;
+                    v_r += box[3 * k]; v_y += box[3 * k + 1]; v_u += box[3 * k + 2];
+                    box[3 * k] = 0.f; box[3 * k + 1] = 0.f; box[3 * k + 2] = 0.f;
+                }
+            }
+            gL[tid] = v_r; gL[C + tid] = v_y; gL[2 * C + tid] = v_u;
+            bad |= !(isfinite(v_r) && isfinite(v_y) && isfinite(v_u));
+        }
+        if (tid < sq) {
+            double v = 0.;
+            for (int w = 0; w < (int)(B >> 6); ++w) v += red[w * sq + tid];
+            v += (double)gam[tid]; gam[tid] = 0.f;
+            int phase = t / F; const int lastp = n_action / sq - 1; phase = phase > lastp ? lastp : phase;
+            if (phase != cur_phase) { if (cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + tid] = (float)ga; ga = 0.; cur_phase = phase; }
+            ga += v;
+        }
+        lds_barrier();
+    }
+    if (tid < sq && cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + tid] = (float)ga;
+    if (bad) net_fault(err, DHTS_FAULT_NAN, 0, 0, tid);
+    if (over && is_mt) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, 0);
+#undef LF
+}
+
+}  // namespace dhts
+
+using namespace dhts;
+
+static inline bool hyb_desc_ok(const dhts_net_desc *d) {
+    return d && d->n_replicas > 0 && d->n_lanes > 0 && d->n_cells > 0 && d->n_steps >= 0 && d->n_inter_sq > 0 &&
+           d->frames_per_phase > 0 && d->n_action >= d->n_inter_sq && d->n_action <= 960 && d->dt > 0 && d->u_max > 0 &&
+           d->vehicle_length > 0 && d->n_cells + d->n_lanes <= 960;
+}
+static inline bool hyb_tables_ok(const dhts_hybrid_tables *t) {
+    const dhts_net_tables *n = t ? &t->net : nullptr;
+    return t && n->lane_ncell && n->lane_off && n->sig_kind && n->inter && n->lane_dx && n->left_src && n->left_gate &&
+           n->right_src && n->schedule && n->replica_stride >= 0 && n->nxt_ptr && n->nxt_idx && n->prv_ptr && n->prv_idx &&
+           n->n_edges >= 0 && t->lane_macro && t->lane_len && t->conv_next && t->routes && t->n_routes > 0 &&
+           t->route_stride > 0 && t->route_stride <= kRouteStride;
+}
+static inline HybTables hyb_tables(const dhts_hybrid_tables *t) {
+    HybTables h;
+    const dhts_net_tables *n = &t->net;
+    h.net.lane_ncell = n->lane_ncell; h.net.lane_off = n->lane_off; h.net.sig_kind = n->sig_kind; h.net.inter = n->inter;
+    h.net.lane_dx = n->lane_dx; h.net.left_src = n->left_src; h.net.left_gate = n->left_gate; h.net.right_src = n->right_src;
+    h.net.schedule = n->schedule; h.net.table_stride = (size_t)n->replica_stride;
+    h.net.nxt_ptr = n->nxt_ptr; h.net.nxt_idx = n->nxt_idx; h.net.prv_ptr = n->prv_ptr; h.net.prv_idx = n->prv_idx; h.net.n_edges = n->n_edges;
+    h.lane_macro = t->lane_macro; h.lane_len = t->lane_len; h.conv_next = t->conv_next; h.routes = t->routes;
+    h.n_routes = t->n_routes; h.route_stride = t->route_stride; h.loss_steps = t->loss_steps;
+    return h;
+}
+static inline int hyb_block(const dhts_net_desc *d) {
+    int need = d->n_cells + d->n_lanes;
+    if (need < 2 * d->n_lanes) need = 2 * d->n_lanes;
+    if (need < d->n_action) need = d->n_action;
+    return ((need + 63) & ~63) + 64;               // + the micro wavefront
+}
+
+extern "C" {
+
+size_t dhts_net_hybrid_workspace_bytes(const dhts_net_desc *d, const dhts_hybrid_tables *t) {
+    if (!hyb_desc_ok(d) || !t || t->n_routes <= 0) return 0;
+    return hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step).per_replica * (size_t)d->n_replicas;
+}
+
+int dhts_net_hybrid_rollout_fwd(const dhts_net_desc *d, const dhts_hybrid_tables *t, const float *action, float *hist,
+                                float *tape, float *kc, float *queue, float *reward, int32_t *counts, void *workspace,
+                                dhts_error *err, void *stream) {
+    if (!hyb_desc_ok(d) || !hyb_tables_ok(t) || !action || !hist || !tape || !kc || !queue || !reward || !counts || !workspace)
+        return DHTS_E_INVALID;
+    const int B = hyb_block(d);
+    if (B > 1024) return DHTS_E_INVALID;
+    const HybWs ws = hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step);
+    const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V).total;
+    if (lds > 160 * 1024) return DHTS_E_INVALID;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)net_hybrid_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DHTS_E_LAUNCH;
+    net_hybrid_fwd_kernel<<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
+        d->n_replicas, d->n_lanes, d->n_cells, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max,
+        d->static_speed, d->vehicle_length, hyb_tables(t), action, hist, reinterpret_cast<float4 *>(tape), kc, queue, reward,
+        counts, reinterpret_cast<char *>(workspace), t->records_per_step, err);
+    return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
+}
+
+int dhts_net_hybrid_rollout_bwd(const dhts_net_desc *d, const dhts_hybrid_tables *t, const float *action, const float *hist,
+                                const float *tape, const float *kc, const float *queue, const float *g_reward,
+                                float *g_action, const void *workspace, dhts_error *err, void *stream) {
+    if (!hyb_desc_ok(d) || !hyb_tables_ok(t) || !action || !hist || !tape || !kc || !queue || !g_action || !workspace)
+        return DHTS_E_INVALID;
+    const int B = hyb_block(d);
+    if (B > 1024) return DHTS_E_INVALID;
+    const HybWs ws = hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step);
+    const int E = t->net.n_edges > 0 ? t->net.n_edges : 1;
+    const size_t lds = hyb_lds_b(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, E).total;
+    if (lds > 160 * 1024) return DHTS_E_INVALID;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)net_hybrid_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DHTS_E_LAUNCH;
+    net_hybrid_bwd_kernel<<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
+        d->n_replicas, d->n_lanes, d->n_cells, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max,
+        d->static_speed, d->vehicle_length, hyb_tables(t), action, hist, reinterpret_cast<const float4 *>(tape), kc, queue,
+        g_reward, g_action, reinterpret_cast<const char *>(workspace), t->records_per_step, err);
+    return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
+}
+
+}  // extern "C"

@@ -12,7 +12,7 @@ CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 SO_PATH = os.path.join(CSRC, "libdhts.so")
 
 OK, E_INVALID, E_LAUNCH, E_NO_DEVICE = 0, -1, -2, -3
-FAULT_NONE, FAULT_CFL, FAULT_COLLISION, FAULT_NAN = 0, 1, 2, 3
+FAULT_NONE, FAULT_CFL, FAULT_COLLISION, FAULT_NAN, FAULT_CAPACITY = 0, 1, 2, 3, 4
 OPT_MACRO_FWD_WAVES = 1
 MACRO_MAX_CELLS = 4000
 MICRO_MAX_VEHICLES = 1024
@@ -34,6 +34,12 @@ class NetTables(C.Structure):
                 ("lane_dx", C.c_void_p), ("left_src", C.c_void_p), ("left_gate", C.c_void_p), ("right_src", C.c_void_p),
                 ("schedule", C.c_void_p), ("replica_stride", C.c_int64), ("nxt_ptr", C.c_void_p), ("nxt_idx", C.c_void_p),
                 ("prv_ptr", C.c_void_p), ("prv_idx", C.c_void_p), ("n_edges", C.c_int32)]
+
+
+class HybridTables(C.Structure):
+    _fields_ = [("net", NetTables), ("lane_macro", C.c_void_p), ("lane_len", C.c_void_p), ("conv_next", C.c_void_p),
+                ("routes", C.c_void_p), ("n_routes", C.c_int32), ("route_stride", C.c_int32),
+                ("records_per_step", C.c_int32), ("loss_steps", C.c_int32)]
 
 
 class MicroDesc(C.Structure):
@@ -61,6 +67,9 @@ SIGNATURES = {
     "dhts_net_macro_tape_bytes": (C.c_size_t, [C.POINTER(NetDesc)]),
     "dhts_net_macro_rollout_fwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetTables)] + [_P] * 9),
     "dhts_net_macro_rollout_bwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetTables)] + [_P] * 10),
+    "dhts_net_hybrid_workspace_bytes": (C.c_size_t, [C.POINTER(NetDesc), C.POINTER(HybridTables)]),
+    "dhts_net_hybrid_rollout_fwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(HybridTables)] + [_P] * 10),
+    "dhts_net_hybrid_rollout_bwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(HybridTables)] + [_P] * 10),
     "dhts_micro_tape_bytes": (C.c_size_t, [C.POINTER(MicroDesc), C.c_int]),
     "dhts_micro_rollout_fwd": (C.c_int, [C.POINTER(MicroDesc), C.c_int] + [_P] * 11),
     "dhts_micro_rollout_bwd": (C.c_int, [C.POINTER(MicroDesc), C.c_int] + [_P] * 10),

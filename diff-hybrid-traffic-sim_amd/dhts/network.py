@@ -144,4 +144,33 @@ class HybridNetworkTables:
             if not is_macro[l] and len(prev[l]) == 0:
                 raise ValueError("micro source lanes (stochastic inflow, _simulator.py:153-174) are not supported")
         self.conv_next = np.where(is_macro[None, :], macro_route, -1).astype(np.int32)
+        # static adjacency (CSR, ascending ids) for the reverse sweep's inbox routing
+        self.nxt_ptr = np.concatenate([[0], np.cumsum([len(n) for n in nxt])]).astype(np.int32)
+        self.nxt_idx = np.array([b for n in nxt for b in sorted(n)], dtype=np.int32)
+        self.prv_ptr = np.concatenate([[0], np.cumsum([len(p_) for p_ in prev])]).astype(np.int32)
+        self.prv_idx = np.array([a for p_ in prev for a in sorted(p_)], dtype=np.int32)
+        self.n_edges = int(len(self.nxt_idx))
+        if max([len(n) for n in nxt] + [len(p_) for p_ in prev]) > 4:
+            raise ValueError("the network kernels support at most 4 upstream and 4 downstream lanes per lane")
         self.schedule = np.ascontiguousarray(np.asarray(schedule, dtype=np.float64).T)      # [T][L]
+
+    @staticmethod
+    def from_env(env):
+        """From an example.control.itscp._env.ItscpEnv (after reset) in `hybrid` mode."""
+        keys = list(env.lane.keys())
+        lanes = [env.lane[k].sim_lane for k in keys]
+        kinds = []
+        for k in keys:
+            if k.loc == "mid" or not k.approaching:
+                kinds.append(SIG_ALWAYS)
+            else:
+                kinds.append(SIG_WE if k.loc in ("west", "east") else SIG_NS)
+        edges = [(a, b) for a in env.simulator.lane for b in env.simulator.lane[a].next_lane.keys()]
+        T, L = env.num_timestep, len(keys)
+        mr = -np.ones((T, L), dtype=np.int32)
+        for t, r in enumerate(env.macro_route_schedule):
+            for a, b in r.next_lane_dict.items():
+                mr[t, a] = b
+        return HybridNetworkTables([int(sl.is_macro()) for sl in lanes], [getattr(sl, "num_cell", 0) for sl in lanes],
+                                   [sl.length for sl in lanes], edges, kinds,
+                                   [k.row * env.num_intersection + k.col for k in keys], mr, [env.schedule[k] for k in keys])

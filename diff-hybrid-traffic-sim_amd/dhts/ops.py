@@ -46,6 +46,9 @@ def raise_on_fault(err):
                              "(step %d, lane %d, interface %d)" % (step, lane, index))
     if code == _lib.FAULT_NAN:
         raise AssertionError("non-finite gradient in the reverse sweep (lane %d)" % lane)   # dmacro_lane.py:308
+    if code == _lib.FAULT_CAPACITY:
+        raise RuntimeError("hybrid network: a fixed capacity was exceeded (record stream / vehicles / lane list / routes); "
+                           "index %d" % index)
     return code   # FAULT_COLLISION is printed-and-tolerated in the reference (_micro_lane.py:155-160)
 
 
@@ -397,3 +400,95 @@ class NetMacroRollout(torch.autograd.Function):
 def net_macro_rollout(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0):
     return NetMacroRollout.apply(action, dev_tables, int(n_inter_sq), int(frames_per_phase), float(dt), float(u_max),
                                  float(static_speed), float(vehicle_length))
+
+
+class DeviceHybridTables:
+    """dhts.network.HybridNetworkTables plus the pre-drawn vehicle routes [n_routes][stride] (int, -1 padded; the k-th
+    vehicle spawned in a replica takes row k), uploaded once and shared by all replicas."""
+
+    def __init__(self, tables, routes, device, records_per_step=0):
+        import numpy as np
+        t = tables
+        self.n_lanes, self.n_cells, self.T = t.n_lanes, t.n_cells, t.T
+        up = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=device)    # noqa: E731
+        pad1 = lambda a: a if len(a) else np.zeros(1, dtype=np.int32)      # noqa: E731
+        routes = np.ascontiguousarray(routes, dtype=np.int32)
+        if routes.ndim != 2 or routes.shape[0] < 1 or routes.shape[1] > 32:
+            raise ValueError("routes must be [n_routes >= 1][stride <= 32]")
+        self.n_routes, self.route_stride = int(routes.shape[0]), int(routes.shape[1])
+        self.records_per_step = int(records_per_step)
+        self._keep = [up(t.lane_ncell, torch.int32), up(t.lane_off, torch.int32), up(t.sig_kind, torch.int32), up(t.inter, torch.int32),
+                      up(t.lane_dx, torch.float64), up(t.left_src, torch.int32), up(t.left_gate, torch.int32),
+                      up(t.right_src, torch.int32), up(t.schedule, torch.float64), up(t.nxt_ptr, torch.int32),
+                      up(pad1(t.nxt_idx), torch.int32), up(t.prv_ptr, torch.int32), up(pad1(t.prv_idx), torch.int32),
+                      up(t.lane_macro, torch.int32), up(t.lane_length, torch.float64), up(t.conv_next, torch.int32),
+                      up(routes, torch.int32)]
+        k = [x.data_ptr() for x in self._keep]
+        self.net = _lib.NetTables(k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], 0, k[9], k[10], k[11], k[12], t.n_edges)
+
+    def c(self, loss_steps=0):
+        k = [x.data_ptr() for x in self._keep]
+        return _lib.HybridTables(self.net, k[13], k[14], k[15], k[16], self.n_routes, self.route_stride, self.records_per_step,
+                                 int(loss_steps))
+
+
+class NetHybridRollout(torch.autograd.Function):
+    """action [R][A] -> reward [R] of R replicas of a signalised hybrid network (ItscpEnv.step(action, True) of the
+    reference in `hybrid` mode); also returns the per-step queue terms and (spawned, deposited, records) per replica.
+    loss_steps > 0 restricts the differentiated reward to the first loss_steps steps (second output `reward_cut`)."""
+
+    @staticmethod
+    def forward(ctx, action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed, vehicle_length, loss_steps):
+        a = _f32c(action.detach(), "action")
+        R, A = a.shape
+        t = dev_tables
+        d = _lib.NetDesc(R, t.n_lanes, t.n_cells, t.T, int(n_inter_sq), int(frames_per_phase), A, float(dt), float(u_max),
+                         float(static_speed), float(vehicle_length))
+        tc = t.c(loss_steps)
+        lib = _lib.lib()
+        ws_n = lib.dhts_net_hybrid_workspace_bytes(C.byref(d), C.byref(tc))
+        if ws_n == 0:
+            raise ValueError("unsupported hybrid network size")
+        dev = a.device
+        Cp = (t.n_cells + 63) // 64 * 64
+        hist = torch.empty(R * (t.T + 1) * 4 * t.n_cells, dtype=torch.float32, device=dev)
+        tape = torch.empty(R * t.T * 3 * Cp * 4, dtype=torch.float32, device=dev)
+        kc = torch.empty(R, t.T, t.n_cells, dtype=torch.float32, device=dev)
+        queue = torch.empty(R, t.T, t.n_lanes, dtype=torch.float32, device=dev)
+        reward = torch.empty(R, dtype=torch.float32, device=dev)
+        counts = torch.zeros(R, 4, dtype=torch.int32, device=dev)
+        ws = torch.empty(ws_n, dtype=torch.uint8, device=dev)
+        err = new_error_record(dev)
+        check(lib.dhts_net_hybrid_rollout_fwd(C.byref(d), C.byref(tc), _ptr(a), _ptr(hist), _ptr(tape), _ptr(kc), _ptr(queue),
+                                              _ptr(reward), _ptr(counts), _ptr(ws), _ptr(err), _stream()),
+              "dhts_net_hybrid_rollout_fwd")
+        raise_on_fault(err)
+        ctx.d, ctx.tables, ctx.loss_steps = d, t, int(loss_steps)
+        ctx.save_for_backward(a, hist, tape, kc, queue, ws)
+        ctx.mark_non_differentiable(reward, queue, counts)
+        if loss_steps and loss_steps > 0:
+            # reference accumulation order: lanes outer, steps inner
+            cut = -(queue[:, :int(loss_steps), :].transpose(1, 2).reshape(R, -1).sum(dim=1))
+        else:
+            cut = reward.clone()
+        return cut, reward, queue, counts
+
+    @staticmethod
+    def backward(ctx, g_cut, _g_reward, _g_queue, _g_counts):
+        a, hist, tape, kc, queue, ws = ctx.saved_tensors
+        d = ctx.d
+        tc = ctx.tables.c(ctx.loss_steps)
+        g_action = torch.empty_like(a)
+        err = new_error_record(a.device)
+        check(_lib.lib().dhts_net_hybrid_rollout_bwd(C.byref(d), C.byref(tc), _ptr(a), _ptr(hist), _ptr(tape), _ptr(kc), _ptr(queue),
+                                                     _ptr(g_cut.contiguous().float()), _ptr(g_action), _ptr(ws), _ptr(err), _stream()),
+              "dhts_net_hybrid_rollout_bwd")
+        raise_on_fault(err)
+        return g_action, None, None, None, None, None, None, None, None
+
+
+def net_hybrid_rollout(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0,
+                       loss_steps=0):
+    """Returns (reward restricted to the first loss_steps steps [differentiable], full reward, queue [R][T][L], counts [R][4])."""
+    return NetHybridRollout.apply(action, dev_tables, int(n_inter_sq), int(frames_per_phase), float(dt), float(u_max),
+                                  float(static_speed), float(vehicle_length), int(loss_steps))

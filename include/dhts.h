@@ -47,6 +47,7 @@ extern "C" {
 #define DHTS_FAULT_CFL 1       /* dt >= dx / max(|speed|, 1e-5) at an interface  (_macro_lane.py:141-146) */
 #define DHTS_FAULT_COLLISION 2 /* gap to the leader < 0                           (_micro_lane.py:151-162) */
 #define DHTS_FAULT_NAN 3       /* non-finite cotangent in the reverse sweep       (dmacro_lane.py:308)     */
+#define DHTS_FAULT_CAPACITY 4  /* hybrid network: record stream / vehicle slots / lane list / route table exhausted */
 
 typedef struct dhts_error {
     int32_t code;  /* DHTS_FAULT_*; 0 = no fault.  Caller zeroes it before the first call. */
@@ -232,6 +233,47 @@ int dhts_net_macro_rollout_fwd(const dhts_net_desc *d, const dhts_net_tables *t,
 int dhts_net_macro_rollout_bwd(const dhts_net_desc *d, const dhts_net_tables *t, const float *action, const float *hist,
                                const float *tape, const float *kc, const float *queue, const float *g_reward, float *g_action,
                                const float *workspace, dhts_error *err, void *stream);
+
+/* ---- HYBRID road network (itscp `hybrid` mode): macro lanes, micro lanes and the hand-offs between them -----------------
+ * As the macro network rollout, with lanes that are either ARZ cell lanes or IDM vehicle lanes and, after every step,
+ * the conversions of road/network/conversion.py:11-215 in lane-id order (RoadNetwork.conversion, road_network.py:113-170):
+ *   macro -> micro  flux capacitor of the last cell (+= r u dt), spawn of a default vehicle (p = 0, v = u_last, ancillary
+ *                   a = capacitor) once it holds one vehicle length and the successor has that much free space (:16-73)
+ *   micro -> macro  the head vehicle past the lane end by more than its length is deposited into the successor's first
+ *                   cells (density a/len * overlap/dx, straight-through clamp, cell speed = vehicle speed) (:76-171)
+ *   micro -> micro  lane change at p >= L (:175-200);  micro -> none at p >= L (:203-215)
+ * plus the head gap of every occupied micro lane: leader further along the route (road_network.py:429-580) blended with the
+ * red-light stop line by position-weighted neighbour signals (_simulator.py:139-276), and the vehicles' terms of the queue
+ * loss (_env.py:694-725).  Vehicles use MicroVehicle.default_micro_vehicle (micro_vehicle.py:31-72).
+ * One workgroup per replica; the (few) scalar operations of the micro side run on one lane of an extra wavefront and are
+ * recorded, with their partial derivatives, on a per-replica record stream that the reverse sweep replays backwards.
+ * Extra tables (device pointers):
+ *   lane_macro [L] int32 (1 = cells, 0 = vehicles; micro lanes have 0 cells), lane_len [L] DOUBLE,
+ *   left_src -3 = own stored upstream ghost (single upstream lane is micro), right_src -1 also when the single downstream
+ *   lane is micro, conv_next [T][L] int32 = the step's macro-route successor of a macro lane (per replica like left_src),
+ *   routes [n_routes][route_stride] int32 (-1 padded): the route of the k-th vehicle spawned in a replica (the reference
+ *   draws it with np.random at spawn time, road_network.py:604-646; callers pre-draw them).
+ * Limits: n_cells + n_lanes <= 960, <= 64 micro lanes, <= 16 spawning lanes, <= 16 vehicles per micro lane,
+ * <= 128 vehicles per replica and episode, route_stride <= 32; records_per_step (average budget of the record stream,
+ * 0 = 512).  loss_steps: only the first loss_steps steps enter reward_cut and the gradient (<= 0: all).
+ */
+typedef struct dhts_hybrid_tables {
+    dhts_net_tables net;
+    const int32_t *lane_macro;
+    const double *lane_len;
+    const int32_t *conv_next;
+    const int32_t *routes;
+    int32_t n_routes, route_stride, records_per_step, loss_steps;
+} dhts_hybrid_tables;
+size_t dhts_net_hybrid_workspace_bytes(const dhts_net_desc *d, const dhts_hybrid_tables *t);
+/* hist / tape / kc / queue / reward as in the macro rollout (kc, tape rows of micro lanes do not exist: they have no cells);
+ * counts [R][4] int32 = (vehicles spawned, vehicles deposited, records written, 0) */
+int dhts_net_hybrid_rollout_fwd(const dhts_net_desc *d, const dhts_hybrid_tables *t, const float *action, float *hist,
+                                float *tape, float *kc, float *queue, float *reward, int32_t *counts, void *workspace,
+                                dhts_error *err, void *stream);
+int dhts_net_hybrid_rollout_bwd(const dhts_net_desc *d, const dhts_hybrid_tables *t, const float *action, const float *hist,
+                                const float *tape, const float *kc, const float *queue, const float *g_reward,
+                                float *g_action, const void *workspace, dhts_error *err, void *stream);
 
 #ifdef __cplusplus
 }

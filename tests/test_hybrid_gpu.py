@@ -1,0 +1,86 @@
+"""The fused HYBRID network kernels (dhts_net_hybrid_rollout_fwd / _bwd) against the reference's own itscp runs (G8
+goldens) and against the CPU oracle: macro-only networks must reproduce the macro network kernels' answers, hybrid
+networks the reference's queues, reward, vehicle counts and d reward / d action."""
+import os
+
+import numpy as np
+import pytest
+
+from test_oracle_golden import itscp_hybrid_tables
+from util import TOL_GRAD, TOL_STATE, meta_of, rel_max
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cuda, g, loss_steps=0, replicas=1, want_grad=True, action=None):
+    import torch
+    from dhts import ops
+    t, m = itscp_hybrid_tables(g)
+    routes = g["spawn_routes"] if g["spawn_routes"].shape[0] else -np.ones((1, 2), np.int32)
+    dt_ = ops.DeviceHybridTables(t, routes, cuda)
+    a0 = g["action"] if action is None else action
+    a = torch.tensor(np.tile(a0[None, :], (replicas, 1)), device=cuda, requires_grad=want_grad)
+    cut, reward, queue, counts = ops.net_hybrid_rollout(a, dt_, m["num_intersection"] ** 2,
+                                                        m["simulation_frequency"] * m["signal_length"],
+                                                        1.0 / m["simulation_frequency"], m["speed_limit"], m["static_speed"],
+                                                        m["vehicle_length"], loss_steps)
+    grad = None
+    if want_grad:
+        cut.sum().backward()
+        grad = a.grad.cpu().numpy()
+    return dict(cut=cut.detach().cpu().numpy(), reward=reward.cpu().numpy(), queue=queue.cpu().numpy(),
+                counts=counts.cpu().numpy(), grad=grad, m=m)
+
+
+@pytest.mark.parametrize("name", ["macro_small", "macro"])
+def test_hybrid_kernels_on_macro_only_network(cuda, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    o = _run(cuda, g)
+    assert rel_max(o["queue"][0].T, g["queue"]) <= TOL_STATE
+    assert abs(float(o["reward"][0]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+    assert rel_max(o["grad"][0], g["g_action"]) <= TOL_GRAD
+    assert o["counts"][0, 0] == 0 and o["counts"][0, 1] == 0
+
+
+def test_hybrid_short_matches_reference(cuda, golden_dir):
+    g = np.load(os.path.join(golden_dir, "itscp_hybrid_short.npz"))
+    o = _run(cuda, g, replicas=3)
+    m = o["m"]
+    for r in range(3):
+        assert o["counts"][r, 0] == m["n_vehicle_spawned"]
+        assert rel_max(o["queue"][r].T, g["queue"]) <= 1e-4
+        assert abs(float(o["reward"][r]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+        assert np.abs(o["grad"][r] - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()
+    assert np.array_equal(o["grad"][0], o["grad"][1]) and np.array_equal(o["queue"][0], o["queue"][2])   # repeatable
+
+
+def test_hybrid_600_steps_matches_reference(cuda, golden_dir):
+    """13 spawns, lane changes, 12 deposits, the loss' running-mean window sliding (153 600 + samples > 100 000)."""
+    g = np.load(os.path.join(golden_dir, "itscp_hybrid.npz"))
+    o = _run(cuda, g, want_grad=False)
+    m = o["m"]
+    assert o["counts"][0, 0] == m["n_vehicle_spawned"] and o["counts"][0, 1] == 12
+    assert rel_max(o["queue"][0].T, g["queue"]) <= 1e-4
+    assert abs(float(o["reward"][0]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+    scale = np.abs(g["g_action"]).max()
+    # gradient of the reward restricted to its first t0 steps (see tests/test_itscp_gpu.py for the last 60 steps of lane 16)
+    for t0, ref in zip(g["g_action_cut_steps"], g["g_action_cut"]):
+        if t0 <= 540:
+            oc = _run(cuda, g, loss_steps=int(t0))
+            assert np.abs(oc["grad"][0] - ref).max() <= 5 * TOL_GRAD * scale, int(t0)
+
+
+def test_hybrid_kernels_vs_oracle_other_action(cuda, golden_dir, oracle):
+    """A different action (other spawn sequence is not implied: same pre-drawn routes must still fit) against the oracle."""
+    g = np.load(os.path.join(golden_dir, "itscp_hybrid_short.npz"))
+    t, m = itscp_hybrid_tables(g)
+    rng = np.random.default_rng(5)
+    action = np.clip(g["action"] + rng.uniform(-0.02, 0.02, len(g["action"])).astype(np.float32), 0.05, 0.95).astype(np.float32)
+    ref = oracle.net_hybrid(t, g["spawn_routes"], action, m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"],
+                            1.0 / m["simulation_frequency"], m["speed_limit"], m["static_speed"], m["vehicle_length"])
+    if ref["rc"] != 0:
+        pytest.skip("perturbed action changes the spawn lanes' order")
+    o = _run(cuda, g, action=action)
+    assert o["counts"][0, 0] == ref["n_spawned"]
+    assert rel_max(o["queue"][0], ref["queue"]) <= 1e-4
+    assert np.abs(o["grad"][0] - ref["g_action"]).max() <= 5 * TOL_GRAD * np.abs(ref["g_action"]).max()
