@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["macro", "micro", "itscp_macro"], default="macro")
+    ap.add_argument("--workload", choices=["macro", "micro", "itscp_macro", "itscp_hybrid"], default="macro")
     ap.add_argument("--lanes", type=int, default=0, help="override lanes per GPU")
     ap.add_argument("--cells", type=int, default=0, help="override cells / vehicles per lane")
     ap.add_argument("--time-steps", type=int, default=0, help="override simulated time steps per rollout")
@@ -247,6 +247,66 @@ class ItscpMacroWorkload:
         return {"value": None, "unit": "cell-steps/s", "cores": 0, "kind": "port", "sample": "not timed for this workload"}
 
 
+class ItscpHybridWorkload:
+    """run_itscp_hybrid.sh's network (3 x 3 intersections, 1 lane, 20 s, signal 4 s: 144 lanes of which the 16 of the
+    centre intersection are micro, 256 cells, 600 steps, 45 actions) x 256 replicas with actions U[0.1, 0.9]: reward and
+    d reward / d action of every replica in one fused launch each way (BASELINE config 4)."""
+    name = "itscp_hybrid_256x(144 lanes, 256 cells, 16 micro lanes)x600"
+    unit_bytes = MACRO_TAPE_B
+
+    def __init__(self, dev, rank, R, _n, _t):
+        import numpy as np
+        from dhts import ops
+        from dhts.network import HybridNetworkTables
+        from example.control.itscp._env import ItscpEnv
+        from example.control.itscp.problem import problem_1
+        self.ops, self.R = ops, R
+        np.random.seed(1000 * rank + 9)
+        env = ItscpEnv()
+        env.schedule_callback = problem_1
+        for k, v in dict(num_intersection=3, lane_length=5.0, num_lane=1, policy_length=20, signal_length=4, mode="hybrid",
+                         speed_limit=60.0).items():
+            env.config[k] = v
+        env.reset()
+        tab = HybridNetworkTables.from_env(env)
+        # pre-drawn routes: 8 per micro lane that a macro lane feeds (RoadNetwork.create_random_route)
+        routes = []
+        for l in range(tab.n_lanes):
+            if tab.lane_macro[l] == 0 and any(tab.lane_macro[a] for a in tab.prev_lanes[l]):
+                for _ in range(8):
+                    r = env.simulator.create_random_route(l).route
+                    routes.append(list(r) + [-1] * (32 - len(r)))
+        self.tab = ops.DeviceHybridTables(tab, np.array(routes, dtype=np.int32), dev)
+        self.sq, self.F, self.dt, self.um = 9, 120, 1.0 / 30.0, 60.0
+        gen = torch.Generator(device="cpu").manual_seed(177 + rank)
+        self.action = (0.1 + 0.8 * torch.rand(R, env.action_size(), generator=gen)).to(dev).requires_grad_(True)
+        self.units = R * tab.n_cells * tab.T
+        self.L, self.N, self.T = R, tab.n_cells, tab.T
+        self.err = ops.new_error_record(dev)
+        self.ev = []
+        self.counts = None
+
+    def one_pass(self, record=False):
+        self.action.grad = None
+        if record:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e[0].record()
+        reward, _, _, self.counts = self.ops.net_hybrid_rollout(self.action, self.tab, self.sq, self.F, self.dt, self.um)
+        if record:
+            e[1].record()
+        loss = -reward.sum()
+        if record:
+            e[2].record()
+        loss.backward()
+        if record:
+            e[3].record()
+            self.ev.append(e)
+        return loss.detach(), self.action.grad, self.action.grad
+
+    def cpu_baseline(self):
+        return {"value": None, "unit": "cell-steps/s", "cores": 0, "kind": "port", "sample": "not timed for this workload"}
+
+
 def main():
     args = parse()
     from dhts import dist as D
@@ -265,6 +325,9 @@ def main():
     elif args.workload == "micro":
         L, N, T = args.lanes or 4096, args.cells or 256, args.time_steps or 1000
         w = MicroWorkload(dev, rank, L, N, T)
+    elif args.workload == "itscp_hybrid":
+        w = ItscpHybridWorkload(dev, rank, args.lanes or 256, 0, 0)
+        L, N, T = w.L, w.N, w.T
     else:
         w = ItscpMacroWorkload(dev, rank, args.lanes or 256, 0, 0)
         L, N, T = w.L, w.N, w.T

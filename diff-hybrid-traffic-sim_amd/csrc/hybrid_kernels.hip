@@ -37,7 +37,7 @@ enum { K_NODE = 1, K_COMMIT = 2, K_DEPOSIT = 3, K_CELLREAD = 4, K_SIGNAL = 5, K_
 
 struct HybTables {
     NetTables net;
-    const int32_t *lane_macro; const double *lane_len; const int32_t *conv_next; const int32_t *routes;
+    const int32_t *lane_macro; const double *lane_len; const int32_t *conv_next; const int32_t *routes; const int32_t *route_ptr;
     int n_routes, route_stride, loss_steps;
 };
 
@@ -107,7 +107,7 @@ __device__ __forceinline__ float stream_load(const float *p) {
 struct HybLds {
     size_t fq, scanw, incl, vsp, vep, s0, s1, g, ab, contrib, ql, sig, lanelen, vp, vv, va, vxold, hdpv, hdvv, capv, qmicro,
         cell_lane, iface_lane, cnext, vidp, vidv, vida, vcur, vrlen, vroute, lane_n, lane_veh, hdpi, hdvi, vcp, capi, mslot,
-        capof, mlane, cbefore, convlist, linfo, caplast, total;
+        capof, mlane, cbefore, convlist, linfo, caplast, rused, total;
 };
 __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V) {
     HybLds o; size_t p = 0; const int NI = C + L;
@@ -120,7 +120,7 @@ __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V) {
     o.cell_lane = F(C); o.iface_lane = F(NI); o.cnext = F(L); o.vidp = F(V); o.vidv = F(V); o.vida = F(V); o.vcur = F(V);
     o.vrlen = F(V); o.vroute = F((size_t)V * kRouteStride); o.lane_n = F(kMaxMicro); o.lane_veh = F(kMaxMicro * kLaneCap);
     o.hdpi = F(kMaxMicro); o.hdvi = F(kMaxMicro); o.vcp = F(kMaxMicro + 1); o.capi = F(kMaxCaps); o.mslot = F(L); o.capof = F(L);
-    o.mlane = F(kMaxMicro); o.cbefore = F(kMaxMicro + 1); o.convlist = F(L); o.linfo = F(L); o.caplast = F(kMaxCaps);
+    o.mlane = F(kMaxMicro); o.cbefore = F(kMaxMicro + 1); o.convlist = F(L); o.linfo = F(L); o.caplast = F(kMaxCaps); o.rused = F(kMaxMicro);
     o.total = p;
     return o;
 }
@@ -148,7 +148,7 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
     float *vp = LF(vp), *vv = LF(vv), *va = LF(va), *vxold = LF(vxold), *hdpv = LF(hdpv), *hdvv = LF(hdvv), *capv = LF(capv), *qmicro = LF(qmicro);
     int *cell_lane_s = LI(cell_lane), *iface_lane_s = LI(iface_lane), *cnext = LI(cnext), *vidp = LI(vidp), *vidv = LI(vidv), *vida = LI(vida);
     int *vcur = LI(vcur), *vrlen = LI(vrlen), *vroute = LI(vroute), *lane_n = LI(lane_n), *lane_veh = LI(lane_veh), *hdpi = LI(hdpi), *hdvi = LI(hdvi);
-    int *vcp = LI(vcp), *capi = LI(capi), *mslot = LI(mslot), *capof = LI(capof), *mlane = LI(mlane), *cbefore = LI(cbefore), *convlist = LI(convlist), *linfo = LI(linfo), *caplast = LI(caplast);
+    int *vcp = LI(vcp), *capi = LI(capi), *mslot = LI(mslot), *capof = LI(capof), *mlane = LI(mlane), *cbefore = LI(cbefore), *convlist = LI(convlist), *linfo = LI(linfo), *caplast = LI(caplast), *rused = LI(rused);
     const float um = (float)um_d, s0f = (float)static_speed, vlen = (float)veh_len, dtf = (float)dt;
     const float *act = action + (size_t)rep * n_action;
     const size_t toff = (size_t)rep * tb.net.table_stride;
@@ -190,7 +190,7 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
                 for (int e = tb.net.nxt_ptr[l]; e < tb.net.nxt_ptr[l + 1]; ++e) spawns |= !tb.lane_macro[tb.net.nxt_idx[e]];
                 if (spawns) { if (nc < kMaxCaps) { capof[l] = nc; caplast[nc] = off + n - 1; } ++nc; convlist[nv++] = l; }
             } else {
-                if (nm < kMaxMicro) { mslot[l] = nm; mlane[nm] = l; cbefore[nm] = cells; lane_n[nm] = 0; }
+                if (nm < kMaxMicro) { mslot[l] = nm; mlane[nm] = l; cbefore[nm] = cells; lane_n[nm] = 0; rused[nm] = 0; }
                 ++nm; convlist[nv++] = l;
             }
         }
@@ -438,14 +438,17 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
                     float space = lanelen[m];
                     if (lane_n[ms]) space = vp[lane_veh[ms * kLaneCap + 0]] - 0.5f * vlen;
                     if (level >= vlen && space >= vlen * 1.0f) {
-                        if (spawned >= V || lane_n[ms] >= kLaneCap || tb.routes[(size_t)spawned * tb.route_stride] != m) { cap_fault = true; continue; }
+                        const int r_lo = tb.route_ptr[m], r_n = tb.route_ptr[m + 1] - r_lo;
+                        if (spawned >= V || lane_n[ms] >= kLaneCap || r_n <= 0) { cap_fault = true; continue; }
                         const int vi = spawned;
+                        const size_t row = (size_t)(r_lo + rused[ms] % r_n);
+                        ++rused[ms];
                         vp[vi] = 0.f; vidp[vi] = -1; vv[vi] = ul; vidv[vi] = lu.id;
                         va[vi] = cp.val - (float)((double)level - veh_len); vida[vi] = cp.id;
                         vcur[vi] = 0;
                         int rl_ = 0;
                         for (int q = 0; q < kRouteStride; ++q) {
-                            const int lid = q < tb.route_stride ? tb.routes[(size_t)spawned * tb.route_stride + q] : -1;
+                            const int lid = q < tb.route_stride ? tb.routes[row * tb.route_stride + q] : -1;
                             vroute[vi * kRouteStride + q] = lid;
                             if (lid >= 0 && rl_ == q) rl_ = q + 1;
                         }
@@ -959,7 +962,7 @@ static inline bool hyb_tables_ok(const dhts_hybrid_tables *t) {
     const dhts_net_tables *n = t ? &t->net : nullptr;
     return t && n->lane_ncell && n->lane_off && n->sig_kind && n->inter && n->lane_dx && n->left_src && n->left_gate &&
            n->right_src && n->schedule && n->replica_stride >= 0 && n->nxt_ptr && n->nxt_idx && n->prv_ptr && n->prv_idx &&
-           n->n_edges >= 0 && t->lane_macro && t->lane_len && t->conv_next && t->routes && t->n_routes > 0 &&
+           n->n_edges >= 0 && t->lane_macro && t->lane_len && t->conv_next && t->routes && t->route_ptr && t->n_routes > 0 &&
            t->route_stride > 0 && t->route_stride <= kRouteStride;
 }
 static inline HybTables hyb_tables(const dhts_hybrid_tables *t) {
@@ -969,7 +972,7 @@ static inline HybTables hyb_tables(const dhts_hybrid_tables *t) {
     h.net.lane_dx = n->lane_dx; h.net.left_src = n->left_src; h.net.left_gate = n->left_gate; h.net.right_src = n->right_src;
     h.net.schedule = n->schedule; h.net.table_stride = (size_t)n->replica_stride;
     h.net.nxt_ptr = n->nxt_ptr; h.net.nxt_idx = n->nxt_idx; h.net.prv_ptr = n->prv_ptr; h.net.prv_idx = n->prv_idx; h.net.n_edges = n->n_edges;
-    h.lane_macro = t->lane_macro; h.lane_len = t->lane_len; h.conv_next = t->conv_next; h.routes = t->routes;
+    h.lane_macro = t->lane_macro; h.lane_len = t->lane_len; h.conv_next = t->conv_next; h.routes = t->routes; h.route_ptr = t->route_ptr;
     h.n_routes = t->n_routes; h.route_stride = t->route_stride; h.loss_steps = t->loss_steps;
     return h;
 }

@@ -83,6 +83,19 @@ class MacroNetworkTables:
                                   [env.schedule[k] for k in keys])
 
 
+def group_routes(routes, n_lanes):
+    """Pre-drawn vehicle routes [n][stride] (-1 padded) -> (rows stably sorted by their first lane, route_ptr [L + 1]).
+    A spawn order recorded from the reference stays intact per lane, which is all the hand-off logic can observe."""
+    routes = np.ascontiguousarray(routes, dtype=np.int32)
+    first = routes[:, 0]
+    order = np.argsort(first, kind="stable")
+    ptr = np.zeros(n_lanes + 1, dtype=np.int32)
+    for f in first:
+        if f >= 0:
+            ptr[f + 1] += 1
+    return routes[order], np.cumsum(ptr).astype(np.int32)
+
+
 class HybridNetworkTables:
     """Tables of a network mixing macro lanes (ARZ cells) and micro lanes (IDM vehicles): the itscp environment in
     `hybrid` mode (reference _env.py:489-498: the lanes of interior intersections are micro).  Ghost sources follow

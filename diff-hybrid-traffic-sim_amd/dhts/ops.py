@@ -404,7 +404,7 @@ def net_macro_rollout(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_ma
 
 class DeviceHybridTables:
     """dhts.network.HybridNetworkTables plus the pre-drawn vehicle routes [n_routes][stride] (int, -1 padded; the k-th
-    vehicle spawned in a replica takes row k), uploaded once and shared by all replicas."""
+    vehicle spawned onto a lane takes the k-th route starting there, cyclically), uploaded once, shared by all replicas."""
 
     def __init__(self, tables, routes, device, records_per_step=0):
         import numpy as np
@@ -412,9 +412,11 @@ class DeviceHybridTables:
         self.n_lanes, self.n_cells, self.T = t.n_lanes, t.n_cells, t.T
         up = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=device)    # noqa: E731
         pad1 = lambda a: a if len(a) else np.zeros(1, dtype=np.int32)      # noqa: E731
+        from .network import group_routes
         routes = np.ascontiguousarray(routes, dtype=np.int32)
         if routes.ndim != 2 or routes.shape[0] < 1 or routes.shape[1] > 32:
             raise ValueError("routes must be [n_routes >= 1][stride <= 32]")
+        routes, route_ptr = group_routes(routes, t.n_lanes)
         self.n_routes, self.route_stride = int(routes.shape[0]), int(routes.shape[1])
         self.records_per_step = int(records_per_step)
         self._keep = [up(t.lane_ncell, torch.int32), up(t.lane_off, torch.int32), up(t.sig_kind, torch.int32), up(t.inter, torch.int32),
@@ -422,13 +424,13 @@ class DeviceHybridTables:
                       up(t.right_src, torch.int32), up(t.schedule, torch.float64), up(t.nxt_ptr, torch.int32),
                       up(pad1(t.nxt_idx), torch.int32), up(t.prv_ptr, torch.int32), up(pad1(t.prv_idx), torch.int32),
                       up(t.lane_macro, torch.int32), up(t.lane_length, torch.float64), up(t.conv_next, torch.int32),
-                      up(routes, torch.int32)]
+                      up(routes, torch.int32), up(route_ptr, torch.int32)]
         k = [x.data_ptr() for x in self._keep]
         self.net = _lib.NetTables(k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], 0, k[9], k[10], k[11], k[12], t.n_edges)
 
     def c(self, loss_steps=0):
         k = [x.data_ptr() for x in self._keep]
-        return _lib.HybridTables(self.net, k[13], k[14], k[15], k[16], self.n_routes, self.route_stride, self.records_per_step,
+        return _lib.HybridTables(self.net, k[13], k[14], k[15], k[16], k[17], self.n_routes, self.route_stride, self.records_per_step,
                                  int(loss_steps))
 
 

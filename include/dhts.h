@@ -251,8 +251,10 @@ int dhts_net_macro_rollout_bwd(const dhts_net_desc *d, const dhts_net_tables *t,
  *   lane_macro [L] int32 (1 = cells, 0 = vehicles; micro lanes have 0 cells), lane_len [L] DOUBLE,
  *   left_src -3 = own stored upstream ghost (single upstream lane is micro), right_src -1 also when the single downstream
  *   lane is micro, conv_next [T][L] int32 = the step's macro-route successor of a macro lane (per replica like left_src),
- *   routes [n_routes][route_stride] int32 (-1 padded): the route of the k-th vehicle spawned in a replica (the reference
- *   draws it with np.random at spawn time, road_network.py:604-646; callers pre-draw them).
+ *   routes [n_routes][route_stride] int32 (-1 padded), grouped by their first lane, and route_ptr [L + 1] int32 (rows
+ *   route_ptr[m] .. route_ptr[m+1] start on micro lane m): the k-th vehicle spawned onto lane m takes row
+ *   route_ptr[m] + k mod (rows of m).  The reference draws a route with np.random at spawn time (road_network.py:604-646);
+ *   callers pre-draw them (dhts/network.py: group_routes keeps a recorded spawn order intact).
  * Limits: n_cells + n_lanes <= 960, <= 64 micro lanes, <= 16 spawning lanes, <= 16 vehicles per micro lane,
  * <= 128 vehicles per replica and episode, route_stride <= 32; records_per_step (average budget of the record stream,
  * 0 = 512).  loss_steps: only the first loss_steps steps enter reward_cut and the gradient (<= 0: all).
@@ -263,6 +265,7 @@ typedef struct dhts_hybrid_tables {
     const double *lane_len;
     const int32_t *conv_next;
     const int32_t *routes;
+    const int32_t *route_ptr;
     int32_t n_routes, route_stride, records_per_step, loss_steps;
 } dhts_hybrid_tables;
 size_t dhts_net_hybrid_workspace_bytes(const dhts_net_desc *d, const dhts_hybrid_tables *t);

@@ -149,8 +149,10 @@ void oracle_net_macro_bwd(const oracle_net_desc *d, const int *lane_ncell, const
  *              left_gate -1 the blended ghost is the red value (0, u_max)),
  *   right_src  -1 also for a macro lane whose single downstream lane is micro (own stored ghost, _simulator.py:116),
  *   conv_next  [T][L] the step's macro-route successor of a macro lane (conversion target, road_network.py:113-130),
- *   routes     [n_routes][route_stride] lane ids (-1 padded): the route of the k-th vehicle spawned (the reference
- *              draws them with np.random at spawn time, road_network.py:604-646; the caller pre-draws / replays them).
+ *   routes     [n_routes][route_stride] lane ids (-1 padded) grouped by first lane, route_ptr [L+1]: the k-th vehicle
+ *              spawned onto lane m takes row route_ptr[m] + k mod (rows of m) (the reference draws them with np.random
+ *              at spawn time, road_network.py:604-646; the caller pre-draws / replays them).  n_routes also bounds
+ *              the number of vehicles of the episode.
  * Forward and reverse sweep in one call: queue [T][L], *reward (all steps), *reward_cut and g_action
  * (d reward_cut / d action, NULL = forward only) for the reward restricted to steps < t_cut; *n_spawned, *n_deposits;
  * hist_out [T+1][4][C] optional.  rc = ORACLE_OK / ORACLE_ERR_CFL / ORACLE_ERR_ROUTE. */
@@ -158,7 +160,7 @@ int oracle_net_hybrid(const oracle_net_desc *d, const int *lane_macro, const dou
                       const int *lane_ncell, const int *lane_off, const double *lane_dx,
                       const int *sig_kind, const int *inter, const int *left_src, const int *left_gate,
                       const int *right_src, const int *conv_next, const double *schedule,
-                      const int *routes, int n_routes, int route_stride, const float *action, int t_cut,
+                      const int *routes, const int *route_ptr, int n_routes, int route_stride, const float *action, int t_cut,
                       float *queue, double *reward, double *reward_cut, float *g_action, int *n_spawned,
                       int *n_deposits, float *hist_out);
 

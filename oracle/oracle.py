@@ -244,11 +244,12 @@ def net_macro(tab, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed
     return out
 
 
-def net_hybrid(tab, routes, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0,
+def net_hybrid(tab, routes, route_ptr, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0,
                t_cut=None, want_grad=True, want_hist=False):
-    """tab: dhts.network.HybridNetworkTables; routes [n][stride] int (-1 padded) in spawn order."""
+    """tab: dhts.network.HybridNetworkTables; routes [n][stride] int (-1 padded) grouped by first lane + route_ptr [L+1]
+    (dhts.network.group_routes)."""
     l = lib()
-    l.oracle_net_hybrid.argtypes = ([C.POINTER(NetDesc)] + [C.c_void_p] * 13 + [C.c_int, C.c_int, C.c_void_p, C.c_int]
+    l.oracle_net_hybrid.argtypes = ([C.POINTER(NetDesc)] + [C.c_void_p] * 14 + [C.c_int, C.c_int, C.c_void_p, C.c_int]
                                     + [C.c_void_p] * 7)
     action = _f32(action)
     T, L, Cn = tab.T, tab.n_lanes, tab.n_cells
@@ -258,7 +259,7 @@ def net_hybrid(tab, routes, action, n_inter_sq, frames_per_phase, dt, u_max, sta
     routes = i32(routes)
     args = [_p(i32(tab.lane_macro)), _p(_f64(tab.lane_length)), _p(i32(tab.lane_ncell)), _p(i32(tab.lane_off)), _p(_f64(tab.lane_dx)),
             _p(i32(tab.sig_kind)), _p(i32(tab.inter)), _p(i32(tab.left_src)), _p(i32(tab.left_gate)), _p(i32(tab.right_src)),
-            _p(i32(tab.conv_next)), _p(_f64(tab.schedule)), _p(routes)]
+            _p(i32(tab.conv_next)), _p(_f64(tab.schedule)), _p(routes), _p(i32(route_ptr))]
     queue = np.zeros((T, L), np.float32)
     reward, reward_cut = C.c_double(0), C.c_double(0)
     g = np.zeros(len(action), np.float32)

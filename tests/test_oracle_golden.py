@@ -174,7 +174,9 @@ def test_itscp_hybrid_network(oracle, golden_dir, name):
     """G8 hybrid: macro lanes, micro lanes, spawns, lane changes and deposits against the reference's own run."""
     g = load(golden_dir, "itscp_%s.npz" % name)
     t, m = itscp_hybrid_tables(g)
-    run = lambda **kw: oracle.net_hybrid(t, g["spawn_routes"], g["action"], m["num_intersection"] ** 2,     # noqa: E731
+    from dhts.network import group_routes
+    routes, route_ptr = group_routes(g["spawn_routes"], t.n_lanes)
+    run = lambda **kw: oracle.net_hybrid(t, routes, route_ptr, g["action"], m["num_intersection"] ** 2,     # noqa: E731
                                          m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"],
                                          m["speed_limit"], m["static_speed"], m["vehicle_length"], **kw)
     o = run()
