@@ -243,19 +243,30 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
     double run_in = 0., run_out = 0.; long long run_cnt = 0;
     float lane_total = 0.f;
     int fault_step = -1, fault_index = 0;
+    // per-step table entries, fetched one step ahead
+    int p_src = 0, p_gate = 0, p_cnext = -1; double p_sched = 0.;
+    auto fetch = [&](int t) {
+        if (t >= T) return;
+        if (is_ghost && g_macro) {
+            const size_t o = toff + (size_t)t * L + g_lane;
+            if (g_side == 0) { p_src = tb.net.left_src[o]; p_gate = tb.net.left_gate[o]; p_sched = tb.net.schedule[o]; }
+            else p_src = tb.net.right_src[o];
+        }
+        if (is_lane) p_cnext = tb.conv_next[toff + (size_t)t * L + tid];
+    };
+    fetch(0);
 
     for (int t = 0; t < T; ++t) {
         const float *cur = (t & 1) ? S1 : S0;
         float *nxt = (t & 1) ? S0 : S1;
         // ================= P1: boundaries =================
-        if (is_lane) cnext[tid] = tb.conv_next[toff + (size_t)t * L + tid];
+        const int src = p_src, gate = p_gate; const double sched = p_sched;
+        if (is_lane) cnext[tid] = p_cnext;
+        fetch(t + 1);
         if (is_ghost && g_macro) {
             float fr, fu, fy, fq;
-            const size_t o = toff + (size_t)t * L + g_lane;
             if (g_side == 0) {
-                const int src = tb.net.left_src[o], gate = tb.net.left_gate[o];
                 if (src == -1) {
-                    const double sched = tb.net.schedule[o];
                     const double gu = um_d * (1. - sqrt(fmax(sched, 0.) + kEps));
                     fr = (float)sched; fu = (float)gu; fy = 0.f; fq = (float)gu;
                 } else {
@@ -263,13 +274,12 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
                     if (src >= 0) { const int last = tb.net.lane_off[src] + tb.net.lane_ncell[src] - 1; gr = cur[last]; gu = cur[2 * C + last]; }
                     float s = 1.f;
                     if (gate == -1) s = 0.f;
-                    else if (gate >= 0) { const int kd = tb.net.sig_kind[gate]; if (kd != 0) s = sig[2 * tb.net.inter[gate] + (kd - 1)]; }
+                    else if (gate >= 0) { const int kd = linfo[gate] & 3; if (kd != 0) s = sig[2 * (linfo[gate] >> 2) + (kd - 1)]; }
                     fr = gr * s + 0.f * (1.0f - s);
                     fu = gu * s + um * (1.0f - s);
                     glue_from_r_u(fr, fu, um, fy, fq);
                 }
             } else {
-                const int src = tb.net.right_src[o];
                 float gr = own_r, gu = own_u;
                 if (src >= 0) { const int first = tb.net.lane_off[src]; gr = cur[first]; gu = cur[2 * C + first]; }
                 own_w[(size_t)t * 2 * L + 2 * g_lane] = own_r; own_w[(size_t)t * 2 * L + 2 * g_lane + 1] = own_u;
@@ -524,7 +534,7 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
             }
             vcp[n_micro] = cnt; vsp[n_micro] = ssum; vep[n_micro] = esum;
         }
-        __syncthreads();
+        lds_barrier();
         // ================= P5a: ordered scans over the cells (new samples and the ones leaving the window) ==========
         float x_new = 0.f;
         {
