@@ -6,15 +6,22 @@
 // gap of the head vehicle) -> one step per lane -> commit -> hand-offs in lane-id order -> queue-length loss.
 //
 // Work split inside the workgroup: the macro side runs one item per thread exactly like network_kernels.hip (ghosts,
-// interface solves, cell updates, ordered prefix mean).  The micro side is a handful of vehicles: ONE lane of an extra
-// wavefront (the "micro thread") walks them serially, with all of its state in LDS, and writes every float32 operation it
-// performs -- with the partial derivatives -- to a per-replica record stream in HBM.  The reverse kernel replays that
-// stream backwards (the same thing torch autograd does for the reference) in step with the hand-written macro adjoint; the
-// two sides meet at the hand-off records (capacitor reads, deposits) and at the signals.
+// interface solves, cell updates, ordered prefix mean).  The micro side is a handful of vehicles on a few lanes: an extra
+// wavefront (the "micro wave") takes it, lane j of that wave owning micro lane j (head gap, IDM steps, loss terms, commits)
+// and flux capacitor j; only the hand-off events themselves (spawn, lane change, despawn, deposit: rare, order-dependent)
+// are walked serially by lane 0.  All micro state lives in LDS.  Every float32 operation of the micro side is written,
+// with its partial derivatives, to a per-replica record stream in HBM: each lane stages its records in LDS and the wave
+// flushes them phase by phase (lane-ordered, coalesced), noting the per-lane counts in an index.  The reverse kernel loads a
+// step's records back into LDS and lets every lane replay its own segments backwards (the same thing torch autograd does
+// for the reference) in step with the hand-written macro adjoint; the two sides meet at the hand-off records (capacitor
+// reads, deposits) and at the signals.  Contributions that cross lanes (the leader of a head vehicle sits on another lane;
+// several lanes look at the same signal) go through per-lane outboxes that lane 0 applies in lane order, so the result does
+// not depend on timing (no atomics).
 //
 // Ids on the record stream: [0, 3V) = persistent slots of the vehicles (position, speed, ancillary a), [3V, 3V + 16) =
-// flux capacitors, above that the step's temporaries, renumbered from the same base every step; COMMIT records copy
-// temporaries into the slots at the end of a step, so the reverse kernel needs adjoint storage for one step only.
+// flux capacitors, above that the step's temporaries: a private range per lane of the micro wave (+ one for the events),
+// reused every step; COMMIT records copy temporaries into the slots at the end of a step and every temporary's adjoint is
+// cleared when its defining record is replayed, so the reverse kernel keeps one step's adjoints in LDS.
 #include <hip/hip_runtime.h>
 
 #include "../../include/dhts.h"
@@ -24,26 +31,30 @@
 
 namespace dhts {
 
-constexpr int kMaxMicro = 64;        // micro lanes per network
+constexpr int kMaxMicro = 40;        // micro lanes per network
 constexpr int kMaxCaps = 16;         // macro lanes with a micro successor
 constexpr int kLaneCap = 16;         // vehicles per micro lane
 constexpr int kMaxVeh = 128;         // vehicles per replica and episode
 constexpr int kRouteStride = 32;     // MAX_ROUTE_LENGTH, road_network.py:17
-constexpr int kMaxLocals = 2048;     // temporaries per step
+constexpr int kLaneLocals = 192;     // temporaries per lane of the micro wave and step
+constexpr int kEventLocals = 64;     // temporaries of the serial event walk per step
+constexpr int kMaxLocals = 64 * kLaneLocals + kEventLocals;
+constexpr int kStage = 64;           // staged records per lane and flush
+constexpr int kPhases = 6;           // record segments per step: head gaps, IDM, capacitors, events, loss, commits
 constexpr int kMaxStepRecords = 1024;
 constexpr int kWindow = 100000;      // RunningMean(100_000), _env.py:122
 
-enum { K_NODE = 1, K_COMMIT = 2, K_DEPOSIT = 3, K_CELLREAD = 4, K_SIGNAL = 5, K_SEED = 6, K_MARK = 7 };
+enum { K_NODE = 1, K_COMMIT = 2, K_DEPOSIT = 3, K_CELLREAD = 4, K_SIGNAL = 5, K_SEED = 6, K_IMPORT = 7 };
 
 struct HybTables {
     NetTables net;
     const int32_t *lane_macro; const double *lane_len; const int32_t *conv_next; const int32_t *routes; const int32_t *route_ptr;
-    int n_routes, route_stride, loss_steps;
+    int n_routes, route_stride, loss_steps, n_micro;
 };
 
 // workspace layout of one replica (bytes, all 16-byte aligned)
 struct HybWs {
-    size_t own_hist, rec_k, rec_i, rec_w, step_off, mark_off, xs, per_replica;
+    size_t own_hist, rec_k, rec_i, rec_w, step_off, seg_cnt, xs, per_replica;
     int rec_cap, V;
 };
 __host__ __device__ inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -58,7 +69,7 @@ __host__ __device__ inline HybWs hyb_ws(int L, int C, int T, int n_routes, int r
     w.rec_i = o; o += up16(sizeof(int4) * (size_t)w.rec_cap);
     w.rec_w = o; o += up16(sizeof(float4) * (size_t)w.rec_cap);
     w.step_off = o; o += up16(sizeof(int) * (size_t)(T + 1));
-    w.mark_off = o; o += up16(sizeof(int) * (size_t)(T + 1));
+    w.seg_cnt = o; o += up16(sizeof(unsigned short) * (size_t)T * kPhases * 64);
     w.xs = o; o += up16(sizeof(float) * (size_t)T * (size_t)(C + kMaxVeh));
     w.per_replica = o;
     return w;
@@ -67,20 +78,29 @@ __host__ __device__ inline HybWs hyb_ws(int L, int C, int T, int n_routes, int r
 struct Tv { float val; int id; };
 __device__ __forceinline__ Tv tv_c(float v) { Tv x; x.val = v; x.id = -1; return x; }
 
-struct Rec {               // the micro thread's handle on the record stream
-    int *k; int4 *i; float4 *w;
-    int n, cap, next_local, base_local;
+struct Rec {               // one lane's handle on its staging area (LDS) and its private range of temporaries
+    int *sk; int *si; float *sw;
+    int cnt, next_local;
     bool over;
 };
 __device__ __forceinline__ void rec_push(Rec &R, int kind, int out, int4 in, float4 w) {
-    if (R.n >= R.cap) { R.over = true; return; }
-    R.k[R.n] = (kind << 24) | (out & 0xffffff); R.i[R.n] = in; R.w[R.n] = w; ++R.n;
+    if (R.cnt >= kStage) { R.over = true; return; }
+    const int c = R.cnt++;
+    R.sk[c] = (kind << 24) | (out & 0xffffff);
+    int *pi = R.si + 4 * c; pi[0] = in.x; pi[1] = in.y; pi[2] = in.z; pi[3] = in.w;
+    float *pw = R.sw + 4 * c; pw[0] = w.x; pw[1] = w.y; pw[2] = w.z; pw[3] = w.w;
 }
 __device__ __forceinline__ Tv tv_leaf(Rec &R, float v) { Tv x; x.val = v; x.id = R.next_local++; return x; }
 __device__ __forceinline__ Tv tv_node4(Rec &R, float v, Tv a, float wa, Tv b, float wb, Tv c, float wc, Tv d, float wd) {
     if (a.id < 0 && b.id < 0 && c.id < 0 && d.id < 0) return tv_c(v);
     Tv x; x.val = v; x.id = R.next_local++;
     rec_push(R, K_NODE, x.id, make_int4(a.id, b.id, c.id, d.id), make_float4(wa, wb, wc, wd));
+    return x;
+}
+// a fresh variable without inputs that still owns a record (so that its adjoint is cleared on replay)
+__device__ __forceinline__ Tv tv_fresh(Rec &R, float v) {
+    Tv x; x.val = v; x.id = R.next_local++;
+    rec_push(R, K_NODE, x.id, make_int4(-1, -1, -1, -1), make_float4(0.f, 0.f, 0.f, 0.f));
     return x;
 }
 __device__ __forceinline__ Tv tv_node2(Rec &R, float v, Tv a, float wa, Tv b, float wb) {
@@ -93,7 +113,11 @@ __device__ __forceinline__ Tv tv_div(Rec &R, Tv a, Tv b) {
     return tv_node2(R, a.val / b.val, a, 1.f / b.val, b, -((a.val / b.val) / b.val));
 }
 __device__ __forceinline__ Tv tv_soft(Rec &R, Tv a, float k) {
-    return tv_node2(R, soft_switch(a.val, k), a, soft_switch_grad(a.val, k), tv_c(0.f), 0.f);
+    const float z = a.val * k;
+    const float zc = fminf(fmaxf(z, -16.f), 16.f);
+    const float sgm = 1.f / (1.f + expf(-zc));
+    const float grad = (z < -16.f || z > 16.f) ? 0.f : sgm * (1.f - sgm) * k;
+    return tv_node2(R, sgm, a, grad, tv_c(0.f), 0.f);
 }
 __device__ __forceinline__ Tv tv_pos_or_zero(Tv a) { return a.val > 0.f ? a : tv_c(0.f); }
 
@@ -107,9 +131,9 @@ __device__ __forceinline__ float stream_load(const float *p) {
 struct HybLds {
     size_t fq, scanw, incl, vsp, vep, s0, s1, g, ab, contrib, ql, sig, lanelen, vp, vv, va, vxold, hdpv, hdvv, capv, qmicro,
         cell_lane, iface_lane, cnext, vidp, vidv, vida, vcur, vrlen, vroute, lane_n, lane_veh, hdpi, hdvi, vcp, capi, mslot,
-        capof, mlane, cbefore, convlist, linfo, caplast, rused, total;
+        capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, stg_k, stg_i, stg_w, total;
 };
-__host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V) {
+__host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS) {
     HybLds o; size_t p = 0; const int NI = C + L;
     auto D = [&](size_t n) { size_t r = p; p += 8 * n; return r; };
     auto F = [&](size_t n) { size_t r = p; p += 4 * ((n + 1) & ~(size_t)1); return r; };
@@ -120,7 +144,8 @@ __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V) {
     o.cell_lane = F(C); o.iface_lane = F(NI); o.cnext = F(L); o.vidp = F(V); o.vidv = F(V); o.vida = F(V); o.vcur = F(V);
     o.vrlen = F(V); o.vroute = F((size_t)V * kRouteStride); o.lane_n = F(kMaxMicro); o.lane_veh = F(kMaxMicro * kLaneCap);
     o.hdpi = F(kMaxMicro); o.hdvi = F(kMaxMicro); o.vcp = F(kMaxMicro + 1); o.capi = F(kMaxCaps); o.mslot = F(L); o.capof = F(L);
-    o.mlane = F(kMaxMicro); o.cbefore = F(kMaxMicro + 1); o.convlist = F(L); o.linfo = F(L); o.caplast = F(kMaxCaps); o.rused = F(kMaxMicro);
+    o.mlane = F(kMaxMicro); o.cbefore = F(kMaxMicro + 1); o.convlist = F(L); o.linfo = F(L); o.caplast = F(kMaxCaps); o.rused = F(kMaxMicro); o.caplane = F(kMaxCaps); o.capleaf = F(kMaxCaps);
+    o.stg_k = F((size_t)NS * kStage); o.stg_i = F((size_t)NS * kStage * 4); o.stg_w = F((size_t)NS * kStage * 4);
     o.total = p;
     return o;
 }
@@ -139,7 +164,8 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
     const int NI = C + L, Cp = (C + 63) & ~63;
     const HybWs ws = hyb_ws(L, C, T, tb.n_routes, records_per_step);
     const int V = ws.V;
-    const HybLds lo = hyb_lds(L, C, sq, V);
+    const int NS = tb.n_micro > kMaxCaps ? tb.n_micro : kMaxCaps;      // lanes of the micro wave that stage records
+    const HybLds lo = hyb_lds(L, C, sq, V, NS);
     double *Fq = reinterpret_cast<double *>(lds + lo.fq), *scanw = reinterpret_cast<double *>(lds + lo.scanw);
     double *incl = reinterpret_cast<double *>(lds + lo.incl), *vsp = reinterpret_cast<double *>(lds + lo.vsp), *vep = reinterpret_cast<double *>(lds + lo.vep);
 #define LF(name) reinterpret_cast<float *>(lds + lo.name)
@@ -148,7 +174,8 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
     float *vp = LF(vp), *vv = LF(vv), *va = LF(va), *vxold = LF(vxold), *hdpv = LF(hdpv), *hdvv = LF(hdvv), *capv = LF(capv), *qmicro = LF(qmicro);
     int *cell_lane_s = LI(cell_lane), *iface_lane_s = LI(iface_lane), *cnext = LI(cnext), *vidp = LI(vidp), *vidv = LI(vidv), *vida = LI(vida);
     int *vcur = LI(vcur), *vrlen = LI(vrlen), *vroute = LI(vroute), *lane_n = LI(lane_n), *lane_veh = LI(lane_veh), *hdpi = LI(hdpi), *hdvi = LI(hdvi);
-    int *vcp = LI(vcp), *capi = LI(capi), *mslot = LI(mslot), *capof = LI(capof), *mlane = LI(mlane), *cbefore = LI(cbefore), *convlist = LI(convlist), *linfo = LI(linfo), *caplast = LI(caplast), *rused = LI(rused);
+    int *vcp = LI(vcp), *capi = LI(capi), *mslot = LI(mslot), *capof = LI(capof), *mlane = LI(mlane), *cbefore = LI(cbefore), *convlist = LI(convlist), *linfo = LI(linfo), *caplast = LI(caplast), *rused = LI(rused), *caplane = LI(caplane), *capleaf = LI(capleaf);
+    int *stg_k = LI(stg_k), *stg_i = LI(stg_i); float *stg_w = LF(stg_w);
     const float um = (float)um_d, s0f = (float)static_speed, vlen = (float)veh_len, dtf = (float)dt;
     const float *act = action + (size_t)rep * n_action;
     const size_t toff = (size_t)rep * tb.net.table_stride;
@@ -158,9 +185,11 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
     float *queue_r = queue + (size_t)rep * T * L;
     char *wsr = workspace + (size_t)rep * ws.per_replica;
     float *own_w = reinterpret_cast<float *>(wsr + ws.own_hist);
-    int *step_off = reinterpret_cast<int *>(wsr + ws.step_off), *mark_off = reinterpret_cast<int *>(wsr + ws.mark_off);
+    int *step_off = reinterpret_cast<int *>(wsr + ws.step_off);
+    unsigned short *seg_cnt = reinterpret_cast<unsigned short *>(wsr + ws.seg_cnt);
     float *xs = reinterpret_cast<float *>(wsr + ws.xs);
-    const bool is_mt = (tid == B - 64);            // the micro thread: lane 0 of the extra wavefront
+    const int mw = tid - (B - 64);                  // lane of the micro wave (the extra wavefront), negative elsewhere
+    const bool in_mw = mw >= 0, is_mt = (mw == 0);
     const int loss_steps = tb.loss_steps > 0 ? tb.loss_steps : T;
 
     // ---- setup: maps, static lists
@@ -188,7 +217,7 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
                 ++mac; cells += n;
                 bool spawns = false;
                 for (int e = tb.net.nxt_ptr[l]; e < tb.net.nxt_ptr[l + 1]; ++e) spawns |= !tb.lane_macro[tb.net.nxt_idx[e]];
-                if (spawns) { if (nc < kMaxCaps) { capof[l] = nc; caplast[nc] = off + n - 1; } ++nc; convlist[nv++] = l; }
+                if (spawns) { if (nc < kMaxCaps) { capof[l] = nc; caplast[nc] = off + n - 1; caplane[nc] = l; } ++nc; convlist[nv++] = l; }
             } else {
                 if (nm < kMaxMicro) { mslot[l] = nm; mlane[nm] = l; cbefore[nm] = cells; lane_n[nm] = 0; rused[nm] = 0; }
                 ++nm; convlist[nv++] = l;
@@ -200,7 +229,7 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
     __syncthreads();
     n_macro = (int)scanw[0]; n_micro = (int)scanw[1]; n_caps = (int)scanw[2]; n_conv = (int)scanw[3];
     const int NIm = C + n_macro;                     // interfaces that exist
-    if (n_micro > kMaxMicro || n_caps > kMaxCaps) { if (tid == 0) net_fault(err, DHTS_FAULT_CAPACITY, -1, 0, n_micro); return; }
+    if (n_micro > kMaxMicro || n_caps > kMaxCaps || n_micro != tb.n_micro) { if (tid == 0) net_fault(err, DHTS_FAULT_CAPACITY, -1, 0, n_micro); return; }
     __syncthreads();
     (void)NI;
     // ---- per-thread roles
@@ -228,17 +257,46 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
     // signals of step 0
     if (tid < sq) { float we, ns, a, pr; int ai; phase_signal(act, n_action, sq, F, 0, tid, we, ns, a, pr, ai); sig[2 * tid] = we; sig[2 * tid + 1] = ns; }
 
-    // ---- micro thread state
+    // ---- micro wave state
+    int *grk = reinterpret_cast<int *>(wsr + ws.rec_k);
+    int4 *gri = reinterpret_cast<int4 *>(wsr + ws.rec_i);
+    float4 *grw = reinterpret_cast<float4 *>(wsr + ws.rec_w);
+    const int base_local = 3 * V + kMaxCaps;
     Rec rec;
-    rec.k = reinterpret_cast<int *>(wsr + ws.rec_k); rec.i = reinterpret_cast<int4 *>(wsr + ws.rec_i);
-    rec.w = reinterpret_cast<float4 *>(wsr + ws.rec_w);
-    rec.n = 0; rec.cap = ws.rec_cap; rec.base_local = 3 * V + kMaxCaps; rec.next_local = rec.base_local; rec.over = false;
+    {
+        const int sl = (in_mw && mw < NS) ? mw : 0;
+        rec.sk = stg_k + sl * kStage; rec.si = stg_i + sl * kStage * 4; rec.sw = stg_w + sl * kStage * 4;
+        rec.cnt = 0; rec.next_local = base_local; rec.over = false;
+    }
+    int rec_n = 0, step_start = 0;                   // records of this replica in HBM so far (uniform over the micro wave)
     int spawned = 0, deposits = 0; bool cap_fault = false;
     IdmParams idm;
     idm.a_max = um_d * 1.0; idm.a_pref = um_d * 0.8; idm.v_target = um_d * 0.9; idm.min_space = veh_len * 0.1; idm.time_pref = 0.1; idm.length = veh_len;
     double sig_sum = 0.; long long sig_cnt = 0;          // signal_rms (never reaches its window in one episode)
     if (is_mt) for (int j = 0; j < kMaxCaps; ++j) { capv[j] = 0.f; capi[j] = -1; }
     __syncthreads();
+    // flush the staged records of all lanes to HBM in lane order, note the per-lane counts (micro wave, convergent)
+    auto flush = [&](int t, int phase) {
+        const int c = (mw < NS) ? rec.cnt : 0;
+        int inc = c;
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d, 64); if (mw >= d) inc += up; }
+        const int total = __shfl(inc, 63, 64), exc = inc - c;
+        seg_cnt[((size_t)t * kPhases + phase) * 64 + mw] = (unsigned short)c;
+        if (rec_n + total > ws.rec_cap) cap_fault = true;
+        else if (total > 0) {
+            for (int s_ = 0; s_ < NS; ++s_) {
+                const int cs = __shfl(c, s_, 64), os = __shfl(exc, s_, 64);
+                for (int r = mw; r < cs; r += 64) {
+                    const int q = s_ * kStage + r;
+                    grk[rec_n + os + r] = stg_k[q];
+                    gri[rec_n + os + r] = make_int4(stg_i[4 * q], stg_i[4 * q + 1], stg_i[4 * q + 2], stg_i[4 * q + 3]);
+                    grw[rec_n + os + r] = make_float4(stg_w[4 * q], stg_w[4 * q + 1], stg_w[4 * q + 2], stg_w[4 * q + 3]);
+                }
+            }
+            rec_n += total;
+        }
+        rec.cnt = 0;
+    };
 
     double run_in = 0., run_out = 0.; long long run_cnt = 0;
     float lane_total = 0.f;
@@ -293,13 +351,16 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
             float *g = G + (size_t)tid * 4;
             g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
         }
-        if (is_mt) {
-            step_off[t] = rec.n;
-            rec.next_local = rec.base_local;
-            for (int k = 0; k < n_micro; ++k) {
-                hdpv[k] = 1000.f; hdvv[k] = 0.f; hdpi[k] = -1; hdvi[k] = -1;
+        if (in_mw) {
+            if (is_mt) step_off[t] = rec_n;
+            step_start = rec_n;
+            rec.next_local = base_local + mw * kLaneLocals;
+            const int k = mw;
+            const bool act = k < n_micro && lane_n[k < n_micro ? k : 0] > 0;
+            if (k < n_micro) { hdpv[k] = 1000.f; hdvv[k] = 0.f; hdpi[k] = -1; hdvi[k] = -1; }
+            Tv fin = tv_c(0.f), green_dp = tv_c(1000.f), green_dv = tv_c(0.f), red_dp = tv_c(0.f);
+            if (act) {
                 const int nv = lane_n[k];
-                if (nv == 0) continue;
                 const int l = mlane[k];
                 const int hv = lane_veh[k * kLaneCap + nv - 1];
                 const int *route = vroute + hv * kRouteStride;
@@ -308,29 +369,28 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
                 Tv hs; hs.val = vv[hv]; hs.id = vidv[hv];
                 const Tv Lc = tv_c(lanelen[l]), half = tv_c(vlen * 0.5f);
                 Tv reach = tv_sub(rec, tv_sub(rec, Lc, hp), half);
-                Tv green_dp = tv_c(1000.f), green_dv = tv_c(0.f);
                 for (int j = cursor; j < rlen - 1; ++j) {
                     const int there = route[j + 1];
                     const int ms = mslot[there];
                     if (ms < 0) break;                       // macro successor: defaults
                     if (lane_n[ms]) {
+                        // the leader is another lane's tail vehicle: imported through two temporaries
                         const int lv = lane_veh[ms * kLaneCap + 0];
-                        Tv lp; lp.val = vp[lv]; lp.id = vidp[lv];
-                        Tv lsp; lsp.val = vv[lv]; lsp.id = vidv[lv];
+                        Tv lp = tv_leaf(rec, vp[lv]), lsp = tv_leaf(rec, vv[lv]);
+                        rec_push(rec, K_IMPORT, 0, make_int4(lp.id, lsp.id, vidp[lv], vidv[lv]), make_float4(0.f, 0.f, 0.f, 0.f));
                         green_dp = tv_pos_or_zero(tv_add(rec, reach, tv_sub(rec, lp, half)));
                         green_dv = tv_sub(rec, hs, lsp);
                         break;
                     }
                     reach = tv_add(rec, reach, tv_c(lanelen[there]));
                 }
-                Tv red_dp = tv_pos_or_zero(tv_sub(rec, tv_sub(rec, Lc, hp), half));
+                red_dp = tv_pos_or_zero(tv_sub(rec, tv_sub(rec, Lc, hp), half));
                 const bool prev_exist = cursor > 0, next_exist = cursor < rlen - 1;
                 Tv prev_s = tv_c(0.f), next_s = tv_c(0.f);
                 if (prev_exist) prev_s = tv_soft(rec, tv_sub(rec, tv_c(0.f), hp), 16.f);
                 Tv curr_s = tv_mul(rec, tv_soft(rec, hp, 16.f), tv_soft(rec, tv_sub(rec, Lc, hp), 16.f));
                 if (next_exist) next_s = tv_soft(rec, tv_sub(rec, hp, Lc), 16.f);
                 Tv total = tv_add(rec, tv_add(rec, prev_s, curr_s), next_s);
-                Tv fin = tv_c(0.f);
                 for (int w = 0; w < 3; ++w) {
                     if ((w == 0 && !prev_exist) || (w == 2 && !next_exist)) continue;
                     const int lid = route[cursor + w - 1];
@@ -344,14 +404,23 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
                     }
                     fin = tv_add(rec, fin, tv_mul(rec, tv_div(rec, sc, total), sv));
                 }
-                sig_sum += (double)fin.val; ++sig_cnt;
-                const float k2 = 32.f / fabsf((float)(sig_sum / (double)sig_cnt));
+            }
+            // signal_rms: running mean over the occupied lanes in lane order (_simulator.py:249-256)
+            double ssum = act ? (double)fin.val : 0.; int scnt = act ? 1 : 0;
+            for (int d = 1; d < 64; d <<= 1) {
+                const double us = __shfl_up(ssum, d, 64); const int uc = __shfl_up(scnt, d, 64);
+                if (mw >= d) { ssum += us; scnt += uc; }
+            }
+            if (act) {
+                const float k2 = 32.f / fabsf((float)((sig_sum + ssum) / (double)(sig_cnt + scnt)));
                 Tv fs = tv_soft(rec, tv_sub(rec, fin, tv_c(0.5f)), k2);
                 Tv one_m = tv_sub(rec, tv_c(1.f), fs);
                 Tv dp_ = tv_add(rec, tv_mul(rec, green_dp, fs), tv_mul(rec, red_dp, one_m));
                 Tv dv_ = tv_add(rec, tv_mul(rec, green_dv, fs), tv_mul(rec, tv_c(0.f), one_m));
                 hdpv[k] = dp_.val; hdpi[k] = dp_.id; hdvv[k] = dv_.val; hdvi[k] = dv_.id;
             }
+            sig_sum += __shfl(ssum, 63, 64); sig_cnt += __shfl(scnt, 63, 64);
+            flush(t, 0);
         }
         lds_barrier();
         // ================= P2: interface solves | IDM steps =================
@@ -370,10 +439,10 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
             ab[0] = f.A[0]; ab[1] = f.A[1]; ab[2] = f.A[2]; ab[3] = f.A[3];
             ab[4] = f.B[0]; ab[5] = f.B[1]; ab[6] = f.B[2]; ab[7] = f.B[3];
         }
-        if (is_mt) {
-            for (int k = 0; k < n_micro; ++k) {
+        if (in_mw) {
+            const int k = mw;
+            if (k < n_micro && lane_n[k] > 0) {
                 const int nv = lane_n[k];
-                if (nv == 0) continue;
                 Tv newp[kLaneCap], newv[kLaneCap];
                 Tv hd_p; hd_p.val = hdpv[k]; hd_p.id = hdpi[k];
                 Tv hd_v; hd_v.val = hdvv[k]; hd_v.id = hdvi[k];
@@ -396,14 +465,15 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
                         newp[i] = tv_node4(rec, o.np, p_, o.dE[0], v_, o.dE[1], pl, o.dLd[0], vl, o.dLd[1]);
                         newv[i] = tv_node4(rec, o.nv, p_, o.dE[2], v_, o.dE[3], pl, o.dLd[2], vl, o.dLd[3]);
                     }
-                    if (newp[i].id < 0) newp[i] = tv_leaf(rec, o.np);
-                    if (newv[i].id < 0) newv[i] = tv_leaf(rec, o.nv);
+                    if (newp[i].id < 0) newp[i] = tv_fresh(rec, o.np);
+                    if (newv[i].id < 0) newv[i] = tv_fresh(rec, o.nv);
                 }
                 for (int i = 0; i < nv; ++i) {
                     const int vi = lane_veh[k * kLaneCap + i];
                     vp[vi] = newp[i].val; vidp[vi] = newp[i].id; vv[vi] = newv[i].val; vidv[vi] = newv[i].id;
                 }
             }
+            flush(t, 1);
         }
         lds_barrier();
         // ================= P3: cell updates + tape | next step's signals =================
@@ -427,112 +497,150 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
         }
         if (tid < sq && t + 1 < T) { float we, ns, a, pr; int ai; phase_signal(act, n_action, sq, F, t + 1, tid, we, ns, a, pr, ai); sig[2 * tid] = we; sig[2 * tid + 1] = ns; }
         lds_barrier();
-        // ================= P4: hand-offs in lane-id order (micro thread) =================
-        if (is_mt) {
-            mark_off[t] = rec.n;
-            rec_push(rec, K_MARK, 0, make_int4(0, 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f));
-            for (int ci = 0; ci < n_conv; ++ci) {
-                const int l = convlist[ci];
-                if (capof[l] >= 0) {
-                    const int m = cnext[l];
-                    if (m < 0 || mslot[m] < 0) continue;
-                    const int j = capof[l], ms = mslot[m];
+        // ================= P4: flux capacitors (lane j of the micro wave), then the hand-off events in lane-id order =========
+        if (in_mw) {
+            // capacitors: += r u dt of the last cell (conversion.py:32-36); the spawn itself is an event below
+            if (mw < n_caps) {
+                const int j = mw, l = caplane[j];
+                const int m = cnext[l];
+                if (m >= 0 && mslot[m] >= 0) {
                     const int last = caplast[j];
-                    const float rl = nxt[last], ul = nxt[2 * C + last];
-                    Tv lr = tv_leaf(rec, rl), lu = tv_leaf(rec, ul);
+                    Tv lr = tv_leaf(rec, nxt[last]), lu = tv_leaf(rec, nxt[2 * C + last]);
                     rec_push(rec, K_CELLREAD, 0, make_int4(lr.id, lu.id, last, 0), make_float4(0.f, 0.f, 0.f, 0.f));
                     Tv cp; cp.val = capv[j]; cp.id = capi[j];
                     cp = tv_add(rec, cp, tv_mul(rec, tv_mul(rec, lr, lu), tv_c(dtf)));
                     capv[j] = cp.val; capi[j] = cp.id;
-                    const float level = cp.val;
-                    float space = lanelen[m];
-                    if (lane_n[ms]) space = vp[lane_veh[ms * kLaneCap + 0]] - 0.5f * vlen;
-                    if (level >= vlen && space >= vlen * 1.0f) {
-                        const int r_lo = tb.route_ptr[m], r_n = tb.route_ptr[m + 1] - r_lo;
-                        if (spawned >= V || lane_n[ms] >= kLaneCap || r_n <= 0) { cap_fault = true; continue; }
-                        const int vi = spawned;
-                        const size_t row = (size_t)(r_lo + rused[ms] % r_n);
-                        ++rused[ms];
-                        vp[vi] = 0.f; vidp[vi] = -1; vv[vi] = ul; vidv[vi] = lu.id;
-                        va[vi] = cp.val - (float)((double)level - veh_len); vida[vi] = cp.id;
-                        vcur[vi] = 0;
-                        int rl_ = 0;
-                        for (int q = 0; q < kRouteStride; ++q) {
-                            const int lid = q < tb.route_stride ? tb.routes[row * tb.route_stride + q] : -1;
-                            vroute[vi * kRouteStride + q] = lid;
-                            if (lid >= 0 && rl_ == q) rl_ = q + 1;
-                        }
-                        vrlen[vi] = rl_;
-                        capv[j] = (float)((double)level - veh_len); capi[j] = -1;
-                        for (int q = lane_n[ms]; q > 0; --q) lane_veh[ms * kLaneCap + q] = lane_veh[ms * kLaneCap + q - 1];
-                        lane_veh[ms * kLaneCap + 0] = vi;
-                        ++lane_n[ms];
-                        ++spawned;
-                    }
-                    continue;
-                }
-                const int k = mslot[l];
-                const int nv = lane_n[k];
-                if (nv == 0) continue;
-                const int vi = lane_veh[k * kLaneCap + nv - 1];
-                const int cursor = vcur[vi], rlen = vrlen[vi];
-                const int nid = cursor < rlen - 1 ? vroute[vi * kRouteStride + cursor + 1] : -1;
-                const float Lf = lanelen[l];
-                if (nid == -1) {
-                    if (vp[vi] >= Lf) --lane_n[k];
-                } else if (mslot[nid] >= 0) {
-                    if (vp[vi] >= Lf) {
-                        const int ms = mslot[nid];
-                        if (lane_n[ms] >= kLaneCap) { cap_fault = true; continue; }
-                        --lane_n[k];
-                        Tv p_; p_.val = vp[vi]; p_.id = vidp[vi];
-                        p_ = tv_sub(rec, p_, tv_c(Lf));
-                        vp[vi] = p_.val; vidp[vi] = p_.id;
-                        for (int q = lane_n[ms]; q > 0; --q) lane_veh[ms * kLaneCap + q] = lane_veh[ms * kLaneCap + q - 1];
-                        lane_veh[ms * kLaneCap + 0] = vi;
-                        ++lane_n[ms];
-                        ++vcur[vi];
-                    }
-                } else if (vp[vi] > Lf + 1.0f * vlen) {
-                    --lane_n[k];
-                    ++deposits;
-                    const float front = vp[vi] - Lf, rear = front - vlen;
-                    const double dxd = tb.net.lane_dx[nid];
-                    const float dx = (float)dxd;
-                    const int ncell = tb.net.lane_ncell[nid], off = tb.net.lane_off[nid];
-                    for (int q = 0; q < ncell; ++q) {
-                        const double c_lo = dxd * q, c_hi = dxd * (q + 1);
-                        if (!(c_hi > (double)rear && c_lo < (double)front)) break;
-                        const bool hi_is_front = (double)front > c_hi, lo_is_rear = (double)rear < c_lo;
-                        const float hi = hi_is_front ? front : (float)c_hi, lo = lo_is_rear ? rear : (float)c_lo;
-                        const float overlap = dx + vlen - (hi - lo);
-                        const int cell = off + q;
-                        float n_r = nxt[cell] + (va[vi] / vlen) * (overlap / dx);
-                        if (n_r > 1.0f - 1e-5f) n_r = n_r - (float)((double)n_r - (1.0 - 1e-5));
-                        else if (n_r < 1e-5f) n_r = n_r - (float)((double)n_r - 1e-5);
-                        rec_push(rec, K_DEPOSIT, nid, make_int4(vida[vi], vidp[vi], vidv[vi], cell),
-                                 make_float4(overlap, (float)(-(int)hi_is_front + (int)lo_is_rear), n_r, va[vi]));
-                        float yy, qq;
-                        glue_from_r_u(n_r, vv[vi], um, yy, qq);
-                        nxt[cell] = n_r; nxt[C + cell] = yy; nxt[2 * C + cell] = vv[vi];     // u_eq keeps its pre-deposit value
-                    }
+                    capleaf[j] = lu.id;                      // the speed leaf, for a spawn in this step
                 }
             }
-            // vehicle samples of the loss' running mean, per micro lane in id order
-            int cnt = 0; double ssum = 0., esum = 0.;
-            for (int k = 0; k < n_micro; ++k) {
-                vcp[k] = cnt; vsp[k] = ssum; vep[k] = esum;
-                for (int i = 0; i < lane_n[k]; ++i) {
+            flush(t, 2);
+            // is there any event at all this step?  (the common case is none)
+            bool ev = false;
+            if (mw < n_caps) {
+                const int j = mw, m = cnext[caplane[j]];
+                if (m >= 0 && mslot[m] >= 0) {
+                    const int ms = mslot[m];
+                    float space = lanelen[m];
+                    if (lane_n[ms]) space = vp[lane_veh[ms * kLaneCap + 0]] - 0.5f * vlen;
+                    ev = capv[j] >= vlen && space >= vlen * 1.0f;
+                }
+            }
+            if (mw < n_micro && lane_n[mw] > 0) {
+                const int vi = lane_veh[mw * kLaneCap + lane_n[mw] - 1];
+                ev = ev || vp[vi] >= lanelen[mlane[mw]];
+            }
+            if (__any(ev) && is_mt) {
+                const int keep_local = rec.next_local;
+                rec.next_local = base_local + 64 * kLaneLocals;
+                for (int ci = 0; ci < n_conv; ++ci) {
+                    const int l = convlist[ci];
+                    if (capof[l] >= 0) {
+                        const int m = cnext[l];
+                        if (m < 0 || mslot[m] < 0) continue;
+                        const int j = capof[l], ms = mslot[m];
+                        const float level = capv[j];
+                        float space = lanelen[m];
+                        if (lane_n[ms]) space = vp[lane_veh[ms * kLaneCap + 0]] - 0.5f * vlen;
+                        if (level >= vlen && space >= vlen * 1.0f) {            // conversion.py:52-73
+                            const int r_lo = tb.route_ptr[m], r_n = tb.route_ptr[m + 1] - r_lo;
+                            if (spawned >= V || lane_n[ms] >= kLaneCap || r_n <= 0) { cap_fault = true; continue; }
+                            const int vi = spawned;
+                            const size_t row = (size_t)(r_lo + rused[ms] % r_n);
+                            ++rused[ms];
+                            vp[vi] = 0.f; vidp[vi] = -1;
+                            vv[vi] = nxt[2 * C + caplast[j]]; vidv[vi] = capleaf[j];
+                            va[vi] = level - (float)((double)level - veh_len); vida[vi] = capi[j];
+                            vcur[vi] = 0;
+                            int rl_ = 0;
+                            for (int q = 0; q < kRouteStride; ++q) {
+                                const int lid = q < tb.route_stride ? tb.routes[row * tb.route_stride + q] : -1;
+                                vroute[vi * kRouteStride + q] = lid;
+                                if (lid >= 0 && rl_ == q) rl_ = q + 1;
+                            }
+                            vrlen[vi] = rl_;
+                            capv[j] = (float)((double)level - veh_len); capi[j] = -1;
+                            for (int q = lane_n[ms]; q > 0; --q) lane_veh[ms * kLaneCap + q] = lane_veh[ms * kLaneCap + q - 1];
+                            lane_veh[ms * kLaneCap + 0] = vi;
+                            ++lane_n[ms];
+                            ++spawned;
+                        }
+                        continue;
+                    }
+                    const int k = mslot[l];
+                    const int nv = lane_n[k];
+                    if (nv == 0) continue;
+                    const int vi = lane_veh[k * kLaneCap + nv - 1];
+                    const int cursor = vcur[vi], rlen = vrlen[vi];
+                    const int nid = cursor < rlen - 1 ? vroute[vi * kRouteStride + cursor + 1] : -1;
+                    const float Lf = lanelen[l];
+                    if (nid == -1) {                                             // micro -> none (:203-215)
+                        if (vp[vi] >= Lf) --lane_n[k];
+                    } else if (mslot[nid] >= 0) {                                // micro -> micro (:175-200)
+                        if (vp[vi] >= Lf) {
+                            const int ms = mslot[nid];
+                            if (lane_n[ms] >= kLaneCap) { cap_fault = true; continue; }
+                            --lane_n[k];
+                            Tv p_; p_.val = vp[vi]; p_.id = vidp[vi];
+                            p_ = tv_sub(rec, p_, tv_c(Lf));
+                            vp[vi] = p_.val; vidp[vi] = p_.id;
+                            for (int q = lane_n[ms]; q > 0; --q) lane_veh[ms * kLaneCap + q] = lane_veh[ms * kLaneCap + q - 1];
+                            lane_veh[ms * kLaneCap + 0] = vi;
+                            ++lane_n[ms];
+                            ++vcur[vi];
+                        }
+                    } else if (vp[vi] > Lf + 1.0f * vlen) {                      // micro -> macro (:76-171)
+                        --lane_n[k];
+                        ++deposits;
+                        const float front = vp[vi] - Lf, rear = front - vlen;
+                        const double dxd = tb.net.lane_dx[nid];
+                        const float dx = (float)dxd;
+                        const int ncell = tb.net.lane_ncell[nid], off = tb.net.lane_off[nid];
+                        for (int q = 0; q < ncell; ++q) {
+                            const double c_lo = dxd * q, c_hi = dxd * (q + 1);
+                            if (!(c_hi > (double)rear && c_lo < (double)front)) break;
+                            const bool hi_is_front = (double)front > c_hi, lo_is_rear = (double)rear < c_lo;
+                            const float hi = hi_is_front ? front : (float)c_hi, lo = lo_is_rear ? rear : (float)c_lo;
+                            const float overlap = dx + vlen - (hi - lo);
+                            const int cell = off + q;
+                            float n_r = nxt[cell] + (va[vi] / vlen) * (overlap / dx);
+                            if (n_r > 1.0f - 1e-5f) n_r = n_r - (float)((double)n_r - (1.0 - 1e-5));
+                            else if (n_r < 1e-5f) n_r = n_r - (float)((double)n_r - 1e-5);
+                            rec_push(rec, K_DEPOSIT, nid, make_int4(vida[vi], vidp[vi], vidv[vi], cell),
+                                     make_float4(overlap, (float)(-(int)hi_is_front + (int)lo_is_rear), n_r, va[vi]));
+                            float yy, qq;
+                            glue_from_r_u(n_r, vv[vi], um, yy, qq);
+                            nxt[cell] = n_r; nxt[C + cell] = yy; nxt[2 * C + cell] = vv[vi];     // u_eq keeps its pre-deposit value
+                        }
+                    }
+                }
+                if (rec.next_local - (base_local + 64 * kLaneLocals) > kEventLocals) cap_fault = true;
+                rec.next_local = keep_local;
+            }
+            flush(t, 3);
+            // vehicle samples of the loss' running mean: exclusive prefixes over the micro lanes in id order
+            {
+                const int k = mw;
+                const int c = k < n_micro ? lane_n[k] : 0;
+                int inc = c;
+                for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d, 64); if (mw >= d) inc += up; }
+                const int exc = inc - c;
+                double ssum = 0., esum = 0.;
+                for (int i = 0; i < c; ++i) {
                     const int vi = lane_veh[k * kLaneCap + i];
-                    const long long idx = run_cnt + cbefore[k] + cnt;
+                    const long long idx = run_cnt + cbefore[k] + exc + i;
                     const float x = s0f - vv[vi];
                     float xo = 0.f;
                     if (idx >= kWindow) xo = stream_load(xs + (idx - kWindow));
                     xs[idx] = x; vxold[vi] = xo;
-                    ssum += (double)x; esum += (double)xo; ++cnt;
+                    ssum += (double)x; esum += (double)xo;
                 }
+                double is_ = ssum, ie_ = esum;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const double us = __shfl_up(is_, d, 64), ue = __shfl_up(ie_, d, 64);
+                    if (mw >= d) { is_ += us; ie_ += ue; }
+                }
+                if (k <= n_micro) { vcp[k] = exc; vsp[k] = is_ - ssum; vep[k] = ie_ - esum; }
             }
-            vcp[n_micro] = cnt; vsp[n_micro] = ssum; vep[n_micro] = esum;
         }
         lds_barrier();
         // ================= P5a: ordered scans over the cells (new samples and the ones leaving the window) ==========
@@ -574,44 +682,51 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
                 float *hn = hist_r + (size_t)(t + 1) * 4 * C;
                 hn[tid] = nxt[tid]; hn[C + tid] = nxt[C + tid]; hn[2 * C + tid] = nxt[2 * C + tid]; hn[3 * C + tid] = nxt[3 * C + tid];
             }
-            if (is_mt) {
-                for (int k = 0; k < n_micro; ++k) {
+            if (in_mw) {
+                const int k = mw;
+                if (k < n_micro) {
                     qmicro[k] = 0.f;
                     const int nv = lane_n[k];
-                    if (nv == 0) continue;
-                    const int cb = cbefore[k];
-                    double pa = run_in + vsp[k], pb = run_out + vep[k];
-                    if (cb > 0) {
-                        const int c = cb - 1;
-                        for (int w = 0; w < (c >> 6); ++w) { pa += scanw[w]; pb += scanw[16 + w]; }
-                        pa += incl[c]; pb += incl[C + c];
+                    if (nv > 0) {
+                        const int cb = cbefore[k];
+                        double pa = run_in + vsp[k], pb = run_out + vep[k];
+                        if (cb > 0) {
+                            const int c = cb - 1;
+                            for (int w = 0; w < (c >> 6); ++w) { pa += scanw[w]; pb += scanw[16 + w]; }
+                            pa += incl[c]; pb += incl[C + c];
+                        }
+                        long long n = run_cnt + cb + vcp[k];
+                        Tv qlen = tv_c(0.f);
+                        for (int i = 0; i < nv; ++i) {
+                            const int vi = lane_veh[k * kLaneCap + i];
+                            Tv v_; v_.val = vv[vi]; v_.id = vidv[vi];
+                            Tv xs_ = tv_sub(rec, tv_c(s0f), v_);
+                            pa += (double)xs_.val; pb += (double)vxold[vi]; ++n;
+                            const double mean = n > kWindow ? (pa - pb) / (double)kWindow : pa / (double)n;
+                            const float kk = 16.f / fabsf((float)mean);
+                            qlen = tv_add(rec, qlen, tv_soft(rec, xs_, kk));
+                        }
+                        qmicro[k] = (qlen.val * qlen.val) * dtf;
+                        if (qlen.id >= 0 && t < loss_steps)
+                            rec_push(rec, K_SEED, 0, make_int4(qlen.id, 0, 0, 0), make_float4(-1.0f * dtf * 2.f * qlen.val, 0.f, 0.f, 0.f));
                     }
-                    long long n = run_cnt + cb + vcp[k];
-                    Tv qlen = tv_c(0.f);
-                    for (int i = 0; i < nv; ++i) {
-                        const int vi = lane_veh[k * kLaneCap + i];
-                        Tv v_; v_.val = vv[vi]; v_.id = vidv[vi];
-                        Tv xs_ = tv_sub(rec, tv_c(s0f), v_);
-                        pa += (double)xs_.val; pb += (double)vxold[vi]; ++n;
-                        const double mean = n > kWindow ? (pa - pb) / (double)kWindow : pa / (double)n;
-                        const float kk = 16.f / fabsf((float)mean);
-                        qlen = tv_add(rec, qlen, tv_soft(rec, xs_, kk));
-                    }
-                    qmicro[k] = (qlen.val * qlen.val) * dtf;
-                    if (qlen.id >= 0 && t < loss_steps)
-                        rec_push(rec, K_SEED, 0, make_int4(qlen.id, 0, 0, 0), make_float4(-1.0f * dtf * 2.f * qlen.val, 0.f, 0.f, 0.f));
                 }
-                // commit temporaries into the persistent slots
-                for (int k = 0; k < n_micro; ++k)
+                flush(t, 4);
+                // commit temporaries into the persistent slots (vehicles by their lane, capacitors by theirs)
+                if (k < n_micro)
                     for (int i = 0; i < lane_n[k]; ++i) {
                         const int vi = lane_veh[k * kLaneCap + i];
                         if (vidp[vi] != 3 * vi) { rec_push(rec, K_COMMIT, 3 * vi, make_int4(vidp[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vidp[vi] = 3 * vi; }
                         if (vidv[vi] != 3 * vi + 1) { rec_push(rec, K_COMMIT, 3 * vi + 1, make_int4(vidv[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vidv[vi] = 3 * vi + 1; }
                         if (vida[vi] != 3 * vi + 2) { rec_push(rec, K_COMMIT, 3 * vi + 2, make_int4(vida[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vida[vi] = 3 * vi + 2; }
                     }
-                for (int j = 0; j < n_caps; ++j)
+                if (mw < n_caps) {
+                    const int j = mw;
                     if (capi[j] != 3 * V + j && capi[j] >= 0) { rec_push(rec, K_COMMIT, 3 * V + j, make_int4(capi[j], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); capi[j] = 3 * V + j; }
-                if (rec.next_local - rec.base_local > kMaxLocals || rec.n - step_off[t] > kMaxStepRecords) cap_fault = true;
+                }
+                if (rec.next_local - (base_local + mw * kLaneLocals) > kLaneLocals) cap_fault = true;
+                flush(t, 5);
+                if (rec_n - step_start > kMaxStepRecords) cap_fault = true;
             }
             run_in += tot_a + vsp[n_micro]; run_out += tot_b + vep[n_micro]; run_cnt += C + vcp[n_micro];
         }
@@ -629,10 +744,12 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
         }
         lds_barrier();
     }
-    if (is_mt) {
-        step_off[T] = rec.n; mark_off[T] = rec.n;
-        counts[4 * rep + 0] = spawned; counts[4 * rep + 1] = deposits; counts[4 * rep + 2] = rec.n; counts[4 * rep + 3] = 0;
-        if (rec.over || cap_fault) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, rec.n);
+    if (in_mw) {
+        if (is_mt) {
+            step_off[T] = rec_n;
+            counts[4 * rep + 0] = spawned; counts[4 * rep + 1] = deposits; counts[4 * rep + 2] = rec_n; counts[4 * rep + 3] = 0;
+        }
+        if (rec.over || cap_fault) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, rec_n);
     }
     if (is_lane) ql[tid] = lane_total;
     __syncthreads();
@@ -650,7 +767,7 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
 // reverse
 // ---------------------------------------------------------------------------------------------------------------------
 struct HybLdsB {
-    size_t red, h0, h1, gl, c0, c2, gq, inl, inf, sg, adj, gam, rk, ri, rw, cell_lane, total;
+    size_t red, h0, h1, gl, c0, c2, gq, inl, inf, sg, adj, gam, rk, ri, rw, cell_lane, obi, obf, total;
 };
 __host__ __device__ inline HybLdsB hyb_lds_b(int L, int C, int sq, int V, int E) {
     HybLdsB o; size_t p = 0;
@@ -661,7 +778,7 @@ __host__ __device__ inline HybLdsB hyb_lds_b(int L, int C, int sq, int V, int E)
     o.gq = F(L); o.inl = F(3 * (size_t)E); o.inf = F(3 * (size_t)E); o.sg = F(6 * (size_t)sq);
     o.adj = F(3 * (size_t)V + kMaxCaps + kMaxLocals); o.gam = F(sq);
     o.rk = F(kMaxStepRecords); o.ri = F(4 * (size_t)kMaxStepRecords); o.rw = F(4 * (size_t)kMaxStepRecords);
-    o.cell_lane = F(C);
+    o.cell_lane = F(C); o.obi = F(64 * 5); o.obf = F(64 * 5);
     o.total = p;
     return o;
 }
@@ -689,6 +806,7 @@ __global__ void net_hybrid_bwd_kernel(int R_, int L, int C, int T, int sq, int F
     float *sg = LF(sg), *adj = LF(adj), *gam = LF(gam), *rw = LF(rw);
     int *rk = reinterpret_cast<int *>(lds + lo.rk), *ri = reinterpret_cast<int *>(lds + lo.ri);
     int *cell_lane_s = reinterpret_cast<int *>(lds + lo.cell_lane);
+    int *obi = reinterpret_cast<int *>(lds + lo.obi); float *obf = LF(obf);
     const float um = (float)um_d, s0f = (float)static_speed, vlen = (float)veh_len;
     const float *act = action + (size_t)rep * n_action;
     const size_t toff = (size_t)rep * tb.net.table_stride;
@@ -698,7 +816,8 @@ __global__ void net_hybrid_bwd_kernel(int R_, int L, int C, int T, int sq, int F
     const float *queue_r = queue + (size_t)rep * T * L;
     const char *wsr = workspace + (size_t)rep * ws.per_replica;
     const float *own_r = reinterpret_cast<const float *>(wsr + ws.own_hist);
-    const int *step_off = reinterpret_cast<const int *>(wsr + ws.step_off), *mark_off = reinterpret_cast<const int *>(wsr + ws.mark_off);
+    const int *step_off = reinterpret_cast<const int *>(wsr + ws.step_off);
+    const unsigned short *seg_cnt = reinterpret_cast<const unsigned short *>(wsr + ws.seg_cnt);
     const int *grk = reinterpret_cast<const int *>(wsr + ws.rec_k);
     const int4 *gri = reinterpret_cast<const int4 *>(wsr + ws.rec_i);
     const float4 *grw = reinterpret_cast<const float4 *>(wsr + ws.rec_w);
@@ -707,7 +826,7 @@ __global__ void net_hybrid_bwd_kernel(int R_, int L, int C, int T, int sq, int F
     const bool is_cell = tid < C, is_ghost = tid < 2 * L, is_lane = tid < L;
     const bool in_mw = tid >= B - 64, is_mt = (tid == B - 64);
     const int mw_lane = tid - (B - 64);
-    const int n_adj = 3 * V + kMaxCaps + kMaxLocals, base_local = 3 * V + kMaxCaps;
+    const int n_adj = 3 * V + kMaxCaps + kMaxLocals;
 
     if (is_lane) {
         const int off = tb.net.lane_off[tid], n = tb.net.lane_ncell[tid];
@@ -804,8 +923,11 @@ __global__ void net_hybrid_bwd_kernel(int R_, int L, int C, int T, int sq, int F
             sg[6 * tid] = we; sg[6 * tid + 1] = ns;
             sg[6 * tid + 2] = soft_switch_grad(a - pr, kSigK); sg[6 * tid + 3] = -soft_switch_grad(pr - a, kSigK);
         }
-        const int r_lo = step_off[t], r_hi = step_off[t + 1], r_mark = mark_off[t];
+        const int r_lo = step_off[t], r_hi = step_off[t + 1];
         const int n_rec = r_hi - r_lo;
+        int seg_lo[kPhases], seg_n[kPhases];            // this lane's record segments of the step (micro wave)
+#pragma unroll
+        for (int ph = 0; ph < kPhases; ++ph) { seg_lo[ph] = 0; seg_n[ph] = 0; }
         if (in_mw) {
             if (n_rec > kMaxStepRecords) over = true;
             else for (int k = mw_lane; k < n_rec; k += 64) {
@@ -814,7 +936,16 @@ __global__ void net_hybrid_bwd_kernel(int R_, int L, int C, int T, int sq, int F
                 ri[4 * k] = a.x; ri[4 * k + 1] = a.y; ri[4 * k + 2] = a.z; ri[4 * k + 3] = a.w;
                 rw[4 * k] = b.x; rw[4 * k + 1] = b.y; rw[4 * k + 2] = b.z; rw[4 * k + 3] = b.w;
             }
-            for (int k = mw_lane; k < kMaxLocals; k += 64) adj[base_local + k] = 0.f;
+            int base = 0;
+#pragma unroll
+            for (int ph = 0; ph < kPhases; ++ph) {
+                const int c = seg_cnt[((size_t)t * kPhases + ph) * 64 + mw_lane];
+                int inc = c;
+                for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d, 64); if (mw_lane >= d) inc += up; }
+                seg_lo[ph] = base + inc - c; seg_n[ph] = over ? 0 : c;
+                base += __shfl(inc, 63, 64);
+            }
+            for (int q = 0; q < 5; ++q) { obi[mw_lane * 5 + q] = -1; obf[mw_lane * 5 + q] = 0.f; }
         }
         lds_barrier();
         // ================= R1: loss taps on the state after step t =================
@@ -828,12 +959,14 @@ __global__ void net_hybrid_bwd_kernel(int R_, int L, int C, int T, int sq, int F
         }
         lds_barrier();
         // ================= R2: micro records of the loss / hand-off part, newest first =================
-        auto replay = [&](int hi, int lo_) {
-            for (int k = hi - 1; k >= lo_; --k) {
+        auto replay = [&](int lo_, int n_) {            // this lane's records [lo_, lo_ + n_), newest first
+            int n_sig = 0;
+            for (int k = lo_ + n_ - 1; k >= lo_; --k) {
                 const int kind = rk[k] >> 24, out = rk[k] & 0xffffff;
                 const int *in = ri + 4 * k; const float *w = rw + 4 * k;
                 if (kind == K_NODE) {
                     const float a = adj[out];
+                    adj[out] = 0.f;
                     if (a != 0.f) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) if (in[q] >= 0) adj[in[q]] += a * w[q];
@@ -856,12 +989,26 @@ __global__ void net_hybrid_bwd_kernel(int R_, int L, int C, int T, int sq, int F
                 } else if (kind == K_CELLREAD) {
                     gL[in[2]] += adj[in[0]];
                     gL[2 * C + in[2]] += adj[in[1]];
+                    adj[in[0]] = 0.f; adj[in[1]] = 0.f;
                 } else if (kind == K_SIGNAL) {
-                    gam[in[1]] += adj[in[0]] * sg[6 * in[1] + 2 + (in[2] - 1)];
+                    // several lanes may look at the same intersection: through the outbox, applied in lane order
+                    if (n_sig < 3) { obi[mw_lane * 5 + 2 + n_sig] = in[1]; obf[mw_lane * 5 + 2 + n_sig] = adj[in[0]] * sg[6 * in[1] + 2 + (in[2] - 1)]; }
+                    ++n_sig;
+                    adj[in[0]] = 0.f;
+                } else if (kind == K_IMPORT) {
+                    // the leader's position / speed slots belong to another lane
+                    obi[mw_lane * 5 + 0] = in[2]; obf[mw_lane * 5 + 0] = adj[in[0]];
+                    obi[mw_lane * 5 + 1] = in[3]; obf[mw_lane * 5 + 1] = adj[in[1]];
+                    adj[in[0]] = 0.f; adj[in[1]] = 0.f;
                 }
             }
         };
-        if (is_mt && !over) replay(n_rec, r_mark - r_lo + 1);
+        if (in_mw) {
+            replay(seg_lo[5], seg_n[5]);                 // commits
+            replay(seg_lo[4], seg_n[4]);                 // vehicles' loss terms
+            replay(seg_lo[3], seg_n[3]);                 // hand-off events (lane 0 holds them)
+            replay(seg_lo[2], seg_n[2]);                 // capacitors
+        }
         lds_barrier();
         // ================= R3: speed cotangents into (r, y); J^T g per cell | rest of the micro records =================
         float v_r = 0.f, v_y = 0.f;
@@ -873,7 +1020,16 @@ __global__ void net_hybrid_bwd_kernel(int R_, int L, int C, int T, int sq, int F
             c2[c] = dot2(d2.x, gr, d2.z, gy); c2[C + c] = dot2(d2.y, gr, d2.w, gy);
             v_r = dot2(d1.x, gr, d1.z, gy); v_y = dot2(d1.y, gr, d1.w, gy);
         }
-        if (is_mt && !over) replay(r_mark - r_lo, 0);
+        if (in_mw) {
+            replay(seg_lo[1], seg_n[1]);                 // IDM steps
+            replay(seg_lo[0], seg_n[0]);                 // head gaps
+            if (is_mt) {                                 // outboxes in lane order
+                for (int s_ = 0; s_ < tb.n_micro; ++s_) {
+                    for (int q = 0; q < 2; ++q) if (obi[s_ * 5 + q] >= 0) adj[obi[s_ * 5 + q]] += obf[s_ * 5 + q];
+                    for (int q = 2; q < 5; ++q) if (obi[s_ * 5 + q] >= 0) gam[obi[s_ * 5 + q]] += obf[s_ * 5 + q];
+                }
+            }
+        }
         lds_barrier();
         // ================= R4: gather inside the lane; ghost cotangents =================
         if (is_cell) {
@@ -973,7 +1129,7 @@ static inline bool hyb_tables_ok(const dhts_hybrid_tables *t) {
     return t && n->lane_ncell && n->lane_off && n->sig_kind && n->inter && n->lane_dx && n->left_src && n->left_gate &&
            n->right_src && n->schedule && n->replica_stride >= 0 && n->nxt_ptr && n->nxt_idx && n->prv_ptr && n->prv_idx &&
            n->n_edges >= 0 && t->lane_macro && t->lane_len && t->conv_next && t->routes && t->route_ptr && t->n_routes > 0 &&
-           t->route_stride > 0 && t->route_stride <= kRouteStride;
+           t->route_stride > 0 && t->route_stride <= kRouteStride && t->n_micro >= 0 && t->n_micro <= kMaxMicro;
 }
 static inline HybTables hyb_tables(const dhts_hybrid_tables *t) {
     HybTables h;
@@ -983,7 +1139,7 @@ static inline HybTables hyb_tables(const dhts_hybrid_tables *t) {
     h.net.schedule = n->schedule; h.net.table_stride = (size_t)n->replica_stride;
     h.net.nxt_ptr = n->nxt_ptr; h.net.nxt_idx = n->nxt_idx; h.net.prv_ptr = n->prv_ptr; h.net.prv_idx = n->prv_idx; h.net.n_edges = n->n_edges;
     h.lane_macro = t->lane_macro; h.lane_len = t->lane_len; h.conv_next = t->conv_next; h.routes = t->routes; h.route_ptr = t->route_ptr;
-    h.n_routes = t->n_routes; h.route_stride = t->route_stride; h.loss_steps = t->loss_steps;
+    h.n_routes = t->n_routes; h.route_stride = t->route_stride; h.loss_steps = t->loss_steps; h.n_micro = t->n_micro;
     return h;
 }
 static inline int hyb_block(const dhts_net_desc *d) {
@@ -1008,7 +1164,7 @@ int dhts_net_hybrid_rollout_fwd(const dhts_net_desc *d, const dhts_hybrid_tables
     const int B = hyb_block(d);
     if (B > 1024) return DHTS_E_INVALID;
     const HybWs ws = hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step);
-    const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V).total;
+    const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, t->n_micro > kMaxCaps ? t->n_micro : kMaxCaps).total;
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)net_hybrid_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -39,7 +39,7 @@ class NetTables(C.Structure):
 class HybridTables(C.Structure):
     _fields_ = [("net", NetTables), ("lane_macro", C.c_void_p), ("lane_len", C.c_void_p), ("conv_next", C.c_void_p),
                 ("routes", C.c_void_p), ("route_ptr", C.c_void_p), ("n_routes", C.c_int32), ("route_stride", C.c_int32),
-                ("records_per_step", C.c_int32), ("loss_steps", C.c_int32)]
+                ("records_per_step", C.c_int32), ("loss_steps", C.c_int32), ("n_micro", C.c_int32)]
 
 
 class MicroDesc(C.Structure):

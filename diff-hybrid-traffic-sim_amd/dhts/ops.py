@@ -419,6 +419,7 @@ class DeviceHybridTables:
         routes, route_ptr = group_routes(routes, t.n_lanes)
         self.n_routes, self.route_stride = int(routes.shape[0]), int(routes.shape[1])
         self.records_per_step = int(records_per_step)
+        self.n_micro = int((np.asarray(t.lane_macro) == 0).sum())
         self._keep = [up(t.lane_ncell, torch.int32), up(t.lane_off, torch.int32), up(t.sig_kind, torch.int32), up(t.inter, torch.int32),
                       up(t.lane_dx, torch.float64), up(t.left_src, torch.int32), up(t.left_gate, torch.int32),
                       up(t.right_src, torch.int32), up(t.schedule, torch.float64), up(t.nxt_ptr, torch.int32),
@@ -431,7 +432,7 @@ class DeviceHybridTables:
     def c(self, loss_steps=0):
         k = [x.data_ptr() for x in self._keep]
         return _lib.HybridTables(self.net, k[13], k[14], k[15], k[16], k[17], self.n_routes, self.route_stride, self.records_per_step,
-                                 int(loss_steps))
+                                 int(loss_steps), self.n_micro)
 
 
 class NetHybridRollout(torch.autograd.Function):

@@ -245,8 +245,9 @@ int dhts_net_macro_rollout_bwd(const dhts_net_desc *d, const dhts_net_tables *t,
  * plus the head gap of every occupied micro lane: leader further along the route (road_network.py:429-580) blended with the
  * red-light stop line by position-weighted neighbour signals (_simulator.py:139-276), and the vehicles' terms of the queue
  * loss (_env.py:694-725).  Vehicles use MicroVehicle.default_micro_vehicle (micro_vehicle.py:31-72).
- * One workgroup per replica; the (few) scalar operations of the micro side run on one lane of an extra wavefront and are
- * recorded, with their partial derivatives, on a per-replica record stream that the reverse sweep replays backwards.
+ * One workgroup per replica; the (few) scalar operations of the micro side run on an extra wavefront (one lane per micro
+ * lane; the hand-off events serially) and are recorded, with their partial derivatives, on a per-replica record stream that
+ * the reverse sweep replays backwards.
  * Extra tables (device pointers):
  *   lane_macro [L] int32 (1 = cells, 0 = vehicles; micro lanes have 0 cells), lane_len [L] DOUBLE,
  *   left_src -3 = own stored upstream ghost (single upstream lane is micro), right_src -1 also when the single downstream
@@ -255,7 +256,7 @@ int dhts_net_macro_rollout_bwd(const dhts_net_desc *d, const dhts_net_tables *t,
  *   route_ptr[m] .. route_ptr[m+1] start on micro lane m): the k-th vehicle spawned onto lane m takes row
  *   route_ptr[m] + k mod (rows of m).  The reference draws a route with np.random at spawn time (road_network.py:604-646);
  *   callers pre-draw them (dhts/network.py: group_routes keeps a recorded spawn order intact).
- * Limits: n_cells + n_lanes <= 960, <= 64 micro lanes, <= 16 spawning lanes, <= 16 vehicles per micro lane,
+ * Limits: n_cells + n_lanes <= 960, <= 40 micro lanes, <= 16 spawning lanes, <= 16 vehicles per micro lane,
  * <= 128 vehicles per replica and episode, route_stride <= 32; records_per_step (average budget of the record stream,
  * 0 = 512).  loss_steps: only the first loss_steps steps enter reward_cut and the gradient (<= 0: all).
  */
@@ -267,6 +268,7 @@ typedef struct dhts_hybrid_tables {
     const int32_t *routes;
     const int32_t *route_ptr;
     int32_t n_routes, route_stride, records_per_step, loss_steps;
+    int32_t n_micro;            /* number of micro lanes (zeros of lane_macro); sizes the kernels' LDS staging */
 } dhts_hybrid_tables;
 size_t dhts_net_hybrid_workspace_bytes(const dhts_net_desc *d, const dhts_hybrid_tables *t);
 /* hist / tape / kc / queue / reward as in the macro rollout (kc, tape rows of micro lanes do not exist: they have no cells);
