@@ -31,7 +31,7 @@
 
 namespace dhts {
 
-constexpr int kMaxMicro = 40;        // micro lanes per network
+constexpr int kMaxMicro = 24;        // micro lanes per network
 constexpr int kMaxCaps = 16;         // macro lanes with a micro successor
 constexpr int kLaneCap = 16;         // vehicles per micro lane
 constexpr int kMaxVeh = 128;         // vehicles per replica and episode
@@ -39,8 +39,8 @@ constexpr int kRouteStride = 32;     // MAX_ROUTE_LENGTH, road_network.py:17
 constexpr int kLaneLocals = 192;     // temporaries per lane of the micro wave and step
 constexpr int kEventLocals = 64;     // temporaries of the serial event walk per step
 constexpr int kMaxLocals = 64 * kLaneLocals + kEventLocals;
-constexpr int kStage = 64;           // staged records per lane and flush
-constexpr int kPhases = 6;           // record segments per step: head gaps, IDM, capacitors, events, loss, commits
+constexpr int kStage = 96;           // staged records per lane and flush
+constexpr int kPhases = 3;           // record segments per step: head gaps + IDM | capacitors + events | loss + commits
 constexpr int kMaxStepRecords = 1024;
 constexpr int kWindow = 100000;      // RunningMean(100_000), _env.py:122
 
@@ -87,8 +87,8 @@ __device__ __forceinline__ void rec_push(Rec &R, int kind, int out, int4 in, flo
     if (R.cnt >= kStage) { R.over = true; return; }
     const int c = R.cnt++;
     R.sk[c] = (kind << 24) | (out & 0xffffff);
-    int *pi = R.si + 4 * c; pi[0] = in.x; pi[1] = in.y; pi[2] = in.z; pi[3] = in.w;
-    float *pw = R.sw + 4 * c; pw[0] = w.x; pw[1] = w.y; pw[2] = w.z; pw[3] = w.w;
+    *reinterpret_cast<int4 *>(R.si + 4 * c) = in;
+    *reinterpret_cast<float4 *>(R.sw + 4 * c) = w;
 }
 __device__ __forceinline__ Tv tv_leaf(Rec &R, float v) { Tv x; x.val = v; x.id = R.next_local++; return x; }
 __device__ __forceinline__ Tv tv_node4(Rec &R, float v, Tv a, float wa, Tv b, float wb, Tv c, float wc, Tv d, float wd) {
@@ -131,12 +131,12 @@ __device__ __forceinline__ float stream_load(const float *p) {
 struct HybLds {
     size_t fq, scanw, incl, vsp, vep, s0, s1, g, ab, contrib, ql, sig, lanelen, vp, vv, va, vxold, hdpv, hdvv, capv, qmicro,
         cell_lane, iface_lane, cnext, vidp, vidv, vida, vcur, vrlen, vroute, lane_n, lane_veh, hdpi, hdvi, vcp, capi, mslot,
-        capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, stg_k, stg_i, stg_w, total;
+        capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, tnp, tnv, tnpi, tnvi, stg_k, stg_i, stg_w, total;
 };
 __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS) {
     HybLds o; size_t p = 0; const int NI = C + L;
-    auto D = [&](size_t n) { size_t r = p; p += 8 * n; return r; };
-    auto F = [&](size_t n) { size_t r = p; p += 4 * ((n + 1) & ~(size_t)1); return r; };
+    auto D = [&](size_t n) { size_t r = p; p += 8 * ((n + 1) & ~(size_t)1); return r; };
+    auto F = [&](size_t n) { size_t r = p; p += 4 * ((n + 3) & ~(size_t)3); return r; };
     o.fq = D(2 * (size_t)NI); o.scanw = D(32); o.incl = D(2 * (size_t)C); o.vsp = D(kMaxMicro + 1); o.vep = D(kMaxMicro + 1);
     o.s0 = F(4 * (size_t)C); o.s1 = F(4 * (size_t)C); o.g = F(8 * (size_t)L); o.ab = F(8 * (size_t)NI); o.contrib = F(C); o.ql = F(L);
     o.sig = F(2 * (size_t)sq); o.lanelen = F(L); o.vp = F(V); o.vv = F(V); o.va = F(V); o.vxold = F(V);
@@ -144,7 +144,7 @@ __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS) {
     o.cell_lane = F(C); o.iface_lane = F(NI); o.cnext = F(L); o.vidp = F(V); o.vidv = F(V); o.vida = F(V); o.vcur = F(V);
     o.vrlen = F(V); o.vroute = F((size_t)V * kRouteStride); o.lane_n = F(kMaxMicro); o.lane_veh = F(kMaxMicro * kLaneCap);
     o.hdpi = F(kMaxMicro); o.hdvi = F(kMaxMicro); o.vcp = F(kMaxMicro + 1); o.capi = F(kMaxCaps); o.mslot = F(L); o.capof = F(L);
-    o.mlane = F(kMaxMicro); o.cbefore = F(kMaxMicro + 1); o.convlist = F(L); o.linfo = F(L); o.caplast = F(kMaxCaps); o.rused = F(kMaxMicro); o.caplane = F(kMaxCaps); o.capleaf = F(kMaxCaps);
+    o.mlane = F(kMaxMicro); o.cbefore = F(kMaxMicro + 1); o.convlist = F(L); o.linfo = F(L); o.caplast = F(kMaxCaps); o.rused = F(kMaxMicro); o.caplane = F(kMaxCaps); o.capleaf = F(kMaxCaps); o.tnp = F(V); o.tnv = F(V); o.tnpi = F(V); o.tnvi = F(V);
     o.stg_k = F((size_t)NS * kStage); o.stg_i = F((size_t)NS * kStage * 4); o.stg_w = F((size_t)NS * kStage * 4);
     o.total = p;
     return o;
@@ -153,7 +153,8 @@ __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS) {
 // ---------------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
+template <int kMaxBlock>
+__global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
                                       double static_speed, double veh_len, HybTables tb, const float *__restrict__ action,
                                       float *__restrict__ hist, float4 *__restrict__ tape, float *__restrict__ kc,
                                       float *__restrict__ queue, float *__restrict__ reward, int *__restrict__ counts,
@@ -174,7 +175,8 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
     float *vp = LF(vp), *vv = LF(vv), *va = LF(va), *vxold = LF(vxold), *hdpv = LF(hdpv), *hdvv = LF(hdvv), *capv = LF(capv), *qmicro = LF(qmicro);
     int *cell_lane_s = LI(cell_lane), *iface_lane_s = LI(iface_lane), *cnext = LI(cnext), *vidp = LI(vidp), *vidv = LI(vidv), *vida = LI(vida);
     int *vcur = LI(vcur), *vrlen = LI(vrlen), *vroute = LI(vroute), *lane_n = LI(lane_n), *lane_veh = LI(lane_veh), *hdpi = LI(hdpi), *hdvi = LI(hdvi);
-    int *vcp = LI(vcp), *capi = LI(capi), *mslot = LI(mslot), *capof = LI(capof), *mlane = LI(mlane), *cbefore = LI(cbefore), *convlist = LI(convlist), *linfo = LI(linfo), *caplast = LI(caplast), *rused = LI(rused), *caplane = LI(caplane), *capleaf = LI(capleaf);
+    int *vcp = LI(vcp), *capi = LI(capi), *mslot = LI(mslot), *capof = LI(capof), *mlane = LI(mlane), *cbefore = LI(cbefore), *convlist = LI(convlist), *linfo = LI(linfo), *caplast = LI(caplast), *rused = LI(rused), *caplane = LI(caplane), *capleaf = LI(capleaf), *tnpi = LI(tnpi), *tnvi = LI(tnvi);
+    float *tnp = LF(tnp), *tnv = LF(tnv);
     int *stg_k = LI(stg_k), *stg_i = LI(stg_i); float *stg_w = LF(stg_w);
     const float um = (float)um_d, s0f = (float)static_speed, vlen = (float)veh_len, dtf = (float)dt;
     const float *act = action + (size_t)rep * n_action;
@@ -284,13 +286,16 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
         seg_cnt[((size_t)t * kPhases + phase) * 64 + mw] = (unsigned short)c;
         if (rec_n + total > ws.rec_cap) cap_fault = true;
         else if (total > 0) {
-            for (int s_ = 0; s_ < NS; ++s_) {
+            unsigned long long mask = __ballot(c > 0);
+            while (mask) {
+                const int s_ = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
                 const int cs = __shfl(c, s_, 64), os = __shfl(exc, s_, 64);
                 for (int r = mw; r < cs; r += 64) {
                     const int q = s_ * kStage + r;
                     grk[rec_n + os + r] = stg_k[q];
-                    gri[rec_n + os + r] = make_int4(stg_i[4 * q], stg_i[4 * q + 1], stg_i[4 * q + 2], stg_i[4 * q + 3]);
-                    grw[rec_n + os + r] = make_float4(stg_w[4 * q], stg_w[4 * q + 1], stg_w[4 * q + 2], stg_w[4 * q + 3]);
+                    gri[rec_n + os + r] = *reinterpret_cast<const int4 *>(stg_i + 4 * q);
+                    grw[rec_n + os + r] = *reinterpret_cast<const float4 *>(stg_w + 4 * q);
                 }
             }
             rec_n += total;
@@ -420,7 +425,6 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
                 hdpv[k] = dp_.val; hdpi[k] = dp_.id; hdvv[k] = dv_.val; hdvi[k] = dv_.id;
             }
             sig_sum += __shfl(ssum, 63, 64); sig_cnt += __shfl(scnt, 63, 64);
-            flush(t, 0);
         }
         lds_barrier();
         // ================= P2: interface solves | IDM steps =================
@@ -443,7 +447,6 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
             const int k = mw;
             if (k < n_micro && lane_n[k] > 0) {
                 const int nv = lane_n[k];
-                Tv newp[kLaneCap], newv[kLaneCap];
                 Tv hd_p; hd_p.val = hdpv[k]; hd_p.id = hdpi[k];
                 Tv hd_v; hd_v.val = hdvv[k]; hd_v.id = hdvi[k];
                 for (int i = 0; i < nv; ++i) {
@@ -451,10 +454,11 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
                     Tv p_; p_.val = vp[vi]; p_.id = vidp[vi];
                     Tv v_; v_.val = vv[vi]; v_.id = vidv[vi];
                     IdmStep o;
+                    Tv np_, nv_;
                     if (i == nv - 1) {
                         idm_step_ieee((double)p_.val, (double)v_.val, (double)hd_p.val, (double)hd_v.val, idm, dt, o);
-                        newp[i] = tv_node4(rec, o.np, p_, o.dE[0] + o.dLd[0], v_, o.dE[1] + o.dLd[1], hd_p, o.dLd[0], hd_v, -o.dLd[1]);
-                        newv[i] = tv_node4(rec, o.nv, p_, o.dE[2] + o.dLd[2], v_, o.dE[3] + o.dLd[3], hd_p, o.dLd[2], hd_v, -o.dLd[3]);
+                        np_ = tv_node4(rec, o.np, p_, o.dE[0] + o.dLd[0], v_, o.dE[1] + o.dLd[1], hd_p, o.dLd[0], hd_v, -o.dLd[1]);
+                        nv_ = tv_node4(rec, o.nv, p_, o.dE[2] + o.dLd[2], v_, o.dE[3] + o.dLd[3], hd_p, o.dLd[2], hd_v, -o.dLd[3]);
                     } else {
                         const int vj = lane_veh[k * kLaneCap + i + 1];
                         Tv pl; pl.val = vp[vj]; pl.id = vidp[vj];
@@ -462,18 +466,19 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
                         const double dp = fabs((double)pl.val - (double)p_.val) - ((veh_len + veh_len) * 0.5);
                         const double dv = (double)v_.val - (double)vl.val;
                         idm_step_ieee((double)p_.val, (double)v_.val, dp, dv, idm, dt, o);
-                        newp[i] = tv_node4(rec, o.np, p_, o.dE[0], v_, o.dE[1], pl, o.dLd[0], vl, o.dLd[1]);
-                        newv[i] = tv_node4(rec, o.nv, p_, o.dE[2], v_, o.dE[3], pl, o.dLd[2], vl, o.dLd[3]);
+                        np_ = tv_node4(rec, o.np, p_, o.dE[0], v_, o.dE[1], pl, o.dLd[0], vl, o.dLd[1]);
+                        nv_ = tv_node4(rec, o.nv, p_, o.dE[2], v_, o.dE[3], pl, o.dLd[2], vl, o.dLd[3]);
                     }
-                    if (newp[i].id < 0) newp[i] = tv_fresh(rec, o.np);
-                    if (newv[i].id < 0) newv[i] = tv_fresh(rec, o.nv);
+                    if (np_.id < 0) np_ = tv_fresh(rec, o.np);
+                    if (nv_.id < 0) nv_ = tv_fresh(rec, o.nv);
+                    tnp[vi] = np_.val; tnpi[vi] = np_.id; tnv[vi] = nv_.val; tnvi[vi] = nv_.id;
                 }
                 for (int i = 0; i < nv; ++i) {
                     const int vi = lane_veh[k * kLaneCap + i];
-                    vp[vi] = newp[i].val; vidp[vi] = newp[i].id; vv[vi] = newv[i].val; vidv[vi] = newv[i].id;
+                    vp[vi] = tnp[vi]; vidp[vi] = tnpi[vi]; vv[vi] = tnv[vi]; vidv[vi] = tnvi[vi];
                 }
             }
-            flush(t, 1);
+            flush(t, 0);
         }
         lds_barrier();
         // ================= P3: cell updates + tape | next step's signals =================
@@ -513,7 +518,6 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
                     capleaf[j] = lu.id;                      // the speed leaf, for a spawn in this step
                 }
             }
-            flush(t, 2);
             // is there any event at all this step?  (the common case is none)
             bool ev = false;
             if (mw < n_caps) {
@@ -527,7 +531,10 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
             }
             if (mw < n_micro && lane_n[mw] > 0) {
                 const int vi = lane_veh[mw * kLaneCap + lane_n[mw] - 1];
-                ev = ev || vp[vi] >= lanelen[mlane[mw]];
+                const int cursor = vcur[vi];
+                const int nid = cursor < vrlen[vi] - 1 ? vroute[vi * kRouteStride + cursor + 1] : -1;
+                const float Lf = lanelen[mlane[mw]];
+                ev = ev || ((nid >= 0 && mslot[nid] < 0) ? vp[vi] > Lf + 1.0f * vlen : vp[vi] >= Lf);
             }
             if (__any(ev) && is_mt) {
                 const int keep_local = rec.next_local;
@@ -616,7 +623,7 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
                 if (rec.next_local - (base_local + 64 * kLaneLocals) > kEventLocals) cap_fault = true;
                 rec.next_local = keep_local;
             }
-            flush(t, 3);
+            flush(t, 1);
             // vehicle samples of the loss' running mean: exclusive prefixes over the micro lanes in id order
             {
                 const int k = mw;
@@ -711,7 +718,6 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
                             rec_push(rec, K_SEED, 0, make_int4(qlen.id, 0, 0, 0), make_float4(-1.0f * dtf * 2.f * qlen.val, 0.f, 0.f, 0.f));
                     }
                 }
-                flush(t, 4);
                 // commit temporaries into the persistent slots (vehicles by their lane, capacitors by theirs)
                 if (k < n_micro)
                     for (int i = 0; i < lane_n[k]; ++i) {
@@ -725,7 +731,7 @@ __global__ void net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F
                     if (capi[j] != 3 * V + j && capi[j] >= 0) { rec_push(rec, K_COMMIT, 3 * V + j, make_int4(capi[j], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); capi[j] = 3 * V + j; }
                 }
                 if (rec.next_local - (base_local + mw * kLaneLocals) > kLaneLocals) cap_fault = true;
-                flush(t, 5);
+                flush(t, 2);
                 if (rec_n - step_start > kMaxStepRecords) cap_fault = true;
             }
             run_in += tot_a + vsp[n_micro]; run_out += tot_b + vep[n_micro]; run_cnt += C + vcp[n_micro];
@@ -786,7 +792,8 @@ __host__ __device__ inline HybLdsB hyb_lds_b(int L, int C, int sq, int V, int E)
 // Phases per step (five barriers): loss taps into the cell cotangents -> micro records of the hand-off / loss part,
 // newest first (deposits and capacitor reads exchange cotangents with the cells) -> J^T g per cell | the rest of the step's
 // micro records -> gather inside the lanes, ghost cotangents to inbox slots, signals -> edge cells take their inboxes.
-__global__ void net_hybrid_bwd_kernel(int R_, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
+template <int kMaxBlock>
+__global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
                                       double static_speed, double veh_len, HybTables tb, const float *__restrict__ action,
                                       const float *__restrict__ hist, const float4 *__restrict__ tape,
                                       const float *__restrict__ kc, const float *__restrict__ queue,
@@ -1004,10 +1011,8 @@ __global__ void net_hybrid_bwd_kernel(int R_, int L, int C, int T, int sq, int F
             }
         };
         if (in_mw) {
-            replay(seg_lo[5], seg_n[5]);                 // commits
-            replay(seg_lo[4], seg_n[4]);                 // vehicles' loss terms
-            replay(seg_lo[3], seg_n[3]);                 // hand-off events (lane 0 holds them)
-            replay(seg_lo[2], seg_n[2]);                 // capacitors
+            replay(seg_lo[2], seg_n[2]);                 // commits, then the vehicles' loss terms
+            replay(seg_lo[1], seg_n[1]);                 // hand-off events (lane 0 holds them), then the capacitors
         }
         lds_barrier();
         // ================= R3: speed cotangents into (r, y); J^T g per cell | rest of the micro records =================
@@ -1021,8 +1026,7 @@ __global__ void net_hybrid_bwd_kernel(int R_, int L, int C, int T, int sq, int F
             v_r = dot2(d1.x, gr, d1.z, gy); v_y = dot2(d1.y, gr, d1.w, gy);
         }
         if (in_mw) {
-            replay(seg_lo[1], seg_n[1]);                 // IDM steps
-            replay(seg_lo[0], seg_n[0]);                 // head gaps
+            replay(seg_lo[0], seg_n[0]);                 // IDM steps, then the head gaps
             if (is_mt) {                                 // outboxes in lane order
                 for (int s_ = 0; s_ < tb.n_micro; ++s_) {
                     for (int q = 0; q < 2; ++q) if (obi[s_ * 5 + q] >= 0) adj[obi[s_ * 5 + q]] += obf[s_ * 5 + q];
@@ -1166,10 +1170,11 @@ int dhts_net_hybrid_rollout_fwd(const dhts_net_desc *d, const dhts_hybrid_tables
     const HybWs ws = hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step);
     const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, t->n_micro > kMaxCaps ? t->n_micro : kMaxCaps).total;
     if (lds > 160 * 1024) return DHTS_E_INVALID;
+    auto kern = B <= 512 ? net_hybrid_fwd_kernel<512> : net_hybrid_fwd_kernel<1024>;
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)net_hybrid_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_LAUNCH;
-    net_hybrid_fwd_kernel<<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
+    kern<<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
         d->n_replicas, d->n_lanes, d->n_cells, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max,
         d->static_speed, d->vehicle_length, hyb_tables(t), action, hist, reinterpret_cast<float4 *>(tape), kc, queue, reward,
         counts, reinterpret_cast<char *>(workspace), t->records_per_step, err);
@@ -1187,10 +1192,11 @@ int dhts_net_hybrid_rollout_bwd(const dhts_net_desc *d, const dhts_hybrid_tables
     const int E = t->net.n_edges > 0 ? t->net.n_edges : 1;
     const size_t lds = hyb_lds_b(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, E).total;
     if (lds > 160 * 1024) return DHTS_E_INVALID;
+    auto kern = B <= 512 ? net_hybrid_bwd_kernel<512> : net_hybrid_bwd_kernel<1024>;
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)net_hybrid_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_LAUNCH;
-    net_hybrid_bwd_kernel<<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
+    kern<<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
         d->n_replicas, d->n_lanes, d->n_cells, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max,
         d->static_speed, d->vehicle_length, hyb_tables(t), action, hist, reinterpret_cast<const float4 *>(tape), kc, queue,
         g_reward, g_action, reinterpret_cast<const char *>(workspace), t->records_per_step, err);
