@@ -902,58 +902,86 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     if (tid < sq) for (int k = tid; k < n_action; k += sq) g_action[(size_t)rep * n_action + k] = 0.f;
     __syncthreads();
 
+    // ---- data of step t, fetched one iteration ahead
+    constexpr int kPre = 3;              // records per lane of the micro wave held in registers (192 per step; more are loaded late)
+    float p_hr = 0.f, p_hy = 0.f, p_hu = 0.f, p_kc = 0.f, p_q = 0.f, p_own_r = 0.f, p_own_u = 0.f;
+    float4 p_d0 = make_float4(0, 0, 0, 0), p_d1 = p_d0, p_d2 = p_d0;
+    int p_src = 0, p_gate = 0, p_rlo = 0, p_nrec = 0, p_seg[kPhases], p_rk[kPre];
+    int4 p_ri[kPre]; float4 p_rw[kPre];
+#pragma unroll
+    for (int ph = 0; ph < kPhases; ++ph) p_seg[ph] = 0;
+#pragma unroll
+    for (int j = 0; j < kPre; ++j) { p_rk[j] = 0; p_ri[j] = make_int4(0, 0, 0, 0); p_rw[j] = make_float4(0, 0, 0, 0); }
+    auto fetch = [&](int t) {
+        if (t < 0) return;
+        if (is_cell) {
+            const float *h = hist_r + (size_t)t * 4 * C;
+            p_hr = h[tid]; p_hy = h[C + tid]; p_hu = h[2 * C + tid];
+            p_kc = kc_r[(size_t)t * C + tid];
+            const float4 *tp = tape_r + (size_t)t * 3 * Cp;
+            p_d0 = tp[tid]; p_d1 = tp[Cp + tid]; p_d2 = tp[2 * Cp + tid];
+        }
+        if (is_lane) p_q = queue_r[(size_t)t * L + tid];
+        if (is_ghost && g_macro) {
+            const size_t o = toff + (size_t)t * L + g_lane;
+            if (g_side == 0) { p_src = tb.net.left_src[o]; p_gate = tb.net.left_gate[o]; }
+            else { p_src = tb.net.right_src[o]; p_own_r = own_r[(size_t)t * 2 * L + 2 * g_lane]; p_own_u = own_r[(size_t)t * 2 * L + 2 * g_lane + 1]; }
+        }
+        if (in_mw) {
+            p_rlo = step_off[t]; p_nrec = step_off[t + 1] - p_rlo;
+#pragma unroll
+            for (int ph = 0; ph < kPhases; ++ph) p_seg[ph] = seg_cnt[((size_t)t * kPhases + ph) * 64 + mw_lane];
+#pragma unroll
+            for (int j = 0; j < kPre; ++j) {
+                const int k = mw_lane + 64 * j;
+                if (k < p_nrec) { p_rk[j] = grk[p_rlo + k]; p_ri[j] = gri[p_rlo + k]; p_rw[j] = grw[p_rlo + k]; }
+            }
+        }
+    };
+    fetch(T - 1);
     for (int t = T - 1; t >= 0; --t) {
         float *Hc = (t & 1) ? H1 : H0;           // row t
         const float *Hn = (t & 1) ? H0 : H1;     // row t+1
-        // ================= R0: this step's data =================
-        float w_kc = 0.f; float4 d0 = make_float4(0, 0, 0, 0), d1 = d0, d2 = d0;
-        int src = 0, gate = 0; float w_own_r = 0.f, w_own_u = 0.f;
-        if (is_cell) {
-            const float *h = hist_r + (size_t)t * 4 * C;
-            Hc[tid] = h[tid]; Hc[C + tid] = h[C + tid]; Hc[2 * C + tid] = h[2 * C + tid];
-            w_kc = kc_r[(size_t)t * C + tid];
-            const float4 *tp = tape_r + (size_t)t * 3 * Cp;
-            d0 = tp[tid]; d1 = tp[Cp + tid]; d2 = tp[2 * Cp + tid];
-        }
-        if (is_lane) {
-            const float w_q = queue_r[(size_t)t * L + tid];
-            gq[tid] = (l_macro && t < loss_steps) ? gscale * (-1.0f) * (float)dt * 2.f * sqrtf(w_q / (float)dt) : 0.f;
-        }
-        if (is_ghost && g_macro) {
-            const size_t o = toff + (size_t)t * L + g_lane;
-            if (g_side == 0) { src = tb.net.left_src[o]; gate = tb.net.left_gate[o]; }
-            else { src = tb.net.right_src[o]; w_own_r = own_r[(size_t)t * 2 * L + 2 * g_lane]; w_own_u = own_r[(size_t)t * 2 * L + 2 * g_lane + 1]; }
-        }
+        // ================= R0: this step's data (fetched during the previous iteration) =================
+        const float w_kc = p_kc; const float4 d0 = p_d0, d1 = p_d1, d2 = p_d2;
+        const int src = p_src, gate = p_gate; const float w_own_r = p_own_r, w_own_u = p_own_u;
+        if (is_cell) { Hc[tid] = p_hr; Hc[C + tid] = p_hy; Hc[2 * C + tid] = p_hu; }
+        if (is_lane) gq[tid] = (l_macro && t < loss_steps) ? gscale * (-1.0f) * (float)dt * 2.f * sqrtf(p_q / (float)dt) : 0.f;
         if (tid < sq) {
             float we, ns, a, pr; int ai;
             phase_signal(act, n_action, sq, F, t, tid, we, ns, a, pr, ai);
             sg[6 * tid] = we; sg[6 * tid + 1] = ns;
             sg[6 * tid + 2] = soft_switch_grad(a - pr, kSigK); sg[6 * tid + 3] = -soft_switch_grad(pr - a, kSigK);
         }
-        const int r_lo = step_off[t], r_hi = step_off[t + 1];
-        const int n_rec = r_hi - r_lo;
         int seg_lo[kPhases], seg_n[kPhases];            // this lane's record segments of the step (micro wave)
 #pragma unroll
         for (int ph = 0; ph < kPhases; ++ph) { seg_lo[ph] = 0; seg_n[ph] = 0; }
         if (in_mw) {
+            const int r_lo = p_rlo, n_rec = p_nrec;
             if (n_rec > kMaxStepRecords) over = true;
-            else for (int k = mw_lane; k < n_rec; k += 64) {
-                rk[k] = grk[r_lo + k];
-                const int4 a = gri[r_lo + k]; const float4 b = grw[r_lo + k];
-                ri[4 * k] = a.x; ri[4 * k + 1] = a.y; ri[4 * k + 2] = a.z; ri[4 * k + 3] = a.w;
-                rw[4 * k] = b.x; rw[4 * k + 1] = b.y; rw[4 * k + 2] = b.z; rw[4 * k + 3] = b.w;
+            else {
+#pragma unroll
+                for (int j = 0; j < kPre; ++j) {
+                    const int k = mw_lane + 64 * j;
+                    if (k < n_rec) { rk[k] = p_rk[j]; *reinterpret_cast<int4 *>(ri + 4 * k) = p_ri[j]; *reinterpret_cast<float4 *>(rw + 4 * k) = p_rw[j]; }
+                }
+                for (int k = mw_lane + 64 * kPre; k < n_rec; k += 64) {
+                    rk[k] = grk[r_lo + k];
+                    *reinterpret_cast<int4 *>(ri + 4 * k) = gri[r_lo + k];
+                    *reinterpret_cast<float4 *>(rw + 4 * k) = grw[r_lo + k];
+                }
             }
             int base = 0;
 #pragma unroll
             for (int ph = 0; ph < kPhases; ++ph) {
-                const int c = seg_cnt[((size_t)t * kPhases + ph) * 64 + mw_lane];
+                const int c = p_seg[ph];
                 int inc = c;
                 for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d, 64); if (mw_lane >= d) inc += up; }
                 seg_lo[ph] = base + inc - c; seg_n[ph] = over ? 0 : c;
                 base += __shfl(inc, 63, 64);
             }
-            for (int q = 0; q < 5; ++q) { obi[mw_lane * 5 + q] = -1; obf[mw_lane * 5 + q] = 0.f; }
         }
+        fetch(t - 1);
         lds_barrier();
         // ================= R1: loss taps on the state after step t =================
         if (is_cell) {
@@ -966,11 +994,16 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         }
         lds_barrier();
         // ================= R2: micro records of the loss / hand-off part, newest first =================
+        bool used_ob = false;
         auto replay = [&](int lo_, int n_) {            // this lane's records [lo_, lo_ + n_), newest first
             int n_sig = 0;
             for (int k = lo_ + n_ - 1; k >= lo_; --k) {
-                const int kind = rk[k] >> 24, out = rk[k] & 0xffffff;
-                const int *in = ri + 4 * k; const float *w = rw + 4 * k;
+                const int kw = rk[k];
+                const int kind = kw >> 24, out = kw & 0xffffff;
+                const int4 in4 = *reinterpret_cast<const int4 *>(ri + 4 * k);
+                const float4 w4 = *reinterpret_cast<const float4 *>(rw + 4 * k);
+                const int in[4] = {in4.x, in4.y, in4.z, in4.w};
+                const float w[4] = {w4.x, w4.y, w4.z, w4.w};
                 if (kind == K_NODE) {
                     const float a = adj[out];
                     adj[out] = 0.f;
@@ -999,11 +1032,13 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
                     adj[in[0]] = 0.f; adj[in[1]] = 0.f;
                 } else if (kind == K_SIGNAL) {
                     // several lanes may look at the same intersection: through the outbox, applied in lane order
+                    used_ob = true;
                     if (n_sig < 3) { obi[mw_lane * 5 + 2 + n_sig] = in[1]; obf[mw_lane * 5 + 2 + n_sig] = adj[in[0]] * sg[6 * in[1] + 2 + (in[2] - 1)]; }
                     ++n_sig;
                     adj[in[0]] = 0.f;
                 } else if (kind == K_IMPORT) {
                     // the leader's position / speed slots belong to another lane
+                    used_ob = true;
                     obi[mw_lane * 5 + 0] = in[2]; obf[mw_lane * 5 + 0] = adj[in[0]];
                     obi[mw_lane * 5 + 1] = in[3]; obf[mw_lane * 5 + 1] = adj[in[1]];
                     adj[in[0]] = 0.f; adj[in[1]] = 0.f;
@@ -1026,9 +1061,13 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             v_r = dot2(d1.x, gr, d1.z, gy); v_y = dot2(d1.y, gr, d1.w, gy);
         }
         if (in_mw) {
+            if (seg_n[0] > 0) for (int q = 0; q < 5; ++q) obi[mw_lane * 5 + q] = -1;
             replay(seg_lo[0], seg_n[0]);                 // IDM steps, then the head gaps
+            unsigned long long obm = __ballot(used_ob);
             if (is_mt) {                                 // outboxes in lane order
-                for (int s_ = 0; s_ < tb.n_micro; ++s_) {
+                while (obm) {
+                    const int s_ = __ffsll((long long)obm) - 1;
+                    obm &= obm - 1;
                     for (int q = 0; q < 2; ++q) if (obi[s_ * 5 + q] >= 0) adj[obi[s_ * 5 + q]] += obf[s_ * 5 + q];
                     for (int q = 2; q < 5; ++q) if (obi[s_ * 5 + q] >= 0) gam[obi[s_ * 5 + q]] += obf[s_ * 5 + q];
                 }
