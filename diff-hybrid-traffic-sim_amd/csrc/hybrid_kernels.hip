@@ -356,78 +356,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             float *g = G + (size_t)tid * 4;
             g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
         }
-        if (in_mw) {
-            if (is_mt) step_off[t] = rec_n;
-            step_start = rec_n;
-            rec.next_local = base_local + mw * kLaneLocals;
-            const int k = mw;
-            const bool act = k < n_micro && lane_n[k < n_micro ? k : 0] > 0;
-            if (k < n_micro) { hdpv[k] = 1000.f; hdvv[k] = 0.f; hdpi[k] = -1; hdvi[k] = -1; }
-            Tv fin = tv_c(0.f), green_dp = tv_c(1000.f), green_dv = tv_c(0.f), red_dp = tv_c(0.f);
-            if (act) {
-                const int nv = lane_n[k];
-                const int l = mlane[k];
-                const int hv = lane_veh[k * kLaneCap + nv - 1];
-                const int *route = vroute + hv * kRouteStride;
-                const int rlen = vrlen[hv], cursor = vcur[hv];
-                Tv hp; hp.val = vp[hv]; hp.id = vidp[hv];
-                Tv hs; hs.val = vv[hv]; hs.id = vidv[hv];
-                const Tv Lc = tv_c(lanelen[l]), half = tv_c(vlen * 0.5f);
-                Tv reach = tv_sub(rec, tv_sub(rec, Lc, hp), half);
-                for (int j = cursor; j < rlen - 1; ++j) {
-                    const int there = route[j + 1];
-                    const int ms = mslot[there];
-                    if (ms < 0) break;                       // macro successor: defaults
-                    if (lane_n[ms]) {
-                        // the leader is another lane's tail vehicle: imported through two temporaries
-                        const int lv = lane_veh[ms * kLaneCap + 0];
-                        Tv lp = tv_leaf(rec, vp[lv]), lsp = tv_leaf(rec, vv[lv]);
-                        rec_push(rec, K_IMPORT, 0, make_int4(lp.id, lsp.id, vidp[lv], vidv[lv]), make_float4(0.f, 0.f, 0.f, 0.f));
-                        green_dp = tv_pos_or_zero(tv_add(rec, reach, tv_sub(rec, lp, half)));
-                        green_dv = tv_sub(rec, hs, lsp);
-                        break;
-                    }
-                    reach = tv_add(rec, reach, tv_c(lanelen[there]));
-                }
-                red_dp = tv_pos_or_zero(tv_sub(rec, tv_sub(rec, Lc, hp), half));
-                const bool prev_exist = cursor > 0, next_exist = cursor < rlen - 1;
-                Tv prev_s = tv_c(0.f), next_s = tv_c(0.f);
-                if (prev_exist) prev_s = tv_soft(rec, tv_sub(rec, tv_c(0.f), hp), 16.f);
-                Tv curr_s = tv_mul(rec, tv_soft(rec, hp, 16.f), tv_soft(rec, tv_sub(rec, Lc, hp), 16.f));
-                if (next_exist) next_s = tv_soft(rec, tv_sub(rec, hp, Lc), 16.f);
-                Tv total = tv_add(rec, tv_add(rec, prev_s, curr_s), next_s);
-                for (int w = 0; w < 3; ++w) {
-                    if ((w == 0 && !prev_exist) || (w == 2 && !next_exist)) continue;
-                    const int lid = route[cursor + w - 1];
-                    const Tv sc = w == 0 ? prev_s : (w == 1 ? curr_s : next_s);
-                    Tv sv = tv_c(1.f);
-                    const int kd = linfo[lid] & 3;
-                    if (kd != 0) {
-                        const int it = linfo[lid] >> 2;
-                        sv = tv_leaf(rec, sig[2 * it + (kd - 1)]);
-                        rec_push(rec, K_SIGNAL, 0, make_int4(sv.id, it, kd, 0), make_float4(0.f, 0.f, 0.f, 0.f));
-                    }
-                    fin = tv_add(rec, fin, tv_mul(rec, tv_div(rec, sc, total), sv));
-                }
-            }
-            // signal_rms: running mean over the occupied lanes in lane order (_simulator.py:249-256)
-            double ssum = act ? (double)fin.val : 0.; int scnt = act ? 1 : 0;
-            for (int d = 1; d < 64; d <<= 1) {
-                const double us = __shfl_up(ssum, d, 64); const int uc = __shfl_up(scnt, d, 64);
-                if (mw >= d) { ssum += us; scnt += uc; }
-            }
-            if (act) {
-                const float k2 = 32.f / fabsf((float)((sig_sum + ssum) / (double)(sig_cnt + scnt)));
-                Tv fs = tv_soft(rec, tv_sub(rec, fin, tv_c(0.5f)), k2);
-                Tv one_m = tv_sub(rec, tv_c(1.f), fs);
-                Tv dp_ = tv_add(rec, tv_mul(rec, green_dp, fs), tv_mul(rec, red_dp, one_m));
-                Tv dv_ = tv_add(rec, tv_mul(rec, green_dv, fs), tv_mul(rec, tv_c(0.f), one_m));
-                hdpv[k] = dp_.val; hdpi[k] = dp_.id; hdvv[k] = dv_.val; hdvi[k] = dv_.id;
-            }
-            sig_sum += __shfl(ssum, 63, 64); sig_cnt += __shfl(scnt, 63, 64);
-        }
         lds_barrier();
-        // ================= P2: interface solves | IDM steps =================
+        // ================= P2: interface solves | head gaps and IDM steps of the micro lanes =================
         if (is_if) {
             const float *gl = G + (size_t)(2 * i_lane) * 4, *gr_ = G + (size_t)(2 * i_lane + 1) * 4;
             double rL, yL, uL, qL, rR, yR, uR, qR;
@@ -444,6 +374,76 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             ab[4] = f.B[0]; ab[5] = f.B[1]; ab[6] = f.B[2]; ab[7] = f.B[3];
         }
         if (in_mw) {
+            {   // head gaps of the occupied micro lanes (they only feed the IDM steps below)
+                if (is_mt) step_off[t] = rec_n;
+                step_start = rec_n;
+                rec.next_local = base_local + mw * kLaneLocals;
+                const int k = mw;
+                const bool act = k < n_micro && lane_n[k < n_micro ? k : 0] > 0;
+                if (k < n_micro) { hdpv[k] = 1000.f; hdvv[k] = 0.f; hdpi[k] = -1; hdvi[k] = -1; }
+                Tv fin = tv_c(0.f), green_dp = tv_c(1000.f), green_dv = tv_c(0.f), red_dp = tv_c(0.f);
+                if (act) {
+                    const int nv = lane_n[k];
+                    const int l = mlane[k];
+                    const int hv = lane_veh[k * kLaneCap + nv - 1];
+                    const int *route = vroute + hv * kRouteStride;
+                    const int rlen = vrlen[hv], cursor = vcur[hv];
+                    Tv hp; hp.val = vp[hv]; hp.id = vidp[hv];
+                    Tv hs; hs.val = vv[hv]; hs.id = vidv[hv];
+                    const Tv Lc = tv_c(lanelen[l]), half = tv_c(vlen * 0.5f);
+                    Tv reach = tv_sub(rec, tv_sub(rec, Lc, hp), half);
+                    for (int j = cursor; j < rlen - 1; ++j) {
+                        const int there = route[j + 1];
+                        const int ms = mslot[there];
+                        if (ms < 0) break;                       // macro successor: defaults
+                        if (lane_n[ms]) {
+                            // the leader is another lane's tail vehicle: imported through two temporaries
+                            const int lv = lane_veh[ms * kLaneCap + 0];
+                            Tv lp = tv_leaf(rec, vp[lv]), lsp = tv_leaf(rec, vv[lv]);
+                            rec_push(rec, K_IMPORT, 0, make_int4(lp.id, lsp.id, vidp[lv], vidv[lv]), make_float4(0.f, 0.f, 0.f, 0.f));
+                            green_dp = tv_pos_or_zero(tv_add(rec, reach, tv_sub(rec, lp, half)));
+                            green_dv = tv_sub(rec, hs, lsp);
+                            break;
+                        }
+                        reach = tv_add(rec, reach, tv_c(lanelen[there]));
+                    }
+                    red_dp = tv_pos_or_zero(tv_sub(rec, tv_sub(rec, Lc, hp), half));
+                    const bool prev_exist = cursor > 0, next_exist = cursor < rlen - 1;
+                    Tv prev_s = tv_c(0.f), next_s = tv_c(0.f);
+                    if (prev_exist) prev_s = tv_soft(rec, tv_sub(rec, tv_c(0.f), hp), 16.f);
+                    Tv curr_s = tv_mul(rec, tv_soft(rec, hp, 16.f), tv_soft(rec, tv_sub(rec, Lc, hp), 16.f));
+                    if (next_exist) next_s = tv_soft(rec, tv_sub(rec, hp, Lc), 16.f);
+                    Tv total = tv_add(rec, tv_add(rec, prev_s, curr_s), next_s);
+                    for (int w = 0; w < 3; ++w) {
+                        if ((w == 0 && !prev_exist) || (w == 2 && !next_exist)) continue;
+                        const int lid = route[cursor + w - 1];
+                        const Tv sc = w == 0 ? prev_s : (w == 1 ? curr_s : next_s);
+                        Tv sv = tv_c(1.f);
+                        const int kd = linfo[lid] & 3;
+                        if (kd != 0) {
+                            const int it = linfo[lid] >> 2;
+                            sv = tv_leaf(rec, sig[2 * it + (kd - 1)]);
+                            rec_push(rec, K_SIGNAL, 0, make_int4(sv.id, it, kd, 0), make_float4(0.f, 0.f, 0.f, 0.f));
+                        }
+                        fin = tv_add(rec, fin, tv_mul(rec, tv_div(rec, sc, total), sv));
+                    }
+                }
+                // signal_rms: running mean over the occupied lanes in lane order (_simulator.py:249-256)
+                double ssum = act ? (double)fin.val : 0.; int scnt = act ? 1 : 0;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const double us = __shfl_up(ssum, d, 64); const int uc = __shfl_up(scnt, d, 64);
+                    if (mw >= d) { ssum += us; scnt += uc; }
+                }
+                if (act) {
+                    const float k2 = 32.f / fabsf((float)((sig_sum + ssum) / (double)(sig_cnt + scnt)));
+                    Tv fs = tv_soft(rec, tv_sub(rec, fin, tv_c(0.5f)), k2);
+                    Tv one_m = tv_sub(rec, tv_c(1.f), fs);
+                    Tv dp_ = tv_add(rec, tv_mul(rec, green_dp, fs), tv_mul(rec, red_dp, one_m));
+                    Tv dv_ = tv_add(rec, tv_mul(rec, green_dv, fs), tv_mul(rec, tv_c(0.f), one_m));
+                    hdpv[k] = dp_.val; hdpi[k] = dp_.id; hdvv[k] = dv_.val; hdvi[k] = dv_.id;
+                }
+                sig_sum += __shfl(ssum, 63, 64); sig_cnt += __shfl(scnt, 63, 64);
+            }
             const int k = mw;
             if (k < n_micro && lane_n[k] > 0) {
                 const int nv = lane_n[k];
@@ -1050,7 +1050,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             replay(seg_lo[1], seg_n[1]);                 // hand-off events (lane 0 holds them), then the capacitors
         }
         lds_barrier();
-        // ================= R3: speed cotangents into (r, y); J^T g per cell | rest of the micro records =================
+        // ================= R3: speed cotangents into (r, y); J^T g per cell =================
         float v_r = 0.f, v_y = 0.f;
         if (is_cell) {
             const int c = tid;
@@ -1060,21 +1060,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             c2[c] = dot2(d2.x, gr, d2.z, gy); c2[C + c] = dot2(d2.y, gr, d2.w, gy);
             v_r = dot2(d1.x, gr, d1.z, gy); v_y = dot2(d1.y, gr, d1.w, gy);
         }
-        if (in_mw) {
-            if (seg_n[0] > 0) for (int q = 0; q < 5; ++q) obi[mw_lane * 5 + q] = -1;
-            replay(seg_lo[0], seg_n[0]);                 // IDM steps, then the head gaps
-            unsigned long long obm = __ballot(used_ob);
-            if (is_mt) {                                 // outboxes in lane order
-                while (obm) {
-                    const int s_ = __ffsll((long long)obm) - 1;
-                    obm &= obm - 1;
-                    for (int q = 0; q < 2; ++q) if (obi[s_ * 5 + q] >= 0) adj[obi[s_ * 5 + q]] += obf[s_ * 5 + q];
-                    for (int q = 2; q < 5; ++q) if (obi[s_ * 5 + q] >= 0) gam[obi[s_ * 5 + q]] += obf[s_ * 5 + q];
-                }
-            }
-        }
         lds_barrier();
-        // ================= R4: gather inside the lane; ghost cotangents =================
+        // ================= R4: gather inside the lane; ghost cotangents | rest of the micro records =================
         if (is_cell) {
             const int c = tid;
             if (c > c_first) { v_r += c2[c - 1]; v_y += c2[C + c - 1]; }
@@ -1120,6 +1107,19 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
                     if (cand_src[i] == src) { box[3 * cand_pos[i]] = add_r; box[3 * cand_pos[i] + 1] = 0.f; box[3 * cand_pos[i] + 2] = add_u; }
             }
             my_aval = a_val; my_akey = a_key;
+        }
+        if (in_mw) {
+            if (seg_n[0] > 0) for (int q = 0; q < 5; ++q) obi[mw_lane * 5 + q] = -1;
+            replay(seg_lo[0], seg_n[0]);                 // IDM steps, then the head gaps
+            unsigned long long obm = __ballot(used_ob);
+            if (is_mt) {                                 // outboxes in lane order
+                while (obm) {
+                    const int s_ = __ffsll((long long)obm) - 1;
+                    obm &= obm - 1;
+                    for (int q = 0; q < 2; ++q) if (obi[s_ * 5 + q] >= 0) adj[obi[s_ * 5 + q]] += obf[s_ * 5 + q];
+                    for (int q = 2; q < 5; ++q) if (obi[s_ * 5 + q] >= 0) gam[obi[s_ * 5 + q]] += obf[s_ * 5 + q];
+                }
+            }
         }
         for (int q = 0; q < sq; ++q) {
             double v = (my_akey == q) ? (double)my_aval : 0.0;
