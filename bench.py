@@ -218,6 +218,7 @@ class ItscpMacroWorkload:
             t.schedule = np.ascontiguousarray(np.array([sched[k] for k in keys], dtype=np.float64).T)
             tabs.append(t)
         self.tab = ops.DeviceNetTables(tabs, dev)
+        self.host_tab = base
         self.sq, self.F, self.dt, self.um = 1, 60, 1.0 / 30.0, 60.0
         gen = torch.Generator(device="cpu").manual_seed(77 + rank)
         self.action = (0.1 + 0.8 * torch.rand(R, env.action_size(), generator=gen)).to(dev).requires_grad_(True)
@@ -244,7 +245,18 @@ class ItscpMacroWorkload:
         return loss.detach(), self.action.grad, self.action.grad
 
     def cpu_baseline(self):
-        return {"value": None, "unit": "cell-steps/s", "cores": 0, "kind": "port", "sample": "not timed for this workload"}
+        """The C oracle of the macro network (scalar, one core): whole episodes of replica 0, repeated for >= 10 s."""
+        from oracle import oracle as O
+        a = self.action[0].detach().cpu().numpy()
+        done, t0 = 0, time.perf_counter()
+        while True:
+            O.net_macro(self.host_tab, a, self.sq, self.F, self.dt, self.um)
+            done += self.N * self.T
+            el = time.perf_counter() - t0
+            if el >= 10.0:
+                break
+        return {"value": done / el, "unit": "cell-steps/s", "cores": 1, "kind": "port",
+                "sample": "replica 0's episode (%d cells x %d steps) fwd+bwd, repeated %.1f s on one core" % (self.N, self.T, el)}
 
 
 class ItscpHybridWorkload:
@@ -277,6 +289,7 @@ class ItscpHybridWorkload:
                     r = env.simulator.create_random_route(l).route
                     routes.append(list(r) + [-1] * (32 - len(r)))
         self.tab = ops.DeviceHybridTables(tab, np.array(routes, dtype=np.int32), dev)
+        self.host_tab, self.host_routes = tab, np.array(routes, dtype=np.int32)
         self.sq, self.F, self.dt, self.um = 9, 120, 1.0 / 30.0, 60.0
         gen = torch.Generator(device="cpu").manual_seed(177 + rank)
         self.action = (0.1 + 0.8 * torch.rand(R, env.action_size(), generator=gen)).to(dev).requires_grad_(True)
@@ -304,7 +317,22 @@ class ItscpHybridWorkload:
         return loss.detach(), self.action.grad, self.action.grad
 
     def cpu_baseline(self):
-        return {"value": None, "unit": "cell-steps/s", "cores": 0, "kind": "port", "sample": "not timed for this workload"}
+        """The C oracle of the hybrid network (scalar, one core): whole episodes of replica 0, repeated for >= 10 s."""
+        from dhts.network import group_routes
+        from oracle import oracle as O
+        a = self.action[0].detach().cpu().numpy()
+        routes, ptr = group_routes(self.host_routes, self.host_tab.n_lanes)
+        done, t0 = 0, time.perf_counter()
+        while True:
+            o = O.net_hybrid(self.host_tab, routes, ptr, a, self.sq, self.F, self.dt, self.um)
+            assert o["rc"] == 0
+            done += self.N * self.T
+            el = time.perf_counter() - t0
+            if el >= 10.0:
+                break
+        return {"value": done / el, "unit": "cell-steps/s", "cores": 1, "kind": "port",
+                "sample": "replica 0's episode (%d cells x %d steps, %d vehicles) fwd+bwd, repeated %.1f s on one core"
+                          % (self.N, self.T, o["n_spawned"], el)}
 
 
 def main():
