@@ -106,6 +106,8 @@ class ItscpEnv:
         self.reward_queue_c = -1.0
         self.macro_route_schedule = [self.simulator.create_random_macro_route() for _ in range(self.num_timestep)]
         self._make_micro_route()
+        self._fused_cache = None            # tables of the fused kernels depend on the schedules / routes drawn above
+        self._fused_done = False
         return self.observe()
 
     def _make_micro_route(self):
@@ -208,11 +210,75 @@ class ItscpEnv:
         self.steps += 1
         self.queue_length.clear()
         self.flux.clear()
-        self._simulate(action, differentiable)
+        if getattr(self, "_fused_done", False):
+            raise NotImplementedError("the fused episode leaves the lane objects at their reset state: call reset() first, "
+                                      "or set config['fused'] = False to step lane by lane")
+        reward = self._step_fused(action) if differentiable else None
+        if reward is None:
+            self._simulate(action, differentiable)
+            reward = self._reward(action)
         obs = self.observe()
-        reward = self._reward(action)
         info = {"img": []}
         return obs, reward, self.steps >= self.config["duration"], info
+
+    # ---- fused episode: the whole differentiable rollout in two kernel launches (dhts_net_*_rollout_fwd / _bwd) -----------
+    def _step_fused(self, action):
+        """First step after reset() in `macro` / `hybrid` mode with config["fused"] (default on): reward (differentiable
+        w.r.t. `action`) and the per-step queue terms from the fused network kernels instead of one operator call per
+        lane and step.  Same numbers as the operator path in `macro` mode; in `hybrid` mode vehicle routes are pre-drawn
+        per spawn lane (`fused_routes`, or 8 per lane from create_random_route) instead of being drawn at spawn time.
+        Returns None when the network or the call is outside what the kernels cover (the operator path runs then)."""
+        if not self.config.get("fused", True) or self.config["mode"] not in ("macro", "hybrid") or self.steps != 1 or self.time != 0:
+            return None
+        if not (isinstance(action, th.Tensor) and action.is_cuda):
+            return None
+        from dhts import ops
+        from dhts.network import HybridNetworkTables, MacroNetworkTables
+        sim = self.simulator
+        if any(sl.is_micro() and sl.num_vehicle() for sl in sim.lane.values()):
+            return None
+        cache = getattr(self, "_fused_cache", None)
+        if cache is None:
+            try:
+                T = self.num_timestep
+                n_cells = sum(getattr(sl, "num_cell", 0) for sl in sim.lane.values() if sl.is_macro())
+                if self.config["mode"] == "macro" and T * n_cells <= 100000:
+                    cache = ("macro", ops.DeviceNetTables(MacroNetworkTables.from_env(self), action.device))
+                else:
+                    tab = HybridNetworkTables.from_env(self)
+                    routes = getattr(self, "fused_routes", None)
+                    if routes is None:
+                        routes = []
+                        for l in range(tab.n_lanes):
+                            if tab.lane_macro[l] == 0 and any(tab.lane_macro[a] for a in tab.prev_lanes[l]):
+                                for _ in range(8):
+                                    r = list(sim.create_random_route(l).route)[:32]
+                                    routes.append(r + [-1] * (32 - len(r)))
+                        if not routes:
+                            routes = [[-1, -1]]
+                    cache = ("hybrid", ops.DeviceHybridTables(tab, np.asarray(routes, dtype=np.int32), action.device))
+            except ValueError:
+                cache = ("none", None)
+            self._fused_cache = cache
+        kind, tab = cache
+        if kind == "none":
+            return None
+        args = (self.num_intersection ** 2, self.config["signal_length"] * self.config["simulation_frequency"],
+                1.0 / self.config["simulation_frequency"], self.simulator.speed_limit, self.config["static_speed"],
+                self.simulator.vehicle_length)
+        a = action.reshape(1, -1)
+        if kind == "macro":
+            reward, queue = ops.net_macro_rollout(a, tab, *args)
+        else:
+            reward, _, queue, counts = ops.net_hybrid_rollout(a, tab, *args)
+            self.fused_counts = counts[0].tolist()
+        q = queue[0].detach().cpu().numpy()                 # [T][L]
+        for i, lid in enumerate(self.lane.keys()):
+            self.queue_length[lid] = [float(x) for x in q[:, i]]
+            self.flux.setdefault(lid, [])
+        self.time = self.num_timestep
+        self._fused_done = True
+        return (-self.reward_queue_c) * reward[0]
 
     def _simulate(self, action, differentiable):
         self.time = 0

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Differentiable traffic-signal control on the itscp environment, gradient arm: the harness counterpart of the reference's
+example/control/itscp/run.py (flags of run_itscp_macro.sh / run_itscp_hybrid.sh) with the signal schedule itself as the
+optimisation variable.
+
+Every iteration calls the reference's entry point ItscpEnv.step(action, True); on this build the whole differentiable episode
+(signals -> boundaries -> lane steps -> hand-offs -> queue loss, and its reverse sweep) runs in two fused kernel launches
+(dhts_net_macro_rollout_* / dhts_net_hybrid_rollout_*).  PyTorch keeps the optimiser (Adam on the actions, clamped to [0, 1]).
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "diff-hybrid-traffic-sim_amd"))
+
+import numpy as np  # noqa: E402
+import torch as th  # noqa: E402
+
+from example.control.itscp._env import ItscpEnv  # noqa: E402
+from example.control.itscp import problem as P  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser("itscp: gradient-based signal control (MI355X)")
+    ap.add_argument("--mode", choices=["macro", "hybrid"], default="hybrid")
+    ap.add_argument("--problem", type=int, default=1)
+    ap.add_argument("--n_intersection", type=int, default=3)
+    ap.add_argument("--n_lane", type=int, default=1)
+    ap.add_argument("--lane_length", type=float, default=5.0)
+    ap.add_argument("--speed_limit", type=float, default=60.0)
+    ap.add_argument("--simulation_length", type=int, default=20)
+    ap.add_argument("--signal_length", type=int, default=4)
+    ap.add_argument("--n_episode", type=int, default=100)
+    ap.add_argument("--lr", type=float, default=1e-2)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    assert th.cuda.is_available(), "needs a GPU (no CPU fallback)"
+    dev = th.device("cuda")
+    env = ItscpEnv()
+    env.schedule_callback = getattr(P, "problem_%d" % args.problem)
+    for k, v in dict(num_intersection=args.n_intersection, lane_length=args.lane_length, num_lane=args.n_lane,
+                     policy_length=args.simulation_length, signal_length=args.signal_length, mode=args.mode,
+                     speed_limit=args.speed_limit, random_seed=args.seed).items():
+        env.config[k] = v
+    env.reset()
+    cache = None
+    rng = np.random.default_rng(args.seed)
+    action = th.tensor(rng.uniform(0.3, 0.7, env.action_size()).astype(np.float32), device=dev, requires_grad=True)
+    opt = th.optim.Adam([action], lr=args.lr)
+    t0 = time.time()
+    for ep in range(args.n_episode):
+        # a fresh episode of the same problem: keep the drawn schedules / routes (and the uploaded tables), rewind the env
+        env.steps = 0
+        env.time = 0
+        env._fused_done = False
+        env._fused_cache = cache if cache is not None else env._fused_cache
+        opt.zero_grad()
+        _, reward, _, _ = env.step(action, True)
+        cache = env._fused_cache
+        (-reward).backward()
+        opt.step()
+        with th.no_grad():
+            action.clamp_(0.0, 1.0)
+        if ep % 10 == 0 or ep == args.n_episode - 1:
+            print("episode %4d  reward %.6f  (%.1f ms / episode)" % (ep, float(reward.detach()), 1e3 * (time.time() - t0) / (ep + 1)))
+
+
+if __name__ == "__main__":
+    main()

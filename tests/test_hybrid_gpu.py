@@ -85,3 +85,35 @@ def test_hybrid_kernels_vs_oracle_other_action(cuda, golden_dir, oracle):
     assert o["counts"][0, 0] == ref["n_spawned"]
     assert rel_max(o["queue"][0], ref["queue"]) <= 1e-4
     assert np.abs(o["grad"][0] - ref["g_action"]).max() <= 5 * TOL_GRAD * np.abs(ref["g_action"]).max()
+
+
+def test_config4_batch_properties(cuda, golden_dir):
+    """BASELINE config 4 at full size (256 replicas of run_itscp_hybrid.sh's network, own action each): bitwise
+    repeatability, replicas independent of their batch position, loss_steps = T equals no restriction."""
+    import torch
+    from dhts import ops
+    g = np.load(os.path.join(golden_dir, "itscp_hybrid.npz"))
+    t, m = itscp_hybrid_tables(g)
+    dt_ = ops.DeviceHybridTables(t, g["spawn_routes"], cuda)
+    args = (m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"],
+            m["speed_limit"], m["static_speed"], m["vehicle_length"])
+    R = 256
+    gen = torch.Generator(device="cpu").manual_seed(4)
+    acts = (0.1 + 0.8 * torch.rand(R, len(g["action"]), generator=gen)).to(cuda)
+    acts[7] = torch.tensor(g["action"], device=cuda)
+
+    def run(a, loss_steps=0):
+        a = a.clone().requires_grad_(True)
+        cut, reward, queue, counts = ops.net_hybrid_rollout(a, dt_, *args, loss_steps)
+        cut.sum().backward()
+        return reward.cpu().numpy(), a.grad.cpu().numpy(), queue.cpu().numpy(), counts.cpu().numpy()
+    r1, g1, q1, c1 = run(acts)
+    r2, g2, q2, c2 = run(acts)
+    assert np.array_equal(r1, r2) and np.array_equal(g1, g2) and np.array_equal(q1, q2) and np.array_equal(c1, c2)
+    assert np.all(np.isfinite(g1)) and np.all(c1[:, 0] >= 1)              # every replica spawns vehicles
+    assert abs(float(r1[7]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"])) and c1[7, 0] == m["n_vehicle_spawned"]
+    for k in (0, 7, 100, 255):
+        rs, gs, qs, cs = run(acts[k:k + 1])
+        assert np.array_equal(rs[0], r1[k]) and np.array_equal(gs[0], g1[k]) and np.array_equal(qs[0], q1[k])
+    r3, g3, _, _ = run(acts, loss_steps=m["T"])
+    assert np.array_equal(r3, r1) and np.array_equal(g3, g1)

@@ -119,3 +119,32 @@ def test_itscp_rollout_matches_reference(cuda, golden_dir, name):
     assert np.abs((total - l16) - (g["g_action"] - late[16])).max() <= 5 * TOL_GRAD * scale
     # (4) and the ill-conditioned remainder stays within the spread of the two branches
     assert np.abs(l16 - late[16]).max() <= 0.25 * np.abs(late[16]).max()
+
+
+@pytest.mark.parametrize("name", ["macro_small", "macro", "hybrid_short"])
+def test_env_step_uses_fused_kernels(cuda, golden_dir, name):
+    """ItscpEnv.step(action, True) -- the reference's entry point (trainer.py:172-190) -- through the fused network
+    kernels: reward, its gradient and the per-step queue terms against the reference's run."""
+    import torch
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    m = meta_of(g)
+    env = build_env(g, m)
+    if name.startswith("hybrid"):
+        env.fused_routes = g["spawn_routes"]
+    keys = list(env.lane.keys())
+    action = torch.tensor(g["action"], device=cuda, requires_grad=True)
+    obs, reward, done, info = env.step(action, True)
+    assert env._fused_done and obs.shape == env.observe().shape
+    reward.backward()
+    queue = np.array([env.queue_length[k] for k in keys])
+    assert rel_max(queue, g["queue"]) <= 1e-4
+    assert abs(float(reward.detach()) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+    assert np.abs(action.grad.cpu().numpy() - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()
+    if name.startswith("hybrid"):
+        assert env.fused_counts[0] == m["n_vehicle_spawned"]
+    with pytest.raises(NotImplementedError):
+        env.step(action, True)
+    env._armed = False
+    env.reset()
+    env.config["fused"] = False           # the lane-by-lane path stays available
+    assert env._step_fused(action) is None
