@@ -60,7 +60,7 @@ struct HybWs {
 __host__ __device__ inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 __host__ __device__ inline HybWs hyb_ws(int L, int C, int T, int n_routes, int records_per_step) {
     HybWs w;
-    w.V = n_routes < kMaxVeh ? n_routes : kMaxVeh;
+    w.V = kMaxVeh; (void)n_routes;
     const int rps = records_per_step > 0 ? records_per_step : 512;
     w.rec_cap = T * rps + 64;
     size_t o = 0;

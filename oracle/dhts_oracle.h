@@ -151,8 +151,7 @@ void oracle_net_macro_bwd(const oracle_net_desc *d, const int *lane_ncell, const
  *   conv_next  [T][L] the step's macro-route successor of a macro lane (conversion target, road_network.py:113-130),
  *   routes     [n_routes][route_stride] lane ids (-1 padded) grouped by first lane, route_ptr [L+1]: the k-th vehicle
  *              spawned onto lane m takes row route_ptr[m] + k mod (rows of m) (the reference draws them with np.random
- *              at spawn time, road_network.py:604-646; the caller pre-draws / replays them).  n_routes also bounds
- *              the number of vehicles of the episode.
+ *              at spawn time, road_network.py:604-646; the caller pre-draws / replays them).  At most 128 vehicles per episode.
  * Forward and reverse sweep in one call: queue [T][L], *reward (all steps), *reward_cut and g_action
  * (d reward_cut / d action, NULL = forward only) for the reward restricted to steps < t_cut; *n_spawned, *n_deposits;
  * hist_out [T+1][4][C] optional.  rc = ORACLE_OK / ORACLE_ERR_CFL / ORACLE_ERR_ROUTE. */
