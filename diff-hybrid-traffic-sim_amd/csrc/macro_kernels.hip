@@ -54,6 +54,7 @@ __device__ __forceinline__ void raise_fault(dhts_error *err, int code, int step,
 // Wave w owns the cells [w C, min(N, (w + 1) C)) with C = 64 p - 1, i.e. at most 64 p interfaces = p passes, so no
 // wave ever needs a pass for a single left-over interface; the state is ping-pong buffered in LDS and the only
 // synchronisation is one workgroup barrier per time step.
+template <bool kIface>
 __global__ __launch_bounds__(512) void macro_rollout_fwd_kernel(
     int L, int N, int T, int p, double dt, double dx, double um,
     const float *__restrict__ r_in, const float *__restrict__ y_in, const float *__restrict__ u_in,
@@ -86,6 +87,8 @@ __global__ __launch_bounds__(512) void macro_rollout_fwd_kernel(
     const int hi = (lo + C < N) ? lo + C : N;        // one past its last cell = its last interface
     const int K = (lo < N) ? ((hi - lo + 1 + 63) >> 6) : 0;
     const int Np = (N + 63) & ~63;
+    const int Nq = (N + 1 + 7) & ~7;                 // interfaces per lane, padded to whole 128-byte lines
+    const size_t tape_row = kIface ? (size_t)2 * Nq : (size_t)3 * Np;
     const double c = dt / dx;                        // update_coefficient, _macro_lane.py:99
     const float cf = (float)c, ncf = (float)(-c);
     const float umf = (float)um;
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(512) void macro_rollout_fwd_kernel(
         // first interface of the pass above (j + 1), broadcast from its thread 0
         double cFr = 0., cFy = 0.;
         float cA0 = 0.f, cA1 = 0.f, cA2 = 0.f, cA3 = 0.f, cB0 = 0.f, cB1 = 0.f, cB2 = 0.f, cB3 = 0.f;
-        float4 *tp = tape ? tape + ((size_t)step * L + lane) * 3 * Np : nullptr;
+        float4 *tp = tape ? tape + ((size_t)step * L + lane) * tape_row : nullptr;
         float *hp = hist ? hist + ((size_t)step * L + lane) * 3 * N : nullptr;
         if (K > 0) {
             // state of the pass about to run, read one pass ahead
@@ -126,13 +129,20 @@ __global__ __launch_bounds__(512) void macro_rollout_fwd_kernel(
 
                 // right interface of cell i = interface i + 1: thread t + 1, or the carried one for thread 63
                 const double Fr_R = take_right(f.Fr, cFr), Fy_R = take_right(f.Fy, cFy);
-                const float A0 = take_right(f.A[0], cA0), A1 = take_right(f.A[1], cA1);
-                const float A2 = take_right(f.A[2], cA2), A3 = take_right(f.A[3], cA3);
-                const float B0 = take_right(f.B[0], cB0), B1 = take_right(f.B[1], cB1);
-                const float B2 = take_right(f.B[2], cB2), B3 = take_right(f.B[3], cB3);
                 cFr = bcast0(f.Fr); cFy = bcast0(f.Fy);
-                cA0 = bcast0(f.A[0]); cA1 = bcast0(f.A[1]); cA2 = bcast0(f.A[2]); cA3 = bcast0(f.A[3]);
-                cB0 = bcast0(f.B[0]); cB1 = bcast0(f.B[1]); cB2 = bcast0(f.B[2]); cB3 = bcast0(f.B[3]);
+                float A0 = 0.f, A1 = 0.f, A2 = 0.f, A3 = 0.f, B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f;
+                if constexpr (!kIface) {
+                    A0 = take_right(f.A[0], cA0); A1 = take_right(f.A[1], cA1);
+                    A2 = take_right(f.A[2], cA2); A3 = take_right(f.A[3], cA3);
+                    B0 = take_right(f.B[0], cB0); B1 = take_right(f.B[1], cB1);
+                    B2 = take_right(f.B[2], cB2); B3 = take_right(f.B[3], cB3);
+                    cA0 = bcast0(f.A[0]); cA1 = bcast0(f.A[1]); cA2 = bcast0(f.A[2]); cA3 = bcast0(f.A[3]);
+                    cB0 = bcast0(f.B[0]); cB1 = bcast0(f.B[1]); cB2 = bcast0(f.B[2]); cB3 = bcast0(f.B[3]);
+                } else if (tp && vi) {
+                    // interface tape: the two 2x2 products of interface i; the reverse sweep forms the cell blocks from them
+                    tp[i] = make_float4(f.A[0], f.A[1], f.A[2], f.A[3]);
+                    tp[Nq + i] = make_float4(f.B[0], f.B[1], f.B[2], f.B[3]);
+                }
 
                 if (vc) {
                     // Godunov update, _macro_lane.py:109-112, float32 store :327-334
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(512) void macro_rollout_fwd_kernel(
                     float nu, nq;
                     glue_from_r_y(nr, ny, umf, nu, nq);      // set_next_state_vector_y, :282-299
                     nxt[i + 1] = nr; nxt[P + i + 1] = ny; nxt[2 * P + i + 1] = nu; nxt[3 * P + i + 1] = nq;
-                    if (tp) {
+                    if (!kIface && tp) {
                         // dMacroLane._backward, dmacro_lane.py:126-129
                         float4 d0, d1, d2;
                         d0.x = ncf * (-f.A[0]); d0.y = ncf * (-f.A[1]); d0.z = ncf * (-f.A[2]); d0.w = ncf * (-f.A[3]);
@@ -170,8 +180,9 @@ __global__ __launch_bounds__(512) void macro_rollout_fwd_kernel(
 
 // grid = L workgroups of `blockDim.x` threads (multiple of 64); dynamic LDS = 6 * (N + 2) floats.
 // g' = J^T g per step: grad_cell[a][k] = dqs[a][k]^T g[a]; g'[b] = (c1[b] + c2[b-1]) + c0[b+1]   (dmacro_lane.py:283-303)
+template <bool kIface>
 __global__ void macro_rollout_bwd_kernel(
-    int L, int N, int T, const float4 *__restrict__ tape,
+    int L, int N, int T, double cc, const float4 *__restrict__ tape,
     const float *__restrict__ g_r_in, const float *__restrict__ g_y_in, const float *__restrict__ g_hist,
     float *__restrict__ g_r_out, float *__restrict__ g_y_out, double *__restrict__ g_ghost, dhts_error *err) {
     extern __shared__ float lds[];
@@ -183,6 +194,9 @@ __global__ void macro_rollout_bwd_kernel(
     float *Gr = lds, *Gy = lds + P, *C0r = lds + 2 * P, *C0y = lds + 3 * P, *C2r = lds + 4 * P, *C2y = lds + 5 * P;
     const size_t base = (size_t)lane * N;
     const int Np = (N + 63) & ~63;
+    const int Nq = (N + 1 + 7) & ~7;
+    const size_t tape_row = kIface ? (size_t)2 * Nq : (size_t)3 * Np;
+    const float cf = (float)cc, ncf = (float)(-cc);
 
     for (int k = t; k < P; k += B) { C0r[k] = 0.f; C0y[k] = 0.f; C2r[k] = 0.f; C2y[k] = 0.f; Gr[k] = 0.f; Gy[k] = 0.f; }
     __syncthreads();
@@ -192,10 +206,20 @@ __global__ void macro_rollout_bwd_kernel(
     double ghl_r = 0., ghl_y = 0., ghr_r = 0., ghr_y = 0.;   // ghost cotangent sums (thread 0 / thread of cell N-1)
     bool bad = false;
     for (int step = T - 1; step >= 0; --step) {
-        const float4 *tp = tape + ((size_t)step * L + lane) * 3 * Np;
+        const float4 *tp = tape + ((size_t)step * L + lane) * tape_row;
         const float *gh = g_hist ? g_hist + ((size_t)step * L + lane) * 2 * N : nullptr;
         for (int k = t; k < N; k += B) {
-            const float4 d0 = tp[k], d1 = tp[Np + k], d2 = tp[2 * Np + k];
+            float4 d0, d1, d2;
+            if constexpr (kIface) {
+                // cell blocks from the interface products exactly as the forward forms them (dmacro_lane.py:126-129)
+                const float4 aL = tp[k], bL = tp[Nq + k], aR = tp[k + 1], bR = tp[Nq + k + 1];
+                d0.x = ncf * (-aL.x); d0.y = ncf * (-aL.y); d0.z = ncf * (-aL.z); d0.w = ncf * (-aL.w);
+                d2.x = ncf * bR.x; d2.y = ncf * bR.y; d2.z = ncf * bR.z; d2.w = ncf * bR.w;
+                d1.x = 1.f - cf * (aR.x - bL.x); d1.y = 0.f - cf * (aR.y - bL.y);
+                d1.z = 0.f - cf * (aR.z - bL.z); d1.w = 1.f - cf * (aR.w - bL.w);
+            } else {
+                d0 = tp[k]; d1 = tp[Np + k]; d2 = tp[2 * Np + k];
+            }
             float gr = Gr[k + 1], gy = Gy[k + 1];
             if (gh) { gr += gh[k]; gy += gh[N + k]; }
             const float c0r = dot2(d0.x, gr, d0.z, gy), c0y = dot2(d0.y, gr, d0.w, gy);
@@ -301,6 +325,50 @@ static inline int grid_1d(int64_t n) {
 
 // test / tuning hook: force the number of wavefronts per lane of the forward kernel (0 = heuristic)
 static int dhts_fwd_waves_override = 0;
+static inline int padded64(int n) { return (n + 63) & ~63; }
+
+template <bool kIface>
+static int macro_fwd_launch(const dhts_macro_desc *d, int T,
+                            const float *r, const float *y, const float *u, const float *ueq, const float *ghost,
+                            float *r_out, float *y_out, float *u_out, float *ueq_out,
+                            float *tape, float *hist, dhts_error *err, void *stream) {
+    if (!macro_desc_ok(d) || T < 0 || !r || !y || !u || !ueq || !ghost || !r_out || !y_out || !u_out || !ueq_out)
+        return DHTS_E_INVALID;
+    const int N = d->n_cells;
+    const size_t lds = sizeof(float) * 8 * (size_t)(N + 2);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)macro_rollout_fwd_kernel<kIface>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DHTS_E_LAUNCH;
+    // Waves per lane: enough wavefronts to put ~2 on every SIMD of the chip (256 CUs x 4 SIMDs; measured best on
+    // 1024 lanes x 512 cells: 1 -> 11.9 ms, 2 -> 9.2, 3 -> 9.6, 4 -> 9.8, 5 -> 11.9), at most 8 per lane, and never
+    // more than the lane has 63-cell chunks.  p = passes per wave, chunk = 64 p - 1 cells.
+    int W = dhts_fwd_waves_override > 0 ? dhts_fwd_waves_override : (int)((2 * 1024 + d->n_lanes - 1) / d->n_lanes);
+    if (W > 8) W = 8;
+    if (W < 1) W = 1;
+    int p = 1;
+    while ((N + (64 * p - 1) - 1) / (64 * p - 1) > W) ++p;
+    W = (N + (64 * p - 1) - 1) / (64 * p - 1);
+    macro_rollout_fwd_kernel<kIface><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(
+        d->n_lanes, N, T, p, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out,
+        reinterpret_cast<float4 *>(tape), hist, err);
+    return launch_status();
+}
+template <bool kIface>
+static int macro_bwd_launch(const dhts_macro_desc *d, int T, const float *tape,
+                            const float *g_r, const float *g_y, const float *g_hist,
+                            float *g_r_out, float *g_y_out, double *g_ghost, dhts_error *err, void *stream) {
+    if (!macro_desc_ok(d) || T < 0 || (T > 0 && !tape) || !g_r || !g_y || !g_r_out || !g_y_out) return DHTS_E_INVALID;
+    const size_t lds = sizeof(float) * 6 * (size_t)(d->n_cells + 2);
+    int B = padded64(d->n_cells);
+    if (B > 512) B = 512;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)macro_rollout_bwd_kernel<kIface>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DHTS_E_LAUNCH;
+    macro_rollout_bwd_kernel<kIface><<<d->n_lanes, B, lds, (hipStream_t)stream>>>(
+        d->n_lanes, d->n_cells, T, d->dt / d->dx, reinterpret_cast<const float4 *>(tape), g_r, g_y, g_hist, g_r_out, g_y_out,
+        g_ghost, err);
+    return launch_status();
+}
 
 extern "C" {
 
@@ -316,7 +384,11 @@ int dhts_padded(int n) { return (n + 63) & ~63; }
 
 size_t dhts_macro_tape_bytes(const dhts_macro_desc *d, int T) {
     if (!macro_desc_ok(d) || T < 0) return 0;
-    return (size_t)T * d->n_lanes * 3 * dhts_padded(d->n_cells) * sizeof(float4);
+    return (size_t)T * d->n_lanes * 2 * ((d->n_cells + 1 + 7) & ~7) * sizeof(float4);
+}
+size_t dhts_macro_step_tape_bytes(const dhts_macro_desc *d) {
+    if (!macro_desc_ok(d)) return 0;
+    return (size_t)d->n_lanes * 3 * dhts_padded(d->n_cells) * sizeof(float4);
 }
 
 int dhts_arz_interface_batch(int64_t n, int variant, const double *in, double dt, double dx, int32_t *case_ind, double *q0,
@@ -350,56 +422,28 @@ int dhts_macro_u_tap_bwd(int64_t n, double u_max, const float *r, const float *y
     return launch_status();
 }
 
+// rollouts keep the compact interface tape (32 B per interface-step)
 int dhts_macro_rollout_fwd(const dhts_macro_desc *d, int T,
                            const float *r, const float *y, const float *u, const float *ueq, const float *ghost,
                            float *r_out, float *y_out, float *u_out, float *ueq_out,
                            float *tape, float *hist, dhts_error *err, void *stream) {
-    if (!macro_desc_ok(d) || T < 0 || !r || !y || !u || !ueq || !ghost || !r_out || !y_out || !u_out || !ueq_out)
-        return DHTS_E_INVALID;
-    const int N = d->n_cells;
-    const size_t lds = sizeof(float) * 8 * (size_t)(N + 2);
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)macro_rollout_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return DHTS_E_LAUNCH;
-    // Waves per lane: enough wavefronts to put ~2 on every SIMD of the chip (256 CUs x 4 SIMDs; measured best on
-    // 1024 lanes x 512 cells: 1 -> 11.9 ms, 2 -> 9.2, 3 -> 9.6, 4 -> 9.8, 5 -> 11.9), at most 8 per lane, and never
-    // more than the lane has 63-cell chunks.  p = passes per wave, chunk = 64 p - 1 cells.
-    int W = dhts_fwd_waves_override > 0 ? dhts_fwd_waves_override : (int)((2 * 1024 + d->n_lanes - 1) / d->n_lanes);
-    if (W > 8) W = 8;
-    if (W < 1) W = 1;
-    int p = 1;
-    while ((N + (64 * p - 1) - 1) / (64 * p - 1) > W) ++p;
-    W = (N + (64 * p - 1) - 1) / (64 * p - 1);
-    macro_rollout_fwd_kernel<<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(
-        d->n_lanes, N, T, p, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out,
-        reinterpret_cast<float4 *>(tape), hist, err);
-    return launch_status();
+    return macro_fwd_launch<true>(d, T, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, tape, hist, err, stream);
 }
-
 int dhts_macro_rollout_bwd(const dhts_macro_desc *d, int T, const float *tape,
                            const float *g_r, const float *g_y, const float *g_hist,
                            float *g_r_out, float *g_y_out, double *g_ghost, dhts_error *err, void *stream) {
-    if (!macro_desc_ok(d) || T < 0 || (T > 0 && !tape) || !g_r || !g_y || !g_r_out || !g_y_out) return DHTS_E_INVALID;
-    const size_t lds = sizeof(float) * 6 * (size_t)(d->n_cells + 2);
-    int B = dhts_padded(d->n_cells);
-    if (B > 512) B = 512;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)macro_rollout_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return DHTS_E_LAUNCH;
-    macro_rollout_bwd_kernel<<<d->n_lanes, B, lds, (hipStream_t)stream>>>(
-        d->n_lanes, d->n_cells, T, reinterpret_cast<const float4 *>(tape), g_r, g_y, g_hist, g_r_out, g_y_out, g_ghost, err);
-    return launch_status();
+    return macro_bwd_launch<true>(d, T, tape, g_r, g_y, g_hist, g_r_out, g_y_out, g_ghost, err, stream);
 }
-
+// the single-step operator keeps the reference's per-cell blocks dqs[a][3][2][2] (48 B per cell)
 int dhts_macro_step_fwd(const dhts_macro_desc *d,
                         const float *r, const float *y, const float *u, const float *ueq, const float *ghost,
                         float *r_out, float *y_out, float *u_out, float *ueq_out,
                         float *tape, dhts_error *err, void *stream) {
-    return dhts_macro_rollout_fwd(d, 1, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, tape, nullptr, err, stream);
+    return macro_fwd_launch<false>(d, 1, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, tape, nullptr, err, stream);
 }
 int dhts_macro_step_bwd(const dhts_macro_desc *d, const float *tape, const float *g_r, const float *g_y,
                         float *g_r_out, float *g_y_out, double *g_ghost, dhts_error *err, void *stream) {
-    return dhts_macro_rollout_bwd(d, 1, tape, g_r, g_y, nullptr, g_r_out, g_y_out, g_ghost, err, stream);
+    return macro_bwd_launch<false>(d, 1, tape, g_r, g_y, nullptr, g_r_out, g_y_out, g_ghost, err, stream);
 }
 
 }  // extern "C"

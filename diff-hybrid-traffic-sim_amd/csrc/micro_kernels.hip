@@ -30,7 +30,7 @@ __device__ __forceinline__ void raise_fault_m(dhts_error *err, int code, int ste
 }
 
 // grid = L workgroups of 64 threads; dynamic LDS = 2 * (V + 1) floats
-template <int K>
+template <int K, bool kCompact>
 __global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
     int L, int V, int T, double dt,
     const float *__restrict__ p_in, const float *__restrict__ v_in, const int32_t *__restrict__ count,
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
     int fault_step = -1, fault_index = 0;
 
     for (int step = 0; step < T; ++step) {
-        float4 *tp = tape ? tape + ((size_t)step * L + lane) * 2 * Vp : nullptr;
+        float4 *tp = tape ? tape + ((size_t)step * L + lane) * (kCompact ? 1 : 2) * Vp : nullptr;
         float *hp = hist ? hist + ((size_t)step * L + lane) * 2 * V : nullptr;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -93,8 +93,13 @@ __global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
                 if (o.collided && fault_step < 0) { fault_step = step; fault_index = i; }
                 Sp[i] = o.np; Sv[i] = o.nv;
                 if (tp) {
-                    tp[i] = make_float4(o.dE[0], o.dE[1], o.dE[2], o.dE[3]);
-                    tp[Vp + i] = make_float4(o.dLd[0], o.dLd[1], o.dLd[2], o.dLd[3]);
+                    if constexpr (kCompact) {
+                        // the first rows are constants: dEgo = [[1, dt], [., .]], dLeading = [[0, 0], [., .]] (didm.py:38-103)
+                        tp[i] = make_float4(o.dE[2], o.dE[3], o.dLd[2], o.dLd[3]);
+                    } else {
+                        tp[i] = make_float4(o.dE[0], o.dE[1], o.dE[2], o.dE[3]);
+                        tp[Vp + i] = make_float4(o.dLd[0], o.dLd[1], o.dLd[2], o.dLd[3]);
+                    }
                 }
                 if (hp) { hp[i] = o.np; hp[V + i] = o.nv; }
             }
@@ -126,8 +131,9 @@ __global__ void idm_batch_kernel(int64_t n, int variant, const double *__restric
 }
 
 // grid = L workgroups of blockDim.x threads; dynamic LDS = 4 * (V + 2) floats
+template <bool kCompact>
 __global__ void micro_rollout_bwd_kernel(
-    int L, int V, int T, const float4 *__restrict__ tape, const int32_t *__restrict__ count,
+    int L, int V, int T, double dt, const float4 *__restrict__ tape, const int32_t *__restrict__ count,
     const float *__restrict__ g_p_in, const float *__restrict__ g_v_in, const float *__restrict__ g_hist,
     float *__restrict__ g_p_out, float *__restrict__ g_v_out, double *__restrict__ g_head, int fold, dhts_error *err) {
     extern __shared__ float lds[];
@@ -147,10 +153,14 @@ __global__ void micro_rollout_bwd_kernel(
 
     double gh_p = 0., gh_v = 0.;       // held by the thread that owns the head vehicle
     for (int step = T - 1; step >= 0; --step) {
-        const float4 *tp = tape + ((size_t)step * L + lane) * 2 * Vp;
+        const float4 *tp = tape + ((size_t)step * L + lane) * (kCompact ? 1 : 2) * Vp;
         const float *gh = g_hist ? g_hist + ((size_t)step * L + lane) * 2 * V : nullptr;
         for (int k = t; k < n; k += B) {
-            const float4 dE = tp[k], dLd = tp[Vp + k];
+            float4 dE, dLd;
+            if constexpr (kCompact) {
+                const float4 c = tp[k];
+                dE = make_float4(1.f, (float)dt, c.x, c.y); dLd = make_float4(0.f, 0.f, c.z, c.w);
+            } else { dE = tp[k]; dLd = tp[Vp + k]; }
             float gp = Gp[k], gv = Gv[k];
             if (gh) { gp += gh[k]; gv += gh[V + k]; }
             Gp[k] = dot2(dE.x, gp, dE.z, gv);          // grad_ps[:-1] = dqs[:, 0]^T g
@@ -198,13 +208,41 @@ static inline bool micro_desc_ok(const dhts_micro_desc *d) {
 }
 static inline int launch_status_m() { return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH; }
 
-template <int K>
+template <int K, bool kCompact>
 static void launch_micro_fwd(const dhts_micro_desc *d, int T, const float *p, const float *v, const int32_t *count,
                              const double *params, const double *head, float *p_out, float *v_out, float *tape,
                              float *hist, dhts_error *err, hipStream_t s) {
     const size_t lds = sizeof(float) * 2 * (size_t)(d->capacity + 1);
-    micro_rollout_fwd_kernel<K><<<d->n_lanes, 64, lds, s>>>(d->n_lanes, d->capacity, T, d->dt, p, v, count, params, head,
+    micro_rollout_fwd_kernel<K, kCompact><<<d->n_lanes, 64, lds, s>>>(d->n_lanes, d->capacity, T, d->dt, p, v, count, params, head,
                                                            p_out, v_out, reinterpret_cast<float4 *>(tape), hist, err);
+}
+
+template <bool kCompact>
+static int micro_fwd_launch(const dhts_micro_desc *d, int T,
+                            const float *p, const float *v, const int32_t *count, const double *params, const double *head,
+                            float *p_out, float *v_out, float *tape, float *hist, dhts_error *err, void *stream) {
+    if (!micro_desc_ok(d) || T < 0 || !p || !v || !params || !head || !p_out || !v_out) return DHTS_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int K = (d->capacity + 63) >> 6;
+    if (K <= 1) launch_micro_fwd<1, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    else if (K <= 2) launch_micro_fwd<2, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    else if (K <= 4) launch_micro_fwd<4, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    else if (K <= 8) launch_micro_fwd<8, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    else launch_micro_fwd<16, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    return launch_status_m();
+}
+template <bool kCompact>
+static int micro_bwd_launch(const dhts_micro_desc *d, int T, const float *tape, const int32_t *count,
+                            const float *g_p, const float *g_v, const float *g_hist,
+                            float *g_p_out, float *g_v_out, double *g_head, int fold, dhts_error *err, void *stream) {
+    if (!micro_desc_ok(d) || T < 0 || (T > 0 && !tape) || !g_p || !g_v || !g_p_out || !g_v_out) return DHTS_E_INVALID;
+    const size_t lds = sizeof(float) * 4 * (size_t)(d->capacity + 2);
+    int B = (d->capacity + 63) & ~63;
+    if (B > 256) B = 256;
+    micro_rollout_bwd_kernel<kCompact><<<d->n_lanes, B, lds, (hipStream_t)stream>>>(
+        d->n_lanes, d->capacity, T, d->dt, reinterpret_cast<const float4 *>(tape), count, g_p, g_v, g_hist, g_p_out, g_v_out,
+        g_head, fold, err);
+    return launch_status_m();
 }
 
 extern "C" {
@@ -220,50 +258,33 @@ int dhts_idm_batch(int64_t n, int variant, const double *in, double *next_pv, fl
 
 size_t dhts_micro_tape_bytes(const dhts_micro_desc *d, int T) {
     if (!micro_desc_ok(d) || T < 0) return 0;
-    return (size_t)T * d->n_lanes * 2 * ((d->capacity + 63) & ~63) * sizeof(float4);
+    return (size_t)T * d->n_lanes * ((d->capacity + 63) & ~63) * sizeof(float4);
+}
+size_t dhts_micro_step_tape_bytes(const dhts_micro_desc *d) {
+    if (!micro_desc_ok(d)) return 0;
+    return (size_t)d->n_lanes * 2 * ((d->capacity + 63) & ~63) * sizeof(float4);
 }
 
 int dhts_micro_rollout_fwd(const dhts_micro_desc *d, int T,
                            const float *p, const float *v, const int32_t *count, const double *params, const double *head,
                            float *p_out, float *v_out, float *tape, float *hist, dhts_error *err, void *stream) {
-    if (!micro_desc_ok(d) || T < 0 || !p || !v || !params || !head || !p_out || !v_out) return DHTS_E_INVALID;
-    hipStream_t s = (hipStream_t)stream;
-    const int K = (d->capacity + 63) >> 6;
-    if (K <= 1) launch_micro_fwd<1>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
-    else if (K <= 2) launch_micro_fwd<2>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
-    else if (K <= 4) launch_micro_fwd<4>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
-    else if (K <= 8) launch_micro_fwd<8>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
-    else launch_micro_fwd<16>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
-    return launch_status_m();
+    return micro_fwd_launch<true>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, stream);
 }
-
-static int micro_bwd_launch(const dhts_micro_desc *d, int T, const float *tape, const int32_t *count,
-                            const float *g_p, const float *g_v, const float *g_hist,
-                            float *g_p_out, float *g_v_out, double *g_head, int fold, dhts_error *err, void *stream) {
-    if (!micro_desc_ok(d) || T < 0 || (T > 0 && !tape) || !g_p || !g_v || !g_p_out || !g_v_out) return DHTS_E_INVALID;
-    const size_t lds = sizeof(float) * 4 * (size_t)(d->capacity + 2);
-    int B = (d->capacity + 63) & ~63;
-    if (B > 256) B = 256;
-    micro_rollout_bwd_kernel<<<d->n_lanes, B, lds, (hipStream_t)stream>>>(
-        d->n_lanes, d->capacity, T, reinterpret_cast<const float4 *>(tape), count, g_p, g_v, g_hist, g_p_out, g_v_out, g_head, fold, err);
-    return launch_status_m();
-}
-
 int dhts_micro_rollout_bwd(const dhts_micro_desc *d, int T, const float *tape, const int32_t *count,
                                       const float *g_p, const float *g_v, const float *g_hist,
                                       float *g_p_out, float *g_v_out, double *g_head, dhts_error *err, void *stream) {
-    return micro_bwd_launch(d, T, tape, count, g_p, g_v, g_hist, g_p_out, g_v_out, g_head, 1, err, stream);
+    return micro_bwd_launch<true>(d, T, tape, count, g_p, g_v, g_hist, g_p_out, g_v_out, g_head, 1, err, stream);
 }
-
+// the single-step operator keeps the reference's dqs[a][2][2][2] (32 B per vehicle)
 int dhts_micro_step_fwd(const dhts_micro_desc *d,
                         const float *p, const float *v, const int32_t *count, const double *params, const double *head,
                         float *p_out, float *v_out, float *tape, dhts_error *err, void *stream) {
-    return dhts_micro_rollout_fwd(d, 1, p, v, count, params, head, p_out, v_out, tape, nullptr, err, stream);
+    return micro_fwd_launch<false>(d, 1, p, v, count, params, head, p_out, v_out, tape, nullptr, err, stream);
 }
 int dhts_micro_step_bwd(const dhts_micro_desc *d, const float *tape, const int32_t *count,
                         const float *g_p, const float *g_v,
                         float *g_p_out, float *g_v_out, double *g_head, dhts_error *err, void *stream) {
-    return micro_bwd_launch(d, 1, tape, count, g_p, g_v, nullptr, g_p_out, g_v_out, g_head, 0, err, stream);
+    return micro_bwd_launch<false>(d, 1, tape, count, g_p, g_v, nullptr, g_p_out, g_v_out, g_head, 0, err, stream);
 }
 
 }  // extern "C"

@@ -54,6 +54,7 @@ SIGNATURES = {
     "dhts_set_option": (C.c_int, [C.c_int, C.c_int]),
     "dhts_padded": (C.c_int, [C.c_int]),
     "dhts_macro_tape_bytes": (C.c_size_t, [C.POINTER(MacroDesc), C.c_int]),
+    "dhts_macro_step_tape_bytes": (C.c_size_t, [C.POINTER(MacroDesc)]),
     "dhts_arz_interface_batch": (C.c_int, [C.c_int64, C.c_int, _P, C.c_double, C.c_double] + [_P] * 10),
     "dhts_idm_batch": (C.c_int, [C.c_int64, C.c_int] + [_P] * 8),
     "dhts_macro_state_from_ru": (C.c_int, [C.c_int64, C.c_double, _P, _P, _P, _P, _P]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     "dhts_net_hybrid_rollout_fwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(HybridTables)] + [_P] * 10),
     "dhts_net_hybrid_rollout_bwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(HybridTables)] + [_P] * 10),
     "dhts_micro_tape_bytes": (C.c_size_t, [C.POINTER(MicroDesc), C.c_int]),
+    "dhts_micro_step_tape_bytes": (C.c_size_t, [C.POINTER(MicroDesc)]),
     "dhts_micro_rollout_fwd": (C.c_int, [C.POINTER(MicroDesc), C.c_int] + [_P] * 11),
     "dhts_micro_rollout_bwd": (C.c_int, [C.POINTER(MicroDesc), C.c_int] + [_P] * 10),
     "dhts_micro_step_fwd": (C.c_int, [C.POINTER(MicroDesc)] + [_P] * 10),

@@ -62,7 +62,32 @@ def macro_desc(L, N, dt, dx, u_max):
 
 
 def macro_tape_numel(desc, T):
+    """float32 elements of the rollout (interface) tape."""
     return _lib.lib().dhts_macro_tape_bytes(C.byref(desc), int(T)) // 4
+
+
+def macro_step_tape_numel(desc):
+    """float32 elements of the single-step operator's tape (the reference's per-cell blocks)."""
+    return _lib.lib().dhts_macro_step_tape_bytes(C.byref(desc)) // 4
+
+
+def macro_step_fwd(desc, r, y, u, ueq, ghost, tape=None, err=None):
+    """One step of L lanes through the operator entry point (dqs-layout tape)."""
+    r, y, u, ueq, ghost = (_f32c(t, n) for t, n in ((r, "r"), (y, "y"), (u, "u"), (ueq, "ueq"), (ghost, "ghost")))
+    out = tuple(torch.empty_like(r) for _ in range(4))
+    check(_lib.lib().dhts_macro_step_fwd(C.byref(desc), _ptr(r), _ptr(y), _ptr(u), _ptr(ueq), _ptr(ghost),
+                                         _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(tape), _ptr(err), _stream()),
+          "dhts_macro_step_fwd")
+    return out
+
+
+def macro_step_bwd(desc, tape, g_r, g_y, err=None):
+    g_r, g_y = _f32c(g_r, "g_r"), _f32c(g_y, "g_y")
+    out = (torch.empty_like(g_r), torch.empty_like(g_y))
+    g_ghost = torch.zeros(desc.n_lanes, 2, 2, dtype=torch.float64, device=g_r.device)
+    check(_lib.lib().dhts_macro_step_bwd(C.byref(desc), _ptr(tape), _ptr(g_r), _ptr(g_y), _ptr(out[0]), _ptr(out[1]),
+                                         _ptr(g_ghost), _ptr(err), _stream()), "dhts_macro_step_bwd")
+    return out[0], out[1], g_ghost
 
 
 def macro_state_from_ru(r, u, u_max):
@@ -193,7 +218,22 @@ def micro_desc(L, V, dt):
 
 
 def micro_tape_numel(desc, T):
+    """float32 elements of the rollout tape (second rows of dEgo / dLeading)."""
     return _lib.lib().dhts_micro_tape_bytes(C.byref(desc), int(T)) // 4
+
+
+def micro_step_tape_numel(desc):
+    """float32 elements of the single-step operator's tape (the reference's dqs)."""
+    return _lib.lib().dhts_micro_step_tape_bytes(C.byref(desc)) // 4
+
+
+def micro_step_fwd(desc, p, v, params, head, count=None, tape=None, err=None):
+    """One step of L lanes through the operator entry point (dqs-layout tape)."""
+    p, v = _f32c(p, "p"), _f32c(v, "v")
+    out = (torch.empty_like(p), torch.empty_like(v))
+    check(_lib.lib().dhts_micro_step_fwd(C.byref(desc), _ptr(p), _ptr(v), _ptr(count), _ptr(params), _ptr(head),
+                                         _ptr(out[0]), _ptr(out[1]), _ptr(tape), _ptr(err), _stream()), "dhts_micro_step_fwd")
+    return out
 
 
 def micro_rollout_fwd(desc, T, p, v, params, head, count=None, tape=None, hist=None, err=None, out=None):

@@ -48,11 +48,11 @@ class dMacroForwardLayer(th.autograd.Function):
         ghost = lane._ghost_tensor()
         ghost[0, 0, 0], ghost[0, 0, 1] = r[0].detach(), y[0].detach()
         ghost[0, 1, 0], ghost[0, 1, 1] = r[-1].detach(), y[-1].detach()
-        tape = th.empty(ops.macro_tape_numel(desc, 1), dtype=th.float32, device=r.device)
+        tape = th.empty(ops.macro_step_tape_numel(desc), dtype=th.float32, device=r.device)
         err = ops.new_error_record(r.device)
-        nr, ny, nu, nq = ops.macro_rollout_fwd(desc, 1, r[1:-1].detach().reshape(1, n), y[1:-1].detach().reshape(1, n),
-                                               cur["u"].detach().reshape(1, n), cur["q"].detach().reshape(1, n), ghost,
-                                               tape=tape, err=err)
+        nr, ny, nu, nq = ops.macro_step_fwd(desc, r[1:-1].detach().reshape(1, n), y[1:-1].detach().reshape(1, n),
+                                            cur["u"].detach().reshape(1, n), cur["q"].detach().reshape(1, n), ghost,
+                                            tape=tape, err=err)
         ops.raise_on_fault(err)
         lane.d_lane.append(dMacroLane.dLane(n, tape))
         ctx.desc, ctx.tape = desc, tape
@@ -65,8 +65,8 @@ class dMacroForwardLayer(th.autograd.Function):
         desc = ctx.desc
         n = desc.n_cells
         err = ops.new_error_record(grad_nr.device)
-        g_r, g_y, g_ghost = ops.macro_rollout_bwd(desc, 1, ctx.tape, grad_nr.contiguous().reshape(1, n),
-                                                  grad_ny.contiguous().reshape(1, n), err=err)
+        g_r, g_y, g_ghost = ops.macro_step_bwd(desc, ctx.tape, grad_nr.contiguous().reshape(1, n),
+                                               grad_ny.contiguous().reshape(1, n), err=err)
         ops.raise_on_fault(err)
         gg = g_ghost[0].float()
         grad_r = th.cat([gg[0, 0:1], g_r[0], gg[1, 0:1]])

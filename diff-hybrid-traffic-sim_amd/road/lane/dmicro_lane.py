@@ -49,9 +49,9 @@ class dMicroForwardLayer(th.autograd.Function):
         pd, sd = p.detach(), s.detach()
         # the head gap exactly as compute_state_delta hands it to the IDM (numbers or 0-dim tensors)
         head = th.tensor([[float(lane.head_position_delta), float(lane.head_speed_delta)]], dtype=th.float64, device=dev)
-        tape = th.empty(ops.micro_tape_numel(desc, 1), dtype=th.float32, device=dev)
+        tape = th.empty(ops.micro_step_tape_numel(desc), dtype=th.float32, device=dev)
         err = ops.new_error_record(dev)
-        np_, nv_ = ops.micro_rollout_fwd(desc, 1, pd[:-1].reshape(1, v), sd[:-1].reshape(1, v), params, head, tape=tape, err=err)
+        np_, nv_ = ops.micro_step_fwd(desc, pd[:-1].reshape(1, v), sd[:-1].reshape(1, v), params, head, tape=tape, err=err)
         code = err.tolist()
         if code[0] == 2:
             print("Collision detected at vehicle %d" % code[3])

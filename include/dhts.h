@@ -76,8 +76,16 @@ int dhts_device_count(void);
 int dhts_set_option(int option, int value);
 /* cells / vehicle slots rounded up to the tape's padded width (multiple of 64) */
 int dhts_padded(int n);
-/* bytes of Jacobian tape for T steps */
+/* bytes of Jacobian tape for T fused steps (dhts_macro_rollout_*): the interface tape
+ *   [step][lane][2][Nq][4] float32, Nq = n_cells + 1 rounded up to 8: plane 0 = A_i = flux'(Q_0) dQ_0/dQ_L, plane 1 =
+ *   B_i = flux'(Q_0) dQ_0/dQ_R of interface i (the two 2x2 products of dMacroLane._backward, dmacro_lane.py:116-124), 32 B per
+ *   interface-step.  The reverse sweep forms the reference's cell blocks dqs[a][0] = c A_a, dqs[a][1] = I - c (A_{a+1} - B_a),
+ *   dqs[a][2] = - c B_{a+1} (c = dt / dx; dmacro_lane.py:126-129) from them with the same float32 operations, so the results
+ *   are those of the 48-byte per-cell tape at two thirds of the memory traffic. */
 size_t dhts_macro_tape_bytes(const dhts_macro_desc *d, int T);
+/* bytes of the single-step operator's tape (dhts_macro_step_*): the reference's per-cell blocks
+ *   [lane][3][Np][4] float32, Np = dhts_padded(n_cells): plane k holds dqs[a][k] of every cell a */
+size_t dhts_macro_step_tape_bytes(const dhts_macro_desc *d);
 
 /*
  * n independent cell interfaces: ARZ.riemann_solve (model/macro/_arz.py:212-332) + dARZ.compute_dLdR and
@@ -149,7 +157,12 @@ typedef struct dhts_micro_desc {
 #define DHTS_MICRO_MAX_VEHICLES 1024
 #define DHTS_MICRO_NPARAM 6 /* accel_max, accel_pref, target_speed, min_space, time_pref, length (micro_vehicle.py:21-28) */
 
+/* bytes of Jacobian tape for T fused steps (dhts_micro_rollout_*): [step][lane][Vp][4] float32 = the second rows of
+ * dEgo and dLeading of every vehicle (16 B per vehicle-step); their first rows are the constants [1, dt] and [0, 0]
+ * (didm.py:38-103), which the reverse sweep re-inserts, so results equal those of the 32-byte dqs[a][2][2][2] tape */
 size_t dhts_micro_tape_bytes(const dhts_micro_desc *d, int T);
+/* bytes of the single-step operator's tape (dhts_micro_step_*): [lane][2][Vp][4] float32, plane k = dqs[a][k] */
+size_t dhts_micro_step_tape_bytes(const dhts_micro_desc *d);
 
 /*
  * n independent vehicles: IDM.compute_acceleration (model/micro/_idm.py:6-50) + one explicit-Euler step

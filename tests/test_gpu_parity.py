@@ -29,6 +29,21 @@ def tape_to_dqs(tape, T, L, N, planes=3):
     return np.ascontiguousarray(t.transpose(0, 1, 3, 2, 4)).reshape(T, L, N, planes, 2, 2)
 
 
+def iface_tape_to_dqs(tape, T, L, N, c):
+    """The rollout's interface tape [T][L][2][Nq][4] (A_i, B_i) -> dqs [T][L][N][3][2][2] with the kernel's own float32
+    operations (dmacro_lane.py:126-129): dqs[a][0] = c A_a, dqs[a][1] = I - c (A_{a+1} - B_a), dqs[a][2] = -c B_{a+1}."""
+    Nq = (N + 1 + 7) // 8 * 8
+    t = tape.cpu().numpy().reshape(T, L, 2, Nq, 4)
+    A, B = t[:, :, 0, :N + 1, :], t[:, :, 1, :N + 1, :]
+    cf, ncf = np.float32(c), np.float32(-c)
+    out = np.zeros((T, L, N, 3, 4), np.float32)
+    out[:, :, :, 0, :] = ncf * (-A[:, :, :N, :])
+    out[:, :, :, 2, :] = ncf * B[:, :, 1:, :]
+    eye = np.array([1, 0, 0, 1], np.float32)
+    out[:, :, :, 1, :] = eye - cf * (A[:, :, 1:, :] - B[:, :, :N, :])
+    return out.reshape(T, L, N, 3, 2, 2)
+
+
 def dqs_to_tape(dqs, planes=3):
     T, L, N = dqs.shape[:3]
     Np = (N + 63) // 64 * 64
@@ -140,11 +155,16 @@ def test_macro_step_vs_golden_and_oracle(cuda, oracle, golden_dir, name):
     desc = ops.macro_desc(1, N, c["dt"], c["dx"], c["u_max"])
     planes = [T_(st[k, 1:-1][None], cuda) for k in range(4)]
     ghost = T_(np.stack([st[:, 0], st[:, -1]])[None], cuda)           # [1][2][4]
-    tape = torch.zeros(ops.macro_tape_numel(desc, 1), device=cuda)
+    tape = torch.zeros(ops.macro_step_tape_numel(desc), device=cuda)
     err = ops.new_error_record(cuda)
-    nr, ny, nu, nq = ops.macro_rollout_fwd(desc, 1, *planes, ghost, tape=tape, err=err)
+    nr, ny, nu, nq = ops.macro_step_fwd(desc, *planes, ghost, tape=tape, err=err)
     assert ops.raise_on_fault(err) == 0
     dqs = tape_to_dqs(tape, 1, 1, N)[0, 0]
+    # the fused rollout entry point (interface tape) gives the same step and the same blocks
+    tape_i = torch.zeros(ops.macro_tape_numel(desc, 1), device=cuda)
+    out_i = ops.macro_rollout_fwd(desc, 1, *planes, ghost, tape=tape_i)
+    assert all(torch.equal(a, b) for a, b in zip(out_i, (nr, ny, nu, nq)))
+    assert np.array_equal(iface_tape_to_dqs(tape_i, 1, 1, N, c["dt"] / c["dx"])[0, 0], dqs)
     o = oracle.macro_step(st, c["dt"], c["dx"], c["u_max"])
     # device double arithmetic follows the oracle's operation order; only pow() vs sqrt()/mul differs
     assert ulp_diff(nr.cpu().numpy()[0], o["nr"]).max() <= 1
@@ -165,7 +185,11 @@ def test_macro_step_vs_golden_and_oracle(cuda, oracle, golden_dir, name):
     assert rel_max(dqs, g[name + "_dqs"]) <= 1e-6
     # backward on the reference's tape and cotangents
     tape_ref = T_(dqs_to_tape(g[name + "_dqs"][None, None]).reshape(-1), cuda)
-    g_r0, g_y0, g_ghost = ops.macro_rollout_bwd(desc, 1, tape_ref, T_(g[name + "_g_nr"][None], cuda), T_(g[name + "_g_ny"][None], cuda))
+    g_r0, g_y0, g_ghost = ops.macro_step_bwd(desc, tape_ref, T_(g[name + "_g_nr"][None], cuda), T_(g[name + "_g_ny"][None], cuda))
+    # the rollout reverse sweep on the interface tape of the same step agrees with the operator on its own tape
+    b_i = ops.macro_rollout_bwd(desc, 1, tape_i, T_(g[name + "_g_nr"][None], cuda), T_(g[name + "_g_ny"][None], cuda))
+    b_s = ops.macro_step_bwd(desc, tape, T_(g[name + "_g_nr"][None], cuda), T_(g[name + "_g_ny"][None], cuda))
+    assert all(torch.equal(a, b) for a, b in zip(b_i, b_s))
     ref_r, ref_y = g[name + "_g_r"], g[name + "_g_y"]
     assert np.array_equal(g_r0.cpu().numpy()[0], ref_r[1:-1]) and np.array_equal(g_y0.cpu().numpy()[0], ref_y[1:-1])
     gg = g_ghost.cpu().numpy()[0]
@@ -284,7 +308,7 @@ def test_macro_tape_matches_oracle_over_rollout(cuda, oracle):
     ghost = torch.stack([tgr, gy, tgu, gq], dim=-1).contiguous()
     tape = torch.zeros(ops.macro_tape_numel(desc, T), device=cuda)
     ops.macro_rollout_fwd(desc, T, r, y, u, q, ghost, tape=tape)
-    dqs = tape_to_dqs(tape, T, L, N)
+    dqs = iface_tape_to_dqs(tape, T, L, N, dt / dx)
     # a 1-ulp difference in a cell's state changes that cell's later tape entries in the last bits, so the
     # comparison is norm-relative; the single-step test above compares a tape bit for bit
     assert rel_max(dqs, f["tape"]) <= 2e-6
@@ -464,10 +488,10 @@ def test_micro_collision_is_recorded_and_tolerated(cuda, oracle):
     v0 = np.array([[10.0, 1.0]], np.float32)
     desc = ops.micro_desc(1, 2, 0.01)
     err = ops.new_error_record(cuda)
-    tape = torch.zeros(ops.micro_tape_numel(desc, 1), device=cuda)
+    tape = torch.zeros(ops.micro_step_tape_numel(desc), device=cuda)
     head = T_(np.array([[1000.0, 0.0]]), cuda, dtype=torch.float64)
-    pT, vT = ops.micro_rollout_fwd(desc, 1, T_(p0, cuda), T_(v0, cuda), T_(par.transpose(2, 0, 1), cuda, dtype=torch.float64),
-                                   head, tape=tape, err=err)
+    pT, vT = ops.micro_step_fwd(desc, T_(p0, cuda), T_(v0, cuda), T_(par.transpose(2, 0, 1), cuda, dtype=torch.float64),
+                                head, tape=tape, err=err)
     code, step, lane, index = err.tolist()
     assert (code, step, lane, index) == (2, 0, 0, 0)
     o = oracle.micro_step(p0[0], v0[0], par[0], 1000.0, 0.0, 0.01)
