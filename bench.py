@@ -268,7 +268,7 @@ class ItscpMacroWorkload:
 
 class ItscpHybridWorkload:
     """run_itscp_hybrid.sh's network (3 x 3 intersections, 1 lane, 20 s, signal 4 s: 144 lanes of which the 16 of the
-    centre intersection are micro, 256 cells, 600 steps, 45 actions) x 256 replicas with actions U[0.1, 0.9]: reward and
+    centre intersection are micro, 256 cells, 600 steps, 45 actions) x 256 replicas with per-replica problem_1 schedules and actions U[0.1, 0.9]: reward and
     d reward / d action of every replica in one fused launch each way (BASELINE config 4)."""
     name = "itscp_hybrid_256x(144 lanes, 256 cells, 16 micro lanes)x600"
     unit_bytes = MACRO_TAPE_B
@@ -296,7 +296,15 @@ class ItscpHybridWorkload:
                 for _ in range(8):
                     r = env.simulator.create_random_route(l).route
                     routes.append(list(r) + [-1] * (32 - len(r)))
-        self.tab = ops.DeviceHybridTables(tab, np.array(routes, dtype=np.int32), dev)
+        tabs = [tab]
+        keys = list(env.lane.keys())
+        for r in range(1, R):       # same topology and per-step routes, a fresh problem_1 inflow schedule per replica
+            sched = env.schedule_callback(keys, env.num_timestep)
+            t = HybridNetworkTables.__new__(HybridNetworkTables)
+            t.__dict__.update(tab.__dict__)
+            t.schedule = np.ascontiguousarray(np.array([sched[k] for k in keys], dtype=np.float64).T)
+            tabs.append(t)
+        self.tab = ops.DeviceHybridTables(tabs, np.array(routes, dtype=np.int32), dev)
         self.host_tab, self.host_routes = tab, np.array(routes, dtype=np.int32)
         self.sq, self.F, self.dt, self.um = 9, 120, 1.0 / 30.0, 60.0
         gen = torch.Generator(device="cpu").manual_seed(177 + rank)

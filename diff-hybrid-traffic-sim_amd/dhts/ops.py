@@ -444,14 +444,19 @@ def net_macro_rollout(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_ma
 
 class DeviceHybridTables:
     """dhts.network.HybridNetworkTables plus the pre-drawn vehicle routes [n_routes][stride] (int, -1 padded; the k-th
-    vehicle spawned onto a lane takes the k-th route starting there, cyclically), uploaded once, shared by all replicas."""
+    vehicle spawned onto a lane takes the k-th route starting there, cyclically), uploaded once.  `tables` may be one
+    HybridNetworkTables (shared by all replicas) or a list of them (one per replica: same topology, own inflow schedules
+    and per-step macro routes)."""
 
     def __init__(self, tables, routes, device, records_per_step=0):
         import numpy as np
-        t = tables
+        many = isinstance(tables, (list, tuple))
+        t = tables[0] if many else tables
         self.n_lanes, self.n_cells, self.T = t.n_lanes, t.n_cells, t.T
+        self.n_replica_tables = len(tables) if many else 0
         up = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=device)    # noqa: E731
         pad1 = lambda a: a if len(a) else np.zeros(1, dtype=np.int32)      # noqa: E731
+        stack = (lambda name: np.stack([getattr(x, name) for x in tables])) if many else (lambda name: getattr(t, name))
         from .network import group_routes
         routes = np.ascontiguousarray(routes, dtype=np.int32)
         if routes.ndim != 2 or routes.shape[0] < 1 or routes.shape[1] > 32:
@@ -461,13 +466,14 @@ class DeviceHybridTables:
         self.records_per_step = int(records_per_step)
         self.n_micro = int((np.asarray(t.lane_macro) == 0).sum())
         self._keep = [up(t.lane_ncell, torch.int32), up(t.lane_off, torch.int32), up(t.sig_kind, torch.int32), up(t.inter, torch.int32),
-                      up(t.lane_dx, torch.float64), up(t.left_src, torch.int32), up(t.left_gate, torch.int32),
-                      up(t.right_src, torch.int32), up(t.schedule, torch.float64), up(t.nxt_ptr, torch.int32),
+                      up(t.lane_dx, torch.float64), up(stack("left_src"), torch.int32), up(stack("left_gate"), torch.int32),
+                      up(stack("right_src"), torch.int32), up(stack("schedule"), torch.float64), up(t.nxt_ptr, torch.int32),
                       up(pad1(t.nxt_idx), torch.int32), up(t.prv_ptr, torch.int32), up(pad1(t.prv_idx), torch.int32),
-                      up(t.lane_macro, torch.int32), up(t.lane_length, torch.float64), up(t.conv_next, torch.int32),
+                      up(t.lane_macro, torch.int32), up(t.lane_length, torch.float64), up(stack("conv_next"), torch.int32),
                       up(routes, torch.int32), up(route_ptr, torch.int32)]
         k = [x.data_ptr() for x in self._keep]
-        self.net = _lib.NetTables(k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], 0, k[9], k[10], k[11], k[12], t.n_edges)
+        self.net = _lib.NetTables(k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], self.T * self.n_lanes if many else 0,
+                                  k[9], k[10], k[11], k[12], t.n_edges)
 
     def c(self, loss_steps=0):
         k = [x.data_ptr() for x in self._keep]
@@ -485,6 +491,8 @@ class NetHybridRollout(torch.autograd.Function):
         a = _f32c(action.detach(), "action")
         R, A = a.shape
         t = dev_tables
+        if t.n_replica_tables not in (0, R):
+            raise ValueError("per-replica tables must match the number of replicas")
         d = _lib.NetDesc(R, t.n_lanes, t.n_cells, t.T, int(n_inter_sq), int(frames_per_phase), A, float(dt), float(u_max),
                          float(static_speed), float(vehicle_length))
         tc = t.c(loss_steps)

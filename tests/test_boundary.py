@@ -89,6 +89,45 @@ def test_network_tables_builder():
     assert t.is_source.tolist() == [True, False, False, True]
 
 
+def test_hybrid_tables_builder_and_route_grouping():
+    """dhts.network.HybridNetworkTables / group_routes: macro lane 0 -> micro lane 1 -> macro lane 2 (the G7 shape) plus a
+    macro fork 3 -> {4, 5}."""
+    import numpy as np
+    from dhts.network import HybridNetworkTables, group_routes
+    T = 2
+    mr = -np.ones((T, 6), dtype=np.int64)
+    mr[:, 0] = 1                                  # the macro route may point at a micro lane (conversion target)
+    mr[0, 3], mr[1, 3] = 4, 5
+    t = HybridNetworkTables([1, 0, 1, 1, 1, 1], [4, 9, 2, 3, 3, 3], [20.0, 15.0, 10.0, 15.0, 15.0, 15.0],
+                            [(0, 1), (1, 2), (3, 4), (3, 5)], [1, 0, 0, 2, 0, 0], [0, 0, 0, 0, 0, 0], mr, np.ones((6, T)))
+    assert t.lane_ncell.tolist() == [4, 0, 2, 3, 3, 3] and t.n_cells == 15 and t.lane_off.tolist() == [0, 4, 4, 6, 9, 12]
+    assert t.lane_dx.tolist() == [5.0, 0.0, 5.0, 5.0, 5.0, 5.0]
+    assert t.left_src[0].tolist() == [-1, -1, -3, -1, 3, 3]        # lane 2's only upstream lane is micro: own ghost
+    assert t.left_gate[0].tolist() == [-2, -1, -1, -2, 3, -1] and t.left_gate[1].tolist() == [-2, -1, -1, -2, -1, 3]
+    assert t.right_src[:, 0].tolist() == [-1, -1] and t.right_src[:, 3].tolist() == [4, 5]
+    assert t.conv_next[:, 0].tolist() == [1, 1] and (t.conv_next[:, 1] == -1).all()
+    assert t.nxt_ptr.tolist() == [0, 1, 2, 2, 4, 4, 4] and t.nxt_idx.tolist() == [1, 2, 4, 5]
+    routes, ptr = group_routes([[1, 2, -1], [4, -1, -1], [1, -1, -1]], 6)
+    assert routes.tolist() == [[1, 2, -1], [1, -1, -1], [4, -1, -1]]      # stable per first lane
+    assert ptr.tolist() == [0, 0, 2, 2, 2, 3, 3]
+    with pytest.raises(ValueError, match="micro source"):
+        HybridNetworkTables([0, 1], [0, 3], [10.0, 15.0], [(0, 1)], [0, 0], [0, 0], -np.ones((T, 2), dtype=np.int64), np.ones((2, T)))
+
+
+def test_hybrid_entry_points_reject_bad_arguments():
+    from dhts import _lib
+    lib = _lib.lib()
+    ok = _lib.NetDesc(4, 144, 256, 600, 9, 120, 45, 1 / 30, 60.0, 0.2, 5.0)
+    tabs = _lib.HybridTables()
+    assert lib.dhts_net_hybrid_workspace_bytes(C.byref(ok), C.byref(tabs)) == 0          # no routes
+    tabs.n_routes, tabs.route_stride = 8, 32
+    assert lib.dhts_net_hybrid_workspace_bytes(C.byref(ok), C.byref(tabs)) > 4 * 600 * 512 * 36
+    assert lib.dhts_net_hybrid_rollout_fwd(C.byref(ok), C.byref(tabs), *([None] * 10)) == _lib.E_INVALID
+    assert lib.dhts_net_hybrid_rollout_bwd(C.byref(ok), C.byref(tabs), *([None] * 10)) == _lib.E_INVALID
+    too_wide = _lib.NetDesc(4, 300, 900, 10, 1, 60, 5, 1 / 30, 60.0, 0.2, 5.0)
+    assert lib.dhts_net_hybrid_workspace_bytes(C.byref(too_wide), C.byref(tabs)) == 0
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from dhts import _lib
     monkeypatch.setattr(_lib, "_lib", None)

@@ -117,3 +117,35 @@ def test_config4_batch_properties(cuda, golden_dir):
         assert np.array_equal(rs[0], r1[k]) and np.array_equal(gs[0], g1[k]) and np.array_equal(qs[0], q1[k])
     r3, g3, _, _ = run(acts, loss_steps=m["T"])
     assert np.array_equal(r3, r1) and np.array_equal(g3, g1)
+
+
+def test_per_replica_tables(cuda, golden_dir):
+    """One table set per replica (own inflow schedules): every replica equals its own single-replica run."""
+    import copy
+    import torch
+    from dhts import ops
+    g = np.load(os.path.join(golden_dir, "itscp_hybrid_short.npz"))
+    t, m = itscp_hybrid_tables(g)
+    rng = np.random.default_rng(3)
+    tabs = []
+    for r in range(3):
+        x = copy.copy(t)
+        x.schedule = np.ascontiguousarray(t.schedule * (1.0 if r == 0 else rng.uniform(0.5, 1.0)))
+        tabs.append(x)
+    args = (m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"],
+            m["speed_limit"], m["static_speed"], m["vehicle_length"])
+    a = torch.tensor(np.tile(g["action"][None, :], (3, 1)), device=cuda)
+
+    def run(dev_tab, act):
+        act = act.clone().requires_grad_(True)
+        cut, reward, queue, counts = ops.net_hybrid_rollout(act, dev_tab, *args)
+        cut.sum().backward()
+        return reward.cpu().numpy(), act.grad.cpu().numpy(), queue.cpu().numpy()
+    rb, gb, qb = run(ops.DeviceHybridTables(tabs, g["spawn_routes"], cuda), a)
+    assert abs(float(rb[0]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+    assert not np.array_equal(qb[0], qb[1])
+    for r in range(3):
+        rs, gs, qs = run(ops.DeviceHybridTables(tabs[r], g["spawn_routes"], cuda), a[r:r + 1])
+        assert np.array_equal(rs[0], rb[r]) and np.array_equal(gs[0], gb[r]) and np.array_equal(qs[0], qb[r])
+    with pytest.raises(ValueError, match="per-replica"):
+        ops.net_hybrid_rollout(a[:2], ops.DeviceHybridTables(tabs, g["spawn_routes"], cuda), *args)
