@@ -11,7 +11,8 @@
 // and flux capacitor j; only the hand-off events themselves (spawn, lane change, despawn, deposit: rare, order-dependent)
 // are walked serially by lane 0.  All micro state lives in LDS.  Every float32 operation of the micro side is written,
 // with its partial derivatives, to a per-replica record stream in HBM: each lane stages its records in LDS and the wave
-// flushes them phase by phase (lane-ordered, coalesced), noting the per-lane counts in an index.  The reverse kernel loads a
+// flushes them three times per step (head gaps + IDM steps | capacitors + events | loss + commits; lane-ordered, coalesced),
+// noting the per-lane counts of every segment in an index.  The reverse kernel loads a
 // step's records back into LDS and lets every lane replay its own segments backwards (the same thing torch autograd does
 // for the reference) in step with the hand-written macro adjoint; the two sides meet at the hand-off records (capacitor
 // reads, deposits) and at the signals.  Contributions that cross lanes (the leader of a head vehicle sits on another lane;
@@ -789,9 +790,11 @@ __host__ __device__ inline HybLdsB hyb_lds_b(int L, int C, int sq, int V, int E)
     return o;
 }
 
-// Phases per step (five barriers): loss taps into the cell cotangents -> micro records of the hand-off / loss part,
-// newest first (deposits and capacitor reads exchange cotangents with the cells) -> J^T g per cell | the rest of the step's
-// micro records -> gather inside the lanes, ghost cotangents to inbox slots, signals -> edge cells take their inboxes.
+// Phases per step (five barriers; the step's data and records are fetched one iteration ahead): stage the step's rows and
+// records in LDS -> loss taps into the cell cotangents -> micro records of the commit / loss / hand-off / capacitor
+// segments, newest first (deposits and capacitor reads exchange cotangents with the cells) -> speed cotangents into (r, y)
+// and J^T g per cell -> gather inside the lanes, ghost cotangents to inbox slots, signals | the head-gap / IDM segment of
+// the micro records and the outboxes -> edge cells take their inboxes.
 template <int kMaxBlock>
 __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
                                       double static_speed, double veh_len, HybTables tb, const float *__restrict__ action,
