@@ -76,8 +76,11 @@ __host__ __device__ inline HybWs hyb_ws(int L, int C, int T, int n_routes, int r
     return w;
 }
 
-struct Tv { float val; int id; };
-__device__ __forceinline__ Tv tv_c(float v) { Tv x; x.val = v; x.id = -1; return x; }
+// a float32 value, the variable it depends on (id < 0: a constant) and d value / d variable: adding or multiplying by a
+// constant and negating only change the scale, so they need no record
+struct Tv { float val; int id; float sc; };
+__device__ __forceinline__ Tv tv_c(float v) { Tv x; x.val = v; x.id = -1; x.sc = 0.f; return x; }
+__device__ __forceinline__ Tv tv_var(float v, int id) { Tv x; x.val = v; x.id = id; x.sc = 1.f; return x; }
 
 struct Rec {               // one lane's handle on its staging area (LDS) and its private range of temporaries
     int *sk; int *si; float *sw;
@@ -91,26 +94,44 @@ __device__ __forceinline__ void rec_push(Rec &R, int kind, int out, int4 in, flo
     *reinterpret_cast<int4 *>(R.si + 4 * c) = in;
     *reinterpret_cast<float4 *>(R.sw + 4 * c) = w;
 }
-__device__ __forceinline__ Tv tv_leaf(Rec &R, float v) { Tv x; x.val = v; x.id = R.next_local++; return x; }
+__device__ __forceinline__ Tv tv_leaf(Rec &R, float v) { return tv_var(v, R.next_local++); }
 __device__ __forceinline__ Tv tv_node4(Rec &R, float v, Tv a, float wa, Tv b, float wb, Tv c, float wc, Tv d, float wd) {
     if (a.id < 0 && b.id < 0 && c.id < 0 && d.id < 0) return tv_c(v);
-    Tv x; x.val = v; x.id = R.next_local++;
-    rec_push(R, K_NODE, x.id, make_int4(a.id, b.id, c.id, d.id), make_float4(wa, wb, wc, wd));
+    const Tv x = tv_var(v, R.next_local++);
+    rec_push(R, K_NODE, x.id, make_int4(a.id, b.id, c.id, d.id), make_float4(wa * a.sc, wb * b.sc, wc * c.sc, wd * d.sc));
     return x;
 }
 // a fresh variable without inputs that still owns a record (so that its adjoint is cleared on replay)
 __device__ __forceinline__ Tv tv_fresh(Rec &R, float v) {
-    Tv x; x.val = v; x.id = R.next_local++;
+    const Tv x = tv_var(v, R.next_local++);
     rec_push(R, K_NODE, x.id, make_int4(-1, -1, -1, -1), make_float4(0.f, 0.f, 0.f, 0.f));
     return x;
 }
 __device__ __forceinline__ Tv tv_node2(Rec &R, float v, Tv a, float wa, Tv b, float wb) {
     return tv_node4(R, v, a, wa, b, wb, tv_c(0.f), 0.f, tv_c(0.f), 0.f);
 }
-__device__ __forceinline__ Tv tv_add(Rec &R, Tv a, Tv b) { return tv_node2(R, a.val + b.val, a, 1.f, b, 1.f); }
-__device__ __forceinline__ Tv tv_sub(Rec &R, Tv a, Tv b) { return tv_node2(R, a.val - b.val, a, 1.f, b, -1.f); }
-__device__ __forceinline__ Tv tv_mul(Rec &R, Tv a, Tv b) { return tv_node2(R, a.val * b.val, a, b.val, b, a.val); }
+// a variable with unit scale (what the per-vehicle / per-lane id tables hold)
+__device__ __forceinline__ Tv tv_unit(Rec &R, Tv a) {
+    return (a.id < 0 || a.sc == 1.f) ? a : tv_node2(R, a.val, a, 1.f, tv_c(0.f), 0.f);
+}
+__device__ __forceinline__ Tv tv_affine(float v, Tv a, float sc) { Tv x; x.val = v; x.id = a.id; x.sc = a.id < 0 ? 0.f : sc; return x; }
+__device__ __forceinline__ Tv tv_add(Rec &R, Tv a, Tv b) {
+    if (b.id < 0) return tv_affine(a.val + b.val, a, a.sc);
+    if (a.id < 0) return tv_affine(a.val + b.val, b, b.sc);
+    return tv_node2(R, a.val + b.val, a, 1.f, b, 1.f);
+}
+__device__ __forceinline__ Tv tv_sub(Rec &R, Tv a, Tv b) {
+    if (b.id < 0) return tv_affine(a.val - b.val, a, a.sc);
+    if (a.id < 0) return tv_affine(a.val - b.val, b, -b.sc);
+    return tv_node2(R, a.val - b.val, a, 1.f, b, -1.f);
+}
+__device__ __forceinline__ Tv tv_mul(Rec &R, Tv a, Tv b) {
+    if (b.id < 0) return tv_affine(a.val * b.val, a, a.sc * b.val);
+    if (a.id < 0) return tv_affine(a.val * b.val, b, b.sc * a.val);
+    return tv_node2(R, a.val * b.val, a, b.val, b, a.val);
+}
 __device__ __forceinline__ Tv tv_div(Rec &R, Tv a, Tv b) {
+    if (b.id < 0) return tv_affine(a.val / b.val, a, a.sc / b.val);
     return tv_node2(R, a.val / b.val, a, 1.f / b.val, b, -((a.val / b.val) / b.val));
 }
 __device__ __forceinline__ Tv tv_soft(Rec &R, Tv a, float k) {
@@ -389,8 +410,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     const int hv = lane_veh[k * kLaneCap + nv - 1];
                     const int *route = vroute + hv * kRouteStride;
                     const int rlen = vrlen[hv], cursor = vcur[hv];
-                    Tv hp; hp.val = vp[hv]; hp.id = vidp[hv];
-                    Tv hs; hs.val = vv[hv]; hs.id = vidv[hv];
+                    Tv hp = tv_var(vp[hv], vidp[hv]);
+                    Tv hs = tv_var(vv[hv], vidv[hv]);
                     const Tv Lc = tv_c(lanelen[l]), half = tv_c(vlen * 0.5f);
                     Tv reach = tv_sub(rec, tv_sub(rec, Lc, hp), half);
                     for (int j = cursor; j < rlen - 1; ++j) {
@@ -441,19 +462,20 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     Tv one_m = tv_sub(rec, tv_c(1.f), fs);
                     Tv dp_ = tv_add(rec, tv_mul(rec, green_dp, fs), tv_mul(rec, red_dp, one_m));
                     Tv dv_ = tv_add(rec, tv_mul(rec, green_dv, fs), tv_mul(rec, tv_c(0.f), one_m));
-                    hdpv[k] = dp_.val; hdpi[k] = dp_.id; hdvv[k] = dv_.val; hdvi[k] = dv_.id;
+                    dp_ = tv_unit(rec, dp_); dv_ = tv_unit(rec, dv_);
+                hdpv[k] = dp_.val; hdpi[k] = dp_.id; hdvv[k] = dv_.val; hdvi[k] = dv_.id;
                 }
                 sig_sum += __shfl(ssum, 63, 64); sig_cnt += __shfl(scnt, 63, 64);
             }
             const int k = mw;
             if (k < n_micro && lane_n[k] > 0) {
                 const int nv = lane_n[k];
-                Tv hd_p; hd_p.val = hdpv[k]; hd_p.id = hdpi[k];
-                Tv hd_v; hd_v.val = hdvv[k]; hd_v.id = hdvi[k];
+                Tv hd_p = tv_var(hdpv[k], hdpi[k]);
+                Tv hd_v = tv_var(hdvv[k], hdvi[k]);
                 for (int i = 0; i < nv; ++i) {
                     const int vi = lane_veh[k * kLaneCap + i];
-                    Tv p_; p_.val = vp[vi]; p_.id = vidp[vi];
-                    Tv v_; v_.val = vv[vi]; v_.id = vidv[vi];
+                    Tv p_ = tv_var(vp[vi], vidp[vi]);
+                    Tv v_ = tv_var(vv[vi], vidv[vi]);
                     IdmStep o;
                     Tv np_, nv_;
                     if (i == nv - 1) {
@@ -462,8 +484,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                         nv_ = tv_node4(rec, o.nv, p_, o.dE[2] + o.dLd[2], v_, o.dE[3] + o.dLd[3], hd_p, o.dLd[2], hd_v, -o.dLd[3]);
                     } else {
                         const int vj = lane_veh[k * kLaneCap + i + 1];
-                        Tv pl; pl.val = vp[vj]; pl.id = vidp[vj];
-                        Tv vl; vl.val = vv[vj]; vl.id = vidv[vj];
+                        Tv pl = tv_var(vp[vj], vidp[vj]);
+                        Tv vl = tv_var(vv[vj], vidv[vj]);
                         const double dp = fabs((double)pl.val - (double)p_.val) - ((veh_len + veh_len) * 0.5);
                         const double dv = (double)v_.val - (double)vl.val;
                         idm_step_ieee((double)p_.val, (double)v_.val, dp, dv, idm, dt, o);
@@ -513,8 +535,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     const int last = caplast[j];
                     Tv lr = tv_leaf(rec, nxt[last]), lu = tv_leaf(rec, nxt[2 * C + last]);
                     rec_push(rec, K_CELLREAD, 0, make_int4(lr.id, lu.id, last, 0), make_float4(0.f, 0.f, 0.f, 0.f));
-                    Tv cp; cp.val = capv[j]; cp.id = capi[j];
-                    cp = tv_add(rec, cp, tv_mul(rec, tv_mul(rec, lr, lu), tv_c(dtf)));
+                    Tv cp = tv_var(capv[j], capi[j]);
+                    cp = tv_unit(rec, tv_add(rec, cp, tv_mul(rec, tv_mul(rec, lr, lu), tv_c(dtf))));
                     capv[j] = cp.val; capi[j] = cp.id;
                     capleaf[j] = lu.id;                      // the speed leaf, for a spawn in this step
                 }
@@ -588,8 +610,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                             const int ms = mslot[nid];
                             if (lane_n[ms] >= kLaneCap) { cap_fault = true; continue; }
                             --lane_n[k];
-                            Tv p_; p_.val = vp[vi]; p_.id = vidp[vi];
-                            p_ = tv_sub(rec, p_, tv_c(Lf));
+                            Tv p_ = tv_var(vp[vi], vidp[vi]);
+                            p_ = tv_unit(rec, tv_sub(rec, p_, tv_c(Lf)));
                             vp[vi] = p_.val; vidp[vi] = p_.id;
                             for (int q = lane_n[ms]; q > 0; --q) lane_veh[ms * kLaneCap + q] = lane_veh[ms * kLaneCap + q - 1];
                             lane_veh[ms * kLaneCap + 0] = vi;
@@ -707,7 +729,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                         Tv qlen = tv_c(0.f);
                         for (int i = 0; i < nv; ++i) {
                             const int vi = lane_veh[k * kLaneCap + i];
-                            Tv v_; v_.val = vv[vi]; v_.id = vidv[vi];
+                            Tv v_ = tv_var(vv[vi], vidv[vi]);
                             Tv xs_ = tv_sub(rec, tv_c(s0f), v_);
                             pa += (double)xs_.val; pb += (double)vxold[vi]; ++n;
                             const double mean = n > kWindow ? (pa - pb) / (double)kWindow : pa / (double)n;
@@ -716,7 +738,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                         }
                         qmicro[k] = (qlen.val * qlen.val) * dtf;
                         if (qlen.id >= 0 && t < loss_steps)
-                            rec_push(rec, K_SEED, 0, make_int4(qlen.id, 0, 0, 0), make_float4(-1.0f * dtf * 2.f * qlen.val, 0.f, 0.f, 0.f));
+                            rec_push(rec, K_SEED, 0, make_int4(qlen.id, 0, 0, 0), make_float4(-1.0f * dtf * 2.f * qlen.val * qlen.sc, 0.f, 0.f, 0.f));
                     }
                 }
                 // commit temporaries into the persistent slots (vehicles by their lane, capacitors by theirs)
