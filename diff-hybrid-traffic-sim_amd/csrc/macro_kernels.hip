@@ -339,10 +339,14 @@ static int macro_fwd_launch(const dhts_macro_desc *d, int T,
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)macro_rollout_fwd_kernel<kIface>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_LAUNCH;
-    // Waves per lane: enough wavefronts to put ~2 on every SIMD of the chip (256 CUs x 4 SIMDs; measured best on
-    // 1024 lanes x 512 cells: 1 -> 11.9 ms, 2 -> 9.2, 3 -> 9.6, 4 -> 9.8, 5 -> 11.9), at most 8 per lane, and never
-    // more than the lane has 63-cell chunks.  p = passes per wave, chunk = 64 p - 1 cells.
-    int W = dhts_fwd_waves_override > 0 ? dhts_fwd_waves_override : (int)((2 * 1024 + d->n_lanes - 1) / d->n_lanes);
+    // Waves per lane: about 5 wavefronts on every SIMD of the chip (256 CUs x 4 SIMDs) when there are few lanes, 2 per lane
+    // when there are many, at most 8, and never more than the lane has 63-cell chunks (p = passes per wave, chunk = 64 p - 1
+    // cells).  Measured forward times in ms for waves per lane 1 / 2 / 3 / 5 / 8 (tools/sweep_fwd_waves.py, 1000 steps):
+    //   4096 x 256: 13.3 / 12.5 / 12.6 / 14.3 / 14.1      2048 x 512: 15.1 / 10.9 / 11.8 / 12.5 / 12.6
+    //   1024 x 512:  7.9 /  6.1 /  6.4 /  5.9 /  6.0       512 x 1000: 14.4 / 10.2 /  7.9 /  5.2 /  4.7
+    //    256 x 2048: 27.6 / 14.9 /  9.6 /  7.0 /  6.5
+    int W = dhts_fwd_waves_override > 0 ? dhts_fwd_waves_override
+                                        : (d->n_lanes >= 1536 ? 2 : (int)((5 * 1024 + d->n_lanes - 1) / d->n_lanes));
     if (W > 8) W = 8;
     if (W < 1) W = 1;
     int p = 1;
