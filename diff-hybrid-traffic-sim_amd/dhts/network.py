@@ -167,6 +167,20 @@ class HybridNetworkTables:
             raise ValueError("the network kernels support at most 4 upstream and 4 downstream lanes per lane")
         self.schedule = np.ascontiguousarray(np.asarray(schedule, dtype=np.float64).T)      # [T][L]
 
+    def check_kernel_limits(self):
+        """Raise ValueError when the network is outside what the fused hybrid kernels hold in one workgroup."""
+        n_micro = int((self.lane_macro == 0).sum())
+        n_spawn = sum(1 for l in range(self.n_lanes)
+                      if self.lane_macro[l] == 1 and any(self.lane_macro[b] == 0 for b in self.next_lanes[l]))
+        if self.n_cells + self.n_lanes > 960:
+            raise ValueError("hybrid kernels: cells + lanes must be <= 960 (got %d)" % (self.n_cells + self.n_lanes))
+        if n_micro > 24:
+            raise ValueError("hybrid kernels: at most 24 micro lanes (got %d)" % n_micro)
+        if n_spawn > 16:
+            raise ValueError("hybrid kernels: at most 16 macro lanes feeding micro lanes (got %d)" % n_spawn)
+        if self.n_cells < 1:
+            raise ValueError("hybrid kernels: the network needs at least one macro cell")
+
     @staticmethod
     def from_env(env):
         """From an example.control.itscp._env.ItscpEnv (after reset) in `hybrid` mode."""

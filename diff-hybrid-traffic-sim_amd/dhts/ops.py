@@ -452,6 +452,7 @@ class DeviceHybridTables:
         import numpy as np
         many = isinstance(tables, (list, tuple))
         t = tables[0] if many else tables
+        t.check_kernel_limits()
         self.n_lanes, self.n_cells, self.T = t.n_lanes, t.n_cells, t.T
         self.n_replica_tables = len(tables) if many else 0
         up = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=device)    # noqa: E731

@@ -110,6 +110,11 @@ def test_hybrid_tables_builder_and_route_grouping():
     routes, ptr = group_routes([[1, 2, -1], [4, -1, -1], [1, -1, -1]], 6)
     assert routes.tolist() == [[1, 2, -1], [1, -1, -1], [4, -1, -1]]      # stable per first lane
     assert ptr.tolist() == [0, 0, 2, 2, 2, 3, 3]
+    t.check_kernel_limits()
+    big = HybridNetworkTables([1] + [0] * 30, [4] + [0] * 30, [20.0] * 31, [(k, k + 1) for k in range(0, 30)],
+                              [0] * 31, [0] * 31, -np.ones((T, 31), dtype=np.int64), np.ones((31, T)))
+    with pytest.raises(ValueError, match="24 micro lanes"):
+        big.check_kernel_limits()
     with pytest.raises(ValueError, match="micro source"):
         HybridNetworkTables([0, 1], [0, 3], [10.0, 15.0], [(0, 1)], [0, 0], [0, 0], -np.ones((T, 2), dtype=np.int64), np.ones((2, T)))
 
