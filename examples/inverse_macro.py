@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--n_lane", type=int, default=1)
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--run_name", default=None)
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one whole episode (rollout, loss, adjoint, Adam step, clamp) in a HIP graph and replay it: "
+                         "for small problems the episode is launch-bound (single GPU only)")
     args = ap.parse_args()
 
     rank, world, local = D.init()
@@ -58,22 +61,65 @@ def main():
             r_tgt, _, u_tgt, _ = dhts.macro_rollout(r_true, u_true, ghost_r, ghost_u, T, args.delta_time, args.cell_length, um)
         r_est = (r_true + th.randn(L, N, device=dev) * 1e-2).clamp(0.0, 1.0).requires_grad_(True)
         u_est = (u_true + th.randn(L, N, device=dev) * 1e-2).clamp(0.0, um).requires_grad_(True)
-        opt = th.optim.Adam([r_est, u_est], lr=1e-3)
+        opt = th.optim.Adam([r_est, u_est], lr=1e-3, capturable=args.graph)
         lines = []
-        t0 = time.time()
-        for ep in range(args.n_episode):
-            rT, _, uT, _ = dhts.macro_rollout(r_est, u_est, ghost_r, ghost_u, T, args.delta_time, args.cell_length, um)
+
+        def episode(check_faults):
+            rT, _, uT, _ = dhts.macro_rollout(r_est, u_est, ghost_r, ghost_u, T, args.delta_time, args.cell_length, um,
+                                              check_faults=check_faults)
             beg = ((r_est - r_true) ** 2).sum() + ((u_est - u_true) ** 2).sum()
             end = ((rT - r_tgt) ** 2).sum() + ((uT - u_tgt) ** 2).sum()
-            opt.zero_grad()
+            opt.zero_grad(set_to_none=False)
             end.backward()
             opt.step()
             with th.no_grad():
                 r_est.clamp_(0.0, 1.0)
                 u_est.clamp_(0.0, um)
-            flat = th.stack([beg.detach(), end.detach()]).float()
-            D.allreduce_sum_(flat)                            # every lane owns its unknowns: only the errors are reduced
-            lines.append("{} {}\n".format(flat[0].item(), flat[1].item()))
+            return th.stack([beg.detach(), end.detach()]).float()
+
+        if args.graph:
+            assert world == 1, "--graph is a single-GPU mode"
+            log = th.zeros(args.n_episode + 4, 2, device=dev)
+            slot = th.zeros(1, dtype=th.long, device=dev)
+            for p_ in (r_est, u_est):
+                p_.grad = th.zeros_like(p_)
+            keep = (r_est.detach().clone(), u_est.detach().clone())
+            side = th.cuda.Stream()
+            side.wait_stream(th.cuda.current_stream())
+            with th.cuda.stream(side):                       # warm-up outside the capture (allocator, Adam state)
+                for _ in range(3):
+                    episode(False)
+            th.cuda.current_stream().wait_stream(side)
+            with th.no_grad():                               # the warm-up episodes do not count
+                r_est.copy_(keep[0]); u_est.copy_(keep[1])
+            opt = th.optim.Adam([r_est, u_est], lr=1e-3, capturable=True)
+            side.wait_stream(th.cuda.current_stream())
+            with th.cuda.stream(side):
+                episode(False)                               # creates the new optimiser's state tensors
+            th.cuda.current_stream().wait_stream(side)
+            with th.no_grad():
+                r_est.copy_(keep[0]); u_est.copy_(keep[1])
+                for st in opt.state.values():
+                    for v_ in st.values():
+                        if isinstance(v_, th.Tensor):
+                            v_.zero_()
+            graph = th.cuda.CUDAGraph()
+            with th.cuda.graph(graph):
+                flat = episode(False)
+                log.index_copy_(0, slot, flat.reshape(1, 2))
+                slot.add_(1)
+            th.cuda.synchronize()
+            t0 = time.time()
+            for ep in range(args.n_episode):
+                graph.replay()
+            th.cuda.synchronize()
+            lines = ["{} {}\n".format(a, b) for a, b in log[:args.n_episode].tolist()]
+        else:
+            t0 = time.time()
+            for ep in range(args.n_episode):
+                flat = episode(True)
+                D.allreduce_sum_(flat)                        # every lane owns its unknowns: only the errors are reduced
+                lines.append("{} {}\n".format(flat[0].item(), flat[1].item()))
         th.cuda.synchronize()
         dt_wall = time.time() - t0
         if rank == 0:
