@@ -722,8 +722,6 @@ def main():
             gen_itscp(os.environ.get("DHTS_HYBRID_NAME", "hybrid"), "hybrid", 3, 1, 5.0, 20, 4, seed=9, action_kind="rand")
         if "hybrid_short" in which:      # 8 s: enough for the first vehicles to cross the interior intersection
             gen_itscp("hybrid_short", "hybrid", 3, 1, 5.0, 8, 2, seed=9, action_kind="rand")
-        if "hybrid_one" in which:        # one intersection: spawns and deposits (micro -> macro) within 8 s
-            gen_itscp("hybrid_one", "hybrid", 1, 1, 5.0, 8, 2, seed=11, action_kind="rand")
 
 
 if __name__ == "__main__":
