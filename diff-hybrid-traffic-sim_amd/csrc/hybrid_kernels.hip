@@ -45,7 +45,7 @@ constexpr int kPhases = 3;           // record segments per step: head gaps + ID
 constexpr int kMaxStepRecords = 1024;
 constexpr int kWindow = 100000;      // RunningMean(100_000), _env.py:122
 
-enum { K_NODE = 1, K_COMMIT = 2, K_DEPOSIT = 3, K_CELLREAD = 4, K_SIGNAL = 5, K_SEED = 6, K_IMPORT = 7 };
+enum { K_NODE = 1, K_COMMIT = 2, K_DEPOSIT = 3, K_CELLREAD = 4, K_SIGNAL = 5, K_SEED = 6, K_IMPORT = 7, K_IDM = 8 };
 
 struct HybTables {
     NetTables net;
@@ -153,7 +153,7 @@ __device__ __forceinline__ float stream_load(const float *p) {
 struct HybLds {
     size_t fq, scanw, incl, vsp, vep, s0, s1, g, ab, contrib, ql, sig, lanelen, vp, vv, va, vxold, hdpv, hdvv, capv, qmicro,
         cell_lane, iface_lane, cnext, vidp, vidv, vida, vcur, vrlen, vroute, lane_n, lane_veh, hdpi, hdvi, vcp, capi, mslot,
-        capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, tnp, tnv, tnpi, tnvi, stg_k, stg_i, stg_w, total;
+        capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, stg_k, stg_i, stg_w, total;
 };
 __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS) {
     HybLds o; size_t p = 0; const int NI = C + L;
@@ -166,7 +166,7 @@ __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS) {
     o.cell_lane = F(C); o.iface_lane = F(NI); o.cnext = F(L); o.vidp = F(V); o.vidv = F(V); o.vida = F(V); o.vcur = F(V);
     o.vrlen = F(V); o.vroute = F((size_t)V * kRouteStride); o.lane_n = F(kMaxMicro); o.lane_veh = F(kMaxMicro * kLaneCap);
     o.hdpi = F(kMaxMicro); o.hdvi = F(kMaxMicro); o.vcp = F(kMaxMicro + 1); o.capi = F(kMaxCaps); o.mslot = F(L); o.capof = F(L);
-    o.mlane = F(kMaxMicro); o.cbefore = F(kMaxMicro + 1); o.convlist = F(L); o.linfo = F(L); o.caplast = F(kMaxCaps); o.rused = F(kMaxMicro); o.caplane = F(kMaxCaps); o.capleaf = F(kMaxCaps); o.tnp = F(V); o.tnv = F(V); o.tnpi = F(V); o.tnvi = F(V);
+    o.mlane = F(kMaxMicro); o.cbefore = F(kMaxMicro + 1); o.convlist = F(L); o.linfo = F(L); o.caplast = F(kMaxCaps); o.rused = F(kMaxMicro); o.caplane = F(kMaxCaps); o.capleaf = F(kMaxCaps);
     o.stg_k = F((size_t)NS * kStage); o.stg_i = F((size_t)NS * kStage * 4); o.stg_w = F((size_t)NS * kStage * 4);
     o.total = p;
     return o;
@@ -197,8 +197,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     float *vp = LF(vp), *vv = LF(vv), *va = LF(va), *vxold = LF(vxold), *hdpv = LF(hdpv), *hdvv = LF(hdvv), *capv = LF(capv), *qmicro = LF(qmicro);
     int *cell_lane_s = LI(cell_lane), *iface_lane_s = LI(iface_lane), *cnext = LI(cnext), *vidp = LI(vidp), *vidv = LI(vidv), *vida = LI(vida);
     int *vcur = LI(vcur), *vrlen = LI(vrlen), *vroute = LI(vroute), *lane_n = LI(lane_n), *lane_veh = LI(lane_veh), *hdpi = LI(hdpi), *hdvi = LI(hdvi);
-    int *vcp = LI(vcp), *capi = LI(capi), *mslot = LI(mslot), *capof = LI(capof), *mlane = LI(mlane), *cbefore = LI(cbefore), *convlist = LI(convlist), *linfo = LI(linfo), *caplast = LI(caplast), *rused = LI(rused), *caplane = LI(caplane), *capleaf = LI(capleaf), *tnpi = LI(tnpi), *tnvi = LI(tnvi);
-    float *tnp = LF(tnp), *tnv = LF(tnv);
+    int *vcp = LI(vcp), *capi = LI(capi), *mslot = LI(mslot), *capof = LI(capof), *mlane = LI(mlane), *cbefore = LI(cbefore), *convlist = LI(convlist), *linfo = LI(linfo), *caplast = LI(caplast), *rused = LI(rused), *caplane = LI(caplane), *capleaf = LI(capleaf);
     int *stg_k = LI(stg_k), *stg_i = LI(stg_i); float *stg_w = LF(stg_w);
     const float um = (float)um_d, s0f = (float)static_speed, vlen = (float)veh_len, dtf = (float)dt;
     const float *act = action + (size_t)rep * n_action;
@@ -472,33 +471,24 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 const int nv = lane_n[k];
                 Tv hd_p = tv_var(hdpv[k], hdpi[k]);
                 Tv hd_v = tv_var(hdvv[k], hdvi[k]);
+                // tail -> head, in place: a follower reads its leader before the leader moves.  One record per vehicle: the
+                // step rewrites the vehicle's own slots (p, v) from (p, v, leader p, leader v) with dEgo = [[1, dt], [e2, e3]],
+                // dLeading = [[0, 0], [l2, l3]] (didm.py:38-103); payload = (e2, e3, l2, l3)
                 for (int i = 0; i < nv; ++i) {
                     const int vi = lane_veh[k * kLaneCap + i];
-                    Tv p_ = tv_var(vp[vi], vidp[vi]);
-                    Tv v_ = tv_var(vv[vi], vidv[vi]);
+                    const float p_ = vp[vi], v_ = vv[vi];
                     IdmStep o;
-                    Tv np_, nv_;
                     if (i == nv - 1) {
-                        idm_step_ieee((double)p_.val, (double)v_.val, (double)hd_p.val, (double)hd_v.val, idm, dt, o);
-                        np_ = tv_node4(rec, o.np, p_, o.dE[0] + o.dLd[0], v_, o.dE[1] + o.dLd[1], hd_p, o.dLd[0], hd_v, -o.dLd[1]);
-                        nv_ = tv_node4(rec, o.nv, p_, o.dE[2] + o.dLd[2], v_, o.dE[3] + o.dLd[3], hd_p, o.dLd[2], hd_v, -o.dLd[3]);
+                        idm_step_ieee((double)p_, (double)v_, (double)hd_p.val, (double)hd_v.val, idm, dt, o);
+                        rec_push(rec, K_IDM, 3 * vi, make_int4(hd_p.id, hd_v.id, 1, 0), make_float4(o.dE[2], o.dE[3], o.dLd[2], o.dLd[3]));
                     } else {
                         const int vj = lane_veh[k * kLaneCap + i + 1];
-                        Tv pl = tv_var(vp[vj], vidp[vj]);
-                        Tv vl = tv_var(vv[vj], vidv[vj]);
-                        const double dp = fabs((double)pl.val - (double)p_.val) - ((veh_len + veh_len) * 0.5);
-                        const double dv = (double)v_.val - (double)vl.val;
-                        idm_step_ieee((double)p_.val, (double)v_.val, dp, dv, idm, dt, o);
-                        np_ = tv_node4(rec, o.np, p_, o.dE[0], v_, o.dE[1], pl, o.dLd[0], vl, o.dLd[1]);
-                        nv_ = tv_node4(rec, o.nv, p_, o.dE[2], v_, o.dE[3], pl, o.dLd[2], vl, o.dLd[3]);
+                        const double dp = fabs((double)vp[vj] - (double)p_) - ((veh_len + veh_len) * 0.5);
+                        const double dv = (double)v_ - (double)vv[vj];
+                        idm_step_ieee((double)p_, (double)v_, dp, dv, idm, dt, o);
+                        rec_push(rec, K_IDM, 3 * vi, make_int4(3 * vj, 3 * vj + 1, 0, 0), make_float4(o.dE[2], o.dE[3], o.dLd[2], o.dLd[3]));
                     }
-                    if (np_.id < 0) np_ = tv_fresh(rec, o.np);
-                    if (nv_.id < 0) nv_ = tv_fresh(rec, o.nv);
-                    tnp[vi] = np_.val; tnpi[vi] = np_.id; tnv[vi] = nv_.val; tnvi[vi] = nv_.id;
-                }
-                for (int i = 0; i < nv; ++i) {
-                    const int vi = lane_veh[k * kLaneCap + i];
-                    vp[vi] = tnp[vi]; vidp[vi] = tnpi[vi]; vv[vi] = tnv[vi]; vidv[vi] = tnvi[vi];
+                    vp[vi] = o.np; vv[vi] = o.nv;
                 }
             }
             flush(t, 0);
@@ -535,9 +525,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     const int last = caplast[j];
                     Tv lr = tv_leaf(rec, nxt[last]), lu = tv_leaf(rec, nxt[2 * C + last]);
                     rec_push(rec, K_CELLREAD, 0, make_int4(lr.id, lu.id, last, 0), make_float4(0.f, 0.f, 0.f, 0.f));
-                    Tv cp = tv_var(capv[j], capi[j]);
-                    cp = tv_unit(rec, tv_add(rec, cp, tv_mul(rec, tv_mul(rec, lr, lu), tv_c(dtf))));
-                    capv[j] = cp.val; capi[j] = cp.id;
+                    // in place on the capacitor's slot: cap += (r u) dt
+                    const Tv prod = tv_mul(rec, tv_mul(rec, lr, lu), tv_c(dtf));
+                    rec_push(rec, K_NODE, 3 * V + j, make_int4(capi[j], prod.id, -1, -1), make_float4(1.f, prod.sc, 0.f, 0.f));
+                    capv[j] = capv[j] + prod.val; capi[j] = 3 * V + j;
                     capleaf[j] = lu.id;                      // the speed leaf, for a spawn in this step
                 }
             }
@@ -839,7 +830,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     int *rk = reinterpret_cast<int *>(lds + lo.rk), *ri = reinterpret_cast<int *>(lds + lo.ri);
     int *cell_lane_s = reinterpret_cast<int *>(lds + lo.cell_lane);
     int *obi = reinterpret_cast<int *>(lds + lo.obi); float *obf = LF(obf);
-    const float um = (float)um_d, s0f = (float)static_speed, vlen = (float)veh_len;
+    const float um = (float)um_d, s0f = (float)static_speed, vlen = (float)veh_len, dtf = (float)dt;
     const float *act = action + (size_t)rep * n_action;
     const size_t toff = (size_t)rep * tb.net.table_stride;
     const float *hist_r = hist + (size_t)rep * (T + 1) * 4 * C;
@@ -1036,6 +1027,18 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
 #pragma unroll
                         for (int q = 0; q < 4; ++q) if (in[q] >= 0) adj[in[q]] += a * w[q];
                     }
+                } else if (kind == K_IDM) {
+                    const float gp = adj[out], gv = adj[out + 1];          // cotangents of the new (p, v)
+                    float op = gp + w[0] * gv, ov = dtf * gp + w[1] * gv;   // dEgo^T
+                    if (in[2]) {                                            // head: leader = (p + head_dp, v - head_dv)
+                        op += w[2] * gv; ov += w[3] * gv;
+                        if (in[0] >= 0) adj[in[0]] += w[2] * gv;
+                        if (in[1] >= 0) adj[in[1]] -= w[3] * gv;
+                    } else {
+                        adj[in[0]] += w[2] * gv;
+                        adj[in[1]] += w[3] * gv;
+                    }
+                    adj[out] = op; adj[out + 1] = ov;
                 } else if (kind == K_COMMIT) {
                     if (in[0] >= 0) adj[in[0]] += adj[out];
                     adj[out] = 0.f;
