@@ -143,6 +143,63 @@ __device__ __forceinline__ Tv tv_soft(Rec &R, Tv a, float k) {
 }
 __device__ __forceinline__ Tv tv_pos_or_zero(Tv a) { return a.val > 0.f ? a : tv_c(0.f); }
 
+// ---- forward-mode duals for the head gap: a value and its gradient w.r.t. the (at most) seven variables it can depend on
+// -- the head vehicle's (p, v), the leader's (p, v) and the signals of the previous / current / next lane of the route.  The
+// ~25 float32 operations of ItscpRoadNetwork.setup_micro_boundary (_simulator.py:176-262) then leave two linear records per
+// output (head_position_delta, head_speed_delta) instead of one record each.
+constexpr int kDu = 7;
+struct Du { float v; float g[kDu]; };
+__device__ __forceinline__ Du du_c(float v) { Du x; x.v = v;
+#pragma unroll
+    for (int i = 0; i < kDu; ++i) x.g[i] = 0.f;
+    return x; }
+__device__ __forceinline__ Du du_var(float v, int i) { Du x = du_c(v); x.g[i] = 1.f; return x; }
+__device__ __forceinline__ Du du_add(Du a, Du b) { Du x; x.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < kDu; ++i) x.g[i] = a.g[i] + b.g[i];
+    return x; }
+__device__ __forceinline__ Du du_sub(Du a, Du b) { Du x; x.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < kDu; ++i) x.g[i] = a.g[i] - b.g[i];
+    return x; }
+__device__ __forceinline__ Du du_mul(Du a, Du b) { Du x; x.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < kDu; ++i) x.g[i] = a.g[i] * b.v + b.g[i] * a.v;
+    return x; }
+__device__ __forceinline__ Du du_div(Du a, Du b) { Du x; x.v = a.v / b.v;
+    const float ia = 1.f / b.v, ib = -((a.v / b.v) / b.v);
+#pragma unroll
+    for (int i = 0; i < kDu; ++i) x.g[i] = a.g[i] * ia + b.g[i] * ib;
+    return x; }
+__device__ __forceinline__ Du du_soft(Du a, float k) {          // dmath.operation.sigmoid(value, constant=k)
+    const float z = a.v * k;
+    const float zc = fminf(fmaxf(z, -16.f), 16.f);
+    const float sgm = 1.f / (1.f + expf(-zc));
+    const float grad = (z < -16.f || z > 16.f) ? 0.f : sgm * (1.f - sgm) * k;
+    Du x; x.v = sgm;
+#pragma unroll
+    for (int i = 0; i < kDu; ++i) x.g[i] = a.g[i] * grad;
+    return x; }
+__device__ __forceinline__ Du du_pos_or_zero(Du a) { return a.v > 0.f ? a : du_c(0.f); }   // x if x > 0 else 0.0
+// out = sum_i g[i] * x_(id[i]) as records: one node for the vehicle inputs, one for the signals (+ the first node)
+__device__ __forceinline__ Tv du_emit(Rec &R, Du a, const int *id) {
+    bool lo = false, hi = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lo = lo || (id[i] >= 0 && a.g[i] != 0.f);
+#pragma unroll
+    for (int i = 4; i < kDu; ++i) hi = hi || (id[i] >= 0 && a.g[i] != 0.f);
+    if (!lo && !hi) return tv_c(a.v);
+    int first = -1;
+    if (lo) {
+        first = R.next_local++;
+        rec_push(R, K_NODE, first, make_int4(id[0], id[1], id[2], id[3]), make_float4(a.g[0], a.g[1], a.g[2], a.g[3]));
+        if (!hi) return tv_var(a.v, first);
+    }
+    const int out = R.next_local++;
+    rec_push(R, K_NODE, out, make_int4(first, id[4], id[5], id[6]), make_float4(1.f, a.g[4], a.g[5], a.g[6]));
+    return tv_var(a.v, out);
+}
+
 // sample `idx - kWindow` of the loss' running-mean stream (written hundreds of steps earlier by another thread of this
 // workgroup: read around the vector L1)
 __device__ __forceinline__ float stream_load(const float *p) {
@@ -402,17 +459,20 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 const int k = mw;
                 const bool act = k < n_micro && lane_n[k < n_micro ? k : 0] > 0;
                 if (k < n_micro) { hdpv[k] = 1000.f; hdvv[k] = 0.f; hdpi[k] = -1; hdvi[k] = -1; }
-                Tv fin = tv_c(0.f), green_dp = tv_c(1000.f), green_dv = tv_c(0.f), red_dp = tv_c(0.f);
+                Du fin = du_c(0.f), green_dp = du_c(1000.f), green_dv = du_c(0.f), red_dp = du_c(0.f);
+                int ids[kDu];
+#pragma unroll
+                for (int q = 0; q < kDu; ++q) ids[q] = -1;
                 if (act) {
                     const int nv = lane_n[k];
                     const int l = mlane[k];
                     const int hv = lane_veh[k * kLaneCap + nv - 1];
                     const int *route = vroute + hv * kRouteStride;
                     const int rlen = vrlen[hv], cursor = vcur[hv];
-                    Tv hp = tv_var(vp[hv], vidp[hv]);
-                    Tv hs = tv_var(vv[hv], vidv[hv]);
-                    const Tv Lc = tv_c(lanelen[l]), half = tv_c(vlen * 0.5f);
-                    Tv reach = tv_sub(rec, tv_sub(rec, Lc, hp), half);
+                    ids[0] = vidp[hv]; ids[1] = vidv[hv];
+                    const Du hp = du_var(vp[hv], 0), hs = du_var(vv[hv], 1);
+                    const Du Lc = du_c(lanelen[l]), half = du_c(vlen * 0.5f);
+                    Du reach = du_sub(du_sub(Lc, hp), half);
                     for (int j = cursor; j < rlen - 1; ++j) {
                         const int there = route[j + 1];
                         const int ms = mslot[there];
@@ -420,49 +480,53 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                         if (lane_n[ms]) {
                             // the leader is another lane's tail vehicle: imported through two temporaries
                             const int lv = lane_veh[ms * kLaneCap + 0];
-                            Tv lp = tv_leaf(rec, vp[lv]), lsp = tv_leaf(rec, vv[lv]);
-                            rec_push(rec, K_IMPORT, 0, make_int4(lp.id, lsp.id, vidp[lv], vidv[lv]), make_float4(0.f, 0.f, 0.f, 0.f));
-                            green_dp = tv_pos_or_zero(tv_add(rec, reach, tv_sub(rec, lp, half)));
-                            green_dv = tv_sub(rec, hs, lsp);
+                            const Tv lp_ = tv_leaf(rec, vp[lv]), lsp_ = tv_leaf(rec, vv[lv]);
+                            rec_push(rec, K_IMPORT, 0, make_int4(lp_.id, lsp_.id, vidp[lv], vidv[lv]), make_float4(0.f, 0.f, 0.f, 0.f));
+                            ids[2] = lp_.id; ids[3] = lsp_.id;
+                            green_dp = du_pos_or_zero(du_add(reach, du_sub(du_var(lp_.val, 2), half)));
+                            green_dv = du_sub(hs, du_var(lsp_.val, 3));
                             break;
                         }
-                        reach = tv_add(rec, reach, tv_c(lanelen[there]));
+                        reach = du_add(reach, du_c(lanelen[there]));
                     }
-                    red_dp = tv_pos_or_zero(tv_sub(rec, tv_sub(rec, Lc, hp), half));
+                    red_dp = du_pos_or_zero(du_sub(du_sub(Lc, hp), half));
                     const bool prev_exist = cursor > 0, next_exist = cursor < rlen - 1;
-                    Tv prev_s = tv_c(0.f), next_s = tv_c(0.f);
-                    if (prev_exist) prev_s = tv_soft(rec, tv_sub(rec, tv_c(0.f), hp), 16.f);
-                    Tv curr_s = tv_mul(rec, tv_soft(rec, hp, 16.f), tv_soft(rec, tv_sub(rec, Lc, hp), 16.f));
-                    if (next_exist) next_s = tv_soft(rec, tv_sub(rec, hp, Lc), 16.f);
-                    Tv total = tv_add(rec, tv_add(rec, prev_s, curr_s), next_s);
+                    Du prev_s = du_c(0.f), next_s = du_c(0.f);
+                    if (prev_exist) prev_s = du_soft(du_sub(du_c(0.f), hp), 16.f);
+                    const Du curr_s = du_mul(du_soft(hp, 16.f), du_soft(du_sub(Lc, hp), 16.f));
+                    if (next_exist) next_s = du_soft(du_sub(hp, Lc), 16.f);
+                    const Du total = du_add(du_add(prev_s, curr_s), next_s);
+#pragma unroll
                     for (int w = 0; w < 3; ++w) {
                         if ((w == 0 && !prev_exist) || (w == 2 && !next_exist)) continue;
                         const int lid = route[cursor + w - 1];
-                        const Tv sc = w == 0 ? prev_s : (w == 1 ? curr_s : next_s);
-                        Tv sv = tv_c(1.f);
+                        const Du sc = w == 0 ? prev_s : (w == 1 ? curr_s : next_s);
+                        Du sv = du_c(1.f);
                         const int kd = linfo[lid] & 3;
                         if (kd != 0) {
                             const int it = linfo[lid] >> 2;
-                            sv = tv_leaf(rec, sig[2 * it + (kd - 1)]);
-                            rec_push(rec, K_SIGNAL, 0, make_int4(sv.id, it, kd, 0), make_float4(0.f, 0.f, 0.f, 0.f));
+                            const Tv leaf = tv_leaf(rec, sig[2 * it + (kd - 1)]);
+                            rec_push(rec, K_SIGNAL, 0, make_int4(leaf.id, it, kd, 0), make_float4(0.f, 0.f, 0.f, 0.f));
+                            ids[4 + w] = leaf.id;
+                            sv = du_var(leaf.val, 4 + w);
                         }
-                        fin = tv_add(rec, fin, tv_mul(rec, tv_div(rec, sc, total), sv));
+                        fin = du_add(fin, du_mul(du_div(sc, total), sv));
                     }
                 }
                 // signal_rms: running mean over the occupied lanes in lane order (_simulator.py:249-256)
-                double ssum = act ? (double)fin.val : 0.; int scnt = act ? 1 : 0;
+                double ssum = act ? (double)fin.v : 0.; int scnt = act ? 1 : 0;
                 for (int d = 1; d < 64; d <<= 1) {
                     const double us = __shfl_up(ssum, d, 64); const int uc = __shfl_up(scnt, d, 64);
                     if (mw >= d) { ssum += us; scnt += uc; }
                 }
                 if (act) {
                     const float k2 = 32.f / fabsf((float)((sig_sum + ssum) / (double)(sig_cnt + scnt)));
-                    Tv fs = tv_soft(rec, tv_sub(rec, fin, tv_c(0.5f)), k2);
-                    Tv one_m = tv_sub(rec, tv_c(1.f), fs);
-                    Tv dp_ = tv_add(rec, tv_mul(rec, green_dp, fs), tv_mul(rec, red_dp, one_m));
-                    Tv dv_ = tv_add(rec, tv_mul(rec, green_dv, fs), tv_mul(rec, tv_c(0.f), one_m));
-                    dp_ = tv_unit(rec, dp_); dv_ = tv_unit(rec, dv_);
-                hdpv[k] = dp_.val; hdpi[k] = dp_.id; hdvv[k] = dv_.val; hdvi[k] = dv_.id;
+                    const Du fs = du_soft(du_sub(fin, du_c(0.5f)), k2);
+                    const Du one_m = du_sub(du_c(1.f), fs);
+                    const Du dp_d = du_add(du_mul(green_dp, fs), du_mul(red_dp, one_m));
+                    const Du dv_d = du_add(du_mul(green_dv, fs), du_mul(du_c(0.f), one_m));
+                    const Tv dp_ = du_emit(rec, dp_d, ids), dv_ = du_emit(rec, dv_d, ids);
+                    hdpv[k] = dp_.val; hdpi[k] = dp_.id; hdvv[k] = dv_.val; hdvi[k] = dv_.id;
                 }
                 sig_sum += __shfl(ssum, 63, 64); sig_cnt += __shfl(scnt, 63, 64);
             }
