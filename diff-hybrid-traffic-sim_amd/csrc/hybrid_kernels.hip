@@ -781,19 +781,30 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                             pa += incl[c]; pb += incl[C + c];
                         }
                         long long n = run_cnt + cb + vcp[k];
-                        Tv qlen = tv_c(0.f);
+                        // q = sum_i sigmoid(k_i (s0 - v_i)); term = q^2 dt; d reward / d v_i = -2 dt q * (-sigmoid'_i): one SEED
+                        // record per vehicle, directly on its speed
+                        float q = 0.f, dsg[kLaneCap];
                         for (int i = 0; i < nv; ++i) {
                             const int vi = lane_veh[k * kLaneCap + i];
-                            Tv v_ = tv_var(vv[vi], vidv[vi]);
-                            Tv xs_ = tv_sub(rec, tv_c(s0f), v_);
-                            pa += (double)xs_.val; pb += (double)vxold[vi]; ++n;
+                            const float x = s0f - vv[vi];
+                            pa += (double)x; pb += (double)vxold[vi]; ++n;
                             const double mean = n > kWindow ? (pa - pb) / (double)kWindow : pa / (double)n;
                             const float kk = 16.f / fabsf((float)mean);
-                            qlen = tv_add(rec, qlen, tv_soft(rec, xs_, kk));
+                            const float z = x * kk;
+                            const float zc = fminf(fmaxf(z, -16.f), 16.f);
+                            const float sgm = 1.f / (1.f + expf(-zc));
+                            dsg[i] = (z < -16.f || z > 16.f) ? 0.f : sgm * (1.f - sgm) * kk;
+                            q = q + sgm;
                         }
-                        qmicro[k] = (qlen.val * qlen.val) * dtf;
-                        if (qlen.id >= 0 && t < loss_steps)
-                            rec_push(rec, K_SEED, 0, make_int4(qlen.id, 0, 0, 0), make_float4(-1.0f * dtf * 2.f * qlen.val * qlen.sc, 0.f, 0.f, 0.f));
+                        qmicro[k] = (q * q) * dtf;
+                        if (t < loss_steps) {
+                            const float gq = -1.0f * dtf * 2.f * q;
+                            for (int i = 0; i < nv; ++i) {
+                                const int vi = lane_veh[k * kLaneCap + i];
+                                if (vidv[vi] >= 0 && dsg[i] != 0.f)
+                                    rec_push(rec, K_SEED, 0, make_int4(vidv[vi], 0, 0, 0), make_float4(gq * (-dsg[i]), 0.f, 0.f, 0.f));
+                            }
+                        }
                     }
                 }
                 // commit temporaries into the persistent slots (vehicles by their lane, capacitors by theirs)
