@@ -178,3 +178,45 @@ def test_hybrid_600_steps_random_actions_vs_oracle(cuda, golden_dir, oracle):
         assert abs(float(Rw[k]) - o["reward"]) <= 1e-5 * abs(o["reward"]), k
         worst = max(worst, np.abs(G[k] - o["g_action"]).max() / np.abs(o["g_action"]).max())
     assert worst <= 2e-3, worst
+
+
+def test_larger_network_vs_oracle(cuda, oracle):
+    """A network the goldens do not cover (3 x 3 intersections, 15 m lanes: more cells than fit a 512-thread workgroup, so
+    the 1024-thread build of the kernels runs), tables straight from the environment classes, against the CPU restatement."""
+    import torch
+    from dhts import ops
+    from dhts.network import HybridNetworkTables, group_routes
+    from example.control.itscp._env import ItscpEnv
+    from example.control.itscp.problem import problem_2
+    np.random.seed(123)
+    env = ItscpEnv()
+    env.schedule_callback = problem_2
+    for k, v in dict(num_intersection=3, lane_length=15.0, num_lane=1, policy_length=12, signal_length=3, mode="hybrid",
+                     speed_limit=60.0).items():
+        env.config[k] = v
+    env.reset()
+    tab = HybridNetworkTables.from_env(env)
+    assert tab.n_cells + tab.n_lanes > 448                       # beyond the 512-thread variant
+    routes = []
+    for l in range(tab.n_lanes):
+        if tab.lane_macro[l] == 0 and any(tab.lane_macro[a] for a in tab.prev_lanes[l]):
+            for _ in range(8):
+                r = list(env.simulator.create_random_route(l).route)[:32]
+                routes.append(r + [-1] * (32 - len(r)))
+    routes = np.array(routes, dtype=np.int32)
+    args = (9, env.config["signal_length"] * env.config["simulation_frequency"], 1.0 / env.config["simulation_frequency"], 60.0, 0.2, 5.0)
+    rng = np.random.default_rng(8)
+    acts = rng.uniform(0.1, 0.9, (3, env.action_size())).astype(np.float32)
+    a = torch.tensor(acts, device=cuda, requires_grad=True)
+    cut, reward, queue, counts = ops.net_hybrid_rollout(a, ops.DeviceHybridTables(tab, routes, cuda), *args)
+    cut.sum().backward()
+    gr, ptr = group_routes(routes, tab.n_lanes)
+    spawned = 0
+    for k in range(len(acts)):
+        o = oracle.net_hybrid(tab, gr, ptr, acts[k], *args)
+        assert o["rc"] == 0 and (int(counts[k, 0]), int(counts[k, 1])) == (o["n_spawned"], o["n_deposits"]), k
+        assert rel_max(queue[k].cpu().numpy(), o["queue"]) <= 1e-4, k
+        assert abs(float(reward[k]) - o["reward"]) <= 1e-5 * abs(o["reward"]), k
+        assert np.abs(a.grad[k].cpu().numpy() - o["g_action"]).max() <= 2e-3 * np.abs(o["g_action"]).max(), k
+        spawned += o["n_spawned"]
+    assert spawned > 0
