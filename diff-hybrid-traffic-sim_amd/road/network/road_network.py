@@ -5,9 +5,7 @@ lane's step, every lane's commit, then the hand-offs in lane-id order.  Each lan
 operator; the batched / time-fused API for many independent lanes is dhts.macro_rollout / dhts.micro_rollout.
 """
 import numpy as np
-import torch as th
 
-from dmath.operation import sigmoid
 from road.lane._macro_lane import MacroLane
 from road.lane._micro_lane import DEFAULT_HEAD_POSITION_DELTA, DEFAULT_HEAD_SPEED_DELTA, MicroLane
 from road.network.conversion import Conversion

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from test_oracle_golden import itscp_hybrid_tables
-from util import TOL_GRAD, TOL_STATE, meta_of, rel_max
+from util import TOL_GRAD, TOL_STATE, rel_max
 
 pytestmark = pytest.mark.gpu
 

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 def build_env(g, m):
     from example.control.itscp._env import ItscpEnv
     from example.control.itscp.problem import problem_1
-    from road.network.route import MacroRoute, MicroRoute
+    from road.network.route import MicroRoute
     env = ItscpEnv()
     env.schedule_callback = problem_1
     for k, v in dict(num_intersection=m["num_intersection"], lane_length=m["lane_length"], num_lane=m["num_lane"],
