@@ -11,8 +11,8 @@
 // and flux capacitor j; only the hand-off events themselves (spawn, lane change, despawn, deposit: rare, order-dependent)
 // are walked serially by lane 0.  All micro state lives in LDS.  Every float32 operation of the micro side is written,
 // with its partial derivatives, to a per-replica record stream in HBM: each lane stages its records in LDS and the wave
-// flushes them three times per step (head gaps + IDM steps | capacitors + events | loss + commits; lane-ordered, coalesced),
-// noting the per-lane counts of every segment in an index.  The reverse kernel loads a
+// flushes them once per step (lane-ordered, coalesced; a lane's block = its segments head gaps + IDM steps | capacitors +
+// events | loss + commits), noting the per-lane counts of every segment in an index.  The reverse kernel loads a
 // step's records back into LDS and lets every lane replay its own segments backwards (the same thing torch autograd does
 // for the reference) in step with the hand-written macro adjoint; the two sides meet at the hand-off records (capacitor
 // reads, deposits) and at the signals.  Contributions that cross lanes (the leader of a head vehicle sits on another lane;
@@ -356,12 +356,18 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     if (is_mt) for (int j = 0; j < kMaxCaps; ++j) { capv[j] = 0.f; capi[j] = -1; }
     __syncthreads();
     // flush the staged records of all lanes to HBM in lane order, note the per-lane counts (micro wave, convergent)
-    auto flush = [&](int t, int phase) {
+    // end of a step: all lanes' staged records go to HBM in lane order (coalesced), each lane's block holding its three
+    // segments (head gaps + IDM | capacitors + events | loss + commits) back to back; the per-lane segment counts go to
+    // the index (micro wave, convergent)
+    int seg_a = 0, seg_b = 0;                        // this lane's staged records at the end of the first / second segment
+    auto flush = [&](int t) {
         const int c = (mw < NS) ? rec.cnt : 0;
         int inc = c;
         for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d, 64); if (mw >= d) inc += up; }
         const int total = __shfl(inc, 63, 64), exc = inc - c;
-        seg_cnt[((size_t)t * kPhases + phase) * 64 + mw] = (unsigned short)c;
+        seg_cnt[((size_t)t * kPhases + 0) * 64 + mw] = (unsigned short)(mw < NS ? seg_a : 0);
+        seg_cnt[((size_t)t * kPhases + 1) * 64 + mw] = (unsigned short)(mw < NS ? seg_b - seg_a : 0);
+        seg_cnt[((size_t)t * kPhases + 2) * 64 + mw] = (unsigned short)(mw < NS ? c - seg_b : 0);
         if (rec_n + total > ws.rec_cap) cap_fault = true;
         else if (total > 0) {
             unsigned long long mask = __ballot(c > 0);
@@ -555,7 +561,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     vp[vi] = o.np; vv[vi] = o.nv;
                 }
             }
-            flush(t, 0);
+            seg_a = rec.cnt;
         }
         lds_barrier();
         // ================= P3: cell updates + tape | next step's signals =================
@@ -701,7 +707,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 if (rec.next_local - (base_local + 64 * kLaneLocals) > kEventLocals) cap_fault = true;
                 rec.next_local = keep_local;
             }
-            flush(t, 1);
+            seg_b = rec.cnt;
             // vehicle samples of the loss' running mean: exclusive prefixes over the micro lanes in id order
             {
                 const int k = mw;
@@ -820,7 +826,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     if (capi[j] != 3 * V + j && capi[j] >= 0) { rec_push(rec, K_COMMIT, 3 * V + j, make_int4(capi[j], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); capi[j] = 3 * V + j; }
                 }
                 if (rec.next_local - (base_local + mw * kLaneLocals) > kLaneLocals) cap_fault = true;
-                flush(t, 2);
+                flush(t);
                 if (rec_n - step_start > kMaxStepRecords) cap_fault = true;
             }
             run_in += tot_a + vsp[n_micro]; run_out += tot_b + vep[n_micro]; run_cnt += C + vcp[n_micro];
@@ -1062,14 +1068,13 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
                     *reinterpret_cast<float4 *>(rw + 4 * k) = grw[r_lo + k];
                 }
             }
-            int base = 0;
-#pragma unroll
-            for (int ph = 0; ph < kPhases; ++ph) {
-                const int c = p_seg[ph];
+            {   // a lane's block = its three segments back to back; blocks follow each other in lane order
+                const int c = p_seg[0] + p_seg[1] + p_seg[2];
                 int inc = c;
                 for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d, 64); if (mw_lane >= d) inc += up; }
-                seg_lo[ph] = base + inc - c; seg_n[ph] = over ? 0 : c;
-                base += __shfl(inc, 63, 64);
+                int lo_ = inc - c;
+#pragma unroll
+                for (int ph = 0; ph < kPhases; ++ph) { seg_lo[ph] = lo_; seg_n[ph] = over ? 0 : p_seg[ph]; lo_ += p_seg[ph]; }
             }
         }
         fetch(t - 1);
