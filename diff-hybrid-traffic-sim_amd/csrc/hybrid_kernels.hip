@@ -41,7 +41,8 @@ constexpr int kLaneLocals = 192;     // temporaries per lane of the micro wave a
 constexpr int kEventLocals = 64;     // temporaries of the serial event walk per step
 constexpr int kMaxLocals = 64 * kLaneLocals + kEventLocals;
 constexpr int kStage = 96;           // staged records per lane and flush
-constexpr int kPhases = 3;           // record segments per step: head gaps + IDM | capacitors + events | loss + commits
+constexpr int kPhases = 3;           // record segments per block: head gaps + previous step's loss seeds + IDM |
+                                     // capacitors + events + commits | (spare)
 constexpr int kMaxStepRecords = 1024;
 constexpr int kWindow = 100000;      // RunningMean(100_000), _env.py:122
 
@@ -69,8 +70,8 @@ __host__ __device__ inline HybWs hyb_ws(int L, int C, int T, int n_routes, int r
     w.rec_k = o; o += up16(sizeof(int) * (size_t)w.rec_cap);
     w.rec_i = o; o += up16(sizeof(int4) * (size_t)w.rec_cap);
     w.rec_w = o; o += up16(sizeof(float4) * (size_t)w.rec_cap);
-    w.step_off = o; o += up16(sizeof(int) * (size_t)(T + 1));
-    w.seg_cnt = o; o += up16(sizeof(unsigned short) * (size_t)T * kPhases * 64);
+    w.step_off = o; o += up16(sizeof(int) * (size_t)(T + 2));                               // blocks 0..T (+ end)
+    w.seg_cnt = o; o += up16(sizeof(unsigned short) * (size_t)(T + 1) * kPhases * 64);
     w.xs = o; o += up16(sizeof(float) * (size_t)T * (size_t)(C + kMaxVeh));
     w.per_replica = o;
     return w;
@@ -403,10 +404,116 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     };
     fetch(0);
 
+    // ---- the loss of the state produced by step t-1 is evaluated inside the phases of step t (its prefix scan beside the
+    //      ghosts, its constants and the vehicles' terms beside the interface solves, its lane sums beside the cell updates);
+    //      the records of step t-1 are flushed beside the ghosts of step t
+    float x_new = 0.f;
+    auto loss_scan = [&](const float *st) {
+        {
+            double a = 0., b = 0.;
+            if (is_cell) {
+                x_new = s0f - st[2 * C + tid];
+                const long long idx = run_cnt + tid + vcp[c_mb];
+                a = (double)x_new;
+                if (idx >= kWindow) b = (double)stream_load(xs + (idx - kWindow));
+                xs[idx] = x_new;
+            }
+            double ia = a, ib = b;
+            for (int d = 1; d < 64; d <<= 1) {
+                const double ua = __shfl_up(ia, d, 64), ub = __shfl_up(ib, d, 64);
+                if ((tid & 63) >= d) { ia += ua; ib += ub; }
+            }
+            if (is_cell) { incl[tid] = ia; incl[C + tid] = ib; }
+            if ((tid & 63) == 63) { scanw[tid >> 6] = ia; scanw[16 + (tid >> 6)] = ib; }
+        }
+    };
+    double tot_a = 0., tot_b = 0.;
+    auto loss_consts = [&](const float *st, int ls) {
+        const int nwc = (C + 63) >> 6;
+        tot_a = 0.; tot_b = 0.;
+        for (int w = 0; w < nwc; ++w) { tot_a += scanw[w]; tot_b += scanw[16 + w]; }
+        if (is_cell) {
+                const int wv = tid >> 6;
+                double base_a = 0., base_b = 0.;
+                for (int w = 0; w < wv; ++w) { base_a += scanw[w]; base_b += scanw[16 + w]; }
+                const long long n = run_cnt + tid + vcp[c_mb] + 1;
+                const double pin = run_in + base_a + incl[tid] + vsp[c_mb];
+                const double pout = run_out + base_b + incl[C + tid] + vep[c_mb];
+                const double mean = n > kWindow ? (pin - pout) / (double)kWindow : pin / (double)n;
+                const float kk = 16.f / fabsf((float)mean);
+                kc_r[(size_t)ls * C + tid] = kk;
+                contrib[tid] = soft_switch(x_new, kk) * (st[tid] * c_dxv);
+                float *hn = hist_r + (size_t)(ls + 1) * 4 * C;
+                hn[tid] = st[tid]; hn[C + tid] = st[C + tid]; hn[2 * C + tid] = st[2 * C + tid]; hn[3 * C + tid] = st[3 * C + tid];
+            }
+    };
+    auto micro_loss = [&](int ls) {                  // micro wave: the vehicles' terms of the same loss
+        if (in_mw) {
+            const int k = mw;
+            if (k < n_micro) {
+                qmicro[k] = 0.f;
+                const int nv = lane_n[k];
+                if (nv > 0) {
+                    const int cb = cbefore[k];
+                    double pa = run_in + vsp[k], pb = run_out + vep[k];
+                    if (cb > 0) {
+                        const int c = cb - 1;
+                        for (int w = 0; w < (c >> 6); ++w) { pa += scanw[w]; pb += scanw[16 + w]; }
+                        pa += incl[c]; pb += incl[C + c];
+                    }
+                    long long n = run_cnt + cb + vcp[k];
+                    // q = sum_i sigmoid(k_i (s0 - v_i)); term = q^2 dt; d reward / d v_i = -2 dt q * (-sigmoid'_i): one SEED
+                    // record per vehicle, directly on its speed
+                    float q = 0.f, dsg[kLaneCap];
+                    for (int i = 0; i < nv; ++i) {
+                        const int vi = lane_veh[k * kLaneCap + i];
+                        const float x = s0f - vv[vi];
+                        pa += (double)x; pb += (double)vxold[vi]; ++n;
+                        const double mean = n > kWindow ? (pa - pb) / (double)kWindow : pa / (double)n;
+                        const float kk = 16.f / fabsf((float)mean);
+                        const float z = x * kk;
+                        const float zc = fminf(fmaxf(z, -16.f), 16.f);
+                        const float sgm = 1.f / (1.f + expf(-zc));
+                        dsg[i] = (z < -16.f || z > 16.f) ? 0.f : sgm * (1.f - sgm) * kk;
+                        q = q + sgm;
+                    }
+                    qmicro[k] = (q * q) * dtf;
+                    if (ls < loss_steps) {
+                        const float gq = -1.0f * dtf * 2.f * q;
+                        for (int i = 0; i < nv; ++i) {
+                            const int vi = lane_veh[k * kLaneCap + i];
+                            if (vidv[vi] >= 0 && dsg[i] != 0.f)
+                                rec_push(rec, K_SEED, 0, make_int4(vidv[vi], 0, 0, 0), make_float4(gq * (-dsg[i]), 0.f, 0.f, 0.f));
+                        }
+                    }
+                }
+            }
+        }
+    };
+    auto run_update = [&]() { run_in += tot_a + vsp[n_micro]; run_out += tot_b + vep[n_micro]; run_cnt += C + vcp[n_micro]; };
+    auto loss_lanes = [&](int ls) {
+        if (is_lane) {
+            float term;
+            if (l_macro) {
+                float q = 0.f;
+                for (int i = 0; i < l_n; ++i) q = q + contrib[l_off + i];
+                term = (q * q) * dtf;
+            } else term = l_ms >= 0 ? qmicro[l_ms] : 0.f;
+            queue_r[(size_t)ls * L + tid] = term;
+            lane_total = lane_total + (-1.0f) * term;
+        }
+    };
+    auto end_block = [&](int blk) {                  // micro wave: the staged records of step `blk` go to HBM
+        if (is_mt) step_off[blk] = rec_n;
+        step_start = rec_n;
+        flush(blk);
+        if (rec_n - step_start > kMaxStepRecords) cap_fault = true;
+    };
+
     for (int t = 0; t < T; ++t) {
         const float *cur = (t & 1) ? S1 : S0;
         float *nxt = (t & 1) ? S0 : S1;
-        // ================= P1: boundaries =================
+        // ================= A: ghosts | loss scan of the state after step t-1 | record flush of step t-1, head gaps =========
         const int src = p_src, gate = p_gate; const double sched = p_sched;
         if (is_lane) cnext[tid] = p_cnext;
         fetch(t + 1);
@@ -440,27 +547,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             float *g = G + (size_t)tid * 4;
             g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
         }
-        lds_barrier();
-        // ================= P2: interface solves | head gaps and IDM steps of the micro lanes =================
-        if (is_if) {
-            const float *gl = G + (size_t)(2 * i_lane) * 4, *gr_ = G + (size_t)(2 * i_lane + 1) * 4;
-            double rL, yL, uL, qL, rR, yR, uR, qR;
-            if (i_k == 0) { rL = gl[0]; yL = gl[1]; uL = gl[2]; qL = gl[3]; }
-            else { const int c = i_off + i_k - 1; rL = cur[c]; yL = cur[C + c]; uL = cur[2 * C + c]; qL = cur[3 * C + c]; }
-            if (i_k == i_n) { rR = gr_[0]; yR = gr_[1]; uR = gr_[2]; qR = gr_[3]; }
-            else { const int c = i_off + i_k; rR = cur[c]; yR = cur[C + c]; uR = cur[2 * C + c]; qR = cur[3 * C + c]; }
-            Iface f;
-            arz_interface(rL, yL, uL, qL, rR, yR, uR, qR, kconst, f);
-            if (f.cfl_bad && fault_step < 0) { fault_step = t; fault_index = i_k; }
-            Fq[2 * tid] = f.Fr; Fq[2 * tid + 1] = f.Fy;
-            float *ab = AB + (size_t)tid * 8;
-            ab[0] = f.A[0]; ab[1] = f.A[1]; ab[2] = f.A[2]; ab[3] = f.A[3];
-            ab[4] = f.B[0]; ab[5] = f.B[1]; ab[6] = f.B[2]; ab[7] = f.B[3];
-        }
+        if (t > 0) loss_scan(cur);
         if (in_mw) {
+            if (t > 0) end_block(t - 1);
             {   // head gaps of the occupied micro lanes (they only feed the IDM steps below)
-                if (is_mt) step_off[t] = rec_n;
-                step_start = rec_n;
                 rec.next_local = base_local + mw * kLaneLocals;
                 const int k = mw;
                 const bool act = k < n_micro && lane_n[k < n_micro ? k : 0] > 0;
@@ -536,6 +626,27 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 }
                 sig_sum += __shfl(ssum, 63, 64); sig_cnt += __shfl(scnt, 63, 64);
             }
+        }
+        lds_barrier();
+        // ================= B: interface solves | loss constants + history row | vehicles' loss terms, IDM steps =================
+        if (is_if) {
+            const float *gl = G + (size_t)(2 * i_lane) * 4, *gr_ = G + (size_t)(2 * i_lane + 1) * 4;
+            double rL, yL, uL, qL, rR, yR, uR, qR;
+            if (i_k == 0) { rL = gl[0]; yL = gl[1]; uL = gl[2]; qL = gl[3]; }
+            else { const int c = i_off + i_k - 1; rL = cur[c]; yL = cur[C + c]; uL = cur[2 * C + c]; qL = cur[3 * C + c]; }
+            if (i_k == i_n) { rR = gr_[0]; yR = gr_[1]; uR = gr_[2]; qR = gr_[3]; }
+            else { const int c = i_off + i_k; rR = cur[c]; yR = cur[C + c]; uR = cur[2 * C + c]; qR = cur[3 * C + c]; }
+            Iface f;
+            arz_interface(rL, yL, uL, qL, rR, yR, uR, qR, kconst, f);
+            if (f.cfl_bad && fault_step < 0) { fault_step = t; fault_index = i_k; }
+            Fq[2 * tid] = f.Fr; Fq[2 * tid + 1] = f.Fy;
+            float *ab = AB + (size_t)tid * 8;
+            ab[0] = f.A[0]; ab[1] = f.A[1]; ab[2] = f.A[2]; ab[3] = f.A[3];
+            ab[4] = f.B[0]; ab[5] = f.B[1]; ab[6] = f.B[2]; ab[7] = f.B[3];
+        }
+        if (t > 0) loss_consts(cur, t - 1);
+        if (in_mw) {
+            if (t > 0) micro_loss(t - 1);
             const int k = mw;
             if (k < n_micro && lane_n[k] > 0) {
                 const int nv = lane_n[k];
@@ -563,8 +674,9 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             }
             seg_a = rec.cnt;
         }
+        if (t > 0) run_update();
         lds_barrier();
-        // ================= P3: cell updates + tape | next step's signals =================
+        // ================= C: cell updates + tape | lane queue terms of step t-1 | next step's signals =================
         if (is_cell) {
             const int c = tid;
             const float cf = (float)c_cc, ncf = (float)(-c_cc);
@@ -584,8 +696,9 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             tp[c] = d0; tp[Cp + c] = d1; tp[2 * Cp + c] = d2;
         }
         if (tid < sq && t + 1 < T) { float we, ns, a, pr; int ai; phase_signal(act, n_action, sq, F, t + 1, tid, we, ns, a, pr, ai); sig[2 * tid] = we; sig[2 * tid + 1] = ns; }
+        if (t > 0) loss_lanes(t - 1);
         lds_barrier();
-        // ================= P4: flux capacitors (lane j of the micro wave), then the hand-off events in lane-id order =========
+        // ================= D: flux capacitors, hand-off events in lane-id order, commits, vehicle samples (micro wave) =====
         if (in_mw) {
             // capacitors: += r u dt of the last cell (conversion.py:32-36); the spawn itself is an event below
             if (mw < n_caps) {
@@ -707,6 +820,20 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 if (rec.next_local - (base_local + 64 * kLaneLocals) > kEventLocals) cap_fault = true;
                 rec.next_local = keep_local;
             }
+            // commit temporaries into the persistent slots (vehicles by their lane, capacitors by theirs)
+            const int k = mw;
+            if (k < n_micro)
+                for (int i = 0; i < lane_n[k]; ++i) {
+                    const int vi = lane_veh[k * kLaneCap + i];
+                    if (vidp[vi] != 3 * vi) { rec_push(rec, K_COMMIT, 3 * vi, make_int4(vidp[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vidp[vi] = 3 * vi; }
+                    if (vidv[vi] != 3 * vi + 1) { rec_push(rec, K_COMMIT, 3 * vi + 1, make_int4(vidv[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vidv[vi] = 3 * vi + 1; }
+                    if (vida[vi] != 3 * vi + 2) { rec_push(rec, K_COMMIT, 3 * vi + 2, make_int4(vida[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vida[vi] = 3 * vi + 2; }
+                }
+            if (mw < n_caps) {
+                const int j = mw;
+                if (capi[j] != 3 * V + j && capi[j] >= 0) { rec_push(rec, K_COMMIT, 3 * V + j, make_int4(capi[j], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); capi[j] = 3 * V + j; }
+            }
+            if (rec.next_local - (base_local + mw * kLaneLocals) > kLaneLocals) cap_fault = true;
             seg_b = rec.cnt;
             // vehicle samples of the loss' running mean: exclusive prefixes over the micro lanes in id order
             {
@@ -734,120 +861,27 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             }
         }
         lds_barrier();
-        // ================= P5a: ordered scans over the cells (new samples and the ones leaving the window) ==========
-        float x_new = 0.f;
-        {
-            double a = 0., b = 0.;
-            if (is_cell) {
-                x_new = s0f - nxt[2 * C + tid];
-                const long long idx = run_cnt + tid + vcp[c_mb];
-                a = (double)x_new;
-                if (idx >= kWindow) b = (double)stream_load(xs + (idx - kWindow));
-                xs[idx] = x_new;
-            }
-            double ia = a, ib = b;
-            for (int d = 1; d < 64; d <<= 1) {
-                const double ua = __shfl_up(ia, d, 64), ub = __shfl_up(ib, d, 64);
-                if ((tid & 63) >= d) { ia += ua; ib += ub; }
-            }
-            if (is_cell) { incl[tid] = ia; incl[C + tid] = ib; }
-            if ((tid & 63) == 63) { scanw[tid >> 6] = ia; scanw[16 + (tid >> 6)] = ib; }
+    }
+    // loss of the final state, last records
+    if (T > 0) {
+        const float *fin = (T & 1) ? S1 : S0;
+        loss_scan(fin);
+        if (in_mw) end_block(T - 1);
+        __syncthreads();
+        loss_consts(fin, T - 1);
+        if (in_mw) {
+            seg_a = 0; seg_b = 0;
+            micro_loss(T - 1);
+            seg_a = rec.cnt; seg_b = rec.cnt;
+            end_block(T);
         }
-        lds_barrier();
-        // ================= P5b: loss constants, history | vehicle loss terms and commits =================
-        {
-            const int nwc = (C + 63) >> 6;
-            double tot_a = 0., tot_b = 0.;
-            for (int w = 0; w < nwc; ++w) { tot_a += scanw[w]; tot_b += scanw[16 + w]; }
-            if (is_cell) {
-                const int wv = tid >> 6;
-                double base_a = 0., base_b = 0.;
-                for (int w = 0; w < wv; ++w) { base_a += scanw[w]; base_b += scanw[16 + w]; }
-                const long long n = run_cnt + tid + vcp[c_mb] + 1;
-                const double pin = run_in + base_a + incl[tid] + vsp[c_mb];
-                const double pout = run_out + base_b + incl[C + tid] + vep[c_mb];
-                const double mean = n > kWindow ? (pin - pout) / (double)kWindow : pin / (double)n;
-                const float kk = 16.f / fabsf((float)mean);
-                kc_r[(size_t)t * C + tid] = kk;
-                contrib[tid] = soft_switch(x_new, kk) * (nxt[tid] * c_dxv);
-                float *hn = hist_r + (size_t)(t + 1) * 4 * C;
-                hn[tid] = nxt[tid]; hn[C + tid] = nxt[C + tid]; hn[2 * C + tid] = nxt[2 * C + tid]; hn[3 * C + tid] = nxt[3 * C + tid];
-            }
-            if (in_mw) {
-                const int k = mw;
-                if (k < n_micro) {
-                    qmicro[k] = 0.f;
-                    const int nv = lane_n[k];
-                    if (nv > 0) {
-                        const int cb = cbefore[k];
-                        double pa = run_in + vsp[k], pb = run_out + vep[k];
-                        if (cb > 0) {
-                            const int c = cb - 1;
-                            for (int w = 0; w < (c >> 6); ++w) { pa += scanw[w]; pb += scanw[16 + w]; }
-                            pa += incl[c]; pb += incl[C + c];
-                        }
-                        long long n = run_cnt + cb + vcp[k];
-                        // q = sum_i sigmoid(k_i (s0 - v_i)); term = q^2 dt; d reward / d v_i = -2 dt q * (-sigmoid'_i): one SEED
-                        // record per vehicle, directly on its speed
-                        float q = 0.f, dsg[kLaneCap];
-                        for (int i = 0; i < nv; ++i) {
-                            const int vi = lane_veh[k * kLaneCap + i];
-                            const float x = s0f - vv[vi];
-                            pa += (double)x; pb += (double)vxold[vi]; ++n;
-                            const double mean = n > kWindow ? (pa - pb) / (double)kWindow : pa / (double)n;
-                            const float kk = 16.f / fabsf((float)mean);
-                            const float z = x * kk;
-                            const float zc = fminf(fmaxf(z, -16.f), 16.f);
-                            const float sgm = 1.f / (1.f + expf(-zc));
-                            dsg[i] = (z < -16.f || z > 16.f) ? 0.f : sgm * (1.f - sgm) * kk;
-                            q = q + sgm;
-                        }
-                        qmicro[k] = (q * q) * dtf;
-                        if (t < loss_steps) {
-                            const float gq = -1.0f * dtf * 2.f * q;
-                            for (int i = 0; i < nv; ++i) {
-                                const int vi = lane_veh[k * kLaneCap + i];
-                                if (vidv[vi] >= 0 && dsg[i] != 0.f)
-                                    rec_push(rec, K_SEED, 0, make_int4(vidv[vi], 0, 0, 0), make_float4(gq * (-dsg[i]), 0.f, 0.f, 0.f));
-                            }
-                        }
-                    }
-                }
-                // commit temporaries into the persistent slots (vehicles by their lane, capacitors by theirs)
-                if (k < n_micro)
-                    for (int i = 0; i < lane_n[k]; ++i) {
-                        const int vi = lane_veh[k * kLaneCap + i];
-                        if (vidp[vi] != 3 * vi) { rec_push(rec, K_COMMIT, 3 * vi, make_int4(vidp[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vidp[vi] = 3 * vi; }
-                        if (vidv[vi] != 3 * vi + 1) { rec_push(rec, K_COMMIT, 3 * vi + 1, make_int4(vidv[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vidv[vi] = 3 * vi + 1; }
-                        if (vida[vi] != 3 * vi + 2) { rec_push(rec, K_COMMIT, 3 * vi + 2, make_int4(vida[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vida[vi] = 3 * vi + 2; }
-                    }
-                if (mw < n_caps) {
-                    const int j = mw;
-                    if (capi[j] != 3 * V + j && capi[j] >= 0) { rec_push(rec, K_COMMIT, 3 * V + j, make_int4(capi[j], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); capi[j] = 3 * V + j; }
-                }
-                if (rec.next_local - (base_local + mw * kLaneLocals) > kLaneLocals) cap_fault = true;
-                flush(t);
-                if (rec_n - step_start > kMaxStepRecords) cap_fault = true;
-            }
-            run_in += tot_a + vsp[n_micro]; run_out += tot_b + vep[n_micro]; run_cnt += C + vcp[n_micro];
-        }
-        lds_barrier();
-        // ================= P5c: lane queue terms =================
-        if (is_lane) {
-            float term;
-            if (l_macro) {
-                float q = 0.f;
-                for (int i = 0; i < l_n; ++i) q = q + contrib[l_off + i];
-                term = (q * q) * dtf;
-            } else term = l_ms >= 0 ? qmicro[l_ms] : 0.f;
-            queue_r[(size_t)t * L + tid] = term;
-            lane_total = lane_total + (-1.0f) * term;
-        }
-        lds_barrier();
+        run_update();
+        __syncthreads();
+        loss_lanes(T - 1);
     }
     if (in_mw) {
         if (is_mt) {
-            step_off[T] = rec_n;
+            step_off[T + 1] = rec_n;
             counts[4 * rep + 0] = spawned; counts[4 * rep + 1] = deposits; counts[4 * rep + 2] = rec_n; counts[4 * rep + 3] = 0;
         }
         if (rec.over || cap_fault) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, rec_n);
@@ -1035,6 +1069,21 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             }
         }
     };
+    // block T of the record stream holds only the loss seeds of the final state (they belong to the vehicles' speeds after
+    // the last step): every lane of the micro wave applies its own
+    if (T > 0 && in_mw) {
+        const int b_lo = step_off[T], b_n = step_off[T + 1] - b_lo;
+        int c = 0;
+#pragma unroll
+        for (int ph = 0; ph < kPhases; ++ph) c += seg_cnt[((size_t)T * kPhases + ph) * 64 + mw_lane];
+        int inc = c;
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d, 64); if (mw_lane >= d) inc += up; }
+        const int lo_ = inc - c;
+        if (lo_ + c <= b_n)
+            for (int k = lo_; k < lo_ + c; ++k)
+                if ((grk[b_lo + k] >> 24) == K_SEED) { const int4 a = gri[b_lo + k]; const float4 b = grw[b_lo + k]; adj[a.x] += gscale * b.x; }
+    }
+    __syncthreads();
     fetch(T - 1);
     for (int t = T - 1; t >= 0; --t) {
         float *Hc = (t & 1) ? H1 : H0;           // row t
