@@ -902,18 +902,19 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
 // reverse
 // ---------------------------------------------------------------------------------------------------------------------
 struct HybLdsB {
-    size_t red, h0, h1, gl, c0, c2, gq, inl, inf, sg, adj, gam, rk, ri, rw, cell_lane, obi, obf, total;
+    size_t red, h0, h1, gl, c0, c2, gq, inl, inf, sg, adj, gam, rk, ri, rw, cell_lane, obi, obf, aval, iptr, iidx, total;
 };
 __host__ __device__ inline HybLdsB hyb_lds_b(int L, int C, int sq, int V, int E) {
     HybLdsB o; size_t p = 0;
     auto D = [&](size_t n) { size_t r = p; p += 8 * n; return r; };
     auto F = [&](size_t n) { size_t r = p; p += 4 * ((n + 3) & ~(size_t)3); return r; };
-    o.red = D(16 * (size_t)sq);
+    o.red = D(2);
     o.h0 = F(3 * (size_t)C); o.h1 = F(3 * (size_t)C); o.gl = F(3 * (size_t)C); o.c0 = F(2 * (size_t)C); o.c2 = F(2 * (size_t)C);
     o.gq = F(L); o.inl = F(3 * (size_t)E); o.inf = F(3 * (size_t)E); o.sg = F(6 * (size_t)sq);
     o.adj = F(3 * (size_t)V + kMaxCaps + kMaxLocals); o.gam = F(sq);
     o.rk = F(kMaxStepRecords); o.ri = F(4 * (size_t)kMaxStepRecords); o.rw = F(4 * (size_t)kMaxStepRecords);
     o.cell_lane = F(C); o.obi = F(64 * 5); o.obf = F(64 * 5);
+    o.aval = F(2 * (size_t)L); o.iptr = F((size_t)sq + 1); o.iidx = F(2 * (size_t)L);
     o.total = p;
     return o;
 }
@@ -939,12 +940,13 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     const int V = ws.V;
     const HybLdsB lo = hyb_lds_b(L, C, sq, V, E);
 #define LF(name) reinterpret_cast<float *>(lds + lo.name)
-    double *red = reinterpret_cast<double *>(lds + lo.red);
     float *H0 = LF(h0), *H1 = LF(h1), *gL = LF(gl), *c0 = LF(c0), *c2 = LF(c2), *gq = LF(gq), *inL = LF(inl), *inF = LF(inf);
     float *sg = LF(sg), *adj = LF(adj), *gam = LF(gam), *rw = LF(rw);
     int *rk = reinterpret_cast<int *>(lds + lo.rk), *ri = reinterpret_cast<int *>(lds + lo.ri);
     int *cell_lane_s = reinterpret_cast<int *>(lds + lo.cell_lane);
     int *obi = reinterpret_cast<int *>(lds + lo.obi); float *obf = LF(obf);
+    float *aval = LF(aval);
+    int *iptr = reinterpret_cast<int *>(lds + lo.iptr), *iidx = reinterpret_cast<int *>(lds + lo.iidx);
     const float um = (float)um_d, s0f = (float)static_speed, vlen = (float)veh_len, dtf = (float)dt;
     const float *act = action + (size_t)rep * n_action;
     const size_t toff = (size_t)rep * tb.net.table_stride;
@@ -971,6 +973,17 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         for (int i = 0; i < n; ++i) cell_lane_s[off + i] = tid;
     }
     for (int k = tid; k < 3 * E; k += B) { inL[k] = 0.f; inF[k] = 0.f; }
+    for (int k = tid; k < 2 * L; k += B) aval[k] = 0.f;
+    // action cotangent: a ghost's contribution goes to the intersection of its own lane (the gate of an upstream ghost is an
+    // approaching lane of the same intersection), so every intersection sums a fixed list of ghost threads in a fixed order
+    if (tid == 0) {
+        int n = 0;
+        for (int q = 0; q < sq; ++q) {
+            iptr[q] = n;
+            for (int l = 0; l < L; ++l) if (tb.lane_macro[l] && tb.net.inter[l] == q) { iidx[n++] = 2 * l; iidx[n++] = 2 * l + 1; }
+        }
+        iptr[sq] = n;
+    }
     for (int k = tid; k < n_adj; k += B) adj[k] = 0.f;
     if (tid < sq) gam[tid] = 0.f;
     if (is_cell) { gL[tid] = 0.f; gL[C + tid] = 0.f; gL[2 * C + tid] = 0.f; }
@@ -1029,7 +1042,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     }
     float gown_r = 0.f, gown_u = 0.f;    // cotangent of the stored downstream ghost (side-1 ghost thread)
     double ga = 0.; int cur_phase = -1;
-    bool bad = false, over = false;
+    bool bad = false, over = false, bad_key = false;
     if (tid < sq) for (int k = tid; k < n_action; k += sq) g_action[(size_t)rep * n_action + k] = 0.f;
     __syncthreads();
 
@@ -1224,7 +1237,6 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             if (c > c_first) { v_r += c2[c - 1]; v_y += c2[C + c - 1]; }
             if (c < c_last) { v_r += c0[c + 1]; v_y += c0[C + c + 1]; }
         }
-        float my_aval = 0.f; int my_akey = -1;
         if (is_ghost && g_macro) {
             float tgt = -1.f, add_r = 0.f, add_u = 0.f, a_val = 0.f; int a_key = -1;
             if (g_side == 0) {
@@ -1263,7 +1275,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
                 for (int i = 0; i < kMaxCand; ++i)
                     if (cand_src[i] == src) { box[3 * cand_pos[i]] = add_r; box[3 * cand_pos[i] + 1] = 0.f; box[3 * cand_pos[i] + 2] = add_u; }
             }
-            my_aval = a_val; my_akey = a_key;
+            aval[tid] = a_val;
+            if (a_key >= 0 && a_key != g_inter) bad_key = true;
         }
         if (in_mw) {
             if (seg_n[0] > 0) for (int q = 0; q < 5; ++q) obi[mw_lane * 5 + q] = -1;
@@ -1277,11 +1290,6 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
                     for (int q = 2; q < 5; ++q) if (obi[s_ * 5 + q] >= 0) gam[obi[s_ * 5 + q]] += obf[s_ * 5 + q];
                 }
             }
-        }
-        for (int q = 0; q < sq; ++q) {
-            double v = (my_akey == q) ? (double)my_aval : 0.0;
-            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-            if ((tid & 63) == 0) red[(tid >> 6) * sq + q] = v;
         }
         lds_barrier();
         // ================= R5: edge cells take their inboxes; action partials =================
@@ -1301,7 +1309,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         }
         if (tid < sq) {
             double v = 0.;
-            for (int w = 0; w < (int)(B >> 6); ++w) v += red[w * sq + tid];
+            for (int k = iptr[tid]; k < iptr[tid + 1]; ++k) v += (double)aval[iidx[k]];
             v += (double)gam[tid]; gam[tid] = 0.f;
             int phase = t / F; const int lastp = n_action / sq - 1; phase = phase > lastp ? lastp : phase;
             if (phase != cur_phase) { if (cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + tid] = (float)ga; ga = 0.; cur_phase = phase; }
@@ -1311,7 +1319,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     }
     if (tid < sq && cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + tid] = (float)ga;
     if (bad) net_fault(err, DHTS_FAULT_NAN, 0, 0, tid);
-    if (over && is_mt) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, 0);
+    if ((over && is_mt) || bad_key) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, bad_key ? -2 : 0);
 #undef LF
 }
 
