@@ -489,7 +489,8 @@ class NetHybridRollout(torch.autograd.Function):
     loss_steps > 0 restricts the differentiated reward to the first loss_steps steps (second output `reward_cut`)."""
 
     @staticmethod
-    def forward(ctx, action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed, vehicle_length, loss_steps):
+    def forward(ctx, action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed, vehicle_length, loss_steps,
+                check_faults=True):
         a = _f32c(action.detach(), "action")
         R, A = a.shape
         t = dev_tables
@@ -516,7 +517,7 @@ class NetHybridRollout(torch.autograd.Function):
                                               _ptr(reward), _ptr(counts), _ptr(ws), _ptr(err), _stream()),
               "dhts_net_hybrid_rollout_fwd")
         raise_on_fault(err)
-        ctx.d, ctx.tables, ctx.loss_steps = d, t, int(loss_steps)
+        ctx.d, ctx.tables, ctx.loss_steps, ctx.check_faults = d, t, int(loss_steps), bool(check_faults)
         ctx.save_for_backward(a, hist, tape, kc, queue, ws)
         ctx.mark_non_differentiable(reward, queue, counts)
         if loss_steps and loss_steps > 0:
@@ -536,12 +537,16 @@ class NetHybridRollout(torch.autograd.Function):
         check(_lib.lib().dhts_net_hybrid_rollout_bwd(C.byref(d), C.byref(tc), _ptr(a), _ptr(hist), _ptr(tape), _ptr(kc), _ptr(queue),
                                                      _ptr(g_cut.contiguous().float()), _ptr(g_action), _ptr(ws), _ptr(err), _stream()),
               "dhts_net_hybrid_rollout_bwd")
-        raise_on_fault(err)
-        return g_action, None, None, None, None, None, None, None, None
+        if ctx.check_faults:
+            raise_on_fault(err)     # a NaN in the reverse sweep asserts like the reference (dmacro_lane.py:308)
+        return g_action, None, None, None, None, None, None, None, None, None
 
 
 def net_hybrid_rollout(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0,
-                       loss_steps=0):
-    """Returns (reward restricted to the first loss_steps steps [differentiable], full reward, queue [R][T][L], counts [R][4])."""
+                       loss_steps=0, check_faults=True):
+    """Returns (reward restricted to the first loss_steps steps [differentiable], full reward, queue [R][T][L], counts [R][4]).
+    check_faults=False: a non-finite cotangent in the reverse sweep (the reference asserts on it, dmacro_lane.py:308; it
+    happens e.g. when a head gap clamps to exactly 0 and the IDM Jacobian divides by it, didm.py:60-70) is left in the
+    returned gradient of that replica instead of raising, so that a batch survives one bad member."""
     return NetHybridRollout.apply(action, dev_tables, int(n_inter_sq), int(frames_per_phase), float(dt), float(u_max),
-                                  float(static_speed), float(vehicle_length), int(loss_steps))
+                                  float(static_speed), float(vehicle_length), int(loss_steps), bool(check_faults))

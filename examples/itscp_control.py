@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--n_episode", type=int, default=100)
     ap.add_argument("--lr", type=float, default=1e-2)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--n_replica", type=int, default=1,
+                    help="> 1: optimise that many random initial schedules of the same problem at once (one workgroup each in the "
+                         "fused kernels) and report the best")
     args = ap.parse_args()
     assert th.cuda.is_available(), "needs a GPU (no CPU fallback)"
     dev = th.device("cuda")
@@ -45,6 +48,8 @@ def main():
                      speed_limit=args.speed_limit, random_seed=args.seed).items():
         env.config[k] = v
     env.reset()
+    if args.n_replica > 1:
+        return batch(args, env, dev)
     cache = None
     rng = np.random.default_rng(args.seed)
     action = th.tensor(rng.uniform(0.3, 0.7, env.action_size()).astype(np.float32), device=dev, requires_grad=True)
@@ -65,6 +70,38 @@ def main():
             action.clamp_(0.0, 1.0)
         if ep % 10 == 0 or ep == args.n_episode - 1:
             print("episode %4d  reward %.6f  (%.1f ms / episode)" % (ep, float(reward.detach()), 1e3 * (time.time() - t0) / (ep + 1)))
+
+
+def batch(args, env, dev):
+    """Many restarts in one launch: the network tables are shared, every replica owns an action vector."""
+    from dhts import ops
+    from dhts.network import HybridNetworkTables
+    tab = HybridNetworkTables.from_env(env)
+    routes = []
+    for l in range(tab.n_lanes):
+        if tab.lane_macro[l] == 0 and any(tab.lane_macro[a] for a in tab.prev_lanes[l]):
+            for _ in range(8):
+                r = list(env.simulator.create_random_route(l).route)[:32]
+                routes.append(r + [-1] * (32 - len(r)))
+    dev_tab = ops.DeviceHybridTables(tab, np.asarray(routes if routes else [[-1, -1]], dtype=np.int32), dev)
+    sim_args = (env.num_intersection ** 2, env.config["signal_length"] * env.config["simulation_frequency"],
+                1.0 / env.config["simulation_frequency"], args.speed_limit)
+    gen = th.Generator(device="cpu").manual_seed(args.seed)
+    action = (0.1 + 0.8 * th.rand(args.n_replica, env.action_size(), generator=gen)).to(dev).requires_grad_(True)
+    opt = th.optim.Adam([action], lr=args.lr)
+    t0 = time.time()
+    for ep in range(args.n_episode):
+        opt.zero_grad()
+        reward, _, _, _ = ops.net_hybrid_rollout(action, dev_tab, *sim_args, check_faults=False)
+        (-reward.sum()).backward()
+        action.grad.nan_to_num_(0.0, 0.0, 0.0)       # a replica whose reverse sweep hit 0 * inf sits this episode out
+        opt.step()
+        with th.no_grad():
+            action.clamp_(0.0, 1.0)
+        if ep % 10 == 0 or ep == args.n_episode - 1:
+            r = reward.detach()
+            print("episode %4d  reward best %.6f  mean %.6f  worst %.6f  (%.1f ms / episode of %d replicas)" % (
+                ep, float(r.max()), float(r.mean()), float(r.min()), 1e3 * (time.time() - t0) / (ep + 1), args.n_replica))
 
 
 if __name__ == "__main__":
