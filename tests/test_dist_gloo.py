@@ -87,3 +87,70 @@ def test_two_rank_gloo_allreduce_matches_single_process(oracle, tmp_path):
     loss = float(np.sum(f["rT"].astype(np.float64) ** 2) + np.sum(f["uT"].astype(np.float64) ** 2))
     ref = [g["g_ghost_r"][:, 0].sum(), g["g_ghost_u"][:, 0].sum(), g["g_ghost_r"][:, 1].sum(), g["g_ghost_u"][:, 1].sum(), loss]
     assert np.allclose(res["flat"], ref, rtol=2e-6)
+
+
+WORKER_NET = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(pkg)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch
+from dhts import dist as D
+from dhts.network import group_routes
+from oracle import oracle as O
+from test_oracle_golden import itscp_hybrid_tables
+import copy
+
+rank, world, local = D.init(backend="gloo")
+g = np.load(os.path.join(%(root)r, "tests", "golden", "itscp_hybrid_short.npz"))
+t, m = itscp_hybrid_tables(g)
+routes, ptr = group_routes(g["spawn_routes"], t.n_lanes)
+args = (m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"],
+        m["speed_limit"], m["static_speed"], m["vehicle_length"])
+R = 3                                                        # replicas: own inflow schedules, ONE shared signal schedule
+scale = [1.0, 0.8, 0.6]
+b, e = D.shard_range(R, rank, world)
+flat = torch.zeros(len(g["action"]) + 1, dtype=torch.float32)
+for r in range(b, e):
+    x = copy.copy(t); x.schedule = np.ascontiguousarray(t.schedule * scale[r])
+    o = O.net_hybrid(x, routes, ptr, g["action"], *args)
+    assert o["rc"] == 0
+    flat[:-1] += torch.tensor(o["g_action"]); flat[-1] += o["reward"]
+D.allreduce_sum_(flat)
+D.barrier()
+if rank == 0:
+    print("RESULT " + json.dumps({"flat": flat.tolist(), "shard": [b, e]}))
+'''
+
+
+def test_two_rank_gloo_replica_sharding(oracle, tmp_path):
+    """BASELINE config 5's pattern on CPU: network replicas sharded over two ranks, the gradient w.r.t. the shared signal
+    schedule and the reward all-reduced in one call."""
+    import copy
+    import json
+    from dhts.network import group_routes
+    from test_oracle_golden import itscp_hybrid_tables
+    script = tmp_path / "worker_net.py"
+    script.write_text(WORKER_NET % {"root": ROOT, "pkg": PKG})
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    res = json.loads([l for l in outs[0][0].splitlines() if l.startswith("RESULT ")][0][len("RESULT "):])
+    assert res["shard"] == [0, 2]
+    g = np.load(os.path.join(ROOT, "tests", "golden", "itscp_hybrid_short.npz"))
+    t, m = itscp_hybrid_tables(g)
+    routes, ptr = group_routes(g["spawn_routes"], t.n_lanes)
+    args = (m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"],
+            m["speed_limit"], m["static_speed"], m["vehicle_length"])
+    ref = np.zeros(len(g["action"]) + 1)
+    for sc in (1.0, 0.8, 0.6):
+        x = copy.copy(t)
+        x.schedule = np.ascontiguousarray(t.schedule * sc)
+        o = oracle.net_hybrid(x, routes, ptr, g["action"], *args)
+        ref[:-1] += o["g_action"]
+        ref[-1] += o["reward"]
+    assert np.allclose(res["flat"], ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max())
