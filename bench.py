@@ -376,18 +376,25 @@ def main():
         w = ItscpMacroWorkload(dev, rank, args.lanes or 256, 0, 0)
         L, N, T = w.L, w.N, w.T
 
-    flat = torch.zeros(1, dtype=torch.float32, device=dev)        # [loss] -- the per-pass RCCL all-reduce
-    for _ in range(args.warmup):
-        loss, _, _ = w.one_pass()
-        flat[0] = loss
+    # the per-pass RCCL all-reduce: [loss] for the straight-lane workloads (every lane owns its unknowns); for the network
+    # workloads the gradient summed over the rank's replicas as if the signal schedule were shared (BASELINE config 5) + loss
+    shared_grad = args.workload.startswith("itscp")
+    flat = torch.zeros((w.action.shape[1] if shared_grad else 0) + 1, dtype=torch.float32, device=dev)
+
+    def reduce_pass(loss, g_a):
+        if shared_grad:
+            flat[:-1] = g_a.sum(dim=0)
+        flat[-1] = loss
         D.allreduce_sum_(flat)
+    for _ in range(args.warmup):
+        loss, g_a, _ = w.one_pass()
+        reduce_pass(loss, g_a)
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, g_a, g_b = w.one_pass(record=True)
-        flat[0] = loss
-        D.allreduce_sum_(flat)
+        reduce_pass(loss, g_a)
     D.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
