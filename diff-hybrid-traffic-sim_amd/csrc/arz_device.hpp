@@ -76,12 +76,13 @@ __device__ __forceinline__ void glue_u_bwd(float r, float y, float um, float g_u
     }
     g_r += gd + gp;
 }
-// adjoint of y = r * (u - u_eq(r))
+// adjoint of y = r * (u - u_eq(r)); ACCUMULATES into g_r and g_u (callers may already hold a cotangent of u, e.g. the
+// loss tap on a deposited cell's speed or the stored-ghost chain)
 __device__ __forceinline__ void glue_y_bwd(float r, float u, float um, float g_y, float &g_r, float &g_u) {
     float ueq = glue_u_eq(r, um);
     float diff = u - ueq;
     float g_diff = g_y * r;
-    g_u = g_diff;
+    g_u += g_diff;
     float acc = g_y * diff;
     if (!(0.f > r)) {
         float t = r + kEpsF;

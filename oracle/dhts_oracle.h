@@ -154,14 +154,14 @@ void oracle_net_macro_bwd(const oracle_net_desc *d, const int *lane_ncell, const
  *              at spawn time, road_network.py:604-646; the caller pre-draws / replays them).  At most 128 vehicles per episode.
  * Forward and reverse sweep in one call: queue [T][L], *reward (all steps), *reward_cut and g_action
  * (d reward_cut / d action, NULL = forward only) for the reward restricted to steps < t_cut; *n_spawned, *n_deposits;
- * hist_out [T+1][4][C] optional.  rc = ORACLE_OK / ORACLE_ERR_CFL / ORACLE_ERR_ROUTE. */
+ * hist_out [T+1][4][C] and kc_out [T][C] (the cells' loss sigmoid constants) optional.  rc = ORACLE_OK / ORACLE_ERR_CFL / ORACLE_ERR_ROUTE. */
 int oracle_net_hybrid(const oracle_net_desc *d, const int *lane_macro, const double *lane_len,
                       const int *lane_ncell, const int *lane_off, const double *lane_dx,
                       const int *sig_kind, const int *inter, const int *left_src, const int *left_gate,
                       const int *right_src, const int *conv_next, const double *schedule,
                       const int *routes, const int *route_ptr, int n_routes, int route_stride, const float *action, int t_cut,
                       float *queue, double *reward, double *reward_cut, float *g_action, int *n_spawned,
-                      int *n_deposits, float *hist_out);
+                      int *n_deposits, float *hist_out, float *kc_out);
 
 #ifdef __cplusplus
 }

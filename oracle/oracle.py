@@ -250,7 +250,7 @@ def net_hybrid(tab, routes, route_ptr, action, n_inter_sq, frames_per_phase, dt,
     (dhts.network.group_routes)."""
     l = lib()
     l.oracle_net_hybrid.argtypes = ([C.POINTER(NetDesc)] + [C.c_void_p] * 14 + [C.c_int, C.c_int, C.c_void_p, C.c_int]
-                                    + [C.c_void_p] * 7)
+                                    + [C.c_void_p] * 8)
     action = _f32(action)
     T, L, Cn = tab.T, tab.n_lanes, tab.n_cells
     d = NetDesc(L, Cn, T, int(n_inter_sq), int(frames_per_phase), len(action), float(dt), float(u_max), float(static_speed),
@@ -265,8 +265,9 @@ def net_hybrid(tab, routes, route_ptr, action, n_inter_sq, frames_per_phase, dt,
     g = np.zeros(len(action), np.float32)
     nsp, ndep = C.c_int(0), C.c_int(0)
     hist = np.zeros((T + 1, 4, Cn), np.float32) if want_hist else None
+    kc = np.zeros((T, Cn), np.float32) if want_hist else None
     rc = l.oracle_net_hybrid(C.byref(d), *args, routes.shape[0], routes.shape[1], _p(action), T if t_cut is None else int(t_cut),
                              _p(queue), C.addressof(reward), C.addressof(reward_cut), _p(g) if want_grad else None,
-                             C.addressof(nsp), C.addressof(ndep), _p(hist) if want_hist else None)
+                             C.addressof(nsp), C.addressof(ndep), _p(hist) if want_hist else None, _p(kc) if want_hist else None)
     return dict(rc=rc, reward=reward.value, reward_cut=reward_cut.value, queue=queue, g_action=g if want_grad else None,
-                n_spawned=nsp.value, n_deposits=ndep.value, hist=hist)
+                n_spawned=nsp.value, n_deposits=ndep.value, hist=hist, kc=kc)

@@ -42,8 +42,11 @@ def test_hybrid_kernels_on_macro_only_network(cuda, golden_dir, name):
     assert o["counts"][0, 0] == 0 and o["counts"][0, 1] == 0
 
 
-def test_hybrid_short_matches_reference(cuda, golden_dir):
-    g = np.load(os.path.join(golden_dir, "itscp_hybrid_short.npz"))
+@pytest.mark.parametrize("name", ["hybrid_short", "hybrid_p2"])
+def test_hybrid_short_matches_reference(cuda, golden_dir, name):
+    """240 steps of problem_1 (5 spawns) and 480 steps of problem_2 with another seed (13 spawns, 10 deposits): queues, reward,
+    vehicle count and the full d reward / d action of the reference's runs."""
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
     o = _run(cuda, g, replicas=3)
     m = o["m"]
     for r in range(3):

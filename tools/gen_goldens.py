@@ -577,12 +577,12 @@ def gen_hybrid(name="hybrid3", N=10, T=500, dx=5.0, dt=0.01, um=30.0, seed=21):
 # G8: itscp environment (example/control/itscp): lane table, schedules, routes, reward and d reward / d action
 # ----------------------------------------------------------------------------------------------
 
-def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, action_kind):
+def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, action_kind, problem=1):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_stubs"))
     from example.control.itscp._env import ItscpEnv
-    from example.control.itscp.problem import problem_1
+    from example.control.itscp import problem as problems
     env = ItscpEnv()
-    env.schedule_callback = problem_1
+    env.schedule_callback = getattr(problems, "problem_%d" % problem)
     env.render_eval = False
     for k, v in dict(num_intersection=n_int, lane_length=lane_length, num_lane=n_lane, render=False, policy_length=sim_len,
                      signal_length=sig_len, mode=mode, speed_limit=60.0, random_seed=seed).items():
@@ -681,7 +681,7 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
         g_lane_late=np.array([g_lane_late[i] for i in sorted(g_lane_late)], dtype=np.float32).reshape(len(g_lane_late), len(a0)),
         meta=meta(seed=seed, mode=mode, num_intersection=n_int, num_lane=n_lane, lane_length=lane_length,
                   policy_length=sim_len, signal_length=sig_len, speed_limit=60.0, cell_length=5.0, simulation_frequency=30,
-                  static_speed=0.2, vehicle_length=5.0, T=T, n_vehicle_spawned=nveh,
+                  static_speed=0.2, vehicle_length=5.0, T=T, n_vehicle_spawned=nveh, problem=problem,
                   ref_seconds_fwd=t1 - t0, ref_seconds_bwd=t2 - t1))
 
 
@@ -720,6 +720,10 @@ def main():
             os.environ.setdefault("DHTS_FINE_CUTS", "150,300,450,480,510,540,570")
             os.environ.setdefault("DHTS_LANE_LATE", "16,54,82,116")
             gen_itscp(os.environ.get("DHTS_HYBRID_NAME", "hybrid"), "hybrid", 3, 1, 5.0, 20, 4, seed=9, action_kind="rand")
+        if "hybrid_p2" in which:         # another inflow pattern (problem_2), seed and horizon (16 s, signal 4 s)
+            os.environ["DHTS_FINE_CUTS"] = "120,240,360"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("hybrid_p2", "hybrid", 3, 1, 5.0, 16, 4, seed=21, action_kind="rand", problem=2)
         if "hybrid_short" in which:      # 8 s: enough for the first vehicles to cross the interior intersection
             gen_itscp("hybrid_short", "hybrid", 3, 1, 5.0, 8, 2, seed=9, action_kind="rand")
 
