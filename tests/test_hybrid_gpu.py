@@ -154,33 +154,35 @@ def test_per_replica_tables(cuda, golden_dir):
         ops.net_hybrid_rollout(a[:2], ops.DeviceHybridTables(tabs, g["spawn_routes"], cuda), *args)
 
 
-def test_hybrid_600_steps_random_actions_vs_oracle(cuda, golden_dir, oracle):
-    """Twelve other signal schedules on the 600-step network (other spawn times, lane orders, 8-14 vehicles, 8-12 deposits,
-    the sliding loss window) against the CPU restatement: identical event counts, queues, reward, and the gradient of the
-    first 450 steps' reward (a bound on the rest is pointless, see the knife-edge note in tests/test_itscp_gpu.py)."""
+@pytest.mark.parametrize("name, seed", [("itscp_hybrid", 11), ("itscp_hybrid_p2", 12)])
+def test_hybrid_random_actions_vs_oracle(cuda, golden_dir, oracle, name, seed):
+    """Twelve other signal schedules on each golden network (other spawn times, lane orders, 8-14 vehicles, 6-12 deposits,
+    the sliding loss window on the 600-step one) against the CPU restatement: identical event counts, queues, reward, and
+    the gradient of the WHOLE episode's reward.  (Kernel and restatement take the same branches on the same float32
+    states, so the knife-edge of tests/test_itscp_gpu.py does not limit this comparison; measured <= 2e-6.)"""
     import torch
     from dhts import ops
     from dhts.network import group_routes
-    g = np.load(os.path.join(golden_dir, "itscp_hybrid.npz"))
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
     t, m = itscp_hybrid_tables(g)
     args = (m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"],
             m["speed_limit"], m["static_speed"], m["vehicle_length"])
     routes = np.concatenate([g["spawn_routes"]] * 4)          # enough routes per spawn lane for any schedule
     gr, ptr = group_routes(routes, t.n_lanes)
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(seed)
     acts = rng.uniform(0.1, 0.9, (12, len(g["action"]))).astype(np.float32)
     a = torch.tensor(acts, device=cuda, requires_grad=True)
-    cut, reward, queue, counts = ops.net_hybrid_rollout(a, ops.DeviceHybridTables(t, routes, cuda), *args, 450)
+    cut, reward, queue, counts = ops.net_hybrid_rollout(a, ops.DeviceHybridTables(t, routes, cuda), *args)
     cut.sum().backward()
     G, Q, Cn, Rw = a.grad.cpu().numpy(), queue.cpu().numpy(), counts.cpu().numpy(), reward.cpu().numpy()
     worst = 0.0
     for k in range(len(acts)):
-        o = oracle.net_hybrid(t, gr, ptr, acts[k], *args, t_cut=450)
+        o = oracle.net_hybrid(t, gr, ptr, acts[k], *args)
         assert o["rc"] == 0 and (Cn[k, 0], Cn[k, 1]) == (o["n_spawned"], o["n_deposits"]), k
         assert rel_max(Q[k], o["queue"]) <= 1e-4, k
         assert abs(float(Rw[k]) - o["reward"]) <= 1e-5 * abs(o["reward"]), k
         worst = max(worst, np.abs(G[k] - o["g_action"]).max() / np.abs(o["g_action"]).max())
-    assert worst <= 2e-3, worst
+    assert worst <= 0.2 * TOL_GRAD, worst
 
 
 def test_larger_network_vs_oracle(cuda, oracle):
