@@ -73,6 +73,16 @@ STRAIGHT = {"north": "south", "west": "east", "east": "west", "south": "north"}
 RIGHT = {"north": "west", "west": "south", "east": "north", "south": "east"}
 
 
+class Box:
+    """The three attributes of gym.spaces.Box the trainer reads (reference _env.py:170-173, trainer.py:26-36,182-187)."""
+
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        self.shape = tuple(shape) if shape is not None else np.shape(low)
+        self.low = np.broadcast_to(np.asarray(low, dtype=dtype), self.shape).copy()
+        self.high = np.broadcast_to(np.asarray(high, dtype=dtype), self.shape).copy()
+        self.dtype = np.dtype(dtype)
+
+
 class ItscpEnv:
 
     def __init__(self, schedule_callback=itscp_random_schedule):
@@ -102,6 +112,8 @@ class ItscpEnv:
         self.num_timestep = self.config["policy_length"] * self.config["duration"] * self.config["simulation_frequency"]
         self._make_road()
         self.schedule = self.schedule_callback(list(self.lane.keys()), self.num_timestep)
+        self.observation_space = Box(0, 1, shape=(self.config["num_schedule_obs"] * len(self.lane),))
+        self.action_space = Box(self.config["action_min"], self.config["action_max"], shape=(self.action_size(),))
         self.time = self.steps = 0
         self.reward_queue_c = -1.0
         self.macro_route_schedule = [self.simulator.create_random_macro_route() for _ in range(self.num_timestep)]
@@ -109,6 +121,28 @@ class ItscpEnv:
         self._fused_cache = None            # tables of the fused kernels depend on the schedules / routes drawn above
         self._fused_done = False
         return self.observe()
+
+    def rewind(self):
+        """Episode state back to what reset() left, keeping the drawn schedules, routes and the uploaded kernel tables.
+        Valid after fused episodes only (they never touch the lane objects); the reference deep-copies the environment
+        per episode instead (trainer.py:172)."""
+        if self.steps and not getattr(self, "_fused_done", False):
+            raise RuntimeError("rewind() after a lane-by-lane episode: the lane objects moved, call reset()")
+        self.time = self.steps = 0
+        self._fused_done = False
+        self.queue_length.clear()
+        self.flux.clear()
+        self.is_static_rms = RunningMean(100_000)
+
+    def __deepcopy__(self, memo):
+        """Episode copy for the lane-by-lane path: everything is copied except the uploaded tables of the fused kernels,
+        which are immutable and shared."""
+        import copy
+        twin = object.__new__(type(self))
+        memo[id(self)] = twin
+        for k, v in self.__dict__.items():
+            twin.__dict__[k] = v if k == "_fused_cache" else copy.deepcopy(v, memo)
+        return twin
 
     def _make_micro_route(self):
         sim = self.simulator
