@@ -363,24 +363,29 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     int seg_a = 0, seg_b = 0;                        // this lane's staged records at the end of the first / second segment
     auto flush = [&](int t) {
         const int c = (mw < NS) ? rec.cnt : 0;
-        int inc = c;
-        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d, 64); if (mw >= d) inc += up; }
-        const int total = __shfl(inc, 63, 64), exc = inc - c;
+        const int inc = wave_scan_add(c);
+        const int total = wave_last(inc), exc = inc - c;
         seg_cnt[((size_t)t * kPhases + 0) * 64 + mw] = (unsigned short)(mw < NS ? seg_a : 0);
         seg_cnt[((size_t)t * kPhases + 1) * 64 + mw] = (unsigned short)(mw < NS ? seg_b - seg_a : 0);
         seg_cnt[((size_t)t * kPhases + 2) * 64 + mw] = (unsigned short)(mw < NS ? c - seg_b : 0);
         if (rec_n + total > ws.rec_cap) cap_fault = true;
         else if (total > 0) {
-            unsigned long long mask = __ballot(c > 0);
-            while (mask) {
-                const int s_ = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const int cs = __shfl(c, s_, 64), os = __shfl(exc, s_, 64);
-                for (int r = mw; r < cs; r += 64) {
-                    const int q = s_ * kStage + r;
-                    grk[rec_n + os + r] = stg_k[q];
-                    gri[rec_n + os + r] = *reinterpret_cast<const int4 *>(stg_i + 4 * q);
-                    grw[rec_n + os + r] = *reinterpret_cast<const float4 *>(stg_w + 4 * q);
+            // output slot o <- (staging lane, index): the owner is found with register traffic only, then every slot of the
+            // step moves in one batch of LDS reads and global stores
+            const unsigned long long mask0 = __ballot(c > 0);
+            for (int o = mw; o < ((total + 63) & ~63); o += 64) {
+                int q = -1;
+                unsigned long long mask = mask0;
+                while (mask) {
+                    const int s_ = __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1);
+                    mask &= mask - 1;
+                    const int cs = __builtin_amdgcn_readlane(c, s_), os = __builtin_amdgcn_readlane(exc, s_);
+                    if (o >= os && o < os + cs) q = s_ * kStage + (o - os);
+                }
+                if (q >= 0) {
+                    grk[rec_n + o] = stg_k[q];
+                    gri[rec_n + o] = *reinterpret_cast<const int4 *>(stg_i + 4 * q);
+                    grw[rec_n + o] = *reinterpret_cast<const float4 *>(stg_w + 4 * q);
                 }
             }
             rec_n += total;
@@ -409,7 +414,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     //      the records of step t-1 are flushed beside the ghosts of step t
     float x_new = 0.f;
     auto loss_scan = [&](const float *st) {
-        {
+        if ((tid & ~63) < C) {                        // waves without cells (the micro wave) have nothing to add
             double a = 0., b = 0.;
             if (is_cell) {
                 x_new = s0f - st[2 * C + tid];
@@ -418,11 +423,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 if (idx >= kWindow) b = (double)stream_load(xs + (idx - kWindow));
                 xs[idx] = x_new;
             }
-            double ia = a, ib = b;
-            for (int d = 1; d < 64; d <<= 1) {
-                const double ua = __shfl_up(ia, d, 64), ub = __shfl_up(ib, d, 64);
-                if ((tid & 63) >= d) { ia += ua; ib += ub; }
-            }
+            const double ia = wave_scan_add(a), ib = wave_scan_add(b);
             if (is_cell) { incl[tid] = ia; incl[C + tid] = ib; }
             if ((tid & 63) == 63) { scanw[tid >> 6] = ia; scanw[16 + (tid >> 6)] = ib; }
         }
@@ -610,11 +611,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     }
                 }
                 // signal_rms: running mean over the occupied lanes in lane order (_simulator.py:249-256)
-                double ssum = act ? (double)fin.v : 0.; int scnt = act ? 1 : 0;
-                for (int d = 1; d < 64; d <<= 1) {
-                    const double us = __shfl_up(ssum, d, 64); const int uc = __shfl_up(scnt, d, 64);
-                    if (mw >= d) { ssum += us; scnt += uc; }
-                }
+                const double ssum = wave_scan_add(act ? (double)fin.v : 0.);
+                const int scnt = wave_scan_add(act ? 1 : 0);
                 if (act) {
                     const float k2 = 32.f / fabsf((float)((sig_sum + ssum) / (double)(sig_cnt + scnt)));
                     const Du fs = du_soft(du_sub(fin, du_c(0.5f)), k2);
@@ -624,7 +622,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     const Tv dp_ = du_emit(rec, dp_d, ids), dv_ = du_emit(rec, dv_d, ids);
                     hdpv[k] = dp_.val; hdpi[k] = dp_.id; hdvv[k] = dv_.val; hdvi[k] = dv_.id;
                 }
-                sig_sum += __shfl(ssum, 63, 64); sig_cnt += __shfl(scnt, 63, 64);
+                sig_sum += wave_last(ssum); sig_cnt += wave_last(scnt);
             }
         }
         lds_barrier();
@@ -839,8 +837,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             {
                 const int k = mw;
                 const int c = k < n_micro ? lane_n[k] : 0;
-                int inc = c;
-                for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d, 64); if (mw >= d) inc += up; }
+                const int inc = wave_scan_add(c);
                 const int exc = inc - c;
                 double ssum = 0., esum = 0.;
                 for (int i = 0; i < c; ++i) {
@@ -852,11 +849,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     xs[idx] = x; vxold[vi] = xo;
                     ssum += (double)x; esum += (double)xo;
                 }
-                double is_ = ssum, ie_ = esum;
-                for (int d = 1; d < 64; d <<= 1) {
-                    const double us = __shfl_up(is_, d, 64), ue = __shfl_up(ie_, d, 64);
-                    if (mw >= d) { is_ += us; ie_ += ue; }
-                }
+                const double is_ = wave_scan_add(ssum), ie_ = wave_scan_add(esum);
                 if (k <= n_micro) { vcp[k] = exc; vsp[k] = is_ - ssum; vep[k] = ie_ - esum; }
             }
         }
@@ -1089,8 +1082,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         int c = 0;
 #pragma unroll
         for (int ph = 0; ph < kPhases; ++ph) c += seg_cnt[((size_t)T * kPhases + ph) * 64 + mw_lane];
-        int inc = c;
-        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d, 64); if (mw_lane >= d) inc += up; }
+        const int inc = wave_scan_add(c);
         const int lo_ = inc - c;
         if (lo_ + c <= b_n)
             for (int k = lo_; k < lo_ + c; ++k)
@@ -1132,8 +1124,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             }
             {   // a lane's block = its three segments back to back; blocks follow each other in lane order
                 const int c = p_seg[0] + p_seg[1] + p_seg[2];
-                int inc = c;
-                for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d, 64); if (mw_lane >= d) inc += up; }
+                const int inc = wave_scan_add(c);
                 int lo_ = inc - c;
 #pragma unroll
                 for (int ph = 0; ph < kPhases; ++ph) { seg_lo[ph] = lo_; seg_n[ph] = over ? 0 : p_seg[ph]; lo_ += p_seg[ph]; }

@@ -26,6 +26,37 @@ __device__ __forceinline__ float soft_switch_grad(float value, float constant) {
 // phases exchange goes through LDS, and nothing a kernel writes to global memory is read back by another thread of it.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Inclusive prefix sums over the 64 lanes of a wavefront with DPP moves only (no LDS crossbar round trips): row_shr 1/2/4/8
+// inside the rows of 16 lanes, then row_bcast15 into rows 1 and 3 and row_bcast31 into rows 2 and 3.  Lanes without a DPP
+// source add the identity.
+namespace dpp {
+constexpr int kRowShr1 = 0x111, kRowShr2 = 0x112, kRowShr4 = 0x114, kRowShr8 = 0x118, kBcast15 = 0x142, kBcast31 = 0x143;
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ int mov0(int x) { return __builtin_amdgcn_update_dpp(0, x, kCtrl, kRowMask, 0xF, false); }
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double mov0(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = mov0<kCtrl, kRowMask>((int)(b & 0xffffffffll)), hi = mov0<kCtrl, kRowMask>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+}  // namespace dpp
+template <typename T>
+__device__ __forceinline__ T wave_scan_add(T x) {
+    x += dpp::mov0<dpp::kRowShr1, 0xF>(x);
+    x += dpp::mov0<dpp::kRowShr2, 0xF>(x);
+    x += dpp::mov0<dpp::kRowShr4, 0xF>(x);
+    x += dpp::mov0<dpp::kRowShr8, 0xF>(x);
+    x += dpp::mov0<dpp::kBcast15, 0xA>(x);
+    x += dpp::mov0<dpp::kBcast31, 0xC>(x);
+    return x;
+}
+__device__ __forceinline__ int wave_last(int x) { return __builtin_amdgcn_readlane(x, 63); }
+__device__ __forceinline__ double wave_last(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 struct NetTables {
     const int32_t *lane_ncell, *lane_off, *sig_kind, *inter;   // [L]
     const double *lane_dx;                                      // [L]

@@ -106,8 +106,7 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
     double l_part = 0., l_incl = 0.;
     auto loss_scan = [&](const float *st) {          // phase 1: wave-level inclusive scan of x = s0 - u, cells in order
         l_part = is_cell ? (double)(s0f - st[2 * C + tid]) : 0.;
-        l_incl = l_part;
-        for (int d = 1; d < 64; d <<= 1) { const double up = __shfl_up(l_incl, d, 64); if ((tid & 63) >= d) l_incl += up; }
+        l_incl = wave_scan_add(l_part);
         if ((tid & 63) == 63) scanw[tid >> 6] = l_incl;
     };
     auto loss_consts = [&](const float *st, int ls) { // phase 2: k_c and the cell's contribution to its lane queue
