@@ -258,7 +258,9 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     int *vcp = LI(vcp), *capi = LI(capi), *mslot = LI(mslot), *capof = LI(capof), *mlane = LI(mlane), *cbefore = LI(cbefore), *convlist = LI(convlist), *linfo = LI(linfo), *caplast = LI(caplast), *rused = LI(rused), *caplane = LI(caplane), *capleaf = LI(capleaf);
     int *stg_k = LI(stg_k), *stg_i = LI(stg_i); float *stg_w = LF(stg_w);
     const float um = (float)um_d, s0f = (float)static_speed, vlen = (float)veh_len, dtf = (float)dt;
-    const float *act = action + (size_t)rep * n_action;
+    // the replica's action vector is read every step by the signal threads: staged in LDS (behind the carve-up)
+    float *act = reinterpret_cast<float *>(lds + lo.total);
+    for (int i = tid; i < n_action; i += B) act[i] = action[(size_t)rep * n_action + i];
     const size_t toff = (size_t)rep * tb.net.table_stride;
     float *hist_r = hist + (size_t)rep * (T + 1) * 4 * C;
     float4 *tape_r = tape + (size_t)rep * T * 3 * Cp;
@@ -335,8 +337,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     if (is_ghost) { g_kind = tb.net.sig_kind[g_lane]; g_inter = tb.net.inter[g_lane]; g_macro = tb.lane_macro[g_lane] != 0; }
     int l_off = 0, l_n = 0, l_ms = -1; bool l_macro = false;
     if (is_lane) { l_off = tb.net.lane_off[tid]; l_n = tb.net.lane_ncell[tid]; l_ms = mslot[tid]; l_macro = tb.lane_macro[tid] != 0; }
-    // signals of step 0
-    if (tid < sq) { float we, ns, a, pr; int ai; phase_signal(act, n_action, sq, F, 0, tid, we, ns, a, pr, ai); sig[2 * tid] = we; sig[2 * tid + 1] = ns; }
+    // signals of step 0 (the staged action vector is complete after the barrier above); signal threads count (phase, frame)
+    int sig_ph = 0, sig_fr = 0;                  // of the step whose signals are computed next
+    if (tid < sq) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, 0, 0, tid, we, ns, a, pr, ai); sig[2 * tid] = we; sig[2 * tid + 1] = ns; }
+    if (++sig_fr == F) { sig_fr = 0; ++sig_ph; }
 
     // ---- micro wave state
     int *grk = reinterpret_cast<int *>(wsr + ws.rec_k);
@@ -693,7 +697,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             float4 *tp = tape_r + (size_t)t * 3 * Cp;
             tp[c] = d0; tp[Cp + c] = d1; tp[2 * Cp + c] = d2;
         }
-        if (tid < sq && t + 1 < T) { float we, ns, a, pr; int ai; phase_signal(act, n_action, sq, F, t + 1, tid, we, ns, a, pr, ai); sig[2 * tid] = we; sig[2 * tid + 1] = ns; }
+        if (tid < sq && t + 1 < T) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, sig_ph, sig_fr, tid, we, ns, a, pr, ai); sig[2 * tid] = we; sig[2 * tid + 1] = ns; }
+        if (++sig_fr == F) { sig_fr = 0; ++sig_ph; }
         if (t > 0) loss_lanes(t - 1);
         lds_barrier();
         // ================= D: flux capacitors, hand-off events in lane-id order, commits, vehicle samples (micro wave) =====
@@ -941,7 +946,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     float *aval = LF(aval);
     int *iptr = reinterpret_cast<int *>(lds + lo.iptr), *iidx = reinterpret_cast<int *>(lds + lo.iidx);
     const float um = (float)um_d, s0f = (float)static_speed, vlen = (float)veh_len, dtf = (float)dt;
-    const float *act = action + (size_t)rep * n_action;
+    float *act = reinterpret_cast<float *>(lds + lo.total);      // the replica's action vector, staged in LDS
+    for (int i = tid; i < n_action; i += B) act[i] = action[(size_t)rep * n_action + i];
     const size_t toff = (size_t)rep * tb.net.table_stride;
     const float *hist_r = hist + (size_t)rep * (T + 1) * 4 * C;
     const float4 *tape_r = tape + (size_t)rep * T * 3 * Cp;
@@ -1035,6 +1041,13 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     }
     float gown_r = 0.f, gown_u = 0.f;    // cotangent of the stored downstream ghost (side-1 ghost thread)
     double ga = 0.; int cur_phase = -1;
+    // action cotangent of intersection q: a row of 16 lanes sums the intersection's ghost list (stride 16), its lane 15 owns
+    // the running sum of the phase; workgroups too small for 16 lanes per intersection keep one thread per intersection
+    const bool row_mode = 16 * sq <= B;
+    const int own_q = row_mode ? (tid >> 4) : tid;
+    const bool in_rows = row_mode ? (tid < 16 * sq) : (tid < sq);
+    const bool is_own = in_rows && (!row_mode || (tid & 15) == 15);
+    int rev_ph = T > 0 ? (T - 1) / F : 0, rev_fr = T > 0 ? (T - 1) % F : 0;      // (t / F, t % F) of the step being reversed
     bool bad = false, over = false, bad_key = false;
     if (tid < sq) for (int k = tid; k < n_action; k += sq) g_action[(size_t)rep * n_action + k] = 0.f;
     __syncthreads();
@@ -1049,30 +1062,43 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     for (int ph = 0; ph < kPhases; ++ph) p_seg[ph] = 0;
 #pragma unroll
     for (int j = 0; j < kPre; ++j) { p_rk[j] = 0; p_ri[j] = make_int4(0, 0, 0, 0); p_rw[j] = make_float4(0, 0, 0, 0); }
+    // Every load below is unconditional with a clamped index: a load inside `if (is_cell)` merges with the register's old
+    // value at the join, the register allocator then copies parts of the loaded tuple right behind the load, and the
+    // s_waitcnt in front of that copy stalls the wave for the full memory latency in every iteration.
+    const int f_cell = is_cell ? tid : 0, f_lane = is_lane ? tid : 0, f_glane = (is_ghost && g_macro) ? g_lane : 0;
+    const int32_t *f_srcp = g_side == 0 ? tb.net.left_src : tb.net.right_src;
+    int n_rlo = 0, n_nrec = 0;           // record range of the step fetched NEXT (its offsets are loaded one call earlier)
+    auto fetch_offsets = [&](int t) {    // step_off[t], step_off[t + 1] for the call after this one
+        const int tt = t < 0 ? 0 : t;
+        const int a = step_off[tt], b = step_off[tt + 1];
+        n_rlo = a; n_nrec = b - a;
+    };
     auto fetch = [&](int t) {
-        if (t < 0) return;
-        if (is_cell) {
-            const float *h = hist_r + (size_t)t * 4 * C;
-            p_hr = h[tid]; p_hy = h[C + tid]; p_hu = h[2 * C + tid];
-            p_kc = kc_r[(size_t)t * C + tid];
-            const float4 *tp = tape_r + (size_t)t * 3 * Cp;
-            p_d0 = tp[tid]; p_d1 = tp[Cp + tid]; p_d2 = tp[2 * Cp + tid];
+        const int tt = t < 0 ? 0 : t;
+        {
+            const float *h = hist_r + (size_t)tt * 4 * C;
+            p_hr = h[f_cell]; p_hy = h[C + f_cell]; p_hu = h[2 * C + f_cell];
+            p_kc = kc_r[(size_t)tt * C + f_cell];
+            const float4 *tp = tape_r + (size_t)tt * 3 * Cp;
+            p_d0 = tp[f_cell]; p_d1 = tp[Cp + f_cell]; p_d2 = tp[2 * Cp + f_cell];
         }
-        if (is_lane) p_q = queue_r[(size_t)t * L + tid];
-        if (is_ghost && g_macro) {
-            const size_t o = toff + (size_t)t * L + g_lane;
-            if (g_side == 0) { p_src = tb.net.left_src[o]; p_gate = tb.net.left_gate[o]; }
-            else { p_src = tb.net.right_src[o]; p_own_r = own_r[(size_t)t * 2 * L + 2 * g_lane]; p_own_u = own_r[(size_t)t * 2 * L + 2 * g_lane + 1]; }
+        p_q = queue_r[(size_t)tt * L + f_lane];
+        {
+            const size_t o = toff + (size_t)tt * L + f_glane;
+            p_src = f_srcp[o]; p_gate = tb.net.left_gate[o];
+            p_own_r = own_r[(size_t)tt * 2 * L + 2 * f_glane]; p_own_u = own_r[(size_t)tt * 2 * L + 2 * f_glane + 1];
         }
-        if (in_mw) {
-            p_rlo = step_off[t]; p_nrec = step_off[t + 1] - p_rlo;
+        if (in_mw) {                                 // wave-uniform
+            p_rlo = n_rlo; p_nrec = n_nrec;          // offsets of step t arrived during the previous iteration
 #pragma unroll
-            for (int ph = 0; ph < kPhases; ++ph) p_seg[ph] = seg_cnt[((size_t)t * kPhases + ph) * 64 + mw_lane];
+            for (int ph = 0; ph < kPhases; ++ph) p_seg[ph] = seg_cnt[((size_t)tt * kPhases + ph) * 64 + mw_lane];
 #pragma unroll
             for (int j = 0; j < kPre; ++j) {
                 const int k = mw_lane + 64 * j;
-                if (k < p_nrec) { p_rk[j] = grk[p_rlo + k]; p_ri[j] = gri[p_rlo + k]; p_rw[j] = grw[p_rlo + k]; }
+                const int kk = p_rlo + (k < p_nrec ? k : 0);
+                p_rk[j] = grk[kk]; p_ri[j] = gri[kk]; p_rw[j] = grw[kk];
             }
+            fetch_offsets(t - 1);
         }
     };
     // block T of the record stream holds only the loss seeds of the final state (they belong to the vehicles' speeds after
@@ -1089,6 +1115,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
                 if ((grk[b_lo + k] >> 24) == K_SEED) { const int4 a = gri[b_lo + k]; const float4 b = grw[b_lo + k]; adj[a.x] += gscale * b.x; }
     }
     __syncthreads();
+    if (in_mw) fetch_offsets(T - 1);
     fetch(T - 1);
     for (int t = T - 1; t >= 0; --t) {
         float *Hc = (t & 1) ? H1 : H0;           // row t
@@ -1100,7 +1127,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         if (is_lane) gq[tid] = (l_macro && t < loss_steps) ? gscale * (-1.0f) * (float)dt * 2.f * sqrtf(p_q / (float)dt) : 0.f;
         if (tid < sq) {
             float we, ns, a, pr; int ai;
-            phase_signal(act, n_action, sq, F, t, tid, we, ns, a, pr, ai);
+            phase_signal_at(act, n_action, sq, F, rev_ph, rev_fr, tid, we, ns, a, pr, ai);
             sg[6 * tid] = we; sg[6 * tid + 1] = ns;
             sg[6 * tid + 2] = soft_switch_grad(a - pr, kSigK); sg[6 * tid + 3] = -soft_switch_grad(pr - a, kSigK);
         }
@@ -1298,17 +1325,26 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             gL[tid] = v_r; gL[C + tid] = v_y; gL[2 * C + tid] = v_u;
             bad |= !(isfinite(v_r) && isfinite(v_y) && isfinite(v_u));
         }
-        if (tid < sq) {
+        if (in_rows) {
             double v = 0.;
-            for (int k = iptr[tid]; k < iptr[tid + 1]; ++k) v += (double)aval[iidx[k]];
-            v += (double)gam[tid]; gam[tid] = 0.f;
-            int phase = t / F; const int lastp = n_action / sq - 1; phase = phase > lastp ? lastp : phase;
-            if (phase != cur_phase) { if (cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + tid] = (float)ga; ga = 0.; cur_phase = phase; }
-            ga += v;
+            if (row_mode) {
+                for (int k = iptr[own_q] + (tid & 15); k < iptr[own_q + 1]; k += 16) v += (double)aval[iidx[k]];
+                v = row_scan_add(v);
+            } else {
+                for (int k = iptr[own_q]; k < iptr[own_q + 1]; ++k) v += (double)aval[iidx[k]];
+            }
+            if (is_own) {
+                v += (double)gam[own_q]; gam[own_q] = 0.f;
+                const int lastp = n_action / sq - 1;
+                const int phase = rev_ph > lastp ? lastp : rev_ph;
+                if (phase != cur_phase) { if (cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + own_q] = (float)ga; ga = 0.; cur_phase = phase; }
+                ga += v;
+            }
         }
+        if (rev_fr == 0) { rev_fr = F - 1; --rev_ph; } else --rev_fr;
         lds_barrier();
     }
-    if (tid < sq && cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + tid] = (float)ga;
+    if (is_own && cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + own_q] = (float)ga;
     if (bad) net_fault(err, DHTS_FAULT_NAN, 0, 0, tid);
     if ((over && is_mt) || bad_key) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, bad_key ? -2 : 0);
 #undef LF
@@ -1363,7 +1399,7 @@ int dhts_net_hybrid_rollout_fwd(const dhts_net_desc *d, const dhts_hybrid_tables
     const int B = hyb_block(d);
     if (B > 1024) return DHTS_E_INVALID;
     const HybWs ws = hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step);
-    const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, t->n_micro > kMaxCaps ? t->n_micro : kMaxCaps).total;
+    const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, t->n_micro > kMaxCaps ? t->n_micro : kMaxCaps).total + up16(sizeof(float) * (size_t)d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     auto kern = B <= 512 ? net_hybrid_fwd_kernel<512> : net_hybrid_fwd_kernel<1024>;
     if (lds > 64 * 1024 &&
@@ -1385,7 +1421,7 @@ int dhts_net_hybrid_rollout_bwd(const dhts_net_desc *d, const dhts_hybrid_tables
     if (B > 1024) return DHTS_E_INVALID;
     const HybWs ws = hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step);
     const int E = t->net.n_edges > 0 ? t->net.n_edges : 1;
-    const size_t lds = hyb_lds_b(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, E).total;
+    const size_t lds = hyb_lds_b(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, E).total + up16(sizeof(float) * (size_t)d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     auto kern = B <= 512 ? net_hybrid_bwd_kernel<512> : net_hybrid_bwd_kernel<1024>;
     if (lds > 64 * 1024 &&

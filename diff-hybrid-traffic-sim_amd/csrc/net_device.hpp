@@ -50,6 +50,15 @@ __device__ __forceinline__ T wave_scan_add(T x) {
     x += dpp::mov0<dpp::kBcast31, 0xC>(x);
     return x;
 }
+// inclusive prefix sum inside each row of 16 lanes (lane 15 of a row ends up with the row's total)
+template <typename T>
+__device__ __forceinline__ T row_scan_add(T x) {
+    x += dpp::mov0<dpp::kRowShr1, 0xF>(x);
+    x += dpp::mov0<dpp::kRowShr2, 0xF>(x);
+    x += dpp::mov0<dpp::kRowShr4, 0xF>(x);
+    x += dpp::mov0<dpp::kRowShr8, 0xF>(x);
+    return x;
+}
 __device__ __forceinline__ int wave_last(int x) { return __builtin_amdgcn_readlane(x, 63); }
 __device__ __forceinline__ double wave_last(double x) {
     const long long b = __double_as_longlong(x);
@@ -72,19 +81,23 @@ __device__ __forceinline__ void net_fault(dhts_error *err, int code, int step, i
     if (atomicCAS(&err->code, 0, code) == 0) { err->step = step; err->lane = lane; err->index = index; }
 }
 
-// phase signals of intersection k at step t: west-east and north-south switches and their inputs (_env.py:885-962)
-__device__ __forceinline__ void phase_signal(const float *action, int n_action, int sq, int F, int t, int k,
-                                             float &we, float &ns, float &a, float &prog, int &a_index) {
-    int phase = t / F;
+// phase signals of intersection k at step t: west-east and north-south switches and their inputs (_env.py:885-962).
+// `phase_raw` = t / F and `frame` = t % F are passed in so that rollouts can count them instead of dividing every step.
+__device__ __forceinline__ void phase_signal_at(const float *action, int n_action, int sq, int F, int phase_raw, int frame, int k,
+                                                float &we, float &ns, float &a, float &prog, int &a_index) {
     const int last = n_action / sq - 1;
-    phase = phase > last ? last : phase;
-    double pr = (double)(t % F) / (double)F;
+    const int phase = phase_raw > last ? last : phase_raw;
+    double pr = (double)frame / (double)F;
     pr = pr > 1.0 ? 1.0 : pr;
     a_index = phase * sq + k;
     a = action[a_index];
     prog = (float)pr;
     we = soft_switch(a - prog, kSigK);
     ns = soft_switch(prog - a, kSigK);
+}
+__device__ __forceinline__ void phase_signal(const float *action, int n_action, int sq, int F, int t, int k,
+                                             float &we, float &ns, float &a, float &prog, int &a_index) {
+    phase_signal_at(action, n_action, sq, F, t / F, t % F, k, we, ns, a, prog, a_index);
 }
 
 }  // namespace dhts
