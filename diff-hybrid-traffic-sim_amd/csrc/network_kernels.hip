@@ -21,6 +21,31 @@
 
 namespace dhts {
 
+// bytes of the kernels' LDS carve-ups in front of the staged tables (shared by the kernels and their host wrappers)
+__host__ __device__ inline size_t net_fwd_lds_base(int L, int C) {
+    const size_t NI = (size_t)C + L;
+    return sizeof(double) * (2 * NI + 16) + sizeof(float) * (8 * (size_t)C + 8 * L + 8 * NI + C + L) + sizeof(int) * ((size_t)C + NI);
+}
+__host__ __device__ inline size_t net_bwd_lds_base(int L, int C, int E, int sq) {
+    return sizeof(double) * (((10 * (size_t)C + L + 4 * E + C + 1) / 2 + 1) + 16 * (size_t)sq) + 64;
+}
+// staged behind the carve-up: the replica's action vector, per lane (first cell | last cell << 16) and (signal kind |
+// intersection << 2), the step's signals [sq][4] = (west-east, north-south, d west-east / d a, d north-south / d a)
+__host__ __device__ inline size_t net_staged_bytes(int L, int sq, int n_action) {
+    return 16 + sizeof(float) * (((size_t)n_action + 3) & ~(size_t)3) + sizeof(int) * 2 * (((size_t)L + 3) & ~(size_t)3) + sizeof(float) * 4 * (size_t)sq;
+}
+struct NetStaged { float *act; int *lfl; int *linfo; float *sig; };
+__device__ __forceinline__ NetStaged net_staged(char *lds, size_t base, int L, int n_action) {
+    NetStaged o;
+    char *p = lds + ((base + 15) & ~(size_t)15);
+    o.act = reinterpret_cast<float *>(p); p += sizeof(float) * ((n_action + 3) & ~3);
+    o.lfl = reinterpret_cast<int *>(p); p += sizeof(int) * ((L + 3) & ~3);
+    o.linfo = reinterpret_cast<int *>(p); p += sizeof(int) * ((L + 3) & ~3);
+    o.sig = reinterpret_cast<float *>(p);
+    return o;
+}
+
+
 // ------------------------------------------------------------------------------------------------------------------
 // Both kernels run one workgroup per replica with at least C + L threads (C + L <= 1024), so that every role has at most
 // one item per thread:  thread i < C + L solves interface i, thread c < C owns cell c, thread j < 2 L owns ghost
@@ -51,7 +76,9 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
     int *iface_lane_s = cell_lane_s + C;                      // [NI] (setup only)
     const float um = (float)um_d;
     const float s0f = (float)static_speed;
-    const float *act = action + (size_t)rep * n_action;
+    const NetStaged st_ = net_staged(reinterpret_cast<char *>(lds_d), net_fwd_lds_base(L, C), L, n_action);
+    float *act = st_.act; float *sig = st_.sig; int *lfl = st_.lfl, *linfo = st_.linfo;
+    for (int i = tid; i < n_action; i += B) act[i] = action[(size_t)rep * n_action + i];
     const size_t toff = (size_t)rep * tb.table_stride;
     float *hist_r = hist + (size_t)rep * (T + 1) * 4 * C;
     float4 *tape_r = tape + (size_t)rep * T * 3 * Cp;
@@ -63,6 +90,8 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
         const int off = tb.lane_off[tid], n = tb.lane_ncell[tid];
         for (int i = 0; i < n; ++i) cell_lane_s[off + i] = tid;
         for (int k = 0; k <= n; ++k) iface_lane_s[off + tid + k] = tid;
+        lfl[tid] = off | ((off + n - 1) << 16);
+        linfo[tid] = tb.sig_kind[tid] | (tb.inter[tid] << 2);
     }
     if (tid < C) {
         S0[tid] = 0.f; S0[C + tid] = 0.f; S0[2 * C + tid] = um; S0[3 * C + tid] = um;          // empty lanes
@@ -88,16 +117,26 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
     if (is_lane) { l_off = tb.lane_off[tid]; l_n = tb.lane_ncell[tid]; }
     __syncthreads();        // setup maps are dead from here on (their LDS is not reused)
 
-    // per-step tables, one step ahead
+    // per-step tables, one step ahead.  Unconditional loads with clamped indices: a load inside a divergent branch merges
+    // with the register's old value, and the copy the register allocator places behind it waits for the load at once.
     int p_src = 0, p_gate = 0; double p_sched = 0.;
+    const int f_glane = is_ghost ? g_lane : 0;
+    const int32_t *f_srcp = g_side == 0 ? tb.left_src : tb.right_src;
     auto fetch = [&](int t) {
-        if (is_ghost && t < T) {
-            const size_t o = toff + (size_t)t * L + g_lane;
-            if (g_side == 0) { p_src = tb.left_src[o]; p_gate = tb.left_gate[o]; p_sched = tb.schedule[o]; }
-            else p_src = tb.right_src[o];
-        }
+        const int tt = t < T ? t : T - 1;
+        const size_t o = toff + (size_t)tt * L + f_glane;
+        p_src = f_srcp[o]; p_gate = tb.left_gate[o]; p_sched = tb.schedule[o];
     };
-    fetch(0);
+    // signals of the step whose ghosts are built next, by the intersection's thread; (phase, frame) are counted
+    int sig_ph = 0, sig_fr = 0;
+    auto signals = [&]() {
+        if (tid < sq) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, sig_ph, sig_fr, tid, we, ns, a, pr, ai); sig[4 * tid] = we; sig[4 * tid + 1] = ns; }
+        if (++sig_fr == F) { sig_fr = 0; ++sig_ph; }
+    };
+    __syncthreads();        // the staged action vector is complete
+    signals();
+    __syncthreads();
+    if (T > 0) fetch(0);
     double run_sum = 0.; long long run_cnt = 0;
     float lane_total = 0.f;
     int fault_step = -1, fault_index = 0;
@@ -144,13 +183,13 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
                     const double gu = um_d * (1. - sqrt(fmax(sched, 0.) + kEps));
                     fr = (float)sched; fu = (float)gu; fy = 0.f; fq = (float)gu;      // y = r (u - u_eq(r)) = 0
                 } else {
-                    const int last = tb.lane_off[src] + tb.lane_ncell[src] - 1;
+                    const int last = lfl[src] >> 16;
                     const float gr = cur[last], gu = cur[2 * C + last];
                     float s = 1.f;
                     if (gate == -1) s = 0.f;
                     else if (gate >= 0) {
-                        const int kd = tb.sig_kind[gate];
-                        if (kd != 0) { float we, ns, a, pr; int ai; phase_signal(act, n_action, sq, F, t, tb.inter[gate], we, ns, a, pr, ai); s = kd == 1 ? we : ns; }
+                        const int kd = linfo[gate] & 3;
+                        if (kd != 0) s = sig[4 * (linfo[gate] >> 2) + (kd - 1)];
                     }
                     fr = gr * s + 0.f * (1.0f - s);
                     fu = gu * s + um * (1.0f - s);
@@ -158,10 +197,9 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
                 }
             } else {
                 float gr = own_r, gu = own_u;
-                if (src >= 0) { const int first = tb.lane_off[src]; gr = cur[first]; gu = cur[2 * C + first]; }
+                if (src >= 0) { const int first = lfl[src] & 0xffff; gr = cur[first]; gu = cur[2 * C + first]; }
                 else { own_w[(size_t)t * 2 * L + 2 * g_lane] = gr; own_w[(size_t)t * 2 * L + 2 * g_lane + 1] = gu; }
-                float sg = 1.f;
-                if (g_kind != 0) { float we, ns, a, pr; int ai; phase_signal(act, n_action, sq, F, t, g_inter, we, ns, a, pr, ai); sg = g_kind == 1 ? we : ns; }
+                const float sg = g_kind != 0 ? sig[4 * g_inter + (g_kind - 1)] : 1.f;
                 const float s2 = soft_switch(sg - 0.5f, kSigK);
                 fr = s2 * gr + (1.0f - s2) * 1.0f;
                 fu = s2 * gu + (1.0f - s2) * 0.0f;
@@ -213,6 +251,7 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
             tp[c] = d0; tp[Cp + c] = d1; tp[2 * Cp + c] = d2;
         }
         if (t > 0) loss_lanes(t - 1);
+        if (t + 1 < T) signals();            // of step t + 1 (this step's ghosts read theirs two barriers ago)
         lds_barrier();
     }
     // loss of the final state
@@ -259,7 +298,9 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
     int *cell_lane_s = reinterpret_cast<int *>(inF + 2 * E);
     double *red = lds_d + red_off;       // [16][sq] per-wave partial sums of the action cotangent
     const float um = (float)um_d, s0f = (float)static_speed;
-    const float *act = action + (size_t)rep * n_action;
+    const NetStaged st_ = net_staged(reinterpret_cast<char *>(lds_d), net_bwd_lds_base(L, C, E, sq), L, n_action);
+    float *act = st_.act; float *sig = st_.sig; int *lfl = st_.lfl, *linfo = st_.linfo;
+    for (int i = tid; i < n_action; i += blockDim.x) act[i] = action[(size_t)rep * n_action + i];
     const size_t toff = (size_t)rep * tb.table_stride;
     const float *hist_r = hist + (size_t)rep * (T + 1) * 4 * C;
     const float4 *tape_r = tape + (size_t)rep * T * 3 * Cp;
@@ -272,6 +313,8 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
     if (is_lane) {
         const int off = tb.lane_off[tid], n = tb.lane_ncell[tid];
         for (int i = 0; i < n; ++i) cell_lane_s[off + i] = tid;
+        lfl[tid] = off | ((off + n - 1) << 16);
+        linfo[tid] = tb.sig_kind[tid] | (tb.inter[tid] << 2);
     }
     for (int k = tid; k < 2 * E; k += blockDim.x) { inL[k] = 0.f; inF[k] = 0.f; }
     __syncthreads();
@@ -325,21 +368,20 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
     float p_hr = 0.f, p_hy = 0.f, p_hu = 0.f, p_kc = 0.f, p_q = 0.f, p_own_r = 0.f, p_own_u = 0.f;
     float4 p_d0 = make_float4(0, 0, 0, 0), p_d1 = p_d0, p_d2 = p_d0;
     int p_src = 0, p_gate = 0;
+    // unconditional loads with clamped indices (see the forward kernel's fetch)
+    const int f_cell = is_cell ? tid : 0, f_lane = is_lane ? tid : 0, f_glane = is_ghost ? g_lane : 0;
+    const int32_t *f_srcp = g_side == 0 ? tb.left_src : tb.right_src;
     auto fetch = [&](int t) {
-        if (t < 0) return;
-        if (is_cell) {
-            const float *h = hist_r + (size_t)t * 4 * C;
-            p_hr = h[tid]; p_hy = h[C + tid]; p_hu = h[2 * C + tid];
-            p_kc = kc_r[(size_t)t * C + tid];
-            const float4 *tp = tape_r + (size_t)t * 3 * Cp;
-            p_d0 = tp[tid]; p_d1 = tp[Cp + tid]; p_d2 = tp[2 * Cp + tid];
-        }
-        if (is_lane) p_q = queue_r[(size_t)t * L + tid];
-        if (is_ghost) {
-            const size_t o = toff + (size_t)t * L + g_lane;
-            if (g_side == 0) { p_src = tb.left_src[o]; p_gate = tb.left_gate[o]; }
-            else { p_src = tb.right_src[o]; p_own_r = own_r[(size_t)t * 2 * L + 2 * g_lane]; p_own_u = own_r[(size_t)t * 2 * L + 2 * g_lane + 1]; }
-        }
+        const int tt = t < 0 ? 0 : t;
+        const float *h = hist_r + (size_t)tt * 4 * C;
+        p_hr = h[f_cell]; p_hy = h[C + f_cell]; p_hu = h[2 * C + f_cell];
+        p_kc = kc_r[(size_t)tt * C + f_cell];
+        const float4 *tp = tape_r + (size_t)tt * 3 * Cp;
+        p_d0 = tp[f_cell]; p_d1 = tp[Cp + f_cell]; p_d2 = tp[2 * Cp + f_cell];
+        p_q = queue_r[(size_t)tt * L + f_lane];
+        const size_t o = toff + (size_t)tt * L + f_glane;
+        p_src = f_srcp[o]; p_gate = tb.left_gate[o];
+        p_own_r = own_r[(size_t)tt * 2 * L + 2 * f_glane]; p_own_u = own_r[(size_t)tt * 2 * L + 2 * f_glane + 1];
     };
     // the final state's history row goes straight to LDS
     if (is_cell) {
@@ -348,7 +390,8 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
         Hn[tid] = h[tid]; Hn[C + tid] = h[C + tid]; Hn[2 * C + tid] = h[2 * C + tid];
     }
     __syncthreads();
-    fetch(T - 1);
+    if (T > 0) fetch(T - 1);
+    int rev_ph = T > 0 ? (T - 1) / F : 0, rev_fr = T > 0 ? (T - 1) % F : 0;      // (t / F, t % F) of the step being reversed
     float g_r = 0.f, g_y = 0.f;          // cotangent of this thread's cell at time t+1
     double ga = 0.;                      // thread q < sq: d reward / d action[cur_phase * sq + q], flushed when the phase changes
     int cur_phase = -1;
@@ -366,7 +409,13 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
         if (is_cell) { Hc[tid] = p_hr; Hc[C + tid] = p_hy; Hc[2 * C + tid] = p_hu; }
         // d reward / d q_l = - 2 q_l dt with q_l = sqrt(term / dt)
         if (is_lane) gq[tid] = gscale * (-1.0f) * (float)dt * 2.f * sqrtf(w_q / (float)dt);
-        fetch(t - 1);
+        if (tid < sq) {                      // this step's signals and their derivatives w.r.t. the action entry
+            float we, ns, a, pr; int ai;
+            phase_signal_at(act, n_action, sq, F, rev_ph, rev_fr, tid, we, ns, a, pr, ai);
+            sig[4 * tid] = we; sig[4 * tid + 1] = ns;
+            sig[4 * tid + 2] = soft_switch_grad(a - pr, kSigK); sig[4 * tid + 3] = -soft_switch_grad(pr - a, kSigK);
+        }
+        if (t > 0) fetch(t - 1);
         lds_barrier();
         // ---- phase B: loss taps on the state after step t, then J^T g of this cell (dmacro_lane.py:283-294)
         float v_r = 0.f, v_y = 0.f;
@@ -393,16 +442,16 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
         }
         float my_aval = 0.f; int my_akey = -1;
         if (is_ghost) {
-            float tgt = -1.f, add_r = 0.f, add_y = 0.f, a_val = 0.f, a_idx = -1.f;
+            float tgt = -1.f, add_r = 0.f, add_y = 0.f, a_val = 0.f; int a_key = -1;
             if (g_side == 0) {
                 if (src >= 0) {
-                    const int last = tb.lane_off[src] + tb.lane_ncell[src] - 1;
+                    const int last = lfl[src] >> 16;
                     const float grn_r = Hc[last], grn_u = Hc[2 * C + last];
-                    float s = 1.f, we = 0.f, ns = 0.f, a = 0.f, pr = 0.f; int ai = -1, kd = 0;
+                    float s = 1.f; int kd = 0, it = 0;
                     if (gate == -1) s = 0.f;
                     else if (gate >= 0) {
-                        kd = tb.sig_kind[gate];
-                        if (kd != 0) { phase_signal(act, n_action, sq, F, t, tb.inter[gate], we, ns, a, pr, ai); s = kd == 1 ? we : ns; }
+                        kd = linfo[gate] & 3; it = linfo[gate] >> 2;
+                        if (kd != 0) s = sig[4 * it + (kd - 1)];
                     }
                     const float fr = grn_r * s + 0.f * (1.0f - s), fu = grn_u * s + um * (1.0f - s);
                     float g_fr = c0[g_off], g_fu = 0.f;
@@ -412,22 +461,20 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
                     tgt = (float)last;
                     if (kd != 0) {
                         const float g_s = g_fr * grn_r + g_fu * (grn_u - um);
-                        const float dsig = kd == 1 ? soft_switch_grad(a - pr, kSigK) : -soft_switch_grad(pr - a, kSigK);
-                        a_val = g_s * dsig; a_idx = (float)ai;
+                        a_val = g_s * sig[4 * it + 2 + (kd - 1)]; a_key = it;
                     }
                 }
             } else {
-                const float grn_r = src < 0 ? w_own_r : Hc[tb.lane_off[src]];
-                const float grn_u = src < 0 ? w_own_u : Hc[2 * C + tb.lane_off[src]];
-                float sg = 1.f, we = 0.f, ns = 0.f, a = 0.f, pr = 0.f; int ai = -1;
-                if (g_kind != 0) { phase_signal(act, n_action, sq, F, t, g_inter, we, ns, a, pr, ai); sg = g_kind == 1 ? we : ns; }
+                const int first = src < 0 ? 0 : (lfl[src] & 0xffff);
+                const float grn_r = src < 0 ? w_own_r : Hc[first];
+                const float grn_u = src < 0 ? w_own_u : Hc[2 * C + first];
+                const float sg = g_kind != 0 ? sig[4 * g_inter + (g_kind - 1)] : 1.f;
                 const float s2 = soft_switch(sg - 0.5f, kSigK);
                 const float fr = s2 * grn_r + (1.0f - s2) * 1.0f, fu = s2 * grn_u + (1.0f - s2) * 0.0f;
                 const int lastc = g_off + g_n - 1;
                 float g_fr = c2[lastc], g_fu = 0.f;
                 glue_y_bwd(fr, fu, um, c2[C + lastc], g_fr, g_fu);
                 if (src >= 0) {
-                    const int first = tb.lane_off[src];
                     add_r = g_fr * s2;
                     glue_u_bwd(Hc[first], Hc[C + first], um, g_fu * s2, add_r, add_y);
                     tgt = (float)first;
@@ -435,8 +482,7 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
                 if (g_kind != 0) {
                     const float g_s2 = g_fr * (grn_r - 1.0f) + g_fu * grn_u;
                     const float g_sig = g_s2 * soft_switch_grad(sg - 0.5f, kSigK);
-                    const float dsig = g_kind == 1 ? soft_switch_grad(a - pr, kSigK) : -soft_switch_grad(pr - a, kSigK);
-                    a_val = g_sig * dsig; a_idx = (float)ai;
+                    a_val = g_sig * sig[4 * g_inter + 2 + (g_kind - 1)]; a_key = g_inter;
                 }
             }
             // route the cell cotangent to the inbox entry of (source lane, this lane)
@@ -446,7 +492,7 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
                 for (int i = 0; i < kMaxCand; ++i)
                     if (cand_src[i] == src) { box[2 * cand_pos[i]] = add_r; box[2 * cand_pos[i] + 1] = add_y; }
             }
-            my_aval = a_val; my_akey = a_idx < 0.f ? -1 : ((int)a_idx) % sq;
+            my_aval = a_val; my_akey = a_key;
         }
         // action cotangent: per intersection, fixed-shape reduction (wave butterfly in double, then the wave partials)
         for (int q = 0; q < sq; ++q) {
@@ -474,10 +520,11 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
             double v = 0.;
             for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += red[w * sq + tid];
             // all contributions of step t belong to the phase of step t
-            int phase = t / F; const int lastp = n_action / sq - 1; phase = phase > lastp ? lastp : phase;
+            const int lastp = n_action / sq - 1; const int phase = rev_ph > lastp ? lastp : rev_ph;
             if (phase != cur_phase) { if (cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + tid] = (float)ga; ga = 0.; cur_phase = phase; }
             ga += v;
         }
+        if (rev_fr == 0) { rev_fr = F - 1; --rev_ph; } else --rev_fr;
         // no barrier here: the next step's first phase only writes rows / gq that nobody reads before its own barrier;
         // inbox entries and the reduction scratch are rewritten two barriers later
     }
@@ -527,9 +574,8 @@ int dhts_net_macro_rollout_fwd(const dhts_net_desc *d, const dhts_net_tables *t,
                                float *kc, float *queue, float *reward, float *workspace, dhts_error *err, void *stream) {
     if (!net_desc_ok(d) || !net_tables_ok(t) || !action || !hist || !tape || !kc || !queue || !reward || !workspace)
         return DHTS_E_INVALID;
-    const int B = net_block(d), L = d->n_lanes, C = d->n_cells, NI = C + L;
-    const size_t lds = sizeof(double) * (2 * (size_t)NI + 16) + sizeof(float) * (8 * (size_t)C + 8 * L + 8 * (size_t)NI + C + L) +
-                       sizeof(int) * ((size_t)C + NI);
+    const int B = net_block(d), L = d->n_lanes, C = d->n_cells;
+    const size_t lds = net_fwd_lds_base(L, C) + net_staged_bytes(L, d->n_inter_sq, d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)net_macro_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -547,7 +593,7 @@ int dhts_net_macro_rollout_bwd(const dhts_net_desc *d, const dhts_net_tables *t,
         return DHTS_E_INVALID;
     const int B = net_block(d), L = d->n_lanes, C = d->n_cells;
     const int E = t->n_edges > 0 ? t->n_edges : 1;
-    const size_t lds = sizeof(double) * (((10 * (size_t)C + L + 4 * E + C + 1) / 2 + 1) + 16 * (size_t)d->n_inter_sq) + 64;
+    const size_t lds = net_bwd_lds_base(L, C, E, d->n_inter_sq) + net_staged_bytes(L, d->n_inter_sq, d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)net_macro_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
