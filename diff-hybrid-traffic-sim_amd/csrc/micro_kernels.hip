@@ -73,13 +73,22 @@ __global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
     for (int step = 0; step < T; ++step) {
         float4 *tp = tape ? tape + ((size_t)step * L + lane) * (kCompact ? 1 : 2) * Vp : nullptr;
         float *hp = hist ? hist + ((size_t)step * L + lane) * 2 * V : nullptr;
+        // every pass reads its own and its leaders' OLD state before anything is written, so the K IDM evaluations of a
+        // thread are independent instruction streams (a wave's LDS operations execute in order: no barrier is needed
+        // between this step's writes and the next step's reads)
+        float rp[K], rv[K], rpl[K], rvl[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int i = (j << 6) + t;
+            const int ic = i < n ? i : 0;
+            rp[j] = Sp[ic]; rv[j] = Sv[ic]; rpl[j] = Sp[ic + 1]; rvl[j] = Sv[ic + 1];
+        }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const int i = (j << 6) + t;
             const bool valid = i < n;
-            const int ic = valid ? i : 0;
-            const double p = Sp[ic], v = Sv[ic];
-            const double pl = Sp[ic + 1], vl = Sv[ic + 1];
+            const double p = rp[j], v = rv[j];
+            const double pl = rpl[j], vl = rvl[j];
             double dp, dv;
             if (i == n - 1) {                         // compute_state_delta, _micro_lane.py:201-204
                 dp = head_dp; dv = head_dv;
