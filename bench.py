@@ -30,7 +30,7 @@ MICRO_TAPE_B = 32           # float32 [2][2][2] per vehicle-step (road/lane/dmic
 # what the rollout kernels actually move per unit: the interface tape (2 x 2x2 per interface, 520 / 512 interfaces per lane
 # here) and the second rows of dEgo / dLeading -- the same information, reconstructed in the reverse sweep
 MACRO_STORED_B = 32.5
-MICRO_STORED_B = 16
+MICRO_STORED_B = 12
 
 
 def parse():

@@ -29,13 +29,18 @@ __device__ __forceinline__ void raise_fault_m(dhts_error *err, int code, int ste
     }
 }
 
+// compact rollout tape entry: (dEgo[1][0], dEgo[1][1], dLeading[1][1]).  The first rows of both blocks are constants
+// ([1, dt] and [0, 0]) and dLeading[1][0] = -dEgo[1][0] bit for bit: dt * (2 a s^2 / gap^3) against dt * (-2 a s^2 / gap^3),
+// both 0 under the acceleration clip (didm.py:38-103) -- 12 bytes per vehicle-step instead of the 32 of dqs[V][2][2][2]
+struct __attribute__((packed, aligned(4))) MicroTape3 { float e2, e3, l3; };
+
 // grid = L workgroups of 64 threads; dynamic LDS = 2 * (V + 1) floats
 template <int K, bool kCompact>
 __global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
     int L, int V, int T, double dt,
     const float *__restrict__ p_in, const float *__restrict__ v_in, const int32_t *__restrict__ count,
     const double *__restrict__ params, const double *__restrict__ head,
-    float *__restrict__ p_out, float *__restrict__ v_out, float4 *__restrict__ tape, float *__restrict__ hist,
+    float *__restrict__ p_out, float *__restrict__ v_out, float *__restrict__ tape, float *__restrict__ hist,
     dhts_error *err) {
     extern __shared__ float lds[];
     const int lane = blockIdx.x;
@@ -71,7 +76,8 @@ __global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
     int fault_step = -1, fault_index = 0;
 
     for (int step = 0; step < T; ++step) {
-        float4 *tp = tape ? tape + ((size_t)step * L + lane) * (kCompact ? 1 : 2) * Vp : nullptr;
+        float4 *tp = (tape && !kCompact) ? reinterpret_cast<float4 *>(tape) + ((size_t)step * L + lane) * 2 * Vp : nullptr;
+        MicroTape3 *tc = (tape && kCompact) ? reinterpret_cast<MicroTape3 *>(tape) + ((size_t)step * L + lane) * Vp : nullptr;
         float *hp = hist ? hist + ((size_t)step * L + lane) * 2 * V : nullptr;
         // every pass reads its own and its leaders' OLD state before anything is written, so the K IDM evaluations of a
         // thread are independent instruction streams (a wave's LDS operations execute in order: no barrier is needed
@@ -101,14 +107,11 @@ __global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
             if (valid) {
                 if (o.collided && fault_step < 0) { fault_step = step; fault_index = i; }
                 Sp[i] = o.np; Sv[i] = o.nv;
-                if (tp) {
-                    if constexpr (kCompact) {
-                        // the first rows are constants: dEgo = [[1, dt], [., .]], dLeading = [[0, 0], [., .]] (didm.py:38-103)
-                        tp[i] = make_float4(o.dE[2], o.dE[3], o.dLd[2], o.dLd[3]);
-                    } else {
-                        tp[i] = make_float4(o.dE[0], o.dE[1], o.dE[2], o.dE[3]);
-                        tp[Vp + i] = make_float4(o.dLd[0], o.dLd[1], o.dLd[2], o.dLd[3]);
-                    }
+                if constexpr (kCompact) {
+                    if (tc) { MicroTape3 e; e.e2 = o.dE[2]; e.e3 = o.dE[3]; e.l3 = o.dLd[3]; tc[i] = e; }
+                } else if (tp) {
+                    tp[i] = make_float4(o.dE[0], o.dE[1], o.dE[2], o.dE[3]);
+                    tp[Vp + i] = make_float4(o.dLd[0], o.dLd[1], o.dLd[2], o.dLd[3]);
                 }
                 if (hp) { hp[i] = o.np; hp[V + i] = o.nv; }
             }
@@ -142,7 +145,7 @@ __global__ void idm_batch_kernel(int64_t n, int variant, const double *__restric
 // grid = L workgroups of blockDim.x threads; dynamic LDS = 4 * (V + 2) floats
 template <bool kCompact>
 __global__ void micro_rollout_bwd_kernel(
-    int L, int V, int T, double dt, const float4 *__restrict__ tape, const int32_t *__restrict__ count,
+    int L, int V, int T, double dt, const float *__restrict__ tape, const int32_t *__restrict__ count,
     const float *__restrict__ g_p_in, const float *__restrict__ g_v_in, const float *__restrict__ g_hist,
     float *__restrict__ g_p_out, float *__restrict__ g_v_out, double *__restrict__ g_head, int fold, dhts_error *err) {
     extern __shared__ float lds[];
@@ -162,13 +165,14 @@ __global__ void micro_rollout_bwd_kernel(
 
     double gh_p = 0., gh_v = 0.;       // held by the thread that owns the head vehicle
     for (int step = T - 1; step >= 0; --step) {
-        const float4 *tp = tape + ((size_t)step * L + lane) * (kCompact ? 1 : 2) * Vp;
+        const float4 *tp = reinterpret_cast<const float4 *>(tape) + ((size_t)step * L + lane) * 2 * Vp;            // reference layout
+        const MicroTape3 *tc = reinterpret_cast<const MicroTape3 *>(tape) + ((size_t)step * L + lane) * Vp;         // compact layout
         const float *gh = g_hist ? g_hist + ((size_t)step * L + lane) * 2 * V : nullptr;
         for (int k = t; k < n; k += B) {
             float4 dE, dLd;
             if constexpr (kCompact) {
-                const float4 c = tp[k];
-                dE = make_float4(1.f, (float)dt, c.x, c.y); dLd = make_float4(0.f, 0.f, c.z, c.w);
+                const MicroTape3 c = tc[k];
+                dE = make_float4(1.f, (float)dt, c.e2, c.e3); dLd = make_float4(0.f, 0.f, -c.e2, c.l3);
             } else { dE = tp[k]; dLd = tp[Vp + k]; }
             float gp = Gp[k], gv = Gv[k];
             if (gh) { gp += gh[k]; gv += gh[V + k]; }
@@ -223,7 +227,7 @@ static void launch_micro_fwd(const dhts_micro_desc *d, int T, const float *p, co
                              float *hist, dhts_error *err, hipStream_t s) {
     const size_t lds = sizeof(float) * 2 * (size_t)(d->capacity + 1);
     micro_rollout_fwd_kernel<K, kCompact><<<d->n_lanes, 64, lds, s>>>(d->n_lanes, d->capacity, T, d->dt, p, v, count, params, head,
-                                                           p_out, v_out, reinterpret_cast<float4 *>(tape), hist, err);
+                                                           p_out, v_out, tape, hist, err);
 }
 
 template <bool kCompact>
@@ -249,7 +253,7 @@ static int micro_bwd_launch(const dhts_micro_desc *d, int T, const float *tape, 
     int B = (d->capacity + 63) & ~63;
     if (B > 256) B = 256;
     micro_rollout_bwd_kernel<kCompact><<<d->n_lanes, B, lds, (hipStream_t)stream>>>(
-        d->n_lanes, d->capacity, T, d->dt, reinterpret_cast<const float4 *>(tape), count, g_p, g_v, g_hist, g_p_out, g_v_out,
+        d->n_lanes, d->capacity, T, d->dt, tape, count, g_p, g_v, g_hist, g_p_out, g_v_out,
         g_head, fold, err);
     return launch_status_m();
 }
@@ -267,7 +271,7 @@ int dhts_idm_batch(int64_t n, int variant, const double *in, double *next_pv, fl
 
 size_t dhts_micro_tape_bytes(const dhts_micro_desc *d, int T) {
     if (!micro_desc_ok(d) || T < 0) return 0;
-    return (size_t)T * d->n_lanes * ((d->capacity + 63) & ~63) * sizeof(float4);
+    return (size_t)T * d->n_lanes * ((d->capacity + 63) & ~63) * sizeof(MicroTape3);
 }
 size_t dhts_micro_step_tape_bytes(const dhts_micro_desc *d) {
     if (!micro_desc_ok(d)) return 0;

@@ -157,9 +157,10 @@ typedef struct dhts_micro_desc {
 #define DHTS_MICRO_MAX_VEHICLES 1024
 #define DHTS_MICRO_NPARAM 6 /* accel_max, accel_pref, target_speed, min_space, time_pref, length (micro_vehicle.py:21-28) */
 
-/* bytes of Jacobian tape for T fused steps (dhts_micro_rollout_*): [step][lane][Vp][4] float32 = the second rows of
- * dEgo and dLeading of every vehicle (16 B per vehicle-step); their first rows are the constants [1, dt] and [0, 0]
- * (didm.py:38-103), which the reverse sweep re-inserts, so results equal those of the 32-byte dqs[a][2][2][2] tape */
+/* bytes of Jacobian tape for T fused steps (dhts_micro_rollout_*): [step][lane][Vp][3] float32 = (dEgo[1][0], dEgo[1][1],
+ * dLeading[1][1]) of every vehicle (12 B per vehicle-step).  The first rows of both blocks are the constants [1, dt] and
+ * [0, 0], and dLeading[1][0] = -dEgo[1][0] bit for bit (didm.py:38-103); the reverse sweep re-inserts them, so results equal
+ * those of the 32-byte dqs[a][2][2][2] tape */
 size_t dhts_micro_tape_bytes(const dhts_micro_desc *d, int T);
 /* bytes of the single-step operator's tape (dhts_micro_step_*): [lane][2][Vp][4] float32, plane k = dqs[a][k] */
 size_t dhts_micro_step_tape_bytes(const dhts_micro_desc *d);

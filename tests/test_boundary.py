@@ -40,7 +40,7 @@ def test_tape_bytes_match_documented_layout():
     assert lib.dhts_macro_tape_bytes(C.byref(d), 1000) == 1000 * 1024 * 2 * 520 * 16    # 32 B per interface-step, 513 -> 520
     assert lib.dhts_macro_step_tape_bytes(C.byref(d)) == 1024 * 3 * 512 * 16           # 48 B per cell (the reference's dqs)
     m = _lib.MicroDesc(4096, 256, 0.01)
-    assert lib.dhts_micro_tape_bytes(C.byref(m), 1000) == 1000 * 4096 * 256 * 16        # 16 B per vehicle-step
+    assert lib.dhts_micro_tape_bytes(C.byref(m), 1000) == 1000 * 4096 * 256 * 12        # 12 B per vehicle-step
     assert lib.dhts_micro_step_tape_bytes(C.byref(m)) == 4096 * 2 * 256 * 16            # 32 B per vehicle (the reference's dqs)
     bad = _lib.MacroDesc(0, 512, 0.01, 5.0, 30.0)
     assert lib.dhts_macro_tape_bytes(C.byref(bad), 10) == 0
