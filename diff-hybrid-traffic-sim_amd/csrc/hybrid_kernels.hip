@@ -444,7 +444,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 const long long n = run_cnt + tid + vcp[c_mb] + 1;
                 const double pin = run_in + base_a + incl[tid] + vsp[c_mb];
                 const double pout = run_out + base_b + incl[C + tid] + vep[c_mb];
-                const double mean = n > kWindow ? (pin - pout) / (double)kWindow : pin / (double)n;
+                const bool full = n > kWindow;             // one IEEE division, operands selected first
+                const double mean = (full ? pin - pout : pin) / (full ? (double)kWindow : (double)n);
                 const float kk = 16.f / fabsf((float)mean);
                 kc_r[(size_t)ls * C + tid] = kk;
                 contrib[tid] = soft_switch(x_new, kk) * (st[tid] * c_dxv);
@@ -474,7 +475,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                         const int vi = lane_veh[k * kLaneCap + i];
                         const float x = s0f - vv[vi];
                         pa += (double)x; pb += (double)vxold[vi]; ++n;
-                        const double mean = n > kWindow ? (pa - pb) / (double)kWindow : pa / (double)n;
+                        const bool full = n > kWindow;
+                        const double mean = (full ? pa - pb : pa) / (full ? (double)kWindow : (double)n);
                         const float kk = 16.f / fabsf((float)mean);
                         const float z = x * kk;
                         const float zc = fminf(fmaxf(z, -16.f), 16.f);
