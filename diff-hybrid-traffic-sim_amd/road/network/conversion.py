@@ -30,7 +30,7 @@ class Conversion:
         r, _, u = prev_lane.get_state_vector()
         prev_lane.add_flux_capacitor(next_lane.id, r[-1] * u[-1] * delta_time)
         stored = prev_lane.flux_capacitor[next_lane.id]
-        level = float(stored)
+        level = float(stored.detach()) if isinstance(stored, th.Tensor) else float(stored)
         nv = MicroVehicle.default_micro_vehicle(next_lane.speed_limit)
         if level >= nv.length and float(next_lane.entering_free_space()) >= nv.length * 1.0:
             nv.position = 0
