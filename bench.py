@@ -119,8 +119,15 @@ class MacroWorkload:
             el = time.perf_counter() - t0
             if el >= 10.0:
                 break
+        # the same code on one core: a single lane leaves the OpenMP loop over lanes with one iteration
+        one, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 2.0:
+            f1 = O.macro_rollout_fwd(r0[:1], u0[:1], gr[:1], gu[:1], T, self.dt, self.dx, self.um)
+            O.macro_rollout_bwd(f1, g_rT=2 * f1["rT"], g_uT=2 * f1["uT"])
+            one += N * T
         return {"value": done / el, "unit": "cell-steps/s", "cores": cores, "kind": "port",
-                "sample": "%d lanes x %d cells x %d steps fwd+bwd, repeated %.1f s (OpenMP over lanes)" % (Lc, N, T, el)}
+                "sample": "%d lanes x %d cells x %d steps fwd+bwd, repeated %.1f s (OpenMP over lanes)" % (Lc, N, T, el),
+                "one_core_value": one / (time.perf_counter() - t1)}
 
 
 class MicroWorkload:
@@ -189,8 +196,14 @@ class MicroWorkload:
             el = time.perf_counter() - t0
             if el >= 10.0:
                 break
+        one, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 2.0:
+            f1 = O.micro_rollout_fwd(p0[:1], v0[:1], par[:1], T, self.dt)
+            O.micro_rollout_bwd(f1, g_pT=2e-4 * f1["pT"], g_vT=2 * f1["vT"])
+            one += V * T
         return {"value": done / el, "unit": "cell-steps/s", "cores": cores, "kind": "port",
-                "sample": "%d lanes x %d vehicles x %d steps fwd+bwd, repeated %.1f s (OpenMP over lanes)" % (Lc, V, T, el)}
+                "sample": "%d lanes x %d vehicles x %d steps fwd+bwd, repeated %.1f s (OpenMP over lanes)" % (Lc, V, T, el),
+                "one_core_value": one / (time.perf_counter() - t1)}
 
 
 class ItscpMacroWorkload:

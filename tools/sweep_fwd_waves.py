@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 w = bench.MacroWorkload(dev, 0, L, N, 1000)
-for waves in (0, 1, 2, 3, 4, 5, 8):
+for waves in (0, 2, 3, 4, 5, 6, 7, 8):
     _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_WAVES, waves)
     w.ev = []
     for _ in range(2):
