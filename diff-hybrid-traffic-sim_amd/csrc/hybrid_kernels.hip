@@ -40,7 +40,8 @@ constexpr int kRouteStride = 32;     // MAX_ROUTE_LENGTH, road_network.py:17
 constexpr int kLaneLocals = 192;     // temporaries per lane of the micro wave and step
 constexpr int kEventLocals = 64;     // temporaries of the serial event walk per step
 constexpr int kMaxLocals = 64 * kLaneLocals + kEventLocals;
-constexpr int kStage = 96;           // staged records per lane and flush
+constexpr int kStage = 96;           // staging slots per lane: two blocks of kStageH (the block being filled, the block being flushed)
+constexpr int kStageH = 48;          // records a lane can stage per step
 constexpr int kPhases = 3;           // record segments per block: head gaps + previous step's loss seeds + IDM |
                                      // capacitors + events + commits | (spare)
 constexpr int kMaxStepRecords = 1024;
@@ -89,7 +90,7 @@ struct Rec {               // one lane's handle on its staging area (LDS) and it
     bool over;
 };
 __device__ __forceinline__ void rec_push(Rec &R, int kind, int out, int4 in, float4 w) {
-    if (R.cnt >= kStage) { R.over = true; return; }
+    if (R.cnt >= kStageH) { R.over = true; return; }
     const int c = R.cnt++;
     R.sk[c] = (kind << 24) | (out & 0xffffff);
     *reinterpret_cast<int4 *>(R.si + 4 * c) = in;
@@ -211,7 +212,7 @@ __device__ __forceinline__ float stream_load(const float *p) {
 struct HybLds {
     size_t fq, scanw, incl, vsp, vep, s0, s1, g, ab, contrib, ql, sig, lanelen, vp, vv, va, vxold, hdpv, hdvv, capv, qmicro,
         cell_lane, iface_lane, cnext, vidp, vidv, vida, vcur, vrlen, vroute, lane_n, lane_veh, hdpi, hdvi, vcp, capi, mslot,
-        capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, stg_k, stg_i, stg_w, total;
+        capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, stg_k, stg_i, stg_w, cnt_s, total;
 };
 __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS) {
     HybLds o; size_t p = 0; const int NI = C + L;
@@ -226,6 +227,7 @@ __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS) {
     o.hdpi = F(kMaxMicro); o.hdvi = F(kMaxMicro); o.vcp = F(kMaxMicro + 1); o.capi = F(kMaxCaps); o.mslot = F(L); o.capof = F(L);
     o.mlane = F(kMaxMicro); o.cbefore = F(kMaxMicro + 1); o.convlist = F(L); o.linfo = F(L); o.caplast = F(kMaxCaps); o.rused = F(kMaxMicro); o.caplane = F(kMaxCaps); o.capleaf = F(kMaxCaps);
     o.stg_k = F((size_t)NS * kStage); o.stg_i = F((size_t)NS * kStage * 4); o.stg_w = F((size_t)NS * kStage * 4);
+    o.cnt_s = F(2 * kPhases * 64);
     o.total = p;
     return o;
 }
@@ -257,6 +259,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     int *vcur = LI(vcur), *vrlen = LI(vrlen), *vroute = LI(vroute), *lane_n = LI(lane_n), *lane_veh = LI(lane_veh), *hdpi = LI(hdpi), *hdvi = LI(hdvi);
     int *vcp = LI(vcp), *capi = LI(capi), *mslot = LI(mslot), *capof = LI(capof), *mlane = LI(mlane), *cbefore = LI(cbefore), *convlist = LI(convlist), *linfo = LI(linfo), *caplast = LI(caplast), *rused = LI(rused), *caplane = LI(caplane), *capleaf = LI(capleaf);
     int *stg_k = LI(stg_k), *stg_i = LI(stg_i); float *stg_w = LF(stg_w);
+    int *cnt_s = LI(cnt_s);                        // [2 blocks][kPhases][64 lanes] staged record counts, micro wave -> flush wave
     const float um = (float)um_d, s0f = (float)static_speed, vlen = (float)veh_len, dtf = (float)dt;
     // the replica's action vector is read every step by the signal threads: staged in LDS (behind the carve-up)
     float *act = reinterpret_cast<float *>(lds + lo.total);
@@ -348,43 +351,60 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     float4 *grw = reinterpret_cast<float4 *>(wsr + ws.rec_w);
     const int base_local = 3 * V + kMaxCaps;
     Rec rec;
-    {
+    rec.next_local = base_local; rec.over = false;
+    auto rec_select = [&](int b) {                   // this lane's staging half `b`, empty
         const int sl = (in_mw && mw < NS) ? mw : 0;
-        rec.sk = stg_k + sl * kStage; rec.si = stg_i + sl * kStage * 4; rec.sw = stg_w + sl * kStage * 4;
-        rec.cnt = 0; rec.next_local = base_local; rec.over = false;
-    }
-    int rec_n = 0, step_start = 0;                   // records of this replica in HBM so far (uniform over the micro wave)
+        rec.sk = stg_k + (sl * 2 + b) * kStageH; rec.si = stg_i + (sl * 2 + b) * kStageH * 4; rec.sw = stg_w + (sl * 2 + b) * kStageH * 4;
+        rec.cnt = 0;
+    };
+    rec_select(0);
+    // The records a step stages are flushed to HBM by ANOTHER wavefront (the one in front of the micro wave, which has little
+    // to do beside the ghosts) while the micro wave already stages the next step's records in the other half.
+    const bool is_fw = (tid >> 6) == (B >> 6) - 2;
+    const int fl = tid & 63;
+    int rec_n = 0;                                   // records of this replica in HBM so far (flush wave, uniform)
+    bool fl_fault = false;
     int spawned = 0, deposits = 0; bool cap_fault = false;
     IdmParams idm;
     idm.a_max = um_d * 1.0; idm.a_pref = um_d * 0.8; idm.v_target = um_d * 0.9; idm.min_space = veh_len * 0.1; idm.time_pref = 0.1; idm.length = veh_len;
     double sig_sum = 0.; long long sig_cnt = 0;          // signal_rms (never reaches its window in one episode)
     if (is_mt) for (int j = 0; j < kMaxCaps; ++j) { capv[j] = 0.f; capi[j] = -1; }
     __syncthreads();
-    // flush the staged records of all lanes to HBM in lane order, note the per-lane counts (micro wave, convergent)
-    // end of a step: all lanes' staged records go to HBM in lane order (coalesced), each lane's block holding its three
-    // segments (head gaps + IDM | capacitors + events | loss + commits) back to back; the per-lane segment counts go to
-    // the index (micro wave, convergent)
+    // end of a step (micro wave): every lane's three segment counts (head gaps + seeds + IDM | capacitors + events |
+    // commits) go to LDS and the lane turns to its other staging half
     int seg_a = 0, seg_b = 0;                        // this lane's staged records at the end of the first / second segment
-    auto flush = [&](int t) {
-        const int c = (mw < NS) ? rec.cnt : 0;
+    auto publish = [&](int blk) {
+        const int b = blk & 1;
+        cnt_s[(b * kPhases + 0) * 64 + mw] = mw < NS ? seg_a : 0;
+        cnt_s[(b * kPhases + 1) * 64 + mw] = mw < NS ? seg_b - seg_a : 0;
+        cnt_s[(b * kPhases + 2) * 64 + mw] = mw < NS ? rec.cnt - seg_b : 0;
+        rec_select(b ^ 1);
+    };
+    // flush wave, one barrier later: block `blk` goes to HBM in lane order (coalesced), each lane's three segments back to
+    // back; the per-lane segment counts go to the index
+    auto flush_block = [&](int blk) {
+        const int b = blk & 1;
+        const int c0 = cnt_s[(b * kPhases + 0) * 64 + fl], c1 = cnt_s[(b * kPhases + 1) * 64 + fl], c2 = cnt_s[(b * kPhases + 2) * 64 + fl];
+        const int c = c0 + c1 + c2;
         const int inc = wave_scan_add(c);
         const int total = wave_last(inc), exc = inc - c;
-        seg_cnt[((size_t)t * kPhases + 0) * 64 + mw] = (unsigned short)(mw < NS ? seg_a : 0);
-        seg_cnt[((size_t)t * kPhases + 1) * 64 + mw] = (unsigned short)(mw < NS ? seg_b - seg_a : 0);
-        seg_cnt[((size_t)t * kPhases + 2) * 64 + mw] = (unsigned short)(mw < NS ? c - seg_b : 0);
-        if (rec_n + total > ws.rec_cap) cap_fault = true;
+        if (fl == 0) step_off[blk] = rec_n;
+        seg_cnt[((size_t)blk * kPhases + 0) * 64 + fl] = (unsigned short)c0;
+        seg_cnt[((size_t)blk * kPhases + 1) * 64 + fl] = (unsigned short)c1;
+        seg_cnt[((size_t)blk * kPhases + 2) * 64 + fl] = (unsigned short)c2;
+        if (rec_n + total > ws.rec_cap) fl_fault = true;
         else if (total > 0) {
             // output slot o <- (staging lane, index): the owner is found with register traffic only, then every slot of the
             // step moves in one batch of LDS reads and global stores
             const unsigned long long mask0 = __ballot(c > 0);
-            for (int o = mw; o < ((total + 63) & ~63); o += 64) {
+            for (int o = fl; o < ((total + 63) & ~63); o += 64) {
                 int q = -1;
                 unsigned long long mask = mask0;
                 while (mask) {
                     const int s_ = __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1);
                     mask &= mask - 1;
                     const int cs = __builtin_amdgcn_readlane(c, s_), os = __builtin_amdgcn_readlane(exc, s_);
-                    if (o >= os && o < os + cs) q = s_ * kStage + (o - os);
+                    if (o >= os && o < os + cs) q = (s_ * 2 + b) * kStageH + (o - os);
                 }
                 if (q >= 0) {
                     grk[rec_n + o] = stg_k[q];
@@ -394,7 +414,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             }
             rec_n += total;
         }
-        rec.cnt = 0;
+        if (total > kMaxStepRecords) fl_fault = true;
     };
 
     double run_in = 0., run_out = 0.; long long run_cnt = 0;
@@ -510,13 +530,6 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             lane_total = lane_total + (-1.0f) * term;
         }
     };
-    auto end_block = [&](int blk) {                  // micro wave: the staged records of step `blk` go to HBM
-        if (is_mt) step_off[blk] = rec_n;
-        step_start = rec_n;
-        flush(blk);
-        if (rec_n - step_start > kMaxStepRecords) cap_fault = true;
-    };
-
     for (int t = 0; t < T; ++t) {
         const float *cur = (t & 1) ? S1 : S0;
         float *nxt = (t & 1) ? S0 : S1;
@@ -555,8 +568,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
         }
         if (t > 0) loss_scan(cur);
+        if (is_fw && t > 0) flush_block(t - 1);
         if (in_mw) {
-            if (t > 0) end_block(t - 1);
             {   // head gaps of the occupied micro lanes (they only feed the IDM steps below)
                 rec.next_local = base_local + mw * kLaneLocals;
                 const int k = mw;
@@ -859,6 +872,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 const double is_ = wave_scan_add(ssum), ie_ = wave_scan_add(esum);
                 if (k <= n_micro) { vcp[k] = exc; vsp[k] = is_ - ssum; vep[k] = ie_ - esum; }
             }
+            publish(t);
         }
         lds_barrier();
     }
@@ -866,25 +880,27 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     if (T > 0) {
         const float *fin = (T & 1) ? S1 : S0;
         loss_scan(fin);
-        if (in_mw) end_block(T - 1);
+        if (is_fw) flush_block(T - 1);
         __syncthreads();
         loss_consts(fin, T - 1);
         if (in_mw) {
             seg_a = 0; seg_b = 0;
             micro_loss(T - 1);
             seg_a = rec.cnt; seg_b = rec.cnt;
-            end_block(T);
+            publish(T);
         }
         run_update();
         __syncthreads();
+        if (is_fw) flush_block(T);
         loss_lanes(T - 1);
     }
+    if (is_fw) {
+        if (fl == 0) { step_off[T + 1] = rec_n; counts[4 * rep + 2] = rec_n; }
+        if (fl_fault) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, rec_n);
+    }
     if (in_mw) {
-        if (is_mt) {
-            step_off[T + 1] = rec_n;
-            counts[4 * rep + 0] = spawned; counts[4 * rep + 1] = deposits; counts[4 * rep + 2] = rec_n; counts[4 * rep + 3] = 0;
-        }
-        if (rec.over || cap_fault) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, rec_n);
+        if (is_mt) { counts[4 * rep + 0] = spawned; counts[4 * rep + 1] = deposits; counts[4 * rep + 3] = 0; }
+        if (rec.over || cap_fault) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, 0);
     }
     if (is_lane) ql[tid] = lane_total;
     __syncthreads();
