@@ -270,8 +270,8 @@ int dhts_net_macro_rollout_bwd(const dhts_net_desc *d, const dhts_net_tables *t,
  *   route_ptr[m] .. route_ptr[m+1] start on micro lane m): the k-th vehicle spawned onto lane m takes row
  *   route_ptr[m] + k mod (rows of m).  The reference draws a route with np.random at spawn time (road_network.py:604-646);
  *   callers pre-draw them (dhts/network.py: group_routes keeps a recorded spawn order intact).
- * Limits: n_cells + n_lanes <= 960, <= 24 micro lanes, <= 16 spawning lanes, <= 16 vehicles per micro lane,
- * <= 128 vehicles per replica and episode, route_stride <= 32; records_per_step (average budget of the record stream,
+ * Limits: n_cells + n_lanes <= 960, <= 24 micro lanes, <= 16 spawning lanes, <= 16 vehicles per micro lane, <= 48 tape
+ * records per micro lane and step (DHTS_FAULT_CAPACITY beyond), <= 128 vehicles per replica and episode, route_stride <= 32; records_per_step (average budget of the record stream,
  * 0 = 512).  loss_steps: only the first loss_steps steps enter reward_cut and the gradient (<= 0: all).
  */
 typedef struct dhts_hybrid_tables {
