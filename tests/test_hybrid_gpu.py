@@ -185,6 +185,24 @@ def test_hybrid_random_actions_vs_oracle(cuda, golden_dir, oracle, name, seed):
     assert worst <= 0.2 * TOL_GRAD, worst
 
 
+def test_exhausted_record_stream_is_a_loud_fault(cuda, golden_dir):
+    """A record stream budget far below what the episode writes (records_per_step = 1): DHTS_FAULT_CAPACITY comes back as
+    RuntimeError instead of a silently truncated tape (include/dhts.h: dhts_hybrid_tables.records_per_step)."""
+    import torch
+    from dhts import ops
+    g = np.load(os.path.join(golden_dir, "itscp_hybrid_short.npz"))
+    t, m = itscp_hybrid_tables(g)
+    args = (m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"],
+            m["speed_limit"], m["static_speed"], m["vehicle_length"])
+    a = torch.tensor(g["action"][None, :], device=cuda)
+    small = ops.DeviceHybridTables(t, g["spawn_routes"], cuda, records_per_step=1)
+    with pytest.raises(RuntimeError, match="capacity"):
+        ops.net_hybrid_rollout(a, small, *args)
+    ok = ops.DeviceHybridTables(t, g["spawn_routes"], cuda)
+    _, reward, _, counts = ops.net_hybrid_rollout(a, ok, *args)                  # the error record does not stick to the library
+    assert abs(float(reward[0]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"])) and int(counts[0, 0]) == m["n_vehicle_spawned"]
+
+
 def test_larger_network_vs_oracle(cuda, oracle):
     """A network the goldens do not cover (3 x 3 intersections, 15 m lanes: more cells than fit a 512-thread workgroup, so
     the 1024-thread build of the kernels runs), tables straight from the environment classes, against the CPU restatement."""
