@@ -240,6 +240,8 @@ def test_larger_network_vs_oracle(cuda, oracle):
         assert o["rc"] == 0 and (int(counts[k, 0]), int(counts[k, 1])) == (o["n_spawned"], o["n_deposits"]), k
         assert rel_max(queue[k].cpu().numpy(), o["queue"]) <= 1e-4, k
         assert abs(float(reward[k]) - o["reward"]) <= 1e-5 * abs(o["reward"]), k
-        assert np.abs(a.grad[k].cpu().numpy() - o["g_action"]).max() <= 2e-3 * np.abs(o["g_action"]).max(), k
+        err_k = np.abs(a.grad[k].cpu().numpy() - o["g_action"]).max() / np.abs(o["g_action"]).max()
+        print("larger network, action %d: gradient vs oracle %.2e" % (k, err_k))
+        assert err_k <= TOL_GRAD, k
         spawned += o["n_spawned"]
     assert spawned > 0

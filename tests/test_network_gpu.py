@@ -75,3 +75,34 @@ def test_network_replica_batch_vs_oracle(cuda, oracle, golden_dir):
         o = oracle.net_macro(tabs[r], acts[r], sq, F, dt, um)
         assert abs(float(reward3[r]) - o["reward"]) <= 1e-5 * max(abs(o["reward"]), 1e-6)
         assert rel_max(a3.grad[r].cpu().numpy(), o["g_action"]) <= TOL_GRAD
+
+
+def test_multi_intersection_network_vs_oracle(cuda, oracle):
+    """2 x 2 intersections (four signal entries per phase; lanes gated by another intersection's signal), tables straight
+    from the environment classes: the kernels' per-intersection signal table and action reduction against the oracle."""
+    import torch
+    from dhts import ops
+    from dhts.network import MacroNetworkTables
+    from example.control.itscp._env import ItscpEnv
+    from example.control.itscp.problem import problem_3
+    np.random.seed(77)
+    env = ItscpEnv()
+    env.schedule_callback = problem_3
+    for k, v in dict(num_intersection=2, lane_length=10.0, num_lane=2, policy_length=4, signal_length=1, mode="macro",
+                     speed_limit=60.0).items():
+        env.config[k] = v
+    env.reset()
+    tab = MacroNetworkTables.from_env(env)
+    sq, F, dt, um = 4, env.config["signal_length"] * env.config["simulation_frequency"], 1.0 / env.config["simulation_frequency"], 60.0
+    assert env.action_size() == 4 * sq and tab.n_cells * env.num_timestep <= 100000
+    rng = np.random.default_rng(9)
+    acts = rng.uniform(0.1, 0.9, (5, env.action_size())).astype(np.float32)
+    a = torch.tensor(acts, device=cuda, requires_grad=True)
+    reward, queue = ops.net_macro_rollout(a, ops.DeviceNetTables(tab, cuda), sq, F, dt, um)
+    reward.sum().backward()
+    for k in range(len(acts)):
+        o = oracle.net_macro(tab, acts[k], sq, F, dt, um)
+        assert rel_max(queue[k].cpu().numpy(), o["queue"]) <= TOL_STATE, k
+        assert abs(float(reward[k]) - o["reward"]) <= 1e-5 * abs(o["reward"]), k
+        assert rel_max(a.grad[k].cpu().numpy(), o["g_action"]) <= TOL_GRAD, k
+        assert np.count_nonzero(o["g_action"]) >= 8, k            # several intersections and phases carry gradient
