@@ -106,22 +106,13 @@ __global__ __launch_bounds__(512) void macro_rollout_fwd_kernel(
         float4 *tp = tape ? tape + ((size_t)step * L + lane) * tape_row : nullptr;
         float *hp = hist ? hist + ((size_t)step * L + lane) * 3 * N : nullptr;
         if (K > 0) {
-            // state of the pass about to run, read one pass ahead
-            int ip = lo + ((K - 1) << 6) + t;
-            ip = ip <= hi ? ip : hi;
-            float pL0 = Sr[ip], pL1 = Sy[ip], pL2 = Su[ip], pL3 = Sq[ip];
-            float pR0 = Sr[ip + 1], pR1 = Sy[ip + 1], pR2 = Su[ip + 1], pR3 = Sq[ip + 1];
             for (int j = K - 1; j >= 0; --j) {
                 const int i = lo + (j << 6) + t;   // interface i, and cell i to its right
                 const bool vi = i <= hi;
                 const bool vc = i < hi;
-                const double rL = pL0, yL = pL1, uL = pL2, qL = pL3;
-                const double rR = pR0, yR = pR1, uR = pR2, qR = pR3;
-                if (j > 0) {
-                    const int in = i - 64;         // always <= hi
-                    pL0 = Sr[in]; pL1 = Sy[in]; pL2 = Su[in]; pL3 = Sq[in];
-                    pR0 = Sr[in + 1]; pR1 = Sy[in + 1]; pR2 = Su[in + 1]; pR3 = Sq[in + 1];
-                }
+                const int ip = vi ? i : hi;
+                const double rL = Sr[ip], yL = Sy[ip], uL = Su[ip], qL = Sq[ip];
+                const double rR = Sr[ip + 1], yR = Sy[ip + 1], uR = Su[ip + 1], qR = Sq[ip + 1];
                 Iface f;
                 arz_interface(rL, yL, uL, qL, rR, yR, uR, qR, kc, f);
                 // CFL: dt < dx / max(|speed|, 1e-5) for both speeds (_macro_lane.py:141-146)
