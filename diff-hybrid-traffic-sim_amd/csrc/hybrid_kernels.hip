@@ -212,7 +212,7 @@ __device__ __forceinline__ float stream_load(const float *p) {
 struct HybLds {
     size_t fq, scanw, incl, vsp, vep, s0, s1, g, ab, contrib, ql, sig, lanelen, vp, vv, va, vxold, hdpv, hdvv, capv, qmicro,
         cell_lane, iface_lane, cnext, vidp, vidv, vida, vcur, vrlen, vroute, lane_n, lane_veh, hdpi, hdvi, vcp, capi, mslot,
-        capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, stg_k, stg_i, stg_w, cnt_s, total;
+        capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, stg_k, stg_i, stg_w, cnt_s, lfl, total;
 };
 __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS) {
     HybLds o; size_t p = 0; const int NI = C + L;
@@ -227,7 +227,7 @@ __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS) {
     o.hdpi = F(kMaxMicro); o.hdvi = F(kMaxMicro); o.vcp = F(kMaxMicro + 1); o.capi = F(kMaxCaps); o.mslot = F(L); o.capof = F(L);
     o.mlane = F(kMaxMicro); o.cbefore = F(kMaxMicro + 1); o.convlist = F(L); o.linfo = F(L); o.caplast = F(kMaxCaps); o.rused = F(kMaxMicro); o.caplane = F(kMaxCaps); o.capleaf = F(kMaxCaps);
     o.stg_k = F((size_t)NS * kStage); o.stg_i = F((size_t)NS * kStage * 4); o.stg_w = F((size_t)NS * kStage * 4);
-    o.cnt_s = F(2 * kPhases * 64);
+    o.cnt_s = F(2 * kPhases * 64); o.lfl = F(L);
     o.total = p;
     return o;
 }
@@ -259,6 +259,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     int *vcur = LI(vcur), *vrlen = LI(vrlen), *vroute = LI(vroute), *lane_n = LI(lane_n), *lane_veh = LI(lane_veh), *hdpi = LI(hdpi), *hdvi = LI(hdvi);
     int *vcp = LI(vcp), *capi = LI(capi), *mslot = LI(mslot), *capof = LI(capof), *mlane = LI(mlane), *cbefore = LI(cbefore), *convlist = LI(convlist), *linfo = LI(linfo), *caplast = LI(caplast), *rused = LI(rused), *caplane = LI(caplane), *capleaf = LI(capleaf);
     int *stg_k = LI(stg_k), *stg_i = LI(stg_i); float *stg_w = LF(stg_w);
+    int *lfl = LI(lfl);                            // per lane: first cell | last cell << 16
     int *cnt_s = LI(cnt_s);                        // [2 blocks][kPhases][64 lanes] staged record counts, micro wave -> flush wave
     const float um = (float)um_d, s0f = (float)static_speed, vlen = (float)veh_len, dtf = (float)dt;
     // the replica's action vector is read every step by the signal threads: staged in LDS (behind the carve-up)
@@ -284,6 +285,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         for (int i = 0; i < n; ++i) cell_lane_s[off + i] = tid;
         lanelen[tid] = (float)tb.lane_len[tid];
         linfo[tid] = tb.net.sig_kind[tid] | (tb.net.inter[tid] << 2);
+        lfl[tid] = off | ((off + n - 1) << 16);
         ql[tid] = 0.f;
     }
     if (tid < C) {
@@ -545,7 +547,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     fr = (float)sched; fu = (float)gu; fy = 0.f; fq = (float)gu;
                 } else {
                     float gr = 0.f, gu = um;             // src == -3: own stored ghost behind a red gate
-                    if (src >= 0) { const int last = tb.net.lane_off[src] + tb.net.lane_ncell[src] - 1; gr = cur[last]; gu = cur[2 * C + last]; }
+                    if (src >= 0) { const int last = lfl[src] >> 16; gr = cur[last]; gu = cur[2 * C + last]; }
                     float s = 1.f;
                     if (gate == -1) s = 0.f;
                     else if (gate >= 0) { const int kd = linfo[gate] & 3; if (kd != 0) s = sig[2 * (linfo[gate] >> 2) + (kd - 1)]; }
@@ -555,7 +557,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 }
             } else {
                 float gr = own_r, gu = own_u;
-                if (src >= 0) { const int first = tb.net.lane_off[src]; gr = cur[first]; gu = cur[2 * C + first]; }
+                if (src >= 0) { const int first = lfl[src] & 0xffff; gr = cur[first]; gu = cur[2 * C + first]; }
                 own_w[(size_t)t * 2 * L + 2 * g_lane] = own_r; own_w[(size_t)t * 2 * L + 2 * g_lane + 1] = own_u;
                 const float sg = g_kind != 0 ? sig[2 * g_inter + (g_kind - 1)] : 1.f;
                 const float s2 = soft_switch(sg - 0.5f, kSigK);
@@ -918,7 +920,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
 // reverse
 // ---------------------------------------------------------------------------------------------------------------------
 struct HybLdsB {
-    size_t red, h0, h1, gl, c0, c2, gq, inl, inf, sg, adj, gam, rk, ri, rw, cell_lane, obi, obf, aval, iptr, iidx, total;
+    size_t red, h0, h1, gl, c0, c2, gq, inl, inf, sg, adj, gam, rk, ri, rw, cell_lane, obi, obf, aval, iptr, iidx, lfl, linfo, total;
 };
 __host__ __device__ inline HybLdsB hyb_lds_b(int L, int C, int sq, int V, int E) {
     HybLdsB o; size_t p = 0;
@@ -931,6 +933,7 @@ __host__ __device__ inline HybLdsB hyb_lds_b(int L, int C, int sq, int V, int E)
     o.rk = F(kMaxStepRecords); o.ri = F(4 * (size_t)kMaxStepRecords); o.rw = F(4 * (size_t)kMaxStepRecords);
     o.cell_lane = F(C); o.obi = F(64 * 5); o.obf = F(64 * 5);
     o.aval = F(2 * (size_t)L); o.iptr = F((size_t)sq + 1); o.iidx = F(2 * (size_t)L);
+    o.lfl = F(L); o.linfo = F(L);
     o.total = p;
     return o;
 }
@@ -963,6 +966,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     int *obi = reinterpret_cast<int *>(lds + lo.obi); float *obf = LF(obf);
     float *aval = LF(aval);
     int *iptr = reinterpret_cast<int *>(lds + lo.iptr), *iidx = reinterpret_cast<int *>(lds + lo.iidx);
+    int *lfl = reinterpret_cast<int *>(lds + lo.lfl), *linfo = reinterpret_cast<int *>(lds + lo.linfo);   // lane tables (first | last << 16), (kind | inter << 2)
     const float um = (float)um_d, s0f = (float)static_speed, vlen = (float)veh_len, dtf = (float)dt;
     float *act = reinterpret_cast<float *>(lds + lo.total);      // the replica's action vector, staged in LDS
     for (int i = tid; i < n_action; i += B) act[i] = action[(size_t)rep * n_action + i];
@@ -988,6 +992,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     if (is_lane) {
         const int off = tb.net.lane_off[tid], n = tb.net.lane_ncell[tid];
         for (int i = 0; i < n; ++i) cell_lane_s[off + i] = tid;
+        lfl[tid] = off | ((off + n - 1) << 16);
+        linfo[tid] = tb.net.sig_kind[tid] | (tb.net.inter[tid] << 2);
     }
     for (int k = tid; k < 3 * E; k += B) { inL[k] = 0.f; inF[k] = 0.f; }
     for (int k = tid; k < 2 * L; k += B) aval[k] = 0.f;
@@ -1277,11 +1283,11 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             float tgt = -1.f, add_r = 0.f, add_u = 0.f, a_val = 0.f; int a_key = -1;
             if (g_side == 0) {
                 if (src >= 0) {
-                    const int last = tb.net.lane_off[src] + tb.net.lane_ncell[src] - 1;
+                    const int last = lfl[src] >> 16;
                     const float grn_r = Hc[last], grn_u = Hc[2 * C + last];
                     float s = 1.f; int kd = 0, it = 0;
                     if (gate == -1) s = 0.f;
-                    else if (gate >= 0) { kd = tb.net.sig_kind[gate]; it = tb.net.inter[gate]; if (kd != 0) s = sg[6 * it + (kd - 1)]; }
+                    else if (gate >= 0) { kd = linfo[gate] & 3; it = linfo[gate] >> 2; if (kd != 0) s = sg[6 * it + (kd - 1)]; }
                     const float fr = grn_r * s + 0.f * (1.0f - s), fu = grn_u * s + um * (1.0f - s);
                     float g_fr = c0[g_off], g_fu = 0.f;
                     glue_y_bwd(fr, fu, um, c0[C + g_off], g_fr, g_fu);
@@ -1290,15 +1296,16 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
                     if (kd != 0) { a_val = (g_fr * grn_r + g_fu * (grn_u - um)) * sg[6 * it + 2 + (kd - 1)]; a_key = it; }
                 }
             } else {
-                const float grn_r = src < 0 ? w_own_r : Hc[tb.net.lane_off[src]];
-                const float grn_u = src < 0 ? w_own_u : Hc[2 * C + tb.net.lane_off[src]];
+                const int first = src < 0 ? 0 : (lfl[src] & 0xffff);
+                const float grn_r = src < 0 ? w_own_r : Hc[first];
+                const float grn_u = src < 0 ? w_own_u : Hc[2 * C + first];
                 const float sgl = g_kind != 0 ? sg[6 * g_inter + (g_kind - 1)] : 1.f;
                 const float s2 = soft_switch(sgl - 0.5f, kSigK);
                 const float fr = s2 * grn_r + (1.0f - s2) * 1.0f, fu = s2 * grn_u + (1.0f - s2) * 0.0f;
                 const int lastc = g_off + g_n - 1;
                 float g_fr = c2[lastc] + gown_r, g_fu = gown_u;      // the blended ghost is also the stored one
                 glue_y_bwd(fr, fu, um, c2[C + lastc], g_fr, g_fu);
-                if (src >= 0) { add_r = g_fr * s2; add_u = g_fu * s2; tgt = (float)tb.net.lane_off[src]; gown_r = 0.f; gown_u = 0.f; }
+                if (src >= 0) { add_r = g_fr * s2; add_u = g_fu * s2; tgt = (float)first; gown_r = 0.f; gown_u = 0.f; }
                 else { gown_r = g_fr * s2; gown_u = g_fu * s2; }
                 if (g_kind != 0) {
                     const float g_s2 = g_fr * (grn_r - 1.0f) + g_fu * grn_u;
