@@ -65,7 +65,9 @@ class MacroWorkload:
         gy, gq = ops.macro_state_from_ru(gr, gu, self.um)
         self.ghost = torch.stack([gr, gy, gu, gq], dim=-1).contiguous()
         self.desc = ops.macro_desc(L, N, self.dt, self.dx, self.um)
-        self.tape = torch.empty(ops.macro_tape_numel(self.desc, T), dtype=torch.float32, device=dev)
+        # zeros, not empty: the first touch of 17 GB would otherwise be billed to the first warm-up launch (and to the average
+        # of a rocprofv3 --stats run of this command)
+        self.tape = torch.zeros(ops.macro_tape_numel(self.desc, T), dtype=torch.float32, device=dev)
         self.err = ops.new_error_record(dev)
         self.out = tuple(torch.empty(L, N, device=dev) for _ in range(4))
         self.gout = (torch.empty(L, N, device=dev), torch.empty(L, N, device=dev))
@@ -148,7 +150,7 @@ class MicroWorkload:
         self.params = par[:, None, None].expand(6, L, V).contiguous()
         self.head = torch.tensor([[1000.0, 0.0]], dtype=torch.float64, device=dev).expand(L, 2).contiguous()
         self.desc = ops.micro_desc(L, V, self.dt)
-        self.tape = torch.empty(ops.micro_tape_numel(self.desc, T), dtype=torch.float32, device=dev)
+        self.tape = torch.zeros(ops.micro_tape_numel(self.desc, T), dtype=torch.float32, device=dev)
         self.err = ops.new_error_record(dev)
         self.out = (torch.empty(L, V, device=dev), torch.empty(L, V, device=dev))
         self.gout = (torch.empty(L, V, device=dev), torch.empty(L, V, device=dev))
