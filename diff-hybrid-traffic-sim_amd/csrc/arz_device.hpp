@@ -110,6 +110,8 @@ struct IfaceDebug {  // intermediate results exported only by the known-answer e
 
 struct IfaceConst {  // per-launch constants
     double um, inv_um, inv_15um, dt, dx;
+    double cfl_lim;      // dx / dt (production path: |speed| < dx / dt instead of dt * |speed| < dx)
+    __host__ __device__ void set_grid(double dt_, double dx_) { dt = dt_; dx = dx_; cfl_lim = dx_ / dt_; }
 };
 
 // Reference-order version: IEEE double division and square root exactly where the reference divides and takes
@@ -308,7 +310,8 @@ __device__ __forceinline__ void arz_interface_fast(double rL, double yL, double 
     const double n0 = (vacL || (same && !vacR)) ? 0.0 : (b4 ? fabs(diff) : fabs(s0_avg));
     const double d0 = b4 ? den : 1.0;
     const double s1 = vacL ? fabs(uL) : ((vacR) ? fabs(s0_avg) : fabs(uR));
-    const bool bad = !(k.dt * fmax(n0, 1e-5 * d0) < k.dx * d0) || !(k.dt * fmax(s1, 1e-5) < k.dx);
+    // dt * max(|speed|, 1e-5) < dx  <=>  |speed| < dx / dt and 1e-5 < dx / dt; the negated forms keep NaN speeds "bad"
+    const bool bad = !(n0 < k.cfl_lim * d0) || !(s1 < k.cfl_lim) || !(1e-5 < k.cfl_lim);
     o.cfl_bad = bad;
 
     // ---- Q_0 (_arz.py:155-199, 316-326), its Jacobians (darz.py:12-192) ----

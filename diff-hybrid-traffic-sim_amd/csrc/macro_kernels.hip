@@ -55,7 +55,7 @@ __device__ __forceinline__ void raise_fault(dhts_error *err, int code, int step,
 // wave ever needs a pass for a single left-over interface; the state is ping-pong buffered in LDS and the only
 // synchronisation is one workgroup barrier per time step.
 template <bool kIface>
-__global__ __launch_bounds__(512) void macro_rollout_fwd_kernel(
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) void macro_rollout_fwd_kernel(
     int L, int N, int T, int p, double dt, double dx, double um,
     const float *__restrict__ r_in, const float *__restrict__ y_in, const float *__restrict__ u_in,
     const float *__restrict__ q_in, const float *__restrict__ ghost,
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512) void macro_rollout_fwd_kernel(
     const float cf = (float)c, ncf = (float)(-c);
     const float umf = (float)um;
     IfaceConst kc;
-    kc.um = um; kc.inv_um = 1.0 / um; kc.inv_15um = 1.0 / (kG1 * um); kc.dt = dt; kc.dx = dx;
+    kc.um = um; kc.inv_um = 1.0 / um; kc.inv_15um = 1.0 / (kG1 * um); kc.set_grid(dt, dx);
     int fault_step = -1, fault_index = 0;
 
     for (int step = 0; step < T; ++step) {
@@ -251,7 +251,7 @@ __global__ void arz_interface_batch_kernel(int64_t n, int variant, const double 
                                            float *__restrict__ A, float *__restrict__ B, int32_t *__restrict__ cfl_bad) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         IfaceConst kc;
-        kc.um = in[8 * n + i]; kc.inv_um = 1.0 / kc.um; kc.inv_15um = 1.0 / (kG1 * kc.um); kc.dt = dt; kc.dx = dx;
+        kc.um = in[8 * n + i]; kc.inv_um = 1.0 / kc.um; kc.inv_15um = 1.0 / (kG1 * kc.um); kc.set_grid(dt, dx);
         Iface f;
         IfaceDebug dbg;
         if (variant == 1)
