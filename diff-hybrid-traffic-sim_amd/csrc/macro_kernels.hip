@@ -365,11 +365,17 @@ static int macro_bwd_launch(const dhts_macro_desc *d, int T, const float *tape,
     return launch_status();
 }
 
+extern int dhts_micro_fwd_waves_override;     // micro_kernels.hip
+
 extern "C" {
 
 int dhts_set_option(int option, int value) {
     if (option == DHTS_OPT_MACRO_FWD_WAVES && value >= 0 && value <= 8) {
         dhts_fwd_waves_override = value;
+        return DHTS_OK;
+    }
+    if (option == DHTS_OPT_MICRO_FWD_WAVES && (value == 0 || value == 1 || value == 2 || value == 4)) {
+        dhts_micro_fwd_waves_override = value;
         return DHTS_OK;
     }
     return DHTS_E_INVALID;

@@ -34,9 +34,11 @@ __device__ __forceinline__ void raise_fault_m(dhts_error *err, int code, int ste
 // both 0 under the acceleration clip (didm.py:38-103) -- 12 bytes per vehicle-step instead of the 32 of dqs[V][2][2][2]
 struct __attribute__((packed, aligned(4))) MicroTape3 { float e2, e3, l3; };
 
-// grid = L workgroups of 64 threads; dynamic LDS = 2 * (V + 1) floats
-template <int K, bool kCompact>
-__global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
+// grid = L workgroups of 64 * kW threads; dynamic LDS = 2 * (V + 1) floats (kW = 1) or twice that (kW > 1: the state
+// ping-pongs between two buffers so that one workgroup barrier per step separates a step's reads from the next step's).
+// kW wavefronts per lane: thread `tid` of pass j owns slot (64 kW) j + tid.
+template <int K, int kW, bool kCompact>
+__global__ __launch_bounds__(64 * kW) void micro_rollout_fwd_kernel(
     int L, int V, int T, double dt,
     const float *__restrict__ p_in, const float *__restrict__ v_in, const int32_t *__restrict__ count,
     const double *__restrict__ params, const double *__restrict__ head,
@@ -45,6 +47,7 @@ __global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
     extern __shared__ float lds[];
     const int lane = blockIdx.x;
     const int t = threadIdx.x;
+    constexpr int kStride = 64 * kW;
     float *Sp = lds, *Sv = lds + (V + 1);
     const size_t base = (size_t)lane * V;
     const int n = count ? count[lane] : V;
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
     const double inv_dt = 1.0 / dt;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        const int i = (j << 6) + t;
+        const int i = j * kStride + t;
         const int ic = i < V ? i : V - 1;
         const int il = (i + 1) < V ? (i + 1) : V - 1;
         IdmParams raw;
@@ -69,8 +72,8 @@ __global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
         prm[j] = idm_derive(raw);
         len_lead[j] = params[5 * plane + base + il];
     }
-    for (int k = t; k < V; k += 64) { Sp[k] = p_in[base + k]; Sv[k] = v_in[base + k]; }
-    if (t == 0) { Sp[V] = 0.f; Sv[V] = 0.f; }
+    for (int k = t; k < V; k += kStride) { Sp[k] = p_in[base + k]; Sv[k] = v_in[base + k]; }
+    if (t == 0) { Sp[V] = 0.f; Sv[V] = 0.f; if (kW > 1) { Sp[2 * (V + 1) + V] = 0.f; Sv[2 * (V + 1) + V] = 0.f; } }
     __syncthreads();
     const double head_dp = head[(size_t)lane * 2], head_dv = head[(size_t)lane * 2 + 1];
     int fault_step = -1, fault_index = 0;
@@ -82,16 +85,19 @@ __global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
         // every pass reads its own and its leaders' OLD state before anything is written, so the K IDM evaluations of a
         // thread are independent instruction streams (a wave's LDS operations execute in order: no barrier is needed
         // between this step's writes and the next step's reads)
+        // kW > 1: read buffer (step & 1), write the other one
+        const float *Rp = Sp + ((kW > 1 && (step & 1)) ? 2 * (V + 1) : 0), *Rv = Sv + ((kW > 1 && (step & 1)) ? 2 * (V + 1) : 0);
+        float *Wp = Sp + ((kW > 1 && !(step & 1)) ? 2 * (V + 1) : 0), *Wv = Sv + ((kW > 1 && !(step & 1)) ? 2 * (V + 1) : 0);
         float rp[K], rv[K], rpl[K], rvl[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const int i = (j << 6) + t;
+            const int i = j * kStride + t;
             const int ic = i < n ? i : 0;
-            rp[j] = Sp[ic]; rv[j] = Sv[ic]; rpl[j] = Sp[ic + 1]; rvl[j] = Sv[ic + 1];
+            rp[j] = Rp[ic]; rv[j] = Rv[ic]; rpl[j] = Rp[ic + 1]; rvl[j] = Rv[ic + 1];
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const int i = (j << 6) + t;
+            const int i = j * kStride + t;
             const bool valid = i < n;
             const double p = rp[j], v = rv[j];
             const double pl = rpl[j], vl = rvl[j];
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
             idm_step(p, v, dp, dv, prm[j], dt, inv_dt, o);
             if (valid) {
                 if (o.collided && fault_step < 0) { fault_step = step; fault_index = i; }
-                Sp[i] = o.np; Sv[i] = o.nv;
+                Wp[i] = o.np; Wv[i] = o.nv;
                 if constexpr (kCompact) {
                     if (tc) { MicroTape3 e; e.e2 = o.dE[2]; e.e3 = o.dE[3]; e.l3 = o.dLd[3]; tc[i] = e; }
                 } else if (tp) {
@@ -116,9 +122,11 @@ __global__ __launch_bounds__(64) void micro_rollout_fwd_kernel(
                 if (hp) { hp[i] = o.np; hp[V + i] = o.nv; }
             }
         }
+        if constexpr (kW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // LDS-only: tape stores stay in flight
     }
     __syncthreads();
-    for (int k = t; k < V; k += 64) { p_out[base + k] = Sp[k]; v_out[base + k] = Sv[k]; }
+    const float *Fp = Sp + ((kW > 1 && (T & 1)) ? 2 * (V + 1) : 0), *Fv = Sv + ((kW > 1 && (T & 1)) ? 2 * (V + 1) : 0);
+    for (int k = t; k < V; k += kStride) { p_out[base + k] = Fp[k]; v_out[base + k] = Fv[k]; }
     if (fault_step >= 0) raise_fault_m(err, DHTS_FAULT_COLLISION, fault_step, lane, fault_index);
 }
 
@@ -221,13 +229,28 @@ static inline bool micro_desc_ok(const dhts_micro_desc *d) {
 }
 static inline int launch_status_m() { return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH; }
 
-template <int K, bool kCompact>
+int dhts_micro_fwd_waves_override = 0;      // DHTS_OPT_MICRO_FWD_WAVES: 0 = heuristic, 1 / 2 / 4 wavefronts per lane
+
+template <int K, int kW, bool kCompact>
 static void launch_micro_fwd(const dhts_micro_desc *d, int T, const float *p, const float *v, const int32_t *count,
                              const double *params, const double *head, float *p_out, float *v_out, float *tape,
                              float *hist, dhts_error *err, hipStream_t s) {
-    const size_t lds = sizeof(float) * 2 * (size_t)(d->capacity + 1);
-    micro_rollout_fwd_kernel<K, kCompact><<<d->n_lanes, 64, lds, s>>>(d->n_lanes, d->capacity, T, d->dt, p, v, count, params, head,
-                                                           p_out, v_out, tape, hist, err);
+    const size_t lds = sizeof(float) * (kW > 1 ? 4 : 2) * (size_t)(d->capacity + 1);
+    micro_rollout_fwd_kernel<K, kW, kCompact><<<d->n_lanes, 64 * kW, lds, s>>>(d->n_lanes, d->capacity, T, d->dt, p, v, count, params,
+                                                                        head, p_out, v_out, tape, hist, err);
+}
+
+// passes per thread for kW wavefronts per lane
+template <int kW, bool kCompact>
+static void dispatch_micro_fwd(const dhts_micro_desc *d, int T, const float *p, const float *v, const int32_t *count,
+                               const double *params, const double *head, float *p_out, float *v_out, float *tape,
+                               float *hist, dhts_error *err, hipStream_t s) {
+    const int K = (d->capacity + 64 * kW - 1) / (64 * kW);
+    if (K <= 1) launch_micro_fwd<1, kW, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    else if (K <= 2) launch_micro_fwd<2, kW, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    else if (K <= 4) launch_micro_fwd<4, kW, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    else if (K <= 8) launch_micro_fwd<8, kW, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    else launch_micro_fwd<16, kW, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
 }
 
 template <bool kCompact>
@@ -236,12 +259,13 @@ static int micro_fwd_launch(const dhts_micro_desc *d, int T,
                             float *p_out, float *v_out, float *tape, float *hist, dhts_error *err, void *stream) {
     if (!micro_desc_ok(d) || T < 0 || !p || !v || !params || !head || !p_out || !v_out) return DHTS_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    const int K = (d->capacity + 63) >> 6;
-    if (K <= 1) launch_micro_fwd<1, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
-    else if (K <= 2) launch_micro_fwd<2, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
-    else if (K <= 4) launch_micro_fwd<4, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
-    else if (K <= 8) launch_micro_fwd<8, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
-    else launch_micro_fwd<16, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    // wavefronts per lane: one wave keeps the whole lane free of barriers; with few lanes per SIMD more waves per lane buy
+    // the latency hiding back (256 CUs x 4 SIMDs x 8 waves)
+    int W = dhts_micro_fwd_waves_override;
+    if (W == 0) W = (d->capacity > 64 && (long long)d->n_lanes * 2 <= 8192) ? 2 : 1;
+    if (W >= 4 && d->capacity > 128) dispatch_micro_fwd<4, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    else if (W >= 2 && d->capacity > 64) dispatch_micro_fwd<2, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    else dispatch_micro_fwd<1, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
     return launch_status_m();
 }
 template <bool kCompact>

@@ -73,6 +73,8 @@ int dhts_device_count(void);
 /* tuning knobs (process-wide, not part of the numerical contract).
  * DHTS_OPT_MACRO_FWD_WAVES: wavefronts per traffic lane in the macro forward kernel, 1..8; 0 = heuristic. */
 #define DHTS_OPT_MACRO_FWD_WAVES 1
+/* DHTS_OPT_MICRO_FWD_WAVES: wavefronts per traffic lane in the micro forward kernel, 1, 2 or 4; 0 = heuristic. */
+#define DHTS_OPT_MICRO_FWD_WAVES 2
 int dhts_set_option(int option, int value);
 /* cells / vehicle slots rounded up to the tape's padded width (multiple of 64) */
 int dhts_padded(int n);

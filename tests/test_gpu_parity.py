@@ -445,13 +445,24 @@ def test_micro_rollout_vs_oracle_sizes(cuda, oracle, V):
     assert rel_max(head.grad.cpu().numpy(), b["g_head"]) <= 1e-4
 
 
-def test_micro_ragged_and_empty_lanes(cuda, oracle):
-    """Per-lane vehicle counts: empty lane, single vehicle, partly filled, full."""
+@pytest.fixture
+def micro_fwd_waves(request):
+    """DHTS_OPT_MICRO_FWD_WAVES for one test: 1 / 2 / 4 wavefronts per lane in the micro forward kernel (0 = heuristic)."""
+    from dhts import _lib
+    assert _lib.lib().dhts_set_option(_lib.OPT_MICRO_FWD_WAVES, request.param) == 0
+    yield request.param
+    _lib.lib().dhts_set_option(_lib.OPT_MICRO_FWD_WAVES, 0)
+
+
+@pytest.mark.parametrize("micro_fwd_waves", [0, 1, 2, 4], indirect=True)
+def test_micro_ragged_and_empty_lanes(cuda, oracle, micro_fwd_waves):
+    """Per-lane vehicle counts: empty lane, single vehicle, partly filled, full -- for every wavefronts-per-lane variant of
+    the forward kernel (T odd and even ends in either ping-pong buffer)."""
     import torch
     from dhts import ops
     rng = np.random.default_rng(9)
-    V, T, dt = 100, 20, 0.01
-    counts = [0, 1, 37, 64, 65, 100]
+    V, T, dt = 200, 20 + (micro_fwd_waves & 1), 0.01
+    counts = [0, 1, 37, 64, 65, 128, 129, 200]
     L = len(counts)
     p0 = (np.arange(V)[None, :] * 20.0 + rng.uniform(0, 10, (L, V))).astype(np.float32)
     v0 = rng.uniform(9, 21, (L, V)).astype(np.float32)
