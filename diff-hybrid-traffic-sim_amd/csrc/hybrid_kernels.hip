@@ -959,7 +959,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     const int V = ws.V;
     const HybLdsB lo = hyb_lds_b(L, C, sq, V, E);
 #define LF(name) reinterpret_cast<float *>(lds + lo.name)
-    float *H0 = LF(h0), *H1 = LF(h1), *gL = LF(gl), *c0 = LF(c0), *c2 = LF(c2), *gq = LF(gq), *inL = LF(inl), *inF = LF(inf);
+    float *H0 = LF(h0), *H1 = LF(h1), *gL = LF(gl), *c0 = LF(c0), *c2 = LF(c2), *inL = LF(inl), *inF = LF(inf);
     float *sg = LF(sg), *adj = LF(adj), *gam = LF(gam), *rw = LF(rw);
     int *rk = reinterpret_cast<int *>(lds + lo.rk), *ri = reinterpret_cast<int *>(lds + lo.ri);
     int *cell_lane_s = reinterpret_cast<int *>(lds + lo.cell_lane);
@@ -1022,8 +1022,6 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         g_kind = tb.net.sig_kind[g_lane]; g_inter = tb.net.inter[g_lane]; g_off = tb.net.lane_off[g_lane]; g_n = tb.net.lane_ncell[g_lane];
         g_macro = tb.lane_macro[g_lane] != 0;
     }
-    bool l_macro = false;
-    if (is_lane) l_macro = tb.lane_macro[tid] != 0;
     // static inbox routing (see network_kernels.hip)
     constexpr int kMaxCand = 4, kMaxEnt = 8;
     int cand_src[kMaxCand], cand_pos[kMaxCand], n_cand = 0;
@@ -1106,7 +1104,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             const float4 *tp = tape_r + (size_t)tt * 3 * Cp;
             p_d0 = tp[f_cell]; p_d1 = tp[Cp + f_cell]; p_d2 = tp[2 * Cp + f_cell];
         }
-        p_q = queue_r[(size_t)tt * L + f_lane];
+        p_q = queue_r[(size_t)tt * L + (is_cell ? c_lane : f_lane)];      // cells: the queue term of their own lane
         {
             const size_t o = toff + (size_t)tt * L + f_glane;
             p_src = f_srcp[o]; p_gate = tb.net.left_gate[o];
@@ -1148,7 +1146,16 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         const float w_kc = p_kc; const float4 d0 = p_d0, d1 = p_d1, d2 = p_d2;
         const int src = p_src, gate = p_gate; const float w_own_r = p_own_r, w_own_u = p_own_u;
         if (is_cell) { Hc[tid] = p_hr; Hc[C + tid] = p_hy; Hc[2 * C + tid] = p_hu; }
-        if (is_lane) gq[tid] = (l_macro && t < loss_steps) ? gscale * (-1.0f) * (float)dt * 2.f * sqrtf(p_q / (float)dt) : 0.f;
+        // loss taps on the state after step t (row t + 1 is in LDS since the previous iteration): d reward / d q_l = -2 q_l dt
+        // with q_l = sqrt(term / dt), evaluated by every cell for its own lane
+        if (is_cell) {
+            const int c = tid;
+            const float gql = t < loss_steps ? gscale * (-1.0f) * (float)dt * 2.f * sqrtf(p_q / (float)dt) : 0.f;
+            const float rr = Hn[c], uu = Hn[2 * C + c];
+            const float x = s0f - uu;
+            gL[c] += gql * soft_switch(x, w_kc) * c_dxv;
+            gL[2 * C + c] += gql * (rr * c_dxv) * (-soft_switch_grad(x, w_kc));
+        }
         if (tid < sq) {
             float we, ns, a, pr; int ai;
             phase_signal_at(act, n_action, sq, F, rev_ph, rev_fr, tid, we, ns, a, pr, ai);
@@ -1182,16 +1189,6 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             }
         }
         fetch(t - 1);
-        lds_barrier();
-        // ================= R1: loss taps on the state after step t =================
-        if (is_cell) {
-            const int c = tid;
-            const float rr = Hn[c], uu = Hn[2 * C + c];
-            const float x = s0f - uu;
-            const float gql = gq[c_lane];
-            gL[c] += gql * soft_switch(x, w_kc) * c_dxv;
-            gL[2 * C + c] += gql * (rr * c_dxv) * (-soft_switch_grad(x, w_kc));
-        }
         lds_barrier();
         // ================= R2: micro records of the loss / hand-off part, newest first =================
         bool used_ob = false;
