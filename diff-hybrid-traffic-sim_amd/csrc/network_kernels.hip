@@ -274,7 +274,7 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
     if (fault_step >= 0) net_fault(err, DHTS_FAULT_CFL, fault_step, i_lane, fault_index);
 }
 
-// reverse: three barriers per step, global reads (history rows, loss constants, tape, queue terms, tables) fetched one step
+// reverse: two barriers per step, global reads (history rows, loss constants, tape, queue terms, tables) fetched one step
 // ahead into registers.
 // LDS floats: H0, H1 [3][C] (history rows r, y, u; ping-pong) | c0, c2 [2][C] | gq [L] | inL, inF [E][2] | doubles red [16][sq]
 // Limits (checked on the host side of the Python layer): a lane has at most 4 upstream and 4 downstream neighbours.
@@ -378,7 +378,7 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
         p_kc = kc_r[(size_t)tt * C + f_cell];
         const float4 *tp = tape_r + (size_t)tt * 3 * Cp;
         p_d0 = tp[f_cell]; p_d1 = tp[Cp + f_cell]; p_d2 = tp[2 * Cp + f_cell];
-        p_q = queue_r[(size_t)tt * L + f_lane];
+        p_q = queue_r[(size_t)tt * L + (is_cell ? c_lane : f_lane)];      // cells: the queue term of their own lane
         const size_t o = toff + (size_t)tt * L + f_glane;
         p_src = f_srcp[o]; p_gate = tb.left_gate[o];
         p_own_r = own_r[(size_t)tt * 2 * L + 2 * f_glane]; p_own_u = own_r[(size_t)tt * 2 * L + 2 * f_glane + 1];
@@ -407,8 +407,6 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
         const float4 d0 = p_d0, d1 = p_d1, d2 = p_d2;
         const int src = p_src, gate = p_gate;
         if (is_cell) { Hc[tid] = p_hr; Hc[C + tid] = p_hy; Hc[2 * C + tid] = p_hu; }
-        // d reward / d q_l = - 2 q_l dt with q_l = sqrt(term / dt)
-        if (is_lane) gq[tid] = gscale * (-1.0f) * (float)dt * 2.f * sqrtf(w_q / (float)dt);
         if (tid < sq) {                      // this step's signals and their derivatives w.r.t. the action entry
             float we, ns, a, pr; int ai;
             phase_signal_at(act, n_action, sq, F, rev_ph, rev_fr, tid, we, ns, a, pr, ai);
@@ -416,8 +414,9 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
             sig[4 * tid + 2] = soft_switch_grad(a - pr, kSigK); sig[4 * tid + 3] = -soft_switch_grad(pr - a, kSigK);
         }
         if (t > 0) fetch(t - 1);
-        lds_barrier();
-        // ---- phase B: loss taps on the state after step t, then J^T g of this cell (dmacro_lane.py:283-294)
+        // ---- phase B (no barrier in front: row t + 1 is in LDS since the previous iteration and every cell evaluates its own
+        //      lane's loss weight d reward / d q_l = - 2 q_l dt, q_l = sqrt(term / dt)): loss taps on the state after step t,
+        //      then J^T g of this cell (dmacro_lane.py:283-294)
         float v_r = 0.f, v_y = 0.f;
         if (is_cell) {
             const int c = tid;
@@ -425,7 +424,7 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
             const float x = s0f - uu;
             const float is_static = soft_switch(x, w_kc);
             const float nveh = rr * c_dxv;
-            const float gql = gq[c_lane];
+            const float gql = gscale * (-1.0f) * (float)dt * 2.f * sqrtf(w_q / (float)dt);
             float gr = g_r + gql * is_static * c_dxv;
             float gy = g_y;
             glue_u_bwd(rr, yy, um, gql * nveh * (-soft_switch_grad(x, w_kc)), gr, gy);
