@@ -150,46 +150,59 @@ __device__ __forceinline__ Tv tv_pos_or_zero(Tv a) { return a.val > 0.f ? a : tv
 // ~25 float32 operations of ItscpRoadNetwork.setup_micro_boundary (_simulator.py:176-262) then leave two linear records per
 // output (head_position_delta, head_speed_delta) instead of one record each.
 constexpr int kDu = 7;
-struct Du { float v; float g[kDu]; };
-__device__ __forceinline__ Du du_c(float v) { Du x; x.v = v;
+// Du<M>: bit i of M says the value MAY depend on variable i; components outside M are exact zeros and are neither stored
+// nor computed.  Every component follows the same float32 formula as the reference's operator (sum, product, quotient,
+// sigmoid rule), component by component, so a narrower mask changes no result.
+template <unsigned M> struct Du { float v; float g[kDu]; };
+template <unsigned M> __device__ __forceinline__ constexpr bool du_has(int i) { return (M >> i) & 1u; }
+__device__ __forceinline__ Du<0> du_c(float v) { Du<0> x; x.v = v;
 #pragma unroll
     for (int i = 0; i < kDu; ++i) x.g[i] = 0.f;
     return x; }
-__device__ __forceinline__ Du du_var(float v, int i) { Du x = du_c(v); x.g[i] = 1.f; return x; }
-__device__ __forceinline__ Du du_add(Du a, Du b) { Du x; x.v = a.v + b.v;
+template <int I> __device__ __forceinline__ Du<(1u << I)> du_var(float v, float seed = 1.f) { Du<(1u << I)> x; x.v = v;
 #pragma unroll
-    for (int i = 0; i < kDu; ++i) x.g[i] = a.g[i] + b.g[i];
+    for (int i = 0; i < kDu; ++i) x.g[i] = 0.f;
+    x.g[I] = seed;
     return x; }
-__device__ __forceinline__ Du du_sub(Du a, Du b) { Du x; x.v = a.v - b.v;
+// widen: the same number under a larger mask
+template <unsigned N, unsigned M> __device__ __forceinline__ Du<N> du_as(Du<M> a) { static_assert((M & ~N) == 0, "mask"); Du<N> x; x.v = a.v;
 #pragma unroll
-    for (int i = 0; i < kDu; ++i) x.g[i] = a.g[i] - b.g[i];
+    for (int i = 0; i < kDu; ++i) x.g[i] = du_has<M>(i) ? a.g[i] : 0.f;
     return x; }
-__device__ __forceinline__ Du du_mul(Du a, Du b) { Du x; x.v = a.v * b.v;
+template <unsigned A, unsigned B> __device__ __forceinline__ Du<(A | B)> du_add(Du<A> a, Du<B> b) { Du<(A | B)> x; x.v = a.v + b.v;
 #pragma unroll
-    for (int i = 0; i < kDu; ++i) x.g[i] = a.g[i] * b.v + b.g[i] * a.v;
+    for (int i = 0; i < kDu; ++i) x.g[i] = (du_has<A>(i) && du_has<B>(i)) ? a.g[i] + b.g[i] : (du_has<A>(i) ? a.g[i] : (du_has<B>(i) ? b.g[i] : 0.f));
     return x; }
-__device__ __forceinline__ Du du_div(Du a, Du b) { Du x; x.v = a.v / b.v;
+template <unsigned A, unsigned B> __device__ __forceinline__ Du<(A | B)> du_sub(Du<A> a, Du<B> b) { Du<(A | B)> x; x.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < kDu; ++i) x.g[i] = (du_has<A>(i) && du_has<B>(i)) ? a.g[i] - b.g[i] : (du_has<A>(i) ? a.g[i] : (du_has<B>(i) ? -b.g[i] : 0.f));
+    return x; }
+template <unsigned A, unsigned B> __device__ __forceinline__ Du<(A | B)> du_mul(Du<A> a, Du<B> b) { Du<(A | B)> x; x.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < kDu; ++i) x.g[i] = (du_has<A>(i) && du_has<B>(i)) ? a.g[i] * b.v + b.g[i] * a.v : (du_has<A>(i) ? a.g[i] * b.v : (du_has<B>(i) ? b.g[i] * a.v : 0.f));
+    return x; }
+template <unsigned A, unsigned B> __device__ __forceinline__ Du<(A | B)> du_div(Du<A> a, Du<B> b) { Du<(A | B)> x; x.v = a.v / b.v;
     const float ia = 1.f / b.v, ib = -((a.v / b.v) / b.v);
 #pragma unroll
-    for (int i = 0; i < kDu; ++i) x.g[i] = a.g[i] * ia + b.g[i] * ib;
+    for (int i = 0; i < kDu; ++i) x.g[i] = (du_has<A>(i) && du_has<B>(i)) ? a.g[i] * ia + b.g[i] * ib : (du_has<A>(i) ? a.g[i] * ia : (du_has<B>(i) ? b.g[i] * ib : 0.f));
     return x; }
-__device__ __forceinline__ Du du_soft(Du a, float k) {          // dmath.operation.sigmoid(value, constant=k)
+template <unsigned A> __device__ __forceinline__ Du<A> du_soft(Du<A> a, float k) {          // dmath.operation.sigmoid(value, constant=k)
     const float z = a.v * k;
     const float zc = fminf(fmaxf(z, -16.f), 16.f);
     const float sgm = 1.f / (1.f + expf(-zc));
     const float grad = (z < -16.f || z > 16.f) ? 0.f : sgm * (1.f - sgm) * k;
-    Du x; x.v = sgm;
+    Du<A> x; x.v = sgm;
 #pragma unroll
-    for (int i = 0; i < kDu; ++i) x.g[i] = a.g[i] * grad;
+    for (int i = 0; i < kDu; ++i) x.g[i] = du_has<A>(i) ? a.g[i] * grad : 0.f;
     return x; }
-__device__ __forceinline__ Du du_pos_or_zero(Du a) { return a.v > 0.f ? a : du_c(0.f); }   // x if x > 0 else 0.0
+template <unsigned A> __device__ __forceinline__ Du<A> du_pos_or_zero(Du<A> a) { return a.v > 0.f ? a : du_as<A>(du_c(0.f)); }   // x if x > 0 else 0.0
 // out = sum_i g[i] * x_(id[i]) as records: one node for the vehicle inputs, one for the signals (+ the first node)
-__device__ __forceinline__ Tv du_emit(Rec &R, Du a, const int *id) {
+template <unsigned A> __device__ __forceinline__ Tv du_emit(Rec &R, Du<A> a, const int *id) {
     bool lo = false, hi = false;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lo = lo || (id[i] >= 0 && a.g[i] != 0.f);
+    for (int i = 0; i < 4; ++i) lo = lo || (du_has<A>(i) && id[i] >= 0 && a.g[i] != 0.f);
 #pragma unroll
-    for (int i = 4; i < kDu; ++i) hi = hi || (id[i] >= 0 && a.g[i] != 0.f);
+    for (int i = 4; i < kDu; ++i) hi = hi || (du_has<A>(i) && id[i] >= 0 && a.g[i] != 0.f);
     if (!lo && !hi) return tv_c(a.v);
     int first = -1;
     if (lo) {
@@ -577,7 +590,13 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 const int k = mw;
                 const bool act = k < n_micro && lane_n[k < n_micro ? k : 0] > 0;
                 if (k < n_micro) { hdpv[k] = 1000.f; hdvv[k] = 0.f; hdpi[k] = -1; hdvi[k] = -1; }
-                Du fin = du_c(0.f), green_dp = du_c(1000.f), green_dv = du_c(0.f), red_dp = du_c(0.f);
+                // variables: 0 = head position, 1 = head speed, 2 / 3 = leader position / speed, 4..6 = signals of the previous /
+                // current / next lane of the route; every quantity carries only the components it can depend on
+                constexpr unsigned kP = 1u, kS = 2u, kLP = 4u, kLS = 8u, kSig = 16u | 32u | 64u;
+                Du<kP | kSig> fin = du_as<kP | kSig>(du_c(0.f));
+                Du<kP | kLP> green_dp = du_as<kP | kLP>(du_c(1000.f));
+                Du<kS | kLS> green_dv = du_as<kS | kLS>(du_c(0.f));
+                Du<kP> red_dp = du_as<kP>(du_c(0.f));
                 int ids[kDu];
 #pragma unroll
                 for (int q = 0; q < kDu; ++q) ids[q] = -1;
@@ -588,9 +607,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     const int *route = vroute + hv * kRouteStride;
                     const int rlen = vrlen[hv], cursor = vcur[hv];
                     ids[0] = vidp[hv]; ids[1] = vidv[hv];
-                    const Du hp = du_var(vp[hv], 0), hs = du_var(vv[hv], 1);
-                    const Du Lc = du_c(lanelen[l]), half = du_c(vlen * 0.5f);
-                    Du reach = du_sub(du_sub(Lc, hp), half);
+                    const Du<kP> hp = du_var<0>(vp[hv]);
+                    const Du<kS> hs = du_var<1>(vv[hv]);
+                    const Du<0> Lc = du_c(lanelen[l]), half = du_c(vlen * 0.5f);
+                    Du<kP> reach = du_sub(du_sub(Lc, hp), half);
                     for (int j = cursor; j < rlen - 1; ++j) {
                         const int there = route[j + 1];
                         const int ms = mslot[there];
@@ -601,45 +621,48 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                             const Tv lp_ = tv_leaf(rec, vp[lv]), lsp_ = tv_leaf(rec, vv[lv]);
                             rec_push(rec, K_IMPORT, 0, make_int4(lp_.id, lsp_.id, vidp[lv], vidv[lv]), make_float4(0.f, 0.f, 0.f, 0.f));
                             ids[2] = lp_.id; ids[3] = lsp_.id;
-                            green_dp = du_pos_or_zero(du_add(reach, du_sub(du_var(lp_.val, 2), half)));
-                            green_dv = du_sub(hs, du_var(lsp_.val, 3));
+                            green_dp = du_pos_or_zero(du_add(reach, du_sub(du_var<2>(lp_.val), half)));
+                            green_dv = du_sub(hs, du_var<3>(lsp_.val));
                             break;
                         }
                         reach = du_add(reach, du_c(lanelen[there]));
                     }
                     red_dp = du_pos_or_zero(du_sub(du_sub(Lc, hp), half));
                     const bool prev_exist = cursor > 0, next_exist = cursor < rlen - 1;
-                    Du prev_s = du_c(0.f), next_s = du_c(0.f);
+                    Du<kP> prev_s = du_as<kP>(du_c(0.f)), next_s = du_as<kP>(du_c(0.f));
                     if (prev_exist) prev_s = du_soft(du_sub(du_c(0.f), hp), 16.f);
-                    const Du curr_s = du_mul(du_soft(hp, 16.f), du_soft(du_sub(Lc, hp), 16.f));
+                    const Du<kP> curr_s = du_mul(du_soft(hp, 16.f), du_soft(du_sub(Lc, hp), 16.f));
                     if (next_exist) next_s = du_soft(du_sub(hp, Lc), 16.f);
-                    const Du total = du_add(du_add(prev_s, curr_s), next_s);
-#pragma unroll
-                    for (int w = 0; w < 3; ++w) {
-                        if ((w == 0 && !prev_exist) || (w == 2 && !next_exist)) continue;
-                        const int lid = route[cursor + w - 1];
-                        const Du sc = w == 0 ? prev_s : (w == 1 ? curr_s : next_s);
-                        Du sv = du_c(1.f);
-                        const int kd = linfo[lid] & 3;
-                        if (kd != 0) {
-                            const int it = linfo[lid] >> 2;
-                            const Tv leaf = tv_leaf(rec, sig[2 * it + (kd - 1)]);
-                            rec_push(rec, K_SIGNAL, 0, make_int4(leaf.id, it, kd, 0), make_float4(0.f, 0.f, 0.f, 0.f));
-                            ids[4 + w] = leaf.id;
-                            sv = du_var(leaf.val, 4 + w);
-                        }
-                        fin = du_add(fin, du_mul(du_div(sc, total), sv));
+                    const Du<kP> total = du_add(du_add(prev_s, curr_s), next_s);
+                    // one term of the position-weighted blend: (score / total) * signal of that lane (1 for a lane without one)
+#define DHTS_BLEND_TERM(W, SC)                                                                                                  \
+                    {                                                                                                           \
+                        const int lid = route[cursor + (W) - 1];                                                                \
+                        const int kd = linfo[lid] & 3;                                                                          \
+                        float sval = 1.f, sseed = 0.f;                                                                          \
+                        if (kd != 0) {                                                                                          \
+                            const int it = linfo[lid] >> 2;                                                                     \
+                            const Tv leaf = tv_leaf(rec, sig[2 * it + (kd - 1)]);                                               \
+                            rec_push(rec, K_SIGNAL, 0, make_int4(leaf.id, it, kd, 0), make_float4(0.f, 0.f, 0.f, 0.f));         \
+                            ids[4 + (W)] = leaf.id;                                                                             \
+                            sval = leaf.val; sseed = 1.f;                                                                       \
+                        }                                                                                                       \
+                        fin = du_add(fin, du_mul(du_div(SC, total), du_var<4 + (W)>(sval, sseed)));                             \
                     }
+                    if (prev_exist) DHTS_BLEND_TERM(0, prev_s)
+                    DHTS_BLEND_TERM(1, curr_s)
+                    if (next_exist) DHTS_BLEND_TERM(2, next_s)
+#undef DHTS_BLEND_TERM
                 }
                 // signal_rms: running mean over the occupied lanes in lane order (_simulator.py:249-256)
                 const double ssum = wave_scan_add(act ? (double)fin.v : 0.);
                 const int scnt = wave_scan_add(act ? 1 : 0);
                 if (act) {
                     const float k2 = 32.f / fabsf((float)((sig_sum + ssum) / (double)(sig_cnt + scnt)));
-                    const Du fs = du_soft(du_sub(fin, du_c(0.5f)), k2);
-                    const Du one_m = du_sub(du_c(1.f), fs);
-                    const Du dp_d = du_add(du_mul(green_dp, fs), du_mul(red_dp, one_m));
-                    const Du dv_d = du_add(du_mul(green_dv, fs), du_mul(du_c(0.f), one_m));
+                    const auto fs = du_soft(du_sub(fin, du_c(0.5f)), k2);
+                    const auto one_m = du_sub(du_c(1.f), fs);
+                    const auto dp_d = du_add(du_mul(green_dp, fs), du_mul(red_dp, one_m));
+                    const auto dv_d = du_add(du_mul(green_dv, fs), du_mul(du_c(0.f), one_m));
                     const Tv dp_ = du_emit(rec, dp_d, ids), dv_ = du_emit(rec, dv_d, ids);
                     hdpv[k] = dp_.val; hdpi[k] = dp_.id; hdvv[k] = dv_.val; hdvi[k] = dv_.id;
                 }

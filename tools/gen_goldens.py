@@ -724,6 +724,10 @@ def main():
             os.environ["DHTS_FINE_CUTS"] = "120,240,360"
             os.environ.pop("DHTS_LANE_LATE", None)
             gen_itscp("hybrid_p2", "hybrid", 3, 1, 5.0, 16, 4, seed=21, action_kind="rand", problem=2)
+        if "hybrid_p3" in which:         # problem_3's inflow, signal length 3 s over 12 s (other phase grid), another seed
+            os.environ["DHTS_FINE_CUTS"] = "90,180,270"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("hybrid_p3", "hybrid", 3, 1, 5.0, 12, 3, seed=33, action_kind="rand", problem=3)
         if "hybrid_short" in which:      # 8 s: enough for the first vehicles to cross the interior intersection
             gen_itscp("hybrid_short", "hybrid", 3, 1, 5.0, 8, 2, seed=9, action_kind="rand")
 
