@@ -32,7 +32,7 @@ def _run(cuda, g, loss_steps=0, replicas=1, want_grad=True, action=None):
                 counts=counts.cpu().numpy(), grad=grad, m=m)
 
 
-@pytest.mark.parametrize("name", ["macro_small", "macro"])
+@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2"])
 def test_hybrid_kernels_on_macro_only_network(cuda, golden_dir, name):
     g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
     o = _run(cuda, g)

@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 
 def build_env(g, m):
     from example.control.itscp._env import ItscpEnv
-    from example.control.itscp.problem import problem_1
+    from example.control.itscp import problem as problems
     from road.network.route import MicroRoute
     env = ItscpEnv()
-    env.schedule_callback = problem_1
+    env.schedule_callback = getattr(problems, "problem_%d" % int(m.get("problem", 1)))
     for k, v in dict(num_intersection=m["num_intersection"], lane_length=m["lane_length"], num_lane=m["num_lane"],
                      policy_length=m["policy_length"], signal_length=m["signal_length"], mode=m["mode"],
                      speed_limit=m["speed_limit"], random_seed=m["seed"]).items():
@@ -37,7 +37,7 @@ def build_env(g, m):
     return env
 
 
-@pytest.mark.parametrize("name", ["macro_small", "macro", "hybrid_short", "hybrid"])
+@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "hybrid_short", "hybrid"])
 def test_itscp_rollout_matches_reference(cuda, golden_dir, name):
     import torch
     path = os.path.join(golden_dir, "itscp_%s.npz" % name)
@@ -121,7 +121,7 @@ def test_itscp_rollout_matches_reference(cuda, golden_dir, name):
     assert np.abs(l16 - late[16]).max() <= 0.25 * np.abs(late[16]).max()
 
 
-@pytest.mark.parametrize("name", ["macro_small", "macro", "hybrid_short"])
+@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "hybrid_short"])
 def test_env_step_uses_fused_kernels(cuda, golden_dir, name):
     """ItscpEnv.step(action, True) -- the reference's entry point (trainer.py:172-190) -- through the fused network
     kernels: reward, its gradient and the per-step queue terms against the reference's run."""

@@ -15,7 +15,7 @@ def load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name))
 
 
-@pytest.mark.parametrize("name", ["macro_small", "macro"])
+@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2"])
 def test_network_rollout_vs_reference(cuda, golden_dir, name):
     import torch
     from dhts import ops

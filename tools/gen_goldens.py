@@ -714,6 +714,8 @@ def main():
             gen_itscp("macro_small", "macro", 1, 1, 10.0, 2, 1, seed=5, action_kind="rand")
         if "macro" in which:
             gen_itscp("macro", "macro", 1, 3, 30.0, 10, 2, seed=7, action_kind="rand")
+        if "macro_2x2" in which:         # four intersections: lanes gated by a neighbouring intersection's signal
+            gen_itscp("macro_2x2", "macro", 2, 2, 10.0, 4, 1, seed=17, action_kind="rand", problem=3)
         if "hybrid" in which:
             # bisecting aids recorded with this case: gradients of the reward restricted to its first t0 steps and
             # of the last-quarter loss of the lanes vehicles are deposited into (see tests/test_itscp_gpu.py)
