@@ -357,7 +357,11 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     if (is_lane) { l_off = tb.net.lane_off[tid]; l_n = tb.net.lane_ncell[tid]; l_ms = mslot[tid]; l_macro = tb.lane_macro[tid] != 0; }
     // signals of step 0 (the staged action vector is complete after the barrier above); signal threads count (phase, frame)
     int sig_ph = 0, sig_fr = 0;                  // of the step whose signals are computed next
-    if (tid < sq) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, 0, 0, tid, we, ns, a, pr, ai); sig[2 * tid] = we; sig[2 * tid + 1] = ns; }
+    // the intersections' signal threads sit in the wavefront in front of the micro wave (little else to do there), not in wave 0
+    const int sg_base = sq <= 64 ? (((B >> 6) - 2) << 6) : 0;
+    const bool is_sg = tid >= sg_base && tid < sg_base + sq;
+    const int sg_q = tid - sg_base;
+    if (is_sg) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, 0, 0, sg_q, we, ns, a, pr, ai); sig[2 * sg_q] = we; sig[2 * sg_q + 1] = ns; }
     if (++sig_fr == F) { sig_fr = 0; ++sig_ph; }
 
     // ---- micro wave state
@@ -737,7 +741,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             float4 *tp = tape_r + (size_t)t * 3 * Cp;
             tp[c] = d0; tp[Cp + c] = d1; tp[2 * Cp + c] = d2;
         }
-        if (tid < sq && t + 1 < T) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, sig_ph, sig_fr, tid, we, ns, a, pr, ai); sig[2 * tid] = we; sig[2 * tid + 1] = ns; }
+        if (is_sg && t + 1 < T) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, sig_ph, sig_fr, sg_q, we, ns, a, pr, ai); sig[2 * sg_q] = we; sig[2 * sg_q + 1] = ns; }
         if (++sig_fr == F) { sig_fr = 0; ++sig_ph; }
         if (t > 0) loss_lanes(t - 1);
         lds_barrier();
@@ -1091,6 +1095,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     const bool row_mode = 16 * sq <= B;
     const int own_q = row_mode ? (tid >> 4) : tid;
     const bool in_rows = row_mode ? (tid < 16 * sq) : (tid < sq);
+    // signal threads: in the wavefront in front of the micro wave, like in the forward kernel
+    const int sg_base = sq <= 64 ? (((B >> 6) - 2) << 6) : 0;
+    const bool is_sg = tid >= sg_base && tid < sg_base + sq;
+    const int sg_q = tid - sg_base;
     const bool is_own = in_rows && (!row_mode || (tid & 15) == 15);
     int rev_ph = T > 0 ? (T - 1) / F : 0, rev_fr = T > 0 ? (T - 1) % F : 0;      // (t / F, t % F) of the step being reversed
     bool bad = false, over = false, bad_key = false;
@@ -1179,11 +1187,11 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             gL[c] += gql * soft_switch(x, w_kc) * c_dxv;
             gL[2 * C + c] += gql * (rr * c_dxv) * (-soft_switch_grad(x, w_kc));
         }
-        if (tid < sq) {
+        if (is_sg) {
             float we, ns, a, pr; int ai;
-            phase_signal_at(act, n_action, sq, F, rev_ph, rev_fr, tid, we, ns, a, pr, ai);
-            sg[6 * tid] = we; sg[6 * tid + 1] = ns;
-            sg[6 * tid + 2] = soft_switch_grad(a - pr, kSigK); sg[6 * tid + 3] = -soft_switch_grad(pr - a, kSigK);
+            phase_signal_at(act, n_action, sq, F, rev_ph, rev_fr, sg_q, we, ns, a, pr, ai);
+            sg[6 * sg_q] = we; sg[6 * sg_q + 1] = ns;
+            sg[6 * sg_q + 2] = soft_switch_grad(a - pr, kSigK); sg[6 * sg_q + 3] = -soft_switch_grad(pr - a, kSigK);
         }
         int seg_lo[kPhases], seg_n[kPhases];            // this lane's record segments of the step (micro wave)
 #pragma unroll
