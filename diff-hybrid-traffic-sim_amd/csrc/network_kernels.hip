@@ -129,8 +129,11 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
     };
     // signals of the step whose ghosts are built next, by the intersection's thread; (phase, frame) are counted
     int sig_ph = 0, sig_fr = 0;
+    const int sg_base = (sq <= 64 && B >= 128) ? (((B >> 6) - 1) << 6) : 0;      // signal threads: the last (least loaded) wavefront
+    const bool is_sg = tid >= sg_base && tid < sg_base + sq;
+    const int sg_q = tid - sg_base;
     auto signals = [&]() {
-        if (tid < sq) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, sig_ph, sig_fr, tid, we, ns, a, pr, ai); sig[4 * tid] = we; sig[4 * tid + 1] = ns; }
+        if (is_sg) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, sig_ph, sig_fr, sg_q, we, ns, a, pr, ai); sig[4 * sg_q] = we; sig[4 * sg_q + 1] = ns; }
         if (++sig_fr == F) { sig_fr = 0; ++sig_ph; }
     };
     __syncthreads();        // the staged action vector is complete
@@ -392,6 +395,9 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
     __syncthreads();
     if (T > 0) fetch(T - 1);
     int rev_ph = T > 0 ? (T - 1) / F : 0, rev_fr = T > 0 ? (T - 1) % F : 0;      // (t / F, t % F) of the step being reversed
+    const int sg_base = (sq <= 64 && (int)blockDim.x >= 128) ? ((((int)blockDim.x >> 6) - 1) << 6) : 0;   // signal threads: last wavefront
+    const bool is_sg = tid >= sg_base && tid < sg_base + sq;
+    const int sg_q = tid - sg_base;
     float g_r = 0.f, g_y = 0.f;          // cotangent of this thread's cell at time t+1
     double ga = 0.;                      // thread q < sq: d reward / d action[cur_phase * sq + q], flushed when the phase changes
     int cur_phase = -1;
@@ -407,11 +413,11 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
         const float4 d0 = p_d0, d1 = p_d1, d2 = p_d2;
         const int src = p_src, gate = p_gate;
         if (is_cell) { Hc[tid] = p_hr; Hc[C + tid] = p_hy; Hc[2 * C + tid] = p_hu; }
-        if (tid < sq) {                      // this step's signals and their derivatives w.r.t. the action entry
+        if (is_sg) {                         // this step's signals and their derivatives w.r.t. the action entry
             float we, ns, a, pr; int ai;
-            phase_signal_at(act, n_action, sq, F, rev_ph, rev_fr, tid, we, ns, a, pr, ai);
-            sig[4 * tid] = we; sig[4 * tid + 1] = ns;
-            sig[4 * tid + 2] = soft_switch_grad(a - pr, kSigK); sig[4 * tid + 3] = -soft_switch_grad(pr - a, kSigK);
+            phase_signal_at(act, n_action, sq, F, rev_ph, rev_fr, sg_q, we, ns, a, pr, ai);
+            sig[4 * sg_q] = we; sig[4 * sg_q + 1] = ns;
+            sig[4 * sg_q + 2] = soft_switch_grad(a - pr, kSigK); sig[4 * sg_q + 3] = -soft_switch_grad(pr - a, kSigK);
         }
         if (t > 0) fetch(t - 1);
         // ---- phase B (no barrier in front: row t + 1 is in LDS since the previous iteration and every cell evaluates its own
