@@ -1092,14 +1092,17 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     double ga = 0.; int cur_phase = -1;
     // action cotangent of intersection q: a row of 16 lanes sums the intersection's ghost list (stride 16), its lane 15 owns
     // the running sum of the phase; workgroups too small for 16 lanes per intersection keep one thread per intersection
-    const bool row_mode = 16 * sq <= B;
-    const int own_q = row_mode ? (tid >> 4) : tid;
-    const bool in_rows = row_mode ? (tid < 16 * sq) : (tid < sq);
+    const bool row_mode = 16 * sq <= B - 64;
+    // the rows sit in the wavefronts right in front of the micro wave (the least loaded ones), 64-aligned so that a row of
+    // the reduction is a DPP row
+    const int row_base = row_mode ? (B - 64) - ((16 * sq + 63) & ~63) : 0;
+    const int own_q = row_mode ? ((tid - row_base) >> 4) : tid;
+    const bool in_rows = row_mode ? (tid >= row_base && tid < row_base + 16 * sq) : (tid < sq);
     // signal threads: in the wavefront in front of the micro wave, like in the forward kernel
     const int sg_base = sq <= 64 ? (((B >> 6) - 2) << 6) : 0;
     const bool is_sg = tid >= sg_base && tid < sg_base + sq;
     const int sg_q = tid - sg_base;
-    const bool is_own = in_rows && (!row_mode || (tid & 15) == 15);
+    const bool is_own = in_rows && (!row_mode || ((tid - row_base) & 15) == 15);
     int rev_ph = T > 0 ? (T - 1) / F : 0, rev_fr = T > 0 ? (T - 1) % F : 0;      // (t / F, t % F) of the step being reversed
     bool bad = false, over = false, bad_key = false;
     if (tid < sq) for (int k = tid; k < n_action; k += sq) g_action[(size_t)rep * n_action + k] = 0.f;
@@ -1381,7 +1384,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         if (in_rows) {
             double v = 0.;
             if (row_mode) {
-                for (int k = iptr[own_q] + (tid & 15); k < iptr[own_q + 1]; k += 16) v += (double)aval[iidx[k]];
+                for (int k = iptr[own_q] + ((tid - row_base) & 15); k < iptr[own_q + 1]; k += 16) v += (double)aval[iidx[k]];
                 v = row_scan_add(v);
             } else {
                 for (int k = iptr[own_q]; k < iptr[own_q + 1]; ++k) v += (double)aval[iidx[k]];
