@@ -780,7 +780,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 const float Lf = lanelen[mlane[mw]];
                 ev = ev || ((nid >= 0 && mslot[nid] < 0) ? vp[vi] > Lf + 1.0f * vlen : vp[vi] >= Lf);
             }
-            if (__any(ev) && is_mt) {
+            const bool any_ev = __any(ev);
+            if (any_ev && is_mt) {
                 const int keep_local = rec.next_local;
                 rec.next_local = base_local + 64 * kLaneLocals;
                 for (int ci = 0; ci < n_conv; ++ci) {
@@ -867,16 +868,17 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 if (rec.next_local - (base_local + 64 * kLaneLocals) > kEventLocals) cap_fault = true;
                 rec.next_local = keep_local;
             }
-            // commit temporaries into the persistent slots (vehicles by their lane, capacitors by theirs)
+            // commit temporaries into the persistent slots (vehicles by their lane, capacitors by theirs); only hand-off events
+            // leave values in temporaries
             const int k = mw;
-            if (k < n_micro)
+            if (any_ev && k < n_micro)
                 for (int i = 0; i < lane_n[k]; ++i) {
                     const int vi = lane_veh[k * kLaneCap + i];
                     if (vidp[vi] != 3 * vi) { rec_push(rec, K_COMMIT, 3 * vi, make_int4(vidp[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vidp[vi] = 3 * vi; }
                     if (vidv[vi] != 3 * vi + 1) { rec_push(rec, K_COMMIT, 3 * vi + 1, make_int4(vidv[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vidv[vi] = 3 * vi + 1; }
                     if (vida[vi] != 3 * vi + 2) { rec_push(rec, K_COMMIT, 3 * vi + 2, make_int4(vida[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vida[vi] = 3 * vi + 2; }
                 }
-            if (mw < n_caps) {
+            if (any_ev && mw < n_caps) {
                 const int j = mw;
                 if (capi[j] != 3 * V + j && capi[j] >= 0) { rec_push(rec, K_COMMIT, 3 * V + j, make_int4(capi[j], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); capi[j] = 3 * V + j; }
             }
