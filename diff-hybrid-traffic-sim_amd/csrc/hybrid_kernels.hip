@@ -401,6 +401,26 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     };
     // flush wave, one barrier later: block `blk` goes to HBM in lane order (coalesced), each lane's three segments back to
     // back; the per-lane segment counts go to the index
+    double run_in = 0., run_out = 0.; long long run_cnt = 0;
+    // flush wave: vehicle samples of the loss' running mean of the state the last step left (stream positions follow the
+    // cells of the lanes in front, lane id order), exclusive prefix sums per micro lane for the loss constants
+    auto vehicle_samples = [&]() {
+        const int k = fl;
+        const int c = k < n_micro ? lane_n[k] : 0;
+        const int exc = k <= n_micro ? vcp[k] : 0;
+        double ssum = 0., esum = 0.;
+        for (int i = 0; i < c; ++i) {
+            const int vi = lane_veh[k * kLaneCap + i];
+            const long long idx = run_cnt + cbefore[k] + exc + i;
+            const float x = s0f - vv[vi];
+            float xo = 0.f;
+            if (idx >= kWindow) xo = stream_load(xs + (idx - kWindow));
+            xs[idx] = x; vxold[vi] = xo;
+            ssum += (double)x; esum += (double)xo;
+        }
+        const double is_ = wave_scan_add(ssum), ie_ = wave_scan_add(esum);
+        if (k <= n_micro) { vsp[k] = is_ - ssum; vep[k] = ie_ - esum; }
+    };
     auto flush_block = [&](int blk) {
         const int b = blk & 1;
         const int c0 = cnt_s[(b * kPhases + 0) * 64 + fl], c1 = cnt_s[(b * kPhases + 1) * 64 + fl], c2 = cnt_s[(b * kPhases + 2) * 64 + fl];
@@ -436,7 +456,6 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         if (total > kMaxStepRecords) fl_fault = true;
     };
 
-    double run_in = 0., run_out = 0.; long long run_cnt = 0;
     float lane_total = 0.f;
     int fault_step = -1, fault_index = 0;
     // per-step table entries, fetched one step ahead
@@ -587,7 +606,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
         }
         if (t > 0) loss_scan(cur);
-        if (is_fw && t > 0) flush_block(t - 1);
+        if (is_fw && t > 0) { vehicle_samples(); flush_block(t - 1); }
         if (in_mw) {
             {   // head gaps of the occupied micro lanes (they only feed the IDM steps below)
                 rec.next_local = base_local + mw * kLaneLocals;
@@ -884,24 +903,13 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             }
             if (rec.next_local - (base_local + mw * kLaneLocals) > kLaneLocals) cap_fault = true;
             seg_b = rec.cnt;
-            // vehicle samples of the loss' running mean: exclusive prefixes over the micro lanes in id order
+            // vehicle counts in front of every micro lane (lane id order): the cells need them for their stream positions in
+            // the next phase; the vehicles' samples themselves are taken there by the flush wave
             {
                 const int k = mw;
                 const int c = k < n_micro ? lane_n[k] : 0;
                 const int inc = wave_scan_add(c);
-                const int exc = inc - c;
-                double ssum = 0., esum = 0.;
-                for (int i = 0; i < c; ++i) {
-                    const int vi = lane_veh[k * kLaneCap + i];
-                    const long long idx = run_cnt + cbefore[k] + exc + i;
-                    const float x = s0f - vv[vi];
-                    float xo = 0.f;
-                    if (idx >= kWindow) xo = stream_load(xs + (idx - kWindow));
-                    xs[idx] = x; vxold[vi] = xo;
-                    ssum += (double)x; esum += (double)xo;
-                }
-                const double is_ = wave_scan_add(ssum), ie_ = wave_scan_add(esum);
-                if (k <= n_micro) { vcp[k] = exc; vsp[k] = is_ - ssum; vep[k] = ie_ - esum; }
+                if (k <= n_micro) vcp[k] = inc - c;
             }
             publish(t);
         }
@@ -911,7 +919,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     if (T > 0) {
         const float *fin = (T & 1) ? S1 : S0;
         loss_scan(fin);
-        if (is_fw) flush_block(T - 1);
+        if (is_fw) { vehicle_samples(); flush_block(T - 1); }
         __syncthreads();
         loss_consts(fin, T - 1);
         if (in_mw) {
