@@ -42,8 +42,8 @@ constexpr int kEventLocals = 64;     // temporaries of the serial event walk per
 constexpr int kMaxLocals = 64 * kLaneLocals + kEventLocals;
 constexpr int kStage = 96;           // staging slots per lane: two blocks of kStageH (the block being filled, the block being flushed)
 constexpr int kStageH = 48;          // records a lane can stage per step
-constexpr int kPhases = 3;           // record segments per block: head gaps + previous step's loss seeds + IDM |
-                                     // capacitors + events + commits | (spare)
+constexpr int kPhases = 3;           // record segments per block (= step): head gaps + IDM | capacitors + events |
+                                     // commits + the loss seeds of the state the step leaves
 constexpr int kMaxStepRecords = 1024;
 constexpr int kWindow = 100000;      // RunningMean(100_000), _env.py:122
 
@@ -225,7 +225,7 @@ __device__ __forceinline__ float stream_load(const float *p) {
 struct HybLds {
     size_t fq, scanw, incl, vsp, vep, s0, s1, g, ab, contrib, ql, sig, lanelen, vp, vv, va, vxold, hdpv, hdvv, capv, qmicro,
         cell_lane, iface_lane, cnext, vidp, vidv, vida, vcur, vrlen, vroute, lane_n, lane_veh, hdpi, hdvi, vcp, capi, mslot,
-        capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, stg_k, stg_i, stg_w, cnt_s, lfl, total;
+        capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, stg_k, stg_i, stg_w, cnt_s, lfl, vx, total;
 };
 __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS) {
     HybLds o; size_t p = 0; const int NI = C + L;
@@ -240,7 +240,7 @@ __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS) {
     o.hdpi = F(kMaxMicro); o.hdvi = F(kMaxMicro); o.vcp = F(kMaxMicro + 1); o.capi = F(kMaxCaps); o.mslot = F(L); o.capof = F(L);
     o.mlane = F(kMaxMicro); o.cbefore = F(kMaxMicro + 1); o.convlist = F(L); o.linfo = F(L); o.caplast = F(kMaxCaps); o.rused = F(kMaxMicro); o.caplane = F(kMaxCaps); o.capleaf = F(kMaxCaps);
     o.stg_k = F((size_t)NS * kStage); o.stg_i = F((size_t)NS * kStage * 4); o.stg_w = F((size_t)NS * kStage * 4);
-    o.cnt_s = F(2 * kPhases * 64); o.lfl = F(L);
+    o.cnt_s = F(2 * kPhases * 64); o.lfl = F(L); o.vx = F(V);
     o.total = p;
     return o;
 }
@@ -272,6 +272,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     int *vcur = LI(vcur), *vrlen = LI(vrlen), *vroute = LI(vroute), *lane_n = LI(lane_n), *lane_veh = LI(lane_veh), *hdpi = LI(hdpi), *hdvi = LI(hdvi);
     int *vcp = LI(vcp), *capi = LI(capi), *mslot = LI(mslot), *capof = LI(capof), *mlane = LI(mlane), *cbefore = LI(cbefore), *convlist = LI(convlist), *linfo = LI(linfo), *caplast = LI(caplast), *rused = LI(rused), *caplane = LI(caplane), *capleaf = LI(capleaf);
     int *stg_k = LI(stg_k), *stg_i = LI(stg_i); float *stg_w = LF(stg_w);
+    float *vx = LF(vx);                            // per vehicle: static_speed - speed of the state the last step left (loss sample)
     int *lfl = LI(lfl);                            // per lane: first cell | last cell << 16
     int *cnt_s = LI(cnt_s);                        // [2 blocks][kPhases][64 lanes] staged record counts, micro wave -> flush wave
     const float um = (float)um_d, s0f = (float)static_speed, vlen = (float)veh_len, dtf = (float)dt;
@@ -389,8 +390,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     double sig_sum = 0.; long long sig_cnt = 0;          // signal_rms (never reaches its window in one episode)
     if (is_mt) for (int j = 0; j < kMaxCaps; ++j) { capv[j] = 0.f; capi[j] = -1; }
     __syncthreads();
-    // end of a step (micro wave): every lane's three segment counts (head gaps + seeds + IDM | capacitors + events |
-    // commits) go to LDS and the lane turns to its other staging half
+    // end of a step (micro wave): every lane's three segment counts (head gaps + IDM | capacitors + events | commits; the
+    // flush wave appends the loss seeds to the third) go to LDS and the lane turns to its other staging half
     int seg_a = 0, seg_b = 0;                        // this lane's staged records at the end of the first / second segment
     auto publish = [&](int blk) {
         const int b = blk & 1;
@@ -415,7 +416,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             const float x = s0f - vv[vi];
             float xo = 0.f;
             if (idx >= kWindow) xo = stream_load(xs + (idx - kWindow));
-            xs[idx] = x; vxold[vi] = xo;
+            xs[idx] = x; vxold[vi] = xo; vx[vi] = x;
             ssum += (double)x; esum += (double)xo;
         }
         const double is_ = wave_scan_add(ssum), ie_ = wave_scan_add(esum);
@@ -511,9 +512,12 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 hn[tid] = st[tid]; hn[C + tid] = st[C + tid]; hn[2 * C + tid] = st[2 * C + tid]; hn[3 * C + tid] = st[3 * C + tid];
             }
     };
-    auto micro_loss = [&](int ls) {                  // micro wave: the vehicles' terms of the same loss
-        if (in_mw) {
-            const int k = mw;
+    // flush wave (lane fl = micro lane fl): the vehicles' terms of the same loss, from the samples it took beside the ghosts
+    // (the micro wave is moving the vehicles meanwhile).  The seeds belong to the speeds the last step left, i.e. behind the
+    // last record of block `blk` = ls: they are appended to that block's third segment, which is flushed one phase later.
+    auto micro_loss = [&](int ls, int blk) {
+        if (is_fw) {
+            const int k = fl;
             if (k < n_micro) {
                 qmicro[k] = 0.f;
                 const int nv = lane_n[k];
@@ -531,7 +535,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     float q = 0.f, dsg[kLaneCap];
                     for (int i = 0; i < nv; ++i) {
                         const int vi = lane_veh[k * kLaneCap + i];
-                        const float x = s0f - vv[vi];
+                        const float x = vx[vi];
                         pa += (double)x; pb += (double)vxold[vi]; ++n;
                         const bool full = n > kWindow;
                         const double mean = (full ? pa - pb : pa) / (full ? (double)kWindow : (double)n);
@@ -545,11 +549,21 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     qmicro[k] = (q * q) * dtf;
                     if (ls < loss_steps) {
                         const float gq = -1.0f * dtf * 2.f * q;
+                        const int b = blk & 1;
+                        int at = cnt_s[(b * kPhases + 0) * 64 + k] + cnt_s[(b * kPhases + 1) * 64 + k] + cnt_s[(b * kPhases + 2) * 64 + k];
+                        int added = 0;
                         for (int i = 0; i < nv; ++i) {
                             const int vi = lane_veh[k * kLaneCap + i];
-                            if (vidv[vi] >= 0 && dsg[i] != 0.f)
-                                rec_push(rec, K_SEED, 0, make_int4(vidv[vi], 0, 0, 0), make_float4(gq * (-dsg[i]), 0.f, 0.f, 0.f));
+                            if (vidv[vi] >= 0 && dsg[i] != 0.f) {
+                                if (at >= kStageH) { fl_fault = true; break; }
+                                const int q_ = (k * 2 + b) * kStageH + at;
+                                stg_k[q_] = K_SEED << 24;
+                                *reinterpret_cast<int4 *>(stg_i + 4 * q_) = make_int4(vidv[vi], 0, 0, 0);
+                                *reinterpret_cast<float4 *>(stg_w + 4 * q_) = make_float4(gq * (-dsg[i]), 0.f, 0.f, 0.f);
+                                ++at; ++added;
+                            }
                         }
+                        cnt_s[(b * kPhases + 2) * 64 + k] += added;
                     }
                 }
             }
@@ -606,7 +620,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
         }
         if (t > 0) loss_scan(cur);
-        if (is_fw && t > 0) { vehicle_samples(); flush_block(t - 1); }
+        if (is_fw && t > 0) vehicle_samples();
         if (in_mw) {
             {   // head gaps of the occupied micro lanes (they only feed the IDM steps below)
                 rec.next_local = base_local + mw * kLaneLocals;
@@ -710,8 +724,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             ab[4] = f.B[0]; ab[5] = f.B[1]; ab[6] = f.B[2]; ab[7] = f.B[3];
         }
         if (t > 0) loss_consts(cur, t - 1);
+        if (t > 0) micro_loss(t - 1, t - 1);
         if (in_mw) {
-            if (t > 0) micro_loss(t - 1);
             const int k = mw;
             if (k < n_micro && lane_n[k] > 0) {
                 const int nv = lane_n[k];
@@ -763,6 +777,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         if (is_sg && t + 1 < T) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, sig_ph, sig_fr, sg_q, we, ns, a, pr, ai); sig[2 * sg_q] = we; sig[2 * sg_q + 1] = ns; }
         if (++sig_fr == F) { sig_fr = 0; ++sig_ph; }
         if (t > 0) loss_lanes(t - 1);
+        if (is_fw && t > 0) flush_block(t - 1);          // with the seeds the previous phase appended
         lds_barrier();
         // ================= D: flux capacitors, hand-off events in lane-id order, commits, vehicle samples (micro wave) =====
         if (in_mw) {
@@ -919,18 +934,14 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     if (T > 0) {
         const float *fin = (T & 1) ? S1 : S0;
         loss_scan(fin);
-        if (is_fw) { vehicle_samples(); flush_block(T - 1); }
+        if (is_fw) vehicle_samples();
         __syncthreads();
         loss_consts(fin, T - 1);
-        if (in_mw) {
-            seg_a = 0; seg_b = 0;
-            micro_loss(T - 1);
-            seg_a = rec.cnt; seg_b = rec.cnt;
-            publish(T);
-        }
+        micro_loss(T - 1, T - 1);
+        if (in_mw) { seg_a = 0; seg_b = 0; publish(T); }      // block T stays empty (the reverse sweep still looks at it)
         run_update();
         __syncthreads();
-        if (is_fw) flush_block(T);
+        if (is_fw) { flush_block(T - 1); flush_block(T); }
         loss_lanes(T - 1);
     }
     if (is_fw) {
@@ -1167,8 +1178,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             fetch_offsets(t - 1);
         }
     };
-    // block T of the record stream holds only the loss seeds of the final state (they belong to the vehicles' speeds after
-    // the last step): every lane of the micro wave applies its own
+    // block T of the record stream is empty in streams this build writes (the loss seeds of the final state sit at the end
+    // of block T - 1); seeds found there are still applied
     if (T > 0 && in_mw) {
         const int b_lo = step_off[T], b_n = step_off[T + 1] - b_lo;
         int c = 0;
