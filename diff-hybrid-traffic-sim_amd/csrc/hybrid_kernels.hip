@@ -691,6 +691,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     if (next_exist) DHTS_BLEND_TERM(2, next_s)
 #undef DHTS_BLEND_TERM
                 }
+                // The barrier between this phase and the next sits HERE for the micro wave: nobody else reads what the rest of
+                // the head-gap evaluation writes (it only feeds this wave's IDM steps), and the next phase has slack for it
+                // (IDM steps against the interface solves) while this one does not (head gaps against ghosts + loss scan).
+                lds_barrier();
                 // signal_rms: running mean over the occupied lanes in lane order (_simulator.py:249-256)
                 const double ssum = wave_scan_add(act ? (double)fin.v : 0.);
                 const int scnt = wave_scan_add(act ? 1 : 0);
@@ -705,8 +709,9 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 }
                 sig_sum += wave_last(ssum); sig_cnt += wave_last(scnt);
             }
+        } else {
+            lds_barrier();
         }
-        lds_barrier();
         // ================= B: interface solves | loss constants + history row | vehicles' loss terms, IDM steps =================
         if (is_if) {
             const float *gl = G + (size_t)(2 * i_lane) * 4, *gr_ = G + (size_t)(2 * i_lane + 1) * 4;
