@@ -237,7 +237,7 @@ __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS) {
     o.hdpv = F(kMaxMicro); o.hdvv = F(kMaxMicro); o.capv = F(kMaxCaps); o.qmicro = F(kMaxMicro);
     o.cell_lane = F(C); o.iface_lane = F(NI); o.cnext = F(L); o.vidp = F(V); o.vidv = F(V); o.vida = F(V); o.vcur = F(V);
     o.vrlen = F(V); o.vroute = F((size_t)V * kRouteStride); o.lane_n = F(kMaxMicro); o.lane_veh = F(kMaxMicro * kLaneCap);
-    o.hdpi = F(kMaxMicro); o.hdvi = F(kMaxMicro); o.vcp = F(kMaxMicro + 1); o.capi = F(kMaxCaps); o.mslot = F(L); o.capof = F(L);
+    o.hdpi = F(kMaxMicro); o.hdvi = F(kMaxMicro); o.vcp = F(2 * (kMaxMicro + 1)); o.capi = F(kMaxCaps); o.mslot = F(L); o.capof = F(L);
     o.mlane = F(kMaxMicro); o.cbefore = F(kMaxMicro + 1); o.convlist = F(L); o.linfo = F(L); o.caplast = F(kMaxCaps); o.rused = F(kMaxMicro); o.caplane = F(kMaxCaps); o.capleaf = F(kMaxCaps);
     o.stg_k = F((size_t)NS * kStage); o.stg_i = F((size_t)NS * kStage * 4); o.stg_w = F((size_t)NS * kStage * 4);
     o.cnt_s = F(2 * kPhases * 64); o.lfl = F(L); o.vx = F(V);
@@ -403,12 +403,15 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     // flush wave, one barrier later: block `blk` goes to HBM in lane order (coalesced), each lane's three segments back to
     // back; the per-lane segment counts go to the index
     double run_in = 0., run_out = 0.; long long run_cnt = 0;
+    // vehicle counts in front of the micro lanes, one buffer per parity of the loss index (the micro wave writes the next
+    // one while the cells still evaluate the constants of the previous loss)
+    auto vcp_of = [&](int ls) { return vcp + (ls & 1) * (kMaxMicro + 1); };
     // flush wave: vehicle samples of the loss' running mean of the state the last step left (stream positions follow the
     // cells of the lanes in front, lane id order), exclusive prefix sums per micro lane for the loss constants
-    auto vehicle_samples = [&]() {
+    auto vehicle_samples = [&](int ls) {
         const int k = fl;
         const int c = k < n_micro ? lane_n[k] : 0;
-        const int exc = k <= n_micro ? vcp[k] : 0;
+        const int exc = k <= n_micro ? vcp_of(ls)[k] : 0;
         double ssum = 0., esum = 0.;
         for (int i = 0; i < c; ++i) {
             const int vi = lane_veh[k * kLaneCap + i];
@@ -476,12 +479,13 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     //      ghosts, its constants and the vehicles' terms beside the interface solves, its lane sums beside the cell updates);
     //      the records of step t-1 are flushed beside the ghosts of step t
     float x_new = 0.f;
-    auto loss_scan = [&](const float *st) {
+    auto loss_scan = [&](const float *st, int ls) {
+        const int *vcp_l = vcp_of(ls);
         if ((tid & ~63) < C) {                        // waves without cells (the micro wave) have nothing to add
             double a = 0., b = 0.;
             if (is_cell) {
                 x_new = s0f - st[2 * C + tid];
-                const long long idx = run_cnt + tid + vcp[c_mb];
+                const long long idx = run_cnt + tid + vcp_l[c_mb];
                 a = (double)x_new;
                 if (idx >= kWindow) b = (double)stream_load(xs + (idx - kWindow));
                 xs[idx] = x_new;
@@ -493,6 +497,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     };
     double tot_a = 0., tot_b = 0.;
     auto loss_consts = [&](const float *st, int ls) {
+        const int *vcp_l = vcp_of(ls);
         const int nwc = (C + 63) >> 6;
         tot_a = 0.; tot_b = 0.;
         for (int w = 0; w < nwc; ++w) { tot_a += scanw[w]; tot_b += scanw[16 + w]; }
@@ -500,7 +505,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 const int wv = tid >> 6;
                 double base_a = 0., base_b = 0.;
                 for (int w = 0; w < wv; ++w) { base_a += scanw[w]; base_b += scanw[16 + w]; }
-                const long long n = run_cnt + tid + vcp[c_mb] + 1;
+                const long long n = run_cnt + tid + vcp_l[c_mb] + 1;
                 const double pin = run_in + base_a + incl[tid] + vsp[c_mb];
                 const double pout = run_out + base_b + incl[C + tid] + vep[c_mb];
                 const bool full = n > kWindow;             // one IEEE division, operands selected first
@@ -529,7 +534,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                         for (int w = 0; w < (c >> 6); ++w) { pa += scanw[w]; pb += scanw[16 + w]; }
                         pa += incl[c]; pb += incl[C + c];
                     }
-                    long long n = run_cnt + cb + vcp[k];
+                    long long n = run_cnt + cb + vcp_of(ls)[k];
                     // q = sum_i sigmoid(k_i (s0 - v_i)); term = q^2 dt; d reward / d v_i = -2 dt q * (-sigmoid'_i): one SEED
                     // record per vehicle, directly on its speed
                     float q = 0.f, dsg[kLaneCap];
@@ -569,7 +574,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             }
         }
     };
-    auto run_update = [&]() { run_in += tot_a + vsp[n_micro]; run_out += tot_b + vep[n_micro]; run_cnt += C + vcp[n_micro]; };
+    auto run_update = [&](int ls) { run_in += tot_a + vsp[n_micro]; run_out += tot_b + vep[n_micro]; run_cnt += C + vcp_of(ls)[n_micro]; };
     auto loss_lanes = [&](int ls) {
         if (is_lane) {
             float term;
@@ -619,8 +624,9 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             float *g = G + (size_t)tid * 4;
             g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
         }
-        if (t > 0) loss_scan(cur);
-        if (is_fw && t > 0) vehicle_samples();
+        if (t > 0) loss_scan(cur, t - 1);
+        if (t > 1) loss_lanes(t - 2);               // its constants were evaluated beside the hand-offs of the last step
+        if (is_fw && t > 0) vehicle_samples(t - 1);
         if (in_mw) {
             {   // head gaps of the occupied micro lanes (they only feed the IDM steps below)
                 rec.next_local = base_local + mw * kLaneLocals;
@@ -728,7 +734,6 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             ab[0] = f.A[0]; ab[1] = f.A[1]; ab[2] = f.A[2]; ab[3] = f.A[3];
             ab[4] = f.B[0]; ab[5] = f.B[1]; ab[6] = f.B[2]; ab[7] = f.B[3];
         }
-        if (t > 0) loss_consts(cur, t - 1);
         if (t > 0) micro_loss(t - 1, t - 1);
         if (in_mw) {
             const int k = mw;
@@ -758,7 +763,6 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             }
             seg_a = rec.cnt;
         }
-        if (t > 0) run_update();
         lds_barrier();
         // ================= C: cell updates + tape | lane queue terms of step t-1 | next step's signals =================
         if (is_cell) {
@@ -781,10 +785,11 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         }
         if (is_sg && t + 1 < T) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, sig_ph, sig_fr, sg_q, we, ns, a, pr, ai); sig[2 * sg_q] = we; sig[2 * sg_q + 1] = ns; }
         if (++sig_fr == F) { sig_fr = 0; ++sig_ph; }
-        if (t > 0) loss_lanes(t - 1);
         if (is_fw && t > 0) flush_block(t - 1);          // with the seeds the previous phase appended
         lds_barrier();
-        // ================= D: flux capacitors, hand-off events in lane-id order, commits, vehicle samples (micro wave) =====
+        // ================= D: flux capacitors, hand-off events in lane-id order, commits (micro wave) | loss constants of
+        //                    the state after step t-1 + its history row (the cells have nothing else to do here) =========
+        if (t > 0) { loss_consts(cur, t - 1); run_update(t - 1); }
         if (in_mw) {
             // capacitors: += r u dt of the last cell (conversion.py:32-36); the spawn itself is an event below
             if (mw < n_caps) {
@@ -929,7 +934,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 const int k = mw;
                 const int c = k < n_micro ? lane_n[k] : 0;
                 const int inc = wave_scan_add(c);
-                if (k <= n_micro) vcp[k] = inc - c;
+                if (k <= n_micro) vcp_of(t)[k] = inc - c;
             }
             publish(t);
         }
@@ -938,13 +943,14 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     // loss of the final state, last records
     if (T > 0) {
         const float *fin = (T & 1) ? S1 : S0;
-        loss_scan(fin);
-        if (is_fw) vehicle_samples();
+        if (T > 1) loss_lanes(T - 2);
+        loss_scan(fin, T - 1);
+        if (is_fw) vehicle_samples(T - 1);
         __syncthreads();
         loss_consts(fin, T - 1);
         micro_loss(T - 1, T - 1);
         if (in_mw) { seg_a = 0; seg_b = 0; publish(T); }      // block T stays empty (the reverse sweep still looks at it)
-        run_update();
+        run_update(T - 1);
         __syncthreads();
         if (is_fw) { flush_block(T - 1); flush_block(T); }
         loss_lanes(T - 1);
