@@ -730,6 +730,10 @@ def main():
             os.environ["DHTS_FINE_CUTS"] = "90,180,270"
             os.environ.pop("DHTS_LANE_LATE", None)
             gen_itscp("hybrid_p3", "hybrid", 3, 1, 5.0, 12, 3, seed=33, action_kind="rand", problem=3)
+        if "hybrid_l10" in which:        # 10 m lanes (two cells each: deposits straddle cells, longer IDM lanes), problem_2
+            os.environ["DHTS_FINE_CUTS"] = "100,200"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("hybrid_l10", "hybrid", 3, 1, 10.0, 10, 2, seed=55, action_kind="rand", problem=2)
         if "hybrid_short" in which:      # 8 s: enough for the first vehicles to cross the interior intersection
             gen_itscp("hybrid_short", "hybrid", 3, 1, 5.0, 8, 2, seed=9, action_kind="rand")
 
