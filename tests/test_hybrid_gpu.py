@@ -42,7 +42,7 @@ def test_hybrid_kernels_on_macro_only_network(cuda, golden_dir, name):
     assert o["counts"][0, 0] == 0 and o["counts"][0, 1] == 0
 
 
-@pytest.mark.parametrize("name", ["hybrid_short", "hybrid_p2", "hybrid_p3"])
+@pytest.mark.parametrize("name", ["hybrid_short", "hybrid_p2", "hybrid_p3", "hybrid_l10"])
 def test_hybrid_short_matches_reference(cuda, golden_dir, name):
     """240 steps of problem_1 (5 spawns) and 480 steps of problem_2 with another seed (13 spawns, 10 deposits): queues, reward,
     vehicle count and the full d reward / d action of the reference's runs."""
@@ -154,7 +154,7 @@ def test_per_replica_tables(cuda, golden_dir):
         ops.net_hybrid_rollout(a[:2], ops.DeviceHybridTables(tabs, g["spawn_routes"], cuda), *args)
 
 
-@pytest.mark.parametrize("name, seed", [("itscp_hybrid", 11), ("itscp_hybrid_p2", 12), ("itscp_hybrid_p3", 13)])
+@pytest.mark.parametrize("name, seed", [("itscp_hybrid", 11), ("itscp_hybrid_p2", 12), ("itscp_hybrid_p3", 13), ("itscp_hybrid_l10", 14)])
 def test_hybrid_random_actions_vs_oracle(cuda, golden_dir, oracle, name, seed):
     """Twelve other signal schedules on each golden network (other spawn times, lane orders, 8-14 vehicles, 6-12 deposits,
     the sliding loss window on the 600-step one) against the CPU restatement: identical event counts, queues, reward, and

@@ -121,7 +121,7 @@ def test_itscp_rollout_matches_reference(cuda, golden_dir, name):
     assert np.abs(l16 - late[16]).max() <= 0.25 * np.abs(late[16]).max()
 
 
-@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "hybrid_short", "hybrid_p2", "hybrid_p3"])
+@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "hybrid_short", "hybrid_p2", "hybrid_p3", "hybrid_l10"])
 def test_env_step_uses_fused_kernels(cuda, golden_dir, name):
     """ItscpEnv.step(action, True) -- the reference's entry point (trainer.py:172-190) -- through the fused network
     kernels: reward, its gradient and the per-step queue terms against the reference's run."""

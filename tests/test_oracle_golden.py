@@ -169,7 +169,7 @@ def itscp_hybrid_tables(g):
                                g["macro_route"], g["schedule"]), m
 
 
-@pytest.mark.parametrize("name", ["hybrid_short", "hybrid_p2", "hybrid_p3", "hybrid"])
+@pytest.mark.parametrize("name", ["hybrid_short", "hybrid_p2", "hybrid_p3", "hybrid_l10", "hybrid"])
 def test_itscp_hybrid_network(oracle, golden_dir, name):
     """G8 hybrid: macro lanes, micro lanes, spawns, lane changes and deposits against the reference's own run."""
     g = load(golden_dir, "itscp_%s.npz" % name)
