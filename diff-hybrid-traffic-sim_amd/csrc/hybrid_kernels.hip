@@ -1226,7 +1226,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             float we, ns, a, pr; int ai;
             phase_signal_at(act, n_action, sq, F, rev_ph, rev_fr, sg_q, we, ns, a, pr, ai);
             sg[6 * sg_q] = we; sg[6 * sg_q + 1] = ns;
-            sg[6 * sg_q + 2] = soft_switch_grad(a - pr, kSigK); sg[6 * sg_q + 3] = -soft_switch_grad(pr - a, kSigK);
+            // d sigmoid(k x) / d x = s (1 - s) k with the sigmoid values just computed (0 outside the clamp, like the operator)
+            const float zs = (a - pr) * kSigK;
+            const bool sat = zs < -16.f || zs > 16.f;
+            sg[6 * sg_q + 2] = sat ? 0.f : we * (1.f - we) * kSigK; sg[6 * sg_q + 3] = sat ? 0.f : -(ns * (1.f - ns) * kSigK);
         }
         int seg_lo[kPhases], seg_n[kPhases];            // this lane's record segments of the step (micro wave)
 #pragma unroll

@@ -417,7 +417,10 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
             float we, ns, a, pr; int ai;
             phase_signal_at(act, n_action, sq, F, rev_ph, rev_fr, sg_q, we, ns, a, pr, ai);
             sig[4 * sg_q] = we; sig[4 * sg_q + 1] = ns;
-            sig[4 * sg_q + 2] = soft_switch_grad(a - pr, kSigK); sig[4 * sg_q + 3] = -soft_switch_grad(pr - a, kSigK);
+            // d sigmoid(k x) / d x = s (1 - s) k with the sigmoid values just computed (0 outside the clamp, like the operator)
+            const float zs = (a - pr) * kSigK;
+            const bool sat = zs < -16.f || zs > 16.f;
+            sig[4 * sg_q + 2] = sat ? 0.f : we * (1.f - we) * kSigK; sig[4 * sg_q + 3] = sat ? 0.f : -(ns * (1.f - ns) * kSigK);
         }
         if (t > 0) fetch(t - 1);
         // ---- phase B (no barrier in front: row t + 1 is in LDS since the previous iteration and every cell evaluates its own
