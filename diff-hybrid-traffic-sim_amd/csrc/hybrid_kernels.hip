@@ -47,7 +47,7 @@ constexpr int kPhases = 3;           // record segments per block (= step): head
 constexpr int kMaxStepRecords = 1024;
 constexpr int kWindow = 100000;      // RunningMean(100_000), _env.py:122
 
-enum { K_NODE = 1, K_COMMIT = 2, K_DEPOSIT = 3, K_CELLREAD = 4, K_SIGNAL = 5, K_SEED = 6, K_IMPORT = 7, K_IDM = 8 };
+enum { K_NODE = 1, K_COMMIT = 2, K_DEPOSIT = 3, K_CELLREAD = 4, K_SIGNAL = 5, K_SEED = 6, K_IMPORT = 7, K_IDM = 8, K_CAP = 9 };
 
 struct HybTables {
     NetTables net;
@@ -797,13 +797,14 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 const int m = cnext[l];
                 if (m >= 0 && mslot[m] >= 0) {
                     const int last = caplast[j];
-                    Tv lr = tv_leaf(rec, nxt[last]), lu = tv_leaf(rec, nxt[2 * C + last]);
-                    rec_push(rec, K_CELLREAD, 0, make_int4(lr.id, lu.id, last, 0), make_float4(0.f, 0.f, 0.f, 0.f));
-                    // in place on the capacitor's slot: cap += (r u) dt
-                    const Tv prod = tv_mul(rec, tv_mul(rec, lr, lu), tv_c(dtf));
-                    rec_push(rec, K_NODE, 3 * V + j, make_int4(capi[j], prod.id, -1, -1), make_float4(1.f, prod.sc, 0.f, 0.f));
-                    capv[j] = capv[j] + prod.val; capi[j] = 3 * V + j;
-                    capleaf[j] = lu.id;                      // the speed leaf, for a spawn in this step
+                    // one compound record, in place on the capacitor's slot: cap += (r u) dt with (r, u) read from the cell
+                    // (the reads of r, u, their product and the sum are one record instead of three); the leaf stands for
+                    // u: a vehicle spawned in this step takes it as its speed
+                    const float r_ = nxt[last], u_ = nxt[2 * C + last];
+                    const int leaf = rec.next_local++;
+                    rec_push(rec, K_CAP, 3 * V + j, make_int4(last, leaf, capi[j], 0), make_float4(dtf, u_, r_, 0.f));
+                    capv[j] = capv[j] + (r_ * u_) * dtf; capi[j] = 3 * V + j;
+                    capleaf[j] = leaf;
                 }
             }
             // is there any event at all this step?  (the common case is none)
@@ -1304,6 +1305,17 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
                     if (in[1] >= 0) adj[in[1]] += g_nr * ((w[3] / vlen) / dx) * w[1];
                     if (in[2] >= 0) adj[in[2]] += g_speed;
                     gL[c] = g_nr; gL[C + c] = 0.f; gL[2 * C + c] = 0.f;
+                } else if (kind == K_CAP) {
+                    // cap' = cap + (r u) dt: the slot's cotangent passes through to the previous value of the capacitor and
+                    // reaches the cell as ((a dt) u, (a dt) r); the u leaf may also carry a spawned vehicle's speed
+                    const float a = adj[out];
+                    adj[out] = 0.f;
+                    if (in[2] >= 0) adj[in[2]] += a;
+                    const float ad = a * w[0];
+                    const float g_u = adj[in[1]] + ad * w[2];
+                    adj[in[1]] = 0.f;
+                    gL[in[0]] += ad * w[1];
+                    gL[2 * C + in[0]] += g_u;
                 } else if (kind == K_CELLREAD) {
                     gL[in[2]] += adj[in[0]];
                     gL[2 * C + in[2]] += adj[in[1]];
@@ -1324,8 +1336,13 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             }
         };
         if (in_mw) {
-            replay(seg_lo[2], seg_n[2]);                 // commits, then the vehicles' loss terms
-            replay(seg_lo[1], seg_n[1]);                 // hand-off events (lane 0 holds them), then the capacitors
+            replay(seg_lo[2], seg_n[2]);                 // the vehicles' loss terms, then the commits
+            // a lane's capacitor record is the first of its second segment.  The charge precedes ALL hand-off events of its
+            // step (a deposit may rewrite the very cell it read), and lanes replay side by side: the events of every lane
+            // first (lane 0 holds them), the capacitors afterwards
+            const int capn = (seg_n[1] > 0 && (rk[seg_lo[1]] >> 24) == K_CAP) ? 1 : 0;
+            replay(seg_lo[1] + capn, seg_n[1] - capn);
+            replay(seg_lo[1], capn);
         }
         lds_barrier();
         // ================= R3: speed cotangents into (r, y); J^T g per cell =================
