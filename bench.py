@@ -52,6 +52,9 @@ class MacroWorkload:
     name = "macro_straight_1024x512x1000"
     unit_bytes = MACRO_TAPE_B
     stored_bytes = MACRO_STORED_B
+    # what each kernel actually runs into (PMC): the forward's double-precision Riemann solves keep the
+    # VALUs ~80 % busy while it writes at 3 TB/s; the reverse sweep streams the tape at 5.7 TB/s
+    limiter = {"rollout_fwd": "valu (f64 issue, ~80 % busy; HBM writes at 3 TB/s)", "rollout_bwd": "hbm (5.7 TB/s of reads)"}
 
     def __init__(self, dev, rank, L, N, T):
         from dhts import ops
@@ -138,6 +141,7 @@ class MicroWorkload:
     name = "micro_idm_4096x256x1000"
     unit_bytes = MICRO_TAPE_B
     stored_bytes = MICRO_STORED_B
+    limiter = {"rollout_fwd": "valu / latency (f64 IDM, ~65 % busy; HBM writes at 3.6 TB/s)", "rollout_bwd": "hbm (5.3 TB/s of reads)"}
 
     def __init__(self, dev, rank, L, V, T):
         from dhts import ops
@@ -213,6 +217,7 @@ class ItscpMacroWorkload:
     actions) x 256 replicas with per-replica problem_1 schedules and actions U[0.1, 0.9]: reward and d reward / d action
     of every replica in one fused launch each way (a stepping stone to BASELINE config 4, which adds micro lanes)."""
     name = "itscp_macro_256x(40 lanes, 236 cells)x300"
+    limiter = {"rollout_fwd": "latency (300 dependent steps, one workgroup per replica)", "rollout_bwd": "latency (300 dependent steps, one workgroup per replica)"}
     unit_bytes = MACRO_TAPE_B
     stored_bytes = MACRO_TAPE_B
 
@@ -286,6 +291,7 @@ class ItscpHybridWorkload:
     centre intersection are micro, 256 cells, 600 steps, 45 actions) x 256 replicas with per-replica problem_1 schedules and actions U[0.1, 0.9]: reward and
     d reward / d action of every replica in one fused launch each way (BASELINE config 4)."""
     name = "itscp_hybrid_256x(144 lanes, 256 cells, 16 micro lanes)x600"
+    limiter = {"rollout_fwd": "latency (600 dependent steps, one workgroup per replica)", "rollout_bwd": "latency (600 dependent steps, one workgroup per replica)"}
     unit_bytes = MACRO_TAPE_B
     stored_bytes = MACRO_TAPE_B
 
@@ -461,6 +467,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (PMC)",
                          "algorithmic_bytes_per_launch": per_launch_bytes,
                          "stored_bytes_per_launch": w.units * w.stored_bytes,
+                         "limiter": getattr(w, "limiter", {}).get(dom, "hbm"),
                          "note": "achieved = algorithmic tape bytes (the reference's dqs: 48 B per cell-step, 32 B per vehicle-step) / "
                                  "kernel time; the kernels store a compact equivalent (stored_bytes_per_launch) and rebuild the blocks "
                                  "in the reverse sweep, so PMC traffic sits below the algorithmic bytes"},
