@@ -33,6 +33,19 @@ def test_version_and_padding():
     assert [lib.dhts_padded(n) for n in (1, 64, 65, 512)] == [64, 64, 128, 512]
 
 
+def test_options_accept_documented_values_only():
+    from dhts import _lib
+    lib = _lib.lib()
+    for v in (0, 1, 5, 8):
+        assert lib.dhts_set_option(_lib.OPT_MACRO_FWD_WAVES, v) == 0
+    assert lib.dhts_set_option(_lib.OPT_MACRO_FWD_WAVES, 9) == _lib.E_INVALID
+    for v in (1, 2, 4, 0):
+        assert lib.dhts_set_option(_lib.OPT_MICRO_FWD_WAVES, v) == 0
+    assert lib.dhts_set_option(_lib.OPT_MICRO_FWD_WAVES, 3) == _lib.E_INVALID
+    assert lib.dhts_set_option(99, 0) == _lib.E_INVALID
+    assert lib.dhts_set_option(_lib.OPT_MACRO_FWD_WAVES, 0) == 0       # back to the heuristics
+
+
 def test_tape_bytes_match_documented_layout():
     from dhts import _lib
     lib = _lib.lib()
