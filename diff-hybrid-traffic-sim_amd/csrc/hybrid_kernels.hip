@@ -1344,6 +1344,31 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             replay(seg_lo[1] + capn, seg_n[1] - capn);
             replay(seg_lo[1], capn);
         }
+        // ghost threads: the forward blend of this step's ghost (everything that needs no cotangent), while only the micro
+        // wave has work; the cotangent part follows two phases later
+        float gh_gr = 0.f, gh_gu = 0.f, gh_s = 1.f, gh_fr = 0.f, gh_fu = 0.f, gh_ds = 0.f, gh_ds2 = 0.f; int gh_cell = -1, gh_kd = 0;
+        if (is_ghost && g_macro) {
+            if (g_side == 0) {
+                if (src >= 0) {
+                    gh_cell = lfl[src] >> 16;
+                    gh_gr = Hc[gh_cell]; gh_gu = Hc[2 * C + gh_cell];
+                    int it = 0;
+                    if (gate == -1) gh_s = 0.f;
+                    else if (gate >= 0) { gh_kd = linfo[gate] & 3; it = linfo[gate] >> 2; if (gh_kd != 0) gh_s = sg[6 * it + (gh_kd - 1)]; }
+                    gh_fr = gh_gr * gh_s + 0.f * (1.0f - gh_s); gh_fu = gh_gu * gh_s + um * (1.0f - gh_s);
+                    if (gh_kd != 0) gh_ds = sg[6 * it + 2 + (gh_kd - 1)];
+                    if (gh_kd != 0 && it != g_inter) bad_key = true;
+                }
+            } else {
+                gh_cell = src < 0 ? -1 : (lfl[src] & 0xffff);
+                gh_gr = src < 0 ? w_own_r : Hc[gh_cell];
+                gh_gu = src < 0 ? w_own_u : Hc[2 * C + gh_cell];
+                const float sgl = g_kind != 0 ? sg[6 * g_inter + (g_kind - 1)] : 1.f;
+                gh_s = soft_switch(sgl - 0.5f, kSigK);
+                gh_fr = gh_s * gh_gr + (1.0f - gh_s) * 1.0f; gh_fu = gh_s * gh_gu + (1.0f - gh_s) * 0.0f;
+                if (g_kind != 0) { gh_ds = soft_switch_grad(sgl - 0.5f, kSigK); gh_ds2 = sg[6 * g_inter + 2 + (g_kind - 1)]; }
+            }
+        }
         lds_barrier();
         // ================= R3: speed cotangents into (r, y); J^T g per cell =================
         float v_r = 0.f, v_y = 0.f;
@@ -1363,36 +1388,24 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             if (c < c_last) { v_r += c0[c + 1]; v_y += c0[C + c + 1]; }
         }
         if (is_ghost && g_macro) {
-            float tgt = -1.f, add_r = 0.f, add_u = 0.f, a_val = 0.f; int a_key = -1;
+            float tgt = -1.f, add_r = 0.f, add_u = 0.f, a_val = 0.f;
             if (g_side == 0) {
                 if (src >= 0) {
-                    const int last = lfl[src] >> 16;
-                    const float grn_r = Hc[last], grn_u = Hc[2 * C + last];
-                    float s = 1.f; int kd = 0, it = 0;
-                    if (gate == -1) s = 0.f;
-                    else if (gate >= 0) { kd = linfo[gate] & 3; it = linfo[gate] >> 2; if (kd != 0) s = sg[6 * it + (kd - 1)]; }
-                    const float fr = grn_r * s + 0.f * (1.0f - s), fu = grn_u * s + um * (1.0f - s);
                     float g_fr = c0[g_off], g_fu = 0.f;
-                    glue_y_bwd(fr, fu, um, c0[C + g_off], g_fr, g_fu);
-                    add_r = g_fr * s; add_u = g_fu * s;
-                    tgt = (float)last;
-                    if (kd != 0) { a_val = (g_fr * grn_r + g_fu * (grn_u - um)) * sg[6 * it + 2 + (kd - 1)]; a_key = it; }
+                    glue_y_bwd(gh_fr, gh_fu, um, c0[C + g_off], g_fr, g_fu);
+                    add_r = g_fr * gh_s; add_u = g_fu * gh_s;
+                    tgt = (float)gh_cell;
+                    if (gh_kd != 0) a_val = (g_fr * gh_gr + g_fu * (gh_gu - um)) * gh_ds;
                 }
             } else {
-                const int first = src < 0 ? 0 : (lfl[src] & 0xffff);
-                const float grn_r = src < 0 ? w_own_r : Hc[first];
-                const float grn_u = src < 0 ? w_own_u : Hc[2 * C + first];
-                const float sgl = g_kind != 0 ? sg[6 * g_inter + (g_kind - 1)] : 1.f;
-                const float s2 = soft_switch(sgl - 0.5f, kSigK);
-                const float fr = s2 * grn_r + (1.0f - s2) * 1.0f, fu = s2 * grn_u + (1.0f - s2) * 0.0f;
                 const int lastc = g_off + g_n - 1;
                 float g_fr = c2[lastc] + gown_r, g_fu = gown_u;      // the blended ghost is also the stored one
-                glue_y_bwd(fr, fu, um, c2[C + lastc], g_fr, g_fu);
-                if (src >= 0) { add_r = g_fr * s2; add_u = g_fu * s2; tgt = (float)first; gown_r = 0.f; gown_u = 0.f; }
-                else { gown_r = g_fr * s2; gown_u = g_fu * s2; }
+                glue_y_bwd(gh_fr, gh_fu, um, c2[C + lastc], g_fr, g_fu);
+                if (src >= 0) { add_r = g_fr * gh_s; add_u = g_fu * gh_s; tgt = (float)gh_cell; gown_r = 0.f; gown_u = 0.f; }
+                else { gown_r = g_fr * gh_s; gown_u = g_fu * gh_s; }
                 if (g_kind != 0) {
-                    const float g_s2 = g_fr * (grn_r - 1.0f) + g_fu * grn_u;
-                    a_val = g_s2 * soft_switch_grad(sgl - 0.5f, kSigK) * sg[6 * g_inter + 2 + (g_kind - 1)]; a_key = g_inter;
+                    const float g_s2 = g_fr * (gh_gr - 1.0f) + g_fu * gh_gu;
+                    a_val = g_s2 * gh_ds * gh_ds2;
                 }
             }
             if (tgt >= 0.f) {
@@ -1402,7 +1415,6 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
                     if (cand_src[i] == src) { box[3 * cand_pos[i]] = add_r; box[3 * cand_pos[i] + 1] = 0.f; box[3 * cand_pos[i] + 2] = add_u; }
             }
             aval[tid] = a_val;
-            if (a_key >= 0 && a_key != g_inter) bad_key = true;
         }
         if (in_mw) {
             if (seg_n[0] > 0) for (int q = 0; q < 5; ++q) obi[mw_lane * 5 + q] = -1;
