@@ -789,7 +789,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         lds_barrier();
         // ================= D: flux capacitors, hand-off events in lane-id order, commits (micro wave) | loss constants of
         //                    the state after step t-1 + its history row (the cells have nothing else to do here) =========
-        if (t > 0) { loss_consts(cur, t - 1); run_update(t - 1); }
+        if (t > 0 && !in_mw) { loss_consts(cur, t - 1); run_update(t - 1); }      // (the micro wave keeps no running sums)
         if (in_mw) {
             // capacitors: += r u dt of the last cell (conversion.py:32-36); the spawn itself is an event below
             if (mw < n_caps) {
