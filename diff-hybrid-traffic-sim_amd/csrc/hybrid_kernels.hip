@@ -785,6 +785,16 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         }
         if (is_sg && t + 1 < T) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, sig_ph, sig_fr, sg_q, we, ns, a, pr, ai); sig[2 * sg_q] = we; sig[2 * sg_q + 1] = ns; }
         if (++sig_fr == F) { sig_fr = 0; ++sig_ph; }
+        // micro wave (idle in this phase): has a head vehicle run past the point where it leaves its lane?  (The vehicles
+        // moved in the last phase; nothing touches them again before the hand-off phase looks at this.)
+        bool ev_head = false;
+        if (in_mw && mw < n_micro && lane_n[mw] > 0) {
+            const int vi = lane_veh[mw * kLaneCap + lane_n[mw] - 1];
+            const int cursor = vcur[vi];
+            const int nid = cursor < vrlen[vi] - 1 ? vroute[vi * kRouteStride + cursor + 1] : -1;
+            const float Lf = lanelen[mlane[mw]];
+            ev_head = (nid >= 0 && mslot[nid] < 0) ? vp[vi] > Lf + 1.0f * vlen : vp[vi] >= Lf;
+        }
         if (is_fw && t > 0) flush_block(t - 1);          // with the seeds the previous phase appended
         lds_barrier();
         // ================= D: flux capacitors, hand-off events in lane-id order, commits (micro wave) | loss constants of
@@ -818,13 +828,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     ev = capv[j] >= vlen && space >= vlen * 1.0f;
                 }
             }
-            if (mw < n_micro && lane_n[mw] > 0) {
-                const int vi = lane_veh[mw * kLaneCap + lane_n[mw] - 1];
-                const int cursor = vcur[vi];
-                const int nid = cursor < vrlen[vi] - 1 ? vroute[vi * kRouteStride + cursor + 1] : -1;
-                const float Lf = lanelen[mlane[mw]];
-                ev = ev || ((nid >= 0 && mslot[nid] < 0) ? vp[vi] > Lf + 1.0f * vlen : vp[vi] >= Lf);
-            }
+            ev = ev || ev_head;
             const bool any_ev = __any(ev);
             if (any_ev && is_mt) {
                 const int keep_local = rec.next_local;
