@@ -795,11 +795,11 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             const float Lf = lanelen[mlane[mw]];
             ev_head = (nid >= 0 && mslot[nid] < 0) ? vp[vi] > Lf + 1.0f * vlen : vp[vi] >= Lf;
         }
-        if (is_fw && t > 0) flush_block(t - 1);          // with the seeds the previous phase appended
         lds_barrier();
         // ================= D: flux capacitors, hand-off events in lane-id order, commits (micro wave) | loss constants of
         //                    the state after step t-1 + its history row (the cells have nothing else to do here) =========
         if (t > 0 && !in_mw) { loss_consts(cur, t - 1); run_update(t - 1); }      // (the micro wave keeps no running sums)
+        if (is_fw && t > 0) flush_block(t - 1);          // the last step's records, with the seeds appended two phases ago
         if (in_mw) {
             // capacitors: += r u dt of the last cell (conversion.py:32-36); the spawn itself is an event below
             if (mw < n_caps) {
