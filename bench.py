@@ -7,14 +7,22 @@ One "step" = one pass of the hot path over one batch of synthetic input: a full 
 (forward sweep writing the Jacobian tape + reverse sweep reading it back) of BASELINE.json configs[1]
 (macro: 1024 lanes x 512 ARZ cells x 1000 time steps) or, with --workload micro,
 configs[2] (4096 lanes x 256 IDM vehicles x 1000 time steps; C3), inputs resident in HBM.
-For N > 1 the driver launches one process per GPU (torch.distributed.run); every rank owns its own shard of
-independent lanes (weak scaling: the per-GPU batch is the configuration above), there is no data-path
-collective, and the scalar loss is all-reduced over RCCL once per pass.
-Rank 0 prints ONE JSON line.
+For N > 1 there is one process per GPU: either the caller launches them (torch.distributed.run sets RANK /
+LOCAL_RANK / WORLD_SIZE) or, when `--gpus N` is given without that environment, this script starts N child
+processes of itself before anything touches a GPU, relays rank 0's JSON line and exits non-zero if a rank fails.
+Every rank owns its own shard of independent lanes / replicas (weak scaling: the per-GPU batch is the
+configuration above), there is no data-path collective, and the flat [d loss / d theta_shared || loss] buffer is
+all-reduced over RCCL once per pass.  Rank 0 prints ONE JSON line.
+
+roofline.achieved / frac are priced in the bytes the dominant kernel MOVES (its compact tape, checked against the PMC
+passes under profiles/); the reference's algorithmic tape bytes (48 B per cell-step, 32 B per vehicle-step) divided by
+the same time are reported beside them as achieved_algorithmic / frac_algorithmic.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,10 +35,9 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured-achievable copy rate
 MACRO_TAPE_B = 48           # float32 [3][2][2] per cell-step   (road/lane/dmacro_lane.py:56): the ALGORITHMIC bytes
 MICRO_TAPE_B = 32           # float32 [2][2][2] per vehicle-step (road/lane/dmicro_lane.py:54)
-# what the rollout kernels actually move per unit: the interface tape (2 x 2x2 per interface, 520 / 512 interfaces per lane
-# here) and the second rows of dEgo / dLeading -- the same information, reconstructed in the reverse sweep
-MACRO_STORED_B = 32.5
-MICRO_STORED_B = 12
+# What the rollout kernels actually move is their compact tape (the interface tape, the second rows of dEgo /
+# dLeading -- the same information, rebuilt into the blocks by the reverse sweep); its size comes from the library
+# (dhts_macro_tape_bytes / dhts_micro_tape_bytes), not from a constant here.
 
 
 def parse():
@@ -43,359 +50,129 @@ def parse():
     ap.add_argument("--cells", type=int, default=0, help="override cells / vehicles per lane")
     ap.add_argument("--time-steps", type=int, default=0, help="override simulated time steps per rollout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the short config 3 / config 4 sub-records of the default run")
     return ap.parse_args()
 
 
-class MacroWorkload:
-    """r0 ~ U[0.05, 0.95], u0 ~ U[0, u_max], fixed random ghosts, dx = 5, dt = 0.01, u_max = 30,
-    loss = sum r_T^2 + sum u_T^2."""
-    name = "macro_straight_1024x512x1000"
-    unit_bytes = MACRO_TAPE_B
-    stored_bytes = MACRO_STORED_B
-    # what each kernel actually runs into (PMC, DESIGN.md section 6): the forward's double-precision Riemann solves keep the
-    # VALUs ~80 % busy while it writes at 3 TB/s; the reverse sweep streams the tape at 5.7 TB/s
-    limiter = {"rollout_fwd": "valu (f64 issue, ~80 % busy; HBM writes at 3 TB/s)", "rollout_bwd": "hbm (5.7 TB/s of reads)"}
-
-    def __init__(self, dev, rank, L, N, T):
-        from dhts import ops
-        self.ops, self.L, self.N, self.T = ops, L, N, T
-        self.dt, self.dx, self.um = 0.01, 5.0, 30.0
-        gen = torch.Generator(device="cpu").manual_seed(2026 + rank)
-        self.r0 = (0.05 + 0.9 * torch.rand(L, N, generator=gen)).to(dev)
-        self.u0 = (self.um * torch.rand(L, N, generator=gen)).to(dev)
-        gr = (0.05 + 0.9 * torch.rand(L, 2, generator=gen)).to(dev)
-        gu = (self.um * torch.rand(L, 2, generator=gen)).to(dev)
-        gy, gq = ops.macro_state_from_ru(gr, gu, self.um)
-        self.ghost = torch.stack([gr, gy, gu, gq], dim=-1).contiguous()
-        self.desc = ops.macro_desc(L, N, self.dt, self.dx, self.um)
-        # zeros, not empty: the first touch of 17 GB would otherwise be billed to the first warm-up launch (and to the average
-        # of a rocprofv3 --stats run of this command)
-        self.tape = torch.zeros(ops.macro_tape_numel(self.desc, T), dtype=torch.float32, device=dev)
-        self.err = ops.new_error_record(dev)
-        self.out = tuple(torch.empty(L, N, device=dev) for _ in range(4))
-        self.gout = (torch.empty(L, N, device=dev), torch.empty(L, N, device=dev))
-        self.g_ghost = torch.zeros(L, 2, 2, dtype=torch.float64, device=dev)
-        self.units = L * N * T                       # cell-steps per pass
-        self.name = "macro_straight_%dx%dx%d" % (L, N, T)
-        self.ev = []
-
-    def one_pass(self, record=False):
-        ops = self.ops
-        y0, q0 = ops.macro_state_from_ru(self.r0, self.u0, self.um)
-        if record:
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            e[0].record()
-        rT, yT, uT, _ = ops.macro_rollout_fwd(self.desc, self.T, self.r0, y0, self.u0, q0, self.ghost,
-                                              tape=self.tape, err=self.err, out=self.out)
-        if record:
-            e[1].record()
-        loss = (rT * rT).sum() + (uT * uT).sum()
-        g_r, g_y = 2.0 * rT, torch.zeros_like(rT)
-        ops.macro_u_tap_bwd(rT, yT, 2.0 * uT, g_r, g_y, self.um)
-        if record:
-            e[2].record()
-        g_r0, g_y0, _ = ops.macro_rollout_bwd(self.desc, self.T, self.tape, g_r, g_y, err=self.err, out=self.gout,
-                                              g_ghost=self.g_ghost)
-        if record:
-            e[3].record()
-            self.ev.append(e)
-        g_u0 = ops.macro_state_from_ru_bwd(self.r0, self.u0, g_y0, g_r0, self.um)
-        return loss, g_r0, g_u0
-
-    def cpu_baseline(self):
-        """The C oracle (a port of the reference's algorithm) on the host cores: bounded sample of the same
-        workload -- 2 lanes per core x 512 cells x 250 steps, repeated for >= 10 s."""
-        import numpy as np
-        from oracle import oracle as O
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-        Lc, N, T = 2 * cores, self.N, 250
-        rng = np.random.default_rng(2026)
-        r0 = rng.uniform(0.05, 0.95, (Lc, N)).astype(np.float32)
-        u0 = rng.uniform(0.0, self.um, (Lc, N)).astype(np.float32)
-        gr = rng.uniform(0.05, 0.95, (Lc, 2)).astype(np.float32)
-        gu = rng.uniform(0.0, self.um, (Lc, 2)).astype(np.float32)
-        O.macro_rollout_fwd(r0[:2], u0[:2], gr[:2], gu[:2], 2, self.dt, self.dx, self.um)   # load + warm
-        done, t0 = 0, time.perf_counter()
-        while True:
-            f = O.macro_rollout_fwd(r0, u0, gr, gu, T, self.dt, self.dx, self.um)
-            O.macro_rollout_bwd(f, g_rT=2 * f["rT"], g_uT=2 * f["uT"])
-            done += Lc * N * T
-            el = time.perf_counter() - t0
-            if el >= 10.0:
-                break
-        # the same code on one core: a single lane leaves the OpenMP loop over lanes with one iteration (SURVEY 8d)
-        one, t1 = 0, time.perf_counter()
-        while time.perf_counter() - t1 < 2.0:
-            f1 = O.macro_rollout_fwd(r0[:1], u0[:1], gr[:1], gu[:1], T, self.dt, self.dx, self.um)
-            O.macro_rollout_bwd(f1, g_rT=2 * f1["rT"], g_uT=2 * f1["uT"])
-            one += N * T
-        return {"value": done / el, "unit": "cell-steps/s", "cores": cores, "kind": "port",
-                "sample": "%d lanes x %d cells x %d steps fwd+bwd, repeated %.1f s (OpenMP over lanes)" % (Lc, N, T, el),
-                "one_core_value": one / (time.perf_counter() - t1)}
+def spawn_ranks(n):
+    """`--gpus n` without a launcher: start n children of this script (RANK / LOCAL_RANK / WORLD_SIZE set), one per GPU.
+    The parent never touches the GPU and never execs; it relays rank 0's stdout and returns the worst exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile() as rank0_out:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=rank0_out if r == 0 else sys.stderr))
+        # a rank that dies leaves the others waiting in a collective: end them (by their own PIDs) instead of hanging
+        rcs = [None] * n
+        while any(c is None for c in rcs):
+            time.sleep(0.2)
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    rcs[r] = p.poll()
+            if any(c not in (None, 0) for c in rcs):
+                deadline = time.time() + 15.0
+                while time.time() < deadline and any(p.poll() is None for p in procs):
+                    time.sleep(0.2)
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                rcs = [p.wait() for p in procs]
+        rank0_out.seek(0)
+        sys.stdout.write(rank0_out.read().decode())
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        print("bench.py: rank(s) failed: %s" % bad, file=sys.stderr)
+        return 1
+    return 0
 
 
-class MicroWorkload:
-    """256 default_micro_vehicle(30) per lane, p_i = 20 i + U[0, 10), v ~ U[9, 21], head gap 1000 / 0,
-    dt = 0.01, loss = sum 1e-4 p_T^2 + sum v_T^2."""
-    name = "micro_idm_4096x256x1000"
-    unit_bytes = MICRO_TAPE_B
-    stored_bytes = MICRO_STORED_B
-    limiter = {"rollout_fwd": "valu / latency (f64 IDM, ~65 % busy; HBM writes at 3.6 TB/s)", "rollout_bwd": "hbm (5.3 TB/s of reads)"}
-
-    def __init__(self, dev, rank, L, V, T):
-        from dhts import ops
-        self.ops, self.L, self.V, self.T = ops, L, V, T
-        self.dt = 0.01
-        gen = torch.Generator(device="cpu").manual_seed(3026 + rank)
-        self.p0 = (torch.arange(V)[None, :] * 20.0 + 10.0 * torch.rand(L, V, generator=gen)).to(dev)
-        self.v0 = (9.0 + 12.0 * torch.rand(L, V, generator=gen)).to(dev)
-        par = torch.tensor([30.0 * 1.0, 30.0 * 0.8, 30.0 * 0.9, 5.0 * 0.1, 0.1, 5.0], dtype=torch.float64, device=dev)
-        self.params = par[:, None, None].expand(6, L, V).contiguous()
-        self.head = torch.tensor([[1000.0, 0.0]], dtype=torch.float64, device=dev).expand(L, 2).contiguous()
-        self.desc = ops.micro_desc(L, V, self.dt)
-        self.tape = torch.zeros(ops.micro_tape_numel(self.desc, T), dtype=torch.float32, device=dev)
-        self.err = ops.new_error_record(dev)
-        self.out = (torch.empty(L, V, device=dev), torch.empty(L, V, device=dev))
-        self.gout = (torch.empty(L, V, device=dev), torch.empty(L, V, device=dev))
-        self.g_head = torch.zeros(L, 2, dtype=torch.float64, device=dev)
-        self.units = L * V * T
-        self.name = "micro_idm_%dx%dx%d" % (L, V, T)
-        self.ev = []
-
-    def one_pass(self, record=False):
-        ops = self.ops
-        if record:
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            e[0].record()
-        pT, vT = ops.micro_rollout_fwd(self.desc, self.T, self.p0, self.v0, self.params, self.head, tape=self.tape,
-                                       err=self.err, out=self.out)
-        if record:
-            e[1].record()
-        loss = 1e-4 * (pT * pT).sum() + (vT * vT).sum()
-        g_p, g_v = 2e-4 * pT, 2.0 * vT
-        if record:
-            e[2].record()
-        g_p0, g_v0, _ = ops.micro_rollout_bwd(self.desc, self.T, self.tape, g_p, g_v, err=self.err, out=self.gout,
-                                              g_head=self.g_head)
-        if record:
-            e[3].record()
-            self.ev.append(e)
-        return loss, g_p0, g_v0
-
-    def cpu_baseline(self):
-        import numpy as np
-        from oracle import oracle as O
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-        Lc, V, T = 4 * cores, self.V, 250
-        rng = np.random.default_rng(3026)
-        p0 = (np.arange(V)[None, :] * 20.0 + rng.uniform(0, 10, (Lc, V))).astype(np.float32)
-        v0 = rng.uniform(9, 21, (Lc, V)).astype(np.float32)
-        par = np.tile(np.array([30.0, 24.0, 27.0, 0.5, 0.1, 5.0]), (Lc, V, 1))
-        O.micro_rollout_fwd(p0[:2], v0[:2], par[:2], 2, self.dt)
-        done, t0 = 0, time.perf_counter()
-        while True:
-            f = O.micro_rollout_fwd(p0, v0, par, T, self.dt)
-            O.micro_rollout_bwd(f, g_pT=2e-4 * f["pT"], g_vT=2 * f["vT"])
-            done += Lc * V * T
-            el = time.perf_counter() - t0
-            if el >= 10.0:
-                break
-        one, t1 = 0, time.perf_counter()
-        while time.perf_counter() - t1 < 2.0:
-            f1 = O.micro_rollout_fwd(p0[:1], v0[:1], par[:1], T, self.dt)
-            O.micro_rollout_bwd(f1, g_pT=2e-4 * f1["pT"], g_vT=2 * f1["vT"])
-            one += V * T
-        return {"value": done / el, "unit": "cell-steps/s", "cores": cores, "kind": "port",
-                "sample": "%d lanes x %d vehicles x %d steps fwd+bwd, repeated %.1f s (OpenMP over lanes)" % (Lc, V, T, el),
-                "one_core_value": one / (time.perf_counter() - t1)}
+def make_workload(name, dev, rank, lanes=0, cells=0, time_steps=0):
+    if name == "macro":
+        return MacroWorkload(dev, rank, lanes or 1024, cells or 512, time_steps or 1000)
+    if name == "micro":
+        return MicroWorkload(dev, rank, lanes or 4096, cells or 256, time_steps or 1000)
+    if name == "itscp_hybrid":
+        return ItscpHybridWorkload(dev, rank, lanes or 256, 0, 0)
+    return ItscpMacroWorkload(dev, rank, lanes or 256, 0, 0)
 
 
-class ItscpMacroWorkload:
-    """run_itscp_macro.sh's network (1 intersection, 3 lanes, 30 m, 10 s, signal 2 s: 40 lanes, 236 cells, 300 steps, 5
-    actions) x 256 replicas with per-replica problem_1 schedules and actions U[0.1, 0.9]: reward and d reward / d action
-    of every replica in one fused launch each way (a stepping stone to BASELINE config 4, which adds micro lanes)."""
-    name = "itscp_macro_256x(40 lanes, 236 cells)x300"
-    limiter = {"rollout_fwd": "latency (300 dependent steps, one workgroup per replica)", "rollout_bwd": "latency (300 dependent steps, one workgroup per replica)"}
-    unit_bytes = MACRO_TAPE_B
-    stored_bytes = MACRO_TAPE_B
-
-    def __init__(self, dev, rank, R, _n, _t):
-        import numpy as np
-        from dhts import ops
-        from dhts.network import MacroNetworkTables
-        from example.control.itscp._env import ItscpEnv
-        from example.control.itscp.problem import problem_1
-        self.ops, self.R = ops, R
-        np.random.seed(1000 * rank + 1)
-        env = ItscpEnv()
-        env.schedule_callback = problem_1
-        for k, v in dict(num_intersection=1, lane_length=30.0, num_lane=3, policy_length=10, signal_length=2, mode="macro",
-                         speed_limit=60.0).items():
-            env.config[k] = v
-        env.reset()
-        base = MacroNetworkTables.from_env(env)
-        tabs = [base]
-        keys = list(env.lane.keys())
-        for r in range(1, R):       # same topology and per-step routes, a fresh problem_1 inflow schedule per replica
-            sched = env.schedule_callback(keys, env.num_timestep)
-            t = MacroNetworkTables.__new__(MacroNetworkTables)
-            t.__dict__.update(base.__dict__)
-            t.schedule = np.ascontiguousarray(np.array([sched[k] for k in keys], dtype=np.float64).T)
-            tabs.append(t)
-        self.tab = ops.DeviceNetTables(tabs, dev)
-        self.host_tab = base
-        self.sq, self.F, self.dt, self.um = 1, 60, 1.0 / 30.0, 60.0
-        gen = torch.Generator(device="cpu").manual_seed(77 + rank)
-        self.action = (0.1 + 0.8 * torch.rand(R, env.action_size(), generator=gen)).to(dev).requires_grad_(True)
-        self.units = R * tabs[0].n_cells * tabs[0].T
-        self.L, self.N, self.T = R, tabs[0].n_cells, tabs[0].T
-        self.err = ops.new_error_record(dev)
-        self.ev = []
-
-    def one_pass(self, record=False):
-        self.action.grad = None
-        if record:
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            e[0].record()
-        reward, _ = self.ops.net_macro_rollout(self.action, self.tab, self.sq, self.F, self.dt, self.um)
-        if record:
-            e[1].record()
-        loss = -reward.sum()
-        if record:
-            e[2].record()
-        loss.backward()
-        if record:
-            e[3].record()
-            self.ev.append(e)
-        return loss.detach(), self.action.grad, self.action.grad
-
-    def cpu_baseline(self):
-        """The C oracle of the macro network (scalar, one core): whole episodes of replica 0, repeated for >= 10 s."""
-        from oracle import oracle as O
-        a = self.action[0].detach().cpu().numpy()
-        done, t0 = 0, time.perf_counter()
-        while True:
-            O.net_macro(self.host_tab, a, self.sq, self.F, self.dt, self.um)
-            done += self.N * self.T
-            el = time.perf_counter() - t0
-            if el >= 10.0:
-                break
-        return {"value": done / el, "unit": "cell-steps/s", "cores": 1, "kind": "port",
-                "sample": "replica 0's episode (%d cells x %d steps) fwd+bwd, repeated %.1f s on one core" % (self.N, self.T, el)}
+def pmc_traffic(w, kernel):
+    """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE, gfx950 FETCH correction applied).  Quoted only for the configuration the passes were taken on and only
+    while the tape the library allocates still has the size the passes saw (a changed layout needs fresh passes)."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        hbm = pmc[w.name][kernel]["hbm_bytes"]
+    except (OSError, ValueError, KeyError):
+        return None
+    moved = w.moved_bytes_per_launch()
+    if abs(hbm - moved) > 0.02 * moved:
+        print("bench.py: profiles/pmc_traffic.json (%d B) disagrees with the library's tape size (%d B) by more than 2 %%: "
+              "traffic not quoted; re-take the PMC passes" % (hbm, moved), file=sys.stderr)
+        return None
+    return hbm
 
 
-class ItscpHybridWorkload:
-    """run_itscp_hybrid.sh's network (3 x 3 intersections, 1 lane, 20 s, signal 4 s: 144 lanes of which the 16 of the
-    centre intersection are micro, 256 cells, 600 steps, 45 actions) x 256 replicas with per-replica problem_1 schedules and actions U[0.1, 0.9]: reward and
-    d reward / d action of every replica in one fused launch each way (BASELINE config 4)."""
-    name = "itscp_hybrid_256x(144 lanes, 256 cells, 16 micro lanes)x600"
-    limiter = {"rollout_fwd": "latency (600 dependent steps, one workgroup per replica)", "rollout_bwd": "latency (600 dependent steps, one workgroup per replica)"}
-    unit_bytes = MACRO_TAPE_B
-    stored_bytes = MACRO_TAPE_B
+def kernel_records(w):
+    """Per-kernel records from the HIP events one_pass(record=True) left on the launch stream (the torch current stream
+    is the stream the C ABI is handed, ops._stream)."""
+    fwd_ms = [e[0].elapsed_time(e[1]) for e in w.ev]
+    bwd_ms = [e[2].elapsed_time(e[3]) for e in w.ev]
+    fwd_avg, bwd_avg = sum(fwd_ms) / len(fwd_ms), sum(bwd_ms) / len(bwd_ms)
+    moved = w.moved_bytes_per_launch()
+    algo = w.units * w.unit_bytes
+    rec = {}
+    for k, ms in (("rollout_fwd", fwd_avg), ("rollout_bwd", bwd_avg)):
+        rec[k] = {"ms": ms, "moved_GB": moved / 1e9, "GBps": moved / ms / 1e6, "frac_of_peak": moved / ms / 1e6 / HBM_PEAK_GBS,
+                  "algorithmic_GB": algo / 1e9, "algorithmic_GBps": algo / ms / 1e6}
+    return rec, ("rollout_fwd" if fwd_avg >= bwd_avg else "rollout_bwd")
 
-    def __init__(self, dev, rank, R, _n, _t):
-        import numpy as np
-        from dhts import ops
-        from dhts.network import HybridNetworkTables
-        from example.control.itscp._env import ItscpEnv
-        from example.control.itscp.problem import problem_1
-        self.ops, self.R = ops, R
-        np.random.seed(1000 * rank + 9)
-        env = ItscpEnv()
-        env.schedule_callback = problem_1
-        for k, v in dict(num_intersection=3, lane_length=5.0, num_lane=1, policy_length=20, signal_length=4, mode="hybrid",
-                         speed_limit=60.0).items():
-            env.config[k] = v
-        env.reset()
-        tab = HybridNetworkTables.from_env(env)
-        # pre-drawn routes: 8 per micro lane that a macro lane feeds (RoadNetwork.create_random_route)
-        routes = []
-        for l in range(tab.n_lanes):
-            if tab.lane_macro[l] == 0 and any(tab.lane_macro[a] for a in tab.prev_lanes[l]):
-                for _ in range(8):
-                    r = env.simulator.create_random_route(l).route
-                    routes.append(list(r) + [-1] * (32 - len(r)))
-        tabs = [tab]
-        keys = list(env.lane.keys())
-        for r in range(1, R):       # same topology and per-step routes, a fresh problem_1 inflow schedule per replica
-            sched = env.schedule_callback(keys, env.num_timestep)
-            t = HybridNetworkTables.__new__(HybridNetworkTables)
-            t.__dict__.update(tab.__dict__)
-            t.schedule = np.ascontiguousarray(np.array([sched[k] for k in keys], dtype=np.float64).T)
-            tabs.append(t)
-        self.tab = ops.DeviceHybridTables(tabs, np.array(routes, dtype=np.int32), dev)
-        self.host_tab, self.host_routes = tab, np.array(routes, dtype=np.int32)
-        self.sq, self.F, self.dt, self.um = 9, 120, 1.0 / 30.0, 60.0
-        gen = torch.Generator(device="cpu").manual_seed(177 + rank)
-        self.action = (0.1 + 0.8 * torch.rand(R, env.action_size(), generator=gen)).to(dev).requires_grad_(True)
-        self.units = R * tab.n_cells * tab.T
-        self.L, self.N, self.T = R, tab.n_cells, tab.T
-        self.err = ops.new_error_record(dev)
-        self.ev = []
-        self.counts = None
 
-    def one_pass(self, record=False):
-        self.action.grad = None
-        if record:
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            e[0].record()
-        reward, _, _, self.counts = self.ops.net_hybrid_rollout(self.action, self.tab, self.sq, self.F, self.dt, self.um)
-        if record:
-            e[1].record()
-        loss = -reward.sum()
-        if record:
-            e[2].record()
-        loss.backward()
-        if record:
-            e[3].record()
-            self.ev.append(e)
-        return loss.detach(), self.action.grad, self.action.grad
-
-    def cpu_baseline(self):
-        """The C oracle of the hybrid network (scalar, one core): whole episodes of replica 0, repeated for >= 10 s."""
-        from dhts.network import group_routes
-        from oracle import oracle as O
-        a = self.action[0].detach().cpu().numpy()
-        routes, ptr = group_routes(self.host_routes, self.host_tab.n_lanes)
-        done, t0 = 0, time.perf_counter()
-        while True:
-            o = O.net_hybrid(self.host_tab, routes, ptr, a, self.sq, self.F, self.dt, self.um)
-            assert o["rc"] == 0
-            done += self.N * self.T
-            el = time.perf_counter() - t0
-            if el >= 10.0:
-                break
-        return {"value": done / el, "unit": "cell-steps/s", "cores": 1, "kind": "port",
-                "sample": "replica 0's episode (%d cells x %d steps, %d vehicles) fwd+bwd, repeated %.1f s on one core"
-                          % (self.N, self.T, o["n_spawned"], el)}
+def also_record(name, dev, passes=5):
+    """A short run of another BASELINE configuration in the same process (not the headline; no collective)."""
+    w = make_workload(name, dev, 0)
+    for _ in range(2):
+        w.one_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        w.one_pass(record=True)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    fault = w.err.tolist()
+    assert fault[0] in (0, 2), "simulation fault during the bench: %s" % (fault,)
+    kernels, dom = kernel_records(w)
+    out = {"workload": w.name, "value": w.units * passes / el, "unit": w.unit_name, "passes": passes,
+           "ms_per_pass": el / passes * 1e3, "dominant_kernel": dom, "limiter": w.limiter.get(dom, "hbm"), "kernels": kernels}
+    if getattr(w, "counts", None) is not None:
+        out["vehicles_spawned_replica0"] = int(w.counts[0, 0])
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))        # before any GPU call: the children own the devices
     from dhts import dist as D
     rank, world, local = D.init()
-    if world != args.gpus:
-        if rank == 0 and world > 1:
-            print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     local = local % torch.cuda.device_count()      # one GPU per rank on a full node; wraps only in single-GPU smoke tests
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    if args.workload == "macro":
-        L, N, T = args.lanes or 1024, args.cells or 512, args.time_steps or 1000
-        w = MacroWorkload(dev, rank, L, N, T)
-    elif args.workload == "micro":
-        L, N, T = args.lanes or 4096, args.cells or 256, args.time_steps or 1000
-        w = MicroWorkload(dev, rank, L, N, T)
-    elif args.workload == "itscp_hybrid":
-        w = ItscpHybridWorkload(dev, rank, args.lanes or 256, 0, 0)
-        L, N, T = w.L, w.N, w.T
-    else:
-        w = ItscpMacroWorkload(dev, rank, args.lanes or 256, 0, 0)
-        L, N, T = w.L, w.N, w.T
+    w = make_workload(args.workload, dev, rank, args.lanes, args.cells, args.time_steps)
+    L, N, T = w.L, w.N, w.T
 
     # the per-pass RCCL all-reduce: [loss] for the straight-lane workloads (every lane owns its unknowns); for the network
     # workloads the gradient summed over the rank's replicas as if the signal schedule were shared (BASELINE config 5) + loss
@@ -406,7 +183,9 @@ def main():
         if shared_grad:
             flat[:-1] = g_a.sum(dim=0)
         flat[-1] = loss
+        local_part = flat.clone() if world > 1 else None
         D.allreduce_sum_(flat)
+        return local_part
     for _ in range(args.warmup):
         loss, g_a, _ = w.one_pass()
         reduce_pass(loss, g_a)
@@ -415,37 +194,21 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, g_a, g_b = w.one_pass(record=True)
-        reduce_pass(loss, g_a)
+        local_part = reduce_pass(loss, g_a)
     D.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, dev)
 
-    from dhts import ops
     fault = w.err.tolist()
     assert fault[0] in (0, 2), "simulation fault during the bench: %s" % (fault,)
     assert torch.isfinite(g_a).all() and torch.isfinite(g_b).all() and bool(torch.isfinite(flat).all())
+    # every rank's own [gradient || loss] of the last pass, gathered so that rank 0 can show the all-reduce summed them
+    parts = D.gather_to_rank0(local_part) if world > 1 else None
 
     if rank == 0:
-        fwd_ms = [e[0].elapsed_time(e[1]) for e in w.ev]
-        bwd_ms = [e[2].elapsed_time(e[3]) for e in w.ev]
-        fwd_avg, bwd_avg = sum(fwd_ms) / len(fwd_ms), sum(bwd_ms) / len(bwd_ms)
-        per_launch_bytes = w.units * w.unit_bytes          # tape bytes one launch writes (fwd) / reads (bwd)
-        kernels = {
-            "rollout_fwd": {"ms": fwd_avg, "algorithmic_GB": per_launch_bytes / 1e9, "GBps": per_launch_bytes / fwd_avg / 1e6},
-            "rollout_bwd": {"ms": bwd_avg, "algorithmic_GB": per_launch_bytes / 1e9, "GBps": per_launch_bytes / bwd_avg / 1e6},
-        }
-        dom = "rollout_fwd" if fwd_avg >= bwd_avg else "rollout_bwd"
-        achieved = kernels[dom]["GBps"]
-        # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE
-        # and --pmc WRITE_SIZE, gfx950 FETCH correction applied); only quoted for the configuration they were taken on
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if w.name in pmc and (L, N, T) in ((1024, 512, 1000), (4096, 256, 1000)):
-                traffic = pmc[w.name][dom]["hbm_bytes"]
-        except (OSError, ValueError, KeyError):
-            traffic = None
+        kernels, dom = kernel_records(w)
+        k = kernels[dom]
         value = w.units * args.steps * world / elapsed
         out = {
             "metric": "differentiable cell-steps/s (fwd+bwd)",
@@ -462,22 +225,38 @@ def main():
             "dtype_detail": "float32 state widened to double for the step, Jacobian tape and adjoint in float32 (the reference's ladder)",
             "data": "synthetic",
             "config": {"workload": w.name, "lanes_per_gpu": L, "units_per_lane": N, "time_steps": T,
-                       "parallelism": "lanes sharded over %d GPU(s), no data-path collective" % world},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (PMC)",
-                         "algorithmic_bytes_per_launch": per_launch_bytes,
-                         "stored_bytes_per_launch": w.units * w.stored_bytes,
-                         "limiter": getattr(w, "limiter", {}).get(dom, "hbm"),
-                         "note": "achieved = algorithmic tape bytes (the reference's dqs: 48 B per cell-step, 32 B per vehicle-step) / "
-                                 "kernel time; the kernels store a compact equivalent (stored_bytes_per_launch) and rebuild the blocks "
-                                 "in the reverse sweep, so PMC traffic sits below the algorithmic bytes"},
-            "whole_path": {"algorithmic_GBps": w.units * 2 * w.unit_bytes * args.steps / elapsed / 1e9,
-                           "frac_of_peak": w.units * 2 * w.unit_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
+                       "parallelism": "%s sharded over %d GPU(s), no data-path collective; one all-reduce of [%s] per pass"
+                                      % ("replicas" if shared_grad else "lanes", world,
+                                         "d loss / d action || loss" if shared_grad else "loss")},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": k["frac_of_peak"], "traffic": pmc_traffic(w, dom), "traffic_unit": "bytes per launch (PMC)",
+                         "moved_bytes_per_launch": w.moved_bytes_per_launch(),
+                         "algorithmic_bytes_per_launch": w.units * w.unit_bytes,
+                         "achieved_algorithmic": k["algorithmic_GBps"], "frac_algorithmic": k["algorithmic_GBps"] / HBM_PEAK_GBS,
+                         "limiter": w.limiter.get(dom, "hbm"),
+                         "note": "achieved = bytes the kernel moves (its compact tape: the same information as the reference's dqs "
+                                 "blocks, which the reverse sweep rebuilds) / HIP-event time of the launch; *_algorithmic = the "
+                                 "reference's tape bytes (48 B per cell-step, 32 B per vehicle-step) / the same time"},
+            "whole_path": {"moved_GBps": 2 * w.moved_bytes_per_launch() * args.steps / elapsed / 1e9,
+                           "frac_of_peak": 2 * w.moved_bytes_per_launch() * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                           "algorithmic_GBps": w.units * 2 * w.unit_bytes * args.steps / elapsed / 1e9},
             "kernels": kernels,
+            "loss_last_pass": flat.tolist()[-1],          # summed over ranks by the all-reduce
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = w.cpu_baseline()
+        if parts is not None:
+            out["allreduce_check"] = {"reduced": flat.tolist()[-1], "sum_of_rank_parts": float(parts[:, -1].double().sum()),
+                                      "rank_parts": parts[:, -1].tolist(),
+                                      "grad_max_abs_diff": float((parts[:, :-1].double().sum(dim=0) - flat[:-1].double().cpu()).abs().max())
+                                      if shared_grad else 0.0}
+        if world == 1:
+            if args.workload == "macro" and not args.lanes and not args.cells and not args.time_steps and not args.no_also:
+                del w.tape            # 17 GB back to the allocator before the other workloads take theirs
+                torch.cuda.empty_cache()
+                out["also"] = [also_record("micro", dev), also_record("itscp_hybrid", dev)]
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = w.cpu_baseline()
         print(json.dumps(out))
+    D.barrier()
 
 
 if __name__ == "__main__":

@@ -1141,7 +1141,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     const int sg_q = tid - sg_base;
     const bool is_own = in_rows && (!row_mode || ((tid - row_base) & 15) == 15);
     int rev_ph = T > 0 ? (T - 1) / F : 0, rev_fr = T > 0 ? (T - 1) % F : 0;      // (t / F, t % F) of the step being reversed
-    bool bad = false, over = false, bad_key = false;
+    bool over = false, bad_key = false;
+    int bad_step = -1;          // first non-finite cotangent this thread meets (reverse order: the latest step)
     if (tid < sq) for (int k = tid; k < n_action; k += sq) g_action[(size_t)rep * n_action + k] = 0.f;
     __syncthreads();
 
@@ -1447,7 +1448,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
                 }
             }
             gL[tid] = v_r; gL[C + tid] = v_y; gL[2 * C + tid] = v_u;
-            bad |= !(isfinite(v_r) && isfinite(v_y) && isfinite(v_u));
+            if (bad_step < 0 && !(isfinite(v_r) && isfinite(v_y) && isfinite(v_u))) bad_step = t;
         }
         if (in_rows) {
             double v = 0.;
@@ -1469,7 +1470,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         lds_barrier();
     }
     if (is_own && cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + own_q] = (float)ga;
-    if (bad) net_fault(err, DHTS_FAULT_NAN, 0, 0, tid);
+    if (bad_step >= 0) net_fault(err, DHTS_FAULT_NAN, bad_step, rep, tid);
     if ((over && is_mt) || bad_key) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, bad_key ? -2 : 0);
 #undef LF
 }

@@ -195,7 +195,7 @@ __global__ void macro_rollout_bwd_kernel(
     __syncthreads();
 
     double ghl_r = 0., ghl_y = 0., ghr_r = 0., ghr_y = 0.;   // ghost cotangent sums (thread 0 / thread of cell N-1)
-    bool bad = false;
+    int bad_step = -1, bad_cell = 0;     // first non-finite cotangent this thread meets (the reverse sweep's first = the latest step)
     for (int step = T - 1; step >= 0; --step) {
         const float4 *tp = tape + ((size_t)step * L + lane) * tape_row;
         const float *gh = g_hist ? g_hist + ((size_t)step * L + lane) * 2 * N : nullptr;
@@ -231,7 +231,7 @@ __global__ void macro_rollout_bwd_kernel(
             const float nr = (Gr[k + 1] + c2lr) + c0rr;
             const float ny = (Gy[k + 1] + c2ly) + c0ry;
             Gr[k + 1] = nr; Gy[k + 1] = ny;
-            bad |= !(isfinite(nr) && isfinite(ny));
+            if (bad_step < 0 && !(isfinite(nr) && isfinite(ny))) { bad_step = step; bad_cell = k; }
         }
         __syncthreads();
     }
@@ -240,7 +240,7 @@ __global__ void macro_rollout_bwd_kernel(
         if (t == 0) { g_ghost[(size_t)lane * 4 + 0] = ghl_r; g_ghost[(size_t)lane * 4 + 1] = ghl_y; }
         if (t == (N - 1) % B) { g_ghost[(size_t)lane * 4 + 2] = ghr_r; g_ghost[(size_t)lane * 4 + 3] = ghr_y; }
     }
-    if (bad) raise_fault(err, DHTS_FAULT_NAN, 0, lane, t);
+    if (bad_step >= 0) raise_fault(err, DHTS_FAULT_NAN, bad_step, lane, bad_cell);
 }
 
 // ---- known-answer entry: n independent interfaces, both solver variants ---------------------------------

@@ -126,7 +126,9 @@ __global__ __launch_bounds__(64 * kW) void micro_rollout_fwd_kernel(
     }
     __syncthreads();
     const float *Fp = Sp + ((kW > 1 && (T & 1)) ? 2 * (V + 1) : 0), *Fv = Sv + ((kW > 1 && (T & 1)) ? 2 * (V + 1) : 0);
-    for (int k = t; k < V; k += kStride) { p_out[base + k] = Fp[k]; v_out[base + k] = Fv[k]; }
+    // slots >= count pass through: a step writes only live slots, and with kW > 1 and an odd T the final buffer is the one the
+    // initial load never filled
+    for (int k = t; k < V; k += kStride) { p_out[base + k] = k < n ? Fp[k] : p_in[base + k]; v_out[base + k] = k < n ? Fv[k] : v_in[base + k]; }
     if (fault_step >= 0) raise_fault_m(err, DHTS_FAULT_COLLISION, fault_step, lane, fault_index);
 }
 

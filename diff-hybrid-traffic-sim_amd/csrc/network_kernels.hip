@@ -401,7 +401,7 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
     float g_r = 0.f, g_y = 0.f;          // cotangent of this thread's cell at time t+1
     double ga = 0.;                      // thread q < sq: d reward / d action[cur_phase * sq + q], flushed when the phase changes
     int cur_phase = -1;
-    bool bad = false;
+    int bad_step = -1;          // first non-finite cotangent this thread meets (reverse order: the latest step)
     // actions of phases the rollout never reaches get a zero gradient (thread q owns the entries of intersection q)
     if (tid < sq) for (int k = tid; k < n_action; k += sq) g_action[(size_t)rep * n_action + k] = 0.f;
 
@@ -522,7 +522,7 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
                 }
             }
             g_r = v_r; g_y = v_y;
-            bad |= !(isfinite(v_r) && isfinite(v_y));
+            if (bad_step < 0 && !(isfinite(v_r) && isfinite(v_y))) bad_step = t;
         }
         if (tid < sq) {
             double v = 0.;
@@ -537,7 +537,7 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
         // inbox entries and the reduction scratch are rewritten two barriers later
     }
     if (tid < sq && cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + tid] = (float)ga;
-    if (bad) net_fault(err, DHTS_FAULT_NAN, 0, 0, tid);
+    if (bad_step >= 0) net_fault(err, DHTS_FAULT_NAN, bad_step, rep, tid);
 }
 
 }  // namespace dhts

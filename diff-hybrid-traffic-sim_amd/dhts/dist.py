@@ -17,8 +17,15 @@ def init(backend=None):
     rank, world, local = env_rank_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            # DHTS_DIST_BACKEND=gloo lets two ranks share one GPU in a smoke test; the default on GPUs is RCCL ("nccl")
-            backend = os.environ.get("DHTS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            # the default on GPUs is RCCL ("nccl"); DHTS_DIST_BACKEND=gloo -- or more ranks than devices -- lets several ranks
+            # share one GPU in a smoke test (RCCL refuses two ranks on one device)
+            backend = os.environ.get("DHTS_DIST_BACKEND")
+            if not backend:
+                n_dev = torch.cuda.device_count()
+                backend = "nccl" if n_dev >= world else "gloo"
+                if n_dev and backend == "gloo" and rank == 0:
+                    print("dhts.dist: %d ranks on %d GPU(s): ranks share devices, collectives over gloo" % (world, n_dev), flush=True,
+                          file=__import__("sys").stderr)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -32,20 +39,47 @@ def shard_range(n_units, rank, world):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def _active():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _staged(t):
+    """gloo moves host memory: a device tensor goes through a host copy there (RCCL takes it as it is)."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
 def allreduce_sum_(flat):
     """In-place sum over ranks of a flat float32 buffer [d loss / d theta_shared || loss]; no-op at world size 1."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if _active():
+        if _staged(flat):
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
 
+def gather_to_rank0(flat):
+    """[world][n] host copy of every rank's flat buffer on rank 0 (None elsewhere); diagnostics only, not on the timed path."""
+    if not _active():
+        return flat.detach().cpu()[None]
+    world = dist.get_world_size()
+    src = flat.detach().cpu() if _staged(flat) else flat.detach()
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src)
+    return torch.stack([p.cpu() for p in parts]) if dist.get_rank() == 0 else None
+
+
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()
 
 
 def max_over_ranks(seconds, device):
+    if _active() and dist.get_backend() == "gloo":
+        device = torch.device("cpu")
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

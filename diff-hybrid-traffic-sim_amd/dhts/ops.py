@@ -45,11 +45,14 @@ def raise_on_fault(err):
         raise AssertionError("Time step size does not meet CFL condition. Please try smaller delta_time. "
                              "(step %d, lane %d, interface %d)" % (step, lane, index))
     if code == _lib.FAULT_NAN:
-        raise AssertionError("non-finite gradient in the reverse sweep (lane %d)" % lane)   # dmacro_lane.py:308
+        raise AssertionError("non-finite gradient in the reverse sweep (step %d, lane %d)" % (step, lane))   # dmacro_lane.py:308
     if code == _lib.FAULT_CAPACITY:
         raise RuntimeError("hybrid network: a fixed capacity was exceeded (record stream / vehicles / lane list / routes); "
                            "index %d" % index)
-    return code   # FAULT_COLLISION is printed-and-tolerated in the reference (_micro_lane.py:155-160)
+    if code == _lib.FAULT_COLLISION:
+        # printed and tolerated in the reference (_micro_lane.py:155-160): the deltas of that vehicle are zeroed, the run goes on
+        print("Collision detected between vehicles (step %d, lane %d, vehicle %d)" % (step, lane, index))
+    return code
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -291,7 +294,7 @@ class MicroRollout(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, p0, v0, params, head, count, T, dt, want_hist=False):
+    def forward(ctx, p0, v0, params, head, count, T, dt, want_hist=False, check_faults=True):
         L, V = p0.shape
         desc = micro_desc(L, V, dt)
         p0c, v0c = _f32c(p0.detach(), "p0"), _f32c(v0.detach(), "v0")
@@ -300,7 +303,9 @@ class MicroRollout(torch.autograd.Function):
         hist = torch.empty(T, L, 2, V, dtype=torch.float32, device=p0.device) if want_hist else None
         err = new_error_record(p0.device)
         pT, vT = micro_rollout_fwd(desc, T, p0c, v0c, params, head.detach(), count=count, tape=tape, hist=hist, err=err)
-        ctx.desc, ctx.T, ctx.tape, ctx.count, ctx.want_hist, ctx.err = desc, T, tape, count, want_hist, err
+        if check_faults:                 # a collision is printed like the reference does, and tolerated
+            raise_on_fault(err)
+        ctx.desc, ctx.T, ctx.tape, ctx.count, ctx.want_hist = desc, T, tape, count, want_hist
         if want_hist:
             return pT, vT, hist
         return pT, vT
@@ -314,11 +319,11 @@ class MicroRollout(torch.autograd.Function):
         g_v = g_vT.contiguous() if g_vT is not None else torch.zeros(L, V, device=dev)
         gh = g_hist.contiguous() if (ctx.want_hist and g_hist is not None) else None
         g_p0, g_v0, g_head = micro_rollout_bwd(desc, T, ctx.tape, g_p, g_v, count=ctx.count, g_hist=gh)
-        return g_p0, g_v0, None, g_head, None, None, None, None
+        return g_p0, g_v0, None, g_head, None, None, None, None, None
 
 
-def micro_rollout(p0, v0, params, head, T, dt, count=None, want_hist=False):
-    return MicroRollout.apply(p0, v0, params, head, count, int(T), float(dt), want_hist)
+def micro_rollout(p0, v0, params, head, T, dt, count=None, want_hist=False, check_faults=True):
+    return MicroRollout.apply(p0, v0, params, head, count, int(T), float(dt), want_hist, bool(check_faults))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -397,7 +402,7 @@ class NetMacroRollout(torch.autograd.Function):
     reference in `macro` mode, reward = - sum of squared queue lengths); also returns the per-step queue terms."""
 
     @staticmethod
-    def forward(ctx, action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed, vehicle_length):
+    def forward(ctx, action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed, vehicle_length, check_faults=True):
         a = _f32c(action.detach(), "action")
         R, A = a.shape
         if dev_tables.n_replica_tables not in (0, R):
@@ -419,8 +424,9 @@ class NetMacroRollout(torch.autograd.Function):
         check(lib.dhts_net_macro_rollout_fwd(C.byref(d), C.byref(dev_tables.c), _ptr(a), _ptr(hist), _ptr(tape), _ptr(kc),
                                              _ptr(queue), _ptr(reward), _ptr(ws), _ptr(err), _stream()),
               "dhts_net_macro_rollout_fwd")
-        raise_on_fault(err)
-        ctx.d, ctx.tables = d, dev_tables
+        if check_faults:                 # reading the record back synchronises: off inside HIP-graph capture
+            raise_on_fault(err)
+        ctx.d, ctx.tables, ctx.check_faults = d, dev_tables, bool(check_faults)
         ctx.save_for_backward(a, hist, tape, kc, queue, ws)
         ctx.mark_non_differentiable(queue)
         return reward, queue
@@ -431,16 +437,21 @@ class NetMacroRollout(torch.autograd.Function):
         d = ctx.d
         g_action = torch.empty_like(a)
         err = new_error_record(a.device)
+        g = g_reward.contiguous().float()          # a named local: the (possibly fresh) tensor must outlive the launch
         check(_lib.lib().dhts_net_macro_rollout_bwd(C.byref(d), C.byref(ctx.tables.c), _ptr(a), _ptr(hist), _ptr(tape), _ptr(kc),
-                                                    _ptr(queue), _ptr(g_reward.contiguous().float()), _ptr(g_action), _ptr(ws), _ptr(err),
+                                                    _ptr(queue), _ptr(g), _ptr(g_action), _ptr(ws), _ptr(err),
                                                     _stream()), "dhts_net_macro_rollout_bwd")
-        raise_on_fault(err)
-        return g_action, None, None, None, None, None, None, None
+        if ctx.check_faults:
+            raise_on_fault(err)
+        return g_action, None, None, None, None, None, None, None, None
 
 
-def net_macro_rollout(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0):
+def net_macro_rollout(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0,
+                      check_faults=True):
+    """Returns (reward [R], queue [R][T][L]).  check_faults=False: nothing is read back (no host sync; usable inside a
+    HIP-graph capture); faults stay in the device record."""
     return NetMacroRollout.apply(action, dev_tables, int(n_inter_sq), int(frames_per_phase), float(dt), float(u_max),
-                                 float(static_speed), float(vehicle_length))
+                                 float(static_speed), float(vehicle_length), bool(check_faults))
 
 
 class DeviceHybridTables:
@@ -516,7 +527,8 @@ class NetHybridRollout(torch.autograd.Function):
         check(lib.dhts_net_hybrid_rollout_fwd(C.byref(d), C.byref(tc), _ptr(a), _ptr(hist), _ptr(tape), _ptr(kc), _ptr(queue),
                                               _ptr(reward), _ptr(counts), _ptr(ws), _ptr(err), _stream()),
               "dhts_net_hybrid_rollout_fwd")
-        raise_on_fault(err)
+        if check_faults:                 # reading the record back synchronises: off inside HIP-graph capture
+            raise_on_fault(err)
         ctx.d, ctx.tables, ctx.loss_steps, ctx.check_faults = d, t, int(loss_steps), bool(check_faults)
         ctx.save_for_backward(a, hist, tape, kc, queue, ws)
         ctx.mark_non_differentiable(reward, queue, counts)
@@ -534,8 +546,9 @@ class NetHybridRollout(torch.autograd.Function):
         tc = ctx.tables.c(ctx.loss_steps)
         g_action = torch.empty_like(a)
         err = new_error_record(a.device)
+        g = g_cut.contiguous().float()             # a named local: the (possibly fresh) tensor must outlive the launch
         check(_lib.lib().dhts_net_hybrid_rollout_bwd(C.byref(d), C.byref(tc), _ptr(a), _ptr(hist), _ptr(tape), _ptr(kc), _ptr(queue),
-                                                     _ptr(g_cut.contiguous().float()), _ptr(g_action), _ptr(ws), _ptr(err), _stream()),
+                                                     _ptr(g), _ptr(g_action), _ptr(ws), _ptr(err), _stream()),
               "dhts_net_hybrid_rollout_bwd")
         if ctx.check_faults:
             raise_on_fault(err)     # a NaN in the reverse sweep asserts like the reference (dmacro_lane.py:308)
@@ -545,7 +558,8 @@ class NetHybridRollout(torch.autograd.Function):
 def net_hybrid_rollout(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0,
                        loss_steps=0, check_faults=True):
     """Returns (reward restricted to the first loss_steps steps [differentiable], full reward, queue [R][T][L], counts [R][4]).
-    check_faults=False: a non-finite cotangent in the reverse sweep (the reference asserts on it, dmacro_lane.py:308; it
+    check_faults=False: nothing is read back in either direction (no host sync; usable inside a HIP-graph capture), and a
+    non-finite cotangent in the reverse sweep (the reference asserts on it, dmacro_lane.py:308; it
     happens e.g. when a head gap clamps to exactly 0 and the IDM Jacobian divides by it, didm.py:60-70) is left in the
     returned gradient of that replica instead of raising, so that a batch survives one bad member."""
     return NetHybridRollout.apply(action, dev_tables, int(n_inter_sq), int(frames_per_phase), float(dt), float(u_max),

@@ -1,0 +1,79 @@
+"""bench.py as the driver runs it: `python bench.py --gpus N` must start N ranks itself.
+
+CPU part: the launcher fails loudly (non-zero, no JSON) when the ranks cannot run.  GPU part (`-m gpu`): two ranks on the
+one leased GPU (collectives over gloo, because RCCL refuses two ranks on one device) -- the JSON line says n_gpus = 2, the
+value counts both ranks' units, and the all-reduced [gradient || loss] buffer equals the sum of the two shards' buffers.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run_bench(args, timeout=900, env=None):
+    e = dict(os.environ)
+    e.pop("RANK", None), e.pop("WORLD_SIZE", None), e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, BENCH] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout,
+                       env=e, cwd=ROOT)
+    return p
+
+
+def last_json(text):
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert lines, "no JSON line in: %r" % text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_launcher_fails_loudly_without_gpus():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu tests")
+    p = run_bench(["--gpus", "2", "--workload", "macro", "--lanes", "8", "--time-steps", "5", "--no-cpu-baseline"], timeout=300)
+    assert p.returncode != 0
+    assert "needs a GPU" in p.stderr and "rank(s) failed" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_two_ranks_macro_lanes(cuda):
+    one = run_bench(["--gpus", "1", "--workload", "macro", "--lanes", "64", "--time-steps", "50", "--steps", "3", "--warmup", "1",
+                     "--no-cpu-baseline"])
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = run_bench(["--gpus", "2", "--workload", "macro", "--lanes", "64", "--time-steps", "50", "--steps", "3", "--warmup", "1",
+                     "--no-cpu-baseline"], env={"DHTS_DIST_BACKEND": "gloo"})
+    assert two.returncode == 0, two.stderr[-3000:]
+    a, b = last_json(one.stdout), last_json(two.stdout)
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["scaling"] == "weak"
+    assert b["config"]["lanes_per_gpu"] == 64
+    # value = units of ALL ranks / max-over-ranks time: both ranks' 64 x 512 x 50 cell-steps per pass
+    units = 64 * 512 * 50
+    assert abs(b["value"] * b["ms_per_step"] * 1e-3 / (2 * units) - 1.0) < 1e-9
+    assert abs(a["value"] * a["ms_per_step"] * 1e-3 / units - 1.0) < 1e-9
+    chk = b["allreduce_check"]
+    assert len(chk["rank_parts"]) == 2 and chk["rank_parts"][0] != chk["rank_parts"][1]      # different shards (seed + rank)
+    assert abs(chk["reduced"] - chk["sum_of_rank_parts"]) <= 1e-6 * abs(chk["sum_of_rank_parts"])
+    # rank 0 of the two-rank run owns the same lanes as the one-rank run: same loss
+    assert chk["rank_parts"][0] == a["loss_last_pass"] and b["loss_last_pass"] == chk["reduced"]
+
+
+@pytest.mark.gpu
+def test_two_ranks_hybrid_replicas_shared_schedule(cuda):
+    """BASELINE config 5's pattern: replicas sharded over ranks, d reward / d (shared signal schedule) + reward all-reduced."""
+    two = run_bench(["--gpus", "2", "--workload", "itscp_hybrid", "--lanes", "8", "--steps", "2", "--warmup", "1",
+                     "--no-cpu-baseline"], env={"DHTS_DIST_BACKEND": "gloo"})
+    assert two.returncode == 0, two.stderr[-3000:]
+    b = last_json(two.stdout)
+    assert b["n_gpus"] == 2 and b["config"]["lanes_per_gpu"] == 8
+    assert "replicas sharded over 2" in b["config"]["parallelism"]
+    chk = b["allreduce_check"]
+    assert abs(chk["reduced"] - chk["sum_of_rank_parts"]) <= 1e-6 * abs(chk["sum_of_rank_parts"])
+    assert chk["grad_max_abs_diff"] <= 1e-6 * max(abs(x) for x in chk["rank_parts"])
+    units = 8 * b["config"]["units_per_lane"] * b["config"]["time_steps"]
+    assert abs(b["value"] * b["ms_per_step"] * 1e-3 / (2 * units) - 1.0) < 1e-9

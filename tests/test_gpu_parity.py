@@ -454,14 +454,16 @@ def micro_fwd_waves(request):
     _lib.lib().dhts_set_option(_lib.OPT_MICRO_FWD_WAVES, 0)
 
 
+@pytest.mark.parametrize("T", [20, 21])
 @pytest.mark.parametrize("micro_fwd_waves", [0, 1, 2, 4], indirect=True)
-def test_micro_ragged_and_empty_lanes(cuda, oracle, micro_fwd_waves):
+def test_micro_ragged_and_empty_lanes(cuda, oracle, micro_fwd_waves, T):
     """Per-lane vehicle counts: empty lane, single vehicle, partly filled, full -- for every wavefronts-per-lane variant of
-    the forward kernel (T odd and even ends in either ping-pong buffer)."""
+    the forward kernel, each with an even and an odd T (the state ends in either ping-pong buffer; slots beyond the count
+    must pass through from the input in both)."""
     import torch
     from dhts import ops
     rng = np.random.default_rng(9)
-    V, T, dt = 200, 20 + (micro_fwd_waves & 1), 0.01
+    V, dt = 200, 0.01
     counts = [0, 1, 37, 64, 65, 128, 129, 200]
     L = len(counts)
     p0 = (np.arange(V)[None, :] * 20.0 + rng.uniform(0, 10, (L, V))).astype(np.float32)
@@ -485,6 +487,7 @@ def test_micro_ragged_and_empty_lanes(cuda, oracle, micro_fwd_waves):
         assert rel_max(pT[l, :n].cpu().numpy(), f["pT"][0]) <= 1e-6
         assert rel_max(vT[l, :n].cpu().numpy(), f["vT"][0]) <= 1e-6
         assert torch.equal(pT[l, n:].cpu(), torch.tensor(p0[l, n:]))      # untouched slots pass through
+        assert torch.equal(vT[l, n:].cpu(), torch.tensor(v0[l, n:]))
         assert rel_max(g_p0[l, :n].cpu().numpy(), b["g_p0"][0]) <= 1e-5
         assert rel_max(g_v0[l, :n].cpu().numpy(), b["g_v0"][0]) <= 1e-5
         assert float(g_p0[l, n:].abs().max()) == 0.0 if n < V else True

@@ -577,6 +577,44 @@ def gen_hybrid(name="hybrid3", N=10, T=500, dx=5.0, dt=0.01, um=30.0, seed=21):
 # G8: itscp environment (example/control/itscp): lane table, schedules, routes, reward and d reward / d action
 # ----------------------------------------------------------------------------------------------
 
+class SolverMargins:
+    """Wraps ARZ.riemann_solve (calls it unchanged) and notes how close the run came to the solver's hard thresholds:
+    the vacuum tests r_L < EPSILON / r_R < EPSILON and the equal-speed test |u_L - u_R| < EPSILON (_arz.py:225-257).
+    A decision taken within float32 rounding of a threshold makes the run's gradient depend on the last bit of the
+    torch build's float32 glue (SURVEY Note P), so goldens meant to pin a gradient log their minimum margin."""
+
+    def __init__(self):
+        self.orig = ARZ.riemann_solve
+        self.n = 0
+        self.min_equal = (np.inf, -1.0, -1.0)       # (margin, u_L, u_R)
+        self.min_vacuum = np.inf
+        self.n_equal = 0
+
+    def __enter__(self):
+        def wrapped(ql, qr, u_max):
+            self.n += 1
+            rl, rr = float(ql.q.r), float(qr.q.r)
+            self.min_vacuum = min(self.min_vacuum, abs(rl - EPSILON))
+            if rl >= EPSILON:
+                self.min_vacuum = min(self.min_vacuum, abs(rr - EPSILON))
+                if rr >= EPSILON:
+                    d = abs(float(ql.u) - float(qr.u))
+                    self.n_equal += d < EPSILON
+                    m = abs(d - EPSILON)
+                    if m < self.min_equal[0]:
+                        self.min_equal = (m, float(ql.u), float(qr.u))
+            return self.orig(ql, qr, u_max)
+        ARZ.riemann_solve = staticmethod(wrapped)
+        return self
+
+    def __exit__(self, *a):
+        ARZ.riemann_solve = staticmethod(self.orig)
+
+    def as_meta(self):
+        return dict(solver_calls=self.n, equal_speed_decisions=int(self.n_equal), min_equal_speed_margin=self.min_equal[0],
+                    min_equal_speed_margin_at=[self.min_equal[1], self.min_equal[2]], min_vacuum_margin=self.min_vacuum)
+
+
 def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, action_kind, problem=1):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_stubs"))
     from example.control.itscp._env import ItscpEnv
@@ -624,7 +662,9 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
     action = th.tensor(a0, requires_grad=True)
     t0 = time.time()
     env.queue_length.clear()
-    env._simulate(action, True)
+    with SolverMargins() as margins:
+        env._simulate(action, True)
+    print("G8 %s: solver margins %s" % (name, margins.as_meta()))
     queue = np.array([[float(x) for x in env.queue_length[k]] for k in keys], dtype=np.float64)   # [lanes][T]
     reward = env._reward(action)
     t1 = time.time()
@@ -682,6 +722,7 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
         meta=meta(seed=seed, mode=mode, num_intersection=n_int, num_lane=n_lane, lane_length=lane_length,
                   policy_length=sim_len, signal_length=sig_len, speed_limit=60.0, cell_length=5.0, simulation_frequency=30,
                   static_speed=0.2, vehicle_length=5.0, T=T, n_vehicle_spawned=nveh, problem=problem,
+                  action_kind=action_kind, **margins.as_meta(),
                   ref_seconds_fwd=t1 - t0, ref_seconds_bwd=t2 - t1))
 
 
@@ -734,6 +775,17 @@ def main():
             os.environ["DHTS_FINE_CUTS"] = "100,200"
             os.environ.pop("DHTS_LANE_LATE", None)
             gen_itscp("hybrid_l10", "hybrid", 3, 1, 10.0, 10, 2, seed=55, action_kind="rand", problem=2)
+        # full-horizon pins of BASELINE config 4's episode (run_itscp_hybrid.sh: 3 x 3, 1 lane, 5 m, 20 s, signal 4 s = 600
+        # steps): action 0.5 (every signal sigmoid at its steepest point) and other seeds / inflow patterns;
+        # meta carries the run's minimum distance to the solver's equal-speed threshold
+        for nm, sd, kind, prob in (("hybrid_half", 9, "half", 1), ("hybrid_s2", 41, "rand", 1), ("hybrid_s3", 77, "rand", 1),
+                                   ("hybrid_p2_600", 63, "rand", 2), ("hybrid_half_p3", 15, "half", 3)):
+            if nm in which:
+                os.environ["DHTS_FINE_CUTS"] = "150,300,450,540"
+                os.environ.pop("DHTS_LANE_LATE", None)
+                gen_itscp(nm, "hybrid", 3, 1, 5.0, 20, 4, seed=sd, action_kind=kind, problem=prob)
+        if "macro_half" in which:        # run_itscp_macro.sh's episode at action 0.5
+            gen_itscp("macro_half", "macro", 1, 3, 30.0, 10, 2, seed=8, action_kind="half")
         if "hybrid_short" in which:      # 8 s: enough for the first vehicles to cross the interior intersection
             gen_itscp("hybrid_short", "hybrid", 3, 1, 5.0, 8, 2, seed=9, action_kind="rand")
 
