@@ -95,6 +95,355 @@ def spawn_ranks(n):
     return 0
 
 
+class MacroWorkload:
+    """r0 ~ U[0.05, 0.95], u0 ~ U[0, u_max], fixed random ghosts, dx = 5, dt = 0.01, u_max = 30,
+    loss = sum r_T^2 + sum u_T^2."""
+    name = "macro_straight_1024x512x1000"
+    unit_bytes = MACRO_TAPE_B
+    unit_name = "cell-steps/s"
+    # what each kernel actually runs into (PMC, DESIGN.md section 6): the forward's double-precision Riemann solves keep the
+    # VALUs ~80 % busy while it writes at 3 TB/s; the reverse sweep streams the tape at 5.7 TB/s
+    limiter = {"rollout_fwd": "valu (f64 issue, ~80 % busy; HBM writes at 3 TB/s)", "rollout_bwd": "hbm (5.7 TB/s of reads)"}
+
+    def __init__(self, dev, rank, L, N, T):
+        from dhts import ops
+        self.ops, self.L, self.N, self.T = ops, L, N, T
+        self.dt, self.dx, self.um = 0.01, 5.0, 30.0
+        gen = torch.Generator(device="cpu").manual_seed(2026 + rank)
+        self.r0 = (0.05 + 0.9 * torch.rand(L, N, generator=gen)).to(dev)
+        self.u0 = (self.um * torch.rand(L, N, generator=gen)).to(dev)
+        gr = (0.05 + 0.9 * torch.rand(L, 2, generator=gen)).to(dev)
+        gu = (self.um * torch.rand(L, 2, generator=gen)).to(dev)
+        gy, gq = ops.macro_state_from_ru(gr, gu, self.um)
+        self.ghost = torch.stack([gr, gy, gu, gq], dim=-1).contiguous()
+        self.desc = ops.macro_desc(L, N, self.dt, self.dx, self.um)
+        # zeros, not empty: the first touch of 17 GB would otherwise be billed to the first warm-up launch (and to the average
+        # of a rocprofv3 --stats run of this command)
+        self.tape = torch.zeros(ops.macro_tape_numel(self.desc, T), dtype=torch.float32, device=dev)
+        self.tape_bytes = self.tape.numel() * 4
+        self.err = ops.new_error_record(dev)
+        self.out = tuple(torch.empty(L, N, device=dev) for _ in range(4))
+        self.gout = (torch.empty(L, N, device=dev), torch.empty(L, N, device=dev))
+        self.g_ghost = torch.zeros(L, 2, 2, dtype=torch.float64, device=dev)
+        self.units = L * N * T                       # cell-steps per pass
+        self.name = "macro_straight_%dx%dx%d" % (L, N, T)
+        self.ev = []
+
+    def moved_bytes_per_launch(self):
+        """the tape one launch writes (forward) / reads (reverse); state, ghosts and cotangents are O(cells), not O(cells x T)"""
+        return self.tape_bytes
+
+    def one_pass(self, record=False):
+        ops = self.ops
+        y0, q0 = ops.macro_state_from_ru(self.r0, self.u0, self.um)
+        if record:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e[0].record()
+        rT, yT, uT, _ = ops.macro_rollout_fwd(self.desc, self.T, self.r0, y0, self.u0, q0, self.ghost,
+                                              tape=self.tape, err=self.err, out=self.out)
+        if record:
+            e[1].record()
+        loss = (rT * rT).sum() + (uT * uT).sum()
+        g_r, g_y = 2.0 * rT, torch.zeros_like(rT)
+        ops.macro_u_tap_bwd(rT, yT, 2.0 * uT, g_r, g_y, self.um)
+        if record:
+            e[2].record()
+        g_r0, g_y0, _ = ops.macro_rollout_bwd(self.desc, self.T, self.tape, g_r, g_y, err=self.err, out=self.gout,
+                                              g_ghost=self.g_ghost)
+        if record:
+            e[3].record()
+            self.ev.append(e)
+        g_u0 = ops.macro_state_from_ru_bwd(self.r0, self.u0, g_y0, g_r0, self.um)
+        return loss, g_r0, g_u0
+
+    def cpu_baseline(self):
+        """The C oracle (a port of the reference's algorithm) on the host cores: bounded sample of the same
+        workload -- 2 lanes per core x 512 cells x 250 steps, repeated for >= 10 s."""
+        import numpy as np
+        from oracle import oracle as O
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+        Lc, N, T = 2 * cores, self.N, 250
+        rng = np.random.default_rng(2026)
+        r0 = rng.uniform(0.05, 0.95, (Lc, N)).astype(np.float32)
+        u0 = rng.uniform(0.0, self.um, (Lc, N)).astype(np.float32)
+        gr = rng.uniform(0.05, 0.95, (Lc, 2)).astype(np.float32)
+        gu = rng.uniform(0.0, self.um, (Lc, 2)).astype(np.float32)
+        O.macro_rollout_fwd(r0[:2], u0[:2], gr[:2], gu[:2], 2, self.dt, self.dx, self.um)   # load + warm
+        done, t0 = 0, time.perf_counter()
+        while True:
+            f = O.macro_rollout_fwd(r0, u0, gr, gu, T, self.dt, self.dx, self.um)
+            O.macro_rollout_bwd(f, g_rT=2 * f["rT"], g_uT=2 * f["uT"])
+            done += Lc * N * T
+            el = time.perf_counter() - t0
+            if el >= 10.0:
+                break
+        # the same code on one core: a single lane leaves the OpenMP loop over lanes with one iteration (SURVEY 8d)
+        one, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 2.0:
+            f1 = O.macro_rollout_fwd(r0[:1], u0[:1], gr[:1], gu[:1], T, self.dt, self.dx, self.um)
+            O.macro_rollout_bwd(f1, g_rT=2 * f1["rT"], g_uT=2 * f1["uT"])
+            one += N * T
+        return {"value": done / el, "unit": "cell-steps/s", "cores": cores, "kind": "port",
+                "sample": "%d lanes x %d cells x %d steps fwd+bwd, repeated %.1f s (OpenMP over lanes)" % (Lc, N, T, el),
+                "one_core_value": one / (time.perf_counter() - t1)}
+
+
+class MicroWorkload:
+    """256 default_micro_vehicle(30) per lane, p_i = 20 i + U[0, 10), v ~ U[9, 21], head gap 1000 / 0,
+    dt = 0.01, loss = sum 1e-4 p_T^2 + sum v_T^2."""
+    name = "micro_idm_4096x256x1000"
+    unit_bytes = MICRO_TAPE_B
+    unit_name = "vehicle-steps/s"
+    limiter = {"rollout_fwd": "valu / latency (f64 IDM, ~65 % busy; HBM writes at 3.6 TB/s)", "rollout_bwd": "hbm (5.3 TB/s of reads)"}
+
+    def __init__(self, dev, rank, L, V, T):
+        from dhts import ops
+        self.ops, self.L, self.V, self.T = ops, L, V, T
+        self.dt = 0.01
+        gen = torch.Generator(device="cpu").manual_seed(3026 + rank)
+        self.p0 = (torch.arange(V)[None, :] * 20.0 + 10.0 * torch.rand(L, V, generator=gen)).to(dev)
+        self.v0 = (9.0 + 12.0 * torch.rand(L, V, generator=gen)).to(dev)
+        par = torch.tensor([30.0 * 1.0, 30.0 * 0.8, 30.0 * 0.9, 5.0 * 0.1, 0.1, 5.0], dtype=torch.float64, device=dev)
+        self.params = par[:, None, None].expand(6, L, V).contiguous()
+        self.head = torch.tensor([[1000.0, 0.0]], dtype=torch.float64, device=dev).expand(L, 2).contiguous()
+        self.desc = ops.micro_desc(L, V, self.dt)
+        self.tape = torch.zeros(ops.micro_tape_numel(self.desc, T), dtype=torch.float32, device=dev)
+        self.tape_bytes = self.tape.numel() * 4
+        self.N = V
+        self.err = ops.new_error_record(dev)
+        self.out = (torch.empty(L, V, device=dev), torch.empty(L, V, device=dev))
+        self.gout = (torch.empty(L, V, device=dev), torch.empty(L, V, device=dev))
+        self.g_head = torch.zeros(L, 2, dtype=torch.float64, device=dev)
+        self.units = L * V * T
+        self.name = "micro_idm_%dx%dx%d" % (L, V, T)
+        self.ev = []
+
+    def moved_bytes_per_launch(self):
+        return self.tape_bytes
+
+    def one_pass(self, record=False):
+        ops = self.ops
+        if record:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e[0].record()
+        pT, vT = ops.micro_rollout_fwd(self.desc, self.T, self.p0, self.v0, self.params, self.head, tape=self.tape,
+                                       err=self.err, out=self.out)
+        if record:
+            e[1].record()
+        loss = 1e-4 * (pT * pT).sum() + (vT * vT).sum()
+        g_p, g_v = 2e-4 * pT, 2.0 * vT
+        if record:
+            e[2].record()
+        g_p0, g_v0, _ = ops.micro_rollout_bwd(self.desc, self.T, self.tape, g_p, g_v, err=self.err, out=self.gout,
+                                              g_head=self.g_head)
+        if record:
+            e[3].record()
+            self.ev.append(e)
+        return loss, g_p0, g_v0
+
+    def cpu_baseline(self):
+        import numpy as np
+        from oracle import oracle as O
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+        Lc, V, T = 4 * cores, self.V, 250
+        rng = np.random.default_rng(3026)
+        p0 = (np.arange(V)[None, :] * 20.0 + rng.uniform(0, 10, (Lc, V))).astype(np.float32)
+        v0 = rng.uniform(9, 21, (Lc, V)).astype(np.float32)
+        par = np.tile(np.array([30.0, 24.0, 27.0, 0.5, 0.1, 5.0]), (Lc, V, 1))
+        O.micro_rollout_fwd(p0[:2], v0[:2], par[:2], 2, self.dt)
+        done, t0 = 0, time.perf_counter()
+        while True:
+            f = O.micro_rollout_fwd(p0, v0, par, T, self.dt)
+            O.micro_rollout_bwd(f, g_pT=2e-4 * f["pT"], g_vT=2 * f["vT"])
+            done += Lc * V * T
+            el = time.perf_counter() - t0
+            if el >= 10.0:
+                break
+        one, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 2.0:
+            f1 = O.micro_rollout_fwd(p0[:1], v0[:1], par[:1], T, self.dt)
+            O.micro_rollout_bwd(f1, g_pT=2e-4 * f1["pT"], g_vT=2 * f1["vT"])
+            one += V * T
+        return {"value": done / el, "unit": "cell-steps/s", "cores": cores, "kind": "port",
+                "sample": "%d lanes x %d vehicles x %d steps fwd+bwd, repeated %.1f s (OpenMP over lanes)" % (Lc, V, T, el),
+                "one_core_value": one / (time.perf_counter() - t1)}
+
+
+class ItscpMacroWorkload:
+    """run_itscp_macro.sh's network (1 intersection, 3 lanes, 30 m, 10 s, signal 2 s: 40 lanes, 236 cells, 300 steps, 5
+    actions) x 256 replicas with per-replica problem_1 schedules and actions U[0.1, 0.9]: reward and d reward / d action
+    of every replica in one fused launch each way (a stepping stone to BASELINE config 4, which adds micro lanes)."""
+    name = "itscp_macro_256x(40 lanes, 236 cells)x300"
+    limiter = {"rollout_fwd": "latency (300 dependent steps, one workgroup per replica)", "rollout_bwd": "latency (300 dependent steps, one workgroup per replica)"}
+    unit_bytes = MACRO_TAPE_B
+    unit_name = "cell-steps/s"
+
+    def moved_bytes_per_launch(self):
+        """per-cell-step blocks (48 B) + state history (16 B) + loss constant (4 B), per-lane-step queue terms"""
+        return self.R * self.T * (self.N * (48 + 16 + 4) + self.n_lanes * 4)
+
+    def __init__(self, dev, rank, R, _n, _t):
+        import numpy as np
+        from dhts import ops
+        from dhts.network import MacroNetworkTables
+        from example.control.itscp._env import ItscpEnv
+        from example.control.itscp.problem import problem_1
+        self.ops, self.R = ops, R
+        np.random.seed(1000 * rank + 1)
+        env = ItscpEnv()
+        env.schedule_callback = problem_1
+        for k, v in dict(num_intersection=1, lane_length=30.0, num_lane=3, policy_length=10, signal_length=2, mode="macro",
+                         speed_limit=60.0).items():
+            env.config[k] = v
+        env.reset()
+        base = MacroNetworkTables.from_env(env)
+        tabs = [base]
+        keys = list(env.lane.keys())
+        for r in range(1, R):       # same topology and per-step routes, a fresh problem_1 inflow schedule per replica
+            sched = env.schedule_callback(keys, env.num_timestep)
+            t = MacroNetworkTables.__new__(MacroNetworkTables)
+            t.__dict__.update(base.__dict__)
+            t.schedule = np.ascontiguousarray(np.array([sched[k] for k in keys], dtype=np.float64).T)
+            tabs.append(t)
+        self.tab = ops.DeviceNetTables(tabs, dev)
+        self.host_tab = base
+        self.sq, self.F, self.dt, self.um = 1, 60, 1.0 / 30.0, 60.0
+        gen = torch.Generator(device="cpu").manual_seed(77 + rank)
+        self.action = (0.1 + 0.8 * torch.rand(R, env.action_size(), generator=gen)).to(dev).requires_grad_(True)
+        self.units = R * tabs[0].n_cells * tabs[0].T
+        self.L, self.N, self.T, self.n_lanes = R, tabs[0].n_cells, tabs[0].T, tabs[0].n_lanes
+        self.name = "itscp_macro_%dx(%d lanes, %d cells)x%d" % (R, self.n_lanes, self.N, self.T)
+        self.err = ops.new_error_record(dev)
+        self.ev = []
+
+    def one_pass(self, record=False):
+        self.action.grad = None
+        if record:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e[0].record()
+        reward, _ = self.ops.net_macro_rollout(self.action, self.tab, self.sq, self.F, self.dt, self.um)
+        if record:
+            e[1].record()
+        loss = -reward.sum()
+        if record:
+            e[2].record()
+        loss.backward()
+        if record:
+            e[3].record()
+            self.ev.append(e)
+        return loss.detach(), self.action.grad, self.action.grad
+
+    def cpu_baseline(self):
+        """The C oracle of the macro network (scalar, one core): whole episodes of replica 0, repeated for >= 10 s."""
+        from oracle import oracle as O
+        a = self.action[0].detach().cpu().numpy()
+        done, t0 = 0, time.perf_counter()
+        while True:
+            O.net_macro(self.host_tab, a, self.sq, self.F, self.dt, self.um)
+            done += self.N * self.T
+            el = time.perf_counter() - t0
+            if el >= 10.0:
+                break
+        return {"value": done / el, "unit": "cell-steps/s", "cores": 1, "kind": "port",
+                "sample": "replica 0's episode (%d cells x %d steps) fwd+bwd, repeated %.1f s on one core" % (self.N, self.T, el)}
+
+
+class ItscpHybridWorkload:
+    """run_itscp_hybrid.sh's network (3 x 3 intersections, 1 lane, 20 s, signal 4 s: 144 lanes of which the 16 of the
+    centre intersection are micro, 256 cells, 600 steps, 45 actions) x 256 replicas with per-replica problem_1 schedules and actions U[0.1, 0.9]: reward and
+    d reward / d action of every replica in one fused launch each way (BASELINE config 4)."""
+    name = "itscp_hybrid_256x(144 lanes, 256 cells, 16 micro lanes)x600"
+    limiter = {"rollout_fwd": "latency (600 dependent steps, one workgroup per replica)", "rollout_bwd": "latency (600 dependent steps, one workgroup per replica)"}
+    unit_bytes = MACRO_TAPE_B
+    unit_name = "cell-steps/s"
+
+    def moved_bytes_per_launch(self):
+        """per-cell-step blocks (48 B) + state history (16 B) + loss constant (4 B), per-lane-step queue terms, and the
+        36-byte records of the micro side (counts[:, 2] = records per replica)"""
+        recs = int(self.counts[:, 2].sum()) if self.counts is not None else 0
+        return self.R * self.T * (self.N * (48 + 16 + 4) + self.n_lanes * 4) + recs * 36
+
+    def __init__(self, dev, rank, R, _n, _t):
+        import numpy as np
+        from dhts import ops
+        from dhts.network import HybridNetworkTables
+        from example.control.itscp._env import ItscpEnv
+        from example.control.itscp.problem import problem_1
+        self.ops, self.R = ops, R
+        np.random.seed(1000 * rank + 9)
+        env = ItscpEnv()
+        env.schedule_callback = problem_1
+        for k, v in dict(num_intersection=3, lane_length=5.0, num_lane=1, policy_length=20, signal_length=4, mode="hybrid",
+                         speed_limit=60.0).items():
+            env.config[k] = v
+        env.reset()
+        tab = HybridNetworkTables.from_env(env)
+        # pre-drawn routes: 8 per micro lane that a macro lane feeds (RoadNetwork.create_random_route)
+        routes = []
+        for l in range(tab.n_lanes):
+            if tab.lane_macro[l] == 0 and any(tab.lane_macro[a] for a in tab.prev_lanes[l]):
+                for _ in range(8):
+                    r = env.simulator.create_random_route(l).route
+                    routes.append(list(r) + [-1] * (32 - len(r)))
+        tabs = [tab]
+        keys = list(env.lane.keys())
+        for r in range(1, R):       # same topology and per-step routes, a fresh problem_1 inflow schedule per replica
+            sched = env.schedule_callback(keys, env.num_timestep)
+            t = HybridNetworkTables.__new__(HybridNetworkTables)
+            t.__dict__.update(tab.__dict__)
+            t.schedule = np.ascontiguousarray(np.array([sched[k] for k in keys], dtype=np.float64).T)
+            tabs.append(t)
+        self.tab = ops.DeviceHybridTables(tabs, np.array(routes, dtype=np.int32), dev)
+        self.host_tab, self.host_routes = tab, np.array(routes, dtype=np.int32)
+        self.sq, self.F, self.dt, self.um = 9, 120, 1.0 / 30.0, 60.0
+        gen = torch.Generator(device="cpu").manual_seed(177 + rank)
+        self.action = (0.1 + 0.8 * torch.rand(R, env.action_size(), generator=gen)).to(dev).requires_grad_(True)
+        self.units = R * tab.n_cells * tab.T
+        self.L, self.N, self.T, self.n_lanes = R, tab.n_cells, tab.T, tab.n_lanes
+        self.name = "itscp_hybrid_%dx(%d lanes, %d cells, %d micro lanes)x%d" % (R, self.n_lanes, self.N,
+                                                                                 int((np.asarray(tab.lane_macro) == 0).sum()), self.T)
+        self.err = ops.new_error_record(dev)
+        self.ev = []
+        self.counts = None
+
+    def one_pass(self, record=False):
+        self.action.grad = None
+        if record:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e[0].record()
+        reward, _, _, self.counts = self.ops.net_hybrid_rollout(self.action, self.tab, self.sq, self.F, self.dt, self.um)
+        if record:
+            e[1].record()
+        loss = -reward.sum()
+        if record:
+            e[2].record()
+        loss.backward()
+        if record:
+            e[3].record()
+            self.ev.append(e)
+        return loss.detach(), self.action.grad, self.action.grad
+
+    def cpu_baseline(self):
+        """The C oracle of the hybrid network (scalar, one core): whole episodes of replica 0, repeated for >= 10 s."""
+        from dhts.network import group_routes
+        from oracle import oracle as O
+        a = self.action[0].detach().cpu().numpy()
+        routes, ptr = group_routes(self.host_routes, self.host_tab.n_lanes)
+        done, t0 = 0, time.perf_counter()
+        while True:
+            o = O.net_hybrid(self.host_tab, routes, ptr, a, self.sq, self.F, self.dt, self.um)
+            assert o["rc"] == 0
+            done += self.N * self.T
+            el = time.perf_counter() - t0
+            if el >= 10.0:
+                break
+        return {"value": done / el, "unit": "cell-steps/s", "cores": 1, "kind": "port",
+                "sample": "replica 0's episode (%d cells x %d steps, %d vehicles) fwd+bwd, repeated %.1f s on one core"
+                          % (self.N, self.T, o["n_spawned"], el)}
+
+
 def make_workload(name, dev, rank, lanes=0, cells=0, time_steps=0):
     if name == "macro":
         return MacroWorkload(dev, rank, lanes or 1024, cells or 512, time_steps or 1000)

@@ -31,6 +31,32 @@ def last_json(text):
     return json.loads(lines[-1])
 
 
+def test_bench_has_no_undefined_globals():
+    """A static pass over bench.py and the entry module (they only run on the GPU box): every global name a function
+    body loads is defined at module level, imported, or a builtin."""
+    import ast
+    import builtins
+    for path in (BENCH, os.path.join(ROOT, "__graft_entry__.py")):
+        tree = ast.parse(open(path).read())
+        defined = set(dir(builtins)) | {"__file__", "__name__"}
+        for node in ast.walk(tree):
+            if isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+                defined.add(node.name)
+                if isinstance(node, ast.FunctionDef):
+                    defined.update(a.arg for a in node.args.args + node.args.kwonlyargs)
+                    defined.update(a.arg for a in (node.args.vararg, node.args.kwarg) if a)
+            elif isinstance(node, (ast.Import, ast.ImportFrom)):
+                defined.update((a.asname or a.name).split(".")[0] for a in node.names)
+            elif isinstance(node, ast.Name) and isinstance(node.ctx, (ast.Store, ast.Del)):
+                defined.add(node.id)
+            elif isinstance(node, ast.arg):
+                defined.add(node.arg)
+            elif isinstance(node, ast.ExceptHandler) and node.name:
+                defined.add(node.name)
+        missing = sorted({n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)} - defined)
+        assert not missing, "%s uses undefined names: %s" % (os.path.basename(path), missing)
+
+
 def test_launcher_fails_loudly_without_gpus():
     import torch
     if torch.cuda.is_available():
