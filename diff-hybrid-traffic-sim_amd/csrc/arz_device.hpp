@@ -110,8 +110,21 @@ struct IfaceDebug {  // intermediate results exported only by the known-answer e
 
 struct IfaceConst {  // per-launch constants
     double um, inv_um, inv_15um, dt, dx;
-    double cfl_lim;      // dx / dt (production path: |speed| < dx / dt instead of dt * |speed| < dx)
-    __host__ __device__ void set_grid(double dt_, double dx_) { dt = dt_; dx = dx_; cfl_lim = dx_ / dt_; }
+    double cfl_lim, cfl_lim2;   // dx / dt and twice that (production path: |speed| < dx / dt instead of dt * |speed| < dx)
+    double ueq_2eps;            // u_eq(eps) = um (1 - sqrt(eps + eps)): u_eq of a clamped left density (_arz.py:155-165)
+    double inv_epsf;            // 1 / float32(eps): the float32 glue divides by max(r, eps) with eps cast to float32
+    float ueq_2eps_f, ueq_neg_f;   // float32 casts of u_eq(eps) and of u_eq(0) = um (1 - sqrt(eps)) (negative density), as the glue uses them
+    bool lim_ok;                // 1e-5 < dx / dt: the max(|speed|, 1e-5) floor of the CFL assert
+    __host__ __device__ void set_um(double um_) {
+        um = um_; inv_um = 1.0 / um_; inv_15um = 1.0 / (1.5 * um_); ueq_2eps = um_ * (1. - sqrt(1e-5 + 1e-5));
+        inv_epsf = 1.0 / (double)1e-5f;
+        const float umf = (float)um_;               // the glue works with the float32 speed limit
+        ueq_2eps_f = (float)((double)umf * (1. - sqrt(1e-5 + 1e-5)));
+        ueq_neg_f = (float)((double)umf * (1. - sqrt(0. + 1e-5)));
+    }
+    __host__ __device__ void set_grid(double dt_, double dx_) {
+        dt = dt_; dx = dx_; cfl_lim = dx_ / dt_; cfl_lim2 = 2.0 * cfl_lim; lim_ok = 1e-5 < cfl_lim;
+    }
 };
 
 // Reference-order version: IEEE double division and square root exactly where the reference divides and takes
@@ -263,115 +276,200 @@ __device__ __forceinline__ void arz_interface_ieee(double rL, double yL, double 
 }
 
 // Production version of the interface solve.  Same formulas and branch structure as arz_interface_ieee, with
-//   * every 1/sqrt(x), 1/x and sqrt(x) of one argument taken from ONE rsq + Newton sequence,
+//   * every 1/sqrt(x), 1/x and sqrt(x) of one argument taken from ONE rsq + Goldschmidt sequence,
 //   * divisions by launch constants turned into multiplications by their reciprocals,
 //   * the shock speed's division removed (only its sign and its CFL bound are used),
-//   * a*b+c contracted to fma.
+//   * a*b+c written as an explicit fma where it is one (the translation unit is compiled with contraction off, so the
+//     result of an interface does not depend on which kernel, or which phase of a kernel, evaluates it).
+// It comes in three pieces so that a kernel can run the cheap part on every interface and the rest only where needed:
+//   arz_pre_fast      left-cell quantities, case index, CFL flag                       (_arz.py:222-314)
+//   arz_trivial_fast  Q_0 = Q_L (case 0: 89 % of the interfaces of BASELINE config 2), flux, flux Jacobian
+//   arz_interface_fast = arz_pre_fast + (trivial | Q_M / Q_C with their Jacobians) + the float32 2x2 products
 // Results differ from the reference-order version by a few double ulps, i.e. by < 1e-8 of a float32 ulp
 // before the float32 stores (tests/test_gpu_parity.py checks the result against the golden vectors).
-__device__ __forceinline__ void arz_interface_fast(double rL, double yL, double uL, double qL,
-                                                   double rR, double yR, double uR, double qR,
-                                                   const IfaceConst &k, Iface &o, IfaceDebug *dbg = nullptr) {
-#pragma clang fp contract(fast)
-    const double um = k.um, inv_um = k.inv_um;
-    const double rLc = fmax(rL, kEps);
-    double sL, hL;
-    sqrt_hrsqrt(rLc, sL, hL);                              // sL = sqrt(rLc); 2 hL = rLc^-1/2
-    const double rsL = hL + hL;
-    const double inv_rLc = rsL * rsL;                      // 1 / rLc
-    const double ueqp_L = -um * hL;                        // u_eq'(rL) = -um * gamma * rLc^(gamma-1)
-    const double sLe = fast_sqrt(fmax(rL, 0.) + kEps);     // sqrt(rL + eps) of u_eq(rL)
+// What a cell contributes to the interface on its right, as a function of its density alone: computed once by whoever
+// owns the cell (the two-phase rollout kernel keeps it beside the state in LDS), or on the spot by arz_pre_fast.
+struct CellPre {
+    double s, h;     // sqrt(max(r, eps)) and 0.5 / that
+    double q0;       // u_eq(r) in double = um (1 - sqrt(max(r, 0) + eps))     (compute_u_eq, _arz.py:133-138)
+};
+__device__ __forceinline__ void arz_cell_pre(double r, double um, CellPre &c) {
+    sqrt_hrsqrt(fmax(r, kEps), c.s, c.h);
+    c.q0 = __builtin_fma(-um, fast_sqrt(fmax(r, 0.) + kEps), um);
+}
 
+struct IfacePre {
+    double rLc, sL, hL, inv_rLc, ueqp_L, q0L;   // max(r_L, eps), its sqrt, 0.5 / sqrt, 1 / it, u_eq'(r_L), u_eq(r_L) in double
+    double dU, bm;                               // u_L - u_R, sqrt(r_m) up to sign
+    int ci;                                      // case_ind: 0 = Q_L, 1 = Q_M, 2 = Q_C
+    bool vacL, cfl_bad;
+};
+
+__device__ __forceinline__ void arz_classify_fast(double rL, double uL, double qL, double rR, double uR, const CellPre &cl,
+                                                  const IfaceConst &k, IfacePre &p) {
+    const double um = k.um;
+    p.rLc = fmax(rL, kEps);
+    p.sL = cl.s; p.hL = cl.h; p.q0L = cl.q0;               // sL = sqrt(rLc); 2 hL = rLc^-1/2
+    const double rsL = p.hL + p.hL;
+    p.inv_rLc = rsL * rsL;                                 // 1 / rLc
+    p.ueqp_L = -um * p.hL;                                 // u_eq'(rL) = -um * gamma * rLc^(gamma-1)
     // ---- Riemann solve: case index, CFL flag (_arz.py:222-314), evaluated branch-free: the six branches only
     //      differ in a handful of cheap candidates, which are all computed and then selected ----
     const bool vacL = rL < kEps;
     const bool vacR = rR < kEps;
-    const bool same = fabs(uL - uR) < kEps;
-    const bool wave_m = !(vacL || vacR || same);           // branches 4, 5, 6
-    const bool b4 = wave_m && (uL > uR);
+    p.vacL = vacL;
+    p.dU = uL - uR;
+    const bool same = fabs(p.dU) < kEps;
+    const bool wave_m = !(vacL | vacR | same);             // branches 4, 5, 6
+    const bool b4 = wave_m & (uL > uR);
     const double qm_u = um + uL - qL;                      // u of Q_m = (0, .) next to vacuum (:235, :301)
-    const bool b5 = wave_m && !b4 && (qm_u > uR);
-    const double bm = sL + (uL - uR) * inv_um;             // sqrt(r_m) up to sign (sqrt(rL) = sL when rL >= eps)
-    const double rm = bm * bm;                             // compute_Qm :194 (used by branches 4 and 5 only)
-    const double abm = fabs(bm);
-    const double l0l = uL + rL * ueqp_L;
-    const double diff = rm * uR - rL * uL;                 // numerator of the shock speed (:263-265)
+    const bool b5 = wave_m & !b4 & (qm_u > uR);
+    p.bm = __builtin_fma(p.dU, k.inv_um, p.sL);            // sqrt(r_m) up to sign (sqrt(rL) = sL when rL >= eps)
+    const double rm = p.bm * p.bm;                         // compute_Qm :194 (used by branches 4 and 5 only)
+    const double abm = fabs(p.bm);
+    const double l0l = __builtin_fma(rL, p.ueqp_L, uL);
+    const double diff = __builtin_fma(rm, uR, -(rL * uL)); // numerator of the shock speed (:263-265)
     const double den = fmax(rm - rL, kEps);
     // lambda_0(Q_m) = u_R + r_m u_eq'(r_m) = u_R - gamma u_max r_m^gamma = u_R - u_max |b| / 2   (r_m >= eps),
     // and u_R + r_m (-u_max gamma eps^(gamma-1)) below eps: no square root needed
-    const double l0m = (rm >= kEps) ? (uR - (0.5 * um) * abm) : (uR + rm * (-um * kHalfRsqrtEps));
+    const double l0m = (rm >= kEps) ? __builtin_fma(-0.5 * um, abm, uR) : __builtin_fma(rm, -um * kHalfRsqrtEps, uR);
     const bool l0l_ok = l0l >= 0.0;
-    const int ci_vac = l0l_ok ? 0 : 2;                     // branches 2 and 6
-    const int ci_b4 = (diff >= 0.0) ? 0 : 1;               // sign of speed0 = diff / den
-    const int ci_b5 = l0l_ok ? 0 : ((l0m <= 0) ? 1 : 2);
-    const int ci = (vacL || (same && !vacR)) ? 0 : (b4 ? ci_b4 : (b5 ? ci_b5 : ci_vac));
-    // CFL: dt * max(|speed|, 1e-5) < dx for speed0 and speed1; speed0 = n0 / d0 with d0 > 0 (no division)
-    const double s0_avg = (l0l + (b5 ? l0m : qm_u)) * 0.5; // branches 2, 5, 6
-    const double n0 = (vacL || (same && !vacR)) ? 0.0 : (b4 ? fabs(diff) : fabs(s0_avg));
-    const double d0 = b4 ? den : 1.0;
-    const double s1 = vacL ? fabs(uL) : ((vacR) ? fabs(s0_avg) : fabs(uR));
-    // dt * max(|speed|, 1e-5) < dx  <=>  |speed| < dx / dt and 1e-5 < dx / dt; the negated forms keep NaN speeds "bad"
-    const bool bad = !(n0 < k.cfl_lim * d0) || !(s1 < k.cfl_lim) || !(1e-5 < k.cfl_lim);
-    o.cfl_bad = bad;
+    const bool zero0 = vacL | (same & !vacR);              // branches 1 and 3: speed0 = 0
+    // case 0 unless the wave that sits on x = 0 is the middle state: branch 4 decides by the sign of speed0 = diff / den,
+    // branches 2, 5, 6 by lambda_0(Q_L); what replaces Q_L is Q_M in branch 4, and in branch 5 when lambda_0(Q_m) <= 0
+    const bool triv = zero0 | (b4 & (diff >= 0.0)) | (!b4 & l0l_ok);
+    const bool mid = b4 | (b5 & (l0m <= 0));
+    p.ci = triv ? 0 : (mid ? 1 : 2);
+    // CFL: dt * max(|speed|, 1e-5) < dx for speed0 and speed1  <=>  |speed| < dx / dt and 1e-5 < dx / dt.  speed0 is 0,
+    // diff / den (den > 0: tested as |diff| < den dx / dt, no division) or the mean of two characteristic speeds (tested
+    // as |sum| < 2 dx / dt); every test is a lane mask, the selection between them mask logic.  A NaN fails every test.
+    const bool ok_b4 = fabs(diff) < k.cfl_lim * den;
+    const bool ok_m = fabs(l0l + l0m) < k.cfl_lim2;        // branch 5
+    const bool ok_q = fabs(l0l + qm_u) < k.cfl_lim2;       // branches 2 and 6
+    const bool ok_avg = (b5 & ok_m) | (!b5 & ok_q);
+    const bool ok0 = zero0 | (b4 & ok_b4) | (!b4 & ok_avg);
+    const bool ok_uL = fabs(uL) < k.cfl_lim, ok_uR = fabs(uR) < k.cfl_lim;
+    const bool ok1 = (vacL & ok_uL) | (!vacL & ((vacR & ok_avg) | (!vacR & ok_uR)));
+    p.cfl_bad = !(ok0 & ok1 & k.lim_ok);
+}
+
+__device__ __forceinline__ void arz_pre_fast(double rL, double uL, double qL, double rR, double uR, const IfaceConst &k,
+                                             IfacePre &p) {
+    CellPre cl;
+    arz_cell_pre(rL, k.um, cl);
+    arz_classify_fast(rL, uL, qL, rR, uR, cl, k, p);
+}
+
+// The hot-path subset of arz_classify_fast: is the interface trivial (case 0) AND provably inside the CFL bound?
+// Every speed the solver can report is bounded by |u_L| + |u_R| + |u_eq,L| / 2 + u_max (1 + sqrt(r_L)) / 2 (shock:
+// |u_R| + u_max sqrt(r_L) / 2 with or without the eps clamp of its denominator; lambda_0(Q_L): |u_L| + u_max sqrt(r_L) / 2;
+// lambda_0(Q_m): |u_R| + u_max |b| / 2 with |b| <= sqrt(r_L) + |u_L - u_R| / u_max; u of the vacuum-side state:
+// u_max + |u_L| + |u_eq,L|).  An interface that fails the bound is treated as non-trivial, i.e. handed to the full solver
+// with its exact CFL test.  Fills the fields of `p` that arz_trivial_fast reads.
+__device__ __forceinline__ bool arz_is_trivial_fast(double rL, double uL, double qL, double rR, double uR, const CellPre &cl,
+                                                    const IfaceConst &k, IfacePre &p) {
+    const double um = k.um;
+    p.rLc = fmax(rL, kEps);
+    p.sL = cl.s; p.hL = cl.h; p.q0L = cl.q0;
+    const double rsL = p.hL + p.hL;
+    p.inv_rLc = rsL * rsL;
+    p.ueqp_L = -um * p.hL;
+    const bool vacL = rL < kEps;
+    const bool vacR = rR < kEps;
+    p.vacL = vacL;
+    p.dU = uL - uR;
+    const bool same = fabs(p.dU) < kEps;
+    const bool b4 = !(vacL | vacR | same) & (uL > uR);
+    p.bm = __builtin_fma(p.dU, k.inv_um, p.sL);
+    const double rm = p.bm * p.bm;
+    const double l0l = __builtin_fma(rL, p.ueqp_L, uL);
+    const double diff = __builtin_fma(rm, uR, -(rL * uL));
+    const bool zero0 = vacL | (same & !vacR);
+    const bool triv = zero0 | (b4 & (diff >= 0.0)) | (!b4 & (l0l >= 0.0));
+    const double bound = __builtin_fma(0.5, fabs(qL), fabs(uL) + fabs(uR)) + __builtin_fma(0.5 * um, p.sL, 0.5 * um);
+    p.ci = 0; p.cfl_bad = false;
+    return triv & (bound < k.cfl_lim) & k.lim_ok;
+}
+
+// flux of Q_0 and the flux Jacobian at Q_0 (darz.py:217-233; float32 entries, fp[1] = 1)
+__device__ __forceinline__ void arz_flux_fp(double r0, double y0, double u0, double q0, double r0c, double h0, double inv_r0c,
+                                            double um, double &Fr, double &Fy, float fp[4]) {
+    Fr = r0 * u0;
+    Fy = y0 * u0;
+    const double ueqp_0 = -um * h0;
+    const double yor = y0 * inv_r0c;
+    fp[0] = (float)__builtin_fma(r0c, ueqp_0, q0);
+    fp[1] = 1.f;
+    fp[2] = (float)__builtin_fma(y0, ueqp_0, -(yor * yor));
+    fp[3] = (float)__builtin_fma(y0 + y0, inv_r0c, q0);
+}
+
+// case 0: Q_0 = compute_Ql(Q_L) (_arz.py:155-165: u re-derived from r, y in double), dQ_0/dQ_L = I, dQ_0/dQ_R = 0
+__device__ __forceinline__ void arz_trivial_fast(double rL, double yL, const IfacePre &p, const IfaceConst &k,
+                                                 double &u0, double &Fr, double &Fy, float fp[4]) {
+    const double qc = p.vacL ? k.ueq_2eps : p.q0L;         // u_eq(max(r_L, eps)): r_L + eps, or eps + eps under the clamp
+    u0 = __builtin_fma(yL, p.inv_rLc, qc);
+    arz_flux_fp(rL, yL, u0, p.q0L, p.rLc, p.hL, p.inv_rLc, k.um, Fr, Fy, fp);
+}
+
+template <bool kHavePre>
+__device__ __forceinline__ void arz_interface_fast_impl(double rL, double yL, double uL, double qL,
+                                                        double rR, double yR, double uR, double qR,
+                                                        const CellPre *cl, const CellPre *cr,
+                                                        const IfaceConst &k, Iface &o, IfaceDebug *dbg) {
+    const double um = k.um, inv_um = k.inv_um;
+    IfacePre p;
+    if constexpr (kHavePre) arz_classify_fast(rL, uL, qL, rR, uR, *cl, k, p);
+    else arz_pre_fast(rL, uL, qL, rR, uR, k, p);
+    o.cfl_bad = p.cfl_bad;
+    const int ci = p.ci;
 
     // ---- Q_0 (_arz.py:155-199, 316-326), its Jacobians (darz.py:12-192) ----
-    double r0, y0, u0, q0, r0c, h0, inv_r0c;
-    float dL[4], dR[4];
+    double r0, y0, u0, q0;
+    float dL[4], dR[4], fp[4];
     if (ci == 0) {
-        const double sLce = vacL ? sqrt(kEps + kEps) : sLe;       // sqrt(rLc + eps)
-        r0 = rL; y0 = yL;
-        u0 = yL * inv_rLc + um * (1. - sLce);
-        q0 = um * (1. - sLe);
-        r0c = rLc; h0 = hL; inv_r0c = inv_rLc;
+        arz_trivial_fast(rL, yL, p, k, u0, o.Fr, o.Fy, fp);
+        r0 = rL; y0 = yL; q0 = p.q0L;
     } else {
         // Q_M (case 1, compute_Qm _arz.py:184-199 + compute_dM darz.py:35-122) and Q_C (case 2, compute_Qc :167-182 +
         // compute_dC darz.py:124-192) share one form: r_0 = b0^2 with b0 = sqrt(r_L) + (u_L - u_R) / u_max   (Q_M)
         //                                                              or (u_L + u_max sqrt(r_L)) / ((gamma+1) u_max) (Q_C),
         // and d b0 / d(r_L, y_L) = sc * (du_L/dr_L + u_max gamma r_L^(gamma-1), du_L/dy_L), sc = 1/u_max or 1/((gamma+1) u_max).
         const bool c1 = (ci == 1);
-        const double base = uL + um * sL;
-        const double b0 = c1 ? bm : base * k.inv_15um;
+        const double hL = p.hL, inv_rLc = p.inv_rLc;
+        const double base = __builtin_fma(um, p.sL, uL);
+        const double b0 = c1 ? p.bm : base * k.inv_15um;
         const double ab0 = fabs(b0);                       // sqrt(r_0) = r_0 ** (1 - gamma)
         r0 = b0 * b0;
         u0 = c1 ? uR : kGoG1 * base;
-        q0 = um * (1. - fast_sqrt(fmax(r0, 0.) + kEps));
+        q0 = __builtin_fma(-um, fast_sqrt(fmax(r0, 0.) + kEps), um);
         y0 = r0 * (u0 - q0);
-        r0c = fmax(r0, kEps);
-        h0 = (r0 >= kEps) ? 0.5 * fast_rcp(ab0) : kHalfRsqrtEps;          // 0.5 / sqrt(r0c)
+        const double r0c = fmax(r0, kEps);
+        const double h0 = (r0 >= kEps) ? 0.5 * fast_rcp(ab0) : kHalfRsqrtEps;          // 0.5 / sqrt(r0c)
         const double rs0 = h0 + h0;
-        inv_r0c = rs0 * rs0;
-        const double w = (-yL * (inv_rLc * inv_rLc) + ueqp_L) + um * hL;  // du_L/dr_L + u_max gamma r_L^(gamma-1)
-        const double a2sc = (2.0 * ab0) * (c1 ? inv_um : k.inv_15um);
-        const double k1 = (u0 - q0) - r0 * (-um * h0);     // d y_0 = k1 d r_0 + r_0 d u_0
+        const double inv_r0c = rs0 * rs0;
+        const double w = __builtin_fma(-yL, inv_rLc * inv_rLc, p.ueqp_L) + um * hL;     // du_L/dr_L + u_max gamma r_L^(gamma-1)
+        const double a2sc = (ab0 + ab0) * (c1 ? inv_um : k.inv_15um);
+        const double k1 = __builtin_fma(r0, um * h0, u0 - q0);  // d y_0 = k1 d r_0 + r_0 d u_0
         const double gL = c1 ? 0.0 : kGoG1;                // d u_0 / d u_L
         const double dr_drL = a2sc * w;
         const double dr_dyL = a2sc * inv_rLc;
         dL[0] = (float)dr_drL; dL[1] = (float)dr_dyL;
-        dL[2] = (float)(dr_drL * k1 + r0 * (gL * w)); dL[3] = (float)(dr_dyL * k1 + r0 * (gL * inv_rLc));
+        dL[2] = (float)__builtin_fma(dr_drL, k1, r0 * (gL * w)); dL[3] = (float)__builtin_fma(dr_dyL, k1, r0 * (gL * inv_rLc));
         if (c1) {
-            const double rRc = fmax(rR, kEps);
             double sR, hR;
-            sqrt_hrsqrt(rRc, sR, hR);
+            if constexpr (kHavePre) { sR = cr->s; hR = cr->h; }
+            else sqrt_hrsqrt(fmax(rR, kEps), sR, hR);
             const double rsR = hR + hR;
             const double inv_rRc = rsR * rsR;
-            const double duR_drR = -yR * (inv_rRc * inv_rRc) + (-um * hR);
+            const double duR_drR = __builtin_fma(-yR, inv_rRc * inv_rRc, -um * hR);
             const double dr_drR = -a2sc * duR_drR;
             const double dr_dyR = -a2sc * inv_rRc;
             dR[0] = (float)dr_drR; dR[1] = (float)dr_dyR;
-            dR[2] = (float)(dr_drR * k1 + r0 * duR_drR); dR[3] = (float)(dr_dyR * k1 + r0 * inv_rRc);
+            dR[2] = (float)__builtin_fma(dr_drR, k1, r0 * duR_drR); dR[3] = (float)__builtin_fma(dr_dyR, k1, r0 * inv_rRc);
         }
+        arz_flux_fp(r0, y0, u0, q0, r0c, h0, inv_r0c, um, o.Fr, o.Fy, fp);
     }
-    o.Fr = r0 * u0;
-    o.Fy = y0 * u0;
-
-    // ---- flux Jacobian at Q_0 (darz.py:217-233), float32 entries ----
-    const double ueqp_0 = -um * h0;
-    const double yor = y0 * inv_r0c;
-    float fp[4];
-    fp[0] = (float)(q0 + r0c * ueqp_0);
-    fp[1] = 1.f;
-    fp[2] = (float)(y0 * ueqp_0 - yor * yor);
-    fp[3] = (float)((2.0 * y0) * inv_r0c + q0);
 
     if (dbg) {
         dbg->ci = ci;
@@ -400,6 +498,18 @@ __device__ __forceinline__ void arz_interface_fast(double rL, double yL, double 
             o.B[0] = o.B[1] = o.B[2] = o.B[3] = 0.f;
         }
     }
+}
+
+__device__ __forceinline__ void arz_interface_fast(double rL, double yL, double uL, double qL,
+                                                   double rR, double yR, double uR, double qR,
+                                                   const IfaceConst &k, Iface &o, IfaceDebug *dbg = nullptr) {
+    arz_interface_fast_impl<false>(rL, yL, uL, qL, rR, yR, uR, qR, nullptr, nullptr, k, o, dbg);
+}
+// the same with the cells' density-only quantities supplied (bitwise the same results: arz_cell_pre is what the other form calls)
+__device__ __forceinline__ void arz_interface_fast_pre(double rL, double yL, double uL, double qL, const CellPre &cl,
+                                                       double rR, double yR, double uR, double qR, const CellPre &cr,
+                                                       const IfaceConst &k, Iface &o) {
+    arz_interface_fast_impl<true>(rL, yL, uL, qL, rR, yR, uR, qR, &cl, &cr, k, o, nullptr);
 }
 
 __device__ __forceinline__ void arz_interface(double rL, double yL, double uL, double qL,

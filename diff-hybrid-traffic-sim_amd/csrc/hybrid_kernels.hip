@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     const bool is_if = tid < NIm, is_cell = tid < C, is_ghost = tid < 2 * L, is_lane = tid < L;
     int i_lane = 0, i_k = 0, i_n = 0, i_off = 0, i_mb = 0;
     IfaceConst kconst;
-    kconst.um = um_d; kconst.inv_um = 1.0 / um_d; kconst.inv_15um = 1.0 / (kG1 * um_d); kconst.set_grid(dt, 1.0);
+    kconst.set_um(um_d); kconst.set_grid(dt, 1.0);
     int c_lane = 0, c_mb = 0, c_macb = 0; double c_cc = 0.; float c_dxv = 0.f;
     if (is_cell) {
         c_lane = cell_lane_s[tid]; c_cc = dt / tb.net.lane_dx[c_lane]; c_dxv = (float)tb.net.lane_dx[c_lane] / vlen;

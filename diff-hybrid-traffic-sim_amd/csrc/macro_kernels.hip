@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     const float cf = (float)c, ncf = (float)(-c);
     const float umf = (float)um;
     IfaceConst kc;
-    kc.um = um; kc.inv_um = 1.0 / um; kc.inv_15um = 1.0 / (kG1 * um); kc.set_grid(dt, dx);
+    kc.set_um(um); kc.set_grid(dt, dx);
     int fault_step = -1, fault_index = 0;
 
     for (int step = 0; step < T; ++step) {
@@ -165,6 +165,191 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         y_out[base + k] = fin[P + k + 1];
         u_out[base + k] = fin[2 * P + k + 1];
         q_out[base + k] = fin[3 * P + k + 1];
+    }
+    if (fault_step >= 0) raise_fault(err, DHTS_FAULT_CFL, fault_step, lane, fault_index);
+}
+
+// ---- the rollout forward kernel: cheap solve everywhere, full solve only where needed ---------------------------------
+__device__ __forceinline__ void lds_only_barrier() {     // global stores (the tape) stay in flight across it
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// One cell's record in LDS (48 bytes; a 48-byte stride keeps 16-byte accesses of 16 consecutive lanes on distinct banks):
+// the float32 state and what the interface to the cell's right needs of it, computed once by the cell's owner.
+struct __attribute__((aligned(16))) CellRec {
+    float4 st;       // r, y, u, u_eq  (FullQ, _arz.py:10-115)
+    double s, h;     // CellPre
+    double q0, pad;
+};
+static_assert(sizeof(CellRec) == 48, "CellRec layout");
+
+// New (u, u_eq) of a cell from its new (r, y) -- FullQ.set_r_y, _arz.py:88-92, float32 torch arithmetic -- together with
+// the cell's CellPre.  The float32 square root and division of the glue come out of the double-precision square roots
+// CellPre needs anyway: sqrtf(t32) = fl32(sE + (t32 - tE) hE) with sE = sqrt(tE), hE = 0.5 / sE, tE = r + eps in double
+// (first-order in t32 - tE = O(1e-7): the remainder is 5e-16 relative), y / r = fl32(y (2 h)^2).  Both agree with the
+// correctly rounded float32 result unless it lies within 2e-14 (relative) of a rounding boundary, i.e. except with
+// probability ~1e-6 per operation -- the level of the fast double layer (fast_math.hpp); the IEEE forms are glue_from_r_y.
+__device__ __forceinline__ void cell_glue_pre(float r, float y, float umf, const IfaceConst &k, float &u, float &q, CellPre &c) {
+    const double rd = (double)r;
+    sqrt_hrsqrt(fmax(rd, kEps), c.s, c.h);
+    const double tE = fmax(rd, 0.) + kEps;
+    double sE, hE;
+    sqrt_hrsqrt(tE, sE, hE);
+    c.q0 = __builtin_fma(-k.um, sE, k.um);
+    const float t32 = r + kEpsF;
+    const float s32 = (float)__builtin_fma((double)t32 - tE, hE, sE);
+    const float one_m = 1.f - s32;
+    q = (0.f > r) ? k.ueq_neg_f : umf * one_m;              // max(r, 0.) picked the Python float 0. (glue_u_eq)
+    const double rs = c.h + c.h;
+    const double inv = (r <= kEpsF) ? k.inv_epsf : rs * rs;  // 1 / max(r, eps32): r below OR AT float32(eps) divides by float32(eps)
+    const float yor = (float)((double)y * inv);
+    u = yor + ((r < kEpsF) ? k.ueq_2eps_f : q);
+}
+
+// grid = L workgroups (one traffic lane each) of W = blockDim.x / 64 wavefronts; wave w owns the cells [64 p w, 64 p (w + 1)),
+// thread t of its pass j the cell c = 64 p w + 64 j + t and that cell's LEFT interface (interface c, between cells c-1 and c).
+// In BASELINE config 2, 89 % of the interface solves end in the trivial case (Q_0 = Q_L, dQ_0/dQ_L = I, dQ_0/dQ_R = 0), but
+// a 64-wide pass is uniformly trivial only 23 % of the time: evaluated in place, the Q_M / Q_C states with their Jacobians
+// (more than half of the work) are paid for by every lane.  And on this chip every vector instruction of a wavefront costs
+// about 4 cycles whatever its type (PMC: profiles/r02*), so the instruction COUNT is what a step costs.  A step therefore
+// runs in two phases:
+//   phase 1 (every cell's thread): finish the previous step -- new (r, y) from the two fluxes of the cell, (u, u_eq) and
+//     the cell's CellPre from one pair of square roots, written to the cell's record -- then read the left neighbour's
+//     record, decide whether the interface is trivial, and if so write its flux (LDS) and its tape entry (A = flux
+//     Jacobian, B = 0); otherwise append it to the lane's queue;
+//   phase 2 (the first threads of the workgroup, one queue entry each): the full solve for the queued interfaces, their
+//     fluxes to LDS, their tape entries to HBM.  Always queued: the first interface of every wave's chunk (its left cell
+//     belongs to another wave) and interface N (no cell owns it).
+// One queue pass serves the whole lane (8 passes of phase 1 at 512 cells), so the expensive path runs about once per 64
+// non-trivial interfaces instead of once per 64 interfaces.  Two LDS-only barriers per step.
+// Dynamic LDS: cell records [N + 2] (index c + 1 = cell c, 0 and N + 1 the ghosts; updated in place) | flux double2 [N + 1]
+// | queue int [N + 2] | 2 counters.
+__global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
+    int L, int N, int T, int p, double dt, double dx, double um,
+    const float *__restrict__ r_in, const float *__restrict__ y_in, const float *__restrict__ u_in,
+    const float *__restrict__ q_in, const float *__restrict__ ghost,
+    float *__restrict__ r_out, float *__restrict__ y_out, float *__restrict__ u_out, float *__restrict__ q_out,
+    float4 *__restrict__ tape, float *__restrict__ hist, dhts_error *err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    const int t = tid & 63;
+    const int wv = tid >> 6;
+    const int W = nthr >> 6;
+    const size_t base = (size_t)lane * N;
+    CellRec *CR = reinterpret_cast<CellRec *>(smem);
+    double2 *FX = reinterpret_cast<double2 *>(CR + (N + 2));
+    int *Q = reinterpret_cast<int *>(FX + (N + 1));
+    int *CNT = Q + (N + 2);
+    IfaceConst kc;
+    kc.set_um(um); kc.set_grid(dt, dx);
+
+    for (int k = tid; k < N + 2; k += nthr) {
+        float4 st;
+        if (k == 0 || k == N + 1) {
+            const float *g = ghost + (size_t)lane * 8 + (k ? 4 : 0);
+            st = make_float4(g[0], g[1], g[2], g[3]);
+        } else {
+            st = make_float4(r_in[base + k - 1], y_in[base + k - 1], u_in[base + k - 1], q_in[base + k - 1]);
+        }
+        CellPre c;
+        arz_cell_pre((double)st.x, um, c);
+        CellRec rec;
+        rec.st = st; rec.s = c.s; rec.h = c.h; rec.q0 = c.q0; rec.pad = 0.;
+        CR[k] = rec;
+    }
+    if (tid == 0) { Q[0] = N; CNT[0] = 1; CNT[1] = 1; }      // entry 0 of every step's queue: interface N
+    __syncthreads();
+
+    const int lo = wv * (p << 6);                    // first cell of this wave
+    const unsigned Nq = (unsigned)(N + 1 + 7) & ~7u; // interfaces per lane, padded to whole 128-byte lines
+    const double c = dt / dx;                        // update_coefficient, _macro_lane.py:99
+    const float umf = (float)um;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int fault_step = -1, fault_index = 0;
+    int rot = 0;                                     // the wave that takes the head of the queue rotates with the step
+
+    for (int n = 0; n <= T; ++n) {
+        const bool upd = n > 0;                      // finish step n - 1
+        const bool solve = n < T;                    // start step n
+        float4 *tp = (tape && solve) ? tape + ((size_t)n * L + lane) * 2 * Nq : nullptr;
+        float *hp = (hist && upd) ? hist + ((size_t)(n - 1) * L + lane) * 3 * N : nullptr;
+        int *cnt = CNT + (n & 1);
+        for (int j = 0; j < p; ++j) {
+            const int i = lo + (j << 6) + t;                // cell i and its left interface i
+            const bool vc = i < N;
+            const unsigned ic = (unsigned)(vc ? i : N - 1);
+            CellRec *own = CR + ic + 1;
+            float4 st = own->st;
+            if (upd) {
+                // Godunov update, _macro_lane.py:109-112, float32 store :327-334
+                const double2 Fl = FX[ic], Fr = FX[ic + 1];
+                st.x = (float)((double)st.x + (Fl.x - Fr.x) * c);
+                st.y = (float)((double)st.y + (Fl.y - Fr.y) * c);
+                CellPre cp;
+                cell_glue_pre(st.x, st.y, umf, kc, st.z, st.w, cp);     // set_next_state_vector_y, :282-299
+                if (vc && solve) { own->st = st; own->s = cp.s; own->h = cp.h; own->q0 = cp.q0; }
+                if (vc && hp) { hp[i] = st.x; hp[N + i] = st.y; hp[2 * N + i] = st.z; }
+            }
+            if (!solve) {
+                if (vc) { r_out[base + i] = st.x; y_out[base + i] = st.y; u_out[base + i] = st.z; q_out[base + i] = st.w; }
+                continue;
+            }
+            // the left neighbour at this time level: written just above by the lane below, or in the previous pass (a wave's
+            // LDS operations complete in order); the first cell of the chunk has its left neighbour in another wave: queued
+            const CellRec *lf = CR + ic;
+            const float4 ls = lf->st;
+            CellPre cl;
+            cl.s = lf->s; cl.h = lf->h; cl.q0 = lf->q0;
+            IfacePre pre;
+            const bool easy = arz_is_trivial_fast((double)ls.x, (double)ls.z, (double)ls.w, (double)st.x, (double)st.z, cl, kc, pre);
+            const bool triv = vc & easy & !((j == 0) & (t == 0));
+            if (triv) {
+                double u0, Fr, Fy;
+                float fp[4];
+                arz_trivial_fast((double)ls.x, (double)ls.y, pre, kc, u0, Fr, Fy, fp);
+                FX[ic] = make_double2(Fr, Fy);
+                if (tp) {
+                    tp[ic] = make_float4(fp[0], fp[1], fp[2], fp[3]);
+                    tp[Nq + ic] = zero4;
+                }
+            }
+            const bool push = vc & !triv;
+            const unsigned long long m = __ballot(push);
+            if (m) {
+                int slot = 0;
+                if (t == 0) slot = atomicAdd(cnt, __popcll(m));
+                slot = __builtin_amdgcn_readfirstlane(slot);
+                if (push) Q[slot + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = i;
+            }
+        }
+        if (!solve) break;
+        lds_only_barrier();
+        const int qn = *cnt;
+        int k0 = tid - (rot << 6);
+        if (k0 < 0) k0 += nthr;
+        for (int k = k0; k < qn; k += nthr) {
+            const unsigned i = (unsigned)Q[k];
+            const CellRec *lf = CR + i, *rt = CR + i + 1;
+            const float4 ls = lf->st, rs = rt->st;
+            CellPre cl, cr;
+            cl.s = lf->s; cl.h = lf->h; cl.q0 = lf->q0;
+            cr.s = rt->s; cr.h = rt->h; cr.q0 = 0.;
+            Iface f;
+            arz_interface_fast_pre((double)ls.x, (double)ls.y, (double)ls.z, (double)ls.w, cl,
+                                   (double)rs.x, (double)rs.y, (double)rs.z, (double)rs.w, cr, kc, f);
+            FX[i] = make_double2(f.Fr, f.Fy);
+            if (tp) {
+                tp[i] = make_float4(f.A[0], f.A[1], f.A[2], f.A[3]);
+                tp[Nq + i] = make_float4(f.B[0], f.B[1], f.B[2], f.B[3]);
+            }
+            // CFL: dt < dx / max(|speed|, 1e-5) for both speeds (_macro_lane.py:141-146)
+            if (f.cfl_bad && fault_step < 0) { fault_step = n; fault_index = (int)i; }
+        }
+        if (tid == 0) CNT[(n + 1) & 1] = 1;
+        if (++rot == W) rot = 0;
+        lds_only_barrier();
     }
     if (fault_step >= 0) raise_fault(err, DHTS_FAULT_CFL, fault_step, lane, fault_index);
 }
@@ -251,7 +436,7 @@ __global__ void arz_interface_batch_kernel(int64_t n, int variant, const double 
                                            float *__restrict__ A, float *__restrict__ B, int32_t *__restrict__ cfl_bad) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         IfaceConst kc;
-        kc.um = in[8 * n + i]; kc.inv_um = 1.0 / kc.um; kc.inv_15um = 1.0 / (kG1 * kc.um); kc.set_grid(dt, dx);
+        kc.set_um(in[8 * n + i]); kc.set_grid(dt, dx);
         Iface f;
         IfaceDebug dbg;
         if (variant == 1)
@@ -314,9 +499,36 @@ static inline int grid_1d(int64_t n) {
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 
-// test / tuning hook: force the number of wavefronts per lane of the forward kernel (0 = heuristic)
+// test / tuning hooks: force the number of wavefronts per lane of the forward kernel (0 = heuristic); select the rollout
+// forward kernel (0 = two-phase kernel, 1 = the one-phase kernel the single-step operator uses)
 static int dhts_fwd_waves_override = 0;
+static int dhts_fwd_variant = 0;
 static inline int padded64(int n) { return (n + 63) & ~63; }
+
+static int macro_fwd2_launch(const dhts_macro_desc *d, int T,
+                             const float *r, const float *y, const float *u, const float *ueq, const float *ghost,
+                             float *r_out, float *y_out, float *u_out, float *ueq_out,
+                             float *tape, float *hist, dhts_error *err, void *stream) {
+    if (!macro_desc_ok(d) || T < 0 || !r || !y || !u || !ueq || !ghost || !r_out || !y_out || !u_out || !ueq_out)
+        return DHTS_E_INVALID;
+    const int N = d->n_cells;
+    const size_t lds = sizeof(CellRec) * (size_t)(N + 2) + 16 * (size_t)(N + 1) + sizeof(int) * (size_t)(N + 2) + 16;
+    if (lds > 160 * 1024) return DHTS_E_INVALID;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DHTS_E_LAUNCH;
+    // Wavefronts per lane: enough lanes x waves to put ~4 wavefronts on every SIMD of the chip (256 CUs x 4 SIMDs), at most 16
+    // per lane, each owning 64 p cells.
+    int W = dhts_fwd_waves_override > 0 ? dhts_fwd_waves_override : (int)((4608 + d->n_lanes - 1) / d->n_lanes);
+    if (W > 16) W = 16;
+    if (W < 1) W = 1;
+    int p = (N + 64 * W - 1) / (64 * W);
+    W = (N + 64 * p - 1) / (64 * p);
+    macro_rollout_fwd2_kernel<<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(
+        d->n_lanes, N, T, p, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out,
+        reinterpret_cast<float4 *>(tape), hist, err);
+    return launch_status();
+}
 
 template <bool kIface>
 static int macro_fwd_launch(const dhts_macro_desc *d, int T,
@@ -370,8 +582,12 @@ extern int dhts_micro_fwd_waves_override;     // micro_kernels.hip
 extern "C" {
 
 int dhts_set_option(int option, int value) {
-    if (option == DHTS_OPT_MACRO_FWD_WAVES && value >= 0 && value <= 8) {
+    if (option == DHTS_OPT_MACRO_FWD_WAVES && value >= 0 && value <= 16) {
         dhts_fwd_waves_override = value;
+        return DHTS_OK;
+    }
+    if (option == DHTS_OPT_MACRO_FWD_VARIANT && (value == 0 || value == 1)) {
+        dhts_fwd_variant = value;
         return DHTS_OK;
     }
     if (option == DHTS_OPT_MICRO_FWD_WAVES && (value == 0 || value == 1 || value == 2 || value == 4)) {
@@ -428,7 +644,9 @@ int dhts_macro_rollout_fwd(const dhts_macro_desc *d, int T,
                            const float *r, const float *y, const float *u, const float *ueq, const float *ghost,
                            float *r_out, float *y_out, float *u_out, float *ueq_out,
                            float *tape, float *hist, dhts_error *err, void *stream) {
-    return macro_fwd_launch<true>(d, T, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, tape, hist, err, stream);
+    if (dhts_fwd_variant == 1)
+        return macro_fwd_launch<true>(d, T, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, tape, hist, err, stream);
+    return macro_fwd2_launch(d, T, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, tape, hist, err, stream);
 }
 int dhts_macro_rollout_bwd(const dhts_macro_desc *d, int T, const float *tape,
                            const float *g_r, const float *g_y, const float *g_hist,

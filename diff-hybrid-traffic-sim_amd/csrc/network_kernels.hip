@@ -102,7 +102,7 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
     const bool is_if = tid < NI, is_cell = tid < C, is_ghost = tid < 2 * L, is_lane = tid < L;
     int i_lane = 0, i_k = 0, i_n = 0, i_off = 0;
     IfaceConst kconst;
-    kconst.um = um_d; kconst.inv_um = 1.0 / um_d; kconst.inv_15um = 1.0 / (kG1 * um_d); kconst.set_grid(dt, 1.0);
+    kconst.set_um(um_d); kconst.set_grid(dt, 1.0);
     if (is_if) {
         i_lane = iface_lane_s[tid]; i_off = tb.lane_off[i_lane]; i_n = tb.lane_ncell[i_lane]; i_k = tid - i_off - i_lane;
         kconst.set_grid(dt, tb.lane_dx[i_lane]);

@@ -15,6 +15,7 @@ OK, E_INVALID, E_LAUNCH, E_NO_DEVICE = 0, -1, -2, -3
 FAULT_NONE, FAULT_CFL, FAULT_COLLISION, FAULT_NAN, FAULT_CAPACITY = 0, 1, 2, 3, 4
 OPT_MACRO_FWD_WAVES = 1
 OPT_MICRO_FWD_WAVES = 2
+OPT_MACRO_FWD_VARIANT = 3
 MACRO_MAX_CELLS = 4000
 MICRO_MAX_VEHICLES = 1024
 

@@ -71,10 +71,14 @@ int dhts_version(void);
 /* number of visible gfx950 devices, or DHTS_E_NO_DEVICE */
 int dhts_device_count(void);
 /* tuning knobs (process-wide, not part of the numerical contract).
- * DHTS_OPT_MACRO_FWD_WAVES: wavefronts per traffic lane in the macro forward kernel, 1..8; 0 = heuristic. */
+ * DHTS_OPT_MACRO_FWD_WAVES: wavefronts per traffic lane in the macro forward kernel, 1..16 (the single-step operator's
+ * kernel uses at most 8); 0 = heuristic. */
 #define DHTS_OPT_MACRO_FWD_WAVES 1
 /* DHTS_OPT_MICRO_FWD_WAVES: wavefronts per traffic lane in the micro forward kernel, 1, 2 or 4; 0 = heuristic. */
 #define DHTS_OPT_MICRO_FWD_WAVES 2
+/* DHTS_OPT_MACRO_FWD_VARIANT: kernel behind dhts_macro_rollout_fwd: 0 = two-phase kernel (trivial interfaces solved in
+ * place, the others queued and solved compacted), 1 = the one-phase kernel of dhts_macro_step_fwd.  Same tape, same results. */
+#define DHTS_OPT_MACRO_FWD_VARIANT 3
 int dhts_set_option(int option, int value);
 /* cells / vehicle slots rounded up to the tape's padded width (multiple of 64) */
 int dhts_padded(int n);

@@ -38,7 +38,7 @@ def test_options_accept_documented_values_only():
     lib = _lib.lib()
     for v in (0, 1, 5, 8):
         assert lib.dhts_set_option(_lib.OPT_MACRO_FWD_WAVES, v) == 0
-    assert lib.dhts_set_option(_lib.OPT_MACRO_FWD_WAVES, 9) == _lib.E_INVALID
+    assert lib.dhts_set_option(_lib.OPT_MACRO_FWD_WAVES, 17) == _lib.E_INVALID
     for v in (1, 2, 4, 0):
         assert lib.dhts_set_option(_lib.OPT_MICRO_FWD_WAVES, v) == 0
     assert lib.dhts_set_option(_lib.OPT_MICRO_FWD_WAVES, 3) == _lib.E_INVALID

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Counter passes over the macro rollout forward kernels (GPU box).  Usage: tools/pmc_macro_fwd.sh <out-dir> <variant> <waves>
+# One rocprofv3 run per counter group (SQ has 8 slots per pass); --kernel-trace only, never with a --sys-trace domain.
+set -u
+OUT=$1; V=${2:-0}; W=${3:-0}
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p "$OUT"; OUT=$(cd "$OUT" && pwd)
+cd /tmp && export TMPDIR=/tmp
+G1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
+G2="SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA"
+G3="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_CVT"
+G4="GRBM_GUI_ACTIVE SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_TRANS_F32 SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT"
+i=0
+for G in "$G1" "$G2" "$G3" "$G4"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $G --output-format csv -d "$OUT/g$i" -- python3 "$REPO/tools/run_macro_fwd.py" "$V" "$W" 2 > "$OUT/g$i.log" 2>&1
+  tail -n 1 "$OUT/g$i.log"
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, os, sys, collections
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"]
+        if "rollout" not in k:
+            continue
+        name = "fwd2" if "fwd2" in k else ("fwd" if "fwd" in k else "bwd")
+        acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(os.path.join(out, "summary.csv"), "w") as f:
+    f.write("kernel,counter,mean_per_dispatch,dispatches\n")
+    for k in sorted(acc):
+        for c in sorted(acc[k]):
+            v = acc[k][c]
+            f.write("%s,%s,%.6g,%d\n" % (k, c, sum(v) / len(v), len(v)))
+print(open(os.path.join(out, "summary.csv")).read())
+PY

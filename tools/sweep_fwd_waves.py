@@ -15,7 +15,9 @@ dev = torch.device("cuda:0")
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 w = bench.MacroWorkload(dev, 0, L, N, 1000)
-for waves in (0, 2, 3, 4, 5, 6, 7, 8):
+sweep = [(1, 0)] + [(0, k) for k in (0, 1, 2, 4, 8, 16)]       # (kernel variant, wavefronts per lane)
+for variant, waves in sweep:
+    _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_VARIANT, variant)
     _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_WAVES, waves)
     w.ev = []
     for _ in range(2):
@@ -25,4 +27,4 @@ for waves in (0, 2, 3, 4, 5, 6, 7, 8):
     torch.cuda.synchronize()
     fwd = sorted(e[0].elapsed_time(e[1]) for e in w.ev)
     bwd = sorted(e[2].elapsed_time(e[3]) for e in w.ev)
-    print("waves/lane %d: fwd median %.3f ms (min %.3f)  bwd median %.3f ms" % (waves, fwd[2], fwd[0], bwd[2]), flush=True)
+    print("variant %d waves/lane %d: fwd median %.3f ms (min %.3f)  bwd median %.3f ms" % (variant, waves, fwd[2], fwd[0], bwd[2]), flush=True)
