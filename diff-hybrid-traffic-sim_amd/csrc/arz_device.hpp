@@ -412,12 +412,85 @@ __device__ __forceinline__ void arz_trivial_fast(double rL, double yL, const Ifa
     arz_flux_fp(rL, yL, u0, p.q0L, p.rLc, p.hL, p.inv_rLc, k.um, Fr, Fy, fp);
 }
 
+// Q_M (case 1, compute_Qm _arz.py:184-199) and Q_C (case 2, compute_Qc :167-182) share one form: r_0 = b0^2 with
+//   b0 = sqrt(r_L) + (u_L - u_R) / u_max (Q_M)   or   (u_L + u_max sqrt(r_L)) / ((gamma+1) u_max) (Q_C).
+struct MidState {
+    double r0, y0, u0, q0;         // Q_0
+    double r0c, h0, inv_r0c;       // max(r_0, eps), 0.5 / sqrt of it, 1 / it
+    double ab0, base;              // |b0| = sqrt(r_0) = r_0 ** (1 - gamma);  u_L + u_max sqrt(r_L)
+};
+__device__ __forceinline__ void arz_mid_state(bool c1, double uL, double uR, double sL, double bm, const IfaceConst &k, MidState &m) {
+    const double um = k.um;
+    m.base = __builtin_fma(um, sL, uL);
+    const double b0 = c1 ? bm : m.base * k.inv_15um;
+    m.ab0 = fabs(b0);
+    m.r0 = b0 * b0;
+    m.u0 = c1 ? uR : kGoG1 * m.base;
+    m.q0 = __builtin_fma(-um, fast_sqrt(fmax(m.r0, 0.) + kEps), um);
+    m.y0 = m.r0 * (m.u0 - m.q0);
+    m.r0c = fmax(m.r0, kEps);
+    m.h0 = (m.r0 >= kEps) ? 0.5 * fast_rcp(m.ab0) : kHalfRsqrtEps;          // 0.5 / sqrt(r0c)
+    const double rs0 = m.h0 + m.h0;
+    m.inv_r0c = rs0 * rs0;
+}
+// compute_dM (darz.py:35-122) / compute_dC (darz.py:124-192), float32 entries:
+// d b0 / d(r_L, y_L) = sc * (du_L/dr_L + u_max gamma r_L^(gamma-1), du_L/dy_L), sc = 1/u_max or 1/((gamma+1) u_max);
+// d y_0 = k1 d r_0 + r_0 d u_0.
+__device__ __forceinline__ void arz_mid_jacobians_left(bool c1, double yL, double hL, double inv_rLc, double ueqp_L,
+                                                       const MidState &m, const IfaceConst &k, float dL[4]) {
+    const double um = k.um;
+    const double w = __builtin_fma(-yL, inv_rLc * inv_rLc, ueqp_L) + um * hL;     // du_L/dr_L + u_max gamma r_L^(gamma-1)
+    const double a2sc = (m.ab0 + m.ab0) * (c1 ? k.inv_um : k.inv_15um);
+    const double k1 = __builtin_fma(m.r0, um * m.h0, m.u0 - m.q0);
+    const double gL = c1 ? 0.0 : kGoG1;                // d u_0 / d u_L
+    const double dr_drL = a2sc * w;
+    const double dr_dyL = a2sc * inv_rLc;
+    dL[0] = (float)dr_drL; dL[1] = (float)dr_dyL;
+    dL[2] = (float)__builtin_fma(dr_drL, k1, m.r0 * (gL * w)); dL[3] = (float)__builtin_fma(dr_dyL, k1, m.r0 * (gL * inv_rLc));
+}
+// dQ_0/dQ_R, Q_M only (hR = 0.5 / sqrt(max(r_R, eps)))
+__device__ __forceinline__ void arz_mid_jacobians_right(double yR, double hR, const MidState &m, const IfaceConst &k, float dR[4]) {
+    const double um = k.um;
+    const double a2sc = (m.ab0 + m.ab0) * k.inv_um;
+    const double k1 = __builtin_fma(m.r0, um * m.h0, m.u0 - m.q0);
+    const double rsR = hR + hR;
+    const double inv_rRc = rsR * rsR;
+    const double duR_drR = __builtin_fma(-yR, inv_rRc * inv_rRc, -um * hR);
+    const double dr_drR = -a2sc * duR_drR;
+    const double dr_dyR = -a2sc * inv_rRc;
+    dR[0] = (float)dr_drR; dR[1] = (float)dr_dyR;
+    dR[2] = (float)__builtin_fma(dr_drR, k1, m.r0 * duR_drR); dR[3] = (float)__builtin_fma(dr_dyR, k1, m.r0 * inv_rRc);
+}
+__device__ __forceinline__ void arz_mid_jacobians(bool c1, double yL, double yR, double hL, double inv_rLc, double ueqp_L, double hR,
+                                                  const MidState &m, const IfaceConst &k, float dL[4], float dR[4]) {
+    arz_mid_jacobians_left(c1, yL, hL, inv_rLc, ueqp_L, m, k, dL);
+    if (c1) arz_mid_jacobians_right(yR, hR, m, k, dR);
+}
+// fp @ dL, fp @ dR in float32 (np.matmul); B = 0 for Q_C
+__device__ __forceinline__ void arz_mid_products_left(const float fp[4], const float dL[4], float A[4]) {
+    A[0] = dot2(fp[0], dL[0], fp[1], dL[2]);
+    A[1] = dot2(fp[0], dL[1], fp[1], dL[3]);
+    A[2] = dot2(fp[2], dL[0], fp[3], dL[2]);
+    A[3] = dot2(fp[2], dL[1], fp[3], dL[3]);
+}
+__device__ __forceinline__ void arz_mid_products_right(const float fp[4], const float dR[4], float B[4]) {
+    B[0] = dot2(fp[0], dR[0], fp[1], dR[2]);
+    B[1] = dot2(fp[0], dR[1], fp[1], dR[3]);
+    B[2] = dot2(fp[2], dR[0], fp[3], dR[2]);
+    B[3] = dot2(fp[2], dR[1], fp[3], dR[3]);
+}
+__device__ __forceinline__ void arz_mid_products(bool c1, const float fp[4], const float dL[4], const float dR[4], float A[4], float B[4]) {
+    arz_mid_products_left(fp, dL, A);
+    if (c1) arz_mid_products_right(fp, dR, B);
+    else B[0] = B[1] = B[2] = B[3] = 0.f;
+}
+
 template <bool kHavePre>
 __device__ __forceinline__ void arz_interface_fast_impl(double rL, double yL, double uL, double qL,
                                                         double rR, double yR, double uR, double qR,
                                                         const CellPre *cl, const CellPre *cr,
                                                         const IfaceConst &k, Iface &o, IfaceDebug *dbg) {
-    const double um = k.um, inv_um = k.inv_um;
+    const double um = k.um;
     IfacePre p;
     if constexpr (kHavePre) arz_classify_fast(rL, uL, qL, rR, uR, *cl, k, p);
     else arz_pre_fast(rL, uL, qL, rR, uR, k, p);
@@ -431,44 +504,17 @@ __device__ __forceinline__ void arz_interface_fast_impl(double rL, double yL, do
         arz_trivial_fast(rL, yL, p, k, u0, o.Fr, o.Fy, fp);
         r0 = rL; y0 = yL; q0 = p.q0L;
     } else {
-        // Q_M (case 1, compute_Qm _arz.py:184-199 + compute_dM darz.py:35-122) and Q_C (case 2, compute_Qc :167-182 +
-        // compute_dC darz.py:124-192) share one form: r_0 = b0^2 with b0 = sqrt(r_L) + (u_L - u_R) / u_max   (Q_M)
-        //                                                              or (u_L + u_max sqrt(r_L)) / ((gamma+1) u_max) (Q_C),
-        // and d b0 / d(r_L, y_L) = sc * (du_L/dr_L + u_max gamma r_L^(gamma-1), du_L/dy_L), sc = 1/u_max or 1/((gamma+1) u_max).
         const bool c1 = (ci == 1);
-        const double hL = p.hL, inv_rLc = p.inv_rLc;
-        const double base = __builtin_fma(um, p.sL, uL);
-        const double b0 = c1 ? p.bm : base * k.inv_15um;
-        const double ab0 = fabs(b0);                       // sqrt(r_0) = r_0 ** (1 - gamma)
-        r0 = b0 * b0;
-        u0 = c1 ? uR : kGoG1 * base;
-        q0 = __builtin_fma(-um, fast_sqrt(fmax(r0, 0.) + kEps), um);
-        y0 = r0 * (u0 - q0);
-        const double r0c = fmax(r0, kEps);
-        const double h0 = (r0 >= kEps) ? 0.5 * fast_rcp(ab0) : kHalfRsqrtEps;          // 0.5 / sqrt(r0c)
-        const double rs0 = h0 + h0;
-        const double inv_r0c = rs0 * rs0;
-        const double w = __builtin_fma(-yL, inv_rLc * inv_rLc, p.ueqp_L) + um * hL;     // du_L/dr_L + u_max gamma r_L^(gamma-1)
-        const double a2sc = (ab0 + ab0) * (c1 ? inv_um : k.inv_15um);
-        const double k1 = __builtin_fma(r0, um * h0, u0 - q0);  // d y_0 = k1 d r_0 + r_0 d u_0
-        const double gL = c1 ? 0.0 : kGoG1;                // d u_0 / d u_L
-        const double dr_drL = a2sc * w;
-        const double dr_dyL = a2sc * inv_rLc;
-        dL[0] = (float)dr_drL; dL[1] = (float)dr_dyL;
-        dL[2] = (float)__builtin_fma(dr_drL, k1, r0 * (gL * w)); dL[3] = (float)__builtin_fma(dr_dyL, k1, r0 * (gL * inv_rLc));
+        MidState m;
+        arz_mid_state(c1, uL, uR, p.sL, p.bm, k, m);
+        double hR = 0.;
         if (c1) {
-            double sR, hR;
-            if constexpr (kHavePre) { sR = cr->s; hR = cr->h; }
-            else sqrt_hrsqrt(fmax(rR, kEps), sR, hR);
-            const double rsR = hR + hR;
-            const double inv_rRc = rsR * rsR;
-            const double duR_drR = __builtin_fma(-yR, inv_rRc * inv_rRc, -um * hR);
-            const double dr_drR = -a2sc * duR_drR;
-            const double dr_dyR = -a2sc * inv_rRc;
-            dR[0] = (float)dr_drR; dR[1] = (float)dr_dyR;
-            dR[2] = (float)__builtin_fma(dr_drR, k1, r0 * duR_drR); dR[3] = (float)__builtin_fma(dr_dyR, k1, r0 * inv_rRc);
+            if constexpr (kHavePre) hR = cr->h;
+            else { double sR; sqrt_hrsqrt(fmax(rR, kEps), sR, hR); }
         }
-        arz_flux_fp(r0, y0, u0, q0, r0c, h0, inv_r0c, um, o.Fr, o.Fy, fp);
+        arz_mid_jacobians(c1, yL, yR, p.hL, p.inv_rLc, p.ueqp_L, hR, m, k, dL, dR);
+        arz_flux_fp(m.r0, m.y0, m.u0, m.q0, m.r0c, m.h0, m.inv_r0c, um, o.Fr, o.Fy, fp);
+        r0 = m.r0; y0 = m.y0; u0 = m.u0; q0 = m.q0;
     }
 
     if (dbg) {
@@ -480,23 +526,11 @@ __device__ __forceinline__ void arz_interface_fast_impl(double rL, double yL, do
             dbg->dR[j] = (ci == 1) ? dR[j] : 0.f;
         }
     }
-    // ---- fp @ dL, fp @ dR in float32 (np.matmul) ----
     if (ci == 0) {          // dL = I, dR = 0: the products are fp and 0 exactly
         o.A[0] = fp[0]; o.A[1] = fp[1]; o.A[2] = fp[2]; o.A[3] = fp[3];
         o.B[0] = o.B[1] = o.B[2] = o.B[3] = 0.f;
     } else {
-        o.A[0] = dot2(fp[0], dL[0], fp[1], dL[2]);
-        o.A[1] = dot2(fp[0], dL[1], fp[1], dL[3]);
-        o.A[2] = dot2(fp[2], dL[0], fp[3], dL[2]);
-        o.A[3] = dot2(fp[2], dL[1], fp[3], dL[3]);
-        if (ci == 1) {
-            o.B[0] = dot2(fp[0], dR[0], fp[1], dR[2]);
-            o.B[1] = dot2(fp[0], dR[1], fp[1], dR[3]);
-            o.B[2] = dot2(fp[2], dR[0], fp[3], dR[2]);
-            o.B[3] = dot2(fp[2], dR[1], fp[3], dR[3]);
-        } else {
-            o.B[0] = o.B[1] = o.B[2] = o.B[3] = 0.f;
-        }
+        arz_mid_products(ci == 1, fp, dL, dR, o.A, o.B);
     }
 }
 
