@@ -67,10 +67,34 @@ def test_hybrid_600_steps_matches_reference(cuda, golden_dir):
     assert abs(float(o["reward"][0]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
     scale = np.abs(g["g_action"]).max()
     # gradient of the reward restricted to its first t0 steps (see tests/test_itscp_gpu.py for the last 60 steps of lane 16)
+    # (achieved by oracle and kernels alike: 2.4e-6 for t0 <= 510, 1.2e-4 at t0 = 540 where the knife edge begins)
     for t0, ref in zip(g["g_action_cut_steps"], g["g_action_cut"]):
         if t0 <= 540:
             oc = _run(cuda, g, loss_steps=int(t0))
-            assert np.abs(oc["grad"][0] - ref).max() <= 5 * TOL_GRAD * scale, int(t0)
+            assert np.abs(oc["grad"][0] - ref).max() <= (TOL_GRAD if t0 <= 510 else 2 * TOL_GRAD) * scale, int(t0)
+
+
+@pytest.mark.parametrize("name", ["hybrid_half", "hybrid_s2", "hybrid_s3", "hybrid_p2_600"])
+def test_hybrid_600_steps_full_horizon_gradient(cuda, golden_dir, name):
+    """BASELINE config 4's exact episode (run_itscp_hybrid.sh: 600 steps, 45 actions), four more reference runs -- action
+    0.5 everywhere (every signal sigmoid at its steepest point) and three random actions over problem_1 / problem_2 inflows:
+    queues, reward, spawn count and the WHOLE d reward / d action within 1e-4 of the reference, and the gradient of the
+    reward restricted to its first 150 / 300 / 450 / 540 steps as well."""
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    o = _run(cuda, g, replicas=2)
+    m = o["m"]
+    assert m["T"] == 600 and g["action"].shape == (45,)
+    scale = np.abs(g["g_action"]).max()
+    for r in range(2):
+        assert o["counts"][r, 0] == m["n_vehicle_spawned"]
+        assert rel_max(o["queue"][r].T, g["queue"]) <= 1e-4
+        assert abs(float(o["reward"][r]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+        assert np.abs(o["grad"][r] - g["g_action"]).max() <= TOL_GRAD * scale
+    err = np.abs(o["grad"][0] - g["g_action"]) / scale
+    print("%s: full-horizon gradient error / max|g|: max %.2e, median %.2e" % (name, err.max(), np.median(err)))
+    for t0, ref in zip(g["g_action_cut_steps"], g["g_action_cut"]):
+        oc = _run(cuda, g, loss_steps=int(t0))
+        assert np.abs(oc["grad"][0] - ref).max() <= TOL_GRAD * scale, int(t0)
 
 
 def test_hybrid_kernels_vs_oracle_other_action(cuda, golden_dir, oracle):

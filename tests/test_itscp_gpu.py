@@ -9,6 +9,10 @@ from util import TOL_GRAD, meta_of, rel_max
 
 pytestmark = pytest.mark.gpu
 
+# the lane-by-lane mirror path differs from the reference by the float32 glue torch evaluates on the GPU instead of the CPU
+# (the operators themselves are the kernels); bounds = what the path achieves on each golden, rounded up
+MIRROR_TOL = {"macro_small": TOL_GRAD, "macro": TOL_GRAD, "macro_2x2": TOL_GRAD, "hybrid_short": TOL_GRAD, "hybrid_p3": TOL_GRAD}
+
 
 def build_env(g, m):
     from example.control.itscp._env import ItscpEnv
@@ -37,7 +41,7 @@ def build_env(g, m):
     return env
 
 
-@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "hybrid_short", "hybrid"])
+@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "hybrid_short", "hybrid_p3", "hybrid"])
 def test_itscp_rollout_matches_reference(cuda, golden_dir, name):
     import torch
     path = os.path.join(golden_dir, "itscp_%s.npz" % name)
@@ -79,7 +83,9 @@ def test_itscp_rollout_matches_reference(cuda, golden_dir, name):
     assert abs(float(reward) - float(g["reward"])) <= 1e-4 * abs(float(g["reward"]))
     if name != "hybrid":
         reward.backward()
-        assert rel_max(action.grad.cpu().numpy(), g["g_action"]) <= 5 * TOL_GRAD
+        e = rel_max(action.grad.cpu().numpy(), g["g_action"])
+        print("mirror path %s: d reward / d action error / max|g| = %.2e" % (name, e))
+        assert e <= MIRROR_TOL[name]
         return
     # ---- the 600-step hybrid case -------------------------------------------------------------------------------
     # From step 480 lane 16 (one cell) holds a deposited standing vehicle behind a red light: u = y / r + u_eq cancels
@@ -121,7 +127,8 @@ def test_itscp_rollout_matches_reference(cuda, golden_dir, name):
     assert np.abs(l16 - late[16]).max() <= 0.25 * np.abs(late[16]).max()
 
 
-@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "hybrid_short", "hybrid_p2", "hybrid_p3", "hybrid_l10"])
+@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "hybrid_short", "hybrid_p2", "hybrid_p3", "hybrid_l10",
+                                  "hybrid_half", "hybrid_s2", "hybrid_s3", "hybrid_p2_600"])
 def test_env_step_uses_fused_kernels(cuda, golden_dir, name):
     """ItscpEnv.step(action, True) -- the reference's entry point (trainer.py:172-190) -- through the fused network
     kernels: reward, its gradient and the per-step queue terms against the reference's run."""

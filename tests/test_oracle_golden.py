@@ -169,9 +169,16 @@ def itscp_hybrid_tables(g):
                                g["macro_route"], g["schedule"]), m
 
 
-@pytest.mark.parametrize("name", ["hybrid_short", "hybrid_p2", "hybrid_p3", "hybrid_l10", "hybrid"])
+FULL_HORIZON_600 = ["hybrid_half", "hybrid_s2", "hybrid_s3", "hybrid_p2_600"]     # run_itscp_hybrid.sh's episode, 600 steps
+
+
+@pytest.mark.parametrize("name", ["hybrid_short", "hybrid_p2", "hybrid_p3", "hybrid_l10", "hybrid"] + FULL_HORIZON_600)
 def test_itscp_hybrid_network(oracle, golden_dir, name):
-    """G8 hybrid: macro lanes, micro lanes, spawns, lane changes and deposits against the reference's own run."""
+    """G8 hybrid: macro lanes, micro lanes, spawns, lane changes and deposits against the reference's own run.
+    FULL_HORIZON_600 = four reference runs of BASELINE config 4's exact episode (3 x 3 intersections, 1 lane, 5 m, 20 s,
+    signal 4 s: 600 steps, 45 actions) -- action 0.5 everywhere and three random actions over two inflow patterns: the
+    WHOLE d reward / d action must match to 1e-4 (achieved: <= 2e-6), and so must the gradient of the reward restricted to
+    its first 150 / 300 / 450 / 540 steps."""
     g = load(golden_dir, "itscp_%s.npz" % name)
     t, m = itscp_hybrid_tables(g)
     from dhts.network import group_routes
@@ -184,12 +191,20 @@ def test_itscp_hybrid_network(oracle, golden_dir, name):
     assert rel_max(o["queue"].T, g["queue"]) <= 1e-4
     assert abs(o["reward"] - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
     scale = np.abs(g["g_action"]).max()
-    if name != "hybrid":             # 240 steps / problem_1 and 480 steps / problem_2 (10 deposits): the full gradient
+    if name != "hybrid":             # every golden but one: the full gradient
         assert np.abs(o["g_action"] - g["g_action"]).max() <= TOL_GRAD * scale
+        if name in FULL_HORIZON_600:
+            assert m["T"] == 600 and len(g["action"]) == 45
+            assert np.abs(o["g_action"] - g["g_action"]).max() <= 1e-5 * scale          # achieved 2e-6
+            for t0, ref in zip(g["g_action_cut_steps"], g["g_action_cut"]):
+                oc = run(t_cut=int(t0))
+                assert np.abs(oc["g_action"] - ref).max() <= 1e-5 * scale, int(t0)
         return
-    # the 600-step case: see tests/test_itscp_gpu.py for why the last 60 steps of lane 16 are excluded
+    # the first 600-step golden sits on a float32 knife edge of the reference's own gradient from step ~540 on (lane 16,
+    # DESIGN.md section 8): the gradient of the reward restricted to its first t0 steps is pinned up to there
+    # (achieved: 2.4e-6 for t0 <= 510, 1.2e-4 at t0 = 540)
     assert o["n_deposits"] == 12
     for t0, ref in zip(g["g_action_cut_steps"], g["g_action_cut"]):
         if t0 <= 540:
             oc = run(t_cut=int(t0))
-            assert np.abs(oc["g_action"] - ref).max() <= 5 * TOL_GRAD * scale, int(t0)
+            assert np.abs(oc["g_action"] - ref).max() <= (1e-5 if t0 <= 510 else 2 * TOL_GRAD) * scale, int(t0)
