@@ -21,10 +21,12 @@
 
 namespace dhts {
 
+constexpr long long kNetWindow = 100000;      // RunningMean(100_000), _env.py:122
+
 // bytes of the kernels' LDS carve-ups in front of the staged tables (shared by the kernels and their host wrappers)
 __host__ __device__ inline size_t net_fwd_lds_base(int L, int C) {
     const size_t NI = (size_t)C + L;
-    return sizeof(double) * (2 * NI + 16) + sizeof(float) * (8 * (size_t)C + 8 * L + 8 * NI + C + L) + sizeof(int) * ((size_t)C + NI);
+    return sizeof(double) * (2 * NI + 32) + sizeof(float) * (8 * (size_t)C + 8 * L + 8 * NI + C + L) + sizeof(int) * ((size_t)C + NI);
 }
 __host__ __device__ inline size_t net_bwd_lds_base(int L, int C, int E, int sq) {
     return sizeof(double) * (((10 * (size_t)C + L + 4 * E + C + 1) / 2 + 1) + 16 * (size_t)sq) + 64;
@@ -54,7 +56,10 @@ __device__ __forceinline__ NetStaged net_staged(char *lds, size_t base, int L, i
 
 // forward: three barriers per step.  The loss of the state produced by step t-1 is evaluated inside the phases of step t
 // (its prefix scan beside the ghost phase, its constants beside the interface solves, its lane sums beside the updates).
-// LDS: doubles Fq [NI][2], scanw [16] | floats S0, S1 [4][C], G [L][2][4], AB [NI][8], contrib [C], ql [L]
+// The loss' RunningMean(100 000) (example/common/rms.py:10-19, _env.py:602-606): the mean behind a sample covers the last
+// 100 000 samples; beyond that many (T * C > 100 000) a second scan subtracts the samples that have left the window,
+// re-read from the state history this kernel writes anyway (sample (step, cell) = static_speed - u of history row step + 1).
+// LDS: doubles Fq [NI][2], scanw [2][16] | floats S0, S1 [4][C], G [L][2][4], AB [NI][8], contrib [C], ql [L]
 __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
                                      double static_speed, double veh_len, NetTables tb, const float *__restrict__ action,
                                      float *__restrict__ hist, float4 *__restrict__ tape, float *__restrict__ kc,
@@ -66,7 +71,7 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
     const int Cp = (C + 63) & ~63;
     double *Fq = lds_d;
     double *scanw = Fq + 2 * NI;
-    float *fl = reinterpret_cast<float *>(scanw + 16);
+    float *fl = reinterpret_cast<float *>(scanw + 32);
     float *S0 = fl, *S1 = S0 + 4 * C;
     float *G = S1 + 4 * C;
     float *AB = G + 8 * L;
@@ -140,28 +145,47 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
     signals();
     __syncthreads();
     if (T > 0) fetch(0);
-    double run_sum = 0.; long long run_cnt = 0;
+    double run_in = 0., run_out = 0.; long long run_cnt = 0;      // sums of the samples taken / of those that left the window
+    int old_row = -1, old_cell = 0;                                // (history row, cell) of the sample `window` before this thread's next one
     float lane_total = 0.f;
     int fault_step = -1, fault_index = 0;
 
     // loss pieces of the state held in `st` (evaluated for step index ls >= 0)
-    double l_part = 0., l_incl = 0.;
-    auto loss_scan = [&](const float *st) {          // phase 1: wave-level inclusive scan of x = s0 - u, cells in order
-        l_part = is_cell ? (double)(s0f - st[2 * C + tid]) : 0.;
-        l_incl = wave_scan_add(l_part);
-        if ((tid & 63) == 63) scanw[tid >> 6] = l_incl;
+    double l_incl = 0., l_incl_out = 0.;
+    auto loss_scan = [&](const float *st) {          // phase 1: wave-level inclusive scans over the cells in order
+        double a = 0., b = 0.;
+        if (is_cell) {
+            a = (double)(s0f - st[2 * C + tid]);     // x = s0 - u
+            const long long idx = run_cnt + tid;
+            if (idx >= kNetWindow) {
+                if (old_row < 0) { const long long j = idx - kNetWindow; old_row = (int)(j / C) + 1; old_cell = (int)(j % C); }
+                else ++old_row;                      // idx grows by C per step: the same cell, one history row later
+                b = (double)(s0f - __hip_atomic_load(hist_r + (size_t)old_row * 4 * C + 2 * C + old_cell, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT));      // written long ago by another thread: around L1
+            }
+        }
+        l_incl = wave_scan_add(a);
+        l_incl_out = wave_scan_add(b);
+        if ((tid & 63) == 63) { scanw[tid >> 6] = l_incl; scanw[16 + (tid >> 6)] = l_incl_out; }
     };
     auto loss_consts = [&](const float *st, int ls) { // phase 2: k_c and the cell's contribution to its lane queue
         const int wv = tid >> 6, nw = B >> 6;
-        double base = 0., total = 0.;
-        for (int k = 0; k < nw; ++k) { const double v = scanw[k]; if (k < wv) base += v; total += v; }
+        double base_a = 0., tot_a = 0., base_b = 0., tot_b = 0.;
+        for (int k = 0; k < nw; ++k) {
+            const double va = scanw[k], vb = scanw[16 + k];
+            if (k < wv) { base_a += va; base_b += vb; }
+            tot_a += va; tot_b += vb;
+        }
         if (is_cell) {
-            const double mean = (run_sum + base + l_incl) / (double)(run_cnt + tid + 1);
+            const long long n = run_cnt + tid + 1;
+            const double pin = run_in + base_a + l_incl, pout = run_out + base_b + l_incl_out;
+            const bool full = n > kNetWindow;         // one IEEE division, operands selected first
+            const double mean = (full ? pin - pout : pin) / (full ? (double)kNetWindow : (double)n);
             const float kk = 16.f / fabsf((float)mean);
             kc_r[(size_t)ls * C + tid] = kk;
             contrib[tid] = soft_switch(s0f - st[2 * C + tid], kk) * (st[tid] * c_dxv);
         }
-        run_sum += total; run_cnt += C;
+        run_in += tot_a; run_out += tot_b; run_cnt += C;
     };
     auto loss_lanes = [&](int ls) {                   // phase 3: q = sum of the lane's cells, term q^2 dt
         if (is_lane) {
@@ -547,7 +571,7 @@ using namespace dhts;
 static inline bool net_desc_ok(const dhts_net_desc *d) {
     return d && d->n_replicas > 0 && d->n_lanes > 0 && d->n_cells > 0 && d->n_steps >= 0 && d->n_inter_sq > 0 &&
            d->frames_per_phase > 0 && d->n_action >= d->n_inter_sq && d->n_action <= 1024 && d->dt > 0 && d->u_max > 0 &&
-           d->vehicle_length > 0 && (long long)d->n_steps * d->n_cells <= 100000 && d->n_cells + d->n_lanes <= 1024 &&
+           d->vehicle_length > 0 && (long long)d->n_steps * d->n_cells < (1ll << 31) && d->n_cells + d->n_lanes <= 1024 &&
            d->n_lanes <= d->n_cells;
 }
 static inline int net_block(const dhts_net_desc *d) {

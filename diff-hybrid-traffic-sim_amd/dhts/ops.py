@@ -412,7 +412,7 @@ class NetMacroRollout(torch.autograd.Function):
         lib = _lib.lib()
         hist_n, tape_n = lib.dhts_net_macro_hist_bytes(C.byref(d)) // 4, lib.dhts_net_macro_tape_bytes(C.byref(d)) // 4
         if hist_n == 0:
-            raise ValueError("unsupported network size (need steps * cells <= 100000)")
+            raise ValueError("unsupported network size (need cells + lanes <= 1024 and lanes <= cells)")
         dev = a.device
         hist = torch.empty(hist_n, dtype=torch.float32, device=dev)
         tape = torch.empty(tape_n, dtype=torch.float32, device=dev)

@@ -276,7 +276,7 @@ class ItscpEnv:
             try:
                 T = self.num_timestep
                 n_cells = sum(getattr(sl, "num_cell", 0) for sl in sim.lane.values() if sl.is_macro())
-                if self.config["mode"] == "macro" and T * n_cells <= 100000:
+                if self.config["mode"] == "macro" and n_cells + len(sim.lane) <= 1024:
                     cache = ("macro", ops.DeviceNetTables(MacroNetworkTables.from_env(self), action.device))
                 else:
                     tab = HybridNetworkTables.from_env(self)

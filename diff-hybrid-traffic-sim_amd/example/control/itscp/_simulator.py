@@ -31,6 +31,9 @@ class ItscpRoadNetwork(RoadNetwork):
         self.lane_waiting_micro_route = {}
         self.signal_rms = RunningMean(100_000)
         self.lane_incoming_acc = {}
+        # the draw that admits a waiting vehicle onto a micro source lane (reference: np.random.random at call time,
+        # _simulator.py:159); a test replays the reference's recorded draws through this hook
+        self.random_draw = lambda: np.random.random((1,)).item()
 
     def interpolate_signal(self, signal, green_value, red_value):
         assert signal >= 0.0 and signal <= 1.0, ""
@@ -62,7 +65,7 @@ class ItscpRoadNetwork(RoadNetwork):
         assert lane.is_micro(), ""
         if not lane.has_prev_lane():                # stochastic inflow of a source lane
             if lane.entering_free_space() > DEFAULT_VEHICLE_LENGTH * 0.5:
-                rand = np.random.random((1,)).item()
+                rand = self.random_draw()
                 wv, wr = self.lane_waiting_micro_vehicle[id], self.lane_waiting_micro_route[id]
                 if rand < self.lane_incoming[id] and len(wv) and len(wr):
                     self.add_vehicle(wv[-1], wr[-1])

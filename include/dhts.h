@@ -225,8 +225,8 @@ int dhts_micro_step_bwd(const dhts_micro_desc *d, const float *tape, const int32
  * Lanes start empty.  Tables (device pointers) are built on the host (dhts/network.py):
  *   lane_ncell, lane_off, sig_kind (0 always green, 1 west-east phase, 2 north-south phase), inter [L] int32; lane_dx [L]
  *   DOUBLE; left_src / left_gate / right_src [T][L] int32 and schedule [T][L] DOUBLE, per replica when replica_stride
- *   (elements between replicas) is non-zero, else shared.  Limits: T * n_cells <= 100000 (the loss' running-mean window),
- *   n_cells + n_lanes <= 1024 (one workgroup per replica), n_action <= 1024, at most 4 upstream / 4 downstream lanes per lane.
+ *   (elements between replicas) is non-zero, else shared.  The loss' RunningMean(100 000) window slides once T * n_cells exceeds it
+ *   (the samples that leave are re-read from the state history).  Limits: n_cells + n_lanes <= 1024 (one workgroup per replica), n_action <= 1024, at most 4 upstream / 4 downstream lanes per lane.
  */
 typedef struct dhts_net_desc {
     int32_t n_replicas, n_lanes, n_cells, n_steps, n_inter_sq, frames_per_phase, n_action;

@@ -78,8 +78,8 @@ def test_network_entry_points_reject_bad_sizes():
     ok = _lib.NetDesc(4, 40, 236, 300, 1, 60, 5, 1 / 30, 60.0, 0.2, 5.0)
     assert lib.dhts_net_macro_hist_bytes(C.byref(ok)) == 4 * 301 * 4 * 236 * 4
     assert lib.dhts_net_macro_tape_bytes(C.byref(ok)) == 4 * 300 * 3 * 256 * 16
-    too_long = _lib.NetDesc(4, 40, 236, 600, 1, 60, 5, 1 / 30, 60.0, 0.2, 5.0)       # 600 * 236 > 100000 samples
-    assert lib.dhts_net_macro_hist_bytes(C.byref(too_long)) == 0
+    long_run = _lib.NetDesc(4, 40, 236, 600, 1, 60, 5, 1 / 30, 60.0, 0.2, 5.0)       # 600 * 236 > 100000 samples: the window slides
+    assert lib.dhts_net_macro_hist_bytes(C.byref(long_run)) == 4 * 601 * 4 * 236 * 4
     too_wide = _lib.NetDesc(4, 300, 900, 10, 1, 60, 5, 1 / 30, 60.0, 0.2, 5.0)        # cells + lanes > 1024
     assert lib.dhts_net_macro_tape_bytes(C.byref(too_wide)) == 0
     tabs = _lib.NetTables()

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from util import TOL_GRAD, TOL_STATE, meta_of, rel_max, ulp_diff
+from util import TOL_GRAD, TOL_STATE, grad_report, meta_of, rel_elem, rel_max, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -216,14 +216,18 @@ def test_macro_rollout_vs_golden(cuda, golden_dir, name):
     assert rel_max(rT.detach().cpu().numpy()[0], g["rT"]) <= TOL_STATE
     assert rel_max(yT.detach().cpu().numpy()[0], g["yT"]) <= TOL_STATE
     assert rel_max(uT.detach().cpu().numpy()[0], g["uT"]) <= TOL_STATE
+    # element-wise as well (floor 1e-6 max|ref| under the division): "state <= 1e-5 relative" entry by entry
+    e_elem = max(rel_elem(rT.detach().cpu().numpy()[0], g["rT"]), rel_elem(uT.detach().cpu().numpy()[0], g["uT"]))
+    print("G4 %s (kernels): element-wise state error %.2e" % (name, e_elem))
+    assert e_elem <= TOL_STATE
     h = hist.detach().cpu().numpy()
     for t in range(len(g["steps_r"])):
         assert rel_max(h[t, 0, 0], g["steps_r"][t]) <= TOL_STATE
         assert rel_max(h[t, 0, 1], g["steps_y"][t]) <= TOL_STATE
         assert rel_max(h[t, 0, 2], g["steps_u"][t]) <= TOL_STATE
     assert abs(float(loss) - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
-    assert rel_max(r0.grad.cpu().numpy()[0], g["g_r0"]) <= TOL_GRAD
-    assert rel_max(u0.grad.cpu().numpy()[0], g["g_u0"]) <= TOL_GRAD
+    assert grad_report("G4 %s (kernels) d loss / d r0" % name, r0.grad.cpu().numpy()[0], g["g_r0"]) <= TOL_GRAD
+    assert grad_report("G4 %s (kernels) d loss / d u0" % name, u0.grad.cpu().numpy()[0], g["g_u0"]) <= TOL_GRAD
     assert rel_max(gr.grad.cpu().numpy()[0], g["g_ghost_r"]) <= TOL_GRAD
     assert rel_max(gu.grad.cpu().numpy()[0], g["g_ghost_u"]) <= TOL_GRAD
 
@@ -490,12 +494,13 @@ def test_micro_rollout_vs_golden(cuda, golden_dir, name):
     loss.backward()
     assert rel_max(pT.detach().cpu().numpy()[0], g["pT"]) <= 1e-6
     assert rel_max(vT.detach().cpu().numpy()[0], g["vT"]) <= 1e-6
+    assert rel_elem(pT.detach().cpu().numpy()[0], g["pT"]) <= 1e-6 and rel_elem(vT.detach().cpu().numpy()[0], g["vT"]) <= 1e-6
     h = hist.detach().cpu().numpy()
     for t in range(len(g["steps_p"])):
         assert ulp_diff(h[t, 0, 0], g["steps_p"][t]).max() <= 1
         assert ulp_diff(h[t, 0, 1], g["steps_v"][t]).max() <= 1
-    assert rel_max(p0.grad.cpu().numpy()[0], g["g_p0"]) <= 1e-5
-    assert rel_max(v0.grad.cpu().numpy()[0], g["g_v0"]) <= 1e-5
+    assert grad_report("G6 %s (kernels) d loss / d p0" % name, p0.grad.cpu().numpy()[0], g["g_p0"]) <= 1e-5
+    assert grad_report("G6 %s (kernels) d loss / d v0" % name, v0.grad.cpu().numpy()[0], g["g_v0"]) <= 1e-5
 
 
 @pytest.mark.parametrize("V", [1, 2, 63, 64, 65, 128, 200, 256, 300, 600, 1024])

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from test_oracle_golden import itscp_hybrid_tables
-from util import TOL_GRAD, TOL_STATE, rel_max
+from util import TOL_GRAD, TOL_STATE, grad_report, rel_elem, rel_max
 
 pytestmark = pytest.mark.gpu
 
@@ -32,7 +32,7 @@ def _run(cuda, g, loss_steps=0, replicas=1, want_grad=True, action=None):
                 counts=counts.cpu().numpy(), grad=grad, m=m)
 
 
-@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2"])
+@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "macro_half", "macro_long"])
 def test_hybrid_kernels_on_macro_only_network(cuda, golden_dir, name):
     g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
     o = _run(cuda, g)

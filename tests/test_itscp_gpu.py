@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 MIRROR_TOL = {"macro_small": TOL_GRAD, "macro": TOL_GRAD, "macro_2x2": TOL_GRAD, "hybrid_short": TOL_GRAD, "hybrid_p3": TOL_GRAD}
 
 
-def build_env(g, m):
+def build_env(g, m, replay_routes=True):
     from example.control.itscp._env import ItscpEnv
     from example.control.itscp import problem as problems
     from road.network.route import MicroRoute
@@ -35,7 +35,8 @@ def build_env(g, m):
         r = spawn[cursor["i"]]
         cursor["i"] += 1
         return r
-    env.route_provider = provider
+    if replay_routes:
+        env.route_provider = provider
     env.reset()
     env._armed = True
     return env
@@ -127,7 +128,45 @@ def test_itscp_rollout_matches_reference(cuda, golden_dir, name):
     assert np.abs(l16 - late[16]).max() <= 0.25 * np.abs(late[16]).max()
 
 
-@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "hybrid_short", "hybrid_p2", "hybrid_p3", "hybrid_l10",
+@pytest.mark.parametrize("name", ["micro_small", "micro"])
+def test_itscp_micro_mode_matches_reference(cuda, golden_dir, name):
+    """itscp `micro` mode (run_itscp_micro.sh: every lane an IDM lane, source lanes admit waiting vehicles stochastically,
+    _simulator.py:153-174) through the mirror classes on the kernels, against the reference's run.  The reference uses the
+    plain autodiff MicroLane there (_env.py:484-487); the mirror's lanes run the analytic operator, which agrees with it to
+    ~1e-6.  Host randomness is replayed: the admission draws in call order, the waiting routes by seed."""
+    import json
+    import torch
+    path = os.path.join(golden_dir, "itscp_%s.npz" % name)
+    if not os.path.exists(path):
+        pytest.skip("golden not generated")
+    g = np.load(path)
+    m = meta_of(g)
+    env = build_env(g, m, replay_routes=False)      # routes are drawn with np.random in the reference's order (same seed)
+    sim = env.simulator
+    keys = list(env.lane.keys())
+    assert len(keys) == len(g["lane_tab"]) and all(env.lane[k].sim_lane.is_micro() for k in keys)
+    # host RNG parity at reset: inflow schedule and the routes of the waiting vehicles, drawn in the reference's order
+    assert np.array_equal(np.array([env.schedule[k] for k in keys]), g["schedule"])
+    want = {int(l): r for l, r in json.loads(str(g["waiting_routes"])).items()}
+    mine = {int(l): [list(r.route) for r in rs] for l, rs in sim.lane_waiting_micro_route.items()}
+    assert mine == want
+    draws = iter(g["rand_draws"].tolist())
+    sim.random_draw = lambda: next(draws)
+    action = torch.tensor(g["action"], device=cuda, requires_grad=True)
+    env._simulate(action, True)
+    reward = env._reward(action)
+    assert next(draws, None) is None                       # every recorded draw was consumed: same admission tests
+    assert sim.num_vehicle == m["n_vehicle_spawned"]
+    queue = np.array([[float(x) for x in env.queue_length[k]] for k in keys])
+    assert rel_max(queue, g["queue"]) <= 1e-4
+    assert abs(float(reward) - float(g["reward"])) <= 1e-4 * abs(float(g["reward"]))
+    reward.backward()
+    e = rel_max(action.grad.cpu().numpy(), g["g_action"])
+    print("mirror path %s: d reward / d action error / max|g| = %.2e" % (name, e))
+    assert e <= TOL_GRAD
+
+
+@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "macro_half", "macro_long", "hybrid_short", "hybrid_p2", "hybrid_p3", "hybrid_l10",
                                   "hybrid_half", "hybrid_s2", "hybrid_s3", "hybrid_p2_600"])
 def test_env_step_uses_fused_kernels(cuda, golden_dir, name):
     """ItscpEnv.step(action, True) -- the reference's entry point (trainer.py:172-190) -- through the fused network

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from test_oracle_golden import itscp_tables
-from util import TOL_GRAD, TOL_STATE, rel_max
+from util import TOL_GRAD, TOL_STATE, grad_report, rel_elem, rel_max
 
 pytestmark = pytest.mark.gpu
 
@@ -15,7 +15,7 @@ def load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name))
 
 
-@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2"])
+@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "macro_half", "macro_long"])
 def test_network_rollout_vs_reference(cuda, golden_dir, name):
     import torch
     from dhts import ops
@@ -28,8 +28,9 @@ def test_network_rollout_vs_reference(cuda, golden_dir, name):
                                           dt, m["speed_limit"], m["static_speed"], m["vehicle_length"])
     reward.sum().backward()
     assert rel_max(queue[0].cpu().numpy().T, g["queue"]) <= TOL_STATE
+    assert rel_elem(queue[0].cpu().numpy().T, g["queue"]) <= 10 * TOL_STATE      # (sum of sigmoids)^2 dt: twice the state's relative error
     assert abs(float(reward[0]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
-    assert rel_max(action.grad[0].cpu().numpy(), g["g_action"]) <= TOL_GRAD
+    assert grad_report("G8 %s (kernels) d reward / d action" % name, action.grad[0].cpu().numpy(), g["g_action"]) <= TOL_GRAD
 
 
 def test_network_replica_batch_vs_oracle(cuda, oracle, golden_dir):

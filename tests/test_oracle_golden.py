@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from util import TOL_GRAD, TOL_STATE, meta_of, rel_max
+from util import grad_report, rel_elem, TOL_GRAD, TOL_STATE, meta_of, rel_max
 
 
 def load(golden_dir, name):
@@ -63,9 +63,14 @@ def test_macro_rollout(oracle, golden_dir, name):
     assert rel_max(f["rT"][0], g["rT"]) <= TOL_STATE
     assert rel_max(f["yT"][0], g["yT"]) <= TOL_STATE
     assert rel_max(f["uT"][0], g["uT"]) <= TOL_STATE
+    # element-wise too (north_star: "state <= 1e-5 relative"), with a floor of 1e-6 max|ref| under the division
+    e_elem = max(rel_elem(f["rT"][0], g["rT"]), rel_elem(f["uT"][0], g["uT"]))
+    print("G4 %s: element-wise state error %.2e" % (name, e_elem))
+    assert e_elem <= TOL_STATE
     for t in range(len(g["steps_r"])):
         assert rel_max(f["hist_r"][t, 0], g["steps_r"][t]) <= TOL_STATE
         assert rel_max(f["hist_u"][t, 0], g["steps_u"][t]) <= TOL_STATE
+        assert rel_elem(f["hist_r"][t, 0], g["steps_r"][t]) <= TOL_STATE and rel_elem(f["hist_u"][t, 0], g["steps_u"][t]) <= TOL_STATE
     if m["tap"] == "final_sq":
         b = oracle.macro_rollout_bwd(f, g_rT=2 * f["rT"], g_uT=2 * f["uT"])
         loss = float(np.sum(f["rT"].astype(np.float64) ** 2) + np.sum(f["uT"].astype(np.float64) ** 2))
@@ -74,8 +79,8 @@ def test_macro_rollout(oracle, golden_dir, name):
         b = oracle.macro_rollout_bwd(f, gh_r=ones, gh_y=ones, gh_u=ones)
         loss = float(f["hist_r"].sum(dtype=np.float64) + f["hist_y"].sum(dtype=np.float64) + f["hist_u"].sum(dtype=np.float64))
     assert abs(loss - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
-    assert rel_max(b["g_r0"][0], g["g_r0"]) <= TOL_GRAD
-    assert rel_max(b["g_u0"][0], g["g_u0"]) <= TOL_GRAD
+    assert grad_report("G4 %s d loss / d r0" % name, b["g_r0"][0], g["g_r0"]) <= TOL_GRAD
+    assert grad_report("G4 %s d loss / d u0" % name, b["g_u0"][0], g["g_u0"]) <= TOL_GRAD
     assert rel_max(b["g_ghost_r"][0], g["g_ghost_r"]) <= TOL_GRAD
     assert rel_max(b["g_ghost_u"][0], g["g_ghost_u"]) <= TOL_GRAD
 
@@ -144,7 +149,7 @@ def itscp_tables(g):
     return MacroNetworkTables(tab[:, 3].astype(int), tab[:, 2], g["edges"], kinds, inter, g["macro_route"], g["schedule"]), m
 
 
-@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2"])
+@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "macro_half", "macro_long"])
 def test_itscp_macro_network(oracle, golden_dir, name):
     g = load(golden_dir, "itscp_%s.npz" % name)
     t, m = itscp_tables(g)
@@ -152,8 +157,9 @@ def test_itscp_macro_network(oracle, golden_dir, name):
                          1.0 / m["simulation_frequency"], m["speed_limit"], m["static_speed"], m["vehicle_length"])
     assert o["rc"] == 0
     assert rel_max(o["queue"].T, g["queue"]) <= TOL_STATE
+    assert rel_elem(o["queue"].T, g["queue"]) <= 10 * TOL_STATE        # a queue term is (sum of sigmoids)^2 dt: twice the state's relative error and the sigmoids' slope
     assert abs(o["reward"] - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
-    assert rel_max(o["g_action"], g["g_action"]) <= TOL_GRAD
+    assert grad_report("G8 %s d reward / d action" % name, o["g_action"], g["g_action"]) <= TOL_GRAD
 
 
 def itscp_hybrid_tables(g):

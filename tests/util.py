@@ -9,6 +9,27 @@ def rel_max(a, ref):
     return float(np.max(np.abs(a - ref)) / max(float(np.max(np.abs(ref))), 1e-30))
 
 
+def rel_elem(a, ref, floor=1e-6):
+    """Element-wise relative error max_i |a_i - ref_i| / max(|ref_i|, floor * max|ref|): the north_star's "state <= 1e-5
+    relative" read entry by entry, with an absolute floor so that entries that are (nearly) zero do not divide by zero."""
+    a, ref = np.asarray(a, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    scale = max(float(np.max(np.abs(ref))), 1e-30)
+    return float(np.max(np.abs(a - ref) / np.maximum(np.abs(ref), floor * scale)))
+
+
+def grad_report(tag, a, ref):
+    """Print the per-entry gradient error percentiles (norm-relative and element-wise) so that the gap between the two
+    criteria is visible in every test log; returns the norm-relative maximum."""
+    a, ref = np.asarray(a, dtype=np.float64).ravel(), np.asarray(ref, dtype=np.float64).ravel()
+    scale = max(float(np.max(np.abs(ref))), 1e-30)
+    e_norm = np.abs(a - ref) / scale
+    e_elem = np.abs(a - ref) / np.maximum(np.abs(ref), 1e-6 * scale)
+    q = (50, 90, 99, 100)
+    print("%s: |dg| / max|g| p50/p90/p99/max = %s ; element-wise = %s" % (
+        tag, " ".join("%.1e" % np.percentile(e_norm, x) for x in q), " ".join("%.1e" % np.percentile(e_elem, x) for x in q)))
+    return float(e_norm.max())
+
+
 def ulp_diff(a, b):
     """Distance in float32 units-in-the-last-place, elementwise (signed-magnitude ordering)."""
     a = np.ascontiguousarray(a, dtype=np.float32).view(np.int32).astype(np.int64)

@@ -662,8 +662,22 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
     action = th.tensor(a0, requires_grad=True)
     t0 = time.time()
     env.queue_length.clear()
-    with SolverMargins() as margins:
-        env._simulate(action, True)
+    # micro mode: source lanes admit a waiting vehicle when np.random.random() < inflow (_simulator.py:153-174): the draws
+    # are host randomness, captured in call order like the routes
+    rand_draws = []
+    orig_random = np.random.random
+
+    def logged_random(*a, **kw):
+        v = orig_random(*a, **kw)
+        rand_draws.append(float(np.asarray(v).reshape(-1)[0]))
+        return v
+    waiting_routes = {int(l): [list(r.route) for r in rs] for l, rs in sim.lane_waiting_micro_route.items()}
+    np.random.random = logged_random
+    try:
+        with SolverMargins() as margins:
+            env._simulate(action, True)
+    finally:
+        np.random.random = orig_random
     print("G8 %s: solver margins %s" % (name, margins.as_meta()))
     queue = np.array([[float(x) for x in env.queue_length[k]] for k in keys], dtype=np.float64)   # [lanes][T]
     reward = env._reward(action)
@@ -717,6 +731,8 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
         action=a0, reward=np.float64(float(reward)), g_action=action.grad.numpy(), queue=queue,
         g_action_macro_lanes=parts["macro"], g_action_micro_lanes=parts["micro"],
         g_action_cut_steps=np.array(cuts, dtype=np.int32), g_action_cut=np.array(g_cut, dtype=np.float32),
+        rand_draws=np.array(rand_draws, dtype=np.float64),
+        waiting_routes=np.array(json.dumps(waiting_routes)),
         g_lane_late_ids=np.array(sorted(g_lane_late), dtype=np.int32),
         g_lane_late=np.array([g_lane_late[i] for i in sorted(g_lane_late)], dtype=np.float32).reshape(len(g_lane_late), len(a0)),
         meta=meta(seed=seed, mode=mode, num_intersection=n_int, num_lane=n_lane, lane_length=lane_length,
@@ -784,8 +800,18 @@ def main():
                 os.environ["DHTS_FINE_CUTS"] = "150,300,450,540"
                 os.environ.pop("DHTS_LANE_LATE", None)
                 gen_itscp(nm, "hybrid", 3, 1, 5.0, 20, 4, seed=sd, action_kind=kind, problem=prob)
+        if "micro" in which:             # run_itscp_micro.sh's flags (plain autodiff MicroLane everywhere, stochastic source lanes)
+            os.environ["DHTS_FINE_CUTS"] = "150"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("micro", "micro", 1, 3, 30.0, 10, 2, seed=13, action_kind="rand")
+        if "micro_small" in which:       # one lane per approach, 4 s
+            os.environ["DHTS_FINE_CUTS"] = "60"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("micro_small", "micro", 1, 1, 30.0, 4, 2, seed=3, action_kind="rand")
         if "macro_half" in which:        # run_itscp_macro.sh's episode at action 0.5
             gen_itscp("macro_half", "macro", 1, 3, 30.0, 10, 2, seed=8, action_kind="half")
+        if "macro_long" in which:        # the same network for 15 s: 236 cells x 450 steps = 106 200 loss samples > the
+            gen_itscp("macro_long", "macro", 1, 3, 30.0, 15, 3, seed=19, action_kind="rand", problem=2)   # RunningMean window of 100 000
         if "hybrid_short" in which:      # 8 s: enough for the first vehicles to cross the interior intersection
             gen_itscp("hybrid_short", "hybrid", 3, 1, 5.0, 8, 2, seed=9, action_kind="rand")
 
