@@ -36,9 +36,9 @@ def main():
                 continue
             for r in rows(d):
                 name = r["Kernel_Name"]
-                if "rollout_fwd_kernel" in name:
+                if "rollout_fwd" in name:
                     k = "rollout_fwd"
-                elif "rollout_bwd_kernel" in name:
+                elif "rollout_bwd" in name:
                     k = "rollout_bwd"
                 else:
                     continue
