@@ -326,24 +326,20 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
                     tp[Nq + ic] = zero4;
                 }
             }
-            const bool push = vc & !triv;
-            const unsigned long long m = __ballot(push);
-            if (m) {
-                int slot = 0;
-                if (t == 0) slot = atomicAdd(cnt, __popcll(m));
-                slot = __builtin_amdgcn_readfirstlane(slot);
-                if (push) Q[slot + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = i;
-            }
+            // append to the lane's queue: the compiler turns the per-lane atomic into ONE LDS atomic per wavefront (add of the
+            // number of active lanes) and hands every lane the old value plus its rank among the active ones
+            if (vc & !triv) Q[atomicAdd(cnt, 1)] = i;
         }
         if (!solve) break;
         lds_only_barrier();
         // ---- phase 2: the queued interfaces ----
-        const int qn = *cnt;
         int k0 = tid - (rot << 6);
         if (k0 < 0) k0 += ncell;
+        const unsigned i_q = (unsigned)Q[k0 <= N ? k0 : 0];  // read beside the count, not behind it (one LDS round trip less)
+        const int qn = *cnt;
         if (k0 < qn) __builtin_amdgcn_s_setprio(3);          // the workgroup's critical path
         for (int k = k0; k < qn; k += ncell) {
-            const unsigned i = (unsigned)Q[k];
+            const unsigned i = (k == k0) ? i_q : (unsigned)Q[k];
             const CellRec *lf = CR + i, *rt = CR + i + 1;
             const float4 ls = lf->st, rs = rt->st;
             const double2 lsh = lf->sh, lq0 = lf->q0, rsh = rt->sh;
