@@ -77,10 +77,12 @@ __device__ __forceinline__ void idm_step_ieee(double p, double v, double dp_raw,
 
 // ---- production version -------------------------------------------------------------------------------------
 // Per-vehicle constants evaluated once per rollout (IEEE operations), so that the time loop has no division by a
-// constant and no square root: 1 / (2 sqrt(a_max a_pref)), 1 / v_target, 1 / v_target^4.
+// constant and no square root: 1 / (2 sqrt(a_max a_pref)), 1 / v_target, 1 / v_target^4, and the products of the
+// step size with a_max that the Jacobian entries start with.
 struct IdmDerived {
     double a_max, min_space, time_pref, length;
     double inv_2sab, inv_vt, inv_vt4;
+    double dt_a, m2_dt_a;           // dt a_max, -2 dt a_max   (set by idm_set_dt)
 };
 __device__ __forceinline__ IdmDerived idm_derive(const IdmParams &m) {
     IdmDerived d;
@@ -89,53 +91,62 @@ __device__ __forceinline__ IdmDerived idm_derive(const IdmParams &m) {
     d.inv_vt = 1.0 / m.v_target;
     const double vt2 = m.v_target * m.v_target;
     d.inv_vt4 = 1.0 / (vt2 * vt2);
+    d.dt_a = 0.; d.m2_dt_a = 0.;
     return d;
 }
+__device__ __forceinline__ void idm_set_dt(IdmDerived &d, double dt) { d.dt_a = dt * d.a_max; d.m2_dt_a = -2.0 * d.dt_a; }
+
 // Same formulas and clip logic as idm_step_ieee; the only division left is ONE reciprocal of the gap.  Results differ
 // from the reference-order version by a few double ulps (< 1e-8 of a float32 ulp before the float32 stores).
+// Every vector instruction costs the same ~4 cycles on this chip whatever its type, so the step is written for
+// instruction COUNT: constant factors folded per vehicle, the rare cases (collision, gap below 1e-5) behind wave-uniform
+// branches instead of per-lane selects, and no separate formulas under the spacing clip -- with s* clipped to 0 the
+// general Jacobian entries reduce to the clipped ones exactly (every s* term is a product with 0).  The three max() are
+// v_max_f64 (a NaN operand yields the other one, where Python's max(x, c) keeps a NaN x): a NaN state stays NaN through
+// p' = p + dt v and v' = v + dt acc all the same.
 __device__ __forceinline__ void idm_step(double p, double v, double dp_raw, double dv_raw, const IdmDerived &m,
                                          double dt, double inv_dt, IdmStep &o) {
-#pragma clang fp contract(fast)
     double dp = dp_raw, dv = dv_raw;
     o.collided = dp < 0;
-    if (o.collided) { dp = 0; dv = 0; }
-    const double dpc = (1e-5 > dp) ? 1e-5 : dp;
+    if (__builtin_amdgcn_ballot_w64(o.collided)) {          // :151-160 "Set deltas to 0" -- rare: wave-uniform branch
+        if (o.collided) { dp = 0; dv = 0; }
+    }
+    const double dpc = fmax(dp, 1e-5);                      // :166 max(position_delta, POSITION_DELTA_EPS)
     const double rdp = fast_rcp(dpc);
 
-    double s = (m.min_space + v * m.time_pref + ((v * dv) * m.inv_2sab));
+    double s = __builtin_fma(v * dv, m.inv_2sab, __builtin_fma(v, m.time_pref, m.min_space));
     const bool clipped_s = (s < 0.0);
-    s = (0. > s) ? 0. : s;
+    s = fmax(s, 0.);
     const double vr = v * m.inv_vt;
     const double vr2 = vr * vr;
     const double sr = s * rdp;
-    double acc = m.a_max * (1.0 - vr2 * vr2 - sr * sr);
+    double acc = m.a_max * __builtin_fma(-sr, sr, __builtin_fma(-vr2, vr2, 1.0));
     const double floor_acc = -v * inv_dt;
     const bool clipped_a = (acc < floor_acc);
-    acc = (floor_acc > acc) ? floor_acc : acc;
+    acc = fmax(acc, floor_acc);
 
-    o.np = (float)(p + dt * v);
-    o.nv = (float)(v + dt * acc);
+    o.np = (float)__builtin_fma(dt, v, p);
+    o.nv = (float)(v + dt * acc);          // not fused: under the acceleration clip dt * (-v / dt) rounds back to -v and the vehicle stops at exactly 0
     o.acc = acc; o.sstar = s; o.clipped_acc = clipped_a; o.clipped_spacing = clipped_s;
 
-    o.dE[0] = 1.f; o.dE[1] = (float)dt; o.dE[2] = 0.f; o.dE[3] = 0.f;
-    o.dLd[0] = o.dLd[1] = o.dLd[2] = o.dLd[3] = 0.f;
-    if (!clipped_a) {
-        // the Jacobians use the UN-clamped gap (dmicro_lane.py:97); it equals the clamped one unless gap < 1e-5
-        const double rdr = (dp_raw >= 1e-5) ? rdp : 1.0 / dp_raw;
-        const double rdr2 = rdr * rdr;
-        const double s2_dp3 = (s * s) * (rdr2 * rdr);
-        const double free_term = -4.0 * ((v * v * v) * m.inv_vt4);
-        const double s_dp2 = s * rdr2;
-        o.dE[2] = (float)(dt * (-2 * m.a_max * s2_dp3));
-        o.dLd[2] = (float)(dt * (2 * m.a_max * s2_dp3));
-        if (clipped_s) {
-            o.dE[3] = (float)(1 + dt * m.a_max * free_term);
-            o.dLd[3] = (float)(dt * m.a_max * (-2 * s_dp2));
-        } else {
-            o.dE[3] = (float)(1 + dt * m.a_max * (free_term - 2 * s_dp2 * (m.time_pref + ((v + dv_raw) * m.inv_2sab))));
-            o.dLd[3] = (float)(dt * m.a_max * (-2 * s_dp2 * (-v * m.inv_2sab)));
-        }
+    // the Jacobians use the UN-clamped gap (dmicro_lane.py:97); it equals the clamped one unless gap < 1e-5
+    double rdr = rdp;
+    if (__builtin_amdgcn_ballot_w64(!(dp_raw >= 1e-5))) {   // rare: wave-uniform branch around the IEEE division
+        if (!(dp_raw >= 1e-5)) rdr = 1.0 / dp_raw;
     }
+    const double rdr2 = rdr * rdr;
+    const double s_dp2 = s * rdr2;
+    const double e2 = m.m2_dt_a * ((s_dp2 * s) * rdr);                    // dt (-2 a s^2 / gap^3)
+    const double free4 = -4.0 * ((v * v * v) * m.inv_vt4);
+    const double tl = __builtin_fma(v + dv_raw, m.inv_2sab, m.time_pref); // T + (v + dv) / (2 sqrt(ab))
+    const double e3 = __builtin_fma(m.dt_a, __builtin_fma(-2.0 * s_dp2, tl, free4), 1.0);
+    const double l3 = (m.m2_dt_a * s_dp2) * (-v * m.inv_2sab);
+    o.dE[0] = 1.f; o.dE[1] = (float)dt;
+    o.dE[2] = clipped_a ? 0.f : (float)e2;
+    o.dE[3] = clipped_a ? 0.f : (float)e3;
+    o.dLd[0] = o.dLd[1] = 0.f;
+    o.dLd[2] = -o.dE[2];
+    o.dLd[3] = clipped_a ? 0.f : (float)l3;
 }
 
 }  // namespace dhts

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(64 * kW) void micro_rollout_fwd_kernel(
         raw.time_pref = params[4 * plane + base + ic];
         raw.length = params[5 * plane + base + ic];
         prm[j] = idm_derive(raw);
+        idm_set_dt(prm[j], dt);
         len_lead[j] = params[5 * plane + base + il];
     }
     for (int k = t; k < V; k += kStride) { Sp[k] = p_in[base + k]; Sv[k] = v_in[base + k]; }
@@ -143,7 +144,7 @@ __global__ void idm_batch_kernel(int64_t n, int variant, const double *__restric
         IdmStep o;
         const double dt = in[8 * n + i];
         if (variant == 1) idm_step_ieee(0.0, in[2 * n + i], in[4 * n + i], in[5 * n + i], m, dt, o);
-        else idm_step(0.0, in[2 * n + i], in[4 * n + i], in[5 * n + i], idm_derive(m), dt, 1.0 / dt, o);
+        else { IdmDerived dm = idm_derive(m); idm_set_dt(dm, dt); idm_step(0.0, in[2 * n + i], in[4 * n + i], in[5 * n + i], dm, dt, 1.0 / dt, o); }
         next_pv[i] = o.np; next_pv[n + i] = o.nv;
         collided[i] = o.collided ? 1 : 0;
         acc_s[i] = o.acc; acc_s[n + i] = o.sstar;
