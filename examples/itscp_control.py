@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--n_replica", type=int, default=1,
                     help="> 1: optimise that many random initial schedules of the same problem at once (one workgroup each in the "
                          "fused kernels) and report the best")
+    ap.add_argument("--graph", action="store_true",
+                    help="with --n_replica > 1: capture one whole iteration (both fused launches, Adam step, clamp, log) in a HIP "
+                         "graph and replay it -- nothing is read back inside an iteration (check_faults=False)")
     args = ap.parse_args()
     assert th.cuda.is_available(), "needs a GPU (no CPU fallback)"
     dev = th.device("cuda")
@@ -88,20 +91,60 @@ def batch(args, env, dev):
                 1.0 / env.config["simulation_frequency"], args.speed_limit)
     gen = th.Generator(device="cpu").manual_seed(args.seed)
     action = (0.1 + 0.8 * th.rand(args.n_replica, env.action_size(), generator=gen)).to(dev).requires_grad_(True)
-    opt = th.optim.Adam([action], lr=args.lr)
-    t0 = time.time()
-    for ep in range(args.n_episode):
-        opt.zero_grad()
+    opt = th.optim.Adam([action], lr=args.lr, capturable=args.graph)
+    action.grad = th.zeros_like(action)
+
+    def iteration():
         reward, _, _, _ = ops.net_hybrid_rollout(action, dev_tab, *sim_args, check_faults=False)
+        opt.zero_grad(set_to_none=False)
         (-reward.sum()).backward()
         action.grad.nan_to_num_(0.0, 0.0, 0.0)       # a replica whose reverse sweep hit 0 * inf sits this episode out
         opt.step()
         with th.no_grad():
             action.clamp_(0.0, 1.0)
+        r = reward.detach()
+        return th.stack([r.max(), r.mean(), r.min()])
+
+    def report(ep, stats, t0):
+        print("episode %4d  reward best %.6f  mean %.6f  worst %.6f  (%.2f ms / episode of %d replicas)" % (
+            ep, stats[0], stats[1], stats[2], 1e3 * (time.time() - t0) / (ep + 1), args.n_replica))
+
+    if args.graph:
+        log = th.zeros(args.n_episode + 4, 3, device=dev)
+        slot = th.zeros(1, dtype=th.long, device=dev)
+        keep = action.detach().clone()
+        side = th.cuda.Stream()
+        side.wait_stream(th.cuda.current_stream())
+        with th.cuda.stream(side):                       # warm-up outside the capture (allocator, Adam state)
+            for _ in range(3):
+                iteration()
+        th.cuda.current_stream().wait_stream(side)
+        with th.no_grad():                               # the warm-up iterations do not count
+            action.copy_(keep)
+            for st in opt.state.values():
+                for v_ in st.values():
+                    if isinstance(v_, th.Tensor):
+                        v_.zero_()
+        graph = th.cuda.CUDAGraph()
+        with th.cuda.graph(graph):
+            stats = iteration()
+            log.index_copy_(0, slot, stats.reshape(1, 3))
+            slot.add_(1)
+        th.cuda.synchronize()
+        t0 = time.time()
+        for ep in range(args.n_episode):
+            graph.replay()
+        th.cuda.synchronize()
+        rows = log[:args.n_episode].tolist()
+        for ep in list(range(0, args.n_episode, 10)) + [args.n_episode - 1]:
+            print("episode %4d  reward best %.6f  mean %.6f  worst %.6f" % (ep, rows[ep][0], rows[ep][1], rows[ep][2]))
+        print("%.2f ms / episode of %d replicas (HIP graph replay)" % (1e3 * (time.time() - t0) / args.n_episode, args.n_replica))
+        return
+    t0 = time.time()
+    for ep in range(args.n_episode):
+        stats = iteration()
         if ep % 10 == 0 or ep == args.n_episode - 1:
-            r = reward.detach()
-            print("episode %4d  reward best %.6f  mean %.6f  worst %.6f  (%.1f ms / episode of %d replicas)" % (
-                ep, float(r.max()), float(r.mean()), float(r.min()), 1e3 * (time.time() - t0) / (ep + 1), args.n_replica))
+            report(ep, stats.tolist(), t0)
 
 
 if __name__ == "__main__":

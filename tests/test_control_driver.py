@@ -119,3 +119,24 @@ def test_trainer_hybrid_episode_gradient(cuda):
     grads = [p.grad for p in tr.controller.parameters()]
     assert all(g is not None and th.isfinite(g).all() and float(g.abs().max()) > 0 for g in grads)
     assert any(not th.equal(b, p.detach()) for b, p in zip(before, tr.controller.parameters()))
+
+
+@pytest.mark.gpu
+def test_itscp_control_graph_replay_matches_eager(cuda):
+    """examples/itscp_control.py --graph: a whole optimiser iteration of a replica batch (both fused launches, Adam, clamp)
+    captured in a HIP graph -- possible because check_faults=False reads nothing back -- gives the rewards of the eager loop."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    base = [sys.executable, os.path.join(ROOT, "examples", "itscp_control.py"), "--mode", "hybrid", "--n_intersection", "3",
+            "--lane_length", "5", "--simulation_length", "6", "--signal_length", "2", "--n_episode", "11", "--n_replica", "6",
+            "--seed", "4"]
+    outs = []
+    for extra in ([], ["--graph"]):
+        p = subprocess.run(base + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-2000:]
+        rows = [[float(x) for x in re.findall(r"(?:best|mean|worst) (-?\d+\.\d+)", l)] for l in p.stdout.splitlines() if l.startswith("episode")]
+        outs.append(np.array([r for r in rows if len(r) == 3]))
+    assert outs[0].shape == outs[1].shape and outs[0].shape[0] >= 2
+    assert np.allclose(outs[0], outs[1], rtol=1e-5, atol=1e-6)
+    assert outs[0][-1, 1] > outs[0][0, 1]          # the mean reward improved

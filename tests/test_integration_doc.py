@@ -1,0 +1,86 @@
+"""INTEGRATION.md's marked code blocks are executed as written, so the document cannot drift from the code (VERDICT r1:
+its macro-network snippet had the wrong signature).  A block is marked by `<!-- snippet: NAME -->` in front of its fence."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import PKG, ROOT
+
+
+def snippets():
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    out = {}
+    for m in re.finditer(r"<!-- snippet: (\w+) -->\s*```python\n(.*?)```", text, re.S):
+        out[m.group(1)] = m.group(2)
+    return out
+
+
+def test_every_marked_snippet_is_known():
+    assert set(snippets()) == {"binding", "rollouts", "net_macro", "net_hybrid"}
+
+
+def test_binding_snippet_loads_the_library():
+    """The ctypes stub of section 2 against the built library (no GPU call: signatures and symbols only)."""
+    code = snippets()["binding"].replace("/path/to/libdhts.so", os.path.join(PKG, "csrc", "libdhts.so"))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md:binding", "exec"), ns)
+    d = ns["MacroDesc"](1, 100, 0.01, 5.0, 30.0)
+    import ctypes as C
+    assert ns["_lib"].dhts_macro_step_tape_bytes(C.byref(d)) == 3 * 128 * 16
+
+
+def _itscp_env(mode, **cfg):
+    from example.control.itscp._env import ItscpEnv
+    from example.control.itscp.problem import problem_1
+    np.random.seed(3)
+    env = ItscpEnv()
+    env.schedule_callback = problem_1
+    for k, v in dict(mode=mode, speed_limit=60.0, **cfg).items():
+        env.config[k] = v
+    env.reset()
+    return env
+
+
+@pytest.mark.gpu
+def test_rollout_snippet(cuda):
+    import torch
+    L, N, V, T = 3, 40, 12, 15
+    g = torch.Generator().manual_seed(1)
+    ns = dict(r0=(0.1 + 0.8 * torch.rand(L, N, generator=g)).to(cuda).requires_grad_(True),
+              u0=(30 * torch.rand(L, N, generator=g)).to(cuda).requires_grad_(True),
+              ghost_r=torch.rand(L, 2, generator=g).to(cuda).requires_grad_(True),
+              ghost_u=(30 * torch.rand(L, 2, generator=g)).to(cuda).requires_grad_(True),
+              r_target=torch.zeros(L, N, device=cuda), u_target=torch.zeros(L, N, device=cuda),
+              T=T, dt=0.01, dx=5.0, u_max=30.0,
+              p0=(torch.arange(V)[None, :] * 20.0 + 5 * torch.rand(L, V, generator=g)).to(cuda).requires_grad_(True),
+              v0=(10 + 5 * torch.rand(L, V, generator=g)).to(cuda).requires_grad_(True),
+              params=torch.tensor([30.0, 24.0, 27.0, 0.5, 0.1, 5.0], dtype=torch.float64, device=cuda)[:, None, None].expand(6, L, V).contiguous(),
+              head=torch.tensor([[1000.0, 0.0]] * L, dtype=torch.float64, device=cuda))
+    code = snippets()["rollouts"].replace('sys.path.insert(0, "diff-hybrid-traffic-sim_amd")', "pass")
+    exec(compile(code, "INTEGRATION.md:rollouts", "exec"), ns)
+    assert ns["r0"].grad is not None and torch.isfinite(ns["r0"].grad).all() and ns["ghost_u"].grad is not None
+    assert ns["pT"].shape == (L, V) and torch.isfinite(ns["vT"]).all()
+
+
+@pytest.mark.gpu
+def test_net_macro_snippet(cuda):
+    import torch
+    env = _itscp_env("macro", num_intersection=1, lane_length=10.0, num_lane=1, policy_length=2, signal_length=1)
+    action = (0.1 + 0.8 * torch.rand(4, env.action_size())).to(cuda).requires_grad_(True)
+    ns = dict(env=env, action=action)
+    exec(compile(snippets()["net_macro"], "INTEGRATION.md:net_macro", "exec"), ns)
+    assert ns["reward"].shape == (4,) and action.grad is not None and torch.isfinite(action.grad).all()
+    assert ns["queue"].shape == (4, env.num_timestep, ns["tab"].n_lanes)
+
+
+@pytest.mark.gpu
+def test_net_hybrid_snippet(cuda):
+    import torch
+    env = _itscp_env("hybrid", num_intersection=3, lane_length=5.0, num_lane=1, policy_length=4, signal_length=2)
+    action = (0.1 + 0.8 * torch.rand(2, env.action_size())).to(cuda).requires_grad_(True)
+    ns = dict(env=env, action=action)
+    exec(compile(snippets()["net_hybrid"], "INTEGRATION.md:net_hybrid", "exec"), ns)
+    assert ns["reward"].shape == (2,) and action.grad is not None and torch.isfinite(action.grad).all()
+    assert ns["counts"].shape == (2, 4)
