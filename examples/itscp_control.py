@@ -136,7 +136,7 @@ def batch(args, env, dev):
             graph.replay()
         th.cuda.synchronize()
         rows = log[:args.n_episode].tolist()
-        for ep in list(range(0, args.n_episode, 10)) + [args.n_episode - 1]:
+        for ep in sorted(set(list(range(0, args.n_episode, 10)) + [args.n_episode - 1])):
             print("episode %4d  reward best %.6f  mean %.6f  worst %.6f" % (ep, rows[ep][0], rows[ep][1], rows[ep][2]))
         print("%.2f ms / episode of %d replicas (HIP graph replay)" % (1e3 * (time.time() - t0) / args.n_episode, args.n_replica))
         return
