@@ -335,7 +335,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     __syncthreads();
     (void)NI;
     // ---- per-thread roles
-    const bool is_if = tid < NIm, is_cell = tid < C, is_ghost = tid < 2 * L, is_lane = tid < L;
+    // ghost threads: the upstream ghosts of all lanes first, the downstream ones from the next wavefront boundary on, so that a
+    // wavefront runs ONE of the two (quite different) blends instead of both under divergence
+    const int g_base1 = (((L + 63) & ~63) + L <= B) ? ((L + 63) & ~63) : L;
+    const bool is_if = tid < NIm, is_cell = tid < C, is_ghost = tid < L || (tid >= g_base1 && tid < g_base1 + L), is_lane = tid < L;
     int i_lane = 0, i_k = 0, i_n = 0, i_off = 0, i_mb = 0;
     IfaceConst kconst;
     kconst.set_um(um_d); kconst.set_grid(dt, 1.0);
@@ -350,7 +353,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         i_k = tid - i_off - i_mb;
         kconst.set_grid(dt, tb.net.lane_dx[i_lane]);
     }
-    const int g_lane = tid >> 1, g_side = tid & 1;
+    const int g_side = tid >= g_base1 ? 1 : 0, g_lane = is_ghost ? (g_side ? tid - g_base1 : tid) : 0;
     int g_kind = 0, g_inter = 0; bool g_macro = false;
     float own_r = 0.f, own_u = um;
     if (is_ghost) { g_kind = tb.net.sig_kind[g_lane]; g_inter = tb.net.inter[g_lane]; g_macro = tb.lane_macro[g_lane] != 0; }
@@ -621,7 +624,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 glue_from_r_u(fr, fu, um, fy, fq);
                 own_r = fr; own_u = fu;
             }
-            float *g = G + (size_t)tid * 4;
+            float *g = G + (size_t)(2 * g_lane + g_side) * 4;
             g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
         }
         if (t > 0) loss_scan(cur, t - 1);
@@ -1048,7 +1051,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     const float4 *grw = reinterpret_cast<const float4 *>(wsr + ws.rec_w);
     const float gscale = g_reward ? g_reward[rep] : 1.f;
     const int loss_steps = tb.loss_steps > 0 ? tb.loss_steps : T;
-    const bool is_cell = tid < C, is_ghost = tid < 2 * L, is_lane = tid < L;
+    const int g_base1 = (((L + 63) & ~63) + L <= B) ? ((L + 63) & ~63) : L;      // ghost threads by side, as in the forward kernel
+    const bool is_cell = tid < C, is_ghost = tid < L || (tid >= g_base1 && tid < g_base1 + L), is_lane = tid < L;
     const bool in_mw = tid >= B - 64, is_mt = (tid == B - 64);
     const int mw_lane = tid - (B - 64);
     const int n_adj = 3 * V + kMaxCaps + kMaxLocals;
@@ -1080,7 +1084,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         c_lane = cell_lane_s[tid]; c_first = tb.net.lane_off[c_lane]; c_last = c_first + tb.net.lane_ncell[c_lane] - 1;
         c_dxv = (float)tb.net.lane_dx[c_lane] / vlen;
     }
-    const int g_lane = tid >> 1, g_side = tid & 1;
+    const int g_side = tid >= g_base1 ? 1 : 0, g_lane = is_ghost ? (g_side ? tid - g_base1 : tid) : 0;
     int g_kind = 0, g_inter = 0, g_off = 0, g_n = 0; bool g_macro = false;
     if (is_ghost) {
         g_kind = tb.net.sig_kind[g_lane]; g_inter = tb.net.inter[g_lane]; g_off = tb.net.lane_off[g_lane]; g_n = tb.net.lane_ncell[g_lane];
@@ -1419,7 +1423,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
                 for (int i = 0; i < kMaxCand; ++i)
                     if (cand_src[i] == src) { box[3 * cand_pos[i]] = add_r; box[3 * cand_pos[i] + 1] = 0.f; box[3 * cand_pos[i] + 2] = add_u; }
             }
-            aval[tid] = a_val;
+            aval[2 * g_lane + g_side] = a_val;          // the intersections sum their ghosts in (lane, side) order
         }
         if (in_mw) {
             if (seg_n[0] > 0) for (int q = 0; q < 5; ++q) obi[mw_lane * 5 + q] = -1;
