@@ -395,7 +395,60 @@ __global__ void macro_rollout_bwd_kernel(
 
     double ghl_r = 0., ghl_y = 0., ghr_r = 0., ghr_y = 0.;   // ghost cotangent sums (thread 0 / thread of cell N-1)
     int bad_step = -1, bad_cell = 0;     // first non-finite cotangent this thread meets (the reverse sweep's first = the latest step)
-    for (int step = T - 1; step >= 0; --step) {
+    int step_hi = T - 1;
+    if constexpr (kIface) {
+        if (N <= B && g_hist == nullptr) {
+            // One cell per thread (the rollouts' common shape): the four interface products of the NEXT step to replay are
+            // loaded while this step computes (unconditional loads, clamped step index), and the two barriers of a step wait
+            // for LDS only, so the loads stay in flight across them -- the tape stream is what bounds this kernel.
+            const int k = t;
+            const bool vk = k < N;
+            const int kl = vk ? k : 0;
+            const float4 *tp0 = tape + (size_t)lane * tape_row + kl;
+            const size_t step_stride = (size_t)L * tape_row;
+            float4 n_aL, n_bL, n_aR, n_bR;
+            {
+                const float4 *tp = tp0 + (size_t)(T > 0 ? T - 1 : 0) * step_stride;
+                n_aL = tp[0]; n_bL = tp[Nq]; n_aR = tp[1]; n_bR = tp[Nq + 1];
+            }
+            for (int step = T - 1; step >= 0; --step) {
+                const float4 aL = n_aL, bL = n_bL, aR = n_aR, bR = n_bR;
+                {
+                    const float4 *tp = tp0 + (size_t)(step > 0 ? step - 1 : 0) * step_stride;
+                    n_aL = tp[0]; n_bL = tp[Nq]; n_aR = tp[1]; n_bR = tp[Nq + 1];
+                }
+                if (vk) {
+                    float4 d0, d1, d2;
+                    d0.x = ncf * (-aL.x); d0.y = ncf * (-aL.y); d0.z = ncf * (-aL.z); d0.w = ncf * (-aL.w);
+                    d2.x = ncf * bR.x; d2.y = ncf * bR.y; d2.z = ncf * bR.z; d2.w = ncf * bR.w;
+                    d1.x = 1.f - cf * (aR.x - bL.x); d1.y = 0.f - cf * (aR.y - bL.y);
+                    d1.z = 0.f - cf * (aR.z - bL.z); d1.w = 1.f - cf * (aR.w - bL.w);
+                    const float gr = Gr[k + 1], gy = Gy[k + 1];
+                    const float c0r = dot2(d0.x, gr, d0.z, gy), c0y = dot2(d0.y, gr, d0.w, gy);
+                    const float c1r = dot2(d1.x, gr, d1.z, gy), c1y = dot2(d1.y, gr, d1.w, gy);
+                    const float c2r = dot2(d2.x, gr, d2.z, gy), c2y = dot2(d2.y, gr, d2.w, gy);
+                    C0r[k] = c0r; C0y[k] = c0y;
+                    C2r[k + 2] = c2r; C2y[k + 2] = c2y;
+                    Gr[k + 1] = c1r; Gy[k + 1] = c1y;
+                    if (k == 0) { ghl_r += (double)c0r; ghl_y += (double)c0y; }
+                    if (k == N - 1) { ghr_r += (double)c2r; ghr_y += (double)c2y; }
+                }
+                lds_only_barrier();
+                if (vk) {
+                    const float c2lr = (k > 0) ? C2r[k + 1] : 0.f, c2ly = (k > 0) ? C2y[k + 1] : 0.f;
+                    const float c0rr = (k < N - 1) ? C0r[k + 1] : 0.f, c0ry = (k < N - 1) ? C0y[k + 1] : 0.f;
+                    const float nr = (Gr[k + 1] + c2lr) + c0rr;
+                    const float ny = (Gy[k + 1] + c2ly) + c0ry;
+                    Gr[k + 1] = nr; Gy[k + 1] = ny;
+                    if (bad_step < 0 && !(isfinite(nr) && isfinite(ny))) { bad_step = step; bad_cell = k; }
+                }
+                lds_only_barrier();
+            }
+            step_hi = -1;            // nothing left for the general loop
+            __syncthreads();
+        }
+    }
+    for (int step = step_hi; step >= 0; --step) {
         const float4 *tp = tape + ((size_t)step * L + lane) * tape_row;
         const float *gh = g_hist ? g_hist + ((size_t)step * L + lane) * 2 * N : nullptr;
         for (int k = t; k < N; k += B) {

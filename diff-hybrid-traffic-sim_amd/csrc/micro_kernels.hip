@@ -175,7 +175,52 @@ __global__ void micro_rollout_bwd_kernel(
     __syncthreads();
 
     double gh_p = 0., gh_v = 0.;       // held by the thread that owns the head vehicle
-    for (int step = T - 1; step >= 0; --step) {
+    int step_hi = T - 1;
+    if constexpr (kCompact) {
+        if (V <= B && g_hist == nullptr) {
+            // One vehicle per thread (the rollouts' common shape): the tape entry of the NEXT step to replay is loaded while
+            // this step computes (unconditional load, clamped step index), and the barriers wait for LDS only, so the load
+            // stays in flight across them -- the tape stream is what bounds this kernel.
+            const int k = t;
+            const bool vk = k < n;
+            const MicroTape3 *tc0 = reinterpret_cast<const MicroTape3 *>(tape) + (size_t)lane * Vp + (k < V ? k : 0);
+            const size_t step_stride = (size_t)L * Vp;
+            MicroTape3 nx = tc0[(size_t)(T > 0 ? T - 1 : 0) * step_stride];
+            const float dtf = (float)dt;
+            for (int step = T - 1; step >= 0; --step) {
+                const MicroTape3 c = nx;
+                nx = tc0[(size_t)(step > 0 ? step - 1 : 0) * step_stride];
+                if (vk) {
+                    const float gp = Gp[k], gv = Gv[k];
+                    Gp[k] = dot2(1.f, gp, c.e2, gv);           // grad_ps[:-1] = dqs[:, 0]^T g
+                    Gv[k] = dot2(dtf, gp, c.e3, gv);
+                    C1p[k + 1] = dot2(0.f, gp, -c.e2, gv);     // grad_ps[1:] += dqs[:, 1]^T g
+                    C1v[k + 1] = dot2(0.f, gp, c.l3, gv);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (vk) {
+                    float np_ = Gp[k], nv_ = Gv[k];
+                    if (k > 0) { np_ += C1p[k]; nv_ += C1v[k]; }
+                    if (k == n - 1) {
+                        const float vp = C1p[n], vv = C1v[n];
+                        if (fold) {
+                            gh_p += (double)vp;
+                            gh_v -= (double)vv;
+                            np_ += vp; nv_ += vv;
+                        } else {
+                            gh_p = (double)vp;
+                            gh_v = (double)vv;
+                        }
+                    }
+                    Gp[k] = np_; Gv[k] = nv_;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            step_hi = -1;
+            __syncthreads();
+        }
+    }
+    for (int step = step_hi; step >= 0; --step) {
         const float4 *tp = reinterpret_cast<const float4 *>(tape) + ((size_t)step * L + lane) * 2 * Vp;            // reference layout
         const MicroTape3 *tc = reinterpret_cast<const MicroTape3 *>(tape) + ((size_t)step * L + lane) * Vp;         // compact layout
         const float *gh = g_hist ? g_hist + ((size_t)step * L + lane) * 2 * V : nullptr;

@@ -309,8 +309,13 @@ int oracle_macro_step(int N, const float *r, const float *y, const float *u, con
                       int *case_out, double *speed_out, int *err_index) {
     int rc = ORACLE_OK;
     int nI = N + 1;
-    fullq *Q0 = (fullq *)malloc(sizeof(fullq) * nI);
-    int *ci = (int *)malloc(sizeof(int) * nI);
+    /* scratch on the stack for ordinary lane lengths: a malloc per lane-step serialises the OpenMP lanes of the timed CPU
+     * baseline on the allocator */
+    const int small = nI <= 2048;
+    fullq Q0_stack[small ? nI : 1];
+    int ci_stack[small ? nI : 1];
+    fullq *Q0 = small ? Q0_stack : (fullq *)malloc(sizeof(fullq) * nI);
+    int *ci = small ? ci_stack : (int *)malloc(sizeof(int) * nI);
     for (int i = 0; i < nI; i++) {                         /* _solve_riemann :116-146 */
         fullq QL = {r[i], y[i], u[i], ueq[i]};
         fullq QR = {r[i + 1], y[i + 1], u[i + 1], ueq[i + 1]};
@@ -358,15 +363,16 @@ int oracle_macro_step(int N, const float *r, const float *y, const float *u, con
             }
         }
     }
-    free(Q0);
-    free(ci);
+    if (!small) { free(Q0); free(ci); }
     return rc;
 }
 
 /* road/lane/dmacro_lane.py:277-309 */
 void oracle_macro_step_bwd(int N, const float *dqs, const float *g_nr, const float *g_ny, float *g_r, float *g_y) {
     /* grad_cell[a][k] = dqs[a][k]^T @ (g_nr[a], g_ny[a]) */
-    float *gc = (float *)malloc(sizeof(float) * (size_t)N * 6);
+    const int small = N <= 2048;
+    float gc_stack[small ? (size_t)N * 6 : 1];
+    float *gc = small ? gc_stack : (float *)malloc(sizeof(float) * (size_t)N * 6);
     for (int a = 0; a < N; a++)
         for (int k = 0; k < 3; k++) {
             const float *d = dqs + (size_t)a * 12 + k * 4;
@@ -382,7 +388,7 @@ void oracle_macro_step_bwd(int N, const float *dqs, const float *g_nr, const flo
         g[0] = gc[0 + c];                                                          /* boundaries */
         g[N + 1] = gc[(N - 1) * 6 + 4 + c];
     }
-    free(gc);
+    if (!small) free(gc);
 }
 
 /* ------------------------------------------------------------------------------------------------
