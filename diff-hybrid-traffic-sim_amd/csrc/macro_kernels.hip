@@ -406,16 +406,19 @@ __global__ void macro_rollout_bwd_kernel(
             const int kl = vk ? k : 0;
             const float4 *tp0 = tape + (size_t)lane * tape_row + kl;
             const size_t step_stride = (size_t)L * tape_row;
-            float4 n_aL, n_bL, n_aR, n_bR;
+            float4 n_aL, n_bL, n_aR, n_bR, m_aL, m_bL, m_aR, m_bR;
             {
                 const float4 *tp = tp0 + (size_t)(T > 0 ? T - 1 : 0) * step_stride;
                 n_aL = tp[0]; n_bL = tp[Nq]; n_aR = tp[1]; n_bR = tp[Nq + 1];
+                const float4 *tq = tp0 + (size_t)(T > 1 ? T - 2 : 0) * step_stride;
+                m_aL = tq[0]; m_bL = tq[Nq]; m_aR = tq[1]; m_bR = tq[Nq + 1];
             }
             for (int step = T - 1; step >= 0; --step) {
                 const float4 aL = n_aL, bL = n_bL, aR = n_aR, bR = n_bR;
+                n_aL = m_aL; n_bL = m_bL; n_aR = m_aR; n_bR = m_bR;
                 {
-                    const float4 *tp = tp0 + (size_t)(step > 0 ? step - 1 : 0) * step_stride;
-                    n_aL = tp[0]; n_bL = tp[Nq]; n_aR = tp[1]; n_bR = tp[Nq + 1];
+                    const float4 *tp = tp0 + (size_t)(step > 1 ? step - 2 : 0) * step_stride;      // two steps ahead
+                    m_aL = tp[0]; m_bL = tp[Nq]; m_aR = tp[1]; m_bR = tp[Nq + 1];
                 }
                 if (vk) {
                     float4 d0, d1, d2;

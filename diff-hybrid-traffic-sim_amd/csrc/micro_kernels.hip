@@ -186,10 +186,12 @@ __global__ void micro_rollout_bwd_kernel(
             const MicroTape3 *tc0 = reinterpret_cast<const MicroTape3 *>(tape) + (size_t)lane * Vp + (k < V ? k : 0);
             const size_t step_stride = (size_t)L * Vp;
             MicroTape3 nx = tc0[(size_t)(T > 0 ? T - 1 : 0) * step_stride];
+            MicroTape3 nx2 = tc0[(size_t)(T > 1 ? T - 2 : 0) * step_stride];
             const float dtf = (float)dt;
             for (int step = T - 1; step >= 0; --step) {
                 const MicroTape3 c = nx;
-                nx = tc0[(size_t)(step > 0 ? step - 1 : 0) * step_stride];
+                nx = nx2;
+                nx2 = tc0[(size_t)(step > 1 ? step - 2 : 0) * step_stride];       // two steps ahead
                 if (vk) {
                     const float gp = Gp[k], gv = Gv[k];
                     Gp[k] = dot2(1.f, gp, c.e2, gv);           // grad_ps[:-1] = dqs[:, 0]^T g
