@@ -109,6 +109,7 @@ __device__ __forceinline__ void idm_step(double p, double v, double dp_raw, doub
     double dp = dp_raw, dv = dv_raw;
     o.collided = dp < 0;
     if (__builtin_amdgcn_ballot_w64(o.collided)) {          // :151-160 "Set deltas to 0" -- rare: wave-uniform branch
+        asm volatile("" ::: "memory");                      // (keeps it a branch: no if-conversion into the hot path)
         if (o.collided) { dp = 0; dv = 0; }
     }
     const double dpc = fmax(dp, 1e-5);                      // :166 max(position_delta, POSITION_DELTA_EPS)
@@ -132,7 +133,8 @@ __device__ __forceinline__ void idm_step(double p, double v, double dp_raw, doub
     // the Jacobians use the UN-clamped gap (dmicro_lane.py:97); it equals the clamped one unless gap < 1e-5
     double rdr = rdp;
     if (__builtin_amdgcn_ballot_w64(!(dp_raw >= 1e-5))) {   // rare: wave-uniform branch around the IEEE division
-        if (!(dp_raw >= 1e-5)) rdr = 1.0 / dp_raw;
+        asm volatile("" ::: "memory");                      // (without it the compiler flattens the branch: 14 instructions of
+        if (!(dp_raw >= 1e-5)) rdr = 1.0 / dp_raw;          //  v_div_scale / fmas / fixup on every vehicle-step)
     }
     const double rdr2 = rdr * rdr;
     const double s_dp2 = s * rdr2;
