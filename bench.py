@@ -101,9 +101,10 @@ class MacroWorkload:
     name = "macro_straight_1024x512x1000"
     unit_bytes = MACRO_TAPE_B
     unit_name = "cell-steps/s"
-    # what each kernel actually runs into (PMC): the forward's double-precision Riemann solves keep the
-    # VALUs ~80 % busy while it writes at 3 TB/s; the reverse sweep streams the tape at 5.7 TB/s
-    limiter = {"rollout_fwd": "valu (f64 issue, ~80 % busy; HBM writes at 3 TB/s)", "rollout_bwd": "hbm (5.7 TB/s of reads)"}
+    # what each kernel actually runs into (PMC counters and s_memtime stamps)
+    limiter = {"rollout_fwd": "instruction issue in phase 1 + the serial queue pass of phase 2 (latency); HBM writes at ~3.9 TB/s, "
+                              "a store-only kernel with this pattern reaches 6.5-6.9",
+               "rollout_bwd": "hbm (reads at ~6.1 TB/s of the ~6.5 a streaming kernel reaches)"}
 
     def __init__(self, dev, rank, L, N, T):
         from dhts import ops
@@ -195,7 +196,8 @@ class MicroWorkload:
     name = "micro_idm_4096x256x1000"
     unit_bytes = MICRO_TAPE_B
     unit_name = "vehicle-steps/s"
-    limiter = {"rollout_fwd": "valu / latency (f64 IDM, ~65 % busy; HBM writes at 3.6 TB/s)", "rollout_bwd": "hbm (5.3 TB/s of reads)"}
+    limiter = {"rollout_fwd": "instruction issue (~70 vector instructions per vehicle-step at ~4 cycles each); HBM writes at ~4.4 TB/s",
+               "rollout_bwd": "hbm (reads at ~6.0 TB/s of the ~6.5 a streaming kernel reaches)"}
 
     def __init__(self, dev, rank, L, V, T):
         from dhts import ops
