@@ -130,9 +130,30 @@ class MacroWorkload:
         self.name = "macro_straight_%dx%dx%d" % (L, N, T)
         self.ev = []
 
+    def tape_census(self):
+        """What one launch moves of the tape, read off the tape's own row headers after a forward pass (include/dhts.h): the
+        trivial flux Jacobians S (12 B per cell), the used part of the header (count, cnt indices) and the cnt exception
+        entries (32 B each), each block rounded up to whole 128-byte lines -- HBM moves lines, not bytes."""
+        if getattr(self, "_census", None) is None:
+            N, rows = self.N, self.T * self.L
+            s_f4 = ((3 * N + 3) // 4 + 7) // 8 * 8
+            h_f4 = (8 + 2 * (N + 1) + 127) // 128 * 8
+            e_f4 = (2 * (N + 1) + 7) // 8 * 8
+            row = self.tape.view(rows, (s_f4 + h_f4 + e_f4) * 4)
+            cnt = row[:, s_f4 * 4].contiguous().view(torch.int32).to(torch.int64)
+            lines = lambda nbytes: (nbytes + 127) // 128 * 128
+            s_bytes = rows * lines(12 * N)
+            h_bytes = int(lines(8 + 2 * cnt).sum().item())
+            e_bytes = int(lines(32 * cnt).sum().item())
+            self._census = {"s_bytes": s_bytes, "header_bytes": h_bytes, "exception_bytes": e_bytes,
+                            "exceptions": int(cnt.sum().item()), "interfaces": rows * (N + 1)}
+        return self._census
+
     def moved_bytes_per_launch(self):
-        """the tape one launch writes (forward) / reads (reverse); state, ghosts and cotangents are O(cells), not O(cells x T)"""
-        return self.tape_bytes
+        """the tape bytes one launch writes (forward) / reads (reverse); state, ghosts and cotangents are O(cells), not
+        O(cells x T)"""
+        c = self.tape_census()
+        return c["s_bytes"] + c["header_bytes"] + c["exception_bytes"]
 
     def one_pass(self, record=False):
         ops = self.ops

@@ -50,6 +50,36 @@ __device__ __forceinline__ void raise_fault(dhts_error *err, int code, int step,
     }
 }
 
+// ---- the rollout tape -----------------------------------------------------------------------------------------------
+// What the reverse sweep needs of a step is, per interface i, A_i = flux'(Q_0) dQ_0/dQ_L and B_i = flux'(Q_0) dQ_0/dQ_R
+// (dmacro_lane.py:116-124).  For a trivial interface (Q_0 = Q_L; 85-89 % of them in BASELINE config 2) dQ_0/dQ_L = I and
+// dQ_0/dQ_R = 0: A_i is the flux Jacobian at Q_L, whose entry [0][1] is the constant 1 (darz.py:217-233), and B_i = 0 --
+// three floats instead of eight.  The other interfaces ("exceptions") keep their (A, B), compacted in the order the forward
+// solved them.  One row per (step, lane), every block on a 128-byte line:
+//   S  float [N][3]                                fp[0], fp[2], fp[3] of interface i < N where it is trivial
+//   H  u32 cnt, u32 0 | u16 idx [N + 1]            idx[j] = interface of exception j < cnt; interface N is always one
+//   E  float4 [N + 1][2]                           (A, B) of exception j; only the first cnt entries are written / read
+// 8.6 KB of traffic per 512-cell row against the 16.6 KB of a dense (A, B) tape and the 24.6 KB of the reference's blocks.
+struct TapeGeom {
+    int s_f4, h_f4, e_f4;
+    size_t row_f4;
+};
+__host__ __device__ inline TapeGeom tape_geom(int N) {
+    TapeGeom g;
+    g.s_f4 = (((3 * N + 3) >> 2) + 7) & ~7;
+    g.h_f4 = ((8 + 2 * (N + 1) + 127) >> 7) << 3;
+    g.e_f4 = (2 * (N + 1) + 7) & ~7;
+    g.row_f4 = (size_t)g.s_f4 + g.h_f4 + g.e_f4;
+    return g;
+}
+__device__ __forceinline__ unsigned *tape_hdr(float4 *row, const TapeGeom &g) { return reinterpret_cast<unsigned *>(row + g.s_f4); }
+__device__ __forceinline__ const unsigned *tape_hdr(const float4 *row, const TapeGeom &g) { return reinterpret_cast<const unsigned *>(row + g.s_f4); }
+__device__ __forceinline__ unsigned short *tape_idx(unsigned *hdr, const TapeGeom &g) { return reinterpret_cast<unsigned short *>(hdr + 2); }
+__device__ __forceinline__ const unsigned short *tape_idx(const unsigned *hdr, const TapeGeom &g) { return reinterpret_cast<const unsigned short *>(hdr + 2); }
+struct __attribute__((packed, aligned(4))) TapeFp { float f0, f2, f3; };
+static_assert(sizeof(TapeFp) == 12, "TapeFp layout");
+__device__ __forceinline__ float4 tape_trivial_A(const TapeFp &s) { return make_float4(s.f0, 1.f, s.f2, s.f3); }
+
 // grid = L workgroups (one traffic lane each) of W = blockDim.x / 64 wavefronts; dynamic LDS = 2 * 4 * (N + 2) floats.
 // Wave w owns the cells [w C, min(N, (w + 1) C)) with C = 64 p - 1, i.e. at most 64 p interfaces = p passes, so no
 // wave ever needs a pass for a single left-over interface; the state is ping-pong buffered in LDS and the only
@@ -87,8 +117,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     const int hi = (lo + C < N) ? lo + C : N;        // one past its last cell = its last interface
     const int K = (lo < N) ? ((hi - lo + 1 + 63) >> 6) : 0;
     const int Np = (N + 63) & ~63;
-    const int Nq = (N + 1 + 7) & ~7;                 // interfaces per lane, padded to whole 128-byte lines
-    const size_t tape_row = kIface ? (size_t)2 * Nq : (size_t)3 * Np;
+    const TapeGeom geo = tape_geom(N);
+    const size_t tape_row = kIface ? geo.row_f4 : (size_t)3 * Np;
     const double c = dt / dx;                        // update_coefficient, _macro_lane.py:99
     const float cf = (float)c, ncf = (float)(-c);
     const float umf = (float)um;
@@ -105,6 +135,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         float cA0 = 0.f, cA1 = 0.f, cA2 = 0.f, cA3 = 0.f, cB0 = 0.f, cB1 = 0.f, cB2 = 0.f, cB3 = 0.f;
         float4 *tp = tape ? tape + ((size_t)step * L + lane) * tape_row : nullptr;
         float *hp = hist ? hist + ((size_t)step * L + lane) * 3 * N : nullptr;
+        if (kIface && tp) {
+            // this kernel keeps every interface as an exception: interface N at slot 0, interface i < N at slot i + 1
+            unsigned *H = tape_hdr(tp, geo);
+            if (tid == 0) { H[0] = (unsigned)(N + 1); H[1] = 0u; }
+        }
         if (K > 0) {
             for (int j = K - 1; j >= 0; --j) {
                 const int i = lo + (j << 6) + t;   // interface i, and cell i to its right
@@ -130,9 +165,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                     cA0 = bcast0(f.A[0]); cA1 = bcast0(f.A[1]); cA2 = bcast0(f.A[2]); cA3 = bcast0(f.A[3]);
                     cB0 = bcast0(f.B[0]); cB1 = bcast0(f.B[1]); cB2 = bcast0(f.B[2]); cB3 = bcast0(f.B[3]);
                 } else if (tp && vi) {
-                    // interface tape: the two 2x2 products of interface i; the reverse sweep forms the cell blocks from them
-                    tp[i] = make_float4(f.A[0], f.A[1], f.A[2], f.A[3]);
-                    tp[Nq + i] = make_float4(f.B[0], f.B[1], f.B[2], f.B[3]);
+                    // the two 2x2 products of interface i; the reverse sweep forms the cell blocks from them
+                    const int slot = (i == N) ? 0 : i + 1;
+                    float4 *E = tp + geo.s_f4 + geo.h_f4;
+                    E[2 * slot] = make_float4(f.A[0], f.A[1], f.A[2], f.A[3]);
+                    E[2 * slot + 1] = make_float4(f.B[0], f.B[1], f.B[2], f.B[3]);
+                    tape_idx(tape_hdr(tp, geo), geo)[slot] = (unsigned short)i;
                 }
 
                 if (vc) {
@@ -215,8 +253,8 @@ __device__ __forceinline__ void cell_glue_pre(float r, float y, float umf, const
 // phase 1 -> phase 2 -> phase 1 ... of ONE lane is what bounds it when few lanes share a CU.  A step therefore runs as
 //   phase 1 (every cell's thread): finish the previous step -- new (r, y) from the two fluxes of the cell, (u, u_eq) and
 //     the cell's CellPre from one pair of square roots, written to the cell's record -- then read the left neighbour's
-//     record, decide whether the interface is trivial, and if so write its flux (LDS) and its tape entry (A = flux
-//     Jacobian, B = 0); otherwise append it to the lane's queue;
+//     record, decide whether the interface is trivial, and if so write its flux (LDS) -- its tape entry is the three
+//     non-constant entries of the flux Jacobian; otherwise append it to the lane's queue;
 //   phase 2 (the first threads of the workgroup, one queue entry each, at raised priority: they are the workgroup's
 //     critical path): the full solve for the queued interfaces, their fluxes to LDS, their tape entries to HBM.  Always
 //     queued: the first interface of every wave's chunk (its left cell belongs to another wave) and interface N (no cell
@@ -281,8 +319,7 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
     if (tid == 0) { Q[0] = N; CNT[0] = 1; CNT[1] = 1; }      // entry 0 of every step's queue: interface N
     __syncthreads();
 
-    const unsigned Nq = (unsigned)(N + 1 + 7) & ~7u; // interfaces per lane, padded to whole 128-byte lines
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const TapeGeom geo = tape_geom(N);
 
     const int lo = wv * (p << 6);                    // first cell of this wave
     const double c = dt / dx;                        // update_coefficient, _macro_lane.py:99
@@ -293,7 +330,9 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
     for (int n = 0; n <= T; ++n) {
         const bool upd = n > 0;                      // finish step n - 1
         const bool solve = n < T;                    // start step n
-        float4 *tp = (tape && solve) ? tape + ((size_t)n * L + lane) * 2 * Nq : nullptr;
+        float4 *tp = (tape && solve) ? tape + ((size_t)n * L + lane) * geo.row_f4 : nullptr;
+        TapeFp *tS = reinterpret_cast<TapeFp *>(tp);
+        unsigned *tH = tape_hdr(tp, geo);
         float *hp = (hist && upd) ? hist + ((size_t)(n - 1) * L + lane) * 3 * N : nullptr;
         int *cnt = CNT + (n & 1);
         for (int j = 0; j < p; ++j) {
@@ -326,19 +365,17 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
             IfacePre pre;
             const bool easy = arz_is_trivial_fast((double)ls.x, (double)ls.z, (double)ls.w, (double)st.x, (double)st.z, cl, kc, pre);
             const bool triv = vc & easy & !((j == 0) & (t == 0));
-            if (triv) {
-                double u0, Fr, Fy;
-                float fp[4];
-                arz_trivial_fast((double)ls.x, (double)ls.y, pre, kc, u0, Fr, Fy, fp);
-                FX[ic] = make_double2(Fr, Fy);
-                if (tp) {
-                    tp[ic] = make_float4(fp[0], fp[1], fp[2], fp[3]);
-                    tp[Nq + ic] = zero4;
-                }
-            }
+            // the trivial solve runs on every lane (the few that are not trivial sit in the same instructions anyway); only
+            // where it applies its flux counts.  Its flux Jacobian is the interface's tape entry.
+            double u0, Fr, Fy;
+            float fp[4];
+            arz_trivial_fast((double)ls.x, (double)ls.y, pre, kc, u0, Fr, Fy, fp);
+            if (triv) FX[ic] = make_double2(Fr, Fy);
             // append to the lane's queue: the compiler turns the per-lane atomic into ONE LDS atomic per wavefront (add of the
             // number of active lanes) and hands every lane the old value plus its rank among the active ones
-            if (vc & !triv) Q[atomicAdd(cnt, 1)] = i;
+            const bool nt = vc & !triv;
+            if (nt) Q[atomicAdd(cnt, 1)] = i;
+            if (tp && vc) tS[ic] = TapeFp{fp[0], fp[2], fp[3]};
         }
         if (!solve) break;
         lds_only_barrier();
@@ -348,6 +385,9 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
         const unsigned i_q = (unsigned)Q[k0 <= N ? k0 : 0];  // read beside the count, not behind it (one LDS round trip less)
         const int qn = *cnt;
         if (k0 < qn) __builtin_amdgcn_s_setprio(3);          // the workgroup's critical path
+        if (tp && k0 == 0) { tH[0] = (unsigned)qn; tH[1] = 0u; }
+        float4 *tE = tp + geo.s_f4 + geo.h_f4;
+        unsigned short *tI = tape_idx(tH, geo);
         for (int k = k0; k < qn; k += ncell) {
             const unsigned i = (k == k0) ? i_q : (unsigned)Q[k];
             const CellRec *lf = CR + i, *rt = CR + i + 1;
@@ -361,8 +401,9 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
                                    (double)rs.x, (double)rs.y, (double)rs.z, (double)rs.w, cr, kc, f);
             FX[i] = make_double2(f.Fr, f.Fy);
             if (tp) {
-                tp[i] = make_float4(f.A[0], f.A[1], f.A[2], f.A[3]);
-                tp[Nq + i] = make_float4(f.B[0], f.B[1], f.B[2], f.B[3]);
+                tE[2 * k] = make_float4(f.A[0], f.A[1], f.A[2], f.A[3]);
+                tE[2 * k + 1] = make_float4(f.B[0], f.B[1], f.B[2], f.B[3]);
+                tI[k] = (unsigned short)i;
             }
             if (f.cfl_bad && fault_step < 0) { fault_step = n; fault_index = (int)i; }
         }
@@ -374,11 +415,28 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
     if (fault_step >= 0) raise_fault(err, DHTS_FAULT_CFL, fault_step, lane, fault_index);
 }
 
-// grid = L workgroups of `blockDim.x` threads (multiple of 64); dynamic LDS = 6 * (N + 2) floats.
+// ---- reverse sweeps -------------------------------------------------------------------------------------------------
 // g' = J^T g per step: grad_cell[a][k] = dqs[a][k]^T g[a]; g'[b] = (c1[b] + c2[b-1]) + c0[b+1]   (dmacro_lane.py:283-303)
-template <bool kIface>
-__global__ void macro_rollout_bwd_kernel(
-    int L, int N, int T, double cc, const float4 *__restrict__ tape,
+// LDS planes of (N + 2) floats: index k + 1 holds cell k; slots 0 and N + 1 stay zero for c2 / c0 so edge cells add 0.
+struct BwdPlanes {
+    float *Gr, *Gy, *C0r, *C0y, *C2r, *C2y;
+};
+__device__ __forceinline__ BwdPlanes bwd_planes(float *lds, int P) {
+    return BwdPlanes{lds, lds + P, lds + 2 * P, lds + 3 * P, lds + 4 * P, lds + 5 * P};
+}
+// the cell blocks from the interface products exactly as the forward forms them (dmacro_lane.py:126-129)
+__device__ __forceinline__ void cell_blocks(const float4 &aL, const float4 &bL, const float4 &aR, const float4 &bR, float cf, float ncf,
+                                            float4 &d0, float4 &d1, float4 &d2) {
+    d0.x = ncf * (-aL.x); d0.y = ncf * (-aL.y); d0.z = ncf * (-aL.z); d0.w = ncf * (-aL.w);
+    d2.x = ncf * bR.x; d2.y = ncf * bR.y; d2.z = ncf * bR.z; d2.w = ncf * bR.w;
+    d1.x = 1.f - cf * (aR.x - bL.x); d1.y = 0.f - cf * (aR.y - bL.y);
+    d1.z = 0.f - cf * (aR.z - bL.z); d1.w = 1.f - cf * (aR.w - bL.w);
+}
+
+// Reverse sweep over the single-step operator's blocked tape [lane][3][Np][4] (T = 1 from the C ABI; any T works).
+// grid = L workgroups of `blockDim.x` threads (multiple of 64); dynamic LDS = 6 * (N + 2) floats.
+__global__ void macro_blocks_bwd_kernel(
+    int L, int N, int T, const float4 *__restrict__ tape,
     const float *__restrict__ g_r_in, const float *__restrict__ g_y_in, const float *__restrict__ g_hist,
     float *__restrict__ g_r_out, float *__restrict__ g_y_out, double *__restrict__ g_ghost, dhts_error *err) {
     extern __shared__ float lds[];
@@ -386,13 +444,11 @@ __global__ void macro_rollout_bwd_kernel(
     const int t = threadIdx.x;
     const int B = blockDim.x;
     const int P = N + 2;
-    // index k + 1 holds cell k; slots 0 and N + 1 stay zero for c2 / c0 so edge cells add 0
-    float *Gr = lds, *Gy = lds + P, *C0r = lds + 2 * P, *C0y = lds + 3 * P, *C2r = lds + 4 * P, *C2y = lds + 5 * P;
+    const BwdPlanes pl = bwd_planes(lds, P);
+    float *Gr = pl.Gr, *Gy = pl.Gy, *C0r = pl.C0r, *C0y = pl.C0y, *C2r = pl.C2r, *C2y = pl.C2y;
     const size_t base = (size_t)lane * N;
     const int Np = (N + 63) & ~63;
-    const int Nq = (N + 1 + 7) & ~7;
-    const size_t tape_row = kIface ? (size_t)2 * Nq : (size_t)3 * Np;
-    const float cf = (float)cc, ncf = (float)(-cc);
+    const size_t tape_row = (size_t)3 * Np;
 
     for (int k = t; k < P; k += B) { C0r[k] = 0.f; C0y[k] = 0.f; C2r[k] = 0.f; C2y[k] = 0.f; Gr[k] = 0.f; Gy[k] = 0.f; }
     __syncthreads();
@@ -401,77 +457,11 @@ __global__ void macro_rollout_bwd_kernel(
 
     double ghl_r = 0., ghl_y = 0., ghr_r = 0., ghr_y = 0.;   // ghost cotangent sums (thread 0 / thread of cell N-1)
     int bad_step = -1, bad_cell = 0;     // first non-finite cotangent this thread meets (the reverse sweep's first = the latest step)
-    int step_hi = T - 1;
-    if constexpr (kIface) {
-        if (N <= B && g_hist == nullptr) {
-            // One cell per thread (the rollouts' common shape): the four interface products of the NEXT step to replay are
-            // loaded while this step computes (unconditional loads, clamped step index), and the two barriers of a step wait
-            // for LDS only, so the loads stay in flight across them -- the tape stream is what bounds this kernel.
-            const int k = t;
-            const bool vk = k < N;
-            const int kl = vk ? k : 0;
-            const float4 *tp0 = tape + (size_t)lane * tape_row + kl;
-            const size_t step_stride = (size_t)L * tape_row;
-            float4 n_aL, n_bL, n_aR, n_bR, m_aL, m_bL, m_aR, m_bR;
-            {
-                const float4 *tp = tp0 + (size_t)(T > 0 ? T - 1 : 0) * step_stride;
-                n_aL = tp[0]; n_bL = tp[Nq]; n_aR = tp[1]; n_bR = tp[Nq + 1];
-                const float4 *tq = tp0 + (size_t)(T > 1 ? T - 2 : 0) * step_stride;
-                m_aL = tq[0]; m_bL = tq[Nq]; m_aR = tq[1]; m_bR = tq[Nq + 1];
-            }
-            for (int step = T - 1; step >= 0; --step) {
-                const float4 aL = n_aL, bL = n_bL, aR = n_aR, bR = n_bR;
-                n_aL = m_aL; n_bL = m_bL; n_aR = m_aR; n_bR = m_bR;
-                {
-                    const float4 *tp = tp0 + (size_t)(step > 1 ? step - 2 : 0) * step_stride;      // two steps ahead
-                    m_aL = tp[0]; m_bL = tp[Nq]; m_aR = tp[1]; m_bR = tp[Nq + 1];
-                }
-                if (vk) {
-                    float4 d0, d1, d2;
-                    d0.x = ncf * (-aL.x); d0.y = ncf * (-aL.y); d0.z = ncf * (-aL.z); d0.w = ncf * (-aL.w);
-                    d2.x = ncf * bR.x; d2.y = ncf * bR.y; d2.z = ncf * bR.z; d2.w = ncf * bR.w;
-                    d1.x = 1.f - cf * (aR.x - bL.x); d1.y = 0.f - cf * (aR.y - bL.y);
-                    d1.z = 0.f - cf * (aR.z - bL.z); d1.w = 1.f - cf * (aR.w - bL.w);
-                    const float gr = Gr[k + 1], gy = Gy[k + 1];
-                    const float c0r = dot2(d0.x, gr, d0.z, gy), c0y = dot2(d0.y, gr, d0.w, gy);
-                    const float c1r = dot2(d1.x, gr, d1.z, gy), c1y = dot2(d1.y, gr, d1.w, gy);
-                    const float c2r = dot2(d2.x, gr, d2.z, gy), c2y = dot2(d2.y, gr, d2.w, gy);
-                    C0r[k] = c0r; C0y[k] = c0y;
-                    C2r[k + 2] = c2r; C2y[k + 2] = c2y;
-                    Gr[k + 1] = c1r; Gy[k + 1] = c1y;
-                    if (k == 0) { ghl_r += (double)c0r; ghl_y += (double)c0y; }
-                    if (k == N - 1) { ghr_r += (double)c2r; ghr_y += (double)c2y; }
-                }
-                lds_only_barrier();
-                if (vk) {
-                    const float c2lr = (k > 0) ? C2r[k + 1] : 0.f, c2ly = (k > 0) ? C2y[k + 1] : 0.f;
-                    const float c0rr = (k < N - 1) ? C0r[k + 1] : 0.f, c0ry = (k < N - 1) ? C0y[k + 1] : 0.f;
-                    const float nr = (Gr[k + 1] + c2lr) + c0rr;
-                    const float ny = (Gy[k + 1] + c2ly) + c0ry;
-                    Gr[k + 1] = nr; Gy[k + 1] = ny;
-                    if (bad_step < 0 && !(isfinite(nr) && isfinite(ny))) { bad_step = step; bad_cell = k; }
-                }
-                lds_only_barrier();
-            }
-            step_hi = -1;            // nothing left for the general loop
-            __syncthreads();
-        }
-    }
-    for (int step = step_hi; step >= 0; --step) {
+    for (int step = T - 1; step >= 0; --step) {
         const float4 *tp = tape + ((size_t)step * L + lane) * tape_row;
         const float *gh = g_hist ? g_hist + ((size_t)step * L + lane) * 2 * N : nullptr;
         for (int k = t; k < N; k += B) {
-            float4 d0, d1, d2;
-            if constexpr (kIface) {
-                // cell blocks from the interface products exactly as the forward forms them (dmacro_lane.py:126-129)
-                const float4 aL = tp[k], bL = tp[Nq + k], aR = tp[k + 1], bR = tp[Nq + k + 1];
-                d0.x = ncf * (-aL.x); d0.y = ncf * (-aL.y); d0.z = ncf * (-aL.z); d0.w = ncf * (-aL.w);
-                d2.x = ncf * bR.x; d2.y = ncf * bR.y; d2.z = ncf * bR.z; d2.w = ncf * bR.w;
-                d1.x = 1.f - cf * (aR.x - bL.x); d1.y = 0.f - cf * (aR.y - bL.y);
-                d1.z = 0.f - cf * (aR.z - bL.z); d1.w = 1.f - cf * (aR.w - bL.w);
-            } else {
-                d0 = tp[k]; d1 = tp[Np + k]; d2 = tp[2 * Np + k];
-            }
+            const float4 d0 = tp[k], d1 = tp[Np + k], d2 = tp[2 * Np + k];
             float gr = Gr[k + 1], gy = Gy[k + 1];
             if (gh) { gr += gh[k]; gy += gh[N + k]; }
             const float c0r = dot2(d0.x, gr, d0.z, gy), c0y = dot2(d0.y, gr, d0.w, gy);
@@ -502,6 +492,300 @@ __global__ void macro_rollout_bwd_kernel(
         if (t == (N - 1) % B) { g_ghost[(size_t)lane * 4 + 2] = ghr_r; g_ghost[(size_t)lane * 4 + 3] = ghr_y; }
     }
     if (bad_step >= 0) raise_fault(err, DHTS_FAULT_NAN, bad_step, lane, bad_cell);
+}
+
+// (A_i, B_i) of interface i from a tape row; SLOT[i] = the exception slot of interface i or 0xffff for a trivial one
+// (tape_fill_slots: cleared, then filled from the row's idx list; the caller puts a barrier behind each of the two passes)
+__device__ __forceinline__ void tape_iface(const float4 *row, const TapeGeom &geo, int N, int i,
+                                           const unsigned short *SLOT, float4 &A, float4 &B) {
+    const unsigned s = SLOT[i];
+    if (s != 0xffffu) {
+        const float4 *E = row + geo.s_f4 + geo.h_f4;
+        A = E[2 * s]; B = E[2 * s + 1];
+    } else {
+        A = tape_trivial_A(reinterpret_cast<const TapeFp *>(row)[i < N ? i : N - 1]);
+        B = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void tape_clear_slots(int N, unsigned short *SLOT, int t, int B) {
+    for (int i = t; i <= N; i += B) SLOT[i] = 0xffffu;
+}
+__device__ __forceinline__ void tape_fill_slots(const float4 *row, const TapeGeom &geo, int N, unsigned short *SLOT, int t, int B) {
+    const unsigned *H = tape_hdr(row, geo);
+    const unsigned short *I = tape_idx(H, geo);
+    int cnt = (int)H[0];
+    if (cnt > N + 1) cnt = N + 1;
+    for (int j = t; j < cnt; j += B) {
+        const int i = I[j];
+        if (i <= N) SLOT[i] = (unsigned short)j;
+    }
+}
+
+// Reverse sweep over the rollout tape, one cell per thread (2 <= N <= blockDim.x, no per-step cotangents: the rollouts' common
+// shape).  grid = L workgroups of `blockDim.x` threads (multiple of 64).
+// Thread k owns cell k, whose blocks are made of the products of interfaces k and k + 1.  Where those are trivial it has them
+// in registers (three floats each, read from the row's S block); thread j < cnt also carries exception j to its interface:
+// (A, B) into XA / XB [interface], the step's tag into STAMP [interface], one barrier interval before they are used -- a cell
+// whose interface carries the step's tag reads the products from there.  The cotangent of the own cell lives in a register;
+// what the neighbours contribute goes through C0 / C2.  XA / XB / STAMP / C0 / C2 alternate between two copies with the step
+// parity, so a step needs ONE barrier (LDS only: the tape loads stay in flight across it).  The tape entries are loaded two
+// steps before they are used, the exception counts three.  The float32 arithmetic is that of the general kernel below
+// (cell_blocks, dot2) two components at a time (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: same operations, same roundings).
+// Dynamic LDS: float2 C0[2][N + 2], C2[2][N + 2] (index k + 1 = cell k; slot 1 of C2 and slot N of C0 are never written and
+// stay zero: the edge cells add 0) | float4 XA[2][N + 1], XB[2][N + 1] | u32 STAMP[2][N + 2].
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_dot(v2f dlo, v2f dhi, v2f g) {           // (dot2(dlo.x, g.x, dhi.x, g.y), dot2(dlo.y, g.x, dhi.y, g.y))
+    const v2f gx = {g.x, g.x}, gy = {g.y, g.y};
+    return __builtin_elementwise_fma(dhi, gy, dlo * gx);
+}
+__host__ __device__ inline size_t bwd_fast_lds_bytes(int N) {
+    return 2 * 2 * 8 * (size_t)(N + 2) + 2 * 2 * 16 * (size_t)(N + 1) + 2 * 4 * (size_t)(N + 2);
+}
+__global__ __launch_bounds__(512) void macro_rollout_bwd_fast_kernel(
+    int L, int N, int T, double cc, const float4 *__restrict__ tape,
+    const float *__restrict__ g_r_in, const float *__restrict__ g_y_in,
+    float *__restrict__ g_r_out, float *__restrict__ g_y_out, double *__restrict__ g_ghost, dhts_error *err) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = blockIdx.x;
+    const int t = threadIdx.x;
+    const int B = blockDim.x;
+    const int P = N + 2;
+    float4 *XA = reinterpret_cast<float4 *>(lds), *XB = XA + 2 * (N + 1);             // [parity][N + 1]
+    v2f *C0 = reinterpret_cast<v2f *>(XB + 2 * (N + 1)), *C2 = C0 + 2 * P;            // [parity][P]
+    unsigned *STAMP = reinterpret_cast<unsigned *>(C2 + 2 * P);                       // [parity][P]
+    const size_t base = (size_t)lane * N;
+    const TapeGeom geo = tape_geom(N);
+    const v2f cf = {(float)cc, (float)cc}, ncf = {(float)(-cc), (float)(-cc)};
+    const v2f zero2 = {0.f, 0.f}, e0 = {1.f, 0.f}, e1 = {0.f, 1.f};
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int k = t;
+    const bool vk = k < N;
+    const unsigned kl = vk ? k : N - 1;
+    const unsigned kr = (kl + 1 < (unsigned)N) ? kl + 1 : N - 1;      // interface N is always an exception: its S entry does not exist
+
+    for (int i = t; i < 2 * P; i += B) { C0[i] = zero2; C2[i] = zero2; STAMP[i] = 0u; }
+    v2f g = zero2;
+    if (vk) g = v2f{g_r_in[base + k], g_y_in[base + k]};
+
+    double gh_r = 0., gh_y = 0.;         // ghost cotangent sums: thread 0 the left ghost's, thread N - 1 the right one's
+    int bad_step = -1;                   // first non-finite cotangent this thread meets (the reverse sweep's first = the latest step)
+    unsigned zv;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zv));     // keeps the count loads on the vector memory path (vmcnt, not lgkmcnt)
+    // byte offsets inside a row (32-bit, on top of the row's uniform base address)
+    const unsigned off_sl = 12u * kl, off_sr = 12u * kr;
+    const unsigned off_c = 16u * geo.s_f4 + zv;
+    const unsigned off_i = 16u * geo.s_f4 + 8u + 2u * t;
+    const unsigned off_e = 16u * (geo.s_f4 + geo.h_f4) + 32u * t;
+    const size_t row_bytes = 16 * geo.row_f4;
+    const char *tb = reinterpret_cast<const char *>(tape) + (size_t)lane * row_bytes;
+    const size_t stride = (size_t)L * row_bytes;
+    // (plain variables and macros, not structs handed to lambdas: those end up in scratch memory)
+#define DHTS_ROW(step_) (tb + (size_t)((step_) > 0 ? (step_) : 0) * stride)
+#define DHTS_LOAD_CNT(step_, c_) c_ = *reinterpret_cast<const int *>(DHTS_ROW(step_) + off_c);
+#define DHTS_LOAD_S(step_, sl_, sr_)                                                     \
+    {                                                                                    \
+        const char *rb_ = DHTS_ROW(step_);                                               \
+        sl_ = *reinterpret_cast<const TapeFp *>(rb_ + off_sl);                           \
+        sr_ = *reinterpret_cast<const TapeFp *>(rb_ + off_sr);                           \
+    }
+#define DHTS_LOAD_E(step_, c_, ea_, eb_, ix_)                                            \
+    if (t < (c_)) {                                                                      \
+        const char *rb_ = DHTS_ROW(step_);                                               \
+        ix_ = *reinterpret_cast<const unsigned short *>(rb_ + off_i);                    \
+        ea_ = *reinterpret_cast<const float4 *>(rb_ + off_e);                            \
+        eb_ = *reinterpret_cast<const float4 *>(rb_ + off_e + 16);                       \
+    }
+    // exception j of step_ to its interface, in the copy of that step's parity
+#define DHTS_SCATTER(step_, c_, ea_, eb_, ix_)                                           \
+    {                                                                                    \
+        const int o_ = ((step_) & 1) * (N + 1), os_ = ((step_) & 1) * P;                 \
+        if ((t < (c_)) & (ix_ <= (unsigned)N)) {                                         \
+            XA[o_ + ix_] = ea_; XB[o_ + ix_] = eb_; STAMP[os_ + ix_] = (unsigned)(step_) + 1u; \
+        }                                                                                \
+        if ((c_) > B) scatter_rest(step_, c_);                                           \
+    }
+    // more exceptions than threads (the one-phase forward kernel flags every interface): the rest, without prefetch
+    auto scatter_rest = [&](int step, int cnt) {
+        const float4 *row = reinterpret_cast<const float4 *>(DHTS_ROW(step));
+        const unsigned short *I = tape_idx(tape_hdr(row, geo), geo);
+        const float4 *E = row + geo.s_f4 + geo.h_f4;
+        const int o = (step & 1) * (N + 1), os = (step & 1) * P;
+        if (cnt > N + 1) cnt = N + 1;
+        for (int j = t + B; j < cnt; j += B) {
+            const int i = I[j];
+            if (i <= N) { XA[o + i] = E[2 * j]; XB[o + i] = E[2 * j + 1]; STAMP[os + i] = (unsigned)step + 1u; }
+        }
+    };
+    // One step s.  Its trivial products are in (sl_, sr_), its exceptions in the LDS copy of its parity; the other register
+    // set (ea_ .. ec_) holds the exceptions of step s - 1, which go to LDS now and make room for those of step s - 3, whose count
+    // cq_ arrived two steps ago; (sl_, sr_) and cq_ are refilled for steps s - 2 and s - 5.
+#define DHTS_HALF(s_, sl_, sr_, ea_, eb_, ix_, ec_, cq_)                                 \
+    {                                                                                    \
+        const int q_ = (s_) & 1, o_ = q_ * (N + 1), os_ = q_ * P;                         \
+        const unsigned tag_ = (unsigned)(s_) + 1u;                                       \
+        v2f c1v = zero2;                                                                 \
+        if (vk) {                                                                        \
+            float4 aL = tape_trivial_A(sl_), bL = zero4, aR = tape_trivial_A(sr_), bR = zero4; \
+            if (STAMP[os_ + k] == tag_) { aL = XA[o_ + k]; bL = XB[o_ + k]; }            \
+            if (STAMP[os_ + k + 1] == tag_) { aR = XA[o_ + k + 1]; bR = XB[o_ + k + 1]; } \
+            const v2f d0lo = ncf * -v2f{aL.x, aL.y}, d0hi = ncf * -v2f{aL.z, aL.w};      \
+            const v2f d2lo = ncf * v2f{bR.x, bR.y}, d2hi = ncf * v2f{bR.z, bR.w};        \
+            const v2f d1lo = e0 - cf * (v2f{aR.x, aR.y} - v2f{bL.x, bL.y});              \
+            const v2f d1hi = e1 - cf * (v2f{aR.z, aR.w} - v2f{bL.z, bL.w});              \
+            const v2f c0 = pk_dot(d0lo, d0hi, g), c2v = pk_dot(d2lo, d2hi, g);           \
+            c1v = pk_dot(d1lo, d1hi, g);                                                 \
+            /* c0 of cell k goes to cell k-1 (slot k), c2 of cell k goes to cell k+1 (slot k+2) */ \
+            C0[os_ + k] = c0;                                                            \
+            C2[os_ + k + 2] = c2v;                                                       \
+            if (k == 0) { gh_r += (double)c0.x; gh_y += (double)c0.y; }                  \
+            if (k == N - 1) { gh_r += (double)c2v.x; gh_y += (double)c2v.y; }            \
+        }                                                                                \
+        if ((s_) >= 1) DHTS_SCATTER((s_) - 1, ec_, ea_, eb_, ix_);                       \
+        ec_ = cq_;                                                                       \
+        DHTS_LOAD_E((s_) - 3, ec_, ea_, eb_, ix_);                                       \
+        DHTS_LOAD_CNT((s_) - 5, cq_);                                                    \
+        DHTS_LOAD_S((s_) - 2, sl_, sr_);                                                 \
+        lds_only_barrier();                                                              \
+        if (vk) {                                                                        \
+            g = (c1v + C2[os_ + k + 1]) + C0[os_ + k + 1];                               \
+            if (bad_step < 0 && !(isfinite(g.x) && isfinite(g.y))) bad_step = (s_);      \
+        }                                                                                \
+    }
+    // register set 1 serves the steps T - 1, T - 3, ..., set 2 the steps T - 2, T - 4, ...
+    TapeFp sl1, sr1, sl2, sr2;
+    float4 ea1 = zero4, eb1 = zero4, ea2 = zero4, eb2 = zero4;
+    unsigned ix1 = 0, ix2 = 0;
+    int ec1, ec2, cq1, cq2;
+    DHTS_LOAD_CNT(T - 1, ec1);
+    DHTS_LOAD_CNT(T - 2, ec2);
+    DHTS_LOAD_CNT(T - 3, cq1);
+    DHTS_LOAD_CNT(T - 4, cq2);
+    DHTS_LOAD_E(T - 1, ec1, ea1, eb1, ix1);
+    DHTS_LOAD_E(T - 2, ec2, ea2, eb2, ix2);
+    DHTS_LOAD_S(T - 1, sl1, sr1);
+    DHTS_LOAD_S(T - 2, sl2, sr2);
+    __syncthreads();                                     // the zeroed planes
+    DHTS_SCATTER(T - 1, ec1, ea1, eb1, ix1);
+    ec1 = cq1;
+    DHTS_LOAD_E(T - 3, ec1, ea1, eb1, ix1);
+    DHTS_LOAD_CNT(T - 5, cq1);
+    lds_only_barrier();
+    // on entry to a step s of set 1: (sl1, sr1) = S(s), exceptions of s in LDS, set 2 holds E(s - 1) and cq2 = count of s - 3;
+    // set 1 holds E(s - 2) and cq1 = count of s - 4
+    int step = T - 1;
+    for (; step >= 1; step -= 2) {
+        DHTS_HALF(step, sl1, sr1, ea2, eb2, ix2, ec2, cq2)
+        DHTS_HALF(step - 1, sl2, sr2, ea1, eb1, ix1, ec1, cq1)
+    }
+    if (step == 0) DHTS_HALF(0, sl1, sr1, ea2, eb2, ix2, ec2, cq2)
+#undef DHTS_ROW
+#undef DHTS_LOAD_CNT
+#undef DHTS_LOAD_S
+#undef DHTS_LOAD_E
+#undef DHTS_SCATTER
+#undef DHTS_HALF
+    if (vk) { g_r_out[base + k] = g.x; g_y_out[base + k] = g.y; }
+    if (g_ghost) {
+        if (t == 0) { g_ghost[(size_t)lane * 4 + 0] = gh_r; g_ghost[(size_t)lane * 4 + 1] = gh_y; }
+        if (t == N - 1) { g_ghost[(size_t)lane * 4 + 2] = gh_r; g_ghost[(size_t)lane * 4 + 3] = gh_y; }
+    }
+    if (bad_step >= 0) raise_fault(err, DHTS_FAULT_NAN, bad_step, lane, k);
+}
+
+// Reverse sweep over the rollout tape, any lane length, per-step cotangents (g_hist) or not.
+// grid = L workgroups of `blockDim.x` threads (multiple of 64).  Dynamic LDS: 6 planes of (N + 2) floats | u16 SLOT[N + 1].
+__global__ __launch_bounds__(512) void macro_rollout_bwd_kernel(
+    int L, int N, int T, double cc, const float4 *__restrict__ tape,
+    const float *__restrict__ g_r_in, const float *__restrict__ g_y_in, const float *__restrict__ g_hist,
+    float *__restrict__ g_r_out, float *__restrict__ g_y_out, double *__restrict__ g_ghost, dhts_error *err) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = blockIdx.x;
+    const int t = threadIdx.x;
+    const int B = blockDim.x;
+    const int P = N + 2;
+    const BwdPlanes pl = bwd_planes(lds, P);
+    float *Gr = pl.Gr, *Gy = pl.Gy, *C0r = pl.C0r, *C0y = pl.C0y, *C2r = pl.C2r, *C2y = pl.C2y;
+    float *xbase = lds + ((6 * P + 3) & ~3);
+    const size_t base = (size_t)lane * N;
+    const TapeGeom geo = tape_geom(N);
+    const float cf = (float)cc, ncf = (float)(-cc);
+
+    for (int k = t; k < P; k += B) { C0r[k] = 0.f; C0y[k] = 0.f; C2r[k] = 0.f; C2y[k] = 0.f; Gr[k] = 0.f; Gy[k] = 0.f; }
+    __syncthreads();
+    for (int k = t; k < N; k += B) { Gr[k + 1] = g_r_in[base + k]; Gy[k + 1] = g_y_in[base + k]; }
+    __syncthreads();
+
+    double ghl_r = 0., ghl_y = 0., ghr_r = 0., ghr_y = 0.;   // ghost cotangent sums (thread 0 / thread of cell N-1)
+    int bad_step = -1, bad_cell = 0;     // first non-finite cotangent this thread meets (the reverse sweep's first = the latest step)
+    {
+        unsigned short *SLOT = reinterpret_cast<unsigned short *>(xbase);
+        for (int step = T - 1; step >= 0; --step) {
+            const float4 *row = tape + ((size_t)step * L + lane) * geo.row_f4;
+            const float *gh = g_hist ? g_hist + ((size_t)step * L + lane) * 2 * N : nullptr;
+            tape_clear_slots(N, SLOT, t, B);
+            __syncthreads();
+            tape_fill_slots(row, geo, N, SLOT, t, B);
+            __syncthreads();
+            for (int k = t; k < N; k += B) {
+                float4 aL, bL, aR, bR, d0, d1, d2;
+                tape_iface(row, geo, N, k, SLOT, aL, bL);
+                tape_iface(row, geo, N, k + 1, SLOT, aR, bR);
+                cell_blocks(aL, bL, aR, bR, cf, ncf, d0, d1, d2);
+                float gr = Gr[k + 1], gy = Gy[k + 1];
+                if (gh) { gr += gh[k]; gy += gh[N + k]; }
+                const float c0r = dot2(d0.x, gr, d0.z, gy), c0y = dot2(d0.y, gr, d0.w, gy);
+                const float c1r = dot2(d1.x, gr, d1.z, gy), c1y = dot2(d1.y, gr, d1.w, gy);
+                const float c2r = dot2(d2.x, gr, d2.z, gy), c2y = dot2(d2.y, gr, d2.w, gy);
+                C0r[k] = c0r; C0y[k] = c0y;
+                C2r[k + 2] = c2r; C2y[k + 2] = c2y;
+                Gr[k + 1] = c1r; Gy[k + 1] = c1y;
+                if (k == 0) { ghl_r += (double)c0r; ghl_y += (double)c0y; }
+                if (k == N - 1) { ghr_r += (double)c2r; ghr_y += (double)c2y; }
+            }
+            __syncthreads();
+            for (int k = t; k < N; k += B) {
+                const float c2lr = (k > 0) ? C2r[k + 1] : 0.f, c2ly = (k > 0) ? C2y[k + 1] : 0.f;
+                const float c0rr = (k < N - 1) ? C0r[k + 1] : 0.f, c0ry = (k < N - 1) ? C0y[k + 1] : 0.f;
+                const float nr = (Gr[k + 1] + c2lr) + c0rr;
+                const float ny = (Gy[k + 1] + c2ly) + c0ry;
+                Gr[k + 1] = nr; Gy[k + 1] = ny;
+                if (bad_step < 0 && !(isfinite(nr) && isfinite(ny))) { bad_step = step; bad_cell = k; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int k = t; k < N; k += B) { g_r_out[base + k] = Gr[k + 1]; g_y_out[base + k] = Gy[k + 1]; }
+    if (g_ghost) {
+        if (t == 0) { g_ghost[(size_t)lane * 4 + 0] = ghl_r; g_ghost[(size_t)lane * 4 + 1] = ghl_y; }
+        if (t == (N - 1) % B) { g_ghost[(size_t)lane * 4 + 2] = ghr_r; g_ghost[(size_t)lane * 4 + 3] = ghr_y; }
+    }
+    if (bad_step >= 0) raise_fault(err, DHTS_FAULT_NAN, bad_step, lane, bad_cell);
+}
+
+// The reference's cell blocks dqs[a][3][2][2] of every (step, lane) from the rollout tape, in the single-step operator's
+// layout [step][lane][3][Np][4], formed with the reverse sweep's own code.  grid = T * L workgroups; LDS = u16 SLOT[N + 1].
+__global__ void macro_tape_expand_kernel(int N, double cc, const float4 *__restrict__ tape, float4 *__restrict__ dqs) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned short *SLOT = reinterpret_cast<unsigned short *>(lds);
+    const TapeGeom geo = tape_geom(N);
+    const int Np = (N + 63) & ~63;
+    const float4 *row = tape + (size_t)blockIdx.x * geo.row_f4;
+    float4 *out = dqs + (size_t)blockIdx.x * 3 * Np;
+    const float cf = (float)cc, ncf = (float)(-cc);
+    tape_clear_slots(N, SLOT, threadIdx.x, blockDim.x);
+    __syncthreads();
+    tape_fill_slots(row, geo, N, SLOT, threadIdx.x, blockDim.x);
+    __syncthreads();
+    for (int k = threadIdx.x; k < Np; k += blockDim.x) {
+        float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f), d1 = d0, d2 = d0;      // the padding is written too (zeros)
+        if (k < N) {
+            float4 aL, bL, aR, bR;
+            tape_iface(row, geo, N, k, SLOT, aL, bL);
+            tape_iface(row, geo, N, k + 1, SLOT, aR, bR);
+            cell_blocks(aL, bL, aR, bR, cf, ncf, d0, d1, d2);
+        }
+        out[k] = d0; out[Np + k] = d1; out[2 * Np + k] = d2;
+    }
 }
 
 // ---- known-answer entry: n independent interfaces, both solver variants ---------------------------------
@@ -638,20 +922,41 @@ static int macro_fwd_launch(const dhts_macro_desc *d, int T,
         reinterpret_cast<float4 *>(tape), hist, err);
     return launch_status();
 }
-template <bool kIface>
-static int macro_bwd_launch(const dhts_macro_desc *d, int T, const float *tape,
-                            const float *g_r, const float *g_y, const float *g_hist,
-                            float *g_r_out, float *g_y_out, double *g_ghost, dhts_error *err, void *stream) {
+static int macro_blocks_bwd_launch(const dhts_macro_desc *d, int T, const float *tape,
+                                  const float *g_r, const float *g_y, const float *g_hist,
+                                  float *g_r_out, float *g_y_out, double *g_ghost, dhts_error *err, void *stream) {
     if (!macro_desc_ok(d) || T < 0 || (T > 0 && !tape) || !g_r || !g_y || !g_r_out || !g_y_out) return DHTS_E_INVALID;
     const size_t lds = sizeof(float) * 6 * (size_t)(d->n_cells + 2);
     int B = padded64(d->n_cells);
     if (B > 512) B = 512;
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)macro_rollout_bwd_kernel<kIface>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        hipFuncSetAttribute((const void *)macro_blocks_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_LAUNCH;
-    macro_rollout_bwd_kernel<kIface><<<d->n_lanes, B, lds, (hipStream_t)stream>>>(
-        d->n_lanes, d->n_cells, T, d->dt / d->dx, reinterpret_cast<const float4 *>(tape), g_r, g_y, g_hist, g_r_out, g_y_out,
-        g_ghost, err);
+    macro_blocks_bwd_kernel<<<d->n_lanes, B, lds, (hipStream_t)stream>>>(
+        d->n_lanes, d->n_cells, T, reinterpret_cast<const float4 *>(tape), g_r, g_y, g_hist, g_r_out, g_y_out, g_ghost, err);
+    return launch_status();
+}
+static int macro_rollout_bwd_launch(const dhts_macro_desc *d, int T, const float *tape,
+                                    const float *g_r, const float *g_y, const float *g_hist,
+                                    float *g_r_out, float *g_y_out, double *g_ghost, dhts_error *err, void *stream) {
+    if (!macro_desc_ok(d) || T < 0 || (T > 0 && !tape) || !g_r || !g_y || !g_r_out || !g_y_out) return DHTS_E_INVALID;
+    const int N = d->n_cells;
+    int B = padded64(N);
+    if (B > 512) B = 512;
+    const bool fast = N >= 2 && N <= B && g_hist == nullptr && T > 0;      // (T = 0: no tape to prefetch from)
+    const size_t planes = sizeof(float) * (size_t)((6 * (N + 2) + 3) & ~3);
+    const size_t lds = fast ? bwd_fast_lds_bytes(N) : planes + 2 * (size_t)(N + 1);
+    if (lds > 160 * 1024) return DHTS_E_INVALID;
+    const void *fn = fast ? (const void *)macro_rollout_bwd_fast_kernel : (const void *)macro_rollout_bwd_kernel;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DHTS_E_LAUNCH;
+    if (fast)
+        macro_rollout_bwd_fast_kernel<<<d->n_lanes, B, lds, (hipStream_t)stream>>>(
+            d->n_lanes, N, T, d->dt / d->dx, reinterpret_cast<const float4 *>(tape), g_r, g_y, g_r_out, g_y_out, g_ghost, err);
+    else
+        macro_rollout_bwd_kernel<<<d->n_lanes, B, lds, (hipStream_t)stream>>>(
+            d->n_lanes, N, T, d->dt / d->dx, reinterpret_cast<const float4 *>(tape), g_r, g_y, g_hist, g_r_out, g_y_out, g_ghost,
+            err);
     return launch_status();
 }
 
@@ -679,7 +984,7 @@ int dhts_padded(int n) { return (n + 63) & ~63; }
 
 size_t dhts_macro_tape_bytes(const dhts_macro_desc *d, int T) {
     if (!macro_desc_ok(d) || T < 0) return 0;
-    return (size_t)T * d->n_lanes * 2 * ((d->n_cells + 1 + 7) & ~7) * sizeof(float4);
+    return (size_t)T * d->n_lanes * tape_geom(d->n_cells).row_f4 * sizeof(float4);
 }
 size_t dhts_macro_step_tape_bytes(const dhts_macro_desc *d) {
     if (!macro_desc_ok(d)) return 0;
@@ -722,14 +1027,25 @@ int dhts_macro_rollout_fwd(const dhts_macro_desc *d, int T,
                            const float *r, const float *y, const float *u, const float *ueq, const float *ghost,
                            float *r_out, float *y_out, float *u_out, float *ueq_out,
                            float *tape, float *hist, dhts_error *err, void *stream) {
-    if (dhts_fwd_variant == 1)
+    // lanes whose records do not fit the two-phase kernel's LDS take the one-phase kernel (same tape format)
+    const bool fits = d && sizeof(CellRec) * (size_t)(d->n_cells + 2) + 16 * (size_t)(d->n_cells + 1) +
+                               sizeof(int) * (size_t)(d->n_cells + 2) + 16 <= 160 * 1024;
+    if (dhts_fwd_variant == 1 || !fits)
         return macro_fwd_launch<true>(d, T, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, tape, hist, err, stream);
     return macro_fwd2_launch(d, T, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, tape, hist, err, stream);
 }
 int dhts_macro_rollout_bwd(const dhts_macro_desc *d, int T, const float *tape,
                            const float *g_r, const float *g_y, const float *g_hist,
                            float *g_r_out, float *g_y_out, double *g_ghost, dhts_error *err, void *stream) {
-    return macro_bwd_launch<true>(d, T, tape, g_r, g_y, g_hist, g_r_out, g_y_out, g_ghost, err, stream);
+    return macro_rollout_bwd_launch(d, T, tape, g_r, g_y, g_hist, g_r_out, g_y_out, g_ghost, err, stream);
+}
+int dhts_macro_tape_expand(const dhts_macro_desc *d, int T, const float *tape, float *dqs, void *stream) {
+    if (!macro_desc_ok(d) || T < 0 || (T > 0 && (!tape || !dqs))) return DHTS_E_INVALID;
+    if (T == 0) return DHTS_OK;
+    const size_t lds = 2 * (size_t)(d->n_cells + 1);
+    macro_tape_expand_kernel<<<(unsigned)((size_t)T * d->n_lanes), 256, lds, (hipStream_t)stream>>>(
+        d->n_cells, d->dt / d->dx, reinterpret_cast<const float4 *>(tape), reinterpret_cast<float4 *>(dqs));
+    return launch_status();
 }
 // the single-step operator keeps the reference's per-cell blocks dqs[a][3][2][2] (48 B per cell)
 int dhts_macro_step_fwd(const dhts_macro_desc *d,
@@ -740,7 +1056,7 @@ int dhts_macro_step_fwd(const dhts_macro_desc *d,
 }
 int dhts_macro_step_bwd(const dhts_macro_desc *d, const float *tape, const float *g_r, const float *g_y,
                         float *g_r_out, float *g_y_out, double *g_ghost, dhts_error *err, void *stream) {
-    return macro_bwd_launch<false>(d, 1, tape, g_r, g_y, nullptr, g_r_out, g_y_out, g_ghost, err, stream);
+    return macro_blocks_bwd_launch(d, 1, tape, g_r, g_y, nullptr, g_r_out, g_y_out, g_ghost, err, stream);
 }
 
 }  // extern "C"

@@ -65,7 +65,7 @@ def macro_desc(L, N, dt, dx, u_max):
 
 
 def macro_tape_numel(desc, T):
-    """float32 elements of the rollout (interface) tape."""
+    """float32 elements of the rollout tape (include/dhts.h: left-cell states + the compacted products of the exceptions)."""
     return _lib.lib().dhts_macro_tape_bytes(C.byref(desc), int(T)) // 4
 
 
@@ -143,6 +143,14 @@ def macro_rollout_bwd(desc, T, tape, g_r, g_y, g_hist=None, err=None, out=None, 
                                             _ptr(out[0]), _ptr(out[1]), _ptr(g_ghost), _ptr(err), _stream()),
           "dhts_macro_rollout_bwd")
     return out[0], out[1], g_ghost
+
+
+def macro_tape_expand(desc, T, tape):
+    """The reference's blocks dqs (dmacro_lane.py:56) of all T steps from a rollout tape: float32 [T][L][3][Np][4]."""
+    Np = _lib.lib().dhts_padded(desc.n_cells)
+    dqs = torch.empty(int(T), desc.n_lanes, 3, Np, 4, dtype=torch.float32, device=tape.device)
+    check(_lib.lib().dhts_macro_tape_expand(C.byref(desc), int(T), _ptr(tape), _ptr(dqs), _stream()), "dhts_macro_tape_expand")
+    return dqs
 
 
 class MacroRollout(torch.autograd.Function):

@@ -77,18 +77,31 @@ int dhts_device_count(void);
 /* DHTS_OPT_MICRO_FWD_WAVES: wavefronts per traffic lane in the micro forward kernel, 1, 2 or 4; 0 = heuristic. */
 #define DHTS_OPT_MICRO_FWD_WAVES 2
 /* DHTS_OPT_MACRO_FWD_VARIANT: kernel behind dhts_macro_rollout_fwd: 0 = two-phase kernel (trivial interfaces solved in
- * place, the others queued and solved compacted), 1 = the one-phase kernel of dhts_macro_step_fwd.  Same tape, same results. */
+ * place, the others queued and solved compacted), 1 = the one-phase kernel of dhts_macro_step_fwd (every interface an exception).  Same tape format, same results. */
 #define DHTS_OPT_MACRO_FWD_VARIANT 3
 int dhts_set_option(int option, int value);
 /* cells / vehicle slots rounded up to the tape's padded width (multiple of 64) */
 int dhts_padded(int n);
-/* bytes of Jacobian tape for T fused steps (dhts_macro_rollout_*): the interface tape
- *   [step][lane][2][Nq][4] float32, Nq = n_cells + 1 rounded up to 8: plane 0 = A_i = flux'(Q_0) dQ_0/dQ_L, plane 1 =
- *   B_i = flux'(Q_0) dQ_0/dQ_R of interface i (the two 2x2 products of dMacroLane._backward, dmacro_lane.py:116-124), 32 B per
- *   interface-step.  The reverse sweep forms the reference's cell blocks dqs[a][0] = c A_a, dqs[a][1] = I - c (A_{a+1} - B_a),
- *   dqs[a][2] = - c B_{a+1} (c = dt / dx; dmacro_lane.py:126-129) from them with the same float32 operations, so the results
- *   are those of the 48-byte per-cell tape at two thirds of the memory traffic. */
+/* bytes of Jacobian tape for T fused steps (dhts_macro_rollout_*).  The rollout tape holds, per (step, lane) row, what the
+ *   reverse sweep needs to form the interface products A_i = flux'(Q_0) dQ_0/dQ_L, B_i = flux'(Q_0) dQ_0/dQ_R (the two 2x2
+ *   products of dMacroLane._backward, dmacro_lane.py:116-124) of every interface i = 0 .. n_cells:
+ *     S  float32 [n_cells][2]      (r, y) of the LEFT cell of interface i (i = 0: the left ghost).  Where Q_0 = Q_L (the trivial
+ *                                  Riemann case) A_i is the flux Jacobian at Q_L and B_i = 0: the reverse sweep recomputes A_i
+ *                                  from these 8 bytes with the forward's own code (bitwise the forward's value);
+ *     H  uint32 cnt, uint32 0 | uint64 mask[ceil(n_cells / 64)] | uint16 idx[n_cells + 1]
+ *                                  bit i of mask: interface i is an "exception" (Q_0 is not Q_L, or the forward kernel chose to
+ *                                  solve it in full); idx[j] = the interface of exception j < cnt; interface n_cells is always one;
+ *     E  float32 [n_cells + 1][2][4]   (A, B) of exception j; only the first cnt entries are written and read.
+ *   Every block starts on a 128-byte line.  The reverse sweep forms the reference's cell blocks dqs[a][0] = c A_a,
+ *   dqs[a][1] = I - c (A_{a+1} - B_a), dqs[a][2] = - c B_{a+1} (c = dt / dx; dmacro_lane.py:126-129) from the products with the
+ *   same float32 operations, so the results are those of the 48-byte per-cell tape; dhts_macro_tape_expand writes them out.
+ *   The row is sized for the worst case (every interface an exception); the bytes MOVED per row are 8 n_cells + the header +
+ *   32 cnt (BASELINE config 2: cnt ~ 0.11 n_cells, 6.3 KB per 512-cell row against 24.6 KB of dqs blocks). */
 size_t dhts_macro_tape_bytes(const dhts_macro_desc *d, int T);
+/* the reference's blocks dqs[a][3][2][2] (dmacro_lane.py:56) of all T steps from a rollout tape, in the single-step operator's
+ *   layout per step: dqs_out [T][lane][3][Np][4] float32 (T x dhts_macro_step_tape_bytes).  For tests and for callers that want
+ *   the Jacobians themselves; the reverse sweep does not need it. */
+int dhts_macro_tape_expand(const dhts_macro_desc *d, int T, const float *tape, float *dqs_out, void *stream);
 /* bytes of the single-step operator's tape (dhts_macro_step_*): the reference's per-cell blocks
  *   [lane][3][Np][4] float32, Np = dhts_padded(n_cells): plane k holds dqs[a][k] of every cell a */
 size_t dhts_macro_step_tape_bytes(const dhts_macro_desc *d);

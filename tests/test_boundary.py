@@ -50,7 +50,7 @@ def test_tape_bytes_match_documented_layout():
     from dhts import _lib
     lib = _lib.lib()
     d = _lib.MacroDesc(1024, 512, 0.01, 5.0, 30.0)
-    assert lib.dhts_macro_tape_bytes(C.byref(d), 1000) == 1000 * 1024 * 2 * 520 * 16    # 32 B per interface-step, 513 -> 520
+    assert lib.dhts_macro_tape_bytes(C.byref(d), 1000) == 1000 * 1024 * (384 + 72 + 1032) * 16  # S 512 x 12 B | header 1034 B -> 9 lines | E 513 x 32 B
     assert lib.dhts_macro_step_tape_bytes(C.byref(d)) == 1024 * 3 * 512 * 16           # 48 B per cell (the reference's dqs)
     m = _lib.MicroDesc(4096, 256, 0.01)
     assert lib.dhts_micro_tape_bytes(C.byref(m), 1000) == 1000 * 4096 * 256 * 12        # 12 B per vehicle-step
