@@ -528,8 +528,8 @@ __device__ __forceinline__ void tape_fill_slots(const float4 *row, const TapeGeo
 // (A, B) into XA / XB [interface], the step's tag into STAMP [interface], one barrier interval before they are used -- a cell
 // whose interface carries the step's tag reads the products from there.  The cotangent of the own cell lives in a register;
 // what the neighbours contribute goes through C0 / C2.  XA / XB / STAMP / C0 / C2 alternate between two copies with the step
-// parity, so a step needs ONE barrier (LDS only: the tape loads stay in flight across it).  The tape entries are loaded two
-// steps before they are used, the exception counts three.  The float32 arithmetic is that of the general kernel below
+// parity, so a step needs ONE barrier (LDS only: the tape loads stay in flight across it).  The tape entries are loaded
+// three steps before they are needed (three register sets trading places, no moves), the exception counts six.  The float32 arithmetic is that of the general kernel below
 // (cell_blocks, dot2) two components at a time (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: same operations, same roundings).
 // Dynamic LDS: float2 C0[2][N + 2], C2[2][N + 2] (index k + 1 = cell k; slot 1 of C2 and slot N of C0 are never written and
 // stay zero: the edge cells add 0) | float4 XA[2][N + 1], XB[2][N + 1] | u32 STAMP[2][N + 2].
@@ -616,74 +616,106 @@ __global__ __launch_bounds__(512) void macro_rollout_bwd_fast_kernel(
             if (i <= N) { XA[o + i] = E[2 * j]; XB[o + i] = E[2 * j + 1]; STAMP[os + i] = (unsigned)step + 1u; }
         }
     };
-    // One step s.  Its trivial products are in (sl_, sr_), its exceptions in the LDS copy of its parity; the other register
-    // set (ea_ .. ec_) holds the exceptions of step s - 1, which go to LDS now and make room for those of step s - 3, whose count
-    // cq_ arrived two steps ago; (sl_, sr_) and cq_ are refilled for steps s - 2 and s - 5.
-#define DHTS_HALF(s_, sl_, sr_, ea_, eb_, ix_, ec_, cq_)                                 \
+    // The blocks of step s_ from its products: the trivial ones in (sl_, sr_), the others in the LDS copy of the step's parity
+    // (both stamps are read before either product)
+#define DHTS_BLOCKS(s_, sl_, sr_)                                                        \
     {                                                                                    \
-        const int q_ = (s_) & 1, o_ = q_ * (N + 1), os_ = q_ * P;                         \
+        const int o_ = ((s_) & 1) * (N + 1), os_ = ((s_) & 1) * P;                       \
         const unsigned tag_ = (unsigned)(s_) + 1u;                                       \
-        v2f c1v = zero2;                                                                 \
+        const unsigned st0_ = STAMP[os_ + k], st1_ = STAMP[os_ + k + 1];                 \
+        float4 aL = tape_trivial_A(sl_), bL = zero4, aR = tape_trivial_A(sr_), bR = zero4; \
+        if (st0_ == tag_) { aL = XA[o_ + k]; bL = XB[o_ + k]; }                          \
+        if (st1_ == tag_) { aR = XA[o_ + k + 1]; bR = XB[o_ + k + 1]; }                  \
+        d0lo = ncf * -v2f{aL.x, aL.y}; d0hi = ncf * -v2f{aL.z, aL.w};                    \
+        d2lo = ncf * v2f{bR.x, bR.y}; d2hi = ncf * v2f{bR.z, bR.w};                      \
+        d1lo = e0 - cf * (v2f{aR.x, aR.y} - v2f{bL.x, bL.y});                            \
+        d1hi = e1 - cf * (v2f{aR.z, aR.w} - v2f{bL.z, bL.w});                            \
+    }
+    // One barrier interval, step s.  Behind the barrier only what depends on the neighbours: the cell's cotangent after step
+    // s + 1 (its own part c1v plus what the two neighbours left in C0 / C2), the three products with the blocks of step s --
+    // formed in the previous interval -- and their hand-over.  Then, off that chain: the blocks of step s - 1 (trivial
+    // products in (sl_, sr_), exceptions scattered one interval ago), the exceptions of step s - 2 from (ea_ .. ec_) to LDS, and
+    // the refills: exceptions of step s - 5 (their count cq_ arrived three intervals ago), the count of step s - 8, the trivial
+    // products of step s - 4.  Everything read from the tape is in flight for three intervals (2 workgroups x 3 steps x 9 KB
+    // per CU: what 6 TB/s at ~2 us of latency need).
+#define DHTS_STEP(s_, sl_, sr_, ea_, eb_, ix_, ec_, cq_)                                 \
+    {                                                                                    \
         if (vk) {                                                                        \
-            float4 aL = tape_trivial_A(sl_), bL = zero4, aR = tape_trivial_A(sr_), bR = zero4; \
-            if (STAMP[os_ + k] == tag_) { aL = XA[o_ + k]; bL = XB[o_ + k]; }            \
-            if (STAMP[os_ + k + 1] == tag_) { aR = XA[o_ + k + 1]; bR = XB[o_ + k + 1]; } \
-            const v2f d0lo = ncf * -v2f{aL.x, aL.y}, d0hi = ncf * -v2f{aL.z, aL.w};      \
-            const v2f d2lo = ncf * v2f{bR.x, bR.y}, d2hi = ncf * v2f{bR.z, bR.w};        \
-            const v2f d1lo = e0 - cf * (v2f{aR.x, aR.y} - v2f{bL.x, bL.y});              \
-            const v2f d1hi = e1 - cf * (v2f{aR.z, aR.w} - v2f{bL.z, bL.w});              \
+            const int os_ = ((s_) & 1) * P, op_ = (((s_) + 1) & 1) * P;                   \
+            g = (c1v + C2[op_ + k + 1]) + C0[op_ + k + 1];                               \
+            if (bad_step < 0 && !(isfinite(g.x) && isfinite(g.y))) bad_step = ((s_) + 1 < T) ? (s_) + 1 : T - 1; \
             const v2f c0 = pk_dot(d0lo, d0hi, g), c2v = pk_dot(d2lo, d2hi, g);           \
             c1v = pk_dot(d1lo, d1hi, g);                                                 \
             /* c0 of cell k goes to cell k-1 (slot k), c2 of cell k goes to cell k+1 (slot k+2) */ \
             C0[os_ + k] = c0;                                                            \
             C2[os_ + k + 2] = c2v;                                                       \
-            if (k == 0) { gh_r += (double)c0.x; gh_y += (double)c0.y; }                  \
-            if (k == N - 1) { gh_r += (double)c2v.x; gh_y += (double)c2v.y; }            \
+            if (__builtin_amdgcn_ballot_w64((k == 0) | (k == N - 1))) {                  \
+                asm volatile("" ::: "memory");          /* a real branch: two wavefronts of the workgroup take it */ \
+                if (k == 0) { gh_r += (double)c0.x; gh_y += (double)c0.y; }              \
+                if (k == N - 1) { gh_r += (double)c2v.x; gh_y += (double)c2v.y; }        \
+            }                                                                            \
+            if ((s_) >= 1) DHTS_BLOCKS((s_) - 1, sl_, sr_)                               \
         }                                                                                \
-        if ((s_) >= 1) DHTS_SCATTER((s_) - 1, ec_, ea_, eb_, ix_);                       \
+        if ((s_) >= 2) DHTS_SCATTER((s_) - 2, ec_, ea_, eb_, ix_);                       \
         ec_ = cq_;                                                                       \
-        DHTS_LOAD_E((s_) - 3, ec_, ea_, eb_, ix_);                                       \
-        DHTS_LOAD_CNT((s_) - 5, cq_);                                                    \
-        DHTS_LOAD_S((s_) - 2, sl_, sr_);                                                 \
+        DHTS_LOAD_E((s_) - 5, ec_, ea_, eb_, ix_);                                       \
+        DHTS_LOAD_CNT((s_) - 8, cq_);                                                    \
+        DHTS_LOAD_S((s_) - 4, sl_, sr_);                                                 \
         lds_only_barrier();                                                              \
-        if (vk) {                                                                        \
-            g = (c1v + C2[os_ + k + 1]) + C0[os_ + k + 1];                               \
-            if (bad_step < 0 && !(isfinite(g.x) && isfinite(g.y))) bad_step = (s_);      \
-        }                                                                                \
     }
-    // register set 1 serves the steps T - 1, T - 3, ..., set 2 the steps T - 2, T - 4, ...
-    TapeFp sl1, sr1, sl2, sr2;
-    float4 ea1 = zero4, eb1 = zero4, ea2 = zero4, eb2 = zero4;
-    unsigned ix1 = 0, ix2 = 0;
-    int ec1, ec2, cq1, cq2;
-    DHTS_LOAD_CNT(T - 1, ec1);
-    DHTS_LOAD_CNT(T - 2, ec2);
-    DHTS_LOAD_CNT(T - 3, cq1);
-    DHTS_LOAD_CNT(T - 4, cq2);
-    DHTS_LOAD_E(T - 1, ec1, ea1, eb1, ix1);
-    DHTS_LOAD_E(T - 2, ec2, ea2, eb2, ix2);
-    DHTS_LOAD_S(T - 1, sl1, sr1);
-    DHTS_LOAD_S(T - 2, sl2, sr2);
+    // register set A serves the steps T - 1, T - 4, ..., set B the steps T - 2, T - 5, ..., set C the steps T - 3, T - 6, ...
+    TapeFp slA, srA, slB, srB, slC, srC;
+    float4 eaA = zero4, ebA = zero4, eaB = zero4, ebB = zero4, eaC = zero4, ebC = zero4;
+    unsigned ixA = 0, ixB = 0, ixC = 0;
+    int ecA, ecB, ecC, cqA, cqB, cqC;
+    v2f d0lo = zero2, d0hi = zero2, d1lo = zero2, d1hi = zero2, d2lo = zero2, d2hi = zero2;
+    v2f c1v = g;                                          // "after step T": the incoming cotangent; C0 / C2 are zero
+    DHTS_LOAD_CNT(T - 1, ecA);
+    DHTS_LOAD_CNT(T - 2, ecB);
+    DHTS_LOAD_CNT(T - 3, ecC);
+    DHTS_LOAD_CNT(T - 4, cqA);
+    DHTS_LOAD_CNT(T - 5, cqB);
+    DHTS_LOAD_CNT(T - 6, cqC);
+    DHTS_LOAD_E(T - 1, ecA, eaA, ebA, ixA);
+    DHTS_LOAD_E(T - 2, ecB, eaB, ebB, ixB);
+    DHTS_LOAD_E(T - 3, ecC, eaC, ebC, ixC);
+    DHTS_LOAD_S(T - 1, slA, srA);
+    DHTS_LOAD_S(T - 2, slB, srB);
+    DHTS_LOAD_S(T - 3, slC, srC);
     __syncthreads();                                     // the zeroed planes
-    DHTS_SCATTER(T - 1, ec1, ea1, eb1, ix1);
-    ec1 = cq1;
-    DHTS_LOAD_E(T - 3, ec1, ea1, eb1, ix1);
-    DHTS_LOAD_CNT(T - 5, cq1);
+    DHTS_SCATTER(T - 1, ecA, eaA, ebA, ixA);
+    if (T >= 2) DHTS_SCATTER(T - 2, ecB, eaB, ebB, ixB);
+    ecA = cqA;
+    ecB = cqB;
+    DHTS_LOAD_E(T - 4, ecA, eaA, ebA, ixA);
+    DHTS_LOAD_E(T - 5, ecB, eaB, ebB, ixB);
+    DHTS_LOAD_CNT(T - 7, cqA);
+    DHTS_LOAD_CNT(T - 8, cqB);
     lds_only_barrier();
-    // on entry to a step s of set 1: (sl1, sr1) = S(s), exceptions of s in LDS, set 2 holds E(s - 1) and cq2 = count of s - 3;
-    // set 1 holds E(s - 2) and cq1 = count of s - 4
+    if (vk) DHTS_BLOCKS(T - 1, slA, srA)
+    DHTS_LOAD_S(T - 4, slA, srA);
+    // on entry to the interval of a step s of class A: the blocks of s are in registers, the exceptions of s - 1 in LDS;
+    // (slB, srB) = S(s - 1), set C holds E(s - 2) and cqC the count of s - 5; (slC, srC) = S(s - 2), set A holds E(s - 3) and
+    // cqA the count of s - 6; (slA, srA) = S(s - 3), set B holds E(s - 4) and cqB the count of s - 7
     int step = T - 1;
-    for (; step >= 1; step -= 2) {
-        DHTS_HALF(step, sl1, sr1, ea2, eb2, ix2, ec2, cq2)
-        DHTS_HALF(step - 1, sl2, sr2, ea1, eb1, ix1, ec1, cq1)
+    for (; step >= 2; step -= 3) {
+        DHTS_STEP(step, slB, srB, eaC, ebC, ixC, ecC, cqC)
+        DHTS_STEP(step - 1, slC, srC, eaA, ebA, ixA, ecA, cqA)
+        DHTS_STEP(step - 2, slA, srA, eaB, ebB, ixB, ecB, cqB)
     }
-    if (step == 0) DHTS_HALF(0, sl1, sr1, ea2, eb2, ix2, ec2, cq2)
+    if (step >= 0) DHTS_STEP(step, slB, srB, eaC, ebC, ixC, ecC, cqC)
+    if (step >= 1) DHTS_STEP(step - 1, slC, srC, eaA, ebA, ixA, ecA, cqA)
+    if (vk) {                                            // after step 0
+        g = (c1v + C2[k + 1]) + C0[k + 1];
+        if (bad_step < 0 && !(isfinite(g.x) && isfinite(g.y))) bad_step = 0;
+    }
+#undef DHTS_BLOCKS
 #undef DHTS_ROW
 #undef DHTS_LOAD_CNT
 #undef DHTS_LOAD_S
 #undef DHTS_LOAD_E
 #undef DHTS_SCATTER
-#undef DHTS_HALF
+#undef DHTS_STEP
     if (vk) { g_r_out[base + k] = g.x; g_y_out[base + k] = g.y; }
     if (g_ghost) {
         if (t == 0) { g_ghost[(size_t)lane * 4 + 0] = gh_r; g_ghost[(size_t)lane * 4 + 1] = gh_y; }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Counter passes over the macro rollout forward kernels (GPU box).  Usage: tools/pmc_macro_fwd.sh <out-dir> <variant> <waves>
+# Counter passes over the macro rollout kernels, forward and reverse (GPU box).  Usage: tools/pmc_macro_fwd.sh <out-dir> <variant> <waves>
 # One rocprofv3 run per counter group (SQ has 8 slots per pass); --kernel-trace only, never with a --sys-trace domain.
 set -u
 OUT=$1; V=${2:-0}; W=${3:-0}
@@ -10,8 +10,11 @@ G1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_
 G2="SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA"
 G3="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_CVT"
 G4="GRBM_GUI_ACTIVE SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_TRANS_F32 SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT"
+G5="FETCH_SIZE"
+G6="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum"
+G7="TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr TA_TA_BUSY_sum"
 i=0
-for G in "$G1" "$G2" "$G3" "$G4"; do
+for G in "$G1" "$G2" "$G3" "$G4" "$G5" "$G6" "$G7"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $G --output-format csv -d "$OUT/g$i" -- python3 "$REPO/tools/run_macro_fwd.py" "$V" "$W" 2 > "$OUT/g$i.log" 2>&1
   tail -n 1 "$OUT/g$i.log"
