@@ -78,6 +78,8 @@ __device__ __forceinline__ unsigned short *tape_idx(unsigned *hdr, const TapeGeo
 __device__ __forceinline__ const unsigned short *tape_idx(const unsigned *hdr, const TapeGeom &g) { return reinterpret_cast<const unsigned short *>(hdr + 2); }
 struct __attribute__((packed, aligned(4))) TapeFp { float f0, f2, f3; };
 static_assert(sizeof(TapeFp) == 12, "TapeFp layout");
+// (stored member by member -- three dword stores: measured faster in the forward kernel than one global_store_dwordx3 and
+// than three planes, 4.32 against 4.41 and 4.44 ms)
 __device__ __forceinline__ float4 tape_trivial_A(const TapeFp &s) { return make_float4(s.f0, 1.f, s.f2, s.f3); }
 
 // grid = L workgroups (one traffic lane each) of W = blockDim.x / 64 wavefronts; dynamic LDS = 2 * 4 * (N + 2) floats.
