@@ -277,6 +277,9 @@ __device__ __forceinline__ void cell_glue_pre(float r, float y, float umf, const
 //     workgroups per CU, which spills 35 registers;
 //   * per-wave queues, every wave solving what it queued itself (no serial section, all waves busy in phase 2): 5.2 ms with
 //     2 waves per lane, 5.9 with 8 -- the full solve's instruction stream is then paid once per wave instead of once per lane;
+//   * the trivial interfaces' tape entries (three floats of the flux Jacobian) formed in phase 2 by the wavefronts that hold no
+//     queue entry instead of in phase 1: 4.48 ms against 4.32 -- with two workgroups per CU those wavefronts are not idle
+//     time, they are the other workgroup's phase 1;
 //   * two traffic lanes per workgroup half a step apart (phase 1 of one lane beside phase 2 of the other in every barrier
 //     interval, 4 + 4 wavefronts, two phase-1 passes per thread interleaved stage by stage): 6.1 ms -- an interval takes
 //     ~5100 cycles for the phase-1 waves and ~4000-4700 for the phase-2 waves that share their SIMDs, against 2000 + 1800
