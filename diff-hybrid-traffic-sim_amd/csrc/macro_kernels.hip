@@ -286,8 +286,9 @@ __device__ __forceinline__ void cell_glue_pre(float r, float y, float umf, const
 //     when the phases alternate: neither chain got shorter by running beside the other.
 // Dynamic LDS: cell records [N + 2] (index c + 1 = cell c, 0 and N + 1 the ghosts; updated in place) | flux double2 [N + 1]
 // | queue int [N + 2] | 2 counters.
+template <bool kOnePass>       // one 64-cell pass per wavefront (p = 1): the per-thread addresses are loop invariants
 __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
-    int L, int N, int T, int p, double dt, double dx, double um,
+    int L, int N, int T, int p_arg, double dt, double dx, double um,
     const float *__restrict__ r_in, const float *__restrict__ y_in, const float *__restrict__ u_in,
     const float *__restrict__ q_in, const float *__restrict__ ghost,
     float *__restrict__ r_out, float *__restrict__ y_out, float *__restrict__ u_out, float *__restrict__ q_out,
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
     __syncthreads();
 
     const TapeGeom geo = tape_geom(N);
+    const int p = kOnePass ? 1 : p_arg;
 
     const int lo = wv * (p << 6);                    // first cell of this wave
     const double c = dt / dx;                        // update_coefficient, _macro_lane.py:99
@@ -332,13 +334,20 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
     int fault_step = -1, fault_index = 0;
     int rot = 0;                                     // the cell wave that takes the head of the queue rotates with the step
 
+    // the tape row / history block of the step, advanced by one step's worth per trip (no 64-bit multiplications in the loop)
+    float4 *tp_run = tape ? tape + (size_t)lane * geo.row_f4 : nullptr;
+    float *hp_run = hist ? hist + (size_t)lane * 3 * N : nullptr;
+    const size_t tp_stride = (size_t)L * geo.row_f4, hp_stride = (size_t)L * 3 * N;
+
     for (int n = 0; n <= T; ++n) {
         const bool upd = n > 0;                      // finish step n - 1
         const bool solve = n < T;                    // start step n
-        float4 *tp = (tape && solve) ? tape + ((size_t)n * L + lane) * geo.row_f4 : nullptr;
+        float4 *tp = solve ? tp_run : nullptr;
         TapeFp *tS = reinterpret_cast<TapeFp *>(tp);
         unsigned *tH = tape_hdr(tp, geo);
-        float *hp = (hist && upd) ? hist + ((size_t)(n - 1) * L + lane) * 3 * N : nullptr;
+        float *hp = upd ? hp_run : nullptr;
+        if (tp_run) tp_run += tp_stride;
+        if (hp_run && upd) hp_run += hp_stride;
         int *cnt = CNT + (n & 1);
         for (int j = 0; j < p; ++j) {
             const int i = lo + (j << 6) + t;                // cell i and its left interface i
@@ -912,7 +921,8 @@ static int macro_fwd2_launch(const dhts_macro_desc *d, int T,
     const size_t lds = sizeof(CellRec) * (size_t)(N + 2) + 16 * (size_t)(N + 1) + sizeof(int) * (size_t)(N + 2) + 16;
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        (hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+         hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess))
         return DHTS_E_LAUNCH;
     // Wavefronts per lane: one 64-cell pass per wavefront whenever the lane fits 16 of them (measured, tools/sweep_fwd_waves.py,
     // forward ms for 1 / 2 / 4 / 8 / 16 waves per lane: 1024 x 512: 7.0 / 5.0 / 4.9 / 4.6 / 4.5; 4096 x 256: 12.9 / 11.8 / 10.4 /
@@ -923,9 +933,14 @@ static int macro_fwd2_launch(const dhts_macro_desc *d, int T,
     if (W < 1) W = 1;
     int p = (N + 64 * W - 1) / (64 * W);
     W = (N + 64 * p - 1) / (64 * p);
-    macro_rollout_fwd2_kernel<<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(
-        d->n_lanes, N, T, p, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out,
-        reinterpret_cast<float4 *>(tape), hist, err);
+    if (p == 1)
+        macro_rollout_fwd2_kernel<true><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(
+            d->n_lanes, N, T, p, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out,
+            reinterpret_cast<float4 *>(tape), hist, err);
+    else
+        macro_rollout_fwd2_kernel<false><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(
+            d->n_lanes, N, T, p, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out,
+            reinterpret_cast<float4 *>(tape), hist, err);
     return launch_status();
 }
 
