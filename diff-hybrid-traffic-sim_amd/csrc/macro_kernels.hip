@@ -552,21 +552,23 @@ __device__ __forceinline__ v2f pk_dot(v2f dlo, v2f dhi, v2f g) {           // (d
     const v2f gx = {g.x, g.x}, gy = {g.y, g.y};
     return __builtin_elementwise_fma(dhi, gy, dlo * gx);
 }
-__host__ __device__ inline size_t bwd_fast_lds_bytes(int N) {
-    return 2 * 2 * 8 * (size_t)(N + 2) + 2 * 2 * 16 * (size_t)(N + 1) + 2 * 4 * (size_t)(N + 2);
+// (the planes are sized by the block, kB = 64 .. 512 threads >= N, so that every LDS address is a register plus a literal)
+__host__ __device__ inline size_t bwd_fast_lds_bytes(int kB) {
+    return 2 * 2 * 8 * (size_t)(kB + 2) + 2 * 2 * 16 * (size_t)(kB + 2) + 2 * 4 * (size_t)(kB + 2);
 }
-__global__ __launch_bounds__(512) void macro_rollout_bwd_fast_kernel(
+template <int kB>
+__global__ __launch_bounds__(kB) __attribute__((amdgpu_waves_per_eu(4, 4))) void macro_rollout_bwd_fast_kernel(     // <= 128 VGPRs
     int L, int N, int T, double cc, const float4 *__restrict__ tape,
     const float *__restrict__ g_r_in, const float *__restrict__ g_y_in,
     float *__restrict__ g_r_out, float *__restrict__ g_y_out, double *__restrict__ g_ghost, dhts_error *err) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = blockIdx.x;
     const int t = threadIdx.x;
-    const int B = blockDim.x;
-    const int P = N + 2;
-    float4 *XA = reinterpret_cast<float4 *>(lds), *XB = XA + 2 * (N + 1);             // [parity][N + 1]
-    v2f *C0 = reinterpret_cast<v2f *>(XB + 2 * (N + 1)), *C2 = C0 + 2 * P;            // [parity][P]
-    unsigned *STAMP = reinterpret_cast<unsigned *>(C2 + 2 * P);                       // [parity][P]
+    constexpr int B = kB;
+    constexpr int P = kB + 2;
+    float4 *XA = reinterpret_cast<float4 *>(lds), *XB = XA + 2 * P;                   // [copy][P]
+    v2f *C0 = reinterpret_cast<v2f *>(XB + 2 * P), *C2 = C0 + 2 * P;                  // [copy][P]
+    unsigned *STAMP = reinterpret_cast<unsigned *>(C2 + 2 * P);                       // [copy][P]
     const size_t base = (size_t)lane * N;
     const TapeGeom geo = tape_geom(N);
     const v2f cf = {(float)cc, (float)cc}, ncf = {(float)(-cc), (float)(-cc)};
@@ -594,87 +596,89 @@ __global__ __launch_bounds__(512) void macro_rollout_bwd_fast_kernel(
     const char *tb = reinterpret_cast<const char *>(tape) + (size_t)lane * row_bytes;
     const size_t stride = (size_t)L * row_bytes;
     // (plain variables and macros, not structs handed to lambdas: those end up in scratch memory)
+    // The two LDS copies are told apart by Q = (T - 1 - step) & 1; the three tape rows a step reads from are running pointers
+    // (no multiplications in the loop).
+    const char *pS = tb + (size_t)(T > 5 ? T - 5 : 0) * stride;      // row of step - 4 in the interval of `step`
+    const char *pE = tb + (size_t)(T > 6 ? T - 6 : 0) * stride;      // row of step - 5
+    const char *pC = tb + (size_t)(T > 9 ? T - 9 : 0) * stride;      // row of step - 8
 #define DHTS_ROW(step_) (tb + (size_t)((step_) > 0 ? (step_) : 0) * stride)
-#define DHTS_LOAD_CNT(step_, c_) c_ = *reinterpret_cast<const int *>(DHTS_ROW(step_) + off_c);
-#define DHTS_LOAD_S(step_, sl_, sr_)                                                     \
+#define DHTS_LOAD_CNT(rb_, c_) c_ = *reinterpret_cast<const int *>((rb_) + off_c);
+#define DHTS_LOAD_S(rb_, sl_, sr_)                                                       \
     {                                                                                    \
-        const char *rb_ = DHTS_ROW(step_);                                               \
-        sl_ = *reinterpret_cast<const TapeFp *>(rb_ + off_sl);                           \
-        sr_ = *reinterpret_cast<const TapeFp *>(rb_ + off_sr);                           \
+        sl_ = *reinterpret_cast<const TapeFp *>((rb_) + off_sl);                         \
+        sr_ = *reinterpret_cast<const TapeFp *>((rb_) + off_sr);                         \
     }
-#define DHTS_LOAD_E(step_, c_, ea_, eb_, ix_)                                            \
+#define DHTS_LOAD_E(rb_, c_, ea_, eb_, ix_)                                              \
     if (t < (c_)) {                                                                      \
-        const char *rb_ = DHTS_ROW(step_);                                               \
-        ix_ = *reinterpret_cast<const unsigned short *>(rb_ + off_i);                    \
-        ea_ = *reinterpret_cast<const float4 *>(rb_ + off_e);                            \
-        eb_ = *reinterpret_cast<const float4 *>(rb_ + off_e + 16);                       \
+        ix_ = *reinterpret_cast<const unsigned short *>((rb_) + off_i);                  \
+        ea_ = *reinterpret_cast<const float4 *>((rb_) + off_e);                          \
+        eb_ = *reinterpret_cast<const float4 *>((rb_) + off_e + 16);                     \
     }
-    // exception j of step_ to its interface, in the copy of that step's parity
-#define DHTS_SCATTER(step_, c_, ea_, eb_, ix_)                                           \
+    // exception j of step_ to its interface, in LDS copy Q
+#define DHTS_SCATTER(step_, Q, c_, ea_, eb_, ix_)                                        \
     {                                                                                    \
-        const int o_ = ((step_) & 1) * (N + 1), os_ = ((step_) & 1) * P;                 \
         if ((t < (c_)) & (ix_ <= (unsigned)N)) {                                         \
-            XA[o_ + ix_] = ea_; XB[o_ + ix_] = eb_; STAMP[os_ + ix_] = (unsigned)(step_) + 1u; \
+            XA[(Q) * P + ix_] = ea_; XB[(Q) * P + ix_] = eb_; STAMP[(Q) * P + ix_] = (unsigned)(step_) + 1u; \
         }                                                                                \
-        if ((c_) > B) scatter_rest(step_, c_);                                           \
+        if ((c_) > B) scatter_rest(step_, c_, XA + (Q) * P, XB + (Q) * P, STAMP + (Q) * P); \
     }
     // more exceptions than threads (the one-phase forward kernel flags every interface): the rest, without prefetch
-    auto scatter_rest = [&](int step, int cnt) {
+    auto scatter_rest = [&](int step, int cnt, float4 *xa, float4 *xb, unsigned *st) {
         const float4 *row = reinterpret_cast<const float4 *>(DHTS_ROW(step));
         const unsigned short *I = tape_idx(tape_hdr(row, geo), geo);
         const float4 *E = row + geo.s_f4 + geo.h_f4;
-        const int o = (step & 1) * (N + 1), os = (step & 1) * P;
         if (cnt > N + 1) cnt = N + 1;
         for (int j = t + B; j < cnt; j += B) {
             const int i = I[j];
-            if (i <= N) { XA[o + i] = E[2 * j]; XB[o + i] = E[2 * j + 1]; STAMP[os + i] = (unsigned)step + 1u; }
+            if (i <= N) { xa[i] = E[2 * j]; xb[i] = E[2 * j + 1]; st[i] = (unsigned)step + 1u; }
         }
     };
-    // The blocks of step s_ from its products: the trivial ones in (sl_, sr_), the others in the LDS copy of the step's parity
-    // (both stamps are read before either product)
-#define DHTS_BLOCKS(s_, sl_, sr_)                                                        \
+    // The blocks of step s_ from its products: the trivial ones in (sl_, sr_), the others in LDS copy Q (both stamps are read
+    // before either product)
+#define DHTS_BLOCKS(s_, Q, sl_, sr_)                                                     \
     {                                                                                    \
-        const int o_ = ((s_) & 1) * (N + 1), os_ = ((s_) & 1) * P;                       \
         const unsigned tag_ = (unsigned)(s_) + 1u;                                       \
-        const unsigned st0_ = STAMP[os_ + k], st1_ = STAMP[os_ + k + 1];                 \
+        const unsigned st0_ = STAMP[(Q) * P + k], st1_ = STAMP[(Q) * P + k + 1];         \
         float4 aL = tape_trivial_A(sl_), bL = zero4, aR = tape_trivial_A(sr_), bR = zero4; \
-        if (st0_ == tag_) { aL = XA[o_ + k]; bL = XB[o_ + k]; }                          \
-        if (st1_ == tag_) { aR = XA[o_ + k + 1]; bR = XB[o_ + k + 1]; }                  \
+        if (st0_ == tag_) { aL = XA[(Q) * P + k]; bL = XB[(Q) * P + k]; }                \
+        if (st1_ == tag_) { aR = XA[(Q) * P + k + 1]; bR = XB[(Q) * P + k + 1]; }        \
         d0lo = ncf * -v2f{aL.x, aL.y}; d0hi = ncf * -v2f{aL.z, aL.w};                    \
         d2lo = ncf * v2f{bR.x, bR.y}; d2hi = ncf * v2f{bR.z, bR.w};                      \
         d1lo = e0 - cf * (v2f{aR.x, aR.y} - v2f{bL.x, bL.y});                            \
         d1hi = e1 - cf * (v2f{aR.z, aR.w} - v2f{bL.z, bL.w});                            \
     }
-    // One barrier interval, step s.  Behind the barrier only what depends on the neighbours: the cell's cotangent after step
-    // s + 1 (its own part c1v plus what the two neighbours left in C0 / C2), the three products with the blocks of step s --
-    // formed in the previous interval -- and their hand-over.  Then, off that chain: the blocks of step s - 1 (trivial
-    // products in (sl_, sr_), exceptions scattered one interval ago), the exceptions of step s - 2 from (ea_ .. ec_) to LDS, and
-    // the refills: exceptions of step s - 5 (their count cq_ arrived three intervals ago), the count of step s - 8, the trivial
-    // products of step s - 4.  Everything read from the tape is in flight for three intervals (2 workgroups x 3 steps x 9 KB
-    // per CU: what 6 TB/s at ~2 us of latency need).
-#define DHTS_STEP(s_, sl_, sr_, ea_, eb_, ix_, ec_, cq_)                                 \
+    // One barrier interval, step s, LDS copy Q (the neighbouring steps use copy R = 1 - Q).  Behind the barrier only what
+    // depends on the neighbours: the cell's cotangent after step s + 1 (its own part c1v plus what the two neighbours left in
+    // C0 / C2), the three products with the blocks of step s -- formed in the previous interval -- and their hand-over.  Then,
+    // off that chain: the blocks of step s - 1 (trivial products in (sl_, sr_), exceptions scattered one interval ago), the
+    // exceptions of step s - 2 from (ea_ .. ec_) to LDS, and the refills: exceptions of step s - 5 (their count cq_ arrived three
+    // intervals ago), the count of step s - 8, the trivial products of step s - 4.  Everything read from the tape is in flight
+    // for three intervals (2 workgroups x 3 steps x 9 KB per CU: what 6 TB/s at ~2 us of latency need).
+#define DHTS_STEP(s_, Q, R, sl_, sr_, ea_, eb_, ix_, ec_, cq_)                           \
     {                                                                                    \
         if (vk) {                                                                        \
-            const int os_ = ((s_) & 1) * P, op_ = (((s_) + 1) & 1) * P;                   \
-            g = (c1v + C2[op_ + k + 1]) + C0[op_ + k + 1];                               \
+            g = (c1v + C2[(R) * P + k + 1]) + C0[(R) * P + k + 1];                       \
             if (bad_step < 0 && !(isfinite(g.x) && isfinite(g.y))) bad_step = ((s_) + 1 < T) ? (s_) + 1 : T - 1; \
             const v2f c0 = pk_dot(d0lo, d0hi, g), c2v = pk_dot(d2lo, d2hi, g);           \
             c1v = pk_dot(d1lo, d1hi, g);                                                 \
             /* c0 of cell k goes to cell k-1 (slot k), c2 of cell k goes to cell k+1 (slot k+2) */ \
-            C0[os_ + k] = c0;                                                            \
-            C2[os_ + k + 2] = c2v;                                                       \
+            C0[(Q) * P + k] = c0;                                                        \
+            C2[(Q) * P + k + 2] = c2v;                                                   \
             if (__builtin_amdgcn_ballot_w64((k == 0) | (k == N - 1))) {                  \
                 asm volatile("" ::: "memory");          /* a real branch: two wavefronts of the workgroup take it */ \
                 if (k == 0) { gh_r += (double)c0.x; gh_y += (double)c0.y; }              \
                 if (k == N - 1) { gh_r += (double)c2v.x; gh_y += (double)c2v.y; }        \
             }                                                                            \
-            if ((s_) >= 1) DHTS_BLOCKS((s_) - 1, sl_, sr_)                               \
+            if ((s_) >= 1) DHTS_BLOCKS((s_) - 1, R, sl_, sr_)                            \
         }                                                                                \
-        if ((s_) >= 2) DHTS_SCATTER((s_) - 2, ec_, ea_, eb_, ix_);                       \
+        if ((s_) >= 2) DHTS_SCATTER((s_) - 2, Q, ec_, ea_, eb_, ix_);                    \
         ec_ = cq_;                                                                       \
-        DHTS_LOAD_E((s_) - 5, ec_, ea_, eb_, ix_);                                       \
-        DHTS_LOAD_CNT((s_) - 8, cq_);                                                    \
-        DHTS_LOAD_S((s_) - 4, sl_, sr_);                                                 \
+        DHTS_LOAD_E(pE, ec_, ea_, eb_, ix_);                                             \
+        DHTS_LOAD_CNT(pC, cq_);                                                          \
+        DHTS_LOAD_S(pS, sl_, sr_);                                                       \
+        pS -= ((s_) > 4) ? stride : 0;                                                   \
+        pE -= ((s_) > 5) ? stride : 0;                                                   \
+        pC -= ((s_) > 8) ? stride : 0;                                                   \
         lds_only_barrier();                                                              \
     }
     // register set A serves the steps T - 1, T - 4, ..., set B the steps T - 2, T - 5, ..., set C the steps T - 3, T - 6, ...
@@ -684,43 +688,45 @@ __global__ __launch_bounds__(512) void macro_rollout_bwd_fast_kernel(
     int ecA, ecB, ecC, cqA, cqB, cqC;
     v2f d0lo = zero2, d0hi = zero2, d1lo = zero2, d1hi = zero2, d2lo = zero2, d2hi = zero2;
     v2f c1v = g;                                          // "after step T": the incoming cotangent; C0 / C2 are zero
-    DHTS_LOAD_CNT(T - 1, ecA);
-    DHTS_LOAD_CNT(T - 2, ecB);
-    DHTS_LOAD_CNT(T - 3, ecC);
-    DHTS_LOAD_CNT(T - 4, cqA);
-    DHTS_LOAD_CNT(T - 5, cqB);
-    DHTS_LOAD_CNT(T - 6, cqC);
-    DHTS_LOAD_E(T - 1, ecA, eaA, ebA, ixA);
-    DHTS_LOAD_E(T - 2, ecB, eaB, ebB, ixB);
-    DHTS_LOAD_E(T - 3, ecC, eaC, ebC, ixC);
-    DHTS_LOAD_S(T - 1, slA, srA);
-    DHTS_LOAD_S(T - 2, slB, srB);
-    DHTS_LOAD_S(T - 3, slC, srC);
+    DHTS_LOAD_CNT(DHTS_ROW(T - 1), ecA);
+    DHTS_LOAD_CNT(DHTS_ROW(T - 2), ecB);
+    DHTS_LOAD_CNT(DHTS_ROW(T - 3), ecC);
+    DHTS_LOAD_CNT(DHTS_ROW(T - 4), cqA);
+    DHTS_LOAD_CNT(DHTS_ROW(T - 5), cqB);
+    DHTS_LOAD_CNT(DHTS_ROW(T - 6), cqC);
+    DHTS_LOAD_E(DHTS_ROW(T - 1), ecA, eaA, ebA, ixA);
+    DHTS_LOAD_E(DHTS_ROW(T - 2), ecB, eaB, ebB, ixB);
+    DHTS_LOAD_E(DHTS_ROW(T - 3), ecC, eaC, ebC, ixC);
+    DHTS_LOAD_S(DHTS_ROW(T - 1), slA, srA);
+    DHTS_LOAD_S(DHTS_ROW(T - 2), slB, srB);
+    DHTS_LOAD_S(DHTS_ROW(T - 3), slC, srC);
     __syncthreads();                                     // the zeroed planes
-    DHTS_SCATTER(T - 1, ecA, eaA, ebA, ixA);
-    if (T >= 2) DHTS_SCATTER(T - 2, ecB, eaB, ebB, ixB);
+    DHTS_SCATTER(T - 1, 0, ecA, eaA, ebA, ixA);
+    if (T >= 2) DHTS_SCATTER(T - 2, 1, ecB, eaB, ebB, ixB);
     ecA = cqA;
     ecB = cqB;
-    DHTS_LOAD_E(T - 4, ecA, eaA, ebA, ixA);
-    DHTS_LOAD_E(T - 5, ecB, eaB, ebB, ixB);
-    DHTS_LOAD_CNT(T - 7, cqA);
-    DHTS_LOAD_CNT(T - 8, cqB);
+    DHTS_LOAD_E(DHTS_ROW(T - 4), ecA, eaA, ebA, ixA);
+    DHTS_LOAD_E(DHTS_ROW(T - 5), ecB, eaB, ebB, ixB);
+    DHTS_LOAD_CNT(DHTS_ROW(T - 7), cqA);
+    DHTS_LOAD_CNT(DHTS_ROW(T - 8), cqB);
     lds_only_barrier();
-    if (vk) DHTS_BLOCKS(T - 1, slA, srA)
-    DHTS_LOAD_S(T - 4, slA, srA);
+    if (vk) DHTS_BLOCKS(T - 1, 0, slA, srA)
+    DHTS_LOAD_S(DHTS_ROW(T - 4), slA, srA);
     // on entry to the interval of a step s of class A: the blocks of s are in registers, the exceptions of s - 1 in LDS;
     // (slB, srB) = S(s - 1), set C holds E(s - 2) and cqC the count of s - 5; (slC, srC) = S(s - 2), set A holds E(s - 3) and
     // cqA the count of s - 6; (slA, srA) = S(s - 3), set B holds E(s - 4) and cqB the count of s - 7
-    int step = T - 1;
+    int step = T - 1, q = 0;
     for (; step >= 2; step -= 3) {
-        DHTS_STEP(step, slB, srB, eaC, ebC, ixC, ecC, cqC)
-        DHTS_STEP(step - 1, slC, srC, eaA, ebA, ixA, ecA, cqA)
-        DHTS_STEP(step - 2, slA, srA, eaB, ebB, ixB, ecB, cqB)
+        DHTS_STEP(step, q, q ^ 1, slB, srB, eaC, ebC, ixC, ecC, cqC)
+        DHTS_STEP(step - 1, q ^ 1, q, slC, srC, eaA, ebA, ixA, ecA, cqA)
+        DHTS_STEP(step - 2, q, q ^ 1, slA, srA, eaB, ebB, ixB, ecB, cqB)
+        q ^= 1;
     }
-    if (step >= 0) DHTS_STEP(step, slB, srB, eaC, ebC, ixC, ecC, cqC)
-    if (step >= 1) DHTS_STEP(step - 1, slC, srC, eaA, ebA, ixA, ecA, cqA)
-    if (vk) {                                            // after step 0
-        g = (c1v + C2[k + 1]) + C0[k + 1];
+    if (step >= 0) DHTS_STEP(step, q, q ^ 1, slB, srB, eaC, ebC, ixC, ecC, cqC)
+    if (step >= 1) DHTS_STEP(step - 1, q ^ 1, q, slC, srC, eaA, ebA, ixA, ecA, cqA)
+    if (vk) {                                            // after step 0, whose copy is Q = (T - 1) & 1
+        const int oq = ((T - 1) & 1) * P;
+        g = (c1v + C2[oq + k + 1]) + C0[oq + k + 1];
         if (bad_step < 0 && !(isfinite(g.x) && isfinite(g.y))) bad_step = 0;
     }
 #undef DHTS_BLOCKS
@@ -995,20 +1001,30 @@ static int macro_rollout_bwd_launch(const dhts_macro_desc *d, int T, const float
     const int N = d->n_cells;
     int B = padded64(N);
     if (B > 512) B = 512;
-    const bool fast = N >= 2 && N <= B && g_hist == nullptr && T > 0;      // (T = 0: no tape to prefetch from)
-    const size_t planes = sizeof(float) * (size_t)((6 * (N + 2) + 3) & ~3);
-    const size_t lds = fast ? bwd_fast_lds_bytes(N) : planes + 2 * (size_t)(N + 1);
+    const bool fast = N >= 2 && N <= 512 && g_hist == nullptr && T > 0;      // (T = 0: no tape to prefetch from)
+    if (fast) {
+        const int kB = N <= 64 ? 64 : (N <= 128 ? 128 : (N <= 256 ? 256 : 512));
+        const size_t lds = bwd_fast_lds_bytes(kB);
+        const float4 *tp = reinterpret_cast<const float4 *>(tape);
+        const double cc = d->dt / d->dx;
+        hipStream_t st = (hipStream_t)stream;
+        if (kB == 64)
+            macro_rollout_bwd_fast_kernel<64><<<d->n_lanes, 64, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_r_out, g_y_out, g_ghost, err);
+        else if (kB == 128)
+            macro_rollout_bwd_fast_kernel<128><<<d->n_lanes, 128, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_r_out, g_y_out, g_ghost, err);
+        else if (kB == 256)
+            macro_rollout_bwd_fast_kernel<256><<<d->n_lanes, 256, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_r_out, g_y_out, g_ghost, err);
+        else
+            macro_rollout_bwd_fast_kernel<512><<<d->n_lanes, 512, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_r_out, g_y_out, g_ghost, err);
+        return launch_status();
+    }
+    const size_t lds = sizeof(float) * (size_t)((6 * (N + 2) + 3) & ~3) + 2 * (size_t)(N + 1);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
-    const void *fn = fast ? (const void *)macro_rollout_bwd_fast_kernel : (const void *)macro_rollout_bwd_kernel;
-    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)macro_rollout_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_LAUNCH;
-    if (fast)
-        macro_rollout_bwd_fast_kernel<<<d->n_lanes, B, lds, (hipStream_t)stream>>>(
-            d->n_lanes, N, T, d->dt / d->dx, reinterpret_cast<const float4 *>(tape), g_r, g_y, g_r_out, g_y_out, g_ghost, err);
-    else
-        macro_rollout_bwd_kernel<<<d->n_lanes, B, lds, (hipStream_t)stream>>>(
-            d->n_lanes, N, T, d->dt / d->dx, reinterpret_cast<const float4 *>(tape), g_r, g_y, g_hist, g_r_out, g_y_out, g_ghost,
-            err);
+    macro_rollout_bwd_kernel<<<d->n_lanes, B, lds, (hipStream_t)stream>>>(
+        d->n_lanes, N, T, d->dt / d->dx, reinterpret_cast<const float4 *>(tape), g_r, g_y, g_hist, g_r_out, g_y_out, g_ghost, err);
     return launch_status();
 }
 
