@@ -43,8 +43,8 @@ MICRO_TAPE_B = 32           # float32 [2][2][2] per vehicle-step (road/lane/dmic
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)      # the first passes of a process run ~8 % slower (clock ramp)
     ap.add_argument("--workload", choices=["macro", "micro", "itscp_macro", "itscp_hybrid"], default="macro")
     ap.add_argument("--lanes", type=int, default=0, help="override lanes per GPU")
     ap.add_argument("--cells", type=int, default=0, help="override cells / vehicles per lane")
@@ -102,9 +102,11 @@ class MacroWorkload:
     unit_bytes = MACRO_TAPE_B
     unit_name = "cell-steps/s"
     # what each kernel actually runs into (PMC counters and s_memtime stamps)
-    limiter = {"rollout_fwd": "instruction issue in phase 1 + the serial queue pass of phase 2 (latency); HBM writes at ~3.9 TB/s, "
-                              "a store-only kernel with this pattern reaches 6.5-6.9",
-               "rollout_bwd": "hbm (reads at ~6.1 TB/s of the ~6.5 a streaming kernel reaches)"}
+    limiter = {"rollout_fwd": "instruction issue (vector + scalar: ~54 % of the SIMD cycles carry a vector instruction at 4 wavefronts per "
+                              "SIMD) and the serial queue pass of phase 2; the tape it writes is 9.2 GB (2.3 TB/s): the kernel without "
+                              "any tape takes 3.77 of the 4.04 ms",
+               "rollout_bwd": "instruction issue + LDS / barrier latency at 4 wavefronts per SIMD (122 VGPRs hold three steps of tape in "
+                              "flight); HBM reads at ~4.7 TB/s"}
 
     def __init__(self, dev, rank, L, N, T):
         from dhts import ops
@@ -607,7 +609,8 @@ def main():
                          "achieved_algorithmic": k["algorithmic_GBps"], "frac_algorithmic": k["algorithmic_GBps"] / HBM_PEAK_GBS,
                          "limiter": w.limiter.get(dom, "hbm"),
                          "note": "achieved = bytes the kernel moves (its compact tape: the same information as the reference's dqs "
-                                 "blocks, which the reverse sweep rebuilds) / HIP-event time of the launch; *_algorithmic = the "
+                                 "blocks, which the reverse sweep rebuilds; macro: counted from the tape's own row headers after "
+                                 "the run, in whole 128-byte lines) / HIP-event time of the launch; *_algorithmic = the "
                                  "reference's tape bytes (48 B per cell-step, 32 B per vehicle-step) / the same time"},
             "whole_path": {"moved_GBps": 2 * w.moved_bytes_per_launch() * args.steps / elapsed / 1e9,
                            "frac_of_peak": 2 * w.moved_bytes_per_launch() * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
@@ -615,6 +618,8 @@ def main():
             "kernels": kernels,
             "loss_last_pass": flat.tolist()[-1],          # summed over ranks by the all-reduce
         }
+        if hasattr(w, "tape_census"):
+            out["roofline"]["tape_census"] = w.tape_census()
         if parts is not None:
             out["allreduce_check"] = {"reduced": flat.tolist()[-1], "sum_of_rank_parts": float(parts[:, -1].double().sum()),
                                       "rank_parts": parts[:, -1].tolist(),
@@ -622,7 +627,7 @@ def main():
                                       if shared_grad else 0.0}
         if world == 1:
             if args.workload == "macro" and not args.lanes and not args.cells and not args.time_steps and not args.no_also:
-                del w.tape            # 17 GB back to the allocator before the other workloads take theirs
+                del w.tape            # 24 GB back to the allocator before the other workloads take theirs
                 torch.cuda.empty_cache()
                 out["also"] = [also_record("micro", dev), also_record("itscp_hybrid", dev)]
             if not args.no_cpu_baseline:

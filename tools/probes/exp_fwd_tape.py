@@ -34,3 +34,23 @@ print("fwd without tape min / median ms: %.3f %.3f" % timed(lambda: ops.macro_ro
 g_r, g_y = 2.0 * w.out[0], torch.zeros_like(w.out[0])
 print("bwd              min / median ms: %.3f %.3f" % timed(lambda: ops.macro_rollout_bwd(w.desc, w.T, w.tape, g_r, g_y, err=w.err, out=w.gout, g_ghost=w.g_ghost)))
 print(w.tape_census())
+
+# the two kernels alternating, as in a training loop (bench.py's one_pass without the glue kernels in between)
+ev = []
+for i in range(10):
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record()
+    ops.macro_rollout_fwd(w.desc, w.T, w.r0, y0, w.u0, q0, w.ghost, tape=w.tape, err=w.err, out=w.out)
+    e[1].record()
+    ops.macro_rollout_bwd(w.desc, w.T, w.tape, g_r, g_y, err=w.err, out=w.gout, g_ghost=w.g_ghost)
+    e[2].record()
+    ev.append(e)
+torch.cuda.synchronize()
+print("alternating: fwd ms", ["%.3f" % e[0].elapsed_time(e[1]) for e in ev[2:]])
+print("alternating: bwd ms", ["%.3f" % e[1].elapsed_time(e[2]) for e in ev[2:]])
+w.ev = []
+for _ in range(6):
+    w.one_pass(record=True)
+torch.cuda.synchronize()
+print("one_pass: fwd ms", ["%.3f" % e[0].elapsed_time(e[1]) for e in w.ev[1:]])
+print("one_pass: bwd ms", ["%.3f" % e[2].elapsed_time(e[3]) for e in w.ev[1:]])
