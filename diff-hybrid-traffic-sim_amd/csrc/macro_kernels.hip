@@ -14,6 +14,8 @@
 // Reference: road/lane/_macro_lane.py:83-146, road/lane/dmacro_lane.py:96-132 and :277-309.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/dhts.h"
 #include "arz_device.hpp"
 
@@ -286,7 +288,10 @@ __device__ __forceinline__ void cell_glue_pre(float r, float y, float umf, const
 //     when the phases alternate: neither chain got shorter by running beside the other.
 // Dynamic LDS: cell records [N + 2] (index c + 1 = cell c, 0 and N + 1 the ghosts; updated in place) | flux double2 [N + 1]
 // | queue int [N + 2] | 2 counters.
-template <bool kOnePass>       // one 64-cell pass per wavefront (p = 1): the per-thread addresses are loop invariants
+// kOnePass: one 64-cell pass per wavefront (p = 1): the per-thread addresses are loop invariants; kFull: every thread owns a cell
+// (N = blockDim.x): no validity masks; kHist: the state history may be asked for.  The step body is instantiated with
+// literal (finish the previous step, start this one) flags: first step, steps in between, last.
+template <bool kOnePass, bool kFull, bool kHist>
 __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
     int L, int N, int T, int p_arg, double dt, double dx, double um,
     const float *__restrict__ r_in, const float *__restrict__ y_in, const float *__restrict__ u_in,
@@ -336,22 +341,22 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
 
     // the tape row / history block of the step, advanced by one step's worth per trip (no 64-bit multiplications in the loop)
     float4 *tp_run = tape ? tape + (size_t)lane * geo.row_f4 : nullptr;
-    float *hp_run = hist ? hist + (size_t)lane * 3 * N : nullptr;
+    float *hp_run = (kHist && hist) ? hist + (size_t)lane * 3 * N : nullptr;
     const size_t tp_stride = (size_t)L * geo.row_f4, hp_stride = (size_t)L * 3 * N;
 
-    for (int n = 0; n <= T; ++n) {
-        const bool upd = n > 0;                      // finish step n - 1
-        const bool solve = n < T;                    // start step n
+    auto body = [&](auto upd_c, auto solve_c, const int n) {
+        constexpr bool upd = decltype(upd_c)::value;       // finish step n - 1
+        constexpr bool solve = decltype(solve_c)::value;   // start step n
         float4 *tp = solve ? tp_run : nullptr;
         TapeFp *tS = reinterpret_cast<TapeFp *>(tp);
         unsigned *tH = tape_hdr(tp, geo);
-        float *hp = upd ? hp_run : nullptr;
+        float *hp = (kHist && upd) ? hp_run : nullptr;
         if (tp_run) tp_run += tp_stride;
-        if (hp_run && upd) hp_run += hp_stride;
+        if (kHist && hp_run && upd) hp_run += hp_stride;
         int *cnt = CNT + (n & 1);
         for (int j = 0; j < p; ++j) {
             const int i = lo + (j << 6) + t;                // cell i and its left interface i
-            const bool vc = i < N;
+            const bool vc = kFull || i < N;
             const unsigned ic = (unsigned)(vc ? i : N - 1);
             CellRec *own = CR + ic + 1;
             float4 st = own->st;
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
             if (nt) Q[atomicAdd(cnt, 1)] = i;
             if (tp && vc) tS[ic] = TapeFp{fp[0], fp[2], fp[3]};
         }
-        if (!solve) break;
+        if (!solve) return;
         lds_only_barrier();
         // ---- phase 2: the queued interfaces ----
         int k0 = tid - (rot << 6);
@@ -425,6 +430,15 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
         if (tid == 0) CNT[(n + 1) & 1] = 1;
         if (++rot == Wc) rot = 0;
         lds_only_barrier();
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    if (T == 0) {
+        body(no{}, no{}, 0);
+    } else {
+        body(no{}, yes{}, 0);
+        for (int n = 1; n < T; ++n) body(yes{}, yes{}, n);
+        body(yes{}, no{}, T);
     }
     if (fault_step >= 0) raise_fault(err, DHTS_FAULT_CFL, fault_step, lane, fault_index);
 }
@@ -927,8 +941,9 @@ static int macro_fwd2_launch(const dhts_macro_desc *d, int T,
     const size_t lds = sizeof(CellRec) * (size_t)(N + 2) + 16 * (size_t)(N + 1) + sizeof(int) * (size_t)(N + 2) + 16;
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     if (lds > 64 * 1024 &&
-        (hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-         hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess))
+        (hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+         hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+         hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess))
         return DHTS_E_LAUNCH;
     // Wavefronts per lane: one 64-cell pass per wavefront whenever the lane fits 16 of them (measured, tools/sweep_fwd_waves.py,
     // forward ms for 1 / 2 / 4 / 8 / 16 waves per lane: 1024 x 512: 7.0 / 5.0 / 4.9 / 4.6 / 4.5; 4096 x 256: 12.9 / 11.8 / 10.4 /
@@ -939,14 +954,15 @@ static int macro_fwd2_launch(const dhts_macro_desc *d, int T,
     if (W < 1) W = 1;
     int p = (N + 64 * W - 1) / (64 * W);
     W = (N + 64 * p - 1) / (64 * p);
-    if (p == 1)
-        macro_rollout_fwd2_kernel<true><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(
-            d->n_lanes, N, T, p, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out,
-            reinterpret_cast<float4 *>(tape), hist, err);
+#define DHTS_FWD2_ARGS d->n_lanes, N, T, p, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, \
+                       reinterpret_cast<float4 *>(tape), hist, err
+    if (p == 1 && N == 64 * W && hist == nullptr)
+        macro_rollout_fwd2_kernel<true, true, false><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(DHTS_FWD2_ARGS);
+    else if (p == 1)
+        macro_rollout_fwd2_kernel<true, false, true><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(DHTS_FWD2_ARGS);
     else
-        macro_rollout_fwd2_kernel<false><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(
-            d->n_lanes, N, T, p, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out,
-            reinterpret_cast<float4 *>(tape), hist, err);
+        macro_rollout_fwd2_kernel<false, false, true><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(DHTS_FWD2_ARGS);
+#undef DHTS_FWD2_ARGS
     return launch_status();
 }
 
