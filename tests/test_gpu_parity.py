@@ -370,6 +370,51 @@ def test_macro_rollout_short_horizons(cuda, oracle, T):
     assert rel_max(out[0].cpu().numpy(), f["rT"]) <= 1e-6 and rel_max(out[2].cpu().numpy(), f["uT"]) <= 1e-6
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("N,T", [(2, 5), (64, 9), (130, 31), (256, 16), (512, 23)])
+def test_macro_reverse_sweeps_agree_on_one_tape(cuda, N, T, variant):
+    """The rollout's three ways from a tape to a gradient give the same bits: the pipelined one-cell-per-thread kernel (every
+    block size, tapes of the two-phase forward kernel and -- all interfaces exceptions, more of them than threads at N = 512
+    -- of the one-phase kernel), the general kernel (forced by a zero per-step cotangent), and the single-step operator's
+    sweep over the blocks dhts_macro_tape_expand writes out, one step at a time.  (Against the oracle:
+    test_macro_rollout_vs_oracle_sizes and the goldens.)"""
+    import torch
+    from dhts import _lib, ops
+    rng = np.random.default_rng(100 + N)
+    L, dt, dx, um = 5, 0.01, 5.0, 30.0
+    r0 = rng.uniform(0.0, 1.0, (L, N)).astype(np.float32)
+    r0[1, : min(N, 3)] = 0.0                       # vacuum at the left boundary
+    u0 = rng.uniform(0.0, um, (L, N)).astype(np.float32)
+    gr = rng.uniform(0.05, 0.95, (L, 2)).astype(np.float32)
+    gu = rng.uniform(0.0, um, (L, 2)).astype(np.float32)
+    r, u = T_(r0, cuda), T_(u0, cuda)
+    y, q = ops.macro_state_from_ru(r, u, um)
+    tgr, tgu = T_(gr, cuda), T_(gu, cuda)
+    gy, gq = ops.macro_state_from_ru(tgr, tgu, um)
+    ghost = torch.stack([tgr, gy, tgu, gq], dim=-1).contiguous()
+    desc = ops.macro_desc(L, N, dt, dx, um)
+    tape = torch.full((ops.macro_tape_numel(desc, T),), float("nan"), device=cuda)     # unwritten parts must never be read
+    try:
+        assert _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_VARIANT, variant) == 0
+        rT, yT, uT, _ = ops.macro_rollout_fwd(desc, T, r, y, u, q, ghost, tape=tape)
+    finally:
+        _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_VARIANT, 0)
+    g_r, g_y = 2 * rT, torch.zeros_like(rT)
+    ops.macro_u_tap_bwd(rT, yT, 2 * uT, g_r, g_y, um)
+    fast = ops.macro_rollout_bwd(desc, T, tape, g_r, g_y)
+    general = ops.macro_rollout_bwd(desc, T, tape, g_r, g_y, g_hist=torch.zeros(T, L, 2, N, device=cuda))
+    assert torch.equal(fast[0], general[0]) and torch.equal(fast[1], general[1]) and torch.equal(fast[2], general[2])
+    dqs = ops.macro_tape_expand(desc, T, tape)                 # [T][L][3][Np][4]
+    assert torch.isfinite(dqs).all()
+    a, b = g_r.clone(), g_y.clone()
+    gh = torch.zeros(L, 2, 2, dtype=torch.float64, device=cuda)
+    for t in range(T - 1, -1, -1):
+        a, b, g1 = ops.macro_step_bwd(desc, dqs[t].contiguous(), a, b)
+        gh += g1
+    assert torch.equal(fast[0], a) and torch.equal(fast[1], b)
+    assert rel_max(fast[2].cpu().numpy(), gh.cpu().numpy()) <= 1e-6      # (the ghosts' sums differ in the order of their doubles)
+
+
 def test_macro_tape_matches_oracle_over_rollout(cuda, oracle):
     """The whole Jacobian tape of a rollout, entry by entry."""
     import torch
