@@ -37,7 +37,9 @@ struct __attribute__((packed, aligned(4))) MicroTape3 { float e2, e3, l3; };
 // grid = L workgroups of 64 * kW threads; dynamic LDS = 2 * (V + 1) floats (kW = 1) or twice that (kW > 1: the state
 // ping-pongs between two buffers so that one workgroup barrier per step separates a step's reads from the next step's).
 // kW wavefronts per lane: thread `tid` of pass j owns slot (64 kW) j + tid.
-template <int K, int kW, bool kCompact>
+// kFull: every slot of every lane holds a vehicle (no counts, V = 64 kW K): no validity masks, no index clamps, and only the
+// last pass can hold the head vehicle.
+template <int K, int kW, bool kCompact, bool kFull>
 __global__ __launch_bounds__(64 * kW) void micro_rollout_fwd_kernel(
     int L, int V, int T, double dt,
     const float *__restrict__ p_in, const float *__restrict__ v_in, const int32_t *__restrict__ count,
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(64 * kW) void micro_rollout_fwd_kernel(
     constexpr int kStride = 64 * kW;
     float *Sp = lds, *Sv = lds + (V + 1);
     const size_t base = (size_t)lane * V;
-    const int n = count ? count[lane] : V;
+    const int n = (!kFull && count) ? count[lane] : V;
     const int Vp = (V + 63) & ~63;
     const size_t plane = (size_t)L * V;
 
@@ -93,17 +95,17 @@ __global__ __launch_bounds__(64 * kW) void micro_rollout_fwd_kernel(
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const int i = j * kStride + t;
-            const int ic = i < n ? i : 0;
+            const int ic = (kFull || i < n) ? i : 0;
             rp[j] = Rp[ic]; rv[j] = Rv[ic]; rpl[j] = Rp[ic + 1]; rvl[j] = Rv[ic + 1];
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const int i = j * kStride + t;
-            const bool valid = i < n;
+            const bool valid = kFull || i < n;
             const double p = rp[j], v = rv[j];
             const double pl = rpl[j], vl = rvl[j];
             double dp, dv;
-            if (i == n - 1) {                         // compute_state_delta, _micro_lane.py:201-204
+            if ((!kFull || j == K - 1) && i == n - 1) {      // compute_state_delta, _micro_lane.py:201-204
                 dp = head_dp; dv = head_dv;
             } else {                                  // :206-212
                 dp = fabs(pl - p) - ((len_lead[j] + prm[j].length) * 0.5);
@@ -286,8 +288,12 @@ static void launch_micro_fwd(const dhts_micro_desc *d, int T, const float *p, co
                              const double *params, const double *head, float *p_out, float *v_out, float *tape,
                              float *hist, dhts_error *err, hipStream_t s) {
     const size_t lds = sizeof(float) * (kW > 1 ? 4 : 2) * (size_t)(d->capacity + 1);
-    micro_rollout_fwd_kernel<K, kW, kCompact><<<d->n_lanes, 64 * kW, lds, s>>>(d->n_lanes, d->capacity, T, d->dt, p, v, count, params,
-                                                                        head, p_out, v_out, tape, hist, err);
+    if (count == nullptr && d->capacity == 64 * kW * K)
+        micro_rollout_fwd_kernel<K, kW, kCompact, true><<<d->n_lanes, 64 * kW, lds, s>>>(d->n_lanes, d->capacity, T, d->dt, p, v, count,
+                                                                                 params, head, p_out, v_out, tape, hist, err);
+    else
+        micro_rollout_fwd_kernel<K, kW, kCompact, false><<<d->n_lanes, 64 * kW, lds, s>>>(d->n_lanes, d->capacity, T, d->dt, p, v, count,
+                                                                                  params, head, p_out, v_out, tape, hist, err);
 }
 
 // passes per thread for kW wavefronts per lane
