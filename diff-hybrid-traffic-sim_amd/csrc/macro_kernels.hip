@@ -288,10 +288,12 @@ __device__ __forceinline__ void cell_glue_pre(float r, float y, float umf, const
 //     when the phases alternate: neither chain got shorter by running beside the other.
 // Dynamic LDS: cell records [N + 2] (index c + 1 = cell c, 0 and N + 1 the ghosts; updated in place) | flux double2 [N + 1]
 // | queue int [N + 2] | 2 counters.
-// kOnePass: one 64-cell pass per wavefront (p = 1): the per-thread addresses are loop invariants; kFull: every thread owns a cell
-// (N = blockDim.x): no validity masks; kHist: the state history may be asked for.  The step body is instantiated with
-// literal (finish the previous step, start this one) flags: first step, steps in between, last.
-template <bool kOnePass, bool kFull, bool kHist>
+// kP: 64-cell passes per wavefront as a literal (1 or 2; 0 = the run-time value p_arg): the pass loop is unrolled, the
+// per-thread addresses are loop invariants, and with two passes a wavefront has two independent cells' instruction streams
+// to interleave; kFull: every thread-pass owns a cell (N = kP blockDim.x): no validity masks; kHist: the state history may
+// be asked for.  The step body is instantiated with literal (finish the previous step, start this one) flags: first step,
+// steps in between, last.
+template <int kP, bool kFull, bool kHist>
 __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
     int L, int N, int T, int p_arg, double dt, double dx, double um,
     const float *__restrict__ r_in, const float *__restrict__ y_in, const float *__restrict__ u_in,
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
     __syncthreads();
 
     const TapeGeom geo = tape_geom(N);
-    const int p = kOnePass ? 1 : p_arg;
+    const int p = kP > 0 ? kP : p_arg;
 
     const int lo = wv * (p << 6);                    // first cell of this wave
     const double c = dt / dx;                        // update_coefficient, _macro_lane.py:99
@@ -354,6 +356,7 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
         if (tp_run) tp_run += tp_stride;
         if (kHist && hp_run && upd) hp_run += hp_stride;
         int *cnt = CNT + (n & 1);
+#pragma unroll
         for (int j = 0; j < p; ++j) {
             const int i = lo + (j << 6) + t;                // cell i and its left interface i
             const bool vc = kFull || i < N;
@@ -941,15 +944,18 @@ static int macro_fwd2_launch(const dhts_macro_desc *d, int T,
     const size_t lds = sizeof(CellRec) * (size_t)(N + 2) + 16 * (size_t)(N + 1) + sizeof(int) * (size_t)(N + 2) + 16;
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     if (lds > 64 * 1024 &&
-        (hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-         hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-         hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess))
+        (hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel<1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+         hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel<2, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+         hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+         hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+         hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess))
         return DHTS_E_LAUNCH;
-    // Wavefronts per lane: one 64-cell pass per wavefront whenever the lane fits 16 of them (measured, tools/sweep_fwd_waves.py,
-    // forward ms for 1 / 2 / 4 / 8 / 16 waves per lane: 1024 x 512: 7.0 / 5.0 / 4.9 / 4.6 / 4.5; 4096 x 256: 12.9 / 11.8 / 10.4 /
-    // 10.2 / 10.3; 256 x 2048: 22.8 / 12.5 / 6.8 / 4.8 / 4.6): phase 1 is then one short pass for every wave, and the serial
-    // queue pass of phase 2 is what remains.
-    int W = dhts_fwd_waves_override > 0 ? dhts_fwd_waves_override : 16;
+    // Wavefronts per lane: two 64-cell passes per wavefront whenever the lane fits 16 of them -- the two passes of a thread are
+    // independent instruction streams the compiler interleaves (one pass leaves a wavefront waiting on its own chain), and at
+    // 1024 x 512 the four-wave workgroups of all lanes are resident at once (4 per CU) instead of taking two rounds.  Measured
+    // (tools/sweep_fwd_waves.py, forward ms for 1 / 2 / 4 / 8 / 16 waves per lane; literal pass counts 1, 2, run-time above):
+    //   1024 x 512: 7.5 / 3.95 / 3.50 / 4.07 / -      4096 x 256: 9.3 / 7.50 / 7.93 / - / -      256 x 2048: 19.6 / 10.7 / 6.0 / 4.09 / 3.54
+    int W = dhts_fwd_waves_override > 0 ? dhts_fwd_waves_override : (N + 127) / 128;
     if (W > 16) W = 16;
     if (W < 1) W = 1;
     int p = (N + 64 * W - 1) / (64 * W);
@@ -957,11 +963,16 @@ static int macro_fwd2_launch(const dhts_macro_desc *d, int T,
 #define DHTS_FWD2_ARGS d->n_lanes, N, T, p, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, \
                        reinterpret_cast<float4 *>(tape), hist, err
     if (p == 1 && N == 64 * W && hist == nullptr)
-        macro_rollout_fwd2_kernel<true, true, false><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(DHTS_FWD2_ARGS);
+        macro_rollout_fwd2_kernel<1, true, false><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(DHTS_FWD2_ARGS);
+    else if (p == 2 && N == 128 * W && hist == nullptr)
+        macro_rollout_fwd2_kernel<2, true, false><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(DHTS_FWD2_ARGS);
+
     else if (p == 1)
-        macro_rollout_fwd2_kernel<true, false, true><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(DHTS_FWD2_ARGS);
+        macro_rollout_fwd2_kernel<1, false, true><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(DHTS_FWD2_ARGS);
+    else if (p == 2)
+        macro_rollout_fwd2_kernel<2, false, true><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(DHTS_FWD2_ARGS);
     else
-        macro_rollout_fwd2_kernel<false, false, true><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(DHTS_FWD2_ARGS);
+        macro_rollout_fwd2_kernel<0, false, true><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(DHTS_FWD2_ARGS);
 #undef DHTS_FWD2_ARGS
     return launch_status();
 }

@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 w = bench.MacroWorkload(dev, 0, L, N, 1000)
-sweep = [(1, 0)] + [(0, k) for k in (0, 1, 2, 4, 8, 16)]       # (kernel variant, wavefronts per lane)
+sweep = [(1, 0)] + [(0, k) for k in (0, 1, 2, 4, 8, 16) if 64 * k <= N or k == 0]       # (kernel variant, wavefronts per lane)
 for variant, waves in sweep:
     _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_VARIANT, variant)
     _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_WAVES, waves)
