@@ -103,8 +103,8 @@ class MacroWorkload:
     unit_name = "cell-steps/s"
     # what each kernel actually runs into (PMC counters and s_memtime stamps)
     limiter = {"rollout_fwd": "instruction issue (vector + scalar: ~54 % of the SIMD cycles carry a vector instruction at 4 wavefronts per "
-                              "SIMD) and the serial queue pass of phase 2; the tape it writes is 9.2 GB (2.4 TB/s): the kernel without "
-                              "any tape takes 3.53 of the 3.70 ms (back to back; 3.8 between reverse sweeps)",
+                              "SIMD) and the serial queue pass of phase 2; the tape it writes is 9.0 GB (2.6 TB/s): the kernel without "
+                              "any tape takes 2.94 of the 3.44 ms",
                "rollout_bwd": "instruction issue + LDS / barrier latency at 4 wavefronts per SIMD (122 VGPRs hold three steps of tape in "
                               "flight); HBM reads at ~4.7 TB/s"}
 
