@@ -265,10 +265,13 @@ __device__ __forceinline__ void cell_glue_pre(float r, float y, float umf, const
 //     owns it).
 // One queue pass serves the whole lane (8 passes of phase 1 at 512 cells), so the expensive path runs about once per 64
 // non-trivial interfaces instead of once per 64 interfaces.  Two LDS-only barriers per step.
-// Where the time goes (s_memtime stamps, config 2, 8 waves per lane, 2 workgroups per CU): phase 1 ~2000 cycles (every
-// SIMD busy: instruction throughput), phase 2 ~1800 cycles on the one or two waves that hold queue entries while the others
-// wait -- a dependent chain (three LDS round trips, the classification, two rsq / rcp chains, the Jacobians), latency not
-// instruction count -- and ~600 cycles of barrier skew.  Measured and dropped (tools/probes/*.hip.txt):
+// Where the time went when a wavefront made one pass (s_memtime stamps, config 2, 8 waves per lane, 2 workgroups per CU,
+// 4.4 ms): phase 1 ~2000 cycles (every SIMD busy: instruction throughput), phase 2 ~1800 cycles on the one or two waves that
+// hold queue entries while the others wait -- a dependent chain (three LDS round trips, the classification, two rsq / rcp
+// chains, the Jacobians), latency not instruction count -- and ~600 cycles of barrier skew.  Since then (3.4 ms): the scalar
+// diet (running pointers, literal flags: every instruction of a wavefront, scalar ones included, takes a turn of its
+// issue slot) and two unrolled passes per wavefront (two independent cells per thread to interleave; four-wave workgroups,
+// all lanes of config 2 resident at once).  Measured and dropped (tools/probes/*.hip.txt; times against the kernel of their day):
 //   * fluxes only in phase 2, Jacobians one step behind on another wave: the Jacobian chain is as long as the full solve,
 //     so the phase does not get shorter; a fifth / ninth dedicated wavefront per workgroup costs a workgroup of occupancy;
 //   * the solve cut into three roles (flux | A | B) on three waves side by side: every role still takes ~1700 cycles;
