@@ -61,7 +61,7 @@ __device__ __forceinline__ void raise_fault(dhts_error *err, int code, int step,
 //   S  float [N][3]                                fp[0], fp[2], fp[3] of interface i < N where it is trivial
 //   H  u32 cnt, u32 0 | u16 idx [N + 1]            idx[j] = interface of exception j < cnt; interface N is always one
 //   E  float4 [N + 1][2]                           (A, B) of exception j; only the first cnt entries are written / read
-// 8.6 KB of traffic per 512-cell row against the 16.6 KB of a dense (A, B) tape and the 24.6 KB of the reference's blocks.
+// 8.8 KB of traffic per 512-cell row against the 16.6 KB of a dense (A, B) tape and the 24.6 KB of the reference's blocks.
 struct TapeGeom {
     int s_f4, h_f4, e_f4;
     size_t row_f4;
@@ -1120,7 +1120,7 @@ int dhts_macro_u_tap_bwd(int64_t n, double u_max, const float *r, const float *y
     return launch_status();
 }
 
-// rollouts keep the compact interface tape (32 B per interface-step)
+// rollouts keep the compact tape described above (three floats per trivial interface + the exceptions' products)
 int dhts_macro_rollout_fwd(const dhts_macro_desc *d, int T,
                            const float *r, const float *y, const float *u, const float *ueq, const float *ghost,
                            float *r_out, float *y_out, float *u_out, float *ueq_out,
