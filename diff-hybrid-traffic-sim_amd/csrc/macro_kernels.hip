@@ -1031,10 +1031,13 @@ static int macro_rollout_bwd_launch(const dhts_macro_desc *d, int T, const float
     const int N = d->n_cells;
     int B = padded64(N);
     if (B > 512) B = 512;
-    const bool fast = N >= 2 && N <= 512 && g_hist == nullptr && T > 0;      // (T = 0: no tape to prefetch from)
+    const bool fast = N >= 2 && N <= 1024 && g_hist == nullptr && T > 0;      // (T = 0: no tape to prefetch from)
     if (fast) {
-        const int kB = N <= 64 ? 64 : (N <= 128 ? 128 : (N <= 256 ? 256 : 512));
+        const int kB = N <= 64 ? 64 : (N <= 128 ? 128 : (N <= 256 ? 256 : (N <= 512 ? 512 : 1024)));
         const size_t lds = bwd_fast_lds_bytes(kB);
+        if (kB == 1024 && hipFuncSetAttribute((const void *)macro_rollout_bwd_fast_kernel<1024>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return DHTS_E_LAUNCH;
         const float4 *tp = reinterpret_cast<const float4 *>(tape);
         const double cc = d->dt / d->dx;
         hipStream_t st = (hipStream_t)stream;
@@ -1044,8 +1047,10 @@ static int macro_rollout_bwd_launch(const dhts_macro_desc *d, int T, const float
             macro_rollout_bwd_fast_kernel<128><<<d->n_lanes, 128, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_r_out, g_y_out, g_ghost, err);
         else if (kB == 256)
             macro_rollout_bwd_fast_kernel<256><<<d->n_lanes, 256, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_r_out, g_y_out, g_ghost, err);
-        else
+        else if (kB == 512)
             macro_rollout_bwd_fast_kernel<512><<<d->n_lanes, 512, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_r_out, g_y_out, g_ghost, err);
+        else
+            macro_rollout_bwd_fast_kernel<1024><<<d->n_lanes, 1024, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_r_out, g_y_out, g_ghost, err);
         return launch_status();
     }
     const size_t lds = sizeof(float) * (size_t)((6 * (N + 2) + 3) & ~3) + 2 * (size_t)(N + 1);

@@ -371,7 +371,7 @@ def test_macro_rollout_short_horizons(cuda, oracle, T):
 
 
 @pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("N,T", [(2, 5), (64, 9), (130, 31), (256, 16), (512, 23)])
+@pytest.mark.parametrize("N,T", [(2, 5), (64, 9), (130, 31), (256, 16), (512, 23), (700, 14), (1024, 11), (1100, 7)])
 def test_macro_reverse_sweeps_agree_on_one_tape(cuda, N, T, variant):
     """The rollout's three ways from a tape to a gradient give the same bits: the pipelined one-cell-per-thread kernel (every
     block size, tapes of the two-phase forward kernel and -- all interfaces exceptions, more of them than threads at N = 512
