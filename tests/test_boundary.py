@@ -46,6 +46,18 @@ def test_options_accept_documented_values_only():
     assert lib.dhts_set_option(_lib.OPT_MACRO_FWD_WAVES, 0) == 0       # back to the heuristics
 
 
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 100, 512, 513, 1000, 4000])
+def test_macro_tape_rows_follow_the_documented_geometry(N):
+    """include/dhts.h: a row = S float[N][3] | H u32 cnt, u32 0, u16 idx[N + 1] | E float[N + 1][2][4], every block rounded up to
+    whole 128-byte lines (bench.py's tape census and the tests' decoders rely on exactly this)."""
+    from dhts import _lib
+    lib = _lib.lib()
+    d = _lib.MacroDesc(3, N, 0.01, 5.0, 30.0)
+    line = lambda nbytes: (nbytes + 127) // 128 * 128
+    row = line(12 * N) + line(8 + 2 * (N + 1)) + line(32 * (N + 1))
+    assert lib.dhts_macro_tape_bytes(C.byref(d), 7) == 7 * 3 * row
+
+
 def test_tape_bytes_match_documented_layout():
     from dhts import _lib
     lib = _lib.lib()
