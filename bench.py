@@ -86,7 +86,9 @@ def spawn_ranks(n):
                         p.kill()
                 rcs = [p.wait() for p in procs]
         rank0_out.seek(0)
-        sys.stdout.write(rank0_out.read().decode())
+        # rank 0's JSON line goes to stdout; anything a backend printed beside it (gloo's connection banner) to stderr
+        for line in rank0_out.read().decode().splitlines(True):
+            (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
         sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
     if bad:
