@@ -340,17 +340,26 @@ __device__ __forceinline__ void arz_classify_fast(double rL, double uL, double q
     const bool triv = zero0 | (b4 & (diff >= 0.0)) | (!b4 & l0l_ok);
     const bool mid = b4 | (b5 & (l0m <= 0));
     p.ci = triv ? 0 : (mid ? 1 : 2);
-    // CFL: dt * max(|speed|, 1e-5) < dx for speed0 and speed1  <=>  |speed| < dx / dt and 1e-5 < dx / dt.  speed0 is 0,
-    // diff / den (den > 0: tested as |diff| < den dx / dt, no division) or the mean of two characteristic speeds (tested
-    // as |sum| < 2 dx / dt); every test is a lane mask, the selection between them mask logic.  A NaN fails every test.
-    const bool ok_b4 = fabs(diff) < k.cfl_lim * den;
-    const bool ok_m = fabs(l0l + l0m) < k.cfl_lim2;        // branch 5
-    const bool ok_q = fabs(l0l + qm_u) < k.cfl_lim2;       // branches 2 and 6
-    const bool ok_avg = (b5 & ok_m) | (!b5 & ok_q);
-    const bool ok0 = zero0 | (b4 & ok_b4) | (!b4 & ok_avg);
-    const bool ok_uL = fabs(uL) < k.cfl_lim, ok_uR = fabs(uR) < k.cfl_lim;
-    const bool ok1 = (vacL & ok_uL) | (!vacL & ((vacR & ok_avg) | (!vacR & ok_uR)));
-    p.cfl_bad = !(ok0 & ok1 & k.lim_ok);
+    // CFL: dt * max(|speed|, 1e-5) < dx for speed0 and speed1  <=>  |speed| < dx / dt and 1e-5 < dx / dt.  Every speed the solver
+    // can report is bounded by the sum below (see arz_is_trivial_fast): where that bound is inside the limit -- everywhere, in
+    // a run that is not about to fail -- the exact tests are skipped (a wave-uniform branch; a NaN fails the bound's test and
+    // then every exact one).
+    const double bound = __builtin_fma(0.5, fabs(qL), fabs(uL) + fabs(uR)) + __builtin_fma(0.5 * um, p.sL, 0.5 * um);
+    const bool sure = (bound < k.cfl_lim) & k.lim_ok;
+    p.cfl_bad = false;
+    if (__builtin_amdgcn_ballot_w64(!sure)) {
+        asm volatile("" ::: "memory");                     // (keeps it a branch)
+        // speed0 is 0, diff / den (den > 0: tested as |diff| < den dx / dt, no division) or the mean of two characteristic
+        // speeds (tested as |sum| < 2 dx / dt); every test is a lane mask, the selection between them mask logic.
+        const bool ok_b4 = fabs(diff) < k.cfl_lim * den;
+        const bool ok_m = fabs(l0l + l0m) < k.cfl_lim2;        // branch 5
+        const bool ok_q = fabs(l0l + qm_u) < k.cfl_lim2;       // branches 2 and 6
+        const bool ok_avg = (b5 & ok_m) | (!b5 & ok_q);
+        const bool ok0 = zero0 | (b4 & ok_b4) | (!b4 & ok_avg);
+        const bool ok_uL = fabs(uL) < k.cfl_lim, ok_uR = fabs(uR) < k.cfl_lim;
+        const bool ok1 = (vacL & ok_uL) | (!vacL & ((vacR & ok_avg) | (!vacR & ok_uR)));
+        p.cfl_bad = !(ok0 & ok1 & k.lim_ok);
+    }
 }
 
 __device__ __forceinline__ void arz_pre_fast(double rL, double uL, double qL, double rR, double uR, const IfaceConst &k,
