@@ -770,21 +770,13 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         // ================= C: cell updates + tape | lane queue terms of step t-1 | next step's signals =================
         if (is_cell) {
             const int c = tid;
-            const float cf = (float)c_cc, ncf = (float)(-c_cc);
             const int iL = c + c_macb, iR = iL + 1;
             const float nr = (float)((double)cur[c] + (Fq[2 * iL] - Fq[2 * iR]) * c_cc);
             const float ny = (float)((double)cur[C + c] + (Fq[2 * iL + 1] - Fq[2 * iR + 1]) * c_cc);
             float nu, nq;
             glue_from_r_y(nr, ny, um, nu, nq);
             nxt[c] = nr; nxt[C + c] = ny; nxt[2 * C + c] = nu; nxt[3 * C + c] = nq;
-            const float *aL = AB + (size_t)iL * 8, *aR = AB + (size_t)iR * 8;
-            float4 d0, d1, d2;
-            d0.x = ncf * (-aL[0]); d0.y = ncf * (-aL[1]); d0.z = ncf * (-aL[2]); d0.w = ncf * (-aL[3]);
-            d2.x = ncf * aR[4]; d2.y = ncf * aR[5]; d2.z = ncf * aR[6]; d2.w = ncf * aR[7];
-            d1.x = 1.f - cf * (aR[0] - aL[4]); d1.y = 0.f - cf * (aR[1] - aL[5]);
-            d1.z = 0.f - cf * (aR[2] - aL[6]); d1.w = 1.f - cf * (aR[3] - aL[7]);
-            float4 *tp = tape_r + (size_t)t * 3 * Cp;
-            tp[c] = d0; tp[Cp + c] = d1; tp[2 * Cp + c] = d2;
+            // (the step's tape blocks are assembled in the next phase: the hand-offs wait for the new state, not for them)
         }
         if (is_sg && t + 1 < T) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, sig_ph, sig_fr, sg_q, we, ns, a, pr, ai); sig[2 * sg_q] = we; sig[2 * sg_q + 1] = ns; }
         if (++sig_fr == F) { sig_fr = 0; ++sig_ph; }
@@ -801,6 +793,21 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         lds_barrier();
         // ================= D: flux capacitors, hand-off events in lane-id order, commits (micro wave) | loss constants of
         //                    the state after step t-1 + its history row (the cells have nothing else to do here) =========
+        if (is_cell) {
+            // the cell's tape blocks from the interface products of phase B (dmacro_lane.py:126-129): the cells have slack in
+            // this phase (the micro wave's hand-offs are its critical path), none in the last one
+            const int c = tid;
+            const float cf = (float)c_cc, ncf = (float)(-c_cc);
+            const int iL = c + c_macb, iR = iL + 1;
+            const float *aL = AB + (size_t)iL * 8, *aR = AB + (size_t)iR * 8;
+            float4 d0, d1, d2;
+            d0.x = ncf * (-aL[0]); d0.y = ncf * (-aL[1]); d0.z = ncf * (-aL[2]); d0.w = ncf * (-aL[3]);
+            d2.x = ncf * aR[4]; d2.y = ncf * aR[5]; d2.z = ncf * aR[6]; d2.w = ncf * aR[7];
+            d1.x = 1.f - cf * (aR[0] - aL[4]); d1.y = 0.f - cf * (aR[1] - aL[5]);
+            d1.z = 0.f - cf * (aR[2] - aL[6]); d1.w = 1.f - cf * (aR[3] - aL[7]);
+            float4 *tp = tape_r + (size_t)t * 3 * Cp;
+            tp[c] = d0; tp[Cp + c] = d1; tp[2 * Cp + c] = d2;
+        }
         if (t > 0 && !in_mw) { loss_consts(cur, t - 1); run_update(t - 1); }      // (the micro wave keeps no running sums)
         if (is_fw && t > 0) flush_block(t - 1);          // the last step's records, with the seeds appended two phases ago
         if (in_mw) {
