@@ -47,6 +47,35 @@ constexpr int kPhases = 3;           // record segments per block (= step): head
 constexpr int kMaxStepRecords = 1024;
 constexpr int kWindow = 100000;      // RunningMean(100_000), _env.py:122
 
+// Phase timing for tools/probes/exp_hyb_stamps.py: compiled in with -DDHTS_HYB_STAMPS only (a separate build of the library,
+// never the product).  Every barrier of a step stamps s_memtime before and behind itself; work(i) = arriving at barrier i -
+// leaving the one before, drain(i) = the wave's own outstanding LDS / scalar operations, barrier(i) = the rest; summed over the steps, written by the first lane of every wavefront
+// of the first eight replicas.
+#ifdef DHTS_HYB_STAMPS
+__device__ long long dhts_hyb_stamps[2][8][16][24];
+#define HYB_STAMP_DECL long long st_last_ = __builtin_amdgcn_s_memtime(), st_acc_[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define HYB_BARRIER(i)                                                                      \
+    {                                                                                       \
+        const long long a_ = __builtin_amdgcn_s_memtime();                                  \
+        st_acc_[i] += a_ - st_last_;                           /* work */                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
+        const long long b_ = __builtin_amdgcn_s_memtime();                                  \
+        st_acc_[8 + (i)] += b_ - a_;                           /* drain of the wave's own LDS / scalar operations */ \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                     \
+        st_last_ = __builtin_amdgcn_s_memtime();                                            \
+        st_acc_[16 + (i)] += st_last_ - b_;                    /* barrier */                \
+    }
+#define HYB_STAMP_WRITE(kernel_, rep_, tid_, B_)                                            \
+    if ((rep_) < 8) {                                                                       \
+        const int role_ = ((tid_) & 63) == 0 ? (tid_) >> 6 : -1;   /* one row per wavefront */ \
+        if (role_ >= 0 && role_ < 16) for (int q_ = 0; q_ < 24; ++q_) dhts_hyb_stamps[kernel_][rep_][role_][q_] = st_acc_[q_]; \
+    }
+#else
+#define HYB_STAMP_DECL
+#define HYB_BARRIER(i) lds_barrier()
+#define HYB_STAMP_WRITE(kernel_, rep_, tid_, B_)
+#endif
+
 enum { K_NODE = 1, K_COMMIT = 2, K_DEPOSIT = 3, K_CELLREAD = 4, K_SIGNAL = 5, K_SEED = 6, K_IMPORT = 7, K_IDM = 8, K_CAP = 9 };
 
 struct HybTables {
@@ -590,6 +619,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             lane_total = lane_total + (-1.0f) * term;
         }
     };
+    HYB_STAMP_DECL
     for (int t = 0; t < T; ++t) {
         const float *cur = (t & 1) ? S1 : S0;
         float *nxt = (t & 1) ? S0 : S1;
@@ -703,7 +733,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 // The barrier between this phase and the next sits HERE for the micro wave: nobody else reads what the rest of
                 // the head-gap evaluation writes (it only feeds this wave's IDM steps), and the next phase has slack for it
                 // (IDM steps against the interface solves) while this one does not (head gaps against ghosts + loss scan).
-                lds_barrier();
+                HYB_BARRIER(0);
                 // signal_rms: running mean over the occupied lanes in lane order (_simulator.py:249-256)
                 const double ssum = wave_scan_add(act ? (double)fin.v : 0.);
                 const int scnt = wave_scan_add(act ? 1 : 0);
@@ -719,7 +749,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 sig_sum += wave_last(ssum); sig_cnt += wave_last(scnt);
             }
         } else {
-            lds_barrier();
+            HYB_BARRIER(0);
         }
         // ================= B: interface solves | loss constants + history row | vehicles' loss terms, IDM steps =================
         if (is_if) {
@@ -766,7 +796,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             }
             seg_a = rec.cnt;
         }
-        lds_barrier();
+        HYB_BARRIER(1);
         // ================= C: cell updates + tape | lane queue terms of step t-1 | next step's signals =================
         if (is_cell) {
             const int c = tid;
@@ -790,7 +820,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             const float Lf = lanelen[mlane[mw]];
             ev_head = (nid >= 0 && mslot[nid] < 0) ? vp[vi] > Lf + 1.0f * vlen : vp[vi] >= Lf;
         }
-        lds_barrier();
+        HYB_BARRIER(2);
         // ================= D: flux capacitors, hand-off events in lane-id order, commits (micro wave) | loss constants of
         //                    the state after step t-1 + its history row (the cells have nothing else to do here) =========
         if (is_cell) {
@@ -953,8 +983,9 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             }
             publish(t);
         }
-        lds_barrier();
+        HYB_BARRIER(3);
     }
+    HYB_STAMP_WRITE(0, rep, tid, B)
     // loss of the final state, last records
     if (T > 0) {
         const float *fin = (T & 1) ? S1 : S0;
@@ -1222,6 +1253,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     __syncthreads();
     if (in_mw) fetch_offsets(T - 1);
     fetch(T - 1);
+    HYB_STAMP_DECL
     for (int t = T - 1; t >= 0; --t) {
         float *Hc = (t & 1) ? H1 : H0;           // row t
         const float *Hn = (t & 1) ? H0 : H1;     // row t+1
@@ -1275,7 +1307,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             }
         }
         fetch(t - 1);
-        lds_barrier();
+        HYB_BARRIER(0);
         // ================= R2: micro records of the loss / hand-off part, newest first =================
         bool used_ob = false;
         auto replay = [&](int lo_, int n_) {            // this lane's records [lo_, lo_ + n_), newest first
@@ -1385,7 +1417,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
                 if (g_kind != 0) { gh_ds = soft_switch_grad(sgl - 0.5f, kSigK); gh_ds2 = sg[6 * g_inter + 2 + (g_kind - 1)]; }
             }
         }
-        lds_barrier();
+        HYB_BARRIER(1);
         // ================= R3: speed cotangents into (r, y); J^T g per cell =================
         float v_r = 0.f, v_y = 0.f;
         if (is_cell) {
@@ -1396,7 +1428,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             c2[c] = dot2(d2.x, gr, d2.z, gy); c2[C + c] = dot2(d2.y, gr, d2.w, gy);
             v_r = dot2(d1.x, gr, d1.z, gy); v_y = dot2(d1.y, gr, d1.w, gy);
         }
-        lds_barrier();
+        HYB_BARRIER(2);
         // ================= R4: gather inside the lane; ghost cotangents | rest of the micro records =================
         if (is_cell) {
             const int c = tid;
@@ -1445,7 +1477,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
                 }
             }
         }
-        lds_barrier();
+        HYB_BARRIER(3);
         // ================= R5: edge cells take their inboxes; action partials =================
         if (is_cell) {
             float v_u = 0.f;
@@ -1478,8 +1510,9 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             }
         }
         if (rev_fr == 0) { rev_fr = F - 1; --rev_ph; } else --rev_fr;
-        lds_barrier();
+        HYB_BARRIER(4);
     }
+    HYB_STAMP_WRITE(1, rep, tid, B)
     if (is_own && cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + own_q] = (float)ga;
     if (bad_step >= 0) net_fault(err, DHTS_FAULT_NAN, bad_step, rep, tid);
     if ((over && is_mt) || bad_key) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, bad_key ? -2 : 0);
@@ -1519,6 +1552,12 @@ static inline int hyb_block(const dhts_net_desc *d) {
     if (need < d->n_action) need = d->n_action;
     return ((need + 63) & ~63) + 64;               // + the micro wavefront
 }
+
+#ifdef DHTS_HYB_STAMPS
+extern "C" int dhts_debug_stamps(long long *out) {       // [2 kernels][8 replicas][16 waves][24]: work 0..7, drain 8..15, barrier 16..23
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dhts::dhts_hyb_stamps), sizeof(long long) * 2 * 8 * 16 * 24) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" {
 

@@ -1,25 +1,43 @@
-import os, sys, ctypes as C
-ROOT = "/root/repo"
-sys.path.insert(0, os.path.join(ROOT, "diff-hybrid-traffic-sim_amd")); sys.path.insert(0, ROOT)
-import numpy as np, torch, bench
-from dhts import _lib
+#!/usr/bin/env python3
+"""Phase table of the hybrid network kernels (config 4): cycles per step each role spends working / waiting in front of every
+barrier.  Needs the instrumented build of the library:
+
+    cd diff-hybrid-traffic-sim_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DDHTS_HYB_STAMPS \
+        -c -o /tmp/hyb_st.o hybrid_kernels.hip && hipcc --offload-arch=gfx950 -shared -fPIC -o libdhts_stamps.so \
+        dhts_common.o macro_kernels.o micro_kernels.o network_kernels.o /tmp/hyb_st.o
+    python tools/probes/exp_hyb_stamps.py
+"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "diff-hybrid-traffic-sim_amd"))
+sys.path.insert(0, ROOT)
+from dhts import _lib  # noqa: E402
+_lib.SO_PATH = os.path.join(ROOT, "diff-hybrid-traffic-sim_amd", "csrc", "libdhts_stamps.so")
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
 dev = torch.device("cuda:0")
 w = bench.ItscpHybridWorkload(dev, 0, 256, 0, 0)
-for _ in range(3): w.one_pass()
+for _ in range(3):
+    w.one_pass()
 w.ev = []
-for _ in range(5): w.one_pass(record=True)
+for _ in range(5):
+    w.one_pass(record=True)
 torch.cuda.synchronize()
-print("fwd %.3f ms bwd %.3f ms" % (np.median([e[0].elapsed_time(e[1]) for e in w.ev]), np.median([e[2].elapsed_time(e[3]) for e in w.ev])))
-lib = C.CDLL(os.path.join(ROOT, "diff-hybrid-traffic-sim_amd/csrc/libdhts.so"))
-buf = (C.c_longlong * (8 * 3 * 8))()
-assert lib.dhts_debug_read(buf) == 0
-a = np.array(buf[:]).reshape(8, 3, 8)
-for rep in (0, 3):
-    for role, nm in enumerate(("cell wave 0", "flush wave", "micro wave")):
-        print("replica %d %-12s work A/B/C/D %s   wait A/B/C/D %s   sum %d" % (rep, nm, a[rep, role, :4], a[rep, role, 4:], a[rep, role].sum()))
-
-assert lib.dhts_debug_read2(buf) == 0
-b = np.array(buf[:]).reshape(8, 3, 8)
-for rep in (0,):
-    for role, nm in enumerate(("cell wave 0", "flush wave", "micro wave")):
-        print("replica %d %-12s A: ghosts %d scan %d lanes %d vsamples %d | D: caps %d prescreen %d events %d commits+publish %d" % ((rep, nm) + tuple(b[rep, role])))
+print("instrumented: fwd %.3f ms bwd %.3f ms" % (np.median([e[0].elapsed_time(e[1]) for e in w.ev]), np.median([e[2].elapsed_time(e[3]) for e in w.ev])))
+buf = (C.c_longlong * (2 * 8 * 16 * 24))()
+assert _lib.lib().dhts_debug_stamps(buf) == 0
+a = np.array(buf[:], dtype=np.int64).reshape(2, 8, 16, 24)
+T = 600
+for kern, name, nb in ((0, "forward", 4), (1, "reverse", 5)):
+    print(name, "(cycles per step, mean over replicas 0..7)")
+    m = a[kern].mean(axis=0) / T
+    for wave in range(8):
+        nm = "wave %d%s" % (wave, " (flush)" if wave == 6 else (" (micro)" if wave == 7 else ""))
+        print("  %-14s work %s   drain %s   barrier %s   total %d" % (nm, np.round(m[wave, :nb]).astype(int), np.round(m[wave, 8:8 + nb]).astype(int),
+                                                                       np.round(m[wave, 16:16 + nb]).astype(int), int(m[wave].sum())))
