@@ -350,7 +350,7 @@ class ItscpMacroWorkload:
         if record:
             e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             e[0].record()
-        reward, _ = self.ops.net_macro_rollout(self.action, self.tab, self.sq, self.F, self.dt, self.um)
+        reward, _ = self.ops.net_macro_rollout(self.action, self.tab, self.sq, self.F, self.dt, self.um, err=self.err)
         if record:
             e[1].record()
         loss = -reward.sum()
@@ -440,7 +440,8 @@ class ItscpHybridWorkload:
         if record:
             e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             e[0].record()
-        reward, _, _, self.counts = self.ops.net_hybrid_rollout(self.action, self.tab, self.sq, self.F, self.dt, self.um)
+        # faults go to the workload's own sticky record, read once behind the timed region (as for the straight lanes)
+        reward, _, _, self.counts = self.ops.net_hybrid_rollout(self.action, self.tab, self.sq, self.F, self.dt, self.um, err=self.err)
         if record:
             e[1].record()
         loss = -reward.sum()

@@ -410,7 +410,8 @@ class NetMacroRollout(torch.autograd.Function):
     reference in `macro` mode, reward = - sum of squared queue lengths); also returns the per-step queue terms."""
 
     @staticmethod
-    def forward(ctx, action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed, vehicle_length, check_faults=True):
+    def forward(ctx, action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed, vehicle_length, check_faults=True,
+                err=None):
         a = _f32c(action.detach(), "action")
         R, A = a.shape
         if dev_tables.n_replica_tables not in (0, R):
@@ -428,13 +429,16 @@ class NetMacroRollout(torch.autograd.Function):
         queue = torch.empty(R, dev_tables.T, dev_tables.n_lanes, dtype=torch.float32, device=dev)
         reward = torch.empty(R, dtype=torch.float32, device=dev)
         ws = torch.zeros(R * dev_tables.T * 2 * dev_tables.n_lanes, dtype=torch.float32, device=dev)
-        err = new_error_record(dev)
+        own_err = err is None              # a caller's record is sticky across calls and read by the caller (no sync here)
+        if own_err:
+            err = new_error_record(dev)
         check(lib.dhts_net_macro_rollout_fwd(C.byref(d), C.byref(dev_tables.c), _ptr(a), _ptr(hist), _ptr(tape), _ptr(kc),
                                              _ptr(queue), _ptr(reward), _ptr(ws), _ptr(err), _stream()),
               "dhts_net_macro_rollout_fwd")
-        if check_faults:                 # reading the record back synchronises: off inside HIP-graph capture
+        if check_faults and own_err:     # reading the record back synchronises: off inside HIP-graph capture
             raise_on_fault(err)
-        ctx.d, ctx.tables, ctx.check_faults = d, dev_tables, bool(check_faults)
+        ctx.d, ctx.tables, ctx.check_faults = d, dev_tables, bool(check_faults) and own_err
+        ctx.err = None if own_err else err
         ctx.save_for_backward(a, hist, tape, kc, queue, ws)
         ctx.mark_non_differentiable(queue)
         return reward, queue
@@ -444,22 +448,23 @@ class NetMacroRollout(torch.autograd.Function):
         a, hist, tape, kc, queue, ws = ctx.saved_tensors
         d = ctx.d
         g_action = torch.empty_like(a)
-        err = new_error_record(a.device)
+        err = ctx.err if ctx.err is not None else new_error_record(a.device)
         g = g_reward.contiguous().float()          # a named local: the (possibly fresh) tensor must outlive the launch
         check(_lib.lib().dhts_net_macro_rollout_bwd(C.byref(d), C.byref(ctx.tables.c), _ptr(a), _ptr(hist), _ptr(tape), _ptr(kc),
                                                     _ptr(queue), _ptr(g), _ptr(g_action), _ptr(ws), _ptr(err),
                                                     _stream()), "dhts_net_macro_rollout_bwd")
         if ctx.check_faults:
             raise_on_fault(err)
-        return g_action, None, None, None, None, None, None, None, None
+        return g_action, None, None, None, None, None, None, None, None, None
 
 
 def net_macro_rollout(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0,
-                      check_faults=True):
+                      check_faults=True, err=None):
     """Returns (reward [R], queue [R][T][L]).  check_faults=False: nothing is read back (no host sync; usable inside a
-    HIP-graph capture); faults stay in the device record."""
+    HIP-graph capture); faults stay in the device record.  err: a caller-owned sticky fault record (new_error_record) used
+    by both directions and read by the caller when it wants to (raise_on_fault)."""
     return NetMacroRollout.apply(action, dev_tables, int(n_inter_sq), int(frames_per_phase), float(dt), float(u_max),
-                                 float(static_speed), float(vehicle_length), bool(check_faults))
+                                 float(static_speed), float(vehicle_length), bool(check_faults), err)
 
 
 class DeviceHybridTables:
@@ -509,7 +514,7 @@ class NetHybridRollout(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed, vehicle_length, loss_steps,
-                check_faults=True):
+                check_faults=True, err=None):
         a = _f32c(action.detach(), "action")
         R, A = a.shape
         t = dev_tables
@@ -531,13 +536,16 @@ class NetHybridRollout(torch.autograd.Function):
         reward = torch.empty(R, dtype=torch.float32, device=dev)
         counts = torch.zeros(R, 4, dtype=torch.int32, device=dev)
         ws = torch.empty(ws_n, dtype=torch.uint8, device=dev)
-        err = new_error_record(dev)
+        own_err = err is None              # a caller's record is sticky across calls and read by the caller (no sync here)
+        if own_err:
+            err = new_error_record(dev)
         check(lib.dhts_net_hybrid_rollout_fwd(C.byref(d), C.byref(tc), _ptr(a), _ptr(hist), _ptr(tape), _ptr(kc), _ptr(queue),
                                               _ptr(reward), _ptr(counts), _ptr(ws), _ptr(err), _stream()),
               "dhts_net_hybrid_rollout_fwd")
-        if check_faults:                 # reading the record back synchronises: off inside HIP-graph capture
+        if check_faults and own_err:     # reading the record back synchronises: off inside HIP-graph capture
             raise_on_fault(err)
-        ctx.d, ctx.tables, ctx.loss_steps, ctx.check_faults = d, t, int(loss_steps), bool(check_faults)
+        ctx.d, ctx.tables, ctx.loss_steps, ctx.check_faults = d, t, int(loss_steps), bool(check_faults) and own_err
+        ctx.err = None if own_err else err
         ctx.save_for_backward(a, hist, tape, kc, queue, ws)
         ctx.mark_non_differentiable(reward, queue, counts)
         if loss_steps and loss_steps > 0:
@@ -553,22 +561,24 @@ class NetHybridRollout(torch.autograd.Function):
         d = ctx.d
         tc = ctx.tables.c(ctx.loss_steps)
         g_action = torch.empty_like(a)
-        err = new_error_record(a.device)
+        err = ctx.err if ctx.err is not None else new_error_record(a.device)
         g = g_cut.contiguous().float()             # a named local: the (possibly fresh) tensor must outlive the launch
         check(_lib.lib().dhts_net_hybrid_rollout_bwd(C.byref(d), C.byref(tc), _ptr(a), _ptr(hist), _ptr(tape), _ptr(kc), _ptr(queue),
                                                      _ptr(g), _ptr(g_action), _ptr(ws), _ptr(err), _stream()),
               "dhts_net_hybrid_rollout_bwd")
         if ctx.check_faults:
             raise_on_fault(err)     # a NaN in the reverse sweep asserts like the reference (dmacro_lane.py:308)
-        return g_action, None, None, None, None, None, None, None, None, None
+        return g_action, None, None, None, None, None, None, None, None, None, None
 
 
 def net_hybrid_rollout(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0,
-                       loss_steps=0, check_faults=True):
+                       loss_steps=0, check_faults=True, err=None):
     """Returns (reward restricted to the first loss_steps steps [differentiable], full reward, queue [R][T][L], counts [R][4]).
     check_faults=False: nothing is read back in either direction (no host sync; usable inside a HIP-graph capture), and a
     non-finite cotangent in the reverse sweep (the reference asserts on it, dmacro_lane.py:308; it
     happens e.g. when a head gap clamps to exactly 0 and the IDM Jacobian divides by it, didm.py:60-70) is left in the
-    returned gradient of that replica instead of raising, so that a batch survives one bad member."""
+    returned gradient of that replica instead of raising, so that a batch survives one bad member.
+    err: a caller-owned sticky fault record (new_error_record) used by both directions instead of a fresh one per call; the
+    caller reads it when it wants to (raise_on_fault) -- a training loop checks once per so many iterations, not twice per pass."""
     return NetHybridRollout.apply(action, dev_tables, int(n_inter_sq), int(frames_per_phase), float(dt), float(u_max),
-                                  float(static_speed), float(vehicle_length), int(loss_steps), bool(check_faults))
+                                  float(static_speed), float(vehicle_length), int(loss_steps), bool(check_faults), err)
