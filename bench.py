@@ -104,7 +104,7 @@ class MacroWorkload:
     unit_bytes = MACRO_TAPE_B
     unit_name = "cell-steps/s"
     # what each kernel actually runs into (PMC counters and s_memtime stamps)
-    limiter = {"rollout_fwd": "instruction issue (vector + scalar: ~54 % of the SIMD cycles carry a vector instruction at 4 wavefronts per "
+    limiter = {"rollout_fwd": "instruction issue (vector + scalar: 66 % of the SIMD cycles carry a vector instruction at 4 wavefronts per "
                               "SIMD) and the serial queue pass of phase 2; the tape it writes is 9.0 GB (2.6 TB/s): the kernel without "
                               "any tape takes 2.94 of the 3.44 ms",
                "rollout_bwd": "instruction issue + LDS / barrier latency at 4 wavefronts per SIMD (122 VGPRs hold three steps of tape in "
