@@ -110,6 +110,11 @@ class MacroWorkload:
                "rollout_bwd": "instruction issue + LDS / barrier latency at 4 wavefronts per SIMD (122 VGPRs hold three steps of tape in "
                               "flight); HBM reads at ~4.7 TB/s"}
 
+    # instruction-issue side of the two kernels (rocprofv3 --pmc passes of tools/pmc_macro_fwd.sh on config 2, not live): share of
+    # the SIMD cycles that carry a vector instruction, instructions per cell-step
+    issue = {"rollout_fwd": {"vector_alu_busy": 0.66, "vector_per_cell_step": 144, "scalar_per_cell_step": 50},
+             "rollout_bwd": {"vector_alu_busy": 0.60, "vector_per_cell_step": 74, "scalar_per_cell_step": 45}}
+
     def __init__(self, dev, rank, L, N, T):
         from dhts import ops
         self.ops, self.L, self.N, self.T = ops, L, N, T
@@ -623,6 +628,9 @@ def main():
         }
         if hasattr(w, "tape_census"):
             out["roofline"]["tape_census"] = w.tape_census()
+        if hasattr(w, "issue") and w.name == "macro_straight_1024x512x1000":
+            out["roofline"]["issue_side"] = dict(w.issue.get(dom, {}), source="PMC passes of tools/pmc_macro_fwd.sh on this configuration "
+                                                 "(profiles/README.md), not measured by this run")
         if parts is not None:
             out["allreduce_check"] = {"reduced": flat.tolist()[-1], "sum_of_rank_parts": float(parts[:, -1].double().sum()),
                                       "rank_parts": parts[:, -1].tolist(),
