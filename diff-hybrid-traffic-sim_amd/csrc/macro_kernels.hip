@@ -576,10 +576,12 @@ __device__ __forceinline__ v2f pk_dot(v2f dlo, v2f dhi, v2f g) {           // (d
 __host__ __device__ inline size_t bwd_fast_lds_bytes(int kB) {
     return 2 * 2 * 8 * (size_t)(kB + 2) + 2 * 2 * 16 * (size_t)(kB + 2) + 2 * 4 * (size_t)(kB + 2);
 }
-template <int kB>
+// kHist: per-step cotangents g_hist [T][L][2][N] (a loss on the state history) are added to the cell's cotangent in front of
+// every step; they ride in the register sets of the trivial products, three steps ahead.
+template <int kB, bool kHist>
 __global__ __launch_bounds__(kB) __attribute__((amdgpu_waves_per_eu(4, 4))) void macro_rollout_bwd_fast_kernel(     // <= 128 VGPRs
     int L, int N, int T, double cc, const float4 *__restrict__ tape,
-    const float *__restrict__ g_r_in, const float *__restrict__ g_y_in,
+    const float *__restrict__ g_r_in, const float *__restrict__ g_y_in, const float *__restrict__ g_hist,
     float *__restrict__ g_r_out, float *__restrict__ g_y_out, double *__restrict__ g_ghost, dhts_error *err) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = blockIdx.x;
@@ -618,15 +620,21 @@ __global__ __launch_bounds__(kB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // (plain variables and macros, not structs handed to lambdas: those end up in scratch memory)
     // The two LDS copies are told apart by Q = (T - 1 - step) & 1; the three tape rows a step reads from are running pointers
     // (no multiplications in the loop).
+    // per-step cotangents: row of step - 4 as well (the set refilled in the interval of `step` serves step - 4's blocks AND the
+    // cotangent added in front of step - 4)
+    const size_t hstride = (size_t)L * 2 * N;
+    const float *hb = kHist ? g_hist + (size_t)lane * 2 * N + kl : nullptr;
+    const float *pH = kHist ? hb + (size_t)(T > 5 ? T - 5 : 0) * hstride : nullptr;
     const char *pS = tb + (size_t)(T > 5 ? T - 5 : 0) * stride;      // row of step - 4 in the interval of `step`
     const char *pE = tb + (size_t)(T > 6 ? T - 6 : 0) * stride;      // row of step - 5
     const char *pC = tb + (size_t)(T > 9 ? T - 9 : 0) * stride;      // row of step - 8
 #define DHTS_ROW(step_) (tb + (size_t)((step_) > 0 ? (step_) : 0) * stride)
 #define DHTS_LOAD_CNT(rb_, c_) c_ = *reinterpret_cast<const int *>((rb_) + off_c);
-#define DHTS_LOAD_S(rb_, sl_, sr_)                                                       \
+#define DHTS_LOAD_S(rb_, hp_, sl_, sr_, gh_)                                             \
     {                                                                                    \
         sl_ = *reinterpret_cast<const TapeFp *>((rb_) + off_sl);                         \
         sr_ = *reinterpret_cast<const TapeFp *>((rb_) + off_sr);                         \
+        if (kHist) gh_ = v2f{(hp_)[0], (hp_)[N]};                                        \
     }
 #define DHTS_LOAD_E(rb_, c_, ea_, eb_, ix_)                                              \
     if (t < (c_)) {                                                                      \
@@ -674,10 +682,11 @@ __global__ __launch_bounds__(kB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // exceptions of step s - 2 from (ea_ .. ec_) to LDS, and the refills: exceptions of step s - 5 (their count cq_ arrived three
     // intervals ago), the count of step s - 8, the trivial products of step s - 4.  Everything read from the tape is in flight
     // for three intervals (2 workgroups x 3 steps x 9 KB per CU: what 6 TB/s at ~2 us of latency need).
-#define DHTS_STEP(s_, Q, R, sl_, sr_, ea_, eb_, ix_, ec_, cq_)                           \
+#define DHTS_STEP(s_, Q, R, sl_, sr_, gh_, ea_, eb_, ix_, ec_, cq_)                      \
     {                                                                                    \
         if (vk) {                                                                        \
             g = (c1v + C2[(R) * P + k + 1]) + C0[(R) * P + k + 1];                       \
+            if (kHist) g += gh_cur;                /* the cotangent of the state after step s, if the loss looks at it */ \
             if (bad_step < 0 && !(isfinite(g.x) && isfinite(g.y))) bad_step = ((s_) + 1 < T) ? (s_) + 1 : T - 1; \
             const v2f c0 = pk_dot(d0lo, d0hi, g), c2v = pk_dot(d2lo, d2hi, g);           \
             c1v = pk_dot(d1lo, d1hi, g);                                                 \
@@ -690,12 +699,14 @@ __global__ __launch_bounds__(kB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 if (k == N - 1) { gh_r += (double)c2v.x; gh_y += (double)c2v.y; }        \
             }                                                                            \
             if ((s_) >= 1) DHTS_BLOCKS((s_) - 1, R, sl_, sr_)                            \
+            if (kHist) gh_cur = gh_;               /* of step s - 1: the set is refilled below */ \
         }                                                                                \
         if ((s_) >= 2) DHTS_SCATTER((s_) - 2, Q, ec_, ea_, eb_, ix_);                    \
         ec_ = cq_;                                                                       \
         DHTS_LOAD_E(pE, ec_, ea_, eb_, ix_);                                             \
         DHTS_LOAD_CNT(pC, cq_);                                                          \
-        DHTS_LOAD_S(pS, sl_, sr_);                                                       \
+        DHTS_LOAD_S(pS, pH, sl_, sr_, gh_);                                              \
+        if (kHist) pH -= ((s_) > 4) ? hstride : 0;                                       \
         pS -= ((s_) > 4) ? stride : 0;                                                   \
         pE -= ((s_) > 5) ? stride : 0;                                                   \
         pC -= ((s_) > 8) ? stride : 0;                                                   \
@@ -717,9 +728,11 @@ __global__ __launch_bounds__(kB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     DHTS_LOAD_E(DHTS_ROW(T - 1), ecA, eaA, ebA, ixA);
     DHTS_LOAD_E(DHTS_ROW(T - 2), ecB, eaB, ebB, ixB);
     DHTS_LOAD_E(DHTS_ROW(T - 3), ecC, eaC, ebC, ixC);
-    DHTS_LOAD_S(DHTS_ROW(T - 1), slA, srA);
-    DHTS_LOAD_S(DHTS_ROW(T - 2), slB, srB);
-    DHTS_LOAD_S(DHTS_ROW(T - 3), slC, srC);
+#define DHTS_HROW(step_) (hb + (size_t)((step_) > 0 ? (step_) : 0) * hstride)
+    v2f ghA = zero2, ghB = zero2, ghC = zero2, gh_cur = zero2;
+    DHTS_LOAD_S(DHTS_ROW(T - 1), DHTS_HROW(T - 1), slA, srA, ghA);
+    DHTS_LOAD_S(DHTS_ROW(T - 2), DHTS_HROW(T - 2), slB, srB, ghB);
+    DHTS_LOAD_S(DHTS_ROW(T - 3), DHTS_HROW(T - 3), slC, srC, ghC);
     __syncthreads();                                     // the zeroed planes
     DHTS_SCATTER(T - 1, 0, ecA, eaA, ebA, ixA);
     if (T >= 2) DHTS_SCATTER(T - 2, 1, ecB, eaB, ebB, ixB);
@@ -731,19 +744,21 @@ __global__ __launch_bounds__(kB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     DHTS_LOAD_CNT(DHTS_ROW(T - 8), cqB);
     lds_only_barrier();
     if (vk) DHTS_BLOCKS(T - 1, 0, slA, srA)
-    DHTS_LOAD_S(DHTS_ROW(T - 4), slA, srA);
+    if (kHist) gh_cur = ghA;                             // of step T - 1
+    DHTS_LOAD_S(DHTS_ROW(T - 4), DHTS_HROW(T - 4), slA, srA, ghA);
+#undef DHTS_HROW
     // on entry to the interval of a step s of class A: the blocks of s are in registers, the exceptions of s - 1 in LDS;
     // (slB, srB) = S(s - 1), set C holds E(s - 2) and cqC the count of s - 5; (slC, srC) = S(s - 2), set A holds E(s - 3) and
     // cqA the count of s - 6; (slA, srA) = S(s - 3), set B holds E(s - 4) and cqB the count of s - 7
     int step = T - 1, q = 0;
     for (; step >= 2; step -= 3) {
-        DHTS_STEP(step, q, q ^ 1, slB, srB, eaC, ebC, ixC, ecC, cqC)
-        DHTS_STEP(step - 1, q ^ 1, q, slC, srC, eaA, ebA, ixA, ecA, cqA)
-        DHTS_STEP(step - 2, q, q ^ 1, slA, srA, eaB, ebB, ixB, ecB, cqB)
+        DHTS_STEP(step, q, q ^ 1, slB, srB, ghB, eaC, ebC, ixC, ecC, cqC)
+        DHTS_STEP(step - 1, q ^ 1, q, slC, srC, ghC, eaA, ebA, ixA, ecA, cqA)
+        DHTS_STEP(step - 2, q, q ^ 1, slA, srA, ghA, eaB, ebB, ixB, ecB, cqB)
         q ^= 1;
     }
-    if (step >= 0) DHTS_STEP(step, q, q ^ 1, slB, srB, eaC, ebC, ixC, ecC, cqC)
-    if (step >= 1) DHTS_STEP(step - 1, q ^ 1, q, slC, srC, eaA, ebA, ixA, ecA, cqA)
+    if (step >= 0) DHTS_STEP(step, q, q ^ 1, slB, srB, ghB, eaC, ebC, ixC, ecC, cqC)
+    if (step >= 1) DHTS_STEP(step - 1, q ^ 1, q, slC, srC, ghC, eaA, ebA, ixA, ecA, cqA)
     if (vk) {                                            // after step 0, whose copy is Q = (T - 1) & 1
         const int oq = ((T - 1) & 1) * P;
         g = (c1v + C2[oq + k + 1]) + C0[oq + k + 1];
@@ -1031,26 +1046,32 @@ static int macro_rollout_bwd_launch(const dhts_macro_desc *d, int T, const float
     const int N = d->n_cells;
     int B = padded64(N);
     if (B > 512) B = 512;
-    const bool fast = N >= 2 && N <= 1024 && g_hist == nullptr && T > 0;      // (T = 0: no tape to prefetch from)
+    const bool fast = N >= 2 && N <= 1024 && T > 0;      // (T = 0: no tape to prefetch from)
     if (fast) {
         const int kB = N <= 64 ? 64 : (N <= 128 ? 128 : (N <= 256 ? 256 : (N <= 512 ? 512 : 1024)));
         const size_t lds = bwd_fast_lds_bytes(kB);
-        if (kB == 1024 && hipFuncSetAttribute((const void *)macro_rollout_bwd_fast_kernel<1024>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (kB == 1024 &&
+            (hipFuncSetAttribute((const void *)macro_rollout_bwd_fast_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds) != hipSuccess ||
+             hipFuncSetAttribute((const void *)macro_rollout_bwd_fast_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds) != hipSuccess))
             return DHTS_E_LAUNCH;
         const float4 *tp = reinterpret_cast<const float4 *>(tape);
         const double cc = d->dt / d->dx;
         hipStream_t st = (hipStream_t)stream;
-        if (kB == 64)
-            macro_rollout_bwd_fast_kernel<64><<<d->n_lanes, 64, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_r_out, g_y_out, g_ghost, err);
-        else if (kB == 128)
-            macro_rollout_bwd_fast_kernel<128><<<d->n_lanes, 128, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_r_out, g_y_out, g_ghost, err);
-        else if (kB == 256)
-            macro_rollout_bwd_fast_kernel<256><<<d->n_lanes, 256, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_r_out, g_y_out, g_ghost, err);
-        else if (kB == 512)
-            macro_rollout_bwd_fast_kernel<512><<<d->n_lanes, 512, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_r_out, g_y_out, g_ghost, err);
-        else
-            macro_rollout_bwd_fast_kernel<1024><<<d->n_lanes, 1024, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_r_out, g_y_out, g_ghost, err);
+#define DHTS_BWD_FAST(KB)                                                                                                        \
+    if (g_hist)                                                                                                                  \
+        macro_rollout_bwd_fast_kernel<KB, true><<<d->n_lanes, KB, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_hist, g_r_out, \
+                                                                             g_y_out, g_ghost, err);                            \
+    else                                                                                                                         \
+        macro_rollout_bwd_fast_kernel<KB, false><<<d->n_lanes, KB, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_hist, g_r_out, \
+                                                                              g_y_out, g_ghost, err);
+        if (kB == 64) { DHTS_BWD_FAST(64) }
+        else if (kB == 128) { DHTS_BWD_FAST(128) }
+        else if (kB == 256) { DHTS_BWD_FAST(256) }
+        else if (kB == 512) { DHTS_BWD_FAST(512) }
+        else { DHTS_BWD_FAST(1024) }
+#undef DHTS_BWD_FAST
         return launch_status();
     }
     const size_t lds = sizeof(float) * (size_t)((6 * (N + 2) + 3) & ~3) + 2 * (size_t)(N + 1);

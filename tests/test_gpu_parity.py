@@ -373,10 +373,10 @@ def test_macro_rollout_short_horizons(cuda, oracle, T):
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("N,T", [(2, 5), (64, 9), (130, 31), (256, 16), (512, 23), (700, 14), (1024, 11), (1100, 7)])
 def test_macro_reverse_sweeps_agree_on_one_tape(cuda, N, T, variant):
-    """The rollout's three ways from a tape to a gradient give the same bits: the pipelined one-cell-per-thread kernel (every
-    block size, tapes of the two-phase forward kernel and -- all interfaces exceptions, more of them than threads at N = 512
-    -- of the one-phase kernel), the general kernel (forced by a zero per-step cotangent), and the single-step operator's
-    sweep over the blocks dhts_macro_tape_expand writes out, one step at a time.  (Against the oracle:
+    """The rollout's ways from a tape to a gradient give the same bits: the pipelined one-cell-per-thread kernel (every
+    block size up to 1024 cells, with and without per-step cotangents; tapes of the two-phase forward kernel and -- all
+    interfaces exceptions, more of them than threads -- of the one-phase kernel), the general kernel (lanes above 1024 cells),
+    and the single-step operator's sweep over the blocks dhts_macro_tape_expand writes out, one step at a time.  (Against the oracle:
     test_macro_rollout_vs_oracle_sizes and the goldens.)"""
     import torch
     from dhts import _lib, ops
@@ -413,6 +413,13 @@ def test_macro_reverse_sweeps_agree_on_one_tape(cuda, N, T, variant):
         gh += g1
     assert torch.equal(fast[0], a) and torch.equal(fast[1], b)
     assert rel_max(fast[2].cpu().numpy(), gh.cpu().numpy()) <= 1e-6      # (the ghosts' sums differ in the order of their doubles)
+    # per-step cotangents (a loss on the state history): the sweep adds g_hist[t] in front of step t
+    g_hist = torch.randn(T, L, 2, N, device=cuda)
+    with_hist = ops.macro_rollout_bwd(desc, T, tape, g_r, g_y, g_hist=g_hist)
+    a, b = g_r.clone(), g_y.clone()
+    for t in range(T - 1, -1, -1):
+        a, b, _ = ops.macro_step_bwd(desc, dqs[t].contiguous(), a + g_hist[t, :, 0], b + g_hist[t, :, 1])
+    assert torch.equal(with_hist[0], a) and torch.equal(with_hist[1], b)
 
 
 def test_macro_tape_matches_oracle_over_rollout(cuda, oracle):

@@ -54,3 +54,7 @@ for _ in range(6):
 torch.cuda.synchronize()
 print("one_pass: fwd ms", ["%.3f" % e[0].elapsed_time(e[1]) for e in w.ev[1:]])
 print("one_pass: bwd ms", ["%.3f" % e[2].elapsed_time(e[3]) for e in w.ev[1:]])
+
+# reverse sweep with per-step cotangents (a loss on the state history)
+gh = torch.zeros(w.T, w.L, 2, w.N, device=dev)
+print("bwd with g_hist  min / median ms: %.3f %.3f" % timed(lambda: ops.macro_rollout_bwd(w.desc, w.T, w.tape, g_r, g_y, g_hist=gh, err=w.err, out=w.gout, g_ghost=w.g_ghost)))
