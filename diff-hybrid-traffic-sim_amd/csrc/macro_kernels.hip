@@ -555,8 +555,7 @@ __device__ __forceinline__ void tape_fill_slots(const float4 *row, const TapeGeo
     }
 }
 
-// Reverse sweep over the rollout tape, one cell per thread (2 <= N <= blockDim.x, no per-step cotangents: the rollouts' common
-// shape).  grid = L workgroups of `blockDim.x` threads (multiple of 64).
+// Reverse sweep over the rollout tape, one cell per thread (2 <= N <= blockDim.x <= 1024: the rollouts' common shape).  grid = L workgroups of `blockDim.x` threads (multiple of 64).
 // Thread k owns cell k, whose blocks are made of the products of interfaces k and k + 1.  Where those are trivial it has them
 // in registers (three floats each, read from the row's S block); thread j < cnt also carries exception j to its interface:
 // (A, B) into XA / XB [interface], the step's tag into STAMP [interface], one barrier interval before they are used -- a cell
@@ -779,7 +778,7 @@ __global__ __launch_bounds__(kB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (bad_step >= 0) raise_fault(err, DHTS_FAULT_NAN, bad_step, lane, k);
 }
 
-// Reverse sweep over the rollout tape, any lane length, per-step cotangents (g_hist) or not.
+// Reverse sweep over the rollout tape, any lane length (lanes above 1024 cells, single cells), per-step cotangents (g_hist) or not.
 // grid = L workgroups of `blockDim.x` threads (multiple of 64).  Dynamic LDS: 6 planes of (N + 2) floats | u16 SLOT[N + 1].
 __global__ __launch_bounds__(512) void macro_rollout_bwd_kernel(
     int L, int N, int T, double cc, const float4 *__restrict__ tape,
