@@ -179,23 +179,34 @@ __global__ void micro_rollout_bwd_kernel(
     double gh_p = 0., gh_v = 0.;       // held by the thread that owns the head vehicle
     int step_hi = T - 1;
     if constexpr (kCompact) {
-        if (V <= B && g_hist == nullptr) {
+        if (V <= B) {
             // One vehicle per thread (the rollouts' common shape): the tape entry of the NEXT step to replay is loaded while
             // this step computes (unconditional load, clamped step index), and the barriers wait for LDS only, so the load
-            // stays in flight across them -- the tape stream is what bounds this kernel.
+            // stays in flight across them -- the tape stream is what bounds this kernel.  Per-step cotangents (a loss on the
+            // state history) travel the same way.
             const int k = t;
             const bool vk = k < n;
             const MicroTape3 *tc0 = reinterpret_cast<const MicroTape3 *>(tape) + (size_t)lane * Vp + (k < V ? k : 0);
             const size_t step_stride = (size_t)L * Vp;
             MicroTape3 nx = tc0[(size_t)(T > 0 ? T - 1 : 0) * step_stride];
             MicroTape3 nx2 = tc0[(size_t)(T > 1 ? T - 2 : 0) * step_stride];
+            const float *gh0 = g_hist ? g_hist + (size_t)lane * 2 * V + (k < V ? k : 0) : nullptr;
+            const size_t h_stride = (size_t)L * 2 * V;
+            float hp1 = 0.f, hv1 = 0.f, hp2 = 0.f, hv2 = 0.f;
+            if (gh0) {
+                const float *a = gh0 + (size_t)(T > 0 ? T - 1 : 0) * h_stride, *b = gh0 + (size_t)(T > 1 ? T - 2 : 0) * h_stride;
+                hp1 = a[0]; hv1 = a[V]; hp2 = b[0]; hv2 = b[V];
+            }
             const float dtf = (float)dt;
             for (int step = T - 1; step >= 0; --step) {
                 const MicroTape3 c = nx;
-                nx = nx2;
+                const float chp = hp1, chv = hv1;
+                nx = nx2; hp1 = hp2; hv1 = hv2;
                 nx2 = tc0[(size_t)(step > 1 ? step - 2 : 0) * step_stride];       // two steps ahead
+                if (gh0) { const float *a = gh0 + (size_t)(step > 1 ? step - 2 : 0) * h_stride; hp2 = a[0]; hv2 = a[V]; }
                 if (vk) {
-                    const float gp = Gp[k], gv = Gv[k];
+                    float gp = Gp[k], gv = Gv[k];
+                    if (gh0) { gp += chp; gv += chv; }
                     Gp[k] = dot2(1.f, gp, c.e2, gv);           // grad_ps[:-1] = dqs[:, 0]^T g
                     Gv[k] = dot2(dtf, gp, c.e3, gv);
                     C1p[k + 1] = dot2(0.f, gp, -c.e2, gv);     // grad_ps[1:] += dqs[:, 1]^T g
