@@ -103,27 +103,28 @@ class MacroWorkload:
     name = "macro_straight_1024x512x1000"
     unit_bytes = MACRO_TAPE_B
     unit_name = "cell-steps/s"
-    # what each kernel actually runs into (PMC counters and s_memtime stamps)
-    limiter = {"rollout_fwd": "instruction issue (vector + scalar: 66 % of the SIMD cycles carry a vector instruction at 4 wavefronts per "
-                              "SIMD) and the serial queue pass of phase 2; the tape it writes is 9.0 GB (2.6 TB/s): the kernel without "
-                              "any tape takes 2.94 of the 3.44 ms",
-               "rollout_bwd": "instruction issue + LDS / barrier latency at 4 wavefronts per SIMD (122 VGPRs hold three steps of tape in "
-                              "flight); HBM reads at ~4.7 TB/s"}
+    # what each kernel runs into, qualitatively; every NUMBER quoted beside it comes from the counter passes
+    # committed as profiles/issue_counters.json (issue_side below) or from this run's own events
+    limiter = {"rollout_fwd": "instruction issue (vector + scalar) at 4 wavefronts per SIMD and the serial queue pass of phase 2, not HBM",
+               "rollout_bwd": "instruction issue + LDS / barrier latency at 4 wavefronts per SIMD (three steps of tape in flight)"}
 
-    # instruction-issue side of the two kernels (rocprofv3 --pmc passes of tools/pmc_macro_fwd.sh on config 2, not live): share of
-    # the SIMD cycles that carry a vector instruction, instructions per cell-step
-    issue = {"rollout_fwd": {"vector_alu_busy": 0.66, "vector_per_cell_step": 144, "scalar_per_cell_step": 50},
-             "rollout_bwd": {"vector_alu_busy": 0.60, "vector_per_cell_step": 74, "scalar_per_cell_step": 45}}
+    @staticmethod
+    def inputs(rank, L, N, um=30.0):
+        """The seeded synthetic inputs of a rank (CPU tensors): r0, u0 [L][N], ghost r, ghost u [L][2].  tests/test_gpu_parity.py
+        takes lanes of exactly these tensors to pin the benchmarked kernel instantiations against the oracle."""
+        gen = torch.Generator(device="cpu").manual_seed(2026 + rank)
+        r0 = 0.05 + 0.9 * torch.rand(L, N, generator=gen)
+        u0 = um * torch.rand(L, N, generator=gen)
+        gr = 0.05 + 0.9 * torch.rand(L, 2, generator=gen)
+        gu = um * torch.rand(L, 2, generator=gen)
+        return r0, u0, gr, gu
 
     def __init__(self, dev, rank, L, N, T):
         from dhts import ops
         self.ops, self.L, self.N, self.T = ops, L, N, T
         self.dt, self.dx, self.um = 0.01, 5.0, 30.0
-        gen = torch.Generator(device="cpu").manual_seed(2026 + rank)
-        self.r0 = (0.05 + 0.9 * torch.rand(L, N, generator=gen)).to(dev)
-        self.u0 = (self.um * torch.rand(L, N, generator=gen)).to(dev)
-        gr = (0.05 + 0.9 * torch.rand(L, 2, generator=gen)).to(dev)
-        gu = (self.um * torch.rand(L, 2, generator=gen)).to(dev)
+        r0, u0, gr, gu = self.inputs(rank, L, N, self.um)
+        self.r0, self.u0, gr, gu = r0.to(dev), u0.to(dev), gr.to(dev), gu.to(dev)
         gy, gq = ops.macro_state_from_ru(gr, gu, self.um)
         self.ghost = torch.stack([gr, gy, gu, gq], dim=-1).contiguous()
         self.desc = ops.macro_desc(L, N, self.dt, self.dx, self.um)
@@ -226,17 +227,25 @@ class MicroWorkload:
     name = "micro_idm_4096x256x1000"
     unit_bytes = MICRO_TAPE_B
     unit_name = "vehicle-steps/s"
-    limiter = {"rollout_fwd": "instruction issue (~70 vector instructions per vehicle-step at ~4 cycles each); HBM writes at ~4.4 TB/s",
-               "rollout_bwd": "hbm (reads at ~6.0 TB/s of the ~6.5 a streaming kernel reaches)"}
+    limiter = {"rollout_fwd": "instruction issue (vector) beside the HBM write stream", "rollout_bwd": "hbm (the tape read stream)"}
+
+    PARAMS = (30.0 * 1.0, 30.0 * 0.8, 30.0 * 0.9, 5.0 * 0.1, 0.1, 5.0)     # default_micro_vehicle(30), micro_vehicle.py:31-72
+
+    @staticmethod
+    def inputs(rank, L, V):
+        """The seeded synthetic inputs of a rank (CPU tensors): p0, v0 [L][V] (tests pin the benchmarked instantiations on them)."""
+        gen = torch.Generator(device="cpu").manual_seed(3026 + rank)
+        p0 = torch.arange(V)[None, :] * 20.0 + 10.0 * torch.rand(L, V, generator=gen)
+        v0 = 9.0 + 12.0 * torch.rand(L, V, generator=gen)
+        return p0, v0
 
     def __init__(self, dev, rank, L, V, T):
         from dhts import ops
         self.ops, self.L, self.V, self.T = ops, L, V, T
         self.dt = 0.01
-        gen = torch.Generator(device="cpu").manual_seed(3026 + rank)
-        self.p0 = (torch.arange(V)[None, :] * 20.0 + 10.0 * torch.rand(L, V, generator=gen)).to(dev)
-        self.v0 = (9.0 + 12.0 * torch.rand(L, V, generator=gen)).to(dev)
-        par = torch.tensor([30.0 * 1.0, 30.0 * 0.8, 30.0 * 0.9, 5.0 * 0.1, 0.1, 5.0], dtype=torch.float64, device=dev)
+        p0, v0 = self.inputs(rank, L, V)
+        self.p0, self.v0 = p0.to(dev), v0.to(dev)
+        par = torch.tensor(self.PARAMS, dtype=torch.float64, device=dev)
         self.params = par[:, None, None].expand(6, L, V).contiguous()
         self.head = torch.tensor([[1000.0, 0.0]], dtype=torch.float64, device=dev).expand(L, 2).contiguous()
         self.desc = ops.micro_desc(L, V, self.dt)
@@ -504,6 +513,38 @@ def pmc_traffic(w, kernel):
     return hbm
 
 
+def kernel_symbols_sha16():
+    """Fingerprint of the kernels libdhts.so holds: sha256 over the sorted demangled names of its kernel symbols.  Counter
+    summaries under profiles/ carry the fingerprint of the library they were taken on and are not quoted for another."""
+    import hashlib
+    from dhts import _lib
+    try:
+        txt = subprocess.run(["nm", "-D", "--defined-only", "-C", _lib.SO_PATH], capture_output=True, text=True, check=True).stdout
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    names = sorted({ln.split(None, 2)[2].split("(")[0].strip() for ln in txt.splitlines()
+                    if "_kernel" in ln and "__device_stub__" not in ln and len(ln.split(None, 2)) == 3})
+    return hashlib.sha256("\n".join(names).encode()).hexdigest()[:16]
+
+
+def issue_counters(w, kernel):
+    """Instruction-issue side of `kernel` from the counter passes committed as profiles/issue_counters.json (tools/pmc_macro_fwd.sh:
+    rocprofv3 --pmc SQ_* passes over this configuration).  Not measured by this run; refused when the library's kernels are
+    not the ones the passes saw."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "issue_counters.json")))
+        side = rec[w.name][kernel]
+    except (OSError, ValueError, KeyError):
+        return None
+    have = kernel_symbols_sha16()
+    if have is None or rec.get("kernel_symbols_sha16") != have:
+        print("bench.py: profiles/issue_counters.json was taken on another build of libdhts.so (kernel symbols %s, now %s): "
+              "issue_side not quoted; re-run tools/pmc_macro_fwd.sh" % (rec.get("kernel_symbols_sha16"), have), file=sys.stderr)
+        return None
+    return dict(side, source="%s (rocprofv3 --pmc passes of tools/pmc_macro_fwd.sh on this configuration), not measured by this run"
+                % rec.get("source", "profiles/issue_counters.json"))
+
+
 def kernel_records(w):
     """Per-kernel records from the HIP events one_pass(record=True) left on the launch stream (the torch current stream
     is the stream the C ABI is handed, ops._stream)."""
@@ -628,9 +669,9 @@ def main():
         }
         if hasattr(w, "tape_census"):
             out["roofline"]["tape_census"] = w.tape_census()
-        if hasattr(w, "issue") and w.name == "macro_straight_1024x512x1000":
-            out["roofline"]["issue_side"] = dict(w.issue.get(dom, {}), source="PMC passes of tools/pmc_macro_fwd.sh on this configuration "
-                                                 "(profiles/README.md), not measured by this run")
+        side = issue_counters(w, dom)
+        if side is not None:
+            out["roofline"]["issue_side"] = side
         if parts is not None:
             out["allreduce_check"] = {"reduced": flat.tolist()[-1], "sum_of_rank_parts": float(parts[:, -1].double().sum()),
                                       "rank_parts": parts[:, -1].tolist(),

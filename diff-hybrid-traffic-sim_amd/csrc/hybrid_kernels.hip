@@ -32,6 +32,12 @@
 
 namespace dhts {
 
+// first thread of the downstream-ghost group: the next wavefront boundary behind the L upstream-ghost threads when both groups
+// fit in front of the micro wavefront (the block's last 64 threads), else right behind them (tid < 2 L)
+__host__ __device__ inline int hyb_ghost_base1(int L, int B) {
+    const int p = (L + 63) & ~63;
+    return (p + L <= B - 64) ? p : L;
+}
 constexpr int kMaxMicro = 24;        // micro lanes per network
 constexpr int kMaxCaps = 16;         // macro lanes with a micro successor
 constexpr int kLaneCap = 16;         // vehicles per micro lane
@@ -366,7 +372,9 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     // ---- per-thread roles
     // ghost threads: the upstream ghosts of all lanes first, the downstream ones from the next wavefront boundary on, so that a
     // wavefront runs ONE of the two (quite different) blends instead of both under divergence
-    const int g_base1 = (((L + 63) & ~63) + L <= B) ? ((L + 63) & ~63) : L;
+    // (B includes the micro wavefront, whose lanes carry no ghost role: the grouped layout must end in front of it -- the
+    // fallback tid < 2 L always does, hyb_block sizes the cell waves for it)
+    const int g_base1 = hyb_ghost_base1(L, B);
     const bool is_if = tid < NIm, is_cell = tid < C, is_ghost = tid < L || (tid >= g_base1 && tid < g_base1 + L), is_lane = tid < L;
     int i_lane = 0, i_k = 0, i_n = 0, i_off = 0, i_mb = 0;
     IfaceConst kconst;
@@ -1089,7 +1097,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     const float4 *grw = reinterpret_cast<const float4 *>(wsr + ws.rec_w);
     const float gscale = g_reward ? g_reward[rep] : 1.f;
     const int loss_steps = tb.loss_steps > 0 ? tb.loss_steps : T;
-    const int g_base1 = (((L + 63) & ~63) + L <= B) ? ((L + 63) & ~63) : L;      // ghost threads by side, as in the forward kernel
+    const int g_base1 = hyb_ghost_base1(L, B);      // ghost threads by side, as in the forward kernel
     const bool is_cell = tid < C, is_ghost = tid < L || (tid >= g_base1 && tid < g_base1 + L), is_lane = tid < L;
     const bool in_mw = tid >= B - 64, is_mt = (tid == B - 64);
     const int mw_lane = tid - (B - 64);

@@ -215,6 +215,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 __device__ __forceinline__ void lds_only_barrier() {     // global stores (the tape) stay in flight across it
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+// Orders this wavefront's LDS stores in front of its later LDS loads FOR THE COMPILER: lanes of one wavefront hand data to
+// each other through LDS (a cell's record to its right neighbour's thread, a pass's records and fluxes to the next pass), and
+// within one thread those addresses never alias, so nothing else stops the scheduler from hoisting the loads.  The hardware
+// executes a wavefront's LDS operations in order; no instruction is emitted.
+__device__ __forceinline__ void wave_lds_handoff() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 // One cell's record in LDS (48 bytes; a 48-byte stride keeps 16-byte accesses of 16 consecutive lanes on distinct banks):
 // the float32 state and what the interface to the cell's right needs of it, computed once by the cell's owner.
@@ -382,6 +390,7 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
             }
             // the left neighbour at this time level: written just above by the lane below, or in the previous pass (a wave's
             // LDS operations complete in order); the first cell of the chunk has its left neighbour in another wave: queued
+            wave_lds_handoff();
             const CellRec *lf = CR + ic;
             const float4 ls = lf->st;
             const double2 lsh = lf->sh, lq0 = lf->q0;
@@ -951,6 +960,25 @@ static int dhts_fwd_waves_override = 0;
 static int dhts_fwd_variant = 0;
 static inline int padded64(int n) { return (n + 63) & ~63; }
 
+// Wavefronts per lane of the two-phase forward kernel: two 64-cell passes per wavefront whenever the lane fits 16 of them -- the
+// two passes of a thread are independent instruction streams, and at 1024 x 512 the four-wave workgroups of all lanes are
+// resident at once (4 per CU) instead of taking two rounds.  Measured (tools/sweep_fwd_waves.py, forward ms for 1 / 2 / 4 / 8 /
+// 16 waves per lane; literal pass counts 1, 2, run-time above):
+//   1024 x 512: 7.5 / 3.95 / 3.50 / 4.07 / -      4096 x 256: 9.3 / 7.50 / 7.93 / - / -      256 x 2048: 19.6 / 10.7 / 6.0 / 4.09 / 3.54
+static void macro_fwd2_plan(int N, int &W, int &p) {
+    W = dhts_fwd_waves_override > 0 ? dhts_fwd_waves_override : (N + 127) / 128;
+    if (W > 16) W = 16;
+    if (W < 1) W = 1;
+    p = (N + 64 * W - 1) / (64 * W);
+    W = (N + 64 * p - 1) / (64 * p);
+}
+static inline bool macro_fwd2_fits(const dhts_macro_desc *d) {
+    return d && sizeof(CellRec) * (size_t)(d->n_cells + 2) + 16 * (size_t)(d->n_cells + 1) + sizeof(int) * (size_t)(d->n_cells + 2) + 16 <=
+                    160 * 1024;
+}
+static inline int macro_bwd_fast_block(int N) { return N <= 64 ? 64 : (N <= 128 ? 128 : (N <= 256 ? 256 : (N <= 512 ? 512 : 1024))); }
+static inline bool macro_bwd_is_fast(int N, int T) { return N >= 2 && N <= 1024 && T > 0; }      // (T = 0: no tape to prefetch from)
+
 static int macro_fwd2_launch(const dhts_macro_desc *d, int T,
                              const float *r, const float *y, const float *u, const float *ueq, const float *ghost,
                              float *r_out, float *y_out, float *u_out, float *ueq_out,
@@ -967,16 +995,8 @@ static int macro_fwd2_launch(const dhts_macro_desc *d, int T,
          hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
          hipFuncSetAttribute((const void *)macro_rollout_fwd2_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess))
         return DHTS_E_LAUNCH;
-    // Wavefronts per lane: two 64-cell passes per wavefront whenever the lane fits 16 of them -- the two passes of a thread are
-    // independent instruction streams the compiler interleaves (one pass leaves a wavefront waiting on its own chain), and at
-    // 1024 x 512 the four-wave workgroups of all lanes are resident at once (4 per CU) instead of taking two rounds.  Measured
-    // (tools/sweep_fwd_waves.py, forward ms for 1 / 2 / 4 / 8 / 16 waves per lane; literal pass counts 1, 2, run-time above):
-    //   1024 x 512: 7.5 / 3.95 / 3.50 / 4.07 / -      4096 x 256: 9.3 / 7.50 / 7.93 / - / -      256 x 2048: 19.6 / 10.7 / 6.0 / 4.09 / 3.54
-    int W = dhts_fwd_waves_override > 0 ? dhts_fwd_waves_override : (N + 127) / 128;
-    if (W > 16) W = 16;
-    if (W < 1) W = 1;
-    int p = (N + 64 * W - 1) / (64 * W);
-    W = (N + 64 * p - 1) / (64 * p);
+    int W, p;
+    macro_fwd2_plan(N, W, p);
 #define DHTS_FWD2_ARGS d->n_lanes, N, T, p, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, \
                        reinterpret_cast<float4 *>(tape), hist, err
     if (p == 1 && N == 64 * W && hist == nullptr)
@@ -1045,9 +1065,8 @@ static int macro_rollout_bwd_launch(const dhts_macro_desc *d, int T, const float
     const int N = d->n_cells;
     int B = padded64(N);
     if (B > 512) B = 512;
-    const bool fast = N >= 2 && N <= 1024 && T > 0;      // (T = 0: no tape to prefetch from)
-    if (fast) {
-        const int kB = N <= 64 ? 64 : (N <= 128 ? 128 : (N <= 256 ? 256 : (N <= 512 ? 512 : 1024)));
+    if (macro_bwd_is_fast(N, T)) {
+        const int kB = macro_bwd_fast_block(N);
         const size_t lds = bwd_fast_lds_bytes(kB);
         if (kB == 1024 &&
             (hipFuncSetAttribute((const void *)macro_rollout_bwd_fast_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1151,9 +1170,7 @@ int dhts_macro_rollout_fwd(const dhts_macro_desc *d, int T,
                            float *r_out, float *y_out, float *u_out, float *ueq_out,
                            float *tape, float *hist, dhts_error *err, void *stream) {
     // lanes whose records do not fit the two-phase kernel's LDS take the one-phase kernel (same tape format)
-    const bool fits = d && sizeof(CellRec) * (size_t)(d->n_cells + 2) + 16 * (size_t)(d->n_cells + 1) +
-                               sizeof(int) * (size_t)(d->n_cells + 2) + 16 <= 160 * 1024;
-    if (dhts_fwd_variant == 1 || !fits)
+    if (dhts_fwd_variant == 1 || !macro_fwd2_fits(d))
         return macro_fwd_launch<true>(d, T, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, tape, hist, err, stream);
     return macro_fwd2_launch(d, T, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, tape, hist, err, stream);
 }
@@ -1161,6 +1178,25 @@ int dhts_macro_rollout_bwd(const dhts_macro_desc *d, int T, const float *tape,
                            const float *g_r, const float *g_y, const float *g_hist,
                            float *g_r_out, float *g_y_out, double *g_ghost, dhts_error *err, void *stream) {
     return macro_rollout_bwd_launch(d, T, tape, g_r, g_y, g_hist, g_r_out, g_y_out, g_ghost, err, stream);
+}
+// which kernel instantiations dhts_macro_rollout_fwd / _bwd launch for this shape: the very functions the launches call
+int dhts_macro_rollout_plan(const dhts_macro_desc *d, int T, int want_hist, int32_t plan[8]) {
+    if (!macro_desc_ok(d) || T < 0 || !plan) return DHTS_E_INVALID;
+    for (int k = 0; k < 8; ++k) plan[k] = 0;
+    const int N = d->n_cells;
+    if (dhts_fwd_variant == 1 || !macro_fwd2_fits(d)) {
+        plan[0] = 1;
+    } else {
+        int W, p;
+        macro_fwd2_plan(N, W, p);
+        plan[1] = W;
+        plan[2] = p;
+        plan[3] = ((p == 1 || p == 2) && N == 64 * p * W && !want_hist) ? 1 : 0;
+    }
+    plan[4] = macro_bwd_is_fast(N, T) ? 1 : 0;
+    plan[5] = plan[4] ? macro_bwd_fast_block(N) : (padded64(N) > 512 ? 512 : padded64(N));
+    plan[6] = want_hist ? 1 : 0;
+    return DHTS_OK;
 }
 int dhts_macro_tape_expand(const dhts_macro_desc *d, int T, const float *tape, float *dqs, void *stream) {
     if (!macro_desc_ok(d) || T < 0 || (T > 0 && (!tape || !dqs))) return DHTS_E_INVALID;

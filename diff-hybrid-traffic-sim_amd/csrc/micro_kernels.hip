@@ -177,9 +177,10 @@ __global__ void micro_rollout_bwd_kernel(
     __syncthreads();
 
     double gh_p = 0., gh_v = 0.;       // held by the thread that owns the head vehicle
+    int bad_step = -1, bad_index = 0;  // first non-finite cotangent this thread meets (the latest step: the sweep runs backwards)
     int step_hi = T - 1;
     if constexpr (kCompact) {
-        if (V <= B) {
+        if (V <= B && T > 0) {         // (T = 0: no tape to prefetch from -- the tape pointer may be NULL)
             // One vehicle per thread (the rollouts' common shape): the tape entry of the NEXT step to replay is loaded while
             // this step computes (unconditional load, clamped step index), and the barriers wait for LDS only, so the load
             // stays in flight across them -- the tape stream is what bounds this kernel.  Per-step cotangents (a loss on the
@@ -188,13 +189,13 @@ __global__ void micro_rollout_bwd_kernel(
             const bool vk = k < n;
             const MicroTape3 *tc0 = reinterpret_cast<const MicroTape3 *>(tape) + (size_t)lane * Vp + (k < V ? k : 0);
             const size_t step_stride = (size_t)L * Vp;
-            MicroTape3 nx = tc0[(size_t)(T > 0 ? T - 1 : 0) * step_stride];
+            MicroTape3 nx = tc0[(size_t)(T - 1) * step_stride];
             MicroTape3 nx2 = tc0[(size_t)(T > 1 ? T - 2 : 0) * step_stride];
             const float *gh0 = g_hist ? g_hist + (size_t)lane * 2 * V + (k < V ? k : 0) : nullptr;
             const size_t h_stride = (size_t)L * 2 * V;
             float hp1 = 0.f, hv1 = 0.f, hp2 = 0.f, hv2 = 0.f;
             if (gh0) {
-                const float *a = gh0 + (size_t)(T > 0 ? T - 1 : 0) * h_stride, *b = gh0 + (size_t)(T > 1 ? T - 2 : 0) * h_stride;
+                const float *a = gh0 + (size_t)(T - 1) * h_stride, *b = gh0 + (size_t)(T > 1 ? T - 2 : 0) * h_stride;
                 hp1 = a[0]; hv1 = a[V]; hp2 = b[0]; hv2 = b[V];
             }
             const float dtf = (float)dt;
@@ -228,6 +229,10 @@ __global__ void micro_rollout_bwd_kernel(
                         }
                     }
                     Gp[k] = np_; Gv[k] = nv_;
+                    // a gap clamped to 0 makes the IDM Jacobian divide by it (didm.py:60-70) and the sweep meet 0 * inf.  The
+                    // reference's micro backward hands such NaNs on silently (dmicro_lane.py:271-298 has no assert, unlike
+                    // dmacro_lane.py:308); the values are kept, and the fault record says where the first one appeared
+                    if (bad_step < 0 && !(isfinite(np_) && isfinite(nv_))) { bad_step = step; bad_index = k; }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
@@ -269,6 +274,7 @@ __global__ void micro_rollout_bwd_kernel(
                 }
             }
             Gp[k] = np_; Gv[k] = nv_;
+            if (bad_step < 0 && !(isfinite(np_) && isfinite(nv_))) { bad_step = step; bad_index = k; }
         }
         __syncthreads();
     }
@@ -280,7 +286,13 @@ __global__ void micro_rollout_bwd_kernel(
         if (n == 0) { if (t == 0) { g_head[(size_t)lane * 2] = 0.; g_head[(size_t)lane * 2 + 1] = 0.; } }
         else if (t == (n - 1) % B) { g_head[(size_t)lane * 2] = gh_p; g_head[(size_t)lane * 2 + 1] = gh_v; }
     }
-    (void)err;
+    // the lane's report: the latest step at which a non-finite cotangent appeared (the first the sweep met), lowest vehicle
+    __shared__ int s_bad;
+    if (t == 0) s_bad = -1;
+    __syncthreads();
+    if (bad_step >= 0) atomicMax(&s_bad, (bad_step << 10) | (1023 - bad_index));      // capacity <= 1024 vehicles
+    __syncthreads();
+    if (t == 0 && s_bad >= 0) raise_fault_m(err, DHTS_FAULT_NAN, s_bad >> 10, lane, 1023 - (s_bad & 1023));
 }
 
 }  // namespace dhts
@@ -307,6 +319,23 @@ static void launch_micro_fwd(const dhts_micro_desc *d, int T, const float *p, co
                                                                                   params, head, p_out, v_out, tape, hist, err);
 }
 
+// wavefronts per lane of the forward kernel (1, 2 or 4)
+static int micro_fwd_waves(const dhts_micro_desc *d) {
+    int W = dhts_micro_fwd_waves_override;
+    if (W == 0) W = (d->capacity > 64 && (long long)d->n_lanes * 2 <= 8192) ? 2 : 1;
+    if (W >= 4 && d->capacity > 128) return 4;
+    if (W >= 2 && d->capacity > 64) return 2;
+    return 1;
+}
+static int micro_fwd_passes(const dhts_micro_desc *d, int W) {       // the literal K dispatch_micro_fwd instantiates
+    const int K = (d->capacity + 64 * W - 1) / (64 * W);
+    return K <= 1 ? 1 : (K <= 2 ? 2 : (K <= 4 ? 4 : (K <= 8 ? 8 : 16)));
+}
+static int micro_bwd_block(const dhts_micro_desc *d) {
+    int B = (d->capacity + 63) & ~63;
+    return B > 256 ? 256 : B;
+}
+
 // passes per thread for kW wavefronts per lane
 template <int kW, bool kCompact>
 static void dispatch_micro_fwd(const dhts_micro_desc *d, int T, const float *p, const float *v, const int32_t *count,
@@ -328,10 +357,9 @@ static int micro_fwd_launch(const dhts_micro_desc *d, int T,
     hipStream_t s = (hipStream_t)stream;
     // wavefronts per lane: one wave keeps the whole lane free of barriers; with few lanes per SIMD more waves per lane buy
     // the latency hiding back (256 CUs x 4 SIMDs x 8 waves)
-    int W = dhts_micro_fwd_waves_override;
-    if (W == 0) W = (d->capacity > 64 && (long long)d->n_lanes * 2 <= 8192) ? 2 : 1;
-    if (W >= 4 && d->capacity > 128) dispatch_micro_fwd<4, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
-    else if (W >= 2 && d->capacity > 64) dispatch_micro_fwd<2, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    const int W = micro_fwd_waves(d);
+    if (W == 4) dispatch_micro_fwd<4, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
+    else if (W == 2) dispatch_micro_fwd<2, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
     else dispatch_micro_fwd<1, kCompact>(d, T, p, v, count, params, head, p_out, v_out, tape, hist, err, s);
     return launch_status_m();
 }
@@ -341,8 +369,7 @@ static int micro_bwd_launch(const dhts_micro_desc *d, int T, const float *tape, 
                             float *g_p_out, float *g_v_out, double *g_head, int fold, dhts_error *err, void *stream) {
     if (!micro_desc_ok(d) || T < 0 || (T > 0 && !tape) || !g_p || !g_v || !g_p_out || !g_v_out) return DHTS_E_INVALID;
     const size_t lds = sizeof(float) * 4 * (size_t)(d->capacity + 2);
-    int B = (d->capacity + 63) & ~63;
-    if (B > 256) B = 256;
+    const int B = micro_bwd_block(d);
     micro_rollout_bwd_kernel<kCompact><<<d->n_lanes, B, lds, (hipStream_t)stream>>>(
         d->n_lanes, d->capacity, T, d->dt, tape, count, g_p, g_v, g_hist, g_p_out, g_v_out,
         g_head, fold, err);
@@ -378,6 +405,18 @@ int dhts_micro_rollout_bwd(const dhts_micro_desc *d, int T, const float *tape, c
                                       const float *g_p, const float *g_v, const float *g_hist,
                                       float *g_p_out, float *g_v_out, double *g_head, dhts_error *err, void *stream) {
     return micro_bwd_launch<true>(d, T, tape, count, g_p, g_v, g_hist, g_p_out, g_v_out, g_head, 1, err, stream);
+}
+// which kernel instantiations dhts_micro_rollout_fwd / _bwd launch for this shape: the very functions the launches call
+int dhts_micro_rollout_plan(const dhts_micro_desc *d, int T, int has_count, int32_t plan[8]) {
+    if (!micro_desc_ok(d) || T < 0 || !plan) return DHTS_E_INVALID;
+    for (int k = 0; k < 8; ++k) plan[k] = 0;
+    const int W = micro_fwd_waves(d), K = micro_fwd_passes(d, W), B = micro_bwd_block(d);
+    plan[0] = W;
+    plan[1] = K;
+    plan[2] = (!has_count && d->capacity == 64 * W * K) ? 1 : 0;
+    plan[3] = (d->capacity <= B && T > 0) ? 1 : 0;
+    plan[4] = B;
+    return DHTS_OK;
 }
 // the single-step operator keeps the reference's dqs[a][2][2][2] (32 B per vehicle)
 int dhts_micro_step_fwd(const dhts_micro_desc *d,

@@ -64,6 +64,7 @@ SIGNATURES = {
     "dhts_macro_u_tap_bwd": (C.c_int, [C.c_int64, C.c_double, _P, _P, _P, _P, _P, _P]),
     "dhts_macro_rollout_fwd": (C.c_int, [C.POINTER(MacroDesc), C.c_int] + [_P] * 13),
     "dhts_macro_rollout_bwd": (C.c_int, [C.POINTER(MacroDesc), C.c_int] + [_P] * 9),
+    "dhts_macro_rollout_plan": (C.c_int, [C.POINTER(MacroDesc), C.c_int, C.c_int, C.POINTER(C.c_int32 * 8)]),
     "dhts_macro_tape_expand": (C.c_int, [C.POINTER(MacroDesc), C.c_int] + [_P] * 3),
     "dhts_macro_step_fwd": (C.c_int, [C.POINTER(MacroDesc)] + [_P] * 12),
     "dhts_macro_step_bwd": (C.c_int, [C.POINTER(MacroDesc)] + [_P] * 8),
@@ -78,6 +79,7 @@ SIGNATURES = {
     "dhts_micro_step_tape_bytes": (C.c_size_t, [C.POINTER(MicroDesc)]),
     "dhts_micro_rollout_fwd": (C.c_int, [C.POINTER(MicroDesc), C.c_int] + [_P] * 11),
     "dhts_micro_rollout_bwd": (C.c_int, [C.POINTER(MicroDesc), C.c_int] + [_P] * 10),
+    "dhts_micro_rollout_plan": (C.c_int, [C.POINTER(MicroDesc), C.c_int, C.c_int, C.POINTER(C.c_int32 * 8)]),
     "dhts_micro_step_fwd": (C.c_int, [C.POINTER(MicroDesc)] + [_P] * 10),
     "dhts_micro_step_bwd": (C.c_int, [C.POINTER(MicroDesc)] + [_P] * 9),
 }

@@ -12,10 +12,16 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def _forced():
+    """DHTS_DIST_FORCE=1: build the process group and run the collectives even with ONE rank -- so that a single-GPU box
+    exercises the RCCL path (communicator set-up, device-buffer all-reduce) the multi-GPU bench will take."""
+    return os.environ.get("DHTS_DIST_FORCE", "0") == "1"
+
+
 def init(backend=None):
     """Initialise torch.distributed from the torchrun environment (backend 'nccl' = RCCL on ROCm)."""
     rank, world, local = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _forced()) and not dist.is_initialized():
         if backend is None:
             # the default on GPUs is RCCL ("nccl"); DHTS_DIST_BACKEND=gloo -- or more ranks than devices -- lets several ranks
             # share one GPU in a smoke test (RCCL refuses two ranks on one device)
@@ -40,7 +46,7 @@ def shard_range(n_units, rank, world):
 
 
 def _active():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _forced())
 
 
 def _staged(t):

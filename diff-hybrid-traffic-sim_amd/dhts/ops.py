@@ -9,6 +9,7 @@ Mirrors the reference operators
 batched over lanes and fused over time steps.
 """
 import ctypes as C
+import warnings
 
 import torch
 
@@ -143,6 +144,14 @@ def macro_rollout_bwd(desc, T, tape, g_r, g_y, g_hist=None, err=None, out=None, 
                                             _ptr(out[0]), _ptr(out[1]), _ptr(g_ghost), _ptr(err), _stream()),
           "dhts_macro_rollout_bwd")
     return out[0], out[1], g_ghost
+
+
+def macro_rollout_plan(desc, T, want_hist=False):
+    """Which kernel instantiations dhts_macro_rollout_fwd / _bwd launch for this shape (include/dhts.h)."""
+    plan = (C.c_int32 * 8)()
+    check(_lib.lib().dhts_macro_rollout_plan(C.byref(desc), int(T), int(bool(want_hist)), C.byref(plan)), "dhts_macro_rollout_plan")
+    keys = ("fwd_one_phase", "fwd_waves", "fwd_passes", "fwd_full_lane", "bwd_pipelined", "bwd_block", "hist")
+    return dict(zip(keys, list(plan)[:7]))
 
 
 def macro_tape_expand(desc, T, tape):
@@ -281,6 +290,14 @@ def micro_rollout_bwd(desc, T, tape, g_p, g_v, count=None, g_hist=None, err=None
     return out[0], out[1], g_head
 
 
+def micro_rollout_plan(desc, T, has_count=False):
+    """Which kernel instantiations dhts_micro_rollout_fwd / _bwd launch for this shape (include/dhts.h)."""
+    plan = (C.c_int32 * 8)()
+    check(_lib.lib().dhts_micro_rollout_plan(C.byref(desc), int(T), int(bool(has_count)), C.byref(plan)), "dhts_micro_rollout_plan")
+    keys = ("fwd_waves", "fwd_passes", "fwd_full_lane", "bwd_one_vehicle_per_thread", "bwd_block")
+    return dict(zip(keys, list(plan)[:5]))
+
+
 def micro_step_bwd(desc, tape, g_p, g_v, count=None):
     """dMicroForwardLayer.backward for a batch of lanes: returns (g_p[L][V], g_v[L][V], g_virtual[L][2] float64),
     g_virtual = raw cotangent of the virtual leader slot (not folded into the head vehicle)."""
@@ -313,7 +330,7 @@ class MicroRollout(torch.autograd.Function):
         pT, vT = micro_rollout_fwd(desc, T, p0c, v0c, params, head.detach(), count=count, tape=tape, hist=hist, err=err)
         if check_faults:                 # a collision is printed like the reference does, and tolerated
             raise_on_fault(err)
-        ctx.desc, ctx.T, ctx.tape, ctx.count, ctx.want_hist = desc, T, tape, count, want_hist
+        ctx.desc, ctx.T, ctx.tape, ctx.count, ctx.want_hist, ctx.check_faults = desc, T, tape, count, want_hist, check_faults
         if want_hist:
             return pT, vT, hist
         return pT, vT
@@ -326,7 +343,14 @@ class MicroRollout(torch.autograd.Function):
         g_p = g_pT.contiguous() if g_pT is not None else torch.zeros(L, V, device=dev)
         g_v = g_vT.contiguous() if g_vT is not None else torch.zeros(L, V, device=dev)
         gh = g_hist.contiguous() if (ctx.want_hist and g_hist is not None) else None
-        g_p0, g_v0, g_head = micro_rollout_bwd(desc, T, ctx.tape, g_p, g_v, count=ctx.count, g_hist=gh)
+        err = new_error_record(dev)
+        g_p0, g_v0, g_head = micro_rollout_bwd(desc, T, ctx.tape, g_p, g_v, count=ctx.count, g_hist=gh, err=err)
+        if ctx.check_faults:             # reading the record back synchronises: off inside HIP-graph capture
+            code, step, lane, index = err.tolist()
+            if code == _lib.FAULT_NAN:
+                # the reference's micro backward returns such NaNs silently (dmicro_lane.py:271-298); so do we, but say where
+                warnings.warn("non-finite gradient in the micro reverse sweep (step %d, lane %d, vehicle %d)" % (step, lane, index),
+                              RuntimeWarning)
         return g_p0, g_v0, None, g_head, None, None, None, None, None
 
 
@@ -514,7 +538,7 @@ class NetHybridRollout(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed, vehicle_length, loss_steps,
-                check_faults=True, err=None):
+                check_faults=True, err=None, err_bwd=None):
         a = _f32c(action.detach(), "action")
         R, A = a.shape
         t = dev_tables
@@ -545,7 +569,7 @@ class NetHybridRollout(torch.autograd.Function):
         if check_faults and own_err:     # reading the record back synchronises: off inside HIP-graph capture
             raise_on_fault(err)
         ctx.d, ctx.tables, ctx.loss_steps, ctx.check_faults = d, t, int(loss_steps), bool(check_faults) and own_err
-        ctx.err = None if own_err else err
+        ctx.err = err_bwd if err_bwd is not None else (None if own_err else err)
         ctx.save_for_backward(a, hist, tape, kc, queue, ws)
         ctx.mark_non_differentiable(reward, queue, counts)
         if loss_steps and loss_steps > 0:
@@ -568,17 +592,19 @@ class NetHybridRollout(torch.autograd.Function):
               "dhts_net_hybrid_rollout_bwd")
         if ctx.check_faults:
             raise_on_fault(err)     # a NaN in the reverse sweep asserts like the reference (dmacro_lane.py:308)
-        return g_action, None, None, None, None, None, None, None, None, None, None
+        return g_action, None, None, None, None, None, None, None, None, None, None, None
 
 
 def net_hybrid_rollout(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0,
-                       loss_steps=0, check_faults=True, err=None):
+                       loss_steps=0, check_faults=True, err=None, err_bwd=None):
     """Returns (reward restricted to the first loss_steps steps [differentiable], full reward, queue [R][T][L], counts [R][4]).
     check_faults=False: nothing is read back in either direction (no host sync; usable inside a HIP-graph capture), and a
     non-finite cotangent in the reverse sweep (the reference asserts on it, dmacro_lane.py:308; it
     happens e.g. when a head gap clamps to exactly 0 and the IDM Jacobian divides by it, didm.py:60-70) is left in the
     returned gradient of that replica instead of raising, so that a batch survives one bad member.
     err: a caller-owned sticky fault record (new_error_record) used by both directions instead of a fresh one per call; the
-    caller reads it when it wants to (raise_on_fault) -- a training loop checks once per so many iterations, not twice per pass."""
+    caller reads it when it wants to (raise_on_fault) -- a training loop checks once per so many iterations, not twice per pass.
+    err_bwd: a second caller-owned record for the reverse sweep alone, for callers that tolerate its NaN fault (a batch with one
+    bad member) but not the forward's CFL / capacity faults: the first fault wins a record, so the two must not share one."""
     return NetHybridRollout.apply(action, dev_tables, int(n_inter_sq), int(frames_per_phase), float(dt), float(u_max),
-                                  float(static_speed), float(vehicle_length), int(loss_steps), bool(check_faults), err)
+                                  float(static_speed), float(vehicle_length), int(loss_steps), bool(check_faults), err, err_bwd)

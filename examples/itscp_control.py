@@ -93,9 +93,21 @@ def batch(args, env, dev):
     action = (0.1 + 0.8 * th.rand(args.n_replica, env.action_size(), generator=gen)).to(dev).requires_grad_(True)
     opt = th.optim.Adam([action], lr=args.lr, capturable=args.graph)
     action.grad = th.zeros_like(action)
+    # Sticky fault records, allocated outside any graph capture and read every so many episodes (a read synchronises).  The
+    # forward's faults (CFL violation: the reference asserts, _macro_lane.py:141-146; an exhausted kernel capacity) end the run;
+    # the reverse sweep's NaN fault is the one thing a batch tolerates (that replica sits the episode out), so it gets its own
+    # record -- the first fault wins a record, and a tolerated NaN must not hide a later CFL violation.
+    err_fwd, err_bwd = ops.new_error_record(dev), ops.new_error_record(dev)
+    n_bad_sweeps = [0]
+
+    def check_faults():
+        ops.raise_on_fault(err_fwd)
+        if err_bwd.tolist()[0] != 0:
+            n_bad_sweeps[0] += 1
+            err_bwd.zero_()
 
     def iteration():
-        reward, _, _, _ = ops.net_hybrid_rollout(action, dev_tab, *sim_args, check_faults=False)
+        reward, _, _, _ = ops.net_hybrid_rollout(action, dev_tab, *sim_args, check_faults=False, err=err_fwd, err_bwd=err_bwd)
         opt.zero_grad(set_to_none=False)
         (-reward.sum()).backward()
         action.grad.nan_to_num_(0.0, 0.0, 0.0)       # a replica whose reverse sweep hit 0 * inf sits this episode out
@@ -134,7 +146,10 @@ def batch(args, env, dev):
         t0 = time.time()
         for ep in range(args.n_episode):
             graph.replay()
+            if ep % 25 == 24:
+                check_faults()
         th.cuda.synchronize()
+        check_faults()
         rows = log[:args.n_episode].tolist()
         for ep in sorted(set(list(range(0, args.n_episode, 10)) + [args.n_episode - 1])):
             print("episode %4d  reward best %.6f  mean %.6f  worst %.6f" % (ep, rows[ep][0], rows[ep][1], rows[ep][2]))
@@ -144,7 +159,10 @@ def batch(args, env, dev):
     for ep in range(args.n_episode):
         stats = iteration()
         if ep % 10 == 0 or ep == args.n_episode - 1:
+            check_faults()
             report(ep, stats.tolist(), t0)
+    if n_bad_sweeps[0]:
+        print("%d fault check(s) found a non-finite reverse sweep (those replicas' gradients were dropped)" % n_bad_sweeps[0])
 
 
 if __name__ == "__main__":

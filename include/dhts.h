@@ -18,12 +18,16 @@
  *     _macro_lane.py:141-146, vehicle collision _micro_lane.py:151-162) are written to the optional
  *     device-side sticky record `dhts_error*` (first fault wins) and read back by the caller after the
  *     rollout; the rollout itself continues the way the reference's arithmetic would.
- *   - Layouts: state planes are [lane][cell] (cell fastest).  The Jacobian tape is internal to this
- *     library but documented so it can be inspected:
- *         macro: [step][lane][3][Np][4] float32, Np = dhts_padded(N) (multiple of 64); plane k = 0/1/2 holds
+ *   - Layouts: state planes are [lane][cell] (cell fastest).  The Jacobian tapes are internal to this
+ *     library but documented so they can be inspected.  There are two formats per model:
+ *       single-step operators (dhts_macro_step_*, dhts_micro_step_*) keep the reference's blocks,
+ *         macro: [lane][3][Np][4] float32, Np = dhts_padded(N) (multiple of 64); plane k = 0/1/2 holds
  *                d(next cell a)/d(cell a-1 / a / a+1) as row-major 2x2 in (r, y) -- the reference's
- *                dqs[a][k] (dmacro_lane.py:50-56) with the cell index moved inside for coalescing.
- *         micro: [step][lane][2][Vp][4] float32; plane 0 = dEgo, plane 1 = dLeading (dmicro_lane.py:48-54).
+ *                dqs[a][k] (dmacro_lane.py:50-56) with the cell index moved inside for coalescing;
+ *         micro: [lane][2][Vp][4] float32; plane 0 = dEgo, plane 1 = dLeading (dmicro_lane.py:48-54);
+ *       rollouts (dhts_macro_rollout_*, dhts_micro_rollout_*) keep COMPACT tapes the reverse sweep
+ *         rebuilds those blocks from: see dhts_macro_tape_bytes and dhts_micro_tape_bytes below;
+ *         dhts_macro_tape_expand writes a rollout's blocks out in the single-step layout.
  */
 #ifndef DHTS_H
 #define DHTS_H
@@ -84,19 +88,22 @@ int dhts_set_option(int option, int value);
 int dhts_padded(int n);
 /* bytes of Jacobian tape for T fused steps (dhts_macro_rollout_*).  The rollout tape holds, per (step, lane) row, what the
  *   reverse sweep needs to form the interface products A_i = flux'(Q_0) dQ_0/dQ_L, B_i = flux'(Q_0) dQ_0/dQ_R (the two 2x2
- *   products of dMacroLane._backward, dmacro_lane.py:116-124) of every interface i = 0 .. n_cells:
- *     S  float32 [n_cells][2]      (r, y) of the LEFT cell of interface i (i = 0: the left ghost).  Where Q_0 = Q_L (the trivial
- *                                  Riemann case) A_i is the flux Jacobian at Q_L and B_i = 0: the reverse sweep recomputes A_i
- *                                  from these 8 bytes with the forward's own code (bitwise the forward's value);
- *     H  uint32 cnt, uint32 0 | uint64 mask[ceil(n_cells / 64)] | uint16 idx[n_cells + 1]
- *                                  bit i of mask: interface i is an "exception" (Q_0 is not Q_L, or the forward kernel chose to
- *                                  solve it in full); idx[j] = the interface of exception j < cnt; interface n_cells is always one;
- *     E  float32 [n_cells + 1][2][4]   (A, B) of exception j; only the first cnt entries are written and read.
- *   Every block starts on a 128-byte line.  The reverse sweep forms the reference's cell blocks dqs[a][0] = c A_a,
- *   dqs[a][1] = I - c (A_{a+1} - B_a), dqs[a][2] = - c B_{a+1} (c = dt / dx; dmacro_lane.py:126-129) from the products with the
- *   same float32 operations, so the results are those of the 48-byte per-cell tape; dhts_macro_tape_expand writes them out.
- *   The row is sized for the worst case (every interface an exception); the bytes MOVED per row are 8 n_cells + the header +
- *   32 cnt (BASELINE config 2: cnt ~ 0.11 n_cells, 6.3 KB per 512-cell row against 24.6 KB of dqs blocks). */
+ *   products of dMacroLane._backward, dmacro_lane.py:116-124) of every interface i = 0 .. n_cells.  ROW LAYOUT (three
+ *   blocks, each rounded up to a whole number of 128-byte lines; tests/test_boundary.py parses the three lines below):
+ *     S: float32 [n_cells][3]                     (fp[0], fp[2], fp[3]) of interface i < n_cells, valid where it is trivial
+ *     H: uint32 cnt, uint32 0, uint16 idx[n_cells + 1]   idx[j] = the interface of exception j < cnt
+ *     E: float32 [n_cells + 1][2][4]              (A, B) of exception j; only the first cnt entries are written and read
+ *   Where Q_0 = Q_L (the trivial Riemann case) dQ_0/dQ_L = I and dQ_0/dQ_R = 0, so A_i is the flux Jacobian fp at Q_L
+ *   (darz.py:217-233), whose entry [0][1] is the constant 1, and B_i = 0: three floats.  Every other interface -- Q_0 is not
+ *   Q_L, or the forward kernel chose to solve it in full; interface n_cells always -- is an "exception" and keeps its two
+ *   products in E, in the order the forward solved them (its S entry is then unspecified).  There is no bit mask: a reader
+ *   marks the interfaces listed in idx[0 .. cnt) and treats the rest as trivial.  The reverse sweep forms the reference's
+ *   cell blocks dqs[a][0] = c A_a, dqs[a][1] = I - c (A_{a+1} - B_a), dqs[a][2] = - c B_{a+1} (c = dt / dx;
+ *   dmacro_lane.py:126-129) from the products with the same float32 operations, so the results are those of the 48-byte
+ *   per-cell tape; dhts_macro_tape_expand writes them out.
+ *   The row is sized for the worst case (every interface an exception); the bytes MOVED per row are 12 n_cells + 8 +
+ *   2 cnt + 32 cnt rounded to lines (BASELINE config 2: cnt ~ 0.15 n_cells, 8.8 KB per 512-cell row against 24.6 KB of
+ *   dqs blocks). */
 size_t dhts_macro_tape_bytes(const dhts_macro_desc *d, int T);
 /* the reference's blocks dqs[a][3][2][2] (dmacro_lane.py:56) of all T steps from a rollout tape, in the single-step operator's
  *   layout per step: dqs_out [T][lane][3][Np][4] float32 (T x dhts_macro_step_tape_bytes).  For tests and for callers that want
@@ -155,6 +162,14 @@ int dhts_macro_rollout_fwd(const dhts_macro_desc *d, int T,
 int dhts_macro_rollout_bwd(const dhts_macro_desc *d, int T, const float *tape,
                            const float *g_r, const float *g_y, const float *g_hist,
                            float *g_r_out, float *g_y_out, double *g_ghost, dhts_error *err, void *stream);
+
+/* Which kernel instantiations the two calls above launch for this shape and the current options (answered by the functions
+ * the launches themselves call; tests pin the benchmarked instantiations with it):
+ *   plan[0] forward kernel: 0 = two-phase, 1 = one-phase     plan[1] wavefronts per lane     plan[2] 64-cell passes per wavefront
+ *   plan[3] 1 = the full-lane, history-free instantiation (n_cells = 64 x passes x wavefronts and hist == NULL)
+ *   plan[4] reverse kernel: 1 = pipelined one-cell-per-thread, 0 = general     plan[5] its block size
+ *   plan[6] 1 = per-step cotangents / history requested (want_hist)            plan[7] 0 */
+int dhts_macro_rollout_plan(const dhts_macro_desc *d, int T, int want_hist, int32_t plan[8]);
 
 /* One step = the drop-in for a batch of dMacroForwardLayer.forward / .backward calls (T = 1 of the above;
  * tape is one step's worth). */
@@ -218,6 +233,12 @@ int dhts_micro_rollout_fwd(const dhts_micro_desc *d, int T,
 int dhts_micro_rollout_bwd(const dhts_micro_desc *d, int T, const float *tape, const int32_t *count,
                            const float *g_p, const float *g_v, const float *g_hist,
                            float *g_p_out, float *g_v_out, double *g_head, dhts_error *err, void *stream);
+
+/* Which kernel instantiations the two calls above launch (see dhts_macro_rollout_plan):
+ *   plan[0] forward wavefronts per lane (1, 2, 4)     plan[1] passes per thread (the literal K: 1, 2, 4, 8, 16)
+ *   plan[2] 1 = the full-lane instantiation (count == NULL and capacity = 64 x wavefronts x passes)
+ *   plan[3] reverse sweep: 1 = the prefetched one-vehicle-per-thread path, 0 = the strided loop     plan[4] its block size */
+int dhts_micro_rollout_plan(const dhts_micro_desc *d, int T, int has_count, int32_t plan[8]);
 
 int dhts_micro_step_fwd(const dhts_micro_desc *d,
                         const float *p, const float *v, const int32_t *count, const double *params, const double *head,

@@ -103,3 +103,55 @@ def test_two_ranks_hybrid_replicas_shared_schedule(cuda):
     assert chk["grad_max_abs_diff"] <= 1e-6 * max(abs(x) for x in chk["rank_parts"])
     units = 8 * b["config"]["units_per_lane"] * b["config"]["time_steps"]
     assert abs(b["value"] * b["ms_per_step"] * 1e-3 / (2 * units) - 1.0) < 1e-9
+
+
+RCCL_CHILD = r"""
+import json, os, sys
+sys.path.insert(0, os.path.join(%(root)r, "diff-hybrid-traffic-sim_amd"))
+import torch
+import torch.distributed as dist
+from dhts import dist as D
+rank, world, local = D.init()
+assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+flat = torch.arange(46, dtype=torch.float32, device=dev)             # [d loss / d action (45) || loss]
+ref = flat.clone()
+D.allreduce_sum_(flat)
+torch.cuda.synchronize()
+assert torch.equal(flat, ref), "a one-rank sum must return the buffer"
+big = torch.ones(1 << 20, dtype=torch.float32, device=dev)           # 4 MB: a ring-sized message, not only a latency-sized one
+D.allreduce_sum_(big)
+assert float(big.sum()) == float(1 << 20)
+parts = D.gather_to_rank0(flat)
+assert parts.shape == (1, 46) and torch.equal(parts[0], ref.cpu())
+assert D.max_over_ranks(1.25, dev) == 1.25
+D.barrier()
+print(json.dumps({"backend": dist.get_backend(), "world": world, "ok": True}))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_on_one_gpu(cuda):
+    """RCCL itself, before the first multi-GPU run: a fresh child process initialises backend "nccl" (= RCCL on ROCm) with one
+    rank (DHTS_DIST_FORCE=1 makes dhts.dist build the group and run its collectives at world size 1) and drives every helper
+    bench.py uses -- all-reduce of a device buffer, max over ranks, gather, barrier."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
+               DHTS_DIST_FORCE="1", DHTS_DIST_BACKEND="nccl")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, "-c", RCCL_CHILD % {"root": ROOT}], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert last_json(p.stdout) == {"backend": "nccl", "world": 1, "ok": True}
+
+
+@pytest.mark.gpu
+def test_bench_over_rccl_with_one_rank(cuda):
+    """bench.py's whole measured loop with its per-pass all-reduce going through RCCL (one rank, DHTS_DIST_FORCE=1)."""
+    p = run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--lanes", "64", "--time-steps", "50", "--no-cpu-baseline", "--no-also"],
+                  env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29534",
+                       "DHTS_DIST_FORCE": "1", "DHTS_DIST_BACKEND": "nccl"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = last_json(p.stdout)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["lanes_per_gpu"] == 64

@@ -46,15 +46,60 @@ def test_options_accept_documented_values_only():
     assert lib.dhts_set_option(_lib.OPT_MACRO_FWD_WAVES, 0) == 0       # back to the heuristics
 
 
+def documented_macro_tape_row():
+    """The ROW LAYOUT lines of dhts_macro_tape_bytes' comment in include/dhts.h, parsed: a list of (block, [(ctype, count
+    expression in n_cells), ...]).  The geometry tests below, bench.py's tape census and tests/test_gpu_parity.py's decoder
+    all stand on these three lines, so a header that drifts from the kernels fails here."""
+    txt = open(os.path.join(ROOT, "include", "dhts.h")).read()
+    doc = txt[txt.index("ROW LAYOUT"):txt.index("size_t dhts_macro_tape_bytes")]
+    blocks = []
+    for name in "SHE":
+        m = re.search(r"^ \*\s+%s: (.*?)(?:\s{3,}|$)" % name, doc, flags=re.M)
+        assert m, "include/dhts.h: no line for block %s of the macro rollout tape" % name
+        fields = []
+        for f in m.group(1).split(","):
+            fm = re.match(r"\s*(float32|uint32|uint16)\s+(\w+)?\s*((?:\[[^\]]+\])*)", f)
+            assert fm, "unparsed field %r" % f
+            dims = re.findall(r"\[([^\]]+)\]", fm.group(3))
+            fields.append((fm.group(1), dims))
+        blocks.append((name, fields))
+    return blocks
+
+
+def documented_macro_tape_row_bytes(N):
+    size = {"float32": 4, "uint32": 4, "uint16": 2}
+    line = lambda nbytes: (nbytes + 127) // 128 * 128      # noqa: E731
+    total, per_block = 0, {}
+    for name, fields in documented_macro_tape_row():
+        nbytes = 0
+        for ctype, dims in fields:
+            n = size[ctype]
+            for d in dims:
+                n *= int(eval(d, {"__builtins__": {}}, {"n_cells": N}))
+            nbytes += n
+        per_block[name] = line(nbytes)
+        total += line(nbytes)
+    return total, per_block
+
+
+def test_header_documents_the_tape_the_kernels_write():
+    """The header's row description, field by field (it described a layout no kernel implemented)."""
+    blocks = dict(documented_macro_tape_row())
+    assert blocks["S"] == [("float32", ["n_cells", "3"])]
+    assert blocks["H"] == [("uint32", []), ("uint32", []), ("uint16", ["n_cells + 1"])]
+    assert blocks["E"] == [("float32", ["n_cells + 1", "2", "4"])]
+    txt = open(os.path.join(ROOT, "include", "dhts.h")).read()
+    assert "mask[" not in txt and "[n_cells][2] " not in txt
+
+
 @pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 100, 512, 513, 1000, 4000])
 def test_macro_tape_rows_follow_the_documented_geometry(N):
-    """include/dhts.h: a row = S float[N][3] | H u32 cnt, u32 0, u16 idx[N + 1] | E float[N + 1][2][4], every block rounded up to
-    whole 128-byte lines (bench.py's tape census and the tests' decoders rely on exactly this)."""
+    """dhts_macro_tape_bytes equals the row include/dhts.h documents (parsed from the header's comment, not restated here),
+    every block rounded up to whole 128-byte lines."""
     from dhts import _lib
     lib = _lib.lib()
     d = _lib.MacroDesc(3, N, 0.01, 5.0, 30.0)
-    line = lambda nbytes: (nbytes + 127) // 128 * 128
-    row = line(12 * N) + line(8 + 2 * (N + 1)) + line(32 * (N + 1))
+    row, _ = documented_macro_tape_row_bytes(N)
     assert lib.dhts_macro_tape_bytes(C.byref(d), 7) == 7 * 3 * row
 
 

@@ -514,6 +514,63 @@ def test_macro_full_size_properties(cuda):
     assert torch.equal(o16[0], rT[sel]) and torch.equal(o16[2], uT[sel])
 
 
+BENCH_LANES = (0, 1, 2, 3, 500, 511, 1022, 1023)      # lanes of bench.py's rank-0 config-2 / config-3 tensors that meet the oracle
+
+
+def test_macro_bench_instantiation_vs_reference_and_oracle(cuda, oracle, golden_dir):
+    """The kernel instantiations bench.py times on BASELINE config 2 -- macro_rollout_fwd2_kernel<2, true, false> (four
+    wavefronts x two passes, full lane, no history) and macro_rollout_bwd_fast_kernel<512, false> -- at the bench's shape:
+    512 cells x 1000 steps.  Lane 4 of the batch is the reference's own 512 x 1000 run (golden c2slice: state <= 1e-5,
+    gradients <= 1e-4); the other eight lanes are lanes of the very tensors bench.py builds for rank 0, compared with the
+    oracle over all 1000 steps.  (test_macro_full_size_properties shows a lane's result does not depend on the batch.)"""
+    import torch
+    import bench
+    import dhts
+    from dhts import ops
+    g = load(golden_dir, "macro_rollout_c2slice.npz")
+    m = meta_of(g)
+    N, T, dt, dx, um = m["N"], m["T"], m["dt"], m["dx"], m["u_max"]
+    assert (N, T, dt, dx, um) == (512, 1000, 0.01, 5.0, 30.0)
+    r0b, u0b, grb, gub = (t.numpy() for t in bench.MacroWorkload.inputs(0, 1024, 512, um))
+    pick = list(BENCH_LANES)
+    r0 = np.concatenate([r0b[pick[:4]], g["r0"][None], r0b[pick[4:]]]).astype(np.float32)
+    u0 = np.concatenate([u0b[pick[:4]], g["u0"][None], u0b[pick[4:]]]).astype(np.float32)
+    gr = np.concatenate([grb[pick[:4]], g["ghost_r"][None], grb[pick[4:]]]).astype(np.float32)
+    gu = np.concatenate([gub[pick[:4]], g["ghost_u"][None], gub[pick[4:]]]).astype(np.float32)
+    L = r0.shape[0]
+    # the launch this test makes is the one the bench makes
+    plan = ops.macro_rollout_plan(ops.macro_desc(L, N, dt, dx, um), T, want_hist=False)
+    assert plan == ops.macro_rollout_plan(ops.macro_desc(1024, N, dt, dx, um), T, want_hist=False)
+    assert plan == dict(fwd_one_phase=0, fwd_waves=4, fwd_passes=2, fwd_full_lane=1, bwd_pipelined=1, bwd_block=512, hist=0)
+    tr0, tu0 = T_(r0, cuda, grad=True), T_(u0, cuda, grad=True)
+    tgr, tgu = T_(gr, cuda, grad=True), T_(gu, cuda, grad=True)
+    rT, yT, uT, _ = dhts.macro_rollout(tr0, tu0, tgr, tgu, T, dt, dx, um)          # no history: the bench's instantiation
+    ((rT ** 2).sum() + (uT ** 2).sum()).backward()
+    rT, yT, uT = (t.detach().cpu().numpy() for t in (rT, yT, uT))
+    g_r0, g_u0, g_gr, g_gu = (t.grad.cpu().numpy() for t in (tr0, tu0, tgr, tgu))
+    # the reference's lane
+    k = 4
+    assert rel_max(rT[k], g["rT"]) <= TOL_STATE and rel_max(yT[k], g["yT"]) <= TOL_STATE and rel_max(uT[k], g["uT"]) <= TOL_STATE
+    e_elem = max(rel_elem(rT[k], g["rT"]), rel_elem(uT[k], g["uT"]))
+    print("G4 c2slice (bench instantiation): element-wise state error %.2e" % e_elem)
+    assert e_elem <= TOL_STATE
+    assert grad_report("G4 c2slice (bench instantiation) d loss / d r0", g_r0[k], g["g_r0"]) <= TOL_GRAD
+    assert grad_report("G4 c2slice (bench instantiation) d loss / d u0", g_u0[k], g["g_u0"]) <= TOL_GRAD
+    assert rel_max(g_gr[k], g["g_ghost_r"]) <= TOL_GRAD and rel_max(g_gu[k], g["g_ghost_u"]) <= TOL_GRAD
+    # config 2's own lanes against the oracle, all 1000 steps
+    f = oracle.macro_rollout_fwd(r0, u0, gr, gu, T, dt, dx, um)
+    assert f["rc"] == 0
+    b = oracle.macro_rollout_bwd(f, g_rT=2 * f["rT"], g_uT=2 * f["uT"])
+    worst_s = worst_g = 0.0
+    for j in range(L):
+        worst_s = max(worst_s, rel_elem(rT[j], f["rT"][j]), rel_elem(uT[j], f["uT"][j]), rel_max(yT[j], f["yT"][j]))
+        worst_g = max(worst_g, rel_max(g_r0[j], b["g_r0"][j]), rel_max(g_u0[j], b["g_u0"][j]))
+        assert rel_max(g_gr[j], b["g_ghost_r"][j]) <= TOL_GRAD and rel_max(g_gu[j], b["g_ghost_u"][j]) <= TOL_GRAD
+    print("config 2 lanes %s (bench instantiation) vs oracle over %d steps: state %.2e (element-wise), gradient %.2e" % (
+        pick, T, worst_s, worst_g))
+    assert worst_s <= TOL_STATE and worst_g <= TOL_GRAD
+
+
 # =================================================================================================================
 # micro
 # =================================================================================================================
@@ -677,3 +734,78 @@ def test_micro_full_size_properties(cuda):
     tape2 = torch.empty_like(tape)
     pT2, vT2 = ops.micro_rollout_fwd(desc, T, p0, v0, params, head, tape=tape2)
     assert torch.equal(pT, pT2) and torch.equal(vT, vT2) and torch.equal(tape, tape2)
+
+
+def test_micro_bench_instantiation_vs_reference_and_oracle(cuda, oracle, golden_dir):
+    """The instantiations bench.py times on BASELINE config 3 -- micro_rollout_fwd_kernel<2, 2, true, true> (two wavefronts x
+    two passes, full lane) and the one-vehicle-per-thread reverse path -- at the bench's shape: 256 vehicles x 1000 steps.
+    Lane 4 is the reference's own 256 x 1000 run (golden c3slice; the oracle reproduces it bit for bit); the other eight are
+    lanes of bench.py's rank-0 tensors against the oracle over all 1000 steps."""
+    import torch
+    import bench
+    import dhts
+    from dhts import ops
+    g = load(golden_dir, "micro_rollout_c3slice.npz")
+    m = meta_of(g)
+    V, T, dt = m["V"], m["T"], m["dt"]
+    assert (V, T, dt) == (256, 1000, 0.01) and np.allclose(g["params"], np.array(bench.MicroWorkload.PARAMS)[None, :])
+    p0b, v0b = (t.numpy() for t in bench.MicroWorkload.inputs(0, 4096, 256))
+    pick = list(BENCH_LANES)
+    p0 = np.concatenate([p0b[pick[:4]], g["p0"][None], p0b[pick[4:]]]).astype(np.float32)
+    v0 = np.concatenate([v0b[pick[:4]], g["v0"][None], v0b[pick[4:]]]).astype(np.float32)
+    L = p0.shape[0]
+    plan = ops.micro_rollout_plan(ops.micro_desc(L, V, dt), T, has_count=False)
+    assert plan == ops.micro_rollout_plan(ops.micro_desc(4096, V, dt), T, has_count=False)
+    assert plan == dict(fwd_waves=2, fwd_passes=2, fwd_full_lane=1, bwd_one_vehicle_per_thread=1, bwd_block=256)
+    par = np.tile(np.array(bench.MicroWorkload.PARAMS), (L, V, 1))
+    params = T_(np.ascontiguousarray(par.transpose(2, 0, 1)), cuda, dtype=torch.float64)
+    head = torch.tensor([[1000.0, 0.0]] * L, dtype=torch.float64, device=cuda)
+    tp0, tv0 = T_(p0, cuda, grad=True), T_(v0, cuda, grad=True)
+    pT, vT = dhts.micro_rollout(tp0, tv0, params, head, T, dt)
+    (1e-4 * (pT ** 2).sum() + (vT ** 2).sum()).backward()
+    pT, vT = pT.detach().cpu().numpy(), vT.detach().cpu().numpy()
+    g_p0, g_v0 = tp0.grad.cpu().numpy(), tv0.grad.cpu().numpy()
+    k = 4
+    assert rel_elem(pT[k], g["pT"]) <= TOL_STATE and rel_elem(vT[k], g["vT"]) <= TOL_STATE
+    assert grad_report("G6 c3slice (bench instantiation) d loss / d p0", g_p0[k], g["g_p0"]) <= TOL_GRAD
+    assert grad_report("G6 c3slice (bench instantiation) d loss / d v0", g_v0[k], g["g_v0"]) <= TOL_GRAD
+    f = oracle.micro_rollout_fwd(p0, v0, par, T, dt)
+    assert f["rc"] == 0
+    b = oracle.micro_rollout_bwd(f, g_pT=np.float32(2e-4) * f["pT"], g_vT=2 * f["vT"])
+    e_s = max(rel_elem(pT, f["pT"]), rel_elem(vT, f["vT"]))
+    e_g = max(rel_max(g_p0, b["g_p0"]), rel_max(g_v0, b["g_v0"]))
+    print("config 3 lanes %s (bench instantiation) vs oracle over %d steps: state %.2e (element-wise), gradient %.2e" % (pick, T, e_s, e_g))
+    assert e_s <= TOL_STATE and e_g <= TOL_GRAD
+
+
+def test_micro_zero_step_backward(cuda):
+    """T = 0: the reverse sweep has no tape (a NULL pointer from an empty tensor) and must hand the cotangents through."""
+    import torch
+    from dhts import ops
+    L, V = 3, 200
+    desc = ops.micro_desc(L, V, 0.01)
+    g_p, g_v = torch.randn(L, V, device=cuda), torch.randn(L, V, device=cuda)
+    tape = torch.empty(0, device=cuda)
+    err = ops.new_error_record(cuda)
+    o_p, o_v, g_head = ops.micro_rollout_bwd(desc, 0, tape, g_p, g_v, err=err)
+    torch.cuda.synchronize()
+    assert torch.equal(o_p, g_p) and torch.equal(o_v, g_v) and float(g_head.abs().max()) == 0.0 and err.tolist()[0] == 0
+    assert ops.micro_rollout_plan(desc, 0)["bwd_one_vehicle_per_thread"] == 0
+
+
+def test_micro_reverse_sweep_reports_non_finite_gradient(cuda):
+    """A non-finite cotangent in the micro reverse sweep is kept in the result (the reference's dMicroForwardLayer.backward
+    has no assert, dmicro_lane.py:271-298) and recorded as DHTS_FAULT_NAN with its step / lane / vehicle."""
+    import torch
+    from dhts import _lib, ops
+    L, V, T = 4, 128, 6
+    desc = ops.micro_desc(L, V, 0.01)
+    tape = torch.zeros(ops.micro_tape_numel(desc, T), device=cuda)
+    t3 = tape.view(T, L, 128, 3)
+    t3[3, 2, 17, 1] = float("inf")                  # dEgo[1][1] of vehicle 17, lane 2, step 3
+    g = torch.ones(L, V, device=cuda)
+    err = ops.new_error_record(cuda)
+    o_p, o_v, _ = ops.micro_rollout_bwd(desc, T, tape, g, g.clone(), err=err)
+    code, step, lane, index = err.tolist()
+    assert (code, step, lane, index) == (_lib.FAULT_NAN, 3, 2, 17)
+    assert not bool(torch.isfinite(o_v[2, 17]))

@@ -53,7 +53,7 @@ def test_macro_step(oracle, golden_dir, name):
 
 
 # ---- G4: macro rollouts ---------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["small", "c1", "sanity", "bench64", "long"])
+@pytest.mark.parametrize("name", ["small", "c1", "sanity", "bench64", "long", "c2slice"])
 def test_macro_rollout(oracle, golden_dir, name):
     g = load(golden_dir, "macro_rollout_%s.npz" % name)
     m = meta_of(g)
@@ -99,7 +99,7 @@ def test_idm_kat_bit_exact(oracle, golden_dir):
 
 
 # ---- G6: micro rollouts: bit-exact state AND gradients ---------------------------------------------------------
-@pytest.mark.parametrize("name", ["inv10", "rand24", "dense16", "long"])
+@pytest.mark.parametrize("name", ["inv10", "rand24", "dense16", "long", "c3slice"])
 def test_micro_rollout_bit_exact(oracle, golden_dir, name):
     g = load(golden_dir, "micro_rollout_%s.npz" % name)
     m = meta_of(g)

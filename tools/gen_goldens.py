@@ -393,6 +393,9 @@ def gen_macro_rollouts(which):
         macro_rollout("bench64", 64, 300, 5.0, 0.01, 30.0, seed=2026, init="bench", tap="final_sq", record_steps=4)
     if "long" in which:      # error growth check at T = 1000
         macro_rollout("long", 48, 1000, 5.0, 0.01, 30.0, seed=11, init="bench", tap="final_sq", record_steps=0)
+    if "c2slice" in which:   # ONE lane of BASELINE config 2 at its full shape: 512 cells x 1000 steps (round 3: pins the
+        # very kernel instantiations bench.py times -- four wavefronts x two passes, no history -- against the reference)
+        macro_rollout("c2slice", 512, 1000, 5.0, 0.01, 30.0, seed=2027, init="bench", tap="final_sq", record_steps=0)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -511,6 +514,8 @@ def gen_micro_rollouts(which):
                       spacing=4.0, jitter=2.0, vlo=0.3, vhi=0.7)
     if "long" in which:      # T = 1000
         micro_rollout("long", 12, 1000, 0.01, 30.0, seed=12, params="default", tap="final_sq", record_steps=0)
+    if "c3slice" in which:   # ONE lane of BASELINE config 3 at its full shape: 256 default vehicles x 1000 steps
+        micro_rollout("c3slice", 256, 1000, 0.01, 30.0, seed=2028, params="default", tap="final_sq", record_steps=0)
 
 
 # ----------------------------------------------------------------------------------------------
