@@ -293,6 +293,11 @@ __device__ __forceinline__ void cell_glue_pre(float r, float y, float umf, const
 //   * the trivial interfaces' tape entries (three floats of the flux Jacobian) formed in phase 2 by the wavefronts that hold no
 //     queue entry instead of in phase 1: 4.48 ms against 4.32 -- with two workgroups per CU those wavefronts are not idle
 //     time, they are the other workgroup's phase 1;
+//   * (round 3; all bitwise equal to the kernel below, gpurun_out/r03b_variants.log) the queue dealt round-robin over all four
+//     wavefronts, 19 entries each, instead of 64 to the first and the rest to the second: 3.84 ms against 3.46 -- a wave
+//     instruction costs its issue slot whatever its EXEC mask, so four wavefronts pay for the solve's stream instead of two;
+//     phase 1 staged over both passes (every update, then every interface, then ONE queue append per wavefront): 3.50 --
+//     the passes' streams interleave but the append was not what the wavefront waited for;
 //   * two traffic lanes per workgroup half a step apart (phase 1 of one lane beside phase 2 of the other in every barrier
 //     interval, 4 + 4 wavefronts, two phase-1 passes per thread interleaved stage by stage): 6.1 ms -- an interval takes
 //     ~5100 cycles for the phase-1 waves and ~4000-4700 for the phase-2 waves that share their SIMDs, against 2000 + 1800
@@ -357,6 +362,11 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
     float *hp_run = (kHist && hist) ? hist + (size_t)lane * 3 * N : nullptr;
     const size_t tp_stride = (size_t)L * geo.row_f4, hp_stride = (size_t)L * 3 * N;
 
+    // (r, y) of a thread's own cells as doubles, carried from step to step: a thread owns the same cells for the whole rollout,
+    // so the update neither re-reads them from the record nor widens them again (literal pass counts only; 3.46 -> 3.39 ms)
+    constexpr bool kKeep = kP > 0;
+    double rd_own[kP > 0 ? kP : 1], yd_own[kP > 0 ? kP : 1];
+
     auto body = [&](auto upd_c, auto solve_c, const int n) {
         constexpr bool upd = decltype(upd_c)::value;       // finish step n - 1
         constexpr bool solve = decltype(solve_c)::value;   // start step n
@@ -373,12 +383,17 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
             const bool vc = kFull || i < N;
             const unsigned ic = (unsigned)(vc ? i : N - 1);
             CellRec *own = CR + ic + 1;
-            float4 st = own->st;
+            float4 st;
+            if (!(kKeep && upd)) st = own->st;
+            if (kKeep && !upd) { rd_own[kP > 0 ? j : 0] = (double)st.x; yd_own[kP > 0 ? j : 0] = (double)st.y; }
             if (upd) {
                 // Godunov update, _macro_lane.py:109-112, float32 store :327-334
                 const double2 Fl = FX[ic], Fr = FX[ic + 1];
-                st.x = (float)((double)st.x + (Fl.x - Fr.x) * c);
-                st.y = (float)((double)st.y + (Fl.y - Fr.y) * c);
+                const double r_old = kKeep ? rd_own[kP > 0 ? j : 0] : (double)st.x;
+                const double y_old = kKeep ? yd_own[kP > 0 ? j : 0] : (double)st.y;
+                st.x = (float)(r_old + (Fl.x - Fr.x) * c);
+                st.y = (float)(y_old + (Fl.y - Fr.y) * c);
+                if (kKeep) { rd_own[kP > 0 ? j : 0] = (double)st.x; yd_own[kP > 0 ? j : 0] = (double)st.y; }
                 CellPre cp;
                 cell_glue_pre(st.x, st.y, umf, kc, st.z, st.w, cp);     // set_next_state_vector_y, :282-299
                 if (vc && solve) { own->st = st; own->sh = make_double2(cp.s, cp.h); own->q0 = make_double2(cp.q0, 0.); }

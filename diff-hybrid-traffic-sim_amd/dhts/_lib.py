@@ -9,7 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
-SO_PATH = os.path.join(CSRC, "libdhts.so")
+# DHTS_LIB: another build of the same library (tuning experiments: tools/build_variants.sh); the default is the in-tree build
+SO_PATH = os.environ.get("DHTS_LIB") or os.path.join(CSRC, "libdhts.so")
 
 OK, E_INVALID, E_LAUNCH, E_NO_DEVICE = 0, -1, -2, -3
 FAULT_NONE, FAULT_CFL, FAULT_COLLISION, FAULT_NAN, FAULT_CAPACITY = 0, 1, 2, 3, 4
