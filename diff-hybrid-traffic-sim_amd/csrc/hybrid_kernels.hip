@@ -123,8 +123,10 @@ struct Rec {               // one lane's handle on its staging area (LDS) and it
     int *sk; int *si; float *sw;
     int cnt, next_local;
     bool over;
+    bool off;              // an evaluation episode keeps no records (nothing will be replayed)
 };
 __device__ __forceinline__ void rec_push(Rec &R, int kind, int out, int4 in, float4 w) {
+    if (R.off) return;
     if (R.cnt >= kStageH) { R.over = true; return; }
     const int c = R.cnt++;
     R.sk[c] = (kind << 24) | (out & 0xffffff);
@@ -283,7 +285,13 @@ __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS) {
 // ---------------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------------
-template <int kMaxBlock>
+// kHard: an EVALUATION episode (ItscpEnv.step(action, False); Trainer.evaluate, trainer.py:94-142): hard signals float(a > progress)
+// (_env.py:928-960), the macro downstream ghost takes float(signal > 0.5) (_simulator.py:128-137), a head vehicle takes the green
+// gap when the signal of its own lane is >= 0.5 and the red one otherwise (scores 0 / 1 / 0, no running mean: _simulator.py:208-
+// 276), a cell / a vehicle is static when its speed is below static_speed (_env.py:607-617, 709-717).  The steps themselves and the hand-offs are the
+// same.  Nothing is kept for a reverse sweep: no records, no tape, no history, no loss constants (hist, tape, kc and the
+// workspace are not touched and may be NULL).
+template <int kMaxBlock, bool kHard>
 __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
                                       double static_speed, double veh_len, HybTables tb, const float *__restrict__ action,
                                       float *__restrict__ hist, float4 *__restrict__ tape, float *__restrict__ kc,
@@ -315,11 +323,11 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     float *act = reinterpret_cast<float *>(lds + lo.total);
     for (int i = tid; i < n_action; i += B) act[i] = action[(size_t)rep * n_action + i];
     const size_t toff = (size_t)rep * tb.net.table_stride;
-    float *hist_r = hist + (size_t)rep * (T + 1) * 4 * C;
-    float4 *tape_r = tape + (size_t)rep * T * 3 * Cp;
-    float *kc_r = kc + (size_t)rep * T * C;
+    float *hist_r = kHard ? nullptr : hist + (size_t)rep * (T + 1) * 4 * C;
+    float4 *tape_r = kHard ? nullptr : tape + (size_t)rep * T * 3 * Cp;
+    float *kc_r = kHard ? nullptr : kc + (size_t)rep * T * C;
     float *queue_r = queue + (size_t)rep * T * L;
-    char *wsr = workspace + (size_t)rep * ws.per_replica;
+    char *wsr = kHard ? nullptr : workspace + (size_t)rep * ws.per_replica;
     float *own_w = reinterpret_cast<float *>(wsr + ws.own_hist);
     int *step_off = reinterpret_cast<int *>(wsr + ws.step_off);
     unsigned short *seg_cnt = reinterpret_cast<unsigned short *>(wsr + ws.seg_cnt);
@@ -339,7 +347,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     }
     if (tid < C) {
         S0[tid] = 0.f; S0[C + tid] = 0.f; S0[2 * C + tid] = um; S0[3 * C + tid] = um;
-        hist_r[tid] = 0.f; hist_r[C + tid] = 0.f; hist_r[2 * C + tid] = um; hist_r[3 * C + tid] = um;
+        if (!kHard) { hist_r[tid] = 0.f; hist_r[C + tid] = 0.f; hist_r[2 * C + tid] = um; hist_r[3 * C + tid] = um; }
     }
     __syncthreads();
     int n_micro = 0, n_caps = 0, n_conv = 0, n_macro = 0;
@@ -402,7 +410,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     const int sg_base = sq <= 64 ? (((B >> 6) - 2) << 6) : 0;
     const bool is_sg = tid >= sg_base && tid < sg_base + sq;
     const int sg_q = tid - sg_base;
-    if (is_sg) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, 0, 0, sg_q, we, ns, a, pr, ai); sig[2 * sg_q] = we; sig[2 * sg_q + 1] = ns; }
+    if (is_sg) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, 0, 0, sg_q, we, ns, a, pr, ai, kHard); sig[2 * sg_q] = we; sig[2 * sg_q + 1] = ns; }
     if (++sig_fr == F) { sig_fr = 0; ++sig_ph; }
 
     // ---- micro wave state
@@ -411,7 +419,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     float4 *grw = reinterpret_cast<float4 *>(wsr + ws.rec_w);
     const int base_local = 3 * V + kMaxCaps;
     Rec rec;
-    rec.next_local = base_local; rec.over = false;
+    rec.next_local = base_local; rec.over = false; rec.off = kHard;
     auto rec_select = [&](int b) {                   // this lane's staging half `b`, empty
         const int sl = (in_mw && mw < NS) ? mw : 0;
         rec.sk = stg_k + (sl * 2 + b) * kStageH; rec.si = stg_i + (sl * 2 + b) * kStageH * 4; rec.sw = stg_w + (sl * 2 + b) * kStageH * 4;
@@ -451,6 +459,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     auto vehicle_samples = [&](int ls) {
         const int k = fl;
         const int c = k < n_micro ? lane_n[k] : 0;
+        if (kHard) {                                   // is_static of every vehicle: 1.0 if speed < static_speed else 0.0
+            for (int i = 0; i < c; ++i) { const int vi = lane_veh[k * kLaneCap + i]; vx[vi] = vv[vi] < s0f ? 1.f : 0.f; }
+            return;
+        }
         const int exc = k <= n_micro ? vcp_of(ls)[k] : 0;
         double ssum = 0., esum = 0.;
         for (int i = 0; i < c; ++i) {
@@ -466,6 +478,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         if (k <= n_micro) { vsp[k] = is_ - ssum; vep[k] = ie_ - esum; }
     };
     auto flush_block = [&](int blk) {
+        if (kHard) return;
         const int b = blk & 1;
         const int c0 = cnt_s[(b * kPhases + 0) * 64 + fl], c1 = cnt_s[(b * kPhases + 1) * 64 + fl], c2 = cnt_s[(b * kPhases + 2) * 64 + fl];
         const int c = c0 + c1 + c2;
@@ -520,6 +533,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     //      the records of step t-1 are flushed beside the ghosts of step t
     float x_new = 0.f;
     auto loss_scan = [&](const float *st, int ls) {
+        if (kHard) return;                            // (no running mean in an evaluation episode)
         const int *vcp_l = vcp_of(ls);
         if ((tid & ~63) < C) {                        // waves without cells (the micro wave) have nothing to add
             double a = 0., b = 0.;
@@ -537,6 +551,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     };
     double tot_a = 0., tot_b = 0.;
     auto loss_consts = [&](const float *st, int ls) {
+        if (kHard) {
+            if (is_cell) contrib[tid] = (st[2 * C + tid] < s0f ? 1.f : 0.f) * (st[tid] * c_dxv);
+            return;
+        }
         const int *vcp_l = vcp_of(ls);
         const int nwc = (C + 63) >> 6;
         tot_a = 0.; tot_b = 0.;
@@ -566,7 +584,11 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             if (k < n_micro) {
                 qmicro[k] = 0.f;
                 const int nv = lane_n[k];
-                if (nv > 0) {
+                if (kHard) {
+                    float q = 0.f;
+                    for (int i = 0; i < nv; ++i) q = q + vx[lane_veh[k * kLaneCap + i]];
+                    qmicro[k] = (q * q) * dtf;
+                } else if (nv > 0) {
                     const int cb = cbefore[k];
                     double pa = run_in + vsp[k], pb = run_out + vep[k];
                     if (cb > 0) {
@@ -614,7 +636,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             }
         }
     };
-    auto run_update = [&](int ls) { run_in += tot_a + vsp[n_micro]; run_out += tot_b + vep[n_micro]; run_cnt += C + vcp_of(ls)[n_micro]; };
+    auto run_update = [&](int ls) { if (kHard) return; run_in += tot_a + vsp[n_micro]; run_out += tot_b + vep[n_micro]; run_cnt += C + vcp_of(ls)[n_micro]; };
     auto loss_lanes = [&](int ls) {
         if (is_lane) {
             float term;
@@ -654,9 +676,9 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             } else {
                 float gr = own_r, gu = own_u;
                 if (src >= 0) { const int first = lfl[src] & 0xffff; gr = cur[first]; gu = cur[2 * C + first]; }
-                own_w[(size_t)t * 2 * L + 2 * g_lane] = own_r; own_w[(size_t)t * 2 * L + 2 * g_lane + 1] = own_u;
+                if (!kHard) { own_w[(size_t)t * 2 * L + 2 * g_lane] = own_r; own_w[(size_t)t * 2 * L + 2 * g_lane + 1] = own_u; }
                 const float sg = g_kind != 0 ? sig[2 * g_inter + (g_kind - 1)] : 1.f;
-                const float s2 = soft_switch(sg - 0.5f, kSigK);
+                const float s2 = kHard ? (sg > 0.5f ? 1.f : 0.f) : soft_switch(sg - 0.5f, kSigK);
                 fr = s2 * gr + (1.0f - s2) * 1.0f;
                 fu = s2 * gu + (1.0f - s2) * 0.0f;
                 glue_from_r_u(fr, fu, um, fy, fq);
@@ -714,9 +736,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     red_dp = du_pos_or_zero(du_sub(du_sub(Lc, hp), half));
                     const bool prev_exist = cursor > 0, next_exist = cursor < rlen - 1;
                     Du<kP> prev_s = du_as<kP>(du_c(0.f)), next_s = du_as<kP>(du_c(0.f));
-                    if (prev_exist) prev_s = du_soft(du_sub(du_c(0.f), hp), 16.f);
-                    const Du<kP> curr_s = du_mul(du_soft(hp, 16.f), du_soft(du_sub(Lc, hp), 16.f));
-                    if (next_exist) next_s = du_soft(du_sub(hp, Lc), 16.f);
+                    // (evaluation episode: the scores are 0 / 1 / 0, _simulator.py:208-232)
+                    if (prev_exist && !kHard) prev_s = du_soft(du_sub(du_c(0.f), hp), 16.f);
+                    const Du<kP> curr_s = kHard ? du_as<kP>(du_c(1.f)) : du_mul(du_soft(hp, 16.f), du_soft(du_sub(Lc, hp), 16.f));
+                    if (next_exist && !kHard) next_s = du_soft(du_sub(hp, Lc), 16.f);
                     const Du<kP> total = du_add(du_add(prev_s, curr_s), next_s);
                     // one term of the position-weighted blend: (score / total) * signal of that lane (1 for a lane without one)
 #define DHTS_BLEND_TERM(W, SC)                                                                                                  \
@@ -745,7 +768,11 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 // signal_rms: running mean over the occupied lanes in lane order (_simulator.py:249-256)
                 const double ssum = wave_scan_add(act ? (double)fin.v : 0.);
                 const int scnt = wave_scan_add(act ? 1 : 0);
-                if (act) {
+                if (act && kHard) {                       // is_signal_green(final_signal): signal >= 0.5 (_simulator.py:264-276)
+                    const bool green = fin.v >= 0.5f;
+                    hdpv[k] = green ? green_dp.v : red_dp.v; hdpi[k] = -1;
+                    hdvv[k] = green ? green_dv.v : 0.f; hdvi[k] = -1;
+                } else if (act) {
                     const float k2 = 32.f / fabsf((float)((sig_sum + ssum) / (double)(sig_cnt + scnt)));
                     const auto fs = du_soft(du_sub(fin, du_c(0.5f)), k2);
                     const auto one_m = du_sub(du_c(1.f), fs);
@@ -816,7 +843,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             nxt[c] = nr; nxt[C + c] = ny; nxt[2 * C + c] = nu; nxt[3 * C + c] = nq;
             // (the step's tape blocks are assembled in the next phase: the hand-offs wait for the new state, not for them)
         }
-        if (is_sg && t + 1 < T) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, sig_ph, sig_fr, sg_q, we, ns, a, pr, ai); sig[2 * sg_q] = we; sig[2 * sg_q + 1] = ns; }
+        if (is_sg && t + 1 < T) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, sig_ph, sig_fr, sg_q, we, ns, a, pr, ai, kHard); sig[2 * sg_q] = we; sig[2 * sg_q + 1] = ns; }
         if (++sig_fr == F) { sig_fr = 0; ++sig_ph; }
         // micro wave (idle in this phase): has a head vehicle run past the point where it leaves its lane?  (The vehicles
         // moved in the last phase; nothing touches them again before the hand-off phase looks at this.)
@@ -831,7 +858,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         HYB_BARRIER(2);
         // ================= D: flux capacitors, hand-off events in lane-id order, commits (micro wave) | loss constants of
         //                    the state after step t-1 + its history row (the cells have nothing else to do here) =========
-        if (is_cell) {
+        if (is_cell && !kHard) {
             // the cell's tape blocks from the interface products of phase B (dmacro_lane.py:126-129): the cells have slack in
             // this phase (the micro wave's hand-offs are its critical path), none in the last one
             const int c = tid;
@@ -1010,7 +1037,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         loss_lanes(T - 1);
     }
     if (is_fw) {
-        if (fl == 0) { step_off[T + 1] = rec_n; counts[4 * rep + 2] = rec_n; }
+        if (fl == 0) { if (!kHard) step_off[T + 1] = rec_n; counts[4 * rep + 2] = rec_n; }
         if (fl_fault) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, rec_n);
     }
     if (in_mw) {
@@ -1584,7 +1611,7 @@ int dhts_net_hybrid_rollout_fwd(const dhts_net_desc *d, const dhts_hybrid_tables
     const HybWs ws = hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step);
     const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, t->n_micro > kMaxCaps ? t->n_micro : kMaxCaps).total + up16(sizeof(float) * (size_t)d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
-    auto kern = B <= 512 ? net_hybrid_fwd_kernel<512> : net_hybrid_fwd_kernel<1024>;
+    auto kern = B <= 512 ? net_hybrid_fwd_kernel<512, false> : net_hybrid_fwd_kernel<1024, false>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_LAUNCH;
@@ -1592,6 +1619,25 @@ int dhts_net_hybrid_rollout_fwd(const dhts_net_desc *d, const dhts_hybrid_tables
         d->n_replicas, d->n_lanes, d->n_cells, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max,
         d->static_speed, d->vehicle_length, hyb_tables(t), action, hist, reinterpret_cast<float4 *>(tape), kc, queue, reward,
         counts, reinterpret_cast<char *>(workspace), t->records_per_step, err);
+    return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
+}
+
+int dhts_net_hybrid_rollout_eval(const dhts_net_desc *d, const dhts_hybrid_tables *t, const float *action, float *queue,
+                                 float *reward, int32_t *counts, dhts_error *err, void *stream) {
+    if (!hyb_desc_ok(d) || !hyb_tables_ok(t) || !action || !queue || !reward || !counts) return DHTS_E_INVALID;
+    const int B = hyb_block(d);
+    if (B > 1024) return DHTS_E_INVALID;
+    const HybWs ws = hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step);
+    const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, t->n_micro > kMaxCaps ? t->n_micro : kMaxCaps).total + up16(sizeof(float) * (size_t)d->n_action);
+    if (lds > 160 * 1024) return DHTS_E_INVALID;
+    auto kern = B <= 512 ? net_hybrid_fwd_kernel<512, true> : net_hybrid_fwd_kernel<1024, true>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DHTS_E_LAUNCH;
+    kern<<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
+        d->n_replicas, d->n_lanes, d->n_cells, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max,
+        d->static_speed, d->vehicle_length, hyb_tables(t), action, nullptr, nullptr, nullptr, queue, reward, counts, nullptr,
+        t->records_per_step, err);
     return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
 }
 

@@ -83,8 +83,9 @@ __device__ __forceinline__ void net_fault(dhts_error *err, int code, int step, i
 
 // phase signals of intersection k at step t: west-east and north-south switches and their inputs (_env.py:885-962).
 // `phase_raw` = t / F and `frame` = t % F are passed in so that rollouts can count them instead of dividing every step.
+// hard = an evaluation episode (differentiable = False): float(a > progress), float(progress > a) (_env.py:928-960).
 __device__ __forceinline__ void phase_signal_at(const float *action, int n_action, int sq, int F, int phase_raw, int frame, int k,
-                                                float &we, float &ns, float &a, float &prog, int &a_index) {
+                                                float &we, float &ns, float &a, float &prog, int &a_index, bool hard = false) {
     const int last = n_action / sq - 1;
     const int phase = phase_raw > last ? last : phase_raw;
     double pr = (double)frame / (double)F;
@@ -92,6 +93,7 @@ __device__ __forceinline__ void phase_signal_at(const float *action, int n_actio
     a_index = phase * sq + k;
     a = action[a_index];
     prog = (float)pr;
+    if (hard) { we = a > prog ? 1.f : 0.f; ns = prog > a ? 1.f : 0.f; return; }
     we = soft_switch(a - prog, kSigK);
     ns = soft_switch(prog - a, kSigK);
 }

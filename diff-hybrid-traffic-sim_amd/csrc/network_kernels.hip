@@ -60,6 +60,11 @@ __device__ __forceinline__ NetStaged net_staged(char *lds, size_t base, int L, i
 // 100 000 samples; beyond that many (T * C > 100 000) a second scan subtracts the samples that have left the window,
 // re-read from the state history this kernel writes anyway (sample (step, cell) = static_speed - u of history row step + 1).
 // LDS: doubles Fq [NI][2], scanw [2][16] | floats S0, S1 [4][C], G [L][2][4], AB [NI][8], contrib [C], ql [L]
+// kHard: an EVALUATION episode (ItscpEnv.step(action, False), what Trainer.evaluate runs, trainer.py:94-142): the signals are
+// float(a > progress) (_env.py:928-960), the downstream ghost takes float(signal > 0.5) (_simulator.py:128-137), a cell is static
+// when u < static_speed (_env.py:607-617: no running mean, no sigmoid); nothing is kept for a reverse sweep (hist, tape, kc and
+// own_hist are not touched and may be NULL).
+template <bool kHard>
 __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
                                      double static_speed, double veh_len, NetTables tb, const float *__restrict__ action,
                                      float *__restrict__ hist, float4 *__restrict__ tape, float *__restrict__ kc,
@@ -85,11 +90,11 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
     float *act = st_.act; float *sig = st_.sig; int *lfl = st_.lfl, *linfo = st_.linfo;
     for (int i = tid; i < n_action; i += B) act[i] = action[(size_t)rep * n_action + i];
     const size_t toff = (size_t)rep * tb.table_stride;
-    float *hist_r = hist + (size_t)rep * (T + 1) * 4 * C;
-    float4 *tape_r = tape + (size_t)rep * T * 3 * Cp;
-    float *kc_r = kc + (size_t)rep * T * C;
+    float *hist_r = kHard ? nullptr : hist + (size_t)rep * (T + 1) * 4 * C;
+    float4 *tape_r = kHard ? nullptr : tape + (size_t)rep * T * 3 * Cp;
+    float *kc_r = kHard ? nullptr : kc + (size_t)rep * T * C;
     float *queue_r = queue + (size_t)rep * T * L;
-    float *own_w = own_hist + (size_t)rep * T * 2 * L;       // downstream green values of sink lanes per step (for the reverse)
+    float *own_w = kHard ? nullptr : own_hist + (size_t)rep * T * 2 * L;       // downstream green values of sink lanes per step (for the reverse)
 
     if (tid < L) {
         const int off = tb.lane_off[tid], n = tb.lane_ncell[tid];
@@ -100,7 +105,7 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
     }
     if (tid < C) {
         S0[tid] = 0.f; S0[C + tid] = 0.f; S0[2 * C + tid] = um; S0[3 * C + tid] = um;          // empty lanes
-        hist_r[tid] = 0.f; hist_r[C + tid] = 0.f; hist_r[2 * C + tid] = um; hist_r[3 * C + tid] = um;
+        if (!kHard) { hist_r[tid] = 0.f; hist_r[C + tid] = 0.f; hist_r[2 * C + tid] = um; hist_r[3 * C + tid] = um; }
     }
     __syncthreads();
     // ---- per-thread roles
@@ -138,7 +143,7 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
     const bool is_sg = tid >= sg_base && tid < sg_base + sq;
     const int sg_q = tid - sg_base;
     auto signals = [&]() {
-        if (is_sg) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, sig_ph, sig_fr, sg_q, we, ns, a, pr, ai); sig[4 * sg_q] = we; sig[4 * sg_q + 1] = ns; }
+        if (is_sg) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, sig_ph, sig_fr, sg_q, we, ns, a, pr, ai, kHard); sig[4 * sg_q] = we; sig[4 * sg_q + 1] = ns; }
         if (++sig_fr == F) { sig_fr = 0; ++sig_ph; }
     };
     __syncthreads();        // the staged action vector is complete
@@ -153,6 +158,7 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
     // loss pieces of the state held in `st` (evaluated for step index ls >= 0)
     double l_incl = 0., l_incl_out = 0.;
     auto loss_scan = [&](const float *st) {          // phase 1: wave-level inclusive scans over the cells in order
+        if (kHard) return;                           // (no running mean in an evaluation episode)
         double a = 0., b = 0.;
         if (is_cell) {
             a = (double)(s0f - st[2 * C + tid]);     // x = s0 - u
@@ -169,6 +175,10 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
         if ((tid & 63) == 63) { scanw[tid >> 6] = l_incl; scanw[16 + (tid >> 6)] = l_incl_out; }
     };
     auto loss_consts = [&](const float *st, int ls) { // phase 2: k_c and the cell's contribution to its lane queue
+        if (kHard) {                                 // is_static = 1.0 if speed < static_speed else 0.0 (_env.py:607-617)
+            if (is_cell) contrib[tid] = (st[2 * C + tid] < s0f ? 1.f : 0.f) * (st[tid] * c_dxv);
+            return;
+        }
         const int wv = tid >> 6, nw = B >> 6;
         double base_a = 0., tot_a = 0., base_b = 0., tot_b = 0.;
         for (int k = 0; k < nw; ++k) {
@@ -225,9 +235,9 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
             } else {
                 float gr = own_r, gu = own_u;
                 if (src >= 0) { const int first = lfl[src] & 0xffff; gr = cur[first]; gu = cur[2 * C + first]; }
-                else { own_w[(size_t)t * 2 * L + 2 * g_lane] = gr; own_w[(size_t)t * 2 * L + 2 * g_lane + 1] = gu; }
+                else if (!kHard) { own_w[(size_t)t * 2 * L + 2 * g_lane] = gr; own_w[(size_t)t * 2 * L + 2 * g_lane + 1] = gu; }
                 const float sg = g_kind != 0 ? sig[4 * g_inter + (g_kind - 1)] : 1.f;
-                const float s2 = soft_switch(sg - 0.5f, kSigK);
+                const float s2 = kHard ? (sg > 0.5f ? 1.f : 0.f) : soft_switch(sg - 0.5f, kSigK);
                 fr = s2 * gr + (1.0f - s2) * 1.0f;
                 fu = s2 * gu + (1.0f - s2) * 0.0f;
                 glue_from_r_u(fr, fu, um, fy, fq);
@@ -266,16 +276,18 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
             float nu, nq;
             glue_from_r_y(nr, ny, um, nu, nq);
             nxt[c] = nr; nxt[C + c] = ny; nxt[2 * C + c] = nu; nxt[3 * C + c] = nq;
-            float *hn = hist_r + (size_t)(t + 1) * 4 * C;
-            hn[c] = nr; hn[C + c] = ny; hn[2 * C + c] = nu; hn[3 * C + c] = nq;
-            const float *aL = AB + (size_t)iL * 8, *aR = AB + (size_t)iR * 8;
-            float4 d0, d1, d2;
-            d0.x = ncf * (-aL[0]); d0.y = ncf * (-aL[1]); d0.z = ncf * (-aL[2]); d0.w = ncf * (-aL[3]);
-            d2.x = ncf * aR[4]; d2.y = ncf * aR[5]; d2.z = ncf * aR[6]; d2.w = ncf * aR[7];
-            d1.x = 1.f - cf * (aR[0] - aL[4]); d1.y = 0.f - cf * (aR[1] - aL[5]);
-            d1.z = 0.f - cf * (aR[2] - aL[6]); d1.w = 1.f - cf * (aR[3] - aL[7]);
-            float4 *tp = tape_r + (size_t)t * 3 * Cp;
-            tp[c] = d0; tp[Cp + c] = d1; tp[2 * Cp + c] = d2;
+            if (!kHard) {
+                float *hn = hist_r + (size_t)(t + 1) * 4 * C;
+                hn[c] = nr; hn[C + c] = ny; hn[2 * C + c] = nu; hn[3 * C + c] = nq;
+                const float *aL = AB + (size_t)iL * 8, *aR = AB + (size_t)iR * 8;
+                float4 d0, d1, d2;
+                d0.x = ncf * (-aL[0]); d0.y = ncf * (-aL[1]); d0.z = ncf * (-aL[2]); d0.w = ncf * (-aL[3]);
+                d2.x = ncf * aR[4]; d2.y = ncf * aR[5]; d2.z = ncf * aR[6]; d2.w = ncf * aR[7];
+                d1.x = 1.f - cf * (aR[0] - aL[4]); d1.y = 0.f - cf * (aR[1] - aL[5]);
+                d1.z = 0.f - cf * (aR[2] - aL[6]); d1.w = 1.f - cf * (aR[3] - aL[7]);
+                float4 *tp = tape_r + (size_t)t * 3 * Cp;
+                tp[c] = d0; tp[Cp + c] = d1; tp[2 * Cp + c] = d2;
+            }
         }
         if (t > 0) loss_lanes(t - 1);
         if (t + 1 < T) signals();            // of step t + 1 (this step's ghosts read theirs two barriers ago)
@@ -610,11 +622,26 @@ int dhts_net_macro_rollout_fwd(const dhts_net_desc *d, const dhts_net_tables *t,
     const size_t lds = net_fwd_lds_base(L, C) + net_staged_bytes(L, d->n_inter_sq, d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)net_macro_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        hipFuncSetAttribute((const void *)net_macro_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_LAUNCH;
-    net_macro_fwd_kernel<<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
+    net_macro_fwd_kernel<false><<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
         d->n_replicas, L, C, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max, d->static_speed,
         d->vehicle_length, net_tables(t), action, hist, reinterpret_cast<float4 *>(tape), kc, queue, reward, workspace, err);
+    return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
+}
+
+int dhts_net_macro_rollout_eval(const dhts_net_desc *d, const dhts_net_tables *t, const float *action, float *queue, float *reward,
+                                dhts_error *err, void *stream) {
+    if (!net_desc_ok(d) || !net_tables_ok(t) || !action || !queue || !reward) return DHTS_E_INVALID;
+    const int B = net_block(d), L = d->n_lanes, C = d->n_cells;
+    const size_t lds = net_fwd_lds_base(L, C) + net_staged_bytes(L, d->n_inter_sq, d->n_action);
+    if (lds > 160 * 1024) return DHTS_E_INVALID;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)net_macro_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DHTS_E_LAUNCH;
+    net_macro_fwd_kernel<true><<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
+        d->n_replicas, L, C, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max, d->static_speed,
+        d->vehicle_length, net_tables(t), action, nullptr, nullptr, nullptr, queue, reward, nullptr, err);
     return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
 }
 

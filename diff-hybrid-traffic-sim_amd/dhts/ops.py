@@ -491,6 +491,27 @@ def net_macro_rollout(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_ma
                                  float(static_speed), float(vehicle_length), bool(check_faults), err)
 
 
+def net_macro_eval(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0, err=None):
+    """An evaluation episode (ItscpEnv.step(action, False) of the reference: hard signal / boundary / is_static thresholds,
+    trainer.py:94-142) of R replicas of a macro network: returns (reward [R], queue [R][T][L]); nothing differentiable."""
+    a = _f32c(action.detach(), "action")
+    R, A = a.shape
+    if dev_tables.n_replica_tables not in (0, R):
+        raise ValueError("per-replica tables must match the number of replicas")
+    d = _lib.NetDesc(R, dev_tables.n_lanes, dev_tables.n_cells, dev_tables.T, int(n_inter_sq), int(frames_per_phase), A,
+                     float(dt), float(u_max), float(static_speed), float(vehicle_length))
+    queue = torch.empty(R, dev_tables.T, dev_tables.n_lanes, dtype=torch.float32, device=a.device)
+    reward = torch.empty(R, dtype=torch.float32, device=a.device)
+    own_err = err is None
+    if own_err:
+        err = new_error_record(a.device)
+    check(_lib.lib().dhts_net_macro_rollout_eval(C.byref(d), C.byref(dev_tables.c), _ptr(a), _ptr(queue), _ptr(reward), _ptr(err),
+                                                 _stream()), "dhts_net_macro_rollout_eval")
+    if own_err:
+        raise_on_fault(err)
+    return reward, queue
+
+
 class DeviceHybridTables:
     """dhts.network.HybridNetworkTables plus the pre-drawn vehicle routes [n_routes][stride] (int, -1 padded; the k-th
     vehicle spawned onto a lane takes the k-th route starting there, cyclically), uploaded once.  `tables` may be one
@@ -593,6 +614,30 @@ class NetHybridRollout(torch.autograd.Function):
         if ctx.check_faults:
             raise_on_fault(err)     # a NaN in the reverse sweep asserts like the reference (dmacro_lane.py:308)
         return g_action, None, None, None, None, None, None, None, None, None, None, None
+
+
+def net_hybrid_eval(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0, err=None):
+    """An evaluation episode (hard thresholds, see net_macro_eval) of R replicas of a hybrid network: returns
+    (reward [R], queue [R][T][L], counts [R][4] = vehicles spawned, vehicles deposited, 0, 0)."""
+    a = _f32c(action.detach(), "action")
+    R, A = a.shape
+    t = dev_tables
+    if t.n_replica_tables not in (0, R):
+        raise ValueError("per-replica tables must match the number of replicas")
+    d = _lib.NetDesc(R, t.n_lanes, t.n_cells, t.T, int(n_inter_sq), int(frames_per_phase), A, float(dt), float(u_max),
+                     float(static_speed), float(vehicle_length))
+    tc = t.c(0)
+    queue = torch.empty(R, t.T, t.n_lanes, dtype=torch.float32, device=a.device)
+    reward = torch.empty(R, dtype=torch.float32, device=a.device)
+    counts = torch.zeros(R, 4, dtype=torch.int32, device=a.device)
+    own_err = err is None
+    if own_err:
+        err = new_error_record(a.device)
+    check(_lib.lib().dhts_net_hybrid_rollout_eval(C.byref(d), C.byref(tc), _ptr(a), _ptr(queue), _ptr(reward), _ptr(counts),
+                                                  _ptr(err), _stream()), "dhts_net_hybrid_rollout_eval")
+    if own_err:
+        raise_on_fault(err)
+    return reward, queue, counts
 
 
 def net_hybrid_rollout(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0,

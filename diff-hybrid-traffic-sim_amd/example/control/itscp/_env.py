@@ -247,7 +247,7 @@ class ItscpEnv:
         if getattr(self, "_fused_done", False):
             raise NotImplementedError("the fused episode leaves the lane objects at their reset state: call reset() first, "
                                       "or set config['fused'] = False to step lane by lane")
-        reward = self._step_fused(action) if differentiable else None
+        reward = self._step_fused(action, differentiable)
         if reward is None:
             self._simulate(action, differentiable)
             reward = self._reward(action)
@@ -256,10 +256,11 @@ class ItscpEnv:
         return obs, reward, self.steps >= self.config["duration"], info
 
     # ---- fused episode: the whole differentiable rollout in two kernel launches (dhts_net_*_rollout_fwd / _bwd) -----------
-    def _step_fused(self, action):
+    def _step_fused(self, action, differentiable=True):
         """First step after reset() in `macro` / `hybrid` mode with config["fused"] (default on): reward (differentiable
         w.r.t. `action`) and the per-step queue terms from the fused network kernels instead of one operator call per
-        lane and step.  Same numbers as the operator path in `macro` mode; in `hybrid` mode vehicle routes are pre-drawn
+        lane and step.  differentiable=False (an evaluation episode, Trainer.evaluate): the same episode with the reference's
+        hard thresholds (dhts_net_*_rollout_eval), one launch, nothing kept for a reverse sweep.  Same numbers as the operator path in `macro` mode; in `hybrid` mode vehicle routes are pre-drawn
         per spawn lane (`fused_routes`, or 8 per lane from create_random_route) instead of being drawn at spawn time.
         Returns None when the network or the call is outside what the kernels cover (the operator path runs then)."""
         if not self.config.get("fused", True) or self.config["mode"] not in ("macro", "hybrid") or self.steps != 1 or self.time != 0:
@@ -302,9 +303,12 @@ class ItscpEnv:
                 self.simulator.vehicle_length)
         a = action.reshape(1, -1)
         if kind == "macro":
-            reward, queue = ops.net_macro_rollout(a, tab, *args)
-        else:
+            reward, queue = ops.net_macro_rollout(a, tab, *args) if differentiable else ops.net_macro_eval(a, tab, *args)
+        elif differentiable:
             reward, _, queue, counts = ops.net_hybrid_rollout(a, tab, *args)
+            self.fused_counts = counts[0].tolist()
+        else:
+            reward, queue, counts = ops.net_hybrid_eval(a, tab, *args)
             self.fused_counts = counts[0].tolist()
         q = queue[0].detach().cpu().numpy()                 # [T][L]
         for i, lid in enumerate(self.lane.keys()):

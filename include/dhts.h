@@ -283,6 +283,13 @@ size_t dhts_net_macro_tape_bytes(const dhts_net_desc *d);   /* Jacobian tape [R]
  * reward [R] float32 = - sum of the queue terms; workspace [R][T][2 L] float32 (kept for the reverse sweep) */
 int dhts_net_macro_rollout_fwd(const dhts_net_desc *d, const dhts_net_tables *t, const float *action, float *hist, float *tape,
                                float *kc, float *queue, float *reward, float *workspace, dhts_error *err, void *stream);
+/* An EVALUATION episode of the same R replicas: ItscpEnv.step(action, False), what Trainer.evaluate runs every num_eval_epoch
+ * epochs (example/control/trainer.py:73-75, 94-142).  The lanes step exactly as above; the thresholds are hard: signals
+ * float(a > progress) / float(progress > a) (_env.py:928-960), downstream ghost float(signal > 0.5) (_simulator.py:128-137),
+ * is_static = 1.0 if speed < static_speed else 0.0 without a running mean (_env.py:607-617).  Nothing is kept for a reverse
+ * sweep.  out: queue [R][T][L], reward [R]. */
+int dhts_net_macro_rollout_eval(const dhts_net_desc *d, const dhts_net_tables *t, const float *action, float *queue, float *reward,
+                                dhts_error *err, void *stream);
 /* hist, tape, kc, queue, workspace from the forward; g_reward [R] (NULL = ones) -> g_action [R][n_action] */
 int dhts_net_macro_rollout_bwd(const dhts_net_desc *d, const dhts_net_tables *t, const float *action, const float *hist,
                                const float *tape, const float *kc, const float *queue, const float *g_reward, float *g_action,
@@ -330,6 +337,13 @@ size_t dhts_net_hybrid_workspace_bytes(const dhts_net_desc *d, const dhts_hybrid
 int dhts_net_hybrid_rollout_fwd(const dhts_net_desc *d, const dhts_hybrid_tables *t, const float *action, float *hist,
                                 float *tape, float *kc, float *queue, float *reward, int32_t *counts, void *workspace,
                                 dhts_error *err, void *stream);
+/* An EVALUATION episode (see dhts_net_macro_rollout_eval) of the hybrid network: additionally a head vehicle takes the green
+ * head gap when the signal of its own lane is >= 0.5 and the red-light gap otherwise (_simulator.py:208-232, 264-276: scores
+ * 0 / 1 / 0, no running mean), and a vehicle is static when its speed is below static_speed (_env.py:709-717).  Steps, hand-offs
+ * and capacities as in dhts_net_hybrid_rollout_fwd; no records, tape, history or workspace.  out: queue [R][T][L], reward [R],
+ * counts [R][4] = (vehicles spawned, vehicles deposited, 0, 0). */
+int dhts_net_hybrid_rollout_eval(const dhts_net_desc *d, const dhts_hybrid_tables *t, const float *action, float *queue,
+                                 float *reward, int32_t *counts, dhts_error *err, void *stream);
 int dhts_net_hybrid_rollout_bwd(const dhts_net_desc *d, const dhts_hybrid_tables *t, const float *action, const float *hist,
                                 const float *tape, const float *kc, const float *queue, const float *g_reward,
                                 float *g_action, const void *workspace, dhts_error *err, void *stream);

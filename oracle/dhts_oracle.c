@@ -669,6 +669,13 @@ static float soft_switch_grad(float value, float constant) {
     return s * (1.f - s) * constant;
 }
 
+/* Evaluation episodes (ItscpEnv.step(action, False); Trainer.evaluate, trainer.py:94-142): hard thresholds instead of the
+ * sigmoids -- float(a > progress) (_env.py:928-960), float(signal > 0.5) (_simulator.py:128-137), is_static = speed <
+ * static_speed without a running mean (_env.py:607-617, 709-717), head gap = green if the lane's own signal >= 0.5 else red
+ * (_simulator.py:208-232, 264-276).  A process-wide switch of this test library (oracle_set_hard), read by the forward passes. */
+static int oracle_hard = 0;
+void oracle_set_hard(int hard) { oracle_hard = hard != 0; }
+
 typedef struct {            /* per step: phase signals of every intersection and their inputs */
     float we, ns, a, prog;
     int a_index;
@@ -687,9 +694,15 @@ static void net_signals(const oracle_net_desc *d, const float *action, int t, ne
         s->a_index = phase * sq + k;
         s->a = action[s->a_index];
         s->prog = (float)pr;
+        if (oracle_hard) { s->we = s->a > s->prog ? 1.f : 0.f; s->ns = s->prog > s->a ? 1.f : 0.f; continue; }
         s->we = soft_switch(s->a - s->prog, 32.f);
         s->ns = soft_switch(s->prog - s->a, 32.f);
     }
+}
+/* macro downstream ghost: sigmoid(signal - 0.5, 32), or float(signal > 0.5) in an evaluation episode */
+static float ghost_switch(float signal) {
+    if (oracle_hard) return signal > 0.5f ? 1.f : 0.f;
+    return soft_switch(signal - 0.5f, 32.f);
 }
 static float lane_signal(const net_signal *sg, int kind, int inter) {
     return kind == 0 ? 1.f : (kind == 1 ? sg[inter].we : sg[inter].ns);
@@ -746,7 +759,7 @@ int oracle_net_macro_fwd(const oracle_net_desc *d, const int *lane_ncell, const 
                 float gr, gu;
                 if (rs < 0) { gr = own_r[2 * l]; gu = own_r[2 * l + 1]; }
                 else { gr = cur[lane_off[rs]]; gu = cur[2 * C + lane_off[rs]]; }
-                float s2 = soft_switch(lane_signal(sg, sig_kind[l], inter[l]) - 0.5f, 32.f);
+                float s2 = ghost_switch(lane_signal(sg, sig_kind[l], inter[l]));
                 float fr = s2 * gr + (1.0f - s2) * 1.0f;
                 float fu = s2 * gu + (1.0f - s2) * 0.0f;
                 r[n + 1] = fr; u[n + 1] = fu;
@@ -764,6 +777,10 @@ int oracle_net_macro_fwd(const oracle_net_desc *d, const int *lane_ncell, const 
             float qlen = 0.f;
             for (int i = 0; i < n; i++) {
                 const float rr = nxt[off + i], uu = nxt[2 * C + off + i];
+                if (oracle_hard) {          /* is_static = 1.0 if speed < static_speed else 0.0; no running mean */
+                    qlen = qlen + (uu < (float)d->static_speed ? 1.f : 0.f) * (rr * (float)lane_dx[l] / (float)d->vehicle_length);
+                    continue;
+                }
                 const float x = (float)d->static_speed - uu;
                 samples[n_samples++] = (double)x;
                 csum_all += (double)x;

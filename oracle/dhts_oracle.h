@@ -128,6 +128,9 @@ void oracle_micro_rollout_bwd(int L, int V, int T, const float *tape,
  *   hist [T+1][4][C] float (r, y, u, u_eq after t steps), tape [T][C][12], kc [T][C] float (sigmoid constants),
  *   queue [T][L] float (per-lane loss terms q^2 dt).  Returns reward = - sum queue in *reward (float32 accumulation
  *   order of the reference: lanes outer, steps inner).  rc = ORACLE_OK / ORACLE_ERR_CFL. */
+/* 1 = the network forward passes below run EVALUATION episodes (hard thresholds, ItscpEnv.step(action, False)); their
+ * gradient outputs are then meaningless.  Process-wide switch of this test library. */
+void oracle_set_hard(int hard);
 typedef struct oracle_net_desc {
     int n_lanes, n_cells, T, n_inter_sq, frames_per_phase, n_action;
     double dt, u_max, static_speed, vehicle_length;

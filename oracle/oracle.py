@@ -216,9 +216,12 @@ class NetDesc(C.Structure):
                 ("static_speed", C.c_double), ("vehicle_length", C.c_double)]
 
 
-def net_macro(tab, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0, want_grad=True):
-    """tab: dhts.network.MacroNetworkTables (plain numpy tables).  Returns reward, queue [T][L], hist, g_action."""
+def net_macro(tab, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0, want_grad=True, hard=False):
+    """tab: dhts.network.MacroNetworkTables (plain numpy tables).  Returns reward, queue [T][L], hist, g_action.
+    hard: an evaluation episode (ItscpEnv.step(action, False)): hard thresholds, no gradient."""
     l = lib()
+    l.oracle_set_hard(1 if hard else 0)
+    want_grad = want_grad and not hard
     l.oracle_net_macro_fwd.argtypes = [C.POINTER(NetDesc)] + [C.c_void_p] * 15
     l.oracle_net_macro_bwd.argtypes = [C.POINTER(NetDesc)] + [C.c_void_p] * 15
     action = _f32(action)
@@ -236,6 +239,7 @@ def net_macro(tab, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed
     reward = C.c_double(0)
     args = [_p(ncell), _p(off), _p(dx), _p(kind), _p(inter), _p(ls), _p(lg), _p(rs), _p(sched), _p(action)]
     rc = l.oracle_net_macro_fwd(C.byref(d), *args, _p(hist), _p(tape), _p(kc), _p(queue), C.addressof(reward))
+    l.oracle_set_hard(0)
     out = dict(rc=rc, reward=reward.value, queue=queue, hist=hist, kc=kc)
     if want_grad:
         g = np.zeros(len(action), np.float32)
@@ -245,10 +249,12 @@ def net_macro(tab, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed
 
 
 def net_hybrid(tab, routes, route_ptr, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0,
-               t_cut=None, want_grad=True, want_hist=False):
+               t_cut=None, want_grad=True, want_hist=False, hard=False):
     """tab: dhts.network.HybridNetworkTables; routes [n][stride] int (-1 padded) grouped by first lane + route_ptr [L+1]
-    (dhts.network.group_routes)."""
+    (dhts.network.group_routes).  hard: an evaluation episode (ItscpEnv.step(action, False)): hard thresholds, no gradient."""
     l = lib()
+    l.oracle_set_hard(1 if hard else 0)
+    want_grad = want_grad and not hard
     l.oracle_net_hybrid.argtypes = ([C.POINTER(NetDesc)] + [C.c_void_p] * 14 + [C.c_int, C.c_int, C.c_void_p, C.c_int]
                                     + [C.c_void_p] * 8)
     action = _f32(action)
@@ -269,5 +275,6 @@ def net_hybrid(tab, routes, route_ptr, action, n_inter_sq, frames_per_phase, dt,
     rc = l.oracle_net_hybrid(C.byref(d), *args, routes.shape[0], routes.shape[1], _p(action), T if t_cut is None else int(t_cut),
                              _p(queue), C.addressof(reward), C.addressof(reward_cut), _p(g) if want_grad else None,
                              C.addressof(nsp), C.addressof(ndep), _p(hist) if want_hist else None, _p(kc) if want_hist else None)
+    l.oracle_set_hard(0)
     return dict(rc=rc, reward=reward.value, reward_cut=reward_cut.value, queue=queue, g_action=g if want_grad else None,
                 n_spawned=nsp.value, n_deposits=ndep.value, hist=hist, kc=kc)

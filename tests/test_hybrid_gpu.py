@@ -269,3 +269,35 @@ def test_larger_network_vs_oracle(cuda, oracle):
         assert err_k <= TOL_GRAD, k
         spawned += o["n_spawned"]
     assert spawned > 0
+
+
+@pytest.mark.parametrize("name", ["eval_hybrid_short", "eval_hybrid_p2", "eval_hybrid"])
+def test_hybrid_evaluation_episode_vs_reference(cuda, oracle, golden_dir, name):
+    """dhts_net_hybrid_rollout_eval = ItscpEnv.step(action, False) of the reference in `hybrid` mode (240 steps; 480 steps over
+    problem_2's inflows; BASELINE config 4's 600-step episode): hard signals and boundaries, head gap green iff the lane's own
+    signal >= 0.5, hard is_static for cells and vehicles.  Replica 0 = the reference's action (queues, reward, spawn count of
+    the fixture), the others random actions against the oracle's evaluation mode."""
+    import torch
+    from dhts import ops
+    from dhts.network import group_routes
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    t, m = itscp_hybrid_tables(g)
+    args = (m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"],
+            m["speed_limit"], m["static_speed"], m["vehicle_length"])
+    rng = np.random.default_rng(47)
+    acts = np.concatenate([g["action"][None], rng.uniform(0.05, 0.95, (3, len(g["action"]))).astype(np.float32)])
+    dtab = ops.DeviceHybridTables(t, g["spawn_routes"], cuda)
+    a = torch.tensor(acts, device=cuda)
+    reward, queue, counts = ops.net_hybrid_eval(a, dtab, *args)
+    q = queue.cpu().numpy()
+    assert int(counts[0, 0]) == m["n_vehicle_spawned"]
+    assert rel_max(q[0].T, g["queue"]) <= TOL_STATE
+    assert abs(float(reward[0]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+    routes, route_ptr = group_routes(g["spawn_routes"], t.n_lanes)
+    for k in range(1, len(acts)):
+        o = oracle.net_hybrid(t, routes, route_ptr, acts[k], *args, hard=True)
+        assert o["rc"] == 0 and int(counts[k, 0]) == o["n_spawned"] and int(counts[k, 1]) == o["n_deposits"], k
+        assert rel_max(q[k], o["queue"]) <= TOL_STATE, k
+        assert abs(float(reward[k]) - o["reward"]) <= 1e-5 * abs(o["reward"]), k
+    reward2, queue2, _ = ops.net_hybrid_eval(a, dtab, *args)
+    assert torch.equal(reward, reward2) and torch.equal(queue, queue2)

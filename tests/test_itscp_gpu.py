@@ -194,3 +194,41 @@ def test_env_step_uses_fused_kernels(cuda, golden_dir, name):
     env.reset()
     env.config["fused"] = False           # the lane-by-lane path stays available
     assert env._step_fused(action) is None
+
+
+@pytest.mark.parametrize("name", ["eval_macro", "eval_macro_2x2", "eval_hybrid_short", "eval_hybrid"])
+def test_env_evaluation_step_uses_fused_kernels(cuda, golden_dir, name):
+    """ItscpEnv.step(action, False) -- what the reference's Trainer.evaluate calls every num_eval_epoch epochs
+    (trainer.py:73-75, 94-142) -- through the fused evaluation kernels (one launch) instead of lane by lane: queues and
+    reward of the reference's own evaluation episode; then the same episode lane by lane on a copy of the short cases (the
+    mirror path the fused one replaces) gives the same numbers."""
+    import copy
+    import time
+    import torch
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    m = meta_of(g)
+    env = build_env(g, m)
+    if "hybrid" in name:
+        env.fused_routes = g["spawn_routes"]
+    keys = list(env.lane.keys())
+    slow = copy.deepcopy(env)
+    action = torch.tensor(g["action"], device=cuda)
+    with torch.no_grad():
+        t0 = time.time()
+        obs, reward, done, info = env.step(action, False)
+        float(reward)
+        t_fused = time.time() - t0
+    assert env._fused_done
+    queue = np.array([env.queue_length[k] for k in keys])
+    assert rel_max(queue, g["queue"]) <= TOL_STATE
+    assert abs(float(reward) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+    if "hybrid" in name:
+        assert env.fused_counts[0] == m["n_vehicle_spawned"]
+    if name in ("eval_macro_2x2",):            # the lane-by-lane mirror of the same episode (seconds for a macro network)
+        slow.config["fused"] = False
+        with torch.no_grad():
+            t0 = time.time()
+            _, reward_slow, _, _ = slow.step(action, False)
+            t_slow = time.time() - t0
+        assert abs(float(reward_slow) - float(reward)) <= 1e-5 * abs(float(reward))
+        print("evaluation episode %s: fused %.1f ms (first call, with table upload), lane by lane %.1f s" % (name, 1e3 * t_fused, t_slow))

@@ -107,3 +107,33 @@ def test_multi_intersection_network_vs_oracle(cuda, oracle):
         assert abs(float(reward[k]) - o["reward"]) <= 1e-5 * abs(o["reward"]), k
         assert rel_max(a.grad[k].cpu().numpy(), o["g_action"]) <= TOL_GRAD, k
         assert np.count_nonzero(o["g_action"]) >= 8, k            # several intersections and phases carry gradient
+
+
+@pytest.mark.parametrize("name", ["eval_macro", "eval_macro_2x2"])
+def test_network_evaluation_episode_vs_reference(cuda, oracle, golden_dir, name):
+    """dhts_net_macro_rollout_eval = ItscpEnv.step(action, False) of the reference (Trainer.evaluate, trainer.py:94-142): hard
+    signals, hard ghost switch, hard is_static.  Replica 0 runs the reference's own action (fixture: queues <= 1e-5, reward
+    <= 1e-5), the others random actions against the oracle's evaluation mode."""
+    import torch
+    from dhts import ops
+    g = load(golden_dir, "itscp_%s.npz" % name)
+    tab, m = itscp_tables(g)
+    args = (m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"],
+            m["speed_limit"], m["static_speed"], m["vehicle_length"])
+    rng = np.random.default_rng(31)
+    acts = np.concatenate([g["action"][None], rng.uniform(0.05, 0.95, (6, len(g["action"]))).astype(np.float32)])
+    acts[1] = 0.5                                           # progress == action exactly at mid-phase: neither light is on
+    a = torch.tensor(acts, device=cuda)
+    reward, queue = ops.net_macro_eval(a, ops.DeviceNetTables(tab, cuda), *args)
+    q = queue.cpu().numpy()
+    assert rel_max(q[0].T, g["queue"]) <= TOL_STATE and rel_elem(q[0].T, g["queue"]) <= 10 * TOL_STATE
+    assert abs(float(reward[0]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+    for k in range(1, len(acts)):
+        o = oracle.net_macro(tab, acts[k], *args, hard=True)
+        assert rel_max(q[k], o["queue"]) <= TOL_STATE, k
+        assert abs(float(reward[k]) - o["reward"]) <= 1e-5 * abs(o["reward"]), k
+    # bitwise repeatable, and not the differentiable episode
+    reward2, queue2 = ops.net_macro_eval(a, ops.DeviceNetTables(tab, cuda), *args)
+    assert torch.equal(reward, reward2) and torch.equal(queue, queue2)
+    soft, _ = ops.net_macro_rollout(a, ops.DeviceNetTables(tab, cuda), *args)
+    assert abs(float(soft[0]) - float(reward[0])) > 1e-3 * abs(float(reward[0]))

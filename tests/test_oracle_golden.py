@@ -162,6 +162,26 @@ def test_itscp_macro_network(oracle, golden_dir, name):
     assert grad_report("G8 %s d reward / d action" % name, o["g_action"], g["g_action"]) <= TOL_GRAD
 
 
+@pytest.mark.parametrize("name", ["eval_macro", "eval_macro_2x2"])
+def test_itscp_macro_network_evaluation_episode(oracle, golden_dir, name):
+    """ItscpEnv.step(action, False) of the reference (what Trainer.evaluate runs): hard signals, hard ghost switch, hard
+    is_static.  The queue terms are squares of sums of whole cells' vehicle counts, so a cell whose speed crosses
+    static_speed one step early or late would show as a large error: equality of every term is the test."""
+    g = load(golden_dir, "itscp_%s.npz" % name)
+    t, m = itscp_tables(g)
+    assert m["differentiable"] is False
+    o = oracle.net_macro(t, g["action"], m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"],
+                         1.0 / m["simulation_frequency"], m["speed_limit"], m["static_speed"], m["vehicle_length"], hard=True)
+    assert o["rc"] == 0
+    assert rel_max(o["queue"].T, g["queue"]) <= TOL_STATE
+    assert rel_elem(o["queue"].T, g["queue"]) <= 10 * TOL_STATE
+    assert abs(o["reward"] - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+    # and the differentiable episode of the same inputs is a different number (the switch does something)
+    o2 = oracle.net_macro(t, g["action"], m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"],
+                          1.0 / m["simulation_frequency"], m["speed_limit"], m["static_speed"], m["vehicle_length"], want_grad=False)
+    assert abs(o2["reward"] - o["reward"]) > 1e-3 * abs(o["reward"])
+
+
 def itscp_hybrid_tables(g):
     from dhts.network import SIG_ALWAYS, SIG_NS, SIG_WE, HybridNetworkTables
     m = meta_of(g)
@@ -214,3 +234,19 @@ def test_itscp_hybrid_network(oracle, golden_dir, name):
         if t0 <= 540:
             oc = run(t_cut=int(t0))
             assert np.abs(oc["g_action"] - ref).max() <= (1e-5 if t0 <= 510 else 2 * TOL_GRAD) * scale, int(t0)
+
+
+@pytest.mark.parametrize("name", ["eval_hybrid_short", "eval_hybrid_p2", "eval_hybrid"])
+def test_itscp_hybrid_network_evaluation_episode(oracle, golden_dir, name):
+    """Evaluation episodes of the hybrid network (240 steps; 480 steps over problem_2's inflows; BASELINE config 4's 600-step
+    episode): hard signals and boundaries, head gap = green iff the lane's own signal >= 0.5, hard is_static for cells and
+    vehicles; same spawns and deposits as the reference's run."""
+    g = load(golden_dir, "itscp_%s.npz" % name)
+    t, m = itscp_hybrid_tables(g)
+    from dhts.network import group_routes
+    routes, route_ptr = group_routes(g["spawn_routes"], t.n_lanes)
+    o = oracle.net_hybrid(t, routes, route_ptr, g["action"], m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"],
+                          1.0 / m["simulation_frequency"], m["speed_limit"], m["static_speed"], m["vehicle_length"], hard=True)
+    assert o["rc"] == 0 and o["n_spawned"] == m["n_vehicle_spawned"]
+    assert rel_max(o["queue"].T, g["queue"]) <= TOL_STATE
+    assert abs(o["reward"] - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))

@@ -620,7 +620,10 @@ class SolverMargins:
                     min_equal_speed_margin_at=[self.min_equal[1], self.min_equal[2]], min_vacuum_margin=self.min_vacuum)
 
 
-def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, action_kind, problem=1):
+def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, action_kind, problem=1, differentiable=True):
+    """differentiable=False: an EVALUATION episode, env._simulate(action, False) under no_grad as Trainer.evaluate runs it
+    (trainer.py:94-142): hard signal thresholds (_env.py:928-960), hard macro / micro boundaries (_simulator.py:116-137,
+    264-276), hard is_static (_env.py:586-618).  The fixture then holds queues and reward only (no gradients)."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_stubs"))
     from example.control.itscp._env import ItscpEnv
     from example.control.itscp import problem as problems
@@ -680,13 +683,35 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
     np.random.random = logged_random
     try:
         with SolverMargins() as margins:
-            env._simulate(action, True)
+            if differentiable:
+                env._simulate(action, True)
+            else:
+                with th.no_grad():
+                    env._simulate(action, False)
     finally:
         np.random.random = orig_random
     print("G8 %s: solver margins %s" % (name, margins.as_meta()))
     queue = np.array([[float(x) for x in env.queue_length[k]] for k in keys], dtype=np.float64)   # [lanes][T]
     reward = env._reward(action)
     t1 = time.time()
+    if not differentiable:
+        nveh = sim.num_vehicle
+        print("G8 %s (evaluation episode): %d lanes, %d cells, T=%d, %d actions, %d vehicles spawned, reward %.6f, %.0fs" % (
+            name, nl, int(lane_tab[:, 3].sum()), T, A, nveh, float(reward), t1 - t0))
+        maxlen = max([len(r) for r in spawn_routes], default=1)
+        sr = -np.ones((len(spawn_routes), maxlen), dtype=np.int32)
+        for i, r in enumerate(spawn_routes):
+            sr[i, :len(r)] = r
+        np.savez_compressed(
+            os.path.join(OUT, "itscp_%s.npz" % name),
+            lane_tab=lane_tab, lane_str=np.array(lane_str), edges=edges, schedule=sched, macro_route=mroute, spawn_routes=sr,
+            action=a0, reward=np.float64(float(reward)), queue=queue, rand_draws=np.array(rand_draws, dtype=np.float64),
+            waiting_routes=np.array(json.dumps(waiting_routes)),
+            meta=meta(seed=seed, mode=mode, num_intersection=n_int, num_lane=n_lane, lane_length=lane_length,
+                      policy_length=sim_len, signal_length=sig_len, speed_limit=60.0, cell_length=5.0, simulation_frequency=30,
+                      static_speed=0.2, vehicle_length=5.0, T=T, n_vehicle_spawned=nveh, problem=problem,
+                      action_kind=action_kind, differentiable=False, **margins.as_meta(), ref_seconds_fwd=t1 - t0))
+        return
     # split of the gradient by lane type (bisecting aid): reward restricted to macro / micro lanes
     parts = {}
     for tag, want_macro in (("macro", True), ("micro", False)):
@@ -817,6 +842,18 @@ def main():
             gen_itscp("macro_half", "macro", 1, 3, 30.0, 10, 2, seed=8, action_kind="half")
         if "macro_long" in which:        # the same network for 15 s: 236 cells x 450 steps = 106 200 loss samples > the
             gen_itscp("macro_long", "macro", 1, 3, 30.0, 15, 3, seed=19, action_kind="rand", problem=2)   # RunningMean window of 100 000
+        # evaluation episodes (differentiable = False): the macro network, the 240-step hybrid episode, BASELINE config 4's
+        # full 600-step hybrid episode, and the hybrid network over problem_2's inflows
+        if "eval_macro" in which:
+            gen_itscp("eval_macro", "macro", 1, 3, 30.0, 10, 2, seed=7, action_kind="rand", differentiable=False)
+        if "eval_macro_2x2" in which:
+            gen_itscp("eval_macro_2x2", "macro", 2, 2, 10.0, 4, 1, seed=17, action_kind="rand", problem=3, differentiable=False)
+        if "eval_hybrid_short" in which:
+            gen_itscp("eval_hybrid_short", "hybrid", 3, 1, 5.0, 8, 2, seed=9, action_kind="rand", differentiable=False)
+        if "eval_hybrid" in which:
+            gen_itscp("eval_hybrid", "hybrid", 3, 1, 5.0, 20, 4, seed=9, action_kind="rand", differentiable=False)
+        if "eval_hybrid_p2" in which:
+            gen_itscp("eval_hybrid_p2", "hybrid", 3, 1, 5.0, 16, 4, seed=21, action_kind="rand", problem=2, differentiable=False)
         if "hybrid_short" in which:      # 8 s: enough for the first vehicles to cross the interior intersection
             gen_itscp("hybrid_short", "hybrid", 3, 1, 5.0, 8, 2, seed=9, action_kind="rand")
 
