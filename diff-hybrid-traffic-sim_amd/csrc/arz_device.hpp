@@ -106,6 +106,7 @@ struct IfaceDebug {  // intermediate results exported only by the known-answer e
     int ci;          // case_ind: 0 = Q_L, 1 = Q_M, 2 = Q_C
     double q0[4];    // Q_0 = (r, y, u, u_eq)
     float dL[4], dR[4], fp[4];
+    double speed[2]; // speed0, speed1 of ARZ.riemann_solve (_arz.py:222-314, returned :316-332)
 };
 
 struct IfaceConst {  // per-launch constants
@@ -126,6 +127,23 @@ struct IfaceConst {  // per-launch constants
         dt = dt_; dx = dx_; cfl_lim = dx_ / dt_; cfl_lim2 = 2.0 * cfl_lim; lim_ok = 1e-5 < cfl_lim;
     }
 };
+
+// The two wave speeds ARZ.riemann_solve reports (_arz.py:222-314), in the reference's own order of operations (IEEE division
+// and square root).  The rollout kernels only need their CFL test -- the production solve never forms the shock speed's
+// quotient -- so this runs for the known-answer entry point alone (dhts_arz_interface_batch, the mirror's ARZ.riemann_solve).
+__device__ __forceinline__ void arz_speeds_ref(double rL, double uL, double qL, double rR, double uR, double um, double &s0, double &s1) {
+    const double ueqp_L = u_eq_prime_d(rL, um);
+    if (rL < kEps) { s0 = 0.0; s1 = uL; return; }
+    const double l0l = uL + rL * ueqp_L;
+    const double qm_u = um + uL - qL;
+    if (rR < kEps) { s0 = (l0l + qm_u) * 0.5; s1 = s0; return; }
+    if (fabs(uL - uR) < kEps) { s0 = 0.0; s1 = uR; return; }
+    const double b = sqrt(rL) + ((uL - uR) / um);
+    const double rm = b * b;
+    if (uL > uR) { s0 = (rm * uR - rL * uL) / pymax(rm - rL, kEps); s1 = uR; return; }
+    if (qm_u > uR) { s0 = (l0l + (uR + rm * u_eq_prime_d(rm, um))) * 0.5; s1 = uR; return; }
+    s0 = (l0l + qm_u) * 0.5; s1 = uR;
+}
 
 // Reference-order version: IEEE double division and square root exactly where the reference divides and takes
 // powers.  Selected with -DDHTS_IEEE_DIV_SQRT (validation builds); the default build uses arz_interface_fast.
@@ -249,6 +267,7 @@ __device__ __forceinline__ void arz_interface_ieee(double rL, double yL, double 
     if (dbg) {
         dbg->ci = ci;
         dbg->q0[0] = r0; dbg->q0[1] = y0; dbg->q0[2] = u0; dbg->q0[3] = q0;
+        dbg->speed[0] = s0; dbg->speed[1] = s1;
         for (int j = 0; j < 4; ++j) {
             dbg->fp[j] = fp[j];
             dbg->dL[j] = (ci == 0) ? ((j == 0 || j == 3) ? 1.f : 0.f) : dL[j];
@@ -529,6 +548,7 @@ __device__ __forceinline__ void arz_interface_fast_impl(double rL, double yL, do
     if (dbg) {
         dbg->ci = ci;
         dbg->q0[0] = r0; dbg->q0[1] = y0; dbg->q0[2] = u0; dbg->q0[3] = q0;
+        arz_speeds_ref(rL, uL, qL, rR, uR, um, dbg->speed[0], dbg->speed[1]);
         for (int j = 0; j < 4; ++j) {
             dbg->fp[j] = fp[j];
             dbg->dL[j] = (ci == 0) ? ((j == 0 || j == 3) ? 1.f : 0.f) : dL[j];

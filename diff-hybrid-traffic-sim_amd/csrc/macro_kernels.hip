@@ -903,7 +903,8 @@ __global__ void macro_tape_expand_kernel(int N, double cc, const float4 *__restr
 __global__ void arz_interface_batch_kernel(int64_t n, int variant, const double *__restrict__ in, double dt, double dx,
                                            int32_t *__restrict__ ci, double *__restrict__ q0, double *__restrict__ flux,
                                            float *__restrict__ dL, float *__restrict__ dR, float *__restrict__ fp,
-                                           float *__restrict__ A, float *__restrict__ B, int32_t *__restrict__ cfl_bad) {
+                                           float *__restrict__ A, float *__restrict__ B, int32_t *__restrict__ cfl_bad,
+                                           double *__restrict__ speed) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         IfaceConst kc;
         kc.set_um(in[8 * n + i]); kc.set_grid(dt, dx);
@@ -918,6 +919,7 @@ __global__ void arz_interface_batch_kernel(int64_t n, int variant, const double 
         ci[i] = dbg.ci;
         flux[i] = f.Fr; flux[n + i] = f.Fy;
         cfl_bad[i] = f.cfl_bad ? 1 : 0;
+        if (speed) { speed[i] = dbg.speed[0]; speed[n + i] = dbg.speed[1]; }
         for (int j = 0; j < 4; ++j) {
             q0[j * n + i] = dbg.q0[j];
             dL[j * n + i] = dbg.dL[j]; dR[j * n + i] = dbg.dR[j]; fp[j * n + i] = dbg.fp[j];
@@ -1149,12 +1151,13 @@ size_t dhts_macro_step_tape_bytes(const dhts_macro_desc *d) {
 }
 
 int dhts_arz_interface_batch(int64_t n, int variant, const double *in, double dt, double dx, int32_t *case_ind, double *q0,
-                             double *flux, float *dL, float *dR, float *fp, float *A, float *B, int32_t *cfl_bad, void *stream) {
+                             double *flux, float *dL, float *dR, float *fp, float *A, float *B, int32_t *cfl_bad, double *speed,
+                             void *stream) {
     if (n < 0 || (variant != 0 && variant != 1) || !in || !case_ind || !q0 || !flux || !dL || !dR || !fp || !A || !B || !cfl_bad)
         return DHTS_E_INVALID;
     if (n == 0) return DHTS_OK;
     arz_interface_batch_kernel<<<grid_1d(n), 256, 0, (hipStream_t)stream>>>(n, variant, in, dt, dx, case_ind, q0, flux, dL, dR, fp,
-                                                                          A, B, cfl_bad);
+                                                                          A, B, cfl_bad, speed);
     return launch_status();
 }
 

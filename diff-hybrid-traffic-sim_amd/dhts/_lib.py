@@ -58,7 +58,7 @@ SIGNATURES = {
     "dhts_padded": (C.c_int, [C.c_int]),
     "dhts_macro_tape_bytes": (C.c_size_t, [C.POINTER(MacroDesc), C.c_int]),
     "dhts_macro_step_tape_bytes": (C.c_size_t, [C.POINTER(MacroDesc)]),
-    "dhts_arz_interface_batch": (C.c_int, [C.c_int64, C.c_int, _P, C.c_double, C.c_double] + [_P] * 10),
+    "dhts_arz_interface_batch": (C.c_int, [C.c_int64, C.c_int, _P, C.c_double, C.c_double] + [_P] * 11),
     "dhts_idm_batch": (C.c_int, [C.c_int64, C.c_int] + [_P] * 8),
     "dhts_macro_state_from_ru": (C.c_int, [C.c_int64, C.c_double, _P, _P, _P, _P, _P]),
     "dhts_macro_state_from_ru_bwd": (C.c_int, [C.c_int64, C.c_double, _P, _P, _P, _P, _P, _P]),

@@ -363,7 +363,8 @@ def micro_rollout(p0, v0, params, head, T, dt, count=None, want_hist=False, chec
 # ---------------------------------------------------------------------------------------------------------
 def arz_interface_batch(inp, dt=0.01, dx=5.0, variant=0):
     """inp: float64 [n][9] = rL yL uL ueqL rR yR uR ueqR u_max (CUDA).  Returns a dict of CUDA tensors:
-    case [n] int32, q0 [n][4] f64, flux [n][2] f64, dL/dR/fp/A/B [n][2][2] f32, cfl_bad [n] bool."""
+    case [n] int32, q0 [n][4] f64, flux [n][2] f64, dL/dR/fp/A/B [n][2][2] f32, cfl_bad [n] bool, speed [n][2] f64
+    (speed0, speed1 of ARZ.riemann_solve)."""
     if inp.dtype != torch.float64 or not inp.is_cuda or inp.dim() != 2 or inp.shape[1] != 9:
         raise TypeError("inp must be a float64 CUDA tensor of shape [n][9]")
     n, dev = inp.shape[0], inp.device
@@ -373,11 +374,12 @@ def arz_interface_batch(inp, dt=0.01, dx=5.0, variant=0):
     flux = torch.empty(2, n, dtype=torch.float64, device=dev)
     f32 = [torch.empty(4, n, dtype=torch.float32, device=dev) for _ in range(5)]
     bad = torch.empty(n, dtype=torch.int32, device=dev)
+    speed = torch.empty(2, n, dtype=torch.float64, device=dev)
     check(_lib.lib().dhts_arz_interface_batch(n, int(variant), _ptr(soa), float(dt), float(dx), _ptr(case), _ptr(q0), _ptr(flux),
-                                              *[_ptr(t) for t in f32], _ptr(bad), _stream()), "dhts_arz_interface_batch")
+                                              *[_ptr(t) for t in f32], _ptr(bad), _ptr(speed), _stream()), "dhts_arz_interface_batch")
     m = [t.t().reshape(n, 2, 2) for t in f32]
     return dict(case=case, q0=q0.t().contiguous(), flux=flux.t().contiguous(), dL=m[0], dR=m[1], fp=m[2], A=m[3], B=m[4],
-                cfl_bad=bad.bool())
+                cfl_bad=bad.bool(), speed=speed.t().contiguous())
 
 
 def idm_batch(inp, variant=0):

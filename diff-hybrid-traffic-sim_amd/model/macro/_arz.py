@@ -149,11 +149,12 @@ class ARZ:
 
     @staticmethod
     def riemann_solve(Q_L, Q_R, u_max):
-        """State at the interface between a left and a right cell (case index and Q_0).  The wave speeds are
-        consumed inside the kernel (CFL check) and are not exported; speed0 / speed1 stay 0 here."""
+        """State at the interface between a left and a right cell: case index, Q_0 and the two wave speeds
+        (reference _arz.py:212-332)."""
         out = ARZ._solve_pair(Q_L, Q_R, u_max)
         rs = ARZ.Riemann()
         rs.case_ind = int(out["case"][0])
+        rs.speed0, rs.speed1 = (float(x) for x in out["speed"][0].tolist())
         q0 = out["q0"][0].tolist()
         rs.Q_0 = ARZ.FullQ(u_max)
         rs.Q_0.q = ARZ.Q(q0[0], q0[1])

@@ -121,10 +121,13 @@ size_t dhts_macro_step_tape_bytes(const dhts_macro_desc *d);
  *   variant 0 = production arithmetic, 1 = reference-order IEEE division / square root
  *   out case_ind [n] int32 (0 = Q_L, 1 = Q_M, 2 = Q_C); q0 [4][n] DOUBLE (r, y, u, u_eq of Q_0);
  *       flux [2][n] DOUBLE (r u, y u of Q_0); dL, dR, fp [4][n] float32 row-major 2x2; A = fp @ dL, B = fp @ dR [4][n];
- *       cfl_bad [n] int32 = the CFL assert of _macro_lane.py:141-146 would fire for (dt, dx)
+ *       cfl_bad [n] int32 = the CFL assert of _macro_lane.py:141-146 would fire for (dt, dx);
+ *       speed [2][n] DOUBLE or NULL = (speed0, speed1) as ARZ.riemann_solve returns them (_arz.py:316-332), reference-order
+ *       arithmetic in both variants (the rollout kernels only test them against the CFL bound)
  */
 int dhts_arz_interface_batch(int64_t n, int variant, const double *in, double dt, double dx, int32_t *case_ind, double *q0,
-                             double *flux, float *dL, float *dR, float *fp, float *A, float *B, int32_t *cfl_bad, void *stream);
+                             double *flux, float *dL, float *dR, float *fp, float *A, float *B, int32_t *cfl_bad, double *speed,
+                             void *stream);
 
 /* float32 glue of FullQ.set_r_u / FullQ.from_r_u (model/macro/_arz.py:73-86 with :121-138):
  * y = r * (u - u_eq(r)), u_eq = u_max * (1 - sqrt(max(r, 0) + 1e-5)); n elements. */

@@ -119,14 +119,18 @@ def macro_step_bwd(dqs, g_nr, g_ny):
     return g_r, g_y
 
 
-def macro_rollout_fwd(r0, u0, ghost_r, ghost_u, T, dt, dx, u_max, want_tape=True, want_hist=False):
+def macro_rollout_fwd(r0, u0, ghost_r, ghost_u, T, dt, dx, u_max, want_tape=True, want_hist=False, out=None):
+    """out: the dict a previous call of the same shape returned -- its arrays (the tape above all: 48 B per cell-step) are
+    written again instead of allocated, so a timing loop does not pay for the first touch of gigabytes of fresh pages on
+    every pass (bench.py's cpu_baseline; with hundreds of threads faulting pages of one address space that dominated)."""
     r0, u0, ghost_r, ghost_u = _f32(r0), _f32(u0), _f32(ghost_r), _f32(ghost_u)
     r0 = r0.reshape(-1, r0.shape[-1])
     u0 = u0.reshape(r0.shape)
     L, N = r0.shape
     ghost_r, ghost_u = ghost_r.reshape(L, 2), ghost_u.reshape(L, 2)
-    rT, yT, uT = (np.zeros((L, N), np.float32) for _ in range(3))
-    tape = np.zeros((T, L, N, 3, 2, 2), np.float32) if want_tape else None
+    reuse = out is not None and out.get("tape") is not None and out["tape"].shape == (T, L, N, 3, 2, 2) and want_tape and not want_hist
+    rT, yT, uT = (out["rT"], out["yT"], out["uT"]) if reuse else (np.zeros((L, N), np.float32) for _ in range(3))
+    tape = out["tape"] if reuse else (np.zeros((T, L, N, 3, 2, 2), np.float32) if want_tape else None)
     hr = hy = hu = None
     if want_hist:
         hr, hy, hu = (np.zeros((T, L, N), np.float32) for _ in range(3))
@@ -183,14 +187,16 @@ def micro_step_bwd(dqs, g_np, g_nv):
     return g_p, g_v
 
 
-def micro_rollout_fwd(p0, v0, params, T, dt, head_dp=1000.0, head_dv=0.0, want_tape=True, want_hist=False):
+def micro_rollout_fwd(p0, v0, params, T, dt, head_dp=1000.0, head_dv=0.0, want_tape=True, want_hist=False, out=None):
+    """out: see macro_rollout_fwd (arrays of a previous call of the same shape are reused)."""
     p0, v0, params = _f32(p0), _f32(v0), _f64(params)
     p0 = p0.reshape(-1, p0.shape[-1])
     v0 = v0.reshape(p0.shape)
     L, V = p0.shape
     params = params.reshape(L, V, 6)
-    pT, vT = np.zeros((L, V), np.float32), np.zeros((L, V), np.float32)
-    tape = np.zeros((T, L, V, 2, 2, 2), np.float32) if want_tape else None
+    reuse = out is not None and out.get("tape") is not None and out["tape"].shape == (T, L, V, 2, 2, 2) and want_tape and not want_hist
+    pT, vT = (out["pT"], out["vT"]) if reuse else (np.zeros((L, V), np.float32), np.zeros((L, V), np.float32))
+    tape = out["tape"] if reuse else (np.zeros((T, L, V, 2, 2, 2), np.float32) if want_tape else None)
     hp = hv = None
     if want_hist:
         hp, hv = np.zeros((T, L, V), np.float32), np.zeros((T, L, V), np.float32)

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from util import TOL_GRAD, meta_of, rel_max
+from util import TOL_GRAD, TOL_STATE, meta_of, rel_max
 
 pytestmark = pytest.mark.gpu
 

@@ -149,6 +149,8 @@ def test_scalar_model_surface(cuda, golden_dir):
         rs = ARZ.riemann_solve(QL, QR, um)
         assert rs.case_ind == int(g["case"][i])
         assert abs(rs.Q_0.q.r - g["q0"][i, 0]) <= 1e-12 and abs(rs.Q_0.u - g["q0"][i, 2]) <= 1e-10
+        assert abs(rs.speed0 - g["speed"][i, 0]) <= 1e-12 * max(1.0, abs(g["speed"][i, 0]))       # both wave speeds, as the
+        assert abs(rs.speed1 - g["speed"][i, 1]) <= 1e-12 * max(1.0, abs(g["speed"][i, 1]))       # reference returns them
         dL, dR = dARZ.compute_dLdR(rs, QL, QR, um)
         assert rel_max(dL, g["dL"][i]) <= 2e-7 and np.abs(dR - g["dR"][i]).max() <= 2e-7 * max(1.0, np.abs(g["dR"][i]).max())
     k = load(golden_dir, "idm_kat.npz")
