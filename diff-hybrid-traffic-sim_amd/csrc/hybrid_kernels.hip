@@ -38,7 +38,7 @@ __host__ __device__ inline int hyb_ghost_base1(int L, int B) {
     const int p = (L + 63) & ~63;
     return (p + L <= B - 64) ? p : L;
 }
-constexpr int kMaxMicro = 24;        // micro lanes per network
+constexpr int kMaxMicro = 64;        // micro lanes per network: lane j of the micro wave owns micro lane j
 constexpr int kMaxCaps = 16;         // macro lanes with a micro successor
 constexpr int kLaneCap = 16;         // vehicles per micro lane
 constexpr int kMaxVeh = 128;         // vehicles per replica and episode
@@ -46,8 +46,10 @@ constexpr int kRouteStride = 32;     // MAX_ROUTE_LENGTH, road_network.py:17
 constexpr int kLaneLocals = 192;     // temporaries per lane of the micro wave and step
 constexpr int kEventLocals = 64;     // temporaries of the serial event walk per step
 constexpr int kMaxLocals = 64 * kLaneLocals + kEventLocals;
-constexpr int kStage = 96;           // staging slots per lane: two blocks of kStageH (the block being filled, the block being flushed)
-constexpr int kStageH = 48;          // records a lane can stage per step
+constexpr int kStageH = 48;          // records a lane can stage per step, at most.  A lane's staging area is two blocks of stage_h
+                                     // records (the block being filled, the block being flushed); stage_h is a per-launch size:
+                                     // kStageH when the LDS has room for that (<= 20 micro lanes beside BASELINE config 4's 256
+                                     // cells), less for networks with more micro lanes (hyb_stage_h)
 constexpr int kPhases = 3;           // record segments per block (= step): head gaps + IDM | capacitors + events |
                                      // commits + the loss seeds of the state the step leaves
 constexpr int kMaxStepRecords = 1024;
@@ -88,6 +90,7 @@ struct HybTables {
     NetTables net;
     const int32_t *lane_macro; const double *lane_len; const int32_t *conv_next; const int32_t *routes; const int32_t *route_ptr;
     int n_routes, route_stride, loss_steps, n_micro;
+    const int32_t *lane_source; const double *draws; int n_draws; size_t draws_stride;     // micro source lanes (itscp `micro` mode)
 };
 
 // workspace layout of one replica (bytes, all 16-byte aligned)
@@ -121,13 +124,13 @@ __device__ __forceinline__ Tv tv_var(float v, int id) { Tv x; x.val = v; x.id = 
 
 struct Rec {               // one lane's handle on its staging area (LDS) and its private range of temporaries
     int *sk; int *si; float *sw;
-    int cnt, next_local;
+    int cnt, next_local, cap;
     bool over;
     bool off;              // an evaluation episode keeps no records (nothing will be replayed)
 };
 __device__ __forceinline__ void rec_push(Rec &R, int kind, int out, int4 in, float4 w) {
     if (R.off) return;
-    if (R.cnt >= kStageH) { R.over = true; return; }
+    if (R.cnt >= R.cap) { R.over = true; return; }
     const int c = R.cnt++;
     R.sk[c] = (kind << 24) | (out & 0xffffff);
     *reinterpret_cast<int4 *>(R.si + 4 * c) = in;
@@ -262,9 +265,9 @@ __device__ __forceinline__ float stream_load(const float *p) {
 struct HybLds {
     size_t fq, scanw, incl, vsp, vep, s0, s1, g, ab, contrib, ql, sig, lanelen, vp, vv, va, vxold, hdpv, hdvv, capv, qmicro,
         cell_lane, iface_lane, cnext, vidp, vidv, vida, vcur, vrlen, vroute, lane_n, lane_veh, hdpi, hdvi, vcp, capi, mslot,
-        capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, stg_k, stg_i, stg_w, cnt_s, lfl, vx, total;
+        capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, stg_k, stg_i, stg_w, cnt_s, lfl, vx, lane_new, total;
 };
-__host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS) {
+__host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS, int stage_h) {
     HybLds o; size_t p = 0; const int NI = C + L;
     auto D = [&](size_t n) { size_t r = p; p += 8 * ((n + 1) & ~(size_t)1); return r; };
     auto F = [&](size_t n) { size_t r = p; p += 4 * ((n + 3) & ~(size_t)3); return r; };
@@ -272,14 +275,29 @@ __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS) {
     o.s0 = F(4 * (size_t)C); o.s1 = F(4 * (size_t)C); o.g = F(8 * (size_t)L); o.ab = F(8 * (size_t)NI); o.contrib = F(C); o.ql = F(L);
     o.sig = F(2 * (size_t)sq); o.lanelen = F(L); o.vp = F(V); o.vv = F(V); o.va = F(V); o.vxold = F(V);
     o.hdpv = F(kMaxMicro); o.hdvv = F(kMaxMicro); o.capv = F(kMaxCaps); o.qmicro = F(kMaxMicro);
-    o.cell_lane = F(C); o.iface_lane = F(NI); o.cnext = F(L); o.vidp = F(V); o.vidv = F(V); o.vida = F(V); o.vcur = F(V);
+    o.cnext = F(L); o.vidp = F(V); o.vidv = F(V); o.vida = F(V); o.vcur = F(V);
     o.vrlen = F(V); o.vroute = F((size_t)V * kRouteStride); o.lane_n = F(kMaxMicro); o.lane_veh = F(kMaxMicro * kLaneCap);
     o.hdpi = F(kMaxMicro); o.hdvi = F(kMaxMicro); o.vcp = F(2 * (kMaxMicro + 1)); o.capi = F(kMaxCaps); o.mslot = F(L); o.capof = F(L);
     o.mlane = F(kMaxMicro); o.cbefore = F(kMaxMicro + 1); o.convlist = F(L); o.linfo = F(L); o.caplast = F(kMaxCaps); o.rused = F(kMaxMicro); o.caplane = F(kMaxCaps); o.capleaf = F(kMaxCaps);
-    o.stg_k = F((size_t)NS * kStage); o.stg_i = F((size_t)NS * kStage * 4); o.stg_w = F((size_t)NS * kStage * 4);
-    o.cnt_s = F(2 * kPhases * 64); o.lfl = F(L); o.vx = F(V);
+    o.stg_k = F((size_t)NS * 2 * stage_h); o.stg_i = F((size_t)NS * 2 * stage_h * 4); o.stg_w = F((size_t)NS * 2 * stage_h * 4);
+    // the cell -> lane and interface -> lane maps exist during set-up only: they lie on the (then still empty) staging area
+    o.cell_lane = o.stg_i; o.iface_lane = o.stg_i + 4 * (((size_t)C + 3) & ~(size_t)3);
+    o.cnt_s = F(2 * kPhases * 64); o.lfl = F(L); o.vx = F(V); o.lane_new = F(kMaxMicro);
     o.total = p;
     return o;
+}
+
+// records a lane of the micro wave can stage per step: what the LDS has room for beside everything else (0 = does not fit)
+__host__ __device__ inline int hyb_stage_h(int L, int C, int sq, int V, int NS, int n_action) {
+    const size_t act = up16(sizeof(float) * (size_t)n_action), budget = 160 * 1024;
+    const size_t fixed = hyb_lds(L, C, sq, V, NS, 0).total + act;
+    if (fixed + 64 >= budget) return 0;
+    int h = (int)((budget - fixed - 64) / ((size_t)NS * 2 * 36));
+    if (h > kStageH) h = kStageH;
+    while (h > 0 && hyb_lds(L, C, sq, V, NS, h).total + act > budget) --h;
+    // (the set-up maps lie on the staging area's index block)
+    if ((size_t)NS * 2 * h * 16 < 4 * ((((size_t)C + 3) & ~(size_t)3) + (((size_t)C + L + 3) & ~(size_t)3))) return 0;
+    return h;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -304,7 +322,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     const HybWs ws = hyb_ws(L, C, T, tb.n_routes, records_per_step);
     const int V = ws.V;
     const int NS = tb.n_micro > kMaxCaps ? tb.n_micro : kMaxCaps;      // lanes of the micro wave that stage records
-    const HybLds lo = hyb_lds(L, C, sq, V, NS);
+    const int stage_h = hyb_stage_h(L, C, sq, V, NS, n_action);
+    const HybLds lo = hyb_lds(L, C, sq, V, NS, stage_h);
     double *Fq = reinterpret_cast<double *>(lds + lo.fq), *scanw = reinterpret_cast<double *>(lds + lo.scanw);
     double *incl = reinterpret_cast<double *>(lds + lo.incl), *vsp = reinterpret_cast<double *>(lds + lo.vsp), *vep = reinterpret_cast<double *>(lds + lo.vep);
 #define LF(name) reinterpret_cast<float *>(lds + lo.name)
@@ -318,6 +337,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     float *vx = LF(vx);                            // per vehicle: static_speed - speed of the state the last step left (loss sample)
     int *lfl = LI(lfl);                            // per lane: first cell | last cell << 16
     int *cnt_s = LI(cnt_s);                        // [2 blocks][kPhases][64 lanes] staged record counts, micro wave -> flush wave
+    int *lane_new = LI(lane_new);                  // per micro lane: 1 = its tail vehicle was admitted at the boundary of the step
+                                                   // that runs now: the loss of the previous state does not count it
     const float um = (float)um_d, s0f = (float)static_speed, vlen = (float)veh_len, dtf = (float)dt;
     // the replica's action vector is read every step by the signal threads: staged in LDS (behind the carve-up)
     float *act = reinterpret_cast<float *>(lds + lo.total);
@@ -364,7 +385,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 for (int e = tb.net.nxt_ptr[l]; e < tb.net.nxt_ptr[l + 1]; ++e) spawns |= !tb.lane_macro[tb.net.nxt_idx[e]];
                 if (spawns) { if (nc < kMaxCaps) { capof[l] = nc; caplast[nc] = off + n - 1; caplane[nc] = l; } ++nc; convlist[nv++] = l; }
             } else {
-                if (nm < kMaxMicro) { mslot[l] = nm; mlane[nm] = l; cbefore[nm] = cells; lane_n[nm] = 0; rused[nm] = 0; }
+                if (nm < kMaxMicro) { mslot[l] = nm; mlane[nm] = l; cbefore[nm] = cells; lane_n[nm] = 0; rused[nm] = 0; lane_new[nm] = 0; }
                 ++nm; convlist[nv++] = l;
             }
         }
@@ -419,10 +440,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     float4 *grw = reinterpret_cast<float4 *>(wsr + ws.rec_w);
     const int base_local = 3 * V + kMaxCaps;
     Rec rec;
-    rec.next_local = base_local; rec.over = false; rec.off = kHard;
+    rec.next_local = base_local; rec.over = false; rec.off = kHard; rec.cap = stage_h;
     auto rec_select = [&](int b) {                   // this lane's staging half `b`, empty
         const int sl = (in_mw && mw < NS) ? mw : 0;
-        rec.sk = stg_k + (sl * 2 + b) * kStageH; rec.si = stg_i + (sl * 2 + b) * kStageH * 4; rec.sw = stg_w + (sl * 2 + b) * kStageH * 4;
+        rec.sk = stg_k + (sl * 2 + b) * stage_h; rec.si = stg_i + (sl * 2 + b) * stage_h * 4; rec.sw = stg_w + (sl * 2 + b) * stage_h * 4;
         rec.cnt = 0;
     };
     rec_select(0);
@@ -458,15 +479,16 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     // cells of the lanes in front, lane id order), exclusive prefix sums per micro lane for the loss constants
     auto vehicle_samples = [&](int ls) {
         const int k = fl;
-        const int c = k < n_micro ? lane_n[k] : 0;
+        const int nw = k < n_micro ? lane_new[k] : 0;  // (a vehicle admitted at this step's boundary sits at the tail: not part of the last state)
+        const int c = k < n_micro ? lane_n[k] - nw : 0;
         if (kHard) {                                   // is_static of every vehicle: 1.0 if speed < static_speed else 0.0
-            for (int i = 0; i < c; ++i) { const int vi = lane_veh[k * kLaneCap + i]; vx[vi] = vv[vi] < s0f ? 1.f : 0.f; }
+            for (int i = 0; i < c; ++i) { const int vi = lane_veh[k * kLaneCap + nw + i]; vx[vi] = vv[vi] < s0f ? 1.f : 0.f; }
             return;
         }
         const int exc = k <= n_micro ? vcp_of(ls)[k] : 0;
         double ssum = 0., esum = 0.;
         for (int i = 0; i < c; ++i) {
-            const int vi = lane_veh[k * kLaneCap + i];
+            const int vi = lane_veh[k * kLaneCap + nw + i];
             const long long idx = run_cnt + cbefore[k] + exc + i;
             const float x = s0f - vv[vi];
             float xo = 0.f;
@@ -500,7 +522,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     const int s_ = __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1);
                     mask &= mask - 1;
                     const int cs = __builtin_amdgcn_readlane(c, s_), os = __builtin_amdgcn_readlane(exc, s_);
-                    if (o >= os && o < os + cs) q = (s_ * 2 + b) * kStageH + (o - os);
+                    if (o >= os && o < os + cs) q = (s_ * 2 + b) * stage_h + (o - os);
                 }
                 if (q >= 0) {
                     grk[rec_n + o] = stg_k[q];
@@ -511,6 +533,68 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             rec_n += total;
         }
         if (total > kMaxStepRecords) fl_fault = true;
+    };
+
+    // ---- micro SOURCE lanes (itscp `micro` mode, _simulator.py:153-174): a micro lane without an upstream lane admits a waiting
+    // vehicle at the boundary of a step when it has room for half a vehicle at its entrance and the host's draw is below the
+    // step's inflow.  The draws are data (tb.draws: the stream np.random.random() yields, consumed in call order = lane order
+    // among the lanes that have room); every lane of the micro wave decides for its own lane, ranks come from ballots.  The
+    // boundary of step t + 1 is evaluated at the end of step t (same state: after the hand-offs); the admitted vehicle
+    // (position 0, speed 0: constants) enters at the tail and is flagged in lane_new so that the loss of the state step t
+    // left, which the next step's phases still evaluate, does not count it.
+    const bool has_src = tb.lane_source != nullptr;
+    bool my_src = false; int my_rlo = 0, my_rn = 0;
+    double my_draw = 2.0, my_sched = 0.;
+    int draw_base = 0;
+    const double *draws_r = has_src ? tb.draws + (size_t)rep * tb.draws_stride : nullptr;
+    if (has_src && in_mw && mw < n_micro) {
+        const int m = mlane[mw];
+        my_src = tb.lane_source[m] != 0;
+        my_rlo = tb.route_ptr[m]; my_rn = tb.route_ptr[m + 1] - my_rlo;
+    }
+    auto src_prefetch = [&](int step) {              // this lane's candidate draw and the inflow of `step`
+        const int di = draw_base + mw;
+        my_draw = draws_r[di < tb.n_draws ? di : (tb.n_draws > 0 ? tb.n_draws - 1 : 0)];
+        const int m = mw < n_micro ? mlane[mw] : 0;
+        my_sched = tb.net.schedule[toff + (size_t)(step < T ? step : T - 1) * L + m];
+    };
+    auto source_admit = [&](int step) {              // micro wave, all lanes; `step` = the step whose boundary this is
+        const int k = mw;
+        float room = 0.f;
+        if (my_src) room = lane_n[k] ? vp[lane_veh[k * kLaneCap + 0]] - 0.5f * vlen : lanelen[mlane[k]];
+        const bool want = my_src && room > vlen * 0.5f;
+        const unsigned long long bw = __ballot(want);
+        const int rank = __popcll(bw & ((1ull << mw) - 1ull));
+        const double draw = __shfl(my_draw, rank);   // lane j holds draws[draw_base + j]
+        if (want && draw_base + rank >= tb.n_draws) cap_fault = true;
+        const bool admit = want && draw < my_sched && rused[k < n_micro ? k : 0] < my_rn;
+        draw_base += __popcll(bw);
+        const unsigned long long ba = __ballot(admit);
+        if (admit) {
+            const int vi = spawned + __popcll(ba & ((1ull << mw) - 1ull));
+            if (vi >= V || lane_n[k] >= kLaneCap) cap_fault = true;
+            else {
+                const size_t row = (size_t)(my_rlo + rused[k]);
+                ++rused[k];
+                vp[vi] = 0.f; vidp[vi] = 3 * vi;      // fresh slots: their adjoints start at zero and nothing upstream reads them
+                vv[vi] = 0.f; vidv[vi] = 3 * vi + 1;
+                va[vi] = vlen; vida[vi] = -1;
+                vcur[vi] = 0;
+                int rl_ = 0;
+                for (int q = 0; q < kRouteStride; ++q) {
+                    const int lid = q < tb.route_stride ? tb.routes[row * tb.route_stride + q] : -1;
+                    vroute[vi * kRouteStride + q] = lid;
+                    if (lid >= 0 && rl_ == q) rl_ = q + 1;
+                }
+                vrlen[vi] = rl_;
+                for (int q = lane_n[k]; q > 0; --q) lane_veh[k * kLaneCap + q] = lane_veh[k * kLaneCap + q - 1];
+                lane_veh[k * kLaneCap + 0] = vi;
+                ++lane_n[k];
+            }
+        }
+        if (k < n_micro) lane_new[k] = admit ? 1 : 0;
+        spawned += __popcll(ba);
+        src_prefetch(step + 1);                      // consumed one step later
     };
 
     float lane_total = 0.f;
@@ -583,10 +667,12 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             const int k = fl;
             if (k < n_micro) {
                 qmicro[k] = 0.f;
-                const int nv = lane_n[k];
+                const int nw = lane_new[k];
+                const int nv = lane_n[k] - nw;
+                const int *lv = lane_veh + k * kLaneCap + nw;
                 if (kHard) {
                     float q = 0.f;
-                    for (int i = 0; i < nv; ++i) q = q + vx[lane_veh[k * kLaneCap + i]];
+                    for (int i = 0; i < nv; ++i) q = q + vx[lv[i]];
                     qmicro[k] = (q * q) * dtf;
                 } else if (nv > 0) {
                     const int cb = cbefore[k];
@@ -601,7 +687,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     // record per vehicle, directly on its speed
                     float q = 0.f, dsg[kLaneCap];
                     for (int i = 0; i < nv; ++i) {
-                        const int vi = lane_veh[k * kLaneCap + i];
+                        const int vi = lv[i];
                         const float x = vx[vi];
                         pa += (double)x; pb += (double)vxold[vi]; ++n;
                         const bool full = n > kWindow;
@@ -620,10 +706,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                         int at = cnt_s[(b * kPhases + 0) * 64 + k] + cnt_s[(b * kPhases + 1) * 64 + k] + cnt_s[(b * kPhases + 2) * 64 + k];
                         int added = 0;
                         for (int i = 0; i < nv; ++i) {
-                            const int vi = lane_veh[k * kLaneCap + i];
+                            const int vi = lv[i];
                             if (vidv[vi] >= 0 && dsg[i] != 0.f) {
-                                if (at >= kStageH) { fl_fault = true; break; }
-                                const int q_ = (k * 2 + b) * kStageH + at;
+                                if (at >= stage_h) { fl_fault = true; break; }
+                                const int q_ = (k * 2 + b) * stage_h + at;
                                 stg_k[q_] = K_SEED << 24;
                                 *reinterpret_cast<int4 *>(stg_i + 4 * q_) = make_int4(vidv[vi], 0, 0, 0);
                                 *reinterpret_cast<float4 *>(stg_w + 4 * q_) = make_float4(gq * (-dsg[i]), 0.f, 0.f, 0.f);
@@ -649,6 +735,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             lane_total = lane_total + (-1.0f) * term;
         }
     };
+    if (has_src && in_mw && T > 0) { src_prefetch(0); source_admit(0); }
+    if (has_src) __syncthreads();
     HYB_STAMP_DECL
     for (int t = 0; t < T; ++t) {
         const float *cur = (t & 1) ? S1 : S0;
@@ -876,6 +964,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         if (t > 0 && !in_mw) { loss_consts(cur, t - 1); run_update(t - 1); }      // (the micro wave keeps no running sums)
         if (is_fw && t > 0) flush_block(t - 1);          // the last step's records, with the seeds appended two phases ago
         if (in_mw) {
+            if (has_src && mw < n_micro) lane_new[mw] = 0;       // the loss of the last state has been evaluated (phases A, B)
             // capacitors: += r u dt of the last cell (conversion.py:32-36); the spawn itself is an event below
             if (mw < n_caps) {
                 const int j = mw, l = caplane[j];
@@ -1015,6 +1104,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 const int c = k < n_micro ? lane_n[k] : 0;
                 const int inc = wave_scan_add(c);
                 if (k <= n_micro) vcp_of(t)[k] = inc - c;
+            }
+            if (has_src) {
+                spawned = __builtin_amdgcn_readfirstlane(spawned);       // (the serial event walk counts on lane 0)
+                if (t + 1 < T) source_admit(t + 1);
             }
             publish(t);
         }
@@ -1559,7 +1652,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
 using namespace dhts;
 
 static inline bool hyb_desc_ok(const dhts_net_desc *d) {
-    return d && d->n_replicas > 0 && d->n_lanes > 0 && d->n_cells > 0 && d->n_steps >= 0 && d->n_inter_sq > 0 &&
+    return d && d->n_replicas > 0 && d->n_lanes > 0 && d->n_cells >= 0 && d->n_steps >= 0 && d->n_inter_sq > 0 &&
            d->frames_per_phase > 0 && d->n_action >= d->n_inter_sq && d->n_action <= 960 && d->dt > 0 && d->u_max > 0 &&
            d->vehicle_length > 0 && d->n_cells + d->n_lanes <= 960;
 }
@@ -1568,7 +1661,8 @@ static inline bool hyb_tables_ok(const dhts_hybrid_tables *t) {
     return t && n->lane_ncell && n->lane_off && n->sig_kind && n->inter && n->lane_dx && n->left_src && n->left_gate &&
            n->right_src && n->schedule && n->replica_stride >= 0 && n->nxt_ptr && n->nxt_idx && n->prv_ptr && n->prv_idx &&
            n->n_edges >= 0 && t->lane_macro && t->lane_len && t->conv_next && t->routes && t->route_ptr && t->n_routes > 0 &&
-           t->route_stride > 0 && t->route_stride <= kRouteStride && t->n_micro >= 0 && t->n_micro <= kMaxMicro;
+           t->route_stride > 0 && t->route_stride <= kRouteStride && t->n_micro >= 0 && t->n_micro <= kMaxMicro &&
+           (t->lane_source == nullptr || (t->draws != nullptr && t->n_draws > 0 && t->draws_stride >= 0));
 }
 static inline HybTables hyb_tables(const dhts_hybrid_tables *t) {
     HybTables h;
@@ -1579,6 +1673,7 @@ static inline HybTables hyb_tables(const dhts_hybrid_tables *t) {
     h.net.nxt_ptr = n->nxt_ptr; h.net.nxt_idx = n->nxt_idx; h.net.prv_ptr = n->prv_ptr; h.net.prv_idx = n->prv_idx; h.net.n_edges = n->n_edges;
     h.lane_macro = t->lane_macro; h.lane_len = t->lane_len; h.conv_next = t->conv_next; h.routes = t->routes; h.route_ptr = t->route_ptr;
     h.n_routes = t->n_routes; h.route_stride = t->route_stride; h.loss_steps = t->loss_steps; h.n_micro = t->n_micro;
+    h.lane_source = t->lane_source; h.draws = t->draws; h.n_draws = t->n_draws; h.draws_stride = (size_t)t->draws_stride;
     return h;
 }
 static inline int hyb_block(const dhts_net_desc *d) {
@@ -1609,7 +1704,10 @@ int dhts_net_hybrid_rollout_fwd(const dhts_net_desc *d, const dhts_hybrid_tables
     const int B = hyb_block(d);
     if (B > 1024) return DHTS_E_INVALID;
     const HybWs ws = hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step);
-    const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, t->n_micro > kMaxCaps ? t->n_micro : kMaxCaps).total + up16(sizeof(float) * (size_t)d->n_action);
+    const int NS = t->n_micro > kMaxCaps ? t->n_micro : kMaxCaps;
+    const int stage_h = hyb_stage_h(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, d->n_action);
+    if (stage_h < 8) return DHTS_E_INVALID;       // (a lane with one vehicle stages ~10 records in a step with a hand-off)
+    const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, stage_h).total + up16(sizeof(float) * (size_t)d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     auto kern = B <= 512 ? net_hybrid_fwd_kernel<512, false> : net_hybrid_fwd_kernel<1024, false>;
     if (lds > 64 * 1024 &&
@@ -1628,7 +1726,10 @@ int dhts_net_hybrid_rollout_eval(const dhts_net_desc *d, const dhts_hybrid_table
     const int B = hyb_block(d);
     if (B > 1024) return DHTS_E_INVALID;
     const HybWs ws = hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step);
-    const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, t->n_micro > kMaxCaps ? t->n_micro : kMaxCaps).total + up16(sizeof(float) * (size_t)d->n_action);
+    const int NS = t->n_micro > kMaxCaps ? t->n_micro : kMaxCaps;
+    const int stage_h = hyb_stage_h(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, d->n_action);
+    if (stage_h < 8) return DHTS_E_INVALID;       // (a lane with one vehicle stages ~10 records in a step with a hand-off)
+    const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, stage_h).total + up16(sizeof(float) * (size_t)d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     auto kern = B <= 512 ? net_hybrid_fwd_kernel<512, true> : net_hybrid_fwd_kernel<1024, true>;
     if (lds > 64 * 1024 &&

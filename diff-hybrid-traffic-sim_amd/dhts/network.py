@@ -153,9 +153,12 @@ class HybridNetworkTables:
                 self.right_src[:, l] = macro_route[:, l]
                 if (macro_route[:, l] < 0).any():
                     raise ValueError("a lane with several downstream lanes was left unmatched")
-        for l in range(L):
-            if not is_macro[l] and len(prev[l]) == 0:
-                raise ValueError("micro source lanes (stochastic inflow, _simulator.py:153-174) are not supported")
+        # micro SOURCE lanes (no upstream lane): they admit waiting vehicles stochastically (_simulator.py:153-174).  The host's
+        # admission draws are data for the kernels: `draws` (set_micro_sources) is the stream np.random.random() would yield, in
+        # call order; the k-th vehicle admitted to such a lane takes the lane's k-th route row (callers list the waiting routes
+        # in admission order, i.e. the reference's waiting list reversed -- it pops from the end)
+        self.lane_source = np.array([int((not is_macro[l]) and len(prev[l]) == 0) for l in range(L)], dtype=np.int32)
+        self.draws = None
         self.conv_next = np.where(is_macro[None, :], macro_route, -1).astype(np.int32)
         # static adjacency (CSR, ascending ids) for the reverse sweep's inbox routing
         self.nxt_ptr = np.concatenate([[0], np.cumsum([len(n) for n in nxt])]).astype(np.int32)
@@ -167,19 +170,27 @@ class HybridNetworkTables:
             raise ValueError("the network kernels support at most 4 upstream and 4 downstream lanes per lane")
         self.schedule = np.ascontiguousarray(np.asarray(schedule, dtype=np.float64).T)      # [T][L]
 
+    def set_micro_sources(self, draws):
+        """The admission draws of the micro source lanes: the values np.random.random() yields (or yielded, for a replay), in
+        call order -- one per source lane and step in which the lane has room for a vehicle."""
+        self.draws = np.ascontiguousarray(draws, dtype=np.float64)
+        return self
+
     def check_kernel_limits(self):
         """Raise ValueError when the network is outside what the fused hybrid kernels hold in one workgroup."""
+        if self.lane_source.any() and self.draws is None:
+            raise ValueError("hybrid kernels: a network with micro source lanes needs its admission draws (set_micro_sources)")
         n_micro = int((self.lane_macro == 0).sum())
         n_spawn = sum(1 for l in range(self.n_lanes)
                       if self.lane_macro[l] == 1 and any(self.lane_macro[b] == 0 for b in self.next_lanes[l]))
         if self.n_cells + self.n_lanes > 960:
             raise ValueError("hybrid kernels: cells + lanes must be <= 960 (got %d)" % (self.n_cells + self.n_lanes))
-        if n_micro > 24:
-            raise ValueError("hybrid kernels: at most 24 micro lanes (got %d)" % n_micro)
+        if n_micro > 64:
+            raise ValueError("hybrid kernels: at most 64 micro lanes (got %d)" % n_micro)
         if n_spawn > 16:
             raise ValueError("hybrid kernels: at most 16 macro lanes feeding micro lanes (got %d)" % n_spawn)
-        if self.n_cells < 1:
-            raise ValueError("hybrid kernels: the network needs at least one macro cell")
+        if self.n_cells < 1 and n_micro < 1:
+            raise ValueError("hybrid kernels: the network has neither cells nor micro lanes")
 
     @staticmethod
     def from_env(env):

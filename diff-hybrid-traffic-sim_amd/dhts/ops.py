@@ -544,14 +544,37 @@ class DeviceHybridTables:
                       up(pad1(t.nxt_idx), torch.int32), up(t.prv_ptr, torch.int32), up(pad1(t.prv_idx), torch.int32),
                       up(t.lane_macro, torch.int32), up(t.lane_length, torch.float64), up(stack("conv_next"), torch.int32),
                       up(routes, torch.int32), up(route_ptr, torch.int32)]
+        # micro source lanes (itscp `micro` mode): the lane flags and the host's admission draws (per replica when `tables` is a list)
+        self.has_sources = bool(np.asarray(t.lane_source).any())
+        self.n_draws, self.draws_stride = 0, 0
+        if self.has_sources:
+            if many:
+                n = max(len(x.draws) for x in tables)
+                d = np.full((len(tables), n), 2.0)           # (a draw of 2.0 admits nobody)
+                for i, x in enumerate(tables):
+                    d[i, :len(x.draws)] = x.draws
+                self.n_draws, self.draws_stride = n, n
+            else:
+                d = np.asarray(t.draws, dtype=np.float64)
+                self.n_draws = len(d)
+            self._keep += [up(t.lane_source, torch.int32), up(d, torch.float64)]
         k = [x.data_ptr() for x in self._keep]
         self.net = _lib.NetTables(k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], self.T * self.n_lanes if many else 0,
                                   k[9], k[10], k[11], k[12], t.n_edges)
 
+    def set_draws(self, draws):
+        """A fresh stream of admission draws for the next episode (micro source lanes; same length as the uploaded one)."""
+        import numpy as np
+        d = torch.as_tensor(np.ascontiguousarray(draws, dtype=np.float64), device=self._keep[19].device)
+        if d.shape != self._keep[19].shape:
+            raise ValueError("draws must keep their shape %s" % (tuple(self._keep[19].shape),))
+        self._keep[19].copy_(d)
+
     def c(self, loss_steps=0):
         k = [x.data_ptr() for x in self._keep]
+        src = (k[18], k[19]) if self.has_sources else (None, None)
         return _lib.HybridTables(self.net, k[13], k[14], k[15], k[16], k[17], self.n_routes, self.route_stride, self.records_per_step,
-                                 int(loss_steps), self.n_micro)
+                                 int(loss_steps), self.n_micro, src[0], src[1], self.n_draws, self.draws_stride)
 
 
 class NetHybridRollout(torch.autograd.Function):
@@ -576,9 +599,10 @@ class NetHybridRollout(torch.autograd.Function):
             raise ValueError("unsupported hybrid network size")
         dev = a.device
         Cp = (t.n_cells + 63) // 64 * 64
-        hist = torch.empty(R * (t.T + 1) * 4 * t.n_cells, dtype=torch.float32, device=dev)
-        tape = torch.empty(R * t.T * 3 * Cp * 4, dtype=torch.float32, device=dev)
-        kc = torch.empty(R, t.T, t.n_cells, dtype=torch.float32, device=dev)
+        # (an all-micro network has no cells: the kernels' unconditional prefetches still want something to read)
+        hist = torch.empty(max(R * (t.T + 1) * 4 * t.n_cells, 64), dtype=torch.float32, device=dev)
+        tape = torch.empty(max(R * t.T * 3 * Cp * 4, 64), dtype=torch.float32, device=dev)
+        kc = torch.empty(max(R * t.T * t.n_cells, 64), dtype=torch.float32, device=dev)
         queue = torch.empty(R, t.T, t.n_lanes, dtype=torch.float32, device=dev)
         reward = torch.empty(R, dtype=torch.float32, device=dev)
         counts = torch.zeros(R, 4, dtype=torch.int32, device=dev)

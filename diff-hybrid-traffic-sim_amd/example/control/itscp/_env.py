@@ -263,7 +263,7 @@ class ItscpEnv:
         hard thresholds (dhts_net_*_rollout_eval), one launch, nothing kept for a reverse sweep.  Same numbers as the operator path in `macro` mode; in `hybrid` mode vehicle routes are pre-drawn
         per spawn lane (`fused_routes`, or 8 per lane from create_random_route) instead of being drawn at spawn time.
         Returns None when the network or the call is outside what the kernels cover (the operator path runs then)."""
-        if not self.config.get("fused", True) or self.config["mode"] not in ("macro", "hybrid") or self.steps != 1 or self.time != 0:
+        if not self.config.get("fused", True) or self.config["mode"] not in ("macro", "hybrid", "micro") or self.steps != 1 or self.time != 0:
             return None
         if not (isinstance(action, th.Tensor) and action.is_cuda):
             return None
@@ -279,6 +279,19 @@ class ItscpEnv:
                 n_cells = sum(getattr(sl, "num_cell", 0) for sl in sim.lane.values() if sl.is_macro())
                 if self.config["mode"] == "macro" and n_cells + len(sim.lane) <= 1024:
                     cache = ("macro", ops.DeviceNetTables(MacroNetworkTables.from_env(self), action.device))
+                elif self.config["mode"] == "micro":
+                    # every lane an IDM lane; source lanes admit their waiting vehicles against np.random draws
+                    # (_simulator.py:153-174): the waiting routes in admission order (the list is popped from its end) are
+                    # the route rows, the draws of the episode are drawn up front (fused_draws replays a recorded stream)
+                    tab = HybridNetworkTables.from_env(self)
+                    rows = []
+                    for l in range(tab.n_lanes):
+                        for r in reversed(sim.lane_waiting_micro_route.get(l, [])):
+                            r = list(r.route)[:32]
+                            rows.append(r + [-1] * (32 - len(r)))
+                    self._fused_n_draws = T * max(1, int(tab.lane_source.sum()))
+                    tab.set_micro_sources(np.full(self._fused_n_draws, 2.0))
+                    cache = ("micro", ops.DeviceHybridTables(tab, np.asarray(rows if rows else [[-1, -1]], dtype=np.int32), action.device))
                 else:
                     tab = HybridNetworkTables.from_env(self)
                     routes = getattr(self, "fused_routes", None)
@@ -302,6 +315,13 @@ class ItscpEnv:
                 1.0 / self.config["simulation_frequency"], self.simulator.speed_limit, self.config["static_speed"],
                 self.simulator.vehicle_length)
         a = action.reshape(1, -1)
+        if kind == "micro":
+            draws = getattr(self, "fused_draws", None)
+            if draws is None:
+                draws = np.random.random(self._fused_n_draws)
+            else:
+                draws = np.concatenate([np.asarray(draws, dtype=np.float64), np.full(self._fused_n_draws, 2.0)])[:self._fused_n_draws]
+            tab.set_draws(draws)
         if kind == "macro":
             reward, queue = ops.net_macro_rollout(a, tab, *args) if differentiable else ops.net_macro_eval(a, tab, *args)
         elif differentiable:

@@ -320,8 +320,9 @@ int dhts_net_macro_rollout_bwd(const dhts_net_desc *d, const dhts_net_tables *t,
  *   route_ptr[m] .. route_ptr[m+1] start on micro lane m): the k-th vehicle spawned onto lane m takes row
  *   route_ptr[m] + k mod (rows of m).  The reference draws a route with np.random at spawn time (road_network.py:604-646);
  *   callers pre-draw them (dhts/network.py: group_routes keeps a recorded spawn order intact).
- * Limits: n_cells + n_lanes <= 960, <= 24 micro lanes, <= 16 spawning lanes, <= 16 vehicles per micro lane, <= 48 tape
- * records per micro lane and step (DHTS_FAULT_CAPACITY beyond), <= 128 vehicles per replica and episode, route_stride <= 32; records_per_step (average budget of the record stream,
+ * Limits: n_cells + n_lanes <= 960 (n_cells = 0 is allowed: an all-micro network), <= 64 micro lanes, <= 16 spawning lanes, <= 16 vehicles per micro lane, <= 48 tape
+ * records per micro lane and step -- fewer when more than ~20 micro lanes share the workgroup's LDS staging, e.g. 18 at 64
+ * micro lanes beside 288 cells; a lane with k vehicles stages ~8 + 2 k (DHTS_FAULT_CAPACITY beyond), <= 128 vehicles per replica and episode, route_stride <= 32; records_per_step (average budget of the record stream,
  * 0 = 512).  loss_steps: only the first loss_steps steps enter reward_cut and the gradient (<= 0: all).
  */
 typedef struct dhts_hybrid_tables {
@@ -333,6 +334,18 @@ typedef struct dhts_hybrid_tables {
     const int32_t *route_ptr;
     int32_t n_routes, route_stride, records_per_step, loss_steps;
     int32_t n_micro;            /* number of micro lanes (zeros of lane_macro); sizes the kernels' LDS staging */
+    /* micro SOURCE lanes -- micro lanes without an upstream lane; itscp `micro` mode, where every lane is an IDM lane and
+     * n_cells = 0 (ItscpRoadNetwork.setup_micro_boundary, _simulator.py:153-174): at the boundary of a step such a lane admits
+     * a waiting vehicle (position 0, speed 0) when it has more than half a vehicle length of room at its entrance and the
+     * host's draw np.random.random() is below the step's inflow schedule[t][lane].  The draws are data: `draws` is the stream
+     * in call order (one draw per source lane with room, lanes in id order, steps in order), n_draws its length (a run that
+     * needs more raises DHTS_FAULT_CAPACITY), draws_stride the elements between replicas (0 = shared).  The k-th vehicle admitted
+     * to lane m takes route row route_ptr[m] + k (no wrap-around: the rows are the lane's waiting list in admission order, and an
+     * exhausted list admits nobody).  lane_source [L] int32 (1 = source lane) or NULL = the network has none. */
+    const int32_t *lane_source;
+    const double *draws;
+    int32_t n_draws;
+    int64_t draws_stride;
 } dhts_hybrid_tables;
 size_t dhts_net_hybrid_workspace_bytes(const dhts_net_desc *d, const dhts_hybrid_tables *t);
 /* hist / tape / kc / queue / reward as in the macro rollout (kc, tape rows of micro lanes do not exist: they have no cells);

@@ -676,6 +676,19 @@ static float soft_switch_grad(float value, float constant) {
 static int oracle_hard = 0;
 void oracle_set_hard(int hard) { oracle_hard = hard != 0; }
 
+/* itscp `micro` mode (run_itscp_micro.sh): micro lanes without an upstream lane admit waiting vehicles stochastically
+ * (ItscpRoadNetwork.setup_micro_boundary, _simulator.py:153-174).  The host's draws np.random.random() are data here: the
+ * recorded stream, consumed in call order (one draw per source lane and step in which the lane has room).  Process-wide
+ * inputs of oracle_net_hybrid (set before the call, cleared after): lane_source [L] (1 = micro lane without upstream lane),
+ * draws [n], and the number of draws the episode consumed. */
+static const int *oracle_src_lanes = NULL;
+static const double *oracle_src_draws = NULL;
+static int oracle_src_n = 0, oracle_src_used = 0;
+void oracle_set_micro_sources(const int *lane_source, const double *draws, int n_draws) {
+    oracle_src_lanes = lane_source; oracle_src_draws = draws; oracle_src_n = n_draws; oracle_src_used = 0;
+}
+int oracle_micro_source_draws_used(void) { return oracle_src_used; }
+
 typedef struct {            /* per step: phase signals of every intersection and their inputs */
     float we, ns, a, prog;
     int a_index;

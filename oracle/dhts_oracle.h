@@ -131,6 +131,10 @@ void oracle_micro_rollout_bwd(int L, int V, int T, const float *tape,
 /* 1 = the network forward passes below run EVALUATION episodes (hard thresholds, ItscpEnv.step(action, False)); their
  * gradient outputs are then meaningless.  Process-wide switch of this test library. */
 void oracle_set_hard(int hard);
+/* micro SOURCE lanes of oracle_net_hybrid (itscp `micro` mode, _simulator.py:153-174): lane_source [L] (1 = micro lane without an
+ * upstream lane), the host's admission draws in call order; NULL = none.  Process-wide, set before the call. */
+void oracle_set_micro_sources(const int *lane_source, const double *draws, int n_draws);
+int oracle_micro_source_draws_used(void);
 typedef struct oracle_net_desc {
     int n_lanes, n_cells, T, n_inter_sq, frames_per_phase, n_action;
     double dt, u_max, static_speed, vehicle_length;

@@ -261,6 +261,14 @@ def net_hybrid(tab, routes, route_ptr, action, n_inter_sq, frames_per_phase, dt,
     l = lib()
     l.oracle_set_hard(1 if hard else 0)
     want_grad = want_grad and not hard
+    l.oracle_set_micro_sources.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    src = np.ascontiguousarray(getattr(tab, "lane_source", np.zeros(tab.n_lanes)), dtype=np.int32)
+    draws = None if getattr(tab, "draws", None) is None else _f64(tab.draws)
+    if src.any():           # itscp `micro` mode: micro source lanes admit vehicles against the recorded draws
+        assert draws is not None, "a network with micro source lanes needs its admission draws (set_micro_sources)"
+        l.oracle_set_micro_sources(_p(src), _p(draws), len(draws))
+    else:
+        l.oracle_set_micro_sources(None, None, 0)
     l.oracle_net_hybrid.argtypes = ([C.POINTER(NetDesc)] + [C.c_void_p] * 14 + [C.c_int, C.c_int, C.c_void_p, C.c_int]
                                     + [C.c_void_p] * 8)
     action = _f32(action)
@@ -282,5 +290,7 @@ def net_hybrid(tab, routes, route_ptr, action, n_inter_sq, frames_per_phase, dt,
                              _p(queue), C.addressof(reward), C.addressof(reward_cut), _p(g) if want_grad else None,
                              C.addressof(nsp), C.addressof(ndep), _p(hist) if want_hist else None, _p(kc) if want_hist else None)
     l.oracle_set_hard(0)
+    draws_used = l.oracle_micro_source_draws_used()
+    l.oracle_set_micro_sources(None, None, 0)
     return dict(rc=rc, reward=reward.value, reward_cut=reward_cut.value, queue=queue, g_action=g if want_grad else None,
-                n_spawned=nsp.value, n_deposits=ndep.value, hist=hist, kc=kc)
+                n_spawned=nsp.value, n_deposits=ndep.value, hist=hist, kc=kc, draws_used=draws_used)

@@ -181,12 +181,19 @@ def test_hybrid_tables_builder_and_route_grouping():
     assert routes.tolist() == [[1, 2, -1], [1, -1, -1], [4, -1, -1]]      # stable per first lane
     assert ptr.tolist() == [0, 0, 2, 2, 2, 3, 3]
     t.check_kernel_limits()
-    big = HybridNetworkTables([1] + [0] * 30, [4] + [0] * 30, [20.0] * 31, [(k, k + 1) for k in range(0, 30)],
+    mid = HybridNetworkTables([1] + [0] * 30, [4] + [0] * 30, [20.0] * 31, [(k, k + 1) for k in range(0, 30)],
                               [0] * 31, [0] * 31, -np.ones((T, 31), dtype=np.int64), np.ones((31, T)))
-    with pytest.raises(ValueError, match="24 micro lanes"):
+    mid.check_kernel_limits()                     # 30 micro lanes: inside the kernels' 64 since round 3
+    big = HybridNetworkTables([1] + [0] * 70, [4] + [0] * 70, [20.0] * 71, [(k, k + 1) for k in range(0, 70)],
+                              [0] * 71, [0] * 71, -np.ones((T, 71), dtype=np.int64), np.ones((71, T)))
+    with pytest.raises(ValueError, match="64 micro lanes"):
         big.check_kernel_limits()
-    with pytest.raises(ValueError, match="micro source"):
-        HybridNetworkTables([0, 1], [0, 3], [10.0, 15.0], [(0, 1)], [0, 0], [0, 0], -np.ones((T, 2), dtype=np.int64), np.ones((2, T)))
+    # a micro SOURCE lane (no upstream lane: stochastic admission, _simulator.py:153-174) needs its draws
+    src = HybridNetworkTables([0, 1], [0, 3], [10.0, 15.0], [(0, 1)], [0, 0], [0, 0], -np.ones((T, 2), dtype=np.int64), np.ones((2, T)))
+    assert src.lane_source.tolist() == [1, 0]
+    with pytest.raises(ValueError, match="admission draws"):
+        src.check_kernel_limits()
+    src.set_micro_sources([0.3, 0.7]).check_kernel_limits()
 
 
 def test_hybrid_entry_points_reject_bad_arguments():

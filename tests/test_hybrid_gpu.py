@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from test_oracle_golden import itscp_hybrid_tables
+from test_oracle_golden import itscp_hybrid_tables, itscp_micro_tables
 from util import TOL_GRAD, TOL_STATE, grad_report, rel_elem, rel_max
 
 pytestmark = pytest.mark.gpu
@@ -301,3 +301,64 @@ def test_hybrid_evaluation_episode_vs_reference(cuda, oracle, golden_dir, name):
         assert abs(float(reward[k]) - o["reward"]) <= 1e-5 * abs(o["reward"]), k
     reward2, queue2, _ = ops.net_hybrid_eval(a, dtab, *args)
     assert torch.equal(reward, reward2) and torch.equal(queue, queue2)
+
+
+@pytest.mark.parametrize("name", ["micro_small", "micro"])
+def test_itscp_micro_mode_through_fused_kernels(cuda, oracle, golden_dir, name):
+    """itscp `micro` mode (run_itscp_micro.sh: 40 IDM lanes, no cells, 65 vehicles admitted stochastically by the source lanes,
+    _simulator.py:153-174) through dhts_net_hybrid_rollout_fwd / _bwd: the recorded admission draws as data, waiting routes as
+    route rows.  Replica 0 = the reference's action: vehicle count, queues (1e-4: the reference steps these lanes in float32
+    tensor arithmetic), reward, d reward / d action <= 1e-4; further replicas against the oracle; the evaluation kernel
+    against the oracle's evaluation mode."""
+    import torch
+    from dhts import ops
+    from dhts.network import group_routes
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    t, m, rows = itscp_micro_tables(g)
+    args = (m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"],
+            m["speed_limit"], m["static_speed"], m["vehicle_length"])
+    rng = np.random.default_rng(5)
+    acts = np.concatenate([g["action"][None], rng.uniform(0.1, 0.9, (3, len(g["action"]))).astype(np.float32)])
+    dtab = ops.DeviceHybridTables(t, rows, cuda)
+    a = torch.tensor(acts, device=cuda, requires_grad=True)
+    cut, reward, queue, counts = ops.net_hybrid_rollout(a, dtab, *args)
+    cut.sum().backward()
+    q, grad = queue.detach().cpu().numpy(), a.grad.cpu().numpy()
+    assert int(counts[0, 0]) == m["n_vehicle_spawned"]
+    assert rel_max(q[0].T, g["queue"]) <= 1e-4
+    assert abs(float(reward[0]) - float(g["reward"])) <= 1e-4 * abs(float(g["reward"]))
+    assert grad_report("G8 %s (kernels) d reward / d action" % name, grad[0], g["g_action"]) <= TOL_GRAD
+    routes, route_ptr = group_routes(rows, t.n_lanes)
+    for k in range(1, len(acts)):
+        o = oracle.net_hybrid(t, routes, route_ptr, acts[k], *args)
+        assert o["rc"] == 0 and int(counts[k, 0]) == o["n_spawned"], k
+        assert rel_max(q[k], o["queue"]) <= 1e-4, k
+        assert abs(float(reward[k]) - o["reward"]) <= 1e-5 * abs(o["reward"]), k
+        assert rel_max(grad[k], o["g_action"]) <= TOL_GRAD, k
+    # evaluation episodes of the same network
+    ev_reward, ev_queue, ev_counts = ops.net_hybrid_eval(a.detach(), dtab, *args)
+    for k in (0, 2):
+        o = oracle.net_hybrid(t, routes, route_ptr, acts[k], *args, hard=True)
+        assert int(ev_counts[k, 0]) == o["n_spawned"] and rel_max(ev_queue[k].cpu().numpy(), o["queue"]) <= 1e-4, k
+        assert abs(float(ev_reward[k]) - o["reward"]) <= 1e-5 * abs(o["reward"]), k
+
+
+@pytest.mark.parametrize("name", ["hybrid_n2", "hybrid_4x4"])
+def test_hybrid_networks_with_more_micro_lanes(cuda, golden_dir, name):
+    """Networks above the 24 micro lanes of round 2: two lanes per approach (28 IDM lanes at the centre intersection, 12 macro
+    lanes feeding them) and 4 x 4 intersections (64 IDM lanes: every lane of the micro wave owns one; the LDS staging shrinks
+    to what fits beside 384 cells) -- reference runs of 240 steps: vehicle count, queues, reward, d reward / d action."""
+    path = os.path.join(golden_dir, "itscp_%s.npz" % name)
+    if not os.path.exists(path):
+        pytest.skip("golden not generated")
+    g = np.load(path)
+    o = _run(cuda, g, replicas=2)
+    m = o["m"]
+    for r in range(2):
+        assert o["counts"][r, 0] == m["n_vehicle_spawned"]
+        assert rel_max(o["queue"][r].T, g["queue"]) <= 1e-4
+        assert abs(float(o["reward"][r]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+        assert np.abs(o["grad"][r] - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()
+    for t0, ref in zip(g["g_action_cut_steps"], g["g_action_cut"]):
+        oc = _run(cuda, g, loss_steps=int(t0))
+        assert np.abs(oc["grad"][0] - ref).max() <= TOL_GRAD * np.abs(g["g_action"]).max(), int(t0)

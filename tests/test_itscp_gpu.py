@@ -232,3 +232,23 @@ def test_env_evaluation_step_uses_fused_kernels(cuda, golden_dir, name):
             t_slow = time.time() - t0
         assert abs(float(reward_slow) - float(reward)) <= 1e-5 * abs(float(reward))
         print("evaluation episode %s: fused %.1f ms (first call, with table upload), lane by lane %.1f s" % (name, 1e3 * t_fused, t_slow))
+
+
+@pytest.mark.parametrize("name", ["micro_small", "micro"])
+def test_env_micro_mode_step_uses_fused_kernels(cuda, golden_dir, name):
+    """ItscpEnv.step(action, True) in `micro` mode through the fused kernels (two launches instead of 40 lanes x 300 steps of
+    operator calls), the reference's recorded admission draws replayed as data (env.fused_draws)."""
+    import torch
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    m = meta_of(g)
+    env = build_env(g, m, replay_routes=False)      # waiting routes drawn with np.random in the reference's order (same seed)
+    keys = list(env.lane.keys())
+    env.fused_draws = g["rand_draws"]
+    action = torch.tensor(g["action"], device=cuda, requires_grad=True)
+    obs, reward, done, info = env.step(action, True)
+    assert env._fused_done and env.fused_counts[0] == m["n_vehicle_spawned"]
+    reward.backward()
+    queue = np.array([env.queue_length[k] for k in keys])
+    assert rel_max(queue, g["queue"]) <= 1e-4
+    assert abs(float(reward.detach()) - float(g["reward"])) <= 1e-4 * abs(float(g["reward"]))
+    assert np.abs(action.grad.cpu().numpy() - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()

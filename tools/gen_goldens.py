@@ -854,6 +854,18 @@ def main():
             gen_itscp("eval_hybrid", "hybrid", 3, 1, 5.0, 20, 4, seed=9, action_kind="rand", differentiable=False)
         if "eval_hybrid_p2" in which:
             gen_itscp("eval_hybrid_p2", "hybrid", 3, 1, 5.0, 16, 4, seed=21, action_kind="rand", problem=2, differentiable=False)
+        # 4 x 4 intersections: the interior 2 x 2 are micro -- 64 IDM lanes, 8 macro lanes feeding them (the fused kernels'
+        # capacity since round 3; run_itscp_hybrid.sh with --n_intersection=4), 8 s
+        if "hybrid_4x4" in which:
+            os.environ["DHTS_FINE_CUTS"] = "120,200"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("hybrid_4x4", "hybrid", 4, 1, 5.0, 8, 2, seed=29, action_kind="rand", problem=2)
+        if "hybrid_n2" in which:         # two lanes per approach: 28 micro lanes at the centre intersection, 12 macro lanes feeding them
+            os.environ["DHTS_FINE_CUTS"] = "120,200"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("hybrid_n2", "hybrid", 3, 2, 5.0, 8, 2, seed=37, action_kind="rand", problem=1)
+        if "eval_hybrid_4x4" in which:
+            gen_itscp("eval_hybrid_4x4", "hybrid", 4, 1, 5.0, 8, 2, seed=29, action_kind="rand", problem=2, differentiable=False)
         if "hybrid_short" in which:      # 8 s: enough for the first vehicles to cross the interior intersection
             gen_itscp("hybrid_short", "hybrid", 3, 1, 5.0, 8, 2, seed=9, action_kind="rand")
 
