@@ -498,6 +498,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         }
         const double is_ = wave_scan_add(ssum), ie_ = wave_scan_add(esum);
         if (k <= n_micro) { vsp[k] = is_ - ssum; vep[k] = ie_ - esum; }
+        if (k == 63 && n_micro == 64) { vsp[64] = is_; vep[64] = ie_; }       // (no lane 64 to hold the totals)
     };
     auto flush_block = [&](int blk) {
         if (kHard) return;
@@ -1104,6 +1105,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 const int c = k < n_micro ? lane_n[k] : 0;
                 const int inc = wave_scan_add(c);
                 if (k <= n_micro) vcp_of(t)[k] = inc - c;
+                if (k == 63 && n_micro == 64) vcp_of(t)[64] = inc;            // (no lane 64 to hold the total)
             }
             if (has_src) {
                 spawned = __builtin_amdgcn_readfirstlane(spawned);       // (the serial event walk counts on lane 0)

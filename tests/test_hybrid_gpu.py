@@ -271,7 +271,7 @@ def test_larger_network_vs_oracle(cuda, oracle):
     assert spawned > 0
 
 
-@pytest.mark.parametrize("name", ["eval_hybrid_short", "eval_hybrid_p2", "eval_hybrid"])
+@pytest.mark.parametrize("name", ["eval_hybrid_short", "eval_hybrid_p2", "eval_hybrid", "eval_hybrid_4x4"])
 def test_hybrid_evaluation_episode_vs_reference(cuda, oracle, golden_dir, name):
     """dhts_net_hybrid_rollout_eval = ItscpEnv.step(action, False) of the reference in `hybrid` mode (240 steps; 480 steps over
     problem_2's inflows; BASELINE config 4's 600-step episode): hard signals and boundaries, head gap green iff the lane's own
@@ -319,6 +319,9 @@ def test_itscp_micro_mode_through_fused_kernels(cuda, oracle, golden_dir, name):
             m["speed_limit"], m["static_speed"], m["vehicle_length"])
     rng = np.random.default_rng(5)
     acts = np.concatenate([g["action"][None], rng.uniform(0.1, 0.9, (3, len(g["action"]))).astype(np.float32)])
+    # other actions open the lights at other times, so their source lanes ask for draws the reference's run never made:
+    # the recorded stream (consumed in full by the reference's action) continues with fresh ones
+    t.set_micro_sources(np.concatenate([g["rand_draws"], rng.random(4 * len(g["rand_draws"]))]))
     dtab = ops.DeviceHybridTables(t, rows, cuda)
     a = torch.tensor(acts, device=cuda, requires_grad=True)
     cut, reward, queue, counts = ops.net_hybrid_rollout(a, dtab, *args)
