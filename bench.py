@@ -410,10 +410,11 @@ class ItscpHybridWorkload:
     unit_name = "cell-steps/s"
 
     def moved_bytes_per_launch(self):
-        """per-cell-step blocks (48 B) + state history (16 B) + loss constant (4 B), per-lane-step queue terms, and the
-        36-byte records of the micro side (counts[:, 2] = records per replica)"""
+        """the interface tape (two 2x2 products = 32 B per interface slot and step), state history (16 B) + loss constant (4 B)
+        per cell-step, per-lane-step queue terms, and the 36-byte records of the micro side (counts[:, 2] = records per replica)"""
         recs = int(self.counts[:, 2].sum()) if self.counts is not None else 0
-        return self.R * self.T * (self.N * (48 + 16 + 4) + self.n_lanes * 4) + recs * 36
+        nip = (self.N + self.n_lanes + 63) // 64 * 64
+        return self.R * self.T * (nip * 32 + self.N * (16 + 4) + self.n_lanes * 4) + recs * 36
 
     def __init__(self, dev, rank, R, _n, _t):
         import numpy as np

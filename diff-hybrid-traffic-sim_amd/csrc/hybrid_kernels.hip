@@ -73,6 +73,14 @@ __device__ long long dhts_hyb_stamps[2][8][16][24];
         st_last_ = __builtin_amdgcn_s_memtime();                                            \
         st_acc_[16 + (i)] += st_last_ - b_;                    /* barrier */                \
     }
+// a point inside a phase: the time since the last stamp goes to work slot 4 + i (slots 4..7 are free in the forward kernel) and
+// is NOT counted in the phase's own work slot
+#define HYB_SUB(i)                                                                          \
+    {                                                                                       \
+        const long long a_ = __builtin_amdgcn_s_memtime();                                  \
+        st_acc_[4 + (i)] += a_ - st_last_;                                                  \
+        st_last_ = a_;                                                                      \
+    }
 #define HYB_STAMP_WRITE(kernel_, rep_, tid_, B_)                                            \
     if ((rep_) < 8) {                                                                       \
         const int role_ = ((tid_) & 63) == 0 ? (tid_) >> 6 : -1;   /* one row per wavefront */ \
@@ -81,6 +89,7 @@ __device__ long long dhts_hyb_stamps[2][8][16][24];
 #else
 #define HYB_STAMP_DECL
 #define HYB_BARRIER(i) lds_barrier()
+#define HYB_SUB(i)
 #define HYB_STAMP_WRITE(kernel_, rep_, tid_, B_)
 #endif
 
@@ -263,7 +272,7 @@ __device__ __forceinline__ float stream_load(const float *p) {
 
 // LDS carve-up shared by both kernels' host wrappers
 struct HybLds {
-    size_t fq, scanw, incl, vsp, vep, s0, s1, g, ab, contrib, ql, sig, lanelen, vp, vv, va, vxold, hdpv, hdvv, capv, qmicro,
+    size_t fq, scanw, incl, vsp, vep, s0, s1, g, contrib, ql, sig, lanelen, vp, vv, va, vxold, hdpv, hdvv, capv, qmicro, tailsp,
         cell_lane, iface_lane, cnext, vidp, vidv, vida, vcur, vrlen, vroute, lane_n, lane_veh, hdpi, hdvi, vcp, capi, mslot,
         capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, stg_k, stg_i, stg_w, cnt_s, lfl, vx, lane_new, total;
 };
@@ -272,9 +281,9 @@ __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS, i
     auto D = [&](size_t n) { size_t r = p; p += 8 * ((n + 1) & ~(size_t)1); return r; };
     auto F = [&](size_t n) { size_t r = p; p += 4 * ((n + 3) & ~(size_t)3); return r; };
     o.fq = D(2 * (size_t)NI); o.scanw = D(32); o.incl = D(2 * (size_t)C); o.vsp = D(kMaxMicro + 1); o.vep = D(kMaxMicro + 1);
-    o.s0 = F(4 * (size_t)C); o.s1 = F(4 * (size_t)C); o.g = F(8 * (size_t)L); o.ab = F(8 * (size_t)NI); o.contrib = F(C); o.ql = F(L);
+    o.s0 = F(4 * (size_t)C); o.s1 = F(4 * (size_t)C); o.g = F(8 * (size_t)L); o.contrib = F(2 * (size_t)C); o.ql = F(L);
     o.sig = F(2 * (size_t)sq); o.lanelen = F(L); o.vp = F(V); o.vv = F(V); o.va = F(V); o.vxold = F(V);
-    o.hdpv = F(kMaxMicro); o.hdvv = F(kMaxMicro); o.capv = F(kMaxCaps); o.qmicro = F(kMaxMicro);
+    o.hdpv = F(kMaxMicro); o.hdvv = F(kMaxMicro); o.capv = F(kMaxCaps); o.qmicro = F(2 * kMaxMicro); o.tailsp = F(kMaxMicro);
     o.cnext = F(L); o.vidp = F(V); o.vidv = F(V); o.vida = F(V); o.vcur = F(V);
     o.vrlen = F(V); o.vroute = F((size_t)V * kRouteStride); o.lane_n = F(kMaxMicro); o.lane_veh = F(kMaxMicro * kLaneCap);
     o.hdpi = F(kMaxMicro); o.hdvi = F(kMaxMicro); o.vcp = F(2 * (kMaxMicro + 1)); o.capi = F(kMaxCaps); o.mslot = F(L); o.capof = F(L);
@@ -286,6 +295,10 @@ __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS, i
     o.total = p;
     return o;
 }
+
+// The hybrid kernels' Jacobian tape: per (replica, step) the two 2x2 products (A, B) of every interface slot -- [R][T][NIp][2]
+// float4, NIp = cells + lanes rounded up to 64 (interface i of the forward kernel's numbering: cells + the macro lanes in front)
+__host__ __device__ inline int hyb_tape_ifaces(int L, int C) { return (C + L + 63) & ~63; }
 
 // records a lane of the micro wave can stage per step: what the LDS has room for beside everything else (0 = does not fit)
 __host__ __device__ inline int hyb_stage_h(int L, int C, int sq, int V, int NS, int n_action) {
@@ -318,7 +331,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     extern __shared__ double lds_d[];
     char *lds = reinterpret_cast<char *>(lds_d);
     const int rep = blockIdx.x, tid = threadIdx.x, B = blockDim.x;
-    const int NI = C + L, Cp = (C + 63) & ~63;
+    const int NI = C + L, NIp = hyb_tape_ifaces(L, C);
     const HybWs ws = hyb_ws(L, C, T, tb.n_routes, records_per_step);
     const int V = ws.V;
     const int NS = tb.n_micro > kMaxCaps ? tb.n_micro : kMaxCaps;      // lanes of the micro wave that stage records
@@ -328,8 +341,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     double *incl = reinterpret_cast<double *>(lds + lo.incl), *vsp = reinterpret_cast<double *>(lds + lo.vsp), *vep = reinterpret_cast<double *>(lds + lo.vep);
 #define LF(name) reinterpret_cast<float *>(lds + lo.name)
 #define LI(name) reinterpret_cast<int *>(lds + lo.name)
-    float *S0 = LF(s0), *S1 = LF(s1), *G = LF(g), *AB = LF(ab), *contrib = LF(contrib), *ql = LF(ql), *sig = LF(sig), *lanelen = LF(lanelen);
+    float *S0 = LF(s0), *S1 = LF(s1), *G = LF(g), *contrib = LF(contrib), *ql = LF(ql), *sig = LF(sig), *lanelen = LF(lanelen);
     float *vp = LF(vp), *vv = LF(vv), *va = LF(va), *vxold = LF(vxold), *hdpv = LF(hdpv), *hdvv = LF(hdvv), *capv = LF(capv), *qmicro = LF(qmicro);
+    float *tailsp = LF(tailsp);                    // per micro lane: free space at its entrance (tail position - half a vehicle, or the
+                                                   // lane's length when it is empty) as of the last IDM step: what a capacitor's spawn test reads
     int *cell_lane_s = LI(cell_lane), *iface_lane_s = LI(iface_lane), *cnext = LI(cnext), *vidp = LI(vidp), *vidv = LI(vidv), *vida = LI(vida);
     int *vcur = LI(vcur), *vrlen = LI(vrlen), *vroute = LI(vroute), *lane_n = LI(lane_n), *lane_veh = LI(lane_veh), *hdpi = LI(hdpi), *hdvi = LI(hdvi);
     int *vcp = LI(vcp), *capi = LI(capi), *mslot = LI(mslot), *capof = LI(capof), *mlane = LI(mlane), *cbefore = LI(cbefore), *convlist = LI(convlist), *linfo = LI(linfo), *caplast = LI(caplast), *rused = LI(rused), *caplane = LI(caplane), *capleaf = LI(capleaf);
@@ -345,7 +360,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     for (int i = tid; i < n_action; i += B) act[i] = action[(size_t)rep * n_action + i];
     const size_t toff = (size_t)rep * tb.net.table_stride;
     float *hist_r = kHard ? nullptr : hist + (size_t)rep * (T + 1) * 4 * C;
-    float4 *tape_r = kHard ? nullptr : tape + (size_t)rep * T * 3 * Cp;
+    float4 *tape_r = kHard ? nullptr : tape + (size_t)rep * T * NIp * 2;
     float *kc_r = kHard ? nullptr : kc + (size_t)rep * T * C;
     float *queue_r = queue + (size_t)rep * T * L;
     char *wsr = kHard ? nullptr : workspace + (size_t)rep * ws.per_replica;
@@ -598,35 +613,69 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         src_prefetch(step + 1);                      // consumed one step later
     };
 
+    // capacitor j (lane j of the micro wave): its macro lane, that lane's last cell and the lane's (at most 4) successors with
+    // their micro slots stay in registers; the step's successor comes from the table one step ahead.  The spawn test then reads
+    // one level of LDS (the capacitor, the successor's entrance space) instead of a chain of six dependent look-ups.
+    int cap_lane = 0, cap_last = 0, cap_nid[4] = {-1, -1, -1, -1}, cap_nms[4] = {-1, -1, -1, -1};
+    int p_capnext = -1;
+    if (in_mw && mw < n_caps) {
+        cap_lane = caplane[mw]; cap_last = caplast[mw];
+        int q = 0;
+        for (int e = tb.net.nxt_ptr[cap_lane]; e < tb.net.nxt_ptr[cap_lane + 1] && q < 4; ++e, ++q) {
+            const int b = tb.net.nxt_idx[e];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i == q) { cap_nid[i] = b; cap_nms[i] = mslot[b]; }
+        }
+    }
+    auto cap_fetch = [&](int t) {                    // conv_next of step t for this capacitor's lane (every thread loads: see fetch)
+        p_capnext = tb.conv_next[toff + (size_t)(t < T ? t : T - 1) * L + cap_lane];
+    };
+    auto cap_target = [&](int m) {                   // micro slot of successor m, or -1 (not a successor / a macro lane)
+        int ms = -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (m >= 0 && cap_nid[i] == m) ms = cap_nms[i];
+        return ms;
+    };
+    if (T > 0) cap_fetch(0);
+
     float lane_total = 0.f;
     int fault_step = -1, fault_index = 0;
     // per-step table entries, fetched one step ahead
+    // Unconditional loads with clamped indices: a load inside a divergent branch merges with the register's old value, and the
+    // copy the register allocator places behind it waits for the load at once -- 2 500 cycles of memory latency per step in
+    // front of the ghosts (s_memtime stamps, round 3) instead of a load that has a whole step to arrive.
     int p_src = 0, p_gate = 0, p_cnext = -1; double p_sched = 0.;
+    const int f_glane = (is_ghost && g_macro) ? g_lane : 0, f_lane = is_lane ? tid : 0;
+    const int32_t *f_srcp = g_side == 0 ? tb.net.left_src : tb.net.right_src;
     auto fetch = [&](int t) {
-        if (t >= T) return;
-        if (is_ghost && g_macro) {
-            const size_t o = toff + (size_t)t * L + g_lane;
-            if (g_side == 0) { p_src = tb.net.left_src[o]; p_gate = tb.net.left_gate[o]; p_sched = tb.net.schedule[o]; }
-            else p_src = tb.net.right_src[o];
-        }
-        if (is_lane) p_cnext = tb.conv_next[toff + (size_t)t * L + tid];
+        const int tt = t < T ? t : (T > 0 ? T - 1 : 0);
+        const size_t o = toff + (size_t)tt * L + f_glane;
+        p_src = f_srcp[o]; p_gate = tb.net.left_gate[o]; p_sched = tb.net.schedule[o];
+        p_cnext = tb.conv_next[toff + (size_t)tt * L + f_lane];
     };
-    fetch(0);
+    if (T > 0) fetch(0);
 
     // ---- the loss of the state produced by step t-1 is evaluated inside the phases of step t (its prefix scan beside the
     //      ghosts, its constants and the vehicles' terms beside the interface solves, its lane sums beside the cell updates);
     //      the records of step t-1 are flushed beside the ghosts of step t
-    float x_new = 0.f;
+    float x_new = 0.f, x_left = 0.f;
+    long long x_idx = 0;
+    // the sample that leaves the running mean's window when this cell's next one enters: requested at the top of the phase
+    // (every thread, clamped index: see fetch), used behind the ghosts
+    auto loss_prefetch = [&](int ls) {
+        if (kHard) return;
+        x_idx = run_cnt + (is_cell ? tid + vcp_of(ls)[c_mb] : 0);
+        x_left = stream_load(xs + (x_idx >= kWindow ? x_idx - kWindow : 0));
+    };
     auto loss_scan = [&](const float *st, int ls) {
         if (kHard) return;                            // (no running mean in an evaluation episode)
-        const int *vcp_l = vcp_of(ls);
         if ((tid & ~63) < C) {                        // waves without cells (the micro wave) have nothing to add
             double a = 0., b = 0.;
             if (is_cell) {
                 x_new = s0f - st[2 * C + tid];
-                const long long idx = run_cnt + tid + vcp_l[c_mb];
+                const long long idx = x_idx;
                 a = (double)x_new;
-                if (idx >= kWindow) b = (double)stream_load(xs + (idx - kWindow));
+                if (idx >= kWindow) b = (double)x_left;
                 xs[idx] = x_new;
             }
             const double ia = wave_scan_add(a), ib = wave_scan_add(b);
@@ -636,8 +685,9 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     };
     double tot_a = 0., tot_b = 0.;
     auto loss_consts = [&](const float *st, int ls) {
+        float *contrib_w = contrib + (ls & 1) * C;      // (two buffers: the lane sums of loss ls are taken one step later)
         if (kHard) {
-            if (is_cell) contrib[tid] = (st[2 * C + tid] < s0f ? 1.f : 0.f) * (st[tid] * c_dxv);
+            if (is_cell) contrib_w[tid] = (st[2 * C + tid] < s0f ? 1.f : 0.f) * (st[tid] * c_dxv);
             return;
         }
         const int *vcp_l = vcp_of(ls);
@@ -655,7 +705,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 const double mean = (full ? pin - pout : pin) / (full ? (double)kWindow : (double)n);
                 const float kk = 16.f / fabsf((float)mean);
                 kc_r[(size_t)ls * C + tid] = kk;
-                contrib[tid] = soft_switch(x_new, kk) * (st[tid] * c_dxv);
+                contrib_w[tid] = soft_switch(x_new, kk) * (st[tid] * c_dxv);
                 float *hn = hist_r + (size_t)(ls + 1) * 4 * C;
                 hn[tid] = st[tid]; hn[C + tid] = st[C + tid]; hn[2 * C + tid] = st[2 * C + tid]; hn[3 * C + tid] = st[3 * C + tid];
             }
@@ -667,14 +717,15 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         if (is_fw) {
             const int k = fl;
             if (k < n_micro) {
-                qmicro[k] = 0.f;
+                float *qm = qmicro + (ls & 1) * kMaxMicro;      // (two buffers: the lane sums of loss ls are taken a step later,
+                qm[k] = 0.f;                                    //  beside the vehicles' terms of loss ls + 1)
                 const int nw = lane_new[k];
                 const int nv = lane_n[k] - nw;
                 const int *lv = lane_veh + k * kLaneCap + nw;
                 if (kHard) {
                     float q = 0.f;
                     for (int i = 0; i < nv; ++i) q = q + vx[lv[i]];
-                    qmicro[k] = (q * q) * dtf;
+                    qm[k] = (q * q) * dtf;
                 } else if (nv > 0) {
                     const int cb = cbefore[k];
                     double pa = run_in + vsp[k], pb = run_out + vep[k];
@@ -700,7 +751,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                         dsg[i] = (z < -16.f || z > 16.f) ? 0.f : sgm * (1.f - sgm) * kk;
                         q = q + sgm;
                     }
-                    qmicro[k] = (q * q) * dtf;
+                    qm[k] = (q * q) * dtf;
                     if (ls < loss_steps) {
                         const float gq = -1.0f * dtf * 2.f * q;
                         const int b = blk & 1;
@@ -729,9 +780,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             float term;
             if (l_macro) {
                 float q = 0.f;
-                for (int i = 0; i < l_n; ++i) q = q + contrib[l_off + i];
+                const float *contrib_r = contrib + (ls & 1) * C;
+                for (int i = 0; i < l_n; ++i) q = q + contrib_r[l_off + i];
                 term = (q * q) * dtf;
-            } else term = l_ms >= 0 ? qmicro[l_ms] : 0.f;
+            } else term = l_ms >= 0 ? qmicro[(ls & 1) * kMaxMicro + l_ms] : 0.f;
             queue_r[(size_t)ls * L + tid] = term;
             lane_total = lane_total + (-1.0f) * term;
         }
@@ -745,7 +797,11 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         // ================= A: ghosts | loss scan of the state after step t-1 | record flush of step t-1, head gaps =========
         const int src = p_src, gate = p_gate; const double sched = p_sched;
         if (is_lane) cnext[tid] = p_cnext;
+        const int capnext_t = p_capnext;             // (micro wave: the capacitor lane's successor of this step)
         fetch(t + 1);
+        cap_fetch(t + 1);
+        if (t > 0) loss_prefetch(t - 1);
+        if (!in_mw) HYB_SUB(0)                       // A, cell waves: this step's table entries taken, the next step's requested
         if (is_ghost && g_macro) {
             float fr, fu, fy, fq;
             if (g_side == 0) {
@@ -776,8 +832,9 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             float *g = G + (size_t)(2 * g_lane + g_side) * 4;
             g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
         }
+        if (!in_mw) HYB_SUB(1)                       // A, cell waves: ghosts
         if (t > 0) loss_scan(cur, t - 1);
-        if (t > 1) loss_lanes(t - 2);               // its constants were evaluated beside the hand-offs of the last step
+        if (!in_mw) HYB_SUB(2)                       // A: loss scan
         if (is_fw && t > 0) vehicle_samples(t - 1);
         if (in_mw) {
             {   // head gaps of the occupied micro lanes (they only feed the IDM steps below)
@@ -887,13 +944,19 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             arz_interface(rL, yL, uL, qL, rR, yR, uR, qR, kconst, f);
             if (f.cfl_bad && fault_step < 0) { fault_step = t; fault_index = i_k; }
             Fq[2 * tid] = f.Fr; Fq[2 * tid + 1] = f.Fy;
-            float *ab = AB + (size_t)tid * 8;
-            ab[0] = f.A[0]; ab[1] = f.A[1]; ab[2] = f.A[2]; ab[3] = f.A[3];
-            ab[4] = f.B[0]; ab[5] = f.B[1]; ab[6] = f.B[2]; ab[7] = f.B[3];
+            // the interface's two 2x2 products go straight to the tape; the reverse sweep forms the cell blocks from them
+            // (dmacro_lane.py:126-129) in a phase where its cell threads wait for the micro wave
+            if (!kHard) {
+                float4 *tp = tape_r + ((size_t)t * NIp + tid) * 2;
+                tp[0] = make_float4(f.A[0], f.A[1], f.A[2], f.A[3]);
+                tp[1] = make_float4(f.B[0], f.B[1], f.B[2], f.B[3]);
+            }
         }
+        if (!in_mw) HYB_SUB(3)                       // B, cell waves: interface solves
         if (t > 0) micro_loss(t - 1, t - 1);
         if (in_mw) {
             const int k = mw;
+            float tail_space = k < n_micro ? lanelen[mlane[k]] : 0.f;
             if (k < n_micro && lane_n[k] > 0) {
                 const int nv = lane_n[k];
                 Tv hd_p = tv_var(hdpv[k], hdpi[k]);
@@ -916,8 +979,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                         rec_push(rec, K_IDM, 3 * vi, make_int4(3 * vj, 3 * vj + 1, 0, 0), make_float4(o.dE[2], o.dE[3], o.dLd[2], o.dLd[3]));
                     }
                     vp[vi] = o.np; vv[vi] = o.nv;
+                    if (i == 0) tail_space = o.np - 0.5f * vlen;
                 }
             }
+            if (k < n_micro) tailsp[k] = tail_space;
             seg_a = rec.cnt;
         }
         HYB_BARRIER(1);
@@ -947,52 +1012,36 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         HYB_BARRIER(2);
         // ================= D: flux capacitors, hand-off events in lane-id order, commits (micro wave) | loss constants of
         //                    the state after step t-1 + its history row (the cells have nothing else to do here) =========
-        if (is_cell && !kHard) {
-            // the cell's tape blocks from the interface products of phase B (dmacro_lane.py:126-129): the cells have slack in
-            // this phase (the micro wave's hand-offs are its critical path), none in the last one
-            const int c = tid;
-            const float cf = (float)c_cc, ncf = (float)(-c_cc);
-            const int iL = c + c_macb, iR = iL + 1;
-            const float *aL = AB + (size_t)iL * 8, *aR = AB + (size_t)iR * 8;
-            float4 d0, d1, d2;
-            d0.x = ncf * (-aL[0]); d0.y = ncf * (-aL[1]); d0.z = ncf * (-aL[2]); d0.w = ncf * (-aL[3]);
-            d2.x = ncf * aR[4]; d2.y = ncf * aR[5]; d2.z = ncf * aR[6]; d2.w = ncf * aR[7];
-            d1.x = 1.f - cf * (aR[0] - aL[4]); d1.y = 0.f - cf * (aR[1] - aL[5]);
-            d1.z = 0.f - cf * (aR[2] - aL[6]); d1.w = 1.f - cf * (aR[3] - aL[7]);
-            float4 *tp = tape_r + (size_t)t * 3 * Cp;
-            tp[c] = d0; tp[Cp + c] = d1; tp[2 * Cp + c] = d2;
-        }
         if (t > 0 && !in_mw) { loss_consts(cur, t - 1); run_update(t - 1); }      // (the micro wave keeps no running sums)
+        // lane sums of the loss of the state step t - 2 left (its constants: this phase of step t - 1, the other contrib buffer;
+        // its vehicles' terms: phase B of step t - 1): the lanes' threads would only wait for the hand-offs here
+        if (t > 1) loss_lanes(t - 2);
         if (is_fw && t > 0) flush_block(t - 1);          // the last step's records, with the seeds appended two phases ago
         if (in_mw) {
             if (has_src && mw < n_micro) lane_new[mw] = 0;       // the loss of the last state has been evaluated (phases A, B)
             // capacitors: += r u dt of the last cell (conversion.py:32-36); the spawn itself is an event below
+            const int cap_ms = cap_target(capnext_t);  // this step's successor of the capacitor's lane, if it is a micro lane
+            float cap_level = 0.f;
             if (mw < n_caps) {
-                const int j = mw, l = caplane[j];
-                const int m = cnext[l];
-                if (m >= 0 && mslot[m] >= 0) {
-                    const int last = caplast[j];
+                const int j = mw;
+                cap_level = capv[j];
+                if (cap_ms >= 0) {
+                    const int last = cap_last;
                     // one compound record, in place on the capacitor's slot: cap += (r u) dt with (r, u) read from the cell
                     // (the reads of r, u, their product and the sum are one record instead of three); the leaf stands for
                     // u: a vehicle spawned in this step takes it as its speed
                     const float r_ = nxt[last], u_ = nxt[2 * C + last];
                     const int leaf = rec.next_local++;
                     rec_push(rec, K_CAP, 3 * V + j, make_int4(last, leaf, capi[j], 0), make_float4(dtf, u_, r_, 0.f));
-                    capv[j] = capv[j] + (r_ * u_) * dtf; capi[j] = 3 * V + j;
+                    cap_level = cap_level + (r_ * u_) * dtf;
+                    capv[j] = cap_level; capi[j] = 3 * V + j;
                     capleaf[j] = leaf;
                 }
             }
+            HYB_SUB(0)                               // D, micro wave: capacitors
             // is there any event at all this step?  (the common case is none)
             bool ev = false;
-            if (mw < n_caps) {
-                const int j = mw, m = cnext[caplane[j]];
-                if (m >= 0 && mslot[m] >= 0) {
-                    const int ms = mslot[m];
-                    float space = lanelen[m];
-                    if (lane_n[ms]) space = vp[lane_veh[ms * kLaneCap + 0]] - 0.5f * vlen;
-                    ev = capv[j] >= vlen && space >= vlen * 1.0f;
-                }
-            }
+            if (mw < n_caps && cap_ms >= 0) ev = cap_level >= vlen && tailsp[cap_ms] >= vlen * 1.0f;
             ev = ev || ev_head;
             const bool any_ev = __any(ev);
             if (any_ev && is_mt) {
@@ -1082,6 +1131,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 if (rec.next_local - (base_local + 64 * kLaneLocals) > kEventLocals) cap_fault = true;
                 rec.next_local = keep_local;
             }
+            HYB_SUB(1)                               // D, micro wave: event pre-screen (+ the rare serial walk)
             // commit temporaries into the persistent slots (vehicles by their lane, capacitors by theirs); only hand-off events
             // leave values in temporaries
             const int k = mw;
@@ -1098,6 +1148,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             }
             if (rec.next_local - (base_local + mw * kLaneLocals) > kLaneLocals) cap_fault = true;
             seg_b = rec.cnt;
+            HYB_SUB(2)                               // D, micro wave: commits
             // vehicle counts in front of every micro lane (lane id order): the cells need them for their stream positions in
             // the next phase; the vehicles' samples themselves are taken there by the flush wave
             {
@@ -1120,6 +1171,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     if (T > 0) {
         const float *fin = (T & 1) ? S1 : S0;
         if (T > 1) loss_lanes(T - 2);
+        loss_prefetch(T - 1);
         loss_scan(fin, T - 1);
         if (is_fw) vehicle_samples(T - 1);
         __syncthreads();
@@ -1188,7 +1240,6 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     extern __shared__ double lds_d[];
     char *lds = reinterpret_cast<char *>(lds_d);
     const int rep = blockIdx.x, tid = threadIdx.x, B = blockDim.x;
-    const int Cp = (C + 63) & ~63;
     const int E = tb.net.n_edges > 0 ? tb.net.n_edges : 1;
     const HybWs ws = hyb_ws(L, C, T, tb.n_routes, records_per_step);
     const int V = ws.V;
@@ -1207,7 +1258,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     for (int i = tid; i < n_action; i += B) act[i] = action[(size_t)rep * n_action + i];
     const size_t toff = (size_t)rep * tb.net.table_stride;
     const float *hist_r = hist + (size_t)rep * (T + 1) * 4 * C;
-    const float4 *tape_r = tape + (size_t)rep * T * 3 * Cp;
+    const int NIp = hyb_tape_ifaces(L, C);
+    const float4 *tape_r = tape + (size_t)rep * T * NIp * 2;
     const float *kc_r = kc + (size_t)rep * T * C;
     const float *queue_r = queue + (size_t)rep * T * L;
     const char *wsr = workspace + (size_t)rep * ws.per_replica;
@@ -1247,11 +1299,15 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     if (tid < sq) gam[tid] = 0.f;
     if (is_cell) { gL[tid] = 0.f; gL[C + tid] = 0.f; gL[2 * C + tid] = 0.f; }
     __syncthreads();
-    int c_lane = 0, c_first = 0, c_last = 0; float c_dxv = 0.f;
+    int c_lane = 0, c_first = 0, c_last = 0, c_macb = 0; float c_dxv = 0.f, c_cf = 0.f, c_ncf = 0.f;
     if (is_cell) {
         c_lane = cell_lane_s[tid]; c_first = tb.net.lane_off[c_lane]; c_last = c_first + tb.net.lane_ncell[c_lane] - 1;
         c_dxv = (float)tb.net.lane_dx[c_lane] / vlen;
+        const double cc = dt / tb.net.lane_dx[c_lane];        // update_coefficient, _macro_lane.py:99
+        c_cf = (float)cc; c_ncf = (float)(-cc);
+        for (int l = 0; l < c_lane; ++l) if (tb.lane_macro[l]) ++c_macb;      // the cell's left interface is slot cell + (macro lanes in front)
     }
+    const int f_iL = is_cell ? tid + c_macb : 0;
     const int g_side = tid >= g_base1 ? 1 : 0, g_lane = is_ghost ? (g_side ? tid - g_base1 : tid) : 0;
     int g_kind = 0, g_inter = 0, g_off = 0, g_n = 0; bool g_macro = false;
     if (is_ghost) {
@@ -1321,7 +1377,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     // ---- data of step t, fetched one iteration ahead
     constexpr int kPre = 3;              // records per lane of the micro wave held in registers (192 per step; more are loaded late)
     float p_hr = 0.f, p_hy = 0.f, p_hu = 0.f, p_kc = 0.f, p_q = 0.f, p_own_r = 0.f, p_own_u = 0.f;
-    float4 p_d0 = make_float4(0, 0, 0, 0), p_d1 = p_d0, p_d2 = p_d0;
+    float4 p_aL = make_float4(0, 0, 0, 0), p_bL = p_aL, p_aR = p_aL, p_bR = p_aL;
     int p_src = 0, p_gate = 0, p_rlo = 0, p_nrec = 0, p_seg[kPhases], p_rk[kPre];
     int4 p_ri[kPre]; float4 p_rw[kPre];
 #pragma unroll
@@ -1345,8 +1401,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             const float *h = hist_r + (size_t)tt * 4 * C;
             p_hr = h[f_cell]; p_hy = h[C + f_cell]; p_hu = h[2 * C + f_cell];
             p_kc = kc_r[(size_t)tt * C + f_cell];
-            const float4 *tp = tape_r + (size_t)tt * 3 * Cp;
-            p_d0 = tp[f_cell]; p_d1 = tp[Cp + f_cell]; p_d2 = tp[2 * Cp + f_cell];
+            const float4 *tp = tape_r + ((size_t)tt * NIp + f_iL) * 2;      // interfaces iL and iL + 1 of the cell: 64 contiguous bytes
+            p_aL = tp[0]; p_bL = tp[1]; p_aR = tp[2]; p_bR = tp[3];
         }
         p_q = queue_r[(size_t)tt * L + (is_cell ? c_lane : f_lane)];      // cells: the queue term of their own lane
         {
@@ -1388,7 +1444,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         float *Hc = (t & 1) ? H1 : H0;           // row t
         const float *Hn = (t & 1) ? H0 : H1;     // row t+1
         // ================= R0: this step's data (fetched during the previous iteration) =================
-        const float w_kc = p_kc; const float4 d0 = p_d0, d1 = p_d1, d2 = p_d2;
+        const float w_kc = p_kc; const float4 aL = p_aL, bL = p_bL, aR = p_aR, bR = p_bR;
         const int src = p_src, gate = p_gate; const float w_own_r = p_own_r, w_own_u = p_own_u;
         if (is_cell) { Hc[tid] = p_hr; Hc[C + tid] = p_hy; Hc[2 * C + tid] = p_hu; }
         // loss taps on the state after step t (row t + 1 is in LDS since the previous iteration): d reward / d q_l = -2 q_l dt
@@ -1554,6 +1610,12 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             const int c = tid;
             float gr = gL[c], gy = gL[C + c];
             glue_u_bwd(Hn[c], Hn[C + c], um, gL[2 * C + c], gr, gy);
+            // the cell's blocks from the interface products, exactly as the reference forms them (dmacro_lane.py:126-129)
+            float4 d0, d1, d2;
+            d0.x = c_ncf * (-aL.x); d0.y = c_ncf * (-aL.y); d0.z = c_ncf * (-aL.z); d0.w = c_ncf * (-aL.w);
+            d2.x = c_ncf * bR.x; d2.y = c_ncf * bR.y; d2.z = c_ncf * bR.z; d2.w = c_ncf * bR.w;
+            d1.x = 1.f - c_cf * (aR.x - bL.x); d1.y = 0.f - c_cf * (aR.y - bL.y);
+            d1.z = 0.f - c_cf * (aR.z - bL.z); d1.w = 1.f - c_cf * (aR.w - bL.w);
             c0[c] = dot2(d0.x, gr, d0.z, gy); c0[C + c] = dot2(d0.y, gr, d0.w, gy);
             c2[c] = dot2(d2.x, gr, d2.z, gy); c2[C + c] = dot2(d2.y, gr, d2.w, gy);
             v_r = dot2(d1.x, gr, d1.z, gy); v_y = dot2(d1.y, gr, d1.w, gy);
@@ -1693,6 +1755,10 @@ extern "C" int dhts_debug_stamps(long long *out) {       // [2 kernels][8 replic
 
 extern "C" {
 
+size_t dhts_net_hybrid_tape_bytes(const dhts_net_desc *d) {
+    if (!hyb_desc_ok(d)) return 0;
+    return sizeof(float4) * 2 * (size_t)d->n_replicas * d->n_steps * hyb_tape_ifaces(d->n_lanes, d->n_cells);
+}
 size_t dhts_net_hybrid_workspace_bytes(const dhts_net_desc *d, const dhts_hybrid_tables *t) {
     if (!hyb_desc_ok(d) || !t || t->n_routes <= 0) return 0;
     return hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step).per_replica * (size_t)d->n_replicas;

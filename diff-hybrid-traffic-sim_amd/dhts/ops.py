@@ -601,7 +601,7 @@ class NetHybridRollout(torch.autograd.Function):
         Cp = (t.n_cells + 63) // 64 * 64
         # (an all-micro network has no cells: the kernels' unconditional prefetches still want something to read)
         hist = torch.empty(max(R * (t.T + 1) * 4 * t.n_cells, 64), dtype=torch.float32, device=dev)
-        tape = torch.empty(max(R * t.T * 3 * Cp * 4, 64), dtype=torch.float32, device=dev)
+        tape = torch.empty(max(lib.dhts_net_hybrid_tape_bytes(C.byref(d)) // 4, 64), dtype=torch.float32, device=dev)
         kc = torch.empty(max(R * t.T * t.n_cells, 64), dtype=torch.float32, device=dev)
         queue = torch.empty(R, t.T, t.n_lanes, dtype=torch.float32, device=dev)
         reward = torch.empty(R, dtype=torch.float32, device=dev)

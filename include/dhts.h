@@ -348,7 +348,13 @@ typedef struct dhts_hybrid_tables {
     int64_t draws_stride;
 } dhts_hybrid_tables;
 size_t dhts_net_hybrid_workspace_bytes(const dhts_net_desc *d, const dhts_hybrid_tables *t);
-/* hist / tape / kc / queue / reward as in the macro rollout (kc, tape rows of micro lanes do not exist: they have no cells);
+/* bytes of the hybrid kernels' Jacobian tape: float32 [R][T][NIp][2][4], NIp = n_cells + n_lanes rounded up to 64: per interface
+ * slot (a lane's n + 1 interfaces, lanes in id order, micro lanes own none) the two 2x2 products A = flux'(Q_0) dQ_0/dQ_L and
+ * B = flux'(Q_0) dQ_0/dQ_R of dMacroLane._backward (dmacro_lane.py:116-124); the reverse sweep forms the cell blocks
+ * dqs[a][0..2] (:126-129) from them.  (The macro-network kernels keep the blocks themselves: dhts_net_macro_tape_bytes.) */
+size_t dhts_net_hybrid_tape_bytes(const dhts_net_desc *d);
+/* hist / kc / queue / reward as in the macro rollout (kc rows of micro lanes do not exist: they have no cells); tape:
+ * dhts_net_hybrid_tape_bytes;
  * counts [R][4] int32 = (vehicles spawned, vehicles deposited, records written, 0) */
 int dhts_net_hybrid_rollout_fwd(const dhts_net_desc *d, const dhts_hybrid_tables *t, const float *action, float *hist,
                                 float *tape, float *kc, float *queue, float *reward, int32_t *counts, void *workspace,

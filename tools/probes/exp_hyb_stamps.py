@@ -41,3 +41,5 @@ for kern, name, nb in ((0, "forward", 4), (1, "reverse", 5)):
         nm = "wave %d%s" % (wave, " (flush)" if wave == 6 else (" (micro)" if wave == 7 else ""))
         print("  %-14s work %s   drain %s   barrier %s   total %d" % (nm, np.round(m[wave, :nb]).astype(int), np.round(m[wave, 8:8 + nb]).astype(int),
                                                                        np.round(m[wave, 16:16 + nb]).astype(int), int(m[wave].sum())))
+        if kern == 0 and m[wave, 4:8].any():      # sub-phase stamps (HYB_SUB): cell waves = table fetch, ghosts, loss scan (phase A), interface
+            print("  %-14s   sub %s" % ("", np.round(m[wave, 4:8]).astype(int)))     # solves (B); micro wave = capacitors, pre-screen, commits (D)
