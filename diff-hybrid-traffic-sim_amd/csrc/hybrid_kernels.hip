@@ -316,6 +316,17 @@ __host__ __device__ inline int hyb_stage_h(int L, int C, int sq, int V, int NS, 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------------
+// Four barriers per step (phases A: ghosts | head gaps, B: interface solves | IDM steps, C: cell updates, D: hand-offs | loss
+// constants).  Where a step goes (s_memtime stamps, -DDHTS_HYB_STAMPS build, 256 replicas of BASELINE config 4;
+// profiles/r03l_hybrid_phase_stamps.log): every phase is set by its slowest role -- the micro wave in A (head gaps, ~4 400 cycles)
+// and B (IDM steps, ~3 100), the lanes' cell waves in D (loss constants + lane sums, ~4 000-4 500) -- and a step by their sum,
+// ~14 700 cycles.  Round 3 took out what was not arithmetic on those paths: the cells' tape blocks (now formed by the reverse
+// sweep from an interface tape the interface threads write), the capacitors' chains of dependent LDS look-ups (static ones in
+// registers, one entrance-space word per micro lane), table fetches inside divergent branches: 4.02 -> 3.68 ms.  Measured and
+// dropped: phases B and C merged with a DPP hand-off of the right flux, (a) 63 slots per wavefront + a helper thread: config 4's
+// 384 slots then need a seventh wavefront, the one that also evaluates the vehicles' loss terms (3.97 ms); (b) 64 slots per
+// wavefront, the one seam cell per wavefront updated by the micro wave at the start of D (3.68 ms: the barrier's time comes
+// back as the longer phases of the roles that were already last; profiles/r03n_hybrid_seam_variant_stamps.log).
 // kHard: an EVALUATION episode (ItscpEnv.step(action, False); Trainer.evaluate, trainer.py:94-142): hard signals float(a > progress)
 // (_env.py:928-960), the macro downstream ghost takes float(signal > 0.5) (_simulator.py:128-137), a head vehicle takes the green
 // gap when the signal of its own lane is >= 0.5 and the red one otherwise (scores 0 / 1 / 0, no running mean: _simulator.py:208-
