@@ -96,6 +96,31 @@ class RoadNetwork:
         else:
             self.setup_micro_boundary(id, differentiable)
 
+    def get_macro_state_of_micro_lane(self, id, differentiable):
+        """(density, speed) a micro lane would have as a macro cell (reference road_network.py:207-297): every vehicle on the
+        lane, every vehicle on an upstream micro lane that is routed onto it (at minus its distance to that lane's end) and
+        every vehicle on a downstream micro lane that came through it (at the lane's length plus its position) counts with
+        the weight lane.on_this_lane(position) -- a product of two sigmoids when differentiable, a 0 / 1 test otherwise;
+        density = sum of weight x length / lane length, capped at 1; speed = weighted mean, or the speed limit when the
+        weights sum to nothing."""
+        lane = self.lane[id]
+        assert lane.is_micro(), ""
+        seen = [(v, v.position) for v in lane.curr_vehicle]
+        for up in lane.prev_lane.values():
+            if not up.is_macro():
+                seen += [(v, -(up.length - v.position)) for v in up.curr_vehicle if self.micro_route[v.id].next_lane_id() == id]
+        for down in lane.next_lane.values():
+            if not down.is_macro():
+                seen += [(v, lane.length + v.position) for v in down.curr_vehicle if self.micro_route[v.id].prev_lane_id() == id]
+        density, speed_sum, weight_sum = 0, 0, 0
+        for v, position in seen:
+            w = lane.on_this_lane(position, differentiable)
+            density = density + w * (v.length / lane.length)
+            speed_sum = speed_sum + w * v.speed
+            weight_sum = weight_sum + w
+        density = min(density, 1.0)
+        return density, (speed_sum / weight_sum if weight_sum > 0 else self.speed_limit)
+
     # ---- macro boundary ------------------------------------------------------------------------------------------
     def get_macro_boundary(self, id, left, differentiable):
         """Ghost (r, u) at one end: the connected macro lane's edge cell (the single neighbour, or this step's

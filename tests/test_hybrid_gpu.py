@@ -367,3 +367,37 @@ def test_hybrid_networks_with_more_micro_lanes(cuda, golden_dir, name):
     for t0, ref in zip(g["g_action_cut_steps"], g["g_action_cut"]):
         oc = _run(cuda, g, loss_steps=int(t0))
         assert np.abs(oc["grad"][0] - ref).max() <= TOL_GRAD * np.abs(g["g_action"]).max(), int(t0)
+
+
+def test_micro_sources_exhausted_waiting_list_and_draws(cuda, oracle, golden_dir):
+    """Micro source lanes at their limits: (a) a waiting list of two vehicles per lane -- an exhausted list admits nobody although
+    its draws are still consumed (_simulator.py:159-174: the draw is made before the list is looked at) -- kernels = oracle;
+    (b) a draw stream that is too short is a capacity fault, not a silent wrap-around."""
+    import torch
+    from dhts import ops
+    from dhts.network import group_routes
+    g = np.load(os.path.join(golden_dir, "itscp_micro_small.npz"))
+    t, m, rows = itscp_micro_tables(g)
+    args = (m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"],
+            m["speed_limit"], m["static_speed"], m["vehicle_length"])
+    rng = np.random.default_rng(8)
+    keep, seen = [], {}
+    for r in rows:                       # the first two waiting routes of every lane
+        seen[int(r[0])] = seen.get(int(r[0]), 0) + 1
+        if seen[int(r[0])] <= 2:
+            keep.append(r)
+    keep = np.asarray(keep, dtype=np.int32)
+    t.set_micro_sources(np.concatenate([g["rand_draws"] * 0.25, rng.random(4000) * 0.25]))      # low draws: every lane wants more than two
+    act = g["action"][None].copy()
+    a = torch.tensor(act, device=cuda, requires_grad=True)
+    cut, reward, queue, counts = ops.net_hybrid_rollout(a, ops.DeviceHybridTables(t, keep, cuda), *args)
+    cut.sum().backward()
+    routes, route_ptr = group_routes(keep, t.n_lanes)
+    o = oracle.net_hybrid(t, routes, route_ptr, act[0], *args)
+    n_src = int(t.lane_source.sum())
+    assert o["rc"] == 0 and int(counts[0, 0]) == o["n_spawned"] == 2 * n_src
+    assert rel_max(queue[0].detach().cpu().numpy(), o["queue"]) <= 1e-4
+    assert rel_max(a.grad[0].cpu().numpy(), o["g_action"]) <= TOL_GRAD
+    t.set_micro_sources(g["rand_draws"][:5])
+    with pytest.raises(RuntimeError, match="capacity"):
+        ops.net_hybrid_eval(a.detach(), ops.DeviceHybridTables(t, rows, cuda), *args)

@@ -279,3 +279,33 @@ def test_hybrid_three_lane_network_like_example(cuda, golden_dir):
     assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
     assert rel_max(r0.grad.cpu().numpy(), g["g_r0"]) <= TOL_GRAD
     assert rel_max(u0.grad.cpu().numpy(), g["g_u0"]) <= TOL_GRAD
+
+
+def test_macro_state_of_micro_lane_like_reference(cuda, golden_dir):
+    """RoadNetwork.get_macro_state_of_micro_lane (reference road_network.py:207-297) on micro -> micro -> micro chains:
+    vehicles on the lane, on the upstream lane routed onto it and on the downstream lane that came through it, soft
+    (sigmoid) and hard weights, against the reference's own values."""
+    import json
+    from road.lane._micro_lane import MicroLane
+    from road.network.road_network import RoadNetwork
+    from road.network.route import MicroRoute
+    from road.vehicle.micro_vehicle import MicroVehicle
+    g = load(golden_dir, "macro_state_of_micro_lane.npz")
+    for case in json.loads(str(g["cases"])):
+        sl = 30.0
+        net = RoadNetwork(sl)
+        for i, ln in enumerate(case["lengths"]):
+            net.add_lane(MicroLane(i, ln, sl))
+        net.connect_lane(0, 1)
+        net.connect_lane(1, 2)
+        for lane_id, pos, spd, route, idx in case["vehicles"]:
+            mv = MicroVehicle.default_micro_vehicle(sl)
+            mv.position, mv.speed = pos, spd
+            r = MicroRoute(list(route))
+            for _ in range(idx):
+                r.increment_curr_idx()
+            net.add_vehicle(mv, r)
+        for flag, key in ((True, "soft"), (False, "hard")):
+            d, s = net.get_macro_state_of_micro_lane(1, flag)
+            assert abs(float(d) - case[key][0]) <= 1e-6 * max(1.0, abs(case[key][0])), (key, float(d), case[key])
+            assert abs(float(s) - case[key][1]) <= 1e-5 * max(1.0, abs(case[key][1])), (key, float(s), case[key])

@@ -772,6 +772,50 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
                   ref_seconds_fwd=t1 - t0, ref_seconds_bwd=t2 - t1))
 
 
+# ----------------------------------------------------------------------------------------------
+# G9: RoadNetwork.get_macro_state_of_micro_lane (road_network.py:207-297) on a micro -> micro -> micro chain
+# ----------------------------------------------------------------------------------------------
+def gen_macro_state_of_micro_lane(seed=3):
+    from road.lane._micro_lane import MicroLane
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(6):
+        sl = 30.0
+        lengths = [float(x) for x in rng.uniform(20.0, 60.0, 3)]
+        net = RoadNetwork(sl)
+        for i in range(3):
+            net.add_lane(MicroLane(i, lengths[i], sl))
+        net.connect_lane(0, 1)
+        net.connect_lane(1, 2)
+        veh = []          # (lane, position, speed, route, route index)
+        for lane_id, route, idx in ((0, [0, 1, 2], 0), (0, [0], 0), (1, [0, 1, 2], 1), (1, [1], 0), (2, [0, 1, 2], 2), (2, [2], 0)):
+            pos_hi = lengths[lane_id]
+            # one vehicle near the lane's far end (close to lane 1 for lane 0), one near its start (close to lane 1 for lane 2)
+            pos = float(rng.uniform(0.8, 1.0) * pos_hi) if lane_id == 0 else float(rng.uniform(0.0, 0.2) * pos_hi) if lane_id == 2 \
+                else float(rng.uniform(0.1, 0.9) * pos_hi)
+            veh.append((lane_id, pos, float(rng.uniform(0.0, sl)), route, idx))
+        veh.sort(key=lambda x: (x[0], x[1]))
+        placed = []
+        for lane_id, pos, spd, route, idx in veh:
+            if any(l == lane_id and abs(p - pos) < 6.0 for l, p, *_ in placed):
+                continue
+            mv = MicroVehicle.default_micro_vehicle(sl)
+            mv.position, mv.speed = pos, spd
+            r = MicroRoute(route)
+            for _k in range(idx):
+                r.increment_curr_idx()
+            net.add_vehicle(mv, r)
+            placed.append((lane_id, pos, spd, route, idx))
+        out = {}
+        for flag in (True, False):
+            d, s = net.get_macro_state_of_micro_lane(1, flag)
+            out[flag] = (float(d), float(s))
+        cases.append(dict(lengths=lengths, vehicles=placed, soft=out[True], hard=out[False]))
+    np.savez_compressed(os.path.join(OUT, "macro_state_of_micro_lane.npz"), cases=np.array(json.dumps(cases)),
+                        meta=meta(seed=seed, speed_limit=30.0))
+    print("G9: %d cases, e.g. soft %s hard %s" % (len(cases), cases[0]["soft"], cases[0]["hard"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="G1,G3,G4,G5,G6")
@@ -795,6 +839,8 @@ def main():
         gen_micro_rollouts(set(args.g6.split(",")))
     if "G7" in only:
         gen_hybrid()
+    if "G9" in only:
+        gen_macro_state_of_micro_lane()
     if "G8" in only:                 # run_itscp_macro.sh / run_itscp_hybrid.sh flag sets (+ a small macro case)
         which = set(args.g8.split(","))
         if "macro_small" in which:
