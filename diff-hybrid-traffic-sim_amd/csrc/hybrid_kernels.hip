@@ -93,7 +93,8 @@ __device__ long long dhts_hyb_stamps[2][8][16][24];
 #define HYB_STAMP_WRITE(kernel_, rep_, tid_, B_)
 #endif
 
-enum { K_NODE = 1, K_COMMIT = 2, K_DEPOSIT = 3, K_CELLREAD = 4, K_SIGNAL = 5, K_SEED = 6, K_IMPORT = 7, K_IDM = 8, K_CAP = 9 };
+enum { K_NODE = 1, K_COMMIT = 2, K_DEPOSIT = 3, K_CELLREAD = 4, K_SIGNAL = 5, K_SEED = 6, K_IMPORT = 7, K_IDM = 8 };
+// (until round 3 a ninth kind carried the capacitors' per-step charge; it is applied without a record now: HybWs::capru / capflag)
 
 struct HybTables {
     NetTables net;
@@ -104,7 +105,7 @@ struct HybTables {
 
 // workspace layout of one replica (bytes, all 16-byte aligned)
 struct HybWs {
-    size_t own_hist, rec_k, rec_i, rec_w, step_off, seg_cnt, xs, per_replica;
+    size_t own_hist, rec_k, rec_i, rec_w, step_off, seg_cnt, xs, capru, capflag, per_replica;
     int rec_cap, V;
 };
 __host__ __device__ inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -121,6 +122,8 @@ __host__ __device__ inline HybWs hyb_ws(int L, int C, int T, int n_routes, int r
     w.step_off = o; o += up16(sizeof(int) * (size_t)(T + 2));                               // blocks 0..T (+ end)
     w.seg_cnt = o; o += up16(sizeof(unsigned short) * (size_t)(T + 1) * kPhases * 64);
     w.xs = o; o += up16(sizeof(float) * (size_t)T * (size_t)(C + kMaxVeh));
+    w.capru = o; o += up16(sizeof(float2) * (size_t)T * kMaxCaps);      // (u, r) every capacitor's charge of a step read
+    w.capflag = o; o += up16(sizeof(unsigned) * (size_t)T);             // bit j: capacitor j charged; bit 16 + j: its previous level was a variable
     w.per_replica = o;
     return w;
 }
@@ -383,6 +386,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     int *step_off = reinterpret_cast<int *>(wsr + ws.step_off);
     unsigned short *seg_cnt = reinterpret_cast<unsigned short *>(wsr + ws.seg_cnt);
     float *xs = reinterpret_cast<float *>(wsr + ws.xs);
+    float2 *capru_w = reinterpret_cast<float2 *>(wsr + ws.capru);
+    unsigned *capflag_w = reinterpret_cast<unsigned *>(wsr + ws.capflag);
     const int mw = tid - (B - 64);                  // lane of the micro wave (the extra wavefront), negative elsewhere
     const bool in_mw = mw >= 0, is_mt = (mw == 0);
     const int loss_steps = tb.loss_steps > 0 ? tb.loss_steps : T;
@@ -468,7 +473,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     int *grk = reinterpret_cast<int *>(wsr + ws.rec_k);
     int4 *gri = reinterpret_cast<int4 *>(wsr + ws.rec_i);
     float4 *grw = reinterpret_cast<float4 *>(wsr + ws.rec_w);
-    const int base_local = 3 * V + kMaxCaps;
+    const int base_local = 3 * V + 2 * kMaxCaps;     // [3V, +16) capacitors, [3V + 16, +16) the speed leaf of each capacitor's charge
     Rec rec;
     rec.next_local = base_local; rec.over = false; rec.off = kHard; rec.cap = stage_h;
     auto rec_select = [&](int b) {                   // this lane's staging half `b`, empty
@@ -1037,21 +1042,28 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             // capacitors: += r u dt of the last cell (conversion.py:32-36); the spawn itself is an event below
             const int cap_ms = cap_target(capnext_t);  // this step's successor of the capacitor's lane, if it is a micro lane
             float cap_level = 0.f;
+            bool cap_prev_var = false;
             if (mw < n_caps) {
                 const int j = mw;
                 cap_level = capv[j];
                 if (cap_ms >= 0) {
                     const int last = cap_last;
-                    // one compound record, in place on the capacitor's slot: cap += (r u) dt with (r, u) read from the cell
-                    // (the reads of r, u, their product and the sum are one record instead of three); the leaf stands for
-                    // u: a vehicle spawned in this step takes it as its speed
+                    // cap += (r u) dt with (r, u) read from the cell, in place on the capacitor's slot.  No record (round 3: the
+                    // sixteen of them were 95 % of the record stream): the reverse sweep's lane j applies the same three
+                    // float32 operations from (u, r) -- kept per step, because a deposit of the same step may rewrite the very
+                    // cell -- and two flag bits: charged, and whether the previous level was a variable (not the constant a spawn
+                    // or the start leaves).  The leaf stands for u: a vehicle spawned in this step takes it as its speed.
                     const float r_ = nxt[last], u_ = nxt[2 * C + last];
-                    const int leaf = rec.next_local++;
-                    rec_push(rec, K_CAP, 3 * V + j, make_int4(last, leaf, capi[j], 0), make_float4(dtf, u_, r_, 0.f));
+                    cap_prev_var = capi[j] >= 0;
+                    if (!kHard) capru_w[(size_t)t * kMaxCaps + j] = make_float2(u_, r_);
                     cap_level = cap_level + (r_ * u_) * dtf;
                     capv[j] = cap_level; capi[j] = 3 * V + j;
-                    capleaf[j] = leaf;
+                    capleaf[j] = 3 * V + kMaxCaps + j;
                 }
+            }
+            if (!kHard) {
+                const unsigned long long bc = __ballot(mw < n_caps && cap_ms >= 0), bp = __ballot(cap_prev_var);
+                if (is_mt) capflag_w[t] = (unsigned)(bc & 0xffffull) | ((unsigned)(bp & 0xffffull) << 16);
             }
             HYB_SUB(0)                               // D, micro wave: capacitors
             // is there any event at all this step?  (the common case is none)
@@ -1231,7 +1243,7 @@ __host__ __device__ inline HybLdsB hyb_lds_b(int L, int C, int sq, int V, int E)
     o.red = D(2);
     o.h0 = F(3 * (size_t)C); o.h1 = F(3 * (size_t)C); o.gl = F(3 * (size_t)C); o.c0 = F(2 * (size_t)C); o.c2 = F(2 * (size_t)C);
     o.gq = F(L); o.inl = F(3 * (size_t)E); o.inf = F(3 * (size_t)E); o.sg = F(6 * (size_t)sq);
-    o.adj = F(3 * (size_t)V + kMaxCaps + kMaxLocals); o.gam = F(sq);
+    o.adj = F(3 * (size_t)V + 2 * kMaxCaps + kMaxLocals); o.gam = F(sq);
     o.rk = F(kMaxStepRecords); o.ri = F(4 * (size_t)kMaxStepRecords); o.rw = F(4 * (size_t)kMaxStepRecords);
     o.cell_lane = F(C); o.obi = F(64 * 5); o.obf = F(64 * 5);
     o.aval = F(2 * (size_t)L); o.iptr = F((size_t)sq + 1); o.iidx = F(2 * (size_t)L);
@@ -1284,13 +1296,15 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     const int *grk = reinterpret_cast<const int *>(wsr + ws.rec_k);
     const int4 *gri = reinterpret_cast<const int4 *>(wsr + ws.rec_i);
     const float4 *grw = reinterpret_cast<const float4 *>(wsr + ws.rec_w);
+    const float2 *capru_r = reinterpret_cast<const float2 *>(wsr + ws.capru);
+    const unsigned *capflag_r = reinterpret_cast<const unsigned *>(wsr + ws.capflag);
     const float gscale = g_reward ? g_reward[rep] : 1.f;
     const int loss_steps = tb.loss_steps > 0 ? tb.loss_steps : T;
     const int g_base1 = hyb_ghost_base1(L, B);      // ghost threads by side, as in the forward kernel
     const bool is_cell = tid < C, is_ghost = tid < L || (tid >= g_base1 && tid < g_base1 + L), is_lane = tid < L;
     const bool in_mw = tid >= B - 64, is_mt = (tid == B - 64);
     const int mw_lane = tid - (B - 64);
-    const int n_adj = 3 * V + kMaxCaps + kMaxLocals;
+    const int n_adj = 3 * V + 2 * kMaxCaps + kMaxLocals;
 
     if (is_lane) {
         const int off = tb.net.lane_off[tid], n = tb.net.lane_ncell[tid];
@@ -1395,6 +1409,19 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     float4 p_aL = make_float4(0, 0, 0, 0), p_bL = p_aL, p_aR = p_aL, p_bR = p_aL;
     int p_src = 0, p_gate = 0, p_rlo = 0, p_nrec = 0, p_seg[kPhases], p_rk[kPre];
     int4 p_ri[kPre]; float4 p_rw[kPre];
+    unsigned p_capflag = 0u; float2 p_capru = make_float2(0.f, 0.f);
+    // capacitor j (lane j of the micro wave): the last cell of its macro lane (numbered as in the forward kernel: macro lanes
+    // with a micro successor, in lane order)
+    int cap_last_r = 0;
+    if (in_mw && mw_lane < kMaxCaps) {
+        int nc = 0;
+        for (int l = 0; l < L; ++l) {
+            if (!tb.lane_macro[l]) continue;
+            bool spawns = false;
+            for (int e = tb.net.nxt_ptr[l]; e < tb.net.nxt_ptr[l + 1]; ++e) spawns |= !tb.lane_macro[tb.net.nxt_idx[e]];
+            if (spawns) { if (nc == mw_lane) cap_last_r = tb.net.lane_off[l] + tb.net.lane_ncell[l] - 1; ++nc; }
+        }
+    }
 #pragma unroll
     for (int ph = 0; ph < kPhases; ++ph) p_seg[ph] = 0;
 #pragma unroll
@@ -1436,6 +1463,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
                 p_rk[j] = grk[kk]; p_ri[j] = gri[kk]; p_rw[j] = grw[kk];
             }
             fetch_offsets(t - 1);
+            p_capflag = capflag_r[tt];
+            p_capru = capru_r[(size_t)tt * kMaxCaps + (mw_lane < kMaxCaps ? mw_lane : 0)];
         }
     };
     // block T of the record stream is empty in streams this build writes (the loss seeds of the final state sit at the end
@@ -1460,6 +1489,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         const float *Hn = (t & 1) ? H0 : H1;     // row t+1
         // ================= R0: this step's data (fetched during the previous iteration) =================
         const float w_kc = p_kc; const float4 aL = p_aL, bL = p_bL, aR = p_aR, bR = p_bR;
+        const unsigned w_capflag = p_capflag; const float2 w_capru = p_capru;
         const int src = p_src, gate = p_gate; const float w_own_r = p_own_r, w_own_u = p_own_u;
         if (is_cell) { Hc[tid] = p_hr; Hc[C + tid] = p_hy; Hc[2 * C + tid] = p_hu; }
         // loss taps on the state after step t (row t + 1 is in LDS since the previous iteration): d reward / d q_l = -2 q_l dt
@@ -1554,17 +1584,6 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
                     if (in[1] >= 0) adj[in[1]] += g_nr * ((w[3] / vlen) / dx) * w[1];
                     if (in[2] >= 0) adj[in[2]] += g_speed;
                     gL[c] = g_nr; gL[C + c] = 0.f; gL[2 * C + c] = 0.f;
-                } else if (kind == K_CAP) {
-                    // cap' = cap + (r u) dt: the slot's cotangent passes through to the previous value of the capacitor and
-                    // reaches the cell as ((a dt) u, (a dt) r); the u leaf may also carry a spawned vehicle's speed
-                    const float a = adj[out];
-                    adj[out] = 0.f;
-                    if (in[2] >= 0) adj[in[2]] += a;
-                    const float ad = a * w[0];
-                    const float g_u = adj[in[1]] + ad * w[2];
-                    adj[in[1]] = 0.f;
-                    gL[in[0]] += ad * w[1];
-                    gL[2 * C + in[0]] += g_u;
                 } else if (kind == K_CELLREAD) {
                     gL[in[2]] += adj[in[0]];
                     gL[2 * C + in[2]] += adj[in[1]];
@@ -1586,12 +1605,21 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         };
         if (in_mw) {
             replay(seg_lo[2], seg_n[2]);                 // the vehicles' loss terms, then the commits
-            // a lane's capacitor record is the first of its second segment.  The charge precedes ALL hand-off events of its
-            // step (a deposit may rewrite the very cell it read), and lanes replay side by side: the events of every lane
-            // first (lane 0 holds them), the capacitors afterwards
-            const int capn = (seg_n[1] > 0 && (rk[seg_lo[1]] >> 24) == K_CAP) ? 1 : 0;
-            replay(seg_lo[1] + capn, seg_n[1] - capn);
-            replay(seg_lo[1], capn);
+            // A capacitor's charge precedes ALL hand-off events of its step (a deposit may rewrite the very cell it read), and
+            // lanes replay side by side: the events of every lane first (lane 0 holds them), the capacitors afterwards
+            replay(seg_lo[1], seg_n[1]);
+            // cap' = cap + (r u) dt (no record since round 3): the slot's cotangent passes through to the previous level if that
+            // was a variable and reaches the cell as ((a dt) u, (a dt) r); the u leaf may also carry a spawned vehicle's speed
+            if (mw_lane < kMaxCaps && ((w_capflag >> mw_lane) & 1u)) {
+                const int out = 3 * V + mw_lane, leaf = 3 * V + kMaxCaps + mw_lane;
+                const float a = adj[out];
+                adj[out] = ((w_capflag >> (16 + mw_lane)) & 1u) ? a : 0.f;
+                const float ad = a * dtf;
+                const float g_u = adj[leaf] + ad * w_capru.y;
+                adj[leaf] = 0.f;
+                gL[cap_last_r] += ad * w_capru.x;
+                gL[2 * C + cap_last_r] += g_u;
+            }
         }
         // ghost threads: the forward blend of this step's ghost (everything that needs no cotangent), while only the micro
         // wave has work; the cotangent part follows two phases later
