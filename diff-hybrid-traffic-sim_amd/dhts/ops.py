@@ -565,6 +565,8 @@ class DeviceHybridTables:
     def set_draws(self, draws):
         """A fresh stream of admission draws for the next episode (micro source lanes; same length as the uploaded one)."""
         import numpy as np
+        if not self.has_sources:
+            raise ValueError("the network has no micro source lanes")
         d = torch.as_tensor(np.ascontiguousarray(draws, dtype=np.float64), device=self._keep[19].device)
         if d.shape != self._keep[19].shape:
             raise ValueError("draws must keep their shape %s" % (tuple(self._keep[19].shape),))
@@ -598,7 +600,6 @@ class NetHybridRollout(torch.autograd.Function):
         if ws_n == 0:
             raise ValueError("unsupported hybrid network size")
         dev = a.device
-        Cp = (t.n_cells + 63) // 64 * 64
         # (an all-micro network has no cells: the kernels' unconditional prefetches still want something to read)
         hist = torch.empty(max(R * (t.T + 1) * 4 * t.n_cells, 64), dtype=torch.float32, device=dev)
         tape = torch.empty(max(lib.dhts_net_hybrid_tape_bytes(C.byref(d)) // 4, 64), dtype=torch.float32, device=dev)
