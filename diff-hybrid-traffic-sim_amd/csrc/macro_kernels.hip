@@ -473,6 +473,174 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
     if (fault_step >= 0) raise_fault(err, DHTS_FAULT_CFL, fault_step, lane, fault_index);
 }
 
+// The same kernel for kG traffic lanes per workgroup (lanes kG b .. kG b + kG - 1; full lanes of kP passes per wavefront, no
+// history): each lane keeps its own records, fluxes and queue -- phase 1 is the kernel above, per lane -- but phase 2 takes the
+// lanes' queues as one list (entry g belongs to the lane whose prefix sum of queue lengths it falls in).  At config 2 a lane
+// queues ~76 interfaces, which is two wavefronts' worth of the full solve's instruction stream (64 + 12 entries); a pair of lanes
+// needs three (64 + 64 + 24).  Measured at config 2 (MI355X, profiles/r03v_macro_fwd_lane_groups.log): one lane per workgroup
+// 3.39 ms, two 3.22 ms, four 3.34 ms (five wavefronts' worth for four lanes, but every barrier then spans 16 wavefronts).
+// Results and tape are bit-identical to the one-lane kernel's.  Dynamic LDS: kG regions of fwd2_region_bytes(N), one per lane.
+__host__ __device__ inline size_t fwd2_region_bytes(int N) {
+    return (sizeof(CellRec) * (size_t)(N + 2) + 16 * (size_t)(N + 1) + sizeof(int) * (size_t)(N + 2) + 16 + 15) & ~(size_t)15;
+}
+template <int kP, int kG>
+__global__ __launch_bounds__(1024) void macro_rollout_fwd2_group_kernel(
+    int L, int N, int T, double dt, double dx, double um,
+    const float *__restrict__ r_in, const float *__restrict__ y_in, const float *__restrict__ u_in,
+    const float *__restrict__ q_in, const float *__restrict__ ghost,
+    float *__restrict__ r_out, float *__restrict__ y_out, float *__restrict__ u_out, float *__restrict__ q_out,
+    float4 *__restrict__ tape, dhts_error *err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int t = tid & 63;
+    const int wv = tid >> 6;
+    const int Wc = blockDim.x >> 6;                  // wavefronts of the workgroup (both lanes)
+    const int Wl = Wc / kG;                          // wavefronts per lane
+    const int sub = wv / Wl;                         // which lane of the group this wavefront belongs to (wave-uniform)
+    const int wl = wv - sub * Wl;
+    const int lane = kG * blockIdx.x + sub;
+    const int ncell = blockDim.x / kG;               // threads per lane = cells per pass set
+    const size_t base = (size_t)lane * N;
+    const size_t reg = fwd2_region_bytes(N);
+    auto region_cr = [&](int s_) { return reinterpret_cast<CellRec *>(smem + (size_t)s_ * reg); };
+    auto region_fx = [&](int s_) { return reinterpret_cast<double2 *>(region_cr(s_) + (N + 2)); };
+    auto region_q = [&](int s_) { return reinterpret_cast<int *>(region_fx(s_) + (N + 1)); };
+    auto region_cnt = [&](int s_) { return region_q(s_) + (N + 2); };
+    CellRec *CR = region_cr(sub);
+    double2 *FX = region_fx(sub);
+    int *Q = region_q(sub);
+    int *CNT = region_cnt(sub);
+    IfaceConst kc;
+    kc.set_um(um); kc.set_grid(dt, dx);
+
+    for (int k = tid - sub * ncell; k < N + 2; k += ncell) {
+        float4 st;
+        if (k == 0 || k == N + 1) {
+            const float *g = ghost + (size_t)lane * 8 + (k ? 4 : 0);
+            st = make_float4(g[0], g[1], g[2], g[3]);
+        } else {
+            st = make_float4(r_in[base + k - 1], y_in[base + k - 1], u_in[base + k - 1], q_in[base + k - 1]);
+        }
+        CellPre c;
+        arz_cell_pre((double)st.x, um, c);
+        CR[k].st = st;
+        CR[k].sh = make_double2(c.s, c.h);
+        CR[k].q0 = make_double2(c.q0, 0.);
+    }
+    if (tid == sub * ncell) { Q[0] = N; CNT[0] = 1; CNT[1] = 1; }      // entry 0 of every step's queue: interface N
+    __syncthreads();
+
+    const TapeGeom geo = tape_geom(N);
+    const int lo = wl * (kP << 6);                   // first cell of this wave in its lane
+    const double c = dt / dx;
+    const float umf = (float)um;
+    int fault_step = -1, fault_index = 0, fault_lane = 0;
+    int rot = 0;
+    // the pair's two tape rows of a step lie side by side (rows are [step][lane])
+    float4 *tp_pair = tape ? tape + (size_t)(kG * blockIdx.x) * geo.row_f4 : nullptr;
+    const size_t tp_stride = (size_t)L * geo.row_f4;
+    double rd_own[kP], yd_own[kP];
+
+    auto body = [&](auto upd_c, auto solve_c, const int n) {
+        constexpr bool upd = decltype(upd_c)::value;
+        constexpr bool solve = decltype(solve_c)::value;
+        float4 *tpp = solve ? tp_pair : nullptr;                        // lane a's row; lane b's follows
+        float4 *tp = tpp ? tpp + (size_t)sub * geo.row_f4 : nullptr;
+        TapeFp *tS = reinterpret_cast<TapeFp *>(tp);
+        if (tp_pair) tp_pair += tp_stride;
+        int *cnt = CNT + (n & 1);
+#pragma unroll
+        for (int j = 0; j < kP; ++j) {
+            const int i = lo + (j << 6) + t;
+            const unsigned ic = (unsigned)i;
+            CellRec *own = CR + ic + 1;
+            float4 st;
+            if (!upd) { st = own->st; rd_own[j] = (double)st.x; yd_own[j] = (double)st.y; }
+            if (upd) {
+                const double2 Fl = FX[ic], Fr = FX[ic + 1];
+                st.x = (float)(rd_own[j] + (Fl.x - Fr.x) * c);
+                st.y = (float)(yd_own[j] + (Fl.y - Fr.y) * c);
+                rd_own[j] = (double)st.x; yd_own[j] = (double)st.y;
+                CellPre cp;
+                cell_glue_pre(st.x, st.y, umf, kc, st.z, st.w, cp);
+                if (solve) { own->st = st; own->sh = make_double2(cp.s, cp.h); own->q0 = make_double2(cp.q0, 0.); }
+            }
+            if (!solve) {
+                r_out[base + i] = st.x; y_out[base + i] = st.y; u_out[base + i] = st.z; q_out[base + i] = st.w;
+                continue;
+            }
+            wave_lds_handoff();
+            const CellRec *lf = CR + ic;
+            const float4 ls = lf->st;
+            const double2 lsh = lf->sh, lq0 = lf->q0;
+            CellPre cl;
+            cl.s = lsh.x; cl.h = lsh.y; cl.q0 = lq0.x;
+            IfacePre pre;
+            const bool easy = arz_is_trivial_fast((double)ls.x, (double)ls.z, (double)ls.w, (double)st.x, (double)st.z, cl, kc, pre);
+            const bool triv = easy & !((j == 0) & (t == 0));
+            double u0, Fr, Fy;
+            float fp[4];
+            arz_trivial_fast((double)ls.x, (double)ls.y, pre, kc, u0, Fr, Fy, fp);
+            if (triv) FX[ic] = make_double2(Fr, Fy);
+            if (!triv) Q[atomicAdd(cnt, 1)] = i;
+            if (tp) tS[ic] = TapeFp{fp[0], fp[2], fp[3]};
+        }
+        if (!solve) return;
+        lds_only_barrier();
+        // ---- phase 2: the group's queues as one list ----
+        int g0 = tid - (rot << 6);
+        if (g0 < 0) g0 += blockDim.x;
+        int qs[kG + 1];                                                  // prefix sums of the lanes' queue lengths
+        qs[0] = 0;
+#pragma unroll
+        for (int s_ = 0; s_ < kG; ++s_) qs[s_ + 1] = qs[s_] + region_cnt(s_)[n & 1];
+        const int qn = qs[kG];
+        if (g0 < qn) __builtin_amdgcn_s_setprio(3);
+        for (int g = g0; g < qn; g += blockDim.x) {
+            int s2 = 0;
+#pragma unroll
+            for (int s_ = 1; s_ < kG; ++s_) s2 += g >= qs[s_] ? 1 : 0;
+            const int k = g - qs[s2];
+            const unsigned i = (unsigned)region_q(s2)[k];
+            CellRec *CR2 = region_cr(s2);
+            const CellRec *lf = CR2 + i, *rt = CR2 + i + 1;
+            const float4 ls = lf->st, rs = rt->st;
+            const double2 lsh = lf->sh, lq0 = lf->q0, rsh = rt->sh;
+            CellPre cl, cr;
+            cl.s = lsh.x; cl.h = lsh.y; cl.q0 = lq0.x;
+            cr.s = rsh.x; cr.h = rsh.y; cr.q0 = 0.;
+            Iface f;
+            arz_interface_fast_pre((double)ls.x, (double)ls.y, (double)ls.z, (double)ls.w, cl,
+                                   (double)rs.x, (double)rs.y, (double)rs.z, (double)rs.w, cr, kc, f);
+            region_fx(s2)[i] = make_double2(f.Fr, f.Fy);
+            if (tpp) {
+                float4 *row = tpp + (size_t)s2 * geo.row_f4;
+                unsigned *tH = tape_hdr(row, geo);
+                float4 *tE = row + geo.s_f4 + geo.h_f4;
+                if (k == 0) { tH[0] = (unsigned)(qs[s2 + 1] - qs[s2]); tH[1] = 0u; }   // (entry 0 of a lane's queue always exists: interface N)
+                tE[2 * k] = make_float4(f.A[0], f.A[1], f.A[2], f.A[3]);
+                tE[2 * k + 1] = make_float4(f.B[0], f.B[1], f.B[2], f.B[3]);
+                tape_idx(tH, geo)[k] = (unsigned short)i;
+            }
+            if (f.cfl_bad && fault_step < 0) { fault_step = n; fault_index = (int)i; fault_lane = kG * blockIdx.x + s2; }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (tid < kG) region_cnt(tid)[(n + 1) & 1] = 1;
+        if (++rot == Wc) rot = 0;
+        lds_only_barrier();
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    if (T == 0) {
+        body(no{}, no{}, 0);
+    } else {
+        body(no{}, yes{}, 0);
+        for (int n = 1; n < T; ++n) body(yes{}, yes{}, n);
+        body(yes{}, no{}, T);
+    }
+    if (fault_step >= 0) raise_fault(err, DHTS_FAULT_CFL, fault_step, fault_lane, fault_index);
+}
+
 // ---- reverse sweeps -------------------------------------------------------------------------------------------------
 // g' = J^T g per step: grad_cell[a][k] = dqs[a][k]^T g[a]; g'[b] = (c1[b] + c2[b-1]) + c0[b+1]   (dmacro_lane.py:283-303)
 // LDS planes of (N + 2) floats: index k + 1 holds cell k; slots 0 and N + 1 stay zero for c2 / c0 so edge cells add 0.
@@ -975,6 +1143,7 @@ static inline int grid_1d(int64_t n) {
 // forward kernel (0 = two-phase kernel, 1 = the one-phase kernel the single-step operator uses)
 static int dhts_fwd_waves_override = 0;
 static int dhts_fwd_variant = 0;
+static int dhts_fwd_group = 2;         // DHTS_OPT_MACRO_FWD_GROUP: traffic lanes per workgroup in the two-phase forward kernel (where it can)
 static inline int padded64(int n) { return (n + 63) & ~63; }
 
 // Wavefronts per lane of the two-phase forward kernel: two 64-cell passes per wavefront whenever the lane fits 16 of them -- the
@@ -992,6 +1161,16 @@ static void macro_fwd2_plan(int N, int &W, int &p) {
 static inline bool macro_fwd2_fits(const dhts_macro_desc *d) {
     return d && sizeof(CellRec) * (size_t)(d->n_cells + 2) + 16 * (size_t)(d->n_cells + 1) + sizeof(int) * (size_t)(d->n_cells + 2) + 16 <=
                     160 * 1024;
+}
+// traffic lanes per workgroup of the two-phase kernel: groups where the grouped kernel exists (full lanes of two passes per
+// wavefront, no history), the group fits a workgroup and the LDS, and the launch still has a workgroup for every CU
+static inline int macro_fwd2_group(const dhts_macro_desc *d, bool want_hist) {
+    int W, p;
+    macro_fwd2_plan(d->n_cells, W, p);
+    const int G = dhts_fwd_group;
+    if (G < 2 || want_hist || p != 2 || d->n_cells != 128 * W || d->n_lanes % G != 0 || d->n_lanes / G < 256) return 1;
+    if (64 * W * G > 1024 || (size_t)G * fwd2_region_bytes(d->n_cells) > 160 * 1024) return 1;
+    return G;
 }
 static inline int macro_bwd_fast_block(int N) { return N <= 64 ? 64 : (N <= 128 ? 128 : (N <= 256 ? 256 : (N <= 512 ? 512 : 1024))); }
 static inline bool macro_bwd_is_fast(int N, int T) { return N >= 2 && N <= 1024 && T > 0; }      // (T = 0: no tape to prefetch from)
@@ -1016,11 +1195,19 @@ static int macro_fwd2_launch(const dhts_macro_desc *d, int T,
     macro_fwd2_plan(N, W, p);
 #define DHTS_FWD2_ARGS d->n_lanes, N, T, p, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, \
                        reinterpret_cast<float4 *>(tape), hist, err
-    if (p == 1 && N == 64 * W && hist == nullptr)
+    const int G = macro_fwd2_group(d, hist != nullptr);
+    if (G > 1) {
+        const size_t ldsg = (size_t)G * fwd2_region_bytes(N);
+        const void *fn = G == 2 ? (const void *)macro_rollout_fwd2_group_kernel<2, 2> : (const void *)macro_rollout_fwd2_group_kernel<2, 4>;
+        if (ldsg > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg) != hipSuccess) return DHTS_E_LAUNCH;
+#define DHTS_FWDG_ARGS d->n_lanes, N, T, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, reinterpret_cast<float4 *>(tape), err
+        if (G == 2) macro_rollout_fwd2_group_kernel<2, 2><<<d->n_lanes / 2, 128 * W, ldsg, (hipStream_t)stream>>>(DHTS_FWDG_ARGS);
+        else macro_rollout_fwd2_group_kernel<2, 4><<<d->n_lanes / 4, 256 * W, ldsg, (hipStream_t)stream>>>(DHTS_FWDG_ARGS);
+#undef DHTS_FWDG_ARGS
+    } else if (p == 1 && N == 64 * W && hist == nullptr)
         macro_rollout_fwd2_kernel<1, true, false><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(DHTS_FWD2_ARGS);
     else if (p == 2 && N == 128 * W && hist == nullptr)
         macro_rollout_fwd2_kernel<2, true, false><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(DHTS_FWD2_ARGS);
-
     else if (p == 1)
         macro_rollout_fwd2_kernel<1, false, true><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(DHTS_FWD2_ARGS);
     else if (p == 2)
@@ -1132,6 +1319,10 @@ int dhts_set_option(int option, int value) {
         dhts_fwd_variant = value;
         return DHTS_OK;
     }
+    if (option == DHTS_OPT_MACRO_FWD_GROUP && (value == 1 || value == 2 || value == 4)) {
+        dhts_fwd_group = value;
+        return DHTS_OK;
+    }
     if (option == DHTS_OPT_MICRO_FWD_WAVES && (value == 0 || value == 1 || value == 2 || value == 4)) {
         dhts_micro_fwd_waves_override = value;
         return DHTS_OK;
@@ -1214,6 +1405,7 @@ int dhts_macro_rollout_plan(const dhts_macro_desc *d, int T, int want_hist, int3
     plan[4] = macro_bwd_is_fast(N, T) ? 1 : 0;
     plan[5] = plan[4] ? macro_bwd_fast_block(N) : (padded64(N) > 512 ? 512 : padded64(N));
     plan[6] = want_hist ? 1 : 0;
+    plan[7] = plan[0] == 0 ? macro_fwd2_group(d, want_hist != 0) : 1;
     return DHTS_OK;
 }
 int dhts_macro_tape_expand(const dhts_macro_desc *d, int T, const float *tape, float *dqs, void *stream) {

@@ -17,6 +17,7 @@ FAULT_NONE, FAULT_CFL, FAULT_COLLISION, FAULT_NAN, FAULT_CAPACITY = 0, 1, 2, 3, 
 OPT_MACRO_FWD_WAVES = 1
 OPT_MICRO_FWD_WAVES = 2
 OPT_MACRO_FWD_VARIANT = 3
+OPT_MACRO_FWD_GROUP = 4
 MACRO_MAX_CELLS = 4000
 MICRO_MAX_VEHICLES = 1024
 

@@ -150,8 +150,8 @@ def macro_rollout_plan(desc, T, want_hist=False):
     """Which kernel instantiations dhts_macro_rollout_fwd / _bwd launch for this shape (include/dhts.h)."""
     plan = (C.c_int32 * 8)()
     check(_lib.lib().dhts_macro_rollout_plan(C.byref(desc), int(T), int(bool(want_hist)), C.byref(plan)), "dhts_macro_rollout_plan")
-    keys = ("fwd_one_phase", "fwd_waves", "fwd_passes", "fwd_full_lane", "bwd_pipelined", "bwd_block", "hist")
-    return dict(zip(keys, list(plan)[:7]))
+    keys = ("fwd_one_phase", "fwd_waves", "fwd_passes", "fwd_full_lane", "bwd_pipelined", "bwd_block", "hist", "fwd_lanes_per_group")
+    return dict(zip(keys, list(plan)))
 
 
 def macro_tape_expand(desc, T, tape):

@@ -83,6 +83,10 @@ int dhts_device_count(void);
 /* DHTS_OPT_MACRO_FWD_VARIANT: kernel behind dhts_macro_rollout_fwd: 0 = two-phase kernel (trivial interfaces solved in
  * place, the others queued and solved compacted), 1 = the one-phase kernel of dhts_macro_step_fwd (every interface an exception).  Same tape format, same results. */
 #define DHTS_OPT_MACRO_FWD_VARIANT 3
+/* DHTS_OPT_MACRO_FWD_GROUP: traffic lanes per workgroup of the two-phase kernel, 1, 2 (default) or 4: where the lanes are full
+ * (n_cells = 128 x wavefronts), no history is asked for and the launch keeps >= 256 workgroups, the queued interfaces of a
+ * group's lanes are solved as one list.  Same results, same tape (dhts_macro_rollout_plan plan[7] says what a shape gets). */
+#define DHTS_OPT_MACRO_FWD_GROUP 4
 int dhts_set_option(int option, int value);
 /* cells / vehicle slots rounded up to the tape's padded width (multiple of 64) */
 int dhts_padded(int n);
@@ -171,7 +175,8 @@ int dhts_macro_rollout_bwd(const dhts_macro_desc *d, int T, const float *tape,
  *   plan[0] forward kernel: 0 = two-phase, 1 = one-phase     plan[1] wavefronts per lane     plan[2] 64-cell passes per wavefront
  *   plan[3] 1 = the full-lane, history-free instantiation (n_cells = 64 x passes x wavefronts and hist == NULL)
  *   plan[4] reverse kernel: 1 = pipelined one-cell-per-thread, 0 = general     plan[5] its block size
- *   plan[6] 1 = per-step cotangents / history requested (want_hist)            plan[7] 0 */
+ *   plan[6] 1 = per-step cotangents / history requested (want_hist)
+ *   plan[7] traffic lanes per workgroup of the two-phase forward kernel (DHTS_OPT_MACRO_FWD_GROUP) */
 int dhts_macro_rollout_plan(const dhts_macro_desc *d, int T, int want_hist, int32_t plan[8]);
 
 /* One step = the drop-in for a batch of dMacroForwardLayer.forward / .backward calls (T = 1 of the above;

@@ -467,6 +467,65 @@ def test_macro_cfl_fault(cuda):
     dhts.macro_rollout(r0, u0, gr, gu, 3, 0.01, 5.0, 30.0)
 
 
+@pytest.mark.parametrize("N,group", [(128, 2), (128, 4), (256, 2), (256, 4), (512, 2)])
+def test_macro_lane_groups_equal_one_lane_per_workgroup(cuda, N, group):
+    """DHTS_OPT_MACRO_FWD_GROUP: the two-phase kernel with 2 or 4 traffic lanes per workgroup (one phase-2 list for the group)
+    against one lane per workgroup, on lanes with vacuum cells, shocks and idle stretches: final state, the blocks the tape
+    expands to and the reverse sweep's gradients bit for bit, with and without a tape; a CFL fault names the lane it is in."""
+    import torch
+    from dhts import _lib, ops
+    rng = np.random.default_rng(100 + N + group)
+    L, T, dt, dx, um = 256 * group, 40, 0.01, 5.0, 30.0
+    r0 = rng.uniform(0.0, 1.0, (L, N)).astype(np.float32)
+    r0[1, 10:20] = 0.0
+    r0[2] = 0.4                              # an idle lane: every interface trivial, the queue holds interface N only
+    r0[5, ::2] = 0.0                         # the longest queue
+    r0[L - 1, N - 3:] = 0.0
+    u0 = rng.uniform(0.0, um, (L, N)).astype(np.float32)
+    u0[2] = 12.0
+    r, u = T_(r0, cuda), T_(u0, cuda)
+    y, q = ops.macro_state_from_ru(r, u, um)
+    gr = T_(rng.uniform(0.0, 1.0, (L, 2)).astype(np.float32), cuda)
+    gu = T_(rng.uniform(0.0, um, (L, 2)).astype(np.float32), cuda)
+    gy, gq = ops.macro_state_from_ru(gr, gu, um)
+    ghost = torch.stack([gr, gy, gu, gq], dim=-1).contiguous()
+    desc = ops.macro_desc(L, N, dt, dx, um)
+    res = []
+    try:
+        for grp in (1, group):
+            assert _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_GROUP, grp) == 0
+            assert ops.macro_rollout_plan(desc, T)["fwd_lanes_per_group"] == grp
+            assert ops.macro_rollout_plan(desc, T, want_hist=True)["fwd_lanes_per_group"] == 1
+            assert ops.macro_rollout_plan(ops.macro_desc(L - 1, N, dt, dx, um), T)["fwd_lanes_per_group"] == 1
+            assert ops.macro_rollout_plan(ops.macro_desc(L, N - 1, dt, dx, um), T)["fwd_lanes_per_group"] == 1
+            tape = torch.full((ops.macro_tape_numel(desc, T),), float("nan"), device=cuda)
+            out = ops.macro_rollout_fwd(desc, T, r, y, u, q, ghost, tape=tape)
+            plain = ops.macro_rollout_fwd(desc, T, r, y, u, q, ghost)
+            for a, b in zip(out, plain):
+                assert torch.equal(a, b)
+            g_r, g_y = 2 * out[0], torch.zeros_like(out[0])
+            ops.macro_u_tap_bwd(out[0], out[1], 2 * out[2], g_r, g_y, um)
+            res.append((out, ops.macro_tape_expand(desc, T, tape), ops.macro_rollout_bwd(desc, T, tape, g_r, g_y)))
+        for a, b in zip(res[0][0], res[1][0]):
+            assert torch.equal(a, b)
+        assert torch.equal(res[0][1], res[1][1])
+        for a, b in zip(res[0][2], res[1][2]):
+            assert torch.equal(a, b)
+        # a fault in the last lane of a group is reported for that lane
+        bad = L - 2 * group - 1
+        u_bad = u.clone()
+        r_bad = r.clone()
+        r_bad[bad, 7:9] = 0.3
+        u_bad[bad, 7:9] = 600.0                                 # dt * speed >= dx
+        y_bad, q_bad = ops.macro_state_from_ru(r_bad, u_bad, um)
+        err = ops.new_error_record(cuda)
+        ops.macro_rollout_fwd(desc, T, r_bad, y_bad, u_bad, q_bad, ghost, err=err)
+        rec = err.cpu().numpy()
+        assert rec[0] == _lib.FAULT_CFL and 0 <= rec[1] < T and rec[2] == bad and 0 <= rec[3] <= N, rec
+    finally:
+        _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_GROUP, 2)
+
+
 def test_macro_full_size_properties(cuda):
     """BASELINE config 2 (1024 lanes x 512 cells x 1000 steps) through size-independent properties:
     bitwise repeatability, replica consistency (identical lanes -> identical results), lane independence
@@ -523,11 +582,11 @@ BENCH_LANES = (0, 1, 2, 3, 500, 511, 1022, 1023)      # lanes of bench.py's rank
 
 
 def test_macro_bench_instantiation_vs_reference_and_oracle(cuda, oracle, golden_dir):
-    """The kernel instantiations bench.py times on BASELINE config 2 -- macro_rollout_fwd2_kernel<2, true, false> (four
-    wavefronts x two passes, full lane, no history) and macro_rollout_bwd_fast_kernel<512, false> -- at the bench's shape:
-    512 cells x 1000 steps.  Lane 4 of the batch is the reference's own 512 x 1000 run (golden c2slice: state <= 1e-5,
-    gradients <= 1e-4); the other eight lanes are lanes of the very tensors bench.py builds for rank 0, compared with the
-    oracle over all 1000 steps.  (test_macro_full_size_properties shows a lane's result does not depend on the batch.)"""
+    """The kernel instantiations bench.py times on BASELINE config 2 -- macro_rollout_fwd2_group_kernel<2, 2> (two traffic
+    lanes per workgroup, four wavefronts x two passes each, no history) and macro_rollout_bwd_fast_kernel<512, false> -- in
+    the bench's own launch: 1024 lanes x 512 cells x 1000 steps, the tensors bench.py builds for rank 0.  Lane 4 of the batch is
+    replaced by the reference's own 512 x 1000 run (golden c2slice: state <= 1e-5, gradients <= 1e-4); eight more lanes are
+    compared with the oracle over all 1000 steps."""
     import torch
     import bench
     import dhts
@@ -536,17 +595,16 @@ def test_macro_bench_instantiation_vs_reference_and_oracle(cuda, oracle, golden_
     m = meta_of(g)
     N, T, dt, dx, um = m["N"], m["T"], m["dt"], m["dx"], m["u_max"]
     assert (N, T, dt, dx, um) == (512, 1000, 0.01, 5.0, 30.0)
-    r0b, u0b, grb, gub = (t.numpy() for t in bench.MacroWorkload.inputs(0, 1024, 512, um))
-    pick = list(BENCH_LANES)
-    r0 = np.concatenate([r0b[pick[:4]], g["r0"][None], r0b[pick[4:]]]).astype(np.float32)
-    u0 = np.concatenate([u0b[pick[:4]], g["u0"][None], u0b[pick[4:]]]).astype(np.float32)
-    gr = np.concatenate([grb[pick[:4]], g["ghost_r"][None], grb[pick[4:]]]).astype(np.float32)
-    gu = np.concatenate([gub[pick[:4]], g["ghost_u"][None], gub[pick[4:]]]).astype(np.float32)
+    # the whole batch bench.py builds for rank 0 (1024 lanes), lane 4 replaced by the reference's lane
+    r0, u0, gr, gu = (t.numpy().astype(np.float32).copy() for t in bench.MacroWorkload.inputs(0, 1024, 512, um))
+    k = 4
+    r0[k], u0[k], gr[k], gu[k] = g["r0"], g["u0"], g["ghost_r"], g["ghost_u"]
+    pick = sorted(set(BENCH_LANES) | {k})
     L = r0.shape[0]
     # the launch this test makes is the one the bench makes
     plan = ops.macro_rollout_plan(ops.macro_desc(L, N, dt, dx, um), T, want_hist=False)
-    assert plan == ops.macro_rollout_plan(ops.macro_desc(1024, N, dt, dx, um), T, want_hist=False)
-    assert plan == dict(fwd_one_phase=0, fwd_waves=4, fwd_passes=2, fwd_full_lane=1, bwd_pipelined=1, bwd_block=512, hist=0)
+    assert plan == dict(fwd_one_phase=0, fwd_waves=4, fwd_passes=2, fwd_full_lane=1, bwd_pipelined=1, bwd_block=512, hist=0,
+                        fwd_lanes_per_group=2)
     tr0, tu0 = T_(r0, cuda, grad=True), T_(u0, cuda, grad=True)
     tgr, tgu = T_(gr, cuda, grad=True), T_(gu, cuda, grad=True)
     rT, yT, uT, _ = dhts.macro_rollout(tr0, tu0, tgr, tgu, T, dt, dx, um)          # no history: the bench's instantiation
@@ -554,7 +612,6 @@ def test_macro_bench_instantiation_vs_reference_and_oracle(cuda, oracle, golden_
     rT, yT, uT = (t.detach().cpu().numpy() for t in (rT, yT, uT))
     g_r0, g_u0, g_gr, g_gu = (t.grad.cpu().numpy() for t in (tr0, tu0, tgr, tgu))
     # the reference's lane
-    k = 4
     assert rel_max(rT[k], g["rT"]) <= TOL_STATE and rel_max(yT[k], g["yT"]) <= TOL_STATE and rel_max(uT[k], g["uT"]) <= TOL_STATE
     e_elem = max(rel_elem(rT[k], g["rT"]), rel_elem(uT[k], g["uT"]))
     print("G4 c2slice (bench instantiation): element-wise state error %.2e" % e_elem)
@@ -563,14 +620,14 @@ def test_macro_bench_instantiation_vs_reference_and_oracle(cuda, oracle, golden_
     assert grad_report("G4 c2slice (bench instantiation) d loss / d u0", g_u0[k], g["g_u0"]) <= TOL_GRAD
     assert rel_max(g_gr[k], g["g_ghost_r"]) <= TOL_GRAD and rel_max(g_gu[k], g["g_ghost_u"]) <= TOL_GRAD
     # config 2's own lanes against the oracle, all 1000 steps
-    f = oracle.macro_rollout_fwd(r0, u0, gr, gu, T, dt, dx, um)
+    f = oracle.macro_rollout_fwd(r0[pick], u0[pick], gr[pick], gu[pick], T, dt, dx, um)
     assert f["rc"] == 0
     b = oracle.macro_rollout_bwd(f, g_rT=2 * f["rT"], g_uT=2 * f["uT"])
     worst_s = worst_g = 0.0
-    for j in range(L):
-        worst_s = max(worst_s, rel_elem(rT[j], f["rT"][j]), rel_elem(uT[j], f["uT"][j]), rel_max(yT[j], f["yT"][j]))
-        worst_g = max(worst_g, rel_max(g_r0[j], b["g_r0"][j]), rel_max(g_u0[j], b["g_u0"][j]))
-        assert rel_max(g_gr[j], b["g_ghost_r"][j]) <= TOL_GRAD and rel_max(g_gu[j], b["g_ghost_u"][j]) <= TOL_GRAD
+    for o, j in enumerate(pick):
+        worst_s = max(worst_s, rel_elem(rT[j], f["rT"][o]), rel_elem(uT[j], f["uT"][o]), rel_max(yT[j], f["yT"][o]))
+        worst_g = max(worst_g, rel_max(g_r0[j], b["g_r0"][o]), rel_max(g_u0[j], b["g_u0"][o]))
+        assert rel_max(g_gr[j], b["g_ghost_r"][o]) <= TOL_GRAD and rel_max(g_gu[j], b["g_ghost_u"][o]) <= TOL_GRAD
     print("config 2 lanes %s (bench instantiation) vs oracle over %d steps: state %.2e (element-wise), gradient %.2e" % (
         pick, T, worst_s, worst_g))
     assert worst_s <= TOL_STATE and worst_g <= TOL_GRAD
