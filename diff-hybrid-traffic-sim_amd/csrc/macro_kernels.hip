@@ -483,7 +483,7 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
 __host__ __device__ inline size_t fwd2_region_bytes(int N) {
     return (sizeof(CellRec) * (size_t)(N + 2) + 16 * (size_t)(N + 1) + sizeof(int) * (size_t)(N + 2) + 16 + 15) & ~(size_t)15;
 }
-template <int kP, int kG>
+template <int kP, int kG, bool kTape>
 __global__ __launch_bounds__(1024) void macro_rollout_fwd2_group_kernel(
     int L, int N, int T, double dt, double dx, double um,
     const float *__restrict__ r_in, const float *__restrict__ y_in, const float *__restrict__ u_in,
@@ -537,17 +537,20 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_group_kernel(
     int fault_step = -1, fault_index = 0, fault_lane = 0;
     int rot = 0;
     // the pair's two tape rows of a step lie side by side (rows are [step][lane])
-    float4 *tp_pair = tape ? tape + (size_t)(kG * blockIdx.x) * geo.row_f4 : nullptr;
+    float4 *tp_pair = kTape ? tape + (size_t)(kG * blockIdx.x) * geo.row_f4 : nullptr;
     const size_t tp_stride = (size_t)L * geo.row_f4;
     double rd_own[kP], yd_own[kP];
+    // where this thread's trivial-interface entries of the current step go: running pointers, one 64-bit add per pass and step
+    TapeFp *ts_own[kP];
+#pragma unroll
+    for (int j = 0; j < kP; ++j)
+        ts_own[j] = kTape ? reinterpret_cast<TapeFp *>(tp_pair + (size_t)sub * geo.row_f4) + (lo + (j << 6) + t) : nullptr;
 
     auto body = [&](auto upd_c, auto solve_c, const int n) {
         constexpr bool upd = decltype(upd_c)::value;
         constexpr bool solve = decltype(solve_c)::value;
-        float4 *tpp = solve ? tp_pair : nullptr;                        // lane a's row; lane b's follows
-        float4 *tp = tpp ? tpp + (size_t)sub * geo.row_f4 : nullptr;
-        TapeFp *tS = reinterpret_cast<TapeFp *>(tp);
-        if (tp_pair) tp_pair += tp_stride;
+        float4 *tpp = (kTape && solve) ? tp_pair : nullptr;            // lane a's row; lane b's follows
+        if (kTape) tp_pair += tp_stride;
         int *cnt = CNT + (n & 1);
 #pragma unroll
         for (int j = 0; j < kP; ++j) {
@@ -583,7 +586,10 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_group_kernel(
             arz_trivial_fast((double)ls.x, (double)ls.y, pre, kc, u0, Fr, Fy, fp);
             if (triv) FX[ic] = make_double2(Fr, Fy);
             if (!triv) Q[atomicAdd(cnt, 1)] = i;
-            if (tp) tS[ic] = TapeFp{fp[0], fp[2], fp[3]};
+            if (kTape) {
+                *ts_own[j] = TapeFp{fp[0], fp[2], fp[3]};
+                ts_own[j] = reinterpret_cast<TapeFp *>(reinterpret_cast<float4 *>(ts_own[j]) + tp_stride);
+            }
         }
         if (!solve) return;
         lds_only_barrier();
@@ -613,7 +619,7 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_group_kernel(
             arz_interface_fast_pre((double)ls.x, (double)ls.y, (double)ls.z, (double)ls.w, cl,
                                    (double)rs.x, (double)rs.y, (double)rs.z, (double)rs.w, cr, kc, f);
             region_fx(s2)[i] = make_double2(f.Fr, f.Fy);
-            if (tpp) {
+            if (kTape) {
                 float4 *row = tpp + (size_t)s2 * geo.row_f4;
                 unsigned *tH = tape_hdr(row, geo);
                 float4 *tE = row + geo.s_f4 + geo.h_f4;
@@ -937,6 +943,7 @@ __global__ __launch_bounds__(kB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (vk) DHTS_BLOCKS(T - 1, 0, slA, srA)
     if (kHist) gh_cur = ghA;                             // of step T - 1
     DHTS_LOAD_S(DHTS_ROW(T - 4), DHTS_HROW(T - 4), slA, srA, ghA);
+    lds_only_barrier();                                  // (the first interval scatters step T - 3 into the copy these blocks were read from)
 #undef DHTS_HROW
     // on entry to the interval of a step s of class A: the blocks of s are in registers, the exceptions of s - 1 in LDS;
     // (slB, srB) = S(s - 1), set C holds E(s - 2) and cqC the count of s - 5; (slC, srC) = S(s - 2), set A holds E(s - 3) and
@@ -968,6 +975,220 @@ __global__ __launch_bounds__(kB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (t == N - 1) { g_ghost[(size_t)lane * 4 + 2] = gh_r; g_ghost[(size_t)lane * 4 + 3] = gh_y; }
     }
     if (bad_step >= 0) raise_fault(err, DHTS_FAULT_NAN, bad_step, lane, k);
+}
+
+// The same sweep with TWO cells per thread (cells t and t + kB; kB + 1 < N <= 2 kB): what lanes of 1026 .. 2048 cells take
+// (kB = 1024) instead of the general kernel below.  (Measured as a replacement of the one-cell kernel at 1024 lanes x 512 cells
+// in round 2 -- four workgroups per CU, every lane resident at once -- it lost, 2.50 against 1.82 ms: the sweep is bound by
+// instruction issue and a thread with two cells issues as many instructions per cell as two threads with one.)
+// Differences to the kernel above: the exceptions' products stay in the order of their list (XA / XB [slot], slot < kB; a
+// row with more exceptions than that leaves the rest in HBM, where the cell that needs one reads it), STAMP [interface] carries
+// (step tag << 12 | slot); two register sets instead of three (tape entries two intervals in flight, counts two more), so
+// the two LDS copies are literals of the two-step loop body.
+// Dynamic LDS: float2 C0[2][P], C2[2][P] | u32 STAMP[2][P] | float4 XA[2][kB], XB[2][kB]      (P = 2 kB + 2)
+__host__ __device__ inline size_t bwd_fast2_lds_bytes(int kB) {
+    const size_t P = 2 * (size_t)kB + 2;
+    return 2 * 2 * 8 * P + 2 * 4 * P + 2 * 2 * 16 * (size_t)kB;
+}
+template <int kB, bool kFull>          // kFull: N = 2 kB, both cells of every thread exist (one basic block per interval)
+__global__ __launch_bounds__(kB) __attribute__((amdgpu_waves_per_eu(4, 4))) void macro_rollout_bwd_fast2_kernel(     // <= 128 VGPRs
+    int L, int N, int T, double cc, const float4 *__restrict__ tape,
+    const float *__restrict__ g_r_in, const float *__restrict__ g_y_in,
+    float *__restrict__ g_r_out, float *__restrict__ g_y_out, double *__restrict__ g_ghost, dhts_error *err) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = blockIdx.x;
+    const int t = threadIdx.x;
+    constexpr int B = kB;
+    constexpr int P = 2 * kB + 2;
+    float4 *XA = reinterpret_cast<float4 *>(lds), *XB = XA + 2 * kB;                  // [copy][kB]
+    v2f *C0 = reinterpret_cast<v2f *>(XB + 2 * kB), *C2 = C0 + 2 * P;                 // [copy][P]
+    unsigned *STAMP = reinterpret_cast<unsigned *>(C2 + 2 * P);                       // [copy][P]
+    const size_t base = (size_t)lane * N;
+    const TapeGeom geo = tape_geom(N);
+    const v2f cf = {(float)cc, (float)cc}, ncf = {(float)(-cc), (float)(-cc)};
+    const v2f zero2 = {0.f, 0.f}, e0 = {1.f, 0.f}, e1 = {0.f, 1.f};
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ka = t, kb = t + kB;
+    const bool va = kFull || ka < N, vb = kFull || kb < N;
+    const unsigned la = va ? ka : N - 1, lb = vb ? kb : N - 1;
+
+    for (int i = t; i < 2 * P; i += B) { C0[i] = zero2; C2[i] = zero2; STAMP[i] = 0u; }
+    v2f ga = zero2, gb = zero2;
+    if (va) ga = v2f{g_r_in[base + ka], g_y_in[base + ka]};
+    if (vb) gb = v2f{g_r_in[base + kb], g_y_in[base + kb]};
+
+    double gh_r = 0., gh_y = 0.;         // ghost cotangent sums: the thread of cell 0 the left ghost's, the thread of cell N - 1 the
+                                         // right one's (never the same thread: the launcher keeps N = kB + 1 away from this kernel)
+    int bad_step = -1;                   // (first non-finite cotangent: step << 1 | which of the two cells)
+    unsigned zv;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zv));     // keeps the count loads on the vector memory path (vmcnt, not lgkmcnt)
+    // (the entry right of cell N - 1 does not exist -- interface N is always an exception -- and is never used: its 12 bytes are
+    // read from the row's padding / header)
+    const unsigned off_la = 12u * la, off_lb = 12u * lb;
+    const unsigned off_c = 16u * geo.s_f4 + zv;
+    const unsigned off_i = 16u * geo.s_f4 + 8u + 2u * t;
+    const unsigned e_base = 16u * (geo.s_f4 + geo.h_f4);
+    const unsigned off_e = e_base + 32u * t;
+    const size_t row_bytes = 16 * geo.row_f4;
+    const char *tb = reinterpret_cast<const char *>(tape) + (size_t)lane * row_bytes;
+    const size_t stride = (size_t)L * row_bytes;
+    const char *pS = tb + (size_t)(T > 4 ? T - 4 : 0) * stride;      // row of step - 3 in the interval of `step`
+    const char *pE = tb + (size_t)(T > 5 ? T - 5 : 0) * stride;      // row of step - 4
+    const char *pC = tb + (size_t)(T > 7 ? T - 7 : 0) * stride;      // row of step - 6
+#define DHTS_ROW(step_) (tb + (size_t)((step_) > 0 ? (step_) : 0) * stride)
+#define DHTS_LOAD_CNT(rb_, c_) c_ = *reinterpret_cast<const int *>((rb_) + off_c);
+#define DHTS_LOAD_S(rb_, S_)                                                             \
+    {                                                                                    \
+        S_##la = *reinterpret_cast<const TapeFp *>((rb_) + off_la);                      \
+        S_##ra = *reinterpret_cast<const TapeFp *>((rb_) + off_la + 12);                 \
+        S_##lb = *reinterpret_cast<const TapeFp *>((rb_) + off_lb);                      \
+        S_##rb = *reinterpret_cast<const TapeFp *>((rb_) + off_lb + 12);                 \
+    }
+    // (ix_ = interface of exception t, 0xffff where the list is shorter; the list's length rides in its upper half)
+#define DHTS_LOAD_E(rb_, c_, ea_, eb_, ix_)                                              \
+    ix_ = 0xffffu | ((unsigned)(c_) << 16);                                              \
+    if (t < (c_)) {                                                                      \
+        ix_ = *reinterpret_cast<const unsigned short *>((rb_) + off_i) | ((unsigned)(c_) << 16); \
+        ea_ = *reinterpret_cast<const float4 *>((rb_) + off_e);                          \
+        eb_ = *reinterpret_cast<const float4 *>((rb_) + off_e + 16);                     \
+    }
+    // exception j = t of step_ into copy Q; its interface's stamp points to it.  Exceptions beyond the block size stay in HBM.
+#define DHTS_SCATTER(step_, Q, ea_, eb_, ix_)                                            \
+    {                                                                                    \
+        const unsigned i_ = (ix_) & 0xffffu;                                             \
+        if (i_ <= (unsigned)N) {                                                         \
+            XA[(Q) * kB + t] = ea_; XB[(Q) * kB + t] = eb_;                              \
+            STAMP[(Q) * P + i_] = (((unsigned)(step_) + 1u) << 12) | (unsigned)t;        \
+        }                                                                                \
+        if ((int)((ix_) >> 16) > B) stamp_rest(step_, (int)((ix_) >> 16), STAMP + (Q) * P); \
+    }
+    auto stamp_rest = [&](int step, int cnt, unsigned *st) {
+        const float4 *row = reinterpret_cast<const float4 *>(DHTS_ROW(step));
+        const unsigned short *I = tape_idx(tape_hdr(row, geo), geo);
+        if (cnt > N + 1) cnt = N + 1;
+        for (int j = t + B; j < cnt; j += B) {
+            const int i = I[j];
+            if (i <= N) st[i] = (((unsigned)step + 1u) << 12) | (unsigned)j;
+        }
+    };
+    // the products of interface i_ of step s_: exception (slot in LDS copy Q, or beyond the block size: in HBM) or trivial (s3_)
+#define DHTS_PRODUCTS(s_, Q, i_, s3_, A_, B_)                                            \
+    {                                                                                    \
+        const unsigned st_ = STAMP[(Q) * P + (i_)];                                      \
+        A_ = tape_trivial_A(s3_); B_ = zero4;                                            \
+        if ((st_ >> 12) == (unsigned)(s_) + 1u) {                                        \
+            const unsigned j_ = st_ & 4095u;                                             \
+            if (j_ < (unsigned)kB) { A_ = XA[(Q) * kB + j_]; B_ = XB[(Q) * kB + j_]; }   \
+            else {                                                                       \
+                const float4 *E_ = reinterpret_cast<const float4 *>(DHTS_ROW(s_) + e_base); \
+                A_ = E_[2 * j_]; B_ = E_[2 * j_ + 1];                                    \
+            }                                                                            \
+        }                                                                                \
+    }
+    // the blocks of cell k_ (suffix X_ = a / b) at step s_
+#define DHTS_BLOCKS(s_, Q, k_, sl_, sr_, X_)                                             \
+    {                                                                                    \
+        float4 aL, bL, aR, bR;                                                           \
+        DHTS_PRODUCTS(s_, Q, k_, sl_, aL, bL)                                            \
+        DHTS_PRODUCTS(s_, Q, (k_) + 1, sr_, aR, bR)                                      \
+        d0lo##X_ = ncf * -v2f{aL.x, aL.y}; d0hi##X_ = ncf * -v2f{aL.z, aL.w};            \
+        d2lo##X_ = ncf * v2f{bR.x, bR.y}; d2hi##X_ = ncf * v2f{bR.z, bR.w};              \
+        d1lo##X_ = e0 - cf * (v2f{aR.x, aR.y} - v2f{bL.x, bL.y});                        \
+        d1hi##X_ = e1 - cf * (v2f{aR.z, aR.w} - v2f{bL.z, bL.w});                        \
+    }
+    // behind the barrier: the cell's cotangent after step s + 1, its three products with the blocks of step s, their hand-over
+#define DHTS_CELL(s_, Q, R, k_, X_)                                                      \
+    {                                                                                    \
+        g##X_ = (c1##X_ + C2[(R) * P + (k_) + 1]) + C0[(R) * P + (k_) + 1];              \
+        if (bad_step < 0 && !(isfinite(g##X_.x) && isfinite(g##X_.y))) bad_step = ((((s_) + 1 < T) ? (s_) + 1 : T - 1) << 1) | ((k_) == kb); \
+        const v2f c0 = pk_dot(d0lo##X_, d0hi##X_, g##X_), c2v = pk_dot(d2lo##X_, d2hi##X_, g##X_); \
+        c1##X_ = pk_dot(d1lo##X_, d1hi##X_, g##X_);                                      \
+        C0[(Q) * P + (k_)] = c0;                                                         \
+        C2[(Q) * P + (k_) + 2] = c2v;                                                    \
+        if (__builtin_amdgcn_ballot_w64(((k_) == 0) | ((k_) == N - 1))) {                \
+            asm volatile("" ::: "memory");          /* a real branch: two wavefronts of the workgroup take it */ \
+            if ((k_) == 0) { gh_r += (double)c0.x; gh_y += (double)c0.y; }               \
+            if ((k_) == N - 1) { gh_r += (double)c2v.x; gh_y += (double)c2v.y; }         \
+        }                                                                                \
+    }
+    // One barrier interval, step s (LDS copy Q, its neighbours' copy R = 1 - Q): the two cells' chain parts, then the blocks of
+    // step s - 1 from the trivial products in set S_ and the exceptions scattered one interval ago, the exceptions of step s - 2
+    // from (ea_ .. ec_) to LDS, and the refills: exceptions of step s - 4 (count cq_), the count of step s - 6, the trivial
+    // products of step s - 3.
+#define DHTS_STEP(s_, Q, R, S_, ea_, eb_, ix_, cq_)                                      \
+    {                                                                                    \
+        if (va) DHTS_CELL(s_, Q, R, ka, a)                                               \
+        if (vb) DHTS_CELL(s_, Q, R, kb, b)                                               \
+        if ((s_) >= 1) {                                                                 \
+            if (va) DHTS_BLOCKS((s_) - 1, R, ka, S_##la, S_##ra, a)                      \
+            if (vb) DHTS_BLOCKS((s_) - 1, R, kb, S_##lb, S_##rb, b)                      \
+        }                                                                                \
+        if ((s_) >= 2) DHTS_SCATTER((s_) - 2, Q, ea_, eb_, ix_);                         \
+        DHTS_LOAD_E(pE, cq_, ea_, eb_, ix_);                                             \
+        DHTS_LOAD_CNT(pC, cq_);                                                          \
+        DHTS_LOAD_S(pS, S_);                                                             \
+        pS -= ((s_) > 3) ? stride : 0;                                                   \
+        pE -= ((s_) > 4) ? stride : 0;                                                   \
+        pC -= ((s_) > 6) ? stride : 0;                                                   \
+        lds_only_barrier();                                                              \
+    }
+    // register set A serves the steps T - 1, T - 3, ..., set B the steps T - 2, T - 4, ...
+    TapeFp SAla, SAra, SAlb, SArb, SBla, SBra, SBlb, SBrb;
+    float4 eaA = zero4, ebA = zero4, eaB = zero4, ebB = zero4;
+    unsigned ixA = 0, ixB = 0;
+    int cqA, cqB;
+    v2f d0loa = zero2, d0hia = zero2, d1loa = zero2, d1hia = zero2, d2loa = zero2, d2hia = zero2;
+    v2f d0lob = zero2, d0hib = zero2, d1lob = zero2, d1hib = zero2, d2lob = zero2, d2hib = zero2;
+    v2f c1a = ga, c1b = gb;                               // "after step T": the incoming cotangent; C0 / C2 are zero
+    DHTS_LOAD_CNT(DHTS_ROW(T - 1), cqA);
+    DHTS_LOAD_CNT(DHTS_ROW(T - 2), cqB);
+    DHTS_LOAD_E(DHTS_ROW(T - 1), cqA, eaA, ebA, ixA);
+    DHTS_LOAD_E(DHTS_ROW(T - 2), cqB, eaB, ebB, ixB);
+    DHTS_LOAD_CNT(DHTS_ROW(T - 3), cqA);
+    DHTS_LOAD_CNT(DHTS_ROW(T - 4), cqB);
+    DHTS_LOAD_S(DHTS_ROW(T - 1), SA);
+    DHTS_LOAD_S(DHTS_ROW(T - 2), SB);
+    __syncthreads();                                     // the zeroed planes
+    DHTS_SCATTER(T - 1, 0, eaA, ebA, ixA);
+    if (T >= 2) DHTS_SCATTER(T - 2, 1, eaB, ebB, ixB);
+    DHTS_LOAD_E(DHTS_ROW(T - 3), cqA, eaA, ebA, ixA);
+    DHTS_LOAD_E(DHTS_ROW(T - 4), cqB, eaB, ebB, ixB);
+    DHTS_LOAD_CNT(DHTS_ROW(T - 5), cqA);
+    DHTS_LOAD_CNT(DHTS_ROW(T - 6), cqB);
+    lds_only_barrier();
+    if (va) DHTS_BLOCKS(T - 1, 0, ka, SAla, SAra, a)
+    if (vb) DHTS_BLOCKS(T - 1, 0, kb, SAlb, SArb, b)
+    DHTS_LOAD_S(DHTS_ROW(T - 3), SA);
+    lds_only_barrier();                                  // (the first interval scatters step T - 3 into the copy these blocks were read from)
+    // on entry to the interval of a step s of class A: the blocks of s are in registers, the exceptions of s - 1 in LDS copy 1;
+    // set B holds S(s - 1) and E(s - 3), cqB the count of s - 5; set A holds S(s - 2) and E(s - 2), cqA the count of s - 4
+    int step = T - 1;
+    for (; step >= 1; step -= 2) {
+        DHTS_STEP(step, 0, 1, SB, eaA, ebA, ixA, cqA)
+        DHTS_STEP(step - 1, 1, 0, SA, eaB, ebB, ixB, cqB)
+    }
+    if (step == 0) DHTS_STEP(0, 0, 1, SB, eaA, ebA, ixA, cqA)
+    {                                                    // after step 0, whose copy is (T - 1) & 1
+        const int oq = ((T - 1) & 1) * P;
+        if (va) { ga = (c1a + C2[oq + ka + 1]) + C0[oq + ka + 1]; if (bad_step < 0 && !(isfinite(ga.x) && isfinite(ga.y))) bad_step = 0; }
+        if (vb) { gb = (c1b + C2[oq + kb + 1]) + C0[oq + kb + 1]; if (bad_step < 0 && !(isfinite(gb.x) && isfinite(gb.y))) bad_step = 1; }
+    }
+#undef DHTS_ROW
+#undef DHTS_LOAD_CNT
+#undef DHTS_LOAD_S
+#undef DHTS_LOAD_E
+#undef DHTS_SCATTER
+#undef DHTS_PRODUCTS
+#undef DHTS_BLOCKS
+#undef DHTS_CELL
+#undef DHTS_STEP
+    if (va) { g_r_out[base + ka] = ga.x; g_y_out[base + ka] = ga.y; }
+    if (vb) { g_r_out[base + kb] = gb.x; g_y_out[base + kb] = gb.y; }
+    if (g_ghost) {
+        if (ka == 0) { g_ghost[(size_t)lane * 4 + 0] = gh_r; g_ghost[(size_t)lane * 4 + 1] = gh_y; }
+        if (ka == N - 1 || kb == N - 1) { g_ghost[(size_t)lane * 4 + 2] = gh_r; g_ghost[(size_t)lane * 4 + 3] = gh_y; }
+    }
+    if (bad_step >= 0) raise_fault(err, DHTS_FAULT_NAN, bad_step >> 1, lane, (bad_step & 1) ? kb : ka);
 }
 
 // Reverse sweep over the rollout tape, any lane length (lanes above 1024 cells, single cells), per-step cotangents (g_hist) or not.
@@ -1174,6 +1395,8 @@ static inline int macro_fwd2_group(const dhts_macro_desc *d, bool want_hist) {
 }
 static inline int macro_bwd_fast_block(int N) { return N <= 64 ? 64 : (N <= 128 ? 128 : (N <= 256 ? 256 : (N <= 512 ? 512 : 1024))); }
 static inline bool macro_bwd_is_fast(int N, int T) { return N >= 2 && N <= 1024 && T > 0; }      // (T = 0: no tape to prefetch from)
+// the two-cells-per-thread sweep (1024 threads): lanes of 1026 .. 2048 cells without per-step cotangents (the step tag has 20 bits)
+static inline bool macro_bwd_is_fast2(int N, int T, bool want_hist) { return N > 1025 && N <= 2048 && T > 0 && T < (1 << 20) - 1 && !want_hist; }
 
 static int macro_fwd2_launch(const dhts_macro_desc *d, int T,
                              const float *r, const float *y, const float *u, const float *ueq, const float *ghost,
@@ -1198,11 +1421,14 @@ static int macro_fwd2_launch(const dhts_macro_desc *d, int T,
     const int G = macro_fwd2_group(d, hist != nullptr);
     if (G > 1) {
         const size_t ldsg = (size_t)G * fwd2_region_bytes(N);
-        const void *fn = G == 2 ? (const void *)macro_rollout_fwd2_group_kernel<2, 2> : (const void *)macro_rollout_fwd2_group_kernel<2, 4>;
+        const void *fn = G == 2 ? (tape ? (const void *)macro_rollout_fwd2_group_kernel<2, 2, true> : (const void *)macro_rollout_fwd2_group_kernel<2, 2, false>)
+                                : (tape ? (const void *)macro_rollout_fwd2_group_kernel<2, 4, true> : (const void *)macro_rollout_fwd2_group_kernel<2, 4, false>);
         if (ldsg > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg) != hipSuccess) return DHTS_E_LAUNCH;
 #define DHTS_FWDG_ARGS d->n_lanes, N, T, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, reinterpret_cast<float4 *>(tape), err
-        if (G == 2) macro_rollout_fwd2_group_kernel<2, 2><<<d->n_lanes / 2, 128 * W, ldsg, (hipStream_t)stream>>>(DHTS_FWDG_ARGS);
-        else macro_rollout_fwd2_group_kernel<2, 4><<<d->n_lanes / 4, 256 * W, ldsg, (hipStream_t)stream>>>(DHTS_FWDG_ARGS);
+        if (G == 2 && tape) macro_rollout_fwd2_group_kernel<2, 2, true><<<d->n_lanes / 2, 128 * W, ldsg, (hipStream_t)stream>>>(DHTS_FWDG_ARGS);
+        else if (G == 2) macro_rollout_fwd2_group_kernel<2, 2, false><<<d->n_lanes / 2, 128 * W, ldsg, (hipStream_t)stream>>>(DHTS_FWDG_ARGS);
+        else if (tape) macro_rollout_fwd2_group_kernel<2, 4, true><<<d->n_lanes / 4, 256 * W, ldsg, (hipStream_t)stream>>>(DHTS_FWDG_ARGS);
+        else macro_rollout_fwd2_group_kernel<2, 4, false><<<d->n_lanes / 4, 256 * W, ldsg, (hipStream_t)stream>>>(DHTS_FWDG_ARGS);
 #undef DHTS_FWDG_ARGS
     } else if (p == 1 && N == 64 * W && hist == nullptr)
         macro_rollout_fwd2_kernel<1, true, false><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(DHTS_FWD2_ARGS);
@@ -1294,6 +1520,22 @@ static int macro_rollout_bwd_launch(const dhts_macro_desc *d, int T, const float
         else if (kB == 512) { DHTS_BWD_FAST(512) }
         else { DHTS_BWD_FAST(1024) }
 #undef DHTS_BWD_FAST
+        return launch_status();
+    }
+    if (macro_bwd_is_fast2(N, T, g_hist != nullptr)) {
+        const size_t lds2 = bwd_fast2_lds_bytes(1024);
+        const float4 *tp = reinterpret_cast<const float4 *>(tape);
+        if (N == 2048) {
+            if (hipFuncSetAttribute((const void *)macro_rollout_bwd_fast2_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+                return DHTS_E_LAUNCH;
+            macro_rollout_bwd_fast2_kernel<1024, true><<<d->n_lanes, 1024, lds2, (hipStream_t)stream>>>(d->n_lanes, N, T, d->dt / d->dx, tp, g_r, g_y, g_r_out,
+                                                                                                     g_y_out, g_ghost, err);
+        } else {
+            if (hipFuncSetAttribute((const void *)macro_rollout_bwd_fast2_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+                return DHTS_E_LAUNCH;
+            macro_rollout_bwd_fast2_kernel<1024, false><<<d->n_lanes, 1024, lds2, (hipStream_t)stream>>>(d->n_lanes, N, T, d->dt / d->dx, tp, g_r, g_y, g_r_out,
+                                                                                                      g_y_out, g_ghost, err);
+        }
         return launch_status();
     }
     const size_t lds = sizeof(float) * (size_t)((6 * (N + 2) + 3) & ~3) + 2 * (size_t)(N + 1);
@@ -1402,8 +1644,8 @@ int dhts_macro_rollout_plan(const dhts_macro_desc *d, int T, int want_hist, int3
         plan[2] = p;
         plan[3] = ((p == 1 || p == 2) && N == 64 * p * W && !want_hist) ? 1 : 0;
     }
-    plan[4] = macro_bwd_is_fast(N, T) ? 1 : 0;
-    plan[5] = plan[4] ? macro_bwd_fast_block(N) : (padded64(N) > 512 ? 512 : padded64(N));
+    plan[4] = macro_bwd_is_fast(N, T) ? 1 : (macro_bwd_is_fast2(N, T, want_hist != 0) ? 2 : 0);
+    plan[5] = plan[4] == 1 ? macro_bwd_fast_block(N) : (plan[4] == 2 ? 1024 : (padded64(N) > 512 ? 512 : padded64(N)));
     plan[6] = want_hist ? 1 : 0;
     plan[7] = plan[0] == 0 ? macro_fwd2_group(d, want_hist != 0) : 1;
     return DHTS_OK;

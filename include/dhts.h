@@ -174,7 +174,7 @@ int dhts_macro_rollout_bwd(const dhts_macro_desc *d, int T, const float *tape,
  * the launches themselves call; tests pin the benchmarked instantiations with it):
  *   plan[0] forward kernel: 0 = two-phase, 1 = one-phase     plan[1] wavefronts per lane     plan[2] 64-cell passes per wavefront
  *   plan[3] 1 = the full-lane, history-free instantiation (n_cells = 64 x passes x wavefronts and hist == NULL)
- *   plan[4] reverse kernel: 1 = pipelined one-cell-per-thread, 0 = general     plan[5] its block size
+ *   plan[4] reverse kernel: 1 = pipelined one-cell-per-thread, 2 = pipelined two-cells-per-thread, 0 = general     plan[5] its block size
  *   plan[6] 1 = per-step cotangents / history requested (want_hist)
  *   plan[7] traffic lanes per workgroup of the two-phase forward kernel (DHTS_OPT_MACRO_FWD_GROUP) */
 int dhts_macro_rollout_plan(const dhts_macro_desc *d, int T, int want_hist, int32_t plan[8]);

@@ -229,7 +229,7 @@ def test_macro_rollout_vs_golden(cuda, golden_dir, name):
     assert rel_max(gu.grad.cpu().numpy()[0], g["g_ghost_u"]) <= TOL_GRAD
 
 
-@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 100, 127, 128, 129, 512, 1000])
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 100, 127, 128, 129, 512, 1000, 1030, 2048, 2500])
 def test_macro_rollout_vs_oracle_sizes(cuda, oracle, N):
     """Lane lengths around the 64-cell pass boundaries, several lanes, against the oracle."""
     import torch
@@ -376,11 +376,13 @@ def test_macro_rollout_short_horizons(cuda, oracle, T):
 
 
 @pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("N,T", [(2, 5), (64, 9), (130, 31), (256, 16), (512, 23), (700, 14), (1024, 11), (1100, 7)])
+@pytest.mark.parametrize("N,T", [(2, 5), (64, 9), (130, 31), (256, 16), (512, 23), (700, 14), (1024, 11), (1025, 4), (1026, 6),
+                                 (1100, 7), (1500, 9), (2047, 5), (2048, 12), (2049, 3)])
 def test_macro_reverse_sweeps_agree_on_one_tape(cuda, N, T, variant):
     """The rollout's ways from a tape to a gradient give the same bits: the pipelined one-cell-per-thread kernel (every
     block size up to 1024 cells, with and without per-step cotangents; tapes of the two-phase forward kernel and -- all
-    interfaces exceptions, more of them than threads -- of the one-phase kernel), the general kernel (lanes above 1024 cells),
+    interfaces exceptions, more of them than threads -- of the one-phase kernel), the pipelined two-cells-per-thread kernel
+    (1026 .. 2048 cells without per-step cotangents), the general kernel (everything else),
     and the single-step operator's sweep over the blocks dhts_macro_tape_expand writes out, one step at a time.  (Against the oracle:
     test_macro_rollout_vs_oracle_sizes and the goldens.)"""
     import torch
@@ -406,6 +408,9 @@ def test_macro_reverse_sweeps_agree_on_one_tape(cuda, N, T, variant):
         _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_VARIANT, 0)
     g_r, g_y = 2 * rT, torch.zeros_like(rT)
     ops.macro_u_tap_bwd(rT, yT, 2 * uT, g_r, g_y, um)
+    plan = ops.macro_rollout_plan(desc, T)
+    assert plan["bwd_pipelined"] == (1 if N <= 1024 else (2 if 1026 <= N <= 2048 else 0))
+    assert ops.macro_rollout_plan(desc, T, want_hist=True)["bwd_pipelined"] == (1 if N <= 1024 else 0)
     fast = ops.macro_rollout_bwd(desc, T, tape, g_r, g_y)
     general = ops.macro_rollout_bwd(desc, T, tape, g_r, g_y, g_hist=torch.zeros(T, L, 2, N, device=cuda))
     assert torch.equal(fast[0], general[0]) and torch.equal(fast[1], general[1]) and torch.equal(fast[2], general[2])
@@ -524,6 +529,34 @@ def test_macro_lane_groups_equal_one_lane_per_workgroup(cuda, N, group):
         assert rec[0] == _lib.FAULT_CFL and 0 <= rec[1] < T and rec[2] == bad and 0 <= rec[3] <= N, rec
     finally:
         _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_GROUP, 2)
+
+
+def test_macro_long_lane_reverse_sweep_is_repeatable(cuda):
+    """256 lanes x 2048 cells x 300 steps from random cells (the first steps queue more exceptions than the reverse sweep has
+    threads): the two-cells-per-thread reverse sweep twice and the general kernel once give the same bits.  (A missing
+    barrier behind the sweep's prologue showed up here as a difference in a few lanes per run.)"""
+    import torch
+    from dhts import ops
+    L, N, T, dt, dx, um = 256, 2048, 300, 0.01, 5.0, 30.0
+    gen = torch.Generator().manual_seed(5)
+    r = (0.05 + 0.9 * torch.rand(L, N, generator=gen)).to(cuda)
+    u = (um * torch.rand(L, N, generator=gen)).to(cuda)
+    gr = (0.05 + 0.9 * torch.rand(L, 2, generator=gen)).to(cuda)
+    gu = (um * torch.rand(L, 2, generator=gen)).to(cuda)
+    y, q = ops.macro_state_from_ru(r, u, um)
+    gy, gq = ops.macro_state_from_ru(gr, gu, um)
+    ghost = torch.stack([gr, gy, gu, gq], dim=-1).contiguous()
+    desc = ops.macro_desc(L, N, dt, dx, um)
+    assert ops.macro_rollout_plan(desc, T)["bwd_pipelined"] == 2
+    tape = torch.empty(ops.macro_tape_numel(desc, T), device=cuda)
+    out = ops.macro_rollout_fwd(desc, T, r, y, u, q, ghost, tape=tape)
+    g_r, g_y = 2 * out[0], torch.zeros_like(out[0])
+    zeros = torch.zeros(T, L, 2, N, device=cuda)
+    general = ops.macro_rollout_bwd(desc, T, tape, g_r, g_y, g_hist=zeros)
+    for _ in range(4):
+        fast = ops.macro_rollout_bwd(desc, T, tape, g_r, g_y)
+        for a, b in zip(fast, general):
+            assert torch.equal(a, b)
 
 
 def test_macro_full_size_properties(cuda):
