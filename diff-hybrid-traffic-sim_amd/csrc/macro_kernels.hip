@@ -1364,7 +1364,7 @@ static inline int grid_1d(int64_t n) {
 // forward kernel (0 = two-phase kernel, 1 = the one-phase kernel the single-step operator uses)
 static int dhts_fwd_waves_override = 0;
 static int dhts_fwd_variant = 0;
-static int dhts_fwd_group = 2;         // DHTS_OPT_MACRO_FWD_GROUP: traffic lanes per workgroup in the two-phase forward kernel (where it can)
+static int dhts_fwd_group = 0;         // DHTS_OPT_MACRO_FWD_GROUP: traffic lanes per workgroup in the two-phase forward kernel (0 = heuristic)
 static inline int padded64(int n) { return (n + 63) & ~63; }
 
 // Wavefronts per lane of the two-phase forward kernel: two 64-cell passes per wavefront whenever the lane fits 16 of them -- the
@@ -1388,7 +1388,12 @@ static inline bool macro_fwd2_fits(const dhts_macro_desc *d) {
 static inline int macro_fwd2_group(const dhts_macro_desc *d, bool want_hist) {
     int W, p;
     macro_fwd2_plan(d->n_cells, W, p);
-    const int G = dhts_fwd_group;
+    // four lanes per workgroup up to three wavefronts per lane, two at four (measured, tools/probes/exp_fwd_groups_shapes.py: 8192
+    // lanes x 128 cells 4.08 / 3.67 / 3.54 ms for 1 / 2 / 4 lanes per workgroup, 4096 x 256 3.82 / 3.45 / 3.40, 1024 x 384 1.57 /
+    // 1.52 / 1.44; at 512 cells -- sixteen wavefronts per barrier with four lanes -- 2 and 4 are within a per cent of each other
+    // either way and config 2's own data prefer 2)
+    int G = dhts_fwd_group > 0 ? dhts_fwd_group : (W <= 3 ? 4 : 2);
+    if (dhts_fwd_group == 0 && G == 4 && (d->n_lanes % 4 != 0 || d->n_lanes / 4 < 256)) G = 2;
     if (G < 2 || want_hist || p != 2 || d->n_cells != 128 * W || d->n_lanes % G != 0 || d->n_lanes / G < 256) return 1;
     if (64 * W * G > 1024 || (size_t)G * fwd2_region_bytes(d->n_cells) > 160 * 1024) return 1;
     return G;
@@ -1561,7 +1566,7 @@ int dhts_set_option(int option, int value) {
         dhts_fwd_variant = value;
         return DHTS_OK;
     }
-    if (option == DHTS_OPT_MACRO_FWD_GROUP && (value == 1 || value == 2 || value == 4)) {
+    if (option == DHTS_OPT_MACRO_FWD_GROUP && (value == 0 || value == 1 || value == 2 || value == 4)) {
         dhts_fwd_group = value;
         return DHTS_OK;
     }

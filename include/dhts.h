@@ -83,9 +83,10 @@ int dhts_device_count(void);
 /* DHTS_OPT_MACRO_FWD_VARIANT: kernel behind dhts_macro_rollout_fwd: 0 = two-phase kernel (trivial interfaces solved in
  * place, the others queued and solved compacted), 1 = the one-phase kernel of dhts_macro_step_fwd (every interface an exception).  Same tape format, same results. */
 #define DHTS_OPT_MACRO_FWD_VARIANT 3
-/* DHTS_OPT_MACRO_FWD_GROUP: traffic lanes per workgroup of the two-phase kernel, 1, 2 (default) or 4: where the lanes are full
- * (n_cells = 128 x wavefronts), no history is asked for and the launch keeps >= 256 workgroups, the queued interfaces of a
- * group's lanes are solved as one list.  Same results, same tape (dhts_macro_rollout_plan plan[7] says what a shape gets). */
+/* DHTS_OPT_MACRO_FWD_GROUP: traffic lanes per workgroup of the two-phase kernel: 0 = heuristic (default: 4 for lanes of up to
+ * three wavefronts, else 2), or 1, 2, 4.  Where the lanes are full (n_cells = 128 x wavefronts), no history is asked for and the
+ * launch keeps >= 256 workgroups, the queued interfaces of a group's lanes are solved as one list.  Same results, same tape
+ * (dhts_macro_rollout_plan plan[7] says what a shape gets). */
 #define DHTS_OPT_MACRO_FWD_GROUP 4
 int dhts_set_option(int option, int value);
 /* cells / vehicle slots rounded up to the tape's padded width (multiple of 64) */

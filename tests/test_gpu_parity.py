@@ -472,7 +472,7 @@ def test_macro_cfl_fault(cuda):
     dhts.macro_rollout(r0, u0, gr, gu, 3, 0.01, 5.0, 30.0)
 
 
-@pytest.mark.parametrize("N,group", [(128, 2), (128, 4), (256, 2), (256, 4), (512, 2)])
+@pytest.mark.parametrize("N,group", [(128, 2), (128, 4), (256, 2), (256, 4), (384, 4), (512, 2), (512, 4)])
 def test_macro_lane_groups_equal_one_lane_per_workgroup(cuda, N, group):
     """DHTS_OPT_MACRO_FWD_GROUP: the two-phase kernel with 2 or 4 traffic lanes per workgroup (one phase-2 list for the group)
     against one lane per workgroup, on lanes with vacuum cells, shocks and idle stretches: final state, the blocks the tape
@@ -500,6 +500,11 @@ def test_macro_lane_groups_equal_one_lane_per_workgroup(cuda, N, group):
         for grp in (1, group):
             assert _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_GROUP, grp) == 0
             assert ops.macro_rollout_plan(desc, T)["fwd_lanes_per_group"] == grp
+            assert _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_GROUP, 0) == 0           # the heuristic: 4 up to three wavefronts per lane
+            assert ops.macro_rollout_plan(ops.macro_desc(1024, N, dt, dx, um), T)["fwd_lanes_per_group"] == (4 if N <= 384 else 2)
+            assert ops.macro_rollout_plan(ops.macro_desc(600, N, dt, dx, um), T)["fwd_lanes_per_group"] == 2
+            assert ops.macro_rollout_plan(ops.macro_desc(300, N, dt, dx, um), T)["fwd_lanes_per_group"] == 1
+            assert _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_GROUP, grp) == 0
             assert ops.macro_rollout_plan(desc, T, want_hist=True)["fwd_lanes_per_group"] == 1
             assert ops.macro_rollout_plan(ops.macro_desc(L - 1, N, dt, dx, um), T)["fwd_lanes_per_group"] == 1
             assert ops.macro_rollout_plan(ops.macro_desc(L, N - 1, dt, dx, um), T)["fwd_lanes_per_group"] == 1
@@ -528,7 +533,7 @@ def test_macro_lane_groups_equal_one_lane_per_workgroup(cuda, N, group):
         rec = err.cpu().numpy()
         assert rec[0] == _lib.FAULT_CFL and 0 <= rec[1] < T and rec[2] == bad and 0 <= rec[3] <= N, rec
     finally:
-        _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_GROUP, 2)
+        _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_GROUP, 0)
 
 
 def test_macro_long_lane_reverse_sweep_is_repeatable(cuda):
