@@ -477,8 +477,8 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
 // history): each lane keeps its own records, fluxes and queue -- phase 1 is the kernel above, per lane -- but phase 2 takes the
 // lanes' queues as one list (entry g belongs to the lane whose prefix sum of queue lengths it falls in).  At config 2 a lane
 // queues ~76 interfaces, which is two wavefronts' worth of the full solve's instruction stream (64 + 12 entries); a pair of lanes
-// needs three (64 + 64 + 24).  Measured at config 2 (MI355X, profiles/r03v_macro_fwd_lane_groups.log): one lane per workgroup
-// 3.39 ms, two 3.22 ms, four 3.34 ms (five wavefronts' worth for four lanes, but every barrier then spans 16 wavefronts).
+// needs three (64 + 64 + 24).  Measured at config 2 (MI355X, profiles/r03x_macro_fwd_lane_groups.log): one lane per workgroup
+// 3.29-3.39 ms, two 3.13-3.22 ms, four 3.15-3.34 ms (five wavefronts' worth for four lanes, but every barrier then spans 16 wavefronts).
 // Results and tape are bit-identical to the one-lane kernel's.  Dynamic LDS: kG regions of fwd2_region_bytes(N), one per lane.
 __host__ __device__ inline size_t fwd2_region_bytes(int N) {
     return (sizeof(CellRec) * (size_t)(N + 2) + 16 * (size_t)(N + 1) + sizeof(int) * (size_t)(N + 2) + 16 + 15) & ~(size_t)15;
