@@ -64,7 +64,11 @@ __device__ __forceinline__ NetStaged net_staged(char *lds, size_t base, int L, i
 // float(a > progress) (_env.py:928-960), the downstream ghost takes float(signal > 0.5) (_simulator.py:128-137), a cell is static
 // when u < static_speed (_env.py:607-617: no running mean, no sigmoid); nothing is kept for a reverse sweep (hist, tape, kc and
 // own_hist are not touched and may be NULL).
-template <bool kHard>
+// kLossWaves: the loss of the previous state is evaluated by wavefronts of its own (threads [Bp, B): one per cell, the first L
+// of them also one per lane) beside the physics threads [0, Bp) instead of by the same threads behind their physics role -- the
+// two are independent within a phase, and a phase then lasts as long as the longer of them, not as their sum.  Taken when
+// pad64(C + L) + pad64(C) threads fit a workgroup.
+template <bool kHard, bool kLossWaves>
 __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
                                      double static_speed, double veh_len, NetTables tb, const float *__restrict__ action,
                                      float *__restrict__ hist, float4 *__restrict__ tape, float *__restrict__ kc,
@@ -109,7 +113,15 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
     }
     __syncthreads();
     // ---- per-thread roles
-    const bool is_if = tid < NI, is_cell = tid < C, is_ghost = tid < 2 * L, is_lane = tid < L;
+    const int Bp = kLossWaves ? B - Cp : 0;         // loss threads start here
+    const int lt = kLossWaves ? tid - Bp : tid;     // index of a loss thread (negative: a physics-only thread)
+    const bool is_phys = !kLossWaves || tid < Bp;
+    const bool is_if = is_phys && tid < NI, is_cell = is_phys && tid < C;
+    const bool is_lcell = lt >= 0 && lt < C, is_llane = lt >= 0 && lt < L;
+    // ghost threads by side: the left ghosts on threads [0, L), the right ones from the next wavefront boundary on where the
+    // physics threads reach that far (a wavefront then runs one side's branch, not both)
+    const int gb1 = (((L + 63) & ~63) + L <= (kLossWaves ? Bp : B)) ? ((L + 63) & ~63) : L;
+    const bool is_ghost = is_phys && (tid < L || (tid >= gb1 && tid < gb1 + L));
     int i_lane = 0, i_k = 0, i_n = 0, i_off = 0;
     IfaceConst kconst;
     kconst.set_um(um_d); kconst.set_grid(dt, 1.0);
@@ -118,13 +130,14 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
         kconst.set_grid(dt, tb.lane_dx[i_lane]);
     }
     int c_lane = 0; double c_cc = 0.; float c_dxv = 0.f;
-    if (is_cell) { c_lane = cell_lane_s[tid]; c_cc = dt / tb.lane_dx[c_lane]; c_dxv = (float)tb.lane_dx[c_lane] / (float)veh_len; }
-    const int g_lane = tid >> 1, g_side = tid & 1;
+    if (is_cell) { c_lane = cell_lane_s[tid]; c_cc = dt / tb.lane_dx[c_lane]; }
+    if (is_lcell) c_dxv = (float)tb.lane_dx[cell_lane_s[lt]] / (float)veh_len;
+    const int g_side = tid >= gb1 ? 1 : 0, g_lane = is_ghost ? (g_side ? tid - gb1 : tid) : 0;
     int g_kind = 0, g_inter = 0;
     float own_r = 0.f, own_u = um;                    // stored downstream ghost of a sink lane (side-1 thread)
     if (is_ghost) { g_kind = tb.sig_kind[g_lane]; g_inter = tb.inter[g_lane]; }
     int l_off = 0, l_n = 0;
-    if (is_lane) { l_off = tb.lane_off[tid]; l_n = tb.lane_ncell[tid]; }
+    if (is_llane) { l_off = tb.lane_off[lt]; l_n = tb.lane_ncell[lt]; }
     __syncthreads();        // setup maps are dead from here on (their LDS is not reused)
 
     // per-step tables, one step ahead.  Unconditional loads with clamped indices: a load inside a divergent branch merges
@@ -159,10 +172,11 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
     double l_incl = 0., l_incl_out = 0.;
     auto loss_scan = [&](const float *st) {          // phase 1: wave-level inclusive scans over the cells in order
         if (kHard) return;                           // (no running mean in an evaluation episode)
+        if (kLossWaves && lt < 0) return;
         double a = 0., b = 0.;
-        if (is_cell) {
-            a = (double)(s0f - st[2 * C + tid]);     // x = s0 - u
-            const long long idx = run_cnt + tid;
+        if (is_lcell) {
+            a = (double)(s0f - st[2 * C + lt]);      // x = s0 - u
+            const long long idx = run_cnt + lt;
             if (idx >= kNetWindow) {
                 if (old_row < 0) { const long long j = idx - kNetWindow; old_row = (int)(j / C) + 1; old_cell = (int)(j % C); }
                 else ++old_row;                      // idx grows by C per step: the same cell, one history row later
@@ -172,37 +186,45 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
         }
         l_incl = wave_scan_add(a);
         l_incl_out = wave_scan_add(b);
-        if ((tid & 63) == 63) { scanw[tid >> 6] = l_incl; scanw[16 + (tid >> 6)] = l_incl_out; }
+        if ((lt & 63) == 63) { scanw[lt >> 6] = l_incl; scanw[16 + (lt >> 6)] = l_incl_out; }
     };
     auto loss_consts = [&](const float *st, int ls) { // phase 2: k_c and the cell's contribution to its lane queue
         if (kHard) {                                 // is_static = 1.0 if speed < static_speed else 0.0 (_env.py:607-617)
-            if (is_cell) contrib[tid] = (st[2 * C + tid] < s0f ? 1.f : 0.f) * (st[tid] * c_dxv);
+            if (is_lcell) contrib[lt] = (st[2 * C + lt] < s0f ? 1.f : 0.f) * (st[lt] * c_dxv);
             return;
         }
-        const int wv = tid >> 6, nw = B >> 6;
+        if (kLossWaves && lt < 0) return;
+        const int wv = lt >> 6, nw = (B - Bp) >> 6;
         double base_a = 0., tot_a = 0., base_b = 0., tot_b = 0.;
         for (int k = 0; k < nw; ++k) {
             const double va = scanw[k], vb = scanw[16 + k];
             if (k < wv) { base_a += va; base_b += vb; }
             tot_a += va; tot_b += vb;
         }
-        if (is_cell) {
-            const long long n = run_cnt + tid + 1;
+        if (is_lcell) {
+            const long long n = run_cnt + lt + 1;
             const double pin = run_in + base_a + l_incl, pout = run_out + base_b + l_incl_out;
             const bool full = n > kNetWindow;         // one IEEE division, operands selected first
             const double mean = (full ? pin - pout : pin) / (full ? (double)kNetWindow : (double)n);
             const float kk = 16.f / fabsf((float)mean);
-            kc_r[(size_t)ls * C + tid] = kk;
-            contrib[tid] = soft_switch(s0f - st[2 * C + tid], kk) * (st[tid] * c_dxv);
+            kc_r[(size_t)ls * C + lt] = kk;
+            contrib[lt] = soft_switch(s0f - st[2 * C + lt], kk) * (st[lt] * c_dxv);
         }
         run_in += tot_a; run_out += tot_b; run_cnt += C;
     };
     auto loss_lanes = [&](int ls) {                   // phase 3: q = sum of the lane's cells, term q^2 dt
-        if (is_lane) {
+        if (is_llane) {
+            // q = the lane's cells added in order (float32, as the reference does); the loads go out eight at a time
             float q = 0.f;
-            for (int i = 0; i < l_n; ++i) q = q + contrib[l_off + i];
+            for (int i0 = 0; i0 < l_n; i0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = contrib[l_off + (i0 + j < l_n ? i0 + j : l_n - 1)];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (i0 + j < l_n) q = q + v[j];
+            }
             const float term = (q * q) * (float)dt;
-            queue_r[(size_t)ls * L + tid] = term;
+            queue_r[(size_t)ls * L + lt] = term;
             lane_total = lane_total + (-1.0f) * term;
         }
     };
@@ -243,7 +265,7 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
                 glue_from_r_u(fr, fu, um, fy, fq);
                 own_r = fr; own_u = fu;
             }
-            float *g = G + (size_t)tid * 4;
+            float *g = G + (size_t)(2 * g_lane + g_side) * 4;
             g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
         }
         if (t > 0) loss_scan(cur);
@@ -303,7 +325,7 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
         loss_lanes(T - 1);
     }
     // reward = - sum over lanes (outer) and steps (inner) of the queue terms (_env.py:770-797)
-    if (is_lane) ql[tid] = lane_total;
+    if (is_llane) ql[lt] = lane_total;
     __syncthreads();
     if (tid == 0) {
         float rew = 0.f;
@@ -591,6 +613,12 @@ static inline int net_block(const dhts_net_desc *d) {
     if (need < d->n_action) need = d->n_action;
     return (need + 63) & ~63;
 }
+// forward kernels: wavefronts of their own for the loss where they fit the workgroup
+static inline int net_fwd_block(const dhts_net_desc *d, bool &loss_waves) {
+    const int Bp = net_block(d), B = Bp + ((d->n_cells + 63) & ~63);
+    loss_waves = B <= 1024;
+    return loss_waves ? B : Bp;
+}
 static inline NetTables net_tables(const dhts_net_tables *t) {
     NetTables n;
     n.lane_ncell = t->lane_ncell; n.lane_off = t->lane_off; n.sig_kind = t->sig_kind; n.inter = t->inter; n.lane_dx = t->lane_dx;
@@ -618,15 +646,19 @@ int dhts_net_macro_rollout_fwd(const dhts_net_desc *d, const dhts_net_tables *t,
                                float *kc, float *queue, float *reward, float *workspace, dhts_error *err, void *stream) {
     if (!net_desc_ok(d) || !net_tables_ok(t) || !action || !hist || !tape || !kc || !queue || !reward || !workspace)
         return DHTS_E_INVALID;
-    const int B = net_block(d), L = d->n_lanes, C = d->n_cells;
+    bool lw;
+    const int B = net_fwd_block(d, lw), L = d->n_lanes, C = d->n_cells;
     const size_t lds = net_fwd_lds_base(L, C) + net_staged_bytes(L, d->n_inter_sq, d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)net_macro_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        (hipFuncSetAttribute((const void *)net_macro_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+         hipFuncSetAttribute((const void *)net_macro_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess))
         return DHTS_E_LAUNCH;
-    net_macro_fwd_kernel<false><<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
-        d->n_replicas, L, C, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max, d->static_speed,
-        d->vehicle_length, net_tables(t), action, hist, reinterpret_cast<float4 *>(tape), kc, queue, reward, workspace, err);
+#define DHTS_NET_FWD_ARGS d->n_replicas, L, C, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max, d->static_speed, \
+        d->vehicle_length, net_tables(t), action, hist, reinterpret_cast<float4 *>(tape), kc, queue, reward, workspace, err
+    if (lw) net_macro_fwd_kernel<false, true><<<d->n_replicas, B, lds, (hipStream_t)stream>>>(DHTS_NET_FWD_ARGS);
+    else net_macro_fwd_kernel<false, false><<<d->n_replicas, B, lds, (hipStream_t)stream>>>(DHTS_NET_FWD_ARGS);
+#undef DHTS_NET_FWD_ARGS
     return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
 }
 
@@ -637,9 +669,9 @@ int dhts_net_macro_rollout_eval(const dhts_net_desc *d, const dhts_net_tables *t
     const size_t lds = net_fwd_lds_base(L, C) + net_staged_bytes(L, d->n_inter_sq, d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)net_macro_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        hipFuncSetAttribute((const void *)net_macro_fwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_LAUNCH;
-    net_macro_fwd_kernel<true><<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
+    net_macro_fwd_kernel<true, false><<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
         d->n_replicas, L, C, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max, d->static_speed,
         d->vehicle_length, net_tables(t), action, nullptr, nullptr, nullptr, queue, reward, nullptr, err);
     return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
