@@ -369,7 +369,9 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
     const float *queue_r = queue + (size_t)rep * T * L;
     const float *own_r = own_hist + (size_t)rep * T * 2 * L;
     const float gscale = g_reward ? g_reward[rep] : 1.f;
-    const bool is_cell = tid < C, is_ghost = tid < 2 * L, is_lane = tid < L;
+    // ghost threads by side, as in the forward kernel: left ghosts on threads [0, L), right ones from the next wavefront boundary
+    const int gb1 = (((L + 63) & ~63) + L <= (int)blockDim.x) ? ((L + 63) & ~63) : L;
+    const bool is_cell = tid < C, is_ghost = tid < L || (tid >= gb1 && tid < gb1 + L), is_lane = tid < L;
 
     if (is_lane) {
         const int off = tb.lane_off[tid], n = tb.lane_ncell[tid];
@@ -378,13 +380,14 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
         linfo[tid] = tb.sig_kind[tid] | (tb.inter[tid] << 2);
     }
     for (int k = tid; k < 2 * E; k += blockDim.x) { inL[k] = 0.f; inF[k] = 0.f; }
+    for (int k = tid; k < 16 * sq; k += blockDim.x) red[k] = 0.;      // (wavefronts without ghost threads never write theirs)
     __syncthreads();
     int c_lane = 0, c_first = 0, c_last = 0; float c_dxv = 0.f;
     if (is_cell) {
         c_lane = cell_lane_s[tid]; c_first = tb.lane_off[c_lane]; c_last = c_first + tb.lane_ncell[c_lane] - 1;
         c_dxv = (float)tb.lane_dx[c_lane] / (float)veh_len;
     }
-    const int g_lane = tid >> 1, g_side = tid & 1;
+    const int g_side = tid >= gb1 ? 1 : 0, g_lane = is_ghost ? (g_side ? tid - gb1 : tid) : 0;
     int g_kind = 0, g_inter = 0, g_off = 0, g_n = 0;
     if (is_ghost) { g_kind = tb.sig_kind[g_lane]; g_inter = tb.inter[g_lane]; g_off = tb.lane_off[g_lane]; g_n = tb.lane_ncell[g_lane]; }
 
@@ -560,12 +563,13 @@ __global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, 
             }
             my_aval = a_val; my_akey = a_key;
         }
-        // action cotangent: per intersection, fixed-shape reduction (wave butterfly in double, then the wave partials)
-        for (int q = 0; q < sq; ++q) {
-            double v = (my_akey == q) ? (double)my_aval : 0.0;
-            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-            if ((tid & 63) == 0) red[(tid >> 6) * sq + q] = v;
-        }
+        // action cotangent: per intersection, fixed-shape reduction in double (the wavefront's sum by DPP moves, then the wave
+        // partials); only the wavefronts that hold ghost threads have anything to add
+        if (__any(is_ghost))
+            for (int q = 0; q < sq; ++q) {
+                const double v = wave_scan_add((my_akey == q) ? (double)my_aval : 0.0);
+                if ((tid & 63) == 63) red[(tid >> 6) * sq + q] = v;
+            }
         lds_barrier();
         // ---- phase D: edge cells take their inbox entries in ascending slot order (lane id ascending, upstream ghost of
         //      lane n = slot 2n before downstream ghost of lane m = slot 2m+1), then clear them; action partials are summed
