@@ -713,11 +713,14 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         const int *vcp_l = vcp_of(ls);
         const int nwc = (C + 63) >> 6;
         tot_a = 0.; tot_b = 0.;
-        for (int w = 0; w < nwc; ++w) { tot_a += scanw[w]; tot_b += scanw[16 + w]; }
+        const int wv = tid >> 6;
+        double base_a = 0., base_b = 0.;                 // (one pass over the wave totals: the sums in front of this wavefront and all)
+        for (int w = 0; w < nwc; ++w) {
+            const double sa = scanw[w], sb = scanw[16 + w];
+            if (w < wv) { base_a += sa; base_b += sb; }
+            tot_a += sa; tot_b += sb;
+        }
         if (is_cell) {
-                const int wv = tid >> 6;
-                double base_a = 0., base_b = 0.;
-                for (int w = 0; w < wv; ++w) { base_a += scanw[w]; base_b += scanw[16 + w]; }
                 const long long n = run_cnt + tid + vcp_l[c_mb] + 1;
                 const double pin = run_in + base_a + incl[tid] + vsp[c_mb];
                 const double pout = run_out + base_b + incl[C + tid] + vep[c_mb];
@@ -799,9 +802,16 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         if (is_lane) {
             float term;
             if (l_macro) {
+                // q = the lane's cells added in order (float32, as the reference does); the loads go out eight at a time
                 float q = 0.f;
                 const float *contrib_r = contrib + (ls & 1) * C;
-                for (int i = 0; i < l_n; ++i) q = q + contrib_r[l_off + i];
+                for (int i0 = 0; i0 < l_n; i0 += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = contrib_r[l_off + (i0 + j < l_n ? i0 + j : l_n - 1)];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (i0 + j < l_n) q = q + v[j];
+                }
                 term = (q * q) * dtf;
             } else term = l_ms >= 0 ? qmicro[(ls & 1) * kMaxMicro + l_ms] : 0.f;
             queue_r[(size_t)ls * L + tid] = term;

@@ -377,7 +377,7 @@ def test_macro_rollout_short_horizons(cuda, oracle, T):
 
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("N,T", [(2, 5), (64, 9), (130, 31), (256, 16), (512, 23), (700, 14), (1024, 11), (1025, 4), (1026, 6),
-                                 (1100, 7), (1500, 9), (2047, 5), (2048, 12), (2049, 3)])
+                                 (1100, 7), (1500, 1), (1500, 2), (1500, 9), (2047, 5), (2048, 12), (2049, 3)])
 def test_macro_reverse_sweeps_agree_on_one_tape(cuda, N, T, variant):
     """The rollout's ways from a tape to a gradient give the same bits: the pipelined one-cell-per-thread kernel (every
     block size up to 1024 cells, with and without per-step cotangents; tapes of the two-phase forward kernel and -- all
