@@ -713,12 +713,12 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         const int *vcp_l = vcp_of(ls);
         const int nwc = (C + 63) >> 6;
         tot_a = 0.; tot_b = 0.;
-        const int wv = tid >> 6;
-        double base_a = 0., base_b = 0.;                 // (one pass over the wave totals: the sums in front of this wavefront and all)
+        // the wave totals added in order: the sum in front of this wavefront (a scalar, so is the loop) and the sum of all
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        double base_a = 0., base_b = 0.;
         for (int w = 0; w < nwc; ++w) {
-            const double sa = scanw[w], sb = scanw[16 + w];
-            if (w < wv) { base_a += sa; base_b += sb; }
-            tot_a += sa; tot_b += sb;
+            if (w == wv) { base_a = tot_a; base_b = tot_b; }
+            tot_a += scanw[w]; tot_b += scanw[16 + w];
         }
         if (is_cell) {
                 const long long n = run_cnt + tid + vcp_l[c_mb] + 1;

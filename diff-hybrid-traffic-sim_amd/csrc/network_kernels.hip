@@ -194,12 +194,12 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
             return;
         }
         if (kLossWaves && lt < 0) return;
-        const int wv = lt >> 6, nw = (B - Bp) >> 6;
+        // the wave totals added in order: the sum in front of this wavefront (a scalar, so is the loop) and the sum of all
+        const int wv = __builtin_amdgcn_readfirstlane(lt >> 6), nw = (B - Bp) >> 6;
         double base_a = 0., tot_a = 0., base_b = 0., tot_b = 0.;
         for (int k = 0; k < nw; ++k) {
-            const double va = scanw[k], vb = scanw[16 + k];
-            if (k < wv) { base_a += va; base_b += vb; }
-            tot_a += va; tot_b += vb;
+            if (k == wv) { base_a = tot_a; base_b = tot_b; }
+            tot_a += scanw[k]; tot_b += scanw[16 + k];
         }
         if (is_lcell) {
             const long long n = run_cnt + lt + 1;
@@ -229,6 +229,15 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
         }
     };
 
+    // Phase timing (-DDHTS_NET_STAMPS builds only: SRC=network_kernels tools/build_variants.sh stamps:"-DDHTS_NET_STAMPS", then
+    // DHTS_LIB=.../variants/libdhts_stamps.so python bench.py --workload itscp_macro --steps 1 --warmup 0 --no-cpu-baseline
+    // --no-also): replica 0 prints, per wavefront, the cycles per step in front of each stamp (either role) and at the barriers.
+#ifdef DHTS_NET_STAMPS
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#define NET_STAMP(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long a_ = __builtin_amdgcn_s_memtime(); st_acc[i] += a_ - st_last; st_last = a_; }
+#else
+#define NET_STAMP(i)
+#endif
     for (int t = 0; t < T; ++t) {
         const float *cur = (t & 1) ? S1 : S0;
         float *nxt = (t & 1) ? S0 : S1;
@@ -268,8 +277,11 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
             float *g = G + (size_t)(2 * g_lane + g_side) * 4;
             g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
         }
+        NET_STAMP(0)
         if (t > 0) loss_scan(cur);
+        NET_STAMP(1)
         lds_barrier();
+        NET_STAMP(6)
         // ---- phase 2: interface solves | loss constants
         if (is_if) {
             const float *gl = G + (size_t)(2 * i_lane) * 4, *gr_ = G + (size_t)(2 * i_lane + 1) * 4;
@@ -286,8 +298,11 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
             ab[0] = f.A[0]; ab[1] = f.A[1]; ab[2] = f.A[2]; ab[3] = f.A[3];
             ab[4] = f.B[0]; ab[5] = f.B[1]; ab[6] = f.B[2]; ab[7] = f.B[3];
         }
+        NET_STAMP(2)
         if (t > 0) loss_consts(cur, t - 1);
+        NET_STAMP(3)
         lds_barrier();
+        NET_STAMP(6)
         // ---- phase 3: cell updates + tape + history (_macro_lane.py:103-114, dmacro_lane.py:126-129) | lane queues
         if (is_cell) {
             const int c = tid;
@@ -311,10 +326,19 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
                 tp[c] = d0; tp[Cp + c] = d1; tp[2 * Cp + c] = d2;
             }
         }
+        NET_STAMP(4)
         if (t > 0) loss_lanes(t - 1);
         if (t + 1 < T) signals();            // of step t + 1 (this step's ghosts read theirs two barriers ago)
+        NET_STAMP(5)
         lds_barrier();
+        NET_STAMP(6)
     }
+#ifdef DHTS_NET_STAMPS
+    if (rep == 0 && (tid & 63) == 0 && T > 0)
+        printf("wave %d: ghosts %lld scan %lld | solve %lld consts %lld | update %lld lanes + signals %lld | barriers %lld  (cycles per step)\n", tid >> 6,
+               st_acc[0] / T, st_acc[1] / T, st_acc[2] / T, st_acc[3] / T, st_acc[4] / T, st_acc[5] / T, st_acc[6] / T);
+#endif
+#undef NET_STAMP
     // loss of the final state
     if (T > 0) {
         const float *fin = (T & 1) ? S1 : S0;
