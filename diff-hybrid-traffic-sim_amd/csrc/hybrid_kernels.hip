@@ -594,20 +594,24 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         const int m = mw < n_micro ? mlane[mw] : 0;
         my_sched = tb.net.schedule[toff + (size_t)(step < T ? step : T - 1) * L + m];
     };
+    // how many lanes below this one have their bit set in a ballot (mbcnt: no 64-bit lane mask kept in registers)
+    auto lanes_below = [](unsigned long long m) {
+        return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    };
     auto source_admit = [&](int step) {              // micro wave, all lanes; `step` = the step whose boundary this is
         const int k = mw;
         float room = 0.f;
         if (my_src) room = lane_n[k] ? vp[lane_veh[k * kLaneCap + 0]] - 0.5f * vlen : lanelen[mlane[k]];
         const bool want = my_src && room > vlen * 0.5f;
         const unsigned long long bw = __ballot(want);
-        const int rank = __popcll(bw & ((1ull << mw) - 1ull));
+        const int rank = lanes_below(bw);
         const double draw = __shfl(my_draw, rank);   // lane j holds draws[draw_base + j]
         if (want && draw_base + rank >= tb.n_draws) cap_fault = true;
         const bool admit = want && draw < my_sched && rused[k < n_micro ? k : 0] < my_rn;
         draw_base += __popcll(bw);
         const unsigned long long ba = __ballot(admit);
         if (admit) {
-            const int vi = spawned + __popcll(ba & ((1ull << mw) - 1ull));
+            const int vi = spawned + lanes_below(ba);
             if (vi >= V || lane_n[k] >= kLaneCap) cap_fault = true;
             else {
                 const size_t row = (size_t)(my_rlo + rused[k]);

@@ -68,8 +68,10 @@ __device__ __forceinline__ NetStaged net_staged(char *lds, size_t base, int L, i
 // of them also one per lane) beside the physics threads [0, Bp) instead of by the same threads behind their physics role -- the
 // two are independent within a phase, and a phase then lasts as long as the longer of them, not as their sum.  Taken when
 // pad64(C + L) + pad64(C) threads fit a workgroup.
-template <bool kHard, bool kLossWaves>
-__global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
+// kMaxBlock: the launch's block size is at most this (512, 640 or 1024 threads: 256, 168 or 128 vector registers per thread --
+// at the 128 of an unbounded kernel the step loop reloaded spilled values from scratch).
+template <bool kHard, bool kLossWaves, int kMaxBlock>
+__global__ void __launch_bounds__(kMaxBlock) net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
                                      double static_speed, double veh_len, NetTables tb, const float *__restrict__ action,
                                      float *__restrict__ hist, float4 *__restrict__ tape, float *__restrict__ kc,
                                      float *__restrict__ queue, float *__restrict__ reward, float *__restrict__ own_hist,
@@ -363,7 +365,8 @@ __global__ void net_macro_fwd_kernel(int R, int L, int C, int T, int sq, int F, 
 // ahead into registers.
 // LDS floats: H0, H1 [3][C] (history rows r, y, u; ping-pong) | c0, c2 [2][C] | gq [L] | inL, inF [E][2] | doubles red [16][sq]
 // Limits (checked on the host side of the Python layer): a lane has at most 4 upstream and 4 downstream neighbours.
-__global__ void net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
+template <int kMaxBlock>
+__global__ void __launch_bounds__(kMaxBlock) net_macro_bwd_kernel(int R, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
                                      double static_speed, double veh_len, NetTables tb, const float *__restrict__ action,
                                      const float *__restrict__ hist, const float4 *__restrict__ tape,
                                      const float *__restrict__ kc, const float *__restrict__ queue,
@@ -678,14 +681,21 @@ int dhts_net_macro_rollout_fwd(const dhts_net_desc *d, const dhts_net_tables *t,
     const int B = net_fwd_block(d, lw), L = d->n_lanes, C = d->n_cells;
     const size_t lds = net_fwd_lds_base(L, C) + net_staged_bytes(L, d->n_inter_sq, d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
-    if (lds > 64 * 1024 &&
-        (hipFuncSetAttribute((const void *)net_macro_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-         hipFuncSetAttribute((const void *)net_macro_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess))
-        return DHTS_E_LAUNCH;
 #define DHTS_NET_FWD_ARGS d->n_replicas, L, C, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max, d->static_speed, \
         d->vehicle_length, net_tables(t), action, hist, reinterpret_cast<float4 *>(tape), kc, queue, reward, workspace, err
-    if (lw) net_macro_fwd_kernel<false, true><<<d->n_replicas, B, lds, (hipStream_t)stream>>>(DHTS_NET_FWD_ARGS);
-    else net_macro_fwd_kernel<false, false><<<d->n_replicas, B, lds, (hipStream_t)stream>>>(DHTS_NET_FWD_ARGS);
+#define DHTS_NET_FWD_LAUNCH(LW, MB)                                                                                                   \
+    {                                                                                                                                 \
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)net_macro_fwd_kernel<false, LW, MB>,                                 \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)              \
+            return DHTS_E_LAUNCH;                                                                                                     \
+        net_macro_fwd_kernel<false, LW, MB><<<d->n_replicas, B, lds, (hipStream_t)stream>>>(DHTS_NET_FWD_ARGS);                       \
+    }
+    if (lw) {
+        if (B <= 512) DHTS_NET_FWD_LAUNCH(true, 512) else if (B <= 640) DHTS_NET_FWD_LAUNCH(true, 640) else DHTS_NET_FWD_LAUNCH(true, 1024)
+    } else {
+        if (B <= 512) DHTS_NET_FWD_LAUNCH(false, 512) else if (B <= 640) DHTS_NET_FWD_LAUNCH(false, 640) else DHTS_NET_FWD_LAUNCH(false, 1024)
+    }
+#undef DHTS_NET_FWD_LAUNCH
 #undef DHTS_NET_FWD_ARGS
     return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
 }
@@ -697,9 +707,9 @@ int dhts_net_macro_rollout_eval(const dhts_net_desc *d, const dhts_net_tables *t
     const size_t lds = net_fwd_lds_base(L, C) + net_staged_bytes(L, d->n_inter_sq, d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)net_macro_fwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        hipFuncSetAttribute((const void *)net_macro_fwd_kernel<true, false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_LAUNCH;
-    net_macro_fwd_kernel<true, false><<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
+    net_macro_fwd_kernel<true, false, 1024><<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
         d->n_replicas, L, C, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max, d->static_speed,
         d->vehicle_length, net_tables(t), action, nullptr, nullptr, nullptr, queue, reward, nullptr, err);
     return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
@@ -714,12 +724,18 @@ int dhts_net_macro_rollout_bwd(const dhts_net_desc *d, const dhts_net_tables *t,
     const int E = t->n_edges > 0 ? t->n_edges : 1;
     const size_t lds = net_bwd_lds_base(L, C, E, d->n_inter_sq) + net_staged_bytes(L, d->n_inter_sq, d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)net_macro_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return DHTS_E_LAUNCH;
-    net_macro_bwd_kernel<<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
-        d->n_replicas, L, C, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max, d->static_speed,
-        d->vehicle_length, net_tables(t), action, hist, reinterpret_cast<const float4 *>(tape), kc, queue, g_reward, g_action, workspace, err);
+#define DHTS_NET_BWD_LAUNCH(MB)                                                                                                       \
+    {                                                                                                                                 \
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)net_macro_bwd_kernel<MB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                   (int)lds) != hipSuccess)                                                          \
+            return DHTS_E_LAUNCH;                                                                                                     \
+        net_macro_bwd_kernel<MB><<<d->n_replicas, B, lds, (hipStream_t)stream>>>(                                                     \
+            d->n_replicas, L, C, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max, d->static_speed,       \
+            d->vehicle_length, net_tables(t), action, hist, reinterpret_cast<const float4 *>(tape), kc, queue, g_reward, g_action,    \
+            workspace, err);                                                                                                          \
+    }
+    if (B <= 512) DHTS_NET_BWD_LAUNCH(512) else DHTS_NET_BWD_LAUNCH(1024)
+#undef DHTS_NET_BWD_LAUNCH
     return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
 }
 
