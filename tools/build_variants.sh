@@ -13,7 +13,8 @@ FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-pa
 SRC=${SRC:-macro_kernels}
 for spec in "$@"; do
   name=${spec%%:*}; defs=${spec#*:}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -c -o "$C/variants/${SRC}_$name.o" "$C/$SRC.hip"
+  EXTRA=""; [ "$SRC" = hybrid_kernels ] && EXTRA="-mllvm -disable-lsr"      # (the product's per-file flags, csrc/Makefile)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $EXTRA $defs -c -o "$C/variants/${SRC}_$name.o" "$C/$SRC.hip"
   OBJS=""
   for u in dhts_common macro_kernels micro_kernels network_kernels hybrid_kernels; do
     if [ "$u" = "$SRC" ]; then OBJS="$OBJS $C/variants/${SRC}_$name.o"; else OBJS="$OBJS $C/$u.o"; fi
