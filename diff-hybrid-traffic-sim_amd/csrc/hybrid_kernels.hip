@@ -1834,7 +1834,8 @@ int dhts_net_hybrid_rollout_fwd(const dhts_net_desc *d, const dhts_hybrid_tables
     if (stage_h < 8) return DHTS_E_INVALID;       // (a lane with one vehicle stages ~10 records in a step with a hand-off)
     const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, stage_h).total + up16(sizeof(float) * (size_t)d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
-    auto kern = B <= 512 ? net_hybrid_fwd_kernel<512, false> : net_hybrid_fwd_kernel<1024, false>;
+    // (the block-size bound sets the vector registers a thread may take: 256 / 168 / 128)
+    auto kern = B <= 512 ? net_hybrid_fwd_kernel<512, false> : (B <= 768 ? net_hybrid_fwd_kernel<768, false> : net_hybrid_fwd_kernel<1024, false>);
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_LAUNCH;
@@ -1856,7 +1857,7 @@ int dhts_net_hybrid_rollout_eval(const dhts_net_desc *d, const dhts_hybrid_table
     if (stage_h < 8) return DHTS_E_INVALID;       // (a lane with one vehicle stages ~10 records in a step with a hand-off)
     const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, stage_h).total + up16(sizeof(float) * (size_t)d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
-    auto kern = B <= 512 ? net_hybrid_fwd_kernel<512, true> : net_hybrid_fwd_kernel<1024, true>;
+    auto kern = B <= 512 ? net_hybrid_fwd_kernel<512, true> : (B <= 768 ? net_hybrid_fwd_kernel<768, true> : net_hybrid_fwd_kernel<1024, true>);
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_LAUNCH;
@@ -1878,7 +1879,7 @@ int dhts_net_hybrid_rollout_bwd(const dhts_net_desc *d, const dhts_hybrid_tables
     const int E = t->net.n_edges > 0 ? t->net.n_edges : 1;
     const size_t lds = hyb_lds_b(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, E).total + up16(sizeof(float) * (size_t)d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
-    auto kern = B <= 512 ? net_hybrid_bwd_kernel<512> : net_hybrid_bwd_kernel<1024>;
+    auto kern = B <= 512 ? net_hybrid_bwd_kernel<512> : (B <= 768 ? net_hybrid_bwd_kernel<768> : net_hybrid_bwd_kernel<1024>);
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_LAUNCH;
