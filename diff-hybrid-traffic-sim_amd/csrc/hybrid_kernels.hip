@@ -24,6 +24,7 @@
 // reused every step; COMMIT records copy temporaries into the slots at the end of a step and every temporary's adjoint is
 // cleared when its defining record is replayed, so the reverse kernel keeps one step's adjoints in LDS.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "../../include/dhts.h"
 #include "arz_device.hpp"
@@ -825,387 +826,21 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     if (has_src && in_mw && T > 0) { src_prefetch(0); source_admit(0); }
     if (has_src) __syncthreads();
     HYB_STAMP_DECL
-    for (int t = 0; t < T; ++t) {
-        const float *cur = (t & 1) ? S1 : S0;
-        float *nxt = (t & 1) ? S0 : S1;
-        // ================= A: ghosts | loss scan of the state after step t-1 | record flush of step t-1, head gaps =========
-        const int src = p_src, gate = p_gate; const double sched = p_sched;
-        if (is_lane) cnext[tid] = p_cnext;
-        const int capnext_t = p_capnext;             // (micro wave: the capacitor lane's successor of this step)
-        fetch(t + 1);
-        cap_fetch(t + 1);
-        if (t > 0) loss_prefetch(t - 1);
-        if (!in_mw) HYB_SUB(0)                       // A, cell waves: this step's table entries taken, the next step's requested
-        if (is_ghost && g_macro) {
-            float fr, fu, fy, fq;
-            if (g_side == 0) {
-                if (src == -1) {
-                    const double gu = um_d * (1. - sqrt(fmax(sched, 0.) + kEps));
-                    fr = (float)sched; fu = (float)gu; fy = 0.f; fq = (float)gu;
-                } else {
-                    float gr = 0.f, gu = um;             // src == -3: own stored ghost behind a red gate
-                    if (src >= 0) { const int last = lfl[src] >> 16; gr = cur[last]; gu = cur[2 * C + last]; }
-                    float s = 1.f;
-                    if (gate == -1) s = 0.f;
-                    else if (gate >= 0) { const int kd = linfo[gate] & 3; if (kd != 0) s = sig[2 * (linfo[gate] >> 2) + (kd - 1)]; }
-                    fr = gr * s + 0.f * (1.0f - s);
-                    fu = gu * s + um * (1.0f - s);
-                    glue_from_r_u(fr, fu, um, fy, fq);
-                }
-            } else {
-                float gr = own_r, gu = own_u;
-                if (src >= 0) { const int first = lfl[src] & 0xffff; gr = cur[first]; gu = cur[2 * C + first]; }
-                if (!kHard) { own_w[(size_t)t * 2 * L + 2 * g_lane] = own_r; own_w[(size_t)t * 2 * L + 2 * g_lane + 1] = own_u; }
-                const float sg = g_kind != 0 ? sig[2 * g_inter + (g_kind - 1)] : 1.f;
-                const float s2 = kHard ? (sg > 0.5f ? 1.f : 0.f) : soft_switch(sg - 0.5f, kSigK);
-                fr = s2 * gr + (1.0f - s2) * 1.0f;
-                fu = s2 * gu + (1.0f - s2) * 0.0f;
-                glue_from_r_u(fr, fu, um, fy, fq);
-                own_r = fr; own_u = fu;
-            }
-            float *g = G + (size_t)(2 * g_lane + g_side) * 4;
-            g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
+    // The step, in two copies: the micro wave's and everybody else's.  Which roles a thread can have is decided by its wavefront,
+    // but the compiler cannot know that: in one loop every thread holds the loop-carried state of every role (prefetch registers,
+    // running sums, record counters, ...) and the kernel sat at the register limits (256 vector registers, ~380 uniform values
+    // for ~100 scalar ones).  The barriers pair up by count, not by place.  (The step's text is included twice rather than
+    // wrapped in a generic lambda: the closure of a lambda that calls the lambdas above is not broken up into registers.)
+    if (in_mw) {
+        for (int t = 0; t < T; ++t) {
+            constexpr bool kMw = true;
+#include "hybrid_fwd_step.inc"
         }
-        if (!in_mw) HYB_SUB(1)                       // A, cell waves: ghosts
-        if (t > 0) loss_scan(cur, t - 1);
-        if (!in_mw) HYB_SUB(2)                       // A: loss scan
-        if (is_fw && t > 0) vehicle_samples(t - 1);
-        if (in_mw) {
-            {   // head gaps of the occupied micro lanes (they only feed the IDM steps below)
-                rec.next_local = base_local + mw * kLaneLocals;
-                const int k = mw;
-                const bool act = k < n_micro && lane_n[k < n_micro ? k : 0] > 0;
-                if (k < n_micro) { hdpv[k] = 1000.f; hdvv[k] = 0.f; hdpi[k] = -1; hdvi[k] = -1; }
-                // variables: 0 = head position, 1 = head speed, 2 / 3 = leader position / speed, 4..6 = signals of the previous /
-                // current / next lane of the route; every quantity carries only the components it can depend on
-                constexpr unsigned kP = 1u, kS = 2u, kLP = 4u, kLS = 8u, kSig = 16u | 32u | 64u;
-                Du<kP | kSig> fin = du_as<kP | kSig>(du_c(0.f));
-                Du<kP | kLP> green_dp = du_as<kP | kLP>(du_c(1000.f));
-                Du<kS | kLS> green_dv = du_as<kS | kLS>(du_c(0.f));
-                Du<kP> red_dp = du_as<kP>(du_c(0.f));
-                int ids[kDu];
-#pragma unroll
-                for (int q = 0; q < kDu; ++q) ids[q] = -1;
-                if (act) {
-                    const int nv = lane_n[k];
-                    const int l = mlane[k];
-                    const int hv = lane_veh[k * kLaneCap + nv - 1];
-                    const int *route = vroute + hv * kRouteStride;
-                    const int rlen = vrlen[hv], cursor = vcur[hv];
-                    ids[0] = vidp[hv]; ids[1] = vidv[hv];
-                    const Du<kP> hp = du_var<0>(vp[hv]);
-                    const Du<kS> hs = du_var<1>(vv[hv]);
-                    const Du<0> Lc = du_c(lanelen[l]), half = du_c(vlen * 0.5f);
-                    Du<kP> reach = du_sub(du_sub(Lc, hp), half);
-                    for (int j = cursor; j < rlen - 1; ++j) {
-                        const int there = route[j + 1];
-                        const int ms = mslot[there];
-                        if (ms < 0) break;                       // macro successor: defaults
-                        if (lane_n[ms]) {
-                            // the leader is another lane's tail vehicle: imported through two temporaries
-                            const int lv = lane_veh[ms * kLaneCap + 0];
-                            const Tv lp_ = tv_leaf(rec, vp[lv]), lsp_ = tv_leaf(rec, vv[lv]);
-                            rec_push(rec, K_IMPORT, 0, make_int4(lp_.id, lsp_.id, vidp[lv], vidv[lv]), make_float4(0.f, 0.f, 0.f, 0.f));
-                            ids[2] = lp_.id; ids[3] = lsp_.id;
-                            green_dp = du_pos_or_zero(du_add(reach, du_sub(du_var<2>(lp_.val), half)));
-                            green_dv = du_sub(hs, du_var<3>(lsp_.val));
-                            break;
-                        }
-                        reach = du_add(reach, du_c(lanelen[there]));
-                    }
-                    red_dp = du_pos_or_zero(du_sub(du_sub(Lc, hp), half));
-                    const bool prev_exist = cursor > 0, next_exist = cursor < rlen - 1;
-                    Du<kP> prev_s = du_as<kP>(du_c(0.f)), next_s = du_as<kP>(du_c(0.f));
-                    // (evaluation episode: the scores are 0 / 1 / 0, _simulator.py:208-232)
-                    if (prev_exist && !kHard) prev_s = du_soft(du_sub(du_c(0.f), hp), 16.f);
-                    const Du<kP> curr_s = kHard ? du_as<kP>(du_c(1.f)) : du_mul(du_soft(hp, 16.f), du_soft(du_sub(Lc, hp), 16.f));
-                    if (next_exist && !kHard) next_s = du_soft(du_sub(hp, Lc), 16.f);
-                    const Du<kP> total = du_add(du_add(prev_s, curr_s), next_s);
-                    // one term of the position-weighted blend: (score / total) * signal of that lane (1 for a lane without one)
-#define DHTS_BLEND_TERM(W, SC)                                                                                                  \
-                    {                                                                                                           \
-                        const int lid = route[cursor + (W) - 1];                                                                \
-                        const int kd = linfo[lid] & 3;                                                                          \
-                        float sval = 1.f, sseed = 0.f;                                                                          \
-                        if (kd != 0) {                                                                                          \
-                            const int it = linfo[lid] >> 2;                                                                     \
-                            const Tv leaf = tv_leaf(rec, sig[2 * it + (kd - 1)]);                                               \
-                            rec_push(rec, K_SIGNAL, 0, make_int4(leaf.id, it, kd, 0), make_float4(0.f, 0.f, 0.f, 0.f));         \
-                            ids[4 + (W)] = leaf.id;                                                                             \
-                            sval = leaf.val; sseed = 1.f;                                                                       \
-                        }                                                                                                       \
-                        fin = du_add(fin, du_mul(du_div(SC, total), du_var<4 + (W)>(sval, sseed)));                             \
-                    }
-                    if (prev_exist) DHTS_BLEND_TERM(0, prev_s)
-                    DHTS_BLEND_TERM(1, curr_s)
-                    if (next_exist) DHTS_BLEND_TERM(2, next_s)
-#undef DHTS_BLEND_TERM
-                }
-                // The barrier between this phase and the next sits HERE for the micro wave: nobody else reads what the rest of
-                // the head-gap evaluation writes (it only feeds this wave's IDM steps), and the next phase has slack for it
-                // (IDM steps against the interface solves) while this one does not (head gaps against ghosts + loss scan).
-                HYB_BARRIER(0);
-                // signal_rms: running mean over the occupied lanes in lane order (_simulator.py:249-256)
-                const double ssum = wave_scan_add(act ? (double)fin.v : 0.);
-                const int scnt = wave_scan_add(act ? 1 : 0);
-                if (act && kHard) {                       // is_signal_green(final_signal): signal >= 0.5 (_simulator.py:264-276)
-                    const bool green = fin.v >= 0.5f;
-                    hdpv[k] = green ? green_dp.v : red_dp.v; hdpi[k] = -1;
-                    hdvv[k] = green ? green_dv.v : 0.f; hdvi[k] = -1;
-                } else if (act) {
-                    const float k2 = 32.f / fabsf((float)((sig_sum + ssum) / (double)(sig_cnt + scnt)));
-                    const auto fs = du_soft(du_sub(fin, du_c(0.5f)), k2);
-                    const auto one_m = du_sub(du_c(1.f), fs);
-                    const auto dp_d = du_add(du_mul(green_dp, fs), du_mul(red_dp, one_m));
-                    const auto dv_d = du_add(du_mul(green_dv, fs), du_mul(du_c(0.f), one_m));
-                    const Tv dp_ = du_emit(rec, dp_d, ids), dv_ = du_emit(rec, dv_d, ids);
-                    hdpv[k] = dp_.val; hdpi[k] = dp_.id; hdvv[k] = dv_.val; hdvi[k] = dv_.id;
-                }
-                sig_sum += wave_last(ssum); sig_cnt += wave_last(scnt);
-            }
-        } else {
-            HYB_BARRIER(0);
+    } else {
+        for (int t = 0; t < T; ++t) {
+            constexpr bool kMw = false;
+#include "hybrid_fwd_step.inc"
         }
-        // ================= B: interface solves | loss constants + history row | vehicles' loss terms, IDM steps =================
-        if (is_if) {
-            const float *gl = G + (size_t)(2 * i_lane) * 4, *gr_ = G + (size_t)(2 * i_lane + 1) * 4;
-            double rL, yL, uL, qL, rR, yR, uR, qR;
-            if (i_k == 0) { rL = gl[0]; yL = gl[1]; uL = gl[2]; qL = gl[3]; }
-            else { const int c = i_off + i_k - 1; rL = cur[c]; yL = cur[C + c]; uL = cur[2 * C + c]; qL = cur[3 * C + c]; }
-            if (i_k == i_n) { rR = gr_[0]; yR = gr_[1]; uR = gr_[2]; qR = gr_[3]; }
-            else { const int c = i_off + i_k; rR = cur[c]; yR = cur[C + c]; uR = cur[2 * C + c]; qR = cur[3 * C + c]; }
-            Iface f;
-            arz_interface(rL, yL, uL, qL, rR, yR, uR, qR, kconst, f);
-            if (f.cfl_bad && fault_step < 0) { fault_step = t; fault_index = i_k; }
-            Fq[2 * tid] = f.Fr; Fq[2 * tid + 1] = f.Fy;
-            // the interface's two 2x2 products go straight to the tape; the reverse sweep forms the cell blocks from them
-            // (dmacro_lane.py:126-129) in a phase where its cell threads wait for the micro wave
-            if (!kHard) {
-                float4 *tp = tape_r + ((size_t)t * NIp + tid) * 2;
-                tp[0] = make_float4(f.A[0], f.A[1], f.A[2], f.A[3]);
-                tp[1] = make_float4(f.B[0], f.B[1], f.B[2], f.B[3]);
-            }
-        }
-        if (!in_mw) HYB_SUB(3)                       // B, cell waves: interface solves
-        if (t > 0) micro_loss(t - 1, t - 1);
-        if (in_mw) {
-            const int k = mw;
-            float tail_space = k < n_micro ? lanelen[mlane[k]] : 0.f;
-            if (k < n_micro && lane_n[k] > 0) {
-                const int nv = lane_n[k];
-                Tv hd_p = tv_var(hdpv[k], hdpi[k]);
-                Tv hd_v = tv_var(hdvv[k], hdvi[k]);
-                // tail -> head, in place: a follower reads its leader before the leader moves.  One record per vehicle: the
-                // step rewrites the vehicle's own slots (p, v) from (p, v, leader p, leader v) with dEgo = [[1, dt], [e2, e3]],
-                // dLeading = [[0, 0], [l2, l3]] (didm.py:38-103); payload = (e2, e3, l2, l3)
-                for (int i = 0; i < nv; ++i) {
-                    const int vi = lane_veh[k * kLaneCap + i];
-                    const float p_ = vp[vi], v_ = vv[vi];
-                    IdmStep o;
-                    if (i == nv - 1) {
-                        idm_step_ieee((double)p_, (double)v_, (double)hd_p.val, (double)hd_v.val, idm, dt, o);
-                        rec_push(rec, K_IDM, 3 * vi, make_int4(hd_p.id, hd_v.id, 1, 0), make_float4(o.dE[2], o.dE[3], o.dLd[2], o.dLd[3]));
-                    } else {
-                        const int vj = lane_veh[k * kLaneCap + i + 1];
-                        const double dp = fabs((double)vp[vj] - (double)p_) - ((veh_len + veh_len) * 0.5);
-                        const double dv = (double)v_ - (double)vv[vj];
-                        idm_step_ieee((double)p_, (double)v_, dp, dv, idm, dt, o);
-                        rec_push(rec, K_IDM, 3 * vi, make_int4(3 * vj, 3 * vj + 1, 0, 0), make_float4(o.dE[2], o.dE[3], o.dLd[2], o.dLd[3]));
-                    }
-                    vp[vi] = o.np; vv[vi] = o.nv;
-                    if (i == 0) tail_space = o.np - 0.5f * vlen;
-                }
-            }
-            if (k < n_micro) tailsp[k] = tail_space;
-            seg_a = rec.cnt;
-        }
-        HYB_BARRIER(1);
-        // ================= C: cell updates + tape | lane queue terms of step t-1 | next step's signals =================
-        if (is_cell) {
-            const int c = tid;
-            const int iL = c + c_macb, iR = iL + 1;
-            const float nr = (float)((double)cur[c] + (Fq[2 * iL] - Fq[2 * iR]) * c_cc);
-            const float ny = (float)((double)cur[C + c] + (Fq[2 * iL + 1] - Fq[2 * iR + 1]) * c_cc);
-            float nu, nq;
-            glue_from_r_y(nr, ny, um, nu, nq);
-            nxt[c] = nr; nxt[C + c] = ny; nxt[2 * C + c] = nu; nxt[3 * C + c] = nq;
-            // (the step's tape blocks are assembled in the next phase: the hand-offs wait for the new state, not for them)
-        }
-        if (is_sg && t + 1 < T) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, sig_ph, sig_fr, sg_q, we, ns, a, pr, ai, kHard); sig[2 * sg_q] = we; sig[2 * sg_q + 1] = ns; }
-        if (++sig_fr == F) { sig_fr = 0; ++sig_ph; }
-        // micro wave (idle in this phase): has a head vehicle run past the point where it leaves its lane?  (The vehicles
-        // moved in the last phase; nothing touches them again before the hand-off phase looks at this.)
-        bool ev_head = false;
-        if (in_mw && mw < n_micro && lane_n[mw] > 0) {
-            const int vi = lane_veh[mw * kLaneCap + lane_n[mw] - 1];
-            const int cursor = vcur[vi];
-            const int nid = cursor < vrlen[vi] - 1 ? vroute[vi * kRouteStride + cursor + 1] : -1;
-            const float Lf = lanelen[mlane[mw]];
-            ev_head = (nid >= 0 && mslot[nid] < 0) ? vp[vi] > Lf + 1.0f * vlen : vp[vi] >= Lf;
-        }
-        HYB_BARRIER(2);
-        // ================= D: flux capacitors, hand-off events in lane-id order, commits (micro wave) | loss constants of
-        //                    the state after step t-1 + its history row (the cells have nothing else to do here) =========
-        if (t > 0 && !in_mw) { loss_consts(cur, t - 1); run_update(t - 1); }      // (the micro wave keeps no running sums)
-        // lane sums of the loss of the state step t - 2 left (its constants: this phase of step t - 1, the other contrib buffer;
-        // its vehicles' terms: phase B of step t - 1): the lanes' threads would only wait for the hand-offs here
-        if (t > 1) loss_lanes(t - 2);
-        if (is_fw && t > 0) flush_block(t - 1);          // the last step's records, with the seeds appended two phases ago
-        if (in_mw) {
-            if (has_src && mw < n_micro) lane_new[mw] = 0;       // the loss of the last state has been evaluated (phases A, B)
-            // capacitors: += r u dt of the last cell (conversion.py:32-36); the spawn itself is an event below
-            const int cap_ms = cap_target(capnext_t);  // this step's successor of the capacitor's lane, if it is a micro lane
-            float cap_level = 0.f;
-            bool cap_prev_var = false;
-            if (mw < n_caps) {
-                const int j = mw;
-                cap_level = capv[j];
-                if (cap_ms >= 0) {
-                    const int last = cap_last;
-                    // cap += (r u) dt with (r, u) read from the cell, in place on the capacitor's slot.  No record (round 3: the
-                    // sixteen of them were 95 % of the record stream): the reverse sweep's lane j applies the same three
-                    // float32 operations from (u, r) -- kept per step, because a deposit of the same step may rewrite the very
-                    // cell -- and two flag bits: charged, and whether the previous level was a variable (not the constant a spawn
-                    // or the start leaves).  The leaf stands for u: a vehicle spawned in this step takes it as its speed.
-                    const float r_ = nxt[last], u_ = nxt[2 * C + last];
-                    cap_prev_var = capi[j] >= 0;
-                    if (!kHard) capru_w[(size_t)t * kMaxCaps + j] = make_float2(u_, r_);
-                    cap_level = cap_level + (r_ * u_) * dtf;
-                    capv[j] = cap_level; capi[j] = 3 * V + j;
-                    capleaf[j] = 3 * V + kMaxCaps + j;
-                }
-            }
-            if (!kHard) {
-                const unsigned long long bc = __ballot(mw < n_caps && cap_ms >= 0), bp = __ballot(cap_prev_var);
-                if (is_mt) capflag_w[t] = (unsigned)(bc & 0xffffull) | ((unsigned)(bp & 0xffffull) << 16);
-            }
-            HYB_SUB(0)                               // D, micro wave: capacitors
-            // is there any event at all this step?  (the common case is none)
-            bool ev = false;
-            if (mw < n_caps && cap_ms >= 0) ev = cap_level >= vlen && tailsp[cap_ms] >= vlen * 1.0f;
-            ev = ev || ev_head;
-            const bool any_ev = __any(ev);
-            if (any_ev && is_mt) {
-                const int keep_local = rec.next_local;
-                rec.next_local = base_local + 64 * kLaneLocals;
-                for (int ci = 0; ci < n_conv; ++ci) {
-                    const int l = convlist[ci];
-                    if (capof[l] >= 0) {
-                        const int m = cnext[l];
-                        if (m < 0 || mslot[m] < 0) continue;
-                        const int j = capof[l], ms = mslot[m];
-                        const float level = capv[j];
-                        float space = lanelen[m];
-                        if (lane_n[ms]) space = vp[lane_veh[ms * kLaneCap + 0]] - 0.5f * vlen;
-                        if (level >= vlen && space >= vlen * 1.0f) {            // conversion.py:52-73
-                            const int r_lo = tb.route_ptr[m], r_n = tb.route_ptr[m + 1] - r_lo;
-                            if (spawned >= V || lane_n[ms] >= kLaneCap || r_n <= 0) { cap_fault = true; continue; }
-                            const int vi = spawned;
-                            const size_t row = (size_t)(r_lo + rused[ms] % r_n);
-                            ++rused[ms];
-                            vp[vi] = 0.f; vidp[vi] = -1;
-                            vv[vi] = nxt[2 * C + caplast[j]]; vidv[vi] = capleaf[j];
-                            va[vi] = level - (float)((double)level - veh_len); vida[vi] = capi[j];
-                            vcur[vi] = 0;
-                            int rl_ = 0;
-                            for (int q = 0; q < kRouteStride; ++q) {
-                                const int lid = q < tb.route_stride ? tb.routes[row * tb.route_stride + q] : -1;
-                                vroute[vi * kRouteStride + q] = lid;
-                                if (lid >= 0 && rl_ == q) rl_ = q + 1;
-                            }
-                            vrlen[vi] = rl_;
-                            capv[j] = (float)((double)level - veh_len); capi[j] = -1;
-                            for (int q = lane_n[ms]; q > 0; --q) lane_veh[ms * kLaneCap + q] = lane_veh[ms * kLaneCap + q - 1];
-                            lane_veh[ms * kLaneCap + 0] = vi;
-                            ++lane_n[ms];
-                            ++spawned;
-                        }
-                        continue;
-                    }
-                    const int k = mslot[l];
-                    const int nv = lane_n[k];
-                    if (nv == 0) continue;
-                    const int vi = lane_veh[k * kLaneCap + nv - 1];
-                    const int cursor = vcur[vi], rlen = vrlen[vi];
-                    const int nid = cursor < rlen - 1 ? vroute[vi * kRouteStride + cursor + 1] : -1;
-                    const float Lf = lanelen[l];
-                    if (nid == -1) {                                             // micro -> none (:203-215)
-                        if (vp[vi] >= Lf) --lane_n[k];
-                    } else if (mslot[nid] >= 0) {                                // micro -> micro (:175-200)
-                        if (vp[vi] >= Lf) {
-                            const int ms = mslot[nid];
-                            if (lane_n[ms] >= kLaneCap) { cap_fault = true; continue; }
-                            --lane_n[k];
-                            Tv p_ = tv_var(vp[vi], vidp[vi]);
-                            p_ = tv_unit(rec, tv_sub(rec, p_, tv_c(Lf)));
-                            vp[vi] = p_.val; vidp[vi] = p_.id;
-                            for (int q = lane_n[ms]; q > 0; --q) lane_veh[ms * kLaneCap + q] = lane_veh[ms * kLaneCap + q - 1];
-                            lane_veh[ms * kLaneCap + 0] = vi;
-                            ++lane_n[ms];
-                            ++vcur[vi];
-                        }
-                    } else if (vp[vi] > Lf + 1.0f * vlen) {                      // micro -> macro (:76-171)
-                        --lane_n[k];
-                        ++deposits;
-                        const float front = vp[vi] - Lf, rear = front - vlen;
-                        const double dxd = tb.net.lane_dx[nid];
-                        const float dx = (float)dxd;
-                        const int ncell = tb.net.lane_ncell[nid], off = tb.net.lane_off[nid];
-                        for (int q = 0; q < ncell; ++q) {
-                            const double c_lo = dxd * q, c_hi = dxd * (q + 1);
-                            if (!(c_hi > (double)rear && c_lo < (double)front)) break;
-                            const bool hi_is_front = (double)front > c_hi, lo_is_rear = (double)rear < c_lo;
-                            const float hi = hi_is_front ? front : (float)c_hi, lo = lo_is_rear ? rear : (float)c_lo;
-                            const float overlap = dx + vlen - (hi - lo);
-                            const int cell = off + q;
-                            float n_r = nxt[cell] + (va[vi] / vlen) * (overlap / dx);
-                            if (n_r > 1.0f - 1e-5f) n_r = n_r - (float)((double)n_r - (1.0 - 1e-5));
-                            else if (n_r < 1e-5f) n_r = n_r - (float)((double)n_r - 1e-5);
-                            rec_push(rec, K_DEPOSIT, nid, make_int4(vida[vi], vidp[vi], vidv[vi], cell),
-                                     make_float4(overlap, (float)(-(int)hi_is_front + (int)lo_is_rear), n_r, va[vi]));
-                            float yy, qq;
-                            glue_from_r_u(n_r, vv[vi], um, yy, qq);
-                            nxt[cell] = n_r; nxt[C + cell] = yy; nxt[2 * C + cell] = vv[vi];     // u_eq keeps its pre-deposit value
-                        }
-                    }
-                }
-                if (rec.next_local - (base_local + 64 * kLaneLocals) > kEventLocals) cap_fault = true;
-                rec.next_local = keep_local;
-            }
-            HYB_SUB(1)                               // D, micro wave: event pre-screen (+ the rare serial walk)
-            // commit temporaries into the persistent slots (vehicles by their lane, capacitors by theirs); only hand-off events
-            // leave values in temporaries
-            const int k = mw;
-            if (any_ev && k < n_micro)
-                for (int i = 0; i < lane_n[k]; ++i) {
-                    const int vi = lane_veh[k * kLaneCap + i];
-                    if (vidp[vi] != 3 * vi) { rec_push(rec, K_COMMIT, 3 * vi, make_int4(vidp[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vidp[vi] = 3 * vi; }
-                    if (vidv[vi] != 3 * vi + 1) { rec_push(rec, K_COMMIT, 3 * vi + 1, make_int4(vidv[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vidv[vi] = 3 * vi + 1; }
-                    if (vida[vi] != 3 * vi + 2) { rec_push(rec, K_COMMIT, 3 * vi + 2, make_int4(vida[vi], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); vida[vi] = 3 * vi + 2; }
-                }
-            if (any_ev && mw < n_caps) {
-                const int j = mw;
-                if (capi[j] != 3 * V + j && capi[j] >= 0) { rec_push(rec, K_COMMIT, 3 * V + j, make_int4(capi[j], 0, 0, 0), make_float4(0.f, 0.f, 0.f, 0.f)); capi[j] = 3 * V + j; }
-            }
-            if (rec.next_local - (base_local + mw * kLaneLocals) > kLaneLocals) cap_fault = true;
-            seg_b = rec.cnt;
-            HYB_SUB(2)                               // D, micro wave: commits
-            // vehicle counts in front of every micro lane (lane id order): the cells need them for their stream positions in
-            // the next phase; the vehicles' samples themselves are taken there by the flush wave
-            {
-                const int k = mw;
-                const int c = k < n_micro ? lane_n[k] : 0;
-                const int inc = wave_scan_add(c);
-                if (k <= n_micro) vcp_of(t)[k] = inc - c;
-                if (k == 63 && n_micro == 64) vcp_of(t)[64] = inc;            // (no lane 64 to hold the total)
-            }
-            if (has_src) {
-                spawned = __builtin_amdgcn_readfirstlane(spawned);       // (the serial event walk counts on lane 0)
-                if (t + 1 < T) source_admit(t + 1);
-            }
-            publish(t);
-        }
-        HYB_BARRIER(3);
     }
     HYB_STAMP_WRITE(0, rep, tid, B)
     // loss of the final state, last records
