@@ -1086,7 +1086,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         const int a = step_off[tt], b = step_off[tt + 1];
         n_rlo = a; n_nrec = b - a;
     };
-    auto fetch = [&](int t) {
+    auto fetch_cells = [&](int t) {      // what the cells', ghosts' and lanes' threads need of step t
         const int tt = t < 0 ? 0 : t;
         {
             const float *h = hist_r + (size_t)tt * 4 * C;
@@ -1101,21 +1101,23 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
             p_src = f_srcp[o]; p_gate = tb.net.left_gate[o];
             p_own_r = own_r[(size_t)tt * 2 * L + 2 * f_glane]; p_own_u = own_r[(size_t)tt * 2 * L + 2 * f_glane + 1];
         }
-        if (in_mw) {                                 // wave-uniform
-            p_rlo = n_rlo; p_nrec = n_nrec;          // offsets of step t arrived during the previous iteration
-#pragma unroll
-            for (int ph = 0; ph < kPhases; ++ph) p_seg[ph] = seg_cnt[((size_t)tt * kPhases + ph) * 64 + mw_lane];
-#pragma unroll
-            for (int j = 0; j < kPre; ++j) {
-                const int k = mw_lane + 64 * j;
-                const int kk = p_rlo + (k < p_nrec ? k : 0);
-                p_rk[j] = grk[kk]; p_ri[j] = gri[kk]; p_rw[j] = grw[kk];
-            }
-            fetch_offsets(t - 1);
-            p_capflag = capflag_r[tt];
-            p_capru = capru_r[(size_t)tt * kMaxCaps + (mw_lane < kMaxCaps ? mw_lane : 0)];
-        }
     };
+    auto fetch_micro = [&](int t) {      // the micro wave's: the step's records, segment counts, capacitor pairs
+        const int tt = t < 0 ? 0 : t;
+        p_rlo = n_rlo; p_nrec = n_nrec;          // offsets of step t arrived during the previous iteration
+#pragma unroll
+        for (int ph = 0; ph < kPhases; ++ph) p_seg[ph] = seg_cnt[((size_t)tt * kPhases + ph) * 64 + mw_lane];
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {
+            const int k = mw_lane + 64 * j;
+            const int kk = p_rlo + (k < p_nrec ? k : 0);
+            p_rk[j] = grk[kk]; p_ri[j] = gri[kk]; p_rw[j] = grw[kk];
+        }
+        fetch_offsets(t - 1);
+        p_capflag = capflag_r[tt];
+        p_capru = capru_r[(size_t)tt * kMaxCaps + (mw_lane < kMaxCaps ? mw_lane : 0)];
+    };
+    auto fetch = [&](int t) { if (in_mw) fetch_micro(t); else fetch_cells(t); };      // (wave-uniform)
     // block T of the record stream is empty in streams this build writes (the loss seeds of the final state sit at the end
     // of block T - 1); seeds found there are still applied
     if (T > 0 && in_mw) {
@@ -1133,268 +1135,17 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     if (in_mw) fetch_offsets(T - 1);
     fetch(T - 1);
     HYB_STAMP_DECL
-    for (int t = T - 1; t >= 0; --t) {
-        float *Hc = (t & 1) ? H1 : H0;           // row t
-        const float *Hn = (t & 1) ? H0 : H1;     // row t+1
-        // ================= R0: this step's data (fetched during the previous iteration) =================
-        const float w_kc = p_kc; const float4 aL = p_aL, bL = p_bL, aR = p_aR, bR = p_bR;
-        const unsigned w_capflag = p_capflag; const float2 w_capru = p_capru;
-        const int src = p_src, gate = p_gate; const float w_own_r = p_own_r, w_own_u = p_own_u;
-        if (is_cell) { Hc[tid] = p_hr; Hc[C + tid] = p_hy; Hc[2 * C + tid] = p_hu; }
-        // loss taps on the state after step t (row t + 1 is in LDS since the previous iteration): d reward / d q_l = -2 q_l dt
-        // with q_l = sqrt(term / dt), evaluated by every cell for its own lane
-        if (is_cell) {
-            const int c = tid;
-            const float gql = t < loss_steps ? gscale * (-1.0f) * (float)dt * 2.f * sqrtf(p_q / (float)dt) : 0.f;
-            const float rr = Hn[c], uu = Hn[2 * C + c];
-            const float x = s0f - uu;
-            gL[c] += gql * soft_switch(x, w_kc) * c_dxv;
-            gL[2 * C + c] += gql * (rr * c_dxv) * (-soft_switch_grad(x, w_kc));
+    // (two copies of the step, by role: see the forward kernel)
+    if (in_mw) {
+        for (int t = T - 1; t >= 0; --t) {
+            constexpr bool kMw = true;
+#include "hybrid_bwd_step.inc"
         }
-        if (is_sg) {
-            float we, ns, a, pr; int ai;
-            phase_signal_at(act, n_action, sq, F, rev_ph, rev_fr, sg_q, we, ns, a, pr, ai);
-            sg[6 * sg_q] = we; sg[6 * sg_q + 1] = ns;
-            // d sigmoid(k x) / d x = s (1 - s) k with the sigmoid values just computed (0 outside the clamp, like the operator)
-            const float zs = (a - pr) * kSigK;
-            const bool sat = zs < -16.f || zs > 16.f;
-            sg[6 * sg_q + 2] = sat ? 0.f : we * (1.f - we) * kSigK; sg[6 * sg_q + 3] = sat ? 0.f : -(ns * (1.f - ns) * kSigK);
+    } else {
+        for (int t = T - 1; t >= 0; --t) {
+            constexpr bool kMw = false;
+#include "hybrid_bwd_step.inc"
         }
-        int seg_lo[kPhases], seg_n[kPhases];            // this lane's record segments of the step (micro wave)
-#pragma unroll
-        for (int ph = 0; ph < kPhases; ++ph) { seg_lo[ph] = 0; seg_n[ph] = 0; }
-        if (in_mw) {
-            const int r_lo = p_rlo, n_rec = p_nrec;
-            if (n_rec > kMaxStepRecords) over = true;
-            else {
-#pragma unroll
-                for (int j = 0; j < kPre; ++j) {
-                    const int k = mw_lane + 64 * j;
-                    if (k < n_rec) { rk[k] = p_rk[j]; *reinterpret_cast<int4 *>(ri + 4 * k) = p_ri[j]; *reinterpret_cast<float4 *>(rw + 4 * k) = p_rw[j]; }
-                }
-                for (int k = mw_lane + 64 * kPre; k < n_rec; k += 64) {
-                    rk[k] = grk[r_lo + k];
-                    *reinterpret_cast<int4 *>(ri + 4 * k) = gri[r_lo + k];
-                    *reinterpret_cast<float4 *>(rw + 4 * k) = grw[r_lo + k];
-                }
-            }
-            {   // a lane's block = its three segments back to back; blocks follow each other in lane order
-                const int c = p_seg[0] + p_seg[1] + p_seg[2];
-                const int inc = wave_scan_add(c);
-                int lo_ = inc - c;
-#pragma unroll
-                for (int ph = 0; ph < kPhases; ++ph) { seg_lo[ph] = lo_; seg_n[ph] = over ? 0 : p_seg[ph]; lo_ += p_seg[ph]; }
-            }
-        }
-        fetch(t - 1);
-        HYB_BARRIER(0);
-        // ================= R2: micro records of the loss / hand-off part, newest first =================
-        bool used_ob = false;
-        auto replay = [&](int lo_, int n_) {            // this lane's records [lo_, lo_ + n_), newest first
-            int n_sig = 0;
-            for (int k = lo_ + n_ - 1; k >= lo_; --k) {
-                const int kw = rk[k];
-                const int kind = kw >> 24, out = kw & 0xffffff;
-                const int4 in4 = *reinterpret_cast<const int4 *>(ri + 4 * k);
-                const float4 w4 = *reinterpret_cast<const float4 *>(rw + 4 * k);
-                const int in[4] = {in4.x, in4.y, in4.z, in4.w};
-                const float w[4] = {w4.x, w4.y, w4.z, w4.w};
-                if (kind == K_NODE) {
-                    const float a = adj[out];
-                    adj[out] = 0.f;
-                    if (a != 0.f) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) if (in[q] >= 0) adj[in[q]] += a * w[q];
-                    }
-                } else if (kind == K_IDM) {
-                    const float gp = adj[out], gv = adj[out + 1];          // cotangents of the new (p, v)
-                    float op = gp + w[0] * gv, ov = dtf * gp + w[1] * gv;   // dEgo^T
-                    if (in[2]) {                                            // head: leader = (p + head_dp, v - head_dv)
-                        op += w[2] * gv; ov += w[3] * gv;
-                        if (in[0] >= 0) adj[in[0]] += w[2] * gv;
-                        if (in[1] >= 0) adj[in[1]] -= w[3] * gv;
-                    } else {
-                        adj[in[0]] += w[2] * gv;
-                        adj[in[1]] += w[3] * gv;
-                    }
-                    adj[out] = op; adj[out + 1] = ov;
-                } else if (kind == K_COMMIT) {
-                    if (in[0] >= 0) adj[in[0]] += adj[out];
-                    adj[out] = 0.f;
-                } else if (kind == K_SEED) {
-                    adj[in[0]] += gscale * w[0];
-                } else if (kind == K_DEPOSIT) {
-                    const int c = in[3];
-                    const float n_r = w[2], speed = Hn[2 * C + c];
-                    float g_nr = gL[c], g_speed = gL[2 * C + c];
-                    glue_y_bwd(n_r, speed, um, gL[C + c], g_nr, g_speed);
-                    const float dx = (float)tb.net.lane_dx[out];
-                    if (in[0] >= 0) adj[in[0]] += g_nr * ((w[0] / dx) / vlen);
-                    if (in[1] >= 0) adj[in[1]] += g_nr * ((w[3] / vlen) / dx) * w[1];
-                    if (in[2] >= 0) adj[in[2]] += g_speed;
-                    gL[c] = g_nr; gL[C + c] = 0.f; gL[2 * C + c] = 0.f;
-                } else if (kind == K_CELLREAD) {
-                    gL[in[2]] += adj[in[0]];
-                    gL[2 * C + in[2]] += adj[in[1]];
-                    adj[in[0]] = 0.f; adj[in[1]] = 0.f;
-                } else if (kind == K_SIGNAL) {
-                    // several lanes may look at the same intersection: through the outbox, applied in lane order
-                    used_ob = true;
-                    if (n_sig < 3) { obi[mw_lane * 5 + 2 + n_sig] = in[1]; obf[mw_lane * 5 + 2 + n_sig] = adj[in[0]] * sg[6 * in[1] + 2 + (in[2] - 1)]; }
-                    ++n_sig;
-                    adj[in[0]] = 0.f;
-                } else if (kind == K_IMPORT) {
-                    // the leader's position / speed slots belong to another lane
-                    used_ob = true;
-                    obi[mw_lane * 5 + 0] = in[2]; obf[mw_lane * 5 + 0] = adj[in[0]];
-                    obi[mw_lane * 5 + 1] = in[3]; obf[mw_lane * 5 + 1] = adj[in[1]];
-                    adj[in[0]] = 0.f; adj[in[1]] = 0.f;
-                }
-            }
-        };
-        if (in_mw) {
-            replay(seg_lo[2], seg_n[2]);                 // the vehicles' loss terms, then the commits
-            // A capacitor's charge precedes ALL hand-off events of its step (a deposit may rewrite the very cell it read), and
-            // lanes replay side by side: the events of every lane first (lane 0 holds them), the capacitors afterwards
-            replay(seg_lo[1], seg_n[1]);
-            // cap' = cap + (r u) dt (no record since round 3): the slot's cotangent passes through to the previous level if that
-            // was a variable and reaches the cell as ((a dt) u, (a dt) r); the u leaf may also carry a spawned vehicle's speed
-            if (mw_lane < kMaxCaps && ((w_capflag >> mw_lane) & 1u)) {
-                const int out = 3 * V + mw_lane, leaf = 3 * V + kMaxCaps + mw_lane;
-                const float a = adj[out];
-                adj[out] = ((w_capflag >> (16 + mw_lane)) & 1u) ? a : 0.f;
-                const float ad = a * dtf;
-                const float g_u = adj[leaf] + ad * w_capru.y;
-                adj[leaf] = 0.f;
-                gL[cap_last_r] += ad * w_capru.x;
-                gL[2 * C + cap_last_r] += g_u;
-            }
-        }
-        // ghost threads: the forward blend of this step's ghost (everything that needs no cotangent), while only the micro
-        // wave has work; the cotangent part follows two phases later
-        float gh_gr = 0.f, gh_gu = 0.f, gh_s = 1.f, gh_fr = 0.f, gh_fu = 0.f, gh_ds = 0.f, gh_ds2 = 0.f; int gh_cell = -1, gh_kd = 0;
-        if (is_ghost && g_macro) {
-            if (g_side == 0) {
-                if (src >= 0) {
-                    gh_cell = lfl[src] >> 16;
-                    gh_gr = Hc[gh_cell]; gh_gu = Hc[2 * C + gh_cell];
-                    int it = 0;
-                    if (gate == -1) gh_s = 0.f;
-                    else if (gate >= 0) { gh_kd = linfo[gate] & 3; it = linfo[gate] >> 2; if (gh_kd != 0) gh_s = sg[6 * it + (gh_kd - 1)]; }
-                    gh_fr = gh_gr * gh_s + 0.f * (1.0f - gh_s); gh_fu = gh_gu * gh_s + um * (1.0f - gh_s);
-                    if (gh_kd != 0) gh_ds = sg[6 * it + 2 + (gh_kd - 1)];
-                    if (gh_kd != 0 && it != g_inter) bad_key = true;
-                }
-            } else {
-                gh_cell = src < 0 ? -1 : (lfl[src] & 0xffff);
-                gh_gr = src < 0 ? w_own_r : Hc[gh_cell];
-                gh_gu = src < 0 ? w_own_u : Hc[2 * C + gh_cell];
-                const float sgl = g_kind != 0 ? sg[6 * g_inter + (g_kind - 1)] : 1.f;
-                gh_s = soft_switch(sgl - 0.5f, kSigK);
-                gh_fr = gh_s * gh_gr + (1.0f - gh_s) * 1.0f; gh_fu = gh_s * gh_gu + (1.0f - gh_s) * 0.0f;
-                if (g_kind != 0) { gh_ds = soft_switch_grad(sgl - 0.5f, kSigK); gh_ds2 = sg[6 * g_inter + 2 + (g_kind - 1)]; }
-            }
-        }
-        HYB_BARRIER(1);
-        // ================= R3: speed cotangents into (r, y); J^T g per cell =================
-        float v_r = 0.f, v_y = 0.f;
-        if (is_cell) {
-            const int c = tid;
-            float gr = gL[c], gy = gL[C + c];
-            glue_u_bwd(Hn[c], Hn[C + c], um, gL[2 * C + c], gr, gy);
-            // the cell's blocks from the interface products, exactly as the reference forms them (dmacro_lane.py:126-129)
-            float4 d0, d1, d2;
-            d0.x = c_ncf * (-aL.x); d0.y = c_ncf * (-aL.y); d0.z = c_ncf * (-aL.z); d0.w = c_ncf * (-aL.w);
-            d2.x = c_ncf * bR.x; d2.y = c_ncf * bR.y; d2.z = c_ncf * bR.z; d2.w = c_ncf * bR.w;
-            d1.x = 1.f - c_cf * (aR.x - bL.x); d1.y = 0.f - c_cf * (aR.y - bL.y);
-            d1.z = 0.f - c_cf * (aR.z - bL.z); d1.w = 1.f - c_cf * (aR.w - bL.w);
-            c0[c] = dot2(d0.x, gr, d0.z, gy); c0[C + c] = dot2(d0.y, gr, d0.w, gy);
-            c2[c] = dot2(d2.x, gr, d2.z, gy); c2[C + c] = dot2(d2.y, gr, d2.w, gy);
-            v_r = dot2(d1.x, gr, d1.z, gy); v_y = dot2(d1.y, gr, d1.w, gy);
-        }
-        HYB_BARRIER(2);
-        // ================= R4: gather inside the lane; ghost cotangents | rest of the micro records =================
-        if (is_cell) {
-            const int c = tid;
-            if (c > c_first) { v_r += c2[c - 1]; v_y += c2[C + c - 1]; }
-            if (c < c_last) { v_r += c0[c + 1]; v_y += c0[C + c + 1]; }
-        }
-        if (is_ghost && g_macro) {
-            float tgt = -1.f, add_r = 0.f, add_u = 0.f, a_val = 0.f;
-            if (g_side == 0) {
-                if (src >= 0) {
-                    float g_fr = c0[g_off], g_fu = 0.f;
-                    glue_y_bwd(gh_fr, gh_fu, um, c0[C + g_off], g_fr, g_fu);
-                    add_r = g_fr * gh_s; add_u = g_fu * gh_s;
-                    tgt = (float)gh_cell;
-                    if (gh_kd != 0) a_val = (g_fr * gh_gr + g_fu * (gh_gu - um)) * gh_ds;
-                }
-            } else {
-                const int lastc = g_off + g_n - 1;
-                float g_fr = c2[lastc] + gown_r, g_fu = gown_u;      // the blended ghost is also the stored one
-                glue_y_bwd(gh_fr, gh_fu, um, c2[C + lastc], g_fr, g_fu);
-                if (src >= 0) { add_r = g_fr * gh_s; add_u = g_fu * gh_s; tgt = (float)gh_cell; gown_r = 0.f; gown_u = 0.f; }
-                else { gown_r = g_fr * gh_s; gown_u = g_fu * gh_s; }
-                if (g_kind != 0) {
-                    const float g_s2 = g_fr * (gh_gr - 1.0f) + g_fu * gh_gu;
-                    a_val = g_s2 * gh_ds * gh_ds2;
-                }
-            }
-            if (tgt >= 0.f) {
-                float *box = g_side == 0 ? inL : inF;
-#pragma unroll
-                for (int i = 0; i < kMaxCand; ++i)
-                    if (cand_src[i] == src) { box[3 * cand_pos[i]] = add_r; box[3 * cand_pos[i] + 1] = 0.f; box[3 * cand_pos[i] + 2] = add_u; }
-            }
-            aval[2 * g_lane + g_side] = a_val;          // the intersections sum their ghosts in (lane, side) order
-        }
-        if (in_mw) {
-            if (seg_n[0] > 0) for (int q = 0; q < 5; ++q) obi[mw_lane * 5 + q] = -1;
-            replay(seg_lo[0], seg_n[0]);                 // IDM steps, then the head gaps
-            unsigned long long obm = __ballot(used_ob);
-            if (is_mt) {                                 // outboxes in lane order
-                while (obm) {
-                    const int s_ = __ffsll((long long)obm) - 1;
-                    obm &= obm - 1;
-                    for (int q = 0; q < 2; ++q) if (obi[s_ * 5 + q] >= 0) adj[obi[s_ * 5 + q]] += obf[s_ * 5 + q];
-                    for (int q = 2; q < 5; ++q) if (obi[s_ * 5 + q] >= 0) gam[obi[s_ * 5 + q]] += obf[s_ * 5 + q];
-                }
-            }
-        }
-        HYB_BARRIER(3);
-        // ================= R5: edge cells take their inboxes; action partials =================
-        if (is_cell) {
-            float v_u = 0.f;
-#pragma unroll
-            for (int i = 0; i < kMaxEnt; ++i) {
-                if (ent[i] >= 0) {
-                    float *box = (ent[i] & 1) ? inF : inL;
-                    const int k = ent[i] >> 1;
-                    v_r += box[3 * k]; v_y += box[3 * k + 1]; v_u += box[3 * k + 2];
-                    box[3 * k] = 0.f; box[3 * k + 1] = 0.f; box[3 * k + 2] = 0.f;
-                }
-            }
-            gL[tid] = v_r; gL[C + tid] = v_y; gL[2 * C + tid] = v_u;
-            if (bad_step < 0 && !(isfinite(v_r) && isfinite(v_y) && isfinite(v_u))) bad_step = t;
-        }
-        if (in_rows) {
-            double v = 0.;
-            if (row_mode) {
-                for (int k = iptr[own_q] + ((tid - row_base) & 15); k < iptr[own_q + 1]; k += 16) v += (double)aval[iidx[k]];
-                v = row_scan_add(v);
-            } else {
-                for (int k = iptr[own_q]; k < iptr[own_q + 1]; ++k) v += (double)aval[iidx[k]];
-            }
-            if (is_own) {
-                v += (double)gam[own_q]; gam[own_q] = 0.f;
-                const int lastp = n_action / sq - 1;
-                const int phase = rev_ph > lastp ? lastp : rev_ph;
-                if (phase != cur_phase) { if (cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + own_q] = (float)ga; ga = 0.; cur_phase = phase; }
-                ga += v;
-            }
-        }
-        if (rev_fr == 0) { rev_fr = F - 1; --rev_ph; } else --rev_fr;
-        HYB_BARRIER(4);
     }
     HYB_STAMP_WRITE(1, rep, tid, B)
     if (is_own && cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + own_q] = (float)ga;
