@@ -240,100 +240,23 @@ __global__ void __launch_bounds__(kMaxBlock) net_macro_fwd_kernel(int R, int L, 
 #else
 #define NET_STAMP(i)
 #endif
-    for (int t = 0; t < T; ++t) {
-        const float *cur = (t & 1) ? S1 : S0;
-        float *nxt = (t & 1) ? S0 : S1;
-        const int src = p_src, gate = p_gate; const double sched = p_sched;
-        fetch(t + 1);
-        // ---- phase 1: ghosts of step t (_simulator.py:56-137) | loss scan of the state after step t-1
-        if (is_ghost) {
-            float fr, fu, fy, fq;
-            if (g_side == 0) {
-                if (src < 0) {                 // source lane: Python floats in the reference
-                    const double gu = um_d * (1. - sqrt(fmax(sched, 0.) + kEps));
-                    fr = (float)sched; fu = (float)gu; fy = 0.f; fq = (float)gu;      // y = r (u - u_eq(r)) = 0
-                } else {
-                    const int last = lfl[src] >> 16;
-                    const float gr = cur[last], gu = cur[2 * C + last];
-                    float s = 1.f;
-                    if (gate == -1) s = 0.f;
-                    else if (gate >= 0) {
-                        const int kd = linfo[gate] & 3;
-                        if (kd != 0) s = sig[4 * (linfo[gate] >> 2) + (kd - 1)];
-                    }
-                    fr = gr * s + 0.f * (1.0f - s);
-                    fu = gu * s + um * (1.0f - s);
-                    glue_from_r_u(fr, fu, um, fy, fq);
-                }
-            } else {
-                float gr = own_r, gu = own_u;
-                if (src >= 0) { const int first = lfl[src] & 0xffff; gr = cur[first]; gu = cur[2 * C + first]; }
-                else if (!kHard) { own_w[(size_t)t * 2 * L + 2 * g_lane] = gr; own_w[(size_t)t * 2 * L + 2 * g_lane + 1] = gu; }
-                const float sg = g_kind != 0 ? sig[4 * g_inter + (g_kind - 1)] : 1.f;
-                const float s2 = kHard ? (sg > 0.5f ? 1.f : 0.f) : soft_switch(sg - 0.5f, kSigK);
-                fr = s2 * gr + (1.0f - s2) * 1.0f;
-                fu = s2 * gu + (1.0f - s2) * 0.0f;
-                glue_from_r_u(fr, fu, um, fy, fq);
-                own_r = fr; own_u = fu;
-            }
-            float *g = G + (size_t)(2 * g_lane + g_side) * 4;
-            g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
+    // With wavefronts of their own for the loss the step loop exists in two copies, the physics threads' and the loss threads'
+    // (each keeps only its own loop-carried state in registers; the barriers pair up by count).
+    if (kLossWaves && is_phys) {
+        for (int t = 0; t < T; ++t) {
+            constexpr int kRole = 1;
+#include "net_fwd_step.inc"
         }
-        NET_STAMP(0)
-        if (t > 0) loss_scan(cur);
-        NET_STAMP(1)
-        lds_barrier();
-        NET_STAMP(6)
-        // ---- phase 2: interface solves | loss constants
-        if (is_if) {
-            const float *gl = G + (size_t)(2 * i_lane) * 4, *gr_ = G + (size_t)(2 * i_lane + 1) * 4;
-            double rL, yL, uL, qL, rR, yR, uR, qR;
-            if (i_k == 0) { rL = gl[0]; yL = gl[1]; uL = gl[2]; qL = gl[3]; }
-            else { const int c = i_off + i_k - 1; rL = cur[c]; yL = cur[C + c]; uL = cur[2 * C + c]; qL = cur[3 * C + c]; }
-            if (i_k == i_n) { rR = gr_[0]; yR = gr_[1]; uR = gr_[2]; qR = gr_[3]; }
-            else { const int c = i_off + i_k; rR = cur[c]; yR = cur[C + c]; uR = cur[2 * C + c]; qR = cur[3 * C + c]; }
-            Iface f;
-            arz_interface(rL, yL, uL, qL, rR, yR, uR, qR, kconst, f);
-            if (f.cfl_bad && fault_step < 0) { fault_step = t; fault_index = i_k; }
-            Fq[2 * tid] = f.Fr; Fq[2 * tid + 1] = f.Fy;
-            float *ab = AB + (size_t)tid * 8;
-            ab[0] = f.A[0]; ab[1] = f.A[1]; ab[2] = f.A[2]; ab[3] = f.A[3];
-            ab[4] = f.B[0]; ab[5] = f.B[1]; ab[6] = f.B[2]; ab[7] = f.B[3];
+    } else if (kLossWaves) {
+        for (int t = 0; t < T; ++t) {
+            constexpr int kRole = 2;
+#include "net_fwd_step.inc"
         }
-        NET_STAMP(2)
-        if (t > 0) loss_consts(cur, t - 1);
-        NET_STAMP(3)
-        lds_barrier();
-        NET_STAMP(6)
-        // ---- phase 3: cell updates + tape + history (_macro_lane.py:103-114, dmacro_lane.py:126-129) | lane queues
-        if (is_cell) {
-            const int c = tid;
-            const float cf = (float)c_cc, ncf = (float)(-c_cc);
-            const int iL = c + c_lane, iR = iL + 1;
-            const float nr = (float)((double)cur[c] + (Fq[2 * iL] - Fq[2 * iR]) * c_cc);
-            const float ny = (float)((double)cur[C + c] + (Fq[2 * iL + 1] - Fq[2 * iR + 1]) * c_cc);
-            float nu, nq;
-            glue_from_r_y(nr, ny, um, nu, nq);
-            nxt[c] = nr; nxt[C + c] = ny; nxt[2 * C + c] = nu; nxt[3 * C + c] = nq;
-            if (!kHard) {
-                float *hn = hist_r + (size_t)(t + 1) * 4 * C;
-                hn[c] = nr; hn[C + c] = ny; hn[2 * C + c] = nu; hn[3 * C + c] = nq;
-                const float *aL = AB + (size_t)iL * 8, *aR = AB + (size_t)iR * 8;
-                float4 d0, d1, d2;
-                d0.x = ncf * (-aL[0]); d0.y = ncf * (-aL[1]); d0.z = ncf * (-aL[2]); d0.w = ncf * (-aL[3]);
-                d2.x = ncf * aR[4]; d2.y = ncf * aR[5]; d2.z = ncf * aR[6]; d2.w = ncf * aR[7];
-                d1.x = 1.f - cf * (aR[0] - aL[4]); d1.y = 0.f - cf * (aR[1] - aL[5]);
-                d1.z = 0.f - cf * (aR[2] - aL[6]); d1.w = 1.f - cf * (aR[3] - aL[7]);
-                float4 *tp = tape_r + (size_t)t * 3 * Cp;
-                tp[c] = d0; tp[Cp + c] = d1; tp[2 * Cp + c] = d2;
-            }
+    } else {
+        for (int t = 0; t < T; ++t) {
+            constexpr int kRole = 0;
+#include "net_fwd_step.inc"
         }
-        NET_STAMP(4)
-        if (t > 0) loss_lanes(t - 1);
-        if (t + 1 < T) signals();            // of step t + 1 (this step's ghosts read theirs two barriers ago)
-        NET_STAMP(5)
-        lds_barrier();
-        NET_STAMP(6)
     }
 #ifdef DHTS_NET_STAMPS
     if (rep == 0 && (tid & 63) == 0 && T > 0)
