@@ -335,6 +335,8 @@ __host__ __device__ inline int hyb_stage_h(int L, int C, int sq, int V, int NS, 
 // (profiles/r03q_hybrid_forward_ablation.log): the micro side's records 0.47 ms (and 0.80 ms of the reverse sweep's 2.65), the
 // loss' ordered running mean with its constants 0.36 ms (0.22 in the reverse sweep), tape / history / vehicles' loss terms the
 // rest.  -O2 / -Os builds of this file run at the same speed (68 KB of code either way, profiles/r03p_hybrid_opt_levels.log).
+// Late in round 3 the step loop was split by role (below: two copies, 256 -> 193 vector registers, no spills): 3.67 -> 3.44 ms, the
+// evaluation kernel 2.08 -> 1.80 ms; the numbers above are of the single loop.
 // kHard: an EVALUATION episode (ItscpEnv.step(action, False); Trainer.evaluate, trainer.py:94-142): hard signals float(a > progress)
 // (_env.py:928-960), the macro downstream ghost takes float(signal > 0.5) (_simulator.py:128-137), a head vehicle takes the green
 // gap when the signal of its own lane is >= 0.5 and the red one otherwise (scores 0 / 1 / 0, no running mean: _simulator.py:208-
