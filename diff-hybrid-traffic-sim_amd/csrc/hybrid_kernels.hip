@@ -894,7 +894,7 @@ __host__ __device__ inline HybLdsB hyb_lds_b(int L, int C, int sq, int V, int E)
     o.red = D(2);
     o.h0 = F(3 * (size_t)C); o.h1 = F(3 * (size_t)C); o.gl = F(3 * (size_t)C); o.c0 = F(2 * (size_t)C); o.c2 = F(2 * (size_t)C);
     o.gq = F(L); o.inl = F(3 * (size_t)E); o.inf = F(3 * (size_t)E); o.sg = F(6 * (size_t)sq);
-    o.adj = F(3 * (size_t)V + 2 * kMaxCaps + kMaxLocals); o.gam = F(sq);
+    o.adj = F(3 * (size_t)V + 2 * kMaxCaps + kMaxLocals); o.gam = F(2 * (size_t)sq);
     o.rk = F(kMaxStepRecords); o.ri = F(4 * (size_t)kMaxStepRecords); o.rw = F(4 * (size_t)kMaxStepRecords);
     o.cell_lane = F(C); o.obi = F(64 * 5); o.obf = F(64 * 5);
     o.aval = F(2 * (size_t)L); o.iptr = F((size_t)sq + 1); o.iidx = F(2 * (size_t)L);
@@ -976,7 +976,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         iptr[sq] = n;
     }
     for (int k = tid; k < n_adj; k += B) adj[k] = 0.f;
-    if (tid < sq) gam[tid] = 0.f;
+    if (tid < 2 * sq) gam[tid] = 0.f;
     if (is_cell) { gL[tid] = 0.f; gL[C + tid] = 0.f; gL[2 * C + tid] = 0.f; }
     __syncthreads();
     int c_lane = 0, c_first = 0, c_last = 0, c_macb = 0; float c_dxv = 0.f, c_cf = 0.f, c_ncf = 0.f;
@@ -1150,6 +1150,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         }
     }
     HYB_STAMP_WRITE(1, rep, tid, B)
+    if (is_own && T > 0) ga += (double)gam[own_q];       // step 0's outboxes (buffer 0; the loop's last barrier is behind them)
     if (is_own && cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + own_q] = (float)ga;
     if (bad_step >= 0) net_fault(err, DHTS_FAULT_NAN, bad_step, rep, tid);
     if ((over && is_mt) || bad_key) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, bad_key ? -2 : 0);
