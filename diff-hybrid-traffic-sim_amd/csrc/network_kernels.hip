@@ -243,6 +243,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_macro_fwd_kernel(int R, int L, 
     // With wavefronts of their own for the loss the step loop exists in two copies, the physics threads' and the loss threads'
     // (each keeps only its own loop-carried state in registers; the barriers pair up by count).
     if (kLossWaves && is_phys) {
+        __builtin_amdgcn_s_setprio(1);        // (the physics threads' phases are the longer ones: 0.752 -> 0.746 ms)
         for (int t = 0; t < T; ++t) {
             constexpr int kRole = 1;
 #include "net_fwd_step.inc"
@@ -416,6 +417,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_macro_bwd_kernel(int R, int L, 
     // actions of phases the rollout never reaches get a zero gradient (thread q owns the entries of intersection q)
     if (tid < sq) for (int k = tid; k < n_action; k += sq) g_action[(size_t)rep * n_action + k] = 0.f;
 
+    if (__any(is_ghost)) __builtin_amdgcn_s_setprio(1);      // the wavefronts with ghost threads carry the longest phase (0.722 -> 0.707 ms)
     for (int t = T - 1; t >= 0; --t) {
         float *Hc = (t & 1) ? H1 : H0;           // row t   (state before step t)
         const float *Hn = (t & 1) ? H0 : H1;     // row t+1 (state after step t)
