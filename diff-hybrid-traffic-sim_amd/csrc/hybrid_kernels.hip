@@ -979,7 +979,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         iptr[sq] = n;
     }
     for (int k = tid; k < n_adj; k += B) adj[k] = 0.f;
-    if (tid < 2 * sq) gam[tid] = 0.f;
+    for (int k = tid; k < 2 * sq; k += B) gam[k] = 0.f;
     if (is_cell) { gL[tid] = 0.f; gL[C + tid] = 0.f; gL[2 * C + tid] = 0.f; }
     __syncthreads();
     int c_lane = 0, c_first = 0, c_last = 0, c_macb = 0; float c_dxv = 0.f, c_cf = 0.f, c_ncf = 0.f;
