@@ -188,7 +188,19 @@ class MacroWorkload:
         g_u0 = ops.macro_state_from_ru_bwd(self.r0, self.u0, g_y0, g_r0, self.um)
         return loss, g_r0, g_u0
 
-    def cpu_baseline(self):
+    def parity_check(self, g_a, g_b):
+        """The last timed pass of THIS run against the oracle's run of the same lanes (cpu_baseline keeps its first pass): final
+        (r, u) and d loss / d (r0, u0) of lanes 0 .. cores - 1, norm-relative per tensor."""
+        o = getattr(self, "oracle_sample", None)
+        if o is None:
+            return None
+        n = o["lanes"]
+        st = max(_rel(self.out[0][:n].cpu().numpy(), o["state"][0]), _rel(self.out[2][:n].cpu().numpy(), o["state"][1]))
+        gr = max(_rel(g_a[:n].cpu().numpy(), o["grad"][0]), _rel(g_b[:n].cpu().numpy(), o["grad"][1]))
+        return {"state_rel": st, "grad_rel": gr, "lanes": n, "against": "oracle (C port, pinned by tests/golden) on the same inputs, all %d steps" % self.T,
+                "what": "r_T, u_T | d loss / d r0, d loss / d u0 of the last timed pass", "tol_state": TOL_STATE, "tol_grad": TOL_GRAD}
+
+    def cpu_baseline(self, seconds=10.0):
         """The C oracle (a port of the reference's algorithm) on the host cores: bounded sample of the same workload -- one
         lane per core x 512 cells x 1000 steps (a lane's tape stays with the thread that wrote it; the arrays of the first
         pass are reused by the later ones, so the passes do not fault in fresh pages), repeated for >= 10 s -- and the same
@@ -200,22 +212,26 @@ class MacroWorkload:
         Lc, N, T = cores, self.N, self.T
         if Lc * N * T * 48 > 16e9:                   # bound the sample's tape to 16 GB of host memory
             T = max(50, int(16e9 // (Lc * N * 48)))
-        r0, u0, gr, gu = (t.numpy() for t in self.inputs(0, Lc, N, self.um))
+        # the first Lc lanes of the very tensors the GPU passes ran on (rank 0's batch)
+        r0, u0, gr, gu = (np.ascontiguousarray(t.numpy()[:Lc]) for t in self.inputs(0, self.L, N, self.um))
         O.macro_rollout_fwd(r0[:2], u0[:2], gr[:2], gu[:2], 2, self.dt, self.dx, self.um)   # load + warm
         f = O.macro_rollout_fwd(r0, u0, gr, gu, T, self.dt, self.dx, self.um)               # first touch of the tape: not timed
+        b = O.macro_rollout_bwd(f, g_rT=2 * f["rT"], g_uT=2 * f["uT"])
+        if T == self.T and f["rc"] == 0:
+            self.oracle_sample = {"lanes": Lc, "state": (f["rT"].copy(), f["uT"].copy()), "grad": (b["g_r0"].copy(), b["g_u0"].copy())}
         done, t0 = 0, time.perf_counter()
         while True:
             f = O.macro_rollout_fwd(r0, u0, gr, gu, T, self.dt, self.dx, self.um, out=f)
             O.macro_rollout_bwd(f, g_rT=2 * f["rT"], g_uT=2 * f["uT"])
             done += Lc * N * T
             el = time.perf_counter() - t0
-            if el >= 10.0:
+            if el >= seconds:
                 break
         del f
         # the same code on one core: a single lane leaves the OpenMP loop over lanes with one iteration
         f1 = O.macro_rollout_fwd(r0[:1], u0[:1], gr[:1], gu[:1], T, self.dt, self.dx, self.um)
         one, t1 = 0, time.perf_counter()
-        while time.perf_counter() - t1 < 2.0:
+        while time.perf_counter() - t1 < 0.2 * seconds:
             f1 = O.macro_rollout_fwd(r0[:1], u0[:1], gr[:1], gu[:1], T, self.dt, self.dx, self.um, out=f1)
             O.macro_rollout_bwd(f1, g_rT=2 * f1["rT"], g_uT=2 * f1["uT"])
             one += N * T
@@ -287,7 +303,18 @@ class MicroWorkload:
             self.ev.append(e)
         return loss, g_p0, g_v0
 
-    def cpu_baseline(self):
+    def parity_check(self, g_a, g_b):
+        """As MacroWorkload.parity_check: final (p, v) and d loss / d (p0, v0) of lanes 0 .. cores - 1."""
+        o = getattr(self, "oracle_sample", None)
+        if o is None:
+            return None
+        n = o["lanes"]
+        st = max(_rel(self.out[0][:n].cpu().numpy(), o["state"][0]), _rel(self.out[1][:n].cpu().numpy(), o["state"][1]))
+        gr = max(_rel(g_a[:n].cpu().numpy(), o["grad"][0]), _rel(g_b[:n].cpu().numpy(), o["grad"][1]))
+        return {"state_rel": st, "grad_rel": gr, "lanes": n, "against": "oracle (C port, pinned by tests/golden) on the same inputs, all %d steps" % self.T,
+                "what": "p_T, v_T | d loss / d p0, d loss / d v0 of the last timed pass", "tol_state": TOL_STATE, "tol_grad": TOL_GRAD}
+
+    def cpu_baseline(self, seconds=10.0):
         """As MacroWorkload.cpu_baseline: one lane per core x 256 vehicles x 1000 steps, tape reused."""
         import numpy as np
         from oracle import oracle as O
@@ -296,22 +323,25 @@ class MicroWorkload:
         Lc, V, T = cores, self.V, self.T
         if Lc * V * T * 32 > 16e9:
             T = max(50, int(16e9 // (Lc * V * 32)))
-        p0, v0 = (t.numpy() for t in self.inputs(0, Lc, V))
+        p0, v0 = (np.ascontiguousarray(t.numpy()[:Lc]) for t in self.inputs(0, self.L, V))     # lanes of rank 0's own batch
         par = np.tile(np.array(self.PARAMS), (Lc, V, 1))
         O.micro_rollout_fwd(p0[:2], v0[:2], par[:2], 2, self.dt)
         f = O.micro_rollout_fwd(p0, v0, par, T, self.dt)
+        b = O.micro_rollout_bwd(f, g_pT=2e-4 * f["pT"], g_vT=2 * f["vT"])
+        if T == self.T and f["rc"] == 0:
+            self.oracle_sample = {"lanes": Lc, "state": (f["pT"].copy(), f["vT"].copy()), "grad": (b["g_p0"].copy(), b["g_v0"].copy())}
         done, t0 = 0, time.perf_counter()
         while True:
             f = O.micro_rollout_fwd(p0, v0, par, T, self.dt, out=f)
             O.micro_rollout_bwd(f, g_pT=2e-4 * f["pT"], g_vT=2 * f["vT"])
             done += Lc * V * T
             el = time.perf_counter() - t0
-            if el >= 10.0:
+            if el >= seconds:
                 break
         del f
         f1 = O.micro_rollout_fwd(p0[:1], v0[:1], par[:1], T, self.dt)
         one, t1 = 0, time.perf_counter()
-        while time.perf_counter() - t1 < 2.0:
+        while time.perf_counter() - t1 < 0.2 * seconds:
             f1 = O.micro_rollout_fwd(p0[:1], v0[:1], par[:1], T, self.dt, out=f1)
             O.micro_rollout_bwd(f1, g_pT=2e-4 * f1["pT"], g_vT=2 * f1["vT"])
             one += V * T
@@ -374,6 +404,7 @@ class ItscpMacroWorkload:
             e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             e[0].record()
         reward, _ = self.ops.net_macro_rollout(self.action, self.tab, self.sq, self.F, self.dt, self.um, err=self.err)
+        self.reward = reward.detach()
         if record:
             e[1].record()
         loss = -reward.sum()
@@ -385,16 +416,28 @@ class ItscpMacroWorkload:
             self.ev.append(e)
         return loss.detach(), self.action.grad, self.action.grad
 
-    def cpu_baseline(self):
+    def parity_check(self, g_a, g_b):
+        """Replica 0 of the last timed pass against the oracle's episode: reward and d reward / d action."""
+        o = getattr(self, "oracle_sample", None)
+        if o is None:
+            return None
+        rew = float(self.reward[0])
+        return {"state_rel": abs(rew - o["reward"]) / max(abs(o["reward"]), 1e-30), "grad_rel": _rel(-g_a[0].cpu().numpy(), o["g_action"]),
+                "lanes": 1, "against": "oracle (C port, pinned by tests/golden) on replica 0's schedule and action, all %d steps" % self.T,
+                "what": "reward | d reward / d action of replica 0 in the last timed pass", "tol_state": TOL_STATE, "tol_grad": TOL_GRAD}
+
+    def cpu_baseline(self, seconds=10.0):
         """The C oracle of the macro network (scalar, one core): whole episodes of replica 0, repeated for >= 10 s."""
         from oracle import oracle as O
         a = self.action[0].detach().cpu().numpy()
         done, t0 = 0, time.perf_counter()
         while True:
-            O.net_macro(self.host_tab, a, self.sq, self.F, self.dt, self.um)
+            o = O.net_macro(self.host_tab, a, self.sq, self.F, self.dt, self.um)
+            if done == 0:
+                self.oracle_sample = {"reward": float(o["reward"]), "g_action": o["g_action"].copy()}
             done += self.N * self.T
             el = time.perf_counter() - t0
-            if el >= 10.0:
+            if el >= seconds:
                 break
         return {"value": done / el, "unit": "cell-steps/s", "cores": 1, "kind": "port",
                 "sample": "replica 0's episode (%d cells x %d steps) fwd+bwd, repeated %.1f s on one core" % (self.N, self.T, el)}
@@ -466,6 +509,7 @@ class ItscpHybridWorkload:
             e[0].record()
         # faults go to the workload's own sticky record, read once behind the timed region (as for the straight lanes)
         reward, _, _, self.counts = self.ops.net_hybrid_rollout(self.action, self.tab, self.sq, self.F, self.dt, self.um, err=self.err)
+        self.reward = reward.detach()
         if record:
             e[1].record()
         loss = -reward.sum()
@@ -477,7 +521,20 @@ class ItscpHybridWorkload:
             self.ev.append(e)
         return loss.detach(), self.action.grad, self.action.grad
 
-    def cpu_baseline(self):
+    def parity_check(self, g_a, g_b):
+        """Replica 0 of the last timed pass against the oracle's episode of the same schedule and action: reward, number of
+        vehicles spawned, d reward / d action (the pass differentiates -sum reward)."""
+        o = getattr(self, "oracle_sample", None)
+        if o is None:
+            return None
+        rew = float(self.reward[0])
+        return {"state_rel": abs(rew - o["reward"]) / max(abs(o["reward"]), 1e-30), "grad_rel": _rel(-g_a[0].cpu().numpy(), o["g_action"]),
+                "lanes": 1, "vehicles_spawned": [int(self.counts[0, 0]), o["n_spawned"]],
+                "against": "oracle (C port, pinned by tests/golden) on replica 0's schedule and action, all %d steps" % self.T,
+                "what": "reward | d reward / d action [%d] of replica 0 in the last timed pass; vehicles spawned (kernel, oracle)" % g_a.shape[1],
+                "tol_state": TOL_STATE, "tol_grad": TOL_GRAD}
+
+    def cpu_baseline(self, seconds=10.0):
         """The C oracle of the hybrid network (scalar, one core): whole episodes of replica 0, repeated for >= 10 s."""
         from dhts.network import group_routes
         from oracle import oracle as O
@@ -487,13 +544,25 @@ class ItscpHybridWorkload:
         while True:
             o = O.net_hybrid(self.host_tab, routes, ptr, a, self.sq, self.F, self.dt, self.um)
             assert o["rc"] == 0
+            if done == 0:
+                self.oracle_sample = {"reward": float(o["reward"]), "n_spawned": int(o["n_spawned"]), "g_action": o["g_action"].copy()}
             done += self.N * self.T
             el = time.perf_counter() - t0
-            if el >= 10.0:
+            if el >= seconds:
                 break
         return {"value": done / el, "unit": "cell-steps/s", "cores": 1, "kind": "port",
                 "sample": "replica 0's episode (%d cells x %d steps, %d vehicles) fwd+bwd, repeated %.1f s on one core"
                           % (self.N, self.T, o["n_spawned"], el)}
+
+
+TOL_STATE, TOL_GRAD = 1e-5, 1e-4     # BASELINE.json north_star: state <= 1e-5 relative, gradients <= 1e-4 (norm-relative)
+
+
+def _rel(a, ref):
+    """max |a - ref| / max |ref| (the criterion of tests/util.py:rel_max)"""
+    import numpy as np
+    a, ref = np.asarray(a, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return float(np.max(np.abs(a - ref)) / max(float(np.max(np.abs(ref))), 1e-30))
 
 
 def make_workload(name, dev, rank, lanes=0, cells=0, time_steps=0):
@@ -592,6 +661,19 @@ def kernel_records(w):
     return rec, ("rollout_fwd" if fwd_avg >= bwd_avg else "rollout_bwd")
 
 
+def check_parity(rec, name):
+    """True (and a line on stderr) when a parity_check record is outside the contract's tolerances."""
+    if rec is None:
+        return False
+    bad = not (rec["state_rel"] <= rec["tol_state"] and rec["grad_rel"] <= rec["tol_grad"])
+    if "vehicles_spawned" in rec:
+        bad |= rec["vehicles_spawned"][0] != rec["vehicles_spawned"][1]
+    rec["ok"] = not bad
+    if bad:
+        print("bench.py: PARITY FAILURE on %s: %s" % (name, json.dumps(rec)), file=sys.stderr)
+    return bad
+
+
 def also_record(name, dev, passes=5):
     """A short run of another BASELINE configuration in the same process (not the headline; no collective)."""
     w = make_workload(name, dev, 0)
@@ -600,7 +682,7 @@ def also_record(name, dev, passes=5):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(passes):
-        w.one_pass(record=True)
+        _, g_a, g_b = w.one_pass(record=True)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     fault = w.err.tolist()
@@ -610,7 +692,7 @@ def also_record(name, dev, passes=5):
            "ms_per_pass": el / passes * 1e3, "dominant_kernel": dom, "limiter": w.limiter.get(dom, "hbm"), "kernels": kernels}
     if getattr(w, "counts", None) is not None:
         out["vehicles_spawned_replica0"] = int(w.counts[0, 0])
-    return out
+    return out, w, (g_a, g_b)
 
 
 def main():
@@ -661,6 +743,7 @@ def main():
     # every rank's own [gradient || loss] of the last pass, gathered so that rank 0 can show the all-reduce summed them
     parts = D.gather_to_rank0(local_part) if world > 1 else None
 
+    parity_failed = False
     if rank == 0:
         kernels, dom = kernel_records(w)
         k = kernels[dom]
@@ -713,11 +796,26 @@ def main():
             if args.workload == "macro" and not args.lanes and not args.cells and not args.time_steps and not args.no_also:
                 del w.tape            # 24 GB back to the allocator before the other workloads take theirs
                 torch.cuda.empty_cache()
-                out["also"] = [also_record("micro", dev), also_record("itscp_hybrid", dev)]
+                out["also"] = []
+                for name in ("micro", "itscp_hybrid"):
+                    rec, w2, g2 = also_record(name, dev)
+                    if not args.no_cpu_baseline:
+                        # the oracle on a sample of this sub-record's own inputs (its rate is reported, the headline's is cpu_baseline)
+                        rec["cpu_baseline"] = w2.cpu_baseline(seconds=3.0)
+                        rec["parity_check"] = w2.parity_check(*g2)
+                        parity_failed |= check_parity(rec["parity_check"], rec["workload"])
+                    del w2, g2
+                    torch.cuda.empty_cache()
+                    out["also"].append(rec)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = w.cpu_baseline()
+                # what this run timed, checked on this box: the last timed pass against the oracle's run of the same inputs
+                out["parity_check"] = w.parity_check(g_a, g_b)
+                parity_failed |= check_parity(out["parity_check"], w.name)
         print(json.dumps(out))
     D.barrier()
+    if parity_failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -394,8 +394,10 @@ __device__ __forceinline__ void arz_pre_fast(double rL, double uL, double qL, do
 // lambda_0(Q_m): |u_R| + u_max |b| / 2 with |b| <= sqrt(r_L) + |u_L - u_R| / u_max; u of the vacuum-side state:
 // u_max + |u_L| + |u_eq,L|).  An interface that fails the bound is treated as non-trivial, i.e. handed to the full solver
 // with its exact CFL test.  Fills the fields of `p` that arz_trivial_fast reads.
-__device__ __forceinline__ bool arz_is_trivial_fast(double rL, double uL, double qL, double rR, double uR, const CellPre &cl,
-                                                    const IfaceConst &k, IfacePre &p) {
+// (vacR = r_R < eps is passed in: a caller that holds r_R as float32 tests it there -- r_R < 1e-5 (double) <=> r_R <= float32(1e-5),
+// because float32(1e-5) < 1e-5 < its successor)
+__device__ __forceinline__ bool arz_is_trivial_fast_v(double rL, double uL, double qL, bool vacR, double uR, const CellPre &cl,
+                                                      const IfaceConst &k, IfacePre &p) {
     const double um = k.um;
     p.rLc = fmax(rL, kEps);
     p.sL = cl.s; p.hL = cl.h; p.q0L = cl.q0;
@@ -403,7 +405,6 @@ __device__ __forceinline__ bool arz_is_trivial_fast(double rL, double uL, double
     p.inv_rLc = rsL * rsL;
     p.ueqp_L = -um * p.hL;
     const bool vacL = rL < kEps;
-    const bool vacR = rR < kEps;
     p.vacL = vacL;
     p.dU = uL - uR;
     const bool same = fabs(p.dU) < kEps;
@@ -417,6 +418,10 @@ __device__ __forceinline__ bool arz_is_trivial_fast(double rL, double uL, double
     const double bound = __builtin_fma(0.5, fabs(qL), fabs(uL) + fabs(uR)) + __builtin_fma(0.5 * um, p.sL, 0.5 * um);
     p.ci = 0; p.cfl_bad = false;
     return triv & (bound < k.cfl_lim) & k.lim_ok;
+}
+__device__ __forceinline__ bool arz_is_trivial_fast(double rL, double uL, double qL, double rR, double uR, const CellPre &cl,
+                                                    const IfaceConst &k, IfacePre &p) {
+    return arz_is_trivial_fast_v(rL, uL, qL, rR < kEps, uR, cl, k, p);
 }
 
 // flux of Q_0 and the flux Jacobian at Q_0 (darz.py:217-233; float32 entries, fp[1] = 1)
@@ -573,6 +578,89 @@ __device__ __forceinline__ void arz_interface_fast_pre(double rL, double yL, dou
                                                        double rR, double yR, double uR, double qR, const CellPre &cr,
                                                        const IfaceConst &k, Iface &o) {
     arz_interface_fast_impl<true>(rL, yL, uL, qL, rR, yR, uR, qR, &cl, &cr, k, o, nullptr);
+}
+
+// arz_interface_fast_pre for a wavefront of QUEUED interfaces (phase 2 of the pair rollout kernel): the same operations on the
+// same operands -- results are bit-identical -- laid out for a short instruction stream of ONE wavefront (phase 2 is a serial
+// section: its length in instructions is what a step pays for it):
+//   * the case logic runs on lane masks (64-bit scalar values from ballots), never through selects of booleans in vector registers;
+//   * Q_M / Q_C with their Jacobians are evaluated by every lane without branches (the few lanes whose interface turns out
+//     trivial -- the interfaces a queue always holds -- are overwritten at the end, in a block a wavefront without such a lane skips);
+//   * the cells' float32 state is taken as stored (no float64 copies of values only compared in float32).
+// ls / rs = (r, y, u, u_eq) of the left / right cell, (sL, hL, q0L) = the left cell's CellPre, hR = 0.5 / sqrt(max(r_R, eps)).
+__device__ __forceinline__ void arz_interface_queued(const float4 ls, double sL, double hL, double q0L, const float4 rs, double hR,
+                                                     const IfaceConst &k, Iface &o) {
+    typedef unsigned long long M;
+    const double um = k.um;
+    const double rL = (double)ls.x, yL = (double)ls.y, uL = (double)ls.z, qL = (double)ls.w;
+    const double yR = (double)rs.y, uR = (double)rs.z;
+    const double rLc = fmax(rL, kEps);
+    const double rsL = hL + hL;
+    const double inv_rLc = rsL * rsL;
+    const double ueqp_L = -um * hL;
+    // ---- case logic (arz_classify_fast) on lane masks ----
+    const M vacL = __builtin_amdgcn_ballot_w64(ls.x <= kEpsF);          // r < 1e-5 (double) <=> r <= float32(1e-5) for a float32 r
+    const M vacR = __builtin_amdgcn_ballot_w64(rs.x <= kEpsF);
+    const double dU = uL - uR;
+    const M same = __builtin_amdgcn_ballot_w64(fabs(dU) < kEps);
+    const M wave_m = ~(vacL | vacR | same);
+    const M b4 = wave_m & __builtin_amdgcn_ballot_w64(ls.z > rs.z);
+    const double qm_u = um + uL - qL;
+    const M b5 = wave_m & ~b4 & __builtin_amdgcn_ballot_w64(qm_u > uR);
+    const double bm = __builtin_fma(dU, k.inv_um, sL);
+    const double rm = bm * bm;
+    const double abm = fabs(bm);
+    const double l0l = __builtin_fma(rL, ueqp_L, uL);
+    const double diff = __builtin_fma(rm, uR, -(rL * uL));
+    const double l0m = (rm >= kEps) ? __builtin_fma(-0.5 * um, abm, uR) : __builtin_fma(rm, -um * kHalfRsqrtEps, uR);
+    const M l0l_ok = __builtin_amdgcn_ballot_w64(l0l >= 0.0);
+    const M zero0 = vacL | (same & ~vacR);
+    const M trivM = zero0 | (b4 & __builtin_amdgcn_ballot_w64(diff >= 0.0)) | (~b4 & l0l_ok);
+    const M midM = b4 | (b5 & __builtin_amdgcn_ballot_w64(l0m <= 0.0));
+    const bool triv = __builtin_amdgcn_inverse_ballot_w64(trivM);
+    const bool c1 = __builtin_amdgcn_inverse_ballot_w64(midM);
+    // ---- CFL (arz_classify_fast): the exact tests only where the cheap bound does not settle it ----
+    const double bound = __builtin_fma(0.5, fabs(qL), fabs(uL) + fabs(uR)) + __builtin_fma(0.5 * um, sL, 0.5 * um);
+    const bool sure = (bound < k.cfl_lim) & k.lim_ok;
+    o.cfl_bad = false;
+    if (__builtin_amdgcn_ballot_w64(!sure)) {
+        asm volatile("" ::: "memory");
+        const bool vL = __builtin_amdgcn_inverse_ballot_w64(vacL), vR = __builtin_amdgcn_inverse_ballot_w64(vacR);
+        const bool is4 = __builtin_amdgcn_inverse_ballot_w64(b4), is5 = __builtin_amdgcn_inverse_ballot_w64(b5);
+        const bool z0 = __builtin_amdgcn_inverse_ballot_w64(zero0);
+        const double den = fmax(rm - rL, kEps);
+        const bool ok_b4 = fabs(diff) < k.cfl_lim * den;
+        const bool ok_m = fabs(l0l + l0m) < k.cfl_lim2;
+        const bool ok_q = fabs(l0l + qm_u) < k.cfl_lim2;
+        const bool ok_avg = (is5 & ok_m) | (!is5 & ok_q);
+        const bool ok0 = z0 | (is4 & ok_b4) | (!is4 & ok_avg);
+        const bool ok_uL = fabs(uL) < k.cfl_lim, ok_uR = fabs(uR) < k.cfl_lim;
+        const bool ok1 = (vL & ok_uL) | (!vL & ((vR & ok_avg) | (!vR & ok_uR)));
+        o.cfl_bad = !(ok0 & ok1 & k.lim_ok);
+    }
+    // ---- Q_M (c1) / Q_C, their Jacobians, the flux and its Jacobian, the products: every lane (arz_mid_state ... arz_mid_products) ----
+    MidState m;
+    arz_mid_state(c1, uL, uR, sL, bm, k, m);
+    float dL[4], dR[4], fp[4];
+    arz_mid_jacobians_left(c1, yL, hL, inv_rLc, ueqp_L, m, k, dL);
+    arz_mid_jacobians_right(yR, hR, m, k, dR);
+    arz_flux_fp(m.r0, m.y0, m.u0, m.q0, m.r0c, m.h0, m.inv_r0c, um, o.Fr, o.Fy, fp);
+    arz_mid_products_left(fp, dL, o.A);
+    float B[4];
+    arz_mid_products_right(fp, dR, B);
+    o.B[0] = c1 ? B[0] : 0.f; o.B[1] = c1 ? B[1] : 0.f; o.B[2] = c1 ? B[2] : 0.f; o.B[3] = c1 ? B[3] : 0.f;
+    // ---- Q_0 = Q_L where the interface is trivial after all ----
+    if (__builtin_amdgcn_ballot_w64(triv)) {
+        asm volatile("" ::: "memory");
+        if (triv) {
+            const double qc = __builtin_amdgcn_inverse_ballot_w64(vacL) ? k.ueq_2eps : q0L;
+            const double u0 = __builtin_fma(yL, inv_rLc, qc);
+            float fpt[4];
+            arz_flux_fp(rL, yL, u0, q0L, rLc, hL, inv_rLc, um, o.Fr, o.Fy, fpt);
+            o.A[0] = fpt[0]; o.A[1] = fpt[1]; o.A[2] = fpt[2]; o.A[3] = fpt[3];
+            o.B[0] = o.B[1] = o.B[2] = o.B[3] = 0.f;
+        }
+    }
 }
 
 __device__ __forceinline__ void arz_interface(double rL, double yL, double uL, double qL,

@@ -483,6 +483,9 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
 __host__ __device__ inline size_t fwd2_region_bytes(int N) {
     return (sizeof(CellRec) * (size_t)(N + 2) + 16 * (size_t)(N + 1) + sizeof(int) * (size_t)(N + 2) + 16 + 15) & ~(size_t)15;
 }
+#ifdef DHTS_FWD3_STAMPS
+extern __device__ long long dhts_fwd_clock[2][16][2];     // macro_fwd_pairs.inc (instrumented builds only)
+#endif
 template <int kP, int kG, bool kTape>
 __global__ __launch_bounds__(1024) void macro_rollout_fwd2_group_kernel(
     int L, int N, int T, double dt, double dx, double um,
@@ -637,6 +640,9 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_group_kernel(
     };
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
+#ifdef DHTS_FWD3_STAMPS
+    const long long clk0_ = __builtin_amdgcn_s_memtime(), rt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
     if (T == 0) {
         body(no{}, no{}, 0);
     } else {
@@ -645,7 +651,15 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_group_kernel(
         body(yes{}, no{}, T);
     }
     if (fault_step >= 0) raise_fault(err, DHTS_FAULT_CFL, fault_step, fault_lane, fault_index);
+#ifdef DHTS_FWD3_STAMPS
+    if (blockIdx.x < 16 && tid == 0) {
+        dhts_fwd_clock[0][blockIdx.x][0] = __builtin_amdgcn_s_memtime() - clk0_;
+        dhts_fwd_clock[0][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - rt0_;
+    }
+#endif
 }
+
+#include "macro_fwd_pairs.inc"
 
 // ---- reverse sweeps -------------------------------------------------------------------------------------------------
 // g' = J^T g per step: grad_cell[a][k] = dqs[a][k]^T g[a]; g'[b] = (c1[b] + c2[b-1]) + c0[b+1]   (dmacro_lane.py:283-303)
@@ -1424,7 +1438,35 @@ static int macro_fwd2_launch(const dhts_macro_desc *d, int T,
 #define DHTS_FWD2_ARGS d->n_lanes, N, T, p, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, \
                        reinterpret_cast<float4 *>(tape), hist, err
     const int G = macro_fwd2_group(d, hist != nullptr);
-    if (G > 1) {
+    if (G > 1 && dhts_fwd_variant >= 2) {
+        // (experiment) the pair kernel: a thread owns two adjacent cells and their right interfaces (macro_fwd_pairs.inc)
+        const size_t ldsg = fwd3_lds_bytes(N, G);
+#define DHTS_FWDG_ARGS d->n_lanes, N, T, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, reinterpret_cast<float4 *>(tape), err
+#define DHTS_FWD3(GG, TT, VV)                                                                                                     \
+    {                                                                                                                             \
+        if (ldsg > 64 * 1024 && hipFuncSetAttribute((const void *)macro_rollout_fwd3_kernel<GG, TT, VV>,                          \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg) != hipSuccess)         \
+            return DHTS_E_LAUNCH;                                                                                                 \
+        macro_rollout_fwd3_kernel<GG, TT, VV><<<d->n_lanes / GG, 64 * GG * W, ldsg, (hipStream_t)stream>>>(DHTS_FWDG_ARGS);        \
+    }
+        const int V = dhts_fwd_variant - 2;
+        if (G == 2 && tape && V == 0) DHTS_FWD3(2, true, 0)
+        else if (G == 2 && tape && V == 1) DHTS_FWD3(2, true, 1)
+        else if (G == 2 && tape && V == 2) DHTS_FWD3(2, true, 2)
+        else if (G == 2 && tape) DHTS_FWD3(2, true, 3)
+        else if (G == 2 && V == 0) DHTS_FWD3(2, false, 0)
+        else if (G == 2 && V == 1) DHTS_FWD3(2, false, 1)
+        else if (G == 2) DHTS_FWD3(2, false, 2)
+        else if (tape && V == 0) DHTS_FWD3(4, true, 0)
+        else if (tape && V == 1) DHTS_FWD3(4, true, 1)
+        else if (tape && V == 2) DHTS_FWD3(4, true, 2)
+        else if (tape) DHTS_FWD3(4, true, 3)
+        else if (V == 0) DHTS_FWD3(4, false, 0)
+        else if (V == 1) DHTS_FWD3(4, false, 1)
+        else DHTS_FWD3(4, false, 2)
+#undef DHTS_FWD3
+#undef DHTS_FWDG_ARGS
+    } else if (G > 1) {
         const size_t ldsg = (size_t)G * fwd2_region_bytes(N);
         const void *fn = G == 2 ? (tape ? (const void *)macro_rollout_fwd2_group_kernel<2, 2, true> : (const void *)macro_rollout_fwd2_group_kernel<2, 2, false>)
                                 : (tape ? (const void *)macro_rollout_fwd2_group_kernel<2, 4, true> : (const void *)macro_rollout_fwd2_group_kernel<2, 4, false>);
@@ -1555,6 +1597,15 @@ static int macro_rollout_bwd_launch(const dhts_macro_desc *d, int T, const float
 
 extern int dhts_micro_fwd_waves_override;     // micro_kernels.hip
 
+#ifdef DHTS_FWD3_STAMPS
+extern "C" int dhts_debug_fwd_clock(long long *out) {         // [2 kernels][16 workgroups][2]
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dhts::dhts_fwd_clock), sizeof(long long) * 2 * 16 * 2) == hipSuccess ? 0 : -1;
+}
+extern "C" int dhts_debug_fwd3_stamps(long long *out) {       // [16 workgroups][16 wavefronts][8], macro_fwd_pairs.inc
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dhts::dhts_fwd3_stamps), sizeof(long long) * 16 * 16 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" {
 
 int dhts_set_option(int option, int value) {
@@ -1562,7 +1613,7 @@ int dhts_set_option(int option, int value) {
         dhts_fwd_waves_override = value;
         return DHTS_OK;
     }
-    if (option == DHTS_OPT_MACRO_FWD_VARIANT && (value == 0 || value == 1)) {
+    if (option == DHTS_OPT_MACRO_FWD_VARIANT && value >= 0 && value <= 5) {
         dhts_fwd_variant = value;
         return DHTS_OK;
     }
