@@ -1412,6 +1412,20 @@ static inline int macro_fwd2_group(const dhts_macro_desc *d, bool want_hist) {
     if (64 * W * G > 1024 || (size_t)G * fwd2_region_bytes(d->n_cells) > 160 * 1024) return 1;
     return G;
 }
+// The pair kernel (macro_fwd_pairs.inc) takes full lanes of 128 W cells without a state history; traffic lanes per workgroup as
+// for the lane-group kernel (four up to three wavefronts per lane, else two; one where the launch would leave CUs without a
+// workgroup or the lanes do not divide).  0 = not this kernel (DHTS_OPT_MACRO_FWD_VARIANT = 2 turns it off).
+static inline int macro_fwd3_group(const dhts_macro_desc *d, bool want_hist) {
+    if (dhts_fwd_variant != 0 || want_hist || d->n_cells % 128 != 0 || d->n_cells > 1024) return 0;
+    const int W = d->n_cells / 128;
+    if (dhts_fwd_waves_override > 0 && dhts_fwd_waves_override != W) return 0;       // (a forced wave count means the lane kernel)
+    int G = dhts_fwd_group > 0 ? dhts_fwd_group : (W <= 3 ? 4 : 2);
+    while (G > 1 && (d->n_lanes % G != 0 || (dhts_fwd_group == 0 && d->n_lanes / G < 256) || 64 * W * G > 1024 ||
+                     (size_t)G * fwd3_region_bytes(d->n_cells) > 160 * 1024))
+        G >>= 1;
+    if ((size_t)G * fwd3_region_bytes(d->n_cells) > 160 * 1024) return 0;
+    return G;
+}
 static inline int macro_bwd_fast_block(int N) { return N <= 64 ? 64 : (N <= 128 ? 128 : (N <= 256 ? 256 : (N <= 512 ? 512 : 1024))); }
 static inline bool macro_bwd_is_fast(int N, int T) { return N >= 2 && N <= 1024 && T > 0; }      // (T = 0: no tape to prefetch from)
 // the two-cells-per-thread sweep (1024 threads): lanes of 1026 .. 2048 cells without per-step cotangents (the step tag has 20 bits)
@@ -1438,32 +1452,24 @@ static int macro_fwd2_launch(const dhts_macro_desc *d, int T,
 #define DHTS_FWD2_ARGS d->n_lanes, N, T, p, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, \
                        reinterpret_cast<float4 *>(tape), hist, err
     const int G = macro_fwd2_group(d, hist != nullptr);
-    if (G > 1 && dhts_fwd_variant >= 2) {
-        // (experiment) the pair kernel: a thread owns two adjacent cells and their right interfaces (macro_fwd_pairs.inc)
-        const size_t ldsg = fwd3_lds_bytes(N, G);
+    const int G3 = macro_fwd3_group(d, hist != nullptr);
+    if (G3 > 0) {
+        // the pair kernel: a thread owns two adjacent cells and their right interfaces (macro_fwd_pairs.inc)
+        const size_t ldsg = (size_t)G3 * fwd3_region_bytes(N);
 #define DHTS_FWDG_ARGS d->n_lanes, N, T, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, reinterpret_cast<float4 *>(tape), err
-#define DHTS_FWD3(GG, TT, VV)                                                                                                     \
+#define DHTS_FWD3(GG, TT)                                                                                                         \
     {                                                                                                                             \
-        if (ldsg > 64 * 1024 && hipFuncSetAttribute((const void *)macro_rollout_fwd3_kernel<GG, TT, VV>,                          \
+        if (ldsg > 64 * 1024 && hipFuncSetAttribute((const void *)macro_rollout_fwd3_kernel<GG, TT>,                              \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg) != hipSuccess)         \
             return DHTS_E_LAUNCH;                                                                                                 \
-        macro_rollout_fwd3_kernel<GG, TT, VV><<<d->n_lanes / GG, 64 * GG * W, ldsg, (hipStream_t)stream>>>(DHTS_FWDG_ARGS);        \
+        macro_rollout_fwd3_kernel<GG, TT><<<d->n_lanes / GG, 64 * GG * (N / 128), ldsg, (hipStream_t)stream>>>(DHTS_FWDG_ARGS);    \
     }
-        const int V = dhts_fwd_variant - 2;
-        if (G == 2 && tape && V == 0) DHTS_FWD3(2, true, 0)
-        else if (G == 2 && tape && V == 1) DHTS_FWD3(2, true, 1)
-        else if (G == 2 && tape && V == 2) DHTS_FWD3(2, true, 2)
-        else if (G == 2 && tape) DHTS_FWD3(2, true, 3)
-        else if (G == 2 && V == 0) DHTS_FWD3(2, false, 0)
-        else if (G == 2 && V == 1) DHTS_FWD3(2, false, 1)
-        else if (G == 2) DHTS_FWD3(2, false, 2)
-        else if (tape && V == 0) DHTS_FWD3(4, true, 0)
-        else if (tape && V == 1) DHTS_FWD3(4, true, 1)
-        else if (tape && V == 2) DHTS_FWD3(4, true, 2)
-        else if (tape) DHTS_FWD3(4, true, 3)
-        else if (V == 0) DHTS_FWD3(4, false, 0)
-        else if (V == 1) DHTS_FWD3(4, false, 1)
-        else DHTS_FWD3(4, false, 2)
+        if (G3 == 1 && tape) DHTS_FWD3(1, true)
+        else if (G3 == 1) DHTS_FWD3(1, false)
+        else if (G3 == 2 && tape) DHTS_FWD3(2, true)
+        else if (G3 == 2) DHTS_FWD3(2, false)
+        else if (tape) DHTS_FWD3(4, true)
+        else DHTS_FWD3(4, false)
 #undef DHTS_FWD3
 #undef DHTS_FWDG_ARGS
     } else if (G > 1) {
@@ -1613,7 +1619,7 @@ int dhts_set_option(int option, int value) {
         dhts_fwd_waves_override = value;
         return DHTS_OK;
     }
-    if (option == DHTS_OPT_MACRO_FWD_VARIANT && value >= 0 && value <= 5) {
+    if (option == DHTS_OPT_MACRO_FWD_VARIANT && value >= 0 && value <= 2) {
         dhts_fwd_variant = value;
         return DHTS_OK;
     }
@@ -1696,6 +1702,7 @@ int dhts_macro_rollout_plan(const dhts_macro_desc *d, int T, int want_hist, int3
     } else {
         int W, p;
         macro_fwd2_plan(N, W, p);
+        plan[0] = macro_fwd3_group(d, want_hist != 0) > 0 ? 2 : 0;
         plan[1] = W;
         plan[2] = p;
         plan[3] = ((p == 1 || p == 2) && N == 64 * p * W && !want_hist) ? 1 : 0;
@@ -1703,7 +1710,7 @@ int dhts_macro_rollout_plan(const dhts_macro_desc *d, int T, int want_hist, int3
     plan[4] = macro_bwd_is_fast(N, T) ? 1 : (macro_bwd_is_fast2(N, T, want_hist != 0) ? 2 : 0);
     plan[5] = plan[4] == 1 ? macro_bwd_fast_block(N) : (plan[4] == 2 ? 1024 : (padded64(N) > 512 ? 512 : padded64(N)));
     plan[6] = want_hist ? 1 : 0;
-    plan[7] = plan[0] == 0 ? macro_fwd2_group(d, want_hist != 0) : 1;
+    plan[7] = plan[0] == 2 ? macro_fwd3_group(d, want_hist != 0) : (plan[0] == 0 ? macro_fwd2_group(d, want_hist != 0) : 1);
     return DHTS_OK;
 }
 int dhts_macro_tape_expand(const dhts_macro_desc *d, int T, const float *tape, float *dqs, void *stream) {

@@ -497,8 +497,10 @@ def test_macro_lane_groups_equal_one_lane_per_workgroup(cuda, N, group):
     desc = ops.macro_desc(L, N, dt, dx, um)
     res = []
     try:
+        assert _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_VARIANT, 2) == 0           # the lane / lane-group kernels (no pair kernel)
         for grp in (1, group):
             assert _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_GROUP, grp) == 0
+            assert ops.macro_rollout_plan(desc, T)["fwd_kernel"] == 0
             assert ops.macro_rollout_plan(desc, T)["fwd_lanes_per_group"] == grp
             assert _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_GROUP, 0) == 0           # the heuristic: 4 up to three wavefronts per lane
             assert ops.macro_rollout_plan(ops.macro_desc(1024, N, dt, dx, um), T)["fwd_lanes_per_group"] == (4 if N <= 384 else 2)
@@ -534,6 +536,81 @@ def test_macro_lane_groups_equal_one_lane_per_workgroup(cuda, N, group):
         assert rec[0] == _lib.FAULT_CFL and 0 <= rec[1] < T and rec[2] == bad and 0 <= rec[3] <= N, rec
     finally:
         _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_GROUP, 0)
+        _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_VARIANT, 0)
+
+
+@pytest.mark.parametrize("N,group", [(128, 1), (128, 4), (256, 2), (384, 4), (512, 1), (512, 2), (512, 4), (1024, 1)])
+def test_macro_pair_kernel_equals_lane_kernel(cuda, N, group):
+    """The pair kernel (a thread owns two adjacent cells and their right interfaces; what full lanes of 128 W cells launch) with
+    1, 2 or 4 traffic lanes per workgroup against the lane kernel (DHTS_OPT_MACRO_FWD_VARIANT = 2, one lane per workgroup): final
+    state, the blocks the tape expands to and the reverse sweep's gradients bit for bit, with and without a tape.  The lanes hold
+    vacuum stretches (the general form of phase 1 beside the dense one), a density of exactly float32(eps), an idle lane (only the
+    standing queue entries), a lane that queues nearly every interface (more entries than a round of phase 2 has threads) and
+    an empty lane; a CFL fault names the lane it is in."""
+    import torch
+    from dhts import _lib, ops
+    rng = np.random.default_rng(300 + N + group)
+    L, T, dt, dx, um = 256 * group, 40, 0.01, 5.0, 30.0
+    r0 = rng.uniform(0.02, 1.0, (L, N)).astype(np.float32)
+    r0[1, 10:20] = 0.0
+    r0[2] = 0.4                              # an idle lane
+    r0[3, 64] = np.float32(1e-5)             # exactly float32(eps)
+    r0[3, 65] = 1e-6
+    r0[5, ::2] = 0.0                         # the longest queue
+    r0[6] = 0.0                              # an empty lane
+    r0[7, 126:130 if N > 128 else 128] = 0.0 # vacuum across a wavefront's chunk boundary
+    r0[L - 1, N - 3:] = 0.0
+    u0 = rng.uniform(0.0, um, (L, N)).astype(np.float32)
+    u0[2] = 12.0
+    r, u = T_(r0, cuda), T_(u0, cuda)
+    y, q = ops.macro_state_from_ru(r, u, um)
+    gr = T_(rng.uniform(0.0, 1.0, (L, 2)).astype(np.float32), cuda)
+    gu = T_(rng.uniform(0.0, um, (L, 2)).astype(np.float32), cuda)
+    gy, gq = ops.macro_state_from_ru(gr, gu, um)
+    ghost = torch.stack([gr, gy, gu, gq], dim=-1).contiguous()
+    desc = ops.macro_desc(L, N, dt, dx, um)
+    res = []
+    try:
+        for variant, grp in ((2, 1), (0, group)):
+            assert _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_VARIANT, variant) == 0
+            assert _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_GROUP, grp) == 0
+            plan = ops.macro_rollout_plan(desc, T)
+            assert plan["fwd_kernel"] == (2 if variant == 0 else 0) and plan["fwd_lanes_per_group"] == grp, plan
+            if variant == 0:
+                # what does not take the pair kernel: a state history, lanes that are not 128 W cells, a forced wave count
+                assert ops.macro_rollout_plan(desc, T, want_hist=True)["fwd_kernel"] == 0
+                assert ops.macro_rollout_plan(ops.macro_desc(L, N - 1, dt, dx, um), T)["fwd_kernel"] == 0
+                assert ops.macro_rollout_plan(ops.macro_desc(L, N + 64, dt, dx, um), T)["fwd_kernel"] == 0
+                # lanes that do not divide by the group take a smaller one
+                assert ops.macro_rollout_plan(ops.macro_desc(L + 1, N, dt, dx, um), T)["fwd_lanes_per_group"] == 1
+            tape = torch.full((ops.macro_tape_numel(desc, T),), float("nan"), device=cuda)      # unwritten parts must never be read
+            out = ops.macro_rollout_fwd(desc, T, r, y, u, q, ghost, tape=tape)
+            plain = ops.macro_rollout_fwd(desc, T, r, y, u, q, ghost)
+            for a, b in zip(out, plain):
+                assert torch.equal(a, b)
+            g_r, g_y = 2 * out[0], torch.zeros_like(out[0])
+            ops.macro_u_tap_bwd(out[0], out[1], 2 * out[2], g_r, g_y, um)
+            res.append((out, ops.macro_tape_expand(desc, T, tape), ops.macro_rollout_bwd(desc, T, tape, g_r, g_y)))
+        for a, b in zip(res[0][0], res[1][0]):
+            assert torch.equal(a, b)
+        assert torch.equal(res[0][1], res[1][1])
+        for a, b in zip(res[0][2], res[1][2]):
+            assert torch.equal(a, b)
+        assert bool(torch.isfinite(res[1][0][0]).all())
+        # a CFL fault in the last lane of a group, on an interface between two wavefronts' chunks, is reported for that lane
+        bad = L - 2 * group - 1
+        u_bad, r_bad = u.clone(), r.clone()
+        c0 = 127 if N > 128 else 7
+        r_bad[bad, c0:c0 + 2] = 0.3
+        u_bad[bad, c0:c0 + 2] = 600.0                           # dt * speed >= dx
+        y_bad, q_bad = ops.macro_state_from_ru(r_bad, u_bad, um)
+        err = ops.new_error_record(cuda)
+        ops.macro_rollout_fwd(desc, T, r_bad, y_bad, u_bad, q_bad, ghost, err=err)
+        rec = err.cpu().numpy()
+        assert rec[0] == _lib.FAULT_CFL and 0 <= rec[1] < T and rec[2] == bad and 0 <= rec[3] <= N, rec
+    finally:
+        _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_GROUP, 0)
+        _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_VARIANT, 0)
 
 
 def test_macro_long_lane_reverse_sweep_is_repeatable(cuda):
@@ -620,8 +697,9 @@ BENCH_LANES = (0, 1, 2, 3, 500, 511, 1022, 1023)      # lanes of bench.py's rank
 
 
 def test_macro_bench_instantiation_vs_reference_and_oracle(cuda, oracle, golden_dir):
-    """The kernel instantiations bench.py times on BASELINE config 2 -- macro_rollout_fwd2_group_kernel<2, 2> (two traffic
-    lanes per workgroup, four wavefronts x two passes each, no history) and macro_rollout_bwd_fast_kernel<512, false> -- in
+    """The kernel instantiations bench.py times on BASELINE config 2 -- macro_rollout_fwd3_kernel<2, true> (the pair kernel: two
+    traffic lanes per workgroup, four wavefronts per lane, two adjacent cells per thread, no history) and
+    macro_rollout_bwd_fast_kernel<512, false> -- in
     the bench's own launch: 1024 lanes x 512 cells x 1000 steps, the tensors bench.py builds for rank 0.  Lane 4 of the batch is
     replaced by the reference's own 512 x 1000 run (golden c2slice: state <= 1e-5, gradients <= 1e-4); eight more lanes are
     compared with the oracle over all 1000 steps."""
@@ -641,7 +719,7 @@ def test_macro_bench_instantiation_vs_reference_and_oracle(cuda, oracle, golden_
     L = r0.shape[0]
     # the launch this test makes is the one the bench makes
     plan = ops.macro_rollout_plan(ops.macro_desc(L, N, dt, dx, um), T, want_hist=False)
-    assert plan == dict(fwd_one_phase=0, fwd_waves=4, fwd_passes=2, fwd_full_lane=1, bwd_pipelined=1, bwd_block=512, hist=0,
+    assert plan == dict(fwd_kernel=2, fwd_waves=4, fwd_passes=2, fwd_full_lane=1, bwd_pipelined=1, bwd_block=512, hist=0,
                         fwd_lanes_per_group=2)
     tr0, tu0 = T_(r0, cuda, grad=True), T_(u0, cuda, grad=True)
     tgr, tgu = T_(gr, cuda, grad=True), T_(gu, cuda, grad=True)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Times the macro rollout forward kernel of BASELINE config 2 for the forward variants of ONE build of libdhts.so
-(DHTS_OPT_MACRO_FWD_VARIANT: 0 = lane-group kernel, 2 / 3 = pair kernel written with the shared device functions / fused) and
-lanes per workgroup, and checks every setting against variant 0 bit for bit (final state, and the gradient the reverse sweep
-makes of its tape).  GPU box:  python3 tools/exp_fwd_pairs.py [variant:group ...]      (default: 0:0 2:0 3:0 3:4)"""
+(DHTS_OPT_MACRO_FWD_VARIANT: 0 = pair kernel, 2 = lane / lane-group kernels of round 3) and lanes per workgroup, and checks every
+setting against the first one bit for bit (final state, and the gradient the reverse sweep makes of its tape).
+GPU box:  [DHTS_LIB=<variant build>] python3 tools/exp_fwd_pairs.py [variant:group ...]      (default: 2:0 0:0 0:4 0:1 2:0 0:0)"""
 import hashlib
 import json
 import os
@@ -18,7 +18,7 @@ from dhts import _lib  # noqa: E402
 
 
 def main():
-    specs = sys.argv[1:] or ["0:0", "2:0", "3:0", "3:4", "0:0"]
+    specs = sys.argv[1:] or ["2:0", "0:0", "0:4", "0:1", "2:0", "0:0"]
     print("library:", _lib.SO_PATH, flush=True)
     dev = torch.device("cuda:0")
     w = bench.MacroWorkload(dev, 0, 1024, 512, 1000)
@@ -42,7 +42,7 @@ def main():
         ref = ref or sha
         census = w.tape_census() if hasattr(w, "tape_census") else None
         print(json.dumps({"variant": v, "group": g, "fwd_min": round(fwd[0], 4), "fwd_med": round(fwd[len(fwd) // 2], 4),
-                          "bwd_med": round(bwd[len(bwd) // 2], 4), "sha": sha, "bitwise_equal_variant0": sha == ref,
+                          "bwd_med": round(bwd[len(bwd) // 2], 4), "sha": sha, "bitwise_equal_first": sha == ref,
                           "fault": w.err.tolist()[0], "loss": float(loss), "tape_bytes": census}), flush=True)
 
 

@@ -16,7 +16,7 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 
-variant = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0      # 0 = pair kernel, 2 = lane-group kernel (clock only)
 group = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dev = torch.device("cuda:0")
 lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
@@ -32,7 +32,7 @@ torch.cuda.synchronize()
 print("variant %d group %d lanes %d, instrumented: fwd %.3f ms" % (variant, group, lanes, np.median([e[0].elapsed_time(e[1]) for e in w.ev])))
 buf = (C.c_longlong * (16 * 16 * 8))()
 assert _lib.lib().dhts_debug_fwd3_stamps(buf) == 0
-if variant < 2:
+if variant != 0:
     buf = (C.c_longlong * (16 * 16 * 8))()
 a = np.array(buf[:], dtype=np.int64).reshape(16, 16, 8).astype(np.float64)
 nw = 16 if group == 4 else 8
@@ -50,6 +50,6 @@ for name, sl in (("workgroups 0..7", slice(0, 8)), ("workgroups G/2..G/2+7", sli
 cb = (C.c_longlong * (2 * 16 * 2))()
 assert _lib.lib().dhts_debug_fwd_clock(cb) == 0
 c = np.array(cb[:], dtype=np.float64).reshape(2, 16, 2)
-k = 1 if variant >= 2 else 0
+k = 1 if variant == 0 else 0
 print("in-kernel clock (s_memtime / s_memrealtime x 100 MHz): median %.0f MHz (min %.0f, max %.0f); step loop of workgroups 0..7: %.3f ms, of workgroups G/2..G/2+7: %.3f ms" % (
     np.median(c[k, :, 0] / c[k, :, 1] * 100), (c[k, :, 0] / c[k, :, 1] * 100).min(), (c[k, :, 0] / c[k, :, 1] * 100).max(), np.median(c[k, :8, 1]) / 1e5, np.median(c[k, 8:, 1]) / 1e5))
