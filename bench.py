@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)      # the first passes of a process run ~8 % slower (clock ramp)
-    ap.add_argument("--workload", choices=["macro", "micro", "itscp_macro", "itscp_hybrid"], default="macro")
+    ap.add_argument("--workload", choices=["macro", "micro", "itscp_macro", "itscp_hybrid", "stub"], default="macro",
+                    help="stub: launcher / collective self-test on any device (tests/test_dist_gloo.py), not a measurement")
     ap.add_argument("--lanes", type=int, default=0, help="override lanes per GPU")
     ap.add_argument("--cells", type=int, default=0, help="override cells / vehicles per lane")
     ap.add_argument("--time-steps", type=int, default=0, help="override simulated time steps per rollout")
@@ -565,7 +566,46 @@ def _rel(a, ref):
     return float(np.max(np.abs(a - ref)) / max(float(np.max(np.abs(ref))), 1e-30))
 
 
+class StubWorkload:
+    """Not a benchmark: a few float operations on whatever device there is, with the interface of the network workloads (a
+    shared "schedule" gradient per rank).  `--workload stub` lets tests/test_dist_gloo.py drive the launcher, the rank
+    environment, the per-pass all-reduce, the gather and rank 0's relay with eight CPU ranks over gloo;
+    DHTS_STUB_FAIL_RANK=k makes rank k die behind the warm-up (the launcher must end the others and return non-zero)."""
+    name = "stub"
+    unit_bytes = 1
+    unit_name = "units/s"
+    limiter = {}
+
+    def __init__(self, dev, rank, R, _n, _t):
+        self.L, self.N, self.T, self.rank = R, 4, 1, rank
+        self.units = R * 4
+        self.action = (torch.arange(R * 3, dtype=torch.float32, device=dev).reshape(R, 3) + 100.0 * rank).requires_grad_(True)
+        self.err = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.ev = []
+        self.passes = 0
+
+    def moved_bytes_per_launch(self):
+        return self.units
+
+    def one_pass(self, record=False):
+        self.passes += 1
+        if os.environ.get("DHTS_STUB_FAIL_RANK") == str(self.rank) and self.passes == 2:
+            os._exit(7)
+        self.action.grad = None
+        loss = (self.action * self.action).sum()
+        loss.backward()
+        return loss.detach(), self.action.grad, self.action.grad
+
+    def cpu_baseline(self, seconds=0.0):
+        return None
+
+    def parity_check(self, g_a, g_b):
+        return None
+
+
 def make_workload(name, dev, rank, lanes=0, cells=0, time_steps=0):
+    if name == "stub":
+        return StubWorkload(dev, rank, lanes or 2, 0, 0)
     if name == "macro":
         return MacroWorkload(dev, rank, lanes or 1024, cells or 512, time_steps or 1000)
     if name == "micro":
@@ -700,20 +740,24 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))        # before any GPU call: the children own the devices
     from dhts import dist as D
-    rank, world, local = D.init()
+    rank, world, local = D.init()                  # (makes this rank's GPU current, then builds the process group on it)
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    local = local % torch.cuda.device_count()      # one GPU per rank on a full node; wraps only in single-GPU smoke tests
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    stub = args.workload == "stub"
+    assert stub or torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    dev = D.local_device(local)                    # one GPU per rank on a full node; wraps only in single-GPU smoke tests
+    if dev is None:
+        dev = torch.device("cpu")                  # (the stub only)
+    else:
+        assert torch.cuda.current_device() == dev.index
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
 
     w = make_workload(args.workload, dev, rank, args.lanes, args.cells, args.time_steps)
     L, N, T = w.L, w.N, w.T
 
     # the per-pass RCCL all-reduce: [loss] for the straight-lane workloads (every lane owns its unknowns); for the network
     # workloads the gradient summed over the rank's replicas as if the signal schedule were shared (BASELINE config 5) + loss
-    shared_grad = args.workload.startswith("itscp")
+    shared_grad = args.workload.startswith("itscp") or stub
     flat = torch.zeros((w.action.shape[1] if shared_grad else 0) + 1, dtype=torch.float32, device=dev)
 
     def reduce_pass(loss, g_a):
@@ -727,13 +771,13 @@ def main():
         loss, g_a, _ = w.one_pass()
         reduce_pass(loss, g_a)
     D.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, g_a, g_b = w.one_pass(record=True)
+        loss, g_a, g_b = w.one_pass(record=not stub)
         local_part = reduce_pass(loss, g_a)
     D.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, dev)
 
@@ -744,7 +788,15 @@ def main():
     parts = D.gather_to_rank0(local_part) if world > 1 else None
 
     parity_failed = False
-    if rank == 0:
+    if rank == 0 and stub:
+        out = {"metric": "stub", "value": w.units * args.steps * world / elapsed, "unit": w.unit_name, "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+               "config": {"workload": w.name, "device": dev.type}, "loss_last_pass": flat.tolist()[-1],
+               "allreduce_check": None if parts is None else {
+                   "reduced": flat.tolist()[-1], "sum_of_rank_parts": float(parts[:, -1].double().sum()), "rank_parts": parts[:, -1].tolist(),
+                   "grad_max_abs_diff": float((parts[:, :-1].double().sum(dim=0) - flat[:-1].double().cpu()).abs().max())}}
+        print(json.dumps(out))
+    elif rank == 0:
         kernels, dom = kernel_records(w)
         k = kernels[dom]
         value = w.units * args.steps * world / elapsed

@@ -18,9 +18,26 @@ def _forced():
     return os.environ.get("DHTS_DIST_FORCE", "0") == "1"
 
 
+def local_device(local=None):
+    """The GPU of this rank: LOCAL_RANK on a full node; wraps only where several ranks share a device (single-GPU smoke tests).
+    None without a GPU."""
+    n_dev = torch.cuda.device_count()           # (counting devices does not initialise the GPU)
+    if n_dev == 0:
+        return None
+    if local is None:
+        local = env_rank_world()[2]
+    return torch.device("cuda", local % n_dev)
+
+
 def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment (backend 'nccl' = RCCL on ROCm)."""
+    """Initialise torch.distributed from the torchrun environment (backend 'nccl' = RCCL on ROCm).  The rank's device is made
+    current BEFORE the process group exists and handed to it (`device_id`): RCCL then binds its communicator to that device at
+    once instead of guessing at the first collective (with eight ranks on a node a lazily bound communicator lands on device 0
+    for every rank that has not called set_device yet, and `barrier()` has to pick a device by itself)."""
     rank, world, local = env_rank_world()
+    dev = local_device(local)
+    if dev is not None:
+        torch.cuda.set_device(dev)
     if (world > 1 or _forced()) and not dist.is_initialized():
         if backend is None:
             # the default on GPUs is RCCL ("nccl"); DHTS_DIST_BACKEND=gloo -- or more ranks than devices -- lets several ranks
@@ -34,7 +51,10 @@ def init(backend=None):
                           file=__import__("sys").stderr)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl" and dev is not None:
+            kw["device_id"] = dev
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
@@ -79,7 +99,10 @@ def gather_to_rank0(flat):
 
 def barrier():
     if _active():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(seconds, device):

@@ -154,3 +154,43 @@ def test_two_rank_gloo_replica_sharding(oracle, tmp_path):
         ref[:-1] += o["g_action"]
         ref[-1] += o["reward"]
     assert np.allclose(res["flat"], ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max())
+
+
+def _run_bench(args, extra_env=None, timeout=240):
+    import time
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)                       # no launcher environment: bench.py starts its own ranks
+    env.update(extra_env or {})
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    return p, time.time() - t0
+
+
+def test_bench_launcher_eight_ranks_over_gloo():
+    """bench.py --gpus 8 without a launcher: eight child ranks (own port, RANK / LOCAL_RANK / WORLD_SIZE set), the per-pass
+    all-reduce of [gradient || loss], max-over-ranks timing, the gather of every rank's part and rank 0's ONE JSON line relayed
+    by the parent -- the stub workload on CPU, collectives over gloo (the launcher and collective code of the 8-GPU run)."""
+    import json
+    p, _ = _run_bench(["--workload", "stub", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout                        # one line, from rank 0
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 8 and o["steps"] == 3 and o["warmup"] == 1
+    chk = o["allreduce_check"]
+    assert len(chk["rank_parts"]) == 8 and len(set(chk["rank_parts"])) == 8          # every rank contributed its own part
+    assert chk["reduced"] == chk["sum_of_rank_parts"] == o["loss_last_pass"] and chk["grad_max_abs_diff"] == 0.0
+    # rank r's loss: sum over (2 x 3) entries of (k + 100 r)^2
+    want = [float(sum((k + 100.0 * r) ** 2 for k in range(6))) for r in range(8)]
+    assert chk["rank_parts"] == want
+
+
+def test_bench_launcher_ends_the_ranks_when_one_dies():
+    """A rank that dies behind the warm-up leaves the others inside a collective: the launcher ends them (its 15 s window) and
+    returns non-zero instead of hanging."""
+    p, took = _run_bench(["--workload", "stub", "--gpus", "8", "--steps", "3", "--warmup", "1"], {"DHTS_STUB_FAIL_RANK": "5"}, timeout=120)
+    assert p.returncode != 0
+    assert "rank(s) failed" in p.stderr and "(5, 7)" in p.stderr, p.stderr[-1500:]
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]               # no result line from a broken run
+    assert took < 90.0
