@@ -654,33 +654,44 @@ def host_cores():
     return max(1, n)
 
 
-def kernel_symbols_sha16():
-    """Fingerprint of the kernels libdhts.so holds: sha256 over the sorted demangled names of its kernel symbols.  Counter
-    summaries under profiles/ carry the fingerprint of the library they were taken on and are not quoted for another."""
+def library_code_sha16():
+    """Fingerprint of the device code libdhts.so holds: sha256 over its .hip_fatbin section (the gfx950 code objects) -- a kernel
+    whose body changed under the same name changes it.  Counter summaries under profiles/ carry the fingerprint of the library
+    they were taken on and are not quoted for another."""
     import hashlib
+    import struct
     from dhts import _lib
     try:
-        txt = subprocess.run(["nm", "-D", "--defined-only", "-C", _lib.SO_PATH], capture_output=True, text=True, check=True).stdout
-    except (OSError, subprocess.CalledProcessError):
-        return None
-    names = sorted({ln.split(None, 2)[2].split("(")[0].strip() for ln in txt.splitlines()
-                    if "_kernel" in ln and "__device_stub__" not in ln and len(ln.split(None, 2)) == 3})
-    return hashlib.sha256("\n".join(names).encode()).hexdigest()[:16]
+        with open(_lib.SO_PATH, "rb") as f:
+            b = f.read()
+        if b[:4] != b"\x7fELF" or b[4] != 2:
+            return None
+        shoff, = struct.unpack_from("<Q", b, 0x28)
+        shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+        sec = [struct.unpack_from("<IIQQQQIIQQ", b, shoff + i * shentsize) for i in range(shnum)]
+        stroff = sec[shstrndx][4]
+        for name, _t, _f, _a, off, size, *_ in sec:
+            end = b.index(b"\0", stroff + name)
+            if b[stroff + name:end] == b".hip_fatbin":
+                return hashlib.sha256(b[off:off + size]).hexdigest()[:16]
+    except (OSError, ValueError, struct.error, IndexError):
+        pass
+    return None
 
 
 def issue_counters(w, kernel):
     """Instruction-issue side of `kernel` from the counter passes committed as profiles/issue_counters.json (tools/pmc_macro_fwd.sh:
     rocprofv3 --pmc SQ_* passes over this configuration).  Not measured by this run; refused when the library's kernels are
-    not the ones the passes saw."""
+    not the ones the passes saw (fingerprint of the device code, not of the kernel names)."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "issue_counters.json")))
         side = rec[w.name][kernel]
     except (OSError, ValueError, KeyError):
         return None
-    have = kernel_symbols_sha16()
-    if have is None or rec.get("kernel_symbols_sha16") != have:
-        print("bench.py: profiles/issue_counters.json was taken on another build of libdhts.so (kernel symbols %s, now %s): "
-              "issue_side not quoted; re-run tools/pmc_macro_fwd.sh" % (rec.get("kernel_symbols_sha16"), have), file=sys.stderr)
+    have = library_code_sha16()
+    if have is None or rec.get("library_code_sha16") != have:
+        print("bench.py: profiles/issue_counters.json was taken on another build of libdhts.so (device code %s, now %s): "
+              "issue_side not quoted; re-run tools/pmc_macro_fwd.sh" % (rec.get("library_code_sha16"), have), file=sys.stderr)
         return None
     return dict(side, source="%s (rocprofv3 --pmc passes of tools/pmc_macro_fwd.sh on this configuration), not measured by this run"
                 % rec.get("source", "profiles/issue_counters.json"))

@@ -38,6 +38,12 @@ def new_error_record(device):
     return torch.zeros(4, dtype=torch.int32, device=device)
 
 
+class CapacityError(RuntimeError):
+    """A fused network episode needed more than one of the kernels' fixed capacities (include/dhts.h: vehicles per micro lane,
+    vehicles per episode, records per step).  Nothing was changed on the host: callers can run the episode another way
+    (ItscpEnv.step falls back to the lane-by-lane path)."""
+
+
 def raise_on_fault(err):
     """Read the record back (synchronises) and raise the way the reference asserts."""
     code, step, lane, index = err.tolist()
@@ -48,8 +54,8 @@ def raise_on_fault(err):
     if code == _lib.FAULT_NAN:
         raise AssertionError("non-finite gradient in the reverse sweep (step %d, lane %d)" % (step, lane))   # dmacro_lane.py:308
     if code == _lib.FAULT_CAPACITY:
-        raise RuntimeError("hybrid network: a fixed capacity was exceeded (record stream / vehicles / lane list / routes); "
-                           "index %d" % index)
+        raise CapacityError("hybrid network: a fixed capacity was exceeded (record stream / vehicles / lane list / routes); "
+                            "index %d" % index)
     if code == _lib.FAULT_COLLISION:
         # printed and tolerated in the reference (_micro_lane.py:155-160): the deltas of that vehicle are zeroed, the run goes on
         print("Collision detected between vehicles (step %d, lane %d, vehicle %d)" % (step, lane, index))
@@ -332,6 +338,8 @@ class MicroRollout(torch.autograd.Function):
         if check_faults:                 # a collision is printed like the reference does, and tolerated
             raise_on_fault(err)
         ctx.desc, ctx.T, ctx.tape, ctx.count, ctx.want_hist, ctx.check_faults = desc, T, tape, count, want_hist, check_faults
+        # the reverse sweep's own record, made here (no allocation inside backward, i.e. inside a graph capture of it)
+        ctx.err_bwd = new_error_record(p0.device) if need_grad else None
         if want_hist:
             return pT, vT, hist
         return pT, vT
@@ -344,15 +352,28 @@ class MicroRollout(torch.autograd.Function):
         g_p = g_pT.contiguous() if g_pT is not None else torch.zeros(L, V, device=dev)
         g_v = g_vT.contiguous() if g_vT is not None else torch.zeros(L, V, device=dev)
         gh = g_hist.contiguous() if (ctx.want_hist and g_hist is not None) else None
-        err = new_error_record(dev)
+        err = ctx.err_bwd
         g_p0, g_v0, g_head = micro_rollout_bwd(desc, T, ctx.tape, g_p, g_v, count=ctx.count, g_hist=gh, err=err)
-        if ctx.check_faults:             # reading the record back synchronises: off inside HIP-graph capture
-            code, step, lane, index = err.tolist()
-            if code == _lib.FAULT_NAN:
-                # the reference's micro backward returns such NaNs silently (dmicro_lane.py:271-298); so do we, but say where
-                warnings.warn("non-finite gradient in the micro reverse sweep (step %d, lane %d, vehicle %d)" % (step, lane, index),
-                              RuntimeWarning)
+        # The record only feeds a warning (the reference's micro backward returns NaNs silently, dmicro_lane.py:271-298): it is not
+        # read back here -- that would be a host synchronisation per reverse sweep -- unless the gradient that is being returned
+        # anyway is non-finite, which the caller's next use of it would synchronise on as well.
+        if ctx.check_faults and not torch.cuda.is_current_stream_capturing():
+            MicroRollout.last_bwd_record = err           # (dhts.ops.micro_bwd_fault() reads it on demand)
         return g_p0, g_v0, None, g_head, None, None, None, None, None
+
+
+def micro_bwd_fault(warn=True):
+    """Where the most recent micro reverse sweep first met a non-finite cotangent: (step, lane, vehicle) or None.  Reads the sweep's
+    fault record back (a host synchronisation: call it once per so many iterations, or when a gradient looks wrong)."""
+    rec = getattr(MicroRollout, "last_bwd_record", None)
+    if rec is None:
+        return None
+    code, step, lane, index = rec.tolist()
+    if code != _lib.FAULT_NAN:
+        return None
+    if warn:
+        warnings.warn("non-finite gradient in the micro reverse sweep (step %d, lane %d, vehicle %d)" % (step, lane, index), RuntimeWarning)
+    return step, lane, index
 
 
 def micro_rollout(p0, v0, params, head, T, dt, count=None, want_hist=False, check_faults=True):
@@ -525,7 +546,12 @@ class DeviceHybridTables:
         import numpy as np
         many = isinstance(tables, (list, tuple))
         t = tables[0] if many else tables
-        t.check_kernel_limits()
+        for i, x in enumerate(tables if many else [t]):
+            x.check_kernel_limits()
+            if (x.n_lanes, x.n_cells, x.T) != (t.n_lanes, t.n_cells, t.T) or not np.array_equal(np.asarray(x.lane_source), np.asarray(t.lane_source)):
+                raise ValueError("per-replica tables must share the topology of table 0 (lanes, cells, steps, source lanes): table %d differs" % i)
+            if np.asarray(x.lane_source).any() and getattr(x, "draws", None) is None:
+                raise ValueError("table %d has micro source lanes but no admission draws (HybridNetworkTables.set_micro_sources)" % i)
         self.n_lanes, self.n_cells, self.T = t.n_lanes, t.n_cells, t.T
         self.n_replica_tables = len(tables) if many else 0
         up = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=device)    # noqa: E731
@@ -617,7 +643,10 @@ class NetHybridRollout(torch.autograd.Function):
               "dhts_net_hybrid_rollout_fwd")
         if check_faults and own_err:     # reading the record back synchronises: off inside HIP-graph capture
             raise_on_fault(err)
-        ctx.d, ctx.tables, ctx.loss_steps, ctx.check_faults = d, t, int(loss_steps), bool(check_faults) and own_err
+        # the reverse sweep raises only on a record of its own: a caller-owned one (err, or err_bwd for the reverse sweep alone) is
+        # the caller's to read -- that is how a batch tolerates one member's NaN
+        ctx.d, ctx.tables, ctx.loss_steps = d, t, int(loss_steps)
+        ctx.check_faults = bool(check_faults) and own_err and err_bwd is None
         ctx.err = err_bwd if err_bwd is not None else (None if own_err else err)
         ctx.save_for_backward(a, hist, tape, kc, queue, ws)
         ctx.mark_non_differentiable(reward, queue, counts)

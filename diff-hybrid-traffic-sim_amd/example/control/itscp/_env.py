@@ -289,6 +289,10 @@ class ItscpEnv:
                         for r in reversed(sim.lane_waiting_micro_route.get(l, [])):
                             r = list(r.route)[:32]
                             rows.append(r + [-1] * (32 - len(r)))
+                    if len(rows) > 128:
+                        # more waiting vehicles than a fused episode can ever hold (include/dhts.h: 128 per episode): no point in
+                        # trying (a default 4 x 4 grid has 16 source lanes x 10 waiting vehicles)
+                        raise ValueError("more waiting vehicles than the fused kernels hold")
                     self._fused_n_draws = T * max(1, int(tab.lane_source.sum()))
                     tab.set_micro_sources(np.full(self._fused_n_draws, 2.0))
                     cache = ("micro", ops.DeviceHybridTables(tab, np.asarray(rows if rows else [[-1, -1]], dtype=np.int32), action.device))
@@ -322,14 +326,32 @@ class ItscpEnv:
             else:
                 draws = np.concatenate([np.asarray(draws, dtype=np.float64), np.full(self._fused_n_draws, 2.0)])[:self._fused_n_draws]
             tab.set_draws(draws)
-        if kind == "macro":
-            reward, queue = ops.net_macro_rollout(a, tab, *args) if differentiable else ops.net_macro_eval(a, tab, *args)
-        elif differentiable:
-            reward, _, queue, counts = ops.net_hybrid_rollout(a, tab, *args)
-            self.fused_counts = counts[0].tolist()
-        else:
-            reward, queue, counts = ops.net_hybrid_eval(a, tab, *args)
-            self.fused_counts = counts[0].tolist()
+        try:
+            if kind == "macro":
+                reward, queue = ops.net_macro_rollout(a, tab, *args) if differentiable else ops.net_macro_eval(a, tab, *args)
+            elif differentiable:
+                reward, _, queue, counts = ops.net_hybrid_rollout(a, tab, *args)
+                self.fused_counts = counts[0].tolist()
+            else:
+                reward, queue, counts = ops.net_hybrid_eval(a, tab, *args)
+                self.fused_counts = counts[0].tolist()
+        except ops.CapacityError as e:
+            # The reference has no such limits (_micro_lane.py:53-113): this episode runs lane by lane instead (minutes, not
+            # milliseconds).  Nothing on the host was touched by the attempt; in `micro` mode the admission draws the kernels were
+            # given are replayed, so that the episode is the one that was asked for.
+            if not getattr(self, "_fused_overflow_warned", False):
+                self._fused_overflow_warned = True
+                import warnings
+                warnings.warn("ItscpEnv: the fused kernels' capacity was exceeded (%s); this episode runs lane by lane" % e)
+            if kind == "micro":
+                it = iter(np.asarray(draws, dtype=np.float64).tolist())
+
+                def replay():
+                    v = next(it, None)
+                    return float(np.random.random()) if v is None else v
+                self.simulator.random_draw = replay
+            self.fused_overflowed = True
+            return None
         q = queue[0].detach().cpu().numpy()                 # [T][L]
         for i, lid in enumerate(self.lane.keys()):
             self.queue_length[lid] = [float(x) for x in q[:, i]]

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from test_oracle_golden import itscp_hybrid_tables, itscp_micro_tables
-from util import TOL_GRAD, TOL_STATE, grad_report, rel_elem, rel_max
+from util import TOL_GRAD, TOL_STATE, grad_report, rel_elem, rel_max, state_report
 
 pytestmark = pytest.mark.gpu
 
@@ -51,7 +51,7 @@ def test_hybrid_short_matches_reference(cuda, golden_dir, name):
     m = o["m"]
     for r in range(3):
         assert o["counts"][r, 0] == m["n_vehicle_spawned"]
-        assert rel_max(o["queue"][r].T, g["queue"]) <= 1e-4
+        assert state_report("queues vs reference", o["queue"][r].T, g["queue"]) <= TOL_STATE
         assert abs(float(o["reward"][r]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
         assert np.abs(o["grad"][r] - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()
     assert np.array_equal(o["grad"][0], o["grad"][1]) and np.array_equal(o["queue"][0], o["queue"][2])   # repeatable
@@ -63,7 +63,7 @@ def test_hybrid_600_steps_matches_reference(cuda, golden_dir):
     o = _run(cuda, g, want_grad=False)
     m = o["m"]
     assert o["counts"][0, 0] == m["n_vehicle_spawned"] and o["counts"][0, 1] == 12
-    assert rel_max(o["queue"][0].T, g["queue"]) <= 1e-4
+    assert state_report("queues vs reference", o["queue"][0].T, g["queue"]) <= TOL_STATE
     assert abs(float(o["reward"][0]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
     scale = np.abs(g["g_action"]).max()
     # gradient of the reward restricted to its first t0 steps (see tests/test_itscp_gpu.py for the last 60 steps of lane 16)
@@ -78,7 +78,7 @@ def test_hybrid_600_steps_matches_reference(cuda, golden_dir):
 def test_hybrid_600_steps_full_horizon_gradient(cuda, golden_dir, name):
     """BASELINE config 4's exact episode (run_itscp_hybrid.sh: 600 steps, 45 actions), four more reference runs -- action
     0.5 everywhere (every signal sigmoid at its steepest point) and three random actions over problem_1 / problem_2 inflows:
-    queues, reward, spawn count and the WHOLE d reward / d action within 1e-4 of the reference, and the gradient of the
+    queues <= 1e-5, reward, spawn count and the WHOLE d reward / d action within 1e-4 of the reference, and the gradient of the
     reward restricted to its first 150 / 300 / 450 / 540 steps as well."""
     g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
     o = _run(cuda, g, replicas=2)
@@ -87,7 +87,7 @@ def test_hybrid_600_steps_full_horizon_gradient(cuda, golden_dir, name):
     scale = np.abs(g["g_action"]).max()
     for r in range(2):
         assert o["counts"][r, 0] == m["n_vehicle_spawned"]
-        assert rel_max(o["queue"][r].T, g["queue"]) <= 1e-4
+        assert state_report("queues vs reference", o["queue"][r].T, g["queue"]) <= TOL_STATE
         assert abs(float(o["reward"][r]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
         assert np.abs(o["grad"][r] - g["g_action"]).max() <= TOL_GRAD * scale
     err = np.abs(o["grad"][0] - g["g_action"]) / scale
@@ -110,7 +110,7 @@ def test_hybrid_kernels_vs_oracle_other_action(cuda, golden_dir, oracle):
     assert ref["rc"] == 0
     o = _run(cuda, g, action=action)
     assert o["counts"][0, 0] == ref["n_spawned"]
-    assert rel_max(o["queue"][0], ref["queue"]) <= 1e-4
+    assert state_report("queues vs oracle", o["queue"][0], ref["queue"]) <= TOL_STATE
     assert np.abs(o["grad"][0] - ref["g_action"]).max() <= 5 * TOL_GRAD * np.abs(ref["g_action"]).max()
 
 
@@ -203,7 +203,7 @@ def test_hybrid_random_actions_vs_oracle(cuda, golden_dir, oracle, name, seed):
     for k in range(len(acts)):
         o = oracle.net_hybrid(t, gr, ptr, acts[k], *args)
         assert o["rc"] == 0 and (Cn[k, 0], Cn[k, 1]) == (o["n_spawned"], o["n_deposits"]), k
-        assert rel_max(Q[k], o["queue"]) <= 1e-4, k
+        assert state_report("queues vs oracle (replica %d)" % k, Q[k], o["queue"]) <= TOL_STATE, k
         assert abs(float(Rw[k]) - o["reward"]) <= 1e-5 * abs(o["reward"]), k
         worst = max(worst, np.abs(G[k] - o["g_action"]).max() / np.abs(o["g_action"]).max())
     assert worst <= 0.2 * TOL_GRAD, worst
@@ -262,7 +262,7 @@ def test_larger_network_vs_oracle(cuda, oracle):
     for k in range(len(acts)):
         o = oracle.net_hybrid(tab, gr, ptr, acts[k], *args)
         assert o["rc"] == 0 and (int(counts[k, 0]), int(counts[k, 1])) == (o["n_spawned"], o["n_deposits"]), k
-        assert rel_max(queue[k].cpu().numpy(), o["queue"]) <= 1e-4, k
+        assert state_report("queues vs oracle (replica %d)" % k, queue[k].cpu().numpy(), o["queue"]) <= TOL_STATE, k
         assert abs(float(reward[k]) - o["reward"]) <= 1e-5 * abs(o["reward"]), k
         err_k = np.abs(a.grad[k].cpu().numpy() - o["g_action"]).max() / np.abs(o["g_action"]).max()
         print("larger network, action %d: gradient vs oracle %.2e" % (k, err_k))
@@ -330,21 +330,24 @@ def test_itscp_micro_mode_through_fused_kernels(cuda, oracle, golden_dir, name):
     cut.sum().backward()
     q, grad = queue.detach().cpu().numpy(), a.grad.cpu().numpy()
     assert int(counts[0, 0]) == m["n_vehicle_spawned"]
-    assert rel_max(q[0].T, g["queue"]) <= 1e-4
+    # (1e-4 here and below, not TOL_STATE: in `micro` mode the reference steps every lane with the autodiff MicroLane in float32
+    # TENSOR arithmetic (_env.py:484-487), which the analytic operator's ladder -- Python floats, float32 stores -- matches to
+    # ~1e-6 per step; over 300 steps the queue terms differ by up to ~5e-5)
+    assert state_report("micro mode queues vs reference", q[0].T, g["queue"]) <= 1e-4
     assert abs(float(reward[0]) - float(g["reward"])) <= 1e-4 * abs(float(g["reward"]))
     assert grad_report("G8 %s (kernels) d reward / d action" % name, grad[0], g["g_action"]) <= TOL_GRAD
     routes, route_ptr = group_routes(rows, t.n_lanes)
     for k in range(1, len(acts)):
         o = oracle.net_hybrid(t, routes, route_ptr, acts[k], *args)
         assert o["rc"] == 0 and int(counts[k, 0]) == o["n_spawned"], k
-        assert rel_max(q[k], o["queue"]) <= 1e-4, k
+        assert state_report("micro mode queues vs oracle (replica %d)" % k, q[k], o["queue"]) <= TOL_STATE, k
         assert abs(float(reward[k]) - o["reward"]) <= 1e-5 * abs(o["reward"]), k
         assert rel_max(grad[k], o["g_action"]) <= TOL_GRAD, k
     # evaluation episodes of the same network
     ev_reward, ev_queue, ev_counts = ops.net_hybrid_eval(a.detach(), dtab, *args)
     for k in (0, 2):
         o = oracle.net_hybrid(t, routes, route_ptr, acts[k], *args, hard=True)
-        assert int(ev_counts[k, 0]) == o["n_spawned"] and rel_max(ev_queue[k].cpu().numpy(), o["queue"]) <= 1e-4, k
+        assert int(ev_counts[k, 0]) == o["n_spawned"] and rel_max(ev_queue[k].cpu().numpy(), o["queue"]) <= TOL_STATE, k
         assert abs(float(ev_reward[k]) - o["reward"]) <= 1e-5 * abs(o["reward"]), k
 
 
@@ -361,7 +364,7 @@ def test_hybrid_networks_with_more_micro_lanes(cuda, golden_dir, name):
     m = o["m"]
     for r in range(2):
         assert o["counts"][r, 0] == m["n_vehicle_spawned"]
-        assert rel_max(o["queue"][r].T, g["queue"]) <= 1e-4
+        assert state_report("queues vs reference", o["queue"][r].T, g["queue"]) <= TOL_STATE
         assert abs(float(o["reward"][r]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
         assert np.abs(o["grad"][r] - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()
     for t0, ref in zip(g["g_action_cut_steps"], g["g_action_cut"]):
@@ -396,7 +399,7 @@ def test_micro_sources_exhausted_waiting_list_and_draws(cuda, oracle, golden_dir
     o = oracle.net_hybrid(t, routes, route_ptr, act[0], *args)
     n_src = int(t.lane_source.sum())
     assert o["rc"] == 0 and int(counts[0, 0]) == o["n_spawned"] == 2 * n_src
-    assert rel_max(queue[0].detach().cpu().numpy(), o["queue"]) <= 1e-4
+    assert state_report("queues vs oracle", queue[0].detach().cpu().numpy(), o["queue"]) <= TOL_STATE
     assert rel_max(a.grad[0].cpu().numpy(), o["g_action"]) <= TOL_GRAD
     t.set_micro_sources(g["rand_draws"][:5])
     with pytest.raises(RuntimeError, match="capacity"):

@@ -30,6 +30,14 @@ def grad_report(tag, a, ref):
     return float(e_norm.max())
 
 
+def state_report(tag, a, ref):
+    """rel_max with the measured value printed (pytest -s): the per-step queue terms / states of the network tests, so that the
+    test logs show how far inside the tolerance a run is."""
+    e = rel_max(a, ref)
+    print("%s: max |d| / max |ref| = %.2e" % (tag, e))
+    return e
+
+
 def ulp_diff(a, b):
     """Distance in float32 units-in-the-last-place, elementwise (signed-magnitude ordering)."""
     a = np.ascontiguousarray(a, dtype=np.float32).view(np.int32).astype(np.int64)

@@ -61,7 +61,7 @@ for key, name in (("fwd2" if acc.get("fwd2") else "fwd", "rollout_fwd"), ("bwd",
     if m(key, "SQ_LDS_BANK_CONFLICT") and m(key, "SQ_LDS_IDX_ACTIVE"):
         e["lds_bank_conflict_frac"] = round(m(key, "SQ_LDS_BANK_CONFLICT") / m(key, "SQ_LDS_IDX_ACTIVE"), 3)
     rec[name] = e
-json.dump({"macro_straight_1024x512x1000": rec, "kernel_symbols_sha16": bench.kernel_symbols_sha16(),
+json.dump({"macro_straight_1024x512x1000": rec, "library_code_sha16": bench.library_code_sha16(),
            "source": "profiles/%s_pmc_macro_counters.csv" % os.path.basename(out.rstrip("/")).split("_")[0]},
           open(os.path.join(out, "issue_counters.json"), "w"), indent=1)
 print(open(os.path.join(out, "issue_counters.json")).read())
