@@ -102,6 +102,10 @@ struct HybTables {
     const int32_t *lane_macro; const double *lane_len; const int32_t *conv_next; const int32_t *routes; const int32_t *route_ptr;
     int n_routes, route_stride, loss_steps, n_micro;
     const int32_t *lane_source; const double *draws; int n_draws; size_t draws_stride;     // micro source lanes (itscp `micro` mode)
+    // a plain RoadNetwork with given initial state and final-state taps (dhts_net_hybrid_state_rollout_*, include/dhts.h)
+    int plain;
+    const float *state0, *ghost0; float *veh_out; int *events;
+    const float *g_stateT, *g_veh; float *g_state0;
 };
 
 // workspace layout of one replica (bytes, all 16-byte aligned)
@@ -405,8 +409,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         ql[tid] = 0.f;
     }
     if (tid < C) {
-        S0[tid] = 0.f; S0[C + tid] = 0.f; S0[2 * C + tid] = um; S0[3 * C + tid] = um;
-        if (!kHard) { hist_r[tid] = 0.f; hist_r[C + tid] = 0.f; hist_r[2 * C + tid] = um; hist_r[3 * C + tid] = um; }
+        float r0 = 0.f, y0 = 0.f, u0 = um, q0 = um;           // an empty road, or the caller's initial state
+        if (tb.state0) { const float *s0 = tb.state0 + (size_t)rep * 4 * C; r0 = s0[tid]; y0 = s0[C + tid]; u0 = s0[2 * C + tid]; q0 = s0[3 * C + tid]; }
+        S0[tid] = r0; S0[C + tid] = y0; S0[2 * C + tid] = u0; S0[3 * C + tid] = q0;
+        if (!kHard) { hist_r[tid] = r0; hist_r[C + tid] = y0; hist_r[2 * C + tid] = u0; hist_r[3 * C + tid] = q0; }
     }
     __syncthreads();
     int n_micro = 0, n_caps = 0, n_conv = 0, n_macro = 0;
@@ -459,8 +465,16 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     }
     const int g_side = tid >= g_base1 ? 1 : 0, g_lane = is_ghost ? (g_side ? tid - g_base1 : tid) : 0;
     int g_kind = 0, g_inter = 0; bool g_macro = false;
-    float own_r = 0.f, own_u = um;
+    float own_r = 0.f, own_u = um;               // the lane's stored downstream ghost (side-1 ghost thread)
+    float gl_r = 0.f, gl_u = um;                 // the lane's stored upstream ghost (side-0 ghost thread)
+    const bool plain = tb.plain != 0;
     if (is_ghost) { g_kind = tb.net.sig_kind[g_lane]; g_inter = tb.net.inter[g_lane]; g_macro = tb.lane_macro[g_lane] != 0; }
+    if (is_ghost && tb.ghost0) {
+        const float *g0 = tb.ghost0 + ((size_t)rep * L + g_lane) * 4;
+        gl_r = g0[0]; gl_u = g0[1]; own_r = g0[2]; own_u = g0[3];
+    }
+    int n_ev = 0;                                // hand-off events logged so far (thread 0 of the micro wave)
+    int *ev_log = tb.events ? tb.events + (size_t)rep * 4 * kMaxVeh : nullptr;
     int l_off = 0, l_n = 0, l_ms = -1; bool l_macro = false;
     if (is_lane) { l_off = tb.net.lane_off[tid]; l_n = tb.net.lane_ncell[tid]; l_ms = mslot[tid]; l_macro = tb.lane_macro[tid] != 0; }
     // signals of step 0 (the staged action vector is complete after the barrier above); signal threads count (phase, frame)
@@ -869,8 +883,17 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         if (fl_fault) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, rec_n);
     }
     if (in_mw) {
-        if (is_mt) { counts[4 * rep + 0] = spawned; counts[4 * rep + 1] = deposits; counts[4 * rep + 3] = 0; }
+        if (is_mt) { counts[4 * rep + 0] = spawned; counts[4 * rep + 1] = deposits; counts[4 * rep + 3] = n_ev; }
         if (rec.over || cap_fault) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, 0);
+        if (tb.veh_out) {
+            // every vehicle ever spawned: gone (-1) unless a lane still lists it (one wavefront: its stores to a row stay in order)
+            float *vo = tb.veh_out + (size_t)rep * 4 * V;
+            const int n_sp = __builtin_amdgcn_readfirstlane(spawned);
+            for (int vi = mw; vi < n_sp; vi += 64) { vo[4 * vi] = -1.f; vo[4 * vi + 1] = vp[vi]; vo[4 * vi + 2] = vv[vi]; vo[4 * vi + 3] = va[vi]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (mw < n_micro) for (int i = 0; i < lane_n[mw]; ++i) vo[4 * lane_veh[mw * kLaneCap + i]] = (float)mlane[mw];
+        }
     }
     if (is_lane) ql[tid] = lane_total;
     __syncthreads();
@@ -978,10 +1001,18 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         }
         iptr[sq] = n;
     }
+    const bool plain = tb.plain != 0;
     for (int k = tid; k < n_adj; k += B) adj[k] = 0.f;
     for (int k = tid; k < 2 * sq; k += B) gam[k] = 0.f;
-    if (is_cell) { gL[tid] = 0.f; gL[C + tid] = 0.f; gL[2 * C + tid] = 0.f; }
+    if (is_cell) {
+        // cotangent of the final state: the caller's tap, if any (the queue loss adds its own below)
+        float t_r = 0.f, t_y = 0.f, t_u = 0.f;
+        if (tb.g_stateT) { const float *g = tb.g_stateT + (size_t)rep * 3 * C; t_r = g[tid]; t_y = g[C + tid]; t_u = g[2 * C + tid]; }
+        gL[tid] = t_r; gL[C + tid] = t_y; gL[2 * C + tid] = t_u;
+    }
     __syncthreads();
+    // ... and of the vehicles' final (position, speed): their committed slots 3 k, 3 k + 1
+    if (tb.g_veh) for (int k = tid; k < V; k += B) { adj[3 * k] = tb.g_veh[((size_t)rep * V + k) * 2]; adj[3 * k + 1] = tb.g_veh[((size_t)rep * V + k) * 2 + 1]; }
     int c_lane = 0, c_first = 0, c_last = 0, c_macb = 0; float c_dxv = 0.f, c_cf = 0.f, c_ncf = 0.f;
     if (is_cell) {
         c_lane = cell_lane_s[tid]; c_first = tb.net.lane_off[c_lane]; c_last = c_first + tb.net.lane_ncell[c_lane] - 1;
@@ -1134,7 +1165,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         const int lo_ = inc - c;
         if (lo_ + c <= b_n)
             for (int k = lo_; k < lo_ + c; ++k)
-                if ((grk[b_lo + k] >> 24) == K_SEED) { const int4 a = gri[b_lo + k]; const float4 b = grw[b_lo + k]; adj[a.x] += gscale * b.x; }
+                if ((grk[b_lo + k] >> 24) == K_SEED && gscale != 0.f) { const int4 a = gri[b_lo + k]; const float4 b = grw[b_lo + k]; adj[a.x] += gscale * b.x; }
     }
     __syncthreads();
     if (in_mw) fetch_offsets(T - 1);
@@ -1153,6 +1184,11 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         }
     }
     HYB_STAMP_WRITE(1, rep, tid, B)
+    // the cotangent of the initial state (the loop's last barrier is behind the cells' last write of gL)
+    if (tb.g_state0 && is_cell) {
+        float *g0 = tb.g_state0 + (size_t)rep * 3 * C;
+        g0[tid] = gL[tid]; g0[C + tid] = gL[C + tid]; g0[2 * C + tid] = gL[2 * C + tid];
+    }
     if (is_own && T > 0) ga += (double)gam[own_q];       // step 0's outboxes (buffer 0; the loop's last barrier is behind them)
     if (is_own && cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + own_q] = (float)ga;
     if (bad_step >= 0) net_fault(err, DHTS_FAULT_NAN, bad_step, rep, tid);
@@ -1187,6 +1223,8 @@ static inline HybTables hyb_tables(const dhts_hybrid_tables *t) {
     h.lane_macro = t->lane_macro; h.lane_len = t->lane_len; h.conv_next = t->conv_next; h.routes = t->routes; h.route_ptr = t->route_ptr;
     h.n_routes = t->n_routes; h.route_stride = t->route_stride; h.loss_steps = t->loss_steps; h.n_micro = t->n_micro;
     h.lane_source = t->lane_source; h.draws = t->draws; h.n_draws = t->n_draws; h.draws_stride = (size_t)t->draws_stride;
+    h.plain = 0; h.state0 = nullptr; h.ghost0 = nullptr; h.veh_out = nullptr; h.events = nullptr;
+    h.g_stateT = nullptr; h.g_veh = nullptr; h.g_state0 = nullptr;
     return h;
 }
 static inline int hyb_block(const dhts_net_desc *d) {
@@ -1213,11 +1251,13 @@ size_t dhts_net_hybrid_workspace_bytes(const dhts_net_desc *d, const dhts_hybrid
     return hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step).per_replica * (size_t)d->n_replicas;
 }
 
-int dhts_net_hybrid_rollout_fwd(const dhts_net_desc *d, const dhts_hybrid_tables *t, const float *action, float *hist,
-                                float *tape, float *kc, float *queue, float *reward, int32_t *counts, void *workspace,
-                                dhts_error *err, void *stream) {
+static int hyb_fwd_launch(const dhts_net_desc *d, const dhts_hybrid_tables *t, const dhts_hybrid_state_io *io, const float *action,
+                          float *hist, float *tape, float *kc, float *queue, float *reward, int32_t *counts, void *workspace,
+                          dhts_error *err, void *stream) {
     if (!hyb_desc_ok(d) || !hyb_tables_ok(t) || !action || !hist || !tape || !kc || !queue || !reward || !counts || !workspace)
         return DHTS_E_INVALID;
+    HybTables ht = hyb_tables(t);
+    if (io) { ht.plain = io->plain; ht.state0 = io->state0; ht.ghost0 = io->ghost0; ht.veh_out = io->veh_out; ht.events = io->events; }
     const int B = hyb_block(d);
     if (B > 1024) return DHTS_E_INVALID;
     const HybWs ws = hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step);
@@ -1233,9 +1273,20 @@ int dhts_net_hybrid_rollout_fwd(const dhts_net_desc *d, const dhts_hybrid_tables
         return DHTS_E_LAUNCH;
     kern<<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
         d->n_replicas, d->n_lanes, d->n_cells, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max,
-        d->static_speed, d->vehicle_length, hyb_tables(t), action, hist, reinterpret_cast<float4 *>(tape), kc, queue, reward,
+        d->static_speed, d->vehicle_length, ht, action, hist, reinterpret_cast<float4 *>(tape), kc, queue, reward,
         counts, reinterpret_cast<char *>(workspace), t->records_per_step, err);
     return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
+}
+int dhts_net_hybrid_rollout_fwd(const dhts_net_desc *d, const dhts_hybrid_tables *t, const float *action, float *hist,
+                                float *tape, float *kc, float *queue, float *reward, int32_t *counts, void *workspace,
+                                dhts_error *err, void *stream) {
+    return hyb_fwd_launch(d, t, nullptr, action, hist, tape, kc, queue, reward, counts, workspace, err, stream);
+}
+int dhts_net_hybrid_state_rollout_fwd(const dhts_net_desc *d, const dhts_hybrid_tables *t, const dhts_hybrid_state_io *io,
+                                      const float *action, float *hist, float *tape, float *kc, float *queue, float *reward,
+                                      int32_t *counts, void *workspace, dhts_error *err, void *stream) {
+    if (!io) return DHTS_E_INVALID;
+    return hyb_fwd_launch(d, t, io, action, hist, tape, kc, queue, reward, counts, workspace, err, stream);
 }
 
 int dhts_net_hybrid_rollout_eval(const dhts_net_desc *d, const dhts_hybrid_tables *t, const float *action, float *queue,
@@ -1260,11 +1311,13 @@ int dhts_net_hybrid_rollout_eval(const dhts_net_desc *d, const dhts_hybrid_table
     return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
 }
 
-int dhts_net_hybrid_rollout_bwd(const dhts_net_desc *d, const dhts_hybrid_tables *t, const float *action, const float *hist,
-                                const float *tape, const float *kc, const float *queue, const float *g_reward,
-                                float *g_action, const void *workspace, dhts_error *err, void *stream) {
+static int hyb_bwd_launch(const dhts_net_desc *d, const dhts_hybrid_tables *t, int plain, const float *action, const float *hist,
+                          const float *tape, const float *kc, const float *queue, const float *g_reward, const float *g_stateT,
+                          const float *g_veh, float *g_action, float *g_state0, const void *workspace, dhts_error *err, void *stream) {
     if (!hyb_desc_ok(d) || !hyb_tables_ok(t) || !action || !hist || !tape || !kc || !queue || !g_action || !workspace)
         return DHTS_E_INVALID;
+    HybTables ht = hyb_tables(t);
+    ht.plain = plain; ht.g_stateT = g_stateT; ht.g_veh = g_veh; ht.g_state0 = g_state0;
     const int B = hyb_block(d);
     if (B > 1024) return DHTS_E_INVALID;
     const HybWs ws = hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step);
@@ -1277,9 +1330,20 @@ int dhts_net_hybrid_rollout_bwd(const dhts_net_desc *d, const dhts_hybrid_tables
         return DHTS_E_LAUNCH;
     kern<<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
         d->n_replicas, d->n_lanes, d->n_cells, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max,
-        d->static_speed, d->vehicle_length, hyb_tables(t), action, hist, reinterpret_cast<const float4 *>(tape), kc, queue,
+        d->static_speed, d->vehicle_length, ht, action, hist, reinterpret_cast<const float4 *>(tape), kc, queue,
         g_reward, g_action, reinterpret_cast<const char *>(workspace), t->records_per_step, err);
     return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
+}
+int dhts_net_hybrid_rollout_bwd(const dhts_net_desc *d, const dhts_hybrid_tables *t, const float *action, const float *hist,
+                                const float *tape, const float *kc, const float *queue, const float *g_reward,
+                                float *g_action, const void *workspace, dhts_error *err, void *stream) {
+    return hyb_bwd_launch(d, t, 0, action, hist, tape, kc, queue, g_reward, nullptr, nullptr, g_action, nullptr, workspace, err, stream);
+}
+int dhts_net_hybrid_state_rollout_bwd(const dhts_net_desc *d, const dhts_hybrid_tables *t, int32_t plain, const float *action,
+                                      const float *hist, const float *tape, const float *kc, const float *queue,
+                                      const float *g_reward, const float *g_stateT, const float *g_veh, float *g_action,
+                                      float *g_state0, const void *workspace, dhts_error *err, void *stream) {
+    return hyb_bwd_launch(d, t, plain, action, hist, tape, kc, queue, g_reward, g_stateT, g_veh, g_action, g_state0, workspace, err, stream);
 }
 
 }  // extern "C"

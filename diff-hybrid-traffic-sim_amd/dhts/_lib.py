@@ -47,6 +47,10 @@ class HybridTables(C.Structure):
                 ("lane_source", C.c_void_p), ("draws", C.c_void_p), ("n_draws", C.c_int32), ("draws_stride", C.c_int64)]
 
 
+class HybridStateIO(C.Structure):
+    _fields_ = [("plain", C.c_int32), ("state0", C.c_void_p), ("ghost0", C.c_void_p), ("veh_out", C.c_void_p), ("events", C.c_void_p)]
+
+
 class MicroDesc(C.Structure):
     _fields_ = [("n_lanes", C.c_int32), ("capacity", C.c_int32), ("dt", C.c_double)]
 
@@ -81,6 +85,8 @@ SIGNATURES = {
     "dhts_net_hybrid_rollout_fwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(HybridTables)] + [_P] * 10),
     "dhts_net_hybrid_rollout_eval": (C.c_int, [C.POINTER(NetDesc), C.POINTER(HybridTables)] + [_P] * 6),
     "dhts_net_hybrid_rollout_bwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(HybridTables)] + [_P] * 10),
+    "dhts_net_hybrid_state_rollout_fwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(HybridTables), C.POINTER(HybridStateIO)] + [_P] * 10),
+    "dhts_net_hybrid_state_rollout_bwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(HybridTables), C.c_int32] + [_P] * 13),
     "dhts_micro_tape_bytes": (C.c_size_t, [C.POINTER(MicroDesc), C.c_int]),
     "dhts_micro_step_tape_bytes": (C.c_size_t, [C.POINTER(MicroDesc)]),
     "dhts_micro_rollout_fwd": (C.c_int, [C.POINTER(MicroDesc), C.c_int] + [_P] * 11),

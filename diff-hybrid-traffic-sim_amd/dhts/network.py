@@ -170,6 +170,29 @@ class HybridNetworkTables:
             raise ValueError("the network kernels support at most 4 upstream and 4 downstream lanes per lane")
         self.schedule = np.ascontiguousarray(np.asarray(schedule, dtype=np.float64).T)      # [T][L]
 
+    @staticmethod
+    def plain(lane_macro, lane_ncell, lane_length, edges, T, macro_route=None):
+        """Tables of a PLAIN road network -- RoadNetwork of the reference without the itscp layer (example/inverse/hybrid.py): no
+        signals, no inflow schedules.  A ghost is the connected macro lane's edge cell (the single neighbour, or macro_route's
+        choice among several: [L] ints, successor of each macro lane, -1 = none, as RoadNetwork.create_random_macro_route draws it
+        once) or the lane's own stored ghost (get_macro_boundary, road_network.py:299-362).  For
+        dhts.ops.net_hybrid_state_rollout (plain = True)."""
+        lane_macro = np.asarray(lane_macro, dtype=np.int32)
+        L = len(lane_macro)
+        mr = -np.ones(L, dtype=np.int32) if macro_route is None else np.asarray(macro_route, dtype=np.int32)
+        nxt = [[] for _ in range(L)]
+        for a, b in np.asarray(edges, dtype=np.int64).reshape(-1, 2).tolist():
+            nxt[a].append(b)
+        for l in range(L):                       # a single macro successor needs no route entry
+            if lane_macro[l] == 1 and mr[l] < 0 and len(nxt[l]) == 1:
+                mr[l] = nxt[l][0]
+        t = HybridNetworkTables(lane_macro, lane_ncell, lane_length, edges, np.zeros(L, dtype=np.int32), np.zeros(L, dtype=np.int32),
+                                np.tile(mr[None, :], (int(T), 1)), np.zeros((L, int(T))))
+        # no inflow schedules: a lane without an upstream lane keeps its stored ghost (code -3), like one behind a micro lane
+        t.left_src = np.where(t.left_src == -1, -3, t.left_src).astype(np.int32)
+        t.is_plain = True
+        return t
+
     def set_micro_sources(self, draws):
         """The admission draws of the micro source lanes: the values np.random.random() yields (or yielded, for a replay), in
         call order -- one per source lane and step in which the lane has room for a vehicle."""

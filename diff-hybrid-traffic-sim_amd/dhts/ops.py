@@ -673,6 +673,100 @@ class NetHybridRollout(torch.autograd.Function):
         return g_action, None, None, None, None, None, None, None, None, None, None, None
 
 
+class NetHybridStateRollout(torch.autograd.Function):
+    """R replicas of a road network of ARZ and IDM lanes that starts from a GIVEN state, all T steps in one launch each way:
+    (r0, u0 [R][C]) -> (rT, yT, uT [R][C], veh [R][128][4], events, counts).  With dev_tables built by
+    HybridNetworkTables.plain(...) and plain = True this is T x RoadNetwork.forward(dt, True) of the reference on the network
+    of example/inverse/hybrid.py (macro -> micro -> macro: flux-capacitor spawns, IDM steps, deposits; hybrid.py:37-146,
+    _inverse.py:91-99) with its backward pass: cotangents of the final (r, u) of every cell and of the final (position, speed)
+    of every vehicle go back to (r0, u0).  ghost0 [R][L][4] = stored (r, u) of each lane's upstream / downstream ghost
+    (set_leftmost_cell / set_rightmost_cell), constants."""
+
+    @staticmethod
+    def forward(ctx, r0, u0, ghost0, dev_tables, dt, u_max, plain, vehicle_length, check_faults):
+        t = dev_tables
+        R, Cc = r0.shape
+        if Cc != t.n_cells:
+            raise ValueError("state must be [R][%d cells]" % t.n_cells)
+        if t.n_replica_tables not in (0, R):
+            raise ValueError("per-replica tables must match the number of replicas")
+        dev = r0.device
+        r0c, u0c = _f32c(r0.detach(), "r0"), _f32c(u0.detach(), "u0")
+        y0, q0 = macro_state_from_ru(r0c, u0c, u_max)
+        state0 = torch.stack([r0c, y0, u0c, q0], dim=1).contiguous()                       # [R][4][C]
+        g0 = None if ghost0 is None else _f32c(ghost0.detach(), "ghost0")
+        if g0 is not None and tuple(g0.shape) != (R, t.n_lanes, 4):
+            raise ValueError("ghost0 must be [R][%d lanes][4]" % t.n_lanes)
+        action = torch.full((R, 1), 0.5, dtype=torch.float32, device=dev)                # no signals: one dummy phase
+        d = _lib.NetDesc(R, t.n_lanes, t.n_cells, t.T, 1, max(int(t.T), 1), 1, float(dt), float(u_max), 0.2, float(vehicle_length))
+        tc = t.c(0)
+        lib = _lib.lib()
+        ws_n = lib.dhts_net_hybrid_workspace_bytes(C.byref(d), C.byref(tc))
+        if ws_n == 0:
+            raise ValueError("unsupported hybrid network size")
+        hist = torch.empty(max(R * (t.T + 1) * 4 * t.n_cells, 64), dtype=torch.float32, device=dev)
+        tape = torch.empty(max(lib.dhts_net_hybrid_tape_bytes(C.byref(d)) // 4, 64), dtype=torch.float32, device=dev)
+        kc = torch.empty(max(R * t.T * t.n_cells, 64), dtype=torch.float32, device=dev)
+        queue = torch.empty(R, t.T, t.n_lanes, dtype=torch.float32, device=dev)
+        reward = torch.empty(R, dtype=torch.float32, device=dev)
+        counts = torch.zeros(R, 4, dtype=torch.int32, device=dev)
+        veh = torch.zeros(R, 128, 4, dtype=torch.float32, device=dev)
+        veh[:, :, 0] = -1.0
+        events = torch.full((R, 256, 2), -1, dtype=torch.int32, device=dev)
+        ws = torch.empty(ws_n, dtype=torch.uint8, device=dev)
+        err = new_error_record(dev)
+        io = _lib.HybridStateIO(1 if plain else 0, _ptr(state0), None if g0 is None else _ptr(g0), _ptr(veh), _ptr(events))
+        check(lib.dhts_net_hybrid_state_rollout_fwd(C.byref(d), C.byref(tc), C.byref(io), _ptr(action), _ptr(hist), _ptr(tape), _ptr(kc),
+                                                    _ptr(queue), _ptr(reward), _ptr(counts), _ptr(ws), _ptr(err), _stream()),
+              "dhts_net_hybrid_state_rollout_fwd")
+        if check_faults:
+            raise_on_fault(err)
+        fin = hist[:R * (t.T + 1) * 4 * t.n_cells].view(R, t.T + 1, 4, t.n_cells)[:, t.T]
+        rT, yT, uT = fin[:, 0].clone(), fin[:, 1].clone(), fin[:, 2].clone()
+        ctx.d, ctx.tables, ctx.plain, ctx.u_max, ctx.check_faults = d, t, bool(plain), float(u_max), bool(check_faults)
+        ctx.save_for_backward(action, hist, tape, kc, queue, ws, r0c, u0c, rT, yT)
+        ctx.mark_non_differentiable(yT, events, counts)
+        return rT, yT, uT, veh, events, counts
+
+    @staticmethod
+    def backward(ctx, g_rT, _g_yT, g_uT, g_veh, _g_ev, _g_counts):
+        action, hist, tape, kc, queue, ws, r0c, u0c, rT, yT = ctx.saved_tensors
+        d, t = ctx.d, ctx.tables
+        R, Cc = r0c.shape
+        dev = r0c.device
+        z = lambda: torch.zeros(R, Cc, dtype=torch.float32, device=dev)      # noqa: E731
+        g_r = g_rT.contiguous().float() if g_rT is not None else z()
+        g_u = g_uT.contiguous().float() if g_uT is not None else z()
+        g_stateT = torch.stack([g_r, z(), g_u], dim=1).contiguous()          # the kernel turns the speed's cotangent into (r, y)'s itself
+        gv = None
+        if g_veh is not None:
+            gv = g_veh[:, :, 1:3].contiguous().float()                        # cotangent of (position, speed)
+        g_reward = torch.zeros(R, dtype=torch.float32, device=dev)            # a pure state tap
+        g_action = torch.empty_like(action)
+        g_state0 = torch.empty(R, 3, Cc, dtype=torch.float32, device=dev)
+        err = new_error_record(dev)
+        tc = t.c(0)
+        check(_lib.lib().dhts_net_hybrid_state_rollout_bwd(C.byref(d), C.byref(tc), 1 if ctx.plain else 0, _ptr(action), _ptr(hist), _ptr(tape),
+                                                           _ptr(kc), _ptr(queue), _ptr(g_reward), _ptr(g_stateT), _ptr(gv), _ptr(g_action),
+                                                           _ptr(g_state0), _ptr(ws), _ptr(err), _stream()),
+              "dhts_net_hybrid_state_rollout_bwd")
+        if ctx.check_faults:
+            raise_on_fault(err)
+        # initial (r, y, u) -> (r0, u0): y0 = r0 (u0 - u_eq(r0)) (FullQ.from_r_u), u0 itself where step 0 read the given speed
+        g_r0 = g_state0[:, 0].contiguous()
+        g_y0 = g_state0[:, 1].contiguous()
+        g_u0 = macro_state_from_ru_bwd(r0c, u0c, g_y0, g_r0, ctx.u_max)
+        g_u0 = g_u0 + g_state0[:, 2]
+        return g_r0, g_u0, None, None, None, None, None, None, None
+
+
+def net_hybrid_state_rollout(r0, u0, dev_tables, dt, u_max, ghost0=None, plain=True, vehicle_length=5.0, check_faults=True):
+    """(rT, yT, uT [R][C], veh [R][128][4] = (lane or -1, position, speed, a) per spawned vehicle, events [R][256][2] = (step, kind),
+    counts [R][4] = (spawned, deposited, records, events)); differentiable in r0, u0 through rT, uT and veh[..., 1:3]."""
+    return NetHybridStateRollout.apply(r0, u0, ghost0, dev_tables, float(dt), float(u_max), bool(plain), float(vehicle_length),
+                                       bool(check_faults))
+
+
 def net_hybrid_eval(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0, err=None):
     """An evaluation episode (hard thresholds, see net_macro_eval) of R replicas of a hybrid network: returns
     (reward [R], queue [R][T][L], counts [R][4] = vehicles spawned, vehicles deposited, 0, 0)."""

@@ -380,6 +380,40 @@ int dhts_net_hybrid_rollout_bwd(const dhts_net_desc *d, const dhts_hybrid_tables
                                 const float *tape, const float *kc, const float *queue, const float *g_reward,
                                 float *g_action, const void *workspace, dhts_error *err, void *stream);
 
+/* ---- the same kernels for a PLAIN road network with given initial state: example/inverse/hybrid.py ----------------------------
+ * RoadNetwork.forward of the reference without the itscp layer (road/network/road_network.py:79-111, 299-362, 429-580): no
+ * signals and no inflow schedules -- a ghost is the connected macro lane's edge cell or the lane's own STORED ghost, unblended
+ * (get_macro_boundary), a head vehicle's gap is the one to its leader along its route (setup_micro_boundary) -- lanes that start
+ * from a GIVEN state, and taps on the FINAL state instead of the queue loss: what example/inverse/hybrid.py:37-146 and
+ * _inverse.py:91-99, 185-242 run T x (3 operator calls + host conversions) for.
+ *   plain       1 = the plain network above (tables: sig_kind all 0, left_src / right_src = neighbour lane or -3 / -1 for the
+ *               stored ghost, schedule unused); 0 = the itscp semantics of dhts_net_hybrid_rollout_fwd with the extra inputs
+ *   state0      [R][4][C] float32 (r, y, u, u_eq) of every cell at step 0 (NULL = empty road: r = y = 0, u = u_eq = u_max)
+ *   ghost0      [R][L][4] float32 (r, u) of each lane's stored upstream ghost, (r, u) of its stored downstream ghost
+ *               (NULL = (0, u_max) both: set_leftmost_cell / set_rightmost_cell defaults)
+ *   veh_out     [R][128][4] float32 out: (lane id or -1 once it left the network, position, speed, ancillary a) of every
+ *               vehicle in spawn order (rows beyond counts[0] are not written)
+ *   events      [R][256][2] int32 out: (step, kind) of the hand-off events in order, kind 0 = macro -> micro spawn, 1 = micro ->
+ *               macro deposit; counts[3] = their number (NULL = not kept)
+ * Reverse: g_stateT [R][3][C] cotangent of the final (r, y, u) per cell and g_veh [R][128][2] cotangent of the final (position,
+ * speed) of vehicle k (either may be NULL) enter beside g_reward (NULL = ones, as above; pass zeros for a pure state tap);
+ * g_state0 [R][3][C] out = cotangent of the initial (r, y, u) -- u collects what reads the GIVEN speed at step 0 (ghosts of
+ * neighbouring lanes, a flux capacitor); the initial y = r (u - u_eq(r)) is the caller's (dhts_macro_state_from_ru_bwd). */
+typedef struct dhts_hybrid_state_io {
+    int32_t plain;
+    const float *state0;
+    const float *ghost0;
+    float *veh_out;
+    int32_t *events;
+} dhts_hybrid_state_io;
+int dhts_net_hybrid_state_rollout_fwd(const dhts_net_desc *d, const dhts_hybrid_tables *t, const dhts_hybrid_state_io *io,
+                                      const float *action, float *hist, float *tape, float *kc, float *queue, float *reward,
+                                      int32_t *counts, void *workspace, dhts_error *err, void *stream);
+int dhts_net_hybrid_state_rollout_bwd(const dhts_net_desc *d, const dhts_hybrid_tables *t, int32_t plain, const float *action,
+                                      const float *hist, const float *tape, const float *kc, const float *queue,
+                                      const float *g_reward, const float *g_stateT, const float *g_veh, float *g_action,
+                                      float *g_state0, const void *workspace, dhts_error *err, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

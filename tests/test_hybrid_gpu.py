@@ -404,3 +404,124 @@ def test_micro_sources_exhausted_waiting_list_and_draws(cuda, oracle, golden_dir
     t.set_micro_sources(g["rand_draws"][:5])
     with pytest.raises(RuntimeError, match="capacity"):
         ops.net_hybrid_eval(a.detach(), ops.DeviceHybridTables(t, rows, cuda), *args)
+
+
+def _plain_three_lane_tables(N, dx, T):
+    from dhts.network import HybridNetworkTables
+    # macro(0) -> micro(1) -> macro(2), each N dx long (example/inverse/hybrid.py:37-82)
+    return HybridNetworkTables.plain([1, 0, 1], [N, 0, N], [N * dx] * 3, [(0, 1), (1, 2)], T, macro_route=[1, -1, -1])
+
+
+def _fused_three_lane(cuda, r0, u0, bd_r, bd_u, N, T, dx, dt, um):
+    """The network of example/inverse/hybrid.py through the fused kernels: lane 0 starts from (r0, u0), lane 2 empty, stored
+    ghosts bd_*[0..3] = (lane 0 left, lane 0 right, lane 2 left, lane 2 right)."""
+    import torch
+    from dhts import ops
+    tab = _plain_three_lane_tables(N, dx, T)
+    dtab = ops.DeviceHybridTables(tab, np.array([[1, 2]], dtype=np.int32), cuda)
+    r_all = torch.cat([r0, torch.zeros(N, device=cuda)])[None]
+    u_all = torch.cat([u0, torch.full((N,), um, device=cuda)])[None]
+    ghost0 = torch.tensor([[[bd_r[0], bd_u[0], bd_r[1], bd_u[1]], [0.0, um, 0.0, um], [bd_r[2], bd_u[2], bd_r[3], bd_u[3]]]],
+                          dtype=torch.float32, device=cuda)
+    return ops.net_hybrid_state_rollout(r_all, u_all, dtab, dt, um, ghost0=ghost0, plain=True)
+
+
+def test_fused_state_rollout_matches_reference_three_lane_network(cuda, golden_dir):
+    """example/inverse/hybrid.py's macro -> micro -> macro network (G7, 500 steps of the reference's RoadNetwork.forward) in ONE
+    launch each way: the fused hybrid kernels started from the given state of lane 0 with the stored ghosts of the example, taps
+    on the final state of all three lanes.  Spawn / deposit steps, vehicle count per step's end, final states <= 1e-5, the loss
+    and d loss / d (r0, u0) <= 1e-4 of the reference's run."""
+    import json
+    import torch
+    g = np.load(os.path.join(golden_dir, "hybrid_hybrid3.npz"))
+    m = json.loads(str(g["meta"]))
+    N, T, dx, dt, um = m["N"], m["T"], m["dx"], m["dt"], m["u_max"]
+    r0 = torch.tensor(g["r0"], device=cuda, requires_grad=True)
+    u0 = torch.tensor(g["u0"], device=cuda, requires_grad=True)
+    rT, yT, uT, veh, events, counts = _fused_three_lane(cuda, r0, u0, g["bd_r"], g["bd_u"], N, T, dx, dt, um)
+    n_ev = int(counts[0, 3])
+    ev = events[0, :n_ev].cpu().numpy()
+    assert [(int(a), int(b)) for a, b in ev] == [(int(e[0]), int(e[1])) for e in g["events"]]
+    assert int(counts[0, 0]) == int((g["events"][:, 1] == 0).sum()) and int(counts[0, 1]) == int((g["events"][:, 1] == 1).sum())
+    v = veh[0, :int(counts[0, 0])]
+    on_b = v[v[:, 0] == 1.0]
+    order = torch.argsort(on_b[:, 1])
+    pB, vB = on_b[order, 1], on_b[order, 2]
+    assert pB.shape[0] == int(g["nveh"][-1]) == len(g["pB"])
+    rA, uA, rC, uC = rT[0, :N], uT[0, :N], rT[0, N:], uT[0, N:]
+    loss = (rC ** 2).sum() + (uC ** 2).sum() + (rA ** 2).sum() + (uA ** 2).sum() + 1e-4 * (pB ** 2).sum() + (vB ** 2).sum()
+    loss.backward()
+    for got, key in ((rA, "rA"), (uA, "uA"), (rC, "rC"), (uC, "uC"), (pB, "pB"), (vB, "vB")):
+        assert state_report("fused three-lane network: " + key, got.detach().cpu().numpy(), g[key]) <= TOL_STATE, key
+    assert rel_max(yT[0, :N].cpu().numpy(), g["yA"]) <= TOL_STATE and rel_max(yT[0, N:].cpu().numpy(), g["yC"]) <= TOL_STATE
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    assert grad_report("fused three-lane network d loss / d r0", r0.grad.cpu().numpy(), g["g_r0"]) <= TOL_GRAD
+    assert grad_report("fused three-lane network d loss / d u0", u0.grad.cpu().numpy(), g["g_u0"]) <= TOL_GRAD
+
+
+@pytest.mark.parametrize("seed,N,T", [(1, 10, 300), (2, 16, 400), (3, 8, 250)])
+def test_fused_state_rollout_matches_lane_by_lane_mirror(cuda, seed, N, T):
+    """Other initial states / ghosts / sizes of the same three-lane network: the fused kernels against the drop-in classes stepped
+    lane by lane (3 T operator calls + host conversions; itself checked against the reference's run above and in
+    tests/test_mirror_gpu.py): same events, final states <= 1e-5, gradients <= 1e-4."""
+    import torch
+    from road.lane.dmacro_lane import dMacroLane
+    from road.lane.dmicro_lane import dMicroLane
+    from road.network.road_network import RoadNetwork
+    rng = np.random.default_rng(seed)
+    dx, dt, um = 5.0, 0.01, 30.0
+    r0n = rng.uniform(0.3, 1.0, N).astype(np.float32)
+    u0n = rng.uniform(8.0, um, N).astype(np.float32)
+    bd_r = rng.uniform(0.0, 1.0, 4).astype(np.float32)
+    bd_u = rng.uniform(0.0, um, 4).astype(np.float32)
+    # lane by lane
+    np.random.seed(seed)
+    r0, u0 = (torch.tensor(x, device=cuda, requires_grad=True) for x in (r0n, u0n))
+    net = RoadNetwork(um)
+    a = dMacroLane(0, N * dx, um, dx)
+    a.set_leftmost_cell(torch.tensor(bd_r[0], device=cuda), torch.tensor(bd_u[0], device=cuda))
+    a.set_rightmost_cell(torch.tensor(bd_r[1], device=cuda), torch.tensor(bd_u[1], device=cuda))
+    net.add_lane(a)
+    a.set_state_vector_u(r0, u0)
+    b = dMicroLane(1, N * dx, um)
+    net.add_lane(b)
+    c = dMacroLane(2, N * dx, um, dx)
+    c.set_leftmost_cell(torch.tensor(bd_r[2], device=cuda), torch.tensor(bd_u[2], device=cuda))
+    c.set_rightmost_cell(torch.tensor(bd_r[3], device=cuda), torch.tensor(bd_u[3], device=cuda))
+    net.add_lane(c)
+    net.connect_lane(0, 1)
+    net.connect_lane(1, 2)
+    net.macro_route = net.create_random_macro_route()
+    ev_ref = []
+    for t in range(T):
+        before, spawned = b.num_vehicle(), net.num_vehicle
+        net.forward(dt, True)
+        if net.num_vehicle > spawned:
+            ev_ref.append((t, 0))
+        if b.num_vehicle() < before + (net.num_vehicle - spawned):
+            ev_ref.append((t, 1))
+
+    def loss_of(rA, uA, rC, uC, pB, vB):
+        return (rC ** 2).sum() + (uC ** 2).sum() + (rA ** 2).sum() + (uA ** 2).sum() + 1e-4 * (pB ** 2).sum() + (vB ** 2).sum()
+    rA, _, uA = a.get_state_vector()
+    rC, _, uC = c.get_state_vector()
+    pB, vB = b.get_state_vector() if b.num_vehicle() else (torch.zeros(0, device=cuda), torch.zeros(0, device=cuda))
+    loss_of(rA, uA, rC, uC, pB, vB).backward()
+    ref = dict(rA=rA, uA=uA, rC=rC, uC=uC, pB=pB, vB=vB)
+    g_r_ref, g_u_ref = r0.grad.cpu().numpy(), u0.grad.cpu().numpy()
+    # fused
+    r1, u1 = (torch.tensor(x, device=cuda, requires_grad=True) for x in (r0n, u0n))
+    rT, yT, uT, veh, events, counts = _fused_three_lane(cuda, r1, u1, bd_r, bd_u, N, T, dx, dt, um)
+    n_ev = int(counts[0, 3])
+    assert [(int(x), int(y)) for x, y in events[0, :n_ev].cpu().numpy()] == ev_ref and len(ev_ref) >= 2
+    v = veh[0, :int(counts[0, 0])]
+    on_b = v[v[:, 0] == 1.0]
+    order = torch.argsort(on_b[:, 1])
+    got = dict(rA=rT[0, :N], uA=uT[0, :N], rC=rT[0, N:], uC=uT[0, N:], pB=on_b[order, 1], vB=on_b[order, 2])
+    assert got["pB"].shape == ref["pB"].shape
+    loss_of(**got).backward()
+    for key in ("rA", "uA", "rC", "uC", "pB", "vB"):
+        if ref[key].numel():
+            assert state_report("fused vs lane by lane (seed %d): %s" % (seed, key), got[key].detach().cpu().numpy(), ref[key].detach().cpu().numpy()) <= TOL_STATE, key
+    assert grad_report("fused vs lane by lane d loss / d r0", r1.grad.cpu().numpy(), g_r_ref) <= TOL_GRAD
+    assert grad_report("fused vs lane by lane d loss / d u0", u1.grad.cpu().numpy(), g_u_ref) <= TOL_GRAD
