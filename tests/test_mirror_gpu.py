@@ -218,13 +218,19 @@ def test_inverse_examples_reduce_the_error(cuda, tmp_path):
         assert float(lines[-1][1]) < 0.7 * float(lines[0][1]), (kind, lines[0], lines[-1])
         import shutil
         shutil.rmtree(tmp_path / "result")
-    # the hybrid three-lane problem (example/inverse/hybrid.py) through the drop-in classes, one operator call per lane-step
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "inverse_hybrid.py"), "--n_episode", "6", "--n_timestep", "120",
-                          "--seed", "3", "--run_name", "h"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l.split() for l in open(tmp_path / "result" / "inverse" / "h" / "gd" / "trial_0.txt").read().split("\n") if l]
-    assert len(lines) == 6 and all(len(l) == 2 for l in lines)
-    assert float(lines[-1][1]) < float(lines[0][1]), lines
+    # the hybrid three-lane problem (example/inverse/hybrid.py): through the fused network kernels (one launch each way per
+    # episode) and, --lane_by_lane, through the drop-in classes (one operator call per lane-step): the same log lines
+    logs = {}
+    for name, extra in (("h", []), ("hl", ["--lane_by_lane"])):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "inverse_hybrid.py"), "--n_episode", "6", "--n_timestep", "120",
+                              "--seed", "3", "--run_name", name] + extra, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        print(out.stdout.strip())
+        lines = [l.split() for l in open(tmp_path / "result" / "inverse" / name / "gd" / "trial_0.txt").read().split("\n") if l]
+        assert len(lines) == 6 and all(len(l) == 2 for l in lines)
+        assert float(lines[-1][1]) < float(lines[0][1]), lines
+        logs[name] = np.array(lines, dtype=np.float64)
+    assert np.allclose(logs["h"], logs["hl"], rtol=2e-4, atol=1e-6), (logs["h"], logs["hl"])
 
 
 def test_hybrid_three_lane_network_like_example(cuda, golden_dir):
