@@ -106,7 +106,8 @@ class MacroWorkload:
     unit_name = "cell-steps/s"
     # what each kernel runs into, qualitatively; every NUMBER quoted beside it comes from the counter passes
     # committed as profiles/issue_counters.json (issue_side below) or from this run's own events
-    limiter = {"rollout_fwd": "instruction issue (vector + scalar) at 4 wavefronts per SIMD and the serial queue pass of phase 2, not HBM",
+    limiter = {"rollout_fwd": "the dependent instruction stream of the wavefronts that solve the queued interfaces (phase 2, 40 % of a step) and "
+                              "instruction issue in phase 1 at 4 wavefronts per SIMD, not HBM",
                "rollout_bwd": "instruction issue + LDS / barrier latency at 4 wavefronts per SIMD (three steps of tape in flight)"}
 
     @staticmethod

@@ -347,7 +347,9 @@ __host__ __device__ inline int hyb_stage_h(int L, int C, int sq, int V, int NS, 
 // 276), a cell / a vehicle is static when its speed is below static_speed (_env.py:607-617, 709-717).  The steps themselves and the hand-offs are the
 // same.  Nothing is kept for a reverse sweep: no records, no tape, no history, no loss constants (hist, tape, kc and the
 // workspace are not touched and may be NULL).
-template <int kMaxBlock, bool kHard>
+// kState: the instantiation behind dhts_net_hybrid_state_rollout_fwd (given initial state / stored ghosts, plain-network
+// semantics, vehicle table and event log out); the itscp instantiations carry none of its tests.
+template <int kMaxBlock, bool kHard, bool kState = false>
 __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
                                       double static_speed, double veh_len, HybTables tb, const float *__restrict__ action,
                                       float *__restrict__ hist, float4 *__restrict__ tape, float *__restrict__ kc,
@@ -410,7 +412,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     }
     if (tid < C) {
         float r0 = 0.f, y0 = 0.f, u0 = um, q0 = um;           // an empty road, or the caller's initial state
-        if (tb.state0) { const float *s0 = tb.state0 + (size_t)rep * 4 * C; r0 = s0[tid]; y0 = s0[C + tid]; u0 = s0[2 * C + tid]; q0 = s0[3 * C + tid]; }
+        if (kState && tb.state0) { const float *s0 = tb.state0 + (size_t)rep * 4 * C; r0 = s0[tid]; y0 = s0[C + tid]; u0 = s0[2 * C + tid]; q0 = s0[3 * C + tid]; }
         S0[tid] = r0; S0[C + tid] = y0; S0[2 * C + tid] = u0; S0[3 * C + tid] = q0;
         if (!kHard) { hist_r[tid] = r0; hist_r[C + tid] = y0; hist_r[2 * C + tid] = u0; hist_r[3 * C + tid] = q0; }
     }
@@ -467,14 +469,14 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     int g_kind = 0, g_inter = 0; bool g_macro = false;
     float own_r = 0.f, own_u = um;               // the lane's stored downstream ghost (side-1 ghost thread)
     float gl_r = 0.f, gl_u = um;                 // the lane's stored upstream ghost (side-0 ghost thread)
-    const bool plain = tb.plain != 0;
+    const bool plain = kState && tb.plain != 0;
     if (is_ghost) { g_kind = tb.net.sig_kind[g_lane]; g_inter = tb.net.inter[g_lane]; g_macro = tb.lane_macro[g_lane] != 0; }
-    if (is_ghost && tb.ghost0) {
+    if (kState && is_ghost && tb.ghost0) {
         const float *g0 = tb.ghost0 + ((size_t)rep * L + g_lane) * 4;
         gl_r = g0[0]; gl_u = g0[1]; own_r = g0[2]; own_u = g0[3];
     }
     int n_ev = 0;                                // hand-off events logged so far (thread 0 of the micro wave)
-    int *ev_log = tb.events ? tb.events + (size_t)rep * 4 * kMaxVeh : nullptr;
+    int *ev_log = (kState && tb.events) ? tb.events + (size_t)rep * 4 * kMaxVeh : nullptr;
     int l_off = 0, l_n = 0, l_ms = -1; bool l_macro = false;
     if (is_lane) { l_off = tb.net.lane_off[tid]; l_n = tb.net.lane_ncell[tid]; l_ms = mslot[tid]; l_macro = tb.lane_macro[tid] != 0; }
     // signals of step 0 (the staged action vector is complete after the barrier above); signal threads count (phase, frame)
@@ -885,7 +887,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     if (in_mw) {
         if (is_mt) { counts[4 * rep + 0] = spawned; counts[4 * rep + 1] = deposits; counts[4 * rep + 3] = n_ev; }
         if (rec.over || cap_fault) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, 0);
-        if (tb.veh_out) {
+        if (kState && tb.veh_out) {
             // every vehicle ever spawned: gone (-1) unless a lane still lists it (one wavefront: its stores to a row stay in order)
             float *vo = tb.veh_out + (size_t)rep * 4 * V;
             const int n_sp = __builtin_amdgcn_readfirstlane(spawned);
@@ -934,7 +936,7 @@ __host__ __device__ inline HybLdsB hyb_lds_b(int L, int C, int sq, int V, int E)
 // segments, newest first (deposits and capacitor reads exchange cotangents with the cells) -> speed cotangents into (r, y)
 // and J^T g per cell -> gather inside the lanes, ghost cotangents to inbox slots, signals | the head-gap / IDM segment of
 // the micro records and the outboxes -> edge cells take their inboxes.
-template <int kMaxBlock>
+template <int kMaxBlock, bool kState = false>
 __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L, int C, int T, int sq, int F, int n_action, double dt, double um_d,
                                       double static_speed, double veh_len, HybTables tb, const float *__restrict__ action,
                                       const float *__restrict__ hist, const float4 *__restrict__ tape,
@@ -1001,18 +1003,18 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         }
         iptr[sq] = n;
     }
-    const bool plain = tb.plain != 0;
+    const bool plain = kState && tb.plain != 0;
     for (int k = tid; k < n_adj; k += B) adj[k] = 0.f;
     for (int k = tid; k < 2 * sq; k += B) gam[k] = 0.f;
     if (is_cell) {
         // cotangent of the final state: the caller's tap, if any (the queue loss adds its own below)
         float t_r = 0.f, t_y = 0.f, t_u = 0.f;
-        if (tb.g_stateT) { const float *g = tb.g_stateT + (size_t)rep * 3 * C; t_r = g[tid]; t_y = g[C + tid]; t_u = g[2 * C + tid]; }
+        if (kState && tb.g_stateT) { const float *g = tb.g_stateT + (size_t)rep * 3 * C; t_r = g[tid]; t_y = g[C + tid]; t_u = g[2 * C + tid]; }
         gL[tid] = t_r; gL[C + tid] = t_y; gL[2 * C + tid] = t_u;
     }
     __syncthreads();
     // ... and of the vehicles' final (position, speed): their committed slots 3 k, 3 k + 1
-    if (tb.g_veh) for (int k = tid; k < V; k += B) { adj[3 * k] = tb.g_veh[((size_t)rep * V + k) * 2]; adj[3 * k + 1] = tb.g_veh[((size_t)rep * V + k) * 2 + 1]; }
+    if (kState && tb.g_veh) for (int k = tid; k < V; k += B) { adj[3 * k] = tb.g_veh[((size_t)rep * V + k) * 2]; adj[3 * k + 1] = tb.g_veh[((size_t)rep * V + k) * 2 + 1]; }
     int c_lane = 0, c_first = 0, c_last = 0, c_macb = 0; float c_dxv = 0.f, c_cf = 0.f, c_ncf = 0.f;
     if (is_cell) {
         c_lane = cell_lane_s[tid]; c_first = tb.net.lane_off[c_lane]; c_last = c_first + tb.net.lane_ncell[c_lane] - 1;
@@ -1165,7 +1167,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
         const int lo_ = inc - c;
         if (lo_ + c <= b_n)
             for (int k = lo_; k < lo_ + c; ++k)
-                if ((grk[b_lo + k] >> 24) == K_SEED && gscale != 0.f) { const int4 a = gri[b_lo + k]; const float4 b = grw[b_lo + k]; adj[a.x] += gscale * b.x; }
+                if ((grk[b_lo + k] >> 24) == K_SEED && (!kState || gscale != 0.f)) { const int4 a = gri[b_lo + k]; const float4 b = grw[b_lo + k]; adj[a.x] += gscale * b.x; }
     }
     __syncthreads();
     if (in_mw) fetch_offsets(T - 1);
@@ -1185,7 +1187,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     }
     HYB_STAMP_WRITE(1, rep, tid, B)
     // the cotangent of the initial state (the loop's last barrier is behind the cells' last write of gL)
-    if (tb.g_state0 && is_cell) {
+    if (kState && tb.g_state0 && is_cell) {
         float *g0 = tb.g_state0 + (size_t)rep * 3 * C;
         g0[tid] = gL[tid]; g0[C + tid] = gL[C + tid]; g0[2 * C + tid] = gL[2 * C + tid];
     }
@@ -1267,7 +1269,8 @@ static int hyb_fwd_launch(const dhts_net_desc *d, const dhts_hybrid_tables *t, c
     const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, stage_h).total + up16(sizeof(float) * (size_t)d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     // (the block-size bound sets the vector registers a thread may take: 256 / 168 / 128)
-    auto kern = B <= 512 ? net_hybrid_fwd_kernel<512, false> : (B <= 768 ? net_hybrid_fwd_kernel<768, false> : net_hybrid_fwd_kernel<1024, false>);
+    auto kern = io ? (B <= 512 ? net_hybrid_fwd_kernel<512, false, true> : (B <= 768 ? net_hybrid_fwd_kernel<768, false, true> : net_hybrid_fwd_kernel<1024, false, true>))
+                   : (B <= 512 ? net_hybrid_fwd_kernel<512, false> : (B <= 768 ? net_hybrid_fwd_kernel<768, false> : net_hybrid_fwd_kernel<1024, false>));
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_LAUNCH;
@@ -1324,7 +1327,9 @@ static int hyb_bwd_launch(const dhts_net_desc *d, const dhts_hybrid_tables *t, i
     const int E = t->net.n_edges > 0 ? t->net.n_edges : 1;
     const size_t lds = hyb_lds_b(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, E).total + up16(sizeof(float) * (size_t)d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
-    auto kern = B <= 512 ? net_hybrid_bwd_kernel<512> : (B <= 768 ? net_hybrid_bwd_kernel<768> : net_hybrid_bwd_kernel<1024>);
+    const bool state_io = plain || g_stateT || g_veh || g_state0;
+    auto kern = state_io ? (B <= 512 ? net_hybrid_bwd_kernel<512, true> : (B <= 768 ? net_hybrid_bwd_kernel<768, true> : net_hybrid_bwd_kernel<1024, true>))
+                         : (B <= 512 ? net_hybrid_bwd_kernel<512> : (B <= 768 ? net_hybrid_bwd_kernel<768> : net_hybrid_bwd_kernel<1024>));
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_LAUNCH;

@@ -18,7 +18,7 @@ def snippets():
 
 
 def test_every_marked_snippet_is_known():
-    assert set(snippets()) == {"binding", "rollouts", "net_macro", "net_hybrid", "net_eval", "net_micro"}
+    assert set(snippets()) == {"binding", "rollouts", "net_macro", "net_hybrid", "net_eval", "net_micro", "net_state"}
 
 
 def test_binding_snippet_loads_the_library():
@@ -113,3 +113,19 @@ def test_net_micro_snippet(cuda):
     exec(compile(snippets()["net_micro"], "INTEGRATION.md:net_micro", "exec"), ns)
     assert ns["reward"].shape == (3,) and action.grad is not None and torch.isfinite(action.grad).all()
     assert ns["tab"].n_cells == 0 and int(ns["counts"][:, 0].min()) > 0          # every replica admitted vehicles
+
+
+@pytest.mark.gpu
+def test_net_state_snippet(cuda):
+    """The plain three-lane network from a given state: the snippet runs, vehicles are spawned and the gradient reaches (r0, u0)."""
+    import torch
+    n_cell, T = 10, 300
+    g = torch.Generator().manual_seed(4)
+    ns = dict(n_cell=n_cell, T=T, dx=5.0, dt=0.01, u_max=30.0,
+              r0=(0.4 + 0.5 * torch.rand(n_cell, generator=g)).to(cuda).requires_grad_(True),
+              u0=(10.0 + 15.0 * torch.rand(n_cell, generator=g)).to(cuda).requires_grad_(True),
+              r_target=torch.zeros(n_cell, device=cuda), u_target=torch.zeros(n_cell, device=cuda),
+              ghost0=torch.tensor([[[0.5, 12.0, 0.3, 20.0], [0.0, 30.0, 0.0, 30.0], [0.1, 25.0, 0.2, 22.0]]], device=cuda))
+    exec(compile(snippets()["net_state"], "INTEGRATION.md:net_state", "exec"), ns)
+    assert ns["n_spawned"] >= 1 and ns["n_events"] >= ns["n_spawned"]
+    assert bool(torch.isfinite(ns["r0"].grad).all()) and float(ns["r0"].grad.abs().max()) > 0 and float(ns["u0"].grad.abs().max()) > 0
