@@ -1419,7 +1419,9 @@ static inline int macro_fwd3_group(const dhts_macro_desc *d, bool want_hist) {
     if (dhts_fwd_variant != 0 || want_hist || d->n_cells % 128 != 0 || d->n_cells > 1024) return 0;
     const int W = d->n_cells / 128;
     if (dhts_fwd_waves_override > 0 && dhts_fwd_waves_override != W) return 0;       // (a forced wave count means the lane kernel)
-    int G = dhts_fwd_group > 0 ? dhts_fwd_group : (W <= 3 ? 4 : 2);
+    // lanes per workgroup: four for lanes of up to three wavefronts, one for four (1024 x 512: 2.59 against 2.65 ms for two,
+    // 512 x 512: 0.93 / 1.10), two above (profiles/r04k_*, r04q_*)
+    int G = dhts_fwd_group > 0 ? dhts_fwd_group : (W <= 3 ? 4 : (W == 4 ? 1 : 2));
     while (G > 1 && (d->n_lanes % G != 0 || (dhts_fwd_group == 0 && d->n_lanes / G < 256) || 64 * W * G > 1024 ||
                      (size_t)G * fwd3_region_bytes(d->n_cells) > 160 * 1024))
         G >>= 1;

@@ -289,10 +289,8 @@ class ItscpEnv:
                         for r in reversed(sim.lane_waiting_micro_route.get(l, [])):
                             r = list(r.route)[:32]
                             rows.append(r + [-1] * (32 - len(r)))
-                    if len(rows) > 128:
-                        # more waiting vehicles than a fused episode can ever hold (include/dhts.h: 128 per episode): no point in
-                        # trying (a default 4 x 4 grid has 16 source lanes x 10 waiting vehicles)
-                        raise ValueError("more waiting vehicles than the fused kernels hold")
+                    # (more rows than the 128 vehicles a fused episode holds are fine: only the admitted ones count, and an
+                    # episode that admits more comes back as ops.CapacityError below)
                     self._fused_n_draws = T * max(1, int(tab.lane_source.sum()))
                     tab.set_micro_sources(np.full(self._fused_n_draws, 2.0))
                     cache = ("micro", ops.DeviceHybridTables(tab, np.asarray(rows if rows else [[-1, -1]], dtype=np.int32), action.device))

@@ -720,7 +720,7 @@ def test_macro_bench_instantiation_vs_reference_and_oracle(cuda, oracle, golden_
     # the launch this test makes is the one the bench makes
     plan = ops.macro_rollout_plan(ops.macro_desc(L, N, dt, dx, um), T, want_hist=False)
     assert plan == dict(fwd_kernel=2, fwd_waves=4, fwd_passes=2, fwd_full_lane=1, bwd_pipelined=1, bwd_block=512, hist=0,
-                        fwd_lanes_per_group=2)
+                        fwd_lanes_per_group=1)
     tr0, tu0 = T_(r0, cuda, grad=True), T_(u0, cuda, grad=True)
     tgr, tgu = T_(gr, cuda, grad=True), T_(gu, cuda, grad=True)
     rT, yT, uT, _ = dhts.macro_rollout(tr0, tu0, tgr, tgu, T, dt, dx, um)          # no history: the bench's instantiation

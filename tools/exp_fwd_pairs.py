@@ -2,7 +2,7 @@
 """Times the macro rollout forward kernel of BASELINE config 2 for the forward variants of ONE build of libdhts.so
 (DHTS_OPT_MACRO_FWD_VARIANT: 0 = pair kernel, 2 = lane / lane-group kernels of round 3) and lanes per workgroup, and checks every
 setting against the first one bit for bit (final state, and the gradient the reverse sweep makes of its tape).
-GPU box:  [DHTS_LIB=<variant build>] python3 tools/exp_fwd_pairs.py [variant:group ...]      (default: 2:0 0:0 0:4 0:1 2:0 0:0)"""
+GPU box:  [DHTS_LIB=<variant build>] [DHTS_EXP_LANES=<lanes, default 1024>] python3 tools/exp_fwd_pairs.py [variant:group ...]      (default: 2:0 0:0 0:4 0:1 2:0 0:0)"""
 import hashlib
 import json
 import os
@@ -21,7 +21,7 @@ def main():
     specs = sys.argv[1:] or ["2:0", "0:0", "0:4", "0:1", "2:0", "0:0"]
     print("library:", _lib.SO_PATH, flush=True)
     dev = torch.device("cuda:0")
-    w = bench.MacroWorkload(dev, 0, 1024, 512, 1000)
+    w = bench.MacroWorkload(dev, 0, int(os.environ.get("DHTS_EXP_LANES", "1024")), 512, 1000)
     ref = None
     for spec in specs:
         v, g = (int(x) for x in spec.split(":"))
