@@ -62,7 +62,11 @@ constexpr int kWindow = 100000;      // RunningMean(100_000), _env.py:122
 // of the first eight replicas.
 #ifdef DHTS_HYB_STAMPS
 __device__ long long dhts_hyb_stamps[2][8][16][24];
-#define HYB_STAMP_DECL long long st_last_ = __builtin_amdgcn_s_memtime(), st_acc_[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+// replica 0, every step: (arrival, release) of every wavefront at every barrier, cycles since the kernel's first stamp
+__device__ int dhts_hyb_trace[2][640][16][10];
+#define HYB_STAMP_DECL long long st_last_ = __builtin_amdgcn_s_memtime(), st_acc_[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+    const long long st_t0_ = st_last_; int st_kern_ = 0;
+#define HYB_STAMP_KERNEL(k_) st_kern_ = (k_);
 #define HYB_BARRIER(i)                                                                      \
     {                                                                                       \
         const long long a_ = __builtin_amdgcn_s_memtime();                                  \
@@ -73,6 +77,10 @@ __device__ long long dhts_hyb_stamps[2][8][16][24];
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                     \
         st_last_ = __builtin_amdgcn_s_memtime();                                            \
         st_acc_[16 + (i)] += st_last_ - b_;                    /* barrier */                \
+        if (blockIdx.x == 0 && (tid & 63) == 0 && t < 640) {                                 \
+            dhts_hyb_trace[st_kern_][t][tid >> 6][2 * (i)] = (int)(a_ - st_t0_);             \
+            dhts_hyb_trace[st_kern_][t][tid >> 6][2 * (i) + 1] = (int)(st_last_ - st_t0_);   \
+        }                                                                                   \
     }
 // a point inside a phase: the time since the last stamp goes to work slot 4 + i (slots 4..7 are free in the forward kernel) and
 // is NOT counted in the phase's own work slot
@@ -82,6 +90,13 @@ __device__ long long dhts_hyb_stamps[2][8][16][24];
         st_acc_[4 + (i)] += a_ - st_last_;                                                  \
         st_last_ = a_;                                                                      \
     }
+// a second set of inner points: slots 12 + i (free in the forward kernel: it has four barriers)
+#define HYB_SUB2(i)                                                                         \
+    {                                                                                       \
+        const long long a_ = __builtin_amdgcn_s_memtime();                                  \
+        st_acc_[12 + (i)] += a_ - st_last_;                                                 \
+        st_last_ = a_;                                                                      \
+    }
 #define HYB_STAMP_WRITE(kernel_, rep_, tid_, B_)                                            \
     if ((rep_) < 8) {                                                                       \
         const int role_ = ((tid_) & 63) == 0 ? (tid_) >> 6 : -1;   /* one row per wavefront */ \
@@ -89,8 +104,10 @@ __device__ long long dhts_hyb_stamps[2][8][16][24];
     }
 #else
 #define HYB_STAMP_DECL
+#define HYB_STAMP_KERNEL(k_)
 #define HYB_BARRIER(i) lds_barrier()
 #define HYB_SUB(i)
+#define HYB_SUB2(i)
 #define HYB_STAMP_WRITE(kernel_, rep_, tid_, B_)
 #endif
 
@@ -357,7 +374,14 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                                       char *__restrict__ workspace, int records_per_step, dhts_error *err) {
     extern __shared__ double lds_d[];
     char *lds = reinterpret_cast<char *>(lds_d);
-    const int rep = blockIdx.x, tid = threadIdx.x, B = blockDim.x;
+    const int rep = blockIdx.x, B = blockDim.x;
+#ifdef DHTS_HYB_PERM
+    // experiment: which roles share a SIMD (hardware wave w runs on SIMD w % 4): the roles of two wavefronts swapped
+    const int hw_ = threadIdx.x >> 6;
+    const int tid = (((hw_ == DHTS_HYB_PERM_A) ? DHTS_HYB_PERM_B : (hw_ == DHTS_HYB_PERM_B ? DHTS_HYB_PERM_A : hw_)) << 6) | (threadIdx.x & 63);
+#else
+    const int tid = threadIdx.x;
+#endif
     const int NI = C + L, NIp = hyb_tape_ifaces(L, C);
     const HybWs ws = hyb_ws(L, C, T, tb.n_routes, records_per_step);
     const int V = ws.V;
@@ -852,7 +876,9 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     if (in_mw) {
         // the step is this wavefront's instruction stream (it is the last to arrive in three of the four phases): it goes first
         // wherever it shares its SIMD's issue slots (forward 3.44 -> 3.25 ms at config 4)
+#ifndef DHTS_HYB_NOPRIO
         __builtin_amdgcn_s_setprio(1);
+#endif
         for (int t = 0; t < T; ++t) {
             constexpr bool kMw = true;
 #include "hybrid_fwd_step.inc"
@@ -1173,6 +1199,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     if (in_mw) fetch_offsets(T - 1);
     fetch(T - 1);
     HYB_STAMP_DECL
+    HYB_STAMP_KERNEL(1)
     // (two copies of the step, by role: see the forward kernel)
     if (in_mw) {
         for (int t = T - 1; t >= 0; --t) {
@@ -1237,6 +1264,9 @@ static inline int hyb_block(const dhts_net_desc *d) {
 }
 
 #ifdef DHTS_HYB_STAMPS
+extern "C" int dhts_debug_trace(int *out) {       // [2 kernels][640 steps][16 waves][5 barriers x (arrival, release)] of replica 0
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dhts::dhts_hyb_trace), sizeof(int) * 2 * 640 * 16 * 10) == hipSuccess ? 0 : -1;
+}
 extern "C" int dhts_debug_stamps(long long *out) {       // [2 kernels][8 replicas][16 waves][24]: work 0..7, drain 8..15, barrier 16..23
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(dhts::dhts_hyb_stamps), sizeof(long long) * 2 * 8 * 16 * 24) == hipSuccess ? 0 : -1;
 }

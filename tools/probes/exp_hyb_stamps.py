@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "diff-hybrid-traffic-sim_amd"))
 sys.path.insert(0, ROOT)
 from dhts import _lib  # noqa: E402
-_lib.SO_PATH = os.path.join(ROOT, "diff-hybrid-traffic-sim_amd", "csrc", "libdhts_stamps.so")
+if not os.environ.get("DHTS_LIB"):
+    _lib.SO_PATH = os.path.join(ROOT, "diff-hybrid-traffic-sim_amd", "csrc", "variants", "libdhts_hstamps.so")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -41,5 +42,7 @@ for kern, name, nb in ((0, "forward", 4), (1, "reverse", 5)):
         nm = "wave %d%s" % (wave, " (flush)" if wave == 6 else (" (micro)" if wave == 7 else ""))
         print("  %-14s work %s   drain %s   barrier %s   total %d" % (nm, np.round(m[wave, :nb]).astype(int), np.round(m[wave, 8:8 + nb]).astype(int),
                                                                        np.round(m[wave, 16:16 + nb]).astype(int), int(m[wave].sum())))
+        if kern == 0 and m[wave, 12:16].any():    # HYB_SUB2: cell waves, phase D = loss constants + history row | lane sums | (rest: flush)
+            print("  %-14s  sub2 %s" % ("", np.round(m[wave, 12:16]).astype(int)))
         if kern == 0 and m[wave, 4:8].any():      # sub-phase stamps (HYB_SUB): cell waves = table fetch, ghosts, loss scan (phase A), interface
             print("  %-14s   sub %s" % ("", np.round(m[wave, 4:8]).astype(int)))     # solves (B); micro wave = capacitors, pre-screen, commits (D)
