@@ -41,7 +41,7 @@ __host__ __device__ inline int hyb_ghost_base1(int L, int B) {
 }
 constexpr int kMaxMicro = 64;        // micro lanes per network: lane j of the micro wave owns micro lane j
 constexpr int kMaxCaps = 16;         // macro lanes with a micro successor
-constexpr int kLaneCap = 16;         // vehicles per micro lane
+constexpr int kLaneCap = 16;         // vehicles per micro lane unless the tables ask for more (dhts_hybrid_tables::lane_capacity: 32, 64, 128)
 constexpr int kMaxVeh = 128;         // vehicles per replica and episode
 constexpr int kRouteStride = 32;     // MAX_ROUTE_LENGTH, road_network.py:17
 constexpr int kLaneLocals = 192;     // temporaries per lane of the micro wave and step
@@ -118,6 +118,7 @@ struct HybTables {
     NetTables net;
     const int32_t *lane_macro; const double *lane_len; const int32_t *conv_next; const int32_t *routes; const int32_t *route_ptr;
     int n_routes, route_stride, loss_steps, n_micro;
+    int lane_sh;                             // log2 of the vehicles a micro lane holds (4 .. 7)
     const int32_t *lane_source; const double *draws; int n_draws; size_t draws_stride;     // micro source lanes (itscp `micro` mode)
     // a plain RoadNetwork with given initial state and final-state taps (dhts_net_hybrid_state_rollout_*, include/dhts.h)
     int plain;
@@ -299,9 +300,9 @@ __device__ __forceinline__ float stream_load(const float *p) {
 struct HybLds {
     size_t fq, scanw, incl, vsp, vep, s0, s1, g, contrib, ql, sig, lanelen, vp, vv, va, vxold, hdpv, hdvv, capv, qmicro, tailsp,
         cell_lane, iface_lane, cnext, vidp, vidv, vida, vcur, vrlen, vroute, lane_n, lane_veh, hdpi, hdvi, vcp, capi, mslot,
-        capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, stg_k, stg_i, stg_w, cnt_s, lfl, vx, lane_new, total;
+        capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, stg_k, stg_i, stg_w, cnt_s, lfl, vx, lane_new, vdsg, total;
 };
-__host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS, int stage_h) {
+__host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS, int stage_h, int lane_sh) {
     HybLds o; size_t p = 0; const int NI = C + L;
     auto D = [&](size_t n) { size_t r = p; p += 8 * ((n + 1) & ~(size_t)1); return r; };
     auto F = [&](size_t n) { size_t r = p; p += 4 * ((n + 3) & ~(size_t)3); return r; };
@@ -310,13 +311,13 @@ __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS, i
     o.sig = F(2 * (size_t)sq); o.lanelen = F(L); o.vp = F(V); o.vv = F(V); o.va = F(V); o.vxold = F(V);
     o.hdpv = F(kMaxMicro); o.hdvv = F(kMaxMicro); o.capv = F(kMaxCaps); o.qmicro = F(2 * kMaxMicro); o.tailsp = F(kMaxMicro);
     o.cnext = F(L); o.vidp = F(V); o.vidv = F(V); o.vida = F(V); o.vcur = F(V);
-    o.vrlen = F(V); o.vroute = F((size_t)V * kRouteStride); o.lane_n = F(kMaxMicro); o.lane_veh = F(kMaxMicro * kLaneCap);
+    o.vrlen = F(V); o.vroute = F((size_t)V * kRouteStride); o.lane_n = F(kMaxMicro); o.lane_veh = F((size_t)NS << lane_sh);
     o.hdpi = F(kMaxMicro); o.hdvi = F(kMaxMicro); o.vcp = F(2 * (kMaxMicro + 1)); o.capi = F(kMaxCaps); o.mslot = F(L); o.capof = F(L);
     o.mlane = F(kMaxMicro); o.cbefore = F(kMaxMicro + 1); o.convlist = F(L); o.linfo = F(L); o.caplast = F(kMaxCaps); o.rused = F(kMaxMicro); o.caplane = F(kMaxCaps); o.capleaf = F(kMaxCaps);
     o.stg_k = F((size_t)NS * 2 * stage_h); o.stg_i = F((size_t)NS * 2 * stage_h * 4); o.stg_w = F((size_t)NS * 2 * stage_h * 4);
     // the cell -> lane and interface -> lane maps exist during set-up only: they lie on the (then still empty) staging area
     o.cell_lane = o.stg_i; o.iface_lane = o.stg_i + 4 * (((size_t)C + 3) & ~(size_t)3);
-    o.cnt_s = F(2 * kPhases * 64); o.lfl = F(L); o.vx = F(V); o.lane_new = F(kMaxMicro);
+    o.cnt_s = F(2 * kPhases * 64); o.lfl = F(L); o.vx = F(V); o.lane_new = F(kMaxMicro); o.vdsg = F(V);
     o.total = p;
     return o;
 }
@@ -326,13 +327,16 @@ __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS, i
 __host__ __device__ inline int hyb_tape_ifaces(int L, int C) { return (C + L + 63) & ~63; }
 
 // records a lane of the micro wave can stage per step: what the LDS has room for beside everything else (0 = does not fit)
-__host__ __device__ inline int hyb_stage_h(int L, int C, int sq, int V, int NS, int n_action) {
+__host__ __device__ inline int hyb_stage_h(int L, int C, int sq, int V, int NS, int n_action, int lane_sh) {
     const size_t act = up16(sizeof(float) * (size_t)n_action), budget = 160 * 1024;
-    const size_t fixed = hyb_lds(L, C, sq, V, NS, 0).total + act;
+    const size_t fixed = hyb_lds(L, C, sq, V, NS, 0, lane_sh).total + act;
     if (fixed + 64 >= budget) return 0;
     int h = (int)((budget - fixed - 64) / ((size_t)NS * 2 * 36));
-    if (h > kStageH) h = kStageH;
-    while (h > 0 && hyb_lds(L, C, sq, V, NS, h).total + act > budget) --h;
+    // (a lane stages one IDM record and one loss seed per vehicle and step beside its head gap's ~15: lanes that hold more than 16
+    // vehicles get room for that, as far as the LDS goes)
+    const int hcap = lane_sh > 4 ? (2 << lane_sh) + 32 : kStageH;
+    if (h > hcap) h = hcap;
+    while (h > 0 && hyb_lds(L, C, sq, V, NS, h, lane_sh).total + act > budget) --h;
     // (the set-up maps lie on the staging area's index block)
     if ((size_t)NS * 2 * h * 16 < 4 * ((((size_t)C + 3) & ~(size_t)3) + (((size_t)C + L + 3) & ~(size_t)3))) return 0;
     return h;
@@ -386,8 +390,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     const HybWs ws = hyb_ws(L, C, T, tb.n_routes, records_per_step);
     const int V = ws.V;
     const int NS = tb.n_micro > kMaxCaps ? tb.n_micro : kMaxCaps;      // lanes of the micro wave that stage records
-    const int stage_h = hyb_stage_h(L, C, sq, V, NS, n_action);
-    const HybLds lo = hyb_lds(L, C, sq, V, NS, stage_h);
+    const int lane_sh = tb.lane_sh;                                   // a micro lane's vehicle list: lane_veh[(k << lane_sh) + i]
+    const int lane_cap = 1 << lane_sh;
+    const int stage_h = hyb_stage_h(L, C, sq, V, NS, n_action, lane_sh);
+    const HybLds lo = hyb_lds(L, C, sq, V, NS, stage_h, lane_sh);
     double *Fq = reinterpret_cast<double *>(lds + lo.fq), *scanw = reinterpret_cast<double *>(lds + lo.scanw);
     double *incl = reinterpret_cast<double *>(lds + lo.incl), *vsp = reinterpret_cast<double *>(lds + lo.vsp), *vep = reinterpret_cast<double *>(lds + lo.vep);
 #define LF(name) reinterpret_cast<float *>(lds + lo.name)
@@ -400,6 +406,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     int *vcur = LI(vcur), *vrlen = LI(vrlen), *vroute = LI(vroute), *lane_n = LI(lane_n), *lane_veh = LI(lane_veh), *hdpi = LI(hdpi), *hdvi = LI(hdvi);
     int *vcp = LI(vcp), *capi = LI(capi), *mslot = LI(mslot), *capof = LI(capof), *mlane = LI(mlane), *cbefore = LI(cbefore), *convlist = LI(convlist), *linfo = LI(linfo), *caplast = LI(caplast), *rused = LI(rused), *caplane = LI(caplane), *capleaf = LI(capleaf);
     int *stg_k = LI(stg_k), *stg_i = LI(stg_i); float *stg_w = LF(stg_w);
+    float *vdsg = LF(vdsg);                        // per vehicle: the derivative of its loss term's sigmoid (flush wave, between its two loops)
     float *vx = LF(vx);                            // per vehicle: static_speed - speed of the state the last step left (loss sample)
     int *lfl = LI(lfl);                            // per lane: first cell | last cell << 16
     int *cnt_s = LI(cnt_s);                        // [2 blocks][kPhases][64 lanes] staged record counts, micro wave -> flush wave
@@ -560,13 +567,13 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         const int nw = k < n_micro ? lane_new[k] : 0;  // (a vehicle admitted at this step's boundary sits at the tail: not part of the last state)
         const int c = k < n_micro ? lane_n[k] - nw : 0;
         if (kHard) {                                   // is_static of every vehicle: 1.0 if speed < static_speed else 0.0
-            for (int i = 0; i < c; ++i) { const int vi = lane_veh[k * kLaneCap + nw + i]; vx[vi] = vv[vi] < s0f ? 1.f : 0.f; }
+            for (int i = 0; i < c; ++i) { const int vi = lane_veh[(k << lane_sh) + nw + i]; vx[vi] = vv[vi] < s0f ? 1.f : 0.f; }
             return;
         }
         const int exc = k <= n_micro ? vcp_of(ls)[k] : 0;
         double ssum = 0., esum = 0.;
         for (int i = 0; i < c; ++i) {
-            const int vi = lane_veh[k * kLaneCap + nw + i];
+            const int vi = lane_veh[(k << lane_sh) + nw + i];
             const long long idx = run_cnt + cbefore[k] + exc + i;
             const float x = s0f - vv[vi];
             float xo = 0.f;
@@ -644,7 +651,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     auto source_admit = [&](int step) {              // micro wave, all lanes; `step` = the step whose boundary this is
         const int k = mw;
         float room = 0.f;
-        if (my_src) room = lane_n[k] ? vp[lane_veh[k * kLaneCap + 0]] - 0.5f * vlen : lanelen[mlane[k]];
+        if (my_src) room = lane_n[k] ? vp[lane_veh[(k << lane_sh) + 0]] - 0.5f * vlen : lanelen[mlane[k]];
         const bool want = my_src && room > vlen * 0.5f;
         const unsigned long long bw = __ballot(want);
         const int rank = lanes_below(bw);
@@ -655,7 +662,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         const unsigned long long ba = __ballot(admit);
         if (admit) {
             const int vi = spawned + lanes_below(ba);
-            if (vi >= V || lane_n[k] >= kLaneCap) cap_fault = true;
+            if (vi >= V || lane_n[k] >= lane_cap) cap_fault = true;
             else {
                 const size_t row = (size_t)(my_rlo + rused[k]);
                 ++rused[k];
@@ -670,8 +677,8 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     if (lid >= 0 && rl_ == q) rl_ = q + 1;
                 }
                 vrlen[vi] = rl_;
-                for (int q = lane_n[k]; q > 0; --q) lane_veh[k * kLaneCap + q] = lane_veh[k * kLaneCap + q - 1];
-                lane_veh[k * kLaneCap + 0] = vi;
+                for (int q = lane_n[k]; q > 0; --q) lane_veh[(k << lane_sh) + q] = lane_veh[(k << lane_sh) + q - 1];
+                lane_veh[(k << lane_sh) + 0] = vi;
                 ++lane_n[k];
             }
         }
@@ -791,7 +798,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 qm[k] = 0.f;                                    //  beside the vehicles' terms of loss ls + 1)
                 const int nw = lane_new[k];
                 const int nv = lane_n[k] - nw;
-                const int *lv = lane_veh + k * kLaneCap + nw;
+                const int *lv = lane_veh + (k << lane_sh) + nw;
                 if (kHard) {
                     float q = 0.f;
                     for (int i = 0; i < nv; ++i) q = q + vx[lv[i]];
@@ -807,7 +814,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     long long n = run_cnt + cb + vcp_of(ls)[k];
                     // q = sum_i sigmoid(k_i (s0 - v_i)); term = q^2 dt; d reward / d v_i = -2 dt q * (-sigmoid'_i): one SEED
                     // record per vehicle, directly on its speed
-                    float q = 0.f, dsg[kLaneCap];
+                    float q = 0.f;
                     for (int i = 0; i < nv; ++i) {
                         const int vi = lv[i];
                         const float x = vx[vi];
@@ -818,7 +825,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                         const float z = x * kk;
                         const float zc = fminf(fmaxf(z, -16.f), 16.f);
                         const float sgm = 1.f / (1.f + expf(-zc));
-                        dsg[i] = (z < -16.f || z > 16.f) ? 0.f : sgm * (1.f - sgm) * kk;
+                        vdsg[vi] = (z < -16.f || z > 16.f) ? 0.f : sgm * (1.f - sgm) * kk;
                         q = q + sgm;
                     }
                     qm[k] = (q * q) * dtf;
@@ -829,12 +836,13 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                         int added = 0;
                         for (int i = 0; i < nv; ++i) {
                             const int vi = lv[i];
-                            if (vidv[vi] >= 0 && dsg[i] != 0.f) {
+                            const float dsg_i = vdsg[vi];
+                            if (vidv[vi] >= 0 && dsg_i != 0.f) {
                                 if (at >= stage_h) { fl_fault = true; break; }
                                 const int q_ = (k * 2 + b) * stage_h + at;
                                 stg_k[q_] = K_SEED << 24;
                                 *reinterpret_cast<int4 *>(stg_i + 4 * q_) = make_int4(vidv[vi], 0, 0, 0);
-                                *reinterpret_cast<float4 *>(stg_w + 4 * q_) = make_float4(gq * (-dsg[i]), 0.f, 0.f, 0.f);
+                                *reinterpret_cast<float4 *>(stg_w + 4 * q_) = make_float4(gq * (-dsg_i), 0.f, 0.f, 0.f);
                                 ++at; ++added;
                             }
                         }
@@ -920,7 +928,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             for (int vi = mw; vi < n_sp; vi += 64) { vo[4 * vi] = -1.f; vo[4 * vi + 1] = vp[vi]; vo[4 * vi + 2] = vv[vi]; vo[4 * vi + 3] = va[vi]; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            if (mw < n_micro) for (int i = 0; i < lane_n[mw]; ++i) vo[4 * lane_veh[mw * kLaneCap + i]] = (float)mlane[mw];
+            if (mw < n_micro) for (int i = 0; i < lane_n[mw]; ++i) vo[4 * lane_veh[(mw << lane_sh) + i]] = (float)mlane[mw];
         }
     }
     if (is_lane) ql[tid] = lane_total;
@@ -1240,7 +1248,11 @@ static inline bool hyb_tables_ok(const dhts_hybrid_tables *t) {
            n->right_src && n->schedule && n->replica_stride >= 0 && n->nxt_ptr && n->nxt_idx && n->prv_ptr && n->prv_idx &&
            n->n_edges >= 0 && t->lane_macro && t->lane_len && t->conv_next && t->routes && t->route_ptr && t->n_routes > 0 &&
            t->route_stride > 0 && t->route_stride <= kRouteStride && t->n_micro >= 0 && t->n_micro <= kMaxMicro &&
+           (t->lane_capacity == 0 || t->lane_capacity == 16 || t->lane_capacity == 32 || t->lane_capacity == 64 || t->lane_capacity == 128) &&
            (t->lane_source == nullptr || (t->draws != nullptr && t->n_draws > 0 && t->draws_stride >= 0));
+}
+static inline int hyb_lane_sh(const dhts_hybrid_tables *t) {       // log2(lane_capacity): 16 (default), 32, 64 or 128 vehicles per micro lane
+    return t->lane_capacity >= 128 ? 7 : (t->lane_capacity >= 64 ? 6 : (t->lane_capacity >= 32 ? 5 : 4));
 }
 static inline HybTables hyb_tables(const dhts_hybrid_tables *t) {
     HybTables h;
@@ -1250,7 +1262,7 @@ static inline HybTables hyb_tables(const dhts_hybrid_tables *t) {
     h.net.schedule = n->schedule; h.net.table_stride = (size_t)n->replica_stride;
     h.net.nxt_ptr = n->nxt_ptr; h.net.nxt_idx = n->nxt_idx; h.net.prv_ptr = n->prv_ptr; h.net.prv_idx = n->prv_idx; h.net.n_edges = n->n_edges;
     h.lane_macro = t->lane_macro; h.lane_len = t->lane_len; h.conv_next = t->conv_next; h.routes = t->routes; h.route_ptr = t->route_ptr;
-    h.n_routes = t->n_routes; h.route_stride = t->route_stride; h.loss_steps = t->loss_steps; h.n_micro = t->n_micro;
+    h.n_routes = t->n_routes; h.route_stride = t->route_stride; h.loss_steps = t->loss_steps; h.n_micro = t->n_micro; h.lane_sh = hyb_lane_sh(t);
     h.lane_source = t->lane_source; h.draws = t->draws; h.n_draws = t->n_draws; h.draws_stride = (size_t)t->draws_stride;
     h.plain = 0; h.state0 = nullptr; h.ghost0 = nullptr; h.veh_out = nullptr; h.events = nullptr;
     h.g_stateT = nullptr; h.g_veh = nullptr; h.g_state0 = nullptr;
@@ -1294,9 +1306,9 @@ static int hyb_fwd_launch(const dhts_net_desc *d, const dhts_hybrid_tables *t, c
     if (B > 1024) return DHTS_E_INVALID;
     const HybWs ws = hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step);
     const int NS = t->n_micro > kMaxCaps ? t->n_micro : kMaxCaps;
-    const int stage_h = hyb_stage_h(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, d->n_action);
+    const int stage_h = hyb_stage_h(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, d->n_action, hyb_lane_sh(t));
     if (stage_h < 8) return DHTS_E_INVALID;       // (a lane with one vehicle stages ~10 records in a step with a hand-off)
-    const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, stage_h).total + up16(sizeof(float) * (size_t)d->n_action);
+    const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, stage_h, hyb_lane_sh(t)).total + up16(sizeof(float) * (size_t)d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     // (the block-size bound sets the vector registers a thread may take: 256 / 168 / 128)
     auto kern = io ? (B <= 512 ? net_hybrid_fwd_kernel<512, false, true> : (B <= 768 ? net_hybrid_fwd_kernel<768, false, true> : net_hybrid_fwd_kernel<1024, false, true>))
@@ -1329,9 +1341,9 @@ int dhts_net_hybrid_rollout_eval(const dhts_net_desc *d, const dhts_hybrid_table
     if (B > 1024) return DHTS_E_INVALID;
     const HybWs ws = hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step);
     const int NS = t->n_micro > kMaxCaps ? t->n_micro : kMaxCaps;
-    const int stage_h = hyb_stage_h(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, d->n_action);
+    const int stage_h = hyb_stage_h(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, d->n_action, hyb_lane_sh(t));
     if (stage_h < 8) return DHTS_E_INVALID;       // (a lane with one vehicle stages ~10 records in a step with a hand-off)
-    const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, stage_h).total + up16(sizeof(float) * (size_t)d->n_action);
+    const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, stage_h, hyb_lane_sh(t)).total + up16(sizeof(float) * (size_t)d->n_action);
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     auto kern = B <= 512 ? net_hybrid_fwd_kernel<512, true> : (B <= 768 ? net_hybrid_fwd_kernel<768, true> : net_hybrid_fwd_kernel<1024, true>);
     if (lds > 64 * 1024 &&

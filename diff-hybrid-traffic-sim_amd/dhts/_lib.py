@@ -44,7 +44,8 @@ class HybridTables(C.Structure):
     _fields_ = [("net", NetTables), ("lane_macro", C.c_void_p), ("lane_len", C.c_void_p), ("conv_next", C.c_void_p),
                 ("routes", C.c_void_p), ("route_ptr", C.c_void_p), ("n_routes", C.c_int32), ("route_stride", C.c_int32),
                 ("records_per_step", C.c_int32), ("loss_steps", C.c_int32), ("n_micro", C.c_int32),
-                ("lane_source", C.c_void_p), ("draws", C.c_void_p), ("n_draws", C.c_int32), ("draws_stride", C.c_int64)]
+                ("lane_source", C.c_void_p), ("draws", C.c_void_p), ("n_draws", C.c_int32), ("draws_stride", C.c_int64),
+                ("lane_capacity", C.c_int32)]
 
 
 class HybridStateIO(C.Structure):

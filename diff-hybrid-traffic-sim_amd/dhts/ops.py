@@ -542,8 +542,11 @@ class DeviceHybridTables:
     HybridNetworkTables (shared by all replicas) or a list of them (one per replica: same topology, own inflow schedules
     and per-step macro routes)."""
 
-    def __init__(self, tables, routes, device, records_per_step=0):
+    def __init__(self, tables, routes, device, records_per_step=0, lane_capacity=0):
         import numpy as np
+        if lane_capacity not in (0, 16, 32, 64, 128):
+            raise ValueError("lane_capacity (vehicles a micro lane holds at once) must be 0 (= 16), 16, 32, 64 or 128")
+        self.lane_capacity = int(lane_capacity)
         many = isinstance(tables, (list, tuple))
         t = tables[0] if many else tables
         for i, x in enumerate(tables if many else [t]):
@@ -603,7 +606,7 @@ class DeviceHybridTables:
         k = [x.data_ptr() for x in self._keep]
         src = (k[18], k[19]) if self.has_sources else (None, None)
         return _lib.HybridTables(self.net, k[13], k[14], k[15], k[16], k[17], self.n_routes, self.route_stride, self.records_per_step,
-                                 int(loss_steps), self.n_micro, src[0], src[1], self.n_draws, self.draws_stride)
+                                 int(loss_steps), self.n_micro, src[0], src[1], self.n_draws, self.draws_stride, self.lane_capacity)
 
 
 class NetHybridRollout(torch.autograd.Function):

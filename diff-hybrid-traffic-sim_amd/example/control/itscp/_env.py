@@ -273,6 +273,7 @@ class ItscpEnv:
         if any(sl.is_micro() and sl.num_vehicle() for sl in sim.lane.values()):
             return None
         cache = getattr(self, "_fused_cache", None)
+        lane_cap = getattr(self, "_fused_lane_capacity", 0)     # vehicles a micro lane holds (0 = the kernels' default 16)
         if cache is None:
             try:
                 T = self.num_timestep
@@ -293,7 +294,8 @@ class ItscpEnv:
                     # episode that admits more comes back as ops.CapacityError below)
                     self._fused_n_draws = T * max(1, int(tab.lane_source.sum()))
                     tab.set_micro_sources(np.full(self._fused_n_draws, 2.0))
-                    cache = ("micro", ops.DeviceHybridTables(tab, np.asarray(rows if rows else [[-1, -1]], dtype=np.int32), action.device))
+                    cache = ("micro", ops.DeviceHybridTables(tab, np.asarray(rows if rows else [[-1, -1]], dtype=np.int32), action.device,
+                                                             lane_capacity=lane_cap))
                 else:
                     tab = HybridNetworkTables.from_env(self)
                     routes = getattr(self, "fused_routes", None)
@@ -306,7 +308,7 @@ class ItscpEnv:
                                     routes.append(r + [-1] * (32 - len(r)))
                         if not routes:
                             routes = [[-1, -1]]
-                    cache = ("hybrid", ops.DeviceHybridTables(tab, np.asarray(routes, dtype=np.int32), action.device))
+                    cache = ("hybrid", ops.DeviceHybridTables(tab, np.asarray(routes, dtype=np.int32), action.device, lane_capacity=lane_cap))
             except ValueError:
                 cache = ("none", None)
             self._fused_cache = cache
@@ -319,7 +321,10 @@ class ItscpEnv:
         a = action.reshape(1, -1)
         if kind == "micro":
             draws = getattr(self, "fused_draws", None)
-            if draws is None:
+            pending = self.__dict__.pop("_fused_pending_draws", None)
+            if pending is not None:
+                draws = pending
+            elif draws is None:
                 draws = np.random.random(self._fused_n_draws)
             else:
                 draws = np.concatenate([np.asarray(draws, dtype=np.float64), np.full(self._fused_n_draws, 2.0)])[:self._fused_n_draws]
@@ -334,6 +339,16 @@ class ItscpEnv:
                 reward, queue, counts = ops.net_hybrid_eval(a, tab, *args)
                 self.fused_counts = counts[0].tolist()
         except ops.CapacityError as e:
+            # First the same episode with room for more vehicles per micro lane (a per-launch LDS sizing, include/dhts.h:
+            # dhts_hybrid_tables::lane_capacity; 16 -> 128 at most, config "fused_max_lane_capacity"): nothing on the host was
+            # touched by the attempt, the tables are rebuilt once and kept.
+            nxt_cap = 128
+            if kind in ("micro", "hybrid") and lane_cap < nxt_cap <= int(self.config.get("fused_max_lane_capacity", 128)):
+                self._fused_lane_capacity = nxt_cap
+                self._fused_cache = None
+                if kind == "micro":
+                    self._fused_pending_draws = draws          # the retry is the same episode: the same admission draws
+                return self._step_fused(action, differentiable)
             # The reference has no such limits (_micro_lane.py:53-113): this episode runs lane by lane instead (minutes, not
             # milliseconds).  Nothing on the host was touched by the attempt; in `micro` mode the admission draws the kernels were
             # given are replayed, so that the episode is the one that was asked for.

@@ -330,8 +330,8 @@ int dhts_net_macro_rollout_bwd(const dhts_net_desc *d, const dhts_net_tables *t,
  *   route_ptr[m] .. route_ptr[m+1] start on micro lane m): the k-th vehicle spawned onto lane m takes row
  *   route_ptr[m] + k mod (rows of m).  The reference draws a route with np.random at spawn time (road_network.py:604-646);
  *   callers pre-draw them (dhts/network.py: group_routes keeps a recorded spawn order intact).
- * Limits: n_cells + n_lanes <= 960 (n_cells = 0 is allowed: an all-micro network), <= 64 micro lanes, <= 16 spawning lanes, <= 16 vehicles per micro lane, <= 48 tape
- * records per micro lane and step -- fewer when more than ~20 micro lanes share the workgroup's LDS staging, e.g. 18 at 64
+ * Limits: n_cells + n_lanes <= 960 (n_cells = 0 is allowed: an all-micro network), <= 64 micro lanes, <= 16 spawning lanes, <= lane_capacity vehicles per micro lane (16 unless asked for: below), <= 48 tape
+ * records per micro lane and step (2 lane_capacity + 32 with a larger lane_capacity) -- fewer when more than ~20 micro lanes share the workgroup's LDS staging, e.g. 18 at 64
  * micro lanes beside 288 cells; a lane with k vehicles stages ~8 + 2 k (DHTS_FAULT_CAPACITY beyond), <= 128 vehicles per replica and episode, route_stride <= 32; records_per_step (average budget of the record stream,
  * 0 = 512).  loss_steps: only the first loss_steps steps enter reward_cut and the gradient (<= 0: all).
  */
@@ -356,6 +356,11 @@ typedef struct dhts_hybrid_tables {
     const double *draws;
     int32_t n_draws;
     int64_t draws_stride;
+    /* vehicles a micro lane holds at once: 0 (= 16), 16, 32, 64 or 128.  A per-launch LDS sizing like n_micro (4 bytes per slot and
+     * micro lane, plus staging for one IDM record and one loss seed per vehicle and step, as far as the 160 KB go): the reference's
+     * lanes are unbounded (_micro_lane.py:53-113), an episode that needs more than the launch was sized for ends in
+     * DHTS_FAULT_CAPACITY and the caller retries with a larger value (ItscpEnv.step does) or runs lane by lane. */
+    int32_t lane_capacity;
 } dhts_hybrid_tables;
 size_t dhts_net_hybrid_workspace_bytes(const dhts_net_desc *d, const dhts_hybrid_tables *t);
 /* bytes of the hybrid kernels' Jacobian tape: float32 [R][T][NIp][2][4], NIp = n_cells + n_lanes rounded up to 64: per interface

@@ -12,12 +12,12 @@ from util import TOL_GRAD, TOL_STATE, grad_report, rel_elem, rel_max, state_repo
 pytestmark = pytest.mark.gpu
 
 
-def _run(cuda, g, loss_steps=0, replicas=1, want_grad=True, action=None):
+def _run(cuda, g, loss_steps=0, replicas=1, want_grad=True, action=None, lane_capacity=0):
     import torch
     from dhts import ops
     t, m = itscp_hybrid_tables(g)
     routes = g["spawn_routes"] if g["spawn_routes"].shape[0] else -np.ones((1, 2), np.int32)
-    dt_ = ops.DeviceHybridTables(t, routes, cuda)
+    dt_ = ops.DeviceHybridTables(t, routes, cuda, lane_capacity=lane_capacity)
     a0 = g["action"] if action is None else action
     a = torch.tensor(np.tile(a0[None, :], (replicas, 1)), device=cuda, requires_grad=want_grad)
     cut, reward, queue, counts = ops.net_hybrid_rollout(a, dt_, m["num_intersection"] ** 2,
@@ -55,6 +55,22 @@ def test_hybrid_short_matches_reference(cuda, golden_dir, name):
         assert abs(float(o["reward"][r]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
         assert np.abs(o["grad"][r] - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()
     assert np.array_equal(o["grad"][0], o["grad"][1]) and np.array_equal(o["queue"][0], o["queue"][2])   # repeatable
+
+
+@pytest.mark.parametrize("cap", [16, 32, 64, 128])
+def test_lane_capacity_is_a_launch_size_not_a_result(cuda, golden_dir, cap):
+    """dhts_hybrid_tables::lane_capacity only sizes the LDS (vehicle lists per micro lane, record staging): an episode that fits
+    the default 16 gives bit-identical numbers at every other size; an invalid size is refused."""
+    import torch
+    from dhts import ops
+    g = np.load(os.path.join(golden_dir, "itscp_hybrid_p2.npz"))
+    ref = _run(cuda, g)
+    o = _run(cuda, g, lane_capacity=cap)
+    assert np.array_equal(o["counts"], ref["counts"]) and np.array_equal(o["queue"], ref["queue"])
+    assert np.array_equal(o["reward"], ref["reward"]) and np.array_equal(o["grad"], ref["grad"])
+    with pytest.raises(ValueError):
+        t, _ = itscp_hybrid_tables(g)
+        ops.DeviceHybridTables(t, g["spawn_routes"], cuda, lane_capacity=48)
 
 
 def test_hybrid_600_steps_matches_reference(cuda, golden_dir):

@@ -256,22 +256,31 @@ def test_env_micro_mode_step_uses_fused_kernels(cuda, golden_dir, name):
     assert np.abs(action.grad.cpu().numpy() - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()
 
 
-def test_env_step_falls_back_when_a_fused_capacity_is_exceeded(cuda):
-    """The fused kernels hold at most 16 vehicles per IDM lane (include/dhts.h); the reference has no such limit
-    (_micro_lane.py:53-113).  A `micro`-mode episode with 150 m approach lanes, a light that is red nine tenths of the time for
-    two of them and an admission at every opportunity puts more than 16 vehicles on those lanes: the fused attempt reports
-    DHTS_FAULT_CAPACITY, ItscpEnv.step warns once and runs the episode lane by lane with the same admission draws."""
-    import warnings
-    import torch
+def _crowded_micro_env(max_lane_capacity):
+    """`micro`-mode episode with 150 m approach lanes, a light that is red nine tenths of the time for two of them and an
+    admission at every opportunity: more than 16 vehicles stand on those lanes."""
     from example.control.itscp._env import ItscpEnv
     env = ItscpEnv()
     env.schedule_callback = lambda keys, T: {k: [1.0] * T for k in keys}            # inflow 1 everywhere: every draw admits
     for k, v in dict(num_intersection=1, num_lane=1, lane_length=150.0, policy_length=16, signal_length=2, mode="micro",
-                     speed_limit=60.0, max_num_micro_vehicle_per_lane=30, random_seed=3).items():
+                     speed_limit=60.0, max_num_micro_vehicle_per_lane=30, random_seed=3,
+                     fused_max_lane_capacity=max_lane_capacity).items():
         env.config[k] = v
     env.reset()
+    env.fused_draws = np.zeros(env.num_timestep * 8)
+    return env
+
+
+def test_env_step_falls_back_when_a_fused_capacity_is_exceeded(cuda):
+    """The fused kernels hold 16 vehicles per IDM lane unless a launch is sized for more (include/dhts.h: lane_capacity); the
+    reference has no such limit (_micro_lane.py:53-113).  With the retry switched off (fused_max_lane_capacity = 16) the fused
+    attempt of a crowded episode reports DHTS_FAULT_CAPACITY, ItscpEnv.step warns once and runs the episode lane by lane with
+    the same admission draws.  With it (the default) the episode is retried with room for 128 vehicles per lane and stays on the
+    fused kernels: same reward, same gradient."""
+    import warnings
+    import torch
+    env = _crowded_micro_env(16)
     T = env.num_timestep
-    env.fused_draws = np.zeros(T * 8)
     action = torch.full((env.action_size(),), 0.1, device=cuda, requires_grad=True)   # west-east green for a tenth of each phase
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
@@ -282,7 +291,23 @@ def test_env_step_falls_back_when_a_fused_capacity_is_exceeded(cuda):
     keys = list(env.lane.keys())
     assert all(len(env.queue_length[k]) == T for k in keys)                             # the whole episode ran, lane by lane
     most = max(env.lane[k].sim_lane.num_vehicle() for k in keys)
-    assert most > 16, most                                                              # ... past what the kernels hold
+    assert most > 16, most                                                              # ... past what the default launch holds
     assert torch.isfinite(reward.detach()).all()
     reward.backward()
     assert bool(torch.isfinite(action.grad).all()) and float(action.grad.abs().max()) > 0.0
+    # the same episode with the retry: one failed launch at 16 vehicles per lane, then the fused kernels sized for 128
+    env2 = _crowded_micro_env(128)
+    action2 = torch.full((env2.action_size(),), 0.1, device=cuda, requires_grad=True)
+    with warnings.catch_warnings(record=True) as w2:
+        warnings.simplefilter("always")
+        _, reward2, _, _ = env2.step(action2, True)
+    assert env2._fused_done and env2._fused_lane_capacity == 128 and not getattr(env2, "fused_overflowed", False)
+    assert not any("capacity" in str(x.message) for x in w2)
+    reward2.backward()
+    q1 = np.array([[float(x) for x in env.queue_length[k]] for k in keys])
+    q2 = np.array([[float(x) for x in env2.queue_length[k]] for k in keys])
+    # (1e-4: `micro` mode -- the lane-by-lane path steps these lanes in float32 tensor arithmetic)
+    assert state_report("crowded micro episode, fused at 128 per lane vs lane by lane: queues", q2, q1) <= 1e-4
+    assert abs(float(reward2.detach()) - float(reward.detach())) <= 1e-4 * abs(float(reward.detach()))
+    g1, g2 = action.grad.cpu().numpy(), action2.grad.cpu().numpy()
+    assert np.abs(g2 - g1).max() <= TOL_GRAD * np.abs(g1).max()
