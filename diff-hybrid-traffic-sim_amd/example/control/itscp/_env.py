@@ -280,6 +280,11 @@ class ItscpEnv:
                 n_cells = sum(getattr(sl, "num_cell", 0) for sl in sim.lane.values() if sl.is_macro())
                 if self.config["mode"] == "macro" and n_cells + len(sim.lane) <= 1024:
                     cache = ("macro", ops.DeviceNetTables(MacroNetworkTables.from_env(self), action.device))
+                elif self.config["mode"] == "macro":
+                    # more cells + lanes than one workgroup holds (e.g. --n_intersection=3 --n_lane=3: 360 lanes, ~2 100 cells): all
+                    # lanes as the batch of the straight-lane step operator, one call per step (dhts/batched.py)
+                    from dhts.batched import BatchedMacroNetwork
+                    cache = ("batched", BatchedMacroNetwork(MacroNetworkTables.from_env(self), action.device))
                 elif self.config["mode"] == "micro":
                     # every lane an IDM lane; source lanes admit their waiting vehicles against np.random draws
                     # (_simulator.py:153-174): the waiting routes in admission order (the list is popped from its end) are
@@ -330,7 +335,10 @@ class ItscpEnv:
                 draws = np.concatenate([np.asarray(draws, dtype=np.float64), np.full(self._fused_n_draws, 2.0)])[:self._fused_n_draws]
             tab.set_draws(draws)
         try:
-            if kind == "macro":
+            if kind == "batched":
+                reward, queue = tab.rollout(a[0], *args, differentiable=differentiable)
+                reward, queue = reward.reshape(1), queue.unsqueeze(0)
+            elif kind == "macro":
                 reward, queue = ops.net_macro_rollout(a, tab, *args) if differentiable else ops.net_macro_eval(a, tab, *args)
             elif differentiable:
                 reward, _, queue, counts = ops.net_hybrid_rollout(a, tab, *args)

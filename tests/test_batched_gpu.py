@@ -1,0 +1,94 @@
+"""Macro networks of any size through the batched-lane path (dhts/batched.py: all lanes of the network as the batch of the
+straight-lane step operator, one call per step): the reference's own itscp runs (G8), and a network that does not fit the fused
+kernels' one workgroup (3 x 3 intersections with 3 lanes per approach: 360 lanes) against the CPU oracle."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from test_oracle_golden import itscp_tables
+from util import TOL_GRAD, TOL_STATE, grad_report, rel_max, state_report
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(m):
+    return (m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"],
+            m["speed_limit"], m["static_speed"], m["vehicle_length"])
+
+
+@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "macro_half", "macro_long"])
+def test_batched_network_vs_reference(cuda, golden_dir, name):
+    import torch
+    from dhts import ops
+    from dhts.batched import BatchedMacroNetwork
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    tab, m = itscp_tables(g)
+    net = BatchedMacroNetwork(tab, cuda)
+    action = torch.tensor(g["action"], device=cuda, requires_grad=True)
+    reward, queue = net.rollout(action, *_args(m))
+    reward.backward()
+    assert state_report("batched %s: queues vs reference" % name, queue.detach().cpu().numpy().T, g["queue"]) <= TOL_STATE
+    assert abs(float(reward) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+    assert grad_report("batched %s d reward / d action" % name, action.grad.cpu().numpy(), g["g_action"]) <= TOL_GRAD
+    # and the fused one-workgroup kernels give the same episode
+    a2 = torch.tensor(g["action"][None], device=cuda, requires_grad=True)
+    r2, q2 = ops.net_macro_rollout(a2, ops.DeviceNetTables(tab, cuda), *_args(m))
+    assert rel_max(queue.detach().cpu().numpy(), q2[0].detach().cpu().numpy()) <= TOL_STATE
+
+
+@pytest.mark.parametrize("name", ["eval_macro", "eval_macro_2x2"])
+def test_batched_network_evaluation_episode_vs_reference(cuda, golden_dir, name):
+    import torch
+    from dhts.batched import BatchedMacroNetwork
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    tab, m = itscp_tables(g)
+    with torch.no_grad():
+        reward, queue = BatchedMacroNetwork(tab, cuda).rollout(torch.tensor(g["action"], device=cuda), *_args(m), differentiable=False)
+    assert state_report("batched %s: queues vs reference" % name, queue.cpu().numpy().T, g["queue"]) <= TOL_STATE
+    assert abs(float(reward) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+
+
+def test_env_step_runs_a_network_beyond_one_workgroup_batched(cuda, oracle):
+    """run_itscp_macro.sh with --n_intersection=3 --n_lane=3 (reference _env.py:221-439): 360 lanes, > 1 024 cells + lanes.
+    ItscpEnv.step takes the batched path (no lane-by-lane stepping) and its reward, queue terms and d reward / d action are the
+    oracle's for the same tables."""
+    import torch
+    from dhts.network import MacroNetworkTables
+    from example.control.itscp._env import ItscpEnv
+    env = ItscpEnv()
+    for k, v in dict(num_intersection=3, num_lane=3, mode="macro", random_seed=5).items():
+        env.config[k] = v
+    env.reset()
+    tab = MacroNetworkTables.from_env(env)
+    assert tab.n_cells + tab.n_lanes > 1024 and tab.n_lanes == 360
+    rng = np.random.default_rng(2)
+    act = rng.uniform(0.2, 0.8, env.action_size()).astype(np.float32)
+    action = torch.tensor(act, device=cuda, requires_grad=True)
+    t0 = time.time()
+    obs, reward, done, info = env.step(action, True)
+    reward.backward()
+    torch.cuda.synchronize()
+    t_diff = time.time() - t0
+    assert env._fused_cache[0] == "batched" and env._fused_done
+    sq, F = env.num_intersection ** 2, env.config["signal_length"] * env.config["simulation_frequency"]
+    o = oracle.net_macro(tab, act, sq, F, 1.0 / env.config["simulation_frequency"], env.simulator.speed_limit,
+                         env.config["static_speed"], env.simulator.vehicle_length)
+    assert o["rc"] == 0
+    keys = list(env.lane.keys())
+    queue = np.array([env.queue_length[k] for k in keys])            # [L][T]
+    assert state_report("360-lane network, batched vs oracle: queues", queue.T, o["queue"]) <= TOL_STATE
+    assert abs(float(reward.detach()) - o["reward"]) <= 1e-5 * abs(o["reward"])
+    assert grad_report("360-lane network d reward / d action", action.grad.cpu().numpy(), o["g_action"]) <= TOL_GRAD
+    env.reset()
+    with torch.no_grad():
+        t0 = time.time()
+        _, reward_e, _, _ = env.step(torch.tensor(act, device=cuda), False)
+        torch.cuda.synchronize()
+        t_eval = time.time() - t0
+    oe = oracle.net_macro(tab, act, sq, F, 1.0 / env.config["simulation_frequency"], env.simulator.speed_limit,
+                          env.config["static_speed"], env.simulator.vehicle_length, hard=True)
+    assert abs(float(reward_e) - oe["reward"]) <= 1e-5 * abs(oe["reward"])
+    print("360 lanes, %d cells, %d steps: differentiable episode (forward + backward) %.2f s, evaluation episode %.2f s on the batched path"
+          % (tab.n_cells, tab.T, t_diff, t_eval))
