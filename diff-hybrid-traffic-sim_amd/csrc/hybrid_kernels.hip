@@ -41,7 +41,7 @@ __host__ __device__ inline int hyb_ghost_base1(int L, int B) {
 }
 constexpr int kMaxMicro = 64;        // micro lanes per network: lane j of the micro wave owns micro lane j
 constexpr int kMaxCaps = 16;         // macro lanes with a micro successor
-constexpr int kLaneCap = 16;         // vehicles per micro lane unless the tables ask for more (dhts_hybrid_tables::lane_capacity: 32, 64, 128)
+// (vehicles per micro lane: 16 unless the tables ask for more -- dhts_hybrid_tables::lane_capacity = 32, 64, 128 -- a per-launch LDS size)
 constexpr int kMaxVeh = 128;         // vehicles per replica and episode
 constexpr int kRouteStride = 32;     // MAX_ROUTE_LENGTH, road_network.py:17
 constexpr int kLaneLocals = 192;     // temporaries per lane of the micro wave and step
@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     const int NIm = C + n_macro;                     // interfaces that exist
     if (n_micro > kMaxMicro || n_caps > kMaxCaps || n_micro != tb.n_micro) { if (tid == 0) net_fault(err, DHTS_FAULT_CAPACITY, -1, 0, n_micro); return; }
     __syncthreads();
-    (void)NI;
+    (void)NI; (void)n_conv;          // (the hand-off walk visits candidates since round 4; convlist stays a set-up table)
     // ---- per-thread roles
     // ghost threads: the upstream ghosts of all lanes first, the downstream ones from the next wavefront boundary on, so that a
     // wavefront runs ONE of the two (quite different) blends instead of both under divergence

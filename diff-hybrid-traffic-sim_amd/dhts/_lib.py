@@ -81,6 +81,8 @@ SIGNATURES = {
     "dhts_net_macro_rollout_fwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetTables)] + [_P] * 9),
     "dhts_net_macro_rollout_eval": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetTables)] + [_P] * 5),
     "dhts_net_macro_rollout_bwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetTables)] + [_P] * 10),
+    "dhts_net_ghosts_fwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetTables), C.c_int, C.c_int] + [_P] * 7),
+    "dhts_net_ghosts_bwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetTables), _P, _P, C.c_int] + [_P] * 13),
     "dhts_net_hybrid_tape_bytes": (C.c_size_t, [C.POINTER(NetDesc)]),
     "dhts_net_hybrid_workspace_bytes": (C.c_size_t, [C.POINTER(NetDesc), C.POINTER(HybridTables)]),
     "dhts_net_hybrid_rollout_fwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(HybridTables)] + [_P] * 10),

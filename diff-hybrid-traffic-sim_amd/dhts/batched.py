@@ -5,16 +5,20 @@ builds grids of any size (example/control/itscp/_env.py:221-439: `--n_intersecti
 cells); until this round such a network ran lane by lane -- one dhts_macro_step_fwd launch plus host glue per lane and step,
 ~50 s per differentiable episode.  This module is the tier between the two: the network's lanes are the BATCH of the
 straight-lane step operator (lanes grouped by (cells, cell length); dhts_macro_step_fwd / _bwd, the same HIP kernels and tape as
-dMacroForwardLayer), the ghost exchange of a step (road_network.py:79-111, _simulator.py:42-60) is a handful of gathers and
-blends over all lanes at once in float32 like the reference's glue, and the queue loss with its RunningMean(100 000)
-(_env.py:586-618, rms.py) is evaluated for all steps at once from the state history (a prefix sum over the sample stream).
-Device tensors and autograd only; no per-lane Python, no host round trip inside the episode (faults are read once at the end).
-The tables are dhts.network.MacroNetworkTables -- the same the fused kernels take.
+dMacroForwardLayer), the ghost exchange of a step (road_network.py:79-111, _simulator.py:42-60) is one kernel over all lanes
+(dhts_net_ghosts_fwd; adjoint dhts_net_ghosts_bwd: csrc/netstep_kernels.hip, the ghost phases of the fused network kernels as
+launches of their own), and the queue loss with its RunningMean(100 000) (_env.py:586-618, rms.py) is evaluated for all steps at
+once from the state history (a prefix sum over the sample stream).  A step is ONE autograd node (`_NetStep`: three launches
+forward, five backward, state and cotangents in flat device arrays whose group blocks the operators address in place);
+`rollout_torch` is the same episode with the ghost exchange written as torch gathers and blends (the reference's glue arithmetic
+op by op; ~40 x the launches), kept as the cross-check of the kernels.  No per-lane Python, no host round trip inside the
+episode (faults are read once at the end).  The tables are dhts.network.MacroNetworkTables -- the same the fused kernels take.
 """
+import ctypes as C
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 
 WINDOW = 100_000      # RunningMean(100_000), reference _env.py:122
 
@@ -76,9 +80,97 @@ class _LaneBatchStep(torch.autograd.Function):
         return g_r, g_y, g_ghost.float(), None, None, None, None, None
 
 
+def _addr(t, off_elems=0):
+    return C.c_void_p(t.data_ptr() + 4 * int(off_elems))
+
+
+class _NetStep(torch.autograd.Function):
+    """One step of the whole network: (r, y [C]; own [L][2]; action [A]) -> (nr, ny, own', u', u_eq').  u, q [C] = u(r, y), u_eq(r)
+    as the previous step's operator left them (values; their dependence on (r, y) is inside the operator's tape and, for the edge
+    cells the ghosts read, inside dhts_net_ghosts_bwd).  Cells and lanes are in the network's GROUP-MAJOR order: a group's lanes
+    and cells are contiguous, the operators work on the flat arrays in place."""
+
+    @staticmethod
+    def forward(ctx, r, y, own, action, u, q, net, step, hard):
+        lib, st = _lib.lib(), ops._stream()
+        r, y, own, action, u, q = (x.contiguous() for x in (r, y, own, action, u, q))
+        L = net.L
+        ghost = torch.empty(L, 2, 4, dtype=torch.float32, device=r.device)
+        own_out = own.clone()           # (side-0 rows are not written)
+        _lib.check(lib.dhts_net_ghosts_fwd(C.byref(net.desc), C.byref(net.dtab.c), int(step), int(hard), _addr(action), _addr(r), _addr(u),
+                                           _addr(own), _addr(own_out), _addr(ghost), st), "dhts_net_ghosts_fwd")
+        nr, ny, nu, nq = (torch.empty_like(r) for _ in range(4))
+        tapes = []
+        for g in net.groups:
+            tape = None if hard else torch.empty(g["tape_numel"], dtype=torch.float32, device=r.device)
+            co, lo = g["cell_off"], g["lane_off"]
+            _lib.check(lib.dhts_macro_step_fwd(C.byref(g["desc"]), _addr(r, co), _addr(y, co), _addr(u, co), _addr(q, co), _addr(ghost, 8 * lo),
+                                               _addr(nr, co), _addr(ny, co), _addr(nu, co), _addr(nq, co),
+                                               _addr(tape) if tape is not None else None, _addr(net.err), st), "dhts_macro_step_fwd")
+            tapes.append(tape)
+        ctx.net, ctx.step, ctx.tapes = net, int(step), tapes
+        ctx.save_for_backward(r, y, u, own, action, nr, ny)
+        ctx.mark_non_differentiable(nu, nq)
+        return nr, ny, own_out, nu, nq
+
+    @staticmethod
+    def backward(ctx, g_nr, g_ny, g_own, _g_nu, _g_nq):
+        net = ctx.net
+        lib, st = _lib.lib(), ops._stream()
+        r, y, u, own, action, nr, ny = ctx.saved_tensors
+        g_nr, g_ny, g_own = g_nr.contiguous(), g_ny.contiguous(), g_own.contiguous()
+        g_r, g_y = torch.empty_like(r), torch.empty_like(r)
+        g_ghost = torch.zeros(net.L, 2, 2, dtype=torch.float64, device=r.device)
+        for g, tape in zip(net.groups, ctx.tapes):
+            co, lo = g["cell_off"], g["lane_off"]
+            _lib.check(lib.dhts_macro_step_bwd(C.byref(g["desc"]), _addr(tape), _addr(g_nr, co), _addr(g_ny, co), _addr(g_r, co), _addr(g_y, co),
+                                               C.c_void_p(g_ghost.data_ptr() + 8 * 4 * lo), _addr(net.err), st), "dhts_macro_step_bwd")
+        g_own_out = torch.empty_like(own)
+        g_action = torch.zeros_like(action)
+        scratch = torch.empty(net.L, 2, 4, dtype=torch.float32, device=r.device)
+        _lib.check(lib.dhts_net_ghosts_bwd(C.byref(net.desc), C.byref(net.dtab.c), _addr(net.inter_ptr), _addr(net.inter_idx), ctx.step,
+                                           _addr(action), _addr(r), _addr(y), _addr(u), _addr(own), C.c_void_p(g_ghost.data_ptr()),
+                                           _addr(g_own), _addr(g_own_out), _addr(g_r), _addr(g_y), _addr(g_action), _addr(scratch), st),
+                   "dhts_net_ghosts_bwd")
+        return g_r, g_y, g_own_out, g_action, None, None, None, None, None
+
+
 def _soft(x, c):
     """dmath/operation.py:3-30: sigmoid(clamp(x * c, -16, 16))."""
     return torch.sigmoid(torch.clamp(x * c, -16.0, 16.0))
+
+
+def permuted_tables(t, perm):
+    """MacroNetworkTables `t` with its lanes renumbered: new lane i = old lane perm[i] (cells follow their lanes)."""
+    from .network import MacroNetworkTables
+    perm = np.asarray(perm, dtype=np.int64)
+    L = t.n_lanes
+    inv = np.empty(L, dtype=np.int64)
+    inv[perm] = np.arange(L)
+    p = MacroNetworkTables.__new__(MacroNetworkTables)
+    p.n_lanes, p.T = L, t.T
+    p.lane_ncell = np.asarray(t.lane_ncell)[perm].astype(np.int32)
+    p.lane_off = np.concatenate([[0], np.cumsum(p.lane_ncell)[:-1]]).astype(np.int32)
+    p.n_cells = t.n_cells
+    p.lane_dx = np.asarray(t.lane_dx)[perm].astype(np.float64)
+    p.sig_kind, p.inter = np.asarray(t.sig_kind)[perm].astype(np.int32), np.asarray(t.inter)[perm].astype(np.int32)
+    remap = lambda a: np.where(a >= 0, inv[np.clip(a, 0, L - 1)], a).astype(np.int32)      # noqa: E731  (negative codes stay)
+    p.left_src, p.left_gate, p.right_src = (np.ascontiguousarray(remap(np.asarray(x)[:, perm])) for x in (t.left_src, t.left_gate, t.right_src))
+    p.schedule = np.ascontiguousarray(np.asarray(t.schedule)[:, perm])
+    nxt = [[] for _ in range(L)]
+    prv = [[] for _ in range(L)]
+    for a in range(L):
+        for e in range(t.nxt_ptr[a], t.nxt_ptr[a + 1]):
+            b = int(t.nxt_idx[e])
+            nxt[inv[a]].append(int(inv[b]))
+            prv[inv[b]].append(int(inv[a]))
+    p.nxt_ptr = np.concatenate([[0], np.cumsum([len(x) for x in nxt])]).astype(np.int32)
+    p.nxt_idx = np.array([b for x in nxt for b in sorted(x)], dtype=np.int32)
+    p.prv_ptr = np.concatenate([[0], np.cumsum([len(x) for x in prv])]).astype(np.int32)
+    p.prv_idx = np.array([a for x in prv for a in sorted(x)], dtype=np.int32)
+    p.n_edges = int(len(p.nxt_idx))
+    p.is_source = np.asarray(t.is_source)[perm]
+    return p
 
 
 class BatchedMacroNetwork:
@@ -88,35 +180,115 @@ class BatchedMacroNetwork:
     def __init__(self, tables, device):
         t = tables
         self.t, self.device = t, device
-        L, C = t.n_lanes, t.n_cells
+        L, Cn = t.n_lanes, t.n_cells
+        self.L, self.T = L, t.T
         up = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=device)      # noqa: E731
         off, n = np.asarray(t.lane_off, dtype=np.int64), np.asarray(t.lane_ncell, dtype=np.int64)
-        self.first, self.last = up(off, torch.long), up(off + n - 1, torch.long)
-        self.left_src, self.left_gate, self.right_src = (up(x, torch.long) for x in (t.left_src, t.left_gate, t.right_src))      # [T][L]
-        self.schedule = up(t.schedule, torch.float64)                                                                                # [T][L]
-        self.kind, self.inter = up(t.sig_kind, torch.long), up(t.inter, torch.long)
         # groups of lanes with the same number of cells and the same cell length: one operator call each per step
         keys = {}
         for l in range(L):
             keys.setdefault((int(n[l]), float(t.lane_dx[l])), []).append(l)
         self.groups = []
-        order = []
+        order, perm = [], []
+        cell_off = 0
         for (nc, dx), lanes in sorted(keys.items()):
             idx = (off[lanes][:, None] + np.arange(nc)[None, :]).reshape(-1)
-            self.groups.append(dict(n=nc, dx=dx, lanes=up(lanes, torch.long), idx=up(idx, torch.long), B=len(lanes)))
+            self.groups.append(dict(n=nc, dx=dx, lanes=up(lanes, torch.long), idx=up(idx, torch.long), B=len(lanes),
+                                    lane_off=len(perm), cell_off=cell_off))
             order.append(idx)
+            perm += lanes
+            cell_off += len(idx)
         order = np.concatenate(order) if order else np.zeros(0, np.int64)
-        inv = np.empty(C, dtype=np.int64)
-        inv[order] = np.arange(C)
-        self.unsort = up(inv, torch.long)          # position of cell c in the concatenation of the groups' outputs
+        inv = np.empty(Cn, dtype=np.int64)
+        inv[order] = np.arange(Cn)
+        self.unsort = up(inv, torch.long)          # position of (original) cell c in the group-major order
+        self.lane_unsort = up(np.argsort(np.asarray(perm, dtype=np.int64)), torch.long)      # position of (original) lane l
         cell_lane = np.repeat(np.arange(L), n)
         self.cell_dx = up(np.asarray(t.lane_dx, dtype=np.float64)[cell_lane], torch.float32)
-        self.T = t.T
+        # the same network with its lanes in group-major order: what the kernels see
+        self.tp = permuted_tables(t, perm)
+        self.dtab = ops.DeviceNetTables(self.tp, device)
+        self.n_inter_tab = int(np.max(t.inter)) + 1 if L else 1
+        self._csr_sq = -1
+        # original order, as torch index tensors: rollout_torch
+        self.first, self.last = up(off, torch.long), up(off + n - 1, torch.long)
+        self.left_src, self.left_gate, self.right_src = (up(x, torch.long) for x in (t.left_src, t.left_gate, t.right_src))      # [T][L]
+        self.schedule = up(t.schedule, torch.float64)                                                                                # [T][L]
+        self.kind, self.inter = up(t.sig_kind, torch.long), up(t.inter, torch.long)
+
+    # ---- the queue loss of an episode from its state history (original lane / cell order) ------------------------------------
+    def _queue_loss(self, R_, U_, dt, static_speed, vehicle_length, differentiable):
+        """_env.py:586-618, 705-733: sigmoid(k (s0 - u)) r dx / vehicle_length summed per lane, squared, times dt;
+        k = 16 / |running mean of all samples (s0 - u) so far, one per cell in visiting order, over the last 100 000|."""
+        T, Cn = R_.shape
+        L, dev = self.L, R_.device
+        x = float(static_speed) - U_
+        if differentiable:
+            with torch.no_grad():
+                xs = x.reshape(-1).to(torch.float64)
+                cs = torch.cumsum(xs, 0)
+                idx = torch.arange(1, xs.numel() + 1, device=dev)
+                cs_old = torch.where(idx > WINDOW, cs[torch.clamp(idx - WINDOW - 1, min=0)], torch.zeros((), dtype=torch.float64, device=dev))
+                mean = (cs - cs_old) / torch.clamp(idx, max=WINDOW).to(torch.float64)
+                k = (16.0 / mean.to(torch.float32).abs()).reshape(T, Cn)
+            static = torch.sigmoid(torch.clamp(x * k, -16.0, 16.0))
+        else:
+            static = (U_ < float(static_speed)).to(torch.float32)
+        contrib = static * (R_ * (self.cell_dx / float(vehicle_length)))
+        queue = torch.zeros(T, L, dtype=torch.float32, device=dev)
+        for g in self.groups:
+            qg = contrib[:, g["idx"]].reshape(T, g["B"], g["n"]).sum(dim=-1)
+            queue = queue.index_copy(1, g["lanes"], (qg * qg) * float(dt))
+        return -queue.sum(), queue
 
     def rollout(self, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0, differentiable=True,
                 n_steps=None):
         """action [A] (device, float32) -> (reward, queue [T][L]).  differentiable=False: an evaluation episode (hard signals,
         hard static test; ItscpEnv.step(action, False))."""
+        dev = self.device
+        L, Cn = self.L, self.t.n_cells
+        T = self.T if n_steps is None else int(n_steps)
+        um = float(u_max)
+        a = action.reshape(-1).to(torch.float32).contiguous()
+        if int(n_inter_sq) < self.n_inter_tab:
+            raise ValueError("the tables name intersection %d but n_inter_sq = %d" % (self.n_inter_tab - 1, n_inter_sq))
+        if self._csr_sq != int(n_inter_sq):          # the ghost slots (2 lane + side) of every intersection, ascending
+            slots = [[] for _ in range(int(n_inter_sq))]
+            for l in range(L):
+                slots[int(self.tp.inter[l])] += [2 * l, 2 * l + 1]
+            up = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.int32, device=dev)      # noqa: E731
+            self.inter_ptr = up(np.concatenate([[0], np.cumsum([len(x) for x in slots])]))
+            self.inter_idx = up(np.array([j for x in slots for j in x] or [0]))
+            self._csr_sq = int(n_inter_sq)
+        self.desc = _lib.NetDesc(1, L, Cn, self.T, int(n_inter_sq), int(frames_per_phase), a.numel(), float(dt), um, float(static_speed),
+                                 float(vehicle_length))
+        self.err = ops.new_error_record(dev)
+        for g in self.groups:
+            g["desc"] = ops.macro_desc(g["B"], g["n"], dt, g["dx"], um)
+            g["tape_numel"] = ops.macro_step_tape_numel(g["desc"])
+        f32 = dict(dtype=torch.float32, device=dev)
+        if T == 0:
+            return torch.zeros((), **f32), torch.zeros(0, L, **f32)
+        r, y = torch.zeros(Cn, **f32), torch.zeros(Cn, **f32)                 # empty lanes (MacroLane.__init__), group-major order
+        u, q = torch.full((Cn,), um, **f32), torch.full((Cn,), um, **f32)
+        own = torch.stack([torch.zeros(L, **f32), torch.full((L,), um, **f32)], dim=-1).contiguous()     # stored downstream ghosts: no flow
+        hr, hy, hu = [], [], []
+        for step in range(T):
+            r, y, own, u, q = _NetStep.apply(r, y, own, a, u, q, self, step, not differentiable)
+            hr.append(r)
+            hy.append(y)
+            hu.append(u)
+        R_, Y_, U_ = torch.stack(hr), torch.stack(hy), torch.stack(hu)        # [T][C]: the state after every step
+        if differentiable:
+            U_ = _SpeedTap.apply(R_.reshape(-1), Y_.reshape(-1), U_.reshape(-1), um).reshape(T, Cn)      # u = u(r, y) of FullQ.set_r_y
+        reward, queue = self._queue_loss(R_[:, self.unsort], U_[:, self.unsort], dt, static_speed, vehicle_length, differentiable)
+        ops.raise_on_fault(self.err)
+        return reward, queue
+
+    def rollout_torch(self, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0, differentiable=True,
+                      n_steps=None):
+        """The same episode with the ghost exchange as torch gathers and blends (the reference's glue op by op) and autograd
+        between the pieces: the cross-check of dhts_net_ghosts_fwd / _bwd (and ~40 x the launches)."""
         t, dev = self.t, self.device
         L, C = t.n_lanes, t.n_cells
         T = self.T if n_steps is None else int(n_steps)
@@ -183,26 +355,6 @@ class BatchedMacroNetwork:
             hist_u.append(u)
         if T == 0:
             return torch.zeros((), **f32), torch.zeros(0, L, **f32)
-        R_, U_ = torch.stack(hist_r), torch.stack(hist_u)                       # [T][C]: the state after every step
-        # ---- queue loss (_env.py:586-618, 705-733): sigmoid(k (s0 - u)) r dx / vehicle_length summed per lane, squared, times dt;
-        #      k = 16 / |running mean of all samples (s0 - u) so far, one per cell in visiting order, over the last 100 000|
-        x = float(static_speed) - U_
-        if differentiable:
-            with torch.no_grad():
-                xs = x.reshape(-1).to(torch.float64)
-                cs = torch.cumsum(xs, 0)
-                idx = torch.arange(1, xs.numel() + 1, device=dev)
-                cs_old = torch.where(idx > WINDOW, cs[torch.clamp(idx - WINDOW - 1, min=0)], torch.zeros((), dtype=torch.float64, device=dev))
-                mean = (cs - cs_old) / torch.clamp(idx, max=WINDOW).to(torch.float64)
-                k = (16.0 / mean.to(torch.float32).abs()).reshape(T, C)
-            static = torch.sigmoid(torch.clamp(x * k, -16.0, 16.0))
-        else:
-            static = (U_ < float(static_speed)).to(torch.float32)
-        contrib = static * (R_ * (self.cell_dx / float(vehicle_length)))
-        queue = torch.zeros(T, L, **f32)
-        for g in self.groups:
-            qg = contrib[:, g["idx"]].reshape(T, g["B"], g["n"]).sum(dim=-1)
-            queue = queue.index_copy(1, g["lanes"], (qg * qg) * float(dt))
-        reward = -queue.sum()
+        reward, queue = self._queue_loss(torch.stack(hist_r), torch.stack(hist_u), dt, static_speed, vehicle_length, differentiable)
         ops.raise_on_fault(err)
         return reward, queue

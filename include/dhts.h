@@ -308,6 +308,29 @@ int dhts_net_macro_rollout_bwd(const dhts_net_desc *d, const dhts_net_tables *t,
                                const float *tape, const float *kc, const float *queue, const float *g_reward, float *g_action,
                                const float *workspace, dhts_error *err, void *stream);
 
+/* ---- Macro road networks of ANY size, step by step (round 4) ---------------------------------------------------------------
+ * The rollouts above keep a replica in one workgroup (cells + lanes <= 1024); the reference builds grids of any size
+ * (example/control/itscp/_env.py:221-439).  A larger network steps as RoadNetwork.forward does (road_network.py:57-111), one
+ * operator call per step for ALL lanes: dhts_net_ghosts_fwd turns the state before step `step` into every lane's two ghost
+ * cells -- the connected neighbour's edge cell, the inflow schedule of a source lane or the stored downstream ghost of a sink
+ * lane, blended between green and red by the signals of that step (ItscpRoadNetwork.setup_macro_boundary,
+ * _simulator.py:42-60; signals _env.py:885-962) -- in the layout dhts_macro_step_fwd takes its ghosts in, the lanes then step
+ * as batches of that operator (lanes of equal cells and cell length), and dhts_net_ghosts_bwd routes the operator's ghost
+ * cotangents (dhts_macro_step_bwd's g_ghost) back: to the neighbours' edge cells (r, y), to the stored ghosts and to the action.
+ * d / t as for dhts_net_macro_rollout_fwd with n_replicas = 1 (lane_off / lane_ncell give the edge cells; rows `step` of
+ * left_src / left_gate / right_src / schedule are read).  r, y, u [C] = the state before the step (u = u(r, y) as the operator
+ * left it); own_in / own_out [L][2] = the lanes' stored downstream ghosts (r, u) before / after (initially (0, u_max));
+ * ghost [L][2][4] = (left, right) x (r, y, u, u_eq); hard != 0 = an evaluation episode's thresholds.
+ * _bwd: g_ghost [L][2][2] double (d / d ghost (r, y)), g_own_in [L][2] = cotangent of own_out; g_own_out [L][2] is written;
+ * g_r, g_y [C] and g_action [n_action] are ACCUMULATED into (edge cells in a fixed order: bit-repeatable); inter_ptr [sq + 1],
+ * inter_idx = the ghost slots (2 lane + side) of every intersection in ascending order; scratch [L][2][4] float32. */
+int dhts_net_ghosts_fwd(const dhts_net_desc *d, const dhts_net_tables *t, int step, int hard, const float *action, const float *r,
+                        const float *u, const float *own_in, float *own_out, float *ghost, void *stream);
+int dhts_net_ghosts_bwd(const dhts_net_desc *d, const dhts_net_tables *t, const int32_t *inter_ptr, const int32_t *inter_idx, int step,
+                        const float *action, const float *r, const float *y, const float *u, const float *own_in,
+                        const double *g_ghost, const float *g_own_in, float *g_own_out, float *g_r, float *g_y, float *g_action,
+                        float *scratch, void *stream);
+
 /* ---- HYBRID road network (itscp `hybrid` mode): macro lanes, micro lanes and the hand-offs between them -----------------
  * As the macro network rollout, with lanes that are either ARZ cell lanes or IDM vehicle lanes and, after every step,
  * the conversions of road/network/conversion.py:11-215 in lane-id order (RoadNetwork.conversion, road_network.py:113-170):

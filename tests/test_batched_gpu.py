@@ -32,6 +32,12 @@ def test_batched_network_vs_reference(cuda, golden_dir, name):
     assert state_report("batched %s: queues vs reference" % name, queue.detach().cpu().numpy().T, g["queue"]) <= TOL_STATE
     assert abs(float(reward) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
     assert grad_report("batched %s d reward / d action" % name, action.grad.cpu().numpy(), g["g_action"]) <= TOL_GRAD
+    # the same episode with the ghost exchange as torch gathers and blends (the reference's glue op by op)
+    a3 = torch.tensor(g["action"], device=cuda, requires_grad=True)
+    r3, q3 = net.rollout_torch(a3, *_args(m))
+    r3.backward()
+    assert rel_max(queue.detach().cpu().numpy(), q3.detach().cpu().numpy()) <= 1e-6
+    assert rel_max(action.grad.cpu().numpy(), a3.grad.cpu().numpy()) <= 1e-5
     # and the fused one-workgroup kernels give the same episode
     a2 = torch.tensor(g["action"][None], device=cuda, requires_grad=True)
     r2, q2 = ops.net_macro_rollout(a2, ops.DeviceNetTables(tab, cuda), *_args(m))
