@@ -18,7 +18,7 @@ def snippets():
 
 
 def test_every_marked_snippet_is_known():
-    assert set(snippets()) == {"binding", "rollouts", "net_macro", "net_hybrid", "net_eval", "net_micro", "net_state"}
+    assert set(snippets()) == {"binding", "rollouts", "net_macro", "net_batched", "net_hybrid", "net_eval", "net_micro", "net_state"}
 
 
 def test_binding_snippet_loads_the_library():
@@ -73,6 +73,12 @@ def test_net_macro_snippet(cuda):
     exec(compile(snippets()["net_macro"], "INTEGRATION.md:net_macro", "exec"), ns)
     assert ns["reward"].shape == (4,) and action.grad is not None and torch.isfinite(action.grad).all()
     assert ns["queue"].shape == (4, env.num_timestep, ns["tab"].n_lanes)
+    # the batched-lane path on the same tables: replica 0's episode
+    fused_reward, fused_queue = ns["reward"].detach(), ns["queue"].detach()
+    exec(compile(snippets()["net_batched"], "INTEGRATION.md:net_batched", "exec"), ns)
+    assert ns["queue"].shape == (env.num_timestep, ns["tab"].n_lanes)
+    assert abs(float(ns["reward"]) - float(fused_reward[0])) <= 1e-5 * abs(float(fused_reward[0]))
+    assert float((ns["queue"] - fused_queue[0]).abs().max()) <= 1e-5 * float(fused_queue[0].abs().max())
 
 
 @pytest.mark.gpu
