@@ -106,8 +106,8 @@ __device__ int dhts_hyb_trace[2][640][16][10];
 #define HYB_STAMP_DECL
 #define HYB_STAMP_KERNEL(k_)
 #define HYB_BARRIER(i) lds_barrier()
-#define HYB_SUB(i)
-#define HYB_SUB2(i)
+#define HYB_SUB(i) {}              // (a statement: the points stand behind `if constexpr (...)`)
+#define HYB_SUB2(i) {}
 #define HYB_STAMP_WRITE(kernel_, rep_, tid_, B_)
 #endif
 
