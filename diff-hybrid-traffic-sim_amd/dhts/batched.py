@@ -140,6 +140,21 @@ def _soft(x, c):
     return torch.sigmoid(torch.clamp(x * c, -16.0, 16.0))
 
 
+class _CapturedReward(torch.autograd.Function):
+    """reward(action) of a replayed episode: the value and d reward / d action both come out of the graph."""
+
+    @staticmethod
+    def forward(ctx, action, reward, grad):
+        ctx.save_for_backward(grad)
+        ctx.shape = action.shape
+        return reward
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (g * grad).reshape(ctx.shape), None, None
+
+
 def permuted_tables(t, perm):
     """MacroNetworkTables `t` with its lanes renumbered: new lane i = old lane perm[i] (cells follow their lanes)."""
     from .network import MacroNetworkTables
@@ -242,9 +257,10 @@ class BatchedMacroNetwork:
         return -queue.sum(), queue
 
     def rollout(self, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0, differentiable=True,
-                n_steps=None):
+                n_steps=None, check_faults=True):
         """action [A] (device, float32) -> (reward, queue [T][L]).  differentiable=False: an evaluation episode (hard signals,
-        hard static test; ItscpEnv.step(action, False))."""
+        hard static test; ItscpEnv.step(action, False)).  check_faults=False: the fault record (self.err) is not read back -- no host
+        synchronisation, e.g. inside a HIP-graph capture."""
         dev = self.device
         L, Cn = self.L, self.t.n_cells
         T = self.T if n_steps is None else int(n_steps)
@@ -282,8 +298,78 @@ class BatchedMacroNetwork:
         if differentiable:
             U_ = _SpeedTap.apply(R_.reshape(-1), Y_.reshape(-1), U_.reshape(-1), um).reshape(T, Cn)      # u = u(r, y) of FullQ.set_r_y
         reward, queue = self._queue_loss(R_[:, self.unsort], U_[:, self.unsort], dt, static_speed, vehicle_length, differentiable)
-        ops.raise_on_fault(self.err)
+        if check_faults:
+            ops.raise_on_fault(self.err)
         return reward, queue
+
+    # ---- the per-step tables of a new episode (schedules, per-step routes) into the device tables, in place ------------------
+    def update(self, tables):
+        """Same topology, new schedules / per-step routes (ItscpEnv.reset draws them anew): the device tables are overwritten in
+        place, so a captured episode (graphed_rollout) stays valid.  Raises ValueError when the topology differs."""
+        t = self.t
+        same = (tables.n_lanes == t.n_lanes and tables.n_cells == t.n_cells and tables.T == t.T and
+                np.array_equal(tables.lane_ncell, t.lane_ncell) and np.array_equal(tables.nxt_idx, t.nxt_idx) and
+                np.array_equal(tables.nxt_ptr, t.nxt_ptr) and np.array_equal(tables.sig_kind, t.sig_kind) and
+                np.array_equal(tables.inter, t.inter) and np.allclose(tables.lane_dx, t.lane_dx, rtol=0, atol=0))
+        if not same:
+            raise ValueError("BatchedMacroNetwork.update: the network's topology changed; build a new one")
+        self.t = tables
+        order = np.argsort(self.lane_unsort.cpu().numpy())          # new lane i = old lane order[i]
+        tp = permuted_tables(tables, order)
+        self.tp = tp
+        d = self.dtab
+        for name in ("left_src", "left_gate", "right_src"):
+            getattr(d, name).copy_(torch.as_tensor(np.ascontiguousarray(getattr(tp, name)), dtype=torch.int32))
+            getattr(self, name).copy_(torch.as_tensor(np.ascontiguousarray(getattr(tables, name)), dtype=torch.long))
+        d.schedule.copy_(torch.as_tensor(np.ascontiguousarray(tp.schedule), dtype=torch.float64))
+        self.schedule.copy_(torch.as_tensor(np.ascontiguousarray(tables.schedule), dtype=torch.float64))
+
+    # ---- a whole episode (forward, and backward for a differentiable one) as ONE HIP graph ------------------------------------
+    def graphed_rollout(self, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0, differentiable=True):
+        """rollout() captured once into a HIP graph (8 launches per step and ~25 small allocations are what an eager episode
+        pays for) and replayed for every later call with the same sizes: the action is copied into the graph's static input, the
+        per-step tables are read from the device tables (update() overwrites them in place).  Returns (reward, queue) like rollout();
+        reward is differentiable w.r.t. `action` through the captured backward pass.  Faults are read after the replay."""
+        key = (int(n_inter_sq), int(frames_per_phase), float(dt), float(u_max), float(static_speed), float(vehicle_length), bool(differentiable),
+               int(action.numel()))
+        g = getattr(self, "_graphs", None)
+        if g is None:
+            g = self._graphs = {}
+        if key not in g:
+            static_a = action.detach().reshape(-1).to(torch.float32).clone().requires_grad_(differentiable)
+            args = key[:6]
+
+            def episode():
+                if differentiable:
+                    static_a.grad = None
+                    reward, queue = self.rollout(static_a, *args, differentiable=True, check_faults=False)
+                    (grad,) = torch.autograd.grad(reward, static_a)
+                    return reward.detach(), queue.detach(), grad
+                with torch.no_grad():
+                    reward, queue = self.rollout(static_a, *args, differentiable=False, check_faults=False)
+                return reward, queue, None
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                     # warm-up outside the capture (allocator, lazy initialisations)
+                for _ in range(2):
+                    episode()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = episode()
+            g[key] = (graph, static_a, out, self.err)
+        graph, static_a, out, err = g[key]
+        with torch.no_grad():
+            static_a.copy_(action.detach().reshape(-1))
+        err.zero_()
+        graph.replay()
+        ops.raise_on_fault(err)
+        reward, queue, grad = out
+        if differentiable and action.requires_grad:
+            reward = _CapturedReward.apply(action, reward.clone(), grad.clone())
+        else:
+            reward = reward.clone()
+        return reward, queue.clone()
 
     def rollout_torch(self, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0, differentiable=True,
                       n_steps=None):

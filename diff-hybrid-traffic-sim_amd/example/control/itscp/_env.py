@@ -284,7 +284,15 @@ class ItscpEnv:
                     # more cells + lanes than one workgroup holds (e.g. --n_intersection=3 --n_lane=3: 360 lanes, ~2 100 cells): all
                     # lanes as the batch of the straight-lane step operator, one call per step (dhts/batched.py)
                     from dhts.batched import BatchedMacroNetwork
-                    cache = ("batched", BatchedMacroNetwork(MacroNetworkTables.from_env(self), action.device))
+                    tabs = MacroNetworkTables.from_env(self)
+                    net = getattr(self, "_batched_net", None)           # survives reset(): same topology, new schedules / routes
+                    try:
+                        if net is None:
+                            raise ValueError
+                        net.update(tabs)                                # in place: an episode captured as a HIP graph stays valid
+                    except ValueError:
+                        net = self._batched_net = BatchedMacroNetwork(tabs, action.device)
+                    cache = ("batched", net)
                 elif self.config["mode"] == "micro":
                     # every lane an IDM lane; source lanes admit their waiting vehicles against np.random draws
                     # (_simulator.py:153-174): the waiting routes in admission order (the list is popped from its end) are
@@ -336,7 +344,18 @@ class ItscpEnv:
             tab.set_draws(draws)
         try:
             if kind == "batched":
-                reward, queue = tab.rollout(a[0], *args, differentiable=differentiable)
+                if self.config.get("batched_graph", True) and not getattr(self, "_batched_graph_failed", False):
+                    try:                                    # the whole episode as one HIP graph (captured at the first call)
+                        reward, queue = tab.graphed_rollout(a[0], *args, differentiable=differentiable)
+                    except RuntimeError as e:
+                        if isinstance(e, ops.CapacityError):
+                            raise
+                        import warnings
+                        warnings.warn("ItscpEnv: HIP-graph capture of the batched episode failed (%s); running it eagerly" % e)
+                        self._batched_graph_failed = True
+                        reward, queue = tab.rollout(a[0], *args, differentiable=differentiable)
+                else:
+                    reward, queue = tab.rollout(a[0], *args, differentiable=differentiable)
                 reward, queue = reward.reshape(1), queue.unsqueeze(0)
             elif kind == "macro":
                 reward, queue = ops.net_macro_rollout(a, tab, *args) if differentiable else ops.net_macro_eval(a, tab, *args)

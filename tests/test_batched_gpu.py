@@ -96,5 +96,47 @@ def test_env_step_runs_a_network_beyond_one_workgroup_batched(cuda, oracle):
     oe = oracle.net_macro(tab, act, sq, F, 1.0 / env.config["simulation_frequency"], env.simulator.speed_limit,
                           env.config["static_speed"], env.simulator.vehicle_length, hard=True)
     assert abs(float(reward_e) - oe["reward"]) <= 1e-5 * abs(oe["reward"])
-    print("360 lanes, %d cells, %d steps: differentiable episode (forward + backward) %.2f s, evaluation episode %.2f s on the batched path"
+    print("360 lanes, %d cells, %d steps: differentiable episode (forward + backward) %.2f s, evaluation episode %.2f s on the batched path (first calls: HIP-graph capture included)"
           % (tab.n_cells, tab.T, t_diff, t_eval))
+    # a second pair of episodes after reset(): new schedules and routes go into the device tables in place, the captured graphs
+    # are replayed; the numbers are again the oracle's for the new tables
+    net = env._batched_net
+    env.config["random_seed"] = 6              # (another inflow schedule and other per-step routes)
+    env.reset()
+    assert env._batched_net is net
+    tab2 = MacroNetworkTables.from_env(env)
+    action2 = torch.tensor(act, device=cuda, requires_grad=True)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    _, reward2, _, _ = env.step(action2, True)
+    reward2.backward()
+    torch.cuda.synchronize()
+    t_replay = time.time() - t0
+    assert env._fused_cache[1] is net and not getattr(env, "_batched_graph_failed", False) and len(net._graphs) == 2
+    o2 = oracle.net_macro(tab2, act, sq, F, 1.0 / env.config["simulation_frequency"], env.simulator.speed_limit,
+                          env.config["static_speed"], env.simulator.vehicle_length)
+    assert abs(float(reward2.detach()) - o2["reward"]) <= 1e-5 * abs(o2["reward"])
+    assert grad_report("360-lane network, replayed graph: d reward / d action", action2.grad.cpu().numpy(), o2["g_action"]) <= TOL_GRAD
+    assert abs(o2["reward"] - o["reward"]) > 1e-6 * abs(o["reward"])          # (the new episode is a different one)
+    print("  replayed differentiable episode with new tables: %.3f s (table upload + replay + oracle-checked)" % t_replay)
+
+
+def test_graphed_rollout_equals_eager(cuda, golden_dir):
+    import torch
+    from dhts.batched import BatchedMacroNetwork
+    g = np.load(os.path.join(golden_dir, "itscp_macro_2x2.npz"))
+    tab, m = itscp_tables(g)
+    net = BatchedMacroNetwork(tab, cuda)
+    a1 = torch.tensor(g["action"], device=cuda, requires_grad=True)
+    r1, q1 = net.rollout(a1, *_args(m))
+    r1.backward()
+    for _ in range(2):          # capture, then replay
+        a2 = torch.tensor(g["action"], device=cuda, requires_grad=True)
+        r2, q2 = net.graphed_rollout(a2, *_args(m))
+        (3.0 * r2).backward()
+        assert torch.equal(r1.detach(), r2.detach()) and torch.equal(q1.detach(), q2)
+        assert torch.equal(3.0 * a1.grad, a2.grad)
+    with torch.no_grad():
+        re, qe = net.rollout(torch.tensor(g["action"], device=cuda), *_args(m), differentiable=False)
+        rg, qg = net.graphed_rollout(torch.tensor(g["action"], device=cuda), *_args(m), differentiable=False)
+    assert torch.equal(re, rg) and torch.equal(qe, qg)
