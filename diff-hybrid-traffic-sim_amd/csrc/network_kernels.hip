@@ -444,12 +444,13 @@ __global__ void __launch_bounds__(kMaxBlock) net_macro_bwd_kernel(int R, int L, 
             const int c = tid;
             const float rr = Hn[c], yy = Hn[C + c], uu = Hn[2 * C + c];
             const float x = s0f - uu;
-            const float is_static = soft_switch(x, w_kc);
+            float is_static, d_static;
+            soft_switch_both(x, w_kc, is_static, d_static);
             const float nveh = rr * c_dxv;
             const float gql = gscale * (-1.0f) * (float)dt * 2.f * sqrtf(w_q / (float)dt);
             float gr = g_r + gql * is_static * c_dxv;
             float gy = g_y;
-            glue_u_bwd(rr, yy, um, gql * nveh * (-soft_switch_grad(x, w_kc)), gr, gy);
+            glue_u_bwd(rr, yy, um, gql * nveh * (-d_static), gr, gy);
             c0[c] = dot2(d0.x, gr, d0.z, gy); c0[C + c] = dot2(d0.y, gr, d0.w, gy);
             c2[c] = dot2(d2.x, gr, d2.z, gy); c2[C + c] = dot2(d2.y, gr, d2.w, gy);
             v_r = dot2(d1.x, gr, d1.z, gy); v_y = dot2(d1.y, gr, d1.w, gy);
