@@ -230,7 +230,7 @@ def test_exhausted_record_stream_is_a_loud_fault(cuda, golden_dir):
     RuntimeError instead of a silently truncated tape (include/dhts.h: dhts_hybrid_tables.records_per_step)."""
     import torch
     from dhts import ops
-    g = np.load(os.path.join(golden_dir, "itscp_hybrid_short.npz"))
+    g = np.load(os.path.join(golden_dir, "itscp_hybrid_p2.npz"))     # (13 vehicles over 480 steps: several records per step on average)
     t, m = itscp_hybrid_tables(g)
     args = (m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"],
             m["speed_limit"], m["static_speed"], m["vehicle_length"])
