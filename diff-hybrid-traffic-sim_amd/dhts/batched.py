@@ -225,6 +225,15 @@ class BatchedMacroNetwork:
         self.dtab = ops.DeviceNetTables(self.tp, device)
         self.n_inter_tab = int(np.max(t.inter)) + 1 if L else 1
         self._csr_sq = -1
+        # the action partials of a lane's two ghosts are summed under the LANE's intersection (dhts_net_ghosts_bwd: inter_idx); the
+        # upstream ghost's signal is the gate lane's, so a signalled upstream lane has to belong to the same intersection (the fused
+        # kernels make the same assumption and flag it at run time; every itscp grid satisfies it: an approaching lane gates the
+        # intersection's own mid lanes)
+        for l in range(L):
+            for e in range(t.prv_ptr[l], t.prv_ptr[l + 1]):
+                g_ = int(t.prv_idx[e])
+                if t.sig_kind[g_] != 0 and t.inter[g_] != t.inter[l]:
+                    raise ValueError("batched path: lane %d is gated by the signal of lane %d, which belongs to another intersection" % (l, g_))
         # original order, as torch index tensors: rollout_torch
         self.first, self.last = up(off, torch.long), up(off + n - 1, torch.long)
         self.left_src, self.left_gate, self.right_src = (up(x, torch.long) for x in (t.left_src, t.left_gate, t.right_src))      # [T][L]
