@@ -109,7 +109,7 @@ class _NetStep(torch.autograd.Function):
                                                _addr(tape) if tape is not None else None, _addr(net.err), st), "dhts_macro_step_fwd")
             tapes.append(tape)
         ctx.net, ctx.step, ctx.tapes = net, int(step), tapes
-        ctx.save_for_backward(r, y, u, own, action, nr, ny)
+        ctx.save_for_backward(r, y, u, own, action)
         ctx.mark_non_differentiable(nu, nq)
         return nr, ny, own_out, nu, nq
 
@@ -117,7 +117,7 @@ class _NetStep(torch.autograd.Function):
     def backward(ctx, g_nr, g_ny, g_own, _g_nu, _g_nq):
         net = ctx.net
         lib, st = _lib.lib(), ops._stream()
-        r, y, u, own, action, nr, ny = ctx.saved_tensors
+        r, y, u, own, action = ctx.saved_tensors
         g_nr, g_ny, g_own = g_nr.contiguous(), g_ny.contiguous(), g_own.contiguous()
         g_r, g_y = torch.empty_like(r), torch.empty_like(r)
         g_ghost = torch.zeros(net.L, 2, 2, dtype=torch.float64, device=r.device)
