@@ -140,3 +140,83 @@ def test_graphed_rollout_equals_eager(cuda, golden_dir):
         re, qe = net.rollout(torch.tensor(g["action"], device=cuda), *_args(m), differentiable=False)
         rg, qg = net.graphed_rollout(torch.tensor(g["action"], device=cuda), *_args(m), differentiable=False)
     assert torch.equal(re, rg) and torch.equal(qe, qg)
+
+
+def _random_network(rng, n_inter, T):
+    """A random signalled macro network: every intersection has approaching lanes (signalled, west-east or north-south), mid
+    lanes behind them (several per approaching lane: the per-step route picks one) and leaving lanes that feed approaching
+    lanes of other intersections or end; cells per lane 1 .. 6, two cell lengths."""
+    from dhts.network import SIG_ALWAYS, SIG_NS, SIG_WE, MacroNetworkTables
+    ncell, length, kinds, inter, edges = [], [], [], [], []
+
+    def lane(n, dx, kind, it):
+        ncell.append(n); length.append(n * dx); kinds.append(kind); inter.append(it)
+        return len(ncell) - 1
+    leaving = []
+    approaching = []
+    for it in range(n_inter):
+        for _ in range(int(rng.integers(2, 4))):
+            a = lane(int(rng.integers(1, 7)), float(rng.choice([5.0, 4.0])), int(rng.choice([SIG_WE, SIG_NS])), it)
+            approaching.append(a)
+            outs = []
+            for _ in range(int(rng.integers(1, 3))):
+                m = lane(int(rng.integers(1, 4)), float(rng.choice([5.0, 4.0])), SIG_ALWAYS, it)
+                o = lane(int(rng.integers(1, 7)), 5.0, SIG_ALWAYS, it)
+                edges.append((a, m)); edges.append((m, o))
+                outs.append(o)
+            leaving += outs
+    rng.shuffle(leaving)
+    free = [a for a in approaching]
+    rng.shuffle(free)
+    for o in leaving[:len(leaving) // 2]:
+        if not free:
+            break
+        a = free.pop()
+        if inter[a] != inter[o]:
+            edges.append((o, a))
+    L = len(ncell)
+    nxt = [[] for _ in range(L)]
+    for a, b in edges:
+        nxt[a].append(b)
+    route = -np.ones((T, L), dtype=np.int32)
+    for t in range(T):
+        for l in range(L):
+            if nxt[l]:
+                route[t, l] = nxt[l][int(rng.integers(0, len(nxt[l])))]
+    sched = rng.uniform(0.05, 0.6, (L, T))
+    return MacroNetworkTables(ncell, length, edges, kinds, inter, route, sched)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_batched_random_network_vs_oracle(cuda, oracle, seed):
+    """Random topologies (merging and splitting lanes with per-step routes, one-cell lanes, two cell lengths, sink lanes with their
+    stored ghosts): queues, reward and d reward / d action of the batched path against the CPU oracle; where the network fits one
+    workgroup, against the fused kernels too."""
+    import torch
+    from dhts import ops
+    from dhts.batched import BatchedMacroNetwork
+    rng = np.random.default_rng(seed)
+    n_inter, T, F = 4, 90, 30
+    tab = _random_network(rng, n_inter, T)
+    act = rng.uniform(0.2, 0.8, 3 * n_inter).astype(np.float32)
+    args = (n_inter, F, 0.1, 20.0, 0.2, 5.0)
+    net = BatchedMacroNetwork(tab, cuda)
+    a = torch.tensor(act, device=cuda, requires_grad=True)
+    reward, queue = net.rollout(a, *args)
+    reward.backward()
+    o = oracle.net_macro(tab, act, *args)
+    assert o["rc"] == 0
+    assert state_report("random network %d (%d lanes, %d cells): queues vs oracle" % (seed, tab.n_lanes, tab.n_cells),
+                        queue.detach().cpu().numpy(), o["queue"]) <= TOL_STATE
+    assert abs(float(reward.detach()) - o["reward"]) <= 1e-5 * abs(o["reward"])
+    assert grad_report("random network %d d reward / d action" % seed, a.grad.cpu().numpy(), o["g_action"]) <= TOL_GRAD
+    if tab.n_cells + tab.n_lanes <= 1024:
+        a2 = torch.tensor(act[None], device=cuda, requires_grad=True)
+        r2, q2 = ops.net_macro_rollout(a2, ops.DeviceNetTables(tab, cuda), *args)
+        r2.sum().backward()
+        assert rel_max(queue.detach().cpu().numpy(), q2[0].detach().cpu().numpy()) <= TOL_STATE
+        assert rel_max(a.grad.cpu().numpy(), a2.grad[0].cpu().numpy()) <= TOL_GRAD
+    with torch.no_grad():
+        re, qe = net.rollout(torch.tensor(act, device=cuda), *args, differentiable=False)
+    oe = oracle.net_macro(tab, act, *args, hard=True)
+    assert abs(float(re) - oe["reward"]) <= 1e-5 * max(abs(oe["reward"]), 1e-6)
