@@ -392,9 +392,9 @@ class ItscpEnv:
                 self.simulator.random_draw = replay
             self.fused_overflowed = True
             return None
-        q = queue[0].detach().cpu().numpy()                 # [T][L]
+        q = np.ascontiguousarray(queue[0].detach().cpu().numpy().T)      # [L][T]
         for i, lid in enumerate(self.lane.keys()):
-            self.queue_length[lid] = [float(x) for x in q[:, i]]
+            self.queue_length[lid] = q[i].tolist()              # (Python floats like the lane-by-lane path's, converted in C)
             self.flux.setdefault(lid, [])
         self.time = self.num_timestep
         self._fused_done = True
