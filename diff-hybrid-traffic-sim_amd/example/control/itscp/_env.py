@@ -134,14 +134,38 @@ class ItscpEnv:
         self.flux.clear()
         self.is_static_rms = RunningMean(100_000)
 
+    def episode_copy(self):
+        """A twin for ONE episode that must not disturb this environment (Trainer.evaluate; the reference deep-copies the
+        environment, trainer.py:172): the episode state is its own, everything else is shared -- a fused episode never touches
+        the lane objects.  Should the episode have to run lane by lane after all, the twin takes its own copy of the lanes first
+        (step -> _own_lanes)."""
+        twin = object.__new__(type(self))
+        twin.__dict__.update(self.__dict__)
+        twin.queue_length, twin.flux = {}, {}
+        twin.config = dict(self.config)
+        twin.is_static_rms = RunningMean(100_000)
+        twin._lanes_shared = True
+        return twin
+
+    def _own_lanes(self):
+        if getattr(self, "_lanes_shared", False):
+            import copy
+            memo = {}
+            self.simulator = copy.deepcopy(self.simulator, memo)
+            self.lane = copy.deepcopy(self.lane, memo)
+            self._lanes_shared = False
+
     def __deepcopy__(self, memo):
         """Episode copy for the lane-by-lane path: everything is copied except the uploaded tables of the fused kernels,
         which are immutable and shared."""
         import copy
         twin = object.__new__(type(self))
         memo[id(self)] = twin
+        # what an episode only reads is shared, not copied: the drawn inflow schedules (lanes x steps numpy scalars -- 86 000 objects
+        # at config 4, 0.4 s per copy) and the per-step macro routes, beside the uploaded tables
+        shared = ("_fused_cache", "_batched_net", "schedule", "macro_route_schedule")
         for k, v in self.__dict__.items():
-            twin.__dict__[k] = v if k == "_fused_cache" else copy.deepcopy(v, memo)
+            twin.__dict__[k] = v if k in shared else copy.deepcopy(v, memo)
         return twin
 
     def _make_micro_route(self):
@@ -249,6 +273,7 @@ class ItscpEnv:
                                       "or set config['fused'] = False to step lane by lane")
         reward = self._step_fused(action, differentiable)
         if reward is None:
+            self._own_lanes()                       # (an episode_copy() twin: the lane-by-lane path moves the lane objects)
             self._simulate(action, differentiable)
             reward = self._reward(action)
         obs = self.observe()
@@ -383,6 +408,7 @@ class ItscpEnv:
                 self._fused_overflow_warned = True
                 import warnings
                 warnings.warn("ItscpEnv: the fused kernels' capacity was exceeded (%s); this episode runs lane by lane" % e)
+            self._own_lanes()                       # (an episode_copy() twin: from here on the lane objects are written to)
             if kind == "micro":
                 it = iter(np.asarray(draws, dtype=np.float64).tolist())
 

@@ -112,7 +112,9 @@ class Trainer:
         if hasattr(env, "rewind"):
             env.rewind()                                # same schedules / routes, episode state back to reset()
             if not differentiable:
-                env = deepcopy(env)                     # the lane-by-lane path mutates the lane objects
+                # an evaluation episode must leave the training environment alone: a twin that shares everything a fused
+                # episode only reads (and copies the lanes if it has to step lane by lane after all)
+                env = env.episode_copy() if hasattr(env, "episode_copy") else deepcopy(env)
         else:
             env = deepcopy(env)
         obs = env.observe()

@@ -311,3 +311,30 @@ def test_env_step_falls_back_when_a_fused_capacity_is_exceeded(cuda):
     assert abs(float(reward2.detach()) - float(reward.detach())) <= 1e-4 * abs(float(reward.detach()))
     g1, g2 = action.grad.cpu().numpy(), action2.grad.cpu().numpy()
     assert np.abs(g2 - g1).max() <= TOL_GRAD * np.abs(g1).max()
+
+
+def test_episode_copy_leaves_the_environment_alone(cuda, golden_dir):
+    """Trainer.evaluate runs its episodes on ItscpEnv.episode_copy() twins (the reference deep-copies the environment,
+    trainer.py:172): a fused episode on the twin shares the lane objects, a lane-by-lane one takes its own copy first; either way
+    the environment can be rewound and gives the same episode afterwards."""
+    import torch
+    g = np.load(os.path.join(golden_dir, "itscp_macro_small.npz"))
+    m = meta_of(g)
+    env = build_env(g, m)
+    action = torch.tensor(g["action"], device=cuda)
+    with torch.no_grad():
+        _, r0, _, _ = env.step(action, False)
+        env.rewind()
+        twin = env.episode_copy()
+        _, r1, _, _ = twin.step(action, False)                 # fused: nothing copied
+        assert twin._fused_done and twin.simulator is env.simulator and float(r1) == float(r0)
+        slow = env.episode_copy()
+        slow.config["fused"] = False
+        assert env.config.get("fused", True)                  # (the twin's configuration is its own)
+        _, r2, _, _ = slow.step(action, False)                 # lane by lane: on the twin's own lanes
+        assert slow.simulator is not env.simulator and not getattr(slow, "_fused_done", False)
+        assert abs(float(r2) - float(r0)) <= 1e-5 * abs(float(r0))
+        assert not any(sl.is_macro() and float(sl.get_state_vector()[0].abs().max()) > 0 for sl in env.simulator.lane.values())   # still empty
+        env.rewind()
+        _, r3, _, _ = env.step(action, False)
+        assert float(r3) == float(r0)
