@@ -52,6 +52,16 @@ class HybridStateIO(C.Structure):
     _fields_ = [("plain", C.c_int32), ("state0", C.c_void_p), ("ghost0", C.c_void_p), ("veh_out", C.c_void_p), ("events", C.c_void_p)]
 
 
+class NetstepGroup(C.Structure):
+    _fields_ = [("lane_pos0", C.c_int32), ("n_lanes", C.c_int32), ("n_cells", C.c_int32), ("cell0", C.c_int32), ("dx", C.c_double)]
+
+
+class NetstepTables(C.Structure):
+    _fields_ = [("hyb", HybridTables), ("lane_gpos", C.c_void_p), ("groups", C.POINTER(NetstepGroup)), ("n_groups", C.c_int32),
+                ("micro_lanes", C.c_void_p), ("lane_mslot", C.c_void_p), ("cap_lanes", C.c_void_p), ("lane_cslot", C.c_void_p),
+                ("n_caps", C.c_int32), ("inter_ptr", C.c_void_p), ("inter_idx", C.c_void_p), ("max_events", C.c_int32)]
+
+
 class MicroDesc(C.Structure):
     _fields_ = [("n_lanes", C.c_int32), ("capacity", C.c_int32), ("dt", C.c_double)]
 
@@ -90,6 +100,9 @@ SIGNATURES = {
     "dhts_net_hybrid_rollout_bwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(HybridTables)] + [_P] * 10),
     "dhts_net_hybrid_state_rollout_fwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(HybridTables), C.POINTER(HybridStateIO)] + [_P] * 10),
     "dhts_net_hybrid_state_rollout_bwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(HybridTables), C.c_int32] + [_P] * 13),
+    "dhts_netstep_workspace_bytes": (C.c_size_t, [C.POINTER(NetDesc), C.POINTER(NetstepTables)]),
+    "dhts_netstep_rollout_fwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetstepTables), C.c_int] + [_P] * 8),
+    "dhts_netstep_rollout_bwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetstepTables)] + [_P] * 8),
     "dhts_micro_tape_bytes": (C.c_size_t, [C.POINTER(MicroDesc), C.c_int]),
     "dhts_micro_step_tape_bytes": (C.c_size_t, [C.POINTER(MicroDesc)]),
     "dhts_micro_rollout_fwd": (C.c_int, [C.POINTER(MicroDesc), C.c_int] + [_P] * 11),

@@ -442,6 +442,61 @@ int dhts_net_hybrid_state_rollout_bwd(const dhts_net_desc *d, const dhts_hybrid_
                                       const float *g_reward, const float *g_stateT, const float *g_veh, float *g_action,
                                       float *g_state0, const void *workspace, dhts_error *err, void *stream);
 
+/* ---- Road networks of ANY size and ANY mix of ARZ / IDM lanes, step by step (round 5) ------------------------------------------
+ * dhts_net_hybrid_rollout_* keep a replica in one workgroup (cells + lanes <= 960, <= 64 IDM lanes, <= 128 vehicles); the
+ * reference's environment builds any grid in any mode (example/control/itscp/_env.py:221-506: `--lane_length`, `--n_lane`,
+ * `--n_intersection` are free).  dhts_netstep_rollout_fwd / _bwd run such an episode step by step, every step a handful of
+ * launches over flat device arrays, all T steps inside ONE call (no host round trip, no per-step Python):
+ *   boundary   ghost cells of every ARZ lane (ItscpRoadNetwork.setup_macro_boundary, _simulator.py:56-137) | admission of
+ *              waiting vehicles on micro source lanes (:153-174), head gap of every occupied IDM lane (:139-276 over
+ *              RoadNetwork.setup_micro_boundary, road_network.py:429-580; forward-mode duals w.r.t. the head vehicle, its
+ *              leader and the three signals it can see) and the IDM step of every vehicle (dMicroForwardLayer,
+ *              dmicro_lane.py:230-269) -- one launch;
+ *   lanes      dhts_macro_step_fwd once per group of ARZ lanes of equal (cells, cell length): dMacroForwardLayer for the batch;
+ *   hand-offs  flux capacitors, then spawn / lane change / despawn / deposit in lane-id order (RoadNetwork.conversion,
+ *              road_network.py:113-170; conversion.py:11-215) with an event list for the reverse sweep, then the queue loss of
+ *              the committed state with its RunningMean(100 000) (_env.py:586-618, 664-742) -- one launch.
+ * The reverse sweep undoes them newest first (loss taps -> events -> IDM / head gaps -> dhts_macro_step_bwd per group -> ghost
+ * cotangents to the neighbours' edge cells, the stored ghosts and the action).  Nothing is fused across steps: a step costs its
+ * launches (~2 + groups forward, ~3 + groups backward), which is what makes any size run; networks inside the limits above
+ * are ~10 x faster through dhts_net_hybrid_rollout_*.
+ * Tables: dhts_hybrid_tables in the network's own lane ids (conversions, loss samples and running means follow lane-id order),
+ * EXCEPT that cells are stored GROUP-MAJOR: hyb.net.lane_off[l] is the first cell of lane l in an order where the lanes of a
+ * group are contiguous (the batched operator works on the state arrays in place); lane_gpos[l] is the lane's row in that order
+ * (ghost rows).  hyb.lane_capacity = vehicles a micro lane holds (any value 1 .. 1024; DHTS_FAULT_CAPACITY beyond), no limit on
+ * the number of micro lanes, spawning lanes or vehicles.  n_replicas must be 1.
+ *   hist   [T + 1][4][C] float32 out: (r, y, u, u_eq) of every cell before step t (row 0: the empty road)
+ *   queue  [T][L] out; reward [2] out = (- sum of all queue terms, the same over the first loss_steps steps)
+ *   counts [4] int32 out = (vehicles spawned or admitted, vehicles deposited, hand-off events, admission draws consumed)
+ * hard != 0: an evaluation episode (hard thresholds, see dhts_net_hybrid_rollout_eval); nothing is kept for a reverse sweep.
+ * _bwd: g_reward [1] or NULL (= 1) -> g_action [n_action] (gradient of reward[1]). */
+typedef struct dhts_netstep_group {
+    int32_t lane_pos0;   /* first row of the group in the group-major lane order */
+    int32_t n_lanes;     /* lanes in the group */
+    int32_t n_cells;     /* cells per lane */
+    int32_t cell0;       /* first cell of the group */
+    double dx;           /* cell length */
+} dhts_netstep_group;
+typedef struct dhts_netstep_tables {
+    dhts_hybrid_tables hyb;
+    const int32_t *lane_gpos;          /* [L] device: row of macro lane l in the group-major lane order (-1: micro lane) */
+    const dhts_netstep_group *groups;  /* HOST pointer */
+    int32_t n_groups;
+    const int32_t *micro_lanes;        /* [hyb.n_micro] device: ids of the micro lanes, ascending */
+    const int32_t *lane_mslot;         /* [L] device: position of lane l in micro_lanes (-1: macro lane) */
+    const int32_t *cap_lanes;          /* [n_caps] device: macro lanes with a micro successor (flux capacitors), ascending */
+    const int32_t *lane_cslot;         /* [L] device: position of lane l in cap_lanes (-1: none) */
+    int32_t n_caps;
+    const int32_t *inter_ptr, *inter_idx; /* device: ghost slots (2 lane + side) of every intersection, ascending ([sq + 1], [..]) */
+    int32_t max_events;                /* capacity of the hand-off event list of an episode (0 = 8 per step) */
+} dhts_netstep_tables;
+size_t dhts_netstep_workspace_bytes(const dhts_net_desc *d, const dhts_netstep_tables *t);
+int dhts_netstep_rollout_fwd(const dhts_net_desc *d, const dhts_netstep_tables *t, int hard, const float *action, float *hist,
+                             float *queue, float *reward, int32_t *counts, void *workspace, dhts_error *err, void *stream);
+int dhts_netstep_rollout_bwd(const dhts_net_desc *d, const dhts_netstep_tables *t, const float *action, const float *hist,
+                             const float *queue, const float *g_reward, float *g_action, void *workspace, dhts_error *err,
+                             void *stream);
+
 #ifdef __cplusplus
 }
 #endif

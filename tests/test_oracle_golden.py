@@ -198,7 +198,10 @@ def itscp_hybrid_tables(g):
 FULL_HORIZON_600 = ["hybrid_half", "hybrid_s2", "hybrid_s3", "hybrid_p2_600"]     # run_itscp_hybrid.sh's episode, 600 steps
 
 
-@pytest.mark.parametrize("name", ["hybrid_short", "hybrid_p2", "hybrid_p3", "hybrid_l10", "hybrid_n2", "hybrid_4x4", "hybrid"] + FULL_HORIZON_600)
+# round 5: hybrid_l30 (30 m lanes), hybrid_5x5 (144 IDM lanes) and hybrid_n2l30 (252 lanes + 1 300 cells) pin the oracle where the
+# fused kernels do not reach (or only just): the stepwise device path is judged by it there
+@pytest.mark.parametrize("name", ["hybrid_short", "hybrid_p2", "hybrid_p3", "hybrid_l10", "hybrid_n2", "hybrid_4x4", "hybrid", "hybrid_l30",
+                                  "hybrid_5x5", "hybrid_n2l30"] + FULL_HORIZON_600)
 def test_itscp_hybrid_network(oracle, golden_dir, name):
     """G8 hybrid: macro lanes, micro lanes, spawns, lane changes and deposits against the reference's own run.
     FULL_HORIZON_600 = four reference runs of BASELINE config 4's exact episode (3 x 3 intersections, 1 lane, 5 m, 20 s,
@@ -269,7 +272,7 @@ def itscp_micro_tables(g):
     return t, m, np.asarray(rows, dtype=np.int32)
 
 
-@pytest.mark.parametrize("name", ["micro_small", "micro"])
+@pytest.mark.parametrize("name", ["micro_small", "micro", "micro_2x2"])
 def test_itscp_micro_mode_network(oracle, golden_dir, name):
     """itscp `micro` mode (run_itscp_micro.sh: 40 IDM lanes, 65 vehicles admitted stochastically over 300 steps; and a 16-lane
     case): source lanes admit waiting vehicles against the host's recorded draws (_simulator.py:153-174), every recorded draw

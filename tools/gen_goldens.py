@@ -912,6 +912,29 @@ def main():
             gen_itscp("hybrid_n2", "hybrid", 3, 2, 5.0, 8, 2, seed=37, action_kind="rand", problem=1)
         if "eval_hybrid_4x4" in which:
             gen_itscp("eval_hybrid_4x4", "hybrid", 4, 1, 5.0, 8, 2, seed=29, action_kind="rand", problem=2, differentiable=False)
+        # networks ABOVE the fused kernels' per-workgroup limits (round 5: pins of the stepwise batched path and of the
+        # oracle at sizes only the oracle used to judge): 360 macro lanes / 1 692 cells; 30 m lanes in hybrid mode
+        # (~1 000 cells + 144 lanes); 5 x 5 intersections (144 IDM lanes); micro mode with 112 IDM lanes
+        if "macro_3x3x3" in which:
+            os.environ["DHTS_FINE_CUTS"] = "60,90"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("macro_3x3x3", "macro", 3, 3, 30.0, 4, 2, seed=61, action_kind="rand", problem=2)
+        if "hybrid_l30" in which:
+            os.environ["DHTS_FINE_CUTS"] = "120,200"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("hybrid_l30", "hybrid", 3, 1, 30.0, 8, 2, seed=71, action_kind="rand", problem=2)
+        if "hybrid_n2l30" in which:      # two lanes per approach, 30 m lanes: 252 lanes + ~1 300 cells (beyond one workgroup)
+            os.environ["DHTS_FINE_CUTS"] = "120,200"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("hybrid_n2l30", "hybrid", 3, 2, 30.0, 8, 2, seed=79, action_kind="rand", problem=1)
+        if "hybrid_5x5" in which:
+            os.environ["DHTS_FINE_CUTS"] = "120,200"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("hybrid_5x5", "hybrid", 5, 1, 5.0, 8, 2, seed=73, action_kind="rand", problem=1)
+        if "micro_2x2" in which:
+            os.environ["DHTS_FINE_CUTS"] = "60"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("micro_2x2", "micro", 2, 2, 10.0, 4, 1, seed=83, action_kind="rand", problem=3)
         if "hybrid_short" in which:      # 8 s: enough for the first vehicles to cross the interior intersection
             gen_itscp("hybrid_short", "hybrid", 3, 1, 5.0, 8, 2, seed=9, action_kind="rand")
 
