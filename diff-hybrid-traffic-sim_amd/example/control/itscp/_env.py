@@ -273,6 +273,7 @@ class ItscpEnv:
                                       "or set config['fused'] = False to step lane by lane")
         reward = self._step_fused(action, differentiable)
         if reward is None:
+            self.last_path = "lane-by-lane"
             self._own_lanes()                       # (an episode_copy() twin: the lane-by-lane path moves the lane objects)
             self._simulate(action, differentiable)
             reward = self._reward(action)
@@ -292,64 +293,14 @@ class ItscpEnv:
             return None
         if not (isinstance(action, th.Tensor) and action.is_cuda):
             return None
-        from dhts import ops
-        from dhts.network import HybridNetworkTables, MacroNetworkTables
+        from dhts import _lib, ops
         sim = self.simulator
         if any(sl.is_micro() and sl.num_vehicle() for sl in sim.lane.values()):
             return None
         cache = getattr(self, "_fused_cache", None)
         lane_cap = getattr(self, "_fused_lane_capacity", 0)     # vehicles a micro lane holds (0 = the kernels' default 16)
         if cache is None:
-            try:
-                T = self.num_timestep
-                n_cells = sum(getattr(sl, "num_cell", 0) for sl in sim.lane.values() if sl.is_macro())
-                if self.config["mode"] == "macro" and n_cells + len(sim.lane) <= 1024:
-                    cache = ("macro", ops.DeviceNetTables(MacroNetworkTables.from_env(self), action.device))
-                elif self.config["mode"] == "macro":
-                    # more cells + lanes than one workgroup holds (e.g. --n_intersection=3 --n_lane=3: 360 lanes, ~2 100 cells): all
-                    # lanes as the batch of the straight-lane step operator, one call per step (dhts/batched.py)
-                    from dhts.batched import BatchedMacroNetwork
-                    tabs = MacroNetworkTables.from_env(self)
-                    net = getattr(self, "_batched_net", None)           # survives reset(): same topology, new schedules / routes
-                    try:
-                        if net is None:
-                            raise ValueError
-                        net.update(tabs)                                # in place: an episode captured as a HIP graph stays valid
-                    except ValueError:
-                        net = self._batched_net = BatchedMacroNetwork(tabs, action.device)
-                    cache = ("batched", net)
-                elif self.config["mode"] == "micro":
-                    # every lane an IDM lane; source lanes admit their waiting vehicles against np.random draws
-                    # (_simulator.py:153-174): the waiting routes in admission order (the list is popped from its end) are
-                    # the route rows, the draws of the episode are drawn up front (fused_draws replays a recorded stream)
-                    tab = HybridNetworkTables.from_env(self)
-                    rows = []
-                    for l in range(tab.n_lanes):
-                        for r in reversed(sim.lane_waiting_micro_route.get(l, [])):
-                            r = list(r.route)[:32]
-                            rows.append(r + [-1] * (32 - len(r)))
-                    # (more rows than the 128 vehicles a fused episode holds are fine: only the admitted ones count, and an
-                    # episode that admits more comes back as ops.CapacityError below)
-                    self._fused_n_draws = T * max(1, int(tab.lane_source.sum()))
-                    tab.set_micro_sources(np.full(self._fused_n_draws, 2.0))
-                    cache = ("micro", ops.DeviceHybridTables(tab, np.asarray(rows if rows else [[-1, -1]], dtype=np.int32), action.device,
-                                                             lane_capacity=lane_cap))
-                else:
-                    tab = HybridNetworkTables.from_env(self)
-                    routes = getattr(self, "fused_routes", None)
-                    if routes is None:
-                        routes = []
-                        for l in range(tab.n_lanes):
-                            if tab.lane_macro[l] == 0 and any(tab.lane_macro[a] for a in tab.prev_lanes[l]):
-                                for _ in range(8):
-                                    r = list(sim.create_random_route(l).route)[:32]
-                                    routes.append(r + [-1] * (32 - len(r)))
-                        if not routes:
-                            routes = [[-1, -1]]
-                    cache = ("hybrid", ops.DeviceHybridTables(tab, np.asarray(routes, dtype=np.int32), action.device, lane_capacity=lane_cap))
-            except ValueError:
-                cache = ("none", None)
-            self._fused_cache = cache
+            cache = self._fused_cache = self._build_fused_cache(action.device, lane_cap)
         kind, tab = cache
         if kind == "none":
             return None
@@ -357,7 +308,8 @@ class ItscpEnv:
                 1.0 / self.config["simulation_frequency"], self.simulator.speed_limit, self.config["static_speed"],
                 self.simulator.vehicle_length)
         a = action.reshape(1, -1)
-        if kind == "micro":
+        draws = None
+        if self.config["mode"] == "micro" and kind in ("micro", "stepwise"):
             draws = getattr(self, "fused_draws", None)
             pending = self.__dict__.pop("_fused_pending_draws", None)
             if pending is not None:
@@ -373,7 +325,7 @@ class ItscpEnv:
                     try:                                    # the whole episode as one HIP graph (captured at the first call)
                         reward, queue = tab.graphed_rollout(a[0], *args, differentiable=differentiable)
                     except RuntimeError as e:
-                        if isinstance(e, ops.CapacityError):
+                        if isinstance(e, ops.CapacityError) or "capture" not in str(e).lower():
                             raise
                         import warnings
                         warnings.warn("ItscpEnv: HIP-graph capture of the batched episode failed (%s); running it eagerly" % e)
@@ -382,6 +334,12 @@ class ItscpEnv:
                 else:
                     reward, queue = tab.rollout(a[0], *args, differentiable=differentiable)
                 reward, queue = reward.reshape(1), queue.unsqueeze(0)
+            elif kind == "stepwise":
+                # a network beyond one workgroup (or an episode beyond the fused kernels' vehicle capacities): step by step on the
+                # device, all lanes at once (dhts/stepwise.py)
+                cut, _, queue, counts = tab.rollout(a[0], *args, differentiable=differentiable)
+                reward, queue = cut.reshape(1), queue.unsqueeze(0)
+                self.fused_counts = counts.tolist()
             elif kind == "macro":
                 reward, queue = ops.net_macro_rollout(a, tab, *args) if differentiable else ops.net_macro_eval(a, tab, *args)
             elif differentiable:
@@ -390,26 +348,35 @@ class ItscpEnv:
             else:
                 reward, queue, counts = ops.net_hybrid_eval(a, tab, *args)
                 self.fused_counts = counts[0].tolist()
-        except ops.CapacityError as e:
-            # First the same episode with room for more vehicles per micro lane (a per-launch LDS sizing, include/dhts.h:
-            # dhts_hybrid_tables::lane_capacity; 16 -> 128 at most, config "fused_max_lane_capacity"): nothing on the host was
-            # touched by the attempt, the tables are rebuilt once and kept.
-            nxt_cap = 128
-            if kind in ("micro", "hybrid") and lane_cap < nxt_cap <= int(self.config.get("fused_max_lane_capacity", 128)):
-                self._fused_lane_capacity = nxt_cap
+        except (ops.CapacityError, _lib.DhtsError) as e:
+            # The episode needs more than this launch was sized for (vehicles per micro lane, vehicles per episode, records), or the
+            # sizing does not fit one workgroup's LDS (DhtsError).  Nothing on the host was touched by the attempt; the ladder is
+            #   fused kernels at 16 vehicles per lane -> fused at 128 -> stepwise device path at 128 -> stepwise at 1024 -> lane by lane,
+            # every rung the SAME episode: same drawn routes (kept in _fused_routes_drawn), same admission draws.
+            ladder = [("fused", 16), ("fused", 128), ("stepwise", 128), ("stepwise", 1024)]
+            here = ("stepwise" if kind == "stepwise" else "fused", lane_cap if lane_cap else (16 if kind != "stepwise" else 32))
+            nxt = None
+            if kind in ("micro", "hybrid", "stepwise"):
+                for rung in ladder:
+                    if (rung[0] == "stepwise", rung[1]) > (here[0] == "stepwise", here[1]) and rung[1] <= int(self.config.get("fused_max_lane_capacity", 1024)):
+                        nxt = rung
+                        break
+            if nxt is not None:
+                self._fused_lane_capacity = nxt[1]
+                self._fused_prefer_stepwise = nxt[0] == "stepwise"
                 self._fused_cache = None
-                if kind == "micro":
+                if draws is not None:
                     self._fused_pending_draws = draws          # the retry is the same episode: the same admission draws
                 return self._step_fused(action, differentiable)
             # The reference has no such limits (_micro_lane.py:53-113): this episode runs lane by lane instead (minutes, not
-            # milliseconds).  Nothing on the host was touched by the attempt; in `micro` mode the admission draws the kernels were
-            # given are replayed, so that the episode is the one that was asked for.
+            # milliseconds).  In `micro` mode the admission draws the kernels were given are replayed, so that the episode is the one
+            # that was asked for.
             if not getattr(self, "_fused_overflow_warned", False):
                 self._fused_overflow_warned = True
                 import warnings
-                warnings.warn("ItscpEnv: the fused kernels' capacity was exceeded (%s); this episode runs lane by lane" % e)
+                warnings.warn("ItscpEnv: the device paths' capacity was exceeded (%s); this episode runs lane by lane" % e)
             self._own_lanes()                       # (an episode_copy() twin: from here on the lane objects are written to)
-            if kind == "micro":
+            if draws is not None:
                 it = iter(np.asarray(draws, dtype=np.float64).tolist())
 
                 def replay():
@@ -418,6 +385,7 @@ class ItscpEnv:
                 self.simulator.random_draw = replay
             self.fused_overflowed = True
             return None
+        self.last_path = {"macro": "fused", "hybrid": "fused", "micro": "fused"}.get(kind, kind)
         q = np.ascontiguousarray(queue[0].detach().cpu().numpy().T)      # [L][T]
         for i, lid in enumerate(self.lane.keys()):
             self.queue_length[lid] = q[i].tolist()              # (Python floats like the lane-by-lane path's, converted in C)
@@ -425,6 +393,91 @@ class ItscpEnv:
         self.time = self.num_timestep
         self._fused_done = True
         return (-self.reward_queue_c) * reward[0]
+
+    def _build_fused_cache(self, device, lane_cap):
+        """(kind, device tables) of this episode: "macro" / "hybrid" / "micro" = the fused kernels (one workgroup per network),
+        "batched" / "stepwise" = the step-by-step device paths for networks beyond that (dhts/batched.py, dhts/stepwise.py),
+        ("none", None) = lane by lane."""
+        from dhts import ops
+        from dhts.network import HybridNetworkTables, MacroNetworkTables
+        sim = self.simulator
+        mode = self.config["mode"]
+        T = self.num_timestep
+        try:
+            n_cells = sum(getattr(sl, "num_cell", 0) for sl in sim.lane.values() if sl.is_macro())
+            if mode == "macro" and n_cells + len(sim.lane) <= 1024:
+                return ("macro", ops.DeviceNetTables(MacroNetworkTables.from_env(self), device))
+            if mode == "macro":
+                # more cells + lanes than one workgroup holds (e.g. --n_intersection=3 --n_lane=3: 360 lanes, ~1 700 cells): all lanes
+                # as the batch of the straight-lane step operator, one call per step (dhts/batched.py; config "macro_path" = "stepwise"
+                # takes dhts/stepwise.py instead)
+                tabs = MacroNetworkTables.from_env(self)
+                if self.config.get("macro_path", "batched") == "stepwise":
+                    return ("stepwise", self._stepwise_net(tabs, np.asarray([[-1, -1]], dtype=np.int32), device, 32))
+                from dhts.batched import BatchedMacroNetwork
+                net = getattr(self, "_batched_net", None)           # survives reset(): same topology, new schedules / routes
+                try:
+                    if net is None:
+                        raise ValueError
+                    net.update(tabs)                                # in place: an episode captured as a HIP graph stays valid
+                except ValueError:
+                    net = self._batched_net = BatchedMacroNetwork(tabs, device)
+                return ("batched", net)
+            tab = HybridNetworkTables.from_env(self)
+            if mode == "micro":
+                # every lane an IDM lane; source lanes admit their waiting vehicles against np.random draws
+                # (_simulator.py:153-174): the waiting routes in admission order (the list is popped from its end) are
+                # the route rows, the draws of the episode are drawn up front (fused_draws replays a recorded stream)
+                rows = []
+                for l in range(tab.n_lanes):
+                    for r in reversed(sim.lane_waiting_micro_route.get(l, [])):
+                        r = list(r.route)[:32]
+                        rows.append(r + [-1] * (32 - len(r)))
+                routes = np.asarray(rows if rows else [[-1, -1]], dtype=np.int32)
+                self._fused_n_draws = T * max(1, int(tab.lane_source.sum()))
+                tab.set_micro_sources(np.full(self._fused_n_draws, 2.0))
+            else:
+                routes = getattr(self, "fused_routes", None)
+                if routes is None:
+                    routes = getattr(self, "_fused_routes_drawn", None)      # (a capacity retry is the same episode: the same routes)
+                if routes is None:
+                    routes = []
+                    for l in range(tab.n_lanes):
+                        if tab.lane_macro[l] == 0 and any(tab.lane_macro[a] for a in tab.prev_lanes[l]):
+                            for _ in range(8):
+                                r = list(sim.create_random_route(l).route)[:32]
+                                routes.append(r + [-1] * (32 - len(r)))
+                    if not routes:
+                        routes = [[-1, -1]]
+                    self._fused_routes_drawn = routes
+                routes = np.asarray(routes, dtype=np.int32)
+            fits = True
+            try:
+                tab.check_kernel_limits()
+            except ValueError:
+                fits = False
+            if fits and not getattr(self, "_fused_prefer_stepwise", False) and lane_cap in (0, 16, 32, 64, 128):
+                return (mode, ops.DeviceHybridTables(tab, routes, device, lane_capacity=lane_cap))
+            # beyond one workgroup (cells + lanes > 960, > 64 IDM lanes, > 16 spawning lanes) or beyond the fused kernels' vehicle
+            # capacities: step by step on the device (dhts/stepwise.py)
+            return ("stepwise", self._stepwise_net(tab, routes, device, lane_cap if lane_cap else 32))
+        except ValueError:
+            return ("none", None)
+
+    def _stepwise_net(self, tab, routes, device, lane_cap):
+        from dhts.stepwise import StepwiseNetwork
+        net = getattr(self, "_stepwise_cache", None)            # survives reset(): same topology -> tables updated in place
+        if net is not None and net[1] == (lane_cap, routes.shape, routes.tobytes()):
+            try:
+                net[0].update(tab)
+                if tab.lane_source.any():
+                    net[0].t.draws = tab.draws
+                return net[0]
+            except ValueError:
+                pass
+        sw = StepwiseNetwork(tab, routes, device, lane_capacity=lane_cap)
+        self._stepwise_cache = (sw, (lane_cap, routes.shape, routes.tobytes()))
+        return sw
 
     def _simulate(self, action, differentiable):
         self.time = 0

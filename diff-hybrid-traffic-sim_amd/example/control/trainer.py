@@ -7,6 +7,9 @@ Same surface and on-disk formats as the reference's Trainer:
   <log_path>/model.zip         th.save({"controller_state_dict", "optimizer_state_dict"})      (trainer.py:213-216)
   <log_path>/best/model.zip    the same, at the best evaluation so far                        (trainer.py:134-142)
 Scalars "loss/train" and "loss/eval" go to TensorBoard when it is installed, else to <log_path>/scalars.tsv.
+<log_path>/paths.txt (this build only) says, per epoch, which path the episodes took: "fused" (one workgroup per network, two
+launches per episode), "batched" / "stepwise" (step by step on the device: networks beyond one workgroup) or "lane-by-lane" (the
+operator per lane and step: minutes per episode) -- so that a flag that moves a run off the fast path is visible in its logs.
 
 What differs, on purpose: the controller and the action live on the GPU and env.step(action, True) runs the fused network
 kernels, so a training episode is two kernel launches; instead of deep-copying the environment for every episode
@@ -47,6 +50,13 @@ class Trainer:
         self.optimizer = th.optim.Adam(self.controller.parameters(), lr)
         self.best_eval_result = -float("inf")
         self.writer = None
+        self.paths = {}                                   # (kind, path) -> episodes since the last log line
+
+    def _log_paths(self, epoch, log_path):
+        if self.paths:
+            with open(log_path + "/paths.txt", "a") as f:
+                f.write("epoch {} {}\n".format(epoch, " ".join("{}:{}={}".format(k[0], k[1], n) for k, n in sorted(self.paths.items()))))
+            self.paths = {}
 
     def train(self, num_episode_per_epoch, num_epoch, num_eval_epoch, num_eval_episode, log_path, progress=True):
         os.makedirs(log_path, exist_ok=True)
@@ -69,6 +79,7 @@ class Trainer:
             if bar is not None:
                 bar.set_description("Loss: {:.6f}".format(float(loss)))
             self.save(log_path + "/model.zip")
+            self._log_paths(epoch, log_path)
 
     def evaluate(self, epoch, num_episode, log_path):
         self.controller.train(False)
@@ -125,6 +136,8 @@ class Trainer:
             episode_reward = episode_reward + reward
             if terminal:
                 break
+        key = ("train" if differentiable else "eval", getattr(env, "last_path", "lane-by-lane"))
+        self.paths[key] = self.paths.get(key, 0) + 1
         return episode_reward, action, info
 
     def save(self, path):

@@ -18,7 +18,7 @@ def _args(m):
             m["speed_limit"], m["static_speed"], m["vehicle_length"])
 
 
-@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "macro_half", "macro_long"])
+@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "macro_half", "macro_long", "macro_3x3x3"])
 def test_batched_network_vs_reference(cuda, golden_dir, name):
     import torch
     from dhts import ops
@@ -38,6 +38,8 @@ def test_batched_network_vs_reference(cuda, golden_dir, name):
     r3.backward()
     assert rel_max(queue.detach().cpu().numpy(), q3.detach().cpu().numpy()) <= 1e-6
     assert rel_max(action.grad.cpu().numpy(), a3.grad.cpu().numpy()) <= 1e-5
+    if tab.n_cells + tab.n_lanes > 1024:          # (macro_3x3x3: 360 lanes + 2 124 cells, beyond one workgroup -- the reference's own run
+        return                                    # above is this network's pin; round 5)
     # and the fused one-workgroup kernels give the same episode
     a2 = torch.tensor(g["action"][None], device=cuda, requires_grad=True)
     r2, q2 = ops.net_macro_rollout(a2, ops.DeviceNetTables(tab, cuda), *_args(m))

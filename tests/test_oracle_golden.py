@@ -149,7 +149,7 @@ def itscp_tables(g):
     return MacroNetworkTables(tab[:, 3].astype(int), tab[:, 2], g["edges"], kinds, inter, g["macro_route"], g["schedule"]), m
 
 
-@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "macro_half", "macro_long"])
+@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "macro_half", "macro_long", "macro_3x3x3"])
 def test_itscp_macro_network(oracle, golden_dir, name):
     g = load(golden_dir, "itscp_%s.npz" % name)
     t, m = itscp_tables(g)

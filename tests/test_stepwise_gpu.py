@@ -185,3 +185,48 @@ def test_stepwise_episode_time(cuda, golden_dir):
     dt_ = (time.perf_counter() - t0) / 3
     print("stepwise differentiable episode (%s: %d lanes, %d cells, %d steps): %.1f ms" % (os.path.basename(path), t.n_lanes, t.n_cells, t.T, 1e3 * dt_))
     assert dt_ <= 0.3
+
+
+@pytest.mark.parametrize("name", ["hybrid_n2l30", "hybrid_5x5", "micro_2x2", "macro_3x3x3"])
+def test_env_step_takes_the_stepwise_path_beyond_the_fused_limits(cuda, golden_dir, name):
+    """ItscpEnv.step(action, True) -- the reference's entry point (trainer.py:172-190) -- on networks the fused kernels cannot hold
+    (252 lanes + 1 152 cells; 144 IDM lanes; 112 IDM lanes in `micro` mode; 360 lanes + 2 124 cells in `macro` mode): the episode
+    runs on the stepwise device path (macro mode: on request, the batched-lane path stays the default there) and reproduces the
+    reference's run; so does the evaluation episode's reward against the stepwise rollout with hard thresholds."""
+    import torch
+    from test_itscp_gpu import build_env
+    from test_oracle_golden import meta_of
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    m = meta_of(g)
+    micro = name.startswith("micro")
+    env = build_env(g, m, replay_routes=not micro)
+    if name.startswith("hybrid"):
+        env.fused_routes = g["spawn_routes"]
+    if micro:
+        env.fused_draws = g["rand_draws"]
+    if name.startswith("macro"):
+        env.config["macro_path"] = "stepwise"
+    keys = list(env.lane.keys())
+    action = torch.tensor(g["action"], device=cuda, requires_grad=True)
+    t0 = time.perf_counter()
+    obs, reward, done, info = env.step(action, True)
+    reward.backward()
+    grad = action.grad.cpu().numpy()
+    t1 = time.perf_counter()
+    assert env._fused_cache[0] == "stepwise" and env._fused_done and env.last_path == "stepwise"
+    queue = np.array([env.queue_length[k] for k in keys])
+    tol_q = 1e-4 if micro else TOL_STATE
+    assert state_report("env.step %s: queues vs reference" % name, queue, g["queue"]) <= tol_q
+    assert abs(float(reward.detach()) - float(g["reward"])) <= (1e-4 if micro else 1e-5) * abs(float(g["reward"]))
+    assert np.abs(grad - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()
+    if not name.startswith("macro"):
+        assert env.fused_counts[0] == m["n_vehicle_spawned"]
+    print("env.step %s on the stepwise path: %.1f ms (first call: tables built and uploaded)" % (name, 1e3 * (t1 - t0)))
+    # an evaluation episode on a twin (Trainer.evaluate)
+    env.rewind()
+    twin = env.episode_copy()
+    if micro:
+        twin.fused_draws = g["rand_draws"]
+    with torch.no_grad():
+        _, r_eval, _, _ = twin.step(action.detach(), False)
+    assert twin.last_path == "stepwise" and np.isfinite(float(r_eval))
