@@ -779,6 +779,25 @@ def main():
         local_part = flat.clone() if world > 1 else None
         D.allreduce_sum_(flat)
         return local_part
+    # The pair kernel's priority rotation (DHTS_OPT_MACRO_FWD_ROTATE, include/dhts.h) encodes an observation about this pool's
+    # dispatcher; correctness does not depend on it, speed may: three untimed passes with it, three without, before the warm-up,
+    # and the run takes what this box prefers (reported as roofline.fwd_rotate)
+    rotate_rec = None
+    if args.workload == "macro" and dev.type == "cuda":
+        from dhts import _lib as _L
+        ms = {}
+        for setting in (1, 0):
+            _L.lib().dhts_set_option(_L.OPT_MACRO_FWD_ROTATE, setting)
+            w.one_pass()
+            sync()
+            tq = time.perf_counter()
+            for _ in range(3):
+                w.one_pass()
+            sync()
+            ms[setting] = (time.perf_counter() - tq) / 3 * 1e3
+        chosen = 1 if ms[1] <= ms[0] else 0
+        _L.lib().dhts_set_option(_L.OPT_MACRO_FWD_ROTATE, chosen)
+        rotate_rec = {"ms_per_pass_with": ms[1], "ms_per_pass_without": ms[0], "chosen": chosen}
     for _ in range(args.warmup):
         loss, g_a, _ = w.one_pass()
         reduce_pass(loss, g_a)
@@ -848,6 +867,8 @@ def main():
         }
         if hasattr(w, "tape_census"):
             out["roofline"]["tape_census"] = w.tape_census()
+        if rotate_rec is not None:
+            out["roofline"]["fwd_rotate"] = rotate_rec
         side = issue_counters(w, dom)
         if side is not None:
             out["roofline"]["issue_side"] = side

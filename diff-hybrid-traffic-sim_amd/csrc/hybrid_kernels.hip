@@ -347,7 +347,7 @@ __host__ __device__ inline int hyb_stage_h(int L, int C, int sq, int V, int NS, 
 // ---------------------------------------------------------------------------------------------------------------------
 // Four barriers per step (phases A: ghosts | head gaps, B: interface solves | IDM steps, C: cell updates, D: hand-offs | loss
 // constants).  Where a step goes (s_memtime stamps, -DDHTS_HYB_STAMPS build, 256 replicas of BASELINE config 4;
-// profiles/r03l_hybrid_phase_stamps.log): every phase is set by its slowest role -- the micro wave in A (head gaps, ~4 400 cycles)
+// profiles/archive/r03l_hybrid_phase_stamps.log): every phase is set by its slowest role -- the micro wave in A (head gaps, ~4 400 cycles)
 // and B (IDM steps, ~3 100), the lanes' cell waves in D (loss constants + lane sums, ~4 000-4 500) -- and a step by their sum,
 // ~14 700 cycles.  Round 3 took out what was not arithmetic on those paths: the cells' tape blocks (now formed by the reverse
 // sweep from an interface tape the interface threads write), the capacitors' chains of dependent LDS look-ups (static ones in
@@ -355,11 +355,11 @@ __host__ __device__ inline int hyb_stage_h(int L, int C, int sq, int V, int NS, 
 // dropped: phases B and C merged with a DPP hand-off of the right flux, (a) 63 slots per wavefront + a helper thread: config 4's
 // 384 slots then need a seventh wavefront, the one that also evaluates the vehicles' loss terms (3.97 ms); (b) 64 slots per
 // wavefront, the one seam cell per wavefront updated by the micro wave at the start of D (3.68 ms: the barrier's time comes
-// back as the longer phases of the roles that were already last; profiles/r03n_hybrid_seam_variant_stamps.log).
+// back as the longer phases of the roles that were already last; profiles/archive/r03n_hybrid_seam_variant_stamps.log).
 // What the differentiable forward pays beyond the evaluation kernel (2.18 ms: same dynamics, nothing kept), by ablation builds
-// (profiles/r03q_hybrid_forward_ablation.log): the micro side's records 0.47 ms (and 0.80 ms of the reverse sweep's 2.65), the
+// (profiles/archive/r03q_hybrid_forward_ablation.log): the micro side's records 0.47 ms (and 0.80 ms of the reverse sweep's 2.65), the
 // loss' ordered running mean with its constants 0.36 ms (0.22 in the reverse sweep), tape / history / vehicles' loss terms the
-// rest.  -O2 / -Os builds of this file run at the same speed (68 KB of code either way, profiles/r03p_hybrid_opt_levels.log).
+// rest.  -O2 / -Os builds of this file run at the same speed (68 KB of code either way, profiles/archive/r03p_hybrid_opt_levels.log).
 // Late in round 3 the step loop was split by role (below: two copies, 256 -> 193 vector registers, no spills): 3.67 -> 3.44 ms, the
 // evaluation kernel 2.08 -> 1.80 ms; the numbers above are of the single loop.
 // kHard: an EVALUATION episode (ItscpEnv.step(action, False); Trainer.evaluate, trainer.py:94-142): hard signals float(a > progress)

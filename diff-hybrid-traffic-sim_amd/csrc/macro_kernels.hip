@@ -477,7 +477,7 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
 // history): each lane keeps its own records, fluxes and queue -- phase 1 is the kernel above, per lane -- but phase 2 takes the
 // lanes' queues as one list (entry g belongs to the lane whose prefix sum of queue lengths it falls in).  At config 2 a lane
 // queues ~76 interfaces, which is two wavefronts' worth of the full solve's instruction stream (64 + 12 entries); a pair of lanes
-// needs three (64 + 64 + 24).  Measured at config 2 (MI355X, profiles/r03x_macro_fwd_lane_groups.log): one lane per workgroup
+// needs three (64 + 64 + 24).  Measured at config 2 (MI355X, profiles/archive/r03x_macro_fwd_lane_groups.log): one lane per workgroup
 // 3.29-3.39 ms, two 3.13-3.22 ms, four 3.15-3.34 ms (five wavefronts' worth for four lanes, but every barrier then spans 16 wavefronts).
 // Results and tape are bit-identical to the one-lane kernel's.  Dynamic LDS: kG regions of fwd2_region_bytes(N), one per lane.
 __host__ __device__ inline size_t fwd2_region_bytes(int N) {
@@ -1378,6 +1378,7 @@ static inline int grid_1d(int64_t n) {
 // forward kernel (0 = two-phase kernel, 1 = the one-phase kernel the single-step operator uses)
 static int dhts_fwd_waves_override = 0;
 static int dhts_fwd_variant = 0;
+static int dhts_fwd_rotate = 1;        // DHTS_OPT_MACRO_FWD_ROTATE: priority rotation between the two halves of the pair kernel's grid
 static int dhts_fwd_group = 0;         // DHTS_OPT_MACRO_FWD_GROUP: traffic lanes per workgroup in the two-phase forward kernel (0 = heuristic)
 static inline int padded64(int n) { return (n + 63) & ~63; }
 
@@ -1416,7 +1417,7 @@ static inline int macro_fwd2_group(const dhts_macro_desc *d, bool want_hist) {
 // for the lane-group kernel (four up to three wavefronts per lane, else two; one where the launch would leave CUs without a
 // workgroup or the lanes do not divide).  0 = not this kernel (DHTS_OPT_MACRO_FWD_VARIANT = 2 turns it off).
 static inline int macro_fwd3_group(const dhts_macro_desc *d, bool want_hist) {
-    if (dhts_fwd_variant != 0 || want_hist || d->n_cells % 128 != 0 || d->n_cells > 1024) return 0;
+    if (dhts_fwd_variant != 0 || want_hist || d->n_cells < 128 || d->n_cells % 128 != 0 || d->n_cells > 1024) return 0;
     const int W = d->n_cells / 128;
     if (dhts_fwd_waves_override > 0 && dhts_fwd_waves_override != W) return 0;       // (a forced wave count means the lane kernel)
     // lanes per workgroup: four for lanes of up to three wavefronts, one for four (1024 x 512: 2.59 against 2.65 ms for two,
@@ -1458,13 +1459,14 @@ static int macro_fwd2_launch(const dhts_macro_desc *d, int T,
     if (G3 > 0) {
         // the pair kernel: a thread owns two adjacent cells and their right interfaces (macro_fwd_pairs.inc)
         const size_t ldsg = (size_t)G3 * fwd3_region_bytes(N);
+#define DHTS_FWD3_ARGS d->n_lanes, N, T, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, reinterpret_cast<float4 *>(tape), err, dhts_fwd_rotate
 #define DHTS_FWDG_ARGS d->n_lanes, N, T, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, reinterpret_cast<float4 *>(tape), err
 #define DHTS_FWD3(GG, TT)                                                                                                         \
     {                                                                                                                             \
         if (ldsg > 64 * 1024 && hipFuncSetAttribute((const void *)macro_rollout_fwd3_kernel<GG, TT>,                              \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg) != hipSuccess)         \
             return DHTS_E_LAUNCH;                                                                                                 \
-        macro_rollout_fwd3_kernel<GG, TT><<<d->n_lanes / GG, 64 * GG * (N / 128), ldsg, (hipStream_t)stream>>>(DHTS_FWDG_ARGS);    \
+        macro_rollout_fwd3_kernel<GG, TT><<<d->n_lanes / GG, 64 * GG * (N / 128), ldsg, (hipStream_t)stream>>>(DHTS_FWD3_ARGS);    \
     }
         if (G3 == 1 && tape) DHTS_FWD3(1, true)
         else if (G3 == 1) DHTS_FWD3(1, false)
@@ -1623,6 +1625,10 @@ int dhts_set_option(int option, int value) {
     }
     if (option == DHTS_OPT_MACRO_FWD_VARIANT && value >= 0 && value <= 2) {
         dhts_fwd_variant = value;
+        return DHTS_OK;
+    }
+    if (option == DHTS_OPT_MACRO_FWD_ROTATE && (value == 0 || value == 1)) {
+        dhts_fwd_rotate = value;
         return DHTS_OK;
     }
     if (option == DHTS_OPT_MACRO_FWD_GROUP && (value == 0 || value == 1 || value == 2 || value == 4)) {

@@ -155,6 +155,36 @@ __global__ void idm_batch_kernel(int64_t n, int variant, const double *__restric
     }
 }
 
+// known-answer entry of the Jacobians ALONE, with the caller's optimal spacing and clip flags (dIDM.compute_dEgo / compute_dLeading
+// take them as arguments, didm.py:13-103: the reference's lane passes flags derived from the CLAMPED gap beside the un-clamped gap
+// itself, dmicro_lane.py:97).  in [12][n] double = a_max a_pref v v_target dp dv min_space time_pref optimal_spacing dt
+// clipped_acceleration clipped_optimal_spacing
+__global__ void idm_jac_batch_kernel(int64_t n, const double *__restrict__ in, float *__restrict__ dE, float *__restrict__ dLd) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double a_max = in[i], a_pref = in[n + i], v = in[2 * n + i], v_t = in[3 * n + i], dp = in[4 * n + i], dv = in[5 * n + i];
+        const double time_pref = in[7 * n + i], s = in[8 * n + i], dt = in[9 * n + i];
+        const bool clipped_a = in[10 * n + i] != 0., clipped_s = in[11 * n + i] != 0.;
+        float e[4] = {1.f, (float)dt, 0.f, 0.f}, l[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!clipped_a) {
+            const double dp2 = dp * dp, dp3 = dp2 * dp;
+            const double s2_dp3 = (s * s) / dp3, s_dp2 = s / dp2;
+            const double vt2 = v_t * v_t;
+            const double free_term = -4.0 * ((v * v * v) / (vt2 * vt2));
+            const double two_sqrt_ab = 2 * sqrt(a_max * a_pref);
+            e[2] = (float)(dt * (-2 * a_max * s2_dp3));
+            l[2] = (float)(dt * (2 * a_max * s2_dp3));
+            if (clipped_s) {
+                e[3] = (float)(1 + dt * a_max * free_term);
+                l[3] = (float)(dt * a_max * (-2 * s_dp2));
+            } else {
+                e[3] = (float)(1 + dt * a_max * (free_term - 2 * s_dp2 * (time_pref + ((v + dv) / two_sqrt_ab))));
+                l[3] = (float)(dt * a_max * (-2 * s_dp2 * (-v / two_sqrt_ab)));
+            }
+        }
+        for (int j = 0; j < 4; ++j) { dE[j * n + i] = e[j]; dLd[j * n + i] = l[j]; }
+    }
+}
+
 // grid = L workgroups of blockDim.x threads; dynamic LDS = 4 * (V + 2) floats
 template <bool kCompact>
 __global__ void micro_rollout_bwd_kernel(
@@ -384,6 +414,13 @@ int dhts_idm_batch(int64_t n, int variant, const double *in, double *next_pv, fl
     if (n == 0) return DHTS_OK;
     int64_t g = (n + 255) / 256;
     idm_batch_kernel<<<(int)(g > 2048 ? 2048 : g), 256, 0, (hipStream_t)stream>>>(n, variant, in, next_pv, dEgo, dLeading, collided, acc_sstar, clips);
+    return launch_status_m();
+}
+
+int dhts_idm_jac_batch(int64_t n, const double *in, float *dEgo, float *dLeading, void *stream) {
+    if (n <= 0 || !in || !dEgo || !dLeading) return DHTS_E_INVALID;
+    const int64_t blocks = (n + 255) / 256;
+    idm_jac_batch_kernel<<<(int)(blocks > 4096 ? 4096 : blocks), 256, 0, (hipStream_t)stream>>>(n, in, dEgo, dLeading);
     return launch_status_m();
 }
 

@@ -18,6 +18,7 @@ OPT_MACRO_FWD_WAVES = 1
 OPT_MICRO_FWD_WAVES = 2
 OPT_MACRO_FWD_VARIANT = 3
 OPT_MACRO_FWD_GROUP = 4
+OPT_MACRO_FWD_ROTATE = 5
 MACRO_MAX_CELLS = 4000
 MICRO_MAX_VEHICLES = 1024
 
@@ -77,6 +78,7 @@ SIGNATURES = {
     "dhts_macro_step_tape_bytes": (C.c_size_t, [C.POINTER(MacroDesc)]),
     "dhts_arz_interface_batch": (C.c_int, [C.c_int64, C.c_int, _P, C.c_double, C.c_double] + [_P] * 11),
     "dhts_idm_batch": (C.c_int, [C.c_int64, C.c_int] + [_P] * 8),
+    "dhts_idm_jac_batch": (C.c_int, [C.c_int64] + [_P] * 4),
     "dhts_macro_state_from_ru": (C.c_int, [C.c_int64, C.c_double, _P, _P, _P, _P, _P]),
     "dhts_macro_state_from_ru_bwd": (C.c_int, [C.c_int64, C.c_double, _P, _P, _P, _P, _P, _P]),
     "dhts_macro_u_tap_bwd": (C.c_int, [C.c_int64, C.c_double, _P, _P, _P, _P, _P, _P]),

@@ -108,7 +108,10 @@ class _NetStep(torch.autograd.Function):
                                                _addr(nr, co), _addr(ny, co), _addr(nu, co), _addr(nq, co),
                                                _addr(tape) if tape is not None else None, _addr(net.err), st), "dhts_macro_step_fwd")
             tapes.append(tape)
+        # what backward reads is snapshotted here: rollout() rebuilds the descriptors and the fault record on every call, and
+        # update() overwrites the per-step tables in place (a pending backward across an update() is refused below)
         ctx.net, ctx.step, ctx.tapes = net, int(step), tapes
+        ctx.desc, ctx.gdescs, ctx.err, ctx.inter, ctx.version = net.desc, [g["desc"] for g in net.groups], net.err, (net.inter_ptr, net.inter_idx), net._version
         ctx.save_for_backward(r, y, u, own, action)
         ctx.mark_non_differentiable(nu, nq)
         return nr, ny, own_out, nu, nq
@@ -116,19 +119,23 @@ class _NetStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_nr, g_ny, g_own, _g_nu, _g_nq):
         net = ctx.net
+        if ctx.tapes and ctx.tapes[0] is None:
+            raise RuntimeError("BatchedMacroNetwork: an evaluation episode (differentiable=False) keeps no tape to back-propagate through")
+        if net._version != ctx.version:
+            raise RuntimeError("BatchedMacroNetwork.update() overwrote the per-step tables this episode ran on: call backward() before update()")
         lib, st = _lib.lib(), ops._stream()
         r, y, u, own, action = ctx.saved_tensors
         g_nr, g_ny, g_own = g_nr.contiguous(), g_ny.contiguous(), g_own.contiguous()
         g_r, g_y = torch.empty_like(r), torch.empty_like(r)
         g_ghost = torch.zeros(net.L, 2, 2, dtype=torch.float64, device=r.device)
-        for g, tape in zip(net.groups, ctx.tapes):
+        for g, gdesc, tape in zip(net.groups, ctx.gdescs, ctx.tapes):
             co, lo = g["cell_off"], g["lane_off"]
-            _lib.check(lib.dhts_macro_step_bwd(C.byref(g["desc"]), _addr(tape), _addr(g_nr, co), _addr(g_ny, co), _addr(g_r, co), _addr(g_y, co),
-                                               C.c_void_p(g_ghost.data_ptr() + 8 * 4 * lo), _addr(net.err), st), "dhts_macro_step_bwd")
+            _lib.check(lib.dhts_macro_step_bwd(C.byref(gdesc), _addr(tape), _addr(g_nr, co), _addr(g_ny, co), _addr(g_r, co), _addr(g_y, co),
+                                               C.c_void_p(g_ghost.data_ptr() + 8 * 4 * lo), _addr(ctx.err), st), "dhts_macro_step_bwd")
         g_own_out = torch.empty_like(own)
         g_action = torch.zeros_like(action)
         scratch = torch.empty(net.L, 2, 4, dtype=torch.float32, device=r.device)
-        _lib.check(lib.dhts_net_ghosts_bwd(C.byref(net.desc), C.byref(net.dtab.c), _addr(net.inter_ptr), _addr(net.inter_idx), ctx.step,
+        _lib.check(lib.dhts_net_ghosts_bwd(C.byref(ctx.desc), C.byref(net.dtab.c), _addr(ctx.inter[0]), _addr(ctx.inter[1]), ctx.step,
                                            _addr(action), _addr(r), _addr(y), _addr(u), _addr(own), C.c_void_p(g_ghost.data_ptr()),
                                            _addr(g_own), _addr(g_own_out), _addr(g_r), _addr(g_y), _addr(g_action), _addr(scratch), st),
                    "dhts_net_ghosts_bwd")
@@ -197,6 +204,9 @@ class BatchedMacroNetwork:
         self.t, self.device = t, device
         L, Cn = t.n_lanes, t.n_cells
         self.L, self.T = L, t.T
+        self._version = 0                       # counts update() calls: a pending backward across one is refused (_NetStep.backward)
+        if L and int(np.min(t.inter)) < 0:
+            raise ValueError("BatchedMacroNetwork: every lane needs an intersection index >= 0 (tables.inter)")
         up = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=device)      # noqa: E731
         off, n = np.asarray(t.lane_off, dtype=np.int64), np.asarray(t.lane_ncell, dtype=np.int64)
         # groups of lanes with the same number of cells and the same cell length: one operator call each per step
@@ -275,6 +285,8 @@ class BatchedMacroNetwork:
         T = self.T if n_steps is None else int(n_steps)
         um = float(u_max)
         a = action.reshape(-1).to(torch.float32).contiguous()
+        if not differentiable:
+            a = a.detach()                      # an evaluation episode keeps no tape: no autograd node may be recorded for it
         if int(n_inter_sq) < self.n_inter_tab:
             raise ValueError("the tables name intersection %d but n_inter_sq = %d" % (self.n_inter_tab - 1, n_inter_sq))
         if self._csr_sq != int(n_inter_sq):          # the ghost slots (2 lane + side) of every intersection, ascending
@@ -298,11 +310,12 @@ class BatchedMacroNetwork:
         u, q = torch.full((Cn,), um, **f32), torch.full((Cn,), um, **f32)
         own = torch.stack([torch.zeros(L, **f32), torch.full((L,), um, **f32)], dim=-1).contiguous()     # stored downstream ghosts: no flow
         hr, hy, hu = [], [], []
-        for step in range(T):
-            r, y, own, u, q = _NetStep.apply(r, y, own, a, u, q, self, step, not differentiable)
-            hr.append(r)
-            hy.append(y)
-            hu.append(u)
+        with torch.set_grad_enabled(bool(differentiable) and torch.is_grad_enabled()):
+            for step in range(T):
+                r, y, own, u, q = _NetStep.apply(r, y, own, a, u, q, self, step, not differentiable)
+                hr.append(r)
+                hy.append(y)
+                hu.append(u)
         R_, Y_, U_ = torch.stack(hr), torch.stack(hy), torch.stack(hu)        # [T][C]: the state after every step
         if differentiable:
             U_ = _SpeedTap.apply(R_.reshape(-1), Y_.reshape(-1), U_.reshape(-1), um).reshape(T, Cn)      # u = u(r, y) of FullQ.set_r_y
@@ -323,6 +336,7 @@ class BatchedMacroNetwork:
         if not same:
             raise ValueError("BatchedMacroNetwork.update: the network's topology changed; build a new one")
         self.t = tables
+        self._version += 1
         order = np.argsort(self.lane_unsort.cpu().numpy())          # new lane i = old lane order[i]
         tp = permuted_tables(tables, order)
         self.tp = tp
@@ -351,8 +365,9 @@ class BatchedMacroNetwork:
             def episode():
                 if differentiable:
                     static_a.grad = None
-                    reward, queue = self.rollout(static_a, *args, differentiable=True, check_faults=False)
-                    (grad,) = torch.autograd.grad(reward, static_a)
+                    with torch.enable_grad():           # (the caller may sit under no_grad: the captured episode differentiates itself)
+                        reward, queue = self.rollout(static_a, *args, differentiable=True, check_faults=False)
+                        (grad,) = torch.autograd.grad(reward, static_a)
                     return reward.detach(), queue.detach(), grad
                 with torch.no_grad():
                     reward, queue = self.rollout(static_a, *args, differentiable=False, check_faults=False)

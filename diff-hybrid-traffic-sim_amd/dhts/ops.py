@@ -353,6 +353,7 @@ class MicroRollout(torch.autograd.Function):
         g_v = g_vT.contiguous() if g_vT is not None else torch.zeros(L, V, device=dev)
         gh = g_hist.contiguous() if (ctx.want_hist and g_hist is not None) else None
         err = ctx.err_bwd
+        err.zero_()                      # (first fault wins: a second backward with retain_graph must not report the first one's)
         g_p0, g_v0, g_head = micro_rollout_bwd(desc, T, ctx.tape, g_p, g_v, count=ctx.count, g_hist=gh, err=err)
         # The record only feeds a warning (the reference's micro backward returns NaNs silently, dmicro_lane.py:271-298): it is not
         # read back here -- that would be a host synchronisation per reverse sweep -- unless the gradient that is being returned
@@ -421,6 +422,20 @@ def idm_batch(inp, variant=0):
           "dhts_idm_batch")
     return dict(next_p=nxt[0], next_v=nxt[1], dEgo=dE.t().reshape(n, 2, 2), dLeading=dLd.t().reshape(n, 2, 2),
                 collided=col.bool(), acc=acs[0], sstar=acs[1], clipped_acc=clips[0].bool(), clipped_spacing=clips[1].bool())
+
+
+def idm_jac_batch(inp):
+    """inp: float64 [n][12] = a_max a_pref v v_target dp dv min_space time_pref optimal_spacing dt clipped_acceleration
+    clipped_optimal_spacing (CUDA) -> dEgo, dLeading [n][2][2] float32: dIDM.compute_dEgo / compute_dLeading with the CALLER's
+    optimal spacing and clip flags (reference didm.py:13-103)."""
+    if inp.dtype != torch.float64 or not inp.is_cuda or inp.dim() != 2 or inp.shape[1] != 12:
+        raise TypeError("inp must be a float64 CUDA tensor of shape [n][12]")
+    n, dev = inp.shape[0], inp.device
+    soa = inp.t().contiguous()
+    dE = torch.empty(4, n, dtype=torch.float32, device=dev)
+    dLd = torch.empty(4, n, dtype=torch.float32, device=dev)
+    check(_lib.lib().dhts_idm_jac_batch(n, _ptr(soa), _ptr(dE), _ptr(dLd), _stream()), "dhts_idm_jac_batch")
+    return dE.t().reshape(n, 2, 2), dLd.t().reshape(n, 2, 2)
 
 
 # ---------------------------------------------------------------------------------------------------------

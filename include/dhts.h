@@ -86,11 +86,17 @@ int dhts_device_count(void);
  * exception), 2 = the two-phase kernels without the pair kernel (one cell and its left interface per thread-pass: the kernels
  * every other shape takes; kept selectable for comparisons).  Same tape format, same results. */
 #define DHTS_OPT_MACRO_FWD_VARIANT 3
-/* DHTS_OPT_MACRO_FWD_GROUP: traffic lanes per workgroup of the two-phase kernel: 0 = heuristic (default: 4 for lanes of up to
- * three wavefronts, else 2), or 1, 2, 4.  Where the lanes are full (n_cells = 128 x wavefronts), no history is asked for and the
+/* DHTS_OPT_MACRO_FWD_GROUP: traffic lanes per workgroup of the two-phase kernels: 0 = heuristic (default: the pair kernel takes 4
+ * for lanes of up to three wavefronts, 1 for lanes of four -- BASELINE config 2 --, 2 above; the lane-group kernel 4 up to three
+ * wavefronts, else 2), or 1, 2, 4.  Where the lanes are full (n_cells = 128 x wavefronts), no history is asked for and the
  * launch keeps >= 256 workgroups, the queued interfaces of a group's lanes are solved as one list.  Same results, same tape
  * (dhts_macro_rollout_plan plan[7] says what a shape gets). */
 #define DHTS_OPT_MACRO_FWD_GROUP 4
+/* DHTS_OPT_MACRO_FWD_ROTATE: 1 (default) = the workgroups of the second half of the pair kernel's grid take turns with the others at
+ * issue priority 1, eight steps at a time; 0 = nobody does.  The rotation rests on an OBSERVATION about the dispatcher (workgroups b
+ * and b + grid / 2 share a compute unit at two workgroups per unit, and the one dispatched second loses the arbitration), is used for
+ * speed only and changes no result; bench.py times both settings during its warm-up and reports which one the box prefers. */
+#define DHTS_OPT_MACRO_FWD_ROTATE 5
 int dhts_set_option(int option, int value);
 /* cells / vehicle slots rounded up to the tape's padded width (multiple of 64) */
 int dhts_padded(int n);
@@ -223,6 +229,14 @@ size_t dhts_micro_step_tape_bytes(const dhts_micro_desc *d);
  */
 int dhts_idm_batch(int64_t n, int variant, const double *in, double *next_pv, float *dEgo, float *dLeading, int32_t *collided,
                    double *acc_sstar, int32_t *clips, void *stream);
+
+/* The Jacobians alone, from the caller's optimal spacing and clip flags: dIDM.compute_dEgo / compute_dLeading as the reference
+ * declares them (model/micro/didm.py:13-103; dMicroLane._backward passes the flags of the forward pass -- derived from the gap
+ * clamped to 1e-5 -- beside the UN-clamped gap, dmicro_lane.py:97).
+ *   in  [12][n] DOUBLE (SoA): a_max a_pref v v_target position_delta speed_delta min_space time_pref optimal_spacing delta_time
+ *       clipped_acceleration clipped_optimal_spacing (0 / 1)
+ *   out dEgo, dLeading [4][n] float32 */
+int dhts_idm_jac_batch(int64_t n, const double *in, float *dEgo, float *dLeading, void *stream);
 
 /*
  * T fused steps of L independent lanes: replaces T x L calls of dMicroForwardLayer.forward

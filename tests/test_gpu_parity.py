@@ -697,8 +697,8 @@ BENCH_LANES = (0, 1, 2, 3, 500, 511, 1022, 1023)      # lanes of bench.py's rank
 
 
 def test_macro_bench_instantiation_vs_reference_and_oracle(cuda, oracle, golden_dir):
-    """The kernel instantiations bench.py times on BASELINE config 2 -- macro_rollout_fwd3_kernel<2, true> (the pair kernel: two
-    traffic lanes per workgroup, four wavefronts per lane, two adjacent cells per thread, no history) and
+    """The kernel instantiations bench.py times on BASELINE config 2 -- macro_rollout_fwd3_kernel<1, true> (the pair kernel: one
+    traffic lane per workgroup at four wavefronts per lane, two adjacent cells per thread, no history) and
     macro_rollout_bwd_fast_kernel<512, false> -- in
     the bench's own launch: 1024 lanes x 512 cells x 1000 steps, the tensors bench.py builds for rank 0.  Lane 4 of the batch is
     replaced by the reference's own 512 x 1000 run (golden c2slice: state <= 1e-5, gradients <= 1e-4); eight more lanes are

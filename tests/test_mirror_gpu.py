@@ -160,6 +160,16 @@ def test_scalar_model_surface(cuda, golden_dir):
         assert abs(acc - k["acc"][i]) <= 1e-10 * max(1.0, abs(k["acc"][i])) and (int(ca), int(cs)) == tuple(k["flags"][i])
         dE = dIDM.compute_dEgo(a_max, a_pref, v, v_t, dp, dv, s0, Tp, s, dt, ca, cs)
         assert rel_max(dE.numpy(), k["dEgo"][i]) <= 1e-6
+    # gaps below 1e-5: the acceleration, the optimal spacing and the clip flags come from the CLAMPED gap, the Jacobians take the
+    # raw one beside them (dmicro_lane.py:97) -- the arguments are the caller's, they are not re-derived from one gap
+    k = load(golden_dir, "idm_kat_smallgap.npz")
+    for i in range(0, len(k["inp"]), 7):
+        a_max, a_pref, v, v_t, dp, dv, s0, Tp, dt = (float(x) for x in k["inp"][i])
+        acc, s, ca, cs = IDM.compute_acceleration(a_max, a_pref, v, v_t, max(dp, 1e-5), dv, s0, Tp, dt)
+        assert abs(acc - k["acc"][i]) <= 1e-10 * max(1.0, abs(k["acc"][i])) and (int(ca), int(cs)) == tuple(k["flags"][i])
+        dE = dIDM.compute_dEgo(a_max, a_pref, v, v_t, dp, dv, s0, Tp, s, dt, ca, cs)
+        dL = dIDM.compute_dLeading(a_max, a_pref, v, v_t, dp, dv, s0, Tp, s, dt, ca, cs)
+        assert rel_max(dE.numpy(), k["dEgo"][i]) <= 1e-6 and rel_max(dL.numpy(), k["dLeading"][i]) <= 1e-6
     # closed forms agree between floats and tensors
     import torch
     assert abs(float(ARZ.compute_u_eq(torch.tensor(0.3), 30.0)) - ARZ.compute_u_eq(0.3, 30.0)) <= 1e-5

@@ -96,6 +96,13 @@ def test_idm_kat_bit_exact(oracle, golden_dir):
         assert np.array_equal(dE, g["dEgo"][i]) and np.array_equal(dLd, g["dLeading"][i]), i
         flags_seen.add(fl)
     assert {(0, 0), (1, 0), (0, 1)} <= flags_seen     # both clips exercised
+    # G5b: raw gaps below 1e-5 -- acceleration, spacing and flags from the clamped gap, Jacobians from the raw one (dmicro_lane.py:97)
+    g = load(golden_dir, "idm_kat_smallgap.npz")
+    for i, (a_max, a_pref, v, v_t, dp, dv, s0, Tp, dt) in enumerate(g["inp"]):
+        acc, s, fl = oracle.idm_acc(a_max, a_pref, v, v_t, max(dp, 1e-5), dv, s0, Tp, dt)
+        assert acc == g["acc"][i] and s == g["sstar"][i] and fl == tuple(g["flags"][i]), i
+        dE, dLd = oracle.idm_jac(a_max, a_pref, v, v_t, dp, dv, s0, Tp, s, dt, fl)
+        assert np.array_equal(dE, g["dEgo"][i]) and np.array_equal(dLd, g["dLeading"][i]), i
 
 
 # ---- G6: micro rollouts: bit-exact state AND gradients ---------------------------------------------------------

@@ -445,6 +445,37 @@ def gen_idm_kat(seed=5):
                         dEgo=dE, dLeading=dLd, meta=meta(seed=seed, columns="a_max a_pref v v_target dp dv min_space time_pref dt"))
 
 
+def gen_idm_kat_smallgap(seed=11):
+    """G5b: vehicles whose raw gap is below POSITION_DELTA_EPS = 1e-5.  MicroLane.forward clamps the gap for the acceleration
+    (_micro_lane.py:166) and dMicroLane._backward hands the UN-clamped gap to the Jacobians together with the optimal spacing and
+    the clip flags of that forward call (dmicro_lane.py:97): the arguments of dIDM.compute_dEgo / compute_dLeading do not all
+    come from one gap."""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for _ in range(60):
+        sl = rng.choice([30.0, 20.0])
+        rows.append((sl * 1.0, sl * 0.8, float(np.float32(rng.uniform(0.0, 0.5 * sl))), sl * 0.9, float(np.float32(rng.uniform(1e-7, 9.9e-6))),
+                     float(np.float32(rng.uniform(-5, 5))), 0.5, 0.1, rng.choice([0.01, 1.0 / 30.0])))
+    for _ in range(20):     # leader much faster: negative optimal spacing, the acceleration is not clipped
+        rows.append((30.0, 24.0, float(np.float32(rng.uniform(1, 20))), 27.0, float(np.float32(rng.uniform(1e-7, 9.9e-6))),
+                     float(np.float32(-rng.uniform(20, 60))), 0.5, 0.1, 0.01))
+    inp = np.array(rows, dtype=np.float64)
+    n = len(rows)
+    acc, sstar = np.zeros(n), np.zeros(n)
+    flags = np.zeros((n, 2), dtype=np.int32)
+    dE, dLd = np.zeros((n, 2, 2), dtype=np.float32), np.zeros((n, 2, 2), dtype=np.float32)
+    for i, (a_max, a_pref, v, v_t, dp, dv, s0, T, dt) in enumerate(rows):
+        a, s, ca, cs = IDM.compute_acceleration(a_max, a_pref, v, v_t, max(dp, 1e-5), dv, s0, T, dt)
+        acc[i], sstar[i] = a, s
+        flags[i] = (int(ca), int(cs))
+        dE[i] = dIDM.compute_dEgo(a_max, a_pref, v, v_t, dp, dv, s0, T, s, dt, ca, cs).numpy()
+        dLd[i] = dIDM.compute_dLeading(a_max, a_pref, v, v_t, dp, dv, s0, T, s, dt, ca, cs).numpy()
+    print("G5b: %d rows; clipped_acc %d, clipped_spacing %d" % (n, flags[:, 0].sum(), flags[:, 1].sum()))
+    np.savez_compressed(os.path.join(OUT, "idm_kat_smallgap.npz"), inp=inp, acc=acc, sstar=sstar, flags=flags, dEgo=dE, dLeading=dLd,
+                        meta=meta(seed=seed, columns="a_max a_pref v v_target dp_raw dv min_space time_pref dt",
+                                  note="acc / sstar / flags from max(dp_raw, 1e-5); Jacobians from dp_raw with that sstar and those flags"))
+
+
 # ----------------------------------------------------------------------------------------------
 # G6: dMicroLane rollouts through RoadNetwork.forward
 # ----------------------------------------------------------------------------------------------
@@ -835,6 +866,8 @@ def main():
         gen_macro_rollouts(set(args.g4.split(",")))
     if "G5" in only:
         gen_idm_kat()
+    if "G5b" in only:
+        gen_idm_kat_smallgap()
     if "G6" in only:
         gen_micro_rollouts(set(args.g6.split(",")))
     if "G7" in only:
