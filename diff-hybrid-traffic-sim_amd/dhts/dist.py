@@ -112,3 +112,39 @@ def max_over_ranks(seconds, device):
     if _active():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def spawn_ranks(n, argv, module=None, script=None):
+    """`--gpus n` without a launcher: start n children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one per GPU) of
+    `python -m module argv...` or `python script argv...`.  The parent never touches a GPU and never execs; rank 0's stdout is the
+    parent's, the other ranks' goes to stderr; a rank that dies ends the others (by their own PIDs) instead of leaving them in a
+    collective.  Returns the worst exit code."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable] + (["-m", module] if module else [os.path.abspath(script)]) + list(argv)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else sys.stderr))
+    rcs = [None] * n
+    while any(c is None for c in rcs):
+        time.sleep(0.2)
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if any(c not in (None, 0) for c in rcs):
+            deadline = time.time() + 15.0
+            while time.time() < deadline and any(p.poll() is None for p in procs):
+                time.sleep(0.2)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            rcs = [p.wait() for p in procs]
+    return max(abs(int(c)) for c in rcs)

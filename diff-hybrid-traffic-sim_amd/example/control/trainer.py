@@ -13,7 +13,15 @@ operator per lane and step: minutes per episode) -- so that a flag that moves a 
 
 What differs, on purpose: the controller and the action live on the GPU and env.step(action, True) runs the fused network
 kernels, so a training episode is two kernel launches; instead of deep-copying the environment for every episode
-(trainer.py:172) the episode state is rewound (ItscpEnv.rewind), which keeps the uploaded tables."""
+(trainer.py:172) the episode state is rewound (ItscpEnv.rewind), which keeps the uploaded tables.
+
+Replica-batched, data-parallel training (this build only; BASELINE config 5 -- "optimisation-batch replicas shard across the GPUs
+... all-reduce of the loss gradient"): Trainer(env, n_replica=R) holds R environments of the same topology with their own drawn
+inflow schedules and routes (example/control/replicas.py).  An "episode" is then ONE controller forward on [R][obs], ONE fused
+launch pair over the R replicas (a launch sized for 256 replicas takes as long as one for a single replica) and the mean reward;
+with torch.distributed initialised (dhts.dist.init; run.py --gpus N starts the ranks) every rank holds R replicas of its own, the
+flat controller gradient [d loss / d theta || loss] is summed over the ranks by one all-reduce (RCCL; <= 1.8 MB, latency-bound)
+and every rank takes the same Adam step."""
 import os
 from copy import deepcopy
 
@@ -41,8 +49,10 @@ def _make_writer(path):
 
 class Trainer:
 
-    def __init__(self, env, network_size=(256, 256), lr=1e-3, device=None):
+    def __init__(self, env, network_size=(256, 256), lr=1e-3, device=None, n_replica=1):
         self.env = env
+        self.n_replica = int(n_replica)
+        self.batch = None                                 # ReplicaBatch, built at the first batched episode
         in_shape, out_shape = env.observation_space.shape, env.action_space.shape
         assert len(in_shape) == 1 and len(out_shape) == 1, "flat observation and action vectors"
         self.device = th.device(device) if device is not None else th.device("cuda" if th.cuda.is_available() else "cpu")
@@ -85,9 +95,19 @@ class Trainer:
         self.controller.train(False)
         total = 0.0
         with th.no_grad():
-            for _ in range(num_episode):
-                reward, _, _ = self.run_episode(False)
-                total += float(reward)
+            if self._batched():
+                from dhts import dist as D
+                acc = th.zeros(2, dtype=th.float32, device=self.device)
+                for _ in range(num_episode):
+                    rewards, _ = self.run_batch(False)
+                    acc[0] += rewards.sum()
+                    acc[1] += rewards.numel()
+                D.allreduce_sum_(acc)
+                total, num_episode = float(acc[0]), float(acc[1])
+            else:
+                for _ in range(num_episode):
+                    reward, _, _ = self.run_episode(False)
+                    total += float(reward)
         avg_reward = total / num_episode
         if self.writer is not None:
             self.writer.add_scalar("loss/eval", -avg_reward, epoch)
@@ -100,6 +120,8 @@ class Trainer:
         return avg_reward
 
     def train_epoch(self, num_episode):
+        if self._batched():
+            return self.train_epoch_batched(num_episode)
         total = 0
         for _ in range(num_episode):
             reward, _, _ = self.run_episode(True)
@@ -109,6 +131,70 @@ class Trainer:
         loss.backward()
         self.optimizer.step()
         return loss.detach()
+
+    # ---- replica-batched, data-parallel training ----------------------------------------------------------------------
+    def _batched(self):
+        from dhts import dist as D
+        return self.n_replica > 1 or D._active()
+
+    def _ensure_batch(self):
+        from dhts import dist as D
+        rank, world, _ = D.env_rank_world() if D._active() else (0, 1, 0)
+        if self.batch is None:
+            from example.control.replicas import ReplicaBatch
+            # every rank draws its own replicas: seeds offset by rank * R (an unseeded environment draws from np.random as it comes)
+            self.batch = ReplicaBatch(self.env, self.n_replica, self.device, seed_offset=rank * self.n_replica)
+        if world > 1 and not getattr(self, "_controller_synced", False):
+            # ... and all ranks start from the SAME controller: rank 0's weights
+            import torch.distributed as dist
+            for p_ in self.controller.parameters():
+                buf = p_.data.cpu() if (p_.is_cuda and dist.get_backend() == "gloo") else p_.data
+                dist.broadcast(buf, src=0)
+                if buf is not p_.data:
+                    p_.data.copy_(buf)
+            self._controller_synced = True
+        return self.batch
+
+    def run_batch(self, differentiable):
+        """One episode of every replica: rewards [R] (differentiable w.r.t. the controller's weights) and the actions [R][A]."""
+        b = self._ensure_batch()
+        obs = th.as_tensor(b.observe(), device=self.device)
+        actions = self.policy_action(obs)
+        rewards = b.rollout(actions, differentiable)
+        key = ("train" if differentiable else "eval", b.path)
+        self.paths[key] = self.paths.get(key, 0) + 1
+        return rewards, actions
+
+    def batch_loss(self, num_episode=1):
+        """- mean reward over the episodes, the replicas and the ranks' share: the quantity whose gradient the ranks sum."""
+        from dhts import dist as D
+        world = D.env_rank_world()[1] if D._active() else 1
+        total = 0
+        for _ in range(num_episode):
+            rewards, _ = self.run_batch(True)
+            total = total + rewards.sum()
+        return (-total) / (num_episode * self.n_replica * world)
+
+    def flat_gradient(self, loss):
+        """[d loss / d theta || loss] as one flat float32 buffer, summed over the ranks (one all-reduce); the parameters' .grad are set
+        from it."""
+        from dhts import dist as D
+        params = [p_ for p_ in self.controller.parameters() if p_.requires_grad]
+        self.optimizer.zero_grad()
+        loss.backward()
+        flat = th.cat([(p_.grad if p_.grad is not None else th.zeros_like(p_)).reshape(-1) for p_ in params] + [loss.detach().reshape(1)])
+        D.allreduce_sum_(flat)
+        o = 0
+        for p_ in params:
+            n = p_.numel()
+            p_.grad = flat[o:o + n].reshape(p_.shape).clone()
+            o += n
+        return flat
+
+    def train_epoch_batched(self, num_episode):
+        flat = self.flat_gradient(self.batch_loss(num_episode))
+        self.optimizer.step()
+        return flat[-1].detach()
 
     def policy_action(self, obs):
         """Controller logits squashed into the action box: low + (high - low) * sigmoid (trainer.py:182-187)."""
