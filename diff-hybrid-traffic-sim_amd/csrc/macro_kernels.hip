@@ -779,6 +779,10 @@ __device__ __forceinline__ void tape_fill_slots(const float4 *row, const TapeGeo
 // Dynamic LDS: float2 C0[2][N + 2], C2[2][N + 2] (index k + 1 = cell k; slot 1 of C2 and slot N of C0 are never written and
 // stay zero: the edge cells add 0) | float4 XA[2][N + 1], XB[2][N + 1] | u32 STAMP[2][N + 2].
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned bits3 __attribute__((ext_vector_type(3)));
+typedef unsigned bits4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ TapeFp tape_fp_bits(bits3 b) { TapeFp f; f.f0 = __uint_as_float(b.x); f.f2 = __uint_as_float(b.y); f.f3 = __uint_as_float(b.z); return f; }
+__device__ __forceinline__ float4 f4_bits(bits4 b) { return make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)); }
 __device__ __forceinline__ v2f pk_dot(v2f dlo, v2f dhi, v2f g) {           // (dot2(dlo.x, g.x, dhi.x, g.y), dot2(dlo.y, g.x, dhi.y, g.y))
     const v2f gx = {g.x, g.x}, gy = {g.y, g.y};
     return __builtin_elementwise_fma(dhi, gy, dlo * gx);
@@ -789,7 +793,8 @@ __host__ __device__ inline size_t bwd_fast_lds_bytes(int kB) {
 }
 // kHist: per-step cotangents g_hist [T][L][2][N] (a loss on the state history) are added to the cell's cotangent in front of
 // every step; they ride in the register sets of the trivial products, three steps ahead.
-template <int kB, bool kHist>
+// kFull: N = kB, every thread holds a cell (BASELINE config 2: 512 cells): no validity masks around the step's pieces.
+template <int kB, bool kHist, bool kFull = false>
 __global__ __launch_bounds__(kB) __attribute__((amdgpu_waves_per_eu(4, 4))) void macro_rollout_bwd_fast_kernel(     // <= 128 VGPRs
     int L, int N, int T, double cc, const float4 *__restrict__ tape,
     const float *__restrict__ g_r_in, const float *__restrict__ g_y_in, const float *__restrict__ g_hist,
@@ -808,21 +813,22 @@ __global__ __launch_bounds__(kB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const v2f zero2 = {0.f, 0.f}, e0 = {1.f, 0.f}, e1 = {0.f, 1.f};
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int k = t;
-    const bool vk = k < N;
+    const bool vk = kFull || k < N;
     const unsigned kl = vk ? k : N - 1;
     const unsigned kr = (kl + 1 < (unsigned)N) ? kl + 1 : N - 1;      // interface N is always an exception: its S entry does not exist
+    // the wavefronts that hold cell 0 / cell N - 1 sum the ghosts' cotangents (a scalar: the test costs the others one s_cbranch)
+    const int edge_wave = __builtin_amdgcn_readfirstlane(((t >> 6) == 0 || (t >> 6) == ((N - 1) >> 6)) ? 1 : 0);
 
     for (int i = t; i < 2 * P; i += B) { C0[i] = zero2; C2[i] = zero2; STAMP[i] = 0u; }
     v2f g = zero2;
     if (vk) g = v2f{g_r_in[base + k], g_y_in[base + k]};
 
     double gh_r = 0., gh_y = 0.;         // ghost cotangent sums: thread 0 the left ghost's, thread N - 1 the right one's
-    int bad_step = -1;                   // first non-finite cotangent this thread meets (the reverse sweep's first = the latest step)
-    unsigned zv;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(zv));     // keeps the count loads on the vector memory path (vmcnt, not lgkmcnt)
+    int n_fin = 0;                       // checks of the cell's cotangent that found it finite: a non-finite one stays so (every later value is a
+                                         // sum of products with it), so the count says where the first one appeared -- T + 1 checks, newest step first
     // byte offsets inside a row (32-bit, on top of the row's uniform base address)
     const unsigned off_sl = 12u * kl, off_sr = 12u * kr;
-    const unsigned off_c = 16u * geo.s_f4 + zv;
+    const unsigned off_c = 16u * geo.s_f4;
     const unsigned off_i = 16u * geo.s_f4 + 8u + 2u * t;
     const unsigned off_e = 16u * (geo.s_f4 + geo.h_f4) + 32u * t;
     const size_t row_bytes = 16 * geo.row_f4;
@@ -840,18 +846,25 @@ __global__ __launch_bounds__(kB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const char *pE = tb + (size_t)(T > 6 ? T - 6 : 0) * stride;      // row of step - 5
     const char *pC = tb + (size_t)(T > 9 ? T - 9 : 0) * stride;      // row of step - 8
 #define DHTS_ROW(step_) (tb + (size_t)((step_) > 0 ? (step_) : 0) * stride)
-#define DHTS_LOAD_CNT(rb_, c_) c_ = *reinterpret_cast<const int *>((rb_) + off_c);
+    // Tape reads are BUFFER loads (round 5): the row's address is a scalar (the running pointer as the descriptor's base), the
+    // thread's place in the row a 32-bit register -- no 64-bit vector add per load (the compiler forms one for a global load whose
+    // zero-extended offset was hoisted out of the loop: six v_lshl_add_u64 per step), and always the vector memory path (vmcnt).
+    const int row_rec = (int)row_bytes;
+#define DHTS_RSRC(rb_) __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(rb_), 0, row_rec, 0x00020000)
+#define DHTS_LOAD_CNT(rb_, c_) c_ = __builtin_amdgcn_raw_buffer_load_b32(DHTS_RSRC(rb_), off_c, 0, 0);
 #define DHTS_LOAD_S(rb_, hp_, sl_, sr_, gh_)                                             \
     {                                                                                    \
-        sl_ = *reinterpret_cast<const TapeFp *>((rb_) + off_sl);                         \
-        sr_ = *reinterpret_cast<const TapeFp *>((rb_) + off_sr);                         \
+        const __amdgpu_buffer_rsrc_t rs_ = DHTS_RSRC(rb_);                               \
+        sl_ = tape_fp_bits(__builtin_amdgcn_raw_buffer_load_b96(rs_, off_sl, 0, 0));     \
+        sr_ = tape_fp_bits(__builtin_amdgcn_raw_buffer_load_b96(rs_, off_sr, 0, 0));     \
         if (kHist) gh_ = v2f{(hp_)[0], (hp_)[N]};                                        \
     }
 #define DHTS_LOAD_E(rb_, c_, ea_, eb_, ix_)                                              \
     if (t < (c_)) {                                                                      \
-        ix_ = *reinterpret_cast<const unsigned short *>((rb_) + off_i);                  \
-        ea_ = *reinterpret_cast<const float4 *>((rb_) + off_e);                          \
-        eb_ = *reinterpret_cast<const float4 *>((rb_) + off_e + 16);                     \
+        const __amdgpu_buffer_rsrc_t rs_ = DHTS_RSRC(rb_);                               \
+        ix_ = __builtin_amdgcn_raw_buffer_load_b16(rs_, off_i, 0, 0);                    \
+        ea_ = f4_bits(__builtin_amdgcn_raw_buffer_load_b128(rs_, off_e, 0, 0));          \
+        eb_ = f4_bits(__builtin_amdgcn_raw_buffer_load_b128(rs_, off_e + 16u, 0, 0));    \
     }
     // exception j of step_ to its interface, in LDS copy Q
 #define DHTS_SCATTER(step_, Q, c_, ea_, eb_, ix_)                                        \
@@ -893,34 +906,33 @@ __global__ __launch_bounds__(kB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // exceptions of step s - 2 from (ea_ .. ec_) to LDS, and the refills: exceptions of step s - 5 (their count cq_ arrived three
     // intervals ago), the count of step s - 8, the trivial products of step s - 4.  Everything read from the tape is in flight
     // for three intervals (2 workgroups x 3 steps x 9 KB per CU: what 6 TB/s at ~2 us of latency need).
-#define DHTS_STEP(s_, Q, R, sl_, sr_, gh_, ea_, eb_, ix_, ec_, cq_)                      \
+#define DHTS_STEP(CL, s_, Q, R, sl_, sr_, gh_, ea_, eb_, ix_, ec_, cq_)                  \
     {                                                                                    \
         if (vk) {                                                                        \
             g = (c1v + C2[(R) * P + k + 1]) + C0[(R) * P + k + 1];                       \
             if (kHist) g += gh_cur;                /* the cotangent of the state after step s, if the loss looks at it */ \
-            if (bad_step < 0 && !(isfinite(g.x) && isfinite(g.y))) bad_step = ((s_) + 1 < T) ? (s_) + 1 : T - 1; \
+            n_fin += (isfinite(g.x) && isfinite(g.y)) ? 1 : 0;                           \
             const v2f c0 = pk_dot(d0lo, d0hi, g), c2v = pk_dot(d2lo, d2hi, g);           \
             c1v = pk_dot(d1lo, d1hi, g);                                                 \
             /* c0 of cell k goes to cell k-1 (slot k), c2 of cell k goes to cell k+1 (slot k+2) */ \
             C0[(Q) * P + k] = c0;                                                        \
             C2[(Q) * P + k + 2] = c2v;                                                   \
-            if (__builtin_amdgcn_ballot_w64((k == 0) | (k == N - 1))) {                  \
-                asm volatile("" ::: "memory");          /* a real branch: two wavefronts of the workgroup take it */ \
+            if (edge_wave) {                      /* a scalar branch: two wavefronts of the workgroup take it */ \
                 if (k == 0) { gh_r += (double)c0.x; gh_y += (double)c0.y; }              \
                 if (k == N - 1) { gh_r += (double)c2v.x; gh_y += (double)c2v.y; }        \
             }                                                                            \
-            if ((s_) >= 1) DHTS_BLOCKS((s_) - 1, R, sl_, sr_)                            \
+            if (!(CL) || (s_) >= 1) DHTS_BLOCKS((s_) - 1, R, sl_, sr_)                   \
             if (kHist) gh_cur = gh_;               /* of step s - 1: the set is refilled below */ \
         }                                                                                \
-        if ((s_) >= 2) DHTS_SCATTER((s_) - 2, Q, ec_, ea_, eb_, ix_);                    \
+        if (!(CL) || (s_) >= 2) DHTS_SCATTER((s_) - 2, Q, ec_, ea_, eb_, ix_);           \
         ec_ = cq_;                                                                       \
         DHTS_LOAD_E(pE, ec_, ea_, eb_, ix_);                                             \
         DHTS_LOAD_CNT(pC, cq_);                                                          \
         DHTS_LOAD_S(pS, pH, sl_, sr_, gh_);                                              \
-        if (kHist) pH -= ((s_) > 4) ? hstride : 0;                                       \
-        pS -= ((s_) > 4) ? stride : 0;                                                   \
-        pE -= ((s_) > 5) ? stride : 0;                                                   \
-        pC -= ((s_) > 8) ? stride : 0;                                                   \
+        if (kHist) pH -= (!(CL) || (s_) > 4) ? hstride : 0;                              \
+        pS -= (!(CL) || (s_) > 4) ? stride : 0;                                          \
+        pE -= (!(CL) || (s_) > 5) ? stride : 0;                                          \
+        pC -= (!(CL) || (s_) > 8) ? stride : 0;                                          \
         lds_only_barrier();                                                              \
     }
     // register set A serves the steps T - 1, T - 4, ..., set B the steps T - 2, T - 5, ..., set C the steps T - 3, T - 6, ...
@@ -963,22 +975,31 @@ __global__ __launch_bounds__(kB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // (slB, srB) = S(s - 1), set C holds E(s - 2) and cqC the count of s - 5; (slC, srC) = S(s - 2), set A holds E(s - 3) and
     // cqA the count of s - 6; (slA, srA) = S(s - 3), set B holds E(s - 4) and cqB the count of s - 7
     int step = T - 1, q = 0;
-    for (; step >= 2; step -= 3) {
-        DHTS_STEP(step, q, q ^ 1, slB, srB, ghB, eaC, ebC, ixC, ecC, cqC)
-        DHTS_STEP(step - 1, q ^ 1, q, slC, srC, ghC, eaA, ebA, ixA, ecA, cqA)
-        DHTS_STEP(step - 2, q, q ^ 1, slA, srA, ghA, eaB, ebB, ixB, ecB, cqB)
+    // the main loop: every row a step prefetches from exists (step - 2 > 8), so the running pointers move without end-of-tape
+    // clamps and the "is there a step s - 1 / s - 2" tests are literals (round 5: 7 scalar instructions per pointer and step less)
+    for (; step >= 11; step -= 3) {
+        DHTS_STEP(0, step, q, q ^ 1, slB, srB, ghB, eaC, ebC, ixC, ecC, cqC)
+        DHTS_STEP(0, step - 1, q ^ 1, q, slC, srC, ghC, eaA, ebA, ixA, ecA, cqA)
+        DHTS_STEP(0, step - 2, q, q ^ 1, slA, srA, ghA, eaB, ebB, ixB, ecB, cqB)
         q ^= 1;
     }
-    if (step >= 0) DHTS_STEP(step, q, q ^ 1, slB, srB, ghB, eaC, ebC, ixC, ecC, cqC)
-    if (step >= 1) DHTS_STEP(step - 1, q ^ 1, q, slC, srC, ghC, eaA, ebA, ixA, ecA, cqA)
+    for (; step >= 2; step -= 3) {
+        DHTS_STEP(1, step, q, q ^ 1, slB, srB, ghB, eaC, ebC, ixC, ecC, cqC)
+        DHTS_STEP(1, step - 1, q ^ 1, q, slC, srC, ghC, eaA, ebA, ixA, ecA, cqA)
+        DHTS_STEP(1, step - 2, q, q ^ 1, slA, srA, ghA, eaB, ebB, ixB, ecB, cqB)
+        q ^= 1;
+    }
+    if (step >= 0) DHTS_STEP(1, step, q, q ^ 1, slB, srB, ghB, eaC, ebC, ixC, ecC, cqC)
+    if (step >= 1) DHTS_STEP(1, step - 1, q ^ 1, q, slC, srC, ghC, eaA, ebA, ixA, ecA, cqA)
     if (vk) {                                            // after step 0, whose copy is Q = (T - 1) & 1
         const int oq = ((T - 1) & 1) * P;
         g = (c1v + C2[oq + k + 1]) + C0[oq + k + 1];
-        if (bad_step < 0 && !(isfinite(g.x) && isfinite(g.y))) bad_step = 0;
+        n_fin += (isfinite(g.x) && isfinite(g.y)) ? 1 : 0;
     }
 #undef DHTS_BLOCKS
 #undef DHTS_ROW
 #undef DHTS_LOAD_CNT
+#undef DHTS_RSRC
 #undef DHTS_LOAD_S
 #undef DHTS_LOAD_E
 #undef DHTS_SCATTER
@@ -988,7 +1009,7 @@ __global__ __launch_bounds__(kB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (t == 0) { g_ghost[(size_t)lane * 4 + 0] = gh_r; g_ghost[(size_t)lane * 4 + 1] = gh_y; }
         if (t == N - 1) { g_ghost[(size_t)lane * 4 + 2] = gh_r; g_ghost[(size_t)lane * 4 + 3] = gh_y; }
     }
-    if (bad_step >= 0) raise_fault(err, DHTS_FAULT_NAN, bad_step, lane, k);
+    if (vk && n_fin < T + 1) raise_fault(err, DHTS_FAULT_NAN, n_fin == 0 ? T - 1 : T - n_fin, lane, k);      // (check i >= 1 looks at the state after step T - i)
 }
 
 // The same sweep with TWO cells per thread (cells t and t + kB; kB + 1 < N <= 2 kB): what lanes of 1026 .. 2048 cells take
@@ -1568,6 +1589,9 @@ static int macro_rollout_bwd_launch(const dhts_macro_desc *d, int T, const float
     if (g_hist)                                                                                                                  \
         macro_rollout_bwd_fast_kernel<KB, true><<<d->n_lanes, KB, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_hist, g_r_out, \
                                                                              g_y_out, g_ghost, err);                            \
+    else if (N == KB && KB >= 128 && KB <= 512)                                                                                  \
+        macro_rollout_bwd_fast_kernel<KB, false, true><<<d->n_lanes, KB, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_hist,   \
+                                                                                    g_r_out, g_y_out, g_ghost, err);            \
     else                                                                                                                         \
         macro_rollout_bwd_fast_kernel<KB, false><<<d->n_lanes, KB, lds, st>>>(d->n_lanes, N, T, cc, tp, g_r, g_y, g_hist, g_r_out, \
                                                                               g_y_out, g_ghost, err);

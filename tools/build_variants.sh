@@ -16,7 +16,7 @@ for spec in "$@"; do
   EXTRA=""; [ "$SRC" = hybrid_kernels ] && EXTRA="-mllvm -disable-lsr"      # (the product's per-file flags, csrc/Makefile)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $EXTRA $defs -c -o "$C/variants/${SRC}_$name.o" "$C/$SRC.hip"
   OBJS=""
-  for u in dhts_common macro_kernels micro_kernels network_kernels netstep_kernels hybrid_kernels; do
+  for u in dhts_common macro_kernels micro_kernels network_kernels netstep_kernels netstep_hybrid hybrid_kernels; do
     if [ "$u" = "$SRC" ]; then OBJS="$OBJS $C/variants/${SRC}_$name.o"; else OBJS="$OBJS $C/$u.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$C/variants/libdhts_$name.so" $OBJS
