@@ -57,7 +57,8 @@ struct NsCounters {
 
 struct NsLayout {           // byte offsets into the workspace
     size_t ghost, g_ghost, slot, own_hist, tape, P, V, A, vroute, vcur, lane_n, rused, capv, counters, sigS, lossS, hg, idm_tape,
-        nv_idm, adm, nv_post, vx, kc_cell, kc_veh, caprec, capflag, ev, ev_off, G, gP, gV, gA, g_cap, g_own, g_act, n_bwd, ghd, total;
+        nv_idm, adm, nv_post, vx, kc_cell, kc_veh, caprec, capflag, ev, ev_off, G, gP, gV, gA, g_cap, g_own, g_act, n_bwd, ghd, pF, pAB,
+        ptape, total;
     size_t tape_step;       // floats of macro tape per step
 };
 __host__ __device__ inline size_t ns_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -74,6 +75,9 @@ struct NsArgs {
     const int32_t *routes, *route_ptr;
     const double *draws;
     const int32_t *nxt_ptr, *nxt_idx, *prv_ptr, *prv_idx, *inter_ptr, *inter_idx;
+    const int32_t *if_lane, *cell_lane;      // the persistent kernels' maps: interface -> lane, cell -> lane (NI = cells + ARZ lanes)
+    int NI;
+    long long table_stride, draws_stride;    // elements between replicas in the [T][L] tables / the draws (0 = shared)
     char *ws;
     NsLayout lo;
     float *hist, *queue, *reward;
@@ -157,16 +161,14 @@ __device__ __forceinline__ void ns_shift_in(float *P, float *V, float *A, int *v
 // =====================================================================================================================
 // forward, part 1: boundaries of step t from the state before it; IDM steps
 // =====================================================================================================================
-__global__ void __launch_bounds__(kNsBlock) ns_boundary_fwd_kernel(NsArgs a, int t, const float *__restrict__ action) {
-    const int tid = threadIdx.x, B = blockDim.x;
+// ghost (lane, side) = item j of every ARZ lane: _simulator.py:56-137, road_network.py:299-362
+__device__ __forceinline__ void ns_ghost_fwd_item(const NsArgs &a, int t, const float *__restrict__ action, int j) {
     const int L = a.L, C = a.C;
     const bool hard = a.hard != 0;
     const float um = a.um;
     const float *cur = a.hist + (size_t)t * 4 * C;
     const size_t row = (size_t)t * L;
-    if (blockIdx.x > 0) {
-        // ---- ghost (lane, side) of every ARZ lane: _simulator.py:56-137, road_network.py:299-362 ----
-        const int j = (blockIdx.x - 1) * B + tid;
+    {
         if (j >= 2 * L) return;
         const int lane = j >> 1, side = j & 1;
         const float *own_in = ns_ptr<float>(a, a.lo.own_hist) + (size_t)t * 2 * L;
@@ -203,15 +205,19 @@ __global__ void __launch_bounds__(kNsBlock) ns_boundary_fwd_kernel(NsArgs a, int
         }
         float *g = ns_ptr<float>(a, a.lo.ghost) + ((size_t)a.lane_gpos[lane] * 2 + side) * 4;
         g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
-        return;
     }
+}
 
-    // ---- the micro side: one workgroup ----
+// the micro side of a step's boundary + the IDM steps: ONE workgroup (all its threads call; hd_s = [Lm][2] floats of LDS)
+__device__ __forceinline__ void ns_micro_fwd(const NsArgs &a, int t, const float *__restrict__ action, float *hd_s) {
+    const int tid = threadIdx.x, B = blockDim.x;
+    const int L = a.L;
+    const bool hard = a.hard != 0;
+    const size_t row = (size_t)t * L;
     const int Lm = a.Lm, cap = a.cap;
     if (Lm == 0) return;
     __shared__ double scan_d[16];
     __shared__ int scan_i[16];
-    extern __shared__ float hd_s[];                   // [Lm][2] head gaps of this step
     const size_t plane = (size_t)Lm * cap;
     float *P0 = ns_ptr<float>(a, a.lo.P) + (size_t)(t & 1) * plane, *P1 = ns_ptr<float>(a, a.lo.P) + (size_t)((t + 1) & 1) * plane;
     float *V0 = ns_ptr<float>(a, a.lo.V) + (size_t)(t & 1) * plane, *V1 = ns_ptr<float>(a, a.lo.V) + (size_t)((t + 1) & 1) * plane;
@@ -388,6 +394,12 @@ __global__ void __launch_bounds__(kNsBlock) ns_boundary_fwd_kernel(NsArgs a, int
     }
 }
 
+__global__ void __launch_bounds__(kNsBlock) ns_boundary_fwd_kernel(NsArgs a, int t, const float *__restrict__ action) {
+    extern __shared__ float hd_dyn[];                 // [Lm][2] head gaps of this step
+    if (blockIdx.x > 0) ns_ghost_fwd_item(a, t, action, (blockIdx.x - 1) * blockDim.x + threadIdx.x);
+    else ns_micro_fwd(a, t, action, hd_dyn);
+}
+
 // =====================================================================================================================
 // forward, part 2: hand-offs in lane-id order on the committed state, then the queue loss
 // =====================================================================================================================
@@ -399,12 +411,11 @@ __device__ __forceinline__ void ns_push_event(const NsArgs &a, NsCounters *cnt, 
     cnt->n_events = k + 1;
 }
 
-__global__ void __launch_bounds__(kNsBlock) ns_convert_fwd_kernel(NsArgs a, int t) {
+__device__ __forceinline__ void ns_convert(const NsArgs &a, int t, int *cand) {      // cand: [L] ints of LDS (candidate flags of the event walk)
     const int tid = threadIdx.x, B = blockDim.x;
     const int L = a.L, C = a.C, Lm = a.Lm, cap = a.cap;
     const bool hard = a.hard != 0;
     const float um = a.um, vlen = a.vlen, dtf = a.dtf, s0f = a.s0f;
-    extern __shared__ int cand[];                      // [L] candidate flags of the event walk
     __shared__ double scan_d[16];
     __shared__ int scan_i[16];
     float *nxt = a.hist + (size_t)(t + 1) * 4 * C;     // committed state: the lanes' operators wrote it
@@ -634,10 +645,14 @@ __global__ void __launch_bounds__(kNsBlock) ns_convert_fwd_kernel(NsArgs a, int 
     if (tid == 0 && !hard) { cnt->loss_n = n0; cnt->loss_sum = S0; }
 }
 
+__global__ void __launch_bounds__(kNsBlock) ns_convert_fwd_kernel(NsArgs a, int t) {
+    extern __shared__ int cand_dyn[];
+    ns_convert(a, t, cand_dyn);
+}
+
 // reward = - sum of the queue terms, lanes outermost (ItscpEnv._reward, _env.py:770-797): one thread per lane sums its steps,
 // lane 0 of the block the lanes; counts out
-__global__ void __launch_bounds__(kNsBlock) ns_reward_kernel(NsArgs a) {
-    extern __shared__ float part[];                   // [2][L]
+__device__ __forceinline__ void ns_reward(const NsArgs &a, float *part) {          // part: [2][L] floats of LDS
     const int tid = threadIdx.x, B = blockDim.x, L = a.L, T = a.T;
     const int cut = (a.loss_steps > 0 && a.loss_steps < T) ? a.loss_steps : T;
     for (int l = tid; l < L; l += B) {
@@ -654,6 +669,10 @@ __global__ void __launch_bounds__(kNsBlock) ns_reward_kernel(NsArgs a) {
         a.counts[0] = cnt->n_spawned; a.counts[1] = cnt->n_deposits; a.counts[2] = cnt->n_events; a.counts[3] = cnt->draws_used;
     }
 }
+__global__ void __launch_bounds__(kNsBlock) ns_reward_kernel(NsArgs a) {
+    extern __shared__ float part_dyn[];
+    ns_reward(a, part_dyn);
+}
 
 // =====================================================================================================================
 // reverse, part 1 (one workgroup): loss taps of the state after step t, the step's events undone newest first, speed cotangents
@@ -663,11 +682,11 @@ __device__ __forceinline__ void ns_shift_out(double *gP, double *gV, double *gA,
     for (int i = 0; i + 1 < n; ++i) { gP[base + i] = gP[base + i + 1]; gV[base + i] = gV[base + i + 1]; gA[base + i] = gA[base + i + 1]; }
 }
 
-__global__ void __launch_bounds__(kNsBlock) ns_micro_bwd_kernel(NsArgs a, int t, const float *__restrict__ action, const float *__restrict__ g_reward) {
+__device__ __forceinline__ void ns_micro_bwd(const NsArgs &a, int t, const float *__restrict__ action, const float *__restrict__ g_reward,
+                                             double *lds_d) {      // lds_d: [2 Lm + 8 blockDim] doubles of LDS (head-gap cotangents | compact lists)
     const int tid = threadIdx.x, B = blockDim.x;
     const int L = a.L, C = a.C, Lm = a.Lm, cap = a.cap;
     const float um = a.um, vlen = a.vlen, dtf = a.dtf, s0f = a.s0f;
-    extern __shared__ double lds_d[];                 // [2 Lm] head-gap cotangents | compact lists
     __shared__ int scan_i[16];
     const float *nxt = a.hist + (size_t)(t + 1) * 4 * C;
     const float *Rn = nxt, *Yn = nxt + C, *Un = nxt + 2 * C;
@@ -888,13 +907,16 @@ __global__ void __launch_bounds__(kNsBlock) ns_micro_bwd_kernel(NsArgs a, int t,
         if (adm[m]) { ns_shift_out(gPp, gVp, gA, (size_t)m * cap, n_bwd[m]); n_bwd[m] -= 1; }
     }
 }
+__global__ void __launch_bounds__(kNsBlock) ns_micro_bwd_kernel(NsArgs a, int t, const float *__restrict__ action, const float *__restrict__ g_reward) {
+    extern __shared__ double lds_dyn[];
+    ns_micro_bwd(a, t, action, g_reward, lds_dyn);
+}
 
 // =====================================================================================================================
 // reverse, part 2: the lanes' ghost cotangents (dhts_macro_step_bwd's g_ghost) to the neighbours' edge cells, the stored ghosts and
 // the action.  slot [L][2][4] = (cotangent for the source cell's r, for its u, the action partial, the action index as a float)
 // =====================================================================================================================
-__global__ void ns_ghosts_bwd_kernel(NsArgs a, int t, const float *__restrict__ action) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void ns_ghost_bwd_item(const NsArgs &a, int t, const float *__restrict__ action, int j) {
     const int L = a.L, C = a.C;
     if (j >= 2 * L) return;
     const int lane = j >> 1, side = j & 1;
@@ -943,11 +965,13 @@ __global__ void ns_ghosts_bwd_kernel(NsArgs a, int t, const float *__restrict__ 
     }
     sl[0] = add_r; sl[1] = add_u; sl[2] = a_val; sl[3] = (float)a_key;
 }
+__global__ void ns_ghosts_bwd_kernel(NsArgs a, int t, const float *__restrict__ action) {
+    ns_ghost_bwd_item(a, t, action, blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 // thread = lane m: its edge cells take what the ghosts that looked at them left, in a fixed order (downstream lanes ascending for
 // the last cell, upstream lanes ascending for the first); threads q < sq sum their intersection's action partials in slot order
-__global__ void ns_ghosts_gather_kernel(NsArgs a, int t) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void ns_ghost_gather_item(const NsArgs &a, int t, int m) {
     const int L = a.L, C = a.C;
     const float *slot = ns_ptr<float>(a, a.lo.slot);
     float *G = ns_ptr<float>(a, a.lo.G) + (size_t)(t & 1) * 3 * C;
@@ -975,6 +999,173 @@ __global__ void ns_ghosts_gather_kernel(NsArgs a, int t) {
         }
         if (key >= 0) ns_ptr<double>(a, a.lo.g_act)[key] += v;
     }
+}
+__global__ void ns_ghosts_gather_kernel(NsArgs a, int t) {
+    ns_ghost_gather_item(a, t, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// =====================================================================================================================
+// PERSISTENT form (round 5): the same step -- the very device functions above -- inside ONE kernel per direction, one workgroup per
+// network replica, all T steps, workgroup barriers where the stepwise form has kernel boundaries.  The workgroup's threads loop
+// over the network's items (ghosts, interfaces, cells: a few per thread for the grids the reference builds); the state of a step
+// is the history row in HBM (L2-resident: tens of KB), interface results and the blocks dqs[c][3][2][2] (dMacroLane._backward,
+// dmacro_lane.py:96-132) go through the replica's workspace.  No cross-workgroup exchange exists, so nothing spins; replicas are
+// independent workgroups (BASELINE config 5's pattern for networks beyond the fused kernels' one-item-per-thread limits).
+// A step costs its phases' latencies (~10 us forward + reverse for 360 lanes / 2 124 cells) instead of ~100 us of launches.
+// =====================================================================================================================
+__device__ __forceinline__ NsArgs ns_replica_args(const NsArgs &a0, int rep) {
+    NsArgs a = a0;
+    a.hist += (size_t)rep * (a.T + 1) * 4 * (a.C > 0 ? a.C : 1);
+    a.queue += (size_t)rep * a.T * a.L;
+    if (a.reward) a.reward += (size_t)rep * 2;
+    if (a.counts) a.counts += (size_t)rep * 4;
+    a.ws += (size_t)rep * a.lo.total;
+    const size_t ts = (size_t)rep * (size_t)a.table_stride;
+    a.left_src += ts; a.left_gate += ts; a.right_src += ts; a.conv_next += ts; a.schedule += ts;
+    if (a.draws) a.draws += (size_t)rep * (size_t)a.draws_stride;
+    return a;
+}
+
+// interfaces of step t: ARZ.riemann_solve + the two Jacobian products per interface (item i = lane_off + gpos + k, k = 0 .. n)
+__device__ __forceinline__ void ns_iface_item(const NsArgs &a, int t, int i, int &fault_step, int &fault_lane, int &fault_index) {
+    const int C = a.C;
+    const int l = a.if_lane[i];
+    const int off = a.lane_off[l], n = a.lane_ncell[l], gp = a.lane_gpos[l];
+    const int k = i - (off + gp);
+    const float *cur = a.hist + (size_t)t * 4 * C;
+    const float *gh = ns_ptr<float>(a, a.lo.ghost) + (size_t)gp * 8;
+    double rL, yL, uL, qL, rR, yR, uR, qR;
+    if (k == 0) { rL = gh[0]; yL = gh[1]; uL = gh[2]; qL = gh[3]; }
+    else { const int c = off + k - 1; rL = cur[c]; yL = cur[C + c]; uL = cur[2 * C + c]; qL = cur[3 * C + c]; }
+    if (k == n) { rR = gh[4]; yR = gh[5]; uR = gh[6]; qR = gh[7]; }
+    else { const int c = off + k; rR = cur[c]; yR = cur[C + c]; uR = cur[2 * C + c]; qR = cur[3 * C + c]; }
+    IfaceConst kc;
+    kc.set_um(a.um_d); kc.set_grid(a.dt_d, a.lane_dx[l]);
+    Iface f;
+    arz_interface(rL, yL, uL, qL, rR, yR, uR, qR, kc, f);
+    if (f.cfl_bad && fault_step < 0) { fault_step = t; fault_lane = l; fault_index = k; }
+    double *F = ns_ptr<double>(a, a.lo.pF) + 2 * (size_t)i;
+    F[0] = f.Fr; F[1] = f.Fy;
+    float4 *ab = ns_ptr<float4>(a, a.lo.pAB) + 2 * (size_t)i;
+    ab[0] = make_float4(f.A[0], f.A[1], f.A[2], f.A[3]);
+    ab[1] = make_float4(f.B[0], f.B[1], f.B[2], f.B[3]);
+}
+// cells of step t: Godunov update, float32 glue, the cell's three blocks (MacroLane.forward, _macro_lane.py:103-114;
+// dmacro_lane.py:126-129) -- the operations of the straight-lane operator's kernel, item by item
+__device__ __forceinline__ void ns_cell_item(const NsArgs &a, int t, int c) {
+    const int C = a.C;
+    const int l = a.cell_lane[c];
+    const int iL = c + a.lane_gpos[l], iR = iL + 1;
+    const double cc = a.dt_d / a.lane_dx[l];
+    const float *cur = a.hist + (size_t)t * 4 * C;
+    float *nxt = a.hist + (size_t)(t + 1) * 4 * C;
+    const double *F = ns_ptr<double>(a, a.lo.pF);
+    const float nr = (float)((double)cur[c] + (F[2 * iL] - F[2 * iR]) * cc);
+    const float ny = (float)((double)cur[C + c] + (F[2 * iL + 1] - F[2 * iR + 1]) * cc);
+    float nu, nq;
+    glue_from_r_y(nr, ny, a.um, nu, nq);
+    nxt[c] = nr; nxt[C + c] = ny; nxt[2 * C + c] = nu; nxt[3 * C + c] = nq;
+    if (!a.hard) {
+        const float cf = (float)cc, ncf = (float)(-cc);
+        const float4 *ab = ns_ptr<float4>(a, a.lo.pAB);
+        const float4 aL = ab[2 * iL], bL = ab[2 * iL + 1], aR = ab[2 * iR], bR = ab[2 * iR + 1];
+        float4 d0, d1, d2;
+        d0.x = ncf * (-aL.x); d0.y = ncf * (-aL.y); d0.z = ncf * (-aL.z); d0.w = ncf * (-aL.w);
+        d2.x = ncf * bR.x; d2.y = ncf * bR.y; d2.z = ncf * bR.z; d2.w = ncf * bR.w;
+        d1.x = 1.f - cf * (aR.x - bL.x); d1.y = 0.f - cf * (aR.y - bL.y);
+        d1.z = 0.f - cf * (aR.z - bL.z); d1.w = 1.f - cf * (aR.w - bL.w);
+        float4 *tp = ns_ptr<float4>(a, a.lo.ptape) + ((size_t)t * C + c) * 3;
+        tp[0] = d0; tp[1] = d1; tp[2] = d2;
+    }
+}
+// reverse of the cells of step t: g[c] <- dqs[c][1]^T g[c] + dqs[c-1][2]^T g[c-1] + dqs[c+1][0]^T g[c+1] inside a lane
+// (dMacroForwardLayer.backward, dmacro_lane.py:277-309); the lane's edge cells leave the ghosts' cotangents
+__device__ __forceinline__ void ns_cell_bwd_item(const NsArgs &a, int t, int c) {
+    const int C = a.C;
+    const int l = a.cell_lane[c];
+    const int off = a.lane_off[l], n = a.lane_ncell[l];
+    const int k = c - off;
+    const float *Gn = ns_ptr<float>(a, a.lo.G) + (size_t)((t + 1) & 1) * 3 * C;
+    float *Gp = ns_ptr<float>(a, a.lo.G) + (size_t)(t & 1) * 3 * C;
+    const float4 *tp = ns_ptr<float4>(a, a.lo.ptape) + ((size_t)t * C + c) * 3;
+    const float gr = Gn[c], gy = Gn[C + c];
+    const float4 d0 = tp[0], d1 = tp[1], d2 = tp[2];
+    float vr = dot2(d1.x, gr, d1.z, gy), vy = dot2(d1.y, gr, d1.w, gy);
+    float c2r = 0.f, c2y = 0.f, c0r = 0.f, c0y = 0.f;
+    if (k > 0) { const float4 e = tp[-3 + 2]; const float hr = Gn[c - 1], hy = Gn[C + c - 1]; c2r = dot2(e.x, hr, e.z, hy); c2y = dot2(e.y, hr, e.w, hy); }
+    if (k < n - 1) { const float4 e = tp[3]; const float hr = Gn[c + 1], hy = Gn[C + c + 1]; c0r = dot2(e.x, hr, e.z, hy); c0y = dot2(e.y, hr, e.w, hy); }
+    Gp[c] = (vr + c2r) + c0r;
+    Gp[C + c] = (vy + c2y) + c0y;
+    Gp[2 * C + c] = 0.f;
+    double *gg = ns_ptr<double>(a, a.lo.g_ghost) + (size_t)a.lane_gpos[l] * 4;
+    if (k == 0) { gg[0] = (double)dot2(d0.x, gr, d0.z, gy); gg[1] = (double)dot2(d0.y, gr, d0.w, gy); }
+    if (k == n - 1) { gg[2] = (double)dot2(d2.x, gr, d2.z, gy); gg[3] = (double)dot2(d2.y, gr, d2.w, gy); }
+    if (!(isfinite(Gp[c]) && isfinite(Gp[C + c]))) net_fault(a.err, DHTS_FAULT_NAN, t, l, k);
+}
+
+__global__ void __launch_bounds__(kNsBlock) ns_persist_fwd_kernel(NsArgs a0, const float *__restrict__ action_all) {
+    extern __shared__ double lds_p[];
+    const NsArgs a = ns_replica_args(a0, blockIdx.x);
+    const float *action = action_all + (size_t)blockIdx.x * a.n_action;
+    const int tid = threadIdx.x, B = blockDim.x;
+    const int L = a.L, C = a.C, T = a.T;
+    // the episode's running state: empty road (MacroLane.__init__), stored ghosts (0, u_max), no vehicles, counters zero
+    for (int i = tid; i < C; i += B) { a.hist[i] = 0.f; a.hist[C + i] = 0.f; a.hist[2 * C + i] = a.um; a.hist[3 * C + i] = a.um; }
+    for (int i = tid; i < L; i += B) { float *o = ns_ptr<float>(a, a.lo.own_hist); o[2 * i] = 0.f; o[2 * i + 1] = a.um; }
+    {
+        unsigned *z = ns_ptr<unsigned>(a, a.lo.P);
+        const size_t nz = (a.lo.counters + sizeof(NsCounters) - a.lo.P) / 4;
+        for (size_t i = tid; i < nz; i += B) z[i] = 0u;
+    }
+    __syncthreads();
+    int fault_step = -1, fault_lane = 0, fault_index = 0;
+    for (int t = 0; t < T; ++t) {
+        for (int j = tid; j < 2 * L; j += B) ns_ghost_fwd_item(a, t, action, j);
+        ns_micro_fwd(a, t, action, reinterpret_cast<float *>(lds_p));
+        __syncthreads();
+        for (int i = tid; i < a.NI; i += B) ns_iface_item(a, t, i, fault_step, fault_lane, fault_index);
+        __syncthreads();
+        for (int c = tid; c < C; c += B) ns_cell_item(a, t, c);
+        __syncthreads();
+        ns_convert(a, t, reinterpret_cast<int *>(lds_p));
+        __syncthreads();
+    }
+    if (fault_step >= 0) net_fault(a.err, DHTS_FAULT_CFL, fault_step, fault_lane, fault_index);
+    ns_reward(a, reinterpret_cast<float *>(lds_p));
+}
+
+__global__ void __launch_bounds__(kNsBlock) ns_persist_bwd_kernel(NsArgs a0, const float *__restrict__ action_all, const float *__restrict__ g_reward,
+                                                                float *__restrict__ g_action_all) {
+    extern __shared__ double lds_p[];
+    const NsArgs a = ns_replica_args(a0, blockIdx.x);
+    const float *action = action_all + (size_t)blockIdx.x * a.n_action;
+    const int tid = threadIdx.x, B = blockDim.x;
+    const int L = a.L, C = a.C, T = a.T, Lm = a.Lm;
+    {   // cotangents start at zero; the lanes hold what the forward left
+        unsigned *z = ns_ptr<unsigned>(a, a.lo.G);
+        const size_t nz = (a.lo.n_bwd - a.lo.G) / 4;
+        for (size_t i = tid; i < nz; i += B) z[i] = 0u;
+        int *n_bwd = ns_ptr<int>(a, a.lo.n_bwd);
+        const int *lane_n = ns_ptr<int>(a, a.lo.lane_n);
+        for (int m = tid; m < Lm; m += B) n_bwd[m] = lane_n[m];
+    }
+    __syncthreads();
+    const int m_items = L > a.sq ? L : a.sq;
+    for (int t = T - 1; t >= 0; --t) {
+        ns_micro_bwd(a, t, action, g_reward ? g_reward + blockIdx.x : nullptr, lds_p);
+        __syncthreads();
+        for (int c = tid; c < C; c += B) ns_cell_bwd_item(a, t, c);
+        __syncthreads();
+        if (C > 0) {
+            for (int j = tid; j < 2 * L; j += B) ns_ghost_bwd_item(a, t, action, j);
+            __syncthreads();
+            for (int m = tid; m < m_items; m += B) ns_ghost_gather_item(a, t, m);
+            __syncthreads();
+        }
+    }
+    float *g_action = g_action_all + (size_t)blockIdx.x * a.n_action;
+    const double *g_act = ns_ptr<double>(a, a.lo.g_act);
+    for (int q = tid; q < a.n_action; q += B) g_action[q] = (float)g_act[q];
 }
 
 __global__ void ns_finish_bwd_kernel(NsArgs a, float *__restrict__ g_action) {
@@ -1012,7 +1203,7 @@ static NsLayout ns_layout(const dhts_net_desc *d, const dhts_netstep_tables *t) 
     auto R = [&](size_t bytes) { size_t r = p; p += ns_up(bytes); return r; };
     o.ghost = R(sizeof(float) * Lg * 8); o.g_ghost = R(sizeof(double) * Lg * 4); o.slot = R(sizeof(float) * L * 8);
     o.own_hist = R(sizeof(float) * (T + 1) * 2 * L);
-    o.tape = R(sizeof(float) * T * tape_step);
+    o.tape = R(t->persistent ? 0 : sizeof(float) * T * tape_step);
     o.P = R(sizeof(float) * 2 * plane); o.V = R(sizeof(float) * 2 * plane); o.A = R(sizeof(float) * plane);
     o.vroute = R(sizeof(int) * plane); o.vcur = R(sizeof(int) * plane); o.lane_n = R(sizeof(int) * Lm); o.rused = R(sizeof(int) * L);
     o.capv = R(sizeof(float) * ncap); o.counters = R(sizeof(NsCounters));
@@ -1026,6 +1217,11 @@ static NsLayout ns_layout(const dhts_net_desc *d, const dhts_netstep_tables *t) 
     o.gP = R(sizeof(double) * 2 * plane); o.gV = R(sizeof(double) * 2 * plane); o.gA = R(sizeof(double) * plane);
     o.g_cap = R(sizeof(double) * ncap); o.g_own = R(sizeof(float) * 2 * L); o.g_act = R(sizeof(double) * (size_t)d->n_action);
     o.n_bwd = R(sizeof(int) * Lm); o.ghd = R(16);
+    // the persistent kernels' own scratch and Jacobian tape (blocks dqs[c][3][2][2] per cell-step: 48 B, dmacro_lane.py:50-56)
+    const size_t NI = C + Lg;
+    o.pF = R(t->persistent ? sizeof(double) * 2 * NI : 0); o.pAB = R(t->persistent ? sizeof(float) * 8 * NI : 0);
+    o.ptape = R(t->persistent ? sizeof(float) * 12 * T * C : 0);
+    if (t->persistent) { o.tape = o.ptape; }          // (the per-group operator tape is not used then)
     o.total = p;
     return o;
 }
@@ -1034,7 +1230,8 @@ static bool ns_ok(const dhts_net_desc *d, const dhts_netstep_tables *t) {
     if (!d || !t) return false;
     const dhts_hybrid_tables &h = t->hyb;
     const int cap = h.lane_capacity > 0 ? h.lane_capacity : 16;
-    return d->n_replicas == 1 && d->n_lanes > 0 && d->n_cells >= 0 && d->n_steps > 0 && d->n_inter_sq > 0 && d->frames_per_phase > 0 &&
+    return (d->n_replicas == 1 || (t->persistent && d->n_replicas > 1)) && (!t->persistent || d->n_cells == 0 || (t->if_lane && t->cell_lane)) &&
+           d->n_lanes > 0 && d->n_cells >= 0 && d->n_steps > 0 && d->n_inter_sq > 0 && d->frames_per_phase > 0 &&
            d->n_action >= d->n_inter_sq && d->dt > 0 && d->u_max > 0 && d->vehicle_length > 0 && cap <= 1024 && h.n_micro >= 0 &&
            h.net.lane_ncell && h.net.lane_off && h.net.sig_kind && h.net.inter && h.net.lane_dx && h.net.left_src && h.net.left_gate &&
            h.net.right_src && h.net.schedule && h.net.nxt_ptr && h.net.nxt_idx && h.net.prv_ptr && h.net.prv_idx && h.lane_macro &&
@@ -1061,6 +1258,8 @@ static NsArgs ns_args(const dhts_net_desc *d, const dhts_netstep_tables *t, int 
     a.schedule = h.net.schedule; a.routes = h.routes; a.route_ptr = h.route_ptr; a.draws = h.draws;
     a.nxt_ptr = h.net.nxt_ptr; a.nxt_idx = h.net.nxt_idx; a.prv_ptr = h.net.prv_ptr; a.prv_idx = h.net.prv_idx;
     a.inter_ptr = t->inter_ptr; a.inter_idx = t->inter_idx;
+    a.if_lane = t->if_lane; a.cell_lane = t->cell_lane; a.table_stride = h.net.replica_stride; a.draws_stride = h.draws_stride;
+    { int lg = 0; for (int g = 0; g < t->n_groups; ++g) lg += t->groups[g].n_lanes; a.NI = d->n_cells + lg; }
     a.ws = reinterpret_cast<char *>(ws); a.lo = ns_layout(d, t);
     a.hist = hist; a.queue = queue; a.reward = reward; a.counts = counts; a.err = err;
     return a;
@@ -1070,7 +1269,7 @@ extern "C" {
 
 size_t dhts_netstep_workspace_bytes(const dhts_net_desc *d, const dhts_netstep_tables *t) {
     if (!ns_ok(d, t)) return 0;
-    return ns_layout(d, t).total;
+    return ns_layout(d, t).total * (size_t)d->n_replicas;
 }
 
 int dhts_netstep_rollout_fwd(const dhts_net_desc *d, const dhts_netstep_tables *t, int hard, const float *action, float *hist,
@@ -1081,6 +1280,15 @@ int dhts_netstep_rollout_fwd(const dhts_net_desc *d, const dhts_netstep_tables *
     const int L = a.L, C = a.C, T = a.T, Lm = a.Lm;
     const size_t plane = (size_t)Lm * a.cap;
     char *ws = a.ws;
+    if (t->persistent) {
+        size_t lds = sizeof(float) * 2 * (size_t)(Lm > 0 ? Lm : 1);              // head gaps | candidate flags | the reward's partial sums
+        if (sizeof(float) * 2 * (size_t)L > lds) lds = sizeof(float) * 2 * (size_t)L;
+        if (lds > 160 * 1024 ||
+            (lds > 48 * 1024 && hipFuncSetAttribute((const void *)ns_persist_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess))
+            return DHTS_E_INVALID;
+        ns_persist_fwd_kernel<<<d->n_replicas, kNsBlock, lds, st>>>(a, action);
+        return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
+    }
     // running state of the episode
     if (hipMemsetAsync(ws + a.lo.P, 0, a.lo.counters + sizeof(NsCounters) - a.lo.P, st) != hipSuccess) return DHTS_E_LAUNCH;
     const int nmax = C > L ? C : L;
@@ -1120,6 +1328,14 @@ int dhts_netstep_rollout_bwd(const dhts_net_desc *d, const dhts_netstep_tables *
     NsArgs a = ns_args(d, t, 0, const_cast<float *>(hist), const_cast<float *>(queue), nullptr, nullptr, workspace, err);
     const int L = a.L, C = a.C, T = a.T, Lm = a.Lm;
     char *ws = a.ws;
+    if (t->persistent) {
+        const size_t lds = sizeof(double) * (2 * (size_t)(Lm > 0 ? Lm : 1) + 8 * (size_t)kNsBlock);
+        if (lds > 160 * 1024 ||
+            hipFuncSetAttribute((const void *)ns_persist_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return DHTS_E_INVALID;
+        ns_persist_bwd_kernel<<<d->n_replicas, kNsBlock, lds, st>>>(a, action, g_reward, g_action);
+        return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
+    }
     // cotangents start at zero; the lanes hold what the forward left (lane_n)
     if (hipMemsetAsync(ws + a.lo.G, 0, a.lo.n_bwd - a.lo.G, st) != hipSuccess) return DHTS_E_LAUNCH;
     if (Lm > 0 && hipMemcpyAsync(ws + a.lo.n_bwd, ws + a.lo.lane_n, sizeof(int) * (size_t)Lm, hipMemcpyDeviceToDevice, st) != hipSuccess)

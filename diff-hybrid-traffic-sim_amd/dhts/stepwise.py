@@ -51,9 +51,24 @@ class StepwiseNetwork:
     vehicle spawned onto a micro lane takes that lane's k-th route (cyclically; waiting lists of micro source lanes in admission
     order, no wrap-around) -- as for dhts.ops.DeviceHybridTables.  lane_capacity: vehicles a micro lane holds at once (1 .. 1024)."""
 
-    def __init__(self, tables, routes, device, lane_capacity=32, max_events=0):
+    def __init__(self, tables, routes, device, lane_capacity=32, max_events=0, persistent=False):
+        """persistent: the whole episode in ONE kernel per direction, one workgroup per replica (csrc/netstep_hybrid.hip: the same
+        device functions with workgroup barriers instead of kernel boundaries; ~10 x fewer microseconds per step for the grids the
+        reference builds).  `tables` may then be a LIST of tables of one topology (own schedules / per-step routes / draws each): one
+        replica per entry, rollout() takes action [R][A] and returns [R]-shaped results."""
         from .network import group_routes
-        t = as_hybrid_tables(tables)
+        many = isinstance(tables, (list, tuple))
+        tabs = [as_hybrid_tables(x) for x in tables] if many else [as_hybrid_tables(tables)]
+        if many and not persistent:
+            raise ValueError("StepwiseNetwork: a list of tables (replicas) needs persistent=True")
+        t = tabs[0]
+        for i, x in enumerate(tabs):
+            if (x.n_lanes, x.n_cells, x.T) != (t.n_lanes, t.n_cells, t.T) or not np.array_equal(x.lane_macro, t.lane_macro) or \
+                    not np.array_equal(x.lane_ncell, t.lane_ncell) or not np.array_equal(np.asarray(x.lane_source), np.asarray(t.lane_source)):
+                raise ValueError("per-replica tables must share the topology of table 0: table %d differs" % i)
+        self.n_replicas = len(tabs) if many else 0            # 0: one network, un-batched shapes
+        self.tabs = tabs
+        self.persistent = bool(persistent)
         self.t, self.device = t, device
         L, T = t.n_lanes, t.T
         self.n_lanes, self.n_cells, self.T = L, t.n_cells, T
@@ -62,7 +77,7 @@ class StepwiseNetwork:
         self.lane_capacity, self.max_events = int(lane_capacity), int(max_events)
         lane_macro = np.asarray(t.lane_macro, dtype=np.int32)
         ncell = np.asarray(t.lane_ncell, dtype=np.int64)
-        if np.asarray(t.lane_source).any() and getattr(t, "draws", None) is None:
+        if np.asarray(t.lane_source).any() and any(getattr(x, "draws", None) is None for x in tabs):
             raise ValueError("a network with micro source lanes needs its admission draws (HybridNetworkTables.set_micro_sources)")
         # ---- groups of ARZ lanes with equal (cells, cell length): contiguous blocks of the group-major cell / lane order ----
         keys = {}
@@ -88,6 +103,14 @@ class StepwiseNetwork:
         order = np.concatenate([own_off[l] + np.arange(ncell[l]) for l in range(L) if lane_macro[l]] or [np.zeros(0, np.int64)])
         assert np.array_equal(order, np.arange(t.n_cells)), "lane_off of the tables must be lane-major over the macro lanes"
         self._garr = (_lib.NetstepGroup * max(1, len(self.groups)))(*[_lib.NetstepGroup(*g) for g in self.groups])
+        # the persistent kernels' maps: interface item lane_off[l] + lane_gpos[l] + k (k = 0 .. n) -> lane; cell -> lane
+        if_lane = np.zeros(max(1, t.n_cells + pos), dtype=np.int32)
+        cell_lane = np.zeros(max(1, t.n_cells), dtype=np.int32)
+        for l in range(L):
+            if lane_macro[l]:
+                b = lane_off[l] + lane_gpos[l]
+                if_lane[b:b + ncell[l] + 1] = l
+                cell_lane[lane_off[l]:lane_off[l] + ncell[l]] = l
         # ---- micro lanes, flux capacitors ----
         micro = [l for l in range(L) if not lane_macro[l]]
         mslot = -np.ones(L, dtype=np.int32)
@@ -114,24 +137,36 @@ class StepwiseNetwork:
         up = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=device)      # noqa: E731
         pad1 = lambda a: a if len(a) else np.zeros(1, dtype=np.int32)      # noqa: E731
         i32, f64 = torch.int32, torch.float64
+        stack = (lambda name: np.stack([getattr(x, name) for x in tabs])) if many else (lambda name: getattr(t, name))
         self.d = dict(
             lane_ncell=up(t.lane_ncell, i32), lane_off=up(lane_off, i32), sig_kind=up(t.sig_kind, i32), inter=up(t.inter, i32),
-            lane_dx=up(t.lane_dx, f64), left_src=up(t.left_src, i32), left_gate=up(t.left_gate, i32), right_src=up(t.right_src, i32),
-            schedule=up(t.schedule, f64), nxt_ptr=up(t.nxt_ptr, i32), nxt_idx=up(pad1(t.nxt_idx), i32), prv_ptr=up(t.prv_ptr, i32),
+            lane_dx=up(t.lane_dx, f64), left_src=up(stack("left_src"), i32), left_gate=up(stack("left_gate"), i32),
+            right_src=up(stack("right_src"), i32), schedule=up(stack("schedule"), f64), nxt_ptr=up(t.nxt_ptr, i32),
+            nxt_idx=up(pad1(t.nxt_idx), i32), prv_ptr=up(t.prv_ptr, i32),
             prv_idx=up(pad1(t.prv_idx), i32), lane_macro=up(lane_macro, i32), lane_len=up(t.lane_length, f64),
-            conv_next=up(t.conv_next, i32), routes=up(routes, i32), route_ptr=up(route_ptr, i32), lane_gpos=up(lane_gpos, i32),
+            conv_next=up(stack("conv_next"), i32), routes=up(routes, i32), route_ptr=up(route_ptr, i32), lane_gpos=up(lane_gpos, i32),
+            if_lane=up(if_lane, i32), cell_lane=up(cell_lane, i32),
             micro_lanes=up(pad1(np.asarray(micro, dtype=np.int32)), i32), lane_mslot=up(mslot, i32),
             cap_lanes=up(pad1(np.asarray(caps, dtype=np.int32)), i32), lane_cslot=up(cslot, i32))
         self.has_sources = bool(np.asarray(t.lane_source).any())
-        self.n_draws = 0
+        self.n_draws, self.draws_stride = 0, 0
         if self.has_sources:
-            d = np.asarray(t.draws, dtype=np.float64)
-            self.n_draws = len(d)
+            if many:
+                n = max(len(x.draws) for x in tabs)
+                d = np.full((len(tabs), n), 2.0)               # (a draw of 2.0 admits nobody)
+                for i, x in enumerate(tabs):
+                    d[i, :len(x.draws)] = x.draws
+                self.n_draws, self.draws_stride = n, n
+            else:
+                d = np.asarray(t.draws, dtype=np.float64)
+                self.n_draws = len(d)
             self.d["lane_source"], self.d["draws"] = up(t.lane_source, i32), up(d, f64)
         self.err = ops.new_error_record(device)
 
     # ---- per-episode data in place (same topology): new schedules / per-step routes / draws ----
     def update(self, tables):
+        if self.n_replicas:
+            raise ValueError("StepwiseNetwork.update: build a new network for other replica tables")
         t = as_hybrid_tables(tables)
         o = self.t
         same = (t.n_lanes == o.n_lanes and t.n_cells == o.n_cells and t.T == o.T and np.array_equal(t.lane_ncell, o.lane_ncell)
@@ -168,12 +203,15 @@ class StepwiseNetwork:
             self._csr_sq = sq
         p = lambda k: d[k].data_ptr()      # noqa: E731
         net = _lib.NetTables(p("lane_ncell"), p("lane_off"), p("sig_kind"), p("inter"), p("lane_dx"), p("left_src"), p("left_gate"),
-                             p("right_src"), p("schedule"), 0, p("nxt_ptr"), p("nxt_idx"), p("prv_ptr"), p("prv_idx"), self.t.n_edges)
+                             p("right_src"), p("schedule"), self.T * self.n_lanes if self.n_replicas else 0, p("nxt_ptr"), p("nxt_idx"),
+                             p("prv_ptr"), p("prv_idx"), self.t.n_edges)
         src = (p("lane_source"), p("draws")) if self.has_sources else (None, None)
         hyb = _lib.HybridTables(net, p("lane_macro"), p("lane_len"), p("conv_next"), p("routes"), p("route_ptr"), self.n_routes,
-                                self.route_stride, 0, int(loss_steps), self.n_micro, src[0], src[1], self.n_draws, 0, self.lane_capacity)
+                                self.route_stride, 0, int(loss_steps), self.n_micro, src[0], src[1], self.n_draws, self.draws_stride,
+                                self.lane_capacity)
         return _lib.NetstepTables(hyb, p("lane_gpos"), self._garr, len(self.groups), p("micro_lanes"), p("lane_mslot"), p("cap_lanes"),
-                                  p("lane_cslot"), self.n_caps, p("inter_ptr"), p("inter_idx"), self.max_events)
+                                  p("lane_cslot"), self.n_caps, p("inter_ptr"), p("inter_idx"), self.max_events, p("if_lane"), p("cell_lane"),
+                                  1 if self.persistent else 0)
 
     def rollout(self, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0, differentiable=True,
                 loss_steps=0, check_faults=True):
@@ -192,10 +230,14 @@ class StepwiseNetwork:
 class _NetstepRollout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, action, net, sq, F, dt, um, s0, vlen, differentiable, loss_steps, check_faults):
-        a = ops._f32c(action.detach().reshape(-1), "action")
+        R = net.n_replicas
+        a = ops._f32c(action.detach().reshape(R, -1) if R else action.detach().reshape(-1), "action")
+        if R and a.shape[0] != R:
+            raise ValueError("action must be [%d][A] for this network's %d replicas" % (R, R))
         dev = a.device
         lib = _lib.lib()
-        d = _lib.NetDesc(1, net.n_lanes, net.n_cells, net.T, sq, F, a.numel(), dt, um, s0, vlen)
+        Rn = max(R, 1)
+        d = _lib.NetDesc(Rn, net.n_lanes, net.n_cells, net.T, sq, F, a.numel() // Rn, dt, um, s0, vlen)
         tc = net._c(sq, loss_steps)
         ws_n = lib.dhts_netstep_workspace_bytes(C.byref(d), C.byref(tc))
         if ws_n == 0:
@@ -203,23 +245,27 @@ class _NetstepRollout(torch.autograd.Function):
         ws = getattr(net, "_ws", None)
         if ws is None or ws.numel() < ws_n:
             ws = net._ws = torch.empty(ws_n, dtype=torch.uint8, device=dev)
-        hist = torch.empty((net.T + 1, 4, max(net.n_cells, 1)), dtype=torch.float32, device=dev)
-        queue = torch.empty(net.T, net.n_lanes, dtype=torch.float32, device=dev)
-        reward = torch.empty(2, dtype=torch.float32, device=dev)
-        counts = torch.zeros(4, dtype=torch.int32, device=dev)
+        hist = torch.empty((Rn, net.T + 1, 4, max(net.n_cells, 1)), dtype=torch.float32, device=dev)
+        queue = torch.empty(Rn, net.T, net.n_lanes, dtype=torch.float32, device=dev)
+        reward = torch.empty(Rn, 2, dtype=torch.float32, device=dev)
+        counts = torch.zeros(Rn, 4, dtype=torch.int32, device=dev)
         net.err.zero_()
         _lib.check(lib.dhts_netstep_rollout_fwd(C.byref(d), C.byref(tc), 0 if differentiable else 1, ops._ptr(a), ops._ptr(hist), ops._ptr(queue),
                                                 ops._ptr(reward), ops._ptr(counts), ops._ptr(ws), ops._ptr(net.err), ops._stream()),
                    "dhts_netstep_rollout_fwd")
         if check_faults:
             ops.raise_on_fault(net.err)
-        net.last_hist = hist
+        net.last_hist = hist if R else hist[0]
         net._episode = ctx.episode = getattr(net, "_episode", 0) + 1
         ctx.net, ctx.d, ctx.tc, ctx.differentiable, ctx.check_faults = net, d, tc, differentiable, check_faults
-        ctx.save_for_backward(a, hist, queue, ws)
+        ctx.save_for_backward(a, hist, queue.reshape(Rn, net.T, net.n_lanes), ws)
         ctx.shape = action.shape
+        if not R:
+            queue, counts = queue[0], counts[0]
         ctx.mark_non_differentiable(queue, counts)
-        return reward[1].clone(), reward[0].clone().detach(), queue, counts
+        if R:
+            return reward[:, 1].clone(), reward[:, 0].clone().detach(), queue, counts
+        return reward[0, 1].clone(), reward[0, 0].clone().detach(), queue, counts
 
     @staticmethod
     def backward(ctx, g_cut, _g_reward, _g_queue, _g_counts):
@@ -229,7 +275,7 @@ class _NetstepRollout(torch.autograd.Function):
         net = ctx.net
         if getattr(net, "_ws", None) is not ws or net._episode != ctx.episode:
             raise RuntimeError("StepwiseNetwork: another rollout ran on this network before backward (one workspace per network)")
-        g = g_cut.reshape(1).contiguous().float()
+        g = g_cut.reshape(-1).contiguous().float()
         g_action = torch.empty_like(a)
         _lib.check(_lib.lib().dhts_netstep_rollout_bwd(C.byref(ctx.d), C.byref(ctx.tc), ops._ptr(a), ops._ptr(hist), ops._ptr(queue), ops._ptr(g),
                                                        ops._ptr(g_action), ops._ptr(ws), ops._ptr(net.err), ops._stream()),

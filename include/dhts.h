@@ -503,6 +503,16 @@ typedef struct dhts_netstep_tables {
     int32_t n_caps;
     const int32_t *inter_ptr, *inter_idx; /* device: ghost slots (2 lane + side) of every intersection, ascending ([sq + 1], [..]) */
     int32_t max_events;                /* capacity of the hand-off event list of an episode (0 = 8 per step) */
+    /* persistent != 0: the PERSISTENT form -- one kernel per direction, one workgroup per replica, all T steps, the workgroup's
+     * threads looping over the network's items with workgroup barriers where the stepwise form has kernel boundaries (same device
+     * functions: same numbers).  ~10 us per step (forward + reverse) at 360 lanes / 2 124 cells against ~100 us of launches; the
+     * one workgroup is the limit (beyond ~10 items per thread the stepwise form, which spreads a step over the chip, wins).
+     * n_replicas > 1 is allowed then: action [R][A], hist [R][T + 1][4][C], queue [R][T][L], reward [R][2], counts [R][4],
+     * g_reward [R], g_action [R][A]; per-replica [T][L] tables through hyb.net.replica_stride / hyb.draws_stride as in
+     * dhts_net_hybrid_rollout_fwd.  if_lane [n_cells + ARZ lanes] (device): the lane of interface item lane_off[l] + lane_gpos[l] +
+     * k, k = 0 .. n; cell_lane [n_cells] (device): the lane of every cell (group-major order). */
+    const int32_t *if_lane, *cell_lane;
+    int32_t persistent;
 } dhts_netstep_tables;
 size_t dhts_netstep_workspace_bytes(const dhts_net_desc *d, const dhts_netstep_tables *t);
 int dhts_netstep_rollout_fwd(const dhts_net_desc *d, const dhts_netstep_tables *t, int hard, const float *action, float *hist,

@@ -19,11 +19,11 @@ def _args(m):
             m["static_speed"], m["vehicle_length"])
 
 
-def _net(cuda, g, lane_capacity=32):
+def _net(cuda, g, lane_capacity=32, persistent=False):
     from dhts.stepwise import StepwiseNetwork
     t, m = itscp_hybrid_tables(g)
     routes = g["spawn_routes"] if g["spawn_routes"].shape[0] else -np.ones((1, 2), np.int32)
-    return StepwiseNetwork(t, routes, cuda, lane_capacity=lane_capacity), t, m
+    return StepwiseNetwork(t, routes, cuda, lane_capacity=lane_capacity, persistent=persistent), t, m
 
 
 def _run(cuda, net, m, action, loss_steps=0, differentiable=True):
@@ -230,3 +230,92 @@ def test_env_step_takes_the_stepwise_path_beyond_the_fused_limits(cuda, golden_d
     with torch.no_grad():
         _, r_eval, _, _ = twin.step(action.detach(), False)
     assert twin.last_path == "stepwise" and np.isfinite(float(r_eval))
+
+
+# ---- the PERSISTENT form: one kernel per direction, one workgroup per replica (same device functions) -------------------------------
+@pytest.mark.parametrize("name", HYBRID + ["macro_small", "macro", "macro_2x2", "macro_long", "macro_3x3x3"])
+def test_persistent_form_equals_stepwise_form_and_reference(cuda, golden_dir, name):
+    """Every hybrid / macro golden through the persistent kernels: the reference's queues, reward, vehicle count and gradient, and the
+    SAME numbers as the stepwise form (same device functions, the lanes' steps item by item with the operator's operations: queues
+    bit-identical, gradient to rounding of its accumulation order)."""
+    path = os.path.join(golden_dir, "itscp_%s.npz" % name)
+    if not os.path.exists(path):
+        pytest.skip("golden not generated")
+    g = np.load(path)
+    net_s, t, m = _net(cuda, g)
+    net_p, _, _ = _net(cuda, g, persistent=True)
+    o_s = _run(cuda, net_s, m, g["action"])
+    o_p = _run(cuda, net_p, m, g["action"])
+    assert np.array_equal(o_p["counts"], o_s["counts"]) and o_p["counts"][0] == m["n_vehicle_spawned"]
+    assert state_report("queues vs reference", o_p["queue"].T, g["queue"]) <= TOL_STATE
+    assert abs(o_p["reward"] - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+    scale = np.abs(g["g_action"]).max()
+    assert np.abs(o_p["grad"] - g["g_action"]).max() <= TOL_GRAD * scale
+    assert np.array_equal(o_p["queue"], o_s["queue"]) and o_p["reward"] == o_s["reward"]
+    print("%s: persistent vs stepwise gradient %.1e of max|g|" % (name, np.abs(o_p["grad"] - o_s["grad"]).max() / scale))
+    assert np.abs(o_p["grad"] - o_s["grad"]).max() <= 1e-6 * scale
+    for t0, ref in zip(g["g_action_cut_steps"][:1], g["g_action_cut"][:1]) if "g_action_cut_steps" in g.files else []:
+        oc = _run(cuda, net_p, m, g["action"], loss_steps=int(t0))
+        assert np.abs(oc["grad"] - ref).max() <= TOL_GRAD * scale, int(t0)
+    o2 = _run(cuda, net_p, m, g["action"])
+    assert np.array_equal(o2["grad"], o_p["grad"]) and np.array_equal(o2["queue"], o_p["queue"])            # repeatable
+    oe_s = _run(cuda, net_s, m, g["action"], differentiable=False)
+    oe_p = _run(cuda, net_p, m, g["action"], differentiable=False)
+    assert np.array_equal(oe_p["queue"], oe_s["queue"]) and np.array_equal(oe_p["counts"], oe_s["counts"])     # evaluation episodes too
+
+
+@pytest.mark.parametrize("name", ["micro_small", "micro_2x2"])
+def test_persistent_form_micro_mode(cuda, golden_dir, name):
+    from dhts.stepwise import StepwiseNetwork
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    t, m, rows = itscp_micro_tables(g)
+    o = _run(cuda, StepwiseNetwork(t, rows, cuda, persistent=True), m, g["action"])
+    o_s = _run(cuda, StepwiseNetwork(t, rows, cuda), m, g["action"])
+    assert o["counts"][0] == m["n_vehicle_spawned"] and o["counts"][3] == len(g["rand_draws"])
+    assert rel_max(o["queue"].T, g["queue"]) <= 1e-4 and rel_max(o["grad"], g["g_action"]) <= TOL_GRAD
+    assert np.array_equal(o["queue"], o_s["queue"]) and np.abs(o["grad"] - o_s["grad"]).max() <= 1e-6 * np.abs(o_s["grad"]).max()
+
+
+def test_persistent_replicas_equal_their_single_runs(cuda, golden_dir):
+    """R replicas of a network beyond the fused limits (own inflow schedules each) as R workgroups of one launch pair: every replica
+    equals its own single-replica run bit for bit; time per batch printed."""
+    import copy
+    import torch
+    from dhts.stepwise import StepwiseNetwork
+    name = "hybrid_n2l30" if os.path.exists(os.path.join(golden_dir, "itscp_hybrid_n2l30.npz")) else "hybrid_5x5"
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    t, m = itscp_hybrid_tables(g)
+    rng = np.random.default_rng(3)
+    R = 4
+    tabs, acts = [], []
+    for r in range(R):
+        x = copy.copy(t)
+        x.schedule = np.ascontiguousarray(t.schedule * (1.0 if r == 0 else rng.uniform(0.5, 1.0)))
+        tabs.append(x)
+        acts.append(g["action"] if r == 0 else rng.uniform(0.1, 0.9, len(g["action"])).astype(np.float32))
+    net = StepwiseNetwork(tabs, g["spawn_routes"], cuda, persistent=True)
+    a = torch.tensor(np.stack(acts), device=cuda, requires_grad=True)
+    cut, reward, queue, counts = net.rollout(a, *_args(m))
+    cut.sum().backward()
+    G, Q = a.grad.cpu().numpy(), queue.cpu().numpy()
+    assert abs(float(reward[0]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"])) and int(counts[0, 0]) == m["n_vehicle_spawned"]
+    assert not np.array_equal(Q[0], Q[1])
+    for r in range(R):
+        o = _run(cuda, StepwiseNetwork(tabs[r], g["spawn_routes"], cuda, persistent=True), m, acts[r])
+        assert np.array_equal(o["queue"], Q[r]) and np.array_equal(o["grad"], G[r]) and o["reward"] == float(reward[r])
+    for R2 in (1, 64):
+        tb = [tabs[r % R] for r in range(R2)]
+        net2 = StepwiseNetwork(tb, g["spawn_routes"], cuda, persistent=True)
+        a2 = torch.tensor(np.stack([acts[r % R] for r in range(R2)]), device=cuda, requires_grad=True)
+
+        def ep():
+            a2.grad = None
+            c2, _, _, _ = net2.rollout(a2, *_args(m), check_faults=False)
+            c2.sum().backward()
+        ep(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ep()
+        torch.cuda.synchronize()
+        print("persistent form, %s (%d lanes, %d cells, %d steps), %2d replica(s): %.2f ms per differentiable batch episode" % (
+            name, t.n_lanes, t.n_cells, t.T, R2, 1e3 * (time.perf_counter() - t0) / 3))
