@@ -76,7 +76,13 @@ struct NsArgs {
     const double *draws;
     const int32_t *nxt_ptr, *nxt_idx, *prv_ptr, *prv_idx, *inter_ptr, *inter_idx;
     const int32_t *if_lane, *cell_lane;      // the persistent kernels' maps: interface -> lane, cell -> lane (NI = cells + ARZ lanes)
-    int NI;
+    int NI, n_edges, n_islots, stage;          // stage: the persistent kernels copy the static tables into LDS (they fit)
+    // what else a persistent kernel keeps in LDS (null = in the workspace / the history): the state rows t and t + 1 ([2][4][C], row r in
+    // copy r & 1), the cotangent planes ([2][3][C]), the per-step table rows of steps t and t + 1 ([2][L] each), ghosts / slots / ghost cotangents
+    float *st, *gl, *gh, *sl;
+    double *gg;
+    int32_t *row_i;        // [2][4][L]: left_src, left_gate, right_src, conv_next
+    double *row_d;         // [2][L]: schedule
     long long table_stride, draws_stride;    // elements between replicas in the [T][L] tables / the draws (0 = shared)
     char *ws;
     NsLayout lo;
@@ -86,6 +92,30 @@ struct NsArgs {
 };
 
 template <typename T> __device__ __forceinline__ T *ns_ptr(const NsArgs &a, size_t off) { return reinterpret_cast<T *>(a.ws + off); }
+// the state before / after step t, the cotangent planes of the state after step r, the per-step table rows of step t
+__device__ __forceinline__ float *ns_state(const NsArgs &a, int r) {
+    return a.st ? a.st + (size_t)(r & 1) * 4 * a.C : a.hist + (size_t)r * 4 * a.C;
+}
+__device__ __forceinline__ float *ns_G(const NsArgs &a, int r) {
+    return (a.gl ? a.gl : ns_ptr<float>(a, a.lo.G)) + (size_t)(r & 1) * 3 * a.C;
+}
+struct NsRow { const int32_t *left_src, *left_gate, *right_src, *conv_next; const double *schedule; };
+__device__ __forceinline__ NsRow ns_row(const NsArgs &a, int t) {
+    NsRow r;
+    if (a.row_i) {
+        const int32_t *b = a.row_i + (size_t)(t & 1) * 4 * a.L;
+        r.left_src = b; r.left_gate = b + a.L; r.right_src = b + 2 * a.L; r.conv_next = b + 3 * a.L;
+        r.schedule = a.row_d + (size_t)(t & 1) * a.L;
+    } else {
+        const size_t o = (size_t)t * a.L;
+        r.left_src = a.left_src + o; r.left_gate = a.left_gate + o; r.right_src = a.right_src + o; r.conv_next = a.conv_next + o;
+        r.schedule = a.schedule + o;
+    }
+    return r;
+}
+__device__ __forceinline__ float *ns_ghosts(const NsArgs &a) { return a.gh ? a.gh : ns_ptr<float>(a, a.lo.ghost); }
+__device__ __forceinline__ float *ns_slots(const NsArgs &a) { return a.sl ? a.sl : ns_ptr<float>(a, a.lo.slot); }
+__device__ __forceinline__ double *ns_gghost(const NsArgs &a) { return a.gg ? a.gg : ns_ptr<double>(a, a.lo.g_ghost); }
 
 // inclusive block scan (blockDim.x = multiple of 64, <= 1024); `w` = 16 elements of LDS scratch; returns the inclusive prefix,
 // `total` = the block's sum.  Two barriers.
@@ -166,8 +196,8 @@ __device__ __forceinline__ void ns_ghost_fwd_item(const NsArgs &a, int t, const 
     const int L = a.L, C = a.C;
     const bool hard = a.hard != 0;
     const float um = a.um;
-    const float *cur = a.hist + (size_t)t * 4 * C;
-    const size_t row = (size_t)t * L;
+    const float *cur = ns_state(a, t);
+    const NsRow rw = ns_row(a, t);
     {
         if (j >= 2 * L) return;
         const int lane = j >> 1, side = j & 1;
@@ -179,9 +209,9 @@ __device__ __forceinline__ void ns_ghost_fwd_item(const NsArgs &a, int t, const 
         }
         float fr, fu, fy, fq;
         if (side == 0) {
-            const int ls = a.left_src[row + lane], lg = a.left_gate[row + lane];
+            const int ls = rw.left_src[lane], lg = rw.left_gate[lane];
             if (ls == -1) {                    // source lane: Python floats in the reference (_simulator.py:68-71)
-                const double sched = a.schedule[row + lane];
+                const double sched = rw.schedule[lane];
                 const double gu = a.um_d * (1. - sqrt(fmax(sched, 0.) + kEps));
                 fr = (float)sched; fu = (float)gu; fy = 0.f; fq = (float)gu;          // y = r (u - u_eq(r)) = 0
             } else {
@@ -193,7 +223,7 @@ __device__ __forceinline__ void ns_ghost_fwd_item(const NsArgs &a, int t, const 
                 glue_from_r_u(fr, fu, um, fy, fq);
             }
         } else {
-            const int rs = a.right_src[row + lane];
+            const int rs = rw.right_src[lane];
             float gr = own_in[2 * lane], gu = own_in[2 * lane + 1];
             if (rs >= 0) { const int first = a.lane_off[rs]; gr = cur[first]; gu = cur[2 * C + first]; }
             const float sg = ns_lane_signal(a, action, t, lane, hard, nullptr, nullptr);
@@ -203,7 +233,7 @@ __device__ __forceinline__ void ns_ghost_fwd_item(const NsArgs &a, int t, const 
             glue_from_r_u(fr, fu, um, fy, fq);
             own_out[2 * lane] = fr; own_out[2 * lane + 1] = fu;
         }
-        float *g = ns_ptr<float>(a, a.lo.ghost) + ((size_t)a.lane_gpos[lane] * 2 + side) * 4;
+        float *g = ns_ghosts(a) + ((size_t)a.lane_gpos[lane] * 2 + side) * 4;
         g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
     }
 }
@@ -253,7 +283,7 @@ __device__ __forceinline__ void ns_micro_fwd(const NsArgs &a, int t, const float
                 else {
                     const double draw = a.draws[idx];
                     const int r_lo = a.route_ptr[l], r_n = a.route_ptr[l + 1] - r_lo;
-                    if (draw < a.schedule[row + l] && rused[l] < r_n) {
+                    if (draw < ns_row(a, t).schedule[l] && rused[l] < r_n) {
                         if (n >= cap) net_fault(a.err, DHTS_FAULT_CAPACITY, t, l, n);
                         else {
                             const size_t b = (size_t)m * cap;
@@ -418,7 +448,8 @@ __device__ __forceinline__ void ns_convert(const NsArgs &a, int t, int *cand) { 
     const float um = a.um, vlen = a.vlen, dtf = a.dtf, s0f = a.s0f;
     __shared__ double scan_d[16];
     __shared__ int scan_i[16];
-    float *nxt = a.hist + (size_t)(t + 1) * 4 * C;     // committed state: the lanes' operators wrote it
+    float *nxt = ns_state(a, t + 1);                   // committed state: the lanes' steps wrote it
+    const NsRow rw = ns_row(a, t);
     float *Rn = nxt, *Yn = nxt + C, *Un = nxt + 2 * C;
     const size_t row = (size_t)t * L;
     const size_t plane = (size_t)Lm * cap;
@@ -439,7 +470,7 @@ __device__ __forceinline__ void ns_convert(const NsArgs &a, int t, int *cand) { 
         // ---- flux capacitors: += r u dt of the last cell (conversion.py:32-45) ----
         for (int k = tid; k < a.ncap; k += B) {
             const int l = a.cap_lanes[k];
-            const int m = a.conv_next[row + l];
+            const int m = rw.conv_next[l];
             int flag = 0;
             if (m >= 0 && !a.lane_macro[m]) {
                 const int last = a.lane_off[l] + a.lane_ncell[l] - 1;
@@ -476,7 +507,7 @@ __device__ __forceinline__ void ns_convert(const NsArgs &a, int t, int *cand) { 
                         if (a.lane_macro[l]) {
                             // macro -> micro (conversion.py:16-73)
                             const int k = a.lane_cslot[l];
-                            const int m = a.conv_next[row + l];
+                            const int m = rw.conv_next[l];
                             if (capflag[k] & NS_CAP_SERIAL) { NsEvent e = {}; e.kind = NS_EV_CAPSERIAL; e.lane = l; ns_push_event(a, cnt, t, e); }
                             const float level = capv[k];
                             const int ms = a.lane_mslot[m];
@@ -688,9 +719,9 @@ __device__ __forceinline__ void ns_micro_bwd(const NsArgs &a, int t, const float
     const int L = a.L, C = a.C, Lm = a.Lm, cap = a.cap;
     const float um = a.um, vlen = a.vlen, dtf = a.dtf, s0f = a.s0f;
     __shared__ int scan_i[16];
-    const float *nxt = a.hist + (size_t)(t + 1) * 4 * C;
+    const float *nxt = ns_state(a, t + 1);
     const float *Rn = nxt, *Yn = nxt + C, *Un = nxt + 2 * C;
-    float *G = ns_ptr<float>(a, a.lo.G) + (size_t)((t + 1) & 1) * 3 * C;       // cotangent of (r, y, u) of the state after step t
+    float *G = ns_G(a, t + 1);                         // cotangent of (r, y, u) of the state after step t
     float *Gr = G, *Gy = G + C, *Gu = G + 2 * C;
     const size_t row = (size_t)t * L;
     const size_t plane = (size_t)Lm * cap;
@@ -920,16 +951,16 @@ __device__ __forceinline__ void ns_ghost_bwd_item(const NsArgs &a, int t, const 
     const int L = a.L, C = a.C;
     if (j >= 2 * L) return;
     const int lane = j >> 1, side = j & 1;
-    float *sl = ns_ptr<float>(a, a.lo.slot) + (size_t)j * 4;
+    float *sl = ns_slots(a) + (size_t)j * 4;
     float add_r = 0.f, add_u = 0.f, a_val = 0.f; int a_key = -1;
     if (a.lane_macro[lane]) {
         const float um = a.um;
-        const float *cur = a.hist + (size_t)t * 4 * C;
-        const size_t row = (size_t)t * L;
-        const double *gg = ns_ptr<double>(a, a.lo.g_ghost) + ((size_t)a.lane_gpos[lane] * 2 + side) * 2;
+        const float *cur = ns_state(a, t);
+        const NsRow rw = ns_row(a, t);
+        const double *gg = ns_gghost(a) + ((size_t)a.lane_gpos[lane] * 2 + side) * 2;
         const float gg_r = (float)gg[0], gg_y = (float)gg[1];
         if (side == 0) {
-            const int ls = a.left_src[row + lane], lg = a.left_gate[row + lane];
+            const int ls = rw.left_src[lane], lg = rw.left_gate[lane];
             if (ls >= 0) {
                 const int last = a.lane_off[ls] + a.lane_ncell[ls] - 1;
                 const float grn_r = cur[last], grn_u = cur[2 * C + last];
@@ -943,7 +974,7 @@ __device__ __forceinline__ void ns_ghost_bwd_item(const NsArgs &a, int t, const 
                 if (ai >= 0) { a_val = (g_fr * grn_r + g_fu * (grn_u - um)) * ds; a_key = ai; }
             }
         } else {
-            const int rs = a.right_src[row + lane];
+            const int rs = rw.right_src[lane];
             const float *own_in = ns_ptr<float>(a, a.lo.own_hist) + (size_t)t * 2 * L;
             float *g_own = ns_ptr<float>(a, a.lo.g_own);
             const int first = rs < 0 ? 0 : a.lane_off[rs];
@@ -973,20 +1004,20 @@ __global__ void ns_ghosts_bwd_kernel(NsArgs a, int t, const float *__restrict__ 
 // the last cell, upstream lanes ascending for the first); threads q < sq sum their intersection's action partials in slot order
 __device__ __forceinline__ void ns_ghost_gather_item(const NsArgs &a, int t, int m) {
     const int L = a.L, C = a.C;
-    const float *slot = ns_ptr<float>(a, a.lo.slot);
-    float *G = ns_ptr<float>(a, a.lo.G) + (size_t)(t & 1) * 3 * C;
-    const size_t row = (size_t)t * L;
+    const float *slot = ns_slots(a);
+    float *G = ns_G(a, t);
+    const NsRow rw = ns_row(a, t);
     if (m < L && a.lane_macro[m]) {
         const int first = a.lane_off[m], last = first + a.lane_ncell[m] - 1;
         float vr = 0.f, vu = 0.f;
         for (int e = a.nxt_ptr[m]; e < a.nxt_ptr[m + 1]; ++e) {
             const int b = a.nxt_idx[e];
-            if (a.lane_macro[b] && a.left_src[row + b] == m) { vr += slot[(size_t)(2 * b) * 4]; vu += slot[(size_t)(2 * b) * 4 + 1]; }
+            if (a.lane_macro[b] && rw.left_src[b] == m) { vr += slot[(size_t)(2 * b) * 4]; vu += slot[(size_t)(2 * b) * 4 + 1]; }
         }
         float wr = 0.f, wu = 0.f;
         for (int e = a.prv_ptr[m]; e < a.prv_ptr[m + 1]; ++e) {
             const int b = a.prv_idx[e];
-            if (a.lane_macro[b] && a.right_src[row + b] == m) { wr += slot[(size_t)(2 * b + 1) * 4]; wu += slot[(size_t)(2 * b + 1) * 4 + 1]; }
+            if (a.lane_macro[b] && rw.right_src[b] == m) { wr += slot[(size_t)(2 * b + 1) * 4]; wu += slot[(size_t)(2 * b + 1) * 4 + 1]; }
         }
         if (first == last) { G[first] += vr + wr; G[2 * C + first] += vu + wu; }
         else { G[last] += vr; G[2 * C + last] += vu; G[first] += wr; G[2 * C + first] += wu; }
@@ -1026,54 +1057,43 @@ __device__ __forceinline__ NsArgs ns_replica_args(const NsArgs &a0, int rep) {
     return a;
 }
 
-// interfaces of step t: ARZ.riemann_solve + the two Jacobian products per interface (item i = lane_off + gpos + k, k = 0 .. n)
-__device__ __forceinline__ void ns_iface_item(const NsArgs &a, int t, int i, int &fault_step, int &fault_lane, int &fault_index) {
-    const int C = a.C;
-    const int l = a.if_lane[i];
-    const int off = a.lane_off[l], n = a.lane_ncell[l], gp = a.lane_gpos[l];
-    const int k = i - (off + gp);
-    const float *cur = a.hist + (size_t)t * 4 * C;
-    const float *gh = ns_ptr<float>(a, a.lo.ghost) + (size_t)gp * 8;
-    double rL, yL, uL, qL, rR, yR, uR, qR;
-    if (k == 0) { rL = gh[0]; yL = gh[1]; uL = gh[2]; qL = gh[3]; }
-    else { const int c = off + k - 1; rL = cur[c]; yL = cur[C + c]; uL = cur[2 * C + c]; qL = cur[3 * C + c]; }
-    if (k == n) { rR = gh[4]; yR = gh[5]; uR = gh[6]; qR = gh[7]; }
-    else { const int c = off + k; rR = cur[c]; yR = cur[C + c]; uR = cur[2 * C + c]; qR = cur[3 * C + c]; }
-    IfaceConst kc;
-    kc.set_um(a.um_d); kc.set_grid(a.dt_d, a.lane_dx[l]);
-    Iface f;
-    arz_interface(rL, yL, uL, qL, rR, yR, uR, qR, kc, f);
-    if (f.cfl_bad && fault_step < 0) { fault_step = t; fault_lane = l; fault_index = k; }
-    double *F = ns_ptr<double>(a, a.lo.pF) + 2 * (size_t)i;
-    F[0] = f.Fr; F[1] = f.Fy;
-    float4 *ab = ns_ptr<float4>(a, a.lo.pAB) + 2 * (size_t)i;
-    ab[0] = make_float4(f.A[0], f.A[1], f.A[2], f.A[3]);
-    ab[1] = make_float4(f.B[0], f.B[1], f.B[2], f.B[3]);
-}
-// cells of step t: Godunov update, float32 glue, the cell's three blocks (MacroLane.forward, _macro_lane.py:103-114;
-// dmacro_lane.py:126-129) -- the operations of the straight-lane operator's kernel, item by item
-__device__ __forceinline__ void ns_cell_item(const NsArgs &a, int t, int c) {
+// One cell of step t: BOTH its interfaces (ARZ.riemann_solve + the two Jacobian products each, redone by the neighbouring cell's
+// thread: a solve costs less than handing its result over), Godunov update, float32 glue, the cell's three blocks (MacroLane.forward,
+// _macro_lane.py:83-146; dMacroLane._backward, dmacro_lane.py:96-132) -- the operations of the straight-lane operator's kernel
+__device__ __forceinline__ void ns_cell_item(const NsArgs &a, int t, int c, int &fault_step, int &fault_lane, int &fault_index) {
     const int C = a.C;
     const int l = a.cell_lane[c];
-    const int iL = c + a.lane_gpos[l], iR = iL + 1;
-    const double cc = a.dt_d / a.lane_dx[l];
-    const float *cur = a.hist + (size_t)t * 4 * C;
-    float *nxt = a.hist + (size_t)(t + 1) * 4 * C;
-    const double *F = ns_ptr<double>(a, a.lo.pF);
-    const float nr = (float)((double)cur[c] + (F[2 * iL] - F[2 * iR]) * cc);
-    const float ny = (float)((double)cur[C + c] + (F[2 * iL + 1] - F[2 * iR + 1]) * cc);
+    const int off = a.lane_off[l], n = a.lane_ncell[l];
+    const int k = c - off;
+    const double dx = a.lane_dx[l];
+    const double cc = a.dt_d / dx;
+    const float *cur = ns_state(a, t);
+    float *nxt = ns_state(a, t + 1);
+    const float *gh = ns_ghosts(a) + (size_t)a.lane_gpos[l] * 8;
+    const double r0 = cur[c], y0 = cur[C + c], u0 = cur[2 * C + c], q0 = cur[3 * C + c];
+    double rL, yL, uL, qL, rR, yR, uR, qR;
+    if (k == 0) { rL = gh[0]; yL = gh[1]; uL = gh[2]; qL = gh[3]; }
+    else { rL = cur[c - 1]; yL = cur[C + c - 1]; uL = cur[2 * C + c - 1]; qL = cur[3 * C + c - 1]; }
+    if (k == n - 1) { rR = gh[4]; yR = gh[5]; uR = gh[6]; qR = gh[7]; }
+    else { rR = cur[c + 1]; yR = cur[C + c + 1]; uR = cur[2 * C + c + 1]; qR = cur[3 * C + c + 1]; }
+    IfaceConst kc;
+    kc.set_um(a.um_d); kc.set_grid(a.dt_d, dx);
+    Iface fl, fr;
+    arz_interface(rL, yL, uL, qL, r0, y0, u0, q0, kc, fl);
+    arz_interface(r0, y0, u0, q0, rR, yR, uR, qR, kc, fr);
+    if (fault_step < 0 && (fl.cfl_bad || (k == n - 1 && fr.cfl_bad))) { fault_step = t; fault_lane = l; fault_index = fl.cfl_bad ? k : n; }
+    const float nr = (float)(r0 + (fl.Fr - fr.Fr) * cc);
+    const float ny = (float)(y0 + (fl.Fy - fr.Fy) * cc);
     float nu, nq;
     glue_from_r_y(nr, ny, a.um, nu, nq);
     nxt[c] = nr; nxt[C + c] = ny; nxt[2 * C + c] = nu; nxt[3 * C + c] = nq;
     if (!a.hard) {
         const float cf = (float)cc, ncf = (float)(-cc);
-        const float4 *ab = ns_ptr<float4>(a, a.lo.pAB);
-        const float4 aL = ab[2 * iL], bL = ab[2 * iL + 1], aR = ab[2 * iR], bR = ab[2 * iR + 1];
         float4 d0, d1, d2;
-        d0.x = ncf * (-aL.x); d0.y = ncf * (-aL.y); d0.z = ncf * (-aL.z); d0.w = ncf * (-aL.w);
-        d2.x = ncf * bR.x; d2.y = ncf * bR.y; d2.z = ncf * bR.z; d2.w = ncf * bR.w;
-        d1.x = 1.f - cf * (aR.x - bL.x); d1.y = 0.f - cf * (aR.y - bL.y);
-        d1.z = 0.f - cf * (aR.z - bL.z); d1.w = 1.f - cf * (aR.w - bL.w);
+        d0.x = ncf * (-fl.A[0]); d0.y = ncf * (-fl.A[1]); d0.z = ncf * (-fl.A[2]); d0.w = ncf * (-fl.A[3]);
+        d2.x = ncf * fr.B[0]; d2.y = ncf * fr.B[1]; d2.z = ncf * fr.B[2]; d2.w = ncf * fr.B[3];
+        d1.x = 1.f - cf * (fr.A[0] - fl.B[0]); d1.y = 0.f - cf * (fr.A[1] - fl.B[1]);
+        d1.z = 0.f - cf * (fr.A[2] - fl.B[2]); d1.w = 1.f - cf * (fr.A[3] - fl.B[3]);
         float4 *tp = ns_ptr<float4>(a, a.lo.ptape) + ((size_t)t * C + c) * 3;
         tp[0] = d0; tp[1] = d1; tp[2] = d2;
     }
@@ -1085,84 +1105,236 @@ __device__ __forceinline__ void ns_cell_bwd_item(const NsArgs &a, int t, int c) 
     const int l = a.cell_lane[c];
     const int off = a.lane_off[l], n = a.lane_ncell[l];
     const int k = c - off;
-    const float *Gn = ns_ptr<float>(a, a.lo.G) + (size_t)((t + 1) & 1) * 3 * C;
-    float *Gp = ns_ptr<float>(a, a.lo.G) + (size_t)(t & 1) * 3 * C;
+    const float *Gn = ns_G(a, t + 1);
+    float *Gp = ns_G(a, t);
     const float4 *tp = ns_ptr<float4>(a, a.lo.ptape) + ((size_t)t * C + c) * 3;
     const float gr = Gn[c], gy = Gn[C + c];
     const float4 d0 = tp[0], d1 = tp[1], d2 = tp[2];
+    float4 e2 = make_float4(0.f, 0.f, 0.f, 0.f), e0 = e2;
+    if (k > 0) e2 = tp[-1];              // dqs[c - 1][2]
+    if (k < n - 1) e0 = tp[3];           // dqs[c + 1][0]
     float vr = dot2(d1.x, gr, d1.z, gy), vy = dot2(d1.y, gr, d1.w, gy);
     float c2r = 0.f, c2y = 0.f, c0r = 0.f, c0y = 0.f;
-    if (k > 0) { const float4 e = tp[-3 + 2]; const float hr = Gn[c - 1], hy = Gn[C + c - 1]; c2r = dot2(e.x, hr, e.z, hy); c2y = dot2(e.y, hr, e.w, hy); }
-    if (k < n - 1) { const float4 e = tp[3]; const float hr = Gn[c + 1], hy = Gn[C + c + 1]; c0r = dot2(e.x, hr, e.z, hy); c0y = dot2(e.y, hr, e.w, hy); }
-    Gp[c] = (vr + c2r) + c0r;
-    Gp[C + c] = (vy + c2y) + c0y;
-    Gp[2 * C + c] = 0.f;
-    double *gg = ns_ptr<double>(a, a.lo.g_ghost) + (size_t)a.lane_gpos[l] * 4;
+    if (k > 0) { const float hr = Gn[c - 1], hy = Gn[C + c - 1]; c2r = dot2(e2.x, hr, e2.z, hy); c2y = dot2(e2.y, hr, e2.w, hy); }
+    if (k < n - 1) { const float hr = Gn[c + 1], hy = Gn[C + c + 1]; c0r = dot2(e0.x, hr, e0.z, hy); c0y = dot2(e0.y, hr, e0.w, hy); }
+    const float pr = (vr + c2r) + c0r, py = (vy + c2y) + c0y;
+    Gp[c] = pr; Gp[C + c] = py; Gp[2 * C + c] = 0.f;
+    double *gg = ns_gghost(a) + (size_t)a.lane_gpos[l] * 4;
     if (k == 0) { gg[0] = (double)dot2(d0.x, gr, d0.z, gy); gg[1] = (double)dot2(d0.y, gr, d0.w, gy); }
     if (k == n - 1) { gg[2] = (double)dot2(d2.x, gr, d2.z, gy); gg[3] = (double)dot2(d2.y, gr, d2.w, gy); }
-    if (!(isfinite(Gp[c]) && isfinite(Gp[C + c]))) net_fault(a.err, DHTS_FAULT_NAN, t, l, k);
+    if (!(isfinite(pr) && isfinite(py))) net_fault(a.err, DHTS_FAULT_NAN, t, l, k);
 }
 
-__global__ void __launch_bounds__(kNsBlock) ns_persist_fwd_kernel(NsArgs a0, const float *__restrict__ action_all) {
+// The static tables of a network (per lane, per interface, per cell, adjacency) staged in LDS for a persistent kernel: every item of
+// every phase starts with a chain of dependent look-ups (item -> lane -> offsets -> state), each link a global-memory latency
+// otherwise.  The functions above read them through NsArgs' pointers, which are simply redirected.
+__host__ __device__ inline size_t ns_al16(size_t x) { return (x + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t ns_stage_bytes(int L, int C, int NI, int Lm, int ncap, int n_edges, int sq, int n_islots, bool sources) {
+    return 8 * ns_al16(4 * (size_t)L) + (sources ? ns_al16(4 * (size_t)L) : 0) + 2 * ns_al16(8 * (size_t)L) + ns_al16(4 * (size_t)NI) +
+           ns_al16(4 * (size_t)(C > 0 ? C : 1)) + ns_al16(4 * (size_t)(Lm > 0 ? Lm : 1)) + ns_al16(4 * (size_t)(ncap > 0 ? ncap : 1)) +
+           2 * ns_al16(4 * (size_t)(L + 1)) + 2 * ns_al16(4 * (size_t)(n_edges > 0 ? n_edges : 1)) + ns_al16(4 * (size_t)(sq + 1)) +
+           ns_al16(4 * (size_t)(n_islots > 0 ? n_islots : 1));
+}
+template <typename T>
+__device__ __forceinline__ const T *ns_stage(const T *src, size_t n, char *&p) {
+    T *dst = reinterpret_cast<T *>(p);
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    p += ns_al16(n * sizeof(T));
+    return dst;
+}
+__device__ __forceinline__ void ns_stage_tables(NsArgs &a, char *p) {
+    if (!a.stage) return;
+    const size_t L = a.L;
+    a.lane_ncell = ns_stage(a.lane_ncell, L, p); a.lane_off = ns_stage(a.lane_off, L, p); a.sig_kind = ns_stage(a.sig_kind, L, p);
+    a.inter = ns_stage(a.inter, L, p); a.lane_macro = ns_stage(a.lane_macro, L, p); a.lane_gpos = ns_stage(a.lane_gpos, L, p);
+    a.lane_mslot = ns_stage(a.lane_mslot, L, p); a.lane_cslot = ns_stage(a.lane_cslot, L, p);
+    if (a.lane_source) a.lane_source = ns_stage(a.lane_source, L, p);
+    a.lane_dx = ns_stage(a.lane_dx, L, p); a.lane_len = ns_stage(a.lane_len, L, p);
+    a.if_lane = ns_stage(a.if_lane, (size_t)a.NI, p); a.cell_lane = ns_stage(a.cell_lane, (size_t)(a.C > 0 ? a.C : 1), p);
+    a.micro_lanes = ns_stage(a.micro_lanes, (size_t)(a.Lm > 0 ? a.Lm : 1), p); a.cap_lanes = ns_stage(a.cap_lanes, (size_t)(a.ncap > 0 ? a.ncap : 1), p);
+    a.nxt_ptr = ns_stage(a.nxt_ptr, L + 1, p); a.prv_ptr = ns_stage(a.prv_ptr, L + 1, p);
+    a.nxt_idx = ns_stage(a.nxt_idx, (size_t)(a.n_edges > 0 ? a.n_edges : 1), p); a.prv_idx = ns_stage(a.prv_idx, (size_t)(a.n_edges > 0 ? a.n_edges : 1), p);
+    a.inter_ptr = ns_stage(a.inter_ptr, (size_t)a.sq + 1, p); a.inter_idx = ns_stage(a.inter_idx, (size_t)(a.n_islots > 0 ? a.n_islots : 1), p);
+}
+
+// what a persistent kernel carves out of its dynamic LDS behind the phases' scratch (host and device agree through this plan)
+struct NsPlan { int scratch, tables, st, gl, rows, misc; };       // byte sizes (0 = not staged)
+__device__ __forceinline__ void ns_carve(NsArgs &a, char *lds, const NsPlan &pl) {
+    char *p = lds + pl.scratch;
+    if (pl.tables) { a.stage = 1; char *q = p; ns_stage_tables(a, q); p += pl.tables; } else a.stage = 0;
+    a.st = nullptr; a.gl = nullptr; a.row_i = nullptr; a.row_d = nullptr; a.gh = nullptr; a.sl = nullptr; a.gg = nullptr;
+    if (pl.st) { a.st = reinterpret_cast<float *>(p); p += pl.st; }
+    if (pl.gl) { a.gl = reinterpret_cast<float *>(p); p += pl.gl; }
+    if (pl.rows) {
+        a.row_d = reinterpret_cast<double *>(p); a.row_i = reinterpret_cast<int32_t *>(p + ns_al16(16 * (size_t)a.L));
+        p += pl.rows;
+    }
+    if (pl.misc) {
+        const size_t lg = ns_al16(32 * (size_t)a.L);
+        a.gg = reinterpret_cast<double *>(p); a.gh = reinterpret_cast<float *>(p + lg); a.sl = reinterpret_cast<float *>(p + 2 * lg);
+    }
+}
+// the table rows of step r into their LDS copy (r & 1): every thread fetches its elements (registers `v`), stores them later
+struct NsRowRegs { int32_t i[4]; double d; };
+__device__ __forceinline__ void ns_rows_fetch(const NsArgs &a, const NsArgs &g, int r, int l, NsRowRegs &v) {      // g: the global pointers
+    const size_t o = (size_t)r * a.L + l;
+    v.i[0] = g.left_src[o]; v.i[1] = g.left_gate[o]; v.i[2] = g.right_src[o]; v.i[3] = g.conv_next[o]; v.d = g.schedule[o];
+}
+__device__ __forceinline__ void ns_rows_store(const NsArgs &a, int r, int l, const NsRowRegs &v) {
+    int32_t *b = a.row_i + (size_t)(r & 1) * 4 * a.L;
+    b[l] = v.i[0]; b[a.L + l] = v.i[1]; b[2 * a.L + l] = v.i[2]; b[3 * a.L + l] = v.i[3];
+    a.row_d[(size_t)(r & 1) * a.L + l] = v.d;
+}
+
+__global__ void __launch_bounds__(kNsBlock) ns_persist_fwd_kernel(NsArgs a0, const float *__restrict__ action_all, NsPlan pl) {
     extern __shared__ double lds_p[];
-    const NsArgs a = ns_replica_args(a0, blockIdx.x);
-    const float *action = action_all + (size_t)blockIdx.x * a.n_action;
+    // the replica's arguments -- ~130 pointers and offsets, some redirected into LDS -- live in LDS themselves: as a local copy they
+    // cost 487 scalar-register spills and 79 vector ones (scratch traffic inside every phase)
+    __shared__ NsArgs ag_s, a_s;
+    if (threadIdx.x == 0) { ag_s = ns_replica_args(a0, blockIdx.x); a_s = ag_s; }
+    __syncthreads();
+    {
+        NsArgs tmp = a_s;
+        ns_carve(tmp, reinterpret_cast<char *>(lds_p), pl);       // (every thread copies its share of the tables)
+        __syncthreads();
+        if (threadIdx.x == 0) a_s = tmp;
+        __syncthreads();
+    }
+    const NsArgs &ag = ag_s;                                    // the global pointers
+    const NsArgs &a = a_s;
+    const float *action = action_all + (size_t)blockIdx.x * a0.n_action;
     const int tid = threadIdx.x, B = blockDim.x;
-    const int L = a.L, C = a.C, T = a.T;
+    const int L = a0.L, C = a0.C, T = a0.T;
     // the episode's running state: empty road (MacroLane.__init__), stored ghosts (0, u_max), no vehicles, counters zero
-    for (int i = tid; i < C; i += B) { a.hist[i] = 0.f; a.hist[C + i] = 0.f; a.hist[2 * C + i] = a.um; a.hist[3 * C + i] = a.um; }
+    {
+        float *s0 = ns_state(a, 0);
+        for (int i = tid; i < C; i += B) {
+            s0[i] = 0.f; s0[C + i] = 0.f; s0[2 * C + i] = a.um; s0[3 * C + i] = a.um;
+            if (a.st) { a.hist[i] = 0.f; a.hist[C + i] = 0.f; a.hist[2 * C + i] = a.um; a.hist[3 * C + i] = a.um; }
+        }
+    }
     for (int i = tid; i < L; i += B) { float *o = ns_ptr<float>(a, a.lo.own_hist); o[2 * i] = 0.f; o[2 * i + 1] = a.um; }
     {
         unsigned *z = ns_ptr<unsigned>(a, a.lo.P);
         const size_t nz = (a.lo.counters + sizeof(NsCounters) - a.lo.P) / 4;
         for (size_t i = tid; i < nz; i += B) z[i] = 0u;
     }
+    if (a.row_i) for (int l = tid; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, ag, 0, l, v); ns_rows_store(a, 0, l, v); }
     __syncthreads();
     int fault_step = -1, fault_lane = 0, fault_index = 0;
+#ifdef DHTS_NS_STAMPS
+    long long st_[6] = {0, 0, 0, 0, 0, 0}, st_last_ = __builtin_amdgcn_s_memtime();
+#define NS_STAMP(i) { const long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_last_; st_last_ = n_; }
+#else
+#define NS_STAMP(i)
+#endif
     for (int t = 0; t < T; ++t) {
+        // the next step's table rows: fetched now (one lane per thread; further lanes of wider networks at the end of the step)
+        NsRowRegs nx;
+        const bool pre = a.row_i && t + 1 < T && tid < L;
+        if (pre) ns_rows_fetch(a, ag, t + 1, tid, nx);
         for (int j = tid; j < 2 * L; j += B) ns_ghost_fwd_item(a, t, action, j);
+        NS_STAMP(0)
         ns_micro_fwd(a, t, action, reinterpret_cast<float *>(lds_p));
         __syncthreads();
-        for (int i = tid; i < a.NI; i += B) ns_iface_item(a, t, i, fault_step, fault_lane, fault_index);
+        NS_STAMP(1)
+        for (int c = tid; c < C; c += B) ns_cell_item(a, t, c, fault_step, fault_lane, fault_index);
         __syncthreads();
-        for (int c = tid; c < C; c += B) ns_cell_item(a, t, c);
-        __syncthreads();
+        NS_STAMP(2)
         ns_convert(a, t, reinterpret_cast<int *>(lds_p));
+        NS_STAMP(3)
+        if (a.st) {                     // the committed state to the history (what the reverse sweep and the callers read)
+            const float *sn = ns_state(a, t + 1);
+            float *hn = a.hist + (size_t)(t + 1) * 4 * C;
+            for (int i = tid; i < 4 * C; i += B) hn[i] = sn[i];
+        }
+        if (pre) ns_rows_store(a, t + 1, tid, nx);
+        if (a.row_i && t + 1 < T) for (int l = tid + B; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, ag, t + 1, l, v); ns_rows_store(a, t + 1, l, v); }
         __syncthreads();
+        NS_STAMP(4)
     }
+#ifdef DHTS_NS_STAMPS
+    if (blockIdx.x == 0 && tid == 0)
+        printf("ns_persist_fwd cycles per step: ghosts %lld | micro boundary + IDM %lld | cells %lld | hand-offs + loss %lld | flush %lld\n",
+               st_[0] / T, st_[1] / T, st_[2] / T, st_[3] / T, st_[4] / T);
+#endif
     if (fault_step >= 0) net_fault(a.err, DHTS_FAULT_CFL, fault_step, fault_lane, fault_index);
     ns_reward(a, reinterpret_cast<float *>(lds_p));
 }
 
 __global__ void __launch_bounds__(kNsBlock) ns_persist_bwd_kernel(NsArgs a0, const float *__restrict__ action_all, const float *__restrict__ g_reward,
-                                                                float *__restrict__ g_action_all) {
+                                                                float *__restrict__ g_action_all, NsPlan pl) {
     extern __shared__ double lds_p[];
-    const NsArgs a = ns_replica_args(a0, blockIdx.x);
-    const float *action = action_all + (size_t)blockIdx.x * a.n_action;
+    __shared__ NsArgs ag_s, a_s;                                // (see ns_persist_fwd_kernel)
+    if (threadIdx.x == 0) { ag_s = ns_replica_args(a0, blockIdx.x); a_s = ag_s; }
+    __syncthreads();
+    {
+        NsArgs tmp = a_s;
+        ns_carve(tmp, reinterpret_cast<char *>(lds_p), pl);
+        __syncthreads();
+        if (threadIdx.x == 0) a_s = tmp;
+        __syncthreads();
+    }
+    const NsArgs &ag = ag_s;
+    const NsArgs &a = a_s;
+    const float *action = action_all + (size_t)blockIdx.x * a0.n_action;
     const int tid = threadIdx.x, B = blockDim.x;
-    const int L = a.L, C = a.C, T = a.T, Lm = a.Lm;
+    const int L = a0.L, C = a0.C, T = a0.T, Lm = a0.Lm;
     {   // cotangents start at zero; the lanes hold what the forward left
         unsigned *z = ns_ptr<unsigned>(a, a.lo.G);
         const size_t nz = (a.lo.n_bwd - a.lo.G) / 4;
         for (size_t i = tid; i < nz; i += B) z[i] = 0u;
+        if (a.gl) for (int i = tid; i < 6 * C; i += B) a.gl[i] = 0.f;
         int *n_bwd = ns_ptr<int>(a, a.lo.n_bwd);
         const int *lane_n = ns_ptr<int>(a, a.lo.lane_n);
         for (int m = tid; m < Lm; m += B) n_bwd[m] = lane_n[m];
     }
+    if (a.st) {                          // rows T and T - 1 of the history
+        for (int r = T; r >= T - 1 && r >= 0; --r) {
+            float *sr = ns_state(a, r);
+            const float *hr = a.hist + (size_t)r * 4 * C;
+            for (int i = tid; i < 4 * C; i += B) sr[i] = hr[i];
+        }
+    }
+    if (a.row_i) for (int l = tid; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, ag, T - 1, l, v); ns_rows_store(a, T - 1, l, v); }
     __syncthreads();
     const int m_items = L > a.sq ? L : a.sq;
+#ifdef DHTS_NS_STAMPS
+    long long st_[6] = {0, 0, 0, 0, 0, 0}, st_last_ = __builtin_amdgcn_s_memtime();
+#endif
     for (int t = T - 1; t >= 0; --t) {
+        NsRowRegs nx;
+        const bool pre = a.row_i && t >= 1 && tid < L;
+        if (pre) ns_rows_fetch(a, ag, t - 1, tid, nx);
         ns_micro_bwd(a, t, action, g_reward ? g_reward + blockIdx.x : nullptr, lds_p);
         __syncthreads();
+        NS_STAMP(0)
         for (int c = tid; c < C; c += B) ns_cell_bwd_item(a, t, c);
         __syncthreads();
+        NS_STAMP(1)
         if (C > 0) {
             for (int j = tid; j < 2 * L; j += B) ns_ghost_bwd_item(a, t, action, j);
             __syncthreads();
+            NS_STAMP(2)
             for (int m = tid; m < m_items; m += B) ns_ghost_gather_item(a, t, m);
-            __syncthreads();
+            NS_STAMP(3)
         }
+        // the state before step t - 1 (row t - 1) into the copy row t + 1 leaves; the rows of step t - 1
+        if (a.st && t >= 1) {
+            float *sr = ns_state(a, t - 1);
+            const float *hr = a.hist + (size_t)(t - 1) * 4 * C;
+            for (int i = tid; i < 4 * C; i += B) sr[i] = hr[i];
+        }
+        if (pre) ns_rows_store(a, t - 1, tid, nx);
+        if (a.row_i && t >= 1) for (int l = tid + B; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, ag, t - 1, l, v); ns_rows_store(a, t - 1, l, v); }
+        __syncthreads();
+        NS_STAMP(4)
     }
+#ifdef DHTS_NS_STAMPS
+    if (blockIdx.x == 0 && tid == 0)
+        printf("ns_persist_bwd cycles per step: taps + events + fold + IDM + head gaps %lld | cells %lld | ghosts %lld | gather %lld | state %lld\n",
+               st_[0] / T, st_[1] / T, st_[2] / T, st_[3] / T, st_[4] / T);
+#endif
     float *g_action = g_action_all + (size_t)blockIdx.x * a.n_action;
     const double *g_act = ns_ptr<double>(a, a.lo.g_act);
     for (int q = tid; q < a.n_action; q += B) g_action[q] = (float)g_act[q];
@@ -1219,7 +1391,7 @@ static NsLayout ns_layout(const dhts_net_desc *d, const dhts_netstep_tables *t) 
     o.n_bwd = R(sizeof(int) * Lm); o.ghd = R(16);
     // the persistent kernels' own scratch and Jacobian tape (blocks dqs[c][3][2][2] per cell-step: 48 B, dmacro_lane.py:50-56)
     const size_t NI = C + Lg;
-    o.pF = R(t->persistent ? sizeof(double) * 2 * NI : 0); o.pAB = R(t->persistent ? sizeof(float) * 8 * NI : 0);
+    o.pF = o.pAB = p; (void)NI;
     o.ptape = R(t->persistent ? sizeof(float) * 12 * T * C : 0);
     if (t->persistent) { o.tape = o.ptape; }          // (the per-group operator tape is not used then)
     o.total = p;
@@ -1259,10 +1431,30 @@ static NsArgs ns_args(const dhts_net_desc *d, const dhts_netstep_tables *t, int 
     a.nxt_ptr = h.net.nxt_ptr; a.nxt_idx = h.net.nxt_idx; a.prv_ptr = h.net.prv_ptr; a.prv_idx = h.net.prv_idx;
     a.inter_ptr = t->inter_ptr; a.inter_idx = t->inter_idx;
     a.if_lane = t->if_lane; a.cell_lane = t->cell_lane; a.table_stride = h.net.replica_stride; a.draws_stride = h.draws_stride;
+    a.n_edges = h.net.n_edges; a.n_islots = t->n_inter_slots; a.stage = 0;
+    a.st = nullptr; a.gl = nullptr; a.gh = nullptr; a.sl = nullptr; a.gg = nullptr; a.row_i = nullptr; a.row_d = nullptr;
     { int lg = 0; for (int g = 0; g < t->n_groups; ++g) lg += t->groups[g].n_lanes; a.NI = d->n_cells + lg; }
     a.ws = reinterpret_cast<char *>(ws); a.lo = ns_layout(d, t);
     a.hist = hist; a.queue = queue; a.reward = reward; a.counts = counts; a.err = err;
     return a;
+}
+
+// What fits into a workgroup's 160 KB beside the phases' scratch, in the order of what it buys: the per-step table rows and the
+// ghost / slot arrays (small, read by every item), the static tables, the cotangent planes (reverse sweep) resp. the state rows,
+// then the other of the two.
+static NsPlan ns_plan(const NsArgs &a, size_t scratch, bool bwd) {
+    NsPlan pl = {(int)scratch, 0, 0, 0, 0, 0};
+    size_t left = 156 * 1024 - scratch;
+    auto take = [&](size_t bytes, int &slot) { if (bytes && bytes <= left) { slot = (int)bytes; left -= bytes; } };
+    take(ns_al16(16 * (size_t)a.L) + ns_al16(32 * (size_t)a.L), pl.rows);
+    take(3 * ns_al16(32 * (size_t)a.L), pl.misc);
+    take(ns_stage_bytes(a.L, a.C, a.NI, a.Lm, a.ncap, a.n_edges, a.sq, a.n_islots, a.lane_source != nullptr), pl.tables);
+    const size_t st = ns_al16(sizeof(float) * 8 * (size_t)a.C), gl = ns_al16(sizeof(float) * 6 * (size_t)a.C);
+    if (a.C > 0) {
+        if (bwd) { take(gl, pl.gl); take(st, pl.st); }
+        else take(st, pl.st);
+    }
+    return pl;
 }
 
 extern "C" {
@@ -1283,10 +1475,12 @@ int dhts_netstep_rollout_fwd(const dhts_net_desc *d, const dhts_netstep_tables *
     if (t->persistent) {
         size_t lds = sizeof(float) * 2 * (size_t)(Lm > 0 ? Lm : 1);              // head gaps | candidate flags | the reward's partial sums
         if (sizeof(float) * 2 * (size_t)L > lds) lds = sizeof(float) * 2 * (size_t)L;
+        const NsPlan pl = ns_plan(a, ns_al16(lds), false);
+        lds = (size_t)pl.scratch + pl.tables + pl.st + pl.gl + pl.rows + pl.misc;
         if (lds > 160 * 1024 ||
             (lds > 48 * 1024 && hipFuncSetAttribute((const void *)ns_persist_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess))
             return DHTS_E_INVALID;
-        ns_persist_fwd_kernel<<<d->n_replicas, kNsBlock, lds, st>>>(a, action);
+        ns_persist_fwd_kernel<<<d->n_replicas, kNsBlock, lds, st>>>(a, action, pl);
         return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
     }
     // running state of the episode
@@ -1329,11 +1523,12 @@ int dhts_netstep_rollout_bwd(const dhts_net_desc *d, const dhts_netstep_tables *
     const int L = a.L, C = a.C, T = a.T, Lm = a.Lm;
     char *ws = a.ws;
     if (t->persistent) {
-        const size_t lds = sizeof(double) * (2 * (size_t)(Lm > 0 ? Lm : 1) + 8 * (size_t)kNsBlock);
+        const NsPlan pl = ns_plan(a, ns_al16(sizeof(double) * (2 * (size_t)(Lm > 0 ? Lm : 1) + 8 * (size_t)kNsBlock)), true);
+        const size_t lds = (size_t)pl.scratch + pl.tables + pl.st + pl.gl + pl.rows + pl.misc;
         if (lds > 160 * 1024 ||
             hipFuncSetAttribute((const void *)ns_persist_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return DHTS_E_INVALID;
-        ns_persist_bwd_kernel<<<d->n_replicas, kNsBlock, lds, st>>>(a, action, g_reward, g_action);
+        ns_persist_bwd_kernel<<<d->n_replicas, kNsBlock, lds, st>>>(a, action, g_reward, g_action, pl);
         return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
     }
     // cotangents start at zero; the lanes hold what the forward left (lane_n)

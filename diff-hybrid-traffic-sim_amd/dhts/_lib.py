@@ -61,7 +61,7 @@ class NetstepTables(C.Structure):
     _fields_ = [("hyb", HybridTables), ("lane_gpos", C.c_void_p), ("groups", C.POINTER(NetstepGroup)), ("n_groups", C.c_int32),
                 ("micro_lanes", C.c_void_p), ("lane_mslot", C.c_void_p), ("cap_lanes", C.c_void_p), ("lane_cslot", C.c_void_p),
                 ("n_caps", C.c_int32), ("inter_ptr", C.c_void_p), ("inter_idx", C.c_void_p), ("max_events", C.c_int32),
-                ("if_lane", C.c_void_p), ("cell_lane", C.c_void_p), ("persistent", C.c_int32)]
+                ("if_lane", C.c_void_p), ("cell_lane", C.c_void_p), ("persistent", C.c_int32), ("n_inter_slots", C.c_int32)]
 
 
 class MicroDesc(C.Structure):

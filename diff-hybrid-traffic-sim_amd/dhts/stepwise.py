@@ -211,7 +211,7 @@ class StepwiseNetwork:
                                 self.lane_capacity)
         return _lib.NetstepTables(hyb, p("lane_gpos"), self._garr, len(self.groups), p("micro_lanes"), p("lane_mslot"), p("cap_lanes"),
                                   p("lane_cslot"), self.n_caps, p("inter_ptr"), p("inter_idx"), self.max_events, p("if_lane"), p("cell_lane"),
-                                  1 if self.persistent else 0)
+                                  1 if self.persistent else 0, int(d["inter_idx"].numel()))
 
     def rollout(self, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0, differentiable=True,
                 loss_steps=0, check_faults=True):

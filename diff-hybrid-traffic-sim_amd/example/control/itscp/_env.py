@@ -349,6 +349,13 @@ class ItscpEnv:
                 reward, queue, counts = ops.net_hybrid_eval(a, tab, *args)
                 self.fused_counts = counts[0].tolist()
         except (ops.CapacityError, _lib.DhtsError) as e:
+            if kind == "stepwise" and isinstance(e, _lib.DhtsError) and getattr(tab, "persistent", False):
+                self._stepwise_no_persistent = True         # the persistent form's LDS does not hold this network: stepwise form
+                self._stepwise_cache = None
+                self._fused_cache = None
+                if draws is not None:
+                    self._fused_pending_draws = draws
+                return self._step_fused(action, differentiable)
             # The episode needs more than this launch was sized for (vehicles per micro lane, vehicles per episode, records), or the
             # sizing does not fit one workgroup's LDS (DhtsError).  Nothing on the host was touched by the attempt; the ladder is
             #   fused kernels at 16 vehicles per lane -> fused at 128 -> stepwise device path at 128 -> stepwise at 1024 -> lane by lane,
@@ -408,11 +415,12 @@ class ItscpEnv:
             if mode == "macro" and n_cells + len(sim.lane) <= 1024:
                 return ("macro", ops.DeviceNetTables(MacroNetworkTables.from_env(self), device))
             if mode == "macro":
-                # more cells + lanes than one workgroup holds (e.g. --n_intersection=3 --n_lane=3: 360 lanes, ~1 700 cells): all lanes
-                # as the batch of the straight-lane step operator, one call per step (dhts/batched.py; config "macro_path" = "stepwise"
-                # takes dhts/stepwise.py instead)
+                # more cells + lanes than one workgroup holds one item per thread of (e.g. --n_intersection=3 --n_lane=3: 360 lanes,
+                # ~1 700 cells): step by step on the device (dhts/stepwise.py, persistent form: 6.9 ms per 120-step differentiable
+                # episode of that network against 11.4 ms for the replayed HIP graph of round 4's batched-lane path, dhts/batched.py,
+                # which config "macro_path" = "batched" still selects)
                 tabs = MacroNetworkTables.from_env(self)
-                if self.config.get("macro_path", "batched") == "stepwise":
+                if self.config.get("macro_path", "stepwise") == "stepwise":
                     return ("stepwise", self._stepwise_net(tabs, np.asarray([[-1, -1]], dtype=np.int32), device, 32))
                 from dhts.batched import BatchedMacroNetwork
                 net = getattr(self, "_batched_net", None)           # survives reset(): same topology, new schedules / routes
@@ -475,7 +483,10 @@ class ItscpEnv:
                 return net[0]
             except ValueError:
                 pass
-        sw = StepwiseNetwork(tab, routes, device, lane_capacity=lane_cap)
+        # persistent form (one kernel per direction) unless asked otherwise; a network whose scratch does not fit one workgroup's LDS
+        # comes back as DhtsError at the first launch and is rebuilt in the stepwise form (one launch per phase and step)
+        persistent = bool(self.config.get("stepwise_persistent", True)) and not getattr(self, "_stepwise_no_persistent", False)
+        sw = StepwiseNetwork(tab, routes, device, lane_capacity=lane_cap, persistent=persistent)
         self._stepwise_cache = (sw, (lane_cap, routes.shape, routes.tobytes()))
         return sw
 

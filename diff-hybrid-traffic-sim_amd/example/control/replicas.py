@@ -6,8 +6,9 @@ The fused network kernels run one workgroup per replica (dhts_net_macro_rollout_
 ONE environment per episode leaves 255 of 256 compute units idle and pays its host time per episode.  `ReplicaBatch` holds R
 environments that share the topology and differ in what reset() draws (inflow schedules, per-step macro routes, admission draws):
 their tables go to the device once as per-replica tables (dhts.ops.DeviceNetTables / DeviceHybridTables take a list), and an
-"episode" of the batch is [R][A] actions -> [R] rewards in two launches.  Networks the fused kernels cannot hold fall back to one
-ItscpEnv.step per replica (the stepwise / batched device paths), same interface.
+"episode" of the batch is [R][A] actions -> [R] rewards in two launches.  Networks the fused kernels cannot hold run as R workgroups
+of the stepwise path's persistent kernels (dhts/stepwise.py: StepwiseNetwork over a list of tables), same interface; only what
+neither holds falls back to one ItscpEnv.step per replica.
 """
 import copy
 
@@ -45,10 +46,11 @@ class ReplicaBatch:
         e0 = self.envs[0]
         mode = e0.config["mode"]
         try:
+            from dhts.stepwise import StepwiseNetwork
             if mode == "macro":
                 tabs = [MacroNetworkTables.from_env(e) for e in self.envs]
                 if tabs[0].n_cells + tabs[0].n_lanes > 1024:
-                    return "per-env", None
+                    return "stepwise", StepwiseNetwork(tabs, np.asarray([[-1, -1]], dtype=np.int32), self.device, persistent=True)
                 return "macro", ops.DeviceNetTables(tabs if self.R > 1 else tabs[0], self.device)
             tabs = [HybridNetworkTables.from_env(e) for e in self.envs]
             sim = e0.simulator
@@ -75,7 +77,11 @@ class ReplicaBatch:
                 routes = np.asarray(routes, dtype=np.int32)
                 for e in self.envs:
                     e.fused_routes = routes              # (the per-environment path of a comparison sees the same routes)
-            tabs[0].check_kernel_limits()
+            try:
+                tabs[0].check_kernel_limits()
+            except ValueError:
+                return "stepwise", StepwiseNetwork(tabs, routes, self.device, lane_capacity=int(e0.config.get("stepwise_lane_capacity", 32)),
+                                                   persistent=True)
             return mode, ops.DeviceHybridTables(tabs if self.R > 1 else tabs[0], routes, self.device)
         except ValueError:
             return "per-env", None
@@ -98,6 +104,9 @@ class ReplicaBatch:
                 _, reward, _, _ = e.step(actions[r], differentiable)
                 out.append(reward.reshape(()) if isinstance(reward, th.Tensor) else th.as_tensor(float(reward), device=self.device))
             return th.stack(out)
+        if self.kind == "stepwise":
+            reward, _, _, _ = self.tab.rollout(actions, *self.args, differentiable=differentiable)
+            return c * reward
         if self.kind == "macro":
             reward, _ = ops.net_macro_rollout(actions, self.tab, *self.args) if differentiable else ops.net_macro_eval(actions, self.tab, *self.args)
         elif differentiable:
@@ -108,4 +117,4 @@ class ReplicaBatch:
 
     @property
     def path(self):
-        return "fused x%d" % self.R if self.kind != "per-env" else "per-env"
+        return "per-env" if self.kind == "per-env" else ("stepwise x%d" % self.R if self.kind == "stepwise" else "fused x%d" % self.R)

@@ -513,6 +513,7 @@ typedef struct dhts_netstep_tables {
      * k, k = 0 .. n; cell_lane [n_cells] (device): the lane of every cell (group-major order). */
     const int32_t *if_lane, *cell_lane;
     int32_t persistent;
+    int32_t n_inter_slots;             /* length of inter_idx (the persistent kernels stage the static tables in LDS) */
 } dhts_netstep_tables;
 size_t dhts_netstep_workspace_bytes(const dhts_net_desc *d, const dhts_netstep_tables *t);
 int dhts_netstep_rollout_fwd(const dhts_net_desc *d, const dhts_netstep_tables *t, int hard, const float *action, float *hist,

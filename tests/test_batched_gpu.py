@@ -66,8 +66,8 @@ def test_env_step_runs_a_network_beyond_one_workgroup_batched(cuda, oracle):
     from dhts.network import MacroNetworkTables
     from example.control.itscp._env import ItscpEnv
     env = ItscpEnv()
-    for k, v in dict(num_intersection=3, num_lane=3, mode="macro", random_seed=5).items():
-        env.config[k] = v
+    for k, v in dict(num_intersection=3, num_lane=3, mode="macro", random_seed=5, macro_path="batched").items():      # (round 5: the
+        env.config[k] = v                                       # default for such networks is the stepwise path, dhts/stepwise.py)
     env.reset()
     tab = MacroNetworkTables.from_env(env)
     assert tab.n_cells + tab.n_lanes > 1024 and tab.n_lanes == 360

@@ -191,8 +191,7 @@ def test_stepwise_episode_time(cuda, golden_dir):
 def test_env_step_takes_the_stepwise_path_beyond_the_fused_limits(cuda, golden_dir, name):
     """ItscpEnv.step(action, True) -- the reference's entry point (trainer.py:172-190) -- on networks the fused kernels cannot hold
     (252 lanes + 1 152 cells; 144 IDM lanes; 112 IDM lanes in `micro` mode; 360 lanes + 2 124 cells in `macro` mode): the episode
-    runs on the stepwise device path (macro mode: on request, the batched-lane path stays the default there) and reproduces the
-    reference's run; so does the evaluation episode's reward against the stepwise rollout with hard thresholds."""
+    runs on the stepwise device path (persistent form) and reproduces the reference's run; an evaluation episode runs there too."""
     import torch
     from test_itscp_gpu import build_env
     from test_oracle_golden import meta_of
@@ -204,8 +203,6 @@ def test_env_step_takes_the_stepwise_path_beyond_the_fused_limits(cuda, golden_d
         env.fused_routes = g["spawn_routes"]
     if micro:
         env.fused_draws = g["rand_draws"]
-    if name.startswith("macro"):
-        env.config["macro_path"] = "stepwise"
     keys = list(env.lane.keys())
     action = torch.tensor(g["action"], device=cuda, requires_grad=True)
     t0 = time.perf_counter()
@@ -213,7 +210,7 @@ def test_env_step_takes_the_stepwise_path_beyond_the_fused_limits(cuda, golden_d
     reward.backward()
     grad = action.grad.cpu().numpy()
     t1 = time.perf_counter()
-    assert env._fused_cache[0] == "stepwise" and env._fused_done and env.last_path == "stepwise"
+    assert env._fused_cache[0] == "stepwise" and env._fused_done and env.last_path == "stepwise" and env._fused_cache[1].persistent
     queue = np.array([env.queue_length[k] for k in keys])
     tol_q = 1e-4 if micro else TOL_STATE
     assert state_report("env.step %s: queues vs reference" % name, queue, g["queue"]) <= tol_q

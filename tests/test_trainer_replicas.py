@@ -223,3 +223,40 @@ def test_replica_batch_gradient_equals_single_environment_trainers(cuda, tmp_pat
         torch.cuda.synchronize()
         dt_ = (time.perf_counter() - t0) / n
         print("Trainer, %3d environment(s) per optimiser step: %.1f ms per step, %.0f environment-episodes/s" % (R, 1e3 * dt_, R / dt_))
+
+
+@pytest.mark.gpu
+def test_replica_batch_of_a_network_beyond_the_fused_limits(cuda):
+    """Trainer(env, n_replica = 3) on a hybrid network the fused kernels cannot hold (two lanes per approach, 30 m lanes: 252 lanes +
+    1 152 cells): the replicas run as workgroups of the stepwise path's persistent kernels, and the batched controller gradient equals
+    the mean of the single-environment trainers' (each on the same path through ItscpEnv.step)."""
+    import torch
+    from example.control.itscp._env import ItscpEnv
+    from example.control.itscp import problem as problems
+    from example.control.trainer import Trainer
+
+    def make(seed):
+        env = ItscpEnv()
+        env.schedule_callback = problems.problem_1
+        for k, v in dict(num_intersection=3, lane_length=30.0, num_lane=2, policy_length=2, signal_length=1, mode="hybrid", speed_limit=60.0,
+                         random_seed=seed).items():
+            env.config[k] = v
+        env.reset()
+        return env
+    torch.manual_seed(3)
+    tr = Trainer(make(31), network_size=(32,), lr=1e-2, n_replica=3)
+    flat = tr.flat_gradient(tr.batch_loss(1)).cpu().numpy()
+    assert tr.batch.path == "stepwise x3"
+    acc = None
+    for k in range(3):
+        e = tr.batch.envs[k]
+        single = Trainer(e, network_size=(32,), lr=1e-2)
+        single.controller.load_state_dict(tr.controller.state_dict())
+        reward, _, _ = single.run_episode(True)
+        assert e.last_path == "stepwise"
+        single.optimizer.zero_grad()
+        (-reward).backward()
+        g = torch.cat([p.grad.reshape(-1) for p in single.controller.parameters()] + [(-reward).detach().reshape(1)]).cpu().numpy()
+        acc = g if acc is None else acc + g
+    acc /= 3
+    assert np.abs(flat - acc).max() <= 1e-5 * np.abs(acc).max()

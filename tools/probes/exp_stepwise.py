@@ -39,19 +39,29 @@ for name in ("hybrid_n2l30", "hybrid_5x5", "micro_2x2", "macro_3x3x3", "hybrid_h
     else:
         t, m = itscp_hybrid_tables(g)
         routes = g["spawn_routes"] if g["spawn_routes"].shape[0] else -np.ones((1, 2), np.int32)
-    net = StepwiseNetwork(t, routes, cuda)
     a = torch.tensor(g["action"], device=cuda, requires_grad=True)
+    for persistent in (False, True):
+        net = StepwiseNetwork(t, routes, cuda, persistent=persistent)
 
-    def episode():
-        a.grad = None
-        cut, _, _, _ = net.rollout(a, *args_of(m), check_faults=False)
-        cut.backward()
+        def episode():
+            a.grad = None
+            cut, _, _, _ = net.rollout(a, *args_of(m), check_faults=False)
+            cut.backward()
 
-    def evaluation():
-        with torch.no_grad():
-            net.rollout(a.detach(), *args_of(m), differentiable=False, check_faults=False)
-    print("%-14s %4d lanes %5d cells %4d IDM lanes %4d steps: differentiable episode %.2f ms, evaluation episode %.2f ms" % (
-        name, t.n_lanes, t.n_cells, net.n_micro, t.T, 1e3 * timed(episode), 1e3 * timed(evaluation)), flush=True)
+        def evaluation():
+            with torch.no_grad():
+                net.rollout(a.detach(), *args_of(m), differentiable=False, check_faults=False)
+        print("%-14s %4d lanes %5d cells %4d IDM lanes %4d steps, %-10s form: differentiable episode %6.2f ms, evaluation episode %6.2f ms" % (
+            name, t.n_lanes, t.n_cells, net.n_micro, t.T, "persistent" if persistent else "stepwise", 1e3 * timed(episode), 1e3 * timed(evaluation)), flush=True)
+    R = 64
+    netr = StepwiseNetwork([t] * R, routes, cuda, persistent=True)
+    ar = torch.tensor(np.tile(g["action"][None], (R, 1)), device=cuda, requires_grad=True)
+
+    def batch():
+        ar.grad = None
+        cut, _, _, _ = netr.rollout(ar, *args_of(m), check_faults=False)
+        cut.sum().backward()
+    print("%-14s persistent form, %d replicas in one launch pair: %.2f ms per differentiable batch episode" % (name, R, 1e3 * timed(batch)), flush=True)
     if name.startswith("macro"):
         tab, _ = itscp_tables(g)
         bn = BatchedMacroNetwork(tab, cuda)
