@@ -18,7 +18,8 @@ def snippets():
 
 
 def test_every_marked_snippet_is_known():
-    assert set(snippets()) == {"binding", "rollouts", "net_macro", "net_batched", "net_hybrid", "net_eval", "net_micro", "net_state"}
+    assert set(snippets()) == {"binding", "rollouts", "net_macro", "net_batched", "net_hybrid", "net_eval", "net_micro", "net_state", "net_stepwise",
+                               "trainer_replicas"}
 
 
 def test_binding_snippet_loads_the_library():
@@ -135,3 +136,26 @@ def test_net_state_snippet(cuda):
     exec(compile(snippets()["net_state"], "INTEGRATION.md:net_state", "exec"), ns)
     assert ns["n_spawned"] >= 1 and ns["n_events"] >= ns["n_spawned"]
     assert bool(torch.isfinite(ns["r0"].grad).all()) and float(ns["r0"].grad.abs().max()) > 0 and float(ns["u0"].grad.abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_net_stepwise_snippet(cuda):
+    """The stepwise path on a hybrid network beyond the fused limits (two lanes per approach, 30 m lanes), single and as three replicas."""
+    import torch
+    env = _itscp_env("hybrid", num_intersection=3, lane_length=30.0, num_lane=2, policy_length=2, signal_length=1)
+    action = (0.1 + 0.8 * torch.rand(env.action_size())).to(cuda).requires_grad_(True)
+    ns = dict(env=env, action=action)
+    exec(compile(snippets()["net_stepwise"], "INTEGRATION.md:net_stepwise", "exec"), ns)
+    assert ns["tab"].n_cells + ns["tab"].n_lanes > 960
+    assert action.grad is not None and bool(torch.isfinite(action.grad).all()) and ns["queue"].shape == (env.num_timestep, ns["tab"].n_lanes)
+    assert ns["rewards"].shape == (3,) and ns["queues"].shape == (3, env.num_timestep, ns["tab"].n_lanes)
+    assert float(ns["rewards"][0]) == float(ns["rewards"][2]) == float(ns["full_reward"])          # same tables, same action: same episode
+
+
+@pytest.mark.gpu
+def test_trainer_replicas_snippet(cuda):
+    import torch
+    env = _itscp_env("hybrid", num_intersection=3, lane_length=5.0, num_lane=1, policy_length=2, signal_length=1, random_seed=5)
+    ns = dict(env=env)
+    exec(compile(snippets()["trainer_replicas"], "INTEGRATION.md:trainer_replicas", "exec"), ns)
+    assert ns["trainer"].batch.path == "fused x8" and bool(torch.isfinite(ns["flat"]).all()) and ns["flat"].numel() > 64 * 64

@@ -5,7 +5,7 @@ set -eu
 P=$1
 cd "$(dirname "$0")/.."
 G=gpurun_out
-for WL in macro micro itscp_hybrid itscp_macro; do
+for WL in macro micro itscp_hybrid itscp_macro itscp_stepwise; do
   cp $G/${P}_${WL}_kernel_stats.csv profiles/
   tail -n 1 $G/${P}_${WL}_bench.json > profiles/${P}_${WL}_bench.json
 done

@@ -9,7 +9,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for WL in macro micro itscp_hybrid itscp_macro; do
+for WL in macro micro itscp_hybrid itscp_macro itscp_stepwise; do
   D=$OUT/${P}_prof_$WL
   rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -- python3 "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-also --workload $WL > "$OUT/${P}_${WL}_bench.json" 2> "$OUT/${P}_${WL}_bench.err"
   S=$(find "$D" -name "*kernel_stats.csv" | head -1)
