@@ -573,7 +573,7 @@ class ItscpStepwiseWorkload(ItscpHybridWorkload):
         import numpy as np
         from dhts import ops
         from dhts.network import HybridNetworkTables
-        from dhts.stepwise import StepwiseNetwork
+        from dhts.stepwise import StepwiseNetwork, default_lane_capacity
         from example.control.itscp._env import ItscpEnv
         from example.control.itscp.problem import problem_1
         self.ops, self.R = ops, R
@@ -599,7 +599,7 @@ class ItscpStepwiseWorkload(ItscpHybridWorkload):
             t.schedule = np.ascontiguousarray(np.array([sched[k] for k in keys], dtype=np.float64).T)
             tabs.append(t)
         self.host_tab, self.host_routes = tab, np.array(routes, dtype=np.int32)
-        self.net = StepwiseNetwork(tabs, self.host_routes, dev, lane_capacity=32, persistent=True)
+        self.net = StepwiseNetwork(tabs, self.host_routes, dev, lane_capacity=default_lane_capacity(tab, env.simulator.vehicle_length), persistent=True)
         self.sq, self.F, self.dt, self.um = 9, 60, 1.0 / 30.0, 60.0
         gen = torch.Generator(device="cpu").manual_seed(277 + rank)
         self.action = (0.1 + 0.8 * torch.rand(R, env.action_size(), generator=gen)).to(dev).requires_grad_(True)

@@ -24,6 +24,8 @@
 // results repeat bit for bit.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/dhts.h"
 #include "arz_device.hpp"
 #include "idm_device.hpp"
@@ -52,7 +54,7 @@ struct NsCounters {
     long long sig_n, loss_n;
     double sig_sum, loss_sum;
     float reward, reward_cut;
-    int pad[2];
+    int n_max, pad;         // n_max: the most vehicles any micro lane has held so far (bounds the loops over vehicle slots)
 };
 
 struct NsLayout {           // byte offsets into the workspace
@@ -63,26 +65,30 @@ struct NsLayout {           // byte offsets into the workspace
 };
 __host__ __device__ inline size_t ns_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct NsArgs {
+// Where a pointer of the argument block points: the stepwise kernels and the un-staged persistent form read everything through generic
+// pointers into HBM / L2; the persistent kernels that stage the static tables, the per-step rows, ghosts / slots (TB) and the state
+// rows / cotangent planes (ST) in LDS hold them as address_space(3) pointers, so that the SAME device functions compile to ds_read /
+// ds_write there (a flat load of an LDS address costs a dependent look-up ~700 cycles, a ds_read ~100: section 9 of DESIGN.md).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NS_LDS __attribute__((address_space(3)))
+#define NS_GLOBAL __attribute__((address_space(1)))
+#else                       // (the host pass only parses the device functions: there the qualified types do not convert to generic ones)
+#define NS_LDS
+#define NS_GLOBAL
+#endif
+template <int AS, class T> struct NsPtrT { typedef T *type; };                     // 0: generic (what the host passes)
+template <class T> struct NsPtrT<1, T> { typedef NS_GLOBAL T *type; };             // 1: global memory
+template <class T> struct NsPtrT<3, T> { typedef NS_LDS T *type; };                // 3: LDS
+
+struct NsCommon {
     int L, C, T, sq, F, n_action, Lm, cap, ncap, hard, route_stride, n_draws, max_events, loss_steps;
     float um, dtf, vlen, s0f;
     double um_d, dt_d, vlen_d;
-    const int32_t *lane_ncell, *lane_off, *sig_kind, *inter, *lane_macro, *lane_gpos, *micro_lanes, *lane_mslot, *cap_lanes, *lane_cslot,
-        *lane_source;
-    const double *lane_dx, *lane_len;
-    const int32_t *left_src, *left_gate, *right_src, *conv_next;
+    const int32_t *left_src, *left_gate, *right_src, *conv_next;     // [T][L] per-step tables (per replica: table_stride)
     const double *schedule;
     const int32_t *routes, *route_ptr;
     const double *draws;
-    const int32_t *nxt_ptr, *nxt_idx, *prv_ptr, *prv_idx, *inter_ptr, *inter_idx;
-    const int32_t *if_lane, *cell_lane;      // the persistent kernels' maps: interface -> lane, cell -> lane (NI = cells + ARZ lanes)
-    int NI, n_edges, n_islots, stage;          // stage: the persistent kernels copy the static tables into LDS (they fit)
-    // what else a persistent kernel keeps in LDS (null = in the workspace / the history): the state rows t and t + 1 ([2][4][C], row r in
-    // copy r & 1), the cotangent planes ([2][3][C]), the per-step table rows of steps t and t + 1 ([2][L] each), ghosts / slots / ghost cotangents
-    float *st, *gl, *gh, *sl;
-    double *gg;
-    int32_t *row_i;        // [2][4][L]: left_src, left_gate, right_src, conv_next
-    double *row_d;         // [2][L]: schedule
+    int NI, n_edges, n_islots, has_source, n_routes;
     long long table_stride, draws_stride;    // elements between replicas in the [T][L] tables / the draws (0 = shared)
     char *ws;
     NsLayout lo;
@@ -90,94 +96,235 @@ struct NsArgs {
     int32_t *counts;
     dhts_error *err;
 };
+// the static tables: X(name, element type, count expression over (a))
+#define NS_TABLES(X) \
+    X(lane_ncell, int32_t, a.L) X(lane_off, int32_t, a.L) X(sig_kind, int32_t, a.L) X(inter, int32_t, a.L) X(lane_macro, int32_t, a.L) \
+    X(lane_gpos, int32_t, a.L) X(lane_mslot, int32_t, a.L) X(lane_cslot, int32_t, a.L) X(lane_source, int32_t, (a.has_source ? a.L : 0)) \
+    X(lane_dx, double, a.L) X(lane_len, double, a.L) X(cell_lane, int32_t, a.C) X(micro_lanes, int32_t, a.Lm) X(cap_lanes, int32_t, a.ncap) \
+    X(nxt_ptr, int32_t, a.L + 1) X(prv_ptr, int32_t, a.L + 1) X(nxt_idx, int32_t, a.n_edges) X(prv_idx, int32_t, a.n_edges) \
+    X(inter_ptr, int32_t, a.sq + 1) X(inter_idx, int32_t, a.n_islots)
 
-template <typename T> __device__ __forceinline__ T *ns_ptr(const NsArgs &a, size_t off) { return reinterpret_cast<T *>(a.ws + off); }
+// the running state of the micro side (forward: vehicles, lane counts, capacitors, counters; reverse: their cotangents), in the
+// order of the workspace layout: X(name, element type, count over (a), planes)
+#define NS_MICRO_FWD(X) \
+    X(P, float, 2 * plane) X(V, float, 2 * plane) X(A, float, plane) X(vroute, int, plane) X(vcur, int, plane) X(lane_n, int, a.Lm) \
+    X(rused, int, a.L) X(capv, float, a.ncap) X(counters, NsCounters, 1)
+#define NS_MICRO_BWD(X) \
+    X(gP, double, 2 * plane) X(gV, double, 2 * plane) X(gA, double, plane) X(g_cap, double, a.ncap) X(g_own, float, 2 * a.L) \
+    X(g_act, double, a.n_action) X(n_bwd, int, a.Lm)
+// what only a persistent kernel's copy of the argument block holds (LDS pointers are 4 bytes on the device and do not exist on the host:
+// the block the host builds and the kernels receive, NsArgs, must not contain any)
+template <bool kDevice> struct NsStaged {};
+template <> struct NsStaged<true> {
+#define NS_X(name, ty, count) NS_LDS ty *m_##name;
+    NS_MICRO_FWD(NS_X) NS_MICRO_BWD(NS_X)
+#undef NS_X
+    // the per-step table rows of steps t and t + 1 ([2][L] each), ghosts / slots / ghost cotangents, the signal table (TB); the state rows
+    // t and t + 1 ([2][4][C], row r in copy r & 1) and the cotangent planes ([2][3][C]) (ST)
+    NS_LDS float *gh, *sl, *sg;
+    NS_LDS int32_t *sgi;
+    NS_LDS double *gg;
+    NS_LDS int32_t *row_i;       // [2][4][L]: left_src, left_gate, right_src, conv_next
+    NS_LDS double *row_d;        // [2][L]: schedule
+    NS_LDS float *st, *gl;
+    NS_LDS const int32_t *routes_l, *rlen_l;     // the route table and its rows' lengths (null: not staged)
+};
+template <int TA, bool ST, bool MS = false> struct NsArgsT : NsCommon, NsStaged<TA != 0> {    // TA: address space of the static tables (3 = staged, with rows and ghosts)
+    static constexpr bool kTB = TA == 3, kST = ST, kMS = MS;
+#define NS_X(name, ty, count) typename NsPtrT<TA, const ty>::type name;
+    NS_TABLES(NS_X)
+#undef NS_X
+};
+typedef NsArgsT<0, false> NsArgs;              // what the host builds and every kernel receives
+
+// (the persistent kernels read the argument block from LDS: a pointer loaded from there is generic to the compiler -- flat_load, which also
+// counts against the LDS wait counter -- unless its TYPE says that it points into global memory)
+template <typename T> __device__ __forceinline__ NS_GLOBAL T *ns_glob(T *p) { return (NS_GLOBAL T *)p; }
+template <typename T> __device__ __forceinline__ NS_GLOBAL T *ns_ptr(const NsCommon &a, size_t off) {
+    return (NS_GLOBAL T *)reinterpret_cast<T *>(a.ws + off);
+}
+// an array of the micro side's running state: in LDS (MS) or in the workspace
+#define NS_MS(a, T, X) ([&]() { if constexpr (std::decay_t<decltype(a)>::kMS) return (a).m_##X; else return ns_ptr<T>(a, (a).lo.X); }())
 // the state before / after step t, the cotangent planes of the state after step r, the per-step table rows of step t
-__device__ __forceinline__ float *ns_state(const NsArgs &a, int r) {
-    return a.st ? a.st + (size_t)(r & 1) * 4 * a.C : a.hist + (size_t)r * 4 * a.C;
+template <class A> __device__ __forceinline__ auto ns_state(const A &a, int r) {
+    if constexpr (A::kST) return a.st + (size_t)(r & 1) * 4 * a.C;
+    else return ns_glob(a.hist) + (size_t)r * 4 * a.C;
 }
-__device__ __forceinline__ float *ns_G(const NsArgs &a, int r) {
-    return (a.gl ? a.gl : ns_ptr<float>(a, a.lo.G)) + (size_t)(r & 1) * 3 * a.C;
+template <class A> __device__ __forceinline__ auto ns_G(const A &a, int r) {
+    if constexpr (A::kST) return a.gl + (size_t)(r & 1) * 3 * a.C;
+    else return ns_ptr<float>(a, a.lo.G) + (size_t)(r & 1) * 3 * a.C;
 }
-struct NsRow { const int32_t *left_src, *left_gate, *right_src, *conv_next; const double *schedule; };
-__device__ __forceinline__ NsRow ns_row(const NsArgs &a, int t) {
-    NsRow r;
-    if (a.row_i) {
-        const int32_t *b = a.row_i + (size_t)(t & 1) * 4 * a.L;
+template <bool TB> struct NsRowT {
+    typename NsPtrT<TB ? 3 : 1, const int32_t>::type left_src, left_gate, right_src, conv_next;
+    typename NsPtrT<TB ? 3 : 1, const double>::type schedule;
+};
+template <class A> __device__ __forceinline__ NsRowT<A::kTB> ns_row(const A &a, int t) {
+    NsRowT<A::kTB> r;
+    if constexpr (A::kTB) {
+        const auto b = a.row_i + (size_t)(t & 1) * 4 * a.L;
         r.left_src = b; r.left_gate = b + a.L; r.right_src = b + 2 * a.L; r.conv_next = b + 3 * a.L;
         r.schedule = a.row_d + (size_t)(t & 1) * a.L;
     } else {
         const size_t o = (size_t)t * a.L;
-        r.left_src = a.left_src + o; r.left_gate = a.left_gate + o; r.right_src = a.right_src + o; r.conv_next = a.conv_next + o;
-        r.schedule = a.schedule + o;
+        r.left_src = ns_glob(a.left_src) + o; r.left_gate = ns_glob(a.left_gate) + o; r.right_src = ns_glob(a.right_src) + o;
+        r.conv_next = ns_glob(a.conv_next) + o; r.schedule = ns_glob(a.schedule) + o;
     }
     return r;
 }
-__device__ __forceinline__ float *ns_ghosts(const NsArgs &a) { return a.gh ? a.gh : ns_ptr<float>(a, a.lo.ghost); }
-__device__ __forceinline__ float *ns_slots(const NsArgs &a) { return a.sl ? a.sl : ns_ptr<float>(a, a.lo.slot); }
-__device__ __forceinline__ double *ns_gghost(const NsArgs &a) { return a.gg ? a.gg : ns_ptr<double>(a, a.lo.g_ghost); }
+template <class A> __device__ __forceinline__ auto ns_ghosts(const A &a) {
+    if constexpr (A::kTB) return a.gh; else return ns_ptr<float>(a, a.lo.ghost);
+}
+template <class A> __device__ __forceinline__ auto ns_slots(const A &a) {
+    if constexpr (A::kTB) return a.sl; else return ns_ptr<float>(a, a.lo.slot);
+}
+template <class A> __device__ __forceinline__ auto ns_gghost(const A &a) {
+    if constexpr (A::kTB) return a.gg; else return ns_ptr<double>(a, a.lo.g_ghost);
+}
 
 // inclusive block scan (blockDim.x = multiple of 64, <= 1024); `w` = 16 elements of LDS scratch; returns the inclusive prefix,
-// `total` = the block's sum.  Two barriers.
+// `total` = the block's sum.  Two barriers; the wavefronts' sums are scanned by every wavefront's lanes 0..15 (one LDS read + a wave
+// scan instead of a 16-step serial loop: 2 000 cycles a call in round 5's stamps).
+__device__ __forceinline__ int ns_readlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ __forceinline__ double ns_readlane(double x, int l) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <typename T>
+__device__ __forceinline__ void ns_wave_sums(const T *w, T &off, T &total) {      // w[k] = sum of wavefront k; off = sum of the wavefronts before mine
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const T v = wave_scan_add(lane < nw ? w[lane] : (T)0);
+    total = ns_readlane(v, 63);
+    const T before = ns_readlane(v, wv > 0 ? wv - 1 : 0);
+    off = wv > 0 ? before : (T)0;
+}
 template <typename T>
 __device__ __forceinline__ T ns_block_scan(T x, T *w, T &total) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     T s = wave_scan_add(x);
     if (lane == 63) w[wv] = s;
     __syncthreads();
-    T off = 0, tot = 0;
-    for (int k = 0; k < nw; ++k) { const T v = w[k]; if (k < wv) off += v; tot += v; }
+    T off;
+    ns_wave_sums(w, off, total);
     __syncthreads();
-    total = tot;
     return s + off;
 }
+// two scans behind one pair of barriers
+template <typename T1, typename T2>
+__device__ __forceinline__ void ns_block_scan2(T1 x1, T2 x2, T1 *w1, T2 *w2, T1 &incl1, T2 &incl2, T1 &total1, T2 &total2) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const T1 s1 = wave_scan_add(x1);
+    const T2 s2 = wave_scan_add(x2);
+    if (lane == 63) { w1[wv] = s1; w2[wv] = s2; }
+    __syncthreads();
+    T1 off1; T2 off2;
+    ns_wave_sums(w1, off1, total1);
+    ns_wave_sums(w2, off2, total2);
+    __syncthreads();
+    incl1 = s1 + off1; incl2 = s2 + off2;
+}
 
-// ---- forward-mode duals of the head gap: value + gradient w.r.t. (p_h, v_h, p_l, v_l, s_prev, s_cur, s_next); every component follows
-// the float32 rule of the reference's operator (sum, product, quotient, sigmoid), so the VALUES are the reference's bit for bit
-struct D7 { float v; float g[7]; };
-__device__ __forceinline__ D7 d7_c(float v) { D7 x; x.v = v;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) x.g[i] = 0.f;
-    return x; }
-__device__ __forceinline__ D7 d7_var(float v, int i) { D7 x = d7_c(v); x.g[i] = 1.f; return x; }
-__device__ __forceinline__ D7 d7_add(D7 a, D7 b) { D7 x; x.v = a.v + b.v;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) x.g[i] = a.g[i] + b.g[i];
-    return x; }
-__device__ __forceinline__ D7 d7_sub(D7 a, D7 b) { D7 x; x.v = a.v - b.v;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) x.g[i] = a.g[i] - b.g[i];
-    return x; }
-__device__ __forceinline__ D7 d7_mul(D7 a, D7 b) { D7 x; x.v = a.v * b.v;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) x.g[i] = a.g[i] * b.v + b.g[i] * a.v;
-    return x; }
-__device__ __forceinline__ D7 d7_div(D7 a, D7 b) { D7 x; x.v = a.v / b.v;
+// The vehicle slots worth visiting: slot i < nq of every micro lane, nq = the smallest power of two >= the fullest lane so far (<= cap).
+// Item j -> (micro lane m, slot i, index into the [Lm][cap] arrays).
+struct NsSlots { int nq, sh, total, cap; };
+__device__ __forceinline__ NsSlots ns_slot_range(int Lm, int cap, int n_max) {
+    NsSlots r; r.cap = cap;
+    int sh = 0;
+    while ((1 << sh) < n_max) sh++;
+    if ((1 << sh) >= cap) { r.nq = cap; r.sh = -1; } else { r.nq = 1 << sh; r.sh = sh; }
+    r.total = Lm * r.nq;
+    return r;
+}
+__device__ __forceinline__ void ns_slot_of(const NsSlots &r, int j, int &m, int &i, size_t &idx) {
+    m = r.sh >= 0 ? j >> r.sh : j / r.cap;
+    i = j - m * r.nq;
+    idx = (size_t)m * r.cap + i;
+}
+
+// sub-phase stamps of thread 0 (a -DDHTS_NS_STAMPS build; tools/probes/exp_persist_stamps.py)
+#ifdef DHTS_NS_STAMPS
+__shared__ long long ns_sub_[24], ns_sub_last_;
+#define NS_SUB0() { if (threadIdx.x == 0) ns_sub_last_ = __builtin_amdgcn_s_memtime(); }
+#define NS_SUB(i) { if (threadIdx.x == 0) { const long long n_ = __builtin_amdgcn_s_memtime(); ns_sub_[i] += n_ - ns_sub_last_; ns_sub_last_ = n_; } }
+#else
+#define NS_SUB0()
+#define NS_SUB(i)
+#endif
+
+// ---- forward-mode duals of the head gap: value + ONE component of the gradient w.r.t. (p_h, v_h, p_l, v_l, s_prev, s_cur, s_next) --
+// eight threads share a lane's head gap, thread q carries component q (the values are computed by all of them, bit for bit alike);
+// every component follows the float32 rule of the reference's operator (sum, product, quotient, sigmoid), so the VALUES are the
+// reference's bit for bit
+struct D1 { float v, g; };
+__device__ __forceinline__ D1 dq_c(float v) { D1 x; x.v = v; x.g = 0.f; return x; }
+__device__ __forceinline__ D1 dq_var(float v, int i, int q) { D1 x; x.v = v; x.g = i == q ? 1.f : 0.f; return x; }
+__device__ __forceinline__ D1 dq_add(D1 a, D1 b) { D1 x; x.v = a.v + b.v; x.g = a.g + b.g; return x; }
+__device__ __forceinline__ D1 dq_sub(D1 a, D1 b) { D1 x; x.v = a.v - b.v; x.g = a.g - b.g; return x; }
+__device__ __forceinline__ D1 dq_mul(D1 a, D1 b) { D1 x; x.v = a.v * b.v; x.g = a.g * b.v + b.g * a.v; return x; }
+__device__ __forceinline__ D1 dq_div(D1 a, D1 b) {
+    D1 x; x.v = a.v / b.v;
     const float ia = 1.f / b.v, ib = -((a.v / b.v) / b.v);
-#pragma unroll
-    for (int i = 0; i < 7; ++i) x.g[i] = a.g[i] * ia + b.g[i] * ib;
-    return x; }
-__device__ __forceinline__ D7 d7_soft(D7 a, float k) {          // dmath.operation.sigmoid(value, constant = k)
+    x.g = a.g * ia + b.g * ib;
+    return x;
+}
+__device__ __forceinline__ D1 dq_soft(D1 a, float k) {          // dmath.operation.sigmoid(value, constant = k)
     float s, ds;
     soft_switch_both(a.v, k, s, ds);
-    D7 x; x.v = s;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) x.g[i] = a.g[i] * ds;
-    return x; }
-__device__ __forceinline__ D7 d7_pos_or_zero(D7 a) { return a.v > 0.f ? a : d7_c(0.f); }     // x if x > 0 else 0.0
+    D1 x; x.v = s; x.g = a.g * ds;
+    return x;
+}
+__device__ __forceinline__ D1 dq_pos_or_zero(D1 a) { return a.v > 0.f ? a : dq_c(0.f); }     // x if x > 0 else 0.0
 
-__device__ __forceinline__ float ns_lane_signal(const NsArgs &a, const float *action, int t, int lid, bool hard, float *ds_da, int *a_index) {
-    const int kd = a.sig_kind[lid];
-    if (kd == 0) { if (ds_da) *ds_da = 0.f; if (a_index) *a_index = -1; return 1.f; }
-    float we, ns, av, pr; int ai;
-    phase_signal_at(action, a.n_action, a.sq, a.F, t / a.F, t % a.F, a.inter[lid], we, ns, av, pr, ai, hard);
-    if (ds_da) {
+// The signals of a step: every ghost, head gap and their adjoints need the green of some lane = one of the two switches of its
+// intersection (phase_signal_at: divisions, two sigmoids).  The staging persistent kernels evaluate them ONCE per intersection and step
+// into a table in LDS (sg[t & 1][sq][4] = we, ns, d we / d action, d ns / d action; sgi[t & 1] = the action index of intersection 0), one step
+// ahead; everybody else evaluates them in place -- the same float expressions either way.
+template <class A> __device__ __forceinline__ void ns_signal_fill(const A &a, const float *action, int t, int q) {
+    if constexpr (A::kTB) {
+        if (q >= a.sq) return;
+        float we, ns, av, pr; int ai;
+        const bool hard = a.hard != 0;
+        phase_signal_at(action, a.n_action, a.sq, a.F, t / a.F, t % a.F, q, we, ns, av, pr, ai, hard);
         const float z = (av - pr) * kSigK;
         const bool sat = hard || z < -16.f || z > 16.f;
-        *ds_da = sat ? 0.f : (kd == 1 ? we * (1.f - we) * kSigK : -(ns * (1.f - ns) * kSigK));
+        const auto s4 = a.sg + ((size_t)(t & 1) * a.sq + q) * 4;
+        s4[0] = we; s4[1] = ns; s4[2] = sat ? 0.f : we * (1.f - we) * kSigK; s4[3] = sat ? 0.f : -(ns * (1.f - ns) * kSigK);
+        if (q == 0) a.sgi[t & 1] = ai;
     }
-    if (a_index) *a_index = ai;
-    return kd == 1 ? we : ns;
+}
+template <class A> __device__ __forceinline__ float ns_lane_signal(const A &a, const float *action, int t, int lid, bool hard, float *ds_da, int *a_index) {
+    const int kd = a.sig_kind[lid];
+    if (kd == 0) { if (ds_da) *ds_da = 0.f; if (a_index) *a_index = -1; return 1.f; }
+    if constexpr (A::kTB) {
+        const int k = a.inter[lid];
+        const auto s4 = a.sg + ((size_t)(t & 1) * a.sq + k) * 4;
+        if (ds_da) *ds_da = kd == 1 ? s4[2] : s4[3];
+        if (a_index) *a_index = a.sgi[t & 1] + k;
+        return kd == 1 ? s4[0] : s4[1];
+    } else {
+        float we, ns, av, pr; int ai;
+        phase_signal_at(action, a.n_action, a.sq, a.F, t / a.F, t % a.F, a.inter[lid], we, ns, av, pr, ai, hard);
+        if (ds_da) {
+            const float z = (av - pr) * kSigK;
+            const bool sat = hard || z < -16.f || z > 16.f;
+            *ds_da = sat ? 0.f : (kd == 1 ? we * (1.f - we) * kSigK : -(ns * (1.f - ns) * kSigK));
+        }
+        if (a_index) *a_index = ai;
+        return kd == 1 ? we : ns;
+    }
+}
+
+// entry k of route row `row` / the row's length (entries before the -1 padding): LDS copies where a persistent kernel staged them
+template <class A> __device__ __forceinline__ int ns_route_at(const A &a, int row, int k) {
+    if constexpr (A::kTB) { if (a.routes_l != nullptr) return a.routes_l[(size_t)row * a.route_stride + k]; }
+    return ns_glob(a.routes)[(size_t)row * a.route_stride + k];
+}
+template <class A> __device__ __forceinline__ int ns_route_len(const A &a, int row) {
+    if constexpr (A::kTB) { if (a.rlen_l != nullptr) return a.rlen_l[row]; }
+    const auto route = ns_glob(a.routes) + (size_t)row * a.route_stride;
+    int rlen = 0;
+    while (rlen < a.route_stride && route[rlen] >= 0) rlen++;
+    return rlen;
 }
 
 // shift the first n slots of a micro lane's rows one slot towards the head (a vehicle enters at the tail, slot 0)
@@ -192,17 +339,20 @@ __device__ __forceinline__ void ns_shift_in(float *P, float *V, float *A, int *v
 // forward, part 1: boundaries of step t from the state before it; IDM steps
 // =====================================================================================================================
 // ghost (lane, side) = item j of every ARZ lane: _simulator.py:56-137, road_network.py:299-362
-__device__ __forceinline__ void ns_ghost_fwd_item(const NsArgs &a, int t, const float *__restrict__ action, int j) {
+// items: side 0 of all lanes, then -- from the next multiple of 64 -- side 1 (a wavefront runs ONE of the two branches)
+__host__ __device__ inline int ns_ghost_items(int L) { return ((L + 63) & ~63) + L; }
+template <class A> __device__ __forceinline__ void ns_ghost_fwd_item(const A &a, int t, const float *__restrict__ action, int item) {
     const int L = a.L, C = a.C;
     const bool hard = a.hard != 0;
     const float um = a.um;
-    const float *cur = ns_state(a, t);
-    const NsRow rw = ns_row(a, t);
+    const auto cur = ns_state(a, t);
+    const auto rw = ns_row(a, t);
     {
-        if (j >= 2 * L) return;
-        const int lane = j >> 1, side = j & 1;
-        const float *own_in = ns_ptr<float>(a, a.lo.own_hist) + (size_t)t * 2 * L;
-        float *own_out = ns_ptr<float>(a, a.lo.own_hist) + (size_t)(t + 1) * 2 * L;
+        const int Lp = (L + 63) & ~63;
+        const int side = item >= Lp ? 1 : 0, lane = item - side * Lp;
+        if (lane >= L) return;
+        auto own_in = ns_ptr<float>(a, a.lo.own_hist) + (size_t)t * 2 * L;
+        auto own_out = ns_ptr<float>(a, a.lo.own_hist) + (size_t)(t + 1) * 2 * L;
         if (!a.lane_macro[lane]) {
             if (side == 1) { own_out[2 * lane] = own_in[2 * lane]; own_out[2 * lane + 1] = own_in[2 * lane + 1]; }
             return;
@@ -233,34 +383,33 @@ __device__ __forceinline__ void ns_ghost_fwd_item(const NsArgs &a, int t, const 
             glue_from_r_u(fr, fu, um, fy, fq);
             own_out[2 * lane] = fr; own_out[2 * lane + 1] = fu;
         }
-        float *g = ns_ghosts(a) + ((size_t)a.lane_gpos[lane] * 2 + side) * 4;
+        const auto g = ns_ghosts(a) + ((size_t)a.lane_gpos[lane] * 2 + side) * 4;
         g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
     }
 }
 
 // the micro side of a step's boundary + the IDM steps: ONE workgroup (all its threads call; hd_s = [Lm][2] floats of LDS)
-__device__ __forceinline__ void ns_micro_fwd(const NsArgs &a, int t, const float *__restrict__ action, float *hd_s) {
+template <class A> __device__ __forceinline__ void ns_micro_fwd(const A &a, int t, const float *__restrict__ action, float *hd_s) {
     const int tid = threadIdx.x, B = blockDim.x;
-    const int L = a.L;
     const bool hard = a.hard != 0;
-    const size_t row = (size_t)t * L;
     const int Lm = a.Lm, cap = a.cap;
     if (Lm == 0) return;
     __shared__ double scan_d[16];
     __shared__ int scan_i[16];
     const size_t plane = (size_t)Lm * cap;
-    float *P0 = ns_ptr<float>(a, a.lo.P) + (size_t)(t & 1) * plane, *P1 = ns_ptr<float>(a, a.lo.P) + (size_t)((t + 1) & 1) * plane;
-    float *V0 = ns_ptr<float>(a, a.lo.V) + (size_t)(t & 1) * plane, *V1 = ns_ptr<float>(a, a.lo.V) + (size_t)((t + 1) & 1) * plane;
-    float *A_ = ns_ptr<float>(a, a.lo.A);
-    int *vroute = ns_ptr<int>(a, a.lo.vroute), *vcur = ns_ptr<int>(a, a.lo.vcur), *lane_n = ns_ptr<int>(a, a.lo.lane_n);
-    int *rused = ns_ptr<int>(a, a.lo.rused);
-    NsCounters *cnt = ns_ptr<NsCounters>(a, a.lo.counters);
-    int *adm = hard ? nullptr : ns_ptr<int>(a, a.lo.adm) + (size_t)t * Lm;
+    auto P0 = NS_MS(a, float, P) + (size_t)(t & 1) * plane, P1 = NS_MS(a, float, P) + (size_t)((t + 1) & 1) * plane;
+    auto V0 = NS_MS(a, float, V) + (size_t)(t & 1) * plane, V1 = NS_MS(a, float, V) + (size_t)((t + 1) & 1) * plane;
+    auto A_ = NS_MS(a, float, A);
+    auto vroute = NS_MS(a, int, vroute), vcur = NS_MS(a, int, vcur), lane_n = NS_MS(a, int, lane_n);
+    auto rused = NS_MS(a, int, rused);
+    auto cnt = NS_MS(a, NsCounters, counters);
+    auto adm = hard ? nullptr : ns_ptr<int>(a, a.lo.adm) + (size_t)t * Lm;
     const float vlen = a.vlen;
 
+    NS_SUB0()
     // ---- admission on micro source lanes (_simulator.py:153-174): room for half a vehicle at the entrance, then ONE draw of the
     // host's stream per such lane, lanes in id order ----
-    if (a.lane_source != nullptr) {
+    if (a.has_source) {
         int carry = 0;
         const int used0 = cnt->draws_used;
         for (int base = 0; base < Lm; base += B) {
@@ -281,8 +430,8 @@ __device__ __forceinline__ void ns_micro_fwd(const NsArgs &a, int t, const float
                 const int idx = used0 + carry + rank;
                 if (idx >= a.n_draws) net_fault(a.err, DHTS_FAULT_CAPACITY, t, l, -1);
                 else {
-                    const double draw = a.draws[idx];
-                    const int r_lo = a.route_ptr[l], r_n = a.route_ptr[l + 1] - r_lo;
+                    const double draw = ns_glob(a.draws)[idx];
+                    const int r_lo = ns_glob(a.route_ptr)[l], r_n = ns_glob(a.route_ptr)[l + 1] - r_lo;
                     if (draw < ns_row(a, t).schedule[l] && rused[l] < r_n) {
                         if (n >= cap) net_fault(a.err, DHTS_FAULT_CAPACITY, t, l, n);
                         else {
@@ -290,6 +439,7 @@ __device__ __forceinline__ void ns_micro_fwd(const NsArgs &a, int t, const float
                             ns_shift_in(P0, V0, A_, vroute, vcur, b, n);
                             P0[b] = 0.f; V0[b] = 0.f; A_[b] = vlen; vroute[b] = r_lo + rused[l]; vcur[b] = 0;
                             rused[l] += 1; lane_n[m] = n + 1;
+                            atomicMax(&cnt->n_max, n + 1);
                             admitted = 1;
                         }
                     }
@@ -308,16 +458,17 @@ __device__ __forceinline__ void ns_micro_fwd(const NsArgs &a, int t, const float
     }
     __syncthreads();
 
+    NS_SUB(0)
     // ---- head gaps (lane-id order for the running mean of the final signal) ----
-    NsHeadGap *hgrow = hard ? nullptr : ns_ptr<NsHeadGap>(a, a.lo.hg) + (size_t)t * Lm;
-    double *sigS = ns_ptr<double>(a, a.lo.sigS);
+    auto hgrow = hard ? nullptr : ns_ptr<NsHeadGap>(a, a.lo.hg) + (size_t)t * Lm;
+    auto sigS = ns_ptr<double>(a, a.lo.sigS);
     long long sig_n0 = cnt->sig_n;
     double sig_sum0 = cnt->sig_sum;
     __syncthreads();
-    for (int base = 0; base < Lm; base += B) {
-        const int m = base + tid;
+    for (int base = 0; base < 8 * Lm; base += B) {
+        const int m = (base + tid) >> 3, q = tid & 7;            // thread q of a lane's eight: gradient component q (q = 7: the record's tail)
         bool occ = false;
-        D7 green_dp = d7_c(1000.f), green_dv = d7_c(0.f), red_dp = d7_c(0.f), fin = d7_c(0.f);
+        D1 green_dp = dq_c(1000.f), green_dv = dq_c(0.f), red_dp = dq_c(0.f), fin = dq_c(0.f);
         int leader = -1, sgl[3] = {-1, -1, -1};
         if (m < Lm) {
             const int n = lane_n[m];
@@ -325,90 +476,92 @@ __device__ __forceinline__ void ns_micro_fwd(const NsArgs &a, int t, const float
                 occ = true;
                 const int l = a.micro_lanes[m];
                 const size_t hs = (size_t)m * cap + n - 1;
-                const D7 hp = d7_var(P0[hs], 0), hv = d7_var(V0[hs], 1);
-                const int *route = a.routes + (size_t)vroute[hs] * a.route_stride;
+                const D1 hp = dq_var(P0[hs], 0, q), hv = dq_var(V0[hs], 1, q);
+                const int rrow = vroute[hs];
                 const int cursor = vcur[hs];
-                int rlen = 0;
-                while (rlen < a.route_stride && route[rlen] >= 0) rlen++;
-                const D7 Lc = d7_c((float)a.lane_len[l]);
+                const int rlen = ns_route_len(a, rrow);
+                const D1 Lc = dq_c((float)a.lane_len[l]);
                 // leader further along the route (road_network.py:459-580)
-                D7 reach = d7_sub(d7_sub(Lc, hp), d7_c(vlen * 0.5f));
+                D1 reach = dq_sub(dq_sub(Lc, hp), dq_c(vlen * 0.5f));
                 for (int k = cursor; k < rlen - 1; k++) {
-                    const int there = route[k + 1];
+                    const int there = ns_route_at(a, rrow, k + 1);
                     if (a.lane_macro[there]) break;
                     const int ms = a.lane_mslot[there];
                     if (lane_n[ms]) {
                         const size_t ts = (size_t)ms * cap;
-                        const D7 lp = d7_var(P0[ts], 2), lv = d7_var(V0[ts], 3);
-                        const D7 gap = d7_add(reach, d7_sub(lp, d7_c(vlen * 0.5f)));
-                        green_dp = d7_pos_or_zero(gap);
-                        green_dv = d7_sub(hv, lv);
+                        const D1 lp = dq_var(P0[ts], 2, q), lv = dq_var(V0[ts], 3, q);
+                        const D1 gap = dq_add(reach, dq_sub(lp, dq_c(vlen * 0.5f)));
+                        green_dp = dq_pos_or_zero(gap);
+                        green_dv = dq_sub(hv, lv);
                         leader = ms;
                         break;
                     }
-                    reach = d7_add(reach, d7_c((float)a.lane_len[there]));
+                    reach = dq_add(reach, dq_c((float)a.lane_len[there]));
                 }
                 // red light: stop line at the lane end (_simulator.py:188-194)
-                red_dp = d7_pos_or_zero(d7_sub(d7_sub(Lc, hp), d7_c(vlen * 0.5f)));
+                red_dp = dq_pos_or_zero(dq_sub(dq_sub(Lc, hp), dq_c(vlen * 0.5f)));
                 const bool prev_exist = cursor > 0, next_exist = cursor < rlen - 1;
-                D7 prev_s = d7_c(0.f), next_s = d7_c(0.f);
-                if (prev_exist && !hard) prev_s = d7_soft(d7_sub(d7_c(0.f), hp), 16.f);
-                const D7 curr_s = hard ? d7_c(1.f) : d7_mul(d7_soft(hp, 16.f), d7_soft(d7_sub(Lc, hp), 16.f));
-                if (next_exist && !hard) next_s = d7_soft(d7_sub(hp, Lc), 16.f);
-                const D7 total = d7_add(d7_add(prev_s, curr_s), next_s);
+                D1 prev_s = dq_c(0.f), next_s = dq_c(0.f);
+                if (prev_exist && !hard) prev_s = dq_soft(dq_sub(dq_c(0.f), hp), 16.f);
+                const D1 curr_s = hard ? dq_c(1.f) : dq_mul(dq_soft(hp, 16.f), dq_soft(dq_sub(Lc, hp), 16.f));
+                if (next_exist && !hard) next_s = dq_soft(dq_sub(hp, Lc), 16.f);
+                const D1 total = dq_add(dq_add(prev_s, curr_s), next_s);
                 for (int w = 0; w < 3; w++) {
                     if ((w == 0 && !prev_exist) || (w == 2 && !next_exist)) continue;
-                    const int lid = route[cursor + w - 1];
-                    const D7 sc = w == 0 ? prev_s : (w == 1 ? curr_s : next_s);
-                    D7 sv;
-                    if (a.sig_kind[lid] == 0) sv = d7_c(1.f);
-                    else { sv = d7_var(ns_lane_signal(a, action, t, lid, hard, nullptr, nullptr), 4 + w); sgl[w] = lid; }
-                    fin = d7_add(fin, d7_mul(d7_div(sc, total), sv));
+                    const int lid = ns_route_at(a, rrow, cursor + w - 1);
+                    const D1 sc = w == 0 ? prev_s : (w == 1 ? curr_s : next_s);
+                    D1 sv;
+                    if (a.sig_kind[lid] == 0) sv = dq_c(1.f);
+                    else { sv = dq_var(ns_lane_signal(a, action, t, lid, hard, nullptr, nullptr), 4 + w, q); sgl[w] = lid; }
+                    fin = dq_add(fin, dq_mul(dq_div(sc, total), sv));
                 }
             }
         }
+        NS_SUB(16)
         // ordered running mean of the final signal over the occupied lanes (signal_rms: _simulator.py:234-262; rms.py)
         float hdp = 1000.f, hdv = 0.f;
         if (hard) {
             if (occ) { const bool green = fin.v >= 0.5f; hdp = green ? green_dp.v : red_dp.v; hdv = green ? green_dv.v : 0.f; }
         } else {
             int tot_n; double tot_s;
-            const int rank = ns_block_scan<int>(occ ? 1 : 0, scan_i, tot_n);
-            const double incl = ns_block_scan<double>(occ ? (double)fin.v : 0., scan_d, tot_s);
+            const bool mine = occ && q == 0;                         // (a lane counts once; its eight threads read the same prefix)
+            int rank; double incl;
+            ns_block_scan2<int, double>(mine ? 1 : 0, mine ? (double)fin.v : 0., scan_i, scan_d, rank, incl, tot_n, tot_s);
+            NS_SUB(17)
             if (occ) {
                 const long long i = sig_n0 + rank - 1;               // 0-based index of this sample in the stream
                 const double S = sig_sum0 + incl;
-                sigS[i] = S;
+                if (q == 0) sigS[i] = S;
                 const double mean = (i + 1 > kNsWindow) ? (S - sigS[i - kNsWindow]) / (double)kNsWindow : S / (double)(i + 1);
                 const float k2 = 32.f / fabsf((float)mean);
-                const D7 fs = d7_soft(d7_sub(fin, d7_c(0.5f)), k2);
-                const D7 one_m = d7_sub(d7_c(1.f), fs);
-                const D7 o_dp = d7_add(d7_mul(green_dp, fs), d7_mul(red_dp, one_m));
-                const D7 o_dv = d7_add(d7_mul(green_dv, fs), d7_mul(d7_c(0.f), one_m));
+                const D1 fs = dq_soft(dq_sub(fin, dq_c(0.5f)), k2);
+                const D1 one_m = dq_sub(dq_c(1.f), fs);
+                const D1 o_dp = dq_add(dq_mul(green_dp, fs), dq_mul(red_dp, one_m));
+                const D1 o_dv = dq_add(dq_mul(green_dv, fs), dq_mul(dq_c(0.f), one_m));
                 hdp = o_dp.v; hdv = o_dv.v;
-                NsHeadGap h;
-#pragma unroll
-                for (int q = 0; q < 7; ++q) { h.jp[q] = o_dp.g[q]; h.jv[q] = o_dv.g[q]; }
-                h.leader = leader; h.sig[0] = sgl[0]; h.sig[1] = sgl[1]; h.sig[2] = sgl[2]; h.valid = 1; h.pad = 0;
-                hgrow[m] = h;
-            } else if (m < Lm) {
+                if (q < 7) { hgrow[m].jp[q] = o_dp.g; hgrow[m].jv[q] = o_dv.g; }
+                else { hgrow[m].leader = leader; hgrow[m].sig[0] = sgl[0]; hgrow[m].sig[1] = sgl[1]; hgrow[m].sig[2] = sgl[2]; hgrow[m].valid = 1; hgrow[m].pad = 0; }
+            } else if (m < Lm && q == 7) {
                 hgrow[m].valid = 0;
             }
             sig_n0 += tot_n; sig_sum0 += tot_s;
         }
-        if (m < Lm) { hd_s[2 * m] = hdp; hd_s[2 * m + 1] = hdv; }
+        if (m < Lm && q == 0) { hd_s[2 * m] = hdp; hd_s[2 * m + 1] = hdv; }
     }
     __syncthreads();
     if (tid == 0 && !hard) { cnt->sig_n = sig_n0; cnt->sig_sum = sig_sum0; }
 
+    NS_SUB(1)
     // ---- one IDM step of every vehicle (explicit Euler; _micro_lane.py:131-214, _idm.py:6-50, didm.py:13-103) ----
     IdmParams prm;              // MicroVehicle.default_micro_vehicle(speed_limit), micro_vehicle.py:31-72
     prm.a_max = a.um_d * 1.0; prm.a_pref = a.um_d * 0.8; prm.v_target = a.um_d * 0.9; prm.min_space = a.vlen_d * 0.1; prm.time_pref = 0.1;
     prm.length = a.vlen_d;
-    float4 *tape = hard ? nullptr : ns_ptr<float4>(a, a.lo.idm_tape) + (size_t)t * plane;
-    int *nv_idm = hard ? nullptr : ns_ptr<int>(a, a.lo.nv_idm) + (size_t)t * Lm;
-    for (size_t idx = tid; idx < plane; idx += B) {
-        const int m = (int)(idx / cap), i = (int)(idx - (size_t)m * cap);
+    auto tape = hard ? nullptr : ns_ptr<float4>(a, a.lo.idm_tape) + (size_t)t * plane;
+    auto nv_idm = hard ? nullptr : ns_ptr<int>(a, a.lo.nv_idm) + (size_t)t * Lm;
+    const NsSlots sr = ns_slot_range(Lm, cap, cnt->n_max);
+    for (int j = tid; j < sr.total; j += B) {
+        int m, i; size_t idx;
+        ns_slot_of(sr, j, m, i, idx);
         const int n = lane_n[m];
         if (i == 0 && nv_idm) nv_idm[m] = n;
         if (i >= n) continue;
@@ -422,6 +575,7 @@ __device__ __forceinline__ void ns_micro_fwd(const NsArgs &a, int t, const float
         P1[idx] = o.np; V1[idx] = o.nv;
         if (tape) tape[idx] = make_float4(o.dE[2], o.dE[3], o.dLd[2], o.dLd[3]);
     }
+    NS_SUB(2)
 }
 
 __global__ void __launch_bounds__(kNsBlock) ns_boundary_fwd_kernel(NsArgs a, int t, const float *__restrict__ action) {
@@ -433,7 +587,7 @@ __global__ void __launch_bounds__(kNsBlock) ns_boundary_fwd_kernel(NsArgs a, int
 // =====================================================================================================================
 // forward, part 2: hand-offs in lane-id order on the committed state, then the queue loss
 // =====================================================================================================================
-__device__ __forceinline__ void ns_push_event(const NsArgs &a, NsCounters *cnt, int t, const NsEvent &e) {
+template <class A> __device__ __forceinline__ void ns_push_event(const A &a, NsCounters *cnt, int t, const NsEvent &e) {
     if (a.hard) return;
     const int k = cnt->n_events;
     if (k >= a.max_events) { net_fault(a.err, DHTS_FAULT_CAPACITY, t, e.lane, -2); return; }
@@ -441,32 +595,33 @@ __device__ __forceinline__ void ns_push_event(const NsArgs &a, NsCounters *cnt, 
     cnt->n_events = k + 1;
 }
 
-__device__ __forceinline__ void ns_convert(const NsArgs &a, int t, int *cand) {      // cand: [L] ints of LDS (candidate flags of the event walk)
+template <class A> __device__ __forceinline__ void ns_convert(const A &a, int t, int *cand) {      // cand: [L] ints of LDS (candidate flags of the event walk)
     const int tid = threadIdx.x, B = blockDim.x;
     const int L = a.L, C = a.C, Lm = a.Lm, cap = a.cap;
     const bool hard = a.hard != 0;
     const float um = a.um, vlen = a.vlen, dtf = a.dtf, s0f = a.s0f;
     __shared__ double scan_d[16];
     __shared__ int scan_i[16];
-    float *nxt = ns_state(a, t + 1);                   // committed state: the lanes' steps wrote it
-    const NsRow rw = ns_row(a, t);
-    float *Rn = nxt, *Yn = nxt + C, *Un = nxt + 2 * C;
+    const auto nxt = ns_state(a, t + 1);               // committed state: the lanes' steps wrote it
+    const auto rw = ns_row(a, t);
+    const auto Rn = nxt, Yn = nxt + C, Un = nxt + 2 * C;
     const size_t row = (size_t)t * L;
     const size_t plane = (size_t)Lm * cap;
-    float *P1 = Lm ? ns_ptr<float>(a, a.lo.P) + (size_t)((t + 1) & 1) * plane : nullptr;
-    float *V1 = Lm ? ns_ptr<float>(a, a.lo.V) + (size_t)((t + 1) & 1) * plane : nullptr;
-    float *A_ = ns_ptr<float>(a, a.lo.A);
-    int *vroute = ns_ptr<int>(a, a.lo.vroute), *vcur = ns_ptr<int>(a, a.lo.vcur), *lane_n = ns_ptr<int>(a, a.lo.lane_n);
-    int *rused = ns_ptr<int>(a, a.lo.rused);
-    float *capv = ns_ptr<float>(a, a.lo.capv);
-    NsCounters *cnt = ns_ptr<NsCounters>(a, a.lo.counters);
-    float4 *caprec = ns_ptr<float4>(a, a.lo.caprec) + (hard ? 0 : (size_t)t * a.ncap);
-    int *capflag = ns_ptr<int>(a, a.lo.capflag) + (hard ? 0 : (size_t)t * a.ncap);
-    int *ev_off = ns_ptr<int>(a, a.lo.ev_off);
+    auto P1 = Lm ? NS_MS(a, float, P) + (size_t)((t + 1) & 1) * plane : nullptr;
+    auto V1 = Lm ? NS_MS(a, float, V) + (size_t)((t + 1) & 1) * plane : nullptr;
+    auto A_ = NS_MS(a, float, A);
+    auto vroute = NS_MS(a, int, vroute), vcur = NS_MS(a, int, vcur), lane_n = NS_MS(a, int, lane_n);
+    auto rused = NS_MS(a, int, rused);
+    auto capv = NS_MS(a, float, capv);
+    auto cnt = NS_MS(a, NsCounters, counters);
+    auto caprec = ns_ptr<float4>(a, a.lo.caprec) + (hard ? 0 : (size_t)t * a.ncap);
+    auto capflag = ns_ptr<int>(a, a.lo.capflag) + (hard ? 0 : (size_t)t * a.ncap);
+    auto ev_off = ns_ptr<int>(a, a.lo.ev_off);
 
     if (Lm > 0) {
         for (int l = tid; l < L; l += B) cand[l] = 0;
         __syncthreads();
+        NS_SUB0()
         // ---- flux capacitors: += r u dt of the last cell (conversion.py:32-45) ----
         for (int k = tid; k < a.ncap; k += B) {
             const int l = a.cap_lanes[k];
@@ -490,6 +645,7 @@ __device__ __forceinline__ void ns_convert(const NsArgs &a, int t, int *cand) { 
         }
         __syncthreads();
         if (tid == 0 && !hard) ev_off[t] = cnt->n_events;
+        NS_SUB(3)
         // ---- the hand-off events, serially in lane-id order (RoadNetwork.conversion, road_network.py:113-170): wavefront 0 finds the
         // next candidate with a ballot, its lane 0 acts; an event can make a LATER lane a candidate ----
         if (tid < 64) {
@@ -515,7 +671,7 @@ __device__ __forceinline__ void ns_convert(const NsArgs &a, int t, int *cand) { 
                             const size_t b = (size_t)ms * cap;
                             const float space = n ? P1[b] - 0.5f * vlen : (float)a.lane_len[m];
                             if (level >= vlen && space >= vlen * 1.0f) {
-                                const int r_lo = a.route_ptr[m], r_n = a.route_ptr[m + 1] - r_lo;
+                                const int r_lo = ns_glob(a.route_ptr)[m], r_n = ns_glob(a.route_ptr)[m + 1] - r_lo;
                                 if (r_n <= 0 || n >= cap) net_fault(a.err, DHTS_FAULT_CAPACITY, t, m, n);
                                 else {
                                     const int rrow = r_lo + rused[m] % r_n;
@@ -525,6 +681,7 @@ __device__ __forceinline__ void ns_convert(const NsArgs &a, int t, int *cand) { 
                                     A_[b] = level - (float)((double)level - (double)vlen);
                                     vroute[b] = rrow; vcur[b] = 0;
                                     lane_n[ms] = n + 1;
+                                    if (n + 1 > cnt->n_max) cnt->n_max = n + 1;
                                     capv[k] = (float)((double)level - (double)vlen);
                                     cnt->n_spawned += 1;
                                     NsEvent e = {}; e.kind = NS_EV_SPAWN; e.lane = l; e.tgt = m;
@@ -536,11 +693,9 @@ __device__ __forceinline__ void ns_convert(const NsArgs &a, int t, int *cand) { 
                             const int n = lane_n[ms];
                             if (n > 0) {
                                 const size_t hs = (size_t)ms * cap + n - 1;
-                                const int *route = a.routes + (size_t)vroute[hs] * a.route_stride;
                                 const int cursor = vcur[hs];
-                                int rlen = 0;
-                                while (rlen < a.route_stride && route[rlen] >= 0) rlen++;
-                                const int nid = cursor < rlen - 1 ? route[cursor + 1] : -1;
+                                const int rlen = ns_route_len(a, vroute[hs]);
+                                const int nid = cursor < rlen - 1 ? ns_route_at(a, vroute[hs], cursor + 1) : -1;
                                 const float Lf = (float)a.lane_len[l];
                                 const float hp = P1[hs], hv = V1[hs], ha = A_[hs];
                                 if (nid == -1) {                                    // micro -> none (conversion.py:203-215)
@@ -561,6 +716,7 @@ __device__ __forceinline__ void ns_convert(const NsArgs &a, int t, int *cand) { 
                                             const float np_ = hp - Lf;
                                             P1[b2] = np_; V1[b2] = hv; A_[b2] = ha; vroute[b2] = vr_; vcur[b2] = cursor + 1;
                                             lane_n[m2] = n2 + 1;
+                                            if (n2 + 1 > cnt->n_max) cnt->n_max = n2 + 1;
                                             if (n2 == 0 && nid > l) cand[nid] = np_ >= (float)a.lane_len[nid];
                                             NsEvent e = {}; e.kind = NS_EV_CHANGE; e.lane = l; e.tgt = nid; ns_push_event(a, cnt, t, e);
                                         }
@@ -618,62 +774,114 @@ __device__ __forceinline__ void ns_convert(const NsArgs &a, int t, int *cand) { 
     }
     if (tid == 0 && !hard) ev_off[t + 1] = cnt->n_events;
 
+    NS_SUB(4)
     // ---- queue-length loss of the committed state (lane-id order; _env.py:664-742 with :586-618) ----
-    int *nv_post = (Lm && !hard) ? ns_ptr<int>(a, a.lo.nv_post) + (size_t)t * Lm : nullptr;
-    float *vx = (Lm && !hard) ? ns_ptr<float>(a, a.lo.vx) + (size_t)t * plane : nullptr;
-    float *kc_cell = hard ? nullptr : ns_ptr<float>(a, a.lo.kc_cell) + (size_t)t * C;
-    float *kc_veh = (Lm && !hard) ? ns_ptr<float>(a, a.lo.kc_veh) + (size_t)t * plane : nullptr;
-    double *lossS = ns_ptr<double>(a, a.lo.lossS);
-    long long n0 = cnt->loss_n;
+    auto nv_post = (Lm && !hard) ? ns_ptr<int>(a, a.lo.nv_post) + (size_t)t * Lm : nullptr;
+    auto vx = (Lm && !hard) ? ns_ptr<float>(a, a.lo.vx) + (size_t)t * plane : nullptr;
+    auto kc_cell = hard ? nullptr : ns_ptr<float>(a, a.lo.kc_cell) + (size_t)t * C;
+    auto kc_veh = (Lm && !hard) ? ns_ptr<float>(a, a.lo.kc_veh) + (size_t)t * plane : nullptr;
+    auto lossS = ns_ptr<double>(a, a.lo.lossS);
+    const long long n_start = cnt->loss_n;
+    long long n0 = n_start;
     double S0 = cnt->loss_sum;
     __syncthreads();
+    if (hard) {
+        for (int l = tid; l < L; l += B) {
+            float qlen = 0.f;
+            if (a.lane_macro[l]) {
+                const int cntl = a.lane_ncell[l], off = a.lane_off[l];
+                const float w = (float)a.lane_dx[l];
+                for (int i = 0; i < cntl; i++) qlen = qlen + (Un[off + i] < s0f ? 1.f : 0.f) * (Rn[off + i] * w / vlen);
+            } else {
+                const int ms = a.lane_mslot[l], cntl = lane_n[ms];
+                for (int i = 0; i < cntl; i++) qlen = qlen + (V1[(size_t)ms * cap + i] < s0f ? 1.f : 0.f);
+            }
+            ns_glob(a.queue)[row + l] = (qlen * qlen) * dtf;
+        }
+        NS_SUB(5)
+        return;
+    }
+    // The constants of the soft queue indicator come from the running mean of ALL samples so far (cells and vehicles, lanes in id
+    // order): (1) a thread per lane counts and sums its samples, an ordered prefix over the lanes follows; (2) a thread per SAMPLE
+    // continues the lane's prefix up to its own sample in the same order, takes the mean, the constant and the sample's term;
+    // (3) a thread per lane adds its terms in order.  Scratch (behind the candidate flags): laneS [L] | laneN [L] | termC [C] | termV [plane]
+    double *laneS = reinterpret_cast<double *>(cand);
+    int *laneN = reinterpret_cast<int *>(laneS + L);
+    float *termC = reinterpret_cast<float *>(laneN + L), *termV = termC + C;
     for (int base = 0; base < L; base += B) {
         const int l = base + tid;
-        int cntl = 0, ms = -1, off = 0;
-        bool macro = false;
+        int cntl = 0;
         double sum = 0.;
         if (l < L) {
-            macro = a.lane_macro[l] != 0;
-            if (macro) {
-                cntl = a.lane_ncell[l]; off = a.lane_off[l];
-                if (!hard) for (int i = 0; i < cntl; i++) sum += (double)(s0f - Un[off + i]);
+            if (a.lane_macro[l]) {
+                cntl = a.lane_ncell[l];
+                const int off = a.lane_off[l];
+                for (int i = 0; i < cntl; i++) sum += (double)(s0f - Un[off + i]);
             } else {
-                ms = a.lane_mslot[l];
+                const int ms = a.lane_mslot[l];
                 cntl = lane_n[ms];
                 if (nv_post) nv_post[ms] = cntl;
-                if (!hard) for (int i = 0; i < cntl; i++) sum += (double)(s0f - V1[(size_t)ms * cap + i]);
+                for (int i = 0; i < cntl; i++) sum += (double)(s0f - V1[(size_t)ms * cap + i]);
             }
         }
-        float qlen = 0.f;
-        if (hard) {
-            if (l < L) {
-                if (macro) { const float w = (float)a.lane_dx[l]; for (int i = 0; i < cntl; i++) qlen = qlen + (Un[off + i] < s0f ? 1.f : 0.f) * (Rn[off + i] * w / vlen); }
-                else for (int i = 0; i < cntl; i++) qlen = qlen + (V1[(size_t)ms * cap + i] < s0f ? 1.f : 0.f);
-            }
-        } else {
-            int tot_n; double tot_s;
-            const int n_incl = ns_block_scan<int>(cntl, scan_i, tot_n);
-            const double s_incl = ns_block_scan<double>(sum, scan_d, tot_s);
-            if (l < L) {
-                long long i_g = n0 + (n_incl - cntl);
-                double S = S0 + (s_incl - sum);
-                const float w = macro ? (float)a.lane_dx[l] : 0.f;
-                for (int i = 0; i < cntl; i++, i_g++) {
-                    const float x = s0f - (macro ? Un[off + i] : V1[(size_t)ms * cap + i]);
-                    S += (double)x;
-                    lossS[i_g] = S;
-                    const double mean = (i_g + 1 > kNsWindow) ? (S - lossS[i_g - kNsWindow]) / (double)kNsWindow : S / (double)(i_g + 1);
-                    const float k = 16.f / fabsf((float)mean);
-                    if (macro) { kc_cell[off + i] = k; qlen = qlen + soft_switch(x, k) * (Rn[off + i] * w / vlen); }
-                    else { kc_veh[(size_t)ms * cap + i] = k; vx[(size_t)ms * cap + i] = x; qlen = qlen + soft_switch(x, k); }
-                }
-            }
-            n0 += tot_n; S0 += tot_s;
-        }
-        if (l < L) a.queue[row + l] = (qlen * qlen) * dtf;
+        int tot_n; double tot_s;
+        int n_incl; double s_incl;
+        ns_block_scan2<int, double>(cntl, sum, scan_i, scan_d, n_incl, s_incl, tot_n, tot_s);
+        if (l < L) { laneN[l] = (int)(n0 - n_start) + (n_incl - cntl); laneS[l] = S0 + (s_incl - sum); }
+        n0 += tot_n; S0 += tot_s;
     }
     __syncthreads();
-    if (tid == 0 && !hard) { cnt->loss_n = n0; cnt->loss_sum = S0; }
+    for (int c = tid; c < C; c += B) {
+        const int l = a.cell_lane[c], off = a.lane_off[l], k = c - off;
+        double S = laneS[l];
+        for (int i = 0; i < k; i++) S += (double)(s0f - Un[off + i]);
+        const float x = s0f - Un[c];
+        S += (double)x;
+        const long long i_g = n_start + laneN[l] + k;
+        lossS[i_g] = S;
+        const double mean = (i_g + 1 > kNsWindow) ? (S - lossS[i_g - kNsWindow]) / (double)kNsWindow : S / (double)(i_g + 1);
+        const float kk = 16.f / fabsf((float)mean);
+        kc_cell[c] = kk;
+        termC[c] = soft_switch(x, kk) * (Rn[c] * (float)a.lane_dx[l] / vlen);
+    }
+    const NsSlots sr = ns_slot_range(Lm, cap, cnt->n_max);
+    for (int j = tid; j < sr.total; j += B) {
+        int ms, i; size_t idx;
+        ns_slot_of(sr, j, ms, i, idx);
+        if (i >= lane_n[ms]) continue;
+        const int l = a.micro_lanes[ms];
+        double S = laneS[l];
+        for (int j = 0; j < i; j++) S += (double)(s0f - V1[(size_t)ms * cap + j]);
+        const float x = s0f - V1[idx];
+        S += (double)x;
+        const long long i_g = n_start + laneN[l] + i;
+        lossS[i_g] = S;
+        const double mean = (i_g + 1 > kNsWindow) ? (S - lossS[i_g - kNsWindow]) / (double)kNsWindow : S / (double)(i_g + 1);
+        const float kk = 16.f / fabsf((float)mean);
+        kc_veh[idx] = kk; vx[idx] = x;
+        termV[idx] = soft_switch(x, kk);
+    }
+    __syncthreads();
+    for (int l = tid; l < L; l += B) {
+        float qlen = 0.f;
+        if (a.lane_macro[l]) {
+            const int cntl = a.lane_ncell[l], off = a.lane_off[l];
+            for (int i = 0; i < cntl; i++) qlen = qlen + termC[off + i];
+        } else {
+            const int ms = a.lane_mslot[l], cntl = lane_n[ms];
+            for (int i = 0; i < cntl; i++) qlen = qlen + termV[(size_t)ms * cap + i];
+        }
+        ns_glob(a.queue)[row + l] = (qlen * qlen) * dtf;
+    }
+    __syncthreads();
+    NS_SUB(5)
+    if (tid == 0) { cnt->loss_n = n0; cnt->loss_sum = S0; }
+}
+
+// LDS scratch of ns_convert: the candidate flags of the event walk [L ints], then the loss's lane prefixes and per-sample terms
+__host__ __device__ inline size_t ns_convert_scratch(int L, int C, size_t plane) {
+    const size_t loss = 12 * (size_t)L + 4 * ((size_t)C + plane) + 16;
+    return loss > 4 * (size_t)L ? loss : 4 * (size_t)L;
 }
 
 __global__ void __launch_bounds__(kNsBlock) ns_convert_fwd_kernel(NsArgs a, int t) {
@@ -683,12 +891,12 @@ __global__ void __launch_bounds__(kNsBlock) ns_convert_fwd_kernel(NsArgs a, int 
 
 // reward = - sum of the queue terms, lanes outermost (ItscpEnv._reward, _env.py:770-797): one thread per lane sums its steps,
 // lane 0 of the block the lanes; counts out
-__device__ __forceinline__ void ns_reward(const NsArgs &a, float *part) {          // part: [2][L] floats of LDS
+template <class A> __device__ __forceinline__ void ns_reward(const A &a, float *part) {          // part: [2][L] floats of LDS
     const int tid = threadIdx.x, B = blockDim.x, L = a.L, T = a.T;
     const int cut = (a.loss_steps > 0 && a.loss_steps < T) ? a.loss_steps : T;
     for (int l = tid; l < L; l += B) {
         float s = 0.f, sc = 0.f;
-        for (int t = 0; t < T; t++) { const float q = (-1.0f) * a.queue[(size_t)t * L + l]; s = s + q; if (t < cut) sc = sc + q; }
+        for (int t = 0; t < T; t++) { const float q = (-1.0f) * ns_glob(a.queue)[(size_t)t * L + l]; s = s + q; if (t < cut) sc = sc + q; }
         part[l] = s; part[L + l] = sc;
     }
     __syncthreads();
@@ -696,7 +904,7 @@ __device__ __forceinline__ void ns_reward(const NsArgs &a, float *part) {       
         float s = 0.f, sc = 0.f;
         for (int l = 0; l < L; l++) { s = s + part[l]; sc = sc + part[L + l]; }
         a.reward[0] = s; a.reward[1] = sc;
-        const NsCounters *cnt = ns_ptr<NsCounters>(a, a.lo.counters);
+        auto cnt = NS_MS(a, NsCounters, counters);
         a.counts[0] = cnt->n_spawned; a.counts[1] = cnt->n_deposits; a.counts[2] = cnt->n_events; a.counts[3] = cnt->draws_used;
     }
 }
@@ -709,67 +917,93 @@ __global__ void __launch_bounds__(kNsBlock) ns_reward_kernel(NsArgs a) {
 // reverse, part 1 (one workgroup): loss taps of the state after step t, the step's events undone newest first, speed cotangents
 // folded into (r, y), IDM adjoint, head-gap Jacobians, admission undone
 // =====================================================================================================================
+// LDS scratch of ns_micro_bwd in bytes: [Lm][2] head-gap cotangents + the compact lists of one pass of lanes, or the loss taps' terms
+__host__ __device__ inline int ns_list_room(int Lm) { const int r = (Lm + 63) & ~63; return r < 64 ? 64 : (r > kNsBlock ? kNsBlock : r); }
+__host__ __device__ inline size_t ns_micro_bwd_scratch(int L, int C, int Lm, size_t plane) {
+    const size_t lists = sizeof(double) * (2 * (size_t)(Lm > 0 ? Lm : 1) + 8 * (size_t)ns_list_room(Lm));
+    const size_t taps = sizeof(float) * ((size_t)C + plane + (size_t)L) + 16;
+    return lists > taps ? lists : taps;
+}
 __device__ __forceinline__ void ns_shift_out(double *gP, double *gV, double *gA, size_t base, int n) {       // slot 0 leaves
     for (int i = 0; i + 1 < n; ++i) { gP[base + i] = gP[base + i + 1]; gV[base + i] = gV[base + i + 1]; gA[base + i] = gA[base + i + 1]; }
 }
 
-__device__ __forceinline__ void ns_micro_bwd(const NsArgs &a, int t, const float *__restrict__ action, const float *__restrict__ g_reward,
-                                             double *lds_d) {      // lds_d: [2 Lm + 8 blockDim] doubles of LDS (head-gap cotangents | compact lists)
+template <class A> __device__ __forceinline__ void ns_micro_bwd(const A &a, int t, const float *__restrict__ action, const float *__restrict__ g_reward,
+                                             double *lds_d, int n_max) {     // n_max: the episode's fullest micro lane (NsCounters)      // lds_d: [2 Lm + 8 blockDim] doubles of LDS (head-gap cotangents | compact lists)
     const int tid = threadIdx.x, B = blockDim.x;
     const int L = a.L, C = a.C, Lm = a.Lm, cap = a.cap;
     const float um = a.um, vlen = a.vlen, dtf = a.dtf, s0f = a.s0f;
-    __shared__ int scan_i[16];
-    const float *nxt = ns_state(a, t + 1);
-    const float *Rn = nxt, *Yn = nxt + C, *Un = nxt + 2 * C;
-    float *G = ns_G(a, t + 1);                         // cotangent of (r, y, u) of the state after step t
-    float *Gr = G, *Gy = G + C, *Gu = G + 2 * C;
-    const size_t row = (size_t)t * L;
+    __shared__ int scan_i[32];
+    const auto nxt = ns_state(a, t + 1);
+    const auto Rn = nxt, Yn = nxt + C, Un = nxt + 2 * C;
+    const auto G = ns_G(a, t + 1);                     // cotangent of (r, y, u) of the state after step t
+    const auto Gr = G, Gy = G + C, Gu = G + 2 * C;
     const size_t plane = (size_t)Lm * cap;
     const float grew = g_reward ? g_reward[0] : 1.f;
     const bool taps = a.loss_steps <= 0 || t < a.loss_steps;
-    double *gPn = ns_ptr<double>(a, a.lo.gP) + (size_t)((t + 1) & 1) * plane, *gPp = ns_ptr<double>(a, a.lo.gP) + (size_t)(t & 1) * plane;
-    double *gVn = ns_ptr<double>(a, a.lo.gV) + (size_t)((t + 1) & 1) * plane, *gVp = ns_ptr<double>(a, a.lo.gV) + (size_t)(t & 1) * plane;
-    double *gA = ns_ptr<double>(a, a.lo.gA);
-    double *g_cap = ns_ptr<double>(a, a.lo.g_cap);
-    int *n_bwd = ns_ptr<int>(a, a.lo.n_bwd);
-    const float4 *caprec = ns_ptr<float4>(a, a.lo.caprec) + (size_t)t * a.ncap;
-    const int *capflag = ns_ptr<int>(a, a.lo.capflag) + (size_t)t * a.ncap;
+    const NsSlots sr = ns_slot_range(Lm, cap, n_max);
+    auto gPn = NS_MS(a, double, gP) + (size_t)((t + 1) & 1) * plane, gPp = NS_MS(a, double, gP) + (size_t)(t & 1) * plane;
+    auto gVn = NS_MS(a, double, gV) + (size_t)((t + 1) & 1) * plane, gVp = NS_MS(a, double, gV) + (size_t)(t & 1) * plane;
+    auto gA = NS_MS(a, double, gA);
+    auto g_cap = NS_MS(a, double, g_cap);
+    auto n_bwd = NS_MS(a, int, n_bwd);
+    auto caprec = ns_ptr<float4>(a, a.lo.caprec) + (size_t)t * a.ncap;
+    auto capflag = ns_ptr<int>(a, a.lo.capflag) + (size_t)t * a.ncap;
 
-    // ---- (a) loss taps: reward = - sum_l q_l^2 dt ----
+    NS_SUB0()
+    // ---- (a) loss taps: reward = - sum_l q_l^2 dt.  A thread per SAMPLE (cell, vehicle) evaluates its term, a thread per lane adds its
+    // lane's terms in order (the queue length) and leaves the lane's seed, a thread per sample applies it.  Scratch: termC [C] | termV
+    // [plane] | laneG [L] floats (the head gaps' lists come later in the step) ----
     if (taps) {
-        const float *kc_cell = ns_ptr<float>(a, a.lo.kc_cell) + (size_t)t * C;
+        float *termC = reinterpret_cast<float *>(lds_d), *termV = termC + C, *laneG = termV + plane;
+        auto kc_cell = ns_ptr<float>(a, a.lo.kc_cell) + (size_t)t * C;
+        auto nv_post = ns_ptr<int>(a, a.lo.nv_post) + (size_t)t * Lm;
+        auto vx = ns_ptr<float>(a, a.lo.vx) + (size_t)t * plane;
+        auto kv = ns_ptr<float>(a, a.lo.kc_veh) + (size_t)t * plane;
+        for (int c = tid; c < C; c += B) {
+            const float w = (float)a.lane_dx[a.cell_lane[c]];
+            termC[c] = soft_switch(s0f - Un[c], kc_cell[c]) * (Rn[c] * w / vlen);
+        }
+        for (int j = tid; j < sr.total; j += B) {
+            int ms, i; size_t idx;
+            ns_slot_of(sr, j, ms, i, idx);
+            if (i < nv_post[ms]) termV[idx] = soft_switch(vx[idx], kv[idx]);
+        }
+        __syncthreads();
         for (int l = tid; l < L; l += B) {
+            float qlen = 0.f;
             if (a.lane_macro[l]) {
                 const int n = a.lane_ncell[l], off = a.lane_off[l];
-                const float w = (float)a.lane_dx[l];
-                float qlen = 0.f;
-                for (int i = 0; i < n; i++) qlen += soft_switch(s0f - Un[off + i], kc_cell[off + i]) * (Rn[off + i] * w / vlen);
-                const float g_q = (-1.0f * dtf * 2.f * qlen) * grew;
-                for (int i = 0; i < n; i++) {
-                    float s, ds;
-                    soft_switch_both(s0f - Un[off + i], kc_cell[off + i], s, ds);
-                    Gr[off + i] += g_q * s * (w / vlen);
-                    Gu[off + i] += g_q * (Rn[off + i] * w / vlen) * (-ds);
-                }
+                for (int i = 0; i < n; i++) qlen += termC[off + i];
             } else {
-                const int ms = a.lane_mslot[l];
-                const int n = ns_ptr<int>(a, a.lo.nv_post)[(size_t)t * Lm + ms];
-                const float *vx = ns_ptr<float>(a, a.lo.vx) + (size_t)t * plane + (size_t)ms * cap;
-                const float *kv = ns_ptr<float>(a, a.lo.kc_veh) + (size_t)t * plane + (size_t)ms * cap;
-                float qlen = 0.f;
-                for (int i = 0; i < n; i++) qlen = qlen + soft_switch(vx[i], kv[i]);
-                const double seed = (double)((-1.0f * dtf * 2.f * qlen) * grew);
-                for (int i = 0; i < n; i++) gVn[(size_t)ms * cap + i] += seed * (double)soft_switch_grad(vx[i], kv[i]) * -1.0;
+                const int ms = a.lane_mslot[l], n = nv_post[ms];
+                for (int i = 0; i < n; i++) qlen = qlen + termV[(size_t)ms * cap + i];
             }
+            laneG[l] = (-1.0f * dtf * 2.f * qlen) * grew;
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += B) {
+            const int l = a.cell_lane[c];
+            const float w = (float)a.lane_dx[l], g_q = laneG[l];
+            float s_, ds;
+            soft_switch_both(s0f - Un[c], kc_cell[c], s_, ds);
+            Gr[c] += g_q * s_ * (w / vlen);
+            Gu[c] += g_q * (Rn[c] * w / vlen) * (-ds);
+        }
+        for (int j = tid; j < sr.total; j += B) {
+            int ms, i; size_t idx;
+            ns_slot_of(sr, j, ms, i, idx);
+            if (i < nv_post[ms]) gVn[idx] += (double)laneG[a.micro_lanes[ms]] * (double)soft_switch_grad(vx[idx], kv[idx]) * -1.0;
         }
     }
     __syncthreads();
 
     if (Lm > 0) {
+        NS_SUB(8)
         // ---- (b) the step's hand-off events, newest first (one thread: they are few) ----
         if (tid == 0) {
-            const int *ev_off = ns_ptr<int>(a, a.lo.ev_off);
-            const NsEvent *ev = ns_ptr<NsEvent>(a, a.lo.ev);
+            auto ev_off = ns_ptr<int>(a, a.lo.ev_off);
+            auto ev = ns_ptr<NsEvent>(a, a.lo.ev);
             for (int k = ev_off[t + 1] - 1; k >= ev_off[t]; --k) {
                 const NsEvent e = ev[k];
                 if (e.kind == NS_EV_SPAWN) {
@@ -824,6 +1058,7 @@ __device__ __forceinline__ void ns_micro_bwd(const NsArgs &a, int t, const float
             }
         }
         __syncthreads();
+        NS_SUB(9)
         // ---- the capacitors' charges: level += (r u) dt (the level's cotangent passes on unchanged) ----
         for (int k = tid; k < a.ncap; k += B) {
             const int fl = capflag[k];
@@ -841,6 +1076,7 @@ __device__ __forceinline__ void ns_micro_bwd(const NsArgs &a, int t, const float
         }
         __syncthreads();
     }
+    NS_SUB(10)
     // ---- (c) cells whose speed is u(r, y): fold the speed cotangent into (r, y) (a deposited cell's went to its vehicle above) ----
     for (int c = tid; c < C; c += B) {
         const float gu = Gu[c];
@@ -849,12 +1085,14 @@ __device__ __forceinline__ void ns_micro_bwd(const NsArgs &a, int t, const float
     if (Lm == 0) return;
     __syncthreads();
 
+    NS_SUB(11)
     // ---- (d) IDM steps: g[i] = dEgo[i]^T g'[i] + dLeading[i-1]^T g'[i-1]; the head's virtual leader returns to the head and to the gap ----
     double *ghd = lds_d;                               // [Lm][2]
-    const float4 *tape = ns_ptr<float4>(a, a.lo.idm_tape) + (size_t)t * plane;
-    const int *nv_idm = ns_ptr<int>(a, a.lo.nv_idm) + (size_t)t * Lm;
-    for (size_t idx = tid; idx < plane; idx += B) {
-        const int m = (int)(idx / cap), i = (int)(idx - (size_t)m * cap);
+    auto tape = ns_ptr<float4>(a, a.lo.idm_tape) + (size_t)t * plane;
+    auto nv_idm = ns_ptr<int>(a, a.lo.nv_idm) + (size_t)t * Lm;
+    for (int j = tid; j < sr.total; j += B) {
+        int m, i; size_t idx;
+        ns_slot_of(sr, j, m, i, idx);
         const int n = nv_idm[m];
         double gp = 0., gv = 0.;
         if (i < n) {
@@ -875,16 +1113,18 @@ __device__ __forceinline__ void ns_micro_bwd(const NsArgs &a, int t, const float
         if (i == 0 && n == 0) { ghd[2 * m] = 0.; ghd[2 * m + 1] = 0.; }
     }
     __syncthreads();
-    if (tid == 0) for (int m = 0; m < Lm; m++) n_bwd[m] = nv_idm[m];      // (equal by construction; keeps a fault from spreading)
+    for (int m = tid; m < Lm; m += B) n_bwd[m] = nv_idm[m];      // (equal by construction; keeps a fault from spreading)
 
+    NS_SUB(12)
     // ---- (e) head gaps: Jacobian^T of (head_dp, head_dv) to the head vehicle, to its leader (another lane's tail) and to the signals ----
-    const NsHeadGap *hgrow = ns_ptr<NsHeadGap>(a, a.lo.hg) + (size_t)t * Lm;
-    double *g_act = ns_ptr<double>(a, a.lo.g_act);
-    int *li_key = reinterpret_cast<int *>(lds_d + 2 * (size_t)Lm);          // compact lists: leader items [<= B], signal items [<= 3 B]
-    double *li_p = lds_d + 2 * (size_t)Lm + (size_t)B * 2;                  // (keys take 4 B ints = 2 B doubles of room)
-    double *li_v = li_p + B;
-    double *si_v = li_v + B;
-    int *si_key = li_key + B;
+    auto hgrow = ns_ptr<NsHeadGap>(a, a.lo.hg) + (size_t)t * Lm;
+    auto g_act = NS_MS(a, double, g_act);
+    const int nB = ns_list_room(Lm);                                        // lanes per pass (<= blockDim.x)
+    int *li_key = reinterpret_cast<int *>(lds_d + 2 * (size_t)Lm);          // compact lists: leader items [<= nB], signal items [<= 3 nB]
+    double *li_p = lds_d + 2 * (size_t)Lm + (size_t)nB * 2;                 // (keys take 4 nB ints = 2 nB doubles of room)
+    double *li_v = li_p + nB;
+    double *si_v = li_v + nB;
+    int *si_key = li_key + nB;
     for (int base = 0; base < Lm; base += B) {
         const int m = base + tid;
         NsHeadGap h; h.valid = 0; h.leader = -1; h.sig[0] = h.sig[1] = h.sig[2] = -1;
@@ -904,8 +1144,9 @@ __device__ __forceinline__ void ns_micro_bwd(const NsArgs &a, int t, const float
         int n_sig = 0;
         if (h.valid) for (int w = 0; w < 3; w++) n_sig += h.sig[w] >= 0;
         int tot_l, tot_s;
-        const int pos_l = ns_block_scan<int>(has_l, scan_i, tot_l) - has_l;
-        int pos_s = ns_block_scan<int>(n_sig, scan_i, tot_s) - n_sig;
+        int pos_l, pos_s;
+        ns_block_scan2<int, int>(has_l, n_sig, scan_i, scan_i + 16, pos_l, pos_s, tot_l, tot_s);
+        pos_l -= has_l; pos_s -= n_sig;
         if (has_l) {
             li_key[pos_l] = h.leader;
             li_p[pos_l] = (double)h.jp[2] * ghp + (double)h.jv[2] * ghv;
@@ -932,32 +1173,36 @@ __device__ __forceinline__ void ns_micro_bwd(const NsArgs &a, int t, const float
         __syncthreads();
     }
 
+    NS_SUB(13)
     // ---- (f) admission undone: the admitted vehicle (position 0, speed 0: constants) leaves through the tail ----
-    const int *adm = ns_ptr<int>(a, a.lo.adm) + (size_t)t * Lm;
+    auto adm = ns_ptr<int>(a, a.lo.adm) + (size_t)t * Lm;
     for (int m = tid; m < Lm; m += B) {
         if (adm[m]) { ns_shift_out(gPp, gVp, gA, (size_t)m * cap, n_bwd[m]); n_bwd[m] -= 1; }
     }
+    NS_SUB(14)
 }
 __global__ void __launch_bounds__(kNsBlock) ns_micro_bwd_kernel(NsArgs a, int t, const float *__restrict__ action, const float *__restrict__ g_reward) {
     extern __shared__ double lds_dyn[];
-    ns_micro_bwd(a, t, action, g_reward, lds_dyn);
+    ns_micro_bwd(a, t, action, g_reward, lds_dyn, ns_ptr<NsCounters>(a, a.lo.counters)->n_max);
 }
 
 // =====================================================================================================================
 // reverse, part 2: the lanes' ghost cotangents (dhts_macro_step_bwd's g_ghost) to the neighbours' edge cells, the stored ghosts and
 // the action.  slot [L][2][4] = (cotangent for the source cell's r, for its u, the action partial, the action index as a float)
 // =====================================================================================================================
-__device__ __forceinline__ void ns_ghost_bwd_item(const NsArgs &a, int t, const float *__restrict__ action, int j) {
+template <class A> __device__ __forceinline__ void ns_ghost_bwd_item(const A &a, int t, const float *__restrict__ action, int item) {
     const int L = a.L, C = a.C;
-    if (j >= 2 * L) return;
-    const int lane = j >> 1, side = j & 1;
-    float *sl = ns_slots(a) + (size_t)j * 4;
+    const int Lp = (L + 63) & ~63;
+    const int side = item >= Lp ? 1 : 0, lane = item - side * Lp;
+    if (lane >= L) return;
+    const int j = 2 * lane + side;
+    const auto sl = ns_slots(a) + (size_t)j * 4;
     float add_r = 0.f, add_u = 0.f, a_val = 0.f; int a_key = -1;
     if (a.lane_macro[lane]) {
         const float um = a.um;
-        const float *cur = ns_state(a, t);
-        const NsRow rw = ns_row(a, t);
-        const double *gg = ns_gghost(a) + ((size_t)a.lane_gpos[lane] * 2 + side) * 2;
+        const auto cur = ns_state(a, t);
+        const auto rw = ns_row(a, t);
+        const auto gg = ns_gghost(a) + ((size_t)a.lane_gpos[lane] * 2 + side) * 2;
         const float gg_r = (float)gg[0], gg_y = (float)gg[1];
         if (side == 0) {
             const int ls = rw.left_src[lane], lg = rw.left_gate[lane];
@@ -975,8 +1220,8 @@ __device__ __forceinline__ void ns_ghost_bwd_item(const NsArgs &a, int t, const 
             }
         } else {
             const int rs = rw.right_src[lane];
-            const float *own_in = ns_ptr<float>(a, a.lo.own_hist) + (size_t)t * 2 * L;
-            float *g_own = ns_ptr<float>(a, a.lo.g_own);
+            auto own_in = ns_ptr<float>(a, a.lo.own_hist) + (size_t)t * 2 * L;
+            auto g_own = NS_MS(a, float, g_own);
             const int first = rs < 0 ? 0 : a.lane_off[rs];
             const float grn_r = rs < 0 ? own_in[2 * lane] : cur[first];
             const float grn_u = rs < 0 ? own_in[2 * lane + 1] : cur[2 * C + first];
@@ -1002,11 +1247,11 @@ __global__ void ns_ghosts_bwd_kernel(NsArgs a, int t, const float *__restrict__ 
 
 // thread = lane m: its edge cells take what the ghosts that looked at them left, in a fixed order (downstream lanes ascending for
 // the last cell, upstream lanes ascending for the first); threads q < sq sum their intersection's action partials in slot order
-__device__ __forceinline__ void ns_ghost_gather_item(const NsArgs &a, int t, int m) {
+template <class A> __device__ __forceinline__ void ns_ghost_gather_item(const A &a, int t, int m) {
     const int L = a.L, C = a.C;
-    const float *slot = ns_slots(a);
-    float *G = ns_G(a, t);
-    const NsRow rw = ns_row(a, t);
+    const auto slot = ns_slots(a);
+    const auto G = ns_G(a, t);
+    const auto rw = ns_row(a, t);
     if (m < L && a.lane_macro[m]) {
         const int first = a.lane_off[m], last = first + a.lane_ncell[m] - 1;
         float vr = 0.f, vu = 0.f;
@@ -1022,17 +1267,34 @@ __device__ __forceinline__ void ns_ghost_gather_item(const NsArgs &a, int t, int
         if (first == last) { G[first] += vr + wr; G[2 * C + first] += vu + wu; }
         else { G[last] += vr; G[2 * C + last] += vu; G[first] += wr; G[2 * C + first] += wu; }
     }
-    if (m < a.sq) {
-        double v = 0.; int key = -1;
-        for (int k = a.inter_ptr[m]; k < a.inter_ptr[m + 1]; ++k) {
-            const float *sl = slot + (size_t)a.inter_idx[k] * 4;
-            if (sl[3] >= 0.f) { v += (double)sl[2]; key = (int)sl[3]; }
-        }
-        if (key >= 0) ns_ptr<double>(a, a.lo.g_act)[key] += v;
-    }
 }
-__global__ void ns_ghosts_gather_kernel(NsArgs a, int t) {
-    ns_ghost_gather_item(a, t, blockIdx.x * blockDim.x + threadIdx.x);
+// one WAVEFRONT per intersection q: its (lane, side) slots' action partials summed in a fixed order (inclusive wave scan, 64 slots at a time)
+template <class A> __device__ __forceinline__ void ns_action_gather_wave(const A &a, int q) {
+    if (q >= a.sq) return;
+    const auto slot = ns_slots(a);
+    const int lane = threadIdx.x & 63;
+    const int lo = a.inter_ptr[q], hi = a.inter_ptr[q + 1];
+    double v = 0.; int key = -1;
+    for (int base = lo; base < hi; base += 64) {
+        const int k = base + lane;
+        double x = 0.; int kk = -1;
+        if (k < hi) {
+            const auto sl = slot + (size_t)a.inter_idx[k] * 4;
+            const float key_f = sl[3];
+            if (key_f >= 0.f) { x = (double)sl[2]; kk = (int)key_f; }
+        }
+        v += wave_last(wave_scan_add(x));
+        const int km = wave_last(wave_scan_add(kk >= 0 ? 1 : 0));
+        if (km) {           // every active slot of an intersection names the same action entry
+            const unsigned long long mk = __builtin_amdgcn_ballot_w64(kk >= 0);
+            key = __builtin_amdgcn_readlane(kk, (int)__builtin_ctzll(mk));
+        }
+    }
+    if (lane == 0 && key >= 0) NS_MS(a, double, g_act)[key] += v;
+}
+__global__ void ns_ghosts_gather_kernel(NsArgs a, int t, int lane_blocks) {        // blocks of 256: lane items, then 4 intersections each
+    if ((int)blockIdx.x < lane_blocks) ns_ghost_gather_item(a, t, blockIdx.x * blockDim.x + threadIdx.x);
+    else ns_action_gather_wave(a, ((int)blockIdx.x - lane_blocks) * 4 + (threadIdx.x >> 6));
 }
 
 // =====================================================================================================================
@@ -1044,8 +1306,7 @@ __global__ void ns_ghosts_gather_kernel(NsArgs a, int t) {
 // independent workgroups (BASELINE config 5's pattern for networks beyond the fused kernels' one-item-per-thread limits).
 // A step costs its phases' latencies (~10 us forward + reverse for 360 lanes / 2 124 cells) instead of ~100 us of launches.
 // =====================================================================================================================
-__device__ __forceinline__ NsArgs ns_replica_args(const NsArgs &a0, int rep) {
-    NsArgs a = a0;
+__device__ __forceinline__ void ns_replica_shift(NsCommon &a, int rep) {       // the arrays replica `rep` owns
     a.hist += (size_t)rep * (a.T + 1) * 4 * (a.C > 0 ? a.C : 1);
     a.queue += (size_t)rep * a.T * a.L;
     if (a.reward) a.reward += (size_t)rep * 2;
@@ -1054,22 +1315,21 @@ __device__ __forceinline__ NsArgs ns_replica_args(const NsArgs &a0, int rep) {
     const size_t ts = (size_t)rep * (size_t)a.table_stride;
     a.left_src += ts; a.left_gate += ts; a.right_src += ts; a.conv_next += ts; a.schedule += ts;
     if (a.draws) a.draws += (size_t)rep * (size_t)a.draws_stride;
-    return a;
 }
 
 // One cell of step t: BOTH its interfaces (ARZ.riemann_solve + the two Jacobian products each, redone by the neighbouring cell's
 // thread: a solve costs less than handing its result over), Godunov update, float32 glue, the cell's three blocks (MacroLane.forward,
 // _macro_lane.py:83-146; dMacroLane._backward, dmacro_lane.py:96-132) -- the operations of the straight-lane operator's kernel
-__device__ __forceinline__ void ns_cell_item(const NsArgs &a, int t, int c, int &fault_step, int &fault_lane, int &fault_index) {
+template <class A> __device__ __forceinline__ void ns_cell_item(const A &a, int t, int c, int &fault_step, int &fault_lane, int &fault_index) {
     const int C = a.C;
     const int l = a.cell_lane[c];
     const int off = a.lane_off[l], n = a.lane_ncell[l];
     const int k = c - off;
     const double dx = a.lane_dx[l];
     const double cc = a.dt_d / dx;
-    const float *cur = ns_state(a, t);
-    float *nxt = ns_state(a, t + 1);
-    const float *gh = ns_ghosts(a) + (size_t)a.lane_gpos[l] * 8;
+    const auto cur = ns_state(a, t);
+    const auto nxt = ns_state(a, t + 1);
+    const auto gh = ns_ghosts(a) + (size_t)a.lane_gpos[l] * 8;
     const double r0 = cur[c], y0 = cur[C + c], u0 = cur[2 * C + c], q0 = cur[3 * C + c];
     double rL, yL, uL, qL, rR, yR, uR, qR;
     if (k == 0) { rL = gh[0]; yL = gh[1]; uL = gh[2]; qL = gh[3]; }
@@ -1094,20 +1354,20 @@ __device__ __forceinline__ void ns_cell_item(const NsArgs &a, int t, int c, int 
         d2.x = ncf * fr.B[0]; d2.y = ncf * fr.B[1]; d2.z = ncf * fr.B[2]; d2.w = ncf * fr.B[3];
         d1.x = 1.f - cf * (fr.A[0] - fl.B[0]); d1.y = 0.f - cf * (fr.A[1] - fl.B[1]);
         d1.z = 0.f - cf * (fr.A[2] - fl.B[2]); d1.w = 1.f - cf * (fr.A[3] - fl.B[3]);
-        float4 *tp = ns_ptr<float4>(a, a.lo.ptape) + ((size_t)t * C + c) * 3;
+        auto tp = ns_ptr<float4>(a, a.lo.ptape) + ((size_t)t * C + c) * 3;
         tp[0] = d0; tp[1] = d1; tp[2] = d2;
     }
 }
 // reverse of the cells of step t: g[c] <- dqs[c][1]^T g[c] + dqs[c-1][2]^T g[c-1] + dqs[c+1][0]^T g[c+1] inside a lane
 // (dMacroForwardLayer.backward, dmacro_lane.py:277-309); the lane's edge cells leave the ghosts' cotangents
-__device__ __forceinline__ void ns_cell_bwd_item(const NsArgs &a, int t, int c) {
+template <class A> __device__ __forceinline__ void ns_cell_bwd_item(const A &a, int t, int c) {
     const int C = a.C;
     const int l = a.cell_lane[c];
     const int off = a.lane_off[l], n = a.lane_ncell[l];
     const int k = c - off;
-    const float *Gn = ns_G(a, t + 1);
-    float *Gp = ns_G(a, t);
-    const float4 *tp = ns_ptr<float4>(a, a.lo.ptape) + ((size_t)t * C + c) * 3;
+    const auto Gn = ns_G(a, t + 1);
+    const auto Gp = ns_G(a, t);
+    auto tp = ns_ptr<float4>(a, a.lo.ptape) + ((size_t)t * C + c) * 3;
     const float gr = Gn[c], gy = Gn[C + c];
     const float4 d0 = tp[0], d1 = tp[1], d2 = tp[2];
     float4 e2 = make_float4(0.f, 0.f, 0.f, 0.f), e0 = e2;
@@ -1119,110 +1379,144 @@ __device__ __forceinline__ void ns_cell_bwd_item(const NsArgs &a, int t, int c) 
     if (k < n - 1) { const float hr = Gn[c + 1], hy = Gn[C + c + 1]; c0r = dot2(e0.x, hr, e0.z, hy); c0y = dot2(e0.y, hr, e0.w, hy); }
     const float pr = (vr + c2r) + c0r, py = (vy + c2y) + c0y;
     Gp[c] = pr; Gp[C + c] = py; Gp[2 * C + c] = 0.f;
-    double *gg = ns_gghost(a) + (size_t)a.lane_gpos[l] * 4;
+    const auto gg = ns_gghost(a) + (size_t)a.lane_gpos[l] * 4;
     if (k == 0) { gg[0] = (double)dot2(d0.x, gr, d0.z, gy); gg[1] = (double)dot2(d0.y, gr, d0.w, gy); }
     if (k == n - 1) { gg[2] = (double)dot2(d2.x, gr, d2.z, gy); gg[3] = (double)dot2(d2.y, gr, d2.w, gy); }
     if (!(isfinite(pr) && isfinite(py))) net_fault(a.err, DHTS_FAULT_NAN, t, l, k);
 }
 
-// The static tables of a network (per lane, per interface, per cell, adjacency) staged in LDS for a persistent kernel: every item of
-// every phase starts with a chain of dependent look-ups (item -> lane -> offsets -> state), each link a global-memory latency
-// otherwise.  The functions above read them through NsArgs' pointers, which are simply redirected.
+// The static tables of a network (per lane, per cell, adjacency) staged in LDS for a persistent kernel: every item of every phase
+// starts with a chain of dependent look-ups (item -> lane -> offsets -> state), each link a global-memory latency otherwise.
 __host__ __device__ inline size_t ns_al16(size_t x) { return (x + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t ns_stage_bytes(int L, int C, int NI, int Lm, int ncap, int n_edges, int sq, int n_islots, bool sources) {
-    return 8 * ns_al16(4 * (size_t)L) + (sources ? ns_al16(4 * (size_t)L) : 0) + 2 * ns_al16(8 * (size_t)L) + ns_al16(4 * (size_t)NI) +
-           ns_al16(4 * (size_t)(C > 0 ? C : 1)) + ns_al16(4 * (size_t)(Lm > 0 ? Lm : 1)) + ns_al16(4 * (size_t)(ncap > 0 ? ncap : 1)) +
-           2 * ns_al16(4 * (size_t)(L + 1)) + 2 * ns_al16(4 * (size_t)(n_edges > 0 ? n_edges : 1)) + ns_al16(4 * (size_t)(sq + 1)) +
-           ns_al16(4 * (size_t)(n_islots > 0 ? n_islots : 1));
+__host__ __device__ inline size_t ns_stage_bytes(const NsCommon &a) {
+    size_t n = 0;
+#define NS_X(name, ty, count) n += ns_al16(sizeof(ty) * (size_t)((count) > 0 ? (count) : 1));
+    NS_TABLES(NS_X)
+#undef NS_X
+    return n;
 }
-template <typename T>
-__device__ __forceinline__ const T *ns_stage(const T *src, size_t n, char *&p) {
-    T *dst = reinterpret_cast<T *>(p);
-    for (size_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
-    p += ns_al16(n * sizeof(T));
-    return dst;
+__host__ __device__ inline size_t ns_micro_state_bytes(const NsCommon &a, bool bwd) {
+    const size_t plane = (size_t)a.Lm * a.cap;
+    size_t n = 0;
+#define NS_X(name, ty, count) n += ns_al16(sizeof(ty) * (size_t)((count) > 0 ? (count) : 1));
+    if (bwd) { NS_MICRO_BWD(NS_X) } else { NS_MICRO_FWD(NS_X) }
+#undef NS_X
+    return n;
 }
-__device__ __forceinline__ void ns_stage_tables(NsArgs &a, char *p) {
-    if (!a.stage) return;
-    const size_t L = a.L;
-    a.lane_ncell = ns_stage(a.lane_ncell, L, p); a.lane_off = ns_stage(a.lane_off, L, p); a.sig_kind = ns_stage(a.sig_kind, L, p);
-    a.inter = ns_stage(a.inter, L, p); a.lane_macro = ns_stage(a.lane_macro, L, p); a.lane_gpos = ns_stage(a.lane_gpos, L, p);
-    a.lane_mslot = ns_stage(a.lane_mslot, L, p); a.lane_cslot = ns_stage(a.lane_cslot, L, p);
-    if (a.lane_source) a.lane_source = ns_stage(a.lane_source, L, p);
-    a.lane_dx = ns_stage(a.lane_dx, L, p); a.lane_len = ns_stage(a.lane_len, L, p);
-    a.if_lane = ns_stage(a.if_lane, (size_t)a.NI, p); a.cell_lane = ns_stage(a.cell_lane, (size_t)(a.C > 0 ? a.C : 1), p);
-    a.micro_lanes = ns_stage(a.micro_lanes, (size_t)(a.Lm > 0 ? a.Lm : 1), p); a.cap_lanes = ns_stage(a.cap_lanes, (size_t)(a.ncap > 0 ? a.ncap : 1), p);
-    a.nxt_ptr = ns_stage(a.nxt_ptr, L + 1, p); a.prv_ptr = ns_stage(a.prv_ptr, L + 1, p);
-    a.nxt_idx = ns_stage(a.nxt_idx, (size_t)(a.n_edges > 0 ? a.n_edges : 1), p); a.prv_idx = ns_stage(a.prv_idx, (size_t)(a.n_edges > 0 ? a.n_edges : 1), p);
-    a.inter_ptr = ns_stage(a.inter_ptr, (size_t)a.sq + 1, p); a.inter_idx = ns_stage(a.inter_idx, (size_t)(a.n_islots > 0 ? a.n_islots : 1), p);
-}
-
-// what a persistent kernel carves out of its dynamic LDS behind the phases' scratch (host and device agree through this plan)
-struct NsPlan { int scratch, tables, st, gl, rows, misc; };       // byte sizes (0 = not staged)
-__device__ __forceinline__ void ns_carve(NsArgs &a, char *lds, const NsPlan &pl) {
-    char *p = lds + pl.scratch;
-    if (pl.tables) { a.stage = 1; char *q = p; ns_stage_tables(a, q); p += pl.tables; } else a.stage = 0;
-    a.st = nullptr; a.gl = nullptr; a.row_i = nullptr; a.row_d = nullptr; a.gh = nullptr; a.sl = nullptr; a.gg = nullptr;
-    if (pl.st) { a.st = reinterpret_cast<float *>(p); p += pl.st; }
-    if (pl.gl) { a.gl = reinterpret_cast<float *>(p); p += pl.gl; }
-    if (pl.rows) {
-        a.row_d = reinterpret_cast<double *>(p); a.row_i = reinterpret_cast<int32_t *>(p + ns_al16(16 * (size_t)a.L));
+// what a persistent kernel carves out of its dynamic LDS behind the phases' scratch (host and device agree through this plan):
+// byte sizes; tables + rows + misc are staged together (TB) or not at all, st + gl likewise (ST)
+struct NsPlan { int scratch, tables, rows, misc, st, gl, ms, routes; };
+template <int TA, bool ST, bool MS>
+__device__ __forceinline__ void ns_carve(NsArgsT<TA, ST, MS> &a, const NsArgs &a0, NS_LDS char *lds, const NsPlan &pl, bool bwd) {
+    NS_LDS char *p = lds + pl.scratch;
+    if constexpr (TA == 3) {
+        NS_LDS char *q = p;
+#define NS_X(name, ty, count) { const size_t n_ = (size_t)((count) > 0 ? (count) : 1); NS_LDS ty *d_ = (NS_LDS ty *)q; \
+            if ((count) > 0) for (size_t i_ = threadIdx.x; i_ < n_; i_ += blockDim.x) d_[i_] = a0.name[i_]; \
+            a.name = d_; q += ns_al16(sizeof(ty) * n_); }
+        NS_TABLES(NS_X)
+#undef NS_X
+        p += pl.tables;
+        a.row_d = (NS_LDS double *)p; a.row_i = (NS_LDS int32_t *)(p + ns_al16(16 * (size_t)a.L));
         p += pl.rows;
-    }
-    if (pl.misc) {
         const size_t lg = ns_al16(32 * (size_t)a.L);
-        a.gg = reinterpret_cast<double *>(p); a.gh = reinterpret_cast<float *>(p + lg); a.sl = reinterpret_cast<float *>(p + 2 * lg);
+        if (bwd) { a.gg = (NS_LDS double *)p; a.sl = (NS_LDS float *)(p + lg); a.gh = nullptr; }
+        else { a.gh = (NS_LDS float *)p; a.gg = nullptr; a.sl = nullptr; }
+        a.sg = (NS_LDS float *)(p + (bwd ? 2 : 1) * lg); a.sgi = (NS_LDS int32_t *)(a.sg + 8 * (size_t)a.sq);
+        p += pl.misc;
+    } else {
+#define NS_X(name, ty, count) a.name = (NS_GLOBAL const ty *)a0.name;
+        NS_TABLES(NS_X)
+#undef NS_X
+        a.gh = nullptr; a.sl = nullptr; a.gg = nullptr; a.row_i = nullptr; a.row_d = nullptr; a.sg = nullptr; a.sgi = nullptr;
     }
+    if constexpr (ST) {
+        a.st = (NS_LDS float *)p; p += pl.st;
+        a.gl = bwd ? (NS_LDS float *)p : nullptr;
+        p += pl.gl;
+    } else { a.st = nullptr; a.gl = nullptr; }
+    if constexpr (TA == 3) {
+        a.routes_l = nullptr; a.rlen_l = nullptr;
+        if (pl.routes) {
+            const size_t n = (size_t)a.n_routes * a.route_stride;
+            NS_LDS int32_t *r_ = (NS_LDS int32_t *)p, *len_ = (NS_LDS int32_t *)(p + ns_al16(4 * n));
+            const auto src = ns_glob(a0.routes);
+            for (size_t i = threadIdx.x; i < n; i += blockDim.x) r_[i] = src[i];
+            for (int r = threadIdx.x; r < a.n_routes; r += blockDim.x) {
+                int k = 0;
+                while (k < a.route_stride && src[(size_t)r * a.route_stride + k] >= 0) k++;
+                len_[r] = k;
+            }
+            a.routes_l = r_; a.rlen_l = len_;
+            p += pl.routes;
+        }
+    }
+    if constexpr (MS) {
+        const size_t plane = (size_t)a.Lm * a.cap;
+#define NS_X(name, ty, count) a.m_##name = (NS_LDS ty *)p; p += ns_al16(sizeof(ty) * (size_t)((count) > 0 ? (count) : 1));
+        if (bwd) { NS_MICRO_BWD(NS_X) } else { NS_MICRO_FWD(NS_X) }
+#undef NS_X
+    }
+}
+// the replica's argument block in LDS (`a_s`): everybody copies the tables, thread 0 writes the scalars and the pointers
+template <int TA, bool ST, bool MS>
+__device__ __forceinline__ void ns_persist_setup(NsArgsT<TA, ST, MS> &a_s, const NsArgs &a0, NS_LDS char *lds, const NsPlan &pl, bool bwd) {
+    NsArgsT<TA, ST, MS> tmp;
+    static_cast<NsCommon &>(tmp) = static_cast<const NsCommon &>(a0);
+    ns_replica_shift(tmp, blockIdx.x);
+    ns_carve(tmp, a0, lds, pl, bwd);
+    if (threadIdx.x == 0) a_s = tmp;
+    __syncthreads();
 }
 // the table rows of step r into their LDS copy (r & 1): every thread fetches its elements (registers `v`), stores them later
 struct NsRowRegs { int32_t i[4]; double d; };
-__device__ __forceinline__ void ns_rows_fetch(const NsArgs &a, const NsArgs &g, int r, int l, NsRowRegs &v) {      // g: the global pointers
+template <class A> __device__ __forceinline__ void ns_rows_fetch(const A &a, int r, int l, NsRowRegs &v) {
     const size_t o = (size_t)r * a.L + l;
-    v.i[0] = g.left_src[o]; v.i[1] = g.left_gate[o]; v.i[2] = g.right_src[o]; v.i[3] = g.conv_next[o]; v.d = g.schedule[o];
+    v.i[0] = ns_glob(a.left_src)[o]; v.i[1] = ns_glob(a.left_gate)[o]; v.i[2] = ns_glob(a.right_src)[o]; v.i[3] = ns_glob(a.conv_next)[o];
+    v.d = ns_glob(a.schedule)[o];
 }
-__device__ __forceinline__ void ns_rows_store(const NsArgs &a, int r, int l, const NsRowRegs &v) {
-    int32_t *b = a.row_i + (size_t)(r & 1) * 4 * a.L;
+template <class A> __device__ __forceinline__ void ns_rows_store(const A &a, int r, int l, const NsRowRegs &v) {
+    const auto b = a.row_i + (size_t)(r & 1) * 4 * a.L;
     b[l] = v.i[0]; b[a.L + l] = v.i[1]; b[2 * a.L + l] = v.i[2]; b[3 * a.L + l] = v.i[3];
     a.row_d[(size_t)(r & 1) * a.L + l] = v.d;
 }
 
+template <int TA, bool ST, bool MS>
 __global__ void __launch_bounds__(kNsBlock) ns_persist_fwd_kernel(NsArgs a0, const float *__restrict__ action_all, NsPlan pl) {
     extern __shared__ double lds_p[];
-    // the replica's arguments -- ~130 pointers and offsets, some redirected into LDS -- live in LDS themselves: as a local copy they
-    // cost 487 scalar-register spills and 79 vector ones (scratch traffic inside every phase)
-    __shared__ NsArgs ag_s, a_s;
-    if (threadIdx.x == 0) { ag_s = ns_replica_args(a0, blockIdx.x); a_s = ag_s; }
-    __syncthreads();
-    {
-        NsArgs tmp = a_s;
-        ns_carve(tmp, reinterpret_cast<char *>(lds_p), pl);       // (every thread copies its share of the tables)
-        __syncthreads();
-        if (threadIdx.x == 0) a_s = tmp;
-        __syncthreads();
-    }
-    const NsArgs &ag = ag_s;                                    // the global pointers
-    const NsArgs &a = a_s;
+    // the replica's arguments -- ~100 pointers and offsets, the staged ones as LDS pointers -- live in LDS themselves: as a local copy
+    // they cost 487 scalar-register spills and 79 vector ones (scratch traffic inside every phase)
+    __shared__ NsArgsT<TA, ST, MS> a_s;
+    ns_persist_setup(a_s, a0, (NS_LDS char *)reinterpret_cast<char *>(lds_p), pl, false);
+    const NsArgsT<TA, ST, MS> &a = a_s;
     const float *action = action_all + (size_t)blockIdx.x * a0.n_action;
     const int tid = threadIdx.x, B = blockDim.x;
     const int L = a0.L, C = a0.C, T = a0.T;
     // the episode's running state: empty road (MacroLane.__init__), stored ghosts (0, u_max), no vehicles, counters zero
     {
-        float *s0 = ns_state(a, 0);
+        const auto s0 = ns_state(a, 0);
         for (int i = tid; i < C; i += B) {
             s0[i] = 0.f; s0[C + i] = 0.f; s0[2 * C + i] = a.um; s0[3 * C + i] = a.um;
-            if (a.st) { a.hist[i] = 0.f; a.hist[C + i] = 0.f; a.hist[2 * C + i] = a.um; a.hist[3 * C + i] = a.um; }
+            if constexpr (ST) { const auto h0 = ns_glob(a.hist); h0[i] = 0.f; h0[C + i] = 0.f; h0[2 * C + i] = a.um; h0[3 * C + i] = a.um; }
         }
     }
-    for (int i = tid; i < L; i += B) { float *o = ns_ptr<float>(a, a.lo.own_hist); o[2 * i] = 0.f; o[2 * i + 1] = a.um; }
-    {
-        unsigned *z = ns_ptr<unsigned>(a, a.lo.P);
+    for (int i = tid; i < L; i += B) { const auto o = ns_ptr<float>(a, a.lo.own_hist); o[2 * i] = 0.f; o[2 * i + 1] = a.um; }
+    if constexpr (MS) {
+        NS_LDS unsigned *z = (NS_LDS unsigned *)a.m_P;
+        const size_t nz = (size_t)pl.ms / 4;
+        for (size_t i = tid; i < nz; i += B) z[i] = 0u;
+    } else {
+        auto z = ns_ptr<unsigned>(a, a.lo.P);
         const size_t nz = (a.lo.counters + sizeof(NsCounters) - a.lo.P) / 4;
         for (size_t i = tid; i < nz; i += B) z[i] = 0u;
     }
-    if (a.row_i) for (int l = tid; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, ag, 0, l, v); ns_rows_store(a, 0, l, v); }
+    if constexpr (TA == 3) for (int l = tid; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, 0, l, v); ns_rows_store(a, 0, l, v); }
+    for (int q = tid; q < a0.sq; q += B) ns_signal_fill(a, action, 0, q);
     __syncthreads();
     int fault_step = -1, fault_lane = 0, fault_index = 0;
 #ifdef DHTS_NS_STAMPS
+    if (threadIdx.x < 24) ns_sub_[threadIdx.x] = 0;
+    __syncthreads();
     long long st_[6] = {0, 0, 0, 0, 0, 0}, st_last_ = __builtin_amdgcn_s_memtime();
 #define NS_STAMP(i) { const long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_last_; st_last_ = n_; }
 #else
@@ -1231,9 +1525,10 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_fwd_kernel(NsArgs a0, con
     for (int t = 0; t < T; ++t) {
         // the next step's table rows: fetched now (one lane per thread; further lanes of wider networks at the end of the step)
         NsRowRegs nx;
-        const bool pre = a.row_i && t + 1 < T && tid < L;
-        if (pre) ns_rows_fetch(a, ag, t + 1, tid, nx);
-        for (int j = tid; j < 2 * L; j += B) ns_ghost_fwd_item(a, t, action, j);
+        const bool pre = TA == 3 && t + 1 < T && tid < L;
+        if (pre) ns_rows_fetch(a, t + 1, tid, nx);
+        if (t + 1 < T) for (int q = B - 1 - tid; q < a0.sq; q += B) ns_signal_fill(a, action, t + 1, q);      // (the last wavefront: idle in the ghost phase)
+        for (int j = tid; j < ns_ghost_items(L); j += B) ns_ghost_fwd_item(a, t, action, j);
         NS_STAMP(0)
         ns_micro_fwd(a, t, action, reinterpret_cast<float *>(lds_p));
         __syncthreads();
@@ -1243,100 +1538,121 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_fwd_kernel(NsArgs a0, con
         NS_STAMP(2)
         ns_convert(a, t, reinterpret_cast<int *>(lds_p));
         NS_STAMP(3)
-        if (a.st) {                     // the committed state to the history (what the reverse sweep and the callers read)
-            const float *sn = ns_state(a, t + 1);
-            float *hn = a.hist + (size_t)(t + 1) * 4 * C;
+        if constexpr (ST) {             // the committed state to the history (what the reverse sweep and the callers read)
+            const auto sn = ns_state(a, t + 1);
+            auto hn = ns_glob(a.hist) + (size_t)(t + 1) * 4 * C;
             for (int i = tid; i < 4 * C; i += B) hn[i] = sn[i];
         }
-        if (pre) ns_rows_store(a, t + 1, tid, nx);
-        if (a.row_i && t + 1 < T) for (int l = tid + B; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, ag, t + 1, l, v); ns_rows_store(a, t + 1, l, v); }
+        if constexpr (TA == 3) {
+            if (pre) ns_rows_store(a, t + 1, tid, nx);
+            if (t + 1 < T) for (int l = tid + B; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, t + 1, l, v); ns_rows_store(a, t + 1, l, v); }
+        }
         __syncthreads();
         NS_STAMP(4)
     }
 #ifdef DHTS_NS_STAMPS
     if (blockIdx.x == 0 && tid == 0)
-        printf("ns_persist_fwd cycles per step: ghosts %lld | micro boundary + IDM %lld | cells %lld | hand-offs + loss %lld | flush %lld\n",
-               st_[0] / T, st_[1] / T, st_[2] / T, st_[3] / T, st_[4] / T);
+        printf("ns_persist_fwd<%d,%d> cycles per step: ghosts %lld | micro boundary + IDM %lld | cells %lld | hand-offs + loss %lld | flush %lld\n",
+               TA, (int)ST + 2 * (int)MS, st_[0] / T, st_[1] / T, st_[2] / T, st_[3] / T, st_[4] / T);
+    if (blockIdx.x == 0 && tid == 0)
+        printf("   micro: admission %lld | head gaps %lld | IDM %lld;  hand-offs: capacitors %lld | event walk %lld | loss %lld\n",
+               ns_sub_[0] / T, ns_sub_[1] / T, ns_sub_[2] / T, ns_sub_[3] / T, ns_sub_[4] / T, ns_sub_[5] / T);
+    if (blockIdx.x == 0 && tid == 0)
+        printf("   head gaps: lane part %lld | scans %lld (rest in 'head gaps')\n", ns_sub_[16] / T, ns_sub_[17] / T);
 #endif
     if (fault_step >= 0) net_fault(a.err, DHTS_FAULT_CFL, fault_step, fault_lane, fault_index);
+    if constexpr (MS) {                  // what the reverse sweep starts from
+        auto lane_n = ns_ptr<int>(a, a.lo.lane_n);
+        for (int m = tid; m < a0.Lm; m += B) lane_n[m] = a.m_lane_n[m];
+        if (tid == 0) *ns_ptr<NsCounters>(a, a.lo.counters) = *a.m_counters;
+    }
     ns_reward(a, reinterpret_cast<float *>(lds_p));
 }
 
+template <int TA, bool ST, bool MS>
 __global__ void __launch_bounds__(kNsBlock) ns_persist_bwd_kernel(NsArgs a0, const float *__restrict__ action_all, const float *__restrict__ g_reward,
                                                                 float *__restrict__ g_action_all, NsPlan pl) {
     extern __shared__ double lds_p[];
-    __shared__ NsArgs ag_s, a_s;                                // (see ns_persist_fwd_kernel)
-    if (threadIdx.x == 0) { ag_s = ns_replica_args(a0, blockIdx.x); a_s = ag_s; }
-    __syncthreads();
-    {
-        NsArgs tmp = a_s;
-        ns_carve(tmp, reinterpret_cast<char *>(lds_p), pl);
-        __syncthreads();
-        if (threadIdx.x == 0) a_s = tmp;
-        __syncthreads();
-    }
-    const NsArgs &ag = ag_s;
-    const NsArgs &a = a_s;
+    __shared__ NsArgsT<TA, ST, MS> a_s;                             // (see ns_persist_fwd_kernel)
+    ns_persist_setup(a_s, a0, (NS_LDS char *)reinterpret_cast<char *>(lds_p), pl, true);
+    const NsArgsT<TA, ST, MS> &a = a_s;
     const float *action = action_all + (size_t)blockIdx.x * a0.n_action;
     const int tid = threadIdx.x, B = blockDim.x;
     const int L = a0.L, C = a0.C, T = a0.T, Lm = a0.Lm;
     {   // cotangents start at zero; the lanes hold what the forward left
-        unsigned *z = ns_ptr<unsigned>(a, a.lo.G);
+        auto z = ns_ptr<unsigned>(a, a.lo.G);
         const size_t nz = (a.lo.n_bwd - a.lo.G) / 4;
         for (size_t i = tid; i < nz; i += B) z[i] = 0u;
-        if (a.gl) for (int i = tid; i < 6 * C; i += B) a.gl[i] = 0.f;
-        int *n_bwd = ns_ptr<int>(a, a.lo.n_bwd);
-        const int *lane_n = ns_ptr<int>(a, a.lo.lane_n);
+        if constexpr (ST) for (int i = tid; i < 6 * C; i += B) a.gl[i] = 0.f;
+        if constexpr (MS) {
+            NS_LDS unsigned *zl = (NS_LDS unsigned *)a.m_gP;
+            for (size_t i = tid; i < (size_t)pl.ms / 4; i += B) zl[i] = 0u;
+            __syncthreads();
+        }
+        auto n_bwd = NS_MS(a, int, n_bwd);
+        auto lane_n = ns_ptr<int>(a, a.lo.lane_n);
         for (int m = tid; m < Lm; m += B) n_bwd[m] = lane_n[m];
     }
-    if (a.st) {                          // rows T and T - 1 of the history
+    if constexpr (ST) {                  // rows T and T - 1 of the history
         for (int r = T; r >= T - 1 && r >= 0; --r) {
-            float *sr = ns_state(a, r);
-            const float *hr = a.hist + (size_t)r * 4 * C;
+            const auto sr = ns_state(a, r);
+            auto hr = ns_glob(a.hist) + (size_t)r * 4 * C;
             for (int i = tid; i < 4 * C; i += B) sr[i] = hr[i];
         }
     }
-    if (a.row_i) for (int l = tid; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, ag, T - 1, l, v); ns_rows_store(a, T - 1, l, v); }
+    if constexpr (TA == 3) for (int l = tid; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, T - 1, l, v); ns_rows_store(a, T - 1, l, v); }
+    for (int q = tid; q < a0.sq; q += B) ns_signal_fill(a, action, T - 1, q);
     __syncthreads();
-    const int m_items = L > a.sq ? L : a.sq;
 #ifdef DHTS_NS_STAMPS
+    if (threadIdx.x < 24) ns_sub_[threadIdx.x] = 0;
+    __syncthreads();
     long long st_[6] = {0, 0, 0, 0, 0, 0}, st_last_ = __builtin_amdgcn_s_memtime();
 #endif
+    const int n_max = ns_ptr<NsCounters>(a, a.lo.counters)->n_max;
     for (int t = T - 1; t >= 0; --t) {
         NsRowRegs nx;
-        const bool pre = a.row_i && t >= 1 && tid < L;
-        if (pre) ns_rows_fetch(a, ag, t - 1, tid, nx);
-        ns_micro_bwd(a, t, action, g_reward ? g_reward + blockIdx.x : nullptr, lds_p);
+        const bool pre = TA == 3 && t >= 1 && tid < L;
+        if (pre) ns_rows_fetch(a, t - 1, tid, nx);
+        if (t >= 1) for (int q = B - 1 - tid; q < a0.sq; q += B) ns_signal_fill(a, action, t - 1, q);
+        ns_micro_bwd(a, t, action, g_reward ? g_reward + blockIdx.x : nullptr, lds_p, n_max);
         __syncthreads();
         NS_STAMP(0)
         for (int c = tid; c < C; c += B) ns_cell_bwd_item(a, t, c);
         __syncthreads();
         NS_STAMP(1)
         if (C > 0) {
-            for (int j = tid; j < 2 * L; j += B) ns_ghost_bwd_item(a, t, action, j);
+            for (int j = tid; j < ns_ghost_items(L); j += B) ns_ghost_bwd_item(a, t, action, j);
             __syncthreads();
             NS_STAMP(2)
-            for (int m = tid; m < m_items; m += B) ns_ghost_gather_item(a, t, m);
+            for (int m = tid; m < L; m += B) ns_ghost_gather_item(a, t, m);
+            for (int q = (B >> 6) - 1 - (tid >> 6); q < a.sq; q += B >> 6) ns_action_gather_wave(a, q);      // (from the last wavefront down)
             NS_STAMP(3)
         }
         // the state before step t - 1 (row t - 1) into the copy row t + 1 leaves; the rows of step t - 1
-        if (a.st && t >= 1) {
-            float *sr = ns_state(a, t - 1);
-            const float *hr = a.hist + (size_t)(t - 1) * 4 * C;
-            for (int i = tid; i < 4 * C; i += B) sr[i] = hr[i];
+        if constexpr (ST) {
+            if (t >= 1) {
+                const auto sr = ns_state(a, t - 1);
+                auto hr = ns_glob(a.hist) + (size_t)(t - 1) * 4 * C;
+                for (int i = tid; i < 4 * C; i += B) sr[i] = hr[i];
+            }
         }
-        if (pre) ns_rows_store(a, t - 1, tid, nx);
-        if (a.row_i && t >= 1) for (int l = tid + B; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, ag, t - 1, l, v); ns_rows_store(a, t - 1, l, v); }
+        if constexpr (TA == 3) {
+            if (pre) ns_rows_store(a, t - 1, tid, nx);
+            if (t >= 1) for (int l = tid + B; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, t - 1, l, v); ns_rows_store(a, t - 1, l, v); }
+        }
         __syncthreads();
         NS_STAMP(4)
     }
 #ifdef DHTS_NS_STAMPS
     if (blockIdx.x == 0 && tid == 0)
-        printf("ns_persist_bwd cycles per step: taps + events + fold + IDM + head gaps %lld | cells %lld | ghosts %lld | gather %lld | state %lld\n",
-               st_[0] / T, st_[1] / T, st_[2] / T, st_[3] / T, st_[4] / T);
+        printf("ns_persist_bwd<%d,%d> cycles per step: taps + events + fold + IDM + head gaps %lld | cells %lld | ghosts %lld | gather %lld | state %lld\n",
+               TA, (int)ST + 2 * (int)MS, st_[0] / T, st_[1] / T, st_[2] / T, st_[3] / T, st_[4] / T);
+    if (blockIdx.x == 0 && tid == 0)
+        printf("   taps %lld | events %lld | capacitor charges %lld | fold %lld | IDM %lld | head gaps %lld | admission %lld\n",
+               ns_sub_[8] / T, ns_sub_[9] / T, ns_sub_[10] / T, ns_sub_[11] / T, ns_sub_[12] / T, ns_sub_[13] / T, ns_sub_[14] / T);
 #endif
     float *g_action = g_action_all + (size_t)blockIdx.x * a.n_action;
-    const double *g_act = ns_ptr<double>(a, a.lo.g_act);
+    auto g_act = NS_MS(a, double, g_act);
     for (int q = tid; q < a.n_action; q += B) g_action[q] = (float)g_act[q];
 }
 
@@ -1349,7 +1665,7 @@ __global__ void ns_finish_bwd_kernel(NsArgs a, float *__restrict__ g_action) {
 __global__ void ns_init_fwd_kernel(NsArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.C) { a.hist[i] = 0.f; a.hist[a.C + i] = 0.f; a.hist[2 * a.C + i] = a.um; a.hist[3 * a.C + i] = a.um; }
-    if (i < a.L) { float *o = ns_ptr<float>(a, a.lo.own_hist); o[2 * i] = 0.f; o[2 * i + 1] = a.um; }
+    if (i < a.L) { const auto o = ns_ptr<float>(a, a.lo.own_hist); o[2 * i] = 0.f; o[2 * i + 1] = a.um; }
 }
 
 }  // namespace dhts
@@ -1402,7 +1718,7 @@ static bool ns_ok(const dhts_net_desc *d, const dhts_netstep_tables *t) {
     if (!d || !t) return false;
     const dhts_hybrid_tables &h = t->hyb;
     const int cap = h.lane_capacity > 0 ? h.lane_capacity : 16;
-    return (d->n_replicas == 1 || (t->persistent && d->n_replicas > 1)) && (!t->persistent || d->n_cells == 0 || (t->if_lane && t->cell_lane)) &&
+    return (d->n_replicas == 1 || (t->persistent && d->n_replicas > 1)) && (d->n_cells == 0 || (t->if_lane && t->cell_lane)) &&
            d->n_lanes > 0 && d->n_cells >= 0 && d->n_steps > 0 && d->n_inter_sq > 0 && d->frames_per_phase > 0 &&
            d->n_action >= d->n_inter_sq && d->dt > 0 && d->u_max > 0 && d->vehicle_length > 0 && cap <= 1024 && h.n_micro >= 0 &&
            h.net.lane_ncell && h.net.lane_off && h.net.sig_kind && h.net.inter && h.net.lane_dx && h.net.left_src && h.net.left_gate &&
@@ -1430,31 +1746,47 @@ static NsArgs ns_args(const dhts_net_desc *d, const dhts_netstep_tables *t, int 
     a.schedule = h.net.schedule; a.routes = h.routes; a.route_ptr = h.route_ptr; a.draws = h.draws;
     a.nxt_ptr = h.net.nxt_ptr; a.nxt_idx = h.net.nxt_idx; a.prv_ptr = h.net.prv_ptr; a.prv_idx = h.net.prv_idx;
     a.inter_ptr = t->inter_ptr; a.inter_idx = t->inter_idx;
-    a.if_lane = t->if_lane; a.cell_lane = t->cell_lane; a.table_stride = h.net.replica_stride; a.draws_stride = h.draws_stride;
-    a.n_edges = h.net.n_edges; a.n_islots = t->n_inter_slots; a.stage = 0;
-    a.st = nullptr; a.gl = nullptr; a.gh = nullptr; a.sl = nullptr; a.gg = nullptr; a.row_i = nullptr; a.row_d = nullptr;
+    a.cell_lane = t->cell_lane; a.table_stride = h.net.replica_stride; a.draws_stride = h.draws_stride;
+    a.n_edges = h.net.n_edges; a.n_islots = t->n_inter_slots; a.has_source = h.lane_source != nullptr; a.n_routes = h.n_routes;
     { int lg = 0; for (int g = 0; g < t->n_groups; ++g) lg += t->groups[g].n_lanes; a.NI = d->n_cells + lg; }
     a.ws = reinterpret_cast<char *>(ws); a.lo = ns_layout(d, t);
     a.hist = hist; a.queue = queue; a.reward = reward; a.counts = counts; a.err = err;
     return a;
 }
 
-// What fits into a workgroup's 160 KB beside the phases' scratch, in the order of what it buys: the per-step table rows and the
-// ghost / slot arrays (small, read by every item), the static tables, the cotangent planes (reverse sweep) resp. the state rows,
-// then the other of the two.
+// What a workgroup's 160 KB hold beside the phases' scratch: the static tables + the per-step table rows + ghosts resp. slots / ghost
+// cotangents (TB: small, the head of every item's look-up chain), then the state rows and -- reverse sweep -- the cotangent planes (ST)
 static NsPlan ns_plan(const NsArgs &a, size_t scratch, bool bwd) {
-    NsPlan pl = {(int)scratch, 0, 0, 0, 0, 0};
-    size_t left = 156 * 1024 - scratch;
-    auto take = [&](size_t bytes, int &slot) { if (bytes && bytes <= left) { slot = (int)bytes; left -= bytes; } };
-    take(ns_al16(16 * (size_t)a.L) + ns_al16(32 * (size_t)a.L), pl.rows);
-    take(3 * ns_al16(32 * (size_t)a.L), pl.misc);
-    take(ns_stage_bytes(a.L, a.C, a.NI, a.Lm, a.ncap, a.n_edges, a.sq, a.n_islots, a.lane_source != nullptr), pl.tables);
-    const size_t st = ns_al16(sizeof(float) * 8 * (size_t)a.C), gl = ns_al16(sizeof(float) * 6 * (size_t)a.C);
-    if (a.C > 0) {
-        if (bwd) { take(gl, pl.gl); take(st, pl.st); }
-        else take(st, pl.st);
-    }
+    NsPlan pl = {(int)scratch, 0, 0, 0, 0, 0, 0, 0};
+    size_t left = 158 * 1024 - scratch;          // (the kernels' static LDS -- argument block, scan scratch -- stays below 2 KB)
+    const size_t tables = ns_stage_bytes(a), rows = ns_al16(16 * (size_t)a.L) + ns_al16(32 * (size_t)a.L);
+    const size_t misc = (bwd ? 2 : 1) * ns_al16(32 * (size_t)a.L) + ns_al16(32 * (size_t)a.sq + 16);
+    if (tables + rows + misc <= left) { pl.tables = (int)tables; pl.rows = (int)rows; pl.misc = (int)misc; left -= tables + rows + misc; }
+    const size_t routes = ns_al16(4 * (size_t)a.n_routes * a.route_stride) + ns_al16(4 * (size_t)a.n_routes);
+    if (pl.tables && !bwd && a.Lm > 0 && a.n_routes > 0 && routes <= 32 * 1024 && routes <= left) { pl.routes = (int)routes; left -= routes; }
+    const size_t ms = ns_micro_state_bytes(a, bwd);
+    if (pl.tables && a.Lm > 0 && ms <= left) { pl.ms = (int)ms; left -= ms; }
+    const size_t st = ns_al16(sizeof(float) * 8 * (size_t)a.C), gl = bwd ? ns_al16(sizeof(float) * 6 * (size_t)a.C) : 0;
+    if (a.C > 0 && st + gl <= left) { pl.st = (int)st; pl.gl = (int)gl; }
     return pl;
+}
+
+template <int TA, bool ST, bool MS>
+static int ns_launch_persist_fwd(const NsArgs &a, const float *action, const NsPlan &pl, size_t lds, int n_replicas, hipStream_t st) {
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute((const void *)ns_persist_fwd_kernel<TA, ST, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DHTS_E_INVALID;
+    ns_persist_fwd_kernel<TA, ST, MS><<<n_replicas, kNsBlock, lds, st>>>(a, action, pl);
+    return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
+}
+template <int TA, bool ST, bool MS>
+static int ns_launch_persist_bwd(const NsArgs &a, const float *action, const float *g_reward, float *g_action, const NsPlan &pl, size_t lds,
+                                 int n_replicas, hipStream_t st) {
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute((const void *)ns_persist_bwd_kernel<TA, ST, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DHTS_E_INVALID;
+    ns_persist_bwd_kernel<TA, ST, MS><<<n_replicas, kNsBlock, lds, st>>>(a, action, g_reward, g_action, pl);
+    return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
 }
 
 extern "C" {
@@ -1475,24 +1807,25 @@ int dhts_netstep_rollout_fwd(const dhts_net_desc *d, const dhts_netstep_tables *
     if (t->persistent) {
         size_t lds = sizeof(float) * 2 * (size_t)(Lm > 0 ? Lm : 1);              // head gaps | candidate flags | the reward's partial sums
         if (sizeof(float) * 2 * (size_t)L > lds) lds = sizeof(float) * 2 * (size_t)L;
+        if (ns_convert_scratch(L, C, plane) > lds) lds = ns_convert_scratch(L, C, plane);
         const NsPlan pl = ns_plan(a, ns_al16(lds), false);
-        lds = (size_t)pl.scratch + pl.tables + pl.st + pl.gl + pl.rows + pl.misc;
-        if (lds > 160 * 1024 ||
-            (lds > 48 * 1024 && hipFuncSetAttribute((const void *)ns_persist_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess))
-            return DHTS_E_INVALID;
-        ns_persist_fwd_kernel<<<d->n_replicas, kNsBlock, lds, st>>>(a, action, pl);
-        return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
+        lds = (size_t)pl.scratch + pl.tables + pl.st + pl.gl + pl.rows + pl.misc + pl.ms + pl.routes;
+        if (lds > 160 * 1024) return DHTS_E_INVALID;
+        if (pl.tables && pl.ms) return pl.st ? ns_launch_persist_fwd<3, true, true>(a, action, pl, lds, d->n_replicas, st) : ns_launch_persist_fwd<3, false, true>(a, action, pl, lds, d->n_replicas, st);
+        if (pl.tables) return pl.st ? ns_launch_persist_fwd<3, true, false>(a, action, pl, lds, d->n_replicas, st) : ns_launch_persist_fwd<3, false, false>(a, action, pl, lds, d->n_replicas, st);
+        return pl.st ? ns_launch_persist_fwd<1, true, false>(a, action, pl, lds, d->n_replicas, st) : ns_launch_persist_fwd<1, false, false>(a, action, pl, lds, d->n_replicas, st);
     }
     // running state of the episode
     if (hipMemsetAsync(ws + a.lo.P, 0, a.lo.counters + sizeof(NsCounters) - a.lo.P, st) != hipSuccess) return DHTS_E_LAUNCH;
     const int nmax = C > L ? C : L;
     ns_init_fwd_kernel<<<(nmax + 255) / 256, 256, 0, st>>>(a);
-    const size_t lds_b = sizeof(float) * 2 * (size_t)(Lm > 0 ? Lm : 1), lds_c = sizeof(int) * (size_t)L;
-    if (lds_b > 48 * 1024 || lds_c > 48 * 1024) return DHTS_E_INVALID;
-    const int ghost_blocks = (2 * L + kNsBlock - 1) / kNsBlock;
+    const size_t lds_b = sizeof(float) * 2 * (size_t)(Lm > 0 ? Lm : 1), lds_c = ns_convert_scratch(L, C, plane);
+    if (lds_b > 48 * 1024 || lds_c > 160 * 1024 ||
+        (lds_c > 48 * 1024 && hipFuncSetAttribute((const void *)ns_convert_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess))
+        return DHTS_E_INVALID;
+    const int ghost_blocks = (ns_ghost_items(L) + kNsBlock - 1) / kNsBlock;
     float *ghost = reinterpret_cast<float *>(ws + a.lo.ghost);
     float *tape0 = reinterpret_cast<float *>(ws + a.lo.tape);
-    (void)plane;
     for (int step = 0; step < T; ++step) {
         ns_boundary_fwd_kernel<<<1 + ghost_blocks, kNsBlock, lds_b, st>>>(a, step, action);
         const float *cur = hist + (size_t)step * 4 * C;
@@ -1523,26 +1856,25 @@ int dhts_netstep_rollout_bwd(const dhts_net_desc *d, const dhts_netstep_tables *
     const int L = a.L, C = a.C, T = a.T, Lm = a.Lm;
     char *ws = a.ws;
     if (t->persistent) {
-        const NsPlan pl = ns_plan(a, ns_al16(sizeof(double) * (2 * (size_t)(Lm > 0 ? Lm : 1) + 8 * (size_t)kNsBlock)), true);
-        const size_t lds = (size_t)pl.scratch + pl.tables + pl.st + pl.gl + pl.rows + pl.misc;
-        if (lds > 160 * 1024 ||
-            hipFuncSetAttribute((const void *)ns_persist_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return DHTS_E_INVALID;
-        ns_persist_bwd_kernel<<<d->n_replicas, kNsBlock, lds, st>>>(a, action, g_reward, g_action, pl);
-        return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
+        const NsPlan pl = ns_plan(a, ns_al16(ns_micro_bwd_scratch(L, C, Lm, (size_t)Lm * a.cap)), true);
+        const size_t lds = (size_t)pl.scratch + pl.tables + pl.st + pl.gl + pl.rows + pl.misc + pl.ms + pl.routes;
+        if (lds > 160 * 1024) return DHTS_E_INVALID;
+        if (pl.tables && pl.ms) return pl.st ? ns_launch_persist_bwd<3, true, true>(a, action, g_reward, g_action, pl, lds, d->n_replicas, st) : ns_launch_persist_bwd<3, false, true>(a, action, g_reward, g_action, pl, lds, d->n_replicas, st);
+        if (pl.tables) return pl.st ? ns_launch_persist_bwd<3, true, false>(a, action, g_reward, g_action, pl, lds, d->n_replicas, st) : ns_launch_persist_bwd<3, false, false>(a, action, g_reward, g_action, pl, lds, d->n_replicas, st);
+        return pl.st ? ns_launch_persist_bwd<1, true, false>(a, action, g_reward, g_action, pl, lds, d->n_replicas, st) : ns_launch_persist_bwd<1, false, false>(a, action, g_reward, g_action, pl, lds, d->n_replicas, st);
     }
     // cotangents start at zero; the lanes hold what the forward left (lane_n)
     if (hipMemsetAsync(ws + a.lo.G, 0, a.lo.n_bwd - a.lo.G, st) != hipSuccess) return DHTS_E_LAUNCH;
     if (Lm > 0 && hipMemcpyAsync(ws + a.lo.n_bwd, ws + a.lo.lane_n, sizeof(int) * (size_t)Lm, hipMemcpyDeviceToDevice, st) != hipSuccess)
         return DHTS_E_LAUNCH;
-    const size_t lds_m = sizeof(double) * (2 * (size_t)(Lm > 0 ? Lm : 1) + 8 * (size_t)kNsBlock);
+    const size_t lds_m = ns_micro_bwd_scratch(L, C, Lm, (size_t)Lm * a.cap);
     if (lds_m > 160 * 1024 ||
         hipFuncSetAttribute((const void *)ns_micro_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m) != hipSuccess)
         return DHTS_E_INVALID;
     float *G = reinterpret_cast<float *>(ws + a.lo.G);
     double *g_ghost = reinterpret_cast<double *>(ws + a.lo.g_ghost);
     const float *tape0 = reinterpret_cast<const float *>(ws + a.lo.tape);
-    const int m = L > a.sq ? L : a.sq;
+    const int lane_blocks = (L + 255) / 256, act_blocks = (a.sq + 3) / 4;
     for (int step = T - 1; step >= 0; --step) {
         ns_micro_bwd_kernel<<<1, kNsBlock, lds_m, st>>>(a, step, action, g_reward);
         float *Gn = G + (size_t)((step + 1) & 1) * 3 * C, *Gp = G + (size_t)(step & 1) * 3 * C;
@@ -1558,8 +1890,8 @@ int dhts_netstep_rollout_bwd(const dhts_net_desc *d, const dhts_netstep_tables *
             tape_off += dhts_macro_step_tape_bytes(&md) / sizeof(float);
         }
         if (C > 0) {
-            ns_ghosts_bwd_kernel<<<(2 * L + 255) / 256, 256, 0, st>>>(a, step, action);
-            ns_ghosts_gather_kernel<<<(m + 255) / 256, 256, 0, st>>>(a, step);
+            ns_ghosts_bwd_kernel<<<(ns_ghost_items(L) + 255) / 256, 256, 0, st>>>(a, step, action);
+            ns_ghosts_gather_kernel<<<lane_blocks + act_blocks, 256, 0, st>>>(a, step, lane_blocks);
         }
     }
     ns_finish_bwd_kernel<<<(a.n_action + 255) / 256, 256, 0, st>>>(a, g_action);

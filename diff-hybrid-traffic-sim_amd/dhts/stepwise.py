@@ -23,6 +23,21 @@ import torch
 from . import _lib, ops
 
 
+def default_lane_capacity(tables, vehicle_length, ceiling=32):
+    """Vehicle slots per micro lane sized from the geometry: the longest micro lane's length in vehicles + 2, as a power of two in
+    4 .. `ceiling`.  Vehicles keep a gap (IDM), so a lane cannot hold more; an episode that does anyway comes back as
+    DHTS_FAULT_CAPACITY (ItscpEnv retries it with more room).  Small capacities keep the persistent kernels' vehicle arrays in LDS."""
+    t = as_hybrid_tables(tables)
+    micro = np.asarray(t.lane_macro) == 0
+    if not micro.any():
+        return 4
+    n = int(float(np.max(np.asarray(t.lane_length, dtype=np.float64)[micro])) / float(vehicle_length)) + 2
+    cap = 4
+    while cap < n:
+        cap *= 2
+    return min(cap, int(ceiling))
+
+
 def as_hybrid_tables(t):
     """A dhts.network.MacroNetworkTables as HybridNetworkTables (every lane an ARZ lane)."""
     from .network import HybridNetworkTables

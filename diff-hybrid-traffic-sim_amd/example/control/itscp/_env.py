@@ -358,10 +358,12 @@ class ItscpEnv:
                 return self._step_fused(action, differentiable)
             # The episode needs more than this launch was sized for (vehicles per micro lane, vehicles per episode, records), or the
             # sizing does not fit one workgroup's LDS (DhtsError).  Nothing on the host was touched by the attempt; the ladder is
-            #   fused kernels at 16 vehicles per lane -> fused at 128 -> stepwise device path at 128 -> stepwise at 1024 -> lane by lane,
+            #   fused kernels at 16 vehicles per lane -> fused at 128 -> stepwise device path at 32 -> 128 -> 1024 -> lane by lane
+            #   (a network that starts on the stepwise path starts at the capacity its geometry asks for, dhts.stepwise.default_lane_capacity),
             # every rung the SAME episode: same drawn routes (kept in _fused_routes_drawn), same admission draws.
-            ladder = [("fused", 16), ("fused", 128), ("stepwise", 128), ("stepwise", 1024)]
-            here = ("stepwise" if kind == "stepwise" else "fused", lane_cap if lane_cap else (16 if kind != "stepwise" else 32))
+            ladder = [("fused", 16), ("fused", 128), ("stepwise", 32), ("stepwise", 128), ("stepwise", 1024)]
+            here = ("stepwise" if kind == "stepwise" else "fused",
+                    lane_cap if lane_cap else (16 if kind != "stepwise" else getattr(self, "_stepwise_lane_capacity", 32)))
             nxt = None
             if kind in ("micro", "hybrid", "stepwise"):
                 for rung in ladder:
@@ -468,7 +470,10 @@ class ItscpEnv:
                 return (mode, ops.DeviceHybridTables(tab, routes, device, lane_capacity=lane_cap))
             # beyond one workgroup (cells + lanes > 960, > 64 IDM lanes, > 16 spawning lanes) or beyond the fused kernels' vehicle
             # capacities: step by step on the device (dhts/stepwise.py)
-            return ("stepwise", self._stepwise_net(tab, routes, device, lane_cap if lane_cap else 32))
+            if not lane_cap:
+                from dhts.stepwise import default_lane_capacity
+                lane_cap = self._stepwise_lane_capacity = default_lane_capacity(tab, self.simulator.vehicle_length)
+            return ("stepwise", self._stepwise_net(tab, routes, device, lane_cap))
         except ValueError:
             return ("none", None)
 

@@ -46,7 +46,7 @@ class ReplicaBatch:
         e0 = self.envs[0]
         mode = e0.config["mode"]
         try:
-            from dhts.stepwise import StepwiseNetwork
+            from dhts.stepwise import StepwiseNetwork, default_lane_capacity
             if mode == "macro":
                 tabs = [MacroNetworkTables.from_env(e) for e in self.envs]
                 if tabs[0].n_cells + tabs[0].n_lanes > 1024:
@@ -80,7 +80,7 @@ class ReplicaBatch:
             try:
                 tabs[0].check_kernel_limits()
             except ValueError:
-                return "stepwise", StepwiseNetwork(tabs, routes, self.device, lane_capacity=int(e0.config.get("stepwise_lane_capacity", 32)),
+                return "stepwise", StepwiseNetwork(tabs, routes, self.device, lane_capacity=int(e0.config.get("stepwise_lane_capacity", 0)) or default_lane_capacity(tabs[0], e0.simulator.vehicle_length),
                                                    persistent=True)
             return mode, ops.DeviceHybridTables(tabs if self.R > 1 else tabs[0], routes, self.device)
         except ValueError:

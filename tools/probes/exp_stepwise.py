@@ -10,7 +10,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "diff-hybrid-traffic-sim_amd"), os.path.join(ROOT, "tests")]
 from test_oracle_golden import itscp_hybrid_tables, itscp_micro_tables, itscp_tables, meta_of      # noqa: E402
-from dhts.stepwise import StepwiseNetwork      # noqa: E402
+from dhts.stepwise import StepwiseNetwork, default_lane_capacity      # noqa: E402
 from dhts.batched import BatchedMacroNetwork      # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
@@ -41,7 +41,7 @@ for name in ("hybrid_n2l30", "hybrid_5x5", "micro_2x2", "macro_3x3x3", "hybrid_h
         routes = g["spawn_routes"] if g["spawn_routes"].shape[0] else -np.ones((1, 2), np.int32)
     a = torch.tensor(g["action"], device=cuda, requires_grad=True)
     for persistent in (False, True):
-        net = StepwiseNetwork(t, routes, cuda, persistent=persistent)
+        net = StepwiseNetwork(t, routes, cuda, lane_capacity=default_lane_capacity(t, m["vehicle_length"]), persistent=persistent)
 
         def episode():
             a.grad = None
@@ -54,7 +54,7 @@ for name in ("hybrid_n2l30", "hybrid_5x5", "micro_2x2", "macro_3x3x3", "hybrid_h
         print("%-14s %4d lanes %5d cells %4d IDM lanes %4d steps, %-10s form: differentiable episode %6.2f ms, evaluation episode %6.2f ms" % (
             name, t.n_lanes, t.n_cells, net.n_micro, t.T, "persistent" if persistent else "stepwise", 1e3 * timed(episode), 1e3 * timed(evaluation)), flush=True)
     R = 64
-    netr = StepwiseNetwork([t] * R, routes, cuda, persistent=True)
+    netr = StepwiseNetwork([t] * R, routes, cuda, lane_capacity=default_lane_capacity(t, m["vehicle_length"]), persistent=True)
     ar = torch.tensor(np.tile(g["action"][None], (R, 1)), device=cuda, requires_grad=True)
 
     def batch():
