@@ -121,7 +121,7 @@ template <> struct NsStaged<true> {
 #undef NS_X
     // the per-step table rows of steps t and t + 1 ([2][L] each), ghosts / slots / ghost cotangents, the signal table (TB); the state rows
     // t and t + 1 ([2][4][C], row r in copy r & 1) and the cotangent planes ([2][3][C]) (ST)
-    NS_LDS float *gh, *sl, *sg;
+    NS_LDS float *gh, *sl, *sg, *ow;        // ow [2][2 L]: the lanes' stored downstream ghosts before steps t and t + 1 (forward)
     NS_LDS int32_t *sgi;
     NS_LDS double *gg;
     NS_LDS int32_t *row_i;       // [2][4][L]: left_src, left_gate, right_src, conv_next
@@ -351,10 +351,17 @@ template <class A> __device__ __forceinline__ void ns_ghost_fwd_item(const A &a,
         const int Lp = (L + 63) & ~63;
         const int side = item >= Lp ? 1 : 0, lane = item - side * Lp;
         if (lane >= L) return;
-        auto own_in = ns_ptr<float>(a, a.lo.own_hist) + (size_t)t * 2 * L;
-        auto own_out = ns_ptr<float>(a, a.lo.own_hist) + (size_t)(t + 1) * 2 * L;
+        auto own_out = ns_ptr<float>(a, a.lo.own_hist) + (size_t)(t + 1) * 2 * L;       // (the history the reverse sweep reads)
+        float own_r = 0.f, own_u = 0.f;
+        if (side == 1) {
+            if constexpr (A::kTB) { const auto o = a.ow + (size_t)(t & 1) * 2 * L; own_r = o[2 * lane]; own_u = o[2 * lane + 1]; }
+            else { const auto o = ns_ptr<float>(a, a.lo.own_hist) + (size_t)t * 2 * L; own_r = o[2 * lane]; own_u = o[2 * lane + 1]; }
+        }
         if (!a.lane_macro[lane]) {
-            if (side == 1) { own_out[2 * lane] = own_in[2 * lane]; own_out[2 * lane + 1] = own_in[2 * lane + 1]; }
+            if (side == 1) {
+                own_out[2 * lane] = own_r; own_out[2 * lane + 1] = own_u;
+                if constexpr (A::kTB) { const auto o = a.ow + (size_t)((t + 1) & 1) * 2 * L; o[2 * lane] = own_r; o[2 * lane + 1] = own_u; }
+            }
             return;
         }
         float fr, fu, fy, fq;
@@ -374,7 +381,7 @@ template <class A> __device__ __forceinline__ void ns_ghost_fwd_item(const A &a,
             }
         } else {
             const int rs = rw.right_src[lane];
-            float gr = own_in[2 * lane], gu = own_in[2 * lane + 1];
+            float gr = own_r, gu = own_u;
             if (rs >= 0) { const int first = a.lane_off[rs]; gr = cur[first]; gu = cur[2 * C + first]; }
             const float sg = ns_lane_signal(a, action, t, lane, hard, nullptr, nullptr);
             const float s2 = hard ? (sg > 0.5f ? 1.f : 0.f) : soft_switch(sg - 0.5f, kSigK);
@@ -382,6 +389,7 @@ template <class A> __device__ __forceinline__ void ns_ghost_fwd_item(const A &a,
             fu = s2 * gu + (1.0f - s2) * 0.0f;
             glue_from_r_u(fr, fu, um, fy, fq);
             own_out[2 * lane] = fr; own_out[2 * lane + 1] = fu;
+            if constexpr (A::kTB) { const auto o = a.ow + (size_t)((t + 1) & 1) * 2 * L; o[2 * lane] = fr; o[2 * lane + 1] = fu; }
         }
         const auto g = ns_ghosts(a) + ((size_t)a.lane_gpos[lane] * 2 + side) * 4;
         g[0] = fr; g[1] = fy; g[2] = fu; g[3] = fq;
@@ -745,6 +753,10 @@ template <class A> __device__ __forceinline__ void ns_convert(const A &a, int t,
                                         float yy, qq;
                                         glue_from_r_u(n_r, hv, um, yy, qq);
                                         Yn[cell] = yy;                          // u_eq keeps its value from before the deposit
+                                        if constexpr (A::kST) {
+                                            const auto hn = ns_glob(a.hist) + (size_t)(t + 1) * 4 * C;
+                                            hn[cell] = n_r; hn[C + cell] = yy; hn[2 * C + cell] = hv;
+                                        }
                                         // a flux capacitor reading this very cell: one of a LATER lane charges again from the deposited
                                         // state (the reference walks the lanes in id order), one of an EARLIER lane keeps what it read
                                         if (ci == a.lane_ncell[nid] - 1) {
@@ -1347,6 +1359,10 @@ template <class A> __device__ __forceinline__ void ns_cell_item(const A &a, int 
     float nu, nq;
     glue_from_r_y(nr, ny, a.um, nu, nq);
     nxt[c] = nr; nxt[C + c] = ny; nxt[2 * C + c] = nu; nxt[3 * C + c] = nq;
+    if constexpr (A::kST) {             // (the state rows live in LDS: the history -- what the reverse sweep and the callers read -- is written here)
+        const auto hn = ns_glob(a.hist) + (size_t)(t + 1) * 4 * C;
+        hn[c] = nr; hn[C + c] = ny; hn[2 * C + c] = nu; hn[3 * C + c] = nq;
+    }
     if (!a.hard) {
         const float cf = (float)cc, ncf = (float)(-cc);
         float4 d0, d1, d2;
@@ -1423,12 +1439,13 @@ __device__ __forceinline__ void ns_carve(NsArgsT<TA, ST, MS> &a, const NsArgs &a
         if (bwd) { a.gg = (NS_LDS double *)p; a.sl = (NS_LDS float *)(p + lg); a.gh = nullptr; }
         else { a.gh = (NS_LDS float *)p; a.gg = nullptr; a.sl = nullptr; }
         a.sg = (NS_LDS float *)(p + (bwd ? 2 : 1) * lg); a.sgi = (NS_LDS int32_t *)(a.sg + 8 * (size_t)a.sq);
+        a.ow = bwd ? nullptr : (NS_LDS float *)(p + lg + ns_al16(32 * (size_t)a.sq + 16));
         p += pl.misc;
     } else {
 #define NS_X(name, ty, count) a.name = (NS_GLOBAL const ty *)a0.name;
         NS_TABLES(NS_X)
 #undef NS_X
-        a.gh = nullptr; a.sl = nullptr; a.gg = nullptr; a.row_i = nullptr; a.row_d = nullptr; a.sg = nullptr; a.sgi = nullptr;
+        a.gh = nullptr; a.sl = nullptr; a.gg = nullptr; a.row_i = nullptr; a.row_d = nullptr; a.sg = nullptr; a.sgi = nullptr; a.ow = nullptr;
     }
     if constexpr (ST) {
         a.st = (NS_LDS float *)p; p += pl.st;
@@ -1500,7 +1517,10 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_fwd_kernel(NsArgs a0, con
             if constexpr (ST) { const auto h0 = ns_glob(a.hist); h0[i] = 0.f; h0[C + i] = 0.f; h0[2 * C + i] = a.um; h0[3 * C + i] = a.um; }
         }
     }
-    for (int i = tid; i < L; i += B) { const auto o = ns_ptr<float>(a, a.lo.own_hist); o[2 * i] = 0.f; o[2 * i + 1] = a.um; }
+    for (int i = tid; i < L; i += B) {
+        const auto o = ns_ptr<float>(a, a.lo.own_hist); o[2 * i] = 0.f; o[2 * i + 1] = a.um;
+        if constexpr (TA == 3) { a.ow[2 * i] = 0.f; a.ow[2 * i + 1] = a.um; }
+    }
     if constexpr (MS) {
         NS_LDS unsigned *z = (NS_LDS unsigned *)a.m_P;
         const size_t nz = (size_t)pl.ms / 4;
@@ -1538,11 +1558,6 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_fwd_kernel(NsArgs a0, con
         NS_STAMP(2)
         ns_convert(a, t, reinterpret_cast<int *>(lds_p));
         NS_STAMP(3)
-        if constexpr (ST) {             // the committed state to the history (what the reverse sweep and the callers read)
-            const auto sn = ns_state(a, t + 1);
-            auto hn = ns_glob(a.hist) + (size_t)(t + 1) * 4 * C;
-            for (int i = tid; i < 4 * C; i += B) hn[i] = sn[i];
-        }
         if constexpr (TA == 3) {
             if (pre) ns_rows_store(a, t + 1, tid, nx);
             if (t + 1 < T) for (int l = tid + B; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, t + 1, l, v); ns_rows_store(a, t + 1, l, v); }
@@ -1617,6 +1632,15 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_bwd_kernel(NsArgs a0, con
         ns_micro_bwd(a, t, action, g_reward ? g_reward + blockIdx.x : nullptr, lds_p, n_max);
         __syncthreads();
         NS_STAMP(0)
+        // the state before step t - 1 (history row t - 1): fetched now (row t + 1, whose LDS copy it replaces, is not read after this
+        // point), stored at the end of the step
+        float sv[8];
+        const bool pre_s = ST && t >= 1 && 4 * C <= 8 * B;
+        if (pre_s) {
+            const auto hr = ns_glob(a.hist) + (size_t)(t - 1) * 4 * C;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = tid + k * B; sv[k] = i < 4 * C ? hr[i] : 0.f; }
+        }
         for (int c = tid; c < C; c += B) ns_cell_bwd_item(a, t, c);
         __syncthreads();
         NS_STAMP(1)
@@ -1630,7 +1654,11 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_bwd_kernel(NsArgs a0, con
         }
         // the state before step t - 1 (row t - 1) into the copy row t + 1 leaves; the rows of step t - 1
         if constexpr (ST) {
-            if (t >= 1) {
+            if (pre_s) {
+                const auto sr = ns_state(a, t - 1);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const int i = tid + k * B; if (i < 4 * C) sr[i] = sv[k]; }
+            } else if (t >= 1) {
                 const auto sr = ns_state(a, t - 1);
                 auto hr = ns_glob(a.hist) + (size_t)(t - 1) * 4 * C;
                 for (int i = tid; i < 4 * C; i += B) sr[i] = hr[i];
@@ -1760,7 +1788,7 @@ static NsPlan ns_plan(const NsArgs &a, size_t scratch, bool bwd) {
     NsPlan pl = {(int)scratch, 0, 0, 0, 0, 0, 0, 0};
     size_t left = 158 * 1024 - scratch;          // (the kernels' static LDS -- argument block, scan scratch -- stays below 2 KB)
     const size_t tables = ns_stage_bytes(a), rows = ns_al16(16 * (size_t)a.L) + ns_al16(32 * (size_t)a.L);
-    const size_t misc = (bwd ? 2 : 1) * ns_al16(32 * (size_t)a.L) + ns_al16(32 * (size_t)a.sq + 16);
+    const size_t misc = (bwd ? 2 : 1) * ns_al16(32 * (size_t)a.L) + ns_al16(32 * (size_t)a.sq + 16) + (bwd ? 0 : ns_al16(16 * (size_t)a.L));
     if (tables + rows + misc <= left) { pl.tables = (int)tables; pl.rows = (int)rows; pl.misc = (int)misc; left -= tables + rows + misc; }
     const size_t routes = ns_al16(4 * (size_t)a.n_routes * a.route_stride) + ns_al16(4 * (size_t)a.n_routes);
     if (pl.tables && !bwd && a.Lm > 0 && a.n_routes > 0 && routes <= 32 * 1024 && routes <= left) { pl.routes = (int)routes; left -= routes; }
