@@ -296,3 +296,14 @@ def test_itscp_micro_mode_network(oracle, golden_dir, name):
     assert rel_max(o["queue"].T, g["queue"]) <= 1e-4
     assert abs(o["reward"] - float(g["reward"])) <= 1e-4 * abs(float(g["reward"]))
     assert grad_report("G8 %s d reward / d action" % name, o["g_action"], g["g_action"]) <= TOL_GRAD
+
+
+
+@pytest.mark.parametrize("name, cap", [("hybrid_n2l30", 8), ("hybrid_l30", 8), ("hybrid_5x5", 8), ("hybrid_p2", 8), ("macro_3x3x3", 4)])
+def test_default_lane_capacity_follows_the_geometry(golden_dir, name, cap):
+    """dhts.stepwise.default_lane_capacity: the longest micro lane in vehicles + 2 as a power of two in 4 .. 32 (host logic)."""
+    from dhts.stepwise import default_lane_capacity
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    t, m = itscp_hybrid_tables(g) if name.startswith("hybrid") else itscp_tables(g)
+    assert default_lane_capacity(t, m["vehicle_length"]) == cap
+    assert default_lane_capacity(t, m["vehicle_length"] / 100.0) == (32 if name.startswith("hybrid") else 4)      # (the ceiling)

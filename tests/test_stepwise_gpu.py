@@ -316,3 +316,58 @@ def test_persistent_replicas_equal_their_single_runs(cuda, golden_dir):
         torch.cuda.synchronize()
         print("persistent form, %s (%d lanes, %d cells, %d steps), %2d replica(s): %.2f ms per differentiable batch episode" % (
             name, t.n_lanes, t.n_cells, t.T, R2, 1e3 * (time.perf_counter() - t0) / 3))
+
+
+@pytest.mark.parametrize("name", ["hybrid_p2", "hybrid_l30", "hybrid_n2l30", "hybrid_5x5"])
+def test_persistent_form_at_the_geometric_capacity(cuda, golden_dir, name):
+    """The capacity sized from the geometry (dhts.stepwise.default_lane_capacity: what ItscpEnv and the trainer's replica batches start
+    from) keeps the micro side's running state in LDS -- other instantiations of the persistent kernels than at 32 slots per lane.
+    Capacity is storage only: same queues bit for bit, same gradient, and the reference's."""
+    from dhts.stepwise import default_lane_capacity
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    t, m = itscp_hybrid_tables(g)
+    cap = default_lane_capacity(t, m["vehicle_length"])
+    assert cap in (4, 8, 16, 32)
+    net_c, _, _ = _net(cuda, g, lane_capacity=cap, persistent=True)
+    net_32, _, _ = _net(cuda, g, lane_capacity=32, persistent=True)
+    net_s, _, _ = _net(cuda, g, lane_capacity=cap, persistent=False)
+    o_c, o_32, o_s = (_run(cuda, n, m, g["action"]) for n in (net_c, net_32, net_s))
+    print("%s: capacity %d" % (name, cap))
+    assert np.array_equal(o_c["queue"], o_32["queue"]) and np.array_equal(o_c["counts"], o_32["counts"]) and o_c["reward"] == o_32["reward"]
+    assert np.array_equal(o_c["queue"], o_s["queue"])
+    scale = np.abs(g["g_action"]).max()
+    assert np.abs(o_c["grad"] - o_32["grad"]).max() <= 1e-6 * scale and np.abs(o_c["grad"] - o_s["grad"]).max() <= 1e-6 * scale
+    assert np.abs(o_c["grad"] - g["g_action"]).max() <= TOL_GRAD * scale
+    assert state_report("queues vs reference", o_c["queue"].T, g["queue"]) <= TOL_STATE
+    oe_c = _run(cuda, net_c, m, g["action"], differentiable=False)
+    oe_32 = _run(cuda, net_32, m, g["action"], differentiable=False)
+    assert np.array_equal(oe_c["queue"], oe_32["queue"])
+
+
+def test_env_capacity_ladder_starts_at_the_geometric_capacity(cuda, golden_dir):
+    """ItscpEnv on a network beyond the fused limits starts the stepwise path at the geometry's capacity; an episode that outgrows a
+    capacity (forced here: one slot per lane) is retried at the next rung with the same routes -- and gives the reference's numbers."""
+    import torch
+    from test_itscp_gpu import build_env
+    from test_oracle_golden import meta_of
+    from dhts.stepwise import default_lane_capacity
+    g = np.load(os.path.join(golden_dir, "itscp_hybrid_n2l30.npz"))
+    m = meta_of(g)
+    env = build_env(g, m, replay_routes=True)
+    env.fused_routes = g["spawn_routes"]
+    action = torch.tensor(g["action"], device=cuda, requires_grad=True)
+    obs, reward, done, info = env.step(action, True)
+    t, _ = itscp_hybrid_tables(g)
+    assert env.last_path == "stepwise" and env._fused_cache[1].lane_capacity == default_lane_capacity(t, m["vehicle_length"]) == 8
+    r0 = float(reward.detach())
+    assert abs(r0 - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+    env2 = build_env(g, m, replay_routes=True)
+    env2.fused_routes = g["spawn_routes"]
+    env2._fused_lane_capacity = 1
+    env2._fused_prefer_stepwise = True
+    a2 = torch.tensor(g["action"], device=cuda, requires_grad=True)
+    _, reward2, _, _ = env2.step(a2, True)
+    reward2.backward()
+    assert env2.last_path == "stepwise" and env2._fused_cache[1].lane_capacity == 32
+    assert float(reward2.detach()) == r0
+    assert np.abs(a2.grad.cpu().numpy() - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()
