@@ -129,13 +129,13 @@ template <> struct NsStaged<true> {
     NS_LDS float *st, *gl;
     NS_LDS const int32_t *routes_l, *rlen_l;     // the route table and its rows' lengths (null: not staged)
 };
-template <int TA, bool ST, bool MS = false> struct NsArgsT : NsCommon, NsStaged<TA != 0> {    // TA: address space of the static tables (3 = staged, with rows and ghosts)
-    static constexpr bool kTB = TA == 3, kST = ST, kMS = MS;
+template <int TA, int SS, bool MS = false> struct NsArgsT : NsCommon, NsStaged<TA != 0> {    // TA: address space of the static tables (3 = staged, with rows and ghosts)
+    static constexpr bool kTB = TA == 3, kST = SS == 2, kSG = SS >= 1, kMS = MS;    // SS: 2 = state rows and cotangent planes in LDS, 1 = the planes only
 #define NS_X(name, ty, count) typename NsPtrT<TA, const ty>::type name;
     NS_TABLES(NS_X)
 #undef NS_X
 };
-typedef NsArgsT<0, false> NsArgs;              // what the host builds and every kernel receives
+typedef NsArgsT<0, 0> NsArgs;              // what the host builds and every kernel receives
 
 // (the persistent kernels read the argument block from LDS: a pointer loaded from there is generic to the compiler -- flat_load, which also
 // counts against the LDS wait counter -- unless its TYPE says that it points into global memory)
@@ -151,7 +151,7 @@ template <class A> __device__ __forceinline__ auto ns_state(const A &a, int r) {
     else return ns_glob(a.hist) + (size_t)r * 4 * a.C;
 }
 template <class A> __device__ __forceinline__ auto ns_G(const A &a, int r) {
-    if constexpr (A::kST) return a.gl + (size_t)(r & 1) * 3 * a.C;
+    if constexpr (A::kSG) return a.gl + (size_t)(r & 1) * 3 * a.C;
     else return ns_ptr<float>(a, a.lo.G) + (size_t)(r & 1) * 3 * a.C;
 }
 template <bool TB> struct NsRowT {
@@ -1422,8 +1422,8 @@ __host__ __device__ inline size_t ns_micro_state_bytes(const NsCommon &a, bool b
 // what a persistent kernel carves out of its dynamic LDS behind the phases' scratch (host and device agree through this plan):
 // byte sizes; tables + rows + misc are staged together (TB) or not at all, st + gl likewise (ST)
 struct NsPlan { int scratch, tables, rows, misc, st, gl, ms, routes; };
-template <int TA, bool ST, bool MS>
-__device__ __forceinline__ void ns_carve(NsArgsT<TA, ST, MS> &a, const NsArgs &a0, NS_LDS char *lds, const NsPlan &pl, bool bwd) {
+template <int TA, int SS, bool MS>
+__device__ __forceinline__ void ns_carve(NsArgsT<TA, SS, MS> &a, const NsArgs &a0, NS_LDS char *lds, const NsPlan &pl, bool bwd) {
     NS_LDS char *p = lds + pl.scratch;
     if constexpr (TA == 3) {
         NS_LDS char *q = p;
@@ -1447,11 +1447,9 @@ __device__ __forceinline__ void ns_carve(NsArgsT<TA, ST, MS> &a, const NsArgs &a
 #undef NS_X
         a.gh = nullptr; a.sl = nullptr; a.gg = nullptr; a.row_i = nullptr; a.row_d = nullptr; a.sg = nullptr; a.sgi = nullptr; a.ow = nullptr;
     }
-    if constexpr (ST) {
-        a.st = (NS_LDS float *)p; p += pl.st;
-        a.gl = bwd ? (NS_LDS float *)p : nullptr;
-        p += pl.gl;
-    } else { a.st = nullptr; a.gl = nullptr; }
+    a.st = nullptr; a.gl = nullptr;
+    if constexpr (SS == 2) { a.st = (NS_LDS float *)p; p += pl.st; }
+    if constexpr (SS >= 1) { a.gl = bwd ? (NS_LDS float *)p : nullptr; p += pl.gl; }
     if constexpr (TA == 3) {
         a.routes_l = nullptr; a.rlen_l = nullptr;
         if (pl.routes) {
@@ -1476,9 +1474,9 @@ __device__ __forceinline__ void ns_carve(NsArgsT<TA, ST, MS> &a, const NsArgs &a
     }
 }
 // the replica's argument block in LDS (`a_s`): everybody copies the tables, thread 0 writes the scalars and the pointers
-template <int TA, bool ST, bool MS>
-__device__ __forceinline__ void ns_persist_setup(NsArgsT<TA, ST, MS> &a_s, const NsArgs &a0, NS_LDS char *lds, const NsPlan &pl, bool bwd) {
-    NsArgsT<TA, ST, MS> tmp;
+template <int TA, int SS, bool MS>
+__device__ __forceinline__ void ns_persist_setup(NsArgsT<TA, SS, MS> &a_s, const NsArgs &a0, NS_LDS char *lds, const NsPlan &pl, bool bwd) {
+    NsArgsT<TA, SS, MS> tmp;
     static_cast<NsCommon &>(tmp) = static_cast<const NsCommon &>(a0);
     ns_replica_shift(tmp, blockIdx.x);
     ns_carve(tmp, a0, lds, pl, bwd);
@@ -1498,14 +1496,15 @@ template <class A> __device__ __forceinline__ void ns_rows_store(const A &a, int
     a.row_d[(size_t)(r & 1) * a.L + l] = v.d;
 }
 
-template <int TA, bool ST, bool MS>
+template <int TA, int SS, bool MS>
 __global__ void __launch_bounds__(kNsBlock) ns_persist_fwd_kernel(NsArgs a0, const float *__restrict__ action_all, NsPlan pl) {
     extern __shared__ double lds_p[];
     // the replica's arguments -- ~100 pointers and offsets, the staged ones as LDS pointers -- live in LDS themselves: as a local copy
     // they cost 487 scalar-register spills and 79 vector ones (scratch traffic inside every phase)
-    __shared__ NsArgsT<TA, ST, MS> a_s;
+    constexpr bool ST = SS == 2;
+    __shared__ NsArgsT<TA, SS, MS> a_s;
     ns_persist_setup(a_s, a0, (NS_LDS char *)reinterpret_cast<char *>(lds_p), pl, false);
-    const NsArgsT<TA, ST, MS> &a = a_s;
+    const NsArgsT<TA, SS, MS> &a = a_s;
     const float *action = action_all + (size_t)blockIdx.x * a0.n_action;
     const int tid = threadIdx.x, B = blockDim.x;
     const int L = a0.L, C = a0.C, T = a0.T;
@@ -1568,7 +1567,7 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_fwd_kernel(NsArgs a0, con
 #ifdef DHTS_NS_STAMPS
     if (blockIdx.x == 0 && tid == 0)
         printf("ns_persist_fwd<%d,%d> cycles per step: ghosts %lld | micro boundary + IDM %lld | cells %lld | hand-offs + loss %lld | flush %lld\n",
-               TA, (int)ST + 2 * (int)MS, st_[0] / T, st_[1] / T, st_[2] / T, st_[3] / T, st_[4] / T);
+               TA, SS + 4 * (int)MS, st_[0] / T, st_[1] / T, st_[2] / T, st_[3] / T, st_[4] / T);
     if (blockIdx.x == 0 && tid == 0)
         printf("   micro: admission %lld | head gaps %lld | IDM %lld;  hand-offs: capacitors %lld | event walk %lld | loss %lld\n",
                ns_sub_[0] / T, ns_sub_[1] / T, ns_sub_[2] / T, ns_sub_[3] / T, ns_sub_[4] / T, ns_sub_[5] / T);
@@ -1584,13 +1583,14 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_fwd_kernel(NsArgs a0, con
     ns_reward(a, reinterpret_cast<float *>(lds_p));
 }
 
-template <int TA, bool ST, bool MS>
+template <int TA, int SS, bool MS>
 __global__ void __launch_bounds__(kNsBlock) ns_persist_bwd_kernel(NsArgs a0, const float *__restrict__ action_all, const float *__restrict__ g_reward,
                                                                 float *__restrict__ g_action_all, NsPlan pl) {
     extern __shared__ double lds_p[];
-    __shared__ NsArgsT<TA, ST, MS> a_s;                             // (see ns_persist_fwd_kernel)
+    constexpr bool ST = SS == 2, SG = SS >= 1;
+    __shared__ NsArgsT<TA, SS, MS> a_s;                             // (see ns_persist_fwd_kernel)
     ns_persist_setup(a_s, a0, (NS_LDS char *)reinterpret_cast<char *>(lds_p), pl, true);
-    const NsArgsT<TA, ST, MS> &a = a_s;
+    const NsArgsT<TA, SS, MS> &a = a_s;
     const float *action = action_all + (size_t)blockIdx.x * a0.n_action;
     const int tid = threadIdx.x, B = blockDim.x;
     const int L = a0.L, C = a0.C, T = a0.T, Lm = a0.Lm;
@@ -1598,7 +1598,7 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_bwd_kernel(NsArgs a0, con
         auto z = ns_ptr<unsigned>(a, a.lo.G);
         const size_t nz = (a.lo.n_bwd - a.lo.G) / 4;
         for (size_t i = tid; i < nz; i += B) z[i] = 0u;
-        if constexpr (ST) for (int i = tid; i < 6 * C; i += B) a.gl[i] = 0.f;
+        if constexpr (SG) for (int i = tid; i < 6 * C; i += B) a.gl[i] = 0.f;
         if constexpr (MS) {
             NS_LDS unsigned *zl = (NS_LDS unsigned *)a.m_gP;
             for (size_t i = tid; i < (size_t)pl.ms / 4; i += B) zl[i] = 0u;
@@ -1674,7 +1674,7 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_bwd_kernel(NsArgs a0, con
 #ifdef DHTS_NS_STAMPS
     if (blockIdx.x == 0 && tid == 0)
         printf("ns_persist_bwd<%d,%d> cycles per step: taps + events + fold + IDM + head gaps %lld | cells %lld | ghosts %lld | gather %lld | state %lld\n",
-               TA, (int)ST + 2 * (int)MS, st_[0] / T, st_[1] / T, st_[2] / T, st_[3] / T, st_[4] / T);
+               TA, SS + 4 * (int)MS, st_[0] / T, st_[1] / T, st_[2] / T, st_[3] / T, st_[4] / T);
     if (blockIdx.x == 0 && tid == 0)
         printf("   taps %lld | events %lld | capacitor charges %lld | fold %lld | IDM %lld | head gaps %lld | admission %lld\n",
                ns_sub_[8] / T, ns_sub_[9] / T, ns_sub_[10] / T, ns_sub_[11] / T, ns_sub_[12] / T, ns_sub_[13] / T, ns_sub_[14] / T);
@@ -1796,24 +1796,25 @@ static NsPlan ns_plan(const NsArgs &a, size_t scratch, bool bwd) {
     if (pl.tables && a.Lm > 0 && ms <= left) { pl.ms = (int)ms; left -= ms; }
     const size_t st = ns_al16(sizeof(float) * 8 * (size_t)a.C), gl = bwd ? ns_al16(sizeof(float) * 6 * (size_t)a.C) : 0;
     if (a.C > 0 && st + gl <= left) { pl.st = (int)st; pl.gl = (int)gl; }
+    else if (a.C > 0 && bwd && gl <= left) pl.gl = (int)gl;          // (the planes are read AND written by four phases of a step; the state rows only read)
     return pl;
 }
 
-template <int TA, bool ST, bool MS>
+template <int TA, int SS, bool MS>
 static int ns_launch_persist_fwd(const NsArgs &a, const float *action, const NsPlan &pl, size_t lds, int n_replicas, hipStream_t st) {
     if (lds > 48 * 1024 &&
-        hipFuncSetAttribute((const void *)ns_persist_fwd_kernel<TA, ST, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        hipFuncSetAttribute((const void *)ns_persist_fwd_kernel<TA, SS, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_INVALID;
-    ns_persist_fwd_kernel<TA, ST, MS><<<n_replicas, kNsBlock, lds, st>>>(a, action, pl);
+    ns_persist_fwd_kernel<TA, SS, MS><<<n_replicas, kNsBlock, lds, st>>>(a, action, pl);
     return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
 }
-template <int TA, bool ST, bool MS>
+template <int TA, int SS, bool MS>
 static int ns_launch_persist_bwd(const NsArgs &a, const float *action, const float *g_reward, float *g_action, const NsPlan &pl, size_t lds,
                                  int n_replicas, hipStream_t st) {
     if (lds > 48 * 1024 &&
-        hipFuncSetAttribute((const void *)ns_persist_bwd_kernel<TA, ST, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        hipFuncSetAttribute((const void *)ns_persist_bwd_kernel<TA, SS, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_INVALID;
-    ns_persist_bwd_kernel<TA, ST, MS><<<n_replicas, kNsBlock, lds, st>>>(a, action, g_reward, g_action, pl);
+    ns_persist_bwd_kernel<TA, SS, MS><<<n_replicas, kNsBlock, lds, st>>>(a, action, g_reward, g_action, pl);
     return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
 }
 
@@ -1839,9 +1840,9 @@ int dhts_netstep_rollout_fwd(const dhts_net_desc *d, const dhts_netstep_tables *
         const NsPlan pl = ns_plan(a, ns_al16(lds), false);
         lds = (size_t)pl.scratch + pl.tables + pl.st + pl.gl + pl.rows + pl.misc + pl.ms + pl.routes;
         if (lds > 160 * 1024) return DHTS_E_INVALID;
-        if (pl.tables && pl.ms) return pl.st ? ns_launch_persist_fwd<3, true, true>(a, action, pl, lds, d->n_replicas, st) : ns_launch_persist_fwd<3, false, true>(a, action, pl, lds, d->n_replicas, st);
-        if (pl.tables) return pl.st ? ns_launch_persist_fwd<3, true, false>(a, action, pl, lds, d->n_replicas, st) : ns_launch_persist_fwd<3, false, false>(a, action, pl, lds, d->n_replicas, st);
-        return pl.st ? ns_launch_persist_fwd<1, true, false>(a, action, pl, lds, d->n_replicas, st) : ns_launch_persist_fwd<1, false, false>(a, action, pl, lds, d->n_replicas, st);
+        if (pl.tables && pl.ms) return pl.st ? ns_launch_persist_fwd<3, 2, true>(a, action, pl, lds, d->n_replicas, st) : ns_launch_persist_fwd<3, 0, true>(a, action, pl, lds, d->n_replicas, st);
+        if (pl.tables) return pl.st ? ns_launch_persist_fwd<3, 2, false>(a, action, pl, lds, d->n_replicas, st) : ns_launch_persist_fwd<3, 0, false>(a, action, pl, lds, d->n_replicas, st);
+        return pl.st ? ns_launch_persist_fwd<1, 2, false>(a, action, pl, lds, d->n_replicas, st) : ns_launch_persist_fwd<1, 0, false>(a, action, pl, lds, d->n_replicas, st);
     }
     // running state of the episode
     if (hipMemsetAsync(ws + a.lo.P, 0, a.lo.counters + sizeof(NsCounters) - a.lo.P, st) != hipSuccess) return DHTS_E_LAUNCH;
@@ -1887,9 +1888,12 @@ int dhts_netstep_rollout_bwd(const dhts_net_desc *d, const dhts_netstep_tables *
         const NsPlan pl = ns_plan(a, ns_al16(ns_micro_bwd_scratch(L, C, Lm, (size_t)Lm * a.cap)), true);
         const size_t lds = (size_t)pl.scratch + pl.tables + pl.st + pl.gl + pl.rows + pl.misc + pl.ms + pl.routes;
         if (lds > 160 * 1024) return DHTS_E_INVALID;
-        if (pl.tables && pl.ms) return pl.st ? ns_launch_persist_bwd<3, true, true>(a, action, g_reward, g_action, pl, lds, d->n_replicas, st) : ns_launch_persist_bwd<3, false, true>(a, action, g_reward, g_action, pl, lds, d->n_replicas, st);
-        if (pl.tables) return pl.st ? ns_launch_persist_bwd<3, true, false>(a, action, g_reward, g_action, pl, lds, d->n_replicas, st) : ns_launch_persist_bwd<3, false, false>(a, action, g_reward, g_action, pl, lds, d->n_replicas, st);
-        return pl.st ? ns_launch_persist_bwd<1, true, false>(a, action, g_reward, g_action, pl, lds, d->n_replicas, st) : ns_launch_persist_bwd<1, false, false>(a, action, g_reward, g_action, pl, lds, d->n_replicas, st);
+#define NS_BWD(TA_, SS_, MS_) ns_launch_persist_bwd<TA_, SS_, MS_>(a, action, g_reward, g_action, pl, lds, d->n_replicas, st)
+        const int ss = pl.st ? 2 : (pl.gl ? 1 : 0);
+        if (pl.tables && pl.ms) return ss == 2 ? NS_BWD(3, 2, true) : (ss == 1 ? NS_BWD(3, 1, true) : NS_BWD(3, 0, true));
+        if (pl.tables) return ss == 2 ? NS_BWD(3, 2, false) : (ss == 1 ? NS_BWD(3, 1, false) : NS_BWD(3, 0, false));
+        return ss == 2 ? NS_BWD(1, 2, false) : (ss == 1 ? NS_BWD(1, 1, false) : NS_BWD(1, 0, false));
+#undef NS_BWD
     }
     // cotangents start at zero; the lanes hold what the forward left (lane_n)
     if (hipMemsetAsync(ws + a.lo.G, 0, a.lo.n_bwd - a.lo.G, st) != hipSuccess) return DHTS_E_LAUNCH;

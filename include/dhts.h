@@ -505,8 +505,12 @@ typedef struct dhts_netstep_tables {
     int32_t max_events;                /* capacity of the hand-off event list of an episode (0 = 8 per step) */
     /* persistent != 0: the PERSISTENT form -- one kernel per direction, one workgroup per replica, all T steps, the workgroup's
      * threads looping over the network's items with workgroup barriers where the stepwise form has kernel boundaries (same device
-     * functions: same numbers).  ~10 us per step (forward + reverse) at 360 lanes / 2 124 cells against ~100 us of launches; the
+     * functions: same numbers).  ~30 us per step (forward + reverse) at 360 lanes / 2 124 cells against ~80 us of launches; the
      * one workgroup is the limit (beyond ~10 items per thread the stepwise form, which spreads a step over the chip, wins).
+     * What fits a workgroup's LDS is kept there for the whole episode (static tables, per-step table rows, ghosts, the step's signals,
+     * routes; the state rows and cotangent planes; the vehicle slots [n_micro][lane_capacity] and their cotangents): size
+     * hyb.lane_capacity to the lanes (longest micro lane in vehicles + 2, dhts/stepwise.py default_lane_capacity) rather than to 32.
+     * cell_lane is read by BOTH forms (the queue loss runs a thread per cell).
      * n_replicas > 1 is allowed then: action [R][A], hist [R][T + 1][4][C], queue [R][T][L], reward [R][2], counts [R][4],
      * g_reward [R], g_action [R][A]; per-replica [T][L] tables through hyb.net.replica_stride / hyb.draws_stride as in
      * dhts_net_hybrid_rollout_fwd.  if_lane [n_cells + ARZ lanes] (device): the lane of interface item lane_off[l] + lane_gpos[l] +
