@@ -562,8 +562,8 @@ class ItscpStepwiseWorkload(ItscpHybridWorkload):
     252 lanes (28 IDM lanes), 1 152 cells, 240 steps, 36 actions -- x 64 replicas (own problem_1 inflow schedules and actions) on the
     stepwise path's persistent kernels (dhts_netstep_rollout_fwd / _bwd, one workgroup per replica; dhts/stepwise.py).  Not a BASELINE
     configuration: the reference's CLI reaches it with two flags, and until round 5 it ran lane by lane (minutes per episode)."""
-    limiter = {"rollout_fwd": "latency (dependent look-ups of the phases of 240 steps, one workgroup per replica)",
-               "rollout_bwd": "latency (dependent look-ups of the phases of 240 steps, one workgroup per replica)"}
+    limiter = {"rollout_fwd": "instruction issue + barriers of ONE compute unit per replica (16 wavefronts, ~17 phases per step, 240 steps; DESIGN section 9)",
+               "rollout_bwd": "instruction issue + barriers of ONE compute unit per replica (16 wavefronts, 240 steps; DESIGN section 9)"}
 
     def moved_bytes_per_launch(self):
         """blocks dqs[c][3][2][2] (48 B) + state history (16 B) + loss constant (4 B) per cell-step, queue terms per lane-step"""
