@@ -128,6 +128,7 @@ template <> struct NsStaged<true> {
     NS_LDS double *row_d;        // [2][L]: schedule
     NS_LDS float *st, *gl;
     NS_LDS const int32_t *routes_l, *rlen_l;     // the route table and its rows' lengths (null: not staged)
+    NS_LDS const double *lane_cc, *lane_cfl;     // dt / dx and dx / dt of every lane (TB: a cell item would divide twice for them)
 };
 template <int TA, int SS, bool MS = false> struct NsArgsT : NsCommon, NsStaged<TA != 0> {    // TA: address space of the static tables (3 = staged, with rows and ghosts)
     static constexpr bool kTB = TA == 3, kST = SS == 2, kSG = SS >= 1, kMS = MS;    // SS: 2 = state rows and cotangent planes in LDS, 1 = the planes only
@@ -1332,13 +1333,23 @@ __device__ __forceinline__ void ns_replica_shift(NsCommon &a, int rep) {       /
 // One cell of step t: BOTH its interfaces (ARZ.riemann_solve + the two Jacobian products each, redone by the neighbouring cell's
 // thread: a solve costs less than handing its result over), Godunov update, float32 glue, the cell's three blocks (MacroLane.forward,
 // _macro_lane.py:83-146; dMacroLane._backward, dmacro_lane.py:96-132) -- the operations of the straight-lane operator's kernel
-template <class A> __device__ __forceinline__ void ns_cell_item(const A &a, int t, int c, int &fault_step, int &fault_lane, int &fault_index) {
+// kc0: the interface constants that depend on the speed limit and dt alone (the persistent kernels evaluate them once, in LDS)
+template <class A> __device__ __forceinline__ void ns_cell_item(const A &a, const IfaceConst &kc0, int t, int c, int &fault_step, int &fault_lane,
+                                                                int &fault_index) {
     const int C = a.C;
     const int l = a.cell_lane[c];
     const int off = a.lane_off[l], n = a.lane_ncell[l];
     const int k = c - off;
     const double dx = a.lane_dx[l];
-    const double cc = a.dt_d / dx;
+    double cc;
+    IfaceConst kc = kc0;
+    if constexpr (A::kTB) {
+        cc = a.lane_cc[l];
+        kc.dx = dx; kc.cfl_lim = a.lane_cfl[l]; kc.cfl_lim2 = 2.0 * kc.cfl_lim; kc.lim_ok = 1e-5 < kc.cfl_lim;
+    } else {
+        cc = a.dt_d / dx;
+        kc.set_grid(a.dt_d, dx);
+    }
     const auto cur = ns_state(a, t);
     const auto nxt = ns_state(a, t + 1);
     const auto gh = ns_ghosts(a) + (size_t)a.lane_gpos[l] * 8;
@@ -1348,8 +1359,6 @@ template <class A> __device__ __forceinline__ void ns_cell_item(const A &a, int 
     else { rL = cur[c - 1]; yL = cur[C + c - 1]; uL = cur[2 * C + c - 1]; qL = cur[3 * C + c - 1]; }
     if (k == n - 1) { rR = gh[4]; yR = gh[5]; uR = gh[6]; qR = gh[7]; }
     else { rR = cur[c + 1]; yR = cur[C + c + 1]; uR = cur[2 * C + c + 1]; qR = cur[3 * C + c + 1]; }
-    IfaceConst kc;
-    kc.set_um(a.um_d); kc.set_grid(a.dt_d, dx);
     Iface fl, fr;
     arz_interface(rL, yL, uL, qL, r0, y0, u0, q0, kc, fl);
     arz_interface(r0, y0, u0, q0, rR, yR, uR, qR, kc, fr);
@@ -1434,6 +1443,11 @@ __device__ __forceinline__ void ns_carve(NsArgsT<TA, SS, MS> &a, const NsArgs &a
 #undef NS_X
         p += pl.tables;
         a.row_d = (NS_LDS double *)p; a.row_i = (NS_LDS int32_t *)(p + ns_al16(16 * (size_t)a.L));
+        if (!bwd) {
+            NS_LDS double *cc_ = (NS_LDS double *)(p + ns_al16(16 * (size_t)a.L) + ns_al16(32 * (size_t)a.L)), *cfl_ = cc_ + a.L;
+            for (int l = threadIdx.x; l < a.L; l += blockDim.x) { const double dx = a0.lane_dx[l]; cc_[l] = a.dt_d / dx; cfl_[l] = dx / a.dt_d; }
+            a.lane_cc = cc_; a.lane_cfl = cfl_;
+        } else { a.lane_cc = nullptr; a.lane_cfl = nullptr; }
         p += pl.rows;
         const size_t lg = ns_al16(32 * (size_t)a.L);
         if (bwd) { a.gg = (NS_LDS double *)p; a.sl = (NS_LDS float *)(p + lg); a.gh = nullptr; }
@@ -1503,6 +1517,8 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_fwd_kernel(NsArgs a0, con
     // they cost 487 scalar-register spills and 79 vector ones (scratch traffic inside every phase)
     constexpr bool ST = SS == 2;
     __shared__ NsArgsT<TA, SS, MS> a_s;
+    __shared__ IfaceConst kc0_s;
+    if (threadIdx.x == 0) { IfaceConst k0; k0.set_um(a0.um_d); k0.set_grid(a0.dt_d, 1.0); kc0_s = k0; }
     ns_persist_setup(a_s, a0, (NS_LDS char *)reinterpret_cast<char *>(lds_p), pl, false);
     const NsArgsT<TA, SS, MS> &a = a_s;
     const float *action = action_all + (size_t)blockIdx.x * a0.n_action;
@@ -1552,7 +1568,7 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_fwd_kernel(NsArgs a0, con
         ns_micro_fwd(a, t, action, reinterpret_cast<float *>(lds_p));
         __syncthreads();
         NS_STAMP(1)
-        for (int c = tid; c < C; c += B) ns_cell_item(a, t, c, fault_step, fault_lane, fault_index);
+        for (int c = tid; c < C; c += B) ns_cell_item(a, kc0_s, t, c, fault_step, fault_lane, fault_index);
         __syncthreads();
         NS_STAMP(2)
         ns_convert(a, t, reinterpret_cast<int *>(lds_p));
@@ -1787,7 +1803,7 @@ static NsArgs ns_args(const dhts_net_desc *d, const dhts_netstep_tables *t, int 
 static NsPlan ns_plan(const NsArgs &a, size_t scratch, bool bwd) {
     NsPlan pl = {(int)scratch, 0, 0, 0, 0, 0, 0, 0};
     size_t left = 158 * 1024 - scratch;          // (the kernels' static LDS -- argument block, scan scratch -- stays below 2 KB)
-    const size_t tables = ns_stage_bytes(a), rows = ns_al16(16 * (size_t)a.L) + ns_al16(32 * (size_t)a.L);
+    const size_t tables = ns_stage_bytes(a), rows = ns_al16(16 * (size_t)a.L) + ns_al16(32 * (size_t)a.L) + (bwd ? 0 : ns_al16(16 * (size_t)a.L));
     const size_t misc = (bwd ? 2 : 1) * ns_al16(32 * (size_t)a.L) + ns_al16(32 * (size_t)a.sq + 16) + (bwd ? 0 : ns_al16(16 * (size_t)a.L));
     if (tables + rows + misc <= left) { pl.tables = (int)tables; pl.rows = (int)rows; pl.misc = (int)misc; left -= tables + rows + misc; }
     const size_t routes = ns_al16(4 * (size_t)a.n_routes * a.route_stride) + ns_al16(4 * (size_t)a.n_routes);
