@@ -1558,10 +1558,11 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_fwd_kernel(NsArgs a0, con
 #define NS_STAMP(i)
 #endif
     for (int t = 0; t < T; ++t) {
-        // the next step's table rows: fetched now (one lane per thread; further lanes of wider networks at the end of the step)
-        NsRowRegs nx;
-        const bool pre = TA == 3 && t + 1 < T && tid < L;
-        if (pre) ns_rows_fetch(a, t + 1, tid, nx);
+        // the next step's table rows into the copy this step does not read -- by the LAST wavefronts (lane l by thread B - 1 - l), which have
+        // no ghost item: held in registers across the step they were spilled, five dependent global loads at the head of every step
+        if constexpr (TA == 3) {
+            if (t + 1 < T) for (int l = B - 1 - tid; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, t + 1, l, v); ns_rows_store(a, t + 1, l, v); }
+        }
         if (t + 1 < T) for (int q = B - 1 - tid; q < a0.sq; q += B) ns_signal_fill(a, action, t + 1, q);      // (the last wavefront: idle in the ghost phase)
         for (int j = tid; j < ns_ghost_items(L); j += B) ns_ghost_fwd_item(a, t, action, j);
         NS_STAMP(0)
@@ -1573,10 +1574,6 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_fwd_kernel(NsArgs a0, con
         NS_STAMP(2)
         ns_convert(a, t, reinterpret_cast<int *>(lds_p));
         NS_STAMP(3)
-        if constexpr (TA == 3) {
-            if (pre) ns_rows_store(a, t + 1, tid, nx);
-            if (t + 1 < T) for (int l = tid + B; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, t + 1, l, v); ns_rows_store(a, t + 1, l, v); }
-        }
         __syncthreads();
         NS_STAMP(4)
     }
@@ -1641,9 +1638,9 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_bwd_kernel(NsArgs a0, con
 #endif
     const int n_max = ns_ptr<NsCounters>(a, a.lo.counters)->n_max;
     for (int t = T - 1; t >= 0; --t) {
-        NsRowRegs nx;
-        const bool pre = TA == 3 && t >= 1 && tid < L;
-        if (pre) ns_rows_fetch(a, t - 1, tid, nx);
+        if constexpr (TA == 3) {             // (see ns_persist_fwd_kernel)
+            if (t >= 1) for (int l = B - 1 - tid; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, t - 1, l, v); ns_rows_store(a, t - 1, l, v); }
+        }
         if (t >= 1) for (int q = B - 1 - tid; q < a0.sq; q += B) ns_signal_fill(a, action, t - 1, q);
         ns_micro_bwd(a, t, action, g_reward ? g_reward + blockIdx.x : nullptr, lds_p, n_max);
         __syncthreads();
@@ -1679,10 +1676,6 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_bwd_kernel(NsArgs a0, con
                 auto hr = ns_glob(a.hist) + (size_t)(t - 1) * 4 * C;
                 for (int i = tid; i < 4 * C; i += B) sr[i] = hr[i];
             }
-        }
-        if constexpr (TA == 3) {
-            if (pre) ns_rows_store(a, t - 1, tid, nx);
-            if (t >= 1) for (int l = tid + B; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, t - 1, l, v); ns_rows_store(a, t - 1, l, v); }
         }
         __syncthreads();
         NS_STAMP(4)
