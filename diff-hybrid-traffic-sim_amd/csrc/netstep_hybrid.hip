@@ -1313,11 +1313,15 @@ __global__ void ns_ghosts_gather_kernel(NsArgs a, int t, int lane_blocks) {     
 // =====================================================================================================================
 // PERSISTENT form (round 5): the same step -- the very device functions above -- inside ONE kernel per direction, one workgroup per
 // network replica, all T steps, workgroup barriers where the stepwise form has kernel boundaries.  The workgroup's threads loop
-// over the network's items (ghosts, interfaces, cells: a few per thread for the grids the reference builds); the state of a step
-// is the history row in HBM (L2-resident: tens of KB), interface results and the blocks dqs[c][3][2][2] (dMacroLane._backward,
-// dmacro_lane.py:96-132) go through the replica's workspace.  No cross-workgroup exchange exists, so nothing spins; replicas are
-// independent workgroups (BASELINE config 5's pattern for networks beyond the fused kernels' one-item-per-thread limits).
-// A step costs its phases' latencies (~10 us forward + reverse for 360 lanes / 2 124 cells) instead of ~100 us of launches.
+// over the network's items (ghosts, cells, samples, vehicle slots: a few per thread for the grids the reference builds).  No
+// cross-workgroup exchange exists, so nothing spins; replicas are independent workgroups (BASELINE config 5's pattern for networks
+// beyond the fused kernels' one-item-per-thread limits).  What fits the workgroup's LDS stays there for the episode -- ns_plan picks
+// the instantiation <TA, SS, MS>: TA = 3 the static tables, the per-step table rows (double-buffered, fetched one step ahead by the
+// last wavefronts), ghosts / slots / ghost cotangents, the step's signal table, the routes; SS = 2 the state rows and cotangent
+// planes, 1 the planes alone; MS the micro side's running state -- and is reached through address_space(3) pointers (ds_read); the
+// rest through address_space(1) pointers into the workspace and the history (tape rows, event list, running-mean streams).
+// A step costs its phases' instruction issue on one compute unit: ~17 + 14 us at 252 lanes / 1 152 cells / 28 IDM lanes (DESIGN
+// section 9 lists the phases) against ~80 us of launches in the stepwise form.
 // =====================================================================================================================
 __device__ __forceinline__ void ns_replica_shift(NsCommon &a, int rep) {       // the arrays replica `rep` owns
     a.hist += (size_t)rep * (a.T + 1) * 4 * (a.C > 0 ? a.C : 1);
