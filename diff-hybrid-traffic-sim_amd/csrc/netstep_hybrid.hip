@@ -252,29 +252,41 @@ __shared__ long long ns_sub_[24], ns_sub_last_;
 #define NS_SUB(i)
 #endif
 
-// ---- forward-mode duals of the head gap: value + ONE component of the gradient w.r.t. (p_h, v_h, p_l, v_l, s_prev, s_cur, s_next) --
-// eight threads share a lane's head gap, thread q carries component q (the values are computed by all of them, bit for bit alike);
-// every component follows the float32 rule of the reference's operator (sum, product, quotient, sigmoid), so the VALUES are the
-// reference's bit for bit
-struct D1 { float v, g; };
-__device__ __forceinline__ D1 dq_c(float v) { D1 x; x.v = v; x.g = 0.f; return x; }
-__device__ __forceinline__ D1 dq_var(float v, int i, int q) { D1 x; x.v = v; x.g = i == q ? 1.f : 0.f; return x; }
-__device__ __forceinline__ D1 dq_add(D1 a, D1 b) { D1 x; x.v = a.v + b.v; x.g = a.g + b.g; return x; }
-__device__ __forceinline__ D1 dq_sub(D1 a, D1 b) { D1 x; x.v = a.v - b.v; x.g = a.g - b.g; return x; }
-__device__ __forceinline__ D1 dq_mul(D1 a, D1 b) { D1 x; x.v = a.v * b.v; x.g = a.g * b.v + b.g * a.v; return x; }
-__device__ __forceinline__ D1 dq_div(D1 a, D1 b) {
-    D1 x; x.v = a.v / b.v;
+// ---- forward-mode duals of the head gap: value + gradient w.r.t. (p_h, v_h, p_l, v_l, s_prev, s_cur, s_next); every component follows
+// the float32 rule of the reference's operator (sum, product, quotient, sigmoid), so the VALUES are the reference's bit for bit.
+// (Eight threads per lane with one component each were tried in round 5: no faster at 28 lanes -- the phase's cost were its scans --
+// and two passes instead of one at 144.)
+struct D7 { float v; float g[7]; };
+__device__ __forceinline__ D7 d7_c(float v) { D7 x; x.v = v;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x.g[i] = 0.f;
+    return x; }
+__device__ __forceinline__ D7 d7_var(float v, int i) { D7 x = d7_c(v); x.g[i] = 1.f; return x; }
+__device__ __forceinline__ D7 d7_add(D7 a, D7 b) { D7 x; x.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x.g[i] = a.g[i] + b.g[i];
+    return x; }
+__device__ __forceinline__ D7 d7_sub(D7 a, D7 b) { D7 x; x.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x.g[i] = a.g[i] - b.g[i];
+    return x; }
+__device__ __forceinline__ D7 d7_mul(D7 a, D7 b) { D7 x; x.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x.g[i] = a.g[i] * b.v + b.g[i] * a.v;
+    return x; }
+__device__ __forceinline__ D7 d7_div(D7 a, D7 b) { D7 x; x.v = a.v / b.v;
     const float ia = 1.f / b.v, ib = -((a.v / b.v) / b.v);
-    x.g = a.g * ia + b.g * ib;
-    return x;
-}
-__device__ __forceinline__ D1 dq_soft(D1 a, float k) {          // dmath.operation.sigmoid(value, constant = k)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x.g[i] = a.g[i] * ia + b.g[i] * ib;
+    return x; }
+__device__ __forceinline__ D7 d7_soft(D7 a, float k) {          // dmath.operation.sigmoid(value, constant = k)
     float s, ds;
     soft_switch_both(a.v, k, s, ds);
-    D1 x; x.v = s; x.g = a.g * ds;
-    return x;
-}
-__device__ __forceinline__ D1 dq_pos_or_zero(D1 a) { return a.v > 0.f ? a : dq_c(0.f); }     // x if x > 0 else 0.0
+    D7 x; x.v = s;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x.g[i] = a.g[i] * ds;
+    return x; }
+__device__ __forceinline__ D7 d7_pos_or_zero(D7 a) { return a.v > 0.f ? a : d7_c(0.f); }     // x if x > 0 else 0.0
 
 // The signals of a step: every ghost, head gap and their adjoints need the green of some lane = one of the two switches of its
 // intersection (phase_signal_at: divisions, two sigmoids).  The staging persistent kernels evaluate them ONCE per intersection and step
@@ -462,22 +474,24 @@ template <class A> __device__ __forceinline__ void ns_micro_fwd(const A &a, int 
         }
         __syncthreads();
         if (tid == 0) cnt->draws_used = used0 + carry;
+        __syncthreads();
     } else if (adm) {
-        for (int m = tid; m < Lm; m += B) adm[m] = 0;
-    }
-    __syncthreads();
+        for (int m = tid; m < Lm; m += B) adm[m] = 0;      // (nothing the head gaps read: no barrier -- in the persistent kernel the wavefronts
+    }                                                      //  without a ghost item start on the head gaps while the others blend ghosts)
 
     NS_SUB(0)
     // ---- head gaps (lane-id order for the running mean of the final signal) ----
     auto hgrow = hard ? nullptr : ns_ptr<NsHeadGap>(a, a.lo.hg) + (size_t)t * Lm;
     auto sigS = ns_ptr<double>(a, a.lo.sigS);
-    long long sig_n0 = cnt->sig_n;
+    long long sig_n0 = cnt->sig_n;                     // (written again behind this phase's scans: their barriers order it)
     double sig_sum0 = cnt->sig_sum;
-    __syncthreads();
-    for (int base = 0; base < 8 * Lm; base += B) {
-        const int m = (base + tid) >> 3, q = tid & 7;            // thread q of a lane's eight: gradient component q (q = 7: the record's tail)
+    // the items sit at the END of the workgroup when they fit one pass (the first wavefronts hold the ghost items); thread order = lane order
+    const int item0 = Lm <= B ? B - ((Lm + 63) & ~63) : 0;
+    for (int base = 0; base < Lm; base += B) {
+        const int item = base + tid - item0;
+        const int m = item >= 0 ? item : Lm;
         bool occ = false;
-        D1 green_dp = dq_c(1000.f), green_dv = dq_c(0.f), red_dp = dq_c(0.f), fin = dq_c(0.f);
+        D7 green_dp = d7_c(1000.f), green_dv = d7_c(0.f), red_dp = d7_c(0.f), fin = d7_c(0.f);
         int leader = -1, sgl[3] = {-1, -1, -1};
         if (m < Lm) {
             const int n = lane_n[m];
@@ -485,44 +499,44 @@ template <class A> __device__ __forceinline__ void ns_micro_fwd(const A &a, int 
                 occ = true;
                 const int l = a.micro_lanes[m];
                 const size_t hs = (size_t)m * cap + n - 1;
-                const D1 hp = dq_var(P0[hs], 0, q), hv = dq_var(V0[hs], 1, q);
+                const D7 hp = d7_var(P0[hs], 0), hv = d7_var(V0[hs], 1);
                 const int rrow = vroute[hs];
                 const int cursor = vcur[hs];
                 const int rlen = ns_route_len(a, rrow);
-                const D1 Lc = dq_c((float)a.lane_len[l]);
+                const D7 Lc = d7_c((float)a.lane_len[l]);
                 // leader further along the route (road_network.py:459-580)
-                D1 reach = dq_sub(dq_sub(Lc, hp), dq_c(vlen * 0.5f));
+                D7 reach = d7_sub(d7_sub(Lc, hp), d7_c(vlen * 0.5f));
                 for (int k = cursor; k < rlen - 1; k++) {
                     const int there = ns_route_at(a, rrow, k + 1);
                     if (a.lane_macro[there]) break;
                     const int ms = a.lane_mslot[there];
                     if (lane_n[ms]) {
                         const size_t ts = (size_t)ms * cap;
-                        const D1 lp = dq_var(P0[ts], 2, q), lv = dq_var(V0[ts], 3, q);
-                        const D1 gap = dq_add(reach, dq_sub(lp, dq_c(vlen * 0.5f)));
-                        green_dp = dq_pos_or_zero(gap);
-                        green_dv = dq_sub(hv, lv);
+                        const D7 lp = d7_var(P0[ts], 2), lv = d7_var(V0[ts], 3);
+                        const D7 gap = d7_add(reach, d7_sub(lp, d7_c(vlen * 0.5f)));
+                        green_dp = d7_pos_or_zero(gap);
+                        green_dv = d7_sub(hv, lv);
                         leader = ms;
                         break;
                     }
-                    reach = dq_add(reach, dq_c((float)a.lane_len[there]));
+                    reach = d7_add(reach, d7_c((float)a.lane_len[there]));
                 }
                 // red light: stop line at the lane end (_simulator.py:188-194)
-                red_dp = dq_pos_or_zero(dq_sub(dq_sub(Lc, hp), dq_c(vlen * 0.5f)));
+                red_dp = d7_pos_or_zero(d7_sub(d7_sub(Lc, hp), d7_c(vlen * 0.5f)));
                 const bool prev_exist = cursor > 0, next_exist = cursor < rlen - 1;
-                D1 prev_s = dq_c(0.f), next_s = dq_c(0.f);
-                if (prev_exist && !hard) prev_s = dq_soft(dq_sub(dq_c(0.f), hp), 16.f);
-                const D1 curr_s = hard ? dq_c(1.f) : dq_mul(dq_soft(hp, 16.f), dq_soft(dq_sub(Lc, hp), 16.f));
-                if (next_exist && !hard) next_s = dq_soft(dq_sub(hp, Lc), 16.f);
-                const D1 total = dq_add(dq_add(prev_s, curr_s), next_s);
+                D7 prev_s = d7_c(0.f), next_s = d7_c(0.f);
+                if (prev_exist && !hard) prev_s = d7_soft(d7_sub(d7_c(0.f), hp), 16.f);
+                const D7 curr_s = hard ? d7_c(1.f) : d7_mul(d7_soft(hp, 16.f), d7_soft(d7_sub(Lc, hp), 16.f));
+                if (next_exist && !hard) next_s = d7_soft(d7_sub(hp, Lc), 16.f);
+                const D7 total = d7_add(d7_add(prev_s, curr_s), next_s);
                 for (int w = 0; w < 3; w++) {
                     if ((w == 0 && !prev_exist) || (w == 2 && !next_exist)) continue;
                     const int lid = ns_route_at(a, rrow, cursor + w - 1);
-                    const D1 sc = w == 0 ? prev_s : (w == 1 ? curr_s : next_s);
-                    D1 sv;
-                    if (a.sig_kind[lid] == 0) sv = dq_c(1.f);
-                    else { sv = dq_var(ns_lane_signal(a, action, t, lid, hard, nullptr, nullptr), 4 + w, q); sgl[w] = lid; }
-                    fin = dq_add(fin, dq_mul(dq_div(sc, total), sv));
+                    const D7 sc = w == 0 ? prev_s : (w == 1 ? curr_s : next_s);
+                    D7 sv;
+                    if (a.sig_kind[lid] == 0) sv = d7_c(1.f);
+                    else { sv = d7_var(ns_lane_signal(a, action, t, lid, hard, nullptr, nullptr), 4 + w); sgl[w] = lid; }
+                    fin = d7_add(fin, d7_mul(d7_div(sc, total), sv));
                 }
             }
         }
@@ -533,29 +547,31 @@ template <class A> __device__ __forceinline__ void ns_micro_fwd(const A &a, int 
             if (occ) { const bool green = fin.v >= 0.5f; hdp = green ? green_dp.v : red_dp.v; hdv = green ? green_dv.v : 0.f; }
         } else {
             int tot_n; double tot_s;
-            const bool mine = occ && q == 0;                         // (a lane counts once; its eight threads read the same prefix)
             int rank; double incl;
-            ns_block_scan2<int, double>(mine ? 1 : 0, mine ? (double)fin.v : 0., scan_i, scan_d, rank, incl, tot_n, tot_s);
+            ns_block_scan2<int, double>(occ ? 1 : 0, occ ? (double)fin.v : 0., scan_i, scan_d, rank, incl, tot_n, tot_s);
             NS_SUB(17)
             if (occ) {
                 const long long i = sig_n0 + rank - 1;               // 0-based index of this sample in the stream
                 const double S = sig_sum0 + incl;
-                if (q == 0) sigS[i] = S;
+                sigS[i] = S;
                 const double mean = (i + 1 > kNsWindow) ? (S - sigS[i - kNsWindow]) / (double)kNsWindow : S / (double)(i + 1);
                 const float k2 = 32.f / fabsf((float)mean);
-                const D1 fs = dq_soft(dq_sub(fin, dq_c(0.5f)), k2);
-                const D1 one_m = dq_sub(dq_c(1.f), fs);
-                const D1 o_dp = dq_add(dq_mul(green_dp, fs), dq_mul(red_dp, one_m));
-                const D1 o_dv = dq_add(dq_mul(green_dv, fs), dq_mul(dq_c(0.f), one_m));
+                const D7 fs = d7_soft(d7_sub(fin, d7_c(0.5f)), k2);
+                const D7 one_m = d7_sub(d7_c(1.f), fs);
+                const D7 o_dp = d7_add(d7_mul(green_dp, fs), d7_mul(red_dp, one_m));
+                const D7 o_dv = d7_add(d7_mul(green_dv, fs), d7_mul(d7_c(0.f), one_m));
                 hdp = o_dp.v; hdv = o_dv.v;
-                if (q < 7) { hgrow[m].jp[q] = o_dp.g; hgrow[m].jv[q] = o_dv.g; }
-                else { hgrow[m].leader = leader; hgrow[m].sig[0] = sgl[0]; hgrow[m].sig[1] = sgl[1]; hgrow[m].sig[2] = sgl[2]; hgrow[m].valid = 1; hgrow[m].pad = 0; }
-            } else if (m < Lm && q == 7) {
+                NsHeadGap h;
+#pragma unroll
+                for (int q = 0; q < 7; ++q) { h.jp[q] = o_dp.g[q]; h.jv[q] = o_dv.g[q]; }
+                h.leader = leader; h.sig[0] = sgl[0]; h.sig[1] = sgl[1]; h.sig[2] = sgl[2]; h.valid = 1; h.pad = 0;
+                hgrow[m] = h;
+            } else if (m < Lm) {
                 hgrow[m].valid = 0;
             }
             sig_n0 += tot_n; sig_sum0 += tot_s;
         }
-        if (m < Lm && q == 0) { hd_s[2 * m] = hdp; hd_s[2 * m + 1] = hdv; }
+        if (m < Lm) { hd_s[2 * m] = hdp; hd_s[2 * m + 1] = hdv; }
     }
     __syncthreads();
     if (tid == 0 && !hard) { cnt->sig_n = sig_n0; cnt->sig_sum = sig_sum0; }
@@ -1562,10 +1578,11 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_fwd_kernel(NsArgs a0, con
 #define NS_STAMP(i)
 #endif
     for (int t = 0; t < T; ++t) {
-        // the next step's table rows into the copy this step does not read -- by the LAST wavefronts (lane l by thread B - 1 - l), which have
-        // no ghost item: held in registers across the step they were spilled, five dependent global loads at the head of every step
+        // the next step's table rows into the copy this step does not read -- by the MIDDLE wavefronts (lane l by thread B / 2 + l), which
+        // have neither a ghost item (the first wavefronts) nor a head gap (the last): held in registers across the step they were
+        // spilled, five dependent global loads at the head of every step
         if constexpr (TA == 3) {
-            if (t + 1 < T) for (int l = B - 1 - tid; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, t + 1, l, v); ns_rows_store(a, t + 1, l, v); }
+            if (t + 1 < T) for (int l = (tid + B / 2) % B; l < L; l += B) { NsRowRegs v; ns_rows_fetch(a, t + 1, l, v); ns_rows_store(a, t + 1, l, v); }
         }
         if (t + 1 < T) for (int q = B - 1 - tid; q < a0.sq; q += B) ns_signal_fill(a, action, t + 1, q);      // (the last wavefront: idle in the ghost phase)
         for (int j = tid; j < ns_ghost_items(L); j += B) ns_ghost_fwd_item(a, t, action, j);
