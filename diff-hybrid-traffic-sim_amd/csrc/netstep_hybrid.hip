@@ -1776,7 +1776,7 @@ static bool ns_ok(const dhts_net_desc *d, const dhts_netstep_tables *t) {
     if (!d || !t) return false;
     const dhts_hybrid_tables &h = t->hyb;
     const int cap = h.lane_capacity > 0 ? h.lane_capacity : 16;
-    return (d->n_replicas == 1 || (t->persistent && d->n_replicas > 1)) && (d->n_cells == 0 || (t->if_lane && t->cell_lane)) &&
+    return (d->n_replicas == 1 || (t->persistent && d->n_replicas > 1)) && (d->n_cells == 0 || t->cell_lane) &&
            d->n_lanes > 0 && d->n_cells >= 0 && d->n_steps > 0 && d->n_inter_sq > 0 && d->frames_per_phase > 0 &&
            d->n_action >= d->n_inter_sq && d->dt > 0 && d->u_max > 0 && d->vehicle_length > 0 && cap <= 1024 && h.n_micro >= 0 &&
            h.net.lane_ncell && h.net.lane_off && h.net.sig_kind && h.net.inter && h.net.lane_dx && h.net.left_src && h.net.left_gate &&

@@ -513,8 +513,9 @@ typedef struct dhts_netstep_tables {
      * cell_lane is read by BOTH forms (the queue loss runs a thread per cell).
      * n_replicas > 1 is allowed then: action [R][A], hist [R][T + 1][4][C], queue [R][T][L], reward [R][2], counts [R][4],
      * g_reward [R], g_action [R][A]; per-replica [T][L] tables through hyb.net.replica_stride / hyb.draws_stride as in
-     * dhts_net_hybrid_rollout_fwd.  if_lane [n_cells + ARZ lanes] (device): the lane of interface item lane_off[l] + lane_gpos[l] +
-     * k, k = 0 .. n; cell_lane [n_cells] (device): the lane of every cell (group-major order). */
+     * dhts_net_hybrid_rollout_fwd.  cell_lane [n_cells] (device): the lane of every cell (group-major order), required whenever
+     * n_cells > 0; if_lane [n_cells + ARZ lanes] (device): the lane of interface item lane_off[l] + lane_gpos[l] + k, k = 0 .. n --
+     * not read by the kernels as they stand (a cell's thread solves both its interfaces), may be NULL. */
     const int32_t *if_lane, *cell_lane;
     int32_t persistent;
     int32_t n_inter_slots;             /* length of inter_idx (the persistent kernels stage the static tables in LDS) */
