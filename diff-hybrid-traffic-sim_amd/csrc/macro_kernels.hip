@@ -1640,6 +1640,8 @@ extern "C" int dhts_debug_fwd3_stamps(long long *out) {       // [16 workgroups]
 }
 #endif
 
+extern int dhts_netstep_lds_kb;      // netstep_hybrid.hip
+
 extern "C" {
 
 int dhts_set_option(int option, int value) {
@@ -1653,6 +1655,10 @@ int dhts_set_option(int option, int value) {
     }
     if (option == DHTS_OPT_MACRO_FWD_ROTATE && (value == 0 || value == 1)) {
         dhts_fwd_rotate = value;
+        return DHTS_OK;
+    }
+    if (option == DHTS_OPT_NETSTEP_LDS_KB && (value == 0 || (value >= 1 && value <= 158))) {
+        dhts_netstep_lds_kb = value;
         return DHTS_OK;
     }
     if (option == DHTS_OPT_MACRO_FWD_GROUP && (value == 0 || value == 1 || value == 2 || value == 4)) {

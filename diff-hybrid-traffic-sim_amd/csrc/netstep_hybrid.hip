@@ -1814,9 +1814,11 @@ static NsArgs ns_args(const dhts_net_desc *d, const dhts_netstep_tables *t, int 
 
 // What a workgroup's 160 KB hold beside the phases' scratch: the static tables + the per-step table rows + ghosts resp. slots / ghost
 // cotangents (TB: small, the head of every item's look-up chain), then the state rows and -- reverse sweep -- the cotangent planes (ST)
+int dhts_netstep_lds_kb = 0;           // DHTS_OPT_NETSTEP_LDS_KB (dhts_set_option, macro_kernels.hip): 0 = all a workgroup may take
 static NsPlan ns_plan(const NsArgs &a, size_t scratch, bool bwd) {
     NsPlan pl = {(int)scratch, 0, 0, 0, 0, 0, 0, 0};
-    size_t left = 158 * 1024 - scratch;          // (the kernels' static LDS -- argument block, scan scratch -- stays below 2 KB)
+    const size_t budget = (size_t)(dhts_netstep_lds_kb > 0 ? dhts_netstep_lds_kb : 158) * 1024;      // (the kernels' static LDS -- argument block, scan scratch -- stays below 2 KB)
+    size_t left = budget > scratch ? budget - scratch : 0;
     const size_t tables = ns_stage_bytes(a), rows = ns_al16(16 * (size_t)a.L) + ns_al16(32 * (size_t)a.L) + (bwd ? 0 : ns_al16(16 * (size_t)a.L));
     const size_t misc = (bwd ? 2 : 1) * ns_al16(32 * (size_t)a.L) + ns_al16(32 * (size_t)a.sq + 16) + (bwd ? 0 : ns_al16(16 * (size_t)a.L));
     if (tables + rows + misc <= left) { pl.tables = (int)tables; pl.rows = (int)rows; pl.misc = (int)misc; left -= tables + rows + misc; }

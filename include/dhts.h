@@ -97,6 +97,10 @@ int dhts_device_count(void);
  * and b + grid / 2 share a compute unit at two workgroups per unit, and the one dispatched second loses the arbitration), is used for
  * speed only and changes no result; bench.py times both settings during its warm-up and reports which one the box prefers. */
 #define DHTS_OPT_MACRO_FWD_ROTATE 5
+/* DHTS_OPT_NETSTEP_LDS_KB: KB of LDS the persistent kernels of dhts_netstep_rollout_* may plan with for what they keep resident (static
+ * tables + per-step rows + ghosts, the micro side's running state, state rows / cotangent planes: dropped in that order of priority when
+ * they do not fit); 1 .. 158, 0 = default (158).  Chooses among instantiations that compute the same numbers -- the tests run them all. */
+#define DHTS_OPT_NETSTEP_LDS_KB 6
 int dhts_set_option(int option, int value);
 /* cells / vehicle slots rounded up to the tape's padded width (multiple of 64) */
 int dhts_padded(int n);

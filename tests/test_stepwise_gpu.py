@@ -371,3 +371,34 @@ def test_env_capacity_ladder_starts_at_the_geometric_capacity(cuda, golden_dir):
     assert env2.last_path == "stepwise" and env2._fused_cache[1].lane_capacity == 32
     assert float(reward2.detach()) == r0
     assert np.abs(a2.grad.cpu().numpy() - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()
+
+
+@pytest.mark.parametrize("name", ["hybrid_n2l30", "hybrid_5x5", "macro_3x3x3", "micro_2x2"])
+def test_persistent_instantiations_agree(cuda, golden_dir, name):
+    """The persistent kernels come in instantiations by what a workgroup's LDS holds (static tables + rows + ghosts, the micro side's
+    running state, state rows / cotangent planes; csrc/netstep_hybrid.hip ns_plan).  DHTS_OPT_NETSTEP_LDS_KB shrinks the budget, so that
+    the same episode runs through the others -- down to nothing staged: same queues and counts bit for bit, same gradient."""
+    from dhts import _lib
+    from dhts.stepwise import StepwiseNetwork, default_lane_capacity
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    if name.startswith("micro"):
+        t, m, routes = itscp_micro_tables(g)
+    else:
+        t, m = itscp_hybrid_tables(g)
+        routes = g["spawn_routes"] if g["spawn_routes"].shape[0] else -np.ones((1, 2), np.int32)
+    net = StepwiseNetwork(t, routes, cuda, lane_capacity=default_lane_capacity(t, m["vehicle_length"]), persistent=True)
+    lib = _lib.lib()
+    try:
+        ref = _run(cuda, net, m, g["action"])
+        ref_e = _run(cuda, net, m, g["action"], differentiable=False)
+        scale = np.abs(ref["grad"]).max()
+        assert np.abs(ref["grad"] - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()
+        for kb in (120, 96, 72, 56, 40, 24, 8):
+            assert lib.dhts_set_option(_lib.OPT_NETSTEP_LDS_KB, kb) == 0
+            o = _run(cuda, net, m, g["action"])
+            assert np.array_equal(o["queue"], ref["queue"]) and np.array_equal(o["counts"], ref["counts"]) and o["reward"] == ref["reward"], kb
+            assert np.abs(o["grad"] - ref["grad"]).max() <= 1e-6 * scale, kb
+            oe = _run(cuda, net, m, g["action"], differentiable=False)
+            assert np.array_equal(oe["queue"], ref_e["queue"]), kb
+    finally:
+        lib.dhts_set_option(_lib.OPT_NETSTEP_LDS_KB, 0)
