@@ -402,3 +402,28 @@ def test_persistent_instantiations_agree(cuda, golden_dir, name):
             assert np.array_equal(oe["queue"], ref_e["queue"]), kb
     finally:
         lib.dhts_set_option(_lib.OPT_NETSTEP_LDS_KB, 0)
+
+
+@pytest.mark.parametrize("name", ["hybrid_n2l30", "hybrid_p2"])
+def test_lane_capacity_is_storage_only(cuda, golden_dir, name):
+    """Any capacity the episode fits in gives the same numbers (odd ones too: the loops over vehicle slots address `capacity` slots
+    per lane but visit a power of two per lane, or all of them); one it does not fit in is a loud CapacityError, never a wrong number."""
+    from dhts import ops
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    ref = None
+    fitted = []
+    for cap in (32, 7, 6, 5, 4, 3, 2):
+        for persistent in (True, False):
+            net, _, m = _net(cuda, g, lane_capacity=cap, persistent=persistent)
+            try:
+                o = _run(cuda, net, m, g["action"])
+            except ops.CapacityError:
+                continue
+            fitted.append((cap, persistent))
+            if ref is None:
+                ref = o
+                assert np.abs(o["grad"] - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()
+            assert np.array_equal(o["queue"], ref["queue"]) and np.array_equal(o["counts"], ref["counts"]), (cap, persistent)
+            assert np.abs(o["grad"] - ref["grad"]).max() <= 1e-6 * np.abs(ref["grad"]).max(), (cap, persistent)
+    print("%s: capacities that fit:" % name, fitted)
+    assert (32, True) in fitted and (32, False) in fitted and len(fitted) >= 6
