@@ -38,6 +38,15 @@ def default_lane_capacity(tables, vehicle_length, ceiling=32):
     return min(cap, int(ceiling))
 
 
+def persistent_form_pays(tables):
+    """Which form a SINGLE episode of this network should take: the persistent kernels (one workgroup for the whole network) while
+    its static tables fit a workgroup's LDS and a thread has a handful of items per phase -- 2.5-3 x faster than the stepwise form
+    at 250-400 lanes; at 1 296 lanes / 784 IDM lanes the stepwise form, which spreads a step over the chip, is 1.4 x faster
+    (tests/test_stepwise_gpu.py::test_network_wider_than_the_workgroup).  Replica batches always take the persistent form."""
+    t = as_hybrid_tables(tables)
+    return t.n_lanes <= 1024 and t.n_cells <= 4096
+
+
 def as_hybrid_tables(t):
     """A dhts.network.MacroNetworkTables as HybridNetworkTables (every lane an ARZ lane)."""
     from .network import HybridNetworkTables

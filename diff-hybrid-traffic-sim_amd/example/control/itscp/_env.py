@@ -488,9 +488,11 @@ class ItscpEnv:
                 return net[0]
             except ValueError:
                 pass
-        # persistent form (one kernel per direction) unless asked otherwise; a network whose scratch does not fit one workgroup's LDS
-        # comes back as DhtsError at the first launch and is rebuilt in the stepwise form (one launch per phase and step)
-        persistent = bool(self.config.get("stepwise_persistent", True)) and not getattr(self, "_stepwise_no_persistent", False)
+        # persistent form (one kernel per direction) where it pays (up to 1 024 lanes / 4 096 cells: dhts.stepwise.persistent_form_pays)
+        # unless config["stepwise_persistent"] says otherwise; a network whose scratch does not fit one workgroup's LDS comes back as
+        # DhtsError at the first launch and is rebuilt in the stepwise form (a handful of launches per step)
+        from dhts.stepwise import persistent_form_pays
+        persistent = bool(self.config.get("stepwise_persistent", persistent_form_pays(tab))) and not getattr(self, "_stepwise_no_persistent", False)
         sw = StepwiseNetwork(tab, routes, device, lane_capacity=lane_cap, persistent=persistent)
         self._stepwise_cache = (sw, (lane_cap, routes.shape, routes.tobytes()))
         return sw

@@ -307,3 +307,14 @@ def test_default_lane_capacity_follows_the_geometry(golden_dir, name, cap):
     t, m = itscp_hybrid_tables(g) if name.startswith("hybrid") else itscp_tables(g)
     assert default_lane_capacity(t, m["vehicle_length"]) == cap
     assert default_lane_capacity(t, m["vehicle_length"] / 100.0) == (32 if name.startswith("hybrid") else 4)      # (the ceiling)
+
+
+def test_persistent_form_pays_up_to_a_workgroup_of_lanes(golden_dir):
+    from dhts.stepwise import persistent_form_pays
+    g = np.load(os.path.join(golden_dir, "itscp_hybrid_5x5.npz"))
+    t, _ = itscp_hybrid_tables(g)
+    assert persistent_form_pays(t)
+    import copy
+    big = copy.copy(t)
+    big.n_lanes = 1296
+    assert not persistent_form_pays(big)

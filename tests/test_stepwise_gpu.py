@@ -427,3 +427,52 @@ def test_lane_capacity_is_storage_only(cuda, golden_dir, name):
             assert np.abs(o["grad"] - ref["grad"]).max() <= 1e-6 * np.abs(ref["grad"]).max(), (cap, persistent)
     print("%s: capacities that fit:" % name, fitted)
     assert (32, True) in fitted and (32, False) in fitted and len(fitted) >= 6
+
+
+def test_network_wider_than_the_workgroup(cuda, oracle):
+    """A 9 x 9 hybrid grid built by the environment itself (1 296 lanes -- more than the persistent kernels' 1 024 threads, so every
+    item loop takes several rounds and the static tables do not fit LDS: the unstaged instantiation; ~470 IDM lanes): persistent
+    form = stepwise form bit for bit, and both against the CPU oracle."""
+    import torch
+    from dhts.network import HybridNetworkTables, group_routes
+    from dhts.stepwise import StepwiseNetwork, default_lane_capacity
+    from example.control.itscp._env import ItscpEnv
+    from example.control.itscp import problem as problems
+    np.random.seed(5)
+    env = ItscpEnv()
+    env.schedule_callback = problems.problem_1
+    for k, v in dict(num_intersection=9, lane_length=5.0, num_lane=1, policy_length=2, signal_length=1, mode="hybrid", speed_limit=60.0,
+                     random_seed=5).items():
+        env.config[k] = v
+    env.reset()
+    t = HybridNetworkTables.from_env(env)
+    assert t.n_lanes > 1024
+    spawn = [l for l in range(t.n_lanes) if t.lane_macro[l] == 0 and any(t.lane_macro[a] for a in t.prev_lanes[l])]
+    routes = [list(env.simulator.create_random_route(l).route)[:32] for l in spawn for _ in range(4)]
+    routes = np.asarray([r + [-1] * (32 - len(r)) for r in routes], dtype=np.int32)
+    gr, ptr = group_routes(routes, t.n_lanes)
+    args = (env.config["num_intersection"] ** 2, env.config["simulation_frequency"] * env.config["signal_length"],
+            1.0 / env.config["simulation_frequency"], env.simulator.speed_limit, env.config["static_speed"], env.simulator.vehicle_length)
+    cap = default_lane_capacity(t, env.simulator.vehicle_length)
+    n_action = env.config["policy_length"] * env.config["num_intersection"] ** 2
+    act = np.random.default_rng(1).uniform(0.1, 0.9, n_action).astype(np.float32)
+    outs = []
+    for persistent in (True, False):
+        net = StepwiseNetwork(t, routes, cuda, lane_capacity=cap, persistent=persistent)
+        a = torch.tensor(act, device=cuda, requires_grad=True)
+        t0 = time.perf_counter()
+        cut, reward, queue, counts = net.rollout(a, *args)
+        cut.backward()
+        torch.cuda.synchronize()
+        outs.append(dict(queue=queue.cpu().numpy(), grad=a.grad.cpu().numpy(), counts=counts.cpu().numpy(), reward=float(reward)))
+        print("%d lanes, %d cells, %d IDM lanes, %d steps, %s form: %.1f ms (first call)" %
+              (t.n_lanes, t.n_cells, net.n_micro, t.T, "persistent" if persistent else "stepwise", 1e3 * (time.perf_counter() - t0)))
+    p, s = outs
+    assert np.array_equal(p["queue"], s["queue"]) and np.array_equal(p["counts"], s["counts"]) and p["reward"] == s["reward"]
+    scale = np.abs(s["grad"]).max()
+    assert np.abs(p["grad"] - s["grad"]).max() <= 1e-6 * scale
+    ref = oracle.net_hybrid(t, gr, ptr, act, *args)
+    assert ref["rc"] == 0 and (p["counts"][0], p["counts"][1]) == (ref["n_spawned"], ref["n_deposits"])
+    assert state_report("queues vs oracle", p["queue"], ref["queue"]) <= TOL_STATE
+    assert abs(p["reward"] - ref["reward"]) <= 1e-5 * abs(ref["reward"])
+    assert np.abs(p["grad"] - ref["g_action"]).max() <= TOL_GRAD * np.abs(ref["g_action"]).max()
