@@ -476,3 +476,9 @@ def test_network_wider_than_the_workgroup(cuda, oracle):
     assert state_report("queues vs oracle", p["queue"], ref["queue"]) <= TOL_STATE
     assert abs(p["reward"] - ref["reward"]) <= 1e-5 * abs(ref["reward"])
     assert np.abs(p["grad"] - ref["g_action"]).max() <= TOL_GRAD * np.abs(ref["g_action"]).max()
+    # the environment itself routes a single episode of this size to the stepwise FORM (dhts.stepwise.persistent_form_pays)
+    a_env = torch.tensor(act, device=cuda, requires_grad=True)
+    _, r_env, _, _ = env.step(a_env, True)
+    r_env.backward()
+    assert env.last_path == "stepwise" and not env._fused_cache[1].persistent
+    assert np.isfinite(float(r_env.detach())) and np.isfinite(a_env.grad.cpu().numpy()).all() and float(a_env.grad.abs().max()) > 0
