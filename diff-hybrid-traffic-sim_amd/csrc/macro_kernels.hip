@@ -1640,7 +1640,7 @@ extern "C" int dhts_debug_fwd3_stamps(long long *out) {       // [16 workgroups]
 }
 #endif
 
-extern int dhts_netstep_lds_kb;      // netstep_hybrid.hip
+extern int dhts_netstep_lds_kb, dhts_netstep_block;      // netstep_hybrid.hip
 
 extern "C" {
 
@@ -1655,6 +1655,10 @@ int dhts_set_option(int option, int value) {
     }
     if (option == DHTS_OPT_MACRO_FWD_ROTATE && (value == 0 || value == 1)) {
         dhts_fwd_rotate = value;
+        return DHTS_OK;
+    }
+    if (option == DHTS_OPT_NETSTEP_BLOCK && (value == 0 || value == 256 || value == 512 || value == 1024)) {
+        dhts_netstep_block = value;
         return DHTS_OK;
     }
     if (option == DHTS_OPT_NETSTEP_LDS_KB && (value == 0 || (value >= 1 && value <= 158))) {

@@ -33,7 +33,10 @@
 
 namespace dhts {
 
-constexpr int kNsBlock = 1024;
+#ifndef DHTS_NS_BLOCK
+#define DHTS_NS_BLOCK 1024
+#endif
+constexpr int kNsBlock = DHTS_NS_BLOCK;       // threads of the one-workgroup kernels (a -DDHTS_NS_BLOCK=512 build: tools/build_variants.sh)
 constexpr long long kNsWindow = 100000;       // RunningMean(100_000), _env.py:122
 constexpr int kNsRouteMax = 32;               // MAX_ROUTE_LENGTH, road_network.py:17
 enum { NS_EV_SPAWN = 1, NS_EV_CHANGE = 2, NS_EV_DESPAWN = 3, NS_EV_DEPOSIT = 4, NS_EV_DEPCELL = 5, NS_EV_CAPSERIAL = 6 };
@@ -1814,6 +1817,7 @@ static NsArgs ns_args(const dhts_net_desc *d, const dhts_netstep_tables *t, int 
 
 // What a workgroup's 160 KB hold beside the phases' scratch: the static tables + the per-step table rows + ghosts resp. slots / ghost
 // cotangents (TB: small, the head of every item's look-up chain), then the state rows and -- reverse sweep -- the cotangent planes (ST)
+int dhts_netstep_block = 0;            // DHTS_OPT_NETSTEP_BLOCK: threads per workgroup of the persistent kernels (0 = heuristic)
 int dhts_netstep_lds_kb = 0;           // DHTS_OPT_NETSTEP_LDS_KB (dhts_set_option, macro_kernels.hip): 0 = all a workgroup may take
 static NsPlan ns_plan(const NsArgs &a, size_t scratch, bool bwd) {
     NsPlan pl = {(int)scratch, 0, 0, 0, 0, 0, 0, 0};
@@ -1832,12 +1836,18 @@ static NsPlan ns_plan(const NsArgs &a, size_t scratch, bool bwd) {
     return pl;
 }
 
+// threads of a persistent workgroup: all 1 024 unless asked otherwise
+static int ns_persist_block(const NsArgs &a) {
+    if (dhts_netstep_block > 0) return dhts_netstep_block;
+    return kNsBlock;
+}
+
 template <int TA, int SS, bool MS>
 static int ns_launch_persist_fwd(const NsArgs &a, const float *action, const NsPlan &pl, size_t lds, int n_replicas, hipStream_t st) {
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute((const void *)ns_persist_fwd_kernel<TA, SS, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_INVALID;
-    ns_persist_fwd_kernel<TA, SS, MS><<<n_replicas, kNsBlock, lds, st>>>(a, action, pl);
+    ns_persist_fwd_kernel<TA, SS, MS><<<n_replicas, ns_persist_block(a), lds, st>>>(a, action, pl);
     return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
 }
 template <int TA, int SS, bool MS>
@@ -1846,7 +1856,7 @@ static int ns_launch_persist_bwd(const NsArgs &a, const float *action, const flo
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute((const void *)ns_persist_bwd_kernel<TA, SS, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_INVALID;
-    ns_persist_bwd_kernel<TA, SS, MS><<<n_replicas, kNsBlock, lds, st>>>(a, action, g_reward, g_action, pl);
+    ns_persist_bwd_kernel<TA, SS, MS><<<n_replicas, ns_persist_block(a), lds, st>>>(a, action, g_reward, g_action, pl);
     return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
 }
 

@@ -20,6 +20,7 @@ OPT_MACRO_FWD_VARIANT = 3
 OPT_MACRO_FWD_GROUP = 4
 OPT_MACRO_FWD_ROTATE = 5
 OPT_NETSTEP_LDS_KB = 6
+OPT_NETSTEP_BLOCK = 7
 MACRO_MAX_CELLS = 4000
 MICRO_MAX_VEHICLES = 1024
 

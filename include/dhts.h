@@ -101,6 +101,8 @@ int dhts_device_count(void);
  * tables + per-step rows + ghosts, the micro side's running state, state rows / cotangent planes: dropped in that order of priority when
  * they do not fit); 1 .. 158, 0 = default (158).  Chooses among instantiations that compute the same numbers -- the tests run them all. */
 #define DHTS_OPT_NETSTEP_LDS_KB 6
+/* DHTS_OPT_NETSTEP_BLOCK: threads per workgroup of the persistent kernels: 256, 512, 1024; 0 = heuristic.  Same results. */
+#define DHTS_OPT_NETSTEP_BLOCK 7
 int dhts_set_option(int option, int value);
 /* cells / vehicle slots rounded up to the tape's padded width (multiple of 64) */
 int dhts_padded(int n);

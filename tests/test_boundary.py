@@ -51,6 +51,9 @@ def test_options_accept_documented_values_only():
     for v in (1, 64, 158, 0):
         assert lib.dhts_set_option(_lib.OPT_NETSTEP_LDS_KB, v) == 0
     assert lib.dhts_set_option(_lib.OPT_NETSTEP_LDS_KB, 159) == _lib.E_INVALID
+    for v in (256, 512, 1024, 0):
+        assert lib.dhts_set_option(_lib.OPT_NETSTEP_BLOCK, v) == 0
+    assert lib.dhts_set_option(_lib.OPT_NETSTEP_BLOCK, 128) == _lib.E_INVALID
     assert lib.dhts_set_option(_lib.OPT_MACRO_FWD_ROTATE, 2) == _lib.E_INVALID and lib.dhts_set_option(_lib.OPT_MACRO_FWD_ROTATE, 1) == 0
     assert lib.dhts_set_option(99, 0) == _lib.E_INVALID
     assert lib.dhts_set_option(_lib.OPT_MACRO_FWD_WAVES, 0) == 0       # back to the heuristics
