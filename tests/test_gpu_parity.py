@@ -987,3 +987,31 @@ def test_micro_reverse_sweep_reports_non_finite_gradient(cuda):
     code, step, lane, index = err.tolist()
     assert (code, step, lane, index) == (_lib.FAULT_NAN, 3, 2, 17)
     assert not bool(torch.isfinite(o_v[2, 17]))
+
+
+def test_micro_bwd_fault_reads_the_autograd_sweeps_record(cuda):
+    """dhts.micro_rollout's reverse sweep does not read its fault record back (no host synchronisation per backward); ops.micro_bwd_fault()
+    does, on demand: None after a finite sweep, (step, lane, vehicle) + a RuntimeWarning after one that met a non-finite cotangent, and the
+    record is cleared between two backward passes over the same graph (retain_graph)."""
+    import warnings
+    import torch
+    from dhts import ops
+    L, V, T = 2, 64, 5
+    p0 = (torch.arange(V, device=cuda, dtype=torch.float32) * 12.0).repeat(L, 1).requires_grad_(True)
+    v0 = torch.full((L, V), 8.0, device=cuda, requires_grad=True)
+    base = torch.tensor([2.0, 1.6, 30.0, 2.0, 1.5, 5.0], dtype=torch.float64, device=cuda)
+    params = base[:, None, None].expand(6, L, V).contiguous()
+    head = torch.tensor([[1000.0, 0.0]] * L, dtype=torch.float64, device=cuda)
+    pT, vT = ops.micro_rollout(p0, v0, params, head, T, 0.05)
+    loss = pT.sum() + vT.sum()
+    loss.backward(retain_graph=True)
+    assert ops.micro_bwd_fault() is None
+    g_bad = torch.ones(L, V, device=cuda)
+    g_bad[1, 7] = float("nan")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        torch.autograd.backward([pT, vT], [torch.ones(L, V, device=cuda), g_bad], retain_graph=True)
+        where = ops.micro_bwd_fault()
+    assert where is not None and where[1] == 1 and where[0] == T - 1 and any(issubclass(x.category, RuntimeWarning) for x in w)
+    loss.backward()                                   # a finite sweep over the same graph: the record starts clean
+    assert ops.micro_bwd_fault(warn=False) is None
