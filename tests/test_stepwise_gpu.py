@@ -491,3 +491,39 @@ def test_network_wider_than_the_workgroup(cuda, oracle):
     r_env.backward()
     assert env.last_path == "stepwise" and not env._fused_cache[1].persistent
     assert np.isfinite(float(r_env.detach())) and np.isfinite(a_env.grad.cpu().numpy()).all() and float(a_env.grad.abs().max()) > 0
+
+
+def test_env_ladder_survives_a_fused_launch_that_does_not_fit(cuda, golden_dir, monkeypatch):
+    """a fused launch whose LDS staging does not fit comes back as DhtsError (not CapacityError).  The ladder treats it
+    like an exceeded capacity: next rung (the stepwise path), same routes, the reference's numbers.  (64 IDM lanes at 128 vehicle slots
+    DO fit on gfx950 -- first half of the test --, so the refusal is injected for the second.)"""
+    import torch
+    from dhts import _lib, ops
+    from test_itscp_gpu import build_env
+    from test_oracle_golden import meta_of
+    g = np.load(os.path.join(golden_dir, "itscp_hybrid_4x4.npz"))
+    m = meta_of(g)
+
+    def episode():
+        env = build_env(g, m, replay_routes=True)
+        env.fused_routes = g["spawn_routes"]
+        env._fused_lane_capacity = 128
+        action = torch.tensor(g["action"], device=cuda, requires_grad=True)
+        _, reward, _, _ = env.step(action, True)
+        reward.backward()
+        assert env._fused_done
+        assert abs(float(reward.detach()) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+        assert np.abs(action.grad.cpu().numpy() - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()
+        assert env.fused_counts[0] == m["n_vehicle_spawned"]
+        return env
+    env = episode()
+    assert env.last_path == "fused" and env._fused_cache[1].lane_capacity == 128
+    real = ops.net_hybrid_rollout
+
+    def refuse(a, tab, *args, **kw):
+        if tab.lane_capacity == 128:
+            raise _lib.DhtsError("dhts_net_hybrid_rollout_fwd: DHTS_E_INVALID (injected: LDS staging does not fit)")
+        return real(a, tab, *args, **kw)
+    monkeypatch.setattr(ops, "net_hybrid_rollout", refuse)
+    env = episode()
+    assert env.last_path == "stepwise" and env._fused_cache[1].lane_capacity == 32
