@@ -813,10 +813,9 @@ template <class A> __device__ __forceinline__ void ns_convert(const A &a, int t,
     auto kc_cell = hard ? nullptr : ns_ptr<float>(a, a.lo.kc_cell) + (size_t)t * C;
     auto kc_veh = (Lm && !hard) ? ns_ptr<float>(a, a.lo.kc_veh) + (size_t)t * plane : nullptr;
     auto lossS = ns_ptr<double>(a, a.lo.lossS);
-    const long long n_start = cnt->loss_n;
-    long long n0 = n_start;
+    const long long n_start = cnt->loss_n;              // (written at the end of the previous call, barriers ago; the walk's changes to the state
+    long long n0 = n_start;                             //  and the vehicles are behind its own barrier: none needed here)
     double S0 = cnt->loss_sum;
-    __syncthreads();
     if (hard) {
         for (int l = tid; l < L; l += B) {
             float qlen = 0.f;
@@ -905,9 +904,8 @@ template <class A> __device__ __forceinline__ void ns_convert(const A &a, int t,
         }
         ns_glob(a.queue)[row + l] = (qlen * qlen) * dtf;
     }
-    __syncthreads();
     NS_SUB(5)
-    if (tid == 0) { cnt->loss_n = n0; cnt->loss_sum = S0; }
+    if (tid == 0) { cnt->loss_n = n0; cnt->loss_sum = S0; }      // (everybody read them before the scans' barriers; the caller's barrier follows)
 }
 
 // LDS scratch of ns_convert: the candidate flags of the event walk [L ints], then the loss's lane prefixes and per-sample terms
@@ -1028,7 +1026,7 @@ template <class A> __device__ __forceinline__ void ns_micro_bwd(const A &a, int 
             if (i < nv_post[ms]) gVn[idx] += (double)laneG[a.micro_lanes[ms]] * (double)soft_switch_grad(vx[idx], kv[idx]) * -1.0;
         }
     }
-    __syncthreads();
+    if (Lm > 0) __syncthreads();       // (without IDM lanes nothing happens between a cell's tap and its fold, both by the cell's own thread)
 
     if (Lm > 0) {
         NS_SUB(8)
