@@ -1168,7 +1168,7 @@ template <class A> __device__ __forceinline__ void ns_micro_bwd(const A &a, int 
                 gVp[hs] += (double)h.jp[1] * ghp + (double)h.jv[1] * ghv;
             }
         }
-        __syncthreads();
+        // (no barrier: lane m's slots are touched by thread m mod blockDim.x alone, here and below)
         // leaders: items compacted in lane order, every target lane adds the ones that name it
         const int has_l = (h.valid && h.leader >= 0) ? 1 : 0;
         int n_sig = 0;
@@ -1200,7 +1200,7 @@ template <class A> __device__ __forceinline__ void ns_micro_bwd(const A &a, int 
             for (int k = 0; k < tot_s; k++) if (si_key[k] == q) { av += si_v[k]; any = true; }
             if (any) g_act[q] += av;
         }
-        __syncthreads();
+        if (base + B < Lm) __syncthreads();           // (the lists are reused by the next pass)
     }
 
     NS_SUB(13)
