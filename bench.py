@@ -559,7 +559,7 @@ class ItscpHybridWorkload:
 
 class ItscpStepwiseWorkload(ItscpHybridWorkload):
     """A hybrid network BEYOND the fused kernels' one-workgroup limits -- run_itscp_hybrid.sh with --n_lane=2 --lane_length=30 over 8 s:
-    252 lanes (28 IDM lanes), 1 152 cells, 240 steps, 36 actions -- x 64 replicas (own problem_1 inflow schedules and actions) on the
+    252 lanes (28 IDM lanes), 1 152 cells, 240 steps, 36 actions -- x 256 replicas like config 4 (own problem_1 inflow schedules and actions) on the
     stepwise path's persistent kernels (dhts_netstep_rollout_fwd / _bwd, one workgroup per replica; dhts/stepwise.py).  Not a BASELINE
     configuration: the reference's CLI reaches it with two flags, and until round 5 it ran lane by lane (minutes per episode)."""
     limiter = {"rollout_fwd": "instruction issue + barriers of ONE compute unit per replica (16 wavefronts, ~17 phases per step, 240 steps; DESIGN section 9)",
@@ -686,7 +686,7 @@ def make_workload(name, dev, rank, lanes=0, cells=0, time_steps=0):
     if name == "itscp_hybrid":
         return ItscpHybridWorkload(dev, rank, lanes or 256, 0, 0)
     if name == "itscp_stepwise":
-        return ItscpStepwiseWorkload(dev, rank, lanes or 64, 0, 0)
+        return ItscpStepwiseWorkload(dev, rank, lanes or 256, 0, 0)
     return ItscpMacroWorkload(dev, rank, lanes or 256, 0, 0)
 
 
