@@ -75,6 +75,56 @@ __device__ __forceinline__ void idm_step_ieee(double p, double v, double dp_raw,
     }
 }
 
+// itscp `micro` mode, differentiable episodes: the reference's lanes are plain MicroLane objects there (example/control/itscp/_env.py:484-498)
+// whose vehicle states become float32 TENSORS with the first head gap, so IDM.compute_acceleration and the Euler step
+// (_idm.py:30-50, _micro_lane.py:166-183) are evaluated by torch: every operation rounds to float32, a Python float operand is cast
+// to float32 first, pow(x, 2.0) is x * x, pow(x, 4.0) is powf (here: the float64 power rounded once).  Values in that ladder;
+// the Jacobian blocks -- what autograd differentiates -- from the analytic formulas at the same operands.
+// dp_raw, dv_raw: gap and speed difference as float32 tensor arithmetic gives them (|p_l - p| - float32((len_l + len) / 2), v - v_l).
+__device__ __forceinline__ void idm_step_f32(float p, float v, float dp_raw, float dv_raw, const IdmParams &m, double dt, IdmStep &o) {
+    float dp = dp_raw, dv = dv_raw;
+    o.collided = dp < 0.f;
+    if (o.collided) { dp = 0.f; dv = 0.f; }
+    const float dpc = ((float)1e-5 > dp) ? (float)1e-5 : dp;
+    const double two_sqrt_ab = 2 * sqrt(m.a_max * m.a_pref);
+    const float dtf = (float)dt;
+    float s = ((float)m.min_space + v * (float)m.time_pref) + ((v * dv) / (float)two_sqrt_ab);
+    const bool clipped_s = (s < 0.0f);
+    s = clipped_s ? 0.0f : s;
+    const float t1 = v / (float)m.v_target;
+    const double t1d = (double)t1, t1d2 = t1d * t1d;
+    const float p1 = (float)(t1d2 * t1d2);
+    const float t2 = s / dpc;
+    const float p2 = t2 * t2;
+    float acc = (float)m.a_max * ((1.0f - p1) - p2);
+    const float floor_acc = (-v) / dtf;
+    const bool clipped_a = (acc < floor_acc);
+    acc = (floor_acc > acc) ? floor_acc : acc;
+    o.np = p + dtf * v;
+    o.nv = v + dtf * acc;
+    o.acc = acc; o.sstar = s; o.clipped_acc = clipped_a; o.clipped_spacing = clipped_s;
+    o.dE[0] = 1.f; o.dE[1] = (float)dt; o.dE[2] = 0.f; o.dE[3] = 0.f;
+    o.dLd[0] = o.dLd[1] = o.dLd[2] = o.dLd[3] = 0.f;
+    if (!clipped_a) {
+        const double vd = v, sd = s, dpr = dp_raw, dvr = dv_raw;
+        const double dp2 = dpr * dpr;
+        const double dp3 = dp2 * dpr;
+        const double s2_dp3 = (sd * sd) / dp3;
+        const double vt2 = m.v_target * m.v_target;
+        const double free_term = -4.0 * ((vd * vd * vd) / (vt2 * vt2));
+        const double s_dp2 = sd / dp2;
+        o.dE[2] = (float)(dt * (-2 * m.a_max * s2_dp3));
+        o.dLd[2] = (float)(dt * (2 * m.a_max * s2_dp3));
+        if (clipped_s) {
+            o.dE[3] = (float)(1 + dt * m.a_max * free_term);
+            o.dLd[3] = (float)(dt * m.a_max * (-2 * s_dp2));
+        } else {
+            o.dE[3] = (float)(1 + dt * m.a_max * (free_term - 2 * s_dp2 * (m.time_pref + ((vd + dvr) / two_sqrt_ab))));
+            o.dLd[3] = (float)(dt * m.a_max * (-2 * s_dp2 * (-vd / two_sqrt_ab)));
+        }
+    }
+}
+
 // ---- production version -------------------------------------------------------------------------------------
 // Per-vehicle constants evaluated once per rollout (IEEE operations), so that the time loop has no division by a
 // constant and no square root: 1 / (2 sqrt(a_max a_pref)), 1 / v_target, 1 / v_target^4, and the products of the

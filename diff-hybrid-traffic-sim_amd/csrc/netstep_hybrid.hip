@@ -587,18 +587,27 @@ template <class A> __device__ __forceinline__ void ns_micro_fwd(const A &a, int 
     auto tape = hard ? nullptr : ns_ptr<float4>(a, a.lo.idm_tape) + (size_t)t * plane;
     auto nv_idm = hard ? nullptr : ns_ptr<int>(a, a.lo.nv_idm) + (size_t)t * Lm;
     const NsSlots sr = ns_slot_range(Lm, cap, cnt->n_max);
+    const bool f32_ladder = a.has_source && !hard;
     for (int j = tid; j < sr.total; j += B) {
         int m, i; size_t idx;
         ns_slot_of(sr, j, m, i, idx);
         const int n = lane_n[m];
         if (i == 0 && nv_idm) nv_idm[m] = n;
         if (i >= n) continue;
-        const double p = P0[idx], v = V0[idx];
-        double dp, dv;
-        if (i == n - 1) { dp = (double)hd_s[2 * m]; dv = (double)hd_s[2 * m + 1]; }
-        else { dp = fabs((double)P0[idx + 1] - p) - ((prm.length + prm.length) * 0.5); dv = v - (double)V0[idx + 1]; }
         IdmStep o;
-        idm_step_ieee(p, v, dp, dv, prm, a.dt_d, o);
+        if (f32_ladder) {            // `micro` mode, differentiable: the reference steps these lanes in float32 tensor arithmetic (idm_device.hpp)
+            const float p = P0[idx], v = V0[idx];
+            float dp, dv;
+            if (i == n - 1) { dp = hd_s[2 * m]; dv = hd_s[2 * m + 1]; }
+            else { dp = fabsf(P0[idx + 1] - p) - (float)((prm.length + prm.length) * 0.5); dv = v - V0[idx + 1]; }
+            idm_step_f32(p, v, dp, dv, prm, a.dt_d, o);
+        } else {
+            const double p = P0[idx], v = V0[idx];
+            double dp, dv;
+            if (i == n - 1) { dp = (double)hd_s[2 * m]; dv = (double)hd_s[2 * m + 1]; }
+            else { dp = fabs((double)P0[idx + 1] - p) - ((prm.length + prm.length) * 0.5); dv = v - (double)V0[idx + 1]; }
+            idm_step_ieee(p, v, dp, dv, prm, a.dt_d, o);
+        }
         if (o.collided) net_fault(a.err, DHTS_FAULT_COLLISION, t, a.micro_lanes[m], i);
         P1[idx] = o.np; V1[idx] = o.nv;
         if (tape) tape[idx] = make_float4(o.dE[2], o.dE[3], o.dLd[2], o.dLd[3]);

@@ -394,7 +394,11 @@ typedef struct dhts_hybrid_tables {
      * in call order (one draw per source lane with room, lanes in id order, steps in order), n_draws its length (a run that
      * needs more raises DHTS_FAULT_CAPACITY), draws_stride the elements between replicas (0 = shared).  The k-th vehicle admitted
      * to lane m takes route row route_ptr[m] + k (no wrap-around: the rows are the lane's waiting list in admission order, and an
-     * exhausted list admits nobody).  lane_source [L] int32 (1 = source lane) or NULL = the network has none. */
+     * exhausted list admits nobody).  lane_source [L] int32 (1 = source lane) or NULL = the network has none.
+     * A network WITH source lanes is the reference's `micro` mode, whose lanes are plain autodiff MicroLane objects stepped in float32
+     * TENSOR arithmetic (example/control/itscp/_env.py:484-498; road/lane/_micro_lane.py:131-214 evaluated by torch): in differentiable
+     * episodes of such a network the IDM step follows that ladder operation by operation (csrc/idm_device.hpp idm_step_f32) instead
+     * of the analytic operator's float64 one (dmicro_lane.py:87-127) that hybrid-mode lanes use. */
     const int32_t *lane_source;
     const double *draws;
     int32_t n_draws;

@@ -571,6 +571,54 @@ int oracle_micro_step(int V, const float *p, const float *v, const double *param
     return rc;
 }
 
+/* itscp `micro` mode: the lanes are plain MicroLane objects whose vehicle states become float32 TENSORS with the first head gap
+ * (road/lane/_micro_lane.py:131-214 with model/micro/_idm.py:6-50 evaluated by torch): every operation rounds to float32, a Python
+ * float operand is cast to float32 first, pow(x, 2.0) is x * x, pow(x, 4.0) is powf.  Values in that ladder; the Jacobian blocks
+ * (what autograd differentiates) from the analytic formulas at the same operands. */
+int oracle_micro_step_f32(int V, const float *p, const float *v, const double *params,
+                          double head_dp, double head_dv, double dt,
+                          float *np_, float *nv_, float *dqs, int *err_index) {
+    int rc = ORACLE_OK;
+    const float dtf = (float)dt;
+    for (int i = 0; i < V; i++) {
+        const double *pr = params + (size_t)i * 6;
+        float dp, dv;
+        if (i == V - 1) {
+            dp = (float)head_dp;
+            dv = (float)head_dv;
+        } else {
+            const double *pl = params + (size_t)(i + 1) * 6;
+            dp = fabsf(p[i + 1] - p[i]) - (float)((pl[5] + pr[5]) * 0.5);
+            dv = v[i] - v[i + 1];
+        }
+        const double dp_raw = dp, dv_raw = dv;
+        if (dp < 0) {
+            if (rc == ORACLE_OK) { rc = ORACLE_ERR_COLLISION; if (err_index) *err_index = i; }
+            dp = 0; dv = 0;
+        }
+        const float dpc = ((float)1e-5 > dp) ? (float)1e-5 : dp;                /* max(position_delta, POSITION_DELTA_EPS) */
+        const float den = (float)(2 * pow(pr[0] * pr[1], 0.5));
+        float s = ((float)pr[3] + v[i] * (float)pr[4]) + ((v[i] * dv) / den);
+        int fl[2];
+        fl[1] = (s < 0.0f);
+        if (s < 0.0f) s = 0.0f;
+        const float t1 = v[i] / (float)pr[2];
+        const float p1 = (float)pow((double)t1, IDM_DELTA);
+        const float t2 = s / dpc;
+        const float p2 = t2 * t2;
+        float acc = (float)pr[0] * ((1.0f - p1) - p2);
+        const float lim = (-v[i]) / dtf;
+        fl[0] = (acc < lim);
+        if (lim > acc) acc = lim;
+        np_[i] = p[i] + dtf * v[i];
+        nv_[i] = v[i] + dtf * acc;
+        if (dqs)
+            oracle_idm_jac(pr[0], pr[1], v[i], pr[2], dp_raw, dv_raw, pr[3], pr[4], (double)s, dt, fl,
+                           dqs + (size_t)i * 8, dqs + (size_t)i * 8 + 4);
+    }
+    return rc;
+}
+
 /* road/lane/dmicro_lane.py:271-298 */
 void oracle_micro_step_bwd(int V, const float *dqs, const float *g_np, const float *g_nv, float *g_p, float *g_v) {
     for (int i = 0; i <= V; i++) g_p[i] = g_v[i] = 0.f;

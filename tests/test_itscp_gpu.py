@@ -158,7 +158,8 @@ def test_itscp_micro_mode_matches_reference(cuda, golden_dir, name):
     assert next(draws, None) is None                       # every recorded draw was consumed: same admission tests
     assert sim.num_vehicle == m["n_vehicle_spawned"]
     queue = np.array([[float(x) for x in env.queue_length[k]] for k in keys])
-    # (1e-4: the reference steps `micro` mode lanes with the autodiff MicroLane in float32 tensor arithmetic, see the docstring)
+    # (1e-4: the reference steps `micro` mode lanes with the autodiff MicroLane in float32 tensor arithmetic; the lane-by-lane MIRROR keeps
+    #  the analytic operator's float64 ladder -- 1.25e-5 / 3.7e-6 -- unlike the device paths and the oracle, which follow the tensor ladder)
     assert state_report("mirror path %s: queues vs reference" % name, queue, g["queue"]) <= 1e-4
     assert abs(float(reward) - float(g["reward"])) <= 1e-4 * abs(float(g["reward"]))
     reward.backward()
@@ -250,9 +251,9 @@ def test_env_micro_mode_step_uses_fused_kernels(cuda, golden_dir, name):
     assert env._fused_done and env.fused_counts[0] == m["n_vehicle_spawned"]
     reward.backward()
     queue = np.array([env.queue_length[k] for k in keys])
-    # (1e-4: `micro` mode -- the reference's lanes run float32 tensor arithmetic there, test_itscp_micro_mode_matches_reference)
-    assert state_report("env.step %s: queues vs reference" % name, queue, g["queue"]) <= 1e-4
-    assert abs(float(reward.detach()) - float(g["reward"])) <= 1e-4 * abs(float(g["reward"]))
+    # (`micro` mode: the fused kernels follow the reference's float32 tensor ladder there, idm_step_f32 -- measured 1.7e-7 / 2.2e-6)
+    assert state_report("env.step %s: queues vs reference" % name, queue, g["queue"]) <= TOL_STATE
+    assert abs(float(reward.detach()) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
     assert np.abs(action.grad.cpu().numpy() - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()
 
 

@@ -90,15 +90,16 @@ def test_stepwise_macro_matches_reference(cuda, golden_dir, name):
 def test_stepwise_micro_mode_matches_reference(cuda, golden_dir, name):
     """itscp `micro` mode: every lane an IDM lane, source lanes admit waiting vehicles against the host's recorded draws; 16, 40 and
     112 lanes (the last beyond the fused kernels' 64).  The reference steps these lanes with the autodiff MicroLane in float32 tensor
-    arithmetic, hence 1e-4 on the queues (tests/test_oracle_golden.py::test_itscp_micro_mode_network)."""
+    arithmetic; the kernels follow that ladder in this mode (csrc/idm_device.hpp idm_step_f32): queues <= 1e-5 like every other mode
+    (measured 1.7e-7 ... 2.2e-6)."""
     from dhts.stepwise import StepwiseNetwork
     g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
     t, m, rows = itscp_micro_tables(g)
     net = StepwiseNetwork(t, rows, cuda, lane_capacity=32)
     o = _run(cuda, net, m, g["action"])
     assert o["counts"][0] == m["n_vehicle_spawned"] and o["counts"][3] == len(g["rand_draws"])
-    assert rel_max(o["queue"].T, g["queue"]) <= 1e-4
-    assert abs(o["reward"] - float(g["reward"])) <= 1e-4 * abs(float(g["reward"]))
+    assert rel_max(o["queue"].T, g["queue"]) <= TOL_STATE
+    assert abs(o["reward"] - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
     assert rel_max(o["grad"], g["g_action"]) <= TOL_GRAD
 
 
@@ -212,9 +213,9 @@ def test_env_step_takes_the_stepwise_path_beyond_the_fused_limits(cuda, golden_d
     t1 = time.perf_counter()
     assert env._fused_cache[0] == "stepwise" and env._fused_done and env.last_path == "stepwise" and env._fused_cache[1].persistent
     queue = np.array([env.queue_length[k] for k in keys])
-    tol_q = 1e-4 if micro else TOL_STATE
+    tol_q = TOL_STATE
     assert state_report("env.step %s: queues vs reference" % name, queue, g["queue"]) <= tol_q
-    assert abs(float(reward.detach()) - float(g["reward"])) <= (1e-4 if micro else 1e-5) * abs(float(g["reward"]))
+    assert abs(float(reward.detach()) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
     assert np.abs(grad - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()
     if not name.startswith("macro"):
         assert env.fused_counts[0] == m["n_vehicle_spawned"]
@@ -269,7 +270,7 @@ def test_persistent_form_micro_mode(cuda, golden_dir, name):
     o = _run(cuda, StepwiseNetwork(t, rows, cuda, persistent=True), m, g["action"])
     o_s = _run(cuda, StepwiseNetwork(t, rows, cuda), m, g["action"])
     assert o["counts"][0] == m["n_vehicle_spawned"] and o["counts"][3] == len(g["rand_draws"])
-    assert rel_max(o["queue"].T, g["queue"]) <= 1e-4 and rel_max(o["grad"], g["g_action"]) <= TOL_GRAD
+    assert rel_max(o["queue"].T, g["queue"]) <= TOL_STATE and rel_max(o["grad"], g["g_action"]) <= TOL_GRAD
     assert np.array_equal(o["queue"], o_s["queue"]) and np.abs(o["grad"] - o_s["grad"]).max() <= 1e-6 * np.abs(o_s["grad"]).max()
 
 
