@@ -960,7 +960,7 @@ __global__ void __launch_bounds__(kNsBlock) ns_reward_kernel(NsArgs a) {
 __host__ __device__ inline int ns_list_room(int Lm) { const int r = (Lm + 63) & ~63; return r < 64 ? 64 : (r > kNsBlock ? kNsBlock : r); }
 __host__ __device__ inline size_t ns_micro_bwd_scratch(int L, int C, int Lm, size_t plane) {
     const size_t lists = sizeof(double) * (2 * (size_t)(Lm > 0 ? Lm : 1) + 8 * (size_t)ns_list_room(Lm));
-    const size_t taps = sizeof(float) * ((size_t)C + plane + (size_t)L) + 16;
+    const size_t taps = sizeof(float) * (3 * (size_t)C + plane + (size_t)L) + 16;
     return lists > taps ? lists : taps;
 }
 __device__ __forceinline__ void ns_shift_out(double *gP, double *gV, double *gA, size_t base, int n) {       // slot 0 leaves
@@ -992,16 +992,19 @@ template <class A> __device__ __forceinline__ void ns_micro_bwd(const A &a, int 
     NS_SUB0()
     // ---- (a) loss taps: reward = - sum_l q_l^2 dt.  A thread per SAMPLE (cell, vehicle) evaluates its term, a thread per lane adds its
     // lane's terms in order (the queue length) and leaves the lane's seed, a thread per sample applies it.  Scratch: termC [C] | termV
-    // [plane] | laneG [L] floats (the head gaps' lists come later in the step) ----
+    // [plane] | laneG [L] | the switches and their derivatives [2][C] floats (the head gaps' lists come later in the step) ----
     if (taps) {
-        float *termC = reinterpret_cast<float *>(lds_d), *termV = termC + C, *laneG = termV + plane;
+        float *termC = reinterpret_cast<float *>(lds_d), *termV = termC + C, *laneG = termV + plane, *swS = laneG + L, *swD = swS + C;
         auto kc_cell = ns_ptr<float>(a, a.lo.kc_cell) + (size_t)t * C;
         auto nv_post = ns_ptr<int>(a, a.lo.nv_post) + (size_t)t * Lm;
         auto vx = ns_ptr<float>(a, a.lo.vx) + (size_t)t * plane;
         auto kv = ns_ptr<float>(a, a.lo.kc_veh) + (size_t)t * plane;
         for (int c = tid; c < C; c += B) {
             const float w = (float)a.lane_dx[a.cell_lane[c]];
-            termC[c] = soft_switch(s0f - Un[c], kc_cell[c]) * (Rn[c] * w / vlen);
+            float s_, ds;                      // (the switch and its derivative once: the third pass reads them back)
+            soft_switch_both(s0f - Un[c], kc_cell[c], s_, ds);
+            swS[c] = s_; swD[c] = ds;
+            termC[c] = s_ * (Rn[c] * w / vlen);
         }
         for (int j = tid; j < sr.total; j += B) {
             int ms, i; size_t idx;
@@ -1024,8 +1027,7 @@ template <class A> __device__ __forceinline__ void ns_micro_bwd(const A &a, int 
         for (int c = tid; c < C; c += B) {
             const int l = a.cell_lane[c];
             const float w = (float)a.lane_dx[l], g_q = laneG[l];
-            float s_, ds;
-            soft_switch_both(s0f - Un[c], kc_cell[c], s_, ds);
+            const float s_ = swS[c], ds = swD[c];
             Gr[c] += g_q * s_ * (w / vlen);
             Gu[c] += g_q * (Rn[c] * w / vlen) * (-ds);
         }
