@@ -319,3 +319,19 @@ def test_persistent_form_pays_up_to_a_workgroup_of_lanes(golden_dir):
     big = copy.copy(t)
     big.n_lanes = 1296
     assert not persistent_form_pays(big)
+
+
+@pytest.mark.parametrize("name", ["eval_micro_small", "eval_micro"])
+def test_itscp_micro_mode_evaluation_episode(oracle, golden_dir, name):
+    """Evaluation episodes in `micro` mode (round 5 fixtures): without gradients nothing in the reference is a tensor -- Python floats all
+    the way --, so the lanes step in the analytic operator's float64 ladder here (not the float32 tensor ladder of the differentiable
+    episodes); hard signals, hard is_static; every recorded admission draw consumed, same vehicles, queues and reward."""
+    g = load(golden_dir, "itscp_%s.npz" % name)
+    t, m, rows = itscp_micro_tables(g)
+    from dhts.network import group_routes
+    routes, route_ptr = group_routes(rows, t.n_lanes)
+    o = oracle.net_hybrid(t, routes, route_ptr, g["action"], m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"],
+                          1.0 / m["simulation_frequency"], m["speed_limit"], m["static_speed"], m["vehicle_length"], hard=True)
+    assert o["rc"] == 0 and o["n_spawned"] == m["n_vehicle_spawned"] and o["draws_used"] == len(g["rand_draws"])
+    assert rel_max(o["queue"].T, g["queue"]) <= TOL_STATE
+    assert abs(o["reward"] - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))

@@ -528,3 +528,26 @@ def test_env_ladder_survives_a_fused_launch_that_does_not_fit(cuda, golden_dir, 
     monkeypatch.setattr(ops, "net_hybrid_rollout", refuse)
     env = episode()
     assert env.last_path == "stepwise" and env._fused_cache[1].lane_capacity == 32
+
+
+@pytest.mark.parametrize("name", ["eval_micro_small", "eval_micro"])
+def test_micro_mode_evaluation_episode_matches_reference(cuda, golden_dir, name):
+    """Evaluation episodes in `micro` mode (Trainer.evaluate on run_itscp_micro.sh's environment): the reference holds Python floats all
+    the way there, the kernels step the lanes in the analytic operator's float64 ladder (the float32 tensor ladder is for differentiable
+    episodes only).  Stepwise form, persistent form and the fused evaluation kernel against the reference's run."""
+    import torch
+    from dhts import ops
+    from dhts.stepwise import StepwiseNetwork, default_lane_capacity
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    t, m, rows = itscp_micro_tables(g)
+    for persistent in (False, True):
+        net = StepwiseNetwork(t, rows, cuda, lane_capacity=default_lane_capacity(t, m["vehicle_length"]), persistent=persistent)
+        o = _run(cuda, net, m, g["action"], differentiable=False)
+        assert o["counts"][0] == m["n_vehicle_spawned"] and o["counts"][3] == len(g["rand_draws"])
+        assert rel_max(o["queue"].T, g["queue"]) <= TOL_STATE, persistent
+        assert abs(o["reward"] - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+    dtab = ops.DeviceHybridTables(t, rows, cuda)
+    reward, queue, counts = ops.net_hybrid_eval(torch.tensor(g["action"][None], device=cuda), dtab, *_args(m))
+    assert int(counts[0, 0]) == m["n_vehicle_spawned"]
+    assert rel_max(queue[0].cpu().numpy().T, g["queue"]) <= TOL_STATE
+    assert abs(float(reward[0]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))

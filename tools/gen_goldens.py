@@ -943,6 +943,11 @@ def main():
             os.environ["DHTS_FINE_CUTS"] = "120,200"
             os.environ.pop("DHTS_LANE_LATE", None)
             gen_itscp("hybrid_n2", "hybrid", 3, 2, 5.0, 8, 2, seed=37, action_kind="rand", problem=1)
+        # evaluation episodes in `micro` mode (round 5): Python floats all the way in the reference (no tensors without gradients)
+        if "eval_micro_small" in which:
+            gen_itscp("eval_micro_small", "micro", 1, 1, 30.0, 4, 2, seed=3, action_kind="rand", differentiable=False)
+        if "eval_micro" in which:
+            gen_itscp("eval_micro", "micro", 1, 3, 30.0, 10, 2, seed=13, action_kind="rand", differentiable=False)
         if "eval_hybrid_4x4" in which:
             gen_itscp("eval_hybrid_4x4", "hybrid", 4, 1, 5.0, 8, 2, seed=29, action_kind="rand", problem=2, differentiable=False)
         # networks ABOVE the fused kernels' per-workgroup limits (round 5: pins of the stepwise batched path and of the
