@@ -169,7 +169,7 @@ def test_itscp_macro_network(oracle, golden_dir, name):
     assert grad_report("G8 %s d reward / d action" % name, o["g_action"], g["g_action"]) <= TOL_GRAD
 
 
-@pytest.mark.parametrize("name", ["eval_macro", "eval_macro_2x2"])
+@pytest.mark.parametrize("name", ["eval_macro", "eval_macro_2x2", "eval_macro_3x3x3"])
 def test_itscp_macro_network_evaluation_episode(oracle, golden_dir, name):
     """ItscpEnv.step(action, False) of the reference (what Trainer.evaluate runs): hard signals, hard ghost switch, hard
     is_static.  The queue terms are squares of sums of whole cells' vehicle counts, so a cell whose speed crosses
@@ -248,7 +248,7 @@ def test_itscp_hybrid_network(oracle, golden_dir, name):
             assert np.abs(oc["g_action"] - ref).max() <= (1e-5 if t0 <= 510 else 2 * TOL_GRAD) * scale, int(t0)
 
 
-@pytest.mark.parametrize("name", ["eval_hybrid_short", "eval_hybrid_p2", "eval_hybrid", "eval_hybrid_4x4"])
+@pytest.mark.parametrize("name", ["eval_hybrid_short", "eval_hybrid_p2", "eval_hybrid", "eval_hybrid_4x4", "eval_hybrid_n2l30", "eval_hybrid_5x5"])
 def test_itscp_hybrid_network_evaluation_episode(oracle, golden_dir, name):
     """Evaluation episodes of the hybrid network (240 steps; 480 steps over problem_2's inflows; BASELINE config 4's 600-step
     episode): hard signals and boundaries, head gap = green iff the lane's own signal >= 0.5, hard is_static for cells and
@@ -321,7 +321,7 @@ def test_persistent_form_pays_up_to_a_workgroup_of_lanes(golden_dir):
     assert not persistent_form_pays(big)
 
 
-@pytest.mark.parametrize("name", ["eval_micro_small", "eval_micro"])
+@pytest.mark.parametrize("name", ["eval_micro_small", "eval_micro", "eval_micro_2x2"])
 def test_itscp_micro_mode_evaluation_episode(oracle, golden_dir, name):
     """Evaluation episodes in `micro` mode (round 5 fixtures): without gradients nothing in the reference is a tensor -- Python floats all
     the way --, so the lanes step in the analytic operator's float64 ladder here (not the float32 tensor ladder of the differentiable

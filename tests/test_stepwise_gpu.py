@@ -103,7 +103,8 @@ def test_stepwise_micro_mode_matches_reference(cuda, golden_dir, name):
     assert rel_max(o["grad"], g["g_action"]) <= TOL_GRAD
 
 
-@pytest.mark.parametrize("name", ["eval_macro", "eval_macro_2x2", "eval_hybrid_short", "eval_hybrid_p2", "eval_hybrid", "eval_hybrid_4x4"])
+@pytest.mark.parametrize("name", ["eval_macro", "eval_macro_2x2", "eval_hybrid_short", "eval_hybrid_p2", "eval_hybrid", "eval_hybrid_4x4",
+                                  "eval_macro_3x3x3", "eval_hybrid_n2l30", "eval_hybrid_5x5"])
 def test_stepwise_evaluation_episode_matches_reference(cuda, golden_dir, name):
     """ItscpEnv.step(action, False) (Trainer.evaluate): hard thresholds."""
     g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
@@ -530,7 +531,7 @@ def test_env_ladder_survives_a_fused_launch_that_does_not_fit(cuda, golden_dir, 
     assert env.last_path == "stepwise" and env._fused_cache[1].lane_capacity == 32
 
 
-@pytest.mark.parametrize("name", ["eval_micro_small", "eval_micro"])
+@pytest.mark.parametrize("name", ["eval_micro_small", "eval_micro", "eval_micro_2x2"])
 def test_micro_mode_evaluation_episode_matches_reference(cuda, golden_dir, name):
     """Evaluation episodes in `micro` mode (Trainer.evaluate on run_itscp_micro.sh's environment): the reference holds Python floats all
     the way there, the kernels step the lanes in the analytic operator's float64 ladder (the float32 tensor ladder is for differentiable
@@ -546,7 +547,11 @@ def test_micro_mode_evaluation_episode_matches_reference(cuda, golden_dir, name)
         assert o["counts"][0] == m["n_vehicle_spawned"] and o["counts"][3] == len(g["rand_draws"])
         assert rel_max(o["queue"].T, g["queue"]) <= TOL_STATE, persistent
         assert abs(o["reward"] - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
-    dtab = ops.DeviceHybridTables(t, rows, cuda)
+    try:
+        dtab = ops.DeviceHybridTables(t, rows, cuda)
+    except ValueError:                  # (112 IDM lanes: beyond the fused kernels)
+        assert name == "eval_micro_2x2"
+        return
     reward, queue, counts = ops.net_hybrid_eval(torch.tensor(g["action"][None], device=cuda), dtab, *_args(m))
     assert int(counts[0, 0]) == m["n_vehicle_spawned"]
     assert rel_max(queue[0].cpu().numpy().T, g["queue"]) <= TOL_STATE

@@ -973,6 +973,16 @@ def main():
             os.environ["DHTS_FINE_CUTS"] = "60"
             os.environ.pop("DHTS_LANE_LATE", None)
             gen_itscp("micro_2x2", "micro", 2, 2, 10.0, 4, 1, seed=83, action_kind="rand", problem=3)
+        # evaluation episodes of the networks above the fused kernels' limits (end of round 5: pins of the stepwise path's evaluation
+        # instantiation at those sizes)
+        if "eval_macro_3x3x3" in which:
+            gen_itscp("eval_macro_3x3x3", "macro", 3, 3, 30.0, 4, 2, seed=61, action_kind="rand", problem=2, differentiable=False)
+        if "eval_hybrid_n2l30" in which:
+            gen_itscp("eval_hybrid_n2l30", "hybrid", 3, 2, 30.0, 8, 2, seed=79, action_kind="rand", problem=1, differentiable=False)
+        if "eval_hybrid_5x5" in which:
+            gen_itscp("eval_hybrid_5x5", "hybrid", 5, 1, 5.0, 8, 2, seed=73, action_kind="rand", problem=1, differentiable=False)
+        if "eval_micro_2x2" in which:
+            gen_itscp("eval_micro_2x2", "micro", 2, 2, 10.0, 4, 1, seed=83, action_kind="rand", problem=3, differentiable=False)
         if "hybrid_short" in which:      # 8 s: enough for the first vehicles to cross the interior intersection
             gen_itscp("hybrid_short", "hybrid", 3, 1, 5.0, 8, 2, seed=9, action_kind="rand")
 
