@@ -321,7 +321,7 @@ def test_hybrid_evaluation_episode_vs_reference(cuda, oracle, golden_dir, name):
     assert torch.equal(reward, reward2) and torch.equal(queue, queue2)
 
 
-@pytest.mark.parametrize("name", ["micro_small", "micro"])
+@pytest.mark.parametrize("name", ["micro_small", "micro", "micro_p2", "micro_l10"])
 def test_itscp_micro_mode_through_fused_kernels(cuda, oracle, golden_dir, name):
     """itscp `micro` mode (run_itscp_micro.sh: 40 IDM lanes, no cells, 65 vehicles admitted stochastically by the source lanes,
     _simulator.py:153-174) through dhts_net_hybrid_rollout_fwd / _bwd: the recorded admission draws as data, waiting routes as

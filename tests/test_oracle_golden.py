@@ -279,7 +279,7 @@ def itscp_micro_tables(g):
     return t, m, np.asarray(rows, dtype=np.int32)
 
 
-@pytest.mark.parametrize("name", ["micro_small", "micro", "micro_2x2"])
+@pytest.mark.parametrize("name", ["micro_small", "micro", "micro_2x2", "micro_p2", "micro_l10"])
 def test_itscp_micro_mode_network(oracle, golden_dir, name):
     """itscp `micro` mode (run_itscp_micro.sh: 40 IDM lanes, 65 vehicles admitted stochastically over 300 steps; and a 16-lane
     case): source lanes admit waiting vehicles against the host's recorded draws (_simulator.py:153-174), every recorded draw

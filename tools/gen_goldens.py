@@ -913,6 +913,16 @@ def main():
             os.environ["DHTS_FINE_CUTS"] = "150"
             os.environ.pop("DHTS_LANE_LATE", None)
             gen_itscp("micro", "micro", 1, 3, 30.0, 10, 2, seed=13, action_kind="rand")
+        # further differentiable `micro`-mode runs (end of round 5: more pins of the float32 tensor ladder): two lanes per approach over
+        # problem_2's inflows, 6 s; one lane per approach with 10 m lanes (vehicles leave their lane every few steps), 1 s signals
+        if "micro_p2" in which:
+            os.environ["DHTS_FINE_CUTS"] = "90"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("micro_p2", "micro", 1, 2, 30.0, 6, 2, seed=23, action_kind="rand", problem=2)
+        if "micro_l10" in which:
+            os.environ["DHTS_FINE_CUTS"] = "90"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("micro_l10", "micro", 1, 1, 10.0, 6, 1, seed=31, action_kind="rand", problem=3)
         if "micro_small" in which:       # one lane per approach, 4 s
             os.environ["DHTS_FINE_CUTS"] = "60"
             os.environ.pop("DHTS_LANE_LATE", None)
