@@ -325,6 +325,44 @@ __global__ void micro_rollout_bwd_kernel(
     if (t == 0 && s_bad >= 0) raise_fault_m(err, DHTS_FAULT_NAN, s_bad >> 10, lane, 1023 - (s_bad & 1023));
 }
 
+// The single-step operator in the float32 TENSOR ladder (idm_step_f32): what the reference's plain MicroLane computes when its vehicle
+// states are torch tensors -- itscp `micro` mode, differentiable episodes (example/control/itscp/_env.py:484-498; _micro_lane.py:131-214
+// evaluated by torch).  One thread per vehicle slot; same tape as dhts_micro_step_fwd ([lane][2][Vp][4]), same reverse operator.
+__global__ void micro_step_tensor_fwd_kernel(int L, int V, double dt, const float *__restrict__ p_in, const float *__restrict__ v_in,
+                                             const int32_t *__restrict__ count, const double *__restrict__ params,
+                                             const double *__restrict__ head, float *__restrict__ p_out, float *__restrict__ v_out,
+                                             float *__restrict__ tape, dhts_error *err) {
+    const int lane = blockIdx.x;
+    const size_t base = (size_t)lane * V, plane = (size_t)L * V;
+    const int n = count ? count[lane] : V;
+    const int Vp = (V + 63) & ~63;
+    float4 *tp = tape ? reinterpret_cast<float4 *>(tape) + (size_t)lane * 2 * Vp : nullptr;
+    int fault_index = -1;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        if (i >= n) { p_out[base + i] = p_in[base + i]; v_out[base + i] = v_in[base + i]; continue; }
+        IdmParams m;
+        m.a_max = params[0 * plane + base + i]; m.a_pref = params[1 * plane + base + i]; m.v_target = params[2 * plane + base + i];
+        m.min_space = params[3 * plane + base + i]; m.time_pref = params[4 * plane + base + i]; m.length = params[5 * plane + base + i];
+        const float pi = p_in[base + i], vi = v_in[base + i];
+        float dp, dv;
+        if (i == n - 1) { dp = (float)head[(size_t)lane * 2]; dv = (float)head[(size_t)lane * 2 + 1]; }
+        else {
+            const double len_l = params[5 * plane + base + i + 1];
+            dp = fabsf(p_in[base + i + 1] - pi) - (float)((len_l + m.length) * 0.5);
+            dv = vi - v_in[base + i + 1];
+        }
+        IdmStep o;
+        idm_step_f32(pi, vi, dp, dv, m, dt, o);
+        if (o.collided && fault_index < 0) fault_index = i;
+        p_out[base + i] = o.np; v_out[base + i] = o.nv;
+        if (tp) {
+            tp[i] = make_float4(o.dE[0], o.dE[1], o.dE[2], o.dE[3]);
+            tp[Vp + i] = make_float4(o.dLd[0], o.dLd[1], o.dLd[2], o.dLd[3]);
+        }
+    }
+    if (fault_index >= 0) raise_fault_m(err, DHTS_FAULT_COLLISION, 0, lane, fault_index);
+}
+
 }  // namespace dhts
 
 using namespace dhts;
@@ -460,6 +498,15 @@ int dhts_micro_step_fwd(const dhts_micro_desc *d,
                         const float *p, const float *v, const int32_t *count, const double *params, const double *head,
                         float *p_out, float *v_out, float *tape, dhts_error *err, void *stream) {
     return micro_fwd_launch<false>(d, 1, p, v, count, params, head, p_out, v_out, tape, nullptr, err, stream);
+}
+int dhts_micro_step_fwd_tensor(const dhts_micro_desc *d,
+                               const float *p, const float *v, const int32_t *count, const double *params, const double *head,
+                               float *p_out, float *v_out, float *tape, dhts_error *err, void *stream) {
+    if (!micro_desc_ok(d) || !p || !v || !params || !head || !p_out || !v_out) return DHTS_E_INVALID;
+    const int B = d->capacity <= 64 ? 64 : (d->capacity <= 128 ? 128 : 256);
+    micro_step_tensor_fwd_kernel<<<d->n_lanes, B, 0, (hipStream_t)stream>>>(d->n_lanes, d->capacity, d->dt, p, v, count, params, head, p_out,
+                                                                          v_out, tape, err);
+    return launch_status_m();
 }
 int dhts_micro_step_bwd(const dhts_micro_desc *d, const float *tape, const int32_t *count,
                         const float *g_p, const float *g_v,

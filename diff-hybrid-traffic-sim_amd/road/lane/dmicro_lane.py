@@ -51,7 +51,10 @@ class dMicroForwardLayer(th.autograd.Function):
         head = th.tensor([[float(lane.head_position_delta), float(lane.head_speed_delta)]], dtype=th.float64, device=dev)
         tape = th.empty(ops.micro_step_tape_numel(desc), dtype=th.float32, device=dev)
         err = ops.new_error_record(dev)
-        np_, nv_ = ops.micro_step_fwd(desc, pd[:-1].reshape(1, v), sd[:-1].reshape(1, v), params, head, tape=tape, err=err)
+        # (a plain MicroLane in a differentiable episode: the reference steps it in float32 tensor arithmetic, _env.py:484-498)
+        tensor_ladder = type(lane).__name__ == "MicroLane" and bool(getattr(lane, "_tensor_ladder", False))
+        np_, nv_ = ops.micro_step_fwd(desc, pd[:-1].reshape(1, v), sd[:-1].reshape(1, v), params, head, tape=tape, err=err,
+                                      tensor_ladder=tensor_ladder)
         code = err.tolist()
         if code[0] == 2:
             print("Collision detected at vehicle %d" % code[3])

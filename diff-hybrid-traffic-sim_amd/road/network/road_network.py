@@ -57,6 +57,9 @@ class RoadNetwork:
         for lane in self.lane.values():
             self.setup_boundary(lane.id, differentiable)
         for lane in self.lane.values():
+            # the reference's PLAIN MicroLane (itscp `micro` mode) holds torch tensors in a differentiable episode and steps in their
+            # float32 arithmetic; its dMicroLane (hybrid mode) and every evaluation episode compute with Python floats
+            lane._tensor_ladder = bool(differentiable)
             lane.forward(delta_time)
         for lane in self.lane.values():
             lane.update_state()

@@ -276,6 +276,14 @@ int dhts_micro_rollout_plan(const dhts_micro_desc *d, int T, int has_count, int3
 int dhts_micro_step_fwd(const dhts_micro_desc *d,
                         const float *p, const float *v, const int32_t *count, const double *params, const double *head,
                         float *p_out, float *v_out, float *tape, dhts_error *err, void *stream);
+/* The same step in the float32 TENSOR ladder: what the reference's plain MicroLane (road/lane/_micro_lane.py:131-214 over
+ * model/micro/_idm.py:6-50) computes when its vehicle states are torch tensors -- every operation rounds to float32, Python float
+ * operands are cast first, pow(x, 2.0) = x * x, pow(x, 4.0) = powf.  itscp `micro` mode steps its lanes that way in differentiable
+ * episodes (example/control/itscp/_env.py:484-498).  Same arguments, same tape (the analytic Jacobian blocks at the same operands:
+ * what autograd differentiates), same reverse operator dhts_micro_step_bwd. */
+int dhts_micro_step_fwd_tensor(const dhts_micro_desc *d,
+                               const float *p, const float *v, const int32_t *count, const double *params, const double *head,
+                               float *p_out, float *v_out, float *tape, dhts_error *err, void *stream);
 /* The single-step reverse keeps the operator form of dMicroForwardLayer.backward: the cotangent of the virtual
  * leader slot is NOT folded back into the head vehicle; g_head [L][2] DOUBLE returns it raw as (g_p[V], g_s[V]). */
 int dhts_micro_step_bwd(const dhts_micro_desc *d, const float *tape, const int32_t *count,
