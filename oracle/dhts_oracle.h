@@ -95,6 +95,11 @@ void oracle_idm_jac(double a_max, double a_pref, double v, double v_target, doub
 int oracle_micro_step(int V, const float *p, const float *v, const double *params,
                       double head_dp, double head_dv, double dt,
                       float *np_, float *nv_, float *dqs, int *err_index);
+/* The same step as the reference's PLAIN MicroLane computes it on torch tensors (itscp `micro` mode, differentiable episodes): every
+ * operation in float32 (road/lane/_micro_lane.py:131-214 + model/micro/_idm.py:30-50 evaluated by torch). */
+int oracle_micro_step_f32(int V, const float *p, const float *v, const double *params,
+                          double head_dp, double head_dv, double dt,
+                          float *np_, float *nv_, float *dqs, int *err_index);
 /* dMicroForwardLayer.backward (dmicro_lane.py:271-298): g_np, g_nv [V] -> g_p, g_v [V+1] */
 void oracle_micro_step_bwd(int V, const float *dqs, const float *g_np, const float *g_nv,
                            float *g_p, float *g_v);

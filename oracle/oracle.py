@@ -43,6 +43,7 @@ def lib():
         _lib.oracle_macro_rollout_fwd.argtypes = [C.c_int] * 3 + [C.c_double] * 3 + [C.c_void_p] * 11
         _lib.oracle_macro_rollout_bwd.argtypes = [C.c_int] * 3 + [C.c_double] + [C.c_void_p] * 19
         _lib.oracle_micro_step.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_double] * 3 + [C.c_void_p] * 4
+        _lib.oracle_micro_step_f32.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_double] * 3 + [C.c_void_p] * 4
         _lib.oracle_micro_step_bwd.argtypes = [C.c_int] + [C.c_void_p] * 5
         _lib.oracle_micro_rollout_fwd.argtypes = [C.c_int] * 3 + [C.c_double] + [C.c_void_p] * 3 + [C.c_double] * 2 + [C.c_void_p] * 5
         _lib.oracle_micro_rollout_bwd.argtypes = [C.c_int] * 3 + [C.c_void_p] * 8
@@ -176,6 +177,18 @@ def micro_step(p, v, params, head_dp, head_dv, dt, want_tape=True):
     ei = C.c_int(-1)
     rc = lib().oracle_micro_step(V, _p(p), _p(v), _p(params), float(head_dp), float(head_dv), float(dt),
                                  _p(np_), _p(nv_), _p(dqs), C.addressof(ei))
+    return dict(rc=rc, np=np_, nv=nv_, dqs=dqs, err_index=ei.value)
+
+
+def micro_step_f32(p, v, params, head_dp, head_dv, dt, want_tape=True):
+    """The same step in the reference's float32 TENSOR ladder (plain MicroLane on torch tensors: itscp `micro` mode)."""
+    p, v, params = _f32(p), _f32(v), _f64(params)
+    V = p.shape[0]
+    np_, nv_ = np.zeros(V, np.float32), np.zeros(V, np.float32)
+    dqs = np.zeros((V, 2, 2, 2), np.float32) if want_tape else None
+    ei = C.c_int(-1)
+    rc = lib().oracle_micro_step_f32(V, _p(p), _p(v), _p(params), float(head_dp), float(head_dv), float(dt),
+                                     _p(np_), _p(nv_), _p(dqs), C.addressof(ei))
     return dict(rc=rc, np=np_, nv=nv_, dqs=dqs, err_index=ei.value)
 
 

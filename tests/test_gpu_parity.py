@@ -1015,3 +1015,38 @@ def test_micro_bwd_fault_reads_the_autograd_sweeps_record(cuda):
     assert where is not None and where[1] == 1 and where[0] == T - 1 and any(issubclass(x.category, RuntimeWarning) for x in w)
     loss.backward()                                   # a finite sweep over the same graph: the record starts clean
     assert ops.micro_bwd_fault(warn=False) is None
+
+
+@pytest.mark.parametrize("V", [1, 5, 64, 97])
+def test_micro_step_tensor_ladder_vs_oracle(cuda, oracle, V):
+    """dhts_micro_step_fwd_tensor (the plain MicroLane's float32 tensor arithmetic: itscp `micro` mode) against the oracle's restatement
+    of the same ladder: next state bit for bit, Jacobian blocks to float32 rounding; and it is NOT the analytic operator's ladder."""
+    import torch
+    from dhts import ops
+    rng = np.random.default_rng(100 + V)
+    L = 3
+    p = np.sort(rng.uniform(0.0, 12.0 * V, (L, V)).astype(np.float32), axis=1)
+    p += np.arange(V, dtype=np.float32)[None, :] * 6.0                       # gaps of at least a vehicle length
+    v = rng.uniform(0.0, 25.0, (L, V)).astype(np.float32)
+    prm = np.empty((L, V, 6)); prm[:] = [2.0, 1.6, 30.0, 2.0, 1.5, 5.0]
+    prm[..., 2] += rng.uniform(-3, 3, (L, V))
+    head = np.stack([rng.uniform(5.0, 60.0, L), rng.uniform(-3.0, 3.0, L)], axis=1)
+    head = head.astype(np.float32).astype(np.float64)                          # (the head gap is a float32 tensor's value there)
+    dt = 1.0 / 30.0
+    desc = ops.micro_desc(L, V, dt)
+    tape = torch.empty(ops.micro_step_tape_numel(desc), dtype=torch.float32, device=cuda)
+    params_d = torch.tensor(np.ascontiguousarray(prm.transpose(2, 0, 1)), dtype=torch.float64, device=cuda)
+    args = (desc, torch.tensor(p, device=cuda), torch.tensor(v, device=cuda), params_d, torch.tensor(head, device=cuda))
+    np_t, nv_t = ops.micro_step_fwd(*args, tape=tape, tensor_ladder=True)
+    np_a, nv_a = ops.micro_step_fwd(*args, tensor_ladder=False)
+    Vp = (V + 63) // 64 * 64
+    tp = tape.view(L, 2, Vp, 4).cpu().numpy()
+    differs = 0
+    for l in range(L):
+        o = oracle.micro_step_f32(p[l], v[l], prm[l], head[l, 0], head[l, 1], dt)
+        assert o["rc"] == 0
+        assert np.array_equal(np_t[l].cpu().numpy(), o["np"]) and np.array_equal(nv_t[l].cpu().numpy(), o["nv"]), l
+        dq = o["dqs"].reshape(V, 2, 4)
+        assert rel_max(tp[l, 0, :V], dq[:, 0]) <= 1e-6 and rel_max(tp[l, 1, :V], dq[:, 1]) <= 1e-6
+        differs += int((nv_a[l].cpu().numpy() != o["nv"]).sum())
+    assert V == 1 or differs > 0
