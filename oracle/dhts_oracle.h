@@ -178,4 +178,8 @@ int oracle_net_hybrid(const oracle_net_desc *d, const int *lane_macro, const dou
 #ifdef __cplusplus
 }
 #endif
+/* 1 = the itscp network oracles evaluate their running means as numpy does on the reference's float32 array (pairwise float32
+ * summation, O(window) per sample); 0 (default) = exact float64 prefix means */
+void oracle_set_numpy_mean(int on);
+
 #endif

@@ -180,6 +180,11 @@ def micro_step(p, v, params, head_dp, head_dv, dt, want_tape=True):
     return dict(rc=rc, np=np_, nv=nv_, dqs=dqs, err_index=ei.value)
 
 
+def set_numpy_mean(on):
+    """The network oracles' running means as numpy computes them on the reference's float32 array (rms.py) -- O(window) per sample."""
+    lib().oracle_set_numpy_mean(1 if on else 0)
+
+
 def micro_step_f32(p, v, params, head_dp, head_dv, dt, want_tape=True):
     """The same step in the reference's float32 TENSOR ladder (plain MicroLane on torch tensors: itscp `micro` mode)."""
     p, v, params = _f32(p), _f32(v), _f64(params)
