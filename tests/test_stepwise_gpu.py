@@ -556,3 +556,29 @@ def test_micro_mode_evaluation_episode_matches_reference(cuda, golden_dir, name)
     assert int(counts[0, 0]) == m["n_vehicle_spawned"]
     assert rel_max(queue[0].cpu().numpy().T, g["queue"]) <= TOL_STATE
     assert abs(float(reward[0]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+
+
+@pytest.mark.parametrize("name, seed", [("micro_small", 11), ("micro_p2", 12), ("micro_l10", 13)])
+def test_micro_mode_random_actions_vs_oracle(cuda, golden_dir, oracle, name, seed):
+    """Other signal schedules in `micro` mode (other admissions, other lane changes) on the float32 tensor ladder: the persistent kernels
+    against the CPU oracle -- same draws consumed, same vehicles, queues, reward, gradient."""
+    from dhts.network import group_routes
+    from dhts.stepwise import StepwiseNetwork, default_lane_capacity
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    t, m, rows = itscp_micro_tables(g)
+    rng = np.random.default_rng(seed)
+    t.set_micro_sources(np.concatenate([g["rand_draws"], rng.random(8 * len(g["rand_draws"]))]))     # (another schedule asks for more draws)
+    rows = np.concatenate([rows] * 3)                                                                  # ... and may admit more vehicles
+    gr, ptr = group_routes(rows, t.n_lanes)
+    net = StepwiseNetwork(t, rows, cuda, lane_capacity=default_lane_capacity(t, m["vehicle_length"]), persistent=True)
+    worst_q = worst_g = 0.0
+    for k in range(3):
+        act = rng.uniform(0.1, 0.9, len(g["action"])).astype(np.float32)
+        o = _run(cuda, net, m, act)
+        ref = oracle.net_hybrid(t, gr, ptr, act, *_args(m))
+        assert ref["rc"] == 0 and o["counts"][0] == ref["n_spawned"] and o["counts"][3] == ref["draws_used"], k
+        worst_q = max(worst_q, rel_max(o["queue"], ref["queue"]))
+        assert abs(o["reward"] - ref["reward"]) <= 1e-5 * abs(ref["reward"])
+        worst_g = max(worst_g, np.abs(o["grad"] - ref["g_action"]).max() / np.abs(ref["g_action"]).max())
+    print("%s: persistent kernels vs oracle on random actions: queues %.1e, gradient %.1e" % (name, worst_q, worst_g))
+    assert worst_q <= TOL_STATE and worst_g <= TOL_GRAD
