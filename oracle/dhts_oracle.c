@@ -303,6 +303,9 @@ static void matmul22(const float a[4], const float b[4], float o[4]) {
     o[3] = dot2(a[2], b[1], a[3], b[3]);
 }
 
+/* the left ghost of an itscp SOURCE lane in double (oracle_set_source_ghost_f64, dhts_oracle_hybrid.inc) */
+static _Thread_local int oracle_src_ghost_on = 0;
+static _Thread_local double oracle_src_ghost[4];
 int oracle_macro_step(int N, const float *r, const float *y, const float *u, const float *ueq,
                       double dt, double dx, double u_max,
                       float *nr, float *ny, float *nu, float *nueq, float *dqs,
@@ -319,6 +322,7 @@ int oracle_macro_step(int N, const float *r, const float *y, const float *u, con
     for (int i = 0; i < nI; i++) {                         /* _solve_riemann :116-146 */
         fullq QL = {r[i], y[i], u[i], ueq[i]};
         fullq QR = {r[i + 1], y[i + 1], u[i + 1], ueq[i + 1]};
+        if (i == 0 && oracle_src_ghost_on) { QL.r = oracle_src_ghost[0]; QL.y = oracle_src_ghost[1]; QL.u = oracle_src_ghost[2]; QL.ueq = oracle_src_ghost[3]; }
         double s0, s1;
         riemann(&QL, &QR, u_max, &ci[i], &Q0[i], &s0, &s1);
         if (case_out) case_out[i] = ci[i];
@@ -343,6 +347,7 @@ int oracle_macro_step(int N, const float *r, const float *y, const float *u, con
         if (nu && nueq) oracle_arz_from_r_y(nrk, nyk, (float)u_max, &nu[k], &nueq[k]);   /* set_next_state_vector_y */
         if (dqs) {                                         /* dMacroLane._backward :96-132 */
             fullq cl = {r[k], y[k], u[k], ueq[k]};
+            if (k == 0 && oracle_src_ghost_on) { cl.r = oracle_src_ghost[0]; cl.y = oracle_src_ghost[1]; cl.u = oracle_src_ghost[2]; cl.ueq = oracle_src_ghost[3]; }
             fullq ct = {r[k + 1], y[k + 1], u[k + 1], ueq[k + 1]};
             fullq cr = {r[k + 2], y[k + 2], u[k + 2], ueq[k + 2]};
             float LdL[4], LdR[4], RdL[4], RdR[4], fpL[4], fpR[4], m[4], m2[4];

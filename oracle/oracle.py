@@ -185,6 +185,11 @@ def set_numpy_mean(on):
     lib().oracle_set_numpy_mean(1 if on else 0)
 
 
+def set_source_ghost_f64(on):
+    """The upstream ghost of an itscp source lane in double (the reference's Python floats) instead of its float32 rounding."""
+    lib().oracle_set_source_ghost_f64(1 if on else 0)
+
+
 def micro_step_f32(p, v, params, head_dp, head_dv, dt, want_tape=True):
     """The same step in the reference's float32 TENSOR ladder (plain MicroLane on torch tensors: itscp `micro` mode)."""
     p, v, params = _f32(p), _f32(v), _f64(params)
