@@ -847,6 +847,7 @@ template <class A> __device__ __forceinline__ void ns_convert(const A &a, int t,
     // (3) a thread per lane adds its terms in order.  Scratch (behind the candidate flags): laneS [L] | laneN [L] | termC [C] | termV [plane]
     double *laneS = reinterpret_cast<double *>(cand);
     int *laneN = reinterpret_cast<int *>(laneS + L);
+    if (Lm == 0) { NS_SUB0() }
     float *termC = reinterpret_cast<float *>(laneN + L), *termV = termC + C;
     for (int base = 0; base < L; base += B) {
         const int l = base + tid;
@@ -871,6 +872,7 @@ template <class A> __device__ __forceinline__ void ns_convert(const A &a, int t,
         n0 += tot_n; S0 += tot_s;
     }
     __syncthreads();
+    NS_SUB(6)
     for (int c = tid; c < C; c += B) {
         const int l = a.cell_lane[c], off = a.lane_off[l], k = c - off;
         double S = laneS[l];
@@ -901,7 +903,9 @@ template <class A> __device__ __forceinline__ void ns_convert(const A &a, int t,
         kc_veh[idx] = kk; vx[idx] = x;
         termV[idx] = soft_switch(x, kk);
     }
+    NS_SUB(7)
     __syncthreads();
+    NS_SUB(15)
     for (int l = tid; l < L; l += B) {
         float qlen = 0.f;
         if (a.lane_macro[l]) {
@@ -1618,7 +1622,8 @@ __global__ void __launch_bounds__(kNsBlock) ns_persist_fwd_kernel(NsArgs a0, con
         printf("   micro: admission %lld | head gaps %lld | IDM %lld;  hand-offs: capacitors %lld | event walk %lld | loss %lld\n",
                ns_sub_[0] / T, ns_sub_[1] / T, ns_sub_[2] / T, ns_sub_[3] / T, ns_sub_[4] / T, ns_sub_[5] / T);
     if (blockIdx.x == 0 && tid == 0)
-        printf("   head gaps: lane part %lld | scans %lld (rest in 'head gaps')\n", ns_sub_[16] / T, ns_sub_[17] / T);
+        printf("   head gaps: lane part %lld | scans %lld (rest in 'head gaps');  loss: lane prefixes %lld | samples (thread 0) %lld | wait %lld | lane sums = 'loss'\n",
+               ns_sub_[16] / T, ns_sub_[17] / T, ns_sub_[6] / T, ns_sub_[7] / T, ns_sub_[15] / T);
 #endif
     if (fault_step >= 0) net_fault(a.err, DHTS_FAULT_CFL, fault_step, fault_lane, fault_index);
     if constexpr (MS) {                  // what the reverse sweep starts from
