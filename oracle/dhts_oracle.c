@@ -303,9 +303,15 @@ static void matmul22(const float a[4], const float b[4], float o[4]) {
     o[3] = dot2(a[2], b[1], a[3], b[3]);
 }
 
-/* the left ghost of an itscp SOURCE lane in double (oracle_set_source_ghost_f64, dhts_oracle_hybrid.inc) */
+/* The upstream ghost of an itscp SOURCE lane enters the Riemann solve as the Python floats the reference holds there
+ * (_simulator.py:68-71: inflow r from the schedule, u = u_eq(r) in double; dMacroLane.decell leaves plain floats alone), not as
+ * their float32 roundings: the network functions park the doubles here for the lane's step.  oracle_set_source_ghost_f64(0) rounds
+ * them like every other ghost cell (what oracle and kernels did until the end of round 5: a 1-ulp effect on the lane's first cell
+ * from the first step on, the first half of the hybrid fixtures' 1.5-4e-6; tests/test_oracle_golden.py::test_source_ghost_in_double). */
 static _Thread_local int oracle_src_ghost_on = 0;
 static _Thread_local double oracle_src_ghost[4];
+static int oracle_source_ghost_f64 = 1;
+void oracle_set_source_ghost_f64(int on) { oracle_source_ghost_f64 = on; }
 int oracle_macro_step(int N, const float *r, const float *y, const float *u, const float *ueq,
                       double dt, double dx, double u_max,
                       float *nr, float *ny, float *nu, float *nueq, float *dqs,
@@ -804,12 +810,17 @@ int oracle_net_macro_fwd(const oracle_net_desc *d, const int *lane_ncell, const 
             for (int i = 0; i < n; i++) { r[i + 1] = cur[off + i]; y[i + 1] = cur[C + off + i]; u[i + 1] = cur[2 * C + off + i]; q[i + 1] = cur[3 * C + off + i]; }
             /* upstream ghost, _simulator.py:56-108 */
             const int ls = left_src[(size_t)t * L + l], lg = left_gate[(size_t)t * L + l];
+            int src_ghost = 0;
             if (ls < 0) {               /* source lane: Python floats all the way (r = schedule, u = u_eq(r), signal 1.0) */
                 double gr = schedule[(size_t)t * L + l];
                 double gu = arz_u_eq(gr, d->u_max);
                 double fr = gr * 1.0 + 0 * (1.0 - 1.0), fu = gu * 1.0 + d->u_max * (1.0 - 1.0);
                 r[0] = (float)fr; u[0] = (float)fu;
                 y[0] = (float)arz_y(fr, fu, d->u_max); q[0] = (float)arz_u_eq(fr, d->u_max);
+                if (oracle_source_ghost_f64) {
+                    src_ghost = 1;
+                    oracle_src_ghost[0] = fr; oracle_src_ghost[1] = arz_y(fr, fu, d->u_max); oracle_src_ghost[2] = fu; oracle_src_ghost[3] = arz_u_eq(fr, d->u_max);
+                }
             } else {
                 const int sl = ls, last = lane_off[sl] + lane_ncell[sl] - 1;
                 float gr = cur[last], gu = cur[2 * C + last];
@@ -832,8 +843,10 @@ int oracle_net_macro_fwd(const oracle_net_desc *d, const int *lane_ncell, const 
                 oracle_arz_from_r_u(fr, fu, um, &y[n + 1], &q[n + 1]);
                 own_r[2 * l] = fr; own_r[2 * l + 1] = fu;      /* set_rightmost_cell overwrites the stored ghost */
             }
+            oracle_src_ghost_on = src_ghost;
             int e = oracle_macro_step(n, r, y, u, q, d->dt, lane_dx[l], d->u_max, nr, ny, nu, nq,
                                       tape + ((size_t)t * C + off) * 12, NULL, NULL, NULL);
+            oracle_src_ghost_on = 0;
             if (e && !rc) rc = e;
             for (int i = 0; i < n; i++) { nxt[off + i] = nr[i]; nxt[C + off + i] = ny[i]; nxt[2 * C + off + i] = nu[i]; nxt[3 * C + off + i] = nq[i]; }
         }

@@ -181,8 +181,9 @@ int oracle_net_hybrid(const oracle_net_desc *d, const int *lane_macro, const dou
 /* 1 = the itscp network oracles evaluate their running means as numpy does on the reference's float32 array (pairwise float32
  * summation, O(window) per sample); 0 (default) = exact float64 prefix means */
 void oracle_set_numpy_mean(int on);
-/* 1 = the upstream ghost of an itscp source lane enters the solve in double, as the reference's Python floats do; 0 (default) = its
- * float32 rounding (what the kernels' float32 ghost cells hold) */
+/* 1 (default) = the upstream ghost of an itscp source lane enters the solve in double, as the reference's Python floats do
+ * (_simulator.py:68-71) -- in oracle_net_macro_fwd and oracle_net_hybrid alike; 0 = its float32 rounding (oracle and kernels until the
+ * end of round 5) */
 void oracle_set_source_ghost_f64(int on);
 
 #endif

@@ -1,8 +1,9 @@
 """Where the oracle and the REFERENCE first part ways inside an itscp hybrid episode (this container only: imports /root/reference like
 tools/gen_goldens.py).  Runs the reference's differentiable episode of a golden's configuration, records every macro cell's (r, y, u)
 and the loss constants' inputs after every step, and compares with the oracle's state history step by step.
-    python tools/probes/ref_state_trace.py hybrid_short [--source-ghost-f64]
-(--source-ghost-f64: the oracle feeds a source lane's upstream ghost to the solve in double, as the reference's Python floats do)"""
+    python tools/probes/ref_state_trace.py hybrid_short [--source-ghost-f32]
+(--source-ghost-f32: the oracle rounds a source lane's upstream ghost to float32 as it did until the end of round 5; the default feeds it
+to the solve in double, as the reference's Python floats do)"""
 import json
 import os
 import sys
@@ -63,7 +64,7 @@ from test_oracle_golden import itscp_hybrid_tables      # noqa: E402
 from dhts.network import group_routes      # noqa: E402
 from oracle import oracle as O      # noqa: E402
 O.build()
-O.set_source_ghost_f64("--source-ghost-f64" in sys.argv)
+O.set_source_ghost_f64("--source-ghost-f32" not in sys.argv)
 t, mm = itscp_hybrid_tables(g)
 routes, route_ptr = group_routes(g["spawn_routes"], t.n_lanes)
 o = O.net_hybrid(t, routes, route_ptr, g["action"], mm["num_intersection"] ** 2, mm["simulation_frequency"] * mm["signal_length"],
