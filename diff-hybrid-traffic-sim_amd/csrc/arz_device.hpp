@@ -50,6 +50,20 @@ __device__ __forceinline__ void glue_from_r_u(float r, float u, float um, float 
     ueq = glue_u_eq(r, um);
     y = r * (u - ueq);
 }
+// The upstream ghost of an itscp SOURCE lane is a cell of Python floats in the reference (_simulator.py:68-71: r = the inflow from the
+// schedule, u = u_eq(r), both double; dMacroLane.decell leaves plain floats alone) and its Riemann solve reads them as such.  Through a
+// float32 ghost quad (r, y, u, u_eq) it travels as {NaN, 0, low word of r, high word of r}: a NaN density marks it (no ordinary ghost
+// has one), u = u_eq = u_eq(r) is evaluated in double where the quad is read, y = r (u - u_eq(r)) = 0.
+__device__ __forceinline__ void ghost_source_pack(double r, float &g0, float &g1, float &g2, float &g3) {
+    g0 = __int_as_float(0x7fc00000); g1 = 0.f;
+    g2 = __int_as_float(__double2loint(r)); g3 = __int_as_float(__double2hiint(r));
+}
+__device__ __forceinline__ bool ghost_is_source(float g0) { return g0 != g0; }
+__device__ __forceinline__ void ghost_source_unpack(float g2, float g3, double um, double &r, double &y, double &u, double &ueq) {
+    r = __hiloint2double(__float_as_int(g3), __float_as_int(g2));
+    u = u_eq_d(r, um);
+    y = 0.; ueq = u;
+}
 // FullQ.set_r_y, _arz.py:88-92
 __device__ __forceinline__ void glue_from_r_y(float r, float y, float um, float &u, float &ueq) {
     ueq = glue_u_eq(r, um);

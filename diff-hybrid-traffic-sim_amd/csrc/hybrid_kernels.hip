@@ -502,6 +502,11 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     float gl_r = 0.f, gl_u = um;                 // the lane's stored upstream ghost (side-0 ghost thread)
     const bool plain = kState && tb.plain != 0;
     if (is_ghost) { g_kind = tb.net.sig_kind[g_lane]; g_inter = tb.net.inter[g_lane]; g_macro = tb.lane_macro[g_lane] != 0; }
+    int g_if0 = 0;                               // side-0 ghost thread of an ARZ lane: the lane's first interface (its thread's flux slots)
+    if (is_ghost && g_macro && g_side == 0) {
+        g_if0 = tb.net.lane_off[g_lane];
+        for (int l = 0; l < g_lane; ++l) if (tb.lane_macro[l]) ++g_if0;
+    }
     if (kState && is_ghost && tb.ghost0) {
         const float *g0 = tb.ghost0 + ((size_t)rep * L + g_lane) * 4;
         gl_r = g0[0]; gl_u = g0[1]; own_r = g0[2]; own_u = g0[3];

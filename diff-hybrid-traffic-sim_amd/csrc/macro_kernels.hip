@@ -129,6 +129,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     IfaceConst kc;
     kc.set_um(um); kc.set_grid(dt, dx);
     int fault_step = -1, fault_index = 0;
+    // an upstream ghost in double (ghost_source_pack, arz_device.hpp: the itscp source lanes of the stepwise network paths)
+    const bool src_ghost = ghost_is_source(ghost[(size_t)lane * 8]);
+    double src_r = 0., src_y = 0., src_u = 0., src_q = 0.;
+    if (src_ghost) ghost_source_unpack(ghost[(size_t)lane * 8 + 2], ghost[(size_t)lane * 8 + 3], um, src_r, src_y, src_u, src_q);
 
     for (int step = 0; step < T; ++step) {
         const float *cur = lds + (step & 1) * 4 * P;
@@ -150,7 +154,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 const bool vi = i <= hi;
                 const bool vc = i < hi;
                 const int ip = vi ? i : hi;
-                const double rL = Sr[ip], yL = Sy[ip], uL = Su[ip], qL = Sq[ip];
+                double rL = Sr[ip], yL = Sy[ip], uL = Su[ip], qL = Sq[ip];
+                if (src_ghost && ip == 0) { rL = src_r; yL = src_y; uL = src_u; qL = src_q; }
                 const double rR = Sr[ip + 1], yR = Sy[ip + 1], uR = Su[ip + 1], qR = Sq[ip + 1];
                 Iface f;
                 arz_interface(rL, yL, uL, qL, rR, yR, uR, qR, kc, f);

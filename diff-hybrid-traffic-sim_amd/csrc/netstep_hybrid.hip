@@ -383,10 +383,8 @@ template <class A> __device__ __forceinline__ void ns_ghost_fwd_item(const A &a,
         float fr, fu, fy, fq;
         if (side == 0) {
             const int ls = rw.left_src[lane], lg = rw.left_gate[lane];
-            if (ls == -1) {                    // source lane: Python floats in the reference (_simulator.py:68-71)
-                const double sched = rw.schedule[lane];
-                const double gu = a.um_d * (1. - sqrt(fmax(sched, 0.) + kEps));
-                fr = (float)sched; fu = (float)gu; fy = 0.f; fq = (float)gu;          // y = r (u - u_eq(r)) = 0
+            if (ls == -1) {                    // source lane: Python floats in the reference, read as such by its solve (ghost_source_pack)
+                ghost_source_pack(rw.schedule[lane], fr, fy, fu, fq);
             } else {
                 float gr = 0.f, gu = um;       // ls == -3: the lane's own stored upstream ghost (its single upstream lane is micro)
                 if (ls >= 0) { const int last = a.lane_off[ls] + a.lane_ncell[ls] - 1; gr = cur[last]; gu = cur[2 * C + last]; }
@@ -1391,7 +1389,11 @@ template <class A> __device__ __forceinline__ void ns_cell_item(const A &a, cons
     const auto gh = ns_ghosts(a) + (size_t)a.lane_gpos[l] * 8;
     const double r0 = cur[c], y0 = cur[C + c], u0 = cur[2 * C + c], q0 = cur[3 * C + c];
     double rL, yL, uL, qL, rR, yR, uR, qR;
-    if (k == 0) { rL = gh[0]; yL = gh[1]; uL = gh[2]; qL = gh[3]; }
+    if (k == 0) {
+        const float g0 = gh[0];
+        if (ghost_is_source(g0)) ghost_source_unpack(gh[2], gh[3], a.um_d, rL, yL, uL, qL);       // a source lane: (r, u) in double
+        else { rL = g0; yL = gh[1]; uL = gh[2]; qL = gh[3]; }
+    }
     else { rL = cur[c - 1]; yL = cur[C + c - 1]; uL = cur[2 * C + c - 1]; qL = cur[3 * C + c - 1]; }
     if (k == n - 1) { rR = gh[4]; yR = gh[5]; uR = gh[6]; qR = gh[7]; }
     else { rR = cur[c + 1]; yR = cur[C + c + 1]; uR = cur[2 * C + c + 1]; qR = cur[3 * C + c + 1]; }

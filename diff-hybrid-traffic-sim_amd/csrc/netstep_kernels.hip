@@ -47,10 +47,8 @@ __global__ void net_ghosts_fwd_kernel(NetStepArgs a, int hard, const float *__re
     float fr, fu, fy, fq;
     if (side == 0) {
         const int src = a.left_src[lane], gate = a.left_gate[lane];
-        if (src < 0) {                 // source lane: Python floats in the reference (_simulator.py:44-47)
-            const double sched = a.schedule[lane];
-            const double gu = a.um_d * (1. - sqrt(fmax(sched, 0.) + kEps));
-            fr = (float)sched; fu = (float)gu; fy = 0.f; fq = (float)gu;      // y = r (u - u_eq(r)) = 0
+        if (src < 0) {                 // source lane: Python floats in the reference (_simulator.py:68-71), read as such by the step operator
+            ghost_source_pack(a.schedule[lane], fr, fy, fu, fq);
         } else {
             const int last = a.off[src] + a.ncell[src] - 1;
             const float gr = r[last], gu = u[last];

@@ -416,6 +416,10 @@ class BatchedMacroNetwork:
         hist_r, hist_u = [], []
         ueq_src = (um * (1.0 - torch.sqrt(torch.clamp(self.schedule, min=0.0) + 1e-5))).to(torch.float32)      # compute_u_eq of the inflow, [T][L]
         sched32 = self.schedule.to(torch.float32)
+        # a source lane's upstream ghost reaches the step operator in double (the reference's Python floats, _simulator.py:68-71): the
+        # quad {NaN, 0, low word of r, high word of r} of csrc/arz_device.hpp::ghost_source_pack
+        sched_words = self.schedule.contiguous().view(torch.int32).reshape(self.schedule.shape[0], L, 2).view(torch.float32)          # [T][L][lo, hi]
+        nan32, zero32 = torch.full((), float("nan"), **f32), torch.zeros((), **f32)
         for step in range(T):
             # ---- signals (_env.py:885-962): within a phase the action splits it, west-east green while progress < a
             ph = min(step // F, n_phase - 1)
@@ -435,6 +439,7 @@ class BatchedMacroNetwork:
             s = torch.where(gate == -2, one, torch.where(gate == -1, torch.zeros((), **f32), lane_sig[torch.clamp(gate, min=0)]))
             lf_r = g_r * s + 0.0 * (1.0 - s)
             lf_u = g_u * s + um * (1.0 - s)
+            is_src = ~has
             # ---- downstream ghosts (:56-60): the connected downstream cell (or the lane's own stored ghost) under the lane's own signal
             src = self.right_src[step]
             has = src >= 0
@@ -446,8 +451,10 @@ class BatchedMacroNetwork:
             rt_u = s2 * g_u + (1.0 - s2) * 0.0
             own_r, own_u = rt_r, rt_u
             gy, gq = _StateFromRU.apply(torch.cat([lf_r, rt_r]), torch.cat([lf_u, rt_u]), um)
-            ghost_ry = torch.stack([torch.stack([lf_r, gy[:L]], dim=-1), torch.stack([rt_r, gy[L:]], dim=-1)], dim=1)          # [L][2][2]
-            ghost_uq = torch.stack([torch.stack([lf_u, gq[:L]], dim=-1), torch.stack([rt_u, gq[L:]], dim=-1)], dim=1).detach()
+            lf_r_, lf_y_ = torch.where(is_src, nan32, lf_r), torch.where(is_src, zero32, gy[:L])
+            lf_u_, lf_q_ = torch.where(is_src, sched_words[step, :, 0], lf_u), torch.where(is_src, sched_words[step, :, 1], gq[:L])
+            ghost_ry = torch.stack([torch.stack([lf_r_, lf_y_], dim=-1), torch.stack([rt_r, gy[L:]], dim=-1)], dim=1)          # [L][2][2]
+            ghost_uq = torch.stack([torch.stack([lf_u_, lf_q_], dim=-1), torch.stack([rt_u, gq[L:]], dim=-1)], dim=1).detach()
             # ---- one ARZ step per group of lanes
             outs = [[], [], [], []]
             for g, desc in zip(self.groups, descs):

@@ -197,7 +197,13 @@ int dhts_macro_rollout_bwd(const dhts_macro_desc *d, int T, const float *tape,
 int dhts_macro_rollout_plan(const dhts_macro_desc *d, int T, int want_hist, int32_t plan[8]);
 
 /* One step = the drop-in for a batch of dMacroForwardLayer.forward / .backward calls (T = 1 of the above;
- * tape is one step's worth). */
+ * tape is one step's worth).
+ * A ghost cell of Python floats: the reference's Riemann solve reads a boundary cell that holds plain floats in double
+ * (dMacroLane.decell leaves them alone); the one such cell of the itscp networks is a SOURCE lane's upstream ghost (_simulator.py:68-71:
+ * r = the inflow of the schedule, u = u_eq(r), hence y = 0).  The step operator takes it as the LEFT quad {NaN, 0, low 32 bits of the
+ * double r, high 32 bits} (bit patterns in the float slots; csrc/arz_device.hpp::ghost_source_pack): a NaN density marks it, u = u_eq(r)
+ * is evaluated in double.  dhts_net_ghosts_fwd writes source lanes that way; the cotangent of such a ghost is of no use.  (The T-step
+ * rollouts of straight lanes above take float32 ghosts only.) */
 int dhts_macro_step_fwd(const dhts_macro_desc *d,
                         const float *r, const float *y, const float *u, const float *ueq, const float *ghost,
                         float *r_out, float *y_out, float *u_out, float *ueq_out,
@@ -348,7 +354,8 @@ int dhts_net_macro_rollout_bwd(const dhts_net_desc *d, const dhts_net_tables *t,
  * d / t as for dhts_net_macro_rollout_fwd with n_replicas = 1 (lane_off / lane_ncell give the edge cells; rows `step` of
  * left_src / left_gate / right_src / schedule are read).  r, y, u [C] = the state before the step (u = u(r, y) as the operator
  * left it); own_in / own_out [L][2] = the lanes' stored downstream ghosts (r, u) before / after (initially (0, u_max));
- * ghost [L][2][4] = (left, right) x (r, y, u, u_eq); hard != 0 = an evaluation episode's thresholds.
+ * ghost [L][2][4] = (left, right) x (r, y, u, u_eq), a source lane's left quad in the double encoding dhts_macro_step_fwd documents;
+ * hard != 0 = an evaluation episode's thresholds.
  * _bwd: g_ghost [L][2][2] double (d / d ghost (r, y)), g_own_in [L][2] = cotangent of own_out; g_own_out [L][2] is written;
  * g_r, g_y [C] and g_action [n_action] are ACCUMULATED into (edge cells in a fixed order: bit-repeatable); inter_ptr [sq + 1],
  * inter_idx = the ghost slots (2 lane + side) of every intersection in ascending order; scratch [L][2][4] float32. */
