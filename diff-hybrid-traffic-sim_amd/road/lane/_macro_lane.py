@@ -169,6 +169,11 @@ class MacroLane(BaseLane):
 
     def set_leftmost_cell(self, r, u):
         self.leftmost_cell.state = self._ghost(r, u)
+        # A boundary cell of plain Python floats stays one in the reference (dMacroLane.decell leaves floats alone) and its Riemann
+        # solve reads it in double; the one such cell of the itscp networks is a source lane's inflow (r, u_eq(r)), which the step
+        # operator takes in double (include/dhts.h, dhts_macro_step_fwd): remembered here for dMacroForwardLayer
+        self._left_source_r = float(r) if (isinstance(r, float) and isinstance(u, float)
+                                           and u == ARZ.compute_u_eq(r, self.speed_limit)) else None
 
     def set_rightmost_cell(self, r, u):
         self.rightmost_cell.state = self._ghost(r, u)

@@ -1,5 +1,6 @@
 """dMacroLane / dMacroForwardLayer on the reference's import path (road.lane.dmacro_lane; reference
 dmacro_lane.py:13-309): the drop-in operator, backed by dhts_macro_step_fwd / dhts_macro_step_bwd."""
+import numpy as np
 import torch as th
 
 from dhts import ops
@@ -48,6 +49,11 @@ class dMacroForwardLayer(th.autograd.Function):
         ghost = lane._ghost_tensor()
         ghost[0, 0, 0], ghost[0, 0, 1] = r[0].detach(), y[0].detach()
         ghost[0, 1, 0], ghost[0, 1, 1] = r[-1].detach(), y[-1].detach()
+        src_r = getattr(lane, "_left_source_r", None)
+        if src_r is not None:            # a source lane's inflow cell: Python floats in the reference, double in the operator
+            lo, hi = np.array([src_r], np.float64).view(np.float32)
+            ghost[0, 0] = th.tensor([float("nan"), 0.0, 0.0, 0.0], dtype=th.float32).to(ghost.device)
+            ghost[0, 0, 2:] = th.from_numpy(np.array([lo, hi], np.float32)).to(ghost.device)
         tape = th.empty(ops.macro_step_tape_numel(desc), dtype=th.float32, device=r.device)
         err = ops.new_error_record(r.device)
         nr, ny, nu, nq = ops.macro_step_fwd(desc, r[1:-1].detach().reshape(1, n), y[1:-1].detach().reshape(1, n),
