@@ -186,7 +186,8 @@ def set_numpy_mean(on):
 
 
 def set_source_ghost_f64(on):
-    """The upstream ghost of an itscp source lane in double (the reference's Python floats) instead of its float32 rounding."""
+    """1 (the default): the upstream ghost of an itscp source lane enters the Riemann solve in double, as the reference's Python floats do
+    (_simulator.py:68-71); 0: its float32 rounding (oracle and kernels until the end of round 5)."""
     lib().oracle_set_source_ghost_f64(1 if on else 0)
 
 

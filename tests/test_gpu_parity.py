@@ -1050,3 +1050,46 @@ def test_micro_step_tensor_ladder_vs_oracle(cuda, oracle, V):
         assert rel_max(tp[l, 0, :V], dq[:, 0]) <= 1e-6 and rel_max(tp[l, 1, :V], dq[:, 1]) <= 1e-6
         differs += int((nv_a[l].cpu().numpy() != o["nv"]).sum())
     assert V == 1 or differs > 0
+
+
+@pytest.mark.gpu
+def test_macro_step_reads_a_source_ghost_in_double(cuda):
+    """A boundary cell of plain Python floats -- an itscp source lane's inflow (r, u_eq(r)), _simulator.py:68-71 -- enters the
+    reference's Riemann solve in double.  The step operator takes it as the left quad {NaN, 0, low word of r, high word of r}
+    (include/dhts.h, dhts_macro_step_fwd): the first cell's update must be the one the interface solver (pinned bit for bit by the
+    reference's known answers above) gives for the DOUBLE ghost, and differ from the float32-rounded ghost's on some lanes."""
+    import torch
+    from dhts import ops
+    rng = np.random.default_rng(7)
+    L, N, dt, dx, um = 2048, 8, 0.05, 1.0, 15.0
+    r = rng.uniform(0.02, 0.6, (L, N)).astype(np.float32)
+    u = rng.uniform(1.0, 12.0, (L, N)).astype(np.float32)
+    ueq64 = um * (1.0 - np.sqrt(np.maximum(r.astype(np.float64), 0.0) + 1e-5))
+    ueq = ueq64.astype(np.float32)
+    y = (r * (u - ueq)).astype(np.float32)
+    src = rng.uniform(0.05, 0.5, L)                                # inflow densities: doubles with all their bits
+    src_u = um * (1.0 - np.sqrt(src + 1e-5))
+    ghost = np.zeros((L, 2, 4), np.float32)
+    ghost[:, 1] = np.stack([r[:, -1], y[:, -1], u[:, -1], ueq[:, -1]], 1)            # (an outflow copy on the right)
+    enc, rnd = ghost.copy(), ghost.copy()
+    words = src.view(np.float32).reshape(L, 2)                     # little endian: low word, high word
+    enc[:, 0, 0], enc[:, 0, 1], enc[:, 0, 2], enc[:, 0, 3] = np.nan, 0.0, words[:, 0], words[:, 1]
+    rnd[:, 0] = np.stack([src.astype(np.float32), np.zeros(L, np.float32), src_u.astype(np.float32), src_u.astype(np.float32)], 1)
+    desc = ops.macro_desc(L, N, dt, dx, um)
+    t = lambda a: torch.tensor(a, device=cuda)
+    out_e = ops.macro_step_fwd(desc, t(r), t(y), t(u), t(ueq), t(enc))
+    out_r = ops.macro_step_fwd(desc, t(r), t(y), t(u), t(ueq), t(rnd))
+    # the two interfaces of cell 0 through the batch solver, in double
+    f64 = lambda a: a.astype(np.float64)
+    i0 = np.stack([src, np.zeros(L), src_u, src_u, f64(r[:, 0]), f64(y[:, 0]), f64(u[:, 0]), f64(ueq[:, 0]), np.full(L, um)], 1)
+    i1 = np.stack([f64(r[:, 0]), f64(y[:, 0]), f64(u[:, 0]), f64(ueq[:, 0]), f64(r[:, 1]), f64(y[:, 1]), f64(u[:, 1]), f64(ueq[:, 1]),
+                   np.full(L, um)], 1)
+    fl = ops.arz_interface_batch(torch.tensor(np.concatenate([i0, i1]), device=cuda), dt=dt, dx=dx)["flux"].cpu().numpy()
+    c = dt / dx
+    nr = (f64(r[:, 0]) + (fl[:L, 0] - fl[L:, 0]) * c).astype(np.float32)
+    ny = (f64(y[:, 0]) + (fl[:L, 1] - fl[L:, 1]) * c).astype(np.float32)
+    assert np.array_equal(out_e[0][:, 0].cpu().numpy(), nr) and np.array_equal(out_e[1][:, 0].cpu().numpy(), ny)
+    assert np.array_equal(out_e[0][:, 1:].cpu().numpy(), out_r[0][:, 1:].cpu().numpy())          # nothing else moves
+    differs = ((out_e[0][:, 0] != out_r[0][:, 0]) | (out_e[1][:, 0] != out_r[1][:, 0])).float().mean().item()
+    print("first cells that differ from the float32-rounded ghost's: %.1f %%" % (100 * differs))        # (a 1-ulp input: it survives the
+    assert 0.01 <= differs                                                                               #  float32 store now and then)
