@@ -228,13 +228,20 @@ void oracle_arz_flux_prime(const double q0[4], double u_max, float fp[4]) {
  * float32, Python scalars cast to float32; torch.pow(x, 0.5) == sqrt on the reference's build).
  * model/macro/_arz.py:82-92 with :121-138
  * ---------------------------------------------------------------------------------------------- */
+/* oracle_set_sqrtf_hook(f): the float32 square root of the glue as the caller's ENVIRONMENT evaluates it.  The reference's
+ * (r + eps) ** 0.5 on a float32 tensor is torch's CPU sqrt kernel, and on the build the goldens were generated with that kernel is
+ * not correctly rounded (one ulp low for 0.6 % of the arguments: MKL's vector sqrt), while sqrtf -- and the device's -- is.  A test
+ * hands torch.sqrt in here to show that this is where the fixtures' last 1e-6 come from
+ * (tests/test_oracle_golden.py::test_glue_square_root_as_torch_computes_it); NULL (default) = sqrtf. */
+static float (*oracle_sqrtf_hook)(float) = NULL;
+void oracle_set_sqrtf_hook(float (*f)(float)) { oracle_sqrtf_hook = f; }
 static float glue_u_eq(float r, float u_max) {
     if (0.f > r) {
         /* max(r, 0.) picked the Python float 0. -> the rest is double, cast where it meets a tensor */
         return (float)((double)u_max * (1. - pow(0. + EPSILON, GAMMA)));
     }
     float t = r + (float)EPSILON;
-    t = sqrtf(t);
+    t = oracle_sqrtf_hook ? oracle_sqrtf_hook(t) : sqrtf(t);
     t = 1.f - t;
     return u_max * t;
 }

@@ -185,5 +185,7 @@ void oracle_set_numpy_mean(int on);
  * (_simulator.py:68-71) -- in oracle_net_macro_fwd and oracle_net_hybrid alike; 0 = its float32 rounding (oracle and kernels until the
  * end of round 5) */
 void oracle_set_source_ghost_f64(int on);
+/* the float32 square root of the glue (u_eq of a float32 tensor) as the caller's environment evaluates it; NULL = sqrtf (dhts_oracle.c) */
+void oracle_set_sqrtf_hook(float (*f)(float));
 
 #endif

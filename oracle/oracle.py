@@ -318,3 +318,16 @@ def net_hybrid(tab, routes, route_ptr, action, n_inter_sq, frames_per_phase, dt,
     l.oracle_set_micro_sources(None, None, 0)
     return dict(rc=rc, reward=reward.value, reward_cut=reward_cut.value, queue=queue, g_action=g if want_grad else None,
                 n_spawned=nsp.value, n_deposits=ndep.value, hist=hist, kc=kc, draws_used=draws_used)
+
+
+_SQRTF_CB = None
+
+
+def set_sqrtf_hook(fn):
+    """The glue's float32 square root through `fn(float) -> float` (e.g. torch.sqrt of a 0-dim float32 tensor: the reference's
+    environment), or None for sqrtf.  Slow (a Python call per evaluation): for the small fixtures."""
+    global _SQRTF_CB
+    cb_t = C.CFUNCTYPE(C.c_float, C.c_float)
+    cb = cb_t(fn) if fn is not None else C.cast(None, cb_t)
+    lib().oracle_set_sqrtf_hook(cb)
+    _SQRTF_CB = cb            # keep the trampoline alive while the C side holds it

@@ -338,10 +338,11 @@ def test_itscp_micro_mode_evaluation_episode(oracle, golden_dir, name):
 
 
 def test_running_mean_as_numpy_computes_it(oracle, golden_dir):
-    """Where the last 2e-6 of the `micro`-mode fixtures come from: the reference keeps its RunningMean samples in a float32 array and
-    takes np.mean of it at every sample (example/common/rms.py:8-22) -- numpy's PAIRWISE float32 summation, O(window) per sample.  With
-    the oracle's means evaluated that way the fixtures agree to 3e-7 (the gradient of `micro_small` bit for bit); the default, and
-    the kernels, keep the exact float64 prefix mean that summation approximates."""
+    """Where the 2e-6 of the `micro`-mode fixtures come from: the reference keeps its RunningMean samples in a float32 array and takes
+    np.mean of it at every sample (example/common/rms.py:8-22) -- numpy's PAIRWISE float32 summation (eight accumulators per block of up
+    to 128 elements, blocks halved above that), O(window) per sample.  With the oracle's means evaluated that way the queues of
+    `micro_small` are the reference's bit for bit and those of `micro` agree to 1e-9 (gradient 2e-7); the default, and the kernels, keep
+    the exact float64 prefix mean that summation approximates."""
     from dhts.network import group_routes
     res = {}
     try:
@@ -357,8 +358,48 @@ def test_running_mean_as_numpy_computes_it(oracle, golden_dir):
     finally:
         oracle.set_numpy_mean(0)
     print(res)
-    assert res[(1, "micro")][0] <= 5e-7 and res[(1, "micro")][1] <= 1e-6 and res[(0, "micro")][0] > 1e-6
-    assert res[(1, "micro_small")][0] <= 5e-7 and res[(1, "micro_small")][1] == 0.0
+    assert res[(1, "micro")][0] <= 1e-8 and res[(1, "micro")][1] <= 5e-7 and res[(0, "micro")][0] > 1e-6
+    assert res[(1, "micro_small")][0] == 0.0 and res[(1, "micro_small")][1] <= 2e-7
+
+
+def test_glue_square_root_as_torch_computes_it(oracle, golden_dir):
+    """Where the last 1e-6 of the macro and hybrid fixtures come from: u_eq of a float32 tensor is (r + eps) ** 0.5 = torch's CPU float32
+    square root, and on the build the goldens were generated with (this container's) that kernel is not correctly rounded -- one ulp low
+    for 0.6 % of the arguments -- while sqrtf, and the device's, is.  With torch.sqrt handed to the oracle's glue AND the running
+    means as numpy computes them, the queues of `macro_small` are the reference's bit for bit and the other fixtures agree to a float32
+    ulp of the largest term; neither is a property of the reference's algorithm, so the oracle's defaults and the kernels keep IEEE's
+    square root and the exact mean."""
+    import torch
+    from dhts.network import group_routes
+    probe = torch.full((), 0.16979104280471802, dtype=torch.float32)
+    if float(torch.sqrt(probe)) != float(np.float32(0.41205707)):
+        pytest.skip("this torch build rounds its float32 sqrt correctly: not the environment the goldens were generated in")
+    buf = torch.zeros((), dtype=torch.float32)
+
+    def torch_sqrt(x):
+        buf.fill_(x)
+        return torch.sqrt(buf).item()
+
+    res = {}
+    try:
+        for name in ("macro_small", "macro", "hybrid_short"):
+            g = load(golden_dir, "itscp_%s.npz" % name)
+            t, m = itscp_hybrid_tables(g)
+            rows = g["spawn_routes"] if g["spawn_routes"].shape[0] else -np.ones((1, 2), np.int32)
+            routes, route_ptr = group_routes(rows, t.n_lanes)
+            for mode in (0, 1):
+                oracle.set_numpy_mean(mode)
+                oracle.set_sqrtf_hook(torch_sqrt if mode else None)
+                o = oracle.net_hybrid(t, routes, route_ptr, g["action"], m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"],
+                                      1.0 / m["simulation_frequency"], m["speed_limit"], m["static_speed"], m["vehicle_length"])
+                assert o["rc"] == 0
+                res[(mode, name)] = rel_max(o["queue"].T, g["queue"])
+    finally:
+        oracle.set_numpy_mean(0)
+        oracle.set_sqrtf_hook(None)
+    print(res)
+    assert res[(1, "macro_small")] == 0.0 < res[(0, "macro_small")]
+    assert res[(1, "macro")] <= 3e-7 < res[(0, "macro")] and res[(1, "hybrid_short")] <= 3e-7 < res[(0, "hybrid_short")]
 
 
 def test_source_ghost_in_double(oracle, golden_dir):
