@@ -400,6 +400,23 @@ def test_glue_square_root_as_torch_computes_it(oracle, golden_dir):
     print(res)
     assert res[(1, "macro_small")] == 0.0 < res[(0, "macro_small")]
     assert res[(1, "macro")] <= 3e-7 < res[(0, "macro")] and res[(1, "hybrid_short")] <= 3e-7 < res[(0, "hybrid_short")]
+    # the straight lanes (no running mean there): with torch's square root the oracle's final state is the reference's BIT FOR BIT on
+    # every G4 rollout -- BASELINE config 1 (100 cells x 200 steps) and one lane of config 2 (512 cells x 1000 steps) among them
+    differing = {}
+    try:
+        for name in ("small", "sanity", "c1", "bench64", "long", "c2slice"):
+            g = load(golden_dir, "macro_rollout_%s.npz" % name)
+            m = meta_of(g)
+            for mode in (0, 1):
+                oracle.set_sqrtf_hook(torch_sqrt if mode else None)
+                f = oracle.macro_rollout_fwd(g["r0"], g["u0"], g["ghost_r"], g["ghost_u"], m["T"], m["dt"], m["dx"], m["u_max"])
+                assert f["rc"] == 0
+                differing[(mode, name)] = int((f["rT"][0] != g["rT"]).sum() + (f["yT"][0] != g["yT"]).sum() + (f["uT"][0] != g["uT"]).sum())
+    finally:
+        oracle.set_sqrtf_hook(None)
+    print(differing)
+    assert all(differing[(1, name)] == 0 for name in ("small", "sanity", "c1", "bench64", "long", "c2slice"))
+    assert differing[(0, "c2slice")] > 500 and differing[(0, "c1")] > 0
 
 
 def test_source_ghost_in_double(oracle, golden_dir):
