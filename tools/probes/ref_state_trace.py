@@ -1,9 +1,10 @@
 """Where the oracle and the REFERENCE first part ways inside an itscp hybrid episode (this container only: imports /root/reference like
 tools/gen_goldens.py).  Runs the reference's differentiable episode of a golden's configuration, records every macro cell's (r, y, u)
 and the loss constants' inputs after every step, and compares with the oracle's state history step by step.
-    python tools/probes/ref_state_trace.py hybrid_short [--source-ghost-f32]
+    python tools/probes/ref_state_trace.py hybrid_short [--source-ghost-f32] [--numpy-mean] [--torch-sqrt]
 (--source-ghost-f32: the oracle rounds a source lane's upstream ghost to float32 as it did until the end of round 5; the default feeds it
-to the solve in double, as the reference's Python floats do)"""
+to the solve in double, as the reference's Python floats do; --numpy-mean / --torch-sqrt: the oracle's running means as numpy's
+float32 summation computes them / its float32 glue square root through this torch build's kernel -- DESIGN section 8, "What is left")"""
 import json
 import os
 import sys
@@ -65,6 +66,16 @@ from dhts.network import group_routes      # noqa: E402
 from oracle import oracle as O      # noqa: E402
 O.build()
 O.set_source_ghost_f64("--source-ghost-f32" not in sys.argv)
+if "--numpy-mean" in sys.argv:              # the running means as numpy sums them (O(window) per sample)
+    O.set_numpy_mean(1)
+if "--torch-sqrt" in sys.argv:              # the glue's float32 square root as this torch build evaluates it
+    import torch as _th
+    _buf = _th.zeros((), dtype=_th.float32)
+
+    def _torch_sqrt(x):
+        _buf.fill_(x)
+        return _th.sqrt(_buf).item()
+    O.set_sqrtf_hook(_torch_sqrt)
 t, mm = itscp_hybrid_tables(g)
 routes, route_ptr = group_routes(g["spawn_routes"], t.n_lanes)
 o = O.net_hybrid(t, routes, route_ptr, g["action"], mm["num_intersection"] ** 2, mm["simulation_frequency"] * mm["signal_length"],
