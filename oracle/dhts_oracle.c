@@ -637,6 +637,41 @@ int oracle_micro_step_f32(int V, const float *p, const float *v, const double *p
     return rc;
 }
 
+/* The HEAD vehicle of a dMicroLane in a differentiable itscp hybrid episode: dMicroLane.detach_vehicle turns the vehicles' states into
+ * Python floats but leaves the lane's head gap alone, and that gap is a float32 TENSOR there (the signal blend of
+ * _simulator.py:260-263) -- so IDM.compute_acceleration (model/micro/_idm.py:6-50) and the Euler step (_micro_lane.py:182-183) run for
+ * this one vehicle in MIXED arithmetic: what combines two Python floats is double, what meets the tensor is float32 (the Python
+ * operand cast first), pow(tensor, 2.0) is x * x.  (v, p: the vehicle's float32 values as Python floats.)  The followers' steps stay
+ * double; so does the head's in an evaluation episode, where the gap is a Python float.  Jacobian blocks from the analytic formulas at
+ * the same operands.  Overwrites the head's entries of np_, nv_, dqs (V >= 1). */
+void oracle_micro_head_mixed(int V, const float *p, const float *v, const double *params, float head_dp, float head_dv, double dt,
+                             float *np_, float *nv_, float *dqs) {
+    const int i = V - 1;
+    const double *pr = params + (size_t)i * 6;
+    const double vd = (double)v[i];
+    float dp = head_dp, dv = head_dv;
+    const double dp_raw = dp, dv_raw = dv;
+    if (dp < 0) { dp = 0; dv = 0; }                               /* (collision: printed, deltas zeroed -- Python ints) */
+    const int eps_wins = (float)1e-5 > dp;                         /* max(position_delta, POSITION_DELTA_EPS) picks the Python float */
+    const float dpc = eps_wins ? (float)1e-5 : dp;                 /* (cast where it meets a tensor) */
+    const double A = pr[3] + vd * pr[4];                           /* min_space + v_curr * time_pref: Python floats */
+    const float den = (float)(2 * pow(pr[0] * pr[1], 0.5));
+    float s = (float)A + (((float)vd * dv) / den);
+    int fl[2];
+    fl[1] = (s < 0.0f);
+    if (s < 0.0f) s = 0.0f;
+    const double D = 1.0 - pow(vd / pr[2], IDM_DELTA);              /* Python floats */
+    const float t2 = s / dpc;
+    float acc = (float)pr[0] * ((float)D - (t2 * t2));
+    const double lim = -vd / dt;
+    fl[0] = (acc < (float)lim);
+    np_[i] = (float)((double)p[i] + dt * vd);                      /* position: Python floats all the way */
+    if ((float)lim > acc) nv_[i] = (float)(vd + dt * lim);         /* max() picked the Python float: the step is double */
+    else nv_[i] = (float)vd + ((float)dt * acc);
+    if (dqs)
+        oracle_idm_jac(pr[0], pr[1], vd, pr[2], dp_raw, dv_raw, pr[3], pr[4], (double)s, dt, fl, dqs + (size_t)i * 8, dqs + (size_t)i * 8 + 4);
+}
+
 /* road/lane/dmicro_lane.py:271-298 */
 void oracle_micro_step_bwd(int V, const float *dqs, const float *g_np, const float *g_nv, float *g_p, float *g_v) {
     for (int i = 0; i <= V; i++) g_p[i] = g_v[i] = 0.f;

@@ -191,5 +191,13 @@ void oracle_set_numpy_mean(int on);
 void oracle_set_source_ghost_f64(int on);
 /* the float32 square root of the glue (u_eq of a float32 tensor) as the caller's environment evaluates it; NULL = sqrtf (dhts_oracle.c) */
 void oracle_set_sqrtf_hook(float (*f)(float));
+/* debugging aid of tools/probes/ref_state_trace.py: oracle_net_hybrid writes (lane or -1, position, speed) of vehicle ids < n_vehicles after
+ * every step into buf [T][n_vehicles][3]; NULL = off */
+void oracle_set_vehicle_trace(float *buf, int n_vehicles);
+/* the head vehicle of an IDM lane of a differentiable itscp hybrid episode: mixed float32 / double arithmetic (dhts_oracle.c); the
+ * switch (default 1) is read by oracle_net_hybrid */
+void oracle_micro_head_mixed(int V, const float *p, const float *v, const double *params, float head_dp, float head_dv, double dt,
+                             float *np_, float *nv_, float *dqs);
+void oracle_set_head_mixed(int on);
 
 #endif
