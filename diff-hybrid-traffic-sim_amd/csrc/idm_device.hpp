@@ -125,6 +125,54 @@ __device__ __forceinline__ void idm_step_f32(float p, float v, float dp_raw, flo
     }
 }
 
+// The HEAD vehicle of a dMicroLane in a differentiable itscp hybrid episode: dMicroLane.detach_vehicle (dmicro_lane.py:228-250) turns
+// the vehicles' states into Python floats but leaves the lane's head gap alone, and there the gap is a float32 TENSOR (the signal
+// blend of example/control/itscp/_simulator.py:260-263) -- so for this one vehicle IDM.compute_acceleration and the Euler step run in
+// MIXED arithmetic: what combines two Python floats is double, what meets the tensor is float32 (the Python operand cast first),
+// pow(tensor, 2.0) is x * x.  p, v: the vehicle's float32 values (Python floats there); dp_raw, dv_raw: the tensor's values.
+// Jacobian blocks from the analytic formulas at the same operands.  (Followers, and every vehicle of an evaluation episode: idm_step_ieee.)
+__device__ __forceinline__ void idm_step_head_mixed(float p, float v, float dp_raw, float dv_raw, const IdmParams &m, double dt, IdmStep &o) {
+    float dp = dp_raw, dv = dv_raw;
+    o.collided = dp < 0.f;
+    if (o.collided) { dp = 0.f; dv = 0.f; }
+    const float dpc = ((float)1e-5 > dp) ? (float)1e-5 : dp;
+    const double vd = v;
+    const double two_sqrt_ab = 2 * sqrt(m.a_max * m.a_pref);
+    const double A = m.min_space + vd * m.time_pref;
+    float s = (float)A + ((v * dv) / (float)two_sqrt_ab);
+    const bool clipped_s = (s < 0.0f);
+    s = clipped_s ? 0.0f : s;
+    const double vr = vd / m.v_target, vr2 = vr * vr;
+    const double D = 1.0 - vr2 * vr2;
+    const float t2 = s / dpc;
+    const float acc = (float)m.a_max * ((float)D - (t2 * t2));
+    const double floor_acc = -vd / dt;
+    const bool clipped_a = (acc < (float)floor_acc);
+    o.np = (float)((double)p + dt * vd);
+    o.nv = ((float)floor_acc > acc) ? (float)(vd + dt * floor_acc) : v + ((float)dt * acc);
+    o.acc = acc; o.sstar = s; o.clipped_acc = clipped_a; o.clipped_spacing = clipped_s;
+    o.dE[0] = 1.f; o.dE[1] = (float)dt; o.dE[2] = 0.f; o.dE[3] = 0.f;
+    o.dLd[0] = o.dLd[1] = o.dLd[2] = o.dLd[3] = 0.f;
+    if (!clipped_a) {
+        const double sd = s, dpr = dp_raw, dvr = dv_raw;
+        const double dp2 = dpr * dpr;
+        const double dp3 = dp2 * dpr;
+        const double s2_dp3 = (sd * sd) / dp3;
+        const double vt2 = m.v_target * m.v_target;
+        const double free_term = -4.0 * ((vd * vd * vd) / (vt2 * vt2));
+        const double s_dp2 = sd / dp2;
+        o.dE[2] = (float)(dt * (-2 * m.a_max * s2_dp3));
+        o.dLd[2] = (float)(dt * (2 * m.a_max * s2_dp3));
+        if (clipped_s) {
+            o.dE[3] = (float)(1 + dt * m.a_max * free_term);
+            o.dLd[3] = (float)(dt * m.a_max * (-2 * s_dp2));
+        } else {
+            o.dE[3] = (float)(1 + dt * m.a_max * (free_term - 2 * s_dp2 * (m.time_pref + ((vd + dvr) / two_sqrt_ab))));
+            o.dLd[3] = (float)(dt * m.a_max * (-2 * s_dp2 * (-vd / two_sqrt_ab)));
+        }
+    }
+}
+
 // ---- production version -------------------------------------------------------------------------------------
 // Per-vehicle constants evaluated once per rollout (IEEE operations), so that the time loop has no division by a
 // constant and no square root: 1 / (2 sqrt(a_max a_pref)), 1 / v_target, 1 / v_target^4, and the products of the
