@@ -15,8 +15,7 @@
  * by importing the reference in the build container (tests/test_oracle_golden.py): known answers bit for bit, rollouts and
  * networks within 1e-5 / 1e-4 at the defaults (measured <= 2.9e-6), and -- with the two library behaviours under the reference
  * switched in (oracle_set_sqrtf_hook: that torch build's float32 sqrt; oracle_set_numpy_mean: numpy's float32 summation tree) --
- * the straight-lane states of every rollout fixture and every queue term of the macro and `micro`-mode network fixtures BIT FOR BIT
- * (hybrid networks: within 6e-7).
+ * the straight-lane states of every rollout fixture and every queue term of the macro, `micro`-mode and hybrid network fixtures BIT FOR BIT.
  */
 #ifndef DHTS_ORACLE_H
 #define DHTS_ORACLE_H
