@@ -125,49 +125,67 @@ __device__ __forceinline__ void idm_step_f32(float p, float v, float dp_raw, flo
     }
 }
 
-// The HEAD vehicle of a dMicroLane in a differentiable itscp hybrid episode: dMicroLane.detach_vehicle (dmicro_lane.py:228-250) turns
-// the vehicles' states into Python floats but leaves the lane's head gap alone, and there the gap is a float32 TENSOR (the signal
-// blend of example/control/itscp/_simulator.py:260-263) -- so for this one vehicle IDM.compute_acceleration and the Euler step run in
-// MIXED arithmetic: what combines two Python floats is double, what meets the tensor is float32 (the Python operand cast first),
-// pow(tensor, 2.0) is x * x.  p, v: the vehicle's float32 values (Python floats there); dp_raw, dv_raw: the tensor's values.
-// Jacobian blocks from the analytic formulas at the same operands.  (Followers, and every vehicle of an evaluation episode: idm_step_ieee.)
-__device__ __forceinline__ void idm_step_head_mixed(float p, float v, float dp_raw, float dv_raw, const IdmParams &m, double dt, IdmStep &o) {
-    float dp = dp_raw, dv = dv_raw;
-    o.collided = dp < 0.f;
-    if (o.collided) { dp = 0.f; dv = 0.f; }
-    const float dpc = ((float)1e-5 > dp) ? (float)1e-5 : dp;
+// A lane of a hybrid network: followers and head vehicle behind ONE instruction stream (they share wavefronts: as two functions every
+// such wavefront ran both bodies).
+// mixed = false: idm_step_ieee's arithmetic, bit for bit (followers; every vehicle of an evaluation episode).
+// mixed = true: the HEAD vehicle of a dMicroLane in a differentiable itscp hybrid episode.  dMicroLane.detach_vehicle (dmicro_lane.py:228-250)
+// turns the vehicles' states into Python floats but leaves the lane's head gap alone, and there the gap is a float32 TENSOR (the signal
+// blend of example/control/itscp/_simulator.py:260-263) -- so for this one vehicle IDM.compute_acceleration and the Euler step run in MIXED
+// arithmetic: what combines two Python floats is double, what meets the tensor is float32 (the Python operand cast first),
+// pow(tensor, 2.0) is x * x; the position update stays double.  p, v: the vehicle's float32 values (Python floats there); dp_raw, dv_raw:
+// the gap and speed difference (the tensor's float32 values, widened).
+// The square root, the free-road term and the Jacobian blocks (analytic, at the same operands) are common; the acceleration and the new
+// speed are evaluated both ways -- the float32 side is a dozen cheap instructions -- and `mixed` selects.
+__device__ __forceinline__ void idm_step_lane(float p, float v, double dp_raw, double dv_raw, bool mixed, const IdmParams &m, double dt, IdmStep &o) {
+    double dp = dp_raw, dv = dv_raw;
+    o.collided = dp < 0;
+    if (o.collided) { dp = 0; dv = 0; }
+    const double dpc = (1e-5 > dp) ? 1e-5 : dp;
     const double vd = v;
     const double two_sqrt_ab = 2 * sqrt(m.a_max * m.a_pref);
-    const double A = m.min_space + vd * m.time_pref;
-    float s = (float)A + ((v * dv) / (float)two_sqrt_ab);
-    const bool clipped_s = (s < 0.0f);
-    s = clipped_s ? 0.0f : s;
     const double vr = vd / m.v_target, vr2 = vr * vr;
-    const double D = 1.0 - vr2 * vr2;
-    const float t2 = s / dpc;
-    const float acc = (float)m.a_max * ((float)D - (t2 * t2));
     const double floor_acc = -vd / dt;
-    const bool clipped_a = (acc < (float)floor_acc);
+    // double (followers; every vehicle of an evaluation episode)
+    double s_d = (m.min_space + vd * m.time_pref + ((vd * dv) / two_sqrt_ab));
+    const bool clipped_s_d = (s_d < 0.0);
+    s_d = (0. > s_d) ? 0. : s_d;
+    const double sr = s_d / dpc;
+    double acc_d = m.a_max * (1.0 - vr2 * vr2 - sr * sr);
+    const bool clipped_a_d = (acc_d < floor_acc);
+    acc_d = (floor_acc > acc_d) ? floor_acc : acc_d;
+    const float nv_d = (float)(vd + dt * acc_d);
+    // mixed (the head vehicle under a float32 tensor gap)
+    const float dpf = (float)dp, dvf = (float)dv;
+    const float dpcf = ((float)1e-5 > dpf) ? (float)1e-5 : dpf;
+    float s_f = (float)(m.min_space + vd * m.time_pref) + ((v * dvf) / (float)two_sqrt_ab);
+    const bool clipped_s_f = (s_f < 0.0f);
+    s_f = clipped_s_f ? 0.0f : s_f;
+    const float t2 = s_f / dpcf;
+    const float acc_f = (float)m.a_max * ((float)(1.0 - vr2 * vr2) - (t2 * t2));
+    const bool clipped_a_f = (acc_f < (float)floor_acc);
+    const float nv_f = ((float)floor_acc > acc_f) ? (float)(vd + dt * floor_acc) : v + ((float)dt * acc_f);
+
+    const double s = mixed ? (double)s_f : s_d;
+    const bool clipped_s = mixed ? clipped_s_f : clipped_s_d, clipped_a = mixed ? clipped_a_f : clipped_a_d;
     o.np = (float)((double)p + dt * vd);
-    o.nv = ((float)floor_acc > acc) ? (float)(vd + dt * floor_acc) : v + ((float)dt * acc);
-    o.acc = acc; o.sstar = s; o.clipped_acc = clipped_a; o.clipped_spacing = clipped_s;
+    o.nv = mixed ? nv_f : nv_d;
+    o.acc = mixed ? (double)acc_f : acc_d; o.sstar = s; o.clipped_acc = clipped_a; o.clipped_spacing = clipped_s;
     o.dE[0] = 1.f; o.dE[1] = (float)dt; o.dE[2] = 0.f; o.dE[3] = 0.f;
     o.dLd[0] = o.dLd[1] = o.dLd[2] = o.dLd[3] = 0.f;
     if (!clipped_a) {
-        const double sd = s, dpr = dp_raw, dvr = dv_raw;
-        const double dp2 = dpr * dpr;
-        const double dp3 = dp2 * dpr;
-        const double s2_dp3 = (sd * sd) / dp3;
+        const double dp2 = dp_raw * dp_raw;
+        const double dp3 = dp2 * dp_raw;
+        const double s2_dp3 = (s * s) / dp3;
         const double vt2 = m.v_target * m.v_target;
         const double free_term = -4.0 * ((vd * vd * vd) / (vt2 * vt2));
-        const double s_dp2 = sd / dp2;
+        const double s_dp2 = s / dp2;
         o.dE[2] = (float)(dt * (-2 * m.a_max * s2_dp3));
         o.dLd[2] = (float)(dt * (2 * m.a_max * s2_dp3));
         if (clipped_s) {
             o.dE[3] = (float)(1 + dt * m.a_max * free_term);
             o.dLd[3] = (float)(dt * m.a_max * (-2 * s_dp2));
         } else {
-            o.dE[3] = (float)(1 + dt * m.a_max * (free_term - 2 * s_dp2 * (m.time_pref + ((vd + dvr) / two_sqrt_ab))));
+            o.dE[3] = (float)(1 + dt * m.a_max * (free_term - 2 * s_dp2 * (m.time_pref + ((vd + dv_raw) / two_sqrt_ab))));
             o.dLd[3] = (float)(dt * m.a_max * (-2 * s_dp2 * (-vd / two_sqrt_ab)));
         }
     }

@@ -605,8 +605,7 @@ template <class A> __device__ __forceinline__ void ns_micro_fwd(const A &a, int 
             if (i == n - 1) { dp = (double)hd_s[2 * m]; dv = (double)hd_s[2 * m + 1]; }
             else { dp = fabs((double)P0[idx + 1] - p) - ((prm.length + prm.length) * 0.5); dv = v - (double)V0[idx + 1]; }
             // (differentiable episode: the head gap is a float32 tensor in the reference, its vehicle's step mixed arithmetic -- idm_device.hpp)
-            if (i == n - 1 && !hard) idm_step_head_mixed(P0[idx], V0[idx], hd_s[2 * m], hd_s[2 * m + 1], prm, a.dt_d, o);
-            else idm_step_ieee(p, v, dp, dv, prm, a.dt_d, o);
+            idm_step_lane(P0[idx], V0[idx], dp, dv, i == n - 1 && !hard, prm, a.dt_d, o);
         }
         if (o.collided) net_fault(a.err, DHTS_FAULT_COLLISION, t, a.micro_lanes[m], i);
         P1[idx] = o.np; V1[idx] = o.nv;
