@@ -328,6 +328,8 @@ __global__ void micro_rollout_bwd_kernel(
 // The single-step operator in the float32 TENSOR ladder (idm_step_f32): what the reference's plain MicroLane computes when its vehicle
 // states are torch tensors -- itscp `micro` mode, differentiable episodes (example/control/itscp/_env.py:484-498; _micro_lane.py:131-214
 // evaluated by torch).  One thread per vehicle slot; same tape as dhts_micro_step_fwd ([lane][2][Vp][4]), same reverse operator.
+// kHeadOnly: the head vehicle alone meets a float32 tensor (its gap) -- mixed arithmetic for it, double for the followers (idm_step_lane)
+template <bool kHeadOnly>
 __global__ void micro_step_tensor_fwd_kernel(int L, int V, double dt, const float *__restrict__ p_in, const float *__restrict__ v_in,
                                              const int32_t *__restrict__ count, const double *__restrict__ params,
                                              const double *__restrict__ head, float *__restrict__ p_out, float *__restrict__ v_out,
@@ -352,7 +354,18 @@ __global__ void micro_step_tensor_fwd_kernel(int L, int V, double dt, const floa
             dv = vi - v_in[base + i + 1];
         }
         IdmStep o;
-        idm_step_f32(pi, vi, dp, dv, m, dt, o);
+        if constexpr (kHeadOnly) {
+            double dpd, dvd;
+            if (i == n - 1) { dpd = (double)(float)head[(size_t)lane * 2]; dvd = (double)(float)head[(size_t)lane * 2 + 1]; }
+            else {
+                const double len_l = params[5 * plane + base + i + 1];
+                dpd = fabs((double)p_in[base + i + 1] - (double)pi) - ((len_l + m.length) * 0.5);
+                dvd = (double)vi - (double)v_in[base + i + 1];
+            }
+            idm_step_lane(pi, vi, dpd, dvd, i == n - 1, m, dt, o);
+        } else {
+            idm_step_f32(pi, vi, dp, dv, m, dt, o);
+        }
         if (o.collided && fault_index < 0) fault_index = i;
         p_out[base + i] = o.np; v_out[base + i] = o.nv;
         if (tp) {
@@ -504,8 +517,17 @@ int dhts_micro_step_fwd_tensor(const dhts_micro_desc *d,
                                float *p_out, float *v_out, float *tape, dhts_error *err, void *stream) {
     if (!micro_desc_ok(d) || !p || !v || !params || !head || !p_out || !v_out) return DHTS_E_INVALID;
     const int B = d->capacity <= 64 ? 64 : (d->capacity <= 128 ? 128 : 256);
-    micro_step_tensor_fwd_kernel<<<d->n_lanes, B, 0, (hipStream_t)stream>>>(d->n_lanes, d->capacity, d->dt, p, v, count, params, head, p_out,
-                                                                          v_out, tape, err);
+    micro_step_tensor_fwd_kernel<false><<<d->n_lanes, B, 0, (hipStream_t)stream>>>(d->n_lanes, d->capacity, d->dt, p, v, count, params, head,
+                                                                                 p_out, v_out, tape, err);
+    return launch_status_m();
+}
+int dhts_micro_step_fwd_tensor_head(const dhts_micro_desc *d,
+                                    const float *p, const float *v, const int32_t *count, const double *params, const double *head,
+                                    float *p_out, float *v_out, float *tape, dhts_error *err, void *stream) {
+    if (!micro_desc_ok(d) || !p || !v || !params || !head || !p_out || !v_out) return DHTS_E_INVALID;
+    const int B = d->capacity <= 64 ? 64 : (d->capacity <= 128 ? 128 : 256);
+    micro_step_tensor_fwd_kernel<true><<<d->n_lanes, B, 0, (hipStream_t)stream>>>(d->n_lanes, d->capacity, d->dt, p, v, count, params, head,
+                                                                                p_out, v_out, tape, err);
     return launch_status_m();
 }
 int dhts_micro_step_bwd(const dhts_micro_desc *d, const float *tape, const int32_t *count,

@@ -115,6 +115,7 @@ SIGNATURES = {
     "dhts_micro_rollout_plan": (C.c_int, [C.POINTER(MicroDesc), C.c_int, C.c_int, C.POINTER(C.c_int32 * 8)]),
     "dhts_micro_step_fwd": (C.c_int, [C.POINTER(MicroDesc)] + [_P] * 10),
     "dhts_micro_step_fwd_tensor": (C.c_int, [C.POINTER(MicroDesc)] + [_P] * 10),
+    "dhts_micro_step_fwd_tensor_head": (C.c_int, [C.POINTER(MicroDesc)] + [_P] * 10),
     "dhts_micro_step_bwd": (C.c_int, [C.POINTER(MicroDesc)] + [_P] * 9),
 }
 

@@ -255,12 +255,14 @@ def micro_step_tape_numel(desc):
     return _lib.lib().dhts_micro_step_tape_bytes(C.byref(desc)) // 4
 
 
-def micro_step_fwd(desc, p, v, params, head, count=None, tape=None, err=None, tensor_ladder=False):
+def micro_step_fwd(desc, p, v, params, head, count=None, tape=None, err=None, tensor_ladder=False, head_tensor=False):
     """One step of L lanes through the operator entry point (dqs-layout tape).  tensor_ladder: the float32 tensor arithmetic of the
-    reference's plain MicroLane (dhts_micro_step_fwd_tensor) instead of the analytic operator's float64 ladder."""
+    reference's plain MicroLane (dhts_micro_step_fwd_tensor) instead of the analytic operator's float64 ladder; head_tensor: only the
+    lanes' head gaps are float32 tensors there (dMicroLane under a tensor gap: dhts_micro_step_fwd_tensor_head)."""
     p, v = _f32c(p, "p"), _f32c(v, "v")
     out = (torch.empty_like(p), torch.empty_like(v))
-    fn = _lib.lib().dhts_micro_step_fwd_tensor if tensor_ladder else _lib.lib().dhts_micro_step_fwd
+    lib = _lib.lib()
+    fn = lib.dhts_micro_step_fwd_tensor if tensor_ladder else (lib.dhts_micro_step_fwd_tensor_head if head_tensor else lib.dhts_micro_step_fwd)
     check(fn(C.byref(desc), _ptr(p), _ptr(v), _ptr(count), _ptr(params), _ptr(head),
              _ptr(out[0]), _ptr(out[1]), _ptr(tape), _ptr(err), _stream()), "dhts_micro_step_fwd")
     return out

@@ -53,8 +53,11 @@ class dMicroForwardLayer(th.autograd.Function):
         err = ops.new_error_record(dev)
         # (a plain MicroLane in a differentiable episode: the reference steps it in float32 tensor arithmetic, _env.py:484-498)
         tensor_ladder = type(lane).__name__ == "MicroLane" and bool(getattr(lane, "_tensor_ladder", False))
+        # (a dMicroLane whose head gap is a tensor: detach_vehicle leaves the gap alone, the reference's head vehicle steps in mixed
+        #  float32 / double arithmetic, reference dmicro_lane.py:228-250 with _idm.py:6-50)
+        head_tensor = not tensor_ladder and isinstance(lane.head_position_delta, th.Tensor)
         np_, nv_ = ops.micro_step_fwd(desc, pd[:-1].reshape(1, v), sd[:-1].reshape(1, v), params, head, tape=tape, err=err,
-                                      tensor_ladder=tensor_ladder)
+                                      tensor_ladder=tensor_ladder, head_tensor=head_tensor)
         code = err.tolist()
         if code[0] == 2:
             print("Collision detected at vehicle %d" % code[3])

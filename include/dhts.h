@@ -290,6 +290,15 @@ int dhts_micro_step_fwd(const dhts_micro_desc *d,
 int dhts_micro_step_fwd_tensor(const dhts_micro_desc *d,
                                const float *p, const float *v, const int32_t *count, const double *params, const double *head,
                                float *p_out, float *v_out, float *tape, dhts_error *err, void *stream);
+/* The same step when only the lane's HEAD GAP is a float32 tensor: dMicroLane.detach_vehicle (road/lane/dmicro_lane.py:228-250) turns the
+ * vehicles' states into Python floats but leaves head_position_delta / head_speed_delta alone, so with a tensor gap (a differentiable
+ * itscp hybrid episode: the signal blend of example/control/itscp/_simulator.py:260-263; a plain network: a leader in sight) the head
+ * vehicle's IDM.compute_acceleration and Euler step run in mixed arithmetic -- double where two Python floats meet, float32 where the
+ * tensor is involved -- and the followers' in double as in dhts_micro_step_fwd.  head [L][2] double holds the tensor's float32 values.
+ * Same arguments, same tape, same reverse operator. */
+int dhts_micro_step_fwd_tensor_head(const dhts_micro_desc *d,
+                                    const float *p, const float *v, const int32_t *count, const double *params, const double *head,
+                                    float *p_out, float *v_out, float *tape, dhts_error *err, void *stream);
 /* The single-step reverse keeps the operator form of dMicroForwardLayer.backward: the cotangent of the virtual
  * leader slot is NOT folded back into the head vehicle; g_head [L][2] DOUBLE returns it raw as (g_p[V], g_s[V]). */
 int dhts_micro_step_bwd(const dhts_micro_desc *d, const float *tape, const int32_t *count,

@@ -44,6 +44,8 @@ def lib():
         _lib.oracle_macro_rollout_bwd.argtypes = [C.c_int] * 3 + [C.c_double] + [C.c_void_p] * 19
         _lib.oracle_micro_step.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_double] * 3 + [C.c_void_p] * 4
         _lib.oracle_micro_step_f32.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_double] * 3 + [C.c_void_p] * 4
+        _lib.oracle_micro_head_mixed.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_double] + [C.c_void_p] * 3
+        _lib.oracle_micro_head_mixed.restype = None
         _lib.oracle_micro_step_bwd.argtypes = [C.c_int] + [C.c_void_p] * 5
         _lib.oracle_micro_rollout_fwd.argtypes = [C.c_int] * 3 + [C.c_double] + [C.c_void_p] * 3 + [C.c_double] * 2 + [C.c_void_p] * 5
         _lib.oracle_micro_rollout_bwd.argtypes = [C.c_int] * 3 + [C.c_void_p] * 8
@@ -201,6 +203,16 @@ def micro_step_f32(p, v, params, head_dp, head_dv, dt, want_tape=True):
     rc = lib().oracle_micro_step_f32(V, _p(p), _p(v), _p(params), float(head_dp), float(head_dv), float(dt),
                                      _p(np_), _p(nv_), _p(dqs), C.addressof(ei))
     return dict(rc=rc, np=np_, nv=nv_, dqs=dqs, err_index=ei.value)
+
+
+def micro_step_head_tensor(p, v, params, head_dp, head_dv, dt):
+    """A dMicroLane's step under a float32 TENSOR head gap (a differentiable itscp hybrid episode): followers in double (micro_step), the
+    head vehicle in the mixed float32 / double arithmetic of the reference (oracle_micro_head_mixed)."""
+    p, v, params = _f32(p), _f32(v), _f64(params)
+    o = micro_step(p, v, params, float(np.float32(head_dp)), float(np.float32(head_dv)), dt)
+    lib().oracle_micro_head_mixed(p.shape[0], _p(p), _p(v), _p(params), float(np.float32(head_dp)), float(np.float32(head_dv)), float(dt),
+                                  _p(o["np"]), _p(o["nv"]), _p(o["dqs"]))
+    return o
 
 
 def micro_step_bwd(dqs, g_np, g_nv):

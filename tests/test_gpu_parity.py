@@ -1093,3 +1093,42 @@ def test_macro_step_reads_a_source_ghost_in_double(cuda):
     differs = ((out_e[0][:, 0] != out_r[0][:, 0]) | (out_e[1][:, 0] != out_r[1][:, 0])).float().mean().item()
     print("first cells that differ from the float32-rounded ghost's: %.1f %%" % (100 * differs))        # (a 1-ulp input: it survives the
     assert 0.01 <= differs                                                                               #  float32 store now and then)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V", [1, 5, 64])
+def test_micro_step_under_a_tensor_head_gap_vs_oracle(cuda, oracle, V):
+    """dhts_micro_step_fwd_tensor_head: a dMicroLane whose head gap is a float32 tensor (differentiable itscp hybrid episodes) -- the
+    reference's detach_vehicle leaves the gap alone, so the HEAD vehicle's IDM and Euler step run in mixed float32 / double arithmetic and
+    the followers' in double.  Against the oracle's restatement (pinned bit for bit by the hybrid fixtures with the library switches in):
+    next state bit for bit, Jacobian blocks to float32 rounding; the followers equal the analytic operator's, the head does not always."""
+    import torch
+    from dhts import ops
+    rng = np.random.default_rng(300 + V)
+    L = 64
+    p = np.sort(rng.uniform(0.0, 12.0 * V, (L, V)).astype(np.float32), axis=1)
+    p += np.arange(V, dtype=np.float32)[None, :] * 6.0
+    v = rng.uniform(0.0, 25.0, (L, V)).astype(np.float32)
+    v[::7, -1] = 0.0                                                          # heads at rest at a red light
+    prm = np.empty((L, V, 6)); prm[:] = [60.0, 48.0, 54.0, 0.5, 0.1, 5.0]
+    head = np.stack([rng.uniform(0.5, 1000.0, L), rng.uniform(-3.0, 3.0, L)], axis=1).astype(np.float32).astype(np.float64)
+    head[::5, 0] = np.float32(999.9999)
+    dt = 1.0 / 30.0
+    desc = ops.micro_desc(L, V, dt)
+    tape = torch.empty(ops.micro_step_tape_numel(desc), dtype=torch.float32, device=cuda)
+    params_d = torch.tensor(np.ascontiguousarray(prm.transpose(2, 0, 1)), dtype=torch.float64, device=cuda)
+    args = (desc, torch.tensor(p, device=cuda), torch.tensor(v, device=cuda), params_d, torch.tensor(head, device=cuda))
+    np_h, nv_h = ops.micro_step_fwd(*args, tape=tape, head_tensor=True)
+    np_a, nv_a = ops.micro_step_fwd(*args)
+    Vp = (V + 63) // 64 * 64
+    tp = tape.view(L, 2, Vp, 4).cpu().numpy()
+    head_differs = 0
+    for l in range(L):
+        o = oracle.micro_step_head_tensor(p[l], v[l], prm[l], head[l, 0], head[l, 1], dt)
+        assert np.array_equal(np_h[l].cpu().numpy(), o["np"]) and np.array_equal(nv_h[l].cpu().numpy(), o["nv"]), l
+        dq = o["dqs"].reshape(V, 2, 4)
+        assert rel_max(tp[l, 0, :V], dq[:, 0]) <= 1e-6 and rel_max(tp[l, 1, :V], dq[:, 1]) <= 1e-6
+        assert np.array_equal(nv_h[l, :-1].cpu().numpy(), nv_a[l, :-1].cpu().numpy())          # followers: the analytic operator's step
+        head_differs += int(nv_h[l, -1].item() != nv_a[l, -1].item())
+    print("heads whose new speed differs from the double step's: %d of %d" % (head_differs, L))
+    assert head_differs > 0
