@@ -807,7 +807,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                 if (kHard) {
                     float q = 0.f;
                     for (int i = 0; i < nv; ++i) q = q + vx[lv[i]];
-                    qm[k] = (q * q) * dtf;
+                    qm[k] = (float)(((double)q * (double)q) * dt);       // (Python floats there: (n ** 2.0) * dt in double, _env.py:709-738)
                 } else if (nv > 0) {
                     const int cb = cbefore[k];
                     double pa = run_in + vsp[k], pb = run_out + vep[k];

@@ -827,7 +827,8 @@ template <class A> __device__ __forceinline__ void ns_convert(const A &a, int t,
     if (hard) {
         for (int l = tid; l < L; l += B) {
             float qlen = 0.f;
-            if (a.lane_macro[l]) {
+            const bool mac = a.lane_macro[l] != 0;
+            if (mac) {
                 const int cntl = a.lane_ncell[l], off = a.lane_off[l];
                 const float w = (float)a.lane_dx[l];
                 for (int i = 0; i < cntl; i++) qlen = qlen + (Un[off + i] < s0f ? 1.f : 0.f) * (Rn[off + i] * w / vlen);
@@ -835,7 +836,8 @@ template <class A> __device__ __forceinline__ void ns_convert(const A &a, int t,
                 const int ms = a.lane_mslot[l], cntl = lane_n[ms];
                 for (int i = 0; i < cntl; i++) qlen = qlen + (V1[(size_t)ms * cap + i] < s0f ? 1.f : 0.f);
             }
-            ns_glob(a.queue)[row + l] = (qlen * qlen) * dtf;
+            // (an IDM lane counts Python floats there: (n ** 2.0) * dt in double, _env.py:709-738; a cell lane's terms are float32 tensors)
+            ns_glob(a.queue)[row + l] = mac ? (qlen * qlen) * dtf : (float)(((double)qlen * (double)qlen) * a.dt_d);
         }
         NS_SUB(5)
         return;
