@@ -1,7 +1,7 @@
 """The oracle against the reference fixtures at its defaults and with the two LIBRARY behaviours under the reference switched in:
 numpy's float32 summation tree for the running means (oracle.set_numpy_mean) and this torch build's float32 square root for the glue
 (oracle.set_sqrtf_hook(torch.sqrt ...)) -- DESIGN section 8, "What is left between the oracle and the reference".  CPU only.
-    python tools/probes/oracle_environment.py [fixture names ...]          (default: every itscp training fixture)
+    python tools/probes/oracle_environment.py [fixture names ...]          (default: every itscp fixture, training and evaluation episodes)
 Prints, per fixture, the queue terms that differ from the reference's / all and the largest difference relative to the largest term."""
 import glob
 import os
@@ -29,11 +29,11 @@ def torch_sqrt(x):
 
 probe = torch.full((), 0.16979104280471802, dtype=torch.float32)
 print("torch %s: sqrt(0.16979104f) = %.9g (IEEE: 0.412057102)" % (torch.__version__, float(torch.sqrt(probe))))
-names = sys.argv[1:] or sorted(os.path.basename(p)[6:-4] for p in glob.glob(os.path.join(ROOT, "tests", "golden", "itscp_*.npz"))
-                               if "eval" not in os.path.basename(p))
+names = sys.argv[1:] or sorted(os.path.basename(p)[6:-4] for p in glob.glob(os.path.join(ROOT, "tests", "golden", "itscp_*.npz")))
 for name in names:
     g = np.load(os.path.join(ROOT, "tests", "golden", "itscp_%s.npz" % name))
-    if name.startswith("micro"):
+    hard = name.startswith("eval_")              # an evaluation episode (Trainer.evaluate): hard thresholds, no running mean, no gradient
+    if "micro" in name:
         t, m, rows = itscp_micro_tables(g)
     else:
         t, m = itscp_hybrid_tables(g)
@@ -47,10 +47,11 @@ for name in names:
             O.set_sqrtf_hook(torch_sqrt if env else None)
             O.set_numpy_mean(env)
             t0 = time.time()
-            o = O.net_hybrid(*args)
+            o = O.net_hybrid(*args, hard=hard)
             q, gq = o["queue"].T.astype(np.float32), g["queue"].astype(np.float32)
-            out.append("%6d of %6d terms differ, %.1e, gradient %.1e, reward %s (%3.0f s)"
-                       % (int((q != gq).sum()), q.size, rel_max(q, gq), np.abs(o["g_action"] - g["g_action"]).max() / np.abs(g["g_action"]).max(),
+            grad = "gradient %.1e, " % (np.abs(o["g_action"] - g["g_action"]).max() / np.abs(g["g_action"]).max()) if not hard else ""
+            out.append("%6d of %6d terms differ, %.1e, %sreward %s (%3.0f s)"
+                       % (int((q != gq).sum()), q.size, rel_max(q, gq), grad,
                           "equal" if np.float32(o["reward"]) == np.float32(float(g["reward"])) else "differs", time.time() - t0))
     finally:
         O.set_sqrtf_hook(None)
