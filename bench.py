@@ -51,7 +51,10 @@ def parse():
     ap.add_argument("--cells", type=int, default=0, help="override cells / vehicles per lane")
     ap.add_argument("--time-steps", type=int, default=0, help="override simulated time steps per rollout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the short config 3 / config 4 sub-records of the default run")
+    ap.add_argument("--no-also", action="store_true", help="skip the sub-records of the default run (N = 1: configs 3 and 4, the stepwise "
+                    "network, the replica sweep, config 2 x 8 lanes; N > 1: config 5)")
+    ap.add_argument("--also-replicas", type=int, default=0, help="N > 1: replicas per rank of the config 5 sub-record (default 256); "
+                    "giving it forces the sub-record even when the headline's shape is overridden (tests)")
     return ap.parse_args()
 
 
@@ -353,6 +356,18 @@ class MicroWorkload:
                 "one_core_value": one_rate, "parallel_efficiency": done / el / (cores * one_rate)}
 
 
+def problem_1_array(keys, T):
+    """problem_1's inflow schedule (example/control/itscp/problem.py:5-70 with one session: one direction draws 0.9 + 0.1 U per
+    lane, the other 0.01 U, constant over the episode) as a [T][lanes] array in one numpy call per replica -- the same
+    distribution, without 86 400 list appends (replicas beyond the 256th of a batch: the 2 048-replica sweep)."""
+    import numpy as np
+    ns = np.random.random() > 0.5
+    hot = np.array([(k.loc in ("north", "south")) if ns else (k.loc in ("west", "east")) for k in keys])
+    r = np.random.random(len(keys))
+    row = np.where(hot, 0.9 + 0.1 * r, 0.01 * r)
+    return np.ascontiguousarray(np.broadcast_to(row[None, :], (T, len(keys))), dtype=np.float64)
+
+
 class ItscpMacroWorkload:
     """run_itscp_macro.sh's network (1 intersection, 3 lanes, 30 m, 10 s, signal 2 s: 40 lanes, 236 cells, 300 steps, 5
     actions) x 256 replicas with per-replica problem_1 schedules and actions U[0.1, 0.9]: reward and d reward / d action
@@ -486,10 +501,13 @@ class ItscpHybridWorkload:
         tabs = [tab]
         keys = list(env.lane.keys())
         for r in range(1, R):       # same topology and per-step routes, a fresh problem_1 inflow schedule per replica
-            sched = env.schedule_callback(keys, env.num_timestep)
             t = HybridNetworkTables.__new__(HybridNetworkTables)
             t.__dict__.update(tab.__dict__)
-            t.schedule = np.ascontiguousarray(np.array([sched[k] for k in keys], dtype=np.float64).T)
+            if r < 256:
+                sched = env.schedule_callback(keys, env.num_timestep)
+                t.schedule = np.ascontiguousarray(np.array([sched[k] for k in keys], dtype=np.float64).T)
+            else:
+                t.schedule = problem_1_array(keys, env.num_timestep)
             tabs.append(t)
         self.tab = ops.DeviceHybridTables(tabs, np.array(routes, dtype=np.int32), dev)
         self.host_tab, self.host_routes = tab, np.array(routes, dtype=np.int32)
@@ -503,6 +521,20 @@ class ItscpHybridWorkload:
         self.err = ops.new_error_record(dev)
         self.ev = []
         self.counts = None
+
+    def restrict(self, R):
+        """The first R replicas of this batch as the batch (same uploaded tables, a prefix of the actions): the replica sweep
+        times several batch sizes of ONE instance."""
+        if getattr(self, "_full", None) is None:
+            self._full = (self.tab, self.action.detach(), self.n_lanes)
+        tab, action, _ = self._full
+        assert R <= action.shape[0]
+        self.tab, self.action = tab.first(R), action[:R].clone().requires_grad_(True)
+        self.R = self.L = R
+        self.units = R * self.N * self.T
+        self.name = self.name.replace(self.name.split("x(")[0], "itscp_hybrid_%d" % R, 1)
+        self.ev, self.counts = [], None
+        return self
 
     def one_pass(self, record=False):
         self.action.grad = None
@@ -690,7 +722,7 @@ def make_workload(name, dev, rank, lanes=0, cells=0, time_steps=0):
     return ItscpMacroWorkload(dev, rank, lanes or 256, 0, 0)
 
 
-def pmc_traffic(w, kernel):
+def pmc_traffic(w, kernel, moved=None):
     """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE, gfx950 FETCH correction applied).  Quoted only for the configuration the passes were taken on and only
     while the tape the library allocates still has the size the passes saw (a changed layout needs fresh passes)."""
@@ -699,7 +731,8 @@ def pmc_traffic(w, kernel):
         hbm = pmc[w.name][kernel]["hbm_bytes"]
     except (OSError, ValueError, KeyError):
         return None
-    moved = w.moved_bytes_per_launch()
+    if moved is None:
+        moved = w.moved_bytes_per_launch()
     if abs(hbm - moved) > 0.02 * moved:
         print("bench.py: profiles/pmc_traffic.json (%d B) disagrees with the library's tape size (%d B) by more than 2 %%: "
               "traffic not quoted; re-take the PMC passes" % (hbm, moved), file=sys.stderr)
@@ -800,9 +833,9 @@ def check_parity(rec, name):
     return bad
 
 
-def also_record(name, dev, passes=5):
+def also_record(name, dev, passes=5, lanes=0):
     """A short run of another BASELINE configuration in the same process (not the headline; no collective)."""
-    w = make_workload(name, dev, 0)
+    w = make_workload(name, dev, 0, lanes=lanes)
     for _ in range(2):
         w.one_pass()
     torch.cuda.synchronize()
@@ -821,6 +854,81 @@ def also_record(name, dev, passes=5):
     return out, w, (g_a, g_b)
 
 
+def allreduce_check(flat, parts, shared_grad):
+    """rank 0's proof that the per-pass collective summed every rank's own [gradient || loss] of the last pass"""
+    if parts is None:
+        return None
+    return {"reduced": flat.tolist()[-1], "sum_of_rank_parts": float(parts[:, -1].double().sum()), "rank_parts": parts[:, -1].tolist(),
+            "buffer_floats": int(flat.numel()),
+            "grad_max_abs_diff": float((parts[:, :-1].double().sum(dim=0) - flat[:-1].double().cpu()).abs().max()) if shared_grad else 0.0}
+
+
+def collective_run(w, steps, warmup, shared_grad, dev, record):
+    """W untimed passes, then exactly `steps` passes bracketed by barrier + synchronize on both sides, each followed by the ONE
+    collective of the path: the all-reduce of [d loss / d theta_shared || loss] (straight lanes own their unknowns: [loss] alone).
+    Returns (max-over-ranks seconds, the reduced buffer, every rank's own part on rank 0, the last pass's gradients)."""
+    from dhts import dist as D
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
+    world = D.env_rank_world()[1]
+    flat = torch.zeros((w.action.shape[1] if shared_grad else 0) + 1, dtype=torch.float32, device=dev)
+
+    def reduce_pass(loss, g_a):
+        if shared_grad:
+            flat[:-1] = g_a.sum(dim=0)
+        flat[-1] = loss
+        local_part = flat.clone() if world > 1 else None
+        D.allreduce_sum_(flat)
+        return local_part
+    for _ in range(warmup):
+        loss, g_a, _ = w.one_pass()
+        reduce_pass(loss, g_a)
+    D.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, g_a, g_b = w.one_pass(record=record)
+        local_part = reduce_pass(loss, g_a)
+    D.barrier()
+    sync()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    fault = w.err.tolist()
+    assert fault[0] in (0, 2), "simulation fault during the bench: %s" % (fault,)
+    assert torch.isfinite(g_a).all() and torch.isfinite(g_b).all() and bool(torch.isfinite(flat).all())
+    # every rank's own [gradient || loss] of the last pass, gathered so that rank 0 can show the all-reduce summed them
+    parts = D.gather_to_rank0(local_part) if world > 1 else None
+    return elapsed, flat, parts, (g_a, g_b)
+
+
+def replica_sweep(dev, sizes=(256, 512, 1024, 2048), passes=3):
+    """Config 4's network at several replicas per GPU, ONE instance (2 048 replicas built once, prefixes timed): the saturated
+    throughput of the hybrid path on one GPU and the one-GPU time of config 5's whole 2 048-replica problem (the strong-scaling
+    denominator).  256 replicas = one workgroup per compute unit."""
+    w = make_workload("itscp_hybrid", dev, 0, lanes=max(sizes))
+    recs = []
+    for R in sizes:
+        w.restrict(R)
+        for _ in range(2):
+            w.one_pass()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            w.one_pass(record=True)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        fault = w.err.tolist()
+        assert fault[0] in (0, 2), "simulation fault during the replica sweep: %s" % (fault,)
+        kernels, _ = kernel_records(w)
+        recs.append({"replicas": R, "replicas_per_cu": R / 256.0, "ms_per_pass": el / passes * 1e3, "value": w.units * passes / el,
+                     "unit": w.unit_name, "fwd_ms": kernels["rollout_fwd"]["ms"], "bwd_ms": kernels["rollout_bwd"]["ms"],
+                     "fwd_GBps": kernels["rollout_fwd"]["GBps"], "bwd_GBps": kernels["rollout_bwd"]["GBps"]})
+    base = recs[0]["value"]
+    for r in recs:
+        r["vs_256_replicas"] = r["value"] / base
+    return {"workload": "itscp_hybrid replica sweep (%d lanes, %d cells x %d steps per replica)" % (w.n_lanes, w.N, w.T),
+            "passes": passes, "points": recs,
+            "note": "one GPU; the last point is BASELINE config 5's whole problem (2 048 replicas) on ONE device"}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -837,22 +945,16 @@ def main():
     else:
         assert torch.cuda.current_device() == dev.index
     sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
+    # who took part: backend + every rank's device (gathered; raises when RCCL ranks share a device)
+    collective = D.collective_record(dev) if world > 1 else None
 
     w = make_workload(args.workload, dev, rank, args.lanes, args.cells, args.time_steps)
     L, N, T = w.L, w.N, w.T
+    default_shape = not args.lanes and not args.cells and not args.time_steps
 
     # the per-pass RCCL all-reduce: [loss] for the straight-lane workloads (every lane owns its unknowns); for the network
     # workloads the gradient summed over the rank's replicas as if the signal schedule were shared (BASELINE config 5) + loss
     shared_grad = args.workload.startswith("itscp") or stub
-    flat = torch.zeros((w.action.shape[1] if shared_grad else 0) + 1, dtype=torch.float32, device=dev)
-
-    def reduce_pass(loss, g_a):
-        if shared_grad:
-            flat[:-1] = g_a.sum(dim=0)
-        flat[-1] = loss
-        local_part = flat.clone() if world > 1 else None
-        D.allreduce_sum_(flat)
-        return local_part
     # The pair kernel's priority rotation (DHTS_OPT_MACRO_FWD_ROTATE, include/dhts.h) encodes an observation about this pool's
     # dispatcher; correctness does not depend on it, speed may: untimed passes with and without it, interleaved, before the warm-up,
     # and the run takes what this box prefers (reported as roofline.fwd_rotate: best pass time of either setting)
@@ -876,38 +978,49 @@ def main():
         chosen = 1 if ms[1] <= ms[0] else 0
         _L.lib().dhts_set_option(_L.OPT_MACRO_FWD_ROTATE, chosen)
         rotate_rec = {"ms_per_pass_with": ms[1], "ms_per_pass_without": ms[0], "chosen": chosen}
-    for _ in range(args.warmup):
-        loss, g_a, _ = w.one_pass()
-        reduce_pass(loss, g_a)
-    D.barrier()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, g_a, g_b = w.one_pass(record=not stub)
-        local_part = reduce_pass(loss, g_a)
-    D.barrier()
-    sync()
-    elapsed = time.perf_counter() - t0
-    elapsed = D.max_over_ranks(elapsed, dev)
+    elapsed, flat, parts, (g_a, g_b) = collective_run(w, args.steps, args.warmup, shared_grad, dev, record=not stub)
 
-    fault = w.err.tolist()
-    assert fault[0] in (0, 2), "simulation fault during the bench: %s" % (fault,)
-    assert torch.isfinite(g_a).all() and torch.isfinite(g_b).all() and bool(torch.isfinite(flat).all())
-    # every rank's own [gradient || loss] of the last pass, gathered so that rank 0 can show the all-reduce summed them
-    parts = D.gather_to_rank0(local_part) if world > 1 else None
+    # N > 1, the driver's default command: BASELINE config 5 behind the headline -- the itscp hybrid network, 256 replicas per rank
+    # (2 048 over 8 GPUs), d reward / d (shared signal schedule) [45] || reward all-reduced once per pass.  Every rank runs it.
+    second = None
+    if world > 1 and not args.no_also and ((args.workload == "macro" and (default_shape or args.also_replicas)) or stub):
+        if not stub:
+            kernels_head = kernel_records(w)           # (the events and the census need the tape: read them before it goes)
+            census_head = w.tape_census() if rank == 0 else None
+            moved_head = w.moved_bytes_per_launch() if rank == 0 else None
+            del w.tape
+            torch.cuda.empty_cache()
+        w5 = make_workload("stub" if stub else "itscp_hybrid", dev, rank, 3 if stub else (args.also_replicas or 256))
+        passes5 = min(args.steps, 5)
+        el5, flat5, parts5, _g5 = collective_run(w5, passes5, 2, True, dev, record=not stub)
+        if rank == 0:
+            second = {"workload": w5.name, "config": "BASELINE config 5: %d replicas per rank x %d ranks = %d replicas" % (w5.L, world, w5.L * world),
+                      "value": w5.units * passes5 * world / el5, "unit": w5.unit_name, "n_gpus": world, "passes": passes5,
+                      "ms_per_pass": el5 / passes5 * 1e3, "scaling": "weak",
+                      "allreduce": "[d reward / d action (%d) || reward] summed over ranks once per pass" % (flat5.numel() - 1),
+                      "allreduce_check": allreduce_check(flat5, parts5, True), "loss_last_pass": flat5.tolist()[-1]}
+            if not stub:
+                k5, dom5 = kernel_records(w5)
+                second.update(dominant_kernel=dom5, kernels=k5, vehicles_spawned_replica0=int(w5.counts[0, 0]))
+        del w5
+    else:
+        kernels_head = census_head = moved_head = None
 
     parity_failed = False
     if rank == 0 and stub:
         out = {"metric": "stub", "value": w.units * args.steps * world / elapsed, "unit": w.unit_name, "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                "config": {"workload": w.name, "device": dev.type}, "loss_last_pass": flat.tolist()[-1],
-               "allreduce_check": None if parts is None else {
-                   "reduced": flat.tolist()[-1], "sum_of_rank_parts": float(parts[:, -1].double().sum()), "rank_parts": parts[:, -1].tolist(),
-                   "grad_max_abs_diff": float((parts[:, :-1].double().sum(dim=0) - flat[:-1].double().cpu()).abs().max())}}
+               "allreduce_check": allreduce_check(flat, parts, True)}
+        if collective is not None:
+            out["collective"] = collective
+        if second is not None:
+            out["also"] = [second]
         print(json.dumps(out))
     elif rank == 0:
-        kernels, dom = kernel_records(w)
+        kernels, dom = kernels_head if kernels_head is not None else kernel_records(w)
         k = kernels[dom]
+        moved = moved_head if moved_head is not None else w.moved_bytes_per_launch()
         value = w.units * args.steps * world / elapsed
         out = {
             "metric": "differentiable cell-steps/s (fwd+bwd)",
@@ -928,8 +1041,8 @@ def main():
                                       % ("replicas" if shared_grad else "lanes", world,
                                          "d loss / d action || loss" if shared_grad else "loss")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": k["frac_of_peak"], "traffic": pmc_traffic(w, dom), "traffic_unit": "bytes per launch (PMC)",
-                         "moved_bytes_per_launch": w.moved_bytes_per_launch(),
+                         "frac": k["frac_of_peak"], "traffic": pmc_traffic(w, dom, moved), "traffic_unit": "bytes per launch (PMC)",
+                         "moved_bytes_per_launch": moved,
                          "algorithmic_bytes_per_launch": w.units * w.unit_bytes,
                          "achieved_algorithmic": k["algorithmic_GBps"], "frac_algorithmic": k["algorithmic_GBps"] / HBM_PEAK_GBS,
                          "limiter": w.limiter.get(dom, "hbm"),
@@ -937,26 +1050,27 @@ def main():
                                  "blocks, which the reverse sweep rebuilds; macro: counted from the tape's own row headers after "
                                  "the run, in whole 128-byte lines) / HIP-event time of the launch; *_algorithmic = the "
                                  "reference's tape bytes (48 B per cell-step, 32 B per vehicle-step) / the same time"},
-            "whole_path": {"moved_GBps": 2 * w.moved_bytes_per_launch() * args.steps / elapsed / 1e9,
-                           "frac_of_peak": 2 * w.moved_bytes_per_launch() * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+            "whole_path": {"moved_GBps": 2 * moved * args.steps / elapsed / 1e9,
+                           "frac_of_peak": 2 * moved * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
                            "algorithmic_GBps": w.units * 2 * w.unit_bytes * args.steps / elapsed / 1e9},
             "kernels": kernels,
             "loss_last_pass": flat.tolist()[-1],          # summed over ranks by the all-reduce
         }
         if hasattr(w, "tape_census"):
-            out["roofline"]["tape_census"] = w.tape_census()
+            out["roofline"]["tape_census"] = census_head if census_head is not None else w.tape_census()
         if rotate_rec is not None:
             out["roofline"]["fwd_rotate"] = rotate_rec
         side = issue_counters(w, dom)
         if side is not None:
             out["roofline"]["issue_side"] = side
         if parts is not None:
-            out["allreduce_check"] = {"reduced": flat.tolist()[-1], "sum_of_rank_parts": float(parts[:, -1].double().sum()),
-                                      "rank_parts": parts[:, -1].tolist(),
-                                      "grad_max_abs_diff": float((parts[:, :-1].double().sum(dim=0) - flat[:-1].double().cpu()).abs().max())
-                                      if shared_grad else 0.0}
+            out["allreduce_check"] = allreduce_check(flat, parts, shared_grad)
+        if collective is not None:
+            out["collective"] = collective
+        if second is not None:
+            out["also"] = [second]
         if world == 1:
-            if args.workload == "macro" and not args.lanes and not args.cells and not args.time_steps and not args.no_also:
+            if args.workload == "macro" and default_shape and not args.no_also:
                 del w.tape            # 24 GB back to the allocator before the other workloads take theirs
                 torch.cuda.empty_cache()
                 out["also"] = []
@@ -970,6 +1084,15 @@ def main():
                     del w2, g2
                     torch.cuda.empty_cache()
                     out["also"].append(rec)
+                # the one-GPU side of the scaling question: config 4's network at 256 ... 2 048 replicas on this device,
+                # and config 2 at 8 x its lanes (what 8 GPUs run together), each as ms per pass and cell-steps/s
+                out["also"].append(replica_sweep(dev))
+                torch.cuda.empty_cache()
+                rec, w2, _g = also_record("macro", dev, passes=3, lanes=8 * L)
+                rec["note"] = "config 2 x 8 lanes on ONE GPU (tape %.1f GB): the one-GPU time of the 8-GPU run's whole problem" % (w2.tape_bytes / 1e9)
+                del w2, _g
+                torch.cuda.empty_cache()
+                out["also"].append(rec)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = w.cpu_baseline()
                 # what this run timed, checked on this box: the last timed pass against the oracle's run of the same inputs

@@ -40,15 +40,16 @@ def init(backend=None):
         torch.cuda.set_device(dev)
     if (world > 1 or _forced()) and not dist.is_initialized():
         if backend is None:
-            # the default on GPUs is RCCL ("nccl"); DHTS_DIST_BACKEND=gloo -- or more ranks than devices -- lets several ranks
-            # share one GPU in a smoke test (RCCL refuses two ranks on one device)
+            # the default on GPUs is RCCL ("nccl").  Several ranks on ONE device (a single-GPU smoke test) need gloo, because RCCL
+            # refuses two ranks on one device -- but only when the caller asks for it by name: a node that shows fewer GPUs than
+            # ranks must not turn an RCCL measurement into a gloo one behind the caller's back
             backend = os.environ.get("DHTS_DIST_BACKEND")
             if not backend:
                 n_dev = torch.cuda.device_count()
-                backend = "nccl" if n_dev >= world else "gloo"
-                if n_dev and backend == "gloo" and rank == 0:
-                    print("dhts.dist: %d ranks on %d GPU(s): ranks share devices, collectives over gloo" % (world, n_dev), flush=True,
-                          file=__import__("sys").stderr)
+                if 0 < n_dev < world:
+                    raise RuntimeError("dhts.dist: %d ranks but only %d GPU(s) visible: refusing to fall back to gloo silently; "
+                                       "set DHTS_DIST_BACKEND=gloo to let ranks share devices (smoke tests only)" % (world, n_dev))
+                backend = "nccl" if n_dev else "gloo"        # (no GPU at all: host-only ranks, e.g. the launcher self-test)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
@@ -95,6 +96,54 @@ def gather_to_rank0(flat):
     parts = [torch.empty_like(src) for _ in range(world)]
     dist.all_gather(parts, src)
     return torch.stack([p.cpu() for p in parts]) if dist.get_rank() == 0 else None
+
+
+def device_identity(device):
+    """What tells this rank's GPU from its neighbours': marketing name, gfx arch, PCI bus id, UUID where the runtime gives one
+    (diagnostics for the N > 1 bench line: the reader can see that N ranks sat on N distinct devices)."""
+    ident = {"rank": dist.get_rank() if dist.is_initialized() else 0, "host": os.uname().nodename,
+             "visible": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")}
+    if device is None or device.type != "cuda":
+        ident["device"] = "cpu"
+        return ident
+    p = torch.cuda.get_device_properties(device)
+    ident.update(device="cuda:%d" % device.index, name=p.name, arch=getattr(p, "gcnArchName", None),
+                 uuid=str(getattr(p, "uuid", "")) or None)
+    bus = None
+    if all(hasattr(p, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        bus = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    else:
+        try:                                               # the HIP runtime torch already loaded
+            import ctypes
+            buf = ctypes.create_string_buffer(64)
+            if ctypes.CDLL("libamdhip64.so").hipDeviceGetPCIBusId(buf, 64, int(device.index)) == 0:
+                bus = buf.value.decode()
+        except OSError:
+            pass
+    ident["pci_bus_id"] = bus
+    return ident
+
+
+def gather_objects(obj):
+    """[world] list of every rank's (picklable) `obj` on every rank; [obj] without a process group.  Diagnostics only."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def collective_record(device):
+    """{"backend", "world", "devices": [per-rank device_identity], "distinct_devices"} -- every rank must call it (a gather).
+    Raises when the backend is RCCL and two ranks report the same device: such a line would not be an N-GPU number."""
+    devs = gather_objects(device_identity(device))
+    backend = dist.get_backend() if dist.is_initialized() else None
+    keys = {(d.get("host"), d.get("pci_bus_id") or d.get("uuid") or d.get("device")) for d in devs}
+    rec = {"backend": backend, "backend_is": "RCCL (torch.distributed 'nccl' on ROCm)" if backend == "nccl" else backend,
+           "world": len(devs), "devices": devs, "distinct_devices": len(keys)}
+    if backend == "nccl" and len(keys) != len(devs):
+        raise RuntimeError("dhts.dist: %d ranks over RCCL but only %d distinct devices: %s" % (len(devs), len(keys), devs))
+    return rec
 
 
 def barrier():

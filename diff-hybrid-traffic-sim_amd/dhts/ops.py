@@ -611,6 +611,17 @@ class DeviceHybridTables:
         self.net = _lib.NetTables(k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], self.T * self.n_lanes if many else 0,
                                   k[9], k[10], k[11], k[12], t.n_edges)
 
+    def first(self, n_replicas):
+        """The same uploaded tables as a batch of the first `n_replicas` replicas (no copy: the per-replica arrays are
+        replica-major, so a shorter batch reads a prefix of them)."""
+        import copy
+        if not 1 <= int(n_replicas) <= max(self.n_replica_tables, 1) and self.n_replica_tables:
+            raise ValueError("tables hold %d replicas" % self.n_replica_tables)
+        v = copy.copy(self)
+        if self.n_replica_tables:
+            v.n_replica_tables = int(n_replicas)
+        return v
+
     def set_draws(self, draws):
         """A fresh stream of admission draws for the next episode (micro source lanes; same length as the uploaded one)."""
         import numpy as np

@@ -105,6 +105,43 @@ def test_two_ranks_hybrid_replicas_shared_schedule(cuda):
     assert abs(b["value"] * b["ms_per_step"] * 1e-3 / (2 * units) - 1.0) < 1e-9
 
 
+@pytest.mark.gpu
+def test_two_ranks_default_command_appends_config5(cuda):
+    """What `bench.py --gpus N` adds for N > 1: behind the config-2 loop every rank runs the itscp hybrid network (here 8 replicas
+    per rank instead of 256) with the all-reduce of [d reward / d action (45) || reward]; the line names the backend and every
+    rank's device."""
+    two = run_bench(["--gpus", "2", "--workload", "macro", "--lanes", "64", "--time-steps", "50", "--steps", "3", "--warmup", "1",
+                     "--no-cpu-baseline", "--also-replicas", "8"], env={"DHTS_DIST_BACKEND": "gloo"})
+    assert two.returncode == 0, two.stderr[-3000:]
+    b = last_json(two.stdout)
+    col = b["collective"]
+    assert col["backend"] == "gloo" and col["world"] == 2 and len(col["devices"]) == 2
+    assert all(d["name"] and d["device"].startswith("cuda:") for d in col["devices"])
+    sec = b["also"][0]
+    assert sec["n_gpus"] == 2 and "8 replicas per rank x 2 ranks = 16 replicas" in sec["config"]
+    chk = sec["allreduce_check"]
+    assert chk["buffer_floats"] == 46 and len(chk["rank_parts"]) == 2 and chk["rank_parts"][0] != chk["rank_parts"][1]
+    assert abs(chk["reduced"] - chk["sum_of_rank_parts"]) <= 1e-6 * abs(chk["sum_of_rank_parts"])
+    assert chk["grad_max_abs_diff"] <= 1e-6 * max(abs(x) for x in chk["rank_parts"])
+    units = 8 * 256 * 600
+    assert abs(sec["value"] * sec["ms_per_pass"] * 1e-3 / (2 * units) - 1.0) < 1e-9
+
+
+@pytest.mark.gpu
+def test_more_ranks_than_gpus_exits_nonzero_without_named_gloo(cuda):
+    """Two ranks, one GPU, no DHTS_DIST_BACKEND: the run must fail instead of reporting a gloo number as if it were RCCL's."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs fewer GPUs than ranks")
+    e = {k: v for k, v in os.environ.items() if k != "DHTS_DIST_BACKEND"}
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--workload", "macro", "--lanes", "8", "--time-steps", "5", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                       env={k: v for k, v in e.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}, cwd=ROOT)
+    assert p.returncode != 0
+    assert "refusing to fall back to gloo" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
 RCCL_CHILD = r"""
 import json, os, sys
 sys.path.insert(0, os.path.join(%(root)r, "diff-hybrid-traffic-sim_amd"))

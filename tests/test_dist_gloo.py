@@ -158,7 +158,7 @@ def test_two_rank_gloo_replica_sharding(oracle, tmp_path):
 
 def _run_bench(args, extra_env=None, timeout=240):
     import time
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", DHTS_DIST_BACKEND="gloo")       # (by name: eight ranks never fit a test box's GPUs)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)                       # no launcher environment: bench.py starts its own ranks
     env.update(extra_env or {})
@@ -184,6 +184,33 @@ def test_bench_launcher_eight_ranks_over_gloo():
     # rank r's loss: sum over (2 x 3) entries of (k + 100 r)^2
     want = [float(sum((k + 100.0 * r) ** 2 for k in range(6))) for r in range(8)]
     assert chk["rank_parts"] == want
+    # who took part: the backend by name and one identity per rank (on a GPU node: name, PCI bus id, uuid of eight distinct devices)
+    col = o["collective"]
+    assert col["backend"] == "gloo" and col["world"] == 8 and [d["rank"] for d in col["devices"]] == list(range(8))
+    # N > 1 appends the second workload (on GPUs: BASELINE config 5, 256 hybrid replicas per rank) with its own per-pass all-reduce
+    # of [gradient || loss]: here the stub at another shape (3 x 3 per rank), timed and checked the same way
+    assert len(o["also"]) == 1
+    sec = o["also"][0]
+    assert sec["n_gpus"] == 8 and sec["passes"] == 3 and sec["value"] > 0 and "x 8 ranks" in sec["config"]
+    chk2 = sec["allreduce_check"]
+    want2 = [float(sum((k + 100.0 * r) ** 2 for k in range(9))) for r in range(8)]
+    assert chk2["rank_parts"] == want2 and chk2["buffer_floats"] == 4
+    assert chk2["reduced"] == chk2["sum_of_rank_parts"] == sec["loss_last_pass"] and chk2["grad_max_abs_diff"] == 0.0
+
+
+def test_more_ranks_than_gpus_is_refused_unless_gloo_is_named(monkeypatch):
+    """dhts.dist.init never picks gloo behind the caller's back on a node that shows some, but fewer, GPUs than ranks."""
+    import pytest
+    import torch
+    from dhts import dist as D
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.delenv("DHTS_DIST_BACKEND", raising=False)
+    with pytest.raises(RuntimeError, match="refusing to fall back to gloo"):
+        D.init()
 
 
 def test_bench_launcher_ends_the_ranks_when_one_dies():
