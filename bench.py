@@ -941,7 +941,9 @@ def replica_sweep(dev, sizes=(256, 512, 1024, 2048), passes=3):
         el = time.perf_counter() - t0
         check_faults(w, "the replica sweep")
         kernels, _ = kernel_records(w)
-        recs.append({"replicas": R, "replicas_per_cu": R / 256.0, "ms_per_pass": el / passes * 1e3, "value": w.units * passes / el,
+        plan = w.ops.net_hybrid_plan(R, w.action.shape[1], w.tab, w.sq)
+        recs.append({"replicas": R, "replicas_per_cu": R / float(plan["cus"]), "two_workgroups_per_cu": plan["packed"],
+                     "lds_bytes_fwd_bwd": [plan["lds_fwd"], plan["lds_bwd"]], "ms_per_pass": el / passes * 1e3, "value": w.units * passes / el,
                      "unit": w.unit_name, "fwd_ms": kernels["rollout_fwd"]["ms"], "bwd_ms": kernels["rollout_bwd"]["ms"],
                      "fwd_GBps": kernels["rollout_fwd"]["GBps"], "bwd_GBps": kernels["rollout_bwd"]["GBps"],
                      "replicas_dropped_nonfinite_gradient": w.dropped_replicas()})
@@ -950,7 +952,9 @@ def replica_sweep(dev, sizes=(256, 512, 1024, 2048), passes=3):
         r["vs_256_replicas"] = r["value"] / base
     return {"workload": "itscp_hybrid replica sweep (%d lanes, %d cells x %d steps per replica)" % (w.n_lanes, w.N, w.T),
             "passes": passes, "points": recs,
-            "note": "one GPU; the last point is BASELINE config 5's whole problem (2 048 replicas) on ONE device"}
+            "note": "one GPU; the last point is BASELINE config 5's whole problem (2 048 replicas) on ONE device.  Beyond one replica "
+                    "per compute unit the kernels are launched two to a unit (DHTS_OPT_HYB_PACK, include/dhts.h: half the LDS and 128 "
+                    "registers per workgroup, same results bit for bit)"}
 
 
 def main():

@@ -46,7 +46,7 @@ constexpr int kMaxVeh = 128;         // vehicles per replica and episode
 constexpr int kRouteStride = 32;     // MAX_ROUTE_LENGTH, road_network.py:17
 constexpr int kLaneLocals = 192;     // temporaries per lane of the micro wave and step
 constexpr int kEventLocals = 64;     // temporaries of the serial event walk per step
-constexpr int kMaxLocals = 64 * kLaneLocals + kEventLocals;
+// (a launch lays out loc_lanes * kLaneLocals + kEventLocals temporaries: HybTables::loc_lanes = 64, or the staging lanes when packed)
 constexpr int kStageH = 48;          // records a lane can stage per step, at most.  A lane's staging area is two blocks of stage_h
                                      // records (the block being filled, the block being flushed); stage_h is a per-launch size:
                                      // kStageH when the LDS has room for that (<= 20 micro lanes beside BASELINE config 4's 256
@@ -119,6 +119,9 @@ struct HybTables {
     const int32_t *lane_macro; const double *lane_len; const int32_t *conv_next; const int32_t *routes; const int32_t *route_ptr;
     int n_routes, route_stride, loss_steps, n_micro;
     int lane_sh;                             // log2 of the vehicles a micro lane holds (4 .. 7)
+    int lds_budget;                          // bytes of LDS the forward kernel sizes its staging area for
+    int loc_lanes;                           // lanes of the micro wave that own a range of temporaries (64; n_staging_lanes when packed)
+    int max_step_records;                    // records a step may hold (the reverse sweep stages a step's records in LDS)
     const int32_t *lane_source; const double *draws; int n_draws; size_t draws_stride;     // micro source lanes (itscp `micro` mode)
     // a plain RoadNetwork with given initial state and final-state taps (dhts_net_hybrid_state_rollout_*, include/dhts.h)
     int plain;
@@ -128,7 +131,7 @@ struct HybTables {
 
 // workspace layout of one replica (bytes, all 16-byte aligned)
 struct HybWs {
-    size_t own_hist, rec_k, rec_i, rec_w, step_off, seg_cnt, xs, capru, capflag, per_replica;
+    size_t own_hist, rec_k, rec_i, rec_w, step_off, seg_cnt, xs, capru, capflag, mode, per_replica;
     int rec_cap, V;
 };
 __host__ __device__ inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -147,6 +150,7 @@ __host__ __device__ inline HybWs hyb_ws(int L, int C, int T, int n_routes, int r
     w.xs = o; o += up16(sizeof(float) * (size_t)T * (size_t)(C + kMaxVeh));
     w.capru = o; o += up16(sizeof(float2) * (size_t)T * kMaxCaps);      // (u, r) every capacitor's charge of a step read
     w.capflag = o; o += up16(sizeof(unsigned) * (size_t)T);             // bit j: capacitor j charged; bit 16 + j: its previous level was a variable
+    w.mode = o; o += 16;                                                // (loc_lanes | max_step_records << 8) the forward sweep ran with
     w.per_replica = o;
     return w;
 }
@@ -327,8 +331,8 @@ __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS, i
 __host__ __device__ inline int hyb_tape_ifaces(int L, int C) { return (C + L + 63) & ~63; }
 
 // records a lane of the micro wave can stage per step: what the LDS has room for beside everything else (0 = does not fit)
-__host__ __device__ inline int hyb_stage_h(int L, int C, int sq, int V, int NS, int n_action, int lane_sh) {
-    const size_t act = up16(sizeof(float) * (size_t)n_action), budget = 160 * 1024;
+__host__ __device__ inline int hyb_stage_h(int L, int C, int sq, int V, int NS, int n_action, int lane_sh, size_t budget = 160 * 1024) {
+    const size_t act = up16(sizeof(float) * (size_t)n_action);
     const size_t fixed = hyb_lds(L, C, sq, V, NS, 0, lane_sh).total + act;
     if (fixed + 64 >= budget) return 0;
     int h = (int)((budget - fixed - 64) / ((size_t)NS * 2 * 36));
@@ -392,7 +396,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     const int NS = tb.n_micro > kMaxCaps ? tb.n_micro : kMaxCaps;      // lanes of the micro wave that stage records
     const int lane_sh = tb.lane_sh;                                   // a micro lane's vehicle list: lane_veh[(k << lane_sh) + i]
     const int lane_cap = 1 << lane_sh;
-    const int stage_h = hyb_stage_h(L, C, sq, V, NS, n_action, lane_sh);
+    const int stage_h = hyb_stage_h(L, C, sq, V, NS, n_action, lane_sh, (size_t)tb.lds_budget);
     const HybLds lo = hyb_lds(L, C, sq, V, NS, stage_h, lane_sh);
     double *Fq = reinterpret_cast<double *>(lds + lo.fq), *scanw = reinterpret_cast<double *>(lds + lo.scanw);
     double *incl = reinterpret_cast<double *>(lds + lo.incl), *vsp = reinterpret_cast<double *>(lds + lo.vsp), *vep = reinterpret_cast<double *>(lds + lo.vep);
@@ -623,7 +627,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
             }
             rec_n += total;
         }
-        if (total > kMaxStepRecords) fl_fault = true;
+        if (total > tb.max_step_records) fl_fault = true;
     };
 
     // ---- micro SOURCE lanes (itscp `micro` mode, _simulator.py:153-174): a micro lane without an upstream lane admits a waiting
@@ -920,7 +924,10 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
         loss_lanes(T - 1);
     }
     if (is_fw) {
-        if (fl == 0) { if (!kHard) step_off[T + 1] = rec_n; counts[4 * rep + 2] = rec_n; }
+        if (fl == 0) {
+            if (!kHard) { step_off[T + 1] = rec_n; *reinterpret_cast<int *>(wsr + ws.mode) = tb.loc_lanes | (tb.max_step_records << 8); }
+            counts[4 * rep + 2] = rec_n;
+        }
         if (fl_fault) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, rec_n);
     }
     if (in_mw) {
@@ -954,15 +961,15 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
 struct HybLdsB {
     size_t red, h0, h1, gl, c0, c2, gq, inl, inf, sg, adj, gam, rk, ri, rw, cell_lane, obi, obf, aval, iptr, iidx, lfl, linfo, total;
 };
-__host__ __device__ inline HybLdsB hyb_lds_b(int L, int C, int sq, int V, int E) {
+__host__ __device__ inline HybLdsB hyb_lds_b(int L, int C, int sq, int V, int E, int loc_lanes = 64, int max_rec = kMaxStepRecords) {
     HybLdsB o; size_t p = 0;
     auto D = [&](size_t n) { size_t r = p; p += 8 * n; return r; };
     auto F = [&](size_t n) { size_t r = p; p += 4 * ((n + 3) & ~(size_t)3); return r; };
     o.red = D(2);
     o.h0 = F(3 * (size_t)C); o.h1 = F(3 * (size_t)C); o.gl = F(3 * (size_t)C); o.c0 = F(2 * (size_t)C); o.c2 = F(2 * (size_t)C);
     o.gq = F(L); o.inl = F(3 * (size_t)E); o.inf = F(3 * (size_t)E); o.sg = F(6 * (size_t)sq);
-    o.adj = F(3 * (size_t)V + 2 * kMaxCaps + kMaxLocals); o.gam = F(2 * (size_t)sq);
-    o.rk = F(kMaxStepRecords); o.ri = F(4 * (size_t)kMaxStepRecords); o.rw = F(4 * (size_t)kMaxStepRecords);
+    o.adj = F(3 * (size_t)V + 2 * kMaxCaps + (size_t)loc_lanes * kLaneLocals + kEventLocals); o.gam = F(2 * (size_t)sq);
+    o.rk = F(max_rec); o.ri = F(4 * (size_t)max_rec); o.rw = F(4 * (size_t)max_rec);
     o.cell_lane = F(C); o.obi = F(64 * 5); o.obf = F(64 * 5);
     o.aval = F(2 * (size_t)L); o.iptr = F((size_t)sq + 1); o.iidx = F(2 * (size_t)L);
     o.lfl = F(L); o.linfo = F(L);
@@ -988,7 +995,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     const int E = tb.net.n_edges > 0 ? tb.net.n_edges : 1;
     const HybWs ws = hyb_ws(L, C, T, tb.n_routes, records_per_step);
     const int V = ws.V;
-    const HybLdsB lo = hyb_lds_b(L, C, sq, V, E);
+    const HybLdsB lo = hyb_lds_b(L, C, sq, V, E, tb.loc_lanes, tb.max_step_records);
 #define LF(name) reinterpret_cast<float *>(lds + lo.name)
     float *H0 = LF(h0), *H1 = LF(h1), *gL = LF(gl), *c0 = LF(c0), *c2 = LF(c2), *inL = LF(inl), *inF = LF(inf);
     float *sg = LF(sg), *adj = LF(adj), *gam = LF(gam), *rw = LF(rw);
@@ -1022,7 +1029,9 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     const bool is_cell = tid < C, is_ghost = tid < L || (tid >= g_base1 && tid < g_base1 + L), is_lane = tid < L;
     const bool in_mw = tid >= B - 64, is_mt = (tid == B - 64);
     const int mw_lane = tid - (B - 64);
-    const int n_adj = 3 * V + 2 * kMaxCaps + kMaxLocals;
+    const int n_adj = 3 * V + 2 * kMaxCaps + tb.loc_lanes * kLaneLocals + kEventLocals;
+    // (the forward sweep's temporaries and step records must be laid out as this launch expects: DHTS_OPT_HYB_PACK unchanged in between)
+    bool bad_mode = *reinterpret_cast<const int *>(wsr + ws.mode) != (tb.loc_lanes | (tb.max_step_records << 8));
 
     if (is_lane) {
         const int off = tb.net.lane_off[tid], n = tb.net.lane_ncell[tid];
@@ -1234,7 +1243,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_bwd_kernel(int R_, int L
     if (is_own && T > 0) ga += (double)gam[own_q];       // step 0's outboxes (buffer 0; the loop's last barrier is behind them)
     if (is_own && cur_phase >= 0) g_action[(size_t)rep * n_action + cur_phase * sq + own_q] = (float)ga;
     if (bad_step >= 0) net_fault(err, DHTS_FAULT_NAN, bad_step, rep, tid);
-    if ((over && is_mt) || bad_key) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, bad_key ? -2 : 0);
+    if ((over && is_mt) || bad_key || (bad_mode && tid == 0)) net_fault(err, DHTS_FAULT_CAPACITY, 0, 0, bad_mode ? -3 : (bad_key ? -2 : 0));
 #undef LF
 }
 
@@ -1269,15 +1278,60 @@ static inline HybTables hyb_tables(const dhts_hybrid_tables *t) {
     h.lane_macro = t->lane_macro; h.lane_len = t->lane_len; h.conv_next = t->conv_next; h.routes = t->routes; h.route_ptr = t->route_ptr;
     h.n_routes = t->n_routes; h.route_stride = t->route_stride; h.loss_steps = t->loss_steps; h.n_micro = t->n_micro; h.lane_sh = hyb_lane_sh(t);
     h.lane_source = t->lane_source; h.draws = t->draws; h.n_draws = t->n_draws; h.draws_stride = (size_t)t->draws_stride;
+    h.lds_budget = 160 * 1024; h.loc_lanes = 64; h.max_step_records = kMaxStepRecords;
     h.plain = 0; h.state0 = nullptr; h.ghost0 = nullptr; h.veh_out = nullptr; h.events = nullptr;
     h.g_stateT = nullptr; h.g_veh = nullptr; h.g_state0 = nullptr;
     return h;
 }
+int dhts_hyb_pack = 2;                           // DHTS_OPT_HYB_PACK (dhts_set_option, macro_kernels.hip): 0 never, 1 always, 2 = more replicas than CUs
+constexpr size_t kHybPackBudget = 79 * 1024;     // two workgroups share a compute unit's 160 KB
 static inline int hyb_block(const dhts_net_desc *d) {
     int need = d->n_cells + d->n_lanes;
     if (need < 2 * d->n_lanes) need = 2 * d->n_lanes;
     if (need < d->n_action) need = d->n_action;
     return ((need + 63) & ~63) + 64;               // + the micro wavefront
+}
+
+static int hyb_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+// How the fused kernels of one (network, batch) are launched -- the same decision for the forward sweep and its reverse (the
+// forward's records name temporaries and fill step blocks whose bounds the reverse sweep's LDS plan must share; a workspace
+// word carries the forward's choice and the reverse sweep raises DHTS_FAULT_CAPACITY, index -3, on a mismatch).
+// packed: TWO replicas per compute unit -- each workgroup plans with half the LDS (a smaller record staging area in the forward
+// kernel; temporaries for the network's own micro lanes and a step's records bounded by what the staging area can hold in the
+// reverse kernel) and runs the 128-register instantiation (four wavefronts per SIMD).  Taken when the batch has more replicas
+// than the device has compute units (one replica per unit is faster per replica: no register spills), the workgroup has at
+// most eight wavefronts, the lanes keep their default capacity of 16 vehicles (a caller climbing the capacity ladder gets
+// the full staging area back) and both plans fit.  Measured at BASELINE config 4's network, 512 / 1 024 replicas: forward 6.16 ->
+// 4.95 / 12.08 -> 9.74 ms, results bit-identical (tools/probes/exp_hyb_pack.py, profiles/r06_hyb_pack.log).
+struct HybPlan { bool packed; size_t fwd_budget; int stage_h, loc_lanes, max_rec; size_t lds_fwd, lds_bwd; int block; };
+static HybPlan hyb_plan(const dhts_net_desc *d, const dhts_hybrid_tables *t, bool state_io) {
+    HybPlan p;
+    const HybWs ws = hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step);
+    const int NS = t->n_micro > kMaxCaps ? t->n_micro : kMaxCaps, lane_sh = hyb_lane_sh(t);
+    const int E = t->net.n_edges > 0 ? t->net.n_edges : 1;
+    const size_t act = up16(sizeof(float) * (size_t)d->n_action);
+    p.block = hyb_block(d);
+    p.packed = false;
+    if (!state_io && p.block <= 512 && lane_sh == 4 && (dhts_hyb_pack == 1 || (dhts_hyb_pack == 2 && d->n_replicas > hyb_cu_count()))) {
+        const int h = hyb_stage_h(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, d->n_action, lane_sh, kHybPackBudget);
+        const int mr = NS * h < kMaxStepRecords ? NS * h : kMaxStepRecords;
+        if (h >= 16 && hyb_lds_b(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, E, NS, mr).total + act <= kHybPackBudget) p.packed = true;
+    }
+    p.fwd_budget = p.packed ? kHybPackBudget : (size_t)160 * 1024;
+    p.stage_h = hyb_stage_h(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, d->n_action, lane_sh, p.fwd_budget);
+    p.loc_lanes = p.packed ? NS : 64;
+    p.max_rec = p.packed ? (NS * p.stage_h < kMaxStepRecords ? NS * p.stage_h : kMaxStepRecords) : kMaxStepRecords;
+    p.lds_fwd = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, p.stage_h, lane_sh).total + act;
+    p.lds_bwd = hyb_lds_b(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, E, p.loc_lanes, p.max_rec).total + act;
+    return p;
 }
 
 #ifdef DHTS_HYB_STAMPS
@@ -1300,6 +1354,14 @@ size_t dhts_net_hybrid_workspace_bytes(const dhts_net_desc *d, const dhts_hybrid
     return hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step).per_replica * (size_t)d->n_replicas;
 }
 
+int dhts_net_hybrid_plan(const dhts_net_desc *d, const dhts_hybrid_tables *t, int32_t plan[8]) {
+    if (!hyb_desc_ok(d) || !hyb_tables_ok(t) || !plan) return DHTS_E_INVALID;
+    const HybPlan p = hyb_plan(d, t, false);
+    plan[0] = p.packed ? 1 : 0; plan[1] = p.block; plan[2] = p.stage_h; plan[3] = (int32_t)p.lds_fwd; plan[4] = (int32_t)p.lds_bwd;
+    plan[5] = p.loc_lanes; plan[6] = p.max_rec; plan[7] = hyb_cu_count();
+    return DHTS_OK;
+}
+
 static int hyb_fwd_launch(const dhts_net_desc *d, const dhts_hybrid_tables *t, const dhts_hybrid_state_io *io, const float *action,
                           float *hist, float *tape, float *kc, float *queue, float *reward, int32_t *counts, void *workspace,
                           dhts_error *err, void *stream) {
@@ -1309,15 +1371,15 @@ static int hyb_fwd_launch(const dhts_net_desc *d, const dhts_hybrid_tables *t, c
     if (io) { ht.plain = io->plain; ht.state0 = io->state0; ht.ghost0 = io->ghost0; ht.veh_out = io->veh_out; ht.events = io->events; }
     const int B = hyb_block(d);
     if (B > 1024) return DHTS_E_INVALID;
-    const HybWs ws = hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step);
-    const int NS = t->n_micro > kMaxCaps ? t->n_micro : kMaxCaps;
-    const int stage_h = hyb_stage_h(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, d->n_action, hyb_lane_sh(t));
-    if (stage_h < 8) return DHTS_E_INVALID;       // (a lane with one vehicle stages ~10 records in a step with a hand-off)
-    const size_t lds = hyb_lds(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, stage_h, hyb_lane_sh(t)).total + up16(sizeof(float) * (size_t)d->n_action);
+    const HybPlan pl = hyb_plan(d, t, io != nullptr);
+    const bool pack = pl.packed;
+    ht.lds_budget = (int)pl.fwd_budget; ht.loc_lanes = pl.loc_lanes; ht.max_step_records = pl.max_rec;
+    if (pl.stage_h < 8) return DHTS_E_INVALID;       // (a lane with one vehicle stages ~10 records in a step with a hand-off)
+    const size_t lds = pl.lds_fwd;
     if (lds > 160 * 1024) return DHTS_E_INVALID;
     // (the block-size bound sets the vector registers a thread may take: 256 / 168 / 128)
     auto kern = io ? (B <= 512 ? net_hybrid_fwd_kernel<512, false, true> : (B <= 768 ? net_hybrid_fwd_kernel<768, false, true> : net_hybrid_fwd_kernel<1024, false, true>))
-                   : (B <= 512 ? net_hybrid_fwd_kernel<512, false> : (B <= 768 ? net_hybrid_fwd_kernel<768, false> : net_hybrid_fwd_kernel<1024, false>));
+                   : (pack ? net_hybrid_fwd_kernel<1024, false> : (B <= 512 ? net_hybrid_fwd_kernel<512, false> : (B <= 768 ? net_hybrid_fwd_kernel<768, false> : net_hybrid_fwd_kernel<1024, false>)));
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_LAUNCH;
@@ -1370,13 +1432,13 @@ static int hyb_bwd_launch(const dhts_net_desc *d, const dhts_hybrid_tables *t, i
     ht.plain = plain; ht.g_stateT = g_stateT; ht.g_veh = g_veh; ht.g_state0 = g_state0;
     const int B = hyb_block(d);
     if (B > 1024) return DHTS_E_INVALID;
-    const HybWs ws = hyb_ws(d->n_lanes, d->n_cells, d->n_steps, t->n_routes, t->records_per_step);
-    const int E = t->net.n_edges > 0 ? t->net.n_edges : 1;
-    const size_t lds = hyb_lds_b(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, E).total + up16(sizeof(float) * (size_t)d->n_action);
-    if (lds > 160 * 1024) return DHTS_E_INVALID;
     const bool state_io = plain || g_stateT || g_veh || g_state0;
+    const HybPlan pl = hyb_plan(d, t, state_io);
+    ht.loc_lanes = pl.loc_lanes; ht.max_step_records = pl.max_rec;
+    const size_t lds = pl.lds_bwd;
+    if (lds > 160 * 1024) return DHTS_E_INVALID;
     auto kern = state_io ? (B <= 512 ? net_hybrid_bwd_kernel<512, true> : (B <= 768 ? net_hybrid_bwd_kernel<768, true> : net_hybrid_bwd_kernel<1024, true>))
-                         : (B <= 512 ? net_hybrid_bwd_kernel<512> : (B <= 768 ? net_hybrid_bwd_kernel<768> : net_hybrid_bwd_kernel<1024>));
+                         : (pl.packed ? net_hybrid_bwd_kernel<1024> : (B <= 512 ? net_hybrid_bwd_kernel<512> : (B <= 768 ? net_hybrid_bwd_kernel<768> : net_hybrid_bwd_kernel<1024>)));
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DHTS_E_LAUNCH;

@@ -1646,6 +1646,7 @@ extern "C" int dhts_debug_fwd3_stamps(long long *out) {       // [16 workgroups]
 #endif
 
 extern int dhts_netstep_lds_kb, dhts_netstep_block;      // netstep_hybrid.hip
+extern int dhts_hyb_pack;                                // hybrid_kernels.hip
 
 extern "C" {
 
@@ -1668,6 +1669,10 @@ int dhts_set_option(int option, int value) {
     }
     if (option == DHTS_OPT_NETSTEP_LDS_KB && (value == 0 || (value >= 1 && value <= 158))) {
         dhts_netstep_lds_kb = value;
+        return DHTS_OK;
+    }
+    if (option == DHTS_OPT_HYB_PACK && value >= 0 && value <= 2) {
+        dhts_hyb_pack = value;
         return DHTS_OK;
     }
     if (option == DHTS_OPT_MACRO_FWD_GROUP && (value == 0 || value == 1 || value == 2 || value == 4)) {

@@ -21,6 +21,7 @@ OPT_MACRO_FWD_GROUP = 4
 OPT_MACRO_FWD_ROTATE = 5
 OPT_NETSTEP_LDS_KB = 6
 OPT_NETSTEP_BLOCK = 7
+OPT_HYB_PACK = 8
 MACRO_MAX_CELLS = 4000
 MICRO_MAX_VEHICLES = 1024
 
@@ -100,6 +101,7 @@ SIGNATURES = {
     "dhts_net_ghosts_bwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetTables), _P, _P, C.c_int] + [_P] * 13),
     "dhts_net_hybrid_tape_bytes": (C.c_size_t, [C.POINTER(NetDesc)]),
     "dhts_net_hybrid_workspace_bytes": (C.c_size_t, [C.POINTER(NetDesc), C.POINTER(HybridTables)]),
+    "dhts_net_hybrid_plan": (C.c_int, [C.POINTER(NetDesc), C.POINTER(HybridTables), C.POINTER(C.c_int32)]),
     "dhts_net_hybrid_rollout_fwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(HybridTables)] + [_P] * 10),
     "dhts_net_hybrid_rollout_eval": (C.c_int, [C.POINTER(NetDesc), C.POINTER(HybridTables)] + [_P] * 6),
     "dhts_net_hybrid_rollout_bwd": (C.c_int, [C.POINTER(NetDesc), C.POINTER(HybridTables)] + [_P] * 10),

@@ -800,6 +800,21 @@ def net_hybrid_state_rollout(r0, u0, dev_tables, dt, u_max, ghost0=None, plain=T
                                        bool(check_faults))
 
 
+def net_hybrid_plan(n_replicas, n_action, dev_tables, n_inter_sq=1, frames_per_phase=1, dt=1.0 / 30.0, u_max=30.0):
+    """What net_hybrid_rollout would launch for a batch of `n_replicas` under the current DHTS_OPT_HYB_PACK (dhts_net_hybrid_plan):
+    {"packed": two replicas per compute unit, "block", "stage_h", "lds_fwd", "lds_bwd", "loc_lanes", "max_step_records", "cus"}."""
+    t = dev_tables
+    d = _lib.NetDesc(int(n_replicas), t.n_lanes, t.n_cells, t.T, int(n_inter_sq), int(frames_per_phase), int(n_action), float(dt),
+                     float(u_max), 0.2, 5.0)
+    tc = t.c(0)
+    plan = (C.c_int32 * 8)()
+    check(_lib.lib().dhts_net_hybrid_plan(C.byref(d), C.byref(tc), plan), "dhts_net_hybrid_plan")
+    keys = ("packed", "block", "stage_h", "lds_fwd", "lds_bwd", "loc_lanes", "max_step_records", "cus")
+    out = dict(zip(keys, [int(x) for x in plan]))
+    out["packed"] = bool(out["packed"])
+    return out
+
+
 def net_hybrid_eval(action, dev_tables, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0, err=None):
     """An evaluation episode (hard thresholds, see net_macro_eval) of R replicas of a hybrid network: returns
     (reward [R], queue [R][T][L], counts [R][4] = vehicles spawned, vehicles deposited, 0, 0)."""

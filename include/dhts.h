@@ -103,6 +103,12 @@ int dhts_device_count(void);
 #define DHTS_OPT_NETSTEP_LDS_KB 6
 /* DHTS_OPT_NETSTEP_BLOCK: threads per workgroup of the persistent kernels: 256, 512, 1024; 0 = heuristic.  Same results. */
 #define DHTS_OPT_NETSTEP_BLOCK 7
+/* DHTS_OPT_HYB_PACK: replicas per compute unit of the fused hybrid network kernels (dhts_net_hybrid_rollout_fwd / _bwd): 0 = one;
+ * 1 = two whenever the plan fits (half the LDS per workgroup: a smaller record staging area, temporaries for the network's own
+ * micro lanes only; the 128-register instantiation); 2 (default) = two when the batch has more replicas than the device has
+ * compute units.  Same results bit for bit; the value must not change between a forward sweep and its reverse (the reverse
+ * sweep raises DHTS_FAULT_CAPACITY with index -3 otherwise).  dhts_net_hybrid_plan tells what a launch would take. */
+#define DHTS_OPT_HYB_PACK 8
 int dhts_set_option(int option, int value);
 /* cells / vehicle slots rounded up to the tape's padded width (multiple of 64) */
 int dhts_padded(int n);
@@ -434,6 +440,12 @@ typedef struct dhts_hybrid_tables {
     int32_t lane_capacity;
 } dhts_hybrid_tables;
 size_t dhts_net_hybrid_workspace_bytes(const dhts_net_desc *d, const dhts_hybrid_tables *t);
+/* What dhts_net_hybrid_rollout_fwd / _bwd would launch for (d, t) under the current DHTS_OPT_HYB_PACK (no device work): plan[0] = 1
+ * when two replicas share a compute unit, [1] threads per workgroup, [2] records a micro lane can stage per step, [3] / [4]
+ * bytes of LDS of the forward / reverse kernel, [5] lanes with a range of temporaries, [6] records a step may hold, [7] compute
+ * units of the current device.  (No reference counterpart: the reference steps one environment in one Python thread,
+ * example/control/trainer.py:168-204.) */
+int dhts_net_hybrid_plan(const dhts_net_desc *d, const dhts_hybrid_tables *t, int32_t plan[8]);
 /* bytes of the hybrid kernels' Jacobian tape: float32 [R][T][NIp][2][4], NIp = n_cells + n_lanes rounded up to 64: per interface
  * slot (a lane's n + 1 interfaces, lanes in id order, micro lanes own none) the two 2x2 products A = flux'(Q_0) dQ_0/dQ_L and
  * B = flux'(Q_0) dQ_0/dQ_R of dMacroLane._backward (dmacro_lane.py:116-124); the reverse sweep forms the cell blocks

@@ -55,6 +55,9 @@ def test_options_accept_documented_values_only():
         assert lib.dhts_set_option(_lib.OPT_NETSTEP_BLOCK, v) == 0
     assert lib.dhts_set_option(_lib.OPT_NETSTEP_BLOCK, 128) == _lib.E_INVALID
     assert lib.dhts_set_option(_lib.OPT_MACRO_FWD_ROTATE, 2) == _lib.E_INVALID and lib.dhts_set_option(_lib.OPT_MACRO_FWD_ROTATE, 1) == 0
+    for v in (0, 1, 2):
+        assert lib.dhts_set_option(_lib.OPT_HYB_PACK, v) == 0
+    assert lib.dhts_set_option(_lib.OPT_HYB_PACK, 3) == _lib.E_INVALID
     assert lib.dhts_set_option(99, 0) == _lib.E_INVALID
     assert lib.dhts_set_option(_lib.OPT_MACRO_FWD_WAVES, 0) == 0       # back to the heuristics
 

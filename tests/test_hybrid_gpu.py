@@ -73,6 +73,47 @@ def test_lane_capacity_is_a_launch_size_not_a_result(cuda, golden_dir, cap):
         ops.DeviceHybridTables(t, g["spawn_routes"], cuda, lane_capacity=48)
 
 
+@pytest.mark.parametrize("name", ["hybrid_p2", "hybrid", "hybrid_s2"])
+def test_two_replicas_per_compute_unit_is_a_launch_shape_not_a_result(cuda, golden_dir, name):
+    """DHTS_OPT_HYB_PACK: the packed launch (half the LDS per workgroup, 128 registers, temporaries for the network's own micro
+    lanes) gives the reference episodes' numbers bit for bit, the plan says what it took, and a reverse sweep that does not
+    share the forward's plan is a loud fault."""
+    import torch
+    from dhts import _lib, ops
+    lib = _lib.lib()
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    try:
+        assert lib.dhts_set_option(_lib.OPT_HYB_PACK, 0) == 0
+        ref = _run(cuda, g, replicas=3)
+        t, m = itscp_hybrid_tables(g)
+        dt_ = ops.DeviceHybridTables(t, g["spawn_routes"], cuda)
+        p0 = ops.net_hybrid_plan(3, len(g["action"]), dt_, m["num_intersection"] ** 2)
+        assert not p0["packed"] and p0["loc_lanes"] == 64 and p0["max_step_records"] == 1024 and p0["block"] == 512
+        assert lib.dhts_set_option(_lib.OPT_HYB_PACK, 1) == 0
+        p1 = ops.net_hybrid_plan(3, len(g["action"]), dt_, m["num_intersection"] ** 2)
+        assert p1["packed"] and p1["lds_fwd"] <= 79 * 1024 and p1["lds_bwd"] <= 79 * 1024 and p1["stage_h"] >= 16
+        assert p1["loc_lanes"] == 16 and p1["max_step_records"] == 16 * p1["stage_h"]
+        o = _run(cuda, g, replicas=3)
+        for k in ("counts", "queue", "reward", "grad", "cut"):
+            assert np.array_equal(o[k], ref[k]), k
+        # auto (the default): packed only when the batch has more replicas than the device has compute units
+        assert lib.dhts_set_option(_lib.OPT_HYB_PACK, 2) == 0
+        cus = p1["cus"]
+        assert not ops.net_hybrid_plan(cus, 45, dt_, 9)["packed"] and ops.net_hybrid_plan(cus + 1, 45, dt_, 9)["packed"]
+        # a caller that climbs the capacity ladder gets the full staging area back
+        assert not ops.net_hybrid_plan(cus + 1, 45, ops.DeviceHybridTables(t, g["spawn_routes"], cuda, lane_capacity=32), 9)["packed"]
+        # forward packed, reverse not: refused (CAPACITY, index -3), never a silent wrong gradient
+        assert lib.dhts_set_option(_lib.OPT_HYB_PACK, 1) == 0
+        a = torch.tensor(g["action"][None, :], device=cuda, requires_grad=True)
+        cut, *_ = ops.net_hybrid_rollout(a, dt_, m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"],
+                                         1.0 / m["simulation_frequency"], m["speed_limit"], m["static_speed"], m["vehicle_length"])
+        assert lib.dhts_set_option(_lib.OPT_HYB_PACK, 0) == 0
+        with pytest.raises(ops.CapacityError):
+            cut.sum().backward()
+    finally:
+        lib.dhts_set_option(_lib.OPT_HYB_PACK, 2)
+
+
 def test_hybrid_600_steps_matches_reference(cuda, golden_dir):
     """13 spawns, lane changes, 12 deposits, the loss' running-mean window sliding (153 600 + samples > 100 000)."""
     g = np.load(os.path.join(golden_dir, "itscp_hybrid.npz"))
