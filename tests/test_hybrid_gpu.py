@@ -114,21 +114,31 @@ def test_two_replicas_per_compute_unit_is_a_launch_shape_not_a_result(cuda, gold
         lib.dhts_set_option(_lib.OPT_HYB_PACK, 2)
 
 
-def test_hybrid_600_steps_matches_reference(cuda, golden_dir):
-    """13 spawns, lane changes, 12 deposits, the loss' running-mean window sliding (153 600 + samples > 100 000)."""
+def test_hybrid_600_steps_matches_reference(cuda, golden_dir, oracle):
+    """13 spawns, lane changes, 12 deposits, the loss' running-mean window sliding (153 600 + samples > 100 000): queues, reward,
+    counts, the WHOLE d reward / d action (achieved 3.5e-6) and the gradient of the reward restricted to its first t0 <= 540
+    steps, all within the contract's 1e-4 of the reference's run.  At t0 = 570 the reference's own number is not defined
+    to better than a lattice of 1.25e-3 max|g| (tests/test_oracle_golden.py::test_restricted_gradient_lattice_of_the_standing_vehicle
+    shows why): there the kernels are held to the oracle instead."""
     g = np.load(os.path.join(golden_dir, "itscp_hybrid.npz"))
-    o = _run(cuda, g, want_grad=False)
+    o = _run(cuda, g)
     m = o["m"]
     assert o["counts"][0, 0] == m["n_vehicle_spawned"] and o["counts"][0, 1] == 12
     assert state_report("queues vs reference", o["queue"][0].T, g["queue"]) <= TOL_STATE
     assert abs(float(o["reward"][0]) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
     scale = np.abs(g["g_action"]).max()
-    # gradient of the reward restricted to its first t0 steps (see tests/test_itscp_gpu.py for the last 60 steps of lane 16)
-    # (achieved by oracle and kernels alike: 2.4e-6 for t0 <= 510, 1.2e-4 at t0 = 540 where the knife edge begins)
+    assert grad_report("itscp_hybrid full-horizon d reward / d action vs reference", o["grad"][0], g["g_action"]) <= TOL_GRAD
+    t, _ = itscp_hybrid_tables(g)
+    from dhts.network import group_routes
+    routes, route_ptr = group_routes(g["spawn_routes"], t.n_lanes)
     for t0, ref in zip(g["g_action_cut_steps"], g["g_action_cut"]):
+        oc = _run(cuda, g, loss_steps=int(t0))
         if t0 <= 540:
-            oc = _run(cuda, g, loss_steps=int(t0))
-            assert np.abs(oc["grad"][0] - ref).max() <= (TOL_GRAD if t0 <= 510 else 2 * TOL_GRAD) * scale, int(t0)
+            assert np.abs(oc["grad"][0] - ref).max() <= TOL_GRAD * scale, int(t0)
+        else:
+            orc = oracle.net_hybrid(t, routes, route_ptr, g["action"], m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"],
+                                    1.0 / m["simulation_frequency"], m["speed_limit"], m["static_speed"], m["vehicle_length"], t_cut=int(t0))
+            assert np.abs(oc["grad"][0] - orc["g_action"]).max() <= 1e-6 * scale, int(t0)
 
 
 @pytest.mark.parametrize("name", ["hybrid_half", "hybrid_s2", "hybrid_s3", "hybrid_p2_600"])
@@ -168,7 +178,7 @@ def test_hybrid_kernels_vs_oracle_other_action(cuda, golden_dir, oracle):
     o = _run(cuda, g, action=action)
     assert o["counts"][0, 0] == ref["n_spawned"]
     assert state_report("queues vs oracle", o["queue"][0], ref["queue"]) <= TOL_STATE
-    assert np.abs(o["grad"][0] - ref["g_action"]).max() <= 5 * TOL_GRAD * np.abs(ref["g_action"]).max()
+    assert np.abs(o["grad"][0] - ref["g_action"]).max() <= TOL_GRAD * np.abs(ref["g_action"]).max()
 
 
 def test_config4_batch_properties(cuda, golden_dir):

@@ -89,13 +89,11 @@ def test_itscp_rollout_matches_reference(cuda, golden_dir, name):
         assert e <= MIRROR_TOL[name]
         return
     # ---- the 600-step hybrid case -------------------------------------------------------------------------------
-    # From step 480 lane 16 (one cell) holds a deposited standing vehicle behind a red light: u = y / r + u_eq cancels
-    # to 0 within float32 rounding (|u| <= 4e-6) while the ghost's speed creeps through the solver's EPSILON = 1e-5,
-    # so for steps 566-569 the test |u_L - u_R| < EPSILON (model/macro/_arz.py, equal-speed branch) is decided by
-    # the last bits of u.  The two branches give the same state but different Jacobians (centre block 1.0 vs 1.144),
-    # and the reverse sweep amplifies by 1.144 per step over the ~90 standing steps before it: the reference's own
-    # d reward / d action for that lane's last-quarter loss is therefore only reproducible by bit-identical float32
-    # glue (torch CPU vs GPU already differ).  Everything else is compared in full:
+    # From step 480 lane 16 (one cell) holds a deposited standing vehicle behind a red light; the reverse sweep amplifies the
+    # cotangent of that lane's late loss terms by 1.144 per step over the ~90 standing steps before them, so the gradient of a
+    # PART of that loss is only defined up to a float32 lattice (tests/test_oracle_golden.py::
+    # test_restricted_gradient_lattice_of_the_standing_vehicle); the parts below are the ones the reference's fixture holds
+    # up to step 540, and they -- like the whole gradient -- are reproduced within the contract's 1e-4:
     def grad_of(part):
         if not (isinstance(part, torch.Tensor) and part.requires_grad):
             return np.zeros(len(g["action"]), np.float32)
@@ -113,19 +111,25 @@ def test_itscp_rollout_matches_reference(cuda, golden_dir, name):
     for t0, ref in zip(g["g_action_cut_steps"], g["g_action_cut"]):
         if t0 <= 540:
             mine = grad_of(neg_sum(x for k in keys for x in env.queue_length[k][:int(t0)]))
-            assert np.abs(mine - ref).max() <= 5 * TOL_GRAD * scale, int(t0)
+            print("mirror hybrid: cut %d error / max|g| = %.2e" % (t0, np.abs(mine - ref).max() / scale))
+            assert np.abs(mine - ref).max() <= TOL_GRAD * scale, int(t0)
     # (2) the last-quarter loss of every other lane that receives deposits
     late = {int(i): ref for i, ref in zip(g["g_lane_late_ids"], g["g_lane_late"])}
     for i, ref in late.items():
         if i != 16:
             mine = grad_of(neg_sum(env.queue_length[keys[i]][(3 * T) // 4:]))
-            assert np.abs(mine - ref).max() <= 5 * TOL_GRAD * max(np.abs(ref).max(), 1e-3 * scale), i
+            print("mirror hybrid: late lane %d error = %.2e (of %.2e)" % (i, np.abs(mine - ref).max(), max(np.abs(ref).max(), 1e-3 * scale)))
+            assert np.abs(mine - ref).max() <= TOL_GRAD * max(np.abs(ref).max(), 1e-3 * scale), i
     # (3) the full-horizon gradient without lane 16's last-quarter loss
     total = grad_of(neg_sum(x for k in keys for x in env.queue_length[k]))
     l16 = grad_of(neg_sum(env.queue_length[keys[16]][(3 * T) // 4:]))
-    assert np.abs((total - l16) - (g["g_action"] - late[16])).max() <= 5 * TOL_GRAD * scale
-    # (4) and the ill-conditioned remainder stays within the spread of the two branches
-    assert np.abs(l16 - late[16]).max() <= 0.25 * np.abs(late[16]).max()
+    print("mirror hybrid: full %.2e  full - lane16 late %.2e  lane16 late %.2e (rel to its own max %.2e)" % (
+        np.abs(total - g["g_action"]).max() / scale, np.abs((total - l16) - (g["g_action"] - late[16])).max() / scale,
+        np.abs(l16 - late[16]).max() / scale, np.abs(l16 - late[16]).max() / np.abs(late[16]).max()))
+    assert np.abs((total - l16) - (g["g_action"] - late[16])).max() <= TOL_GRAD * scale
+    # (4) lane 16's own last-quarter loss (achieved 3.5e-7 of its maximum) and the whole gradient (3.4e-6)
+    assert np.abs(l16 - late[16]).max() <= TOL_GRAD * np.abs(late[16]).max()
+    assert np.abs(total - g["g_action"]).max() <= TOL_GRAD * scale
 
 
 @pytest.mark.parametrize("name", ["micro_small", "micro"])

@@ -226,26 +226,64 @@ def test_itscp_hybrid_network(oracle, golden_dir, name):
                                          m["speed_limit"], m["static_speed"], m["vehicle_length"], **kw)
     o = run()
     assert o["rc"] == 0 and o["n_spawned"] == m["n_vehicle_spawned"]
-    assert rel_max(o["queue"].T, g["queue"]) <= 1e-4
+    assert rel_max(o["queue"].T, g["queue"]) <= TOL_STATE
     assert abs(o["reward"] - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
     scale = np.abs(g["g_action"]).max()
-    if name != "hybrid":             # every golden but one: the full gradient
-        assert np.abs(o["g_action"] - g["g_action"]).max() <= TOL_GRAD * scale
-        if name in FULL_HORIZON_600:
-            assert m["T"] == 600 and len(g["action"]) == 45
-            assert np.abs(o["g_action"] - g["g_action"]).max() <= 1e-5 * scale          # achieved 2e-6
-            for t0, ref in zip(g["g_action_cut_steps"], g["g_action_cut"]):
-                oc = run(t_cut=int(t0))
-                assert np.abs(oc["g_action"] - ref).max() <= 1e-5 * scale, int(t0)
-        return
-    # the first 600-step golden sits on a float32 knife edge of the reference's own gradient from step ~540 on (lane 16,
-    # DESIGN.md section 8): the gradient of the reward restricted to its first t0 steps is pinned up to there
-    # (achieved: 2.4e-6 for t0 <= 510, 1.2e-4 at t0 = 540)
-    assert o["n_deposits"] == 12
-    for t0, ref in zip(g["g_action_cut_steps"], g["g_action_cut"]):
-        if t0 <= 540:
+    assert np.abs(o["g_action"] - g["g_action"]).max() <= TOL_GRAD * scale
+    if name in FULL_HORIZON_600 or name == "hybrid":
+        assert m["T"] == 600 and len(g["action"]) == 45
+        assert np.abs(o["g_action"] - g["g_action"]).max() <= 1e-5 * scale          # achieved 2e-6 (hybrid: 3.5e-6)
+    if name in FULL_HORIZON_600:
+        for t0, ref in zip(g["g_action_cut_steps"], g["g_action_cut"]):
             oc = run(t_cut=int(t0))
-            assert np.abs(oc["g_action"] - ref).max() <= (1e-5 if t0 <= 510 else 2 * TOL_GRAD) * scale, int(t0)
+            assert np.abs(oc["g_action"] - ref).max() <= 1e-5 * scale, int(t0)
+    if name == "hybrid":
+        # the first 600-step golden: from step 480 lane 16 holds a standing vehicle whose late loss terms reach the action through
+        # ~90 steps of 1.144-fold amplification; the gradient of the reward RESTRICTED to its first t0 steps is pinned up to 540
+        # (achieved: 3.3e-6 for t0 <= 510, 7.8e-5 at t0 = 540; t0 = 570: test_restricted_gradient_lattice_of_the_standing_vehicle)
+        assert o["n_deposits"] == 12
+        for t0, ref in zip(g["g_action_cut_steps"], g["g_action_cut"]):
+            if t0 <= 540:
+                oc = run(t_cut=int(t0))
+                assert np.abs(oc["g_action"] - ref).max() <= (1e-5 if t0 <= 510 else TOL_GRAD) * scale, int(t0)
+
+
+def test_restricted_gradient_lattice_of_the_standing_vehicle(oracle, golden_dir):
+    """Why `itscp_hybrid.npz`'s g_action_cut at t0 = 570 is the one reference number no test holds to 1e-4 (it differs by 7.5e-3
+    max|g| from oracle and kernels, which agree with each other to 1.2e-7 there, tests/test_hybrid_gpu.py).  Lane 16's loss
+    terms of steps >= 540 reach the action through the standing vehicle's ~90 steps of 1.144-fold amplification: a float32 ulp of
+    the cotangent where the terms join becomes a LATTICE of 2.2e-2 = 1.25e-3 max|g| in the action gradient.  Shown here on the
+    restatement alone: (1) the whole gradient matches the reference (3.5e-6: all terms join before the amplification);
+    (2) the increments of the restricted gradient from one t0 to the next are whole multiples of one quantum q >= 1e-3 max|g|;
+    (3) the reference's own t0 = 570 number sits on the same lattice, a whole number of quanta (six) away -- which terms are
+    summed first in float32 (autograd's engine order in the reference, the reverse sweep's order here) decides the lattice
+    point, and no restatement short of torch's engine reproduces that choice."""
+    g = load(golden_dir, "itscp_hybrid.npz")
+    t, m = itscp_hybrid_tables(g)
+    from dhts.network import group_routes
+    routes, route_ptr = group_routes(g["spawn_routes"], t.n_lanes)
+    run = lambda **kw: oracle.net_hybrid(t, routes, route_ptr, g["action"], m["num_intersection"] ** 2,     # noqa: E731
+                                         m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"],
+                                         m["speed_limit"], m["static_speed"], m["vehicle_length"], **kw)
+    scale = np.abs(g["g_action"]).max()
+    assert np.abs(run()["g_action"] - g["g_action"]).max() <= 1e-5 * scale                      # (1)
+    ref570 = g["g_action_cut"][list(g["g_action_cut_steps"]).index(570)]
+    cuts = {tc: run(t_cut=tc)["g_action"] for tc in range(562, 579)}
+    d570 = cuts[570] - ref570
+    k = int(np.argmax(np.abs(d570)))
+    assert 1e-3 * scale < abs(d570[k]) < 1e-2 * scale                                            # the mismatch no test holds to 1e-4
+    inc = np.array([cuts[tc + 1][k] - cuts[tc][k] for tc in range(562, 578)], dtype=np.float64)
+    q = None
+    for n in range(1, 33):                                                                       # the lattice constant: the coarsest q = min|inc| / n
+        cand = np.abs(inc).min() / n
+        if np.abs(inc / cand - np.round(inc / cand)).max() <= 0.02:
+            q = cand
+            break
+    assert q is not None and q >= 1e-3 * scale, (q, inc)                                         # (2) quantum 2.2e-2 = 1.25e-3 max|g|
+    n_q = d570[k] / q
+    assert abs(n_q - round(n_q)) <= 0.05 and 1 <= abs(round(n_q)) <= 8, n_q                      # (3) six quanta
+    # every other component of the mismatch is a few quanta of its own (smaller) lattice: nothing above the largest one
+    assert np.abs(d570).max() <= 8 * q
 
 
 @pytest.mark.parametrize("name", ["eval_hybrid_short", "eval_hybrid_p2", "eval_hybrid", "eval_hybrid_4x4", "eval_hybrid_n2l30", "eval_hybrid_5x5"])
