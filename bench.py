@@ -438,10 +438,12 @@ class ItscpMacroWorkload:
         o = getattr(self, "oracle_sample", None)
         if o is None:
             return None
-        rew = float(self.reward[0])
-        return {"state_rel": abs(rew - o["reward"]) / max(abs(o["reward"]), 1e-30), "grad_rel": _rel(-g_a[0].cpu().numpy(), o["g_action"]),
+        rew, rew_chain = float(self.reward[0]), reward_in_reference_order(self)
+        return {"state_rel": abs(rew_chain - o["reward"]) / max(abs(o["reward"]), 1e-30), "grad_rel": _rel(-g_a[0].cpu().numpy(), o["g_action"]),
+                "state_rel_kernel_order": abs(rew - o["reward"]) / max(abs(o["reward"]), 1e-30),
                 "lanes": 1, "against": "oracle (C port, pinned by tests/golden) on replica 0's schedule and action, all %d steps" % self.T,
-                "what": "reward | d reward / d action of replica 0 in the last timed pass", "tol_state": TOL_STATE, "tol_grad": TOL_GRAD}
+                "what": "reward (summed in the reference's order, DHTS_OPT_REWARD_CHAIN, on one more untimed pass; state_rel_kernel_order: as the "
+                        "timed passes sum it) | d reward / d action of replica 0 in the last timed pass", "tol_state": TOL_STATE, "tol_grad": TOL_GRAD}
 
     def cpu_baseline(self, seconds=10.0):
         """The C oracle of the macro network (scalar, one core): whole episodes of replica 0, repeated for >= 10 s."""
@@ -575,11 +577,13 @@ class ItscpHybridWorkload:
         o = getattr(self, "oracle_sample", None)
         if o is None:
             return None
-        rew = float(self.reward[0])
-        return {"state_rel": abs(rew - o["reward"]) / max(abs(o["reward"]), 1e-30), "grad_rel": _rel(-g_a[0].cpu().numpy(), o["g_action"]),
+        rew, rew_chain = float(self.reward[0]), reward_in_reference_order(self)
+        return {"state_rel": abs(rew_chain - o["reward"]) / max(abs(o["reward"]), 1e-30), "grad_rel": _rel(-g_a[0].cpu().numpy(), o["g_action"]),
+                "state_rel_kernel_order": abs(rew - o["reward"]) / max(abs(o["reward"]), 1e-30),
                 "lanes": 1, "vehicles_spawned": [int(self.counts[0, 0]), o["n_spawned"]],
                 "against": "oracle (C port, pinned by tests/golden) on replica 0's schedule and action, all %d steps" % self.T,
-                "what": "reward | d reward / d action [%d] of replica 0 in the last timed pass; vehicles spawned (kernel, oracle)" % g_a.shape[1],
+                "what": "reward (summed in the reference's order, DHTS_OPT_REWARD_CHAIN, on one more untimed pass; state_rel_kernel_order: as the "
+                        "timed passes sum it) | d reward / d action [%d] of replica 0 in the last timed pass; vehicles spawned (kernel, oracle)" % g_a.shape[1],
                 "tol_state": TOL_STATE, "tol_grad": TOL_GRAD}
 
     def cpu_baseline(self, seconds=10.0):
@@ -674,6 +678,18 @@ class ItscpStepwiseWorkload(ItscpHybridWorkload):
             self.ev.append(e)
         g = self.drop_nonfinite(self.action.grad)
         return loss.detach(), g, g
+
+
+def reward_in_reference_order(w):
+    """Replica 0's reward of one more (untimed) pass with DHTS_OPT_REWARD_CHAIN on: ItscpEnv._reward's one float32 chain over lanes
+    (outermost) and steps (example/control/itscp/_env.py:770-797) instead of the rollout kernels' own order."""
+    from dhts import _lib as _L
+    assert _L.lib().dhts_set_option(_L.OPT_REWARD_CHAIN, 1) == 0
+    try:
+        w.one_pass()
+        return float(w.reward[0])
+    finally:
+        _L.lib().dhts_set_option(_L.OPT_REWARD_CHAIN, 0)
 
 
 TOL_STATE, TOL_GRAD = 1e-5, 1e-4     # BASELINE.json north_star: state <= 1e-5 relative, gradients <= 1e-4 (norm-relative)

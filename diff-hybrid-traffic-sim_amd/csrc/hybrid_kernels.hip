@@ -1343,6 +1343,11 @@ extern "C" int dhts_debug_stamps(long long *out) {       // [2 kernels][8 replic
 }
 #endif
 
+// dhts_common.hip: the reward as the reference's one float32 chain, lanes outermost (DHTS_OPT_REWARD_CHAIN)
+extern int dhts_opt_reward_chain;
+int dhts_launch_reward_chain(int R, int T, int L, const float *queue, const int32_t *lane_macro, int hard, double dt, int loss_steps,
+                             float *reward, int stride, void *stream);
+
 extern "C" {
 
 size_t dhts_net_hybrid_tape_bytes(const dhts_net_desc *d) {
@@ -1387,7 +1392,10 @@ static int hyb_fwd_launch(const dhts_net_desc *d, const dhts_hybrid_tables *t, c
         d->n_replicas, d->n_lanes, d->n_cells, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max,
         d->static_speed, d->vehicle_length, ht, action, hist, reinterpret_cast<float4 *>(tape), kc, queue, reward,
         counts, reinterpret_cast<char *>(workspace), t->records_per_step, err);
-    return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
+    if (hipGetLastError() != hipSuccess) return DHTS_E_LAUNCH;
+    // (the state form's reward is a by-product nobody reads: plain networks have no loss)
+    if (dhts_opt_reward_chain && !io) return dhts_launch_reward_chain(d->n_replicas, d->n_steps, d->n_lanes, queue, t->lane_macro, 0, d->dt, 0, reward, 1, stream);
+    return DHTS_OK;
 }
 int dhts_net_hybrid_rollout_fwd(const dhts_net_desc *d, const dhts_hybrid_tables *t, const float *action, float *hist,
                                 float *tape, float *kc, float *queue, float *reward, int32_t *counts, void *workspace,
@@ -1420,7 +1428,9 @@ int dhts_net_hybrid_rollout_eval(const dhts_net_desc *d, const dhts_hybrid_table
         d->n_replicas, d->n_lanes, d->n_cells, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max,
         d->static_speed, d->vehicle_length, hyb_tables(t), action, nullptr, nullptr, nullptr, queue, reward, counts, nullptr,
         t->records_per_step, err);
-    return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
+    if (hipGetLastError() != hipSuccess) return DHTS_E_LAUNCH;
+    if (dhts_opt_reward_chain) return dhts_launch_reward_chain(d->n_replicas, d->n_steps, d->n_lanes, queue, t->lane_macro, 1, d->dt, 0, reward, 1, stream);
+    return DHTS_OK;
 }
 
 static int hyb_bwd_launch(const dhts_net_desc *d, const dhts_hybrid_tables *t, int plain, const float *action, const float *hist,

@@ -1647,6 +1647,7 @@ extern "C" int dhts_debug_fwd3_stamps(long long *out) {       // [16 workgroups]
 
 extern int dhts_netstep_lds_kb, dhts_netstep_block;      // netstep_hybrid.hip
 extern int dhts_hyb_pack;                                // hybrid_kernels.hip
+extern int dhts_opt_reward_chain;                        // dhts_common.hip
 
 extern "C" {
 
@@ -1669,6 +1670,10 @@ int dhts_set_option(int option, int value) {
     }
     if (option == DHTS_OPT_NETSTEP_LDS_KB && (value == 0 || (value >= 1 && value <= 158))) {
         dhts_netstep_lds_kb = value;
+        return DHTS_OK;
+    }
+    if (option == DHTS_OPT_REWARD_CHAIN && (value == 0 || value == 1)) {
+        dhts_opt_reward_chain = value;
         return DHTS_OK;
     }
     if (option == DHTS_OPT_HYB_PACK && value >= 0 && value <= 2) {

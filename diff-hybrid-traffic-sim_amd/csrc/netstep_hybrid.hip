@@ -1879,6 +1879,11 @@ static int ns_launch_persist_bwd(const NsArgs &a, const float *action, const flo
     return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
 }
 
+// dhts_common.hip: the reward as the reference's one float32 chain, lanes outermost (DHTS_OPT_REWARD_CHAIN)
+extern int dhts_opt_reward_chain;
+int dhts_launch_reward_chain(int R, int T, int L, const float *queue, const int32_t *lane_macro, int hard, double dt, int loss_steps,
+                             float *reward, int stride, void *stream);
+
 extern "C" {
 
 size_t dhts_netstep_workspace_bytes(const dhts_net_desc *d, const dhts_netstep_tables *t) {
@@ -1901,9 +1906,13 @@ int dhts_netstep_rollout_fwd(const dhts_net_desc *d, const dhts_netstep_tables *
         const NsPlan pl = ns_plan(a, ns_al16(lds), false);
         lds = (size_t)pl.scratch + pl.tables + pl.st + pl.gl + pl.rows + pl.misc + pl.ms + pl.routes;
         if (lds > 160 * 1024) return DHTS_E_INVALID;
-        if (pl.tables && pl.ms) return pl.st ? ns_launch_persist_fwd<3, 2, true>(a, action, pl, lds, d->n_replicas, st) : ns_launch_persist_fwd<3, 0, true>(a, action, pl, lds, d->n_replicas, st);
-        if (pl.tables) return pl.st ? ns_launch_persist_fwd<3, 2, false>(a, action, pl, lds, d->n_replicas, st) : ns_launch_persist_fwd<3, 0, false>(a, action, pl, lds, d->n_replicas, st);
-        return pl.st ? ns_launch_persist_fwd<1, 2, false>(a, action, pl, lds, d->n_replicas, st) : ns_launch_persist_fwd<1, 0, false>(a, action, pl, lds, d->n_replicas, st);
+        int rc;
+        if (pl.tables && pl.ms) rc = pl.st ? ns_launch_persist_fwd<3, 2, true>(a, action, pl, lds, d->n_replicas, st) : ns_launch_persist_fwd<3, 0, true>(a, action, pl, lds, d->n_replicas, st);
+        else if (pl.tables) rc = pl.st ? ns_launch_persist_fwd<3, 2, false>(a, action, pl, lds, d->n_replicas, st) : ns_launch_persist_fwd<3, 0, false>(a, action, pl, lds, d->n_replicas, st);
+        else rc = pl.st ? ns_launch_persist_fwd<1, 2, false>(a, action, pl, lds, d->n_replicas, st) : ns_launch_persist_fwd<1, 0, false>(a, action, pl, lds, d->n_replicas, st);
+        if (rc == DHTS_OK && dhts_opt_reward_chain)
+            rc = dhts_launch_reward_chain(d->n_replicas, T, L, queue, t->hyb.lane_macro, hard, d->dt, a.loss_steps, reward, 2, stream);
+        return rc;
     }
     // running state of the episode
     if (hipMemsetAsync(ws + a.lo.P, 0, a.lo.counters + sizeof(NsCounters) - a.lo.P, st) != hipSuccess) return DHTS_E_LAUNCH;
@@ -1934,7 +1943,9 @@ int dhts_netstep_rollout_fwd(const dhts_net_desc *d, const dhts_netstep_tables *
         ns_convert_fwd_kernel<<<1, kNsBlock, lds_c, st>>>(a, step);
     }
     ns_reward_kernel<<<1, kNsBlock, sizeof(float) * 2 * (size_t)L, st>>>(a);
-    return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
+    if (hipGetLastError() != hipSuccess) return DHTS_E_LAUNCH;
+    if (dhts_opt_reward_chain) return dhts_launch_reward_chain(1, T, L, queue, t->hyb.lane_macro, hard, d->dt, a.loss_steps, reward, 2, stream);
+    return DHTS_OK;
 }
 
 int dhts_netstep_rollout_bwd(const dhts_net_desc *d, const dhts_netstep_tables *t, const float *action, const float *hist,

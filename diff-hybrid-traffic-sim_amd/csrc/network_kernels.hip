@@ -590,6 +590,11 @@ static inline bool net_tables_ok(const dhts_net_tables *t) {
            t->n_edges >= 0;
 }
 
+// dhts_common.hip: the reward as the reference's one float32 chain, lanes outermost (DHTS_OPT_REWARD_CHAIN)
+extern int dhts_opt_reward_chain;
+int dhts_launch_reward_chain(int R, int T, int L, const float *queue, const int32_t *lane_macro, int hard, double dt, int loss_steps,
+                             float *reward, int stride, void *stream);
+
 extern "C" {
 
 size_t dhts_net_macro_hist_bytes(const dhts_net_desc *d) {
@@ -623,7 +628,9 @@ int dhts_net_macro_rollout_fwd(const dhts_net_desc *d, const dhts_net_tables *t,
     }
 #undef DHTS_NET_FWD_LAUNCH
 #undef DHTS_NET_FWD_ARGS
-    return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
+    if (hipGetLastError() != hipSuccess) return DHTS_E_LAUNCH;
+    if (dhts_opt_reward_chain) return dhts_launch_reward_chain(d->n_replicas, d->n_steps, L, queue, nullptr, 0, d->dt, 0, reward, 1, stream);
+    return DHTS_OK;
 }
 
 int dhts_net_macro_rollout_eval(const dhts_net_desc *d, const dhts_net_tables *t, const float *action, float *queue, float *reward,
@@ -638,7 +645,9 @@ int dhts_net_macro_rollout_eval(const dhts_net_desc *d, const dhts_net_tables *t
     net_macro_fwd_kernel<true, false, 1024><<<d->n_replicas, B, lds, (hipStream_t)stream>>>(
         d->n_replicas, L, C, d->n_steps, d->n_inter_sq, d->frames_per_phase, d->n_action, d->dt, d->u_max, d->static_speed,
         d->vehicle_length, net_tables(t), action, nullptr, nullptr, nullptr, queue, reward, nullptr, err);
-    return hipGetLastError() == hipSuccess ? DHTS_OK : DHTS_E_LAUNCH;
+    if (hipGetLastError() != hipSuccess) return DHTS_E_LAUNCH;
+    if (dhts_opt_reward_chain) return dhts_launch_reward_chain(d->n_replicas, d->n_steps, L, queue, nullptr, 1, d->dt, 0, reward, 1, stream);
+    return DHTS_OK;
 }
 
 int dhts_net_macro_rollout_bwd(const dhts_net_desc *d, const dhts_net_tables *t, const float *action, const float *hist,

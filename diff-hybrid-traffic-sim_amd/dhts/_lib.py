@@ -22,6 +22,7 @@ OPT_MACRO_FWD_ROTATE = 5
 OPT_NETSTEP_LDS_KB = 6
 OPT_NETSTEP_BLOCK = 7
 OPT_HYB_PACK = 8
+OPT_REWARD_CHAIN = 9
 MACRO_MAX_CELLS = 4000
 MICRO_MAX_VEHICLES = 1024
 

@@ -109,6 +109,13 @@ int dhts_device_count(void);
  * compute units.  Same results bit for bit; the value must not change between a forward sweep and its reverse (the reverse
  * sweep raises DHTS_FAULT_CAPACITY with index -3 otherwise).  dhts_net_hybrid_plan tells what a launch would take. */
 #define DHTS_OPT_HYB_PACK 8
+/* DHTS_OPT_REWARD_CHAIN: 1 = every network rollout (dhts_net_macro_rollout_fwd / _eval, dhts_net_hybrid_rollout_fwd / _eval,
+ * dhts_netstep_rollout_fwd) finishes with the reward as ItscpEnv._reward forms it (example/control/itscp/_env.py:770-797): ONE
+ * running float32 sum over lanes (outermost) and steps -- L x T dependent additions, one wavefront per replica, ~0.4 ms at config 4
+ * -- instead of the kernels' own order (a lane's steps first, then the lanes' subtotals: the same real number, another
+ * float32 rounding, 6e-6 relative at config 4).  An evaluation episode follows the reference's mixed chain (a Python float
+ * until the first cell lane's tensor term joins it).  0 (default).  The queue terms and the gradient are the same either way. */
+#define DHTS_OPT_REWARD_CHAIN 9
 int dhts_set_option(int option, int value);
 /* cells / vehicle slots rounded up to the tape's padded width (multiple of 64) */
 int dhts_padded(int n);

@@ -58,6 +58,7 @@ def test_options_accept_documented_values_only():
     for v in (0, 1, 2):
         assert lib.dhts_set_option(_lib.OPT_HYB_PACK, v) == 0
     assert lib.dhts_set_option(_lib.OPT_HYB_PACK, 3) == _lib.E_INVALID
+    assert lib.dhts_set_option(_lib.OPT_REWARD_CHAIN, 2) == _lib.E_INVALID and lib.dhts_set_option(_lib.OPT_REWARD_CHAIN, 0) == 0
     assert lib.dhts_set_option(99, 0) == _lib.E_INVALID
     assert lib.dhts_set_option(_lib.OPT_MACRO_FWD_WAVES, 0) == 0       # back to the heuristics
 
