@@ -819,9 +819,9 @@ def library_code_sha16():
 
 
 def issue_counters(w, kernel):
-    """Instruction-issue side of `kernel` from the counter passes committed as profiles/issue_counters.json (tools/pmc_macro_fwd.sh:
-    rocprofv3 --pmc SQ_* passes over this configuration).  Not measured by this run; refused when the library's kernels are
-    not the ones the passes saw (fingerprint of the device code, not of the kernel names)."""
+    """Instruction-issue side of `kernel` from the counter passes committed as profiles/issue_counters.json (tools/pmc_workloads.sh:
+    rocprofv3 --pmc SQ_* passes over each workload at its BASELINE shape).  Not measured by this run; refused when the library's
+    kernels are not the ones the passes saw (fingerprint of the device code, not of the kernel names)."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "issue_counters.json")))
         side = rec[w.name][kernel]
@@ -830,9 +830,9 @@ def issue_counters(w, kernel):
     have = library_code_sha16()
     if have is None or rec.get("library_code_sha16") != have:
         print("bench.py: profiles/issue_counters.json was taken on another build of libdhts.so (device code %s, now %s): "
-              "issue_side not quoted; re-run tools/pmc_macro_fwd.sh" % (rec.get("library_code_sha16"), have), file=sys.stderr)
+              "issue_side not quoted; re-run tools/pmc_workloads.sh" % (rec.get("library_code_sha16"), have), file=sys.stderr)
         return None
-    return dict(side, source="%s (rocprofv3 --pmc passes of tools/pmc_macro_fwd.sh on this configuration), not measured by this run"
+    return dict(side, source="%s (rocprofv3 --pmc passes of tools/pmc_workloads.sh on this configuration), not measured by this run"
                 % rec.get("source", "profiles/issue_counters.json"))
 
 
@@ -877,6 +877,12 @@ def also_record(name, dev, passes=5, lanes=0):
     el = time.perf_counter() - t0
     check_faults(w, "the bench")
     kernels, dom = kernel_records(w)
+    for k in kernels:          # the counters behind each kernel's `limiter` (committed passes of this very shape, fingerprinted)
+        side, hbm = issue_counters(w, k), pmc_traffic(w, k)
+        if side is not None:
+            kernels[k]["issue_side"] = side
+        if hbm is not None:
+            kernels[k]["traffic_pmc_bytes"] = hbm
     out = {"workload": w.name, "value": w.units * passes / el, "unit": w.unit_name, "passes": passes,
            "ms_per_pass": el / passes * 1e3, "dominant_kernel": dom, "limiter": w.limiter.get(dom, "hbm"), "kernels": kernels}
     if getattr(w, "counts", None) is not None:

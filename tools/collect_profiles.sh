@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copies what one measurement round (tools/profile_round.sh + tools/pmc_macro_fwd.sh, prefix P) left under gpurun_out/ into
+# Copies what one measurement round (tools/profile_round.sh + tools/pmc_workloads.sh, prefix P) left under gpurun_out/ into
 # profiles/ (the tracked copies the docs and bench.py cite).  Usage: tools/collect_profiles.sh r04z
 set -eu
 P=$1
@@ -10,10 +10,9 @@ for WL in macro micro itscp_hybrid itscp_macro itscp_stepwise; do
   tail -n 1 $G/${P}_${WL}_bench.json > profiles/${P}_${WL}_bench.json
 done
 tail -n 1 $G/${P}_macro_bench_unprofiled.json > profiles/${P}_macro_bench_unprofiled.json
-cp $G/${P}_pmc_rollout_kernels.csv profiles/
-cp $G/${P}_pmc_traffic.json profiles/pmc_traffic.json
-cp $G/${P}_pmc_counters/summary.csv profiles/${P}_pmc_macro_counters.csv
+cp $G/${P}_pmc_counters/summary.csv profiles/${P}_pmc_workload_counters.csv
 cp $G/${P}_pmc_counters/issue_counters.json profiles/issue_counters.json
+cp $G/${P}_pmc_counters/pmc_traffic.json profiles/pmc_traffic.json
 [ -f $G/${P}_gputest.log ] && cp $G/${P}_gputest.log profiles/
 [ -f $G/${P}_slow_mirror_test.log ] && cp $G/${P}_slow_mirror_test.log profiles/
 ls -la profiles | grep "${P}_"

@@ -3,4 +3,4 @@ P=${1:-r04z}
 python -m pytest tests -m gpu -q -s > gpurun_out/${P}_gputest.log 2>&1; echo "gputest rc=$?"; tail -3 gpurun_out/${P}_gputest.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 bash tools/profile_round.sh $P 2>&1 | tail -40
-bash tools/pmc_macro_fwd.sh gpurun_out/${P}_pmc_counters 0 0 > gpurun_out/${P}_pmc_counters.log 2>&1; tail -25 gpurun_out/${P}_pmc_counters.log
+bash tools/pmc_workloads.sh gpurun_out/${P}_pmc_counters > gpurun_out/${P}_pmc_counters.log 2>&1; tail -25 gpurun_out/${P}_pmc_counters.log

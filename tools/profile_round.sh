@@ -1,7 +1,6 @@
 #!/bin/bash
 # One measurement round on the GPU box: rocprofv3 kernel stats + the bench line of the same run for the four workloads, an
-# un-profiled default bench run (with the CPU baseline leg), and the PMC traffic passes (FETCH_SIZE / WRITE_SIZE, separate
-# runs, --kernel-trace only) for the two straight-lane workloads.
+# un-profiled default bench run (with the CPU baseline leg).
 #   tools/profile_round.sh <prefix>        ->  gpurun_out/<prefix>_*   (copy what is to be kept into profiles/)
 set -u
 P=$1
@@ -17,11 +16,4 @@ for WL in macro micro itscp_hybrid itscp_macro itscp_stepwise; do
   tail -c 400 "$OUT/${P}_${WL}_bench.json"; echo
 done
 python3 "$REPO/bench.py" > "$OUT/${P}_macro_bench_unprofiled.json" 2> "$OUT/${P}_macro_bench_unprofiled.err"
-PM=$OUT/${P}_pmc
-for WL in macro micro; do
-  for C in FETCH_SIZE WRITE_SIZE; do
-    T=fetch; [ $C = WRITE_SIZE ] && T=write
-    rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$PM/${WL}_$T" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-also --workload $WL > "$PM.${WL}_$T.log" 2>&1
-  done
-done
-python3 "$REPO/tools/pmc_summary.py" "$PM" "$OUT/${P}_pmc_traffic.json" "$OUT/${P}_pmc_rollout_kernels.csv" | tail -30
+# (the PMC passes -- FETCH_SIZE / WRITE_SIZE and the SQ groups, every workload -- are tools/pmc_workloads.sh)
