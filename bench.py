@@ -878,11 +878,13 @@ def also_record(name, dev, passes=5, lanes=0):
     check_faults(w, "the bench")
     kernels, dom = kernel_records(w)
     for k in kernels:          # the counters behind each kernel's `limiter` (committed passes of this very shape, fingerprinted)
-        side, hbm = issue_counters(w, k), pmc_traffic(w, k)
+        side = issue_counters(w, k)
         if side is not None:
             kernels[k]["issue_side"] = side
-        if hbm is not None:
-            kernels[k]["traffic_pmc_bytes"] = hbm
+            if side.get("hbm_bytes_per_launch"):        # HBM bytes of the launch (FETCH_SIZE x 2 + WRITE_SIZE) over THIS run's event time
+                kernels[k]["traffic_pmc_bytes"] = side["hbm_bytes_per_launch"]
+                kernels[k]["traffic_GBps"] = side["hbm_bytes_per_launch"] / kernels[k]["ms"] / 1e6
+                kernels[k]["traffic_frac_of_peak"] = kernels[k]["traffic_GBps"] / HBM_PEAK_GBS
     out = {"workload": w.name, "value": w.units * passes / el, "unit": w.unit_name, "passes": passes,
            "ms_per_pass": el / passes * 1e3, "dominant_kernel": dom, "limiter": w.limiter.get(dom, "hbm"), "kernels": kernels}
     if getattr(w, "counts", None) is not None:

@@ -84,7 +84,6 @@ def main():
                 e["lds_bank_conflict_frac"] = round(m(k, "SQ_LDS_BANK_CONFLICT") / m(k, "SQ_LDS_IDX_ACTIVE"), 3)
             if m(k, "SQ_ACTIVE_INST_LDS") and m(k, "GRBM_GUI_ACTIVE"):
                 e["lds_busy"] = round(m(k, "SQ_ACTIVE_INST_LDS") * 4 / (SIMDS * m(k, "GRBM_GUI_ACTIVE") / 8), 3)
-            rec[k] = e
             t = {}
             if m(k, "FETCH_SIZE") is not None:
                 t["fetch_bytes_corrected"] = m(k, "FETCH_SIZE") * 1024.0 * 2.0
@@ -94,6 +93,13 @@ def main():
                 t["hbm_bytes"] = t.get("fetch_bytes_corrected", 0.0) + t.get("write_bytes", 0.0)
                 t["moved_bytes_counted_by_bench"] = info["moved_bytes"]
                 tr[k] = t
+                # (the same passes, under the same fingerprint: what bench.py quotes per kernel in the also records)
+                e["hbm_bytes_per_launch"] = t["hbm_bytes"]
+                e["hbm_fetch_write_bytes"] = [t.get("fetch_bytes_corrected"), t.get("write_bytes")]
+                ms = info.get("fwd_ms" if k == "rollout_fwd" else "bwd_ms")
+                if ms:
+                    e["hbm_GBps_under_profiler"] = round(t["hbm_bytes"] / ms / 1e6, 1)
+            rec[k] = e
         issue[info["name"]] = rec
         traffic[info["name"]] = tr
     open(os.path.join(out, "summary.csv"), "w").write("\n".join(lines) + "\n")
