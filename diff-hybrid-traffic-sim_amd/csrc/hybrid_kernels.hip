@@ -123,6 +123,7 @@ struct HybTables {
     int loc_lanes;                           // lanes of the micro wave that own a range of temporaries (64; n_staging_lanes when packed)
     int max_step_records;                    // records a step may hold (the reverse sweep stages a step's records in LDS)
     const int32_t *lane_source; const double *draws; int n_draws; size_t draws_stride;     // micro source lanes (itscp `micro` mode)
+    int tensor_ladder;                       // dhts_hybrid_tables::micro_tensor_ladder
     // a plain RoadNetwork with given initial state and final-state taps (dhts_net_hybrid_state_rollout_*, include/dhts.h)
     int plain;
     const float *state0, *ghost0; float *veh_out; int *events;
@@ -1278,6 +1279,7 @@ static inline HybTables hyb_tables(const dhts_hybrid_tables *t) {
     h.lane_macro = t->lane_macro; h.lane_len = t->lane_len; h.conv_next = t->conv_next; h.routes = t->routes; h.route_ptr = t->route_ptr;
     h.n_routes = t->n_routes; h.route_stride = t->route_stride; h.loss_steps = t->loss_steps; h.n_micro = t->n_micro; h.lane_sh = hyb_lane_sh(t);
     h.lane_source = t->lane_source; h.draws = t->draws; h.n_draws = t->n_draws; h.draws_stride = (size_t)t->draws_stride;
+    h.tensor_ladder = t->micro_tensor_ladder;
     h.lds_budget = 160 * 1024; h.loc_lanes = 64; h.max_step_records = kMaxStepRecords;
     h.plain = 0; h.state0 = nullptr; h.ghost0 = nullptr; h.veh_out = nullptr; h.events = nullptr;
     h.g_stateT = nullptr; h.g_veh = nullptr; h.g_state0 = nullptr;

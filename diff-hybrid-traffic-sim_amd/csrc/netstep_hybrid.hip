@@ -91,7 +91,7 @@ struct NsCommon {
     const double *schedule;
     const int32_t *routes, *route_ptr;
     const double *draws;
-    int NI, n_edges, n_islots, has_source, n_routes;
+    int NI, n_edges, n_islots, has_source, n_routes, tensor_ladder;
     long long table_stride, draws_stride;    // elements between replicas in the [T][L] tables / the draws (0 = shared)
     char *ws;
     NsLayout lo;
@@ -585,7 +585,7 @@ template <class A> __device__ __forceinline__ void ns_micro_fwd(const A &a, int 
     auto tape = hard ? nullptr : ns_ptr<float4>(a, a.lo.idm_tape) + (size_t)t * plane;
     auto nv_idm = hard ? nullptr : ns_ptr<int>(a, a.lo.nv_idm) + (size_t)t * Lm;
     const NsSlots sr = ns_slot_range(Lm, cap, cnt->n_max);
-    const bool f32_ladder = a.has_source && !hard;
+    const bool f32_ladder = a.tensor_ladder && !hard;        // (dhts_hybrid_tables::micro_tensor_ladder: said by the host, not inferred from the source lanes)
     for (int j = tid; j < sr.total; j += B) {
         int m, i; size_t idx;
         ns_slot_of(sr, j, m, i, idx);
@@ -1752,8 +1752,16 @@ __global__ void ns_init_fwd_kernel(NsArgs a) {
 
 using namespace dhts;
 
+// Hand-off events an episode may record (64 B each; the reverse sweep replays them).  A step holds at most one leaving head per
+// micro lane (CHANGE / DESPAWN / DEPOSIT + a DEPCELL per cell the deposit touches) and one SPAWN (+ CAPSERIAL) per capacitor;
+// the default budgets a quarter of the lanes doing so in every step -- 8 per step at least, which is what small networks always
+// had -- and a caller that meets DHTS_FAULT_CAPACITY with index -2 raises dhts_netstep_tables::max_events (ItscpEnv does, up to
+// the hard bound T x (4 n_micro + 2 n_caps)).
 static inline int ns_max_events(const dhts_net_desc *d, const dhts_netstep_tables *t) {
-    return t->max_events > 0 ? t->max_events : 8 * d->n_steps + 64;
+    if (t->max_events > 0) return t->max_events;
+    const long long per_step = (t->hyb.n_micro + t->n_caps + 3) / 4;
+    const long long n = (long long)d->n_steps * (per_step > 8 ? per_step : 8) + 64;
+    return n > 0x3fffffff ? 0x3fffffff : (int)n;
 }
 
 static NsLayout ns_layout(const dhts_net_desc *d, const dhts_netstep_tables *t) {
@@ -1827,7 +1835,7 @@ static NsArgs ns_args(const dhts_net_desc *d, const dhts_netstep_tables *t, int 
     a.nxt_ptr = h.net.nxt_ptr; a.nxt_idx = h.net.nxt_idx; a.prv_ptr = h.net.prv_ptr; a.prv_idx = h.net.prv_idx;
     a.inter_ptr = t->inter_ptr; a.inter_idx = t->inter_idx;
     a.cell_lane = t->cell_lane; a.table_stride = h.net.replica_stride; a.draws_stride = h.draws_stride;
-    a.n_edges = h.net.n_edges; a.n_islots = t->n_inter_slots; a.has_source = h.lane_source != nullptr; a.n_routes = h.n_routes;
+    a.n_edges = h.net.n_edges; a.n_islots = t->n_inter_slots; a.has_source = h.lane_source != nullptr; a.n_routes = h.n_routes; a.tensor_ladder = h.micro_tensor_ladder;
     { int lg = 0; for (int g = 0; g < t->n_groups; ++g) lg += t->groups[g].n_lanes; a.NI = d->n_cells + lg; }
     a.ws = reinterpret_cast<char *>(ws); a.lo = ns_layout(d, t);
     a.hist = hist; a.queue = queue; a.reward = reward; a.counts = counts; a.err = err;

@@ -50,7 +50,7 @@ class HybridTables(C.Structure):
                 ("routes", C.c_void_p), ("route_ptr", C.c_void_p), ("n_routes", C.c_int32), ("route_stride", C.c_int32),
                 ("records_per_step", C.c_int32), ("loss_steps", C.c_int32), ("n_micro", C.c_int32),
                 ("lane_source", C.c_void_p), ("draws", C.c_void_p), ("n_draws", C.c_int32), ("draws_stride", C.c_int64),
-                ("lane_capacity", C.c_int32)]
+                ("lane_capacity", C.c_int32), ("micro_tensor_ladder", C.c_int32)]
 
 
 class HybridStateIO(C.Structure):
@@ -126,7 +126,8 @@ _lib = None
 
 
 class DhtsError(RuntimeError):
-    pass
+    """A library call returned a negative DHTS_E_* status (`.status`; None for errors raised by the binding itself)."""
+    status = None
 
 
 def lib():
@@ -150,4 +151,6 @@ def check(status, what):
     if status != OK:
         names = {E_INVALID: "DHTS_E_INVALID (bad argument)", E_LAUNCH: "DHTS_E_LAUNCH (HIP launch failed)",
                  E_NO_DEVICE: "DHTS_E_NO_DEVICE"}
-        raise DhtsError("%s failed: %s" % (what, names.get(status, status)))
+        e = DhtsError("%s failed: %s" % (what, names.get(status, status)))
+        e.status = status
+        raise e

@@ -193,10 +193,13 @@ class HybridNetworkTables:
         t.is_plain = True
         return t
 
-    def set_micro_sources(self, draws):
+    def set_micro_sources(self, draws, tensor_ladder=True):
         """The admission draws of the micro source lanes: the values np.random.random() yields (or yielded, for a replay), in
-        call order -- one per source lane and step in which the lane has room for a vehicle."""
+        call order -- one per source lane and step in which the lane has room for a vehicle.  tensor_ladder: the lanes are itscp
+        `micro` mode's plain MicroLane objects on float32 tensors (the only network the reference builds with source lanes,
+        _env.py:484-498); False for a network of dMicroLane lanes that happens to have an IDM source lane."""
         self.draws = np.ascontiguousarray(draws, dtype=np.float64)
+        self.micro_tensor_ladder = bool(tensor_ladder)
         return self
 
     def check_kernel_limits(self):

@@ -41,7 +41,9 @@ def new_error_record(device):
 class CapacityError(RuntimeError):
     """A fused network episode needed more than one of the kernels' fixed capacities (include/dhts.h: vehicles per micro lane,
     vehicles per episode, records per step).  Nothing was changed on the host: callers can run the episode another way
-    (ItscpEnv.step falls back to the lane-by-lane path)."""
+    (ItscpEnv.step falls back to the lane-by-lane path).  `.index` = the fault record's index field: -2 = the stepwise path's hand-off
+    event list (dhts_netstep_tables::max_events), -3 = a reverse sweep whose plan is not its forward's, else 0 / a count."""
+    index = 0
 
 
 def raise_on_fault(err):
@@ -54,8 +56,10 @@ def raise_on_fault(err):
     if code == _lib.FAULT_NAN:
         raise AssertionError("non-finite gradient in the reverse sweep (step %d, lane %d)" % (step, lane))   # dmacro_lane.py:308
     if code == _lib.FAULT_CAPACITY:
-        raise CapacityError("hybrid network: a fixed capacity was exceeded (record stream / vehicles / lane list / routes); "
-                            "index %d" % index)
+        e = CapacityError("hybrid network: a fixed capacity was exceeded (record stream / vehicles / lane list / routes / events); "
+                          "index %d" % index)
+        e.index = int(index)
+        raise e
     if code == _lib.FAULT_COLLISION:
         # printed and tolerated in the reference (_micro_lane.py:155-160): the deltas of that vehicle are zeroed, the run goes on
         print("Collision detected between vehicles (step %d, lane %d, vehicle %d)" % (step, lane, index))
@@ -595,6 +599,7 @@ class DeviceHybridTables:
                       up(routes, torch.int32), up(route_ptr, torch.int32)]
         # micro source lanes (itscp `micro` mode): the lane flags and the host's admission draws (per replica when `tables` is a list)
         self.has_sources = bool(np.asarray(t.lane_source).any())
+        self.micro_tensor_ladder = bool(getattr(t, "micro_tensor_ladder", False))
         self.n_draws, self.draws_stride = 0, 0
         if self.has_sources:
             if many:
@@ -636,7 +641,8 @@ class DeviceHybridTables:
         k = [x.data_ptr() for x in self._keep]
         src = (k[18], k[19]) if self.has_sources else (None, None)
         return _lib.HybridTables(self.net, k[13], k[14], k[15], k[16], k[17], self.n_routes, self.route_stride, self.records_per_step,
-                                 int(loss_steps), self.n_micro, src[0], src[1], self.n_draws, self.draws_stride, self.lane_capacity)
+                                 int(loss_steps), self.n_micro, src[0], src[1], self.n_draws, self.draws_stride, self.lane_capacity,
+                                 1 if self.micro_tensor_ladder else 0)
 
 
 class NetHybridRollout(torch.autograd.Function):

@@ -173,6 +173,7 @@ class StepwiseNetwork:
             micro_lanes=up(pad1(np.asarray(micro, dtype=np.int32)), i32), lane_mslot=up(mslot, i32),
             cap_lanes=up(pad1(np.asarray(caps, dtype=np.int32)), i32), lane_cslot=up(cslot, i32))
         self.has_sources = bool(np.asarray(t.lane_source).any())
+        self.micro_tensor_ladder = bool(getattr(t, "micro_tensor_ladder", False))
         self.n_draws, self.draws_stride = 0, 0
         if self.has_sources:
             if many:
@@ -199,9 +200,12 @@ class StepwiseNetwork:
         if not same:
             raise ValueError("StepwiseNetwork.update: the network's topology changed; build a new one")
         self.t = t
+        # NEW tensors, not copies into the old ones: a differentiable rollout that has not run its reverse sweep yet keeps
+        # references to the tables it was stepped with (several episodes summed before one backward(): Trainer.train_epoch with
+        # num_episode_per_epoch > 1)
         for name, dt in (("left_src", torch.int32), ("left_gate", torch.int32), ("right_src", torch.int32), ("conv_next", torch.int32),
                          ("schedule", torch.float64)):
-            self.d[name].copy_(torch.as_tensor(np.ascontiguousarray(getattr(t, name)), dtype=dt))
+            self.d[name] = torch.as_tensor(np.ascontiguousarray(getattr(t, name)), dtype=dt, device=self.device)
 
     def set_draws(self, draws):
         if not self.has_sources:
@@ -209,7 +213,7 @@ class StepwiseNetwork:
         d = torch.as_tensor(np.ascontiguousarray(draws, dtype=np.float64))
         if d.shape != self.d["draws"].shape:
             raise ValueError("draws must keep their shape %s" % (tuple(self.d["draws"].shape),))
-        self.d["draws"].copy_(d)
+        self.d["draws"] = d.to(self.device)            # (a new tensor: see update())
 
     def _c(self, n_inter_sq, loss_steps):
         d = self.d
@@ -232,7 +236,7 @@ class StepwiseNetwork:
         src = (p("lane_source"), p("draws")) if self.has_sources else (None, None)
         hyb = _lib.HybridTables(net, p("lane_macro"), p("lane_len"), p("conv_next"), p("routes"), p("route_ptr"), self.n_routes,
                                 self.route_stride, 0, int(loss_steps), self.n_micro, src[0], src[1], self.n_draws, self.draws_stride,
-                                self.lane_capacity)
+                                self.lane_capacity, 1 if self.micro_tensor_ladder else 0)
         return _lib.NetstepTables(hyb, p("lane_gpos"), self._garr, len(self.groups), p("micro_lanes"), p("lane_mslot"), p("cap_lanes"),
                                   p("lane_cslot"), self.n_caps, p("inter_ptr"), p("inter_idx"), self.max_events, p("if_lane"), p("cell_lane"),
                                   1 if self.persistent else 0, int(d["inter_idx"].numel()))
@@ -266,9 +270,14 @@ class _NetstepRollout(torch.autograd.Function):
         ws_n = lib.dhts_netstep_workspace_bytes(C.byref(d), C.byref(tc))
         if ws_n == 0:
             raise ValueError("dhts_netstep: unsupported network / sizes")
-        ws = getattr(net, "_ws", None)
-        if ws is None or ws.numel() < ws_n:
-            ws = net._ws = torch.empty(ws_n, dtype=torch.uint8, device=dev)
+        # the workspace holds what the reverse sweep reads (records, tape, histories): a differentiable rollout owns its own, so that
+        # several episodes can be rolled out before one backward(); evaluation episodes share the network's
+        if differentiable:
+            ws = torch.empty(ws_n, dtype=torch.uint8, device=dev)
+        else:
+            ws = getattr(net, "_ws", None)
+            if ws is None or ws.numel() < ws_n:
+                ws = net._ws = torch.empty(ws_n, dtype=torch.uint8, device=dev)
         hist = torch.empty((Rn, net.T + 1, 4, max(net.n_cells, 1)), dtype=torch.float32, device=dev)
         queue = torch.empty(Rn, net.T, net.n_lanes, dtype=torch.float32, device=dev)
         reward = torch.empty(Rn, 2, dtype=torch.float32, device=dev)
@@ -280,8 +289,8 @@ class _NetstepRollout(torch.autograd.Function):
         if check_faults:
             ops.raise_on_fault(net.err)
         net.last_hist = hist if R else hist[0]
-        net._episode = ctx.episode = getattr(net, "_episode", 0) + 1
         ctx.net, ctx.d, ctx.tc, ctx.differentiable, ctx.check_faults = net, d, tc, differentiable, check_faults
+        ctx.tables = list(net.d.values())             # (tc holds raw pointers: keep the tensors of THIS episode alive, see update())
         ctx.save_for_backward(a, hist, queue.reshape(Rn, net.T, net.n_lanes), ws)
         ctx.shape = action.shape
         if not R:
@@ -297,8 +306,6 @@ class _NetstepRollout(torch.autograd.Function):
             raise RuntimeError("an evaluation episode (differentiable=False) keeps nothing for a reverse sweep")
         a, hist, queue, ws = ctx.saved_tensors
         net = ctx.net
-        if getattr(net, "_ws", None) is not ws or net._episode != ctx.episode:
-            raise RuntimeError("StepwiseNetwork: another rollout ran on this network before backward (one workspace per network)")
         g = g_cut.reshape(-1).contiguous().float()
         g_action = torch.empty_like(a)
         _lib.check(_lib.lib().dhts_netstep_rollout_bwd(C.byref(ctx.d), C.byref(ctx.tc), ops._ptr(a), ops._ptr(hist), ops._ptr(queue), ops._ptr(g),

@@ -348,52 +348,37 @@ class ItscpEnv:
             else:
                 reward, queue, counts = ops.net_hybrid_eval(a, tab, *args)
                 self.fused_counts = counts[0].tolist()
-        except (ops.CapacityError, _lib.DhtsError) as e:
-            if kind == "stepwise" and isinstance(e, _lib.DhtsError) and getattr(tab, "persistent", False):
-                self._stepwise_no_persistent = True         # the persistent form's LDS does not hold this network: stepwise form
+        except _lib.DhtsError as e:
+            # Two library errors have another way to run, both DHTS_E_INVALID sizing refusals: the persistent form of a network whose
+            # scratch does not fit a workgroup's LDS (-> the stepwise form), and a fused hybrid launch whose LDS plan does not fit at
+            # the lane capacity the ladder asked for (-> the next rung, below).  Anything else -- a failed launch, a bad argument, any
+            # error of the macro paths -- is a bug or a broken device and goes to the caller.
+            if e.status != _lib.E_INVALID or kind not in ("hybrid", "micro", "stepwise"):
+                raise
+            if kind == "stepwise":
+                if not getattr(tab, "persistent", False):
+                    raise
+                self._stepwise_no_persistent = True
                 self._stepwise_cache = None
                 self._fused_cache = None
                 if draws is not None:
                     self._fused_pending_draws = draws
                 return self._step_fused(action, differentiable)
-            # The episode needs more than this launch was sized for (vehicles per micro lane, vehicles per episode, records), or the
-            # sizing does not fit one workgroup's LDS (DhtsError).  Nothing on the host was touched by the attempt; the ladder is
-            #   fused kernels at 16 vehicles per lane -> fused at 128 -> stepwise device path at 32 -> 128 -> 1024 -> lane by lane
-            #   (a network that starts on the stepwise path starts at the capacity its geometry asks for, dhts.stepwise.default_lane_capacity),
-            # every rung the SAME episode: same drawn routes (kept in _fused_routes_drawn), same admission draws.
-            ladder = [("fused", 16), ("fused", 128), ("stepwise", 32), ("stepwise", 128), ("stepwise", 1024)]
-            here = ("stepwise" if kind == "stepwise" else "fused",
-                    lane_cap if lane_cap else (16 if kind != "stepwise" else getattr(self, "_stepwise_lane_capacity", 32)))
-            nxt = None
-            if kind in ("micro", "hybrid", "stepwise"):
-                for rung in ladder:
-                    if (rung[0] == "stepwise", rung[1]) > (here[0] == "stepwise", here[1]) and rung[1] <= int(self.config.get("fused_max_lane_capacity", 1024)):
-                        nxt = rung
-                        break
-            if nxt is not None:
-                self._fused_lane_capacity = nxt[1]
-                self._fused_prefer_stepwise = nxt[0] == "stepwise"
-                self._fused_cache = None
-                if draws is not None:
-                    self._fused_pending_draws = draws          # the retry is the same episode: the same admission draws
-                return self._step_fused(action, differentiable)
-            # The reference has no such limits (_micro_lane.py:53-113): this episode runs lane by lane instead (minutes, not
-            # milliseconds).  In `micro` mode the admission draws the kernels were given are replayed, so that the episode is the one
-            # that was asked for.
-            if not getattr(self, "_fused_overflow_warned", False):
-                self._fused_overflow_warned = True
-                import warnings
-                warnings.warn("ItscpEnv: the device paths' capacity was exceeded (%s); this episode runs lane by lane" % e)
-            self._own_lanes()                       # (an episode_copy() twin: from here on the lane objects are written to)
-            if draws is not None:
-                it = iter(np.asarray(draws, dtype=np.float64).tolist())
-
-                def replay():
-                    v = next(it, None)
-                    return float(np.random.random()) if v is None else v
-                self.simulator.random_draw = replay
-            self.fused_overflowed = True
-            return None
+            return self._climb_capacity_ladder(action, differentiable, kind, lane_cap, draws, e)
+        except ops.CapacityError as e:
+            if kind == "stepwise" and e.index == -2:
+                # the hand-off event list (dhts_netstep_tables::max_events), not a lane: more lanes' worth of vehicles would not help.
+                # The hard bound: every micro lane's head leaves (with up to three deposit cells) and every capacitor spawns, every step
+                bound = self.num_timestep * (4 * tab.n_micro + 2 * tab.n_caps) + 64
+                have = tab.max_events if tab.max_events > 0 else 0
+                if have < bound:
+                    self._stepwise_max_events = bound
+                    self._stepwise_cache = None
+                    self._fused_cache = None
+                    if draws is not None:
+                        self._fused_pending_draws = draws
+                    return self._step_fused(action, differentiable)
+            return self._climb_capacity_ladder(action, differentiable, kind, lane_cap, draws, e)
         self.last_path = {"macro": "fused", "hybrid": "fused", "micro": "fused"}.get(kind, kind)
         q = np.ascontiguousarray(queue[0].detach().cpu().numpy().T)      # [L][T]
         for i, lid in enumerate(self.lane.keys()):
@@ -402,6 +387,47 @@ class ItscpEnv:
         self.time = self.num_timestep
         self._fused_done = True
         return (-self.reward_queue_c) * reward[0]
+
+    def _climb_capacity_ladder(self, action, differentiable, kind, lane_cap, draws, e):
+        """The same episode on the next rung (more vehicle slots per micro lane, then the stepwise path), or lane by lane (None)."""
+        # The episode needs more than this launch was sized for (vehicles per micro lane, vehicles per episode, records), or the
+        # sizing does not fit one workgroup's LDS (DhtsError).  Nothing on the host was touched by the attempt; the ladder is
+        #   fused kernels at 16 vehicles per lane -> fused at 128 -> stepwise device path at 32 -> 128 -> 1024 -> lane by lane
+        #   (a network that starts on the stepwise path starts at the capacity its geometry asks for, dhts.stepwise.default_lane_capacity),
+        # every rung the SAME episode: same drawn routes (kept in _fused_routes_drawn), same admission draws.
+        ladder = [("fused", 16), ("fused", 128), ("stepwise", 32), ("stepwise", 128), ("stepwise", 1024)]
+        here = ("stepwise" if kind == "stepwise" else "fused",
+                lane_cap if lane_cap else (16 if kind != "stepwise" else getattr(self, "_stepwise_lane_capacity", 32)))
+        nxt = None
+        if kind in ("micro", "hybrid", "stepwise"):
+            for rung in ladder:
+                if (rung[0] == "stepwise", rung[1]) > (here[0] == "stepwise", here[1]) and rung[1] <= int(self.config.get("fused_max_lane_capacity", 1024)):
+                    nxt = rung
+                    break
+        if nxt is not None:
+            self._fused_lane_capacity = nxt[1]
+            self._fused_prefer_stepwise = nxt[0] == "stepwise"
+            self._fused_cache = None
+            if draws is not None:
+                self._fused_pending_draws = draws          # the retry is the same episode: the same admission draws
+            return self._step_fused(action, differentiable)
+        # The reference has no such limits (_micro_lane.py:53-113): this episode runs lane by lane instead (minutes, not
+        # milliseconds).  In `micro` mode the admission draws the kernels were given are replayed, so that the episode is the one
+        # that was asked for.
+        if not getattr(self, "_fused_overflow_warned", False):
+            self._fused_overflow_warned = True
+            import warnings
+            warnings.warn("ItscpEnv: the device paths' capacity was exceeded (%s); this episode runs lane by lane" % e)
+        self._own_lanes()                       # (an episode_copy() twin: from here on the lane objects are written to)
+        if draws is not None:
+            it = iter(np.asarray(draws, dtype=np.float64).tolist())
+
+            def replay():
+                v = next(it, None)
+                return float(np.random.random()) if v is None else v
+            self.simulator.random_draw = replay
+        self.fused_overflowed = True
+        return None
 
     def _build_fused_cache(self, device, lane_cap):
         """(kind, device tables) of this episode: "macro" / "hybrid" / "micro" = the fused kernels (one workgroup per network),
@@ -479,8 +505,9 @@ class ItscpEnv:
 
     def _stepwise_net(self, tab, routes, device, lane_cap):
         from dhts.stepwise import StepwiseNetwork
-        net = getattr(self, "_stepwise_cache", None)            # survives reset(): same topology -> tables updated in place
-        if net is not None and net[1] == (lane_cap, routes.shape, routes.tobytes()):
+        net = getattr(self, "_stepwise_cache", None)            # survives reset(): same topology -> new per-episode tables only
+        max_events = int(getattr(self, "_stepwise_max_events", 0))
+        if net is not None and net[1] == (lane_cap, routes.shape, routes.tobytes()) and net[0].max_events == max_events:
             try:
                 net[0].update(tab)
                 if tab.lane_source.any():
@@ -493,7 +520,7 @@ class ItscpEnv:
         # DhtsError at the first launch and is rebuilt in the stepwise form (a handful of launches per step)
         from dhts.stepwise import persistent_form_pays
         persistent = bool(self.config.get("stepwise_persistent", persistent_form_pays(tab))) and not getattr(self, "_stepwise_no_persistent", False)
-        sw = StepwiseNetwork(tab, routes, device, lane_capacity=lane_cap, persistent=persistent)
+        sw = StepwiseNetwork(tab, routes, device, lane_capacity=lane_cap, persistent=persistent, max_events=max_events)
         self._stepwise_cache = (sw, (lane_cap, routes.shape, routes.tobytes()))
         return sw
 

@@ -29,12 +29,17 @@ class ReplicaBatch:
             e = copy.deepcopy(env)
             e.__dict__.pop("_fused_cache", None)
             if base > 0:
-                e.config["random_seed"] = base + seed_offset + r * seed_stride
+                e.config["random_seed"] = base + seed_offset + r * seed_stride      # (the copy's own dict)
             e.reset()
             self.envs.append(e)
         if base > 0 and seed_offset:
+            # replica 0 of another rank draws its own episode too -- with the caller's configuration left as it was (a second
+            # batch built from the same environment must not see an accumulated offset)
             env.config["random_seed"] = base + seed_offset
-            env.reset()
+            try:
+                env.reset()
+            finally:
+                env.config["random_seed"] = base
         self.kind, self.tab = self._build()
         e0 = self.envs[0]
         self.args = (e0.num_intersection ** 2, e0.config["signal_length"] * e0.config["simulation_frequency"],
@@ -55,15 +60,21 @@ class ReplicaBatch:
             tabs = [HybridNetworkTables.from_env(e) for e in self.envs]
             sim = e0.simulator
             if mode == "micro":
+                # ONE route table for the batch (the kernels' routes are shared by the replicas): replica 0's waiting lists.  Every
+                # replica environment is given the same lists, so that the per-environment path of a comparison -- or of the
+                # fall-back -- runs the episode the batch runs; what differs between replicas is what the kernels take per replica:
+                # inflow schedules and admission draws.
                 rows = []
                 for l in range(tabs[0].n_lanes):
                     for r in reversed(sim.lane_waiting_micro_route.get(l, [])):
                         r = list(r.route)[:32]
                         rows.append(r + [-1] * (32 - len(r)))
                 routes = np.asarray(rows if rows else [[-1, -1]], dtype=np.int32)
-                n_draws = e0.num_timestep * max(1, int(tabs[0].lane_source.sum()))
+                for e in self.envs[1:]:
+                    e.simulator.lane_waiting_micro_route = copy.deepcopy(sim.lane_waiting_micro_route)
+                self.n_draws = e0.num_timestep * max(1, int(tabs[0].lane_source.sum()))
                 for t in tabs:
-                    t.set_micro_sources(np.random.random(n_draws))
+                    t.set_micro_sources(np.full(self.n_draws, 2.0))       # (placeholders: rollout() draws per episode)
             else:
                 routes = getattr(e0, "fused_routes", None)
                 if routes is None:
@@ -97,6 +108,12 @@ class ReplicaBatch:
         """actions [R][A] (device) -> rewards [R] (reward_queue_c applied like ItscpEnv._reward); differentiable w.r.t. actions."""
         from dhts import ops
         c = -self.envs[0].reward_queue_c
+        if self.kind != "per-env" and getattr(self, "n_draws", 0):
+            # itscp `micro` mode: fresh admission draws for every episode and replica, as ItscpEnv._step_fused draws them per episode
+            # (`fused_draws` [R][n] replays a recorded stream)
+            d = getattr(self, "fused_draws", None)
+            self.last_draws = np.random.random((self.R, self.n_draws)) if d is None else np.asarray(d, dtype=np.float64)
+            self.tab.set_draws(self.last_draws if self.R > 1 or self.kind == "stepwise" else self.last_draws[0])
         if self.kind == "per-env":
             out = []
             for r, e in enumerate(self.envs):

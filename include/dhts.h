@@ -432,10 +432,7 @@ typedef struct dhts_hybrid_tables {
      * needs more raises DHTS_FAULT_CAPACITY), draws_stride the elements between replicas (0 = shared).  The k-th vehicle admitted
      * to lane m takes route row route_ptr[m] + k (no wrap-around: the rows are the lane's waiting list in admission order, and an
      * exhausted list admits nobody).  lane_source [L] int32 (1 = source lane) or NULL = the network has none.
-     * A network WITH source lanes is the reference's `micro` mode, whose lanes are plain autodiff MicroLane objects stepped in float32
-     * TENSOR arithmetic (example/control/itscp/_env.py:484-498; road/lane/_micro_lane.py:131-214 evaluated by torch): in differentiable
-     * episodes of such a network the IDM step follows that ladder operation by operation (csrc/idm_device.hpp idm_step_f32) instead
-     * of the analytic operator's float64 one (dmicro_lane.py:87-127) that hybrid-mode lanes use. */
+     * (Which arithmetic the IDM lanes step in is micro_tensor_ladder's business, below -- not inferred from lane_source.) */
     const int32_t *lane_source;
     const double *draws;
     int32_t n_draws;
@@ -445,6 +442,12 @@ typedef struct dhts_hybrid_tables {
      * lanes are unbounded (_micro_lane.py:53-113), an episode that needs more than the launch was sized for ends in
      * DHTS_FAULT_CAPACITY and the caller retries with a larger value (ItscpEnv.step does) or runs lane by lane. */
     int32_t lane_capacity;
+    /* 1 = the network's IDM lanes are the reference's PLAIN autodiff MicroLane objects on torch tensors -- itscp `micro` mode
+     * (example/control/itscp/_env.py:484-498; road/lane/_micro_lane.py:131-214 evaluated by torch): in differentiable episodes the IDM
+     * step follows that float32 TENSOR ladder operation by operation (csrc/idm_device.hpp idm_step_f32).  0 = dMicroLane lanes (every
+     * other network, with or without source lanes): the analytic operator's float64 ladder (dmicro_lane.py:87-127), the head vehicle in
+     * mixed arithmetic while its gap is a tensor.  The host says which (ItscpEnv's `micro` branch sets 1). */
+    int32_t micro_tensor_ladder;
 } dhts_hybrid_tables;
 size_t dhts_net_hybrid_workspace_bytes(const dhts_net_desc *d, const dhts_hybrid_tables *t);
 /* What dhts_net_hybrid_rollout_fwd / _bwd would launch for (d, t) under the current DHTS_OPT_HYB_PACK (no device work): plan[0] = 1

@@ -789,6 +789,10 @@ void oracle_set_micro_sources(const int *lane_source, const double *draws, int n
     oracle_src_lanes = lane_source; oracle_src_draws = draws; oracle_src_n = n_draws; oracle_src_used = 0;
 }
 int oracle_micro_source_draws_used(void) { return oracle_src_used; }
+/* 1 = the network's IDM lanes are itscp `micro` mode's plain MicroLane objects on float32 tensors (_env.py:484-498): differentiable
+ * episodes step them with oracle_micro_step_f32.  Said by the caller (dhts_hybrid_tables::micro_tensor_ladder), not inferred. */
+static int oracle_tensor_ladder = 0;
+void oracle_set_micro_tensor_ladder(int on) { oracle_tensor_ladder = on; }
 
 typedef struct {            /* per step: phase signals of every intersection and their inputs */
     float we, ns, a, prog;

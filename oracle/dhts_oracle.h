@@ -142,6 +142,7 @@ void oracle_set_hard(int hard);
 /* micro SOURCE lanes of oracle_net_hybrid (itscp `micro` mode, _simulator.py:153-174): lane_source [L] (1 = micro lane without an
  * upstream lane), the host's admission draws in call order; NULL = none.  Process-wide, set before the call. */
 void oracle_set_micro_sources(const int *lane_source, const double *draws, int n_draws);
+void oracle_set_micro_tensor_ladder(int on);
 int oracle_micro_source_draws_used(void);
 typedef struct oracle_net_desc {
     int n_lanes, n_cells, T, n_inter_sq, frames_per_phase, n_action;

@@ -305,6 +305,7 @@ def net_hybrid(tab, routes, route_ptr, action, n_inter_sq, frames_per_phase, dt,
         l.oracle_set_micro_sources(_p(src), _p(draws), len(draws))
     else:
         l.oracle_set_micro_sources(None, None, 0)
+    l.oracle_set_micro_tensor_ladder(1 if getattr(tab, "micro_tensor_ladder", False) else 0)
     l.oracle_net_hybrid.argtypes = ([C.POINTER(NetDesc)] + [C.c_void_p] * 14 + [C.c_int, C.c_int, C.c_void_p, C.c_int]
                                     + [C.c_void_p] * 8)
     action = _f32(action)

@@ -524,11 +524,132 @@ def test_env_ladder_survives_a_fused_launch_that_does_not_fit(cuda, golden_dir, 
 
     def refuse(a, tab, *args, **kw):
         if tab.lane_capacity == 128:
-            raise _lib.DhtsError("dhts_net_hybrid_rollout_fwd: DHTS_E_INVALID (injected: LDS staging does not fit)")
+            e = _lib.DhtsError("dhts_net_hybrid_rollout_fwd: DHTS_E_INVALID (injected: LDS staging does not fit)")
+            e.status = _lib.E_INVALID
+            raise e
         return real(a, tab, *args, **kw)
     monkeypatch.setattr(ops, "net_hybrid_rollout", refuse)
     env = episode()
     assert env.last_path == "stepwise" and env._fused_cache[1].lane_capacity == 32
+
+
+def test_env_does_not_swallow_library_errors(cuda, golden_dir, monkeypatch):
+    """only a DHTS_E_INVALID sizing refusal has another way to run.  A failed launch (or any error of the macro paths)
+    reaches the caller instead of turning into four silent retries and a lane-by-lane episode."""
+    import torch
+    from dhts import _lib, ops
+    from test_itscp_gpu import build_env
+    from test_oracle_golden import meta_of
+    g = np.load(os.path.join(golden_dir, "itscp_hybrid_short.npz"))
+    env = build_env(g, meta_of(g), replay_routes=True)
+    env.fused_routes = g["spawn_routes"]
+
+    def broken(*a, **kw):
+        e = _lib.DhtsError("dhts_net_hybrid_rollout_fwd failed: DHTS_E_LAUNCH (HIP launch failed)")
+        e.status = _lib.E_LAUNCH
+        raise e
+    monkeypatch.setattr(ops, "net_hybrid_rollout", broken)
+    with pytest.raises(_lib.DhtsError, match="E_LAUNCH"):
+        env.step(torch.tensor(g["action"], device=cuda, requires_grad=True), True)
+    assert not getattr(env, "fused_overflowed", False)
+
+
+def test_event_list_overflow_is_told_apart_from_a_full_lane(cuda, golden_dir):
+    """ADVICE round 5: the hand-off event list (dhts_netstep_tables::max_events) is sized from the network, an episode that needs
+    more comes back as DHTS_FAULT_CAPACITY with index -2, and ItscpEnv retries with a larger LIST (not with more vehicle slots per
+    lane, which cannot help) -- same episode, the reference's numbers."""
+    import torch
+    from dhts import ops
+    from dhts.stepwise import StepwiseNetwork
+    from test_itscp_gpu import build_env
+    from test_oracle_golden import meta_of
+    g = np.load(os.path.join(golden_dir, "itscp_hybrid_p2.npz"))
+    t, m = itscp_hybrid_tables(g)
+    a = torch.tensor(g["action"], device=cuda, requires_grad=True)
+    for persistent in (False, True):
+        small = StepwiseNetwork(t, g["spawn_routes"], cuda, lane_capacity=32, max_events=4, persistent=persistent)
+        with pytest.raises(ops.CapacityError) as ei:
+            small.rollout(a, *_args(m))
+        assert ei.value.index == -2
+    # the environment: forced onto the stepwise path with a list of four events -> one retry with the hard bound, same numbers
+    env = build_env(g, m, replay_routes=True)
+    env.fused_routes = g["spawn_routes"]
+    env._fused_prefer_stepwise, env._fused_lane_capacity, env._stepwise_max_events = True, 32, 4
+    action = torch.tensor(g["action"], device=cuda, requires_grad=True)
+    _, reward, _, _ = env.step(action, True)
+    reward.backward()
+    assert env.last_path == "stepwise" and env._fused_cache[1].lane_capacity == 32          # the lane capacity did not climb
+    assert env._fused_cache[1].max_events == m["T"] * (4 * env._fused_cache[1].n_micro + 2 * env._fused_cache[1].n_caps) + 64
+    assert abs(float(reward.detach()) - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+    assert np.abs(action.grad.cpu().numpy() - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()
+
+
+@pytest.mark.parametrize("form", ["fused", "stepwise", "persistent"])
+def test_tensor_ladder_is_said_by_the_host_not_inferred_from_source_lanes(cuda, golden_dir, oracle, form):
+    """ADVICE round 5: dhts_hybrid_tables::micro_tensor_ladder.  A network with an IDM source lane whose lanes are dMicroLane objects
+    (flag 0) steps in the analytic operator's float64 ladder -- oracle and every device form agree on it, and it is NOT the float32
+    tensor ladder of itscp `micro` mode (flag 1), which the same forms reproduce from the reference's fixture."""
+    import torch
+    from dhts import ops
+    from dhts.network import group_routes
+    from dhts.stepwise import StepwiseNetwork
+    from test_oracle_golden import itscp_micro_tables
+    g = np.load(os.path.join(golden_dir, "itscp_micro_small.npz"))
+    res = {}
+    for flag in (True, False):
+        t, m, routes = itscp_micro_tables(g)
+        t.set_micro_sources(g["rand_draws"], tensor_ladder=flag)
+        gr, ptr = group_routes(routes, t.n_lanes)
+        o = oracle.net_hybrid(t, gr, ptr, g["action"], *_args(m))
+        a = torch.tensor(g["action"], device=cuda, requires_grad=True)
+        if form == "fused":
+            cut, reward, queue, counts = ops.net_hybrid_rollout(a[None], ops.DeviceHybridTables(t, routes, cuda), *_args(m))
+            cut.sum().backward()
+            q, grad = queue[0].cpu().numpy(), a.grad.cpu().numpy()
+        else:
+            net = StepwiseNetwork(t, routes, cuda, lane_capacity=32, persistent=form == "persistent")
+            cut, reward, queue, counts = net.rollout(a, *_args(m))
+            cut.backward()
+            q, grad = queue.cpu().numpy(), a.grad.cpu().numpy()
+        assert o["rc"] == 0 and rel_max(q, o["queue"]) <= TOL_STATE
+        assert np.abs(grad - o["g_action"]).max() <= TOL_GRAD * np.abs(o["g_action"]).max()
+        res[flag] = q
+    assert rel_max(res[True].T, g["queue"]) <= TOL_STATE                      # flag 1 = the reference's `micro` mode
+    assert not np.array_equal(res[True], res[False])                          # ... and the two ladders are different arithmetic
+
+
+@pytest.mark.parametrize("persistent", [False, True])
+def test_several_rollouts_before_one_backward(cuda, golden_dir, persistent):
+    """every differentiable rollout owns its workspace and keeps the tables it was stepped with, so episodes can be
+    summed before ONE backward() (Trainer.train_epoch with num_episode_per_epoch > 1) -- here two episodes of a `micro` mode
+    network with different admission draws and actions: the summed gradient equals the two separate ones."""
+    import torch
+    from dhts.stepwise import StepwiseNetwork
+    from test_oracle_golden import itscp_micro_tables
+    g = np.load(os.path.join(golden_dir, "itscp_micro_small.npz"))
+    t, m, routes = itscp_micro_tables(g)
+    net = StepwiseNetwork(t, routes, cuda, lane_capacity=32, persistent=persistent)
+    rng = np.random.default_rng(2)
+    d1 = np.asarray(g["rand_draws"], dtype=np.float64)
+    d2 = rng.random(len(d1))
+    a1 = torch.tensor(g["action"], device=cuda, requires_grad=True)
+    a2 = torch.tensor(rng.uniform(0.2, 0.8, len(g["action"])).astype(np.float32), device=cuda, requires_grad=True)
+    sep = []
+    for d, a in ((d1, a1), (d2, a2)):
+        net.set_draws(d)
+        cut, *_ = net.rollout(a, *_args(m))
+        cut.backward()
+        sep.append((float(cut.detach()), a.grad.clone()))
+        a.grad = None
+    net.set_draws(d1)
+    c1, *_ = net.rollout(a1, *_args(m))
+    net.set_draws(d2)
+    c2, *_ = net.rollout(a2, *_args(m))
+    net.rollout(a2, *_args(m), differentiable=False)                    # (an evaluation episode in between takes the shared workspace)
+    (c1 + c2).backward()
+    assert float(c1.detach()) == sep[0][0] and float(c2.detach()) == sep[1][0]
+    assert torch.equal(a1.grad, sep[0][1]) and torch.equal(a2.grad, sep[1][1])
+    assert abs(sep[0][0] - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
 
 
 @pytest.mark.parametrize("name", ["eval_micro_small", "eval_micro", "eval_micro_2x2"])

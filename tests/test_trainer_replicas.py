@@ -260,3 +260,47 @@ def test_replica_batch_of_a_network_beyond_the_fused_limits(cuda):
         acc = g if acc is None else acc + g
     acc /= 3
     assert np.abs(flat - acc).max() <= 1e-5 * np.abs(acc).max()
+
+
+@pytest.mark.gpu
+def test_trainer_epoch_of_two_episodes_on_a_stepwise_network(cuda):
+    """Trainer.train_epoch(num_episode = 2) sums two episodes and calls backward() once -- on a network that takes the
+    stepwise path (one workspace per differentiable rollout now), single environment and replica batch."""
+    import torch
+    from example.control.itscp._env import ItscpEnv
+    from example.control.itscp import problem as problems
+    from example.control.trainer import Trainer
+
+    def make(seed):
+        env = ItscpEnv()
+        env.schedule_callback = problems.problem_1
+        for k, v in dict(num_intersection=3, lane_length=30.0, num_lane=2, policy_length=2, signal_length=1, mode="hybrid", speed_limit=60.0,
+                         random_seed=seed).items():
+            env.config[k] = v
+        env.reset()
+        return env
+    torch.manual_seed(5)
+    tr = Trainer(make(31), network_size=(32,), lr=1e-2)
+    before = flat = torch.cat([p.detach().reshape(-1).clone() for p in tr.controller.parameters()])
+    reward, _, _ = tr.run_episode(True)
+    tr.optimizer.zero_grad()
+    (-reward).backward()
+    g1 = torch.cat([p.grad.reshape(-1).clone() for p in tr.controller.parameters()])
+    assert tr.env.last_path == "stepwise"
+    # two identical episodes (rewind keeps schedules and routes), one backward: the mean loss' gradient is one episode's
+    total = 0
+    for _ in range(2):
+        r, _, _ = tr.run_episode(True)
+        total = total + r
+    tr.optimizer.zero_grad()
+    ((-total) / 2).backward()
+    g2 = torch.cat([p.grad.reshape(-1) for p in tr.controller.parameters()])
+    assert torch.allclose(g2, g1, rtol=1e-6, atol=1e-7 * float(g1.abs().max()))
+    loss = tr.train_epoch(2)                                            # the trainer's own loop, optimiser step included
+    assert torch.isfinite(loss) and not torch.equal(before, torch.cat([p.detach().reshape(-1) for p in tr.controller.parameters()]))
+    # replica batch on the same path
+    tb = Trainer(make(41), network_size=(32,), lr=1e-2, n_replica=2)
+    f1 = tb.flat_gradient(tb.batch_loss(1)).clone()
+    f2 = tb.flat_gradient(tb.batch_loss(2))
+    assert tb.batch.path == "stepwise x2"
+    assert torch.allclose(f2, f1, rtol=1e-6, atol=1e-7 * float(f1.abs().max()))
