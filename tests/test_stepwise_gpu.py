@@ -628,10 +628,12 @@ def test_several_rollouts_before_one_backward(cuda, golden_dir, persistent):
     from test_oracle_golden import itscp_micro_tables
     g = np.load(os.path.join(golden_dir, "itscp_micro_small.npz"))
     t, m, routes = itscp_micro_tables(g)
-    net = StepwiseNetwork(t, routes, cuda, lane_capacity=32, persistent=persistent)
     rng = np.random.default_rng(2)
-    d1 = np.asarray(g["rand_draws"], dtype=np.float64)
-    d2 = rng.random(len(d1))
+    n = m["T"] * int(t.lane_source.sum())                                # one draw per source lane and step at most
+    d1 = np.concatenate([np.asarray(g["rand_draws"], dtype=np.float64), np.full(n, 2.0)])[:n]      # the recorded stream (the rest is never drawn)
+    d2 = rng.random(n)
+    t.set_micro_sources(d1)
+    net = StepwiseNetwork(t, routes, cuda, lane_capacity=32, persistent=persistent)
     a1 = torch.tensor(g["action"], device=cuda, requires_grad=True)
     a2 = torch.tensor(rng.uniform(0.2, 0.8, len(g["action"])).astype(np.float32), device=cuda, requires_grad=True)
     sep = []
