@@ -124,6 +124,7 @@ struct HybTables {
     int max_step_records;                    // records a step may hold (the reverse sweep stages a step's records in LDS)
     const int32_t *lane_source; const double *draws; int n_draws; size_t draws_stride;     // micro source lanes (itscp `micro` mode)
     int tensor_ladder;                       // dhts_hybrid_tables::micro_tensor_ladder
+    const double *veh_params;                // dhts_hybrid_tables::veh_params ([n_routes][6] beside the route table) or NULL
     // a plain RoadNetwork with given initial state and final-state taps (dhts_net_hybrid_state_rollout_*, include/dhts.h)
     int plain;
     const float *state0, *ghost0; float *veh_out; int *events;
@@ -305,7 +306,7 @@ __device__ __forceinline__ float stream_load(const float *p) {
 struct HybLds {
     size_t fq, scanw, incl, vsp, vep, s0, s1, g, contrib, ql, sig, lanelen, vp, vv, va, vxold, hdpv, hdvv, capv, qmicro, tailsp,
         cell_lane, iface_lane, cnext, vidp, vidv, vida, vcur, vrlen, vroute, lane_n, lane_veh, hdpi, hdvi, vcp, capi, mslot,
-        capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, stg_k, stg_i, stg_w, cnt_s, lfl, vx, lane_new, vdsg, total;
+        capof, mlane, cbefore, convlist, linfo, caplast, rused, caplane, capleaf, stg_k, stg_i, stg_w, cnt_s, lfl, vx, lane_new, vdsg, vrow, total;
 };
 __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS, int stage_h, int lane_sh) {
     HybLds o; size_t p = 0; const int NI = C + L;
@@ -323,6 +324,7 @@ __host__ __device__ inline HybLds hyb_lds(int L, int C, int sq, int V, int NS, i
     // the cell -> lane and interface -> lane maps exist during set-up only: they lie on the (then still empty) staging area
     o.cell_lane = o.stg_i; o.iface_lane = o.stg_i + 4 * (((size_t)C + 3) & ~(size_t)3);
     o.cnt_s = F(2 * kPhases * 64); o.lfl = F(L); o.vx = F(V); o.lane_new = F(kMaxMicro); o.vdsg = F(V);
+    o.vrow = F(V);
     o.total = p;
     return o;
 }
@@ -414,6 +416,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     float *vdsg = LF(vdsg);                        // per vehicle: the derivative of its loss term's sigmoid (flush wave, between its two loops)
     float *vx = LF(vx);                            // per vehicle: static_speed - speed of the state the last step left (loss sample)
     int *lfl = LI(lfl);                            // per lane: first cell | last cell << 16
+    int *vrow = LI(vrow);                          // per vehicle: its route row (= its row of tb.veh_params)
     int *cnt_s = LI(cnt_s);                        // [2 blocks][kPhases][64 lanes] staged record counts, micro wave -> flush wave
     int *lane_new = LI(lane_new);                  // per micro lane: 1 = its tail vehicle was admitted at the boundary of the step
                                                    // that runs now: the loss of the previous state does not count it
@@ -686,7 +689,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
                     vroute[vi * kRouteStride + q] = lid;
                     if (lid >= 0 && rl_ == q) rl_ = q + 1;
                 }
-                vrlen[vi] = rl_;
+                vrlen[vi] = rl_; vrow[vi] = (int)row;
                 for (int q = lane_n[k]; q > 0; --q) lane_veh[(k << lane_sh) + q] = lane_veh[(k << lane_sh) + q - 1];
                 lane_veh[(k << lane_sh) + 0] = vi;
                 ++lane_n[k];
@@ -1279,7 +1282,7 @@ static inline HybTables hyb_tables(const dhts_hybrid_tables *t) {
     h.lane_macro = t->lane_macro; h.lane_len = t->lane_len; h.conv_next = t->conv_next; h.routes = t->routes; h.route_ptr = t->route_ptr;
     h.n_routes = t->n_routes; h.route_stride = t->route_stride; h.loss_steps = t->loss_steps; h.n_micro = t->n_micro; h.lane_sh = hyb_lane_sh(t);
     h.lane_source = t->lane_source; h.draws = t->draws; h.n_draws = t->n_draws; h.draws_stride = (size_t)t->draws_stride;
-    h.tensor_ladder = t->micro_tensor_ladder;
+    h.tensor_ladder = t->micro_tensor_ladder; h.veh_params = t->veh_params;
     h.lds_budget = 160 * 1024; h.loc_lanes = 64; h.max_step_records = kMaxStepRecords;
     h.plain = 0; h.state0 = nullptr; h.ghost0 = nullptr; h.veh_out = nullptr; h.events = nullptr;
     h.g_stateT = nullptr; h.g_veh = nullptr; h.g_state0 = nullptr;

@@ -92,6 +92,7 @@ struct NsCommon {
     const int32_t *routes, *route_ptr;
     const double *draws;
     int NI, n_edges, n_islots, has_source, n_routes, tensor_ladder;
+    const double *veh_params;        // dhts_hybrid_tables::veh_params: [n_routes][6] beside the route table, or NULL (default vehicles)
     long long table_stride, draws_stride;    // elements between replicas in the [T][L] tables / the draws (0 = shared)
     char *ws;
     NsLayout lo;
@@ -593,20 +594,28 @@ template <class A> __device__ __forceinline__ void ns_micro_fwd(const A &a, int 
         if (i == 0 && nv_idm) nv_idm[m] = n;
         if (i >= n) continue;
         IdmStep o;
-        if (f32_ladder) {            // `micro` mode, differentiable: the reference steps these lanes in float32 tensor arithmetic (idm_device.hpp)
-            const float p = P0[idx], v = V0[idx];
-            float dp, dv;
-            if (i == n - 1) { dp = hd_s[2 * m]; dv = hd_s[2 * m + 1]; }
-            else { dp = fabsf(P0[idx + 1] - p) - (float)((prm.length + prm.length) * 0.5); dv = v - V0[idx + 1]; }
-            idm_step_f32(p, v, dp, dv, prm, a.dt_d, o);
-        } else {
-            const double p = P0[idx], v = V0[idx];
-            double dp, dv;
-            if (i == n - 1) { dp = (double)hd_s[2 * m]; dv = (double)hd_s[2 * m + 1]; }
-            else { dp = fabs((double)P0[idx + 1] - p) - ((prm.length + prm.length) * 0.5); dv = v - (double)V0[idx + 1]; }
-            // (differentiable episode: the head gap is a float32 tensor in the reference, its vehicle's step mixed arithmetic -- idm_device.hpp)
-            idm_step_lane(P0[idx], V0[idx], dp, dv, i == n - 1 && !hard, prm, a.dt_d, o);
-        }
+        auto one_step = [&](const IdmParams &pm) {
+            if (f32_ladder) {            // `micro` mode, differentiable: the reference steps these lanes in float32 tensor arithmetic (idm_device.hpp)
+                const float p = P0[idx], v = V0[idx];
+                float dp, dv;
+                if (i == n - 1) { dp = hd_s[2 * m]; dv = hd_s[2 * m + 1]; }
+                else { dp = fabsf(P0[idx + 1] - p) - (float)((pm.length + pm.length) * 0.5); dv = v - V0[idx + 1]; }
+                idm_step_f32(p, v, dp, dv, pm, a.dt_d, o);
+            } else {
+                const double p = P0[idx], v = V0[idx];
+                double dp, dv;
+                if (i == n - 1) { dp = (double)hd_s[2 * m]; dv = (double)hd_s[2 * m + 1]; }
+                else { dp = fabs((double)P0[idx + 1] - p) - ((pm.length + pm.length) * 0.5); dv = v - (double)V0[idx + 1]; }
+                // (differentiable episode: the head gap is a float32 tensor in the reference, its vehicle's step mixed arithmetic -- idm_device.hpp)
+                idm_step_lane(P0[idx], V0[idx], dp, dv, i == n - 1 && !hard, pm, a.dt_d, o);
+            }
+        };
+        if (a.veh_params) {          // this vehicle's own attributes: the row of its route (micro_vehicle.py:5-28)
+            const double *q = a.veh_params + 6 * (size_t)vroute[idx];
+            IdmParams pv;
+            pv.a_max = q[0]; pv.a_pref = q[1]; pv.v_target = q[2]; pv.min_space = q[3]; pv.time_pref = q[4]; pv.length = prm.length;
+            one_step(pv);
+        } else one_step(prm);
         if (o.collided) net_fault(a.err, DHTS_FAULT_COLLISION, t, a.micro_lanes[m], i);
         P1[idx] = o.np; V1[idx] = o.nv;
         if (tape) tape[idx] = make_float4(o.dE[2], o.dE[3], o.dLd[2], o.dLd[3]);
@@ -1835,7 +1844,7 @@ static NsArgs ns_args(const dhts_net_desc *d, const dhts_netstep_tables *t, int 
     a.nxt_ptr = h.net.nxt_ptr; a.nxt_idx = h.net.nxt_idx; a.prv_ptr = h.net.prv_ptr; a.prv_idx = h.net.prv_idx;
     a.inter_ptr = t->inter_ptr; a.inter_idx = t->inter_idx;
     a.cell_lane = t->cell_lane; a.table_stride = h.net.replica_stride; a.draws_stride = h.draws_stride;
-    a.n_edges = h.net.n_edges; a.n_islots = t->n_inter_slots; a.has_source = h.lane_source != nullptr; a.n_routes = h.n_routes; a.tensor_ladder = h.micro_tensor_ladder;
+    a.n_edges = h.net.n_edges; a.n_islots = t->n_inter_slots; a.has_source = h.lane_source != nullptr; a.n_routes = h.n_routes; a.tensor_ladder = h.micro_tensor_ladder; a.veh_params = h.veh_params;
     { int lg = 0; for (int g = 0; g < t->n_groups; ++g) lg += t->groups[g].n_lanes; a.NI = d->n_cells + lg; }
     a.ws = reinterpret_cast<char *>(ws); a.lo = ns_layout(d, t);
     a.hist = hist; a.queue = queue; a.reward = reward; a.counts = counts; a.err = err;

@@ -83,9 +83,10 @@ class MacroNetworkTables:
                                   [env.schedule[k] for k in keys])
 
 
-def group_routes(routes, n_lanes):
+def group_routes(routes, n_lanes, vehicle_params=None):
     """Pre-drawn vehicle routes [n][stride] (-1 padded) -> (rows stably sorted by their first lane, route_ptr [L + 1]).
-    A spawn order recorded from the reference stays intact per lane, which is all the hand-off logic can observe."""
+    A spawn order recorded from the reference stays intact per lane, which is all the hand-off logic can observe.
+    vehicle_params [n][6] (the IDM attributes of the vehicle that takes each row): returned third, in the rows' new order."""
     routes = np.ascontiguousarray(routes, dtype=np.int32)
     first = routes[:, 0]
     order = np.argsort(first, kind="stable")
@@ -93,6 +94,11 @@ def group_routes(routes, n_lanes):
     for f in first:
         if f >= 0:
             ptr[f + 1] += 1
+    if vehicle_params is not None:
+        vp = np.ascontiguousarray(vehicle_params, dtype=np.float64)
+        if vp.shape != (routes.shape[0], 6):
+            raise ValueError("vehicle_params must be [%d routes][6] (accel_max, accel_pref, target_speed, min_space, time_pref, length)" % routes.shape[0])
+        return routes[order], np.cumsum(ptr).astype(np.int32), np.ascontiguousarray(vp[order])
     return routes[order], np.cumsum(ptr).astype(np.int32)
 
 

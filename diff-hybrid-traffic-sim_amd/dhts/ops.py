@@ -565,7 +565,9 @@ class DeviceHybridTables:
     HybridNetworkTables (shared by all replicas) or a list of them (one per replica: same topology, own inflow schedules
     and per-step macro routes)."""
 
-    def __init__(self, tables, routes, device, records_per_step=0, lane_capacity=0):
+    def __init__(self, tables, routes, device, records_per_step=0, lane_capacity=0, vehicle_params=None):
+        """vehicle_params [n_routes][6] (rows as `routes`): the IDM attributes of the vehicle that takes each route row
+        (dhts_hybrid_tables::veh_params); None = every vehicle a default_micro_vehicle(speed_limit)."""
         import numpy as np
         if lane_capacity not in (0, 16, 32, 64, 128):
             raise ValueError("lane_capacity (vehicles a micro lane holds at once) must be 0 (= 16), 16, 32, 64 or 128")
@@ -587,7 +589,12 @@ class DeviceHybridTables:
         routes = np.ascontiguousarray(routes, dtype=np.int32)
         if routes.ndim != 2 or routes.shape[0] < 1 or routes.shape[1] > 32:
             raise ValueError("routes must be [n_routes >= 1][stride <= 32]")
-        routes, route_ptr = group_routes(routes, t.n_lanes)
+        self._veh_params = None
+        if vehicle_params is not None:
+            routes, route_ptr, vp = group_routes(routes, t.n_lanes, vehicle_params)
+            self._veh_params = up(vp, torch.float64)
+        else:
+            routes, route_ptr = group_routes(routes, t.n_lanes)
         self.n_routes, self.route_stride = int(routes.shape[0]), int(routes.shape[1])
         self.records_per_step = int(records_per_step)
         self.n_micro = int((np.asarray(t.lane_macro) == 0).sum())
@@ -642,7 +649,7 @@ class DeviceHybridTables:
         src = (k[18], k[19]) if self.has_sources else (None, None)
         return _lib.HybridTables(self.net, k[13], k[14], k[15], k[16], k[17], self.n_routes, self.route_stride, self.records_per_step,
                                  int(loss_steps), self.n_micro, src[0], src[1], self.n_draws, self.draws_stride, self.lane_capacity,
-                                 1 if self.micro_tensor_ladder else 0)
+                                 1 if self.micro_tensor_ladder else 0, None if self._veh_params is None else self._veh_params.data_ptr())
 
 
 class NetHybridRollout(torch.autograd.Function):

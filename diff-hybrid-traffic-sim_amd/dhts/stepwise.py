@@ -75,7 +75,7 @@ class StepwiseNetwork:
     vehicle spawned onto a micro lane takes that lane's k-th route (cyclically; waiting lists of micro source lanes in admission
     order, no wrap-around) -- as for dhts.ops.DeviceHybridTables.  lane_capacity: vehicles a micro lane holds at once (1 .. 1024)."""
 
-    def __init__(self, tables, routes, device, lane_capacity=32, max_events=0, persistent=False):
+    def __init__(self, tables, routes, device, lane_capacity=32, max_events=0, persistent=False, vehicle_params=None):
         """persistent: the whole episode in ONE kernel per direction, one workgroup per replica (csrc/netstep_hybrid.hip: the same
         device functions with workgroup barriers instead of kernel boundaries; ~10 x fewer microseconds per step for the grids the
         reference builds).  `tables` may then be a LIST of tables of one topology (own schedules / per-step routes / draws each): one
@@ -156,7 +156,11 @@ class StepwiseNetwork:
         routes = np.ascontiguousarray(routes, dtype=np.int32)
         if routes.ndim != 2 or routes.shape[0] < 1 or routes.shape[1] > 32:
             raise ValueError("routes must be [n_routes >= 1][stride <= 32]")
-        routes, route_ptr = group_routes(routes, L)
+        vp = None
+        if vehicle_params is not None:        # [n_routes][6], rows as `routes` (dhts_hybrid_tables::veh_params)
+            routes, route_ptr, vp = group_routes(routes, L, vehicle_params)
+        else:
+            routes, route_ptr = group_routes(routes, L)
         self.n_routes, self.route_stride = int(routes.shape[0]), int(routes.shape[1])
         up = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=device)      # noqa: E731
         pad1 = lambda a: a if len(a) else np.zeros(1, dtype=np.int32)      # noqa: E731
@@ -186,6 +190,8 @@ class StepwiseNetwork:
                 d = np.asarray(t.draws, dtype=np.float64)
                 self.n_draws = len(d)
             self.d["lane_source"], self.d["draws"] = up(t.lane_source, i32), up(d, f64)
+        if vp is not None:
+            self.d["veh_params"] = up(vp, f64)
         self.err = ops.new_error_record(device)
 
     # ---- per-episode data in place (same topology): new schedules / per-step routes / draws ----
@@ -236,7 +242,7 @@ class StepwiseNetwork:
         src = (p("lane_source"), p("draws")) if self.has_sources else (None, None)
         hyb = _lib.HybridTables(net, p("lane_macro"), p("lane_len"), p("conv_next"), p("routes"), p("route_ptr"), self.n_routes,
                                 self.route_stride, 0, int(loss_steps), self.n_micro, src[0], src[1], self.n_draws, self.draws_stride,
-                                self.lane_capacity, 1 if self.micro_tensor_ladder else 0)
+                                self.lane_capacity, 1 if self.micro_tensor_ladder else 0, p("veh_params") if "veh_params" in d else None)
         return _lib.NetstepTables(hyb, p("lane_gpos"), self._garr, len(self.groups), p("micro_lanes"), p("lane_mslot"), p("cap_lanes"),
                                   p("lane_cslot"), self.n_caps, p("inter_ptr"), p("inter_idx"), self.max_events, p("if_lane"), p("cell_lane"),
                                   1 if self.persistent else 0, int(d["inter_idx"].numel()))

@@ -83,6 +83,14 @@ class Box:
         self.dtype = np.dtype(dtype)
 
 
+def _vehicle_attributes(v, sim):
+    """(accel_max, accel_pref, target_speed, min_space, time_pref, length) of a MicroVehicle; None = default_micro_vehicle(speed_limit)."""
+    if v is None:
+        from road.vehicle.micro_vehicle import MicroVehicle
+        v = MicroVehicle.default_micro_vehicle(sim.speed_limit)
+    return [float(v.accel_max), float(v.accel_pref), float(v.target_speed), float(v.min_space), float(v.time_pref), float(v.length)]
+
+
 class ItscpEnv:
 
     def __init__(self, schedule_callback=itscp_random_schedule):
@@ -460,16 +468,24 @@ class ItscpEnv:
                     net = self._batched_net = BatchedMacroNetwork(tabs, device)
                 return ("batched", net)
             tab = HybridNetworkTables.from_env(self)
+            veh_params = getattr(self, "fused_vehicle_params", None)     # [routes][6] beside `fused_routes` (hybrid mode), or None
             if mode == "micro":
                 # every lane an IDM lane; source lanes admit their waiting vehicles against np.random draws
                 # (_simulator.py:153-174): the waiting routes in admission order (the list is popped from its end) are
                 # the route rows, the draws of the episode are drawn up front (fused_draws replays a recorded stream)
-                rows = []
+                rows, vrows = [], []
                 for l in range(tab.n_lanes):
-                    for r in reversed(sim.lane_waiting_micro_route.get(l, [])):
+                    waiting = sim.lane_waiting_micro_vehicle.get(l, [])
+                    for k, r in enumerate(reversed(sim.lane_waiting_micro_route.get(l, []))):
                         r = list(r.route)[:32]
                         rows.append(r + [-1] * (32 - len(r)))
+                        v = waiting[len(waiting) - 1 - k] if k < len(waiting) else None
+                        vrows.append(_vehicle_attributes(v, sim))
                 routes = np.asarray(rows if rows else [[-1, -1]], dtype=np.int32)
+                # the waiting vehicles' own IDM attributes ride beside their routes (dhts_hybrid_tables::veh_params) unless every one of
+                # them is the default vehicle the reference's reset() builds (_env.py:205-219)
+                if any(v != _vehicle_attributes(None, sim) for v in vrows):
+                    veh_params = np.asarray(vrows, dtype=np.float64)
                 self._fused_n_draws = T * max(1, int(tab.lane_source.sum()))
                 tab.set_micro_sources(np.full(self._fused_n_draws, 2.0))
             else:
@@ -493,21 +509,22 @@ class ItscpEnv:
             except ValueError:
                 fits = False
             if fits and not getattr(self, "_fused_prefer_stepwise", False) and lane_cap in (0, 16, 32, 64, 128):
-                return (mode, ops.DeviceHybridTables(tab, routes, device, lane_capacity=lane_cap))
+                return (mode, ops.DeviceHybridTables(tab, routes, device, lane_capacity=lane_cap, vehicle_params=veh_params))
             # beyond one workgroup (cells + lanes > 960, > 64 IDM lanes, > 16 spawning lanes) or beyond the fused kernels' vehicle
             # capacities: step by step on the device (dhts/stepwise.py)
             if not lane_cap:
                 from dhts.stepwise import default_lane_capacity
                 lane_cap = self._stepwise_lane_capacity = default_lane_capacity(tab, self.simulator.vehicle_length)
-            return ("stepwise", self._stepwise_net(tab, routes, device, lane_cap))
+            return ("stepwise", self._stepwise_net(tab, routes, device, lane_cap, veh_params))
         except ValueError:
             return ("none", None)
 
-    def _stepwise_net(self, tab, routes, device, lane_cap):
+    def _stepwise_net(self, tab, routes, device, lane_cap, veh_params=None):
         from dhts.stepwise import StepwiseNetwork
         net = getattr(self, "_stepwise_cache", None)            # survives reset(): same topology -> new per-episode tables only
         max_events = int(getattr(self, "_stepwise_max_events", 0))
-        if net is not None and net[1] == (lane_cap, routes.shape, routes.tobytes()) and net[0].max_events == max_events:
+        vkey = None if veh_params is None else np.asarray(veh_params, dtype=np.float64).tobytes()
+        if net is not None and net[1] == (lane_cap, routes.shape, routes.tobytes(), vkey) and net[0].max_events == max_events:
             try:
                 net[0].update(tab)
                 if tab.lane_source.any():
@@ -520,8 +537,8 @@ class ItscpEnv:
         # DhtsError at the first launch and is rebuilt in the stepwise form (a handful of launches per step)
         from dhts.stepwise import persistent_form_pays
         persistent = bool(self.config.get("stepwise_persistent", persistent_form_pays(tab))) and not getattr(self, "_stepwise_no_persistent", False)
-        sw = StepwiseNetwork(tab, routes, device, lane_capacity=lane_cap, persistent=persistent, max_events=max_events)
-        self._stepwise_cache = (sw, (lane_cap, routes.shape, routes.tobytes()))
+        sw = StepwiseNetwork(tab, routes, device, lane_capacity=lane_cap, persistent=persistent, max_events=max_events, vehicle_params=veh_params)
+        self._stepwise_cache = (sw, (lane_cap, routes.shape, routes.tobytes(), vkey))
         return sw
 
     def _simulate(self, action, differentiable):

@@ -448,6 +448,14 @@ typedef struct dhts_hybrid_tables {
      * other network, with or without source lanes): the analytic operator's float64 ladder (dmicro_lane.py:87-127), the head vehicle in
      * mixed arithmetic while its gap is a tensor.  The host says which (ItscpEnv's `micro` branch sets 1). */
     int32_t micro_tensor_ladder;
+    /* The vehicles' IDM attributes, [n_routes][6] DOUBLE (device) beside the route table -- row i belongs to the vehicle that takes
+     * route row i: (accel_max, accel_pref, target_speed, min_space, time_pref, length) as MicroVehicle holds them
+     * (road/vehicle/micro_vehicle.py:5-28; random_micro_vehicle :75-121) -- or NULL: every vehicle is a
+     * MicroVehicle.default_micro_vehicle(speed_limit) (:31-72), which is all the reference's network code ever builds
+     * (road/network/conversion.py:51, road_network.py:582-591).  Rows are reused with their routes (the k-th vehicle spawned onto
+     * lane m takes row route_ptr[m] + k mod rows of m).  length must equal the descriptor's vehicle_length (the hand-offs and the
+     * loss use one length; both of the reference's factories give DEFAULT_VEHICLE_LENGTH). */
+    const double *veh_params;
 } dhts_hybrid_tables;
 size_t dhts_net_hybrid_workspace_bytes(const dhts_net_desc *d, const dhts_hybrid_tables *t);
 /* What dhts_net_hybrid_rollout_fwd / _bwd would launch for (d, t) under the current DHTS_OPT_HYB_PACK (no device work): plan[0] = 1

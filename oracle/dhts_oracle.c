@@ -793,6 +793,10 @@ int oracle_micro_source_draws_used(void) { return oracle_src_used; }
  * episodes step them with oracle_micro_step_f32.  Said by the caller (dhts_hybrid_tables::micro_tensor_ladder), not inferred. */
 static int oracle_tensor_ladder = 0;
 void oracle_set_micro_tensor_ladder(int on) { oracle_tensor_ladder = on; }
+/* [n_routes][6] attributes of the vehicle that takes each route row (dhts_hybrid_tables::veh_params), or NULL: every vehicle a
+ * MicroVehicle.default_micro_vehicle(speed_limit). */
+static const double *oracle_veh_params = NULL;
+void oracle_set_vehicle_params(const double *p) { oracle_veh_params = p; }
 
 typedef struct {            /* per step: phase signals of every intersection and their inputs */
     float we, ns, a, prog;

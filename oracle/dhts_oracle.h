@@ -143,6 +143,7 @@ void oracle_set_hard(int hard);
  * upstream lane), the host's admission draws in call order; NULL = none.  Process-wide, set before the call. */
 void oracle_set_micro_sources(const int *lane_source, const double *draws, int n_draws);
 void oracle_set_micro_tensor_ladder(int on);
+void oracle_set_vehicle_params(const double *params);      /* [n_routes][6] beside the route table, or NULL */
 int oracle_micro_source_draws_used(void);
 typedef struct oracle_net_desc {
     int n_lanes, n_cells, T, n_inter_sq, frames_per_phase, n_action;

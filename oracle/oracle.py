@@ -291,7 +291,7 @@ def net_macro(tab, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed
 
 
 def net_hybrid(tab, routes, route_ptr, action, n_inter_sq, frames_per_phase, dt, u_max, static_speed=0.2, vehicle_length=5.0,
-               t_cut=None, want_grad=True, want_hist=False, hard=False):
+               t_cut=None, want_grad=True, want_hist=False, hard=False, vehicle_params=None):
     """tab: dhts.network.HybridNetworkTables; routes [n][stride] int (-1 padded) grouped by first lane + route_ptr [L+1]
     (dhts.network.group_routes).  hard: an evaluation episode (ItscpEnv.step(action, False)): hard thresholds, no gradient."""
     l = lib()
@@ -306,6 +306,10 @@ def net_hybrid(tab, routes, route_ptr, action, n_inter_sq, frames_per_phase, dt,
     else:
         l.oracle_set_micro_sources(None, None, 0)
     l.oracle_set_micro_tensor_ladder(1 if getattr(tab, "micro_tensor_ladder", False) else 0)
+    l.oracle_set_vehicle_params.argtypes = [C.c_void_p]
+    vp = None if vehicle_params is None else _f64(vehicle_params)          # [n_routes][6], rows as the GROUPED routes
+    assert vp is None or vp.shape == (np.asarray(routes).shape[0], 6)
+    l.oracle_set_vehicle_params(None if vp is None else _p(vp))
     l.oracle_net_hybrid.argtypes = ([C.POINTER(NetDesc)] + [C.c_void_p] * 14 + [C.c_int, C.c_int, C.c_void_p, C.c_int]
                                     + [C.c_void_p] * 8)
     action = _f32(action)

@@ -591,3 +591,76 @@ def test_fused_state_rollout_matches_lane_by_lane_mirror(cuda, seed, N, T):
             assert state_report("fused vs lane by lane (seed %d): %s" % (seed, key), got[key].detach().cpu().numpy(), ref[key].detach().cpu().numpy()) <= TOL_STATE, key
     assert grad_report("fused vs lane by lane d loss / d r0", r1.grad.cpu().numpy(), g_r_ref) <= TOL_GRAD
     assert grad_report("fused vs lane by lane d loss / d u0", u1.grad.cpu().numpy(), g_u_ref) <= TOL_GRAD
+
+
+@pytest.mark.parametrize("seed,N,T", [(4, 10, 320), (5, 8, 260)])
+def test_fused_state_rollout_with_a_leader_in_sight_across_lanes(cuda, seed, N, T):
+    """A plain network whose IDM lane is followed by ANOTHER IDM lane (macro -> micro -> micro -> macro): while the head vehicle of
+    lane 1 has a leader on lane 2 its head gap is a float32 tensor in the reference (road_network.py:540-580) and its step mixed
+    arithmetic (dmicro_lane.py:155-219 leaves the tensor gap alone) -- the fused state kernels follow since round 6, like the drop-in
+    classes stepped lane by lane: the vehicles' final (position, speed) are EQUAL bit for bit, cells <= 1e-5, gradients <= 1e-4."""
+    import torch
+    from dhts import ops
+    from dhts.network import HybridNetworkTables
+    from road.lane.dmacro_lane import dMacroLane
+    from road.lane.dmicro_lane import dMicroLane
+    from road.network.road_network import RoadNetwork
+    rng = np.random.default_rng(seed)
+    dx, dt, um = 5.0, 0.01, 30.0
+    r0n = rng.uniform(0.4, 1.0, N).astype(np.float32)
+    u0n = rng.uniform(10.0, um, N).astype(np.float32)
+    bd_r = rng.uniform(0.0, 1.0, 4).astype(np.float32)
+    bd_u = rng.uniform(0.0, um, 4).astype(np.float32)
+    Lb = N * dx / 2                                     # two short IDM lanes: vehicles change lanes within the horizon
+    np.random.seed(seed)
+    r0, u0 = (torch.tensor(x, device=cuda, requires_grad=True) for x in (r0n, u0n))
+    net = RoadNetwork(um)
+    a = dMacroLane(0, N * dx, um, dx)
+    a.set_leftmost_cell(torch.tensor(bd_r[0], device=cuda), torch.tensor(bd_u[0], device=cuda))
+    a.set_rightmost_cell(torch.tensor(bd_r[1], device=cuda), torch.tensor(bd_u[1], device=cuda))
+    net.add_lane(a)
+    a.set_state_vector_u(r0, u0)
+    b1, b2 = dMicroLane(1, Lb, um), dMicroLane(2, Lb, um)
+    net.add_lane(b1)
+    net.add_lane(b2)
+    c = dMacroLane(3, N * dx, um, dx)
+    c.set_leftmost_cell(torch.tensor(bd_r[2], device=cuda), torch.tensor(bd_u[2], device=cuda))
+    c.set_rightmost_cell(torch.tensor(bd_r[3], device=cuda), torch.tensor(bd_u[3], device=cuda))
+    net.add_lane(c)
+    for x, y in ((0, 1), (1, 2), (2, 3)):
+        net.connect_lane(x, y)
+    net.macro_route = net.create_random_macro_route()
+    in_sight = 0
+    for t in range(T):
+        net.forward(dt, True)
+        in_sight += int(isinstance(b1.head_position_delta, torch.Tensor))
+    assert in_sight >= 20                               # the case this test is about occurred
+    rA, _, uA = a.get_state_vector()
+    rC, _, uC = c.get_state_vector()
+    veh_ref = sorted([(1, float(v.position), float(v.speed)) for v in b1.curr_vehicle] + [(2, float(v.position), float(v.speed)) for v in b2.curr_vehicle])
+    loss = (rC ** 2).sum() + (uC ** 2).sum() + (rA ** 2).sum() + (uA ** 2).sum()
+    for lane in (b1, b2):
+        if lane.num_vehicle():
+            p_, v_ = lane.get_state_vector()
+            loss = loss + 1e-4 * (p_ ** 2).sum() + (v_ ** 2).sum()
+    loss.backward()
+    # fused
+    tab = HybridNetworkTables.plain([1, 0, 0, 1], [N, 0, 0, N], [N * dx, Lb, Lb, N * dx], [(0, 1), (1, 2), (2, 3)], T, macro_route=[1, -1, -1, -1])
+    dtab = ops.DeviceHybridTables(tab, np.array([[1, 2, 3]], dtype=np.int32), cuda)
+    r1, u1 = (torch.tensor(x, device=cuda, requires_grad=True) for x in (r0n, u0n))
+    r_all = torch.cat([r1, torch.zeros(N, device=cuda)])[None]
+    u_all = torch.cat([u1, torch.full((N,), um, device=cuda)])[None]
+    ghost0 = torch.tensor([[[bd_r[0], bd_u[0], bd_r[1], bd_u[1]], [0.0, um, 0.0, um], [0.0, um, 0.0, um], [bd_r[2], bd_u[2], bd_r[3], bd_u[3]]]],
+                          dtype=torch.float32, device=cuda)
+    rT, yT, uT, veh, events, counts = ops.net_hybrid_state_rollout(r_all, u_all, dtab, dt, um, ghost0=ghost0, plain=True)
+    v = veh[0, :int(counts[0, 0])]
+    on = v[v[:, 0] > 0]
+    veh_got = sorted((int(x[0]), float(x[1]), float(x[2])) for x in on.detach().cpu().numpy())
+    assert len(veh_got) == len(veh_ref) >= 2
+    assert veh_got == veh_ref, (veh_got, veh_ref)       # bit for bit: the same operator arithmetic, head vehicle included
+    loss1 = (rT[0, N:] ** 2).sum() + (uT[0, N:] ** 2).sum() + (rT[0, :N] ** 2).sum() + (uT[0, :N] ** 2).sum() + 1e-4 * (on[:, 1] ** 2).sum() + (on[:, 2] ** 2).sum()
+    loss1.backward()
+    for got, ref, key in ((rT[0, :N], rA, "rA"), (uT[0, :N], uA, "uA"), (rT[0, N:], rC, "rC"), (uT[0, N:], uC, "uC")):
+        assert state_report("leader in sight (seed %d): %s" % (seed, key), got.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= TOL_STATE, key
+    assert grad_report("leader in sight d loss / d r0", r1.grad.cpu().numpy(), r0.grad.cpu().numpy()) <= TOL_GRAD
+    assert grad_report("leader in sight d loss / d u0", u1.grad.cpu().numpy(), u0.grad.cpu().numpy()) <= TOL_GRAD

@@ -343,3 +343,30 @@ def test_episode_copy_leaves_the_environment_alone(cuda, golden_dir):
         env.rewind()
         _, r3, _, _ = env.step(action, False)
         assert float(r3) == float(r0)
+
+
+@pytest.mark.parametrize("path", ["fused", "stepwise"])
+def test_env_steps_waiting_vehicles_with_their_own_attributes(cuda, golden_dir, path):
+    """Round 6: an ItscpEnv in `micro` mode whose waiting vehicles are NOT the default vehicle (here: the attributes of the reference
+    run `micro_rv`, seeded MicroVehicle.random_micro_vehicle draws) hands them to the device paths beside the routes
+    (dhts_hybrid_tables::veh_params): ItscpEnv.step reproduces the reference's reward and d reward / d action."""
+    import json
+    import torch
+    g = np.load(os.path.join(golden_dir, "itscp_micro_rv.npz"))
+    m = meta_of(g)
+    env = build_env(g, m, replay_routes=False)
+    sim = env.simulator
+    want = {int(l): p for l, p in json.loads(str(g["waiting_params"])).items()}
+    for l, lst in sim.lane_waiting_micro_vehicle.items():
+        assert len(lst) == len(want[int(l)])
+        for v, p in zip(lst, want[int(l)]):
+            v.accel_max, v.accel_pref, v.target_speed, v.min_space, v.time_pref, v.length = p
+    env.fused_draws = g["rand_draws"]
+    if path == "stepwise":
+        env._fused_prefer_stepwise, env._fused_lane_capacity = True, 32
+    action = torch.tensor(g["action"], device=cuda, requires_grad=True)
+    _, reward, _, _ = env.step(action, True)
+    reward.backward()
+    assert env.last_path == path and env.fused_counts[0] == m["n_vehicle_spawned"]
+    assert abs(float(reward.detach()) - float(g["reward"])) <= TOL_STATE * abs(float(g["reward"]))
+    assert np.abs(action.grad.cpu().numpy() - g["g_action"]).max() <= TOL_GRAD * np.abs(g["g_action"]).max()

@@ -317,6 +317,26 @@ def itscp_micro_tables(g):
     return t, m, np.asarray(rows, dtype=np.int32)
 
 
+def itscp_vehicle_params(g):
+    """[n_routes][6] IDM attributes in the order of the fixture's route rows (spawn_routes for a hybrid network; the waiting lists in
+    admission order, as itscp_micro_tables lays them out, for `micro` mode), or None for a fixture of default vehicles."""
+    import json
+    if "veh_params" not in g.files:
+        return None
+    if g["veh_params"].shape[0]:
+        return np.ascontiguousarray(g["veh_params"], dtype=np.float64)
+    waiting = {int(l): p for l, p in json.loads(str(g["waiting_params"])).items()}
+    if not any(len(p) for p in waiting.values()):
+        return None
+    routes = {int(l): r for l, r in json.loads(str(g["waiting_routes"])).items()}
+    rows = []
+    for l in sorted(routes):
+        assert len(routes[l]) == len(waiting.get(l, []))
+        for p in reversed(waiting.get(l, [])):
+            rows.append(p)
+    return np.asarray(rows, dtype=np.float64)
+
+
 @pytest.mark.parametrize("name", ["micro_small", "micro", "micro_2x2", "micro_p2", "micro_l10"])
 def test_itscp_micro_mode_network(oracle, golden_dir, name):
     """itscp `micro` mode (run_itscp_micro.sh: 40 IDM lanes, 65 vehicles admitted stochastically over 300 steps; and a 16-lane
@@ -484,3 +504,58 @@ def test_source_ghost_in_double(oracle, golden_dir):
     for name in ("hybrid_short", "hybrid_p2", "hybrid_n2"):
         assert res[(1, name)] < res[(0, name)] <= TOL_STATE
     assert res[(1, "hybrid_p2")] <= 0.7 * res[(0, "hybrid_p2")]
+
+
+ILL_CONDITIONED_FULL_GRADIENT = {"hybrid_rv"}
+
+
+@pytest.mark.parametrize("name", ["micro_rv", "micro_rv_2x2", "hybrid_rv", "hybrid_rv_l10", "eval_hybrid_rv"])
+def test_itscp_network_with_per_vehicle_idm_attributes(oracle, golden_dir, name):
+    """Round 6: vehicles that are NOT default_micro_vehicle -- reference runs whose vehicles take the attributes of a seeded
+    MicroVehicle.random_micro_vehicle (road/vehicle/micro_vehicle.py:75-121; tools/gen_goldens.py random_vehicles): the restatement with
+    the per-vehicle table beside the routes (dhts_hybrid_tables::veh_params) reproduces spawn counts, queues, reward and
+    d reward / d action; with default vehicles it does not."""
+    if not os.path.exists(os.path.join(golden_dir, "itscp_%s.npz" % name)):
+        pytest.skip("golden not generated")
+    from dhts.network import group_routes
+    g = load(golden_dir, "itscp_%s.npz" % name)
+    hard = name.startswith("eval")
+    if "micro" in name:
+        t, m, rows = itscp_micro_tables(g)
+    else:
+        t, m = itscp_hybrid_tables(g)
+        rows = g["spawn_routes"]
+    vp = itscp_vehicle_params(g)
+    assert vp is not None and vp.shape == (rows.shape[0], 6) and not np.allclose(vp[:, 0], vp[0, 0])
+    routes, route_ptr, gvp = group_routes(rows, t.n_lanes, vp)
+    args = (m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"], m["speed_limit"],
+            m["static_speed"], m["vehicle_length"])
+    o = oracle.net_hybrid(t, routes, route_ptr, g["action"], *args, vehicle_params=gvp, hard=hard)
+    assert o["rc"] == 0 and o["n_spawned"] == m["n_vehicle_spawned"] and m["n_vehicle_spawned"] >= 4
+    assert rel_max(o["queue"].T, g["queue"]) <= TOL_STATE
+    assert abs(o["reward"] - float(g["reward"])) <= 1e-5 * abs(float(g["reward"]))
+    run = lambda a, **kw: oracle.net_hybrid(t, routes, route_ptr, a, *args, vehicle_params=gvp, **kw)      # noqa: E731
+    scale = np.abs(g["g_action"]).max() if not hard else 1.0
+    if not hard and name not in ILL_CONDITIONED_FULL_GRADIENT:
+        assert grad_report("G8 %s d reward / d action" % name, o["g_action"], g["g_action"]) <= TOL_GRAD
+    if not hard and "g_action_cut_steps" in g.files:
+        for t0, ref in zip(g["g_action_cut_steps"], g["g_action_cut"]):
+            assert np.abs(run(g["action"], t_cut=int(t0))["g_action"] - ref).max() <= TOL_GRAD * scale, int(t0)
+    if name in ILL_CONDITIONED_FULL_GRADIENT:
+        # 10 deposits, the last ones standing behind a red light for the rest of the 480 steps (the 1.144-per-step amplification of
+        # test_restricted_gradient_lattice_of_the_standing_vehicle, 685 equal-speed decisions within 5e-8 of the solver's threshold):
+        # the gradient of the reward's first 120 / 240 / 360 steps is the reference's to 1e-7 (above), but the WHOLE gradient moves by
+        # percents when the action moves by one float32 ulp -- no restatement can be held to 1e-4 of a number like that, and the
+        # kernels are held to the restatement instead (tests/test_stepwise_gpu.py).  Shown here:
+        rng = np.random.default_rng(0)
+        moved = []
+        for _ in range(3):
+            a = g["action"].copy()
+            for i in range(len(a)):
+                if rng.random() < 0.5:
+                    a[i] = np.nextafter(a[i], np.float32(2.0) if rng.random() < 0.5 else np.float32(-2.0))
+            moved.append(np.abs(run(a)["g_action"] - o["g_action"]).max() / scale)
+        assert max(moved) > 10 * TOL_GRAD, moved
+        assert np.abs(o["g_action"] - g["g_action"]).max() <= max(moved) * scale          # ... and the reference's number is within that spread
+    d = oracle.net_hybrid(t, routes, route_ptr, g["action"], *args, hard=hard)
+    assert d["rc"] != 0 or rel_max(d["queue"].T, g["queue"]) > 1e-3            # the attributes matter

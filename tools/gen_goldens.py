@@ -651,8 +651,14 @@ class SolverMargins:
                     min_equal_speed_margin_at=[self.min_equal[1], self.min_equal[2]], min_vacuum_margin=self.min_vacuum)
 
 
-def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, action_kind, problem=1, differentiable=True):
-    """differentiable=False: an EVALUATION episode, env._simulate(action, False) under no_grad as Trainer.evaluate runs it
+def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, action_kind, problem=1, differentiable=True,
+              random_vehicles=False):
+    """random_vehicles: every vehicle that enters the network takes the attributes of a MicroVehicle.random_micro_vehicle(speed_limit)
+    (road/vehicle/micro_vehicle.py:75-121; the network code itself only ever builds default_micro_vehicle, conversion.py:51,
+    road_network.py:582-591) drawn from a stream of its own (seeded; the run's other host randomness -- routes, admission draws -- is
+    left as it would have been): the waiting vehicles of `micro` mode right after reset(), the flux capacitors' vehicles when they are
+    added.  The fixture holds the six attributes per vehicle (veh_params: spawn order; waiting_params: per lane, list order).
+    differentiable=False: an EVALUATION episode, env._simulate(action, False) under no_grad as Trainer.evaluate runs it
     (trainer.py:94-142): hard signal thresholds (_env.py:928-960), hard macro / micro boundaries (_simulator.py:116-137,
     264-276), hard is_static (_env.py:586-618).  The fixture then holds queues and reward only (no gradients)."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_stubs"))
@@ -666,6 +672,32 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
         env.config[k] = v
     env.reset()
     sim = env.simulator
+    veh_params, waiting_params = [], {}
+    if random_vehicles:
+        from road.vehicle.micro_vehicle import MicroVehicle
+        veh_state = [np.random.RandomState(100000 + seed).get_state()]
+
+        def randomize(nv):
+            keep = np.random.get_state()
+            np.random.set_state(veh_state[0])
+            # (hybrid networks: drawn for 0.7 x the speed limit -- a random vehicle's target speed reaches 1.2 x its argument, and a
+            # vehicle deposited into an ARZ cell above u_max ends the reference's own run in its CFL assert)
+            rv = MicroVehicle.random_micro_vehicle(sim.speed_limit * float(random_vehicles))
+            veh_state[0] = np.random.get_state()
+            np.random.set_state(keep)
+            for k in ("accel_max", "accel_pref", "target_speed", "min_space", "time_pref", "length"):
+                setattr(nv, k, getattr(rv, k))
+            return [float(getattr(nv, k)) for k in ("accel_max", "accel_pref", "target_speed", "min_space", "time_pref", "length")]
+        if mode == "micro":
+            for l, lst in sim.lane_waiting_micro_vehicle.items():
+                waiting_params[int(l)] = [randomize(nv) for nv in lst]
+        else:
+            add_orig = sim.add_vehicle
+
+            def add_logged(nv, nr):
+                veh_params.append(randomize(nv))
+                return add_orig(nv, nr)
+            sim.add_vehicle = add_logged
     keys = list(env.lane.keys())
     nl = len(keys)
     T = env.num_timestep
@@ -738,6 +770,7 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
             lane_tab=lane_tab, lane_str=np.array(lane_str), edges=edges, schedule=sched, macro_route=mroute, spawn_routes=sr,
             action=a0, reward=np.float64(float(reward)), queue=queue, rand_draws=np.array(rand_draws, dtype=np.float64),
             waiting_routes=np.array(json.dumps(waiting_routes)),
+            veh_params=np.array(veh_params, dtype=np.float64).reshape(len(veh_params), 6), waiting_params=np.array(json.dumps(waiting_params)),
             meta=meta(seed=seed, mode=mode, num_intersection=n_int, num_lane=n_lane, lane_length=lane_length,
                       policy_length=sim_len, signal_length=sig_len, speed_limit=60.0, cell_length=5.0, simulation_frequency=30,
                       static_speed=0.2, vehicle_length=5.0, T=T, n_vehicle_spawned=nveh, problem=problem,
@@ -794,6 +827,7 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
         g_action_cut_steps=np.array(cuts, dtype=np.int32), g_action_cut=np.array(g_cut, dtype=np.float32),
         rand_draws=np.array(rand_draws, dtype=np.float64),
         waiting_routes=np.array(json.dumps(waiting_routes)),
+        veh_params=np.array(veh_params, dtype=np.float64).reshape(len(veh_params), 6), waiting_params=np.array(json.dumps(waiting_params)),
         g_lane_late_ids=np.array(sorted(g_lane_late), dtype=np.int32),
         g_lane_late=np.array([g_lane_late[i] for i in sorted(g_lane_late)], dtype=np.float32).reshape(len(g_lane_late), len(a0)),
         meta=meta(seed=seed, mode=mode, num_intersection=n_int, num_lane=n_lane, lane_length=lane_length,
@@ -993,6 +1027,31 @@ def main():
             gen_itscp("eval_hybrid_5x5", "hybrid", 5, 1, 5.0, 8, 2, seed=73, action_kind="rand", problem=1, differentiable=False)
         if "eval_micro_2x2" in which:
             gen_itscp("eval_micro_2x2", "micro", 2, 2, 10.0, 4, 1, seed=83, action_kind="rand", problem=3, differentiable=False)
+        # vehicles with their own IDM attributes (round 6: the per-vehicle parameter table of the network kernels): the hybrid network over
+        # problem_2's inflows for 16 s, and `micro` mode for 4 s / on a 2 x 2 x 2 grid
+        if "hybrid_rv" in which:
+            os.environ["DHTS_FINE_CUTS"] = "120,240,360"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("hybrid_rv", "hybrid", 3, 1, 5.0, 16, 4, seed=121, action_kind="rand", problem=2, random_vehicles=0.7)
+        for nm, sd in (("hybrid_rv_b", 122), ("hybrid_rv_c", 123), ("hybrid_rv_d", 124)):       # 12 s: other seeds (see DESIGN: a fixture whose
+            if nm in which:                                                                      # full gradient is not on a knife edge is kept)
+                os.environ["DHTS_FINE_CUTS"] = "120,240,300"
+                os.environ.pop("DHTS_LANE_LATE", None)
+                gen_itscp(nm, "hybrid", 3, 1, 5.0, 12, 4, seed=sd, action_kind="rand", problem=2, random_vehicles=0.7)
+        if "hybrid_rv_l10" in which:
+            os.environ["DHTS_FINE_CUTS"] = "100,200"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("hybrid_rv_l10", "hybrid", 3, 1, 10.0, 10, 2, seed=155, action_kind="rand", problem=2, random_vehicles=0.7)
+        if "micro_rv" in which:
+            os.environ["DHTS_FINE_CUTS"] = "60"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("micro_rv", "micro", 1, 1, 30.0, 4, 2, seed=103, action_kind="rand", random_vehicles=1.0)
+        if "micro_rv_2x2" in which:
+            os.environ["DHTS_FINE_CUTS"] = "60"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("micro_rv_2x2", "micro", 2, 2, 10.0, 4, 1, seed=183, action_kind="rand", problem=3, random_vehicles=1.0)
+        if "eval_hybrid_rv" in which:
+            gen_itscp("eval_hybrid_rv", "hybrid", 3, 1, 5.0, 16, 4, seed=121, action_kind="rand", problem=2, differentiable=False, random_vehicles=0.7)
         if "hybrid_short" in which:      # 8 s: enough for the first vehicles to cross the interior intersection
             gen_itscp("hybrid_short", "hybrid", 3, 1, 5.0, 8, 2, seed=9, action_kind="rand")
 
