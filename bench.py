@@ -558,7 +558,7 @@ class ItscpHybridWorkload:
             self.ev.append(e)
         # A replica whose reverse sweep met 0 x inf (a head gap clamped to exactly 0, didm.py:60-70: the reference ASSERTS on such an
         # action, dmacro_lane.py:308) leaves NaN in its own row and a DHTS_FAULT_NAN record: a batch drops that member, as the
-        # replica-batched trainer does (DESIGN section 1), and the line says how many there were (no host sync here)
+        # replica-batched trainer does (DESIGN section 7), and the line says how many there were (no host sync here)
         g = self.drop_nonfinite(self.action.grad)
         return loss.detach(), g, g
 
@@ -612,8 +612,8 @@ class ItscpStepwiseWorkload(ItscpHybridWorkload):
     252 lanes (28 IDM lanes), 1 152 cells, 240 steps, 36 actions -- x 256 replicas like config 4 (own problem_1 inflow schedules and actions) on the
     stepwise path's persistent kernels (dhts_netstep_rollout_fwd / _bwd, one workgroup per replica; dhts/stepwise.py).  Not a BASELINE
     configuration: the reference's CLI reaches it with two flags, and until round 5 it ran lane by lane (minutes per episode)."""
-    limiter = {"rollout_fwd": "instruction issue + barriers of ONE compute unit per replica (16 wavefronts, ~17 phases per step, 240 steps; DESIGN section 9)",
-               "rollout_bwd": "instruction issue + barriers of ONE compute unit per replica (16 wavefronts, 240 steps; DESIGN section 9)"}
+    limiter = {"rollout_fwd": "instruction issue + barriers of ONE compute unit per replica (16 wavefronts, ~17 phases per step, 240 steps; docs/history/round_5_design_notebook.md section 9)",
+               "rollout_bwd": "instruction issue + barriers of ONE compute unit per replica (16 wavefronts, 240 steps; docs/history/round_5_design_notebook.md section 9)"}
 
     def moved_bytes_per_launch(self):
         """blocks dqs[c][3][2][2] (48 B) + state history (16 B) + loss constant (4 B) per cell-step, queue terms per lane-step"""

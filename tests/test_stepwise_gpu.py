@@ -143,7 +143,7 @@ def test_stepwise_random_actions_vs_oracle_and_fused(cuda, golden_dir, oracle, n
         assert state_report("queues vs oracle (%d)" % k, o["queue"], ref["queue"]) <= TOL_STATE
         assert abs(o["reward"] - ref["reward"]) <= 1e-5 * abs(ref["reward"])
         # an entry whose value the ORACLE itself does not reproduce after a one-ulp nudge of the action is float32 noise (a solver
-        # branch decided by the last bit, amplified over a standing queue: DESIGN section 8): such entries are not compared
+        # branch decided by the last bit, amplified over a standing queue: DESIGN section 2): such entries are not compared
         nudged = oracle.net_hybrid(t, gr, ptr, np.nextafter(act, np.float32(1.0)), *_args(m))["g_action"]
         scale = np.abs(ref["g_action"]).max()
         stable = np.abs(nudged - ref["g_action"]) <= 2e-5 * scale

@@ -1,6 +1,6 @@
 """The oracle against the reference fixtures at its defaults and with the two LIBRARY behaviours under the reference switched in:
 numpy's float32 summation tree for the running means (oracle.set_numpy_mean) and this torch build's float32 square root for the glue
-(oracle.set_sqrtf_hook(torch.sqrt ...)) -- DESIGN section 8, "What is left between the oracle and the reference".  CPU only.
+(oracle.set_sqrtf_hook(torch.sqrt ...)) -- docs/history/round_5_design_notebook.md section 8, "What is left between the oracle and the reference".  CPU only.
     python tools/probes/oracle_environment.py [fixture names ...]          (default: every itscp fixture, training and evaluation episodes)
 Prints, per fixture, the queue terms that differ from the reference's / all and the largest difference relative to the largest term."""
 import glob

@@ -4,7 +4,7 @@ and the loss constants' inputs after every step, and compares with the oracle's 
     python tools/probes/ref_state_trace.py hybrid_short [--source-ghost-f32] [--numpy-mean] [--torch-sqrt]
 (--source-ghost-f32: the oracle rounds a source lane's upstream ghost to float32 as it did until the end of round 5; the default feeds it
 to the solve in double, as the reference's Python floats do; --numpy-mean / --torch-sqrt: the oracle's running means as numpy's
-float32 summation computes them / its float32 glue square root through this torch build's kernel -- DESIGN section 8, "What is left")"""
+float32 summation computes them / its float32 glue square root through this torch build's kernel -- docs/history/round_5_design_notebook.md section 8, "What is left")"""
 import json
 import os
 import sys
