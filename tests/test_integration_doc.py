@@ -19,7 +19,7 @@ def snippets():
 
 def test_every_marked_snippet_is_known():
     assert set(snippets()) == {"binding", "rollouts", "net_macro", "net_batched", "net_hybrid", "net_eval", "net_micro", "net_state", "net_stepwise",
-                               "trainer_replicas"}
+                               "trainer_replicas", "net_vehicle_params"}
 
 
 def test_binding_snippet_loads_the_library():
@@ -91,6 +91,20 @@ def test_net_hybrid_snippet(cuda):
     exec(compile(snippets()["net_hybrid"], "INTEGRATION.md:net_hybrid", "exec"), ns)
     assert ns["reward"].shape == (2,) and action.grad is not None and torch.isfinite(action.grad).all()
     assert ns["counts"].shape == (2, 4)
+
+
+@pytest.mark.gpu
+def test_net_vehicle_params_snippet(cuda):
+    """Vehicles with their own IDM attributes beside the routes, on the tables the hybrid snippet builds."""
+    import torch
+    env = _itscp_env("hybrid", num_intersection=3, lane_length=5.0, num_lane=1, policy_length=8, signal_length=2)
+    action = (0.1 + 0.8 * torch.rand(2, env.action_size())).to(cuda).requires_grad_(True)
+    ns = dict(env=env, action=action)
+    exec(compile(snippets()["net_hybrid"], "INTEGRATION.md:net_hybrid", "exec"), ns)
+    np.random.seed(11)
+    exec(compile(snippets()["net_vehicle_params"], "INTEGRATION.md:net_vehicle_params", "exec"), ns)
+    assert ns["reward_rv"].shape == (2,) and torch.isfinite(ns["reward_rv"]).all()
+    assert int(ns["counts_rv"][0, 0]) >= 1 and not torch.equal(ns["reward_rv"].detach(), ns["full_reward"])      # other vehicles, another episode
 
 
 @pytest.mark.gpu
