@@ -780,3 +780,57 @@ def test_per_vehicle_idm_attributes_on_every_device_form(cuda, golden_dir, oracl
             assert np.isfinite(grad).all() and np.abs(grad - o["g_action"]).max() <= 0.1 * scale
             return
         assert np.abs(grad - o["g_action"]).max() <= TOL_GRAD * np.abs(o["g_action"]).max()
+
+
+@pytest.mark.parametrize("name, seed", [("hybrid_p2", 11), ("hybrid_l10", 12), ("hybrid_n2", 13)])
+def test_random_vehicle_attributes_and_actions_vs_oracle(cuda, golden_dir, oracle, name, seed):
+    """Other signal schedules AND other vehicles: every route row of a reference network gets the attributes of a
+    random_micro_vehicle(0.7 x speed limit) (rows are reused cyclically with their attributes), the action is random; fused, stepwise and
+    persistent forms against the oracle: spawn counts, queues <= 1e-5, and the gradient of the reward's first half <= 1e-4."""
+    import torch
+    from dhts import ops
+    from dhts.network import group_routes
+    from dhts.stepwise import StepwiseNetwork
+    from road.vehicle.micro_vehicle import MicroVehicle
+    g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+    t, m = itscp_hybrid_tables(g)
+    rng = np.random.default_rng(seed)
+    np.random.seed(seed)
+    rows = g["spawn_routes"][: max(2, len(g["spawn_routes"]) // 2)]            # fewer rows than vehicles: rows (and attributes) wrap around
+    first = sorted(set(int(r[0]) for r in g["spawn_routes"]))
+    have = set(int(r[0]) for r in rows)
+    extra = [r for r in g["spawn_routes"] if int(r[0]) not in have]
+    if extra:                                                                   # (every spawn lane needs at least one row)
+        seen, keep = set(), []
+        for r in extra:
+            if int(r[0]) not in seen:
+                seen.add(int(r[0]))
+                keep.append(r)
+        rows = np.concatenate([rows, np.asarray(keep)])
+    assert set(int(r[0]) for r in rows) == set(first)
+    vp = np.array([MicroVehicle.random_micro_vehicle(0.7 * m["speed_limit"]).params() for _ in rows])
+    action = rng.uniform(0.1, 0.9, len(g["action"])).astype(np.float32)
+    cut_t = m["T"] // 2
+    gr, ptr, gvp = group_routes(rows, t.n_lanes, vp)
+    o = oracle.net_hybrid(t, gr, ptr, action, *_args(m), vehicle_params=gvp, t_cut=cut_t)
+    assert o["rc"] == 0 and o["n_spawned"] >= 2
+    scale = np.abs(o["g_action"]).max()
+    fits = True
+    try:
+        t.check_kernel_limits()
+    except ValueError:
+        fits = False
+    for form in (["fused"] if fits else []) + ["stepwise", "persistent"]:
+        a = torch.tensor(action, device=cuda, requires_grad=True)
+        if form == "fused":
+            cut, reward, queue, counts = ops.net_hybrid_rollout(a[None], ops.DeviceHybridTables(t, rows, cuda, vehicle_params=vp), *_args(m), cut_t)
+            cut.sum().backward()
+            q, n_sp = queue[0].cpu().numpy(), int(counts[0, 0])
+        else:
+            net = StepwiseNetwork(t, rows, cuda, lane_capacity=32, persistent=form == "persistent", vehicle_params=vp)
+            cut, reward, queue, counts = net.rollout(a, *_args(m), loss_steps=cut_t)
+            cut.backward()
+            q, n_sp = queue.cpu().numpy(), int(counts[0])
+        assert n_sp == o["n_spawned"], form
+        assert state_report("%s random vehicles (%s): queues vs oracle" % (name, form), q, o["queue"]) <= TOL_STATE
+        assert np.abs(a.grad.cpu().numpy() - o["g_action"]).max() <= TOL_GRAD * scale, form
