@@ -73,6 +73,38 @@ def test_lane_capacity_is_a_launch_size_not_a_result(cuda, golden_dir, cap):
         ops.DeviceHybridTables(t, g["spawn_routes"], cuda, lane_capacity=48)
 
 
+def test_packed_launch_on_other_networks(cuda, golden_dir):
+    """The packed plan with per-vehicle attributes and other inflows, and on two networks that leave no room for it (the plan says so
+    and the launch is the ordinary one): same numbers as the one-per-unit launch."""
+    from dhts import _lib, ops
+    from test_oracle_golden import itscp_vehicle_params
+    lib = _lib.lib()
+    try:
+        # (10 m lanes: 464 cells + lanes need nine wavefronts, two such workgroups more than a unit's sixteen 128-register slots;
+        # two lanes per approach: 28 IDM lanes leave the staging area too small)
+        for name, packs in (("hybrid_rv_b", True), ("hybrid_rv_d", True), ("hybrid_p3", True), ("hybrid_l10", False), ("hybrid_n2", False)):
+            g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))
+            t, m = itscp_hybrid_tables(g)
+            vp = itscp_vehicle_params(g)
+            tab = ops.DeviceHybridTables(t, g["spawn_routes"], cuda, vehicle_params=vp)
+            res = []
+            for opt in (0, 1):
+                assert lib.dhts_set_option(_lib.OPT_HYB_PACK, opt) == 0
+                plan = ops.net_hybrid_plan(2, len(g["action"]), tab, m["num_intersection"] ** 2)
+                assert plan["packed"] == (bool(opt) and packs), (name, opt, plan)
+                import torch
+                a = torch.tensor(np.tile(g["action"][None], (2, 1)), device=cuda, requires_grad=True)
+                cut, reward, queue, counts = ops.net_hybrid_rollout(a, tab, m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"],
+                                                                    1.0 / m["simulation_frequency"], m["speed_limit"], m["static_speed"], m["vehicle_length"])
+                cut.sum().backward()
+                res.append((reward.clone(), queue.clone(), counts.clone(), a.grad.clone()))
+            for x, y in zip(*res):
+                assert torch.equal(x, y), name
+            assert int(res[0][2][0, 0]) == m["n_vehicle_spawned"]
+    finally:
+        lib.dhts_set_option(_lib.OPT_HYB_PACK, 2)
+
+
 @pytest.mark.parametrize("name", ["hybrid_p2", "hybrid", "hybrid_s2"])
 def test_two_replicas_per_compute_unit_is_a_launch_shape_not_a_result(cuda, golden_dir, name):
     """DHTS_OPT_HYB_PACK: the packed launch (half the LDS per workgroup, 128 registers, temporaries for the network's own micro
