@@ -478,191 +478,12 @@ __global__ __launch_bounds__(1024) void macro_rollout_fwd2_kernel(
     if (fault_step >= 0) raise_fault(err, DHTS_FAULT_CFL, fault_step, lane, fault_index);
 }
 
-// The same kernel for kG traffic lanes per workgroup (lanes kG b .. kG b + kG - 1; full lanes of kP passes per wavefront, no
-// history): each lane keeps its own records, fluxes and queue -- phase 1 is the kernel above, per lane -- but phase 2 takes the
-// lanes' queues as one list (entry g belongs to the lane whose prefix sum of queue lengths it falls in).  At config 2 a lane
-// queues ~76 interfaces, which is two wavefronts' worth of the full solve's instruction stream (64 + 12 entries); a pair of lanes
-// needs three (64 + 64 + 24).  Measured at config 2 (MI355X, profiles/archive/r03x_macro_fwd_lane_groups.log): one lane per workgroup
-// 3.29-3.39 ms, two 3.13-3.22 ms, four 3.15-3.34 ms (five wavefronts' worth for four lanes, but every barrier then spans 16 wavefronts).
-// Results and tape are bit-identical to the one-lane kernel's.  Dynamic LDS: kG regions of fwd2_region_bytes(N), one per lane.
-__host__ __device__ inline size_t fwd2_region_bytes(int N) {
-    return (sizeof(CellRec) * (size_t)(N + 2) + 16 * (size_t)(N + 1) + sizeof(int) * (size_t)(N + 2) + 16 + 15) & ~(size_t)15;
-}
+// (Round 3's lane-group form of this kernel -- kG lanes per workgroup with one phase-2 list over their queues, 3.39 -> 3.22 ms at
+// config 2 -- was what config 2 launched until the pair kernel of round 4 took every shape it covered; no plan selected it any more and
+// it was removed in round 6.  docs/history/rounds_1-3_kernel_notebook.md keeps its measurements.)
 #ifdef DHTS_FWD3_STAMPS
 extern __device__ long long dhts_fwd_clock[2][16][2];     // macro_fwd_pairs.inc (instrumented builds only)
 #endif
-template <int kP, int kG, bool kTape>
-__global__ __launch_bounds__(1024) void macro_rollout_fwd2_group_kernel(
-    int L, int N, int T, double dt, double dx, double um,
-    const float *__restrict__ r_in, const float *__restrict__ y_in, const float *__restrict__ u_in,
-    const float *__restrict__ q_in, const float *__restrict__ ghost,
-    float *__restrict__ r_out, float *__restrict__ y_out, float *__restrict__ u_out, float *__restrict__ q_out,
-    float4 *__restrict__ tape, dhts_error *err) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x;
-    const int t = tid & 63;
-    const int wv = tid >> 6;
-    const int Wc = blockDim.x >> 6;                  // wavefronts of the workgroup (both lanes)
-    const int Wl = Wc / kG;                          // wavefronts per lane
-    const int sub = wv / Wl;                         // which lane of the group this wavefront belongs to (wave-uniform)
-    const int wl = wv - sub * Wl;
-    const int lane = kG * blockIdx.x + sub;
-    const int ncell = blockDim.x / kG;               // threads per lane = cells per pass set
-    const size_t base = (size_t)lane * N;
-    const size_t reg = fwd2_region_bytes(N);
-    auto region_cr = [&](int s_) { return reinterpret_cast<CellRec *>(smem + (size_t)s_ * reg); };
-    auto region_fx = [&](int s_) { return reinterpret_cast<double2 *>(region_cr(s_) + (N + 2)); };
-    auto region_q = [&](int s_) { return reinterpret_cast<int *>(region_fx(s_) + (N + 1)); };
-    auto region_cnt = [&](int s_) { return region_q(s_) + (N + 2); };
-    CellRec *CR = region_cr(sub);
-    double2 *FX = region_fx(sub);
-    int *Q = region_q(sub);
-    int *CNT = region_cnt(sub);
-    IfaceConst kc;
-    kc.set_um(um); kc.set_grid(dt, dx);
-
-    for (int k = tid - sub * ncell; k < N + 2; k += ncell) {
-        float4 st;
-        if (k == 0 || k == N + 1) {
-            const float *g = ghost + (size_t)lane * 8 + (k ? 4 : 0);
-            st = make_float4(g[0], g[1], g[2], g[3]);
-        } else {
-            st = make_float4(r_in[base + k - 1], y_in[base + k - 1], u_in[base + k - 1], q_in[base + k - 1]);
-        }
-        CellPre c;
-        arz_cell_pre((double)st.x, um, c);
-        CR[k].st = st;
-        CR[k].sh = make_double2(c.s, c.h);
-        CR[k].q0 = make_double2(c.q0, 0.);
-    }
-    if (tid == sub * ncell) { Q[0] = N; CNT[0] = 1; CNT[1] = 1; }      // entry 0 of every step's queue: interface N
-    __syncthreads();
-
-    const TapeGeom geo = tape_geom(N);
-    const int lo = wl * (kP << 6);                   // first cell of this wave in its lane
-    const double c = dt / dx;
-    const float umf = (float)um;
-    int fault_step = -1, fault_index = 0, fault_lane = 0;
-    int rot = 0;
-    // the pair's two tape rows of a step lie side by side (rows are [step][lane])
-    float4 *tp_pair = kTape ? tape + (size_t)(kG * blockIdx.x) * geo.row_f4 : nullptr;
-    const size_t tp_stride = (size_t)L * geo.row_f4;
-    double rd_own[kP], yd_own[kP];
-    // where this thread's trivial-interface entries of the current step go: running pointers, one 64-bit add per pass and step
-    TapeFp *ts_own[kP];
-#pragma unroll
-    for (int j = 0; j < kP; ++j)
-        ts_own[j] = kTape ? reinterpret_cast<TapeFp *>(tp_pair + (size_t)sub * geo.row_f4) + (lo + (j << 6) + t) : nullptr;
-
-    auto body = [&](auto upd_c, auto solve_c, const int n) {
-        constexpr bool upd = decltype(upd_c)::value;
-        constexpr bool solve = decltype(solve_c)::value;
-        float4 *tpp = (kTape && solve) ? tp_pair : nullptr;            // lane a's row; lane b's follows
-        if (kTape) tp_pair += tp_stride;
-        int *cnt = CNT + (n & 1);
-#pragma unroll
-        for (int j = 0; j < kP; ++j) {
-            const int i = lo + (j << 6) + t;
-            const unsigned ic = (unsigned)i;
-            CellRec *own = CR + ic + 1;
-            float4 st;
-            if (!upd) { st = own->st; rd_own[j] = (double)st.x; yd_own[j] = (double)st.y; }
-            if (upd) {
-                const double2 Fl = FX[ic], Fr = FX[ic + 1];
-                st.x = (float)(rd_own[j] + (Fl.x - Fr.x) * c);
-                st.y = (float)(yd_own[j] + (Fl.y - Fr.y) * c);
-                rd_own[j] = (double)st.x; yd_own[j] = (double)st.y;
-                CellPre cp;
-                cell_glue_pre(st.x, st.y, umf, kc, st.z, st.w, cp);
-                if (solve) { own->st = st; own->sh = make_double2(cp.s, cp.h); own->q0 = make_double2(cp.q0, 0.); }
-            }
-            if (!solve) {
-                r_out[base + i] = st.x; y_out[base + i] = st.y; u_out[base + i] = st.z; q_out[base + i] = st.w;
-                continue;
-            }
-            wave_lds_handoff();
-            const CellRec *lf = CR + ic;
-            const float4 ls = lf->st;
-            const double2 lsh = lf->sh, lq0 = lf->q0;
-            CellPre cl;
-            cl.s = lsh.x; cl.h = lsh.y; cl.q0 = lq0.x;
-            IfacePre pre;
-            const bool easy = arz_is_trivial_fast((double)ls.x, (double)ls.z, (double)ls.w, (double)st.x, (double)st.z, cl, kc, pre);
-            const bool triv = easy & !((j == 0) & (t == 0));
-            double u0, Fr, Fy;
-            float fp[4];
-            arz_trivial_fast((double)ls.x, (double)ls.y, pre, kc, u0, Fr, Fy, fp);
-            if (triv) FX[ic] = make_double2(Fr, Fy);
-            if (!triv) Q[atomicAdd(cnt, 1)] = i;
-            if (kTape) {
-                *ts_own[j] = TapeFp{fp[0], fp[2], fp[3]};
-                ts_own[j] = reinterpret_cast<TapeFp *>(reinterpret_cast<float4 *>(ts_own[j]) + tp_stride);
-            }
-        }
-        if (!solve) return;
-        lds_only_barrier();
-        // ---- phase 2: the group's queues as one list ----
-        int g0 = tid - (rot << 6);
-        if (g0 < 0) g0 += blockDim.x;
-        int qs[kG + 1];                                                  // prefix sums of the lanes' queue lengths
-        qs[0] = 0;
-#pragma unroll
-        for (int s_ = 0; s_ < kG; ++s_) qs[s_ + 1] = qs[s_] + region_cnt(s_)[n & 1];
-        const int qn = qs[kG];
-        if (g0 < qn) __builtin_amdgcn_s_setprio(3);
-        for (int g = g0; g < qn; g += blockDim.x) {
-            int s2 = 0;
-#pragma unroll
-            for (int s_ = 1; s_ < kG; ++s_) s2 += g >= qs[s_] ? 1 : 0;
-            const int k = g - qs[s2];
-            const unsigned i = (unsigned)region_q(s2)[k];
-            CellRec *CR2 = region_cr(s2);
-            const CellRec *lf = CR2 + i, *rt = CR2 + i + 1;
-            const float4 ls = lf->st, rs = rt->st;
-            const double2 lsh = lf->sh, lq0 = lf->q0, rsh = rt->sh;
-            CellPre cl, cr;
-            cl.s = lsh.x; cl.h = lsh.y; cl.q0 = lq0.x;
-            cr.s = rsh.x; cr.h = rsh.y; cr.q0 = 0.;
-            Iface f;
-            arz_interface_fast_pre((double)ls.x, (double)ls.y, (double)ls.z, (double)ls.w, cl,
-                                   (double)rs.x, (double)rs.y, (double)rs.z, (double)rs.w, cr, kc, f);
-            region_fx(s2)[i] = make_double2(f.Fr, f.Fy);
-            if (kTape) {
-                float4 *row = tpp + (size_t)s2 * geo.row_f4;
-                unsigned *tH = tape_hdr(row, geo);
-                float4 *tE = row + geo.s_f4 + geo.h_f4;
-                if (k == 0) { tH[0] = (unsigned)(qs[s2 + 1] - qs[s2]); tH[1] = 0u; }   // (entry 0 of a lane's queue always exists: interface N)
-                tE[2 * k] = make_float4(f.A[0], f.A[1], f.A[2], f.A[3]);
-                tE[2 * k + 1] = make_float4(f.B[0], f.B[1], f.B[2], f.B[3]);
-                tape_idx(tH, geo)[k] = (unsigned short)i;
-            }
-            if (f.cfl_bad && fault_step < 0) { fault_step = n; fault_index = (int)i; fault_lane = kG * blockIdx.x + s2; }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (tid < kG) region_cnt(tid)[(n + 1) & 1] = 1;
-        if (++rot == Wc) rot = 0;
-        lds_only_barrier();
-    };
-    using yes = std::integral_constant<bool, true>;
-    using no = std::integral_constant<bool, false>;
-#ifdef DHTS_FWD3_STAMPS
-    const long long clk0_ = __builtin_amdgcn_s_memtime(), rt0_ = __builtin_amdgcn_s_memrealtime();
-#endif
-    if (T == 0) {
-        body(no{}, no{}, 0);
-    } else {
-        body(no{}, yes{}, 0);
-        for (int n = 1; n < T; ++n) body(yes{}, yes{}, n);
-        body(yes{}, no{}, T);
-    }
-    if (fault_step >= 0) raise_fault(err, DHTS_FAULT_CFL, fault_step, fault_lane, fault_index);
-#ifdef DHTS_FWD3_STAMPS
-    if (blockIdx.x < 16 && tid == 0) {
-        dhts_fwd_clock[0][blockIdx.x][0] = __builtin_amdgcn_s_memtime() - clk0_;
-        dhts_fwd_clock[0][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - rt0_;
-    }
-#endif
-}
 
 #include "macro_fwd_pairs.inc"
 
@@ -1424,21 +1245,6 @@ static inline bool macro_fwd2_fits(const dhts_macro_desc *d) {
     return d && sizeof(CellRec) * (size_t)(d->n_cells + 2) + 16 * (size_t)(d->n_cells + 1) + sizeof(int) * (size_t)(d->n_cells + 2) + 16 <=
                     160 * 1024;
 }
-// traffic lanes per workgroup of the two-phase kernel: groups where the grouped kernel exists (full lanes of two passes per
-// wavefront, no history), the group fits a workgroup and the LDS, and the launch still has a workgroup for every CU
-static inline int macro_fwd2_group(const dhts_macro_desc *d, bool want_hist) {
-    int W, p;
-    macro_fwd2_plan(d->n_cells, W, p);
-    // four lanes per workgroup up to three wavefronts per lane, two at four (measured, tools/probes/exp_fwd_groups_shapes.py: 8192
-    // lanes x 128 cells 4.08 / 3.67 / 3.54 ms for 1 / 2 / 4 lanes per workgroup, 4096 x 256 3.82 / 3.45 / 3.40, 1024 x 384 1.57 /
-    // 1.52 / 1.44; at 512 cells -- sixteen wavefronts per barrier with four lanes -- 2 and 4 are within a per cent of each other
-    // either way and config 2's own data prefer 2)
-    int G = dhts_fwd_group > 0 ? dhts_fwd_group : (W <= 3 ? 4 : 2);
-    if (dhts_fwd_group == 0 && G == 4 && (d->n_lanes % 4 != 0 || d->n_lanes / 4 < 256)) G = 2;
-    if (G < 2 || want_hist || p != 2 || d->n_cells != 128 * W || d->n_lanes % G != 0 || d->n_lanes / G < 256) return 1;
-    if (64 * W * G > 1024 || (size_t)G * fwd2_region_bytes(d->n_cells) > 160 * 1024) return 1;
-    return G;
-}
 // The pair kernel (macro_fwd_pairs.inc) takes full lanes of 128 W cells without a state history; traffic lanes per workgroup as
 // for the lane-group kernel (four up to three wavefronts per lane, else two; one where the launch would leave CUs without a
 // workgroup or the lanes do not divide).  0 = not this kernel (DHTS_OPT_MACRO_FWD_VARIANT = 2 turns it off).
@@ -1480,7 +1286,6 @@ static int macro_fwd2_launch(const dhts_macro_desc *d, int T,
     macro_fwd2_plan(N, W, p);
 #define DHTS_FWD2_ARGS d->n_lanes, N, T, p, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, \
                        reinterpret_cast<float4 *>(tape), hist, err
-    const int G = macro_fwd2_group(d, hist != nullptr);
     const int G3 = macro_fwd3_group(d, hist != nullptr);
     if (G3 > 0) {
         // the pair kernel: a thread owns two adjacent cells and their right interfaces (macro_fwd_pairs.inc)
@@ -1501,17 +1306,6 @@ static int macro_fwd2_launch(const dhts_macro_desc *d, int T,
         else if (tape) DHTS_FWD3(4, true)
         else DHTS_FWD3(4, false)
 #undef DHTS_FWD3
-#undef DHTS_FWDG_ARGS
-    } else if (G > 1) {
-        const size_t ldsg = (size_t)G * fwd2_region_bytes(N);
-        const void *fn = G == 2 ? (tape ? (const void *)macro_rollout_fwd2_group_kernel<2, 2, true> : (const void *)macro_rollout_fwd2_group_kernel<2, 2, false>)
-                                : (tape ? (const void *)macro_rollout_fwd2_group_kernel<2, 4, true> : (const void *)macro_rollout_fwd2_group_kernel<2, 4, false>);
-        if (ldsg > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg) != hipSuccess) return DHTS_E_LAUNCH;
-#define DHTS_FWDG_ARGS d->n_lanes, N, T, d->dt, d->dx, d->u_max, r, y, u, ueq, ghost, r_out, y_out, u_out, ueq_out, reinterpret_cast<float4 *>(tape), err
-        if (G == 2 && tape) macro_rollout_fwd2_group_kernel<2, 2, true><<<d->n_lanes / 2, 128 * W, ldsg, (hipStream_t)stream>>>(DHTS_FWDG_ARGS);
-        else if (G == 2) macro_rollout_fwd2_group_kernel<2, 2, false><<<d->n_lanes / 2, 128 * W, ldsg, (hipStream_t)stream>>>(DHTS_FWDG_ARGS);
-        else if (tape) macro_rollout_fwd2_group_kernel<2, 4, true><<<d->n_lanes / 4, 256 * W, ldsg, (hipStream_t)stream>>>(DHTS_FWDG_ARGS);
-        else macro_rollout_fwd2_group_kernel<2, 4, false><<<d->n_lanes / 4, 256 * W, ldsg, (hipStream_t)stream>>>(DHTS_FWDG_ARGS);
 #undef DHTS_FWDG_ARGS
     } else if (p == 1 && N == 64 * W && hist == nullptr)
         macro_rollout_fwd2_kernel<1, true, false><<<d->n_lanes, 64 * W, lds, (hipStream_t)stream>>>(DHTS_FWD2_ARGS);
@@ -1767,7 +1561,7 @@ int dhts_macro_rollout_plan(const dhts_macro_desc *d, int T, int want_hist, int3
     plan[4] = macro_bwd_is_fast(N, T) ? 1 : (macro_bwd_is_fast2(N, T, want_hist != 0) ? 2 : 0);
     plan[5] = plan[4] == 1 ? macro_bwd_fast_block(N) : (plan[4] == 2 ? 1024 : (padded64(N) > 512 ? 512 : padded64(N)));
     plan[6] = want_hist ? 1 : 0;
-    plan[7] = plan[0] == 2 ? macro_fwd3_group(d, want_hist != 0) : (plan[0] == 0 ? macro_fwd2_group(d, want_hist != 0) : 1);
+    plan[7] = plan[0] == 2 ? macro_fwd3_group(d, want_hist != 0) : 1;
     return DHTS_OK;
 }
 int dhts_macro_tape_expand(const dhts_macro_desc *d, int T, const float *tape, float *dqs, void *stream) {

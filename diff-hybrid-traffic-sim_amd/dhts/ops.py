@@ -160,7 +160,7 @@ def macro_rollout_plan(desc, T, want_hist=False):
     """Which kernel instantiations dhts_macro_rollout_fwd / _bwd launch for this shape (include/dhts.h)."""
     plan = (C.c_int32 * 8)()
     check(_lib.lib().dhts_macro_rollout_plan(C.byref(desc), int(T), int(bool(want_hist)), C.byref(plan)), "dhts_macro_rollout_plan")
-    # fwd_kernel: 0 = two-phase lane / lane-group kernel, 1 = one-phase, 2 = two-phase pair kernel
+    # fwd_kernel: 0 = two-phase lane kernel, 1 = one-phase, 2 = two-phase pair kernel
     keys = ("fwd_kernel", "fwd_waves", "fwd_passes", "fwd_full_lane", "bwd_pipelined", "bwd_block", "hist", "fwd_lanes_per_group")
     return dict(zip(keys, list(plan)))
 

@@ -83,14 +83,14 @@ int dhts_device_count(void);
 /* DHTS_OPT_MACRO_FWD_VARIANT: kernel behind dhts_macro_rollout_fwd: 0 = two-phase kernels (trivial interfaces solved in
  * place, the others queued and solved compacted; full lanes of 128 W cells without a history take the pair kernel -- a thread owns
  * two adjacent cells and their right interfaces), 1 = the one-phase kernel of dhts_macro_step_fwd (every interface an
- * exception), 2 = the two-phase kernels without the pair kernel (one cell and its left interface per thread-pass: the kernels
- * every other shape takes; kept selectable for comparisons).  Same tape format, same results. */
+ * exception), 2 = the two-phase LANE kernel for every shape (one cell and its left interface per thread-pass, one lane per
+ * workgroup: what ragged lanes and state histories take anyway; selectable so that tests can hold the pair kernel to it).
+ * Same tape format, same results. */
 #define DHTS_OPT_MACRO_FWD_VARIANT 3
-/* DHTS_OPT_MACRO_FWD_GROUP: traffic lanes per workgroup of the two-phase kernels: 0 = heuristic (default: the pair kernel takes 4
- * for lanes of up to three wavefronts, 1 for lanes of four -- BASELINE config 2 --, 2 above; the lane-group kernel 4 up to three
- * wavefronts, else 2), or 1, 2, 4.  Where the lanes are full (n_cells = 128 x wavefronts), no history is asked for and the
- * launch keeps >= 256 workgroups, the queued interfaces of a group's lanes are solved as one list.  Same results, same tape
- * (dhts_macro_rollout_plan plan[7] says what a shape gets). */
+/* DHTS_OPT_MACRO_FWD_GROUP: traffic lanes per workgroup of the pair kernel: 0 = heuristic (default: 4 for lanes of up to three
+ * wavefronts, 1 for lanes of four -- BASELINE config 2 --, 2 above), or 1, 2, 4 (taken where the lanes divide, the launch keeps
+ * >= 256 workgroups and the group fits a workgroup and the LDS).  Same results, same tape (dhts_macro_rollout_plan plan[7] says
+ * what a shape gets). */
 #define DHTS_OPT_MACRO_FWD_GROUP 4
 /* DHTS_OPT_MACRO_FWD_ROTATE: 1 (default) = the workgroups of the second half of the pair kernel's grid take turns with the others at
  * issue priority 1, eight steps at a time; 0 = nobody does.  The rotation rests on an OBSERVATION about the dispatcher (workgroups b
@@ -201,12 +201,12 @@ int dhts_macro_rollout_bwd(const dhts_macro_desc *d, int T, const float *tape,
 
 /* Which kernel instantiations the two calls above launch for this shape and the current options (answered by the functions
  * the launches themselves call; tests pin the benchmarked instantiations with it):
- *   plan[0] forward kernel: 0 = two-phase lane / lane-group kernel, 1 = one-phase, 2 = two-phase pair kernel
+ *   plan[0] forward kernel: 0 = two-phase lane kernel, 1 = one-phase, 2 = two-phase pair kernel
  *   plan[1] wavefronts per lane     plan[2] 64-cell passes per wavefront (pair kernel: two adjacent cells per thread)
  *   plan[3] 1 = the full-lane, history-free instantiation (n_cells = 64 x passes x wavefronts and hist == NULL)
  *   plan[4] reverse kernel: 1 = pipelined one-cell-per-thread, 2 = pipelined two-cells-per-thread, 0 = general     plan[5] its block size
  *   plan[6] 1 = per-step cotangents / history requested (want_hist)
- *   plan[7] traffic lanes per workgroup of the two-phase forward kernels (DHTS_OPT_MACRO_FWD_GROUP) */
+ *   plan[7] traffic lanes per workgroup (the pair kernel: DHTS_OPT_MACRO_FWD_GROUP; 1 otherwise) */
 int dhts_macro_rollout_plan(const dhts_macro_desc *d, int T, int want_hist, int32_t plan[8]);
 
 /* One step = the drop-in for a batch of dMacroForwardLayer.forward / .backward calls (T = 1 of the above;

@@ -472,73 +472,6 @@ def test_macro_cfl_fault(cuda):
     dhts.macro_rollout(r0, u0, gr, gu, 3, 0.01, 5.0, 30.0)
 
 
-@pytest.mark.parametrize("N,group", [(128, 2), (128, 4), (256, 2), (256, 4), (384, 4), (512, 2), (512, 4)])
-def test_macro_lane_groups_equal_one_lane_per_workgroup(cuda, N, group):
-    """DHTS_OPT_MACRO_FWD_GROUP: the two-phase kernel with 2 or 4 traffic lanes per workgroup (one phase-2 list for the group)
-    against one lane per workgroup, on lanes with vacuum cells, shocks and idle stretches: final state, the blocks the tape
-    expands to and the reverse sweep's gradients bit for bit, with and without a tape; a CFL fault names the lane it is in."""
-    import torch
-    from dhts import _lib, ops
-    rng = np.random.default_rng(100 + N + group)
-    L, T, dt, dx, um = 256 * group, 40, 0.01, 5.0, 30.0
-    r0 = rng.uniform(0.0, 1.0, (L, N)).astype(np.float32)
-    r0[1, 10:20] = 0.0
-    r0[2] = 0.4                              # an idle lane: every interface trivial, the queue holds interface N only
-    r0[5, ::2] = 0.0                         # the longest queue
-    r0[L - 1, N - 3:] = 0.0
-    u0 = rng.uniform(0.0, um, (L, N)).astype(np.float32)
-    u0[2] = 12.0
-    r, u = T_(r0, cuda), T_(u0, cuda)
-    y, q = ops.macro_state_from_ru(r, u, um)
-    gr = T_(rng.uniform(0.0, 1.0, (L, 2)).astype(np.float32), cuda)
-    gu = T_(rng.uniform(0.0, um, (L, 2)).astype(np.float32), cuda)
-    gy, gq = ops.macro_state_from_ru(gr, gu, um)
-    ghost = torch.stack([gr, gy, gu, gq], dim=-1).contiguous()
-    desc = ops.macro_desc(L, N, dt, dx, um)
-    res = []
-    try:
-        assert _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_VARIANT, 2) == 0           # the lane / lane-group kernels (no pair kernel)
-        for grp in (1, group):
-            assert _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_GROUP, grp) == 0
-            assert ops.macro_rollout_plan(desc, T)["fwd_kernel"] == 0
-            assert ops.macro_rollout_plan(desc, T)["fwd_lanes_per_group"] == grp
-            assert _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_GROUP, 0) == 0           # the heuristic: 4 up to three wavefronts per lane
-            assert ops.macro_rollout_plan(ops.macro_desc(1024, N, dt, dx, um), T)["fwd_lanes_per_group"] == (4 if N <= 384 else 2)
-            assert ops.macro_rollout_plan(ops.macro_desc(600, N, dt, dx, um), T)["fwd_lanes_per_group"] == 2
-            assert ops.macro_rollout_plan(ops.macro_desc(300, N, dt, dx, um), T)["fwd_lanes_per_group"] == 1
-            assert _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_GROUP, grp) == 0
-            assert ops.macro_rollout_plan(desc, T, want_hist=True)["fwd_lanes_per_group"] == 1
-            assert ops.macro_rollout_plan(ops.macro_desc(L - 1, N, dt, dx, um), T)["fwd_lanes_per_group"] == 1
-            assert ops.macro_rollout_plan(ops.macro_desc(L, N - 1, dt, dx, um), T)["fwd_lanes_per_group"] == 1
-            tape = torch.full((ops.macro_tape_numel(desc, T),), float("nan"), device=cuda)
-            out = ops.macro_rollout_fwd(desc, T, r, y, u, q, ghost, tape=tape)
-            plain = ops.macro_rollout_fwd(desc, T, r, y, u, q, ghost)
-            for a, b in zip(out, plain):
-                assert torch.equal(a, b)
-            g_r, g_y = 2 * out[0], torch.zeros_like(out[0])
-            ops.macro_u_tap_bwd(out[0], out[1], 2 * out[2], g_r, g_y, um)
-            res.append((out, ops.macro_tape_expand(desc, T, tape), ops.macro_rollout_bwd(desc, T, tape, g_r, g_y)))
-        for a, b in zip(res[0][0], res[1][0]):
-            assert torch.equal(a, b)
-        assert torch.equal(res[0][1], res[1][1])
-        for a, b in zip(res[0][2], res[1][2]):
-            assert torch.equal(a, b)
-        # a fault in the last lane of a group is reported for that lane
-        bad = L - 2 * group - 1
-        u_bad = u.clone()
-        r_bad = r.clone()
-        r_bad[bad, 7:9] = 0.3
-        u_bad[bad, 7:9] = 600.0                                 # dt * speed >= dx
-        y_bad, q_bad = ops.macro_state_from_ru(r_bad, u_bad, um)
-        err = ops.new_error_record(cuda)
-        ops.macro_rollout_fwd(desc, T, r_bad, y_bad, u_bad, q_bad, ghost, err=err)
-        rec = err.cpu().numpy()
-        assert rec[0] == _lib.FAULT_CFL and 0 <= rec[1] < T and rec[2] == bad and 0 <= rec[3] <= N, rec
-    finally:
-        _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_GROUP, 0)
-        _lib.lib().dhts_set_option(_lib.OPT_MACRO_FWD_VARIANT, 0)
-
-
 @pytest.mark.parametrize("N,group", [(128, 1), (128, 4), (256, 2), (384, 4), (512, 1), (512, 2), (512, 4), (1024, 1)])
 def test_macro_pair_kernel_equals_lane_kernel(cuda, N, group):
     """The pair kernel (a thread owns two adjacent cells and their right interfaces; what full lanes of 128 W cells launch) with

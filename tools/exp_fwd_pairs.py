@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the macro rollout forward kernel of BASELINE config 2 for the forward variants of ONE build of libdhts.so
-(DHTS_OPT_MACRO_FWD_VARIANT: 0 = pair kernel, 2 = lane / lane-group kernels of round 3) and lanes per workgroup, and checks every
+(DHTS_OPT_MACRO_FWD_VARIANT: 0 = pair kernel, 2 = the lane kernel) and lanes per workgroup, and checks every
 setting against the first one bit for bit (final state, and the gradient the reverse sweep makes of its tape).
 GPU box:  [DHTS_LIB=<variant build>] [DHTS_EXP_LANES=<lanes, default 1024>] python3 tools/exp_fwd_pairs.py [variant:group ...]      (default: 2:0 0:0 0:4 0:1 2:0 0:0)"""
 import hashlib
