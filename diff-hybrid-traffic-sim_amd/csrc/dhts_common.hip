@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(64) reward_chain_kernel(int T, int L, const fl
     if (ln == 0) {
         const float r = tensor ? rf : (float)rd;
         reward[(size_t)rep * stride] = r;
-        if (stride == 2) reward[(size_t)rep * 2 + 1] = tensor ? rc : r;
+        if (stride == 2) reward[(size_t)rep * 2 + 1] = hard ? r : rc;      // (an evaluation episode has no restricted reward)
     }
 }
 

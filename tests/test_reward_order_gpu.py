@@ -122,4 +122,6 @@ def test_stepwise_reward_in_reference_order(cuda, golden_dir, chain_on, name, pe
     assert np.float32(float(reward.detach())) == chain(q, t.lane_macro, hard, dt)
     if not hard:
         assert np.float32(float(cut.detach())) == chain(q[:100], t.lane_macro)
+    else:
+        assert float(cut) == float(reward)                    # (an evaluation episode has no restricted reward)
     assert abs(float(reward.detach()) - float(g["reward"])) <= 2e-6 * abs(float(g["reward"]))
