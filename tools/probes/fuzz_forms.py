@@ -9,7 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "diff-hybrid-traffic-sim_amd"), os.path.join(ROOT, "tests")]
-from test_oracle_golden import itscp_hybrid_tables, itscp_micro_tables      # noqa: E402
+from test_oracle_golden import itscp_hybrid_tables, itscp_micro_tables, itscp_vehicle_params      # noqa: E402
 from dhts import ops      # noqa: E402
 from dhts.stepwise import StepwiseNetwork, default_lane_capacity      # noqa: E402
 
@@ -20,20 +20,23 @@ bad = 0
 names = sorted(os.path.basename(f)[6:-4] for f in glob.glob(os.path.join(ROOT, "tests", "golden", "itscp_*.npz")))
 for name in names:
     g = np.load(os.path.join(ROOT, "tests", "golden", "itscp_%s.npz" % name))
+    vp = itscp_vehicle_params(g)           # (round 6: fixtures of seeded random_micro_vehicle runs carry the vehicles' attributes)
     if "micro" in name:
         t, m, routes = itscp_micro_tables(g)
         t.set_micro_sources(np.concatenate([g["rand_draws"], rng.random(8 * len(g["rand_draws"]) + 64)]))
         routes = np.concatenate([routes] * 3)
+        vp = None if vp is None else np.concatenate([vp] * 3)
     else:
         t, m = itscp_hybrid_tables(g)
         routes = np.concatenate([g["spawn_routes"]] * 4) if g["spawn_routes"].shape[0] else -np.ones((1, 2), np.int32)
+        vp = None if vp is None else np.concatenate([vp] * 4)
     args = (m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"], m["speed_limit"],
             m["static_speed"], m["vehicle_length"])
     hard = name.startswith("eval")
     worst = 0.0
     skipped = 0
     for cap in (default_lane_capacity(t, m["vehicle_length"]), 32):
-        nets = [StepwiseNetwork(t, routes, cuda, lane_capacity=cap, persistent=p) for p in (True, False)]
+        nets = [StepwiseNetwork(t, routes, cuda, lane_capacity=cap, persistent=p, vehicle_params=vp) for p in (True, False)]
         for k in range(n_act):
             act = rng.uniform(0.05, 0.95, len(g["action"])).astype(np.float32)
             outs = []

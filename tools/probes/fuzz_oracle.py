@@ -10,7 +10,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "diff-hybrid-traffic-sim_amd"), os.path.join(ROOT, "tests")]
-from test_oracle_golden import itscp_hybrid_tables, itscp_micro_tables      # noqa: E402
+from test_oracle_golden import itscp_hybrid_tables, itscp_micro_tables, itscp_vehicle_params      # noqa: E402
 from dhts import ops      # noqa: E402
 from dhts.network import group_routes      # noqa: E402
 from dhts.stepwise import StepwiseNetwork, default_lane_capacity      # noqa: E402
@@ -24,23 +24,30 @@ bad = 0
 names = sorted(os.path.basename(f)[6:-4] for f in glob.glob(os.path.join(ROOT, "tests", "golden", "itscp_*.npz")))
 for name in names:
     g = np.load(os.path.join(ROOT, "tests", "golden", "itscp_%s.npz" % name))
+    vp = itscp_vehicle_params(g)           # (round 6: fixtures of seeded random_micro_vehicle runs carry the vehicles' attributes)
     if "micro" in name:
         t, m, routes = itscp_micro_tables(g)
         t.set_micro_sources(np.concatenate([g["rand_draws"], rng.random(8 * len(g["rand_draws"]) + 64)]))
         routes = np.concatenate([routes] * 3)
+        vp = None if vp is None else np.concatenate([vp] * 3)
     else:
         t, m = itscp_hybrid_tables(g)
         routes = np.concatenate([g["spawn_routes"]] * 4) if g["spawn_routes"].shape[0] else -np.ones((1, 2), np.int32)
-    gr, ptr = group_routes(routes, t.n_lanes)
+        vp = None if vp is None else np.concatenate([vp] * 4)
+    if vp is None:
+        gr, ptr = group_routes(routes, t.n_lanes)
+        gvp = None
+    else:
+        gr, ptr, gvp = group_routes(routes, t.n_lanes, vp)
     args = (m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"], m["speed_limit"],
             m["static_speed"], m["vehicle_length"])
     hard = name.startswith("eval")
-    net = StepwiseNetwork(t, routes, cuda, lane_capacity=max(16, default_lane_capacity(t, m["vehicle_length"])), persistent=True)
+    net = StepwiseNetwork(t, routes, cuda, lane_capacity=max(16, default_lane_capacity(t, m["vehicle_length"])), persistent=True, vehicle_params=vp)
     wq = wg = 0.0
     done = skipped = 0
     for k in range(n_act):
         act = rng.uniform(0.05, 0.95, len(g["action"])).astype(np.float32)
-        ref = O.net_hybrid(t, gr, ptr, act, *args, hard=hard, want_grad=not hard)
+        ref = O.net_hybrid(t, gr, ptr, act, *args, hard=hard, want_grad=not hard, vehicle_params=gvp)
         if ref["rc"] != 0:
             skipped += 1
             continue
