@@ -1325,7 +1325,8 @@ static HybPlan hyb_plan(const dhts_net_desc *d, const dhts_hybrid_tables *t, boo
     const size_t act = up16(sizeof(float) * (size_t)d->n_action);
     p.block = hyb_block(d);
     p.packed = false;
-    if (!state_io && p.block <= 512 && lane_sh == 4 && (dhts_hyb_pack == 1 || (dhts_hyb_pack == 2 && d->n_replicas > hyb_cu_count()))) {
+    const int mode = t->two_per_cu > 0 ? 1 : (t->two_per_cu < 0 ? 0 : dhts_hyb_pack);      // the tables' own word first, then the option
+    if (!state_io && p.block <= 512 && lane_sh == 4 && (mode == 1 || (mode == 2 && d->n_replicas > hyb_cu_count()))) {
         const int h = hyb_stage_h(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, NS, d->n_action, lane_sh, kHybPackBudget);
         const int mr = NS * h < kMaxStepRecords ? NS * h : kMaxStepRecords;
         if (h >= 16 && hyb_lds_b(d->n_lanes, d->n_cells, d->n_inter_sq, ws.V, E, NS, mr).total + act <= kHybPackBudget) p.packed = true;

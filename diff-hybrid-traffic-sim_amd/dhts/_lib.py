@@ -50,7 +50,7 @@ class HybridTables(C.Structure):
                 ("routes", C.c_void_p), ("route_ptr", C.c_void_p), ("n_routes", C.c_int32), ("route_stride", C.c_int32),
                 ("records_per_step", C.c_int32), ("loss_steps", C.c_int32), ("n_micro", C.c_int32),
                 ("lane_source", C.c_void_p), ("draws", C.c_void_p), ("n_draws", C.c_int32), ("draws_stride", C.c_int64),
-                ("lane_capacity", C.c_int32), ("micro_tensor_ladder", C.c_int32), ("veh_params", C.c_void_p)]
+                ("lane_capacity", C.c_int32), ("micro_tensor_ladder", C.c_int32), ("veh_params", C.c_void_p), ("two_per_cu", C.c_int32)]
 
 
 class HybridStateIO(C.Structure):

@@ -572,6 +572,7 @@ class DeviceHybridTables:
         if lane_capacity not in (0, 16, 32, 64, 128):
             raise ValueError("lane_capacity (vehicles a micro lane holds at once) must be 0 (= 16), 16, 32, 64 or 128")
         self.lane_capacity = int(lane_capacity)
+        self.two_per_cu = 0                # dhts_hybrid_tables::two_per_cu: 0 = DHTS_OPT_HYB_PACK decides, 1 = packed, -1 = one replica per unit
         many = isinstance(tables, (list, tuple))
         t = tables[0] if many else tables
         for i, x in enumerate(tables if many else [t]):
@@ -649,7 +650,8 @@ class DeviceHybridTables:
         src = (k[18], k[19]) if self.has_sources else (None, None)
         return _lib.HybridTables(self.net, k[13], k[14], k[15], k[16], k[17], self.n_routes, self.route_stride, self.records_per_step,
                                  int(loss_steps), self.n_micro, src[0], src[1], self.n_draws, self.draws_stride, self.lane_capacity,
-                                 1 if self.micro_tensor_ladder else 0, None if self._veh_params is None else self._veh_params.data_ptr())
+                                 1 if self.micro_tensor_ladder else 0, None if self._veh_params is None else self._veh_params.data_ptr(),
+                                 int(self.two_per_cu))
 
 
 class NetHybridRollout(torch.autograd.Function):
@@ -688,7 +690,25 @@ class NetHybridRollout(torch.autograd.Function):
                                               _ptr(reward), _ptr(counts), _ptr(ws), _ptr(err), _stream()),
               "dhts_net_hybrid_rollout_fwd")
         if check_faults and own_err:     # reading the record back synchronises: off inside HIP-graph capture
-            raise_on_fault(err)
+            try:
+                raise_on_fault(err)
+            except CapacityError:
+                # two replicas per compute unit (more replicas than units) halve the record staging area: the same batch once more
+                # with one replica per unit before the caller hears of it (the reverse sweep follows the tables it is given)
+                plan = (C.c_int32 * 8)()
+                check(lib.dhts_net_hybrid_plan(C.byref(d), C.byref(tc), plan), "dhts_net_hybrid_plan")
+                if not plan[0]:
+                    raise
+                import copy
+                t = copy.copy(t)
+                t.two_per_cu = -1
+                tc = t.c(loss_steps)
+                err.zero_()
+                counts.zero_()
+                check(lib.dhts_net_hybrid_rollout_fwd(C.byref(d), C.byref(tc), _ptr(a), _ptr(hist), _ptr(tape), _ptr(kc), _ptr(queue),
+                                                      _ptr(reward), _ptr(counts), _ptr(ws), _ptr(err), _stream()),
+                      "dhts_net_hybrid_rollout_fwd")
+                raise_on_fault(err)
         # the reverse sweep raises only on a record of its own: a caller-owned one (err, or err_bwd for the reverse sweep alone) is
         # the caller's to read -- that is how a batch tolerates one member's NaN
         ctx.d, ctx.tables, ctx.loss_steps = d, t, int(loss_steps)

@@ -242,7 +242,7 @@ class StepwiseNetwork:
         src = (p("lane_source"), p("draws")) if self.has_sources else (None, None)
         hyb = _lib.HybridTables(net, p("lane_macro"), p("lane_len"), p("conv_next"), p("routes"), p("route_ptr"), self.n_routes,
                                 self.route_stride, 0, int(loss_steps), self.n_micro, src[0], src[1], self.n_draws, self.draws_stride,
-                                self.lane_capacity, 1 if self.micro_tensor_ladder else 0, p("veh_params") if "veh_params" in d else None)
+                                self.lane_capacity, 1 if self.micro_tensor_ladder else 0, p("veh_params") if "veh_params" in d else None, 0)
         return _lib.NetstepTables(hyb, p("lane_gpos"), self._garr, len(self.groups), p("micro_lanes"), p("lane_mslot"), p("cap_lanes"),
                                   p("lane_cslot"), self.n_caps, p("inter_ptr"), p("inter_idx"), self.max_events, p("if_lane"), p("cell_lane"),
                                   1 if self.persistent else 0, int(d["inter_idx"].numel()))

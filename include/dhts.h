@@ -456,6 +456,10 @@ typedef struct dhts_hybrid_tables {
      * lane m takes row route_ptr[m] + k mod rows of m).  length must equal the descriptor's vehicle_length (the hand-offs and the
      * loss use one length; both of the reference's factories give DEFAULT_VEHICLE_LENGTH). */
     const double *veh_params;
+    /* Replicas per compute unit of the fused kernels for THIS set of tables: 0 = as DHTS_OPT_HYB_PACK says (default: two when the batch
+     * has more replicas than the device has units), 1 = two whenever the plan fits, -1 = one.  A caller that met DHTS_FAULT_CAPACITY under
+     * the packed plan (its record staging area holds about a third of the unpacked plan's records per lane and step: dhts_net_hybrid_plan plan[2]) retries with -1 (dhts.ops does). */
+    int32_t two_per_cu;
 } dhts_hybrid_tables;
 size_t dhts_net_hybrid_workspace_bytes(const dhts_net_desc *d, const dhts_hybrid_tables *t);
 /* What dhts_net_hybrid_rollout_fwd / _bwd would launch for (d, t) under the current DHTS_OPT_HYB_PACK (no device work): plan[0] = 1

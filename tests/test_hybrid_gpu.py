@@ -105,6 +105,38 @@ def test_packed_launch_on_other_networks(cuda, golden_dir):
         lib.dhts_set_option(_lib.OPT_HYB_PACK, 2)
 
 
+def test_capacity_fault_under_the_packed_plan_is_retried_one_replica_per_unit(cuda, golden_dir, monkeypatch):
+    """Two replicas per compute unit halve the record staging area (17 instead of 48 records per lane and step at config 4's network).  A
+    batch that does not fit comes back as DHTS_FAULT_CAPACITY; dhts.ops runs it once more with one replica per unit (the tables' own
+    two_per_cu word) before the caller hears of it, and the reverse sweep follows the tables of the run that counted.  The fault is
+    injected here (no reference episode fills 17 records per lane)."""
+    import torch
+    from dhts import _lib, ops
+    g = np.load(os.path.join(golden_dir, "itscp_hybrid_p2.npz"))
+    ref = _run(cuda, g, replicas=2)
+    t, m = itscp_hybrid_tables(g)
+    tab = ops.DeviceHybridTables(t, g["spawn_routes"], cuda)
+    tab.two_per_cu = 1
+    assert ops.net_hybrid_plan(2, len(g["action"]), tab, m["num_intersection"] ** 2)["packed"]
+    real, calls = ops.raise_on_fault, []
+
+    def once(err):
+        calls.append(1)
+        if len(calls) == 1:
+            e = ops.CapacityError("injected: the packed plan's staging area is full")
+            e.index = 0
+            raise e
+        return real(err)
+    monkeypatch.setattr(ops, "raise_on_fault", once)
+    a = torch.tensor(np.tile(g["action"][None], (2, 1)), device=cuda, requires_grad=True)
+    cut, reward, queue, counts = ops.net_hybrid_rollout(a, tab, m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"],
+                                                        1.0 / m["simulation_frequency"], m["speed_limit"], m["static_speed"], m["vehicle_length"])
+    assert len(calls) == 2 and tab.two_per_cu == 1                  # (the caller's tables are left as they were)
+    cut.sum().backward()                                            # the reverse sweep shares the second run's plan: no index -3 fault
+    assert np.array_equal(queue.cpu().numpy(), ref["queue"]) and np.array_equal(reward.cpu().numpy(), ref["reward"])
+    assert np.array_equal(a.grad.cpu().numpy(), ref["grad"]) and np.array_equal(counts.cpu().numpy(), ref["counts"])
+
+
 @pytest.mark.parametrize("name", ["hybrid_p2", "hybrid", "hybrid_s2"])
 def test_two_replicas_per_compute_unit_is_a_launch_shape_not_a_result(cuda, golden_dir, name):
     """DHTS_OPT_HYB_PACK: the packed launch (half the LDS per workgroup, 128 registers, temporaries for the network's own micro
@@ -124,6 +156,9 @@ def test_two_replicas_per_compute_unit_is_a_launch_shape_not_a_result(cuda, gold
         assert lib.dhts_set_option(_lib.OPT_HYB_PACK, 1) == 0
         p1 = ops.net_hybrid_plan(3, len(g["action"]), dt_, m["num_intersection"] ** 2)
         assert p1["packed"] and p1["lds_fwd"] <= 79 * 1024 and p1["lds_bwd"] <= 79 * 1024 and p1["stage_h"] >= 16
+        tab_off = ops.DeviceHybridTables(t, g["spawn_routes"], cuda)
+        tab_off.two_per_cu = -1                                     # the tables' own word beats the option
+        assert not ops.net_hybrid_plan(3, len(g["action"]), tab_off, m["num_intersection"] ** 2)["packed"]
         assert p1["loc_lanes"] == 16 and p1["max_step_records"] == 16 * p1["stage_h"]
         o = _run(cuda, g, replicas=3)
         for k in ("counts", "queue", "reward", "grad", "cut"):
