@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Every reference episode the fused hybrid kernels hold, launched with the packed plan forced (two_per_cu = 1): is the plan taken, how many
+records per lane and step does its staging area hold (plan[2]), and does the episode fit (fault record).  GPU box."""
 import glob, os, sys
 ROOT='/root/repo'
 sys.path[:0]=[ROOT, os.path.join(ROOT,'diff-hybrid-traffic-sim_amd'), os.path.join(ROOT,'tests')]
