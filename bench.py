@@ -1153,6 +1153,7 @@ def main():
                 parity_failed |= check_parity(out["parity_check"], w.name)
         print(json.dumps(out))
     D.barrier()
+    D.shutdown()                 # (the process group goes down in order on every rank: no teardown warnings, no straggler)
     if parity_failed:
         sys.exit(3)
 

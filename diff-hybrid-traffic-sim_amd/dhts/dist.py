@@ -154,6 +154,12 @@ def barrier():
             dist.barrier()
 
 
+def shutdown():
+    """Destroy the process group this module built (no-op without one)."""
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def max_over_ranks(seconds, device):
     if _active() and dist.get_backend() == "gloo":
         device = torch.device("cpu")
