@@ -998,7 +998,7 @@ def main():
         assert torch.cuda.current_device() == dev.index
     sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
     # who took part: backend + every rank's device (gathered; raises when RCCL ranks share a device)
-    collective = D.collective_record(dev) if world > 1 else None
+    collective = D.collective_record(dev) if (world > 1 or D._forced()) else None      # (DHTS_DIST_FORCE=1: the one-rank RCCL self-test)
 
     w = make_workload(args.workload, dev, rank, args.lanes, args.cells, args.time_steps)
     L, N, T = w.L, w.N, w.T

@@ -192,3 +192,8 @@ def test_bench_over_rccl_with_one_rank(cuda):
     assert p.returncode == 0, p.stderr[-3000:]
     out = last_json(p.stdout)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["lanes_per_gpu"] == 64
+    # the identity gather of the N > 1 line, over RCCL: backend by name, this rank's device with its PCI bus id and uuid
+    col = out["collective"]
+    assert col["backend"] == "nccl" and col["world"] == 1 and col["distinct_devices"] == 1
+    d = col["devices"][0]
+    assert d["rank"] == 0 and d["device"] == "cuda:0" and d["pci_bus_id"] and d["uuid"] and "gfx950" in d["arch"]
