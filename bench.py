@@ -1138,11 +1138,18 @@ def main():
                     out["also"].append(rec)
                 # the one-GPU side of the scaling question: config 4's network at 256 ... 2 048 replicas on this device,
                 # and config 2 at 8 x its lanes (what 8 GPUs run together), each as ms per pass and cell-steps/s
-                out["also"].append(replica_sweep(dev))
+                # (two big extras -- 25 GB and 195 GB of tape: a device short of memory loses these records, never the line)
+                try:
+                    out["also"].append(replica_sweep(dev))
+                except torch.OutOfMemoryError as e:
+                    out["also"].append({"workload": "itscp_hybrid replica sweep", "skipped": "out of device memory: %s" % str(e)[:120]})
                 torch.cuda.empty_cache()
-                rec, w2, _g = also_record("macro", dev, passes=3, lanes=8 * L)
-                rec["note"] = "config 2 x 8 lanes on ONE GPU (tape %.1f GB): the one-GPU time of the 8-GPU run's whole problem" % (w2.tape_bytes / 1e9)
-                del w2, _g
+                try:
+                    rec, w2, _g = also_record("macro", dev, passes=3, lanes=8 * L)
+                    rec["note"] = "config 2 x 8 lanes on ONE GPU (tape %.1f GB): the one-GPU time of the 8-GPU run's whole problem" % (w2.tape_bytes / 1e9)
+                    del w2, _g
+                except torch.OutOfMemoryError as e:
+                    rec = {"workload": "macro_straight_%dx%dx%d" % (8 * L, N, T), "skipped": "out of device memory: %s" % str(e)[:120]}
                 torch.cuda.empty_cache()
                 out["also"].append(rec)
             if not args.no_cpu_baseline:
