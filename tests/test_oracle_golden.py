@@ -509,7 +509,7 @@ def test_source_ghost_in_double(oracle, golden_dir):
 ILL_CONDITIONED_FULL_GRADIENT = {"hybrid_rv"}
 
 
-@pytest.mark.parametrize("name", ["micro_rv", "micro_rv_2x2", "hybrid_rv", "hybrid_rv_b", "hybrid_rv_d", "hybrid_rv_l10", "eval_hybrid_rv"])
+@pytest.mark.parametrize("name", ["micro_rv", "micro_rv_2x2", "micro_rv_l10", "hybrid_rv", "hybrid_rv_b", "hybrid_rv_d", "hybrid_rv_l10", "hybrid_rv_n2", "eval_hybrid_rv"])
 def test_itscp_network_with_per_vehicle_idm_attributes(oracle, golden_dir, name):
     """Round 6: vehicles that are NOT default_micro_vehicle -- reference runs whose vehicles take the attributes of a seeded
     MicroVehicle.random_micro_vehicle (road/vehicle/micro_vehicle.py:75-121; tools/gen_goldens.py random_vehicles): the restatement with

@@ -708,7 +708,7 @@ def test_micro_mode_random_actions_vs_oracle(cuda, golden_dir, oracle, name, see
 
 
 @pytest.mark.parametrize("form", ["fused", "stepwise", "persistent"])
-@pytest.mark.parametrize("name", ["micro_rv", "micro_rv_2x2", "hybrid_rv", "hybrid_rv_b", "hybrid_rv_d", "hybrid_rv_l10", "eval_hybrid_rv"])
+@pytest.mark.parametrize("name", ["micro_rv", "micro_rv_2x2", "micro_rv_l10", "hybrid_rv", "hybrid_rv_b", "hybrid_rv_d", "hybrid_rv_l10", "hybrid_rv_n2", "eval_hybrid_rv"])
 def test_per_vehicle_idm_attributes_on_every_device_form(cuda, golden_dir, oracle, name, form):
     """Round 6 (dhts_hybrid_tables::veh_params): reference runs whose vehicles carry the attributes of a seeded
     MicroVehicle.random_micro_vehicle (micro_vehicle.py:75-121) through the fused kernels, the stepwise form and the persistent

@@ -1052,6 +1052,14 @@ def main():
             os.environ["DHTS_FINE_CUTS"] = "60"
             os.environ.pop("DHTS_LANE_LATE", None)
             gen_itscp("micro_rv_2x2", "micro", 2, 2, 10.0, 4, 1, seed=183, action_kind="rand", problem=3, random_vehicles=1.0)
+        if "micro_rv_l10" in which:      # 10 m lanes: vehicles leave their lane every few steps, each with its own attributes
+            os.environ["DHTS_FINE_CUTS"] = "90"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("micro_rv_l10", "micro", 1, 1, 10.0, 6, 1, seed=231, action_kind="rand", problem=3, random_vehicles=1.0)
+        if "hybrid_rv_n2" in which:      # two lanes per approach: 28 IDM lanes, 12 spawning lanes
+            os.environ["DHTS_FINE_CUTS"] = "120,200"
+            os.environ.pop("DHTS_LANE_LATE", None)
+            gen_itscp("hybrid_rv_n2", "hybrid", 3, 2, 5.0, 8, 2, seed=137, action_kind="rand", problem=1, random_vehicles=0.7)
         if "eval_hybrid_rv" in which:
             gen_itscp("eval_hybrid_rv", "hybrid", 3, 1, 5.0, 16, 4, seed=121, action_kind="rand", problem=2, differentiable=False, random_vehicles=0.7)
         if "hybrid_short" in which:      # 8 s: enough for the first vehicles to cross the interior intersection

@@ -13,7 +13,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "diff-hybrid-traffic-sim_amd"), os.path.join(ROOT, "tests")]
-from test_oracle_golden import itscp_hybrid_tables, itscp_micro_tables      # noqa: E402
+from test_oracle_golden import itscp_hybrid_tables, itscp_micro_tables, itscp_vehicle_params      # noqa: E402
 from dhts.network import group_routes      # noqa: E402
 from oracle import oracle as O      # noqa: E402
 from util import rel_max      # noqa: E402
@@ -38,7 +38,12 @@ for name in names:
     else:
         t, m = itscp_hybrid_tables(g)
         rows = g["spawn_routes"] if g["spawn_routes"].shape[0] else -np.ones((1, 2), np.int32)
-    routes, route_ptr = group_routes(rows, t.n_lanes)
+    vp = itscp_vehicle_params(g)             # (round 6: runs whose vehicles carry seeded random_micro_vehicle attributes)
+    if vp is None:
+        routes, route_ptr = group_routes(rows, t.n_lanes)
+        gvp = None
+    else:
+        routes, route_ptr, gvp = group_routes(rows, t.n_lanes, vp)
     args = (t, routes, route_ptr, g["action"], m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"],
             1.0 / m["simulation_frequency"], m["speed_limit"], m["static_speed"], m["vehicle_length"])
     out = []
@@ -47,7 +52,7 @@ for name in names:
             O.set_sqrtf_hook(torch_sqrt if env else None)
             O.set_numpy_mean(env)
             t0 = time.time()
-            o = O.net_hybrid(*args, hard=hard)
+            o = O.net_hybrid(*args, hard=hard, vehicle_params=gvp)
             q, gq = o["queue"].T.astype(np.float32), g["queue"].astype(np.float32)
             grad = "gradient %.1e, " % (np.abs(o["g_action"] - g["g_action"]).max() / np.abs(g["g_action"]).max()) if not hard else ""
             out.append("%6d of %6d terms differ, %.1e, %sreward %s (%3.0f s)"
