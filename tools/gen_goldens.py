@@ -652,8 +652,10 @@ class SolverMargins:
 
 
 def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, action_kind, problem=1, differentiable=True,
-              random_vehicles=False):
-    """random_vehicles: every vehicle that enters the network takes the attributes of a MicroVehicle.random_micro_vehicle(speed_limit)
+              random_vehicles=False, action_override=None, draws_override=None):
+    """action_override / draws_override (tools/probes/ref_replay_case.py): another action vector, and the admission draws of `micro` mode
+    taken from a given stream instead of np.random -- the reference on a case a fuzz run found, to adjudicate between oracle and kernels.
+    random_vehicles: every vehicle that enters the network takes the attributes of a MicroVehicle.random_micro_vehicle(speed_limit)
     (road/vehicle/micro_vehicle.py:75-121; the network code itself only ever builds default_micro_vehicle, conversion.py:51,
     road_network.py:582-591) drawn from a stream of its own (seeded; the run's other host randomness -- routes, admission draws -- is
     left as it would have been): the waiting vehicles of `micro` mode right after reset(), the flux capacitors' vehicles when they are
@@ -730,6 +732,9 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
         a0 = np.full(A, 0.5, dtype=np.float32)
     else:
         a0 = rng.uniform(0.1, 0.9, A).astype(np.float32)
+    if action_override is not None:
+        a0 = np.asarray(action_override, dtype=np.float32)
+        assert a0.shape == (A,)
     action = th.tensor(a0, requires_grad=True)
     t0 = time.time()
     env.queue_length.clear()
@@ -738,8 +743,12 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
     rand_draws = []
     orig_random = np.random.random
 
+    replay = None if draws_override is None else iter(np.asarray(draws_override, dtype=np.float64).tolist())
+
     def logged_random(*a, **kw):
         v = orig_random(*a, **kw)
+        if replay is not None:
+            v = np.full(np.shape(v), next(replay)) if np.shape(v) else next(replay)
         rand_draws.append(float(np.asarray(v).reshape(-1)[0]))
         return v
     waiting_routes = {int(l): [list(r.route) for r in rs] for l, rs in sim.lane_waiting_micro_route.items()}

@@ -18,6 +18,10 @@ from oracle import oracle as O      # noqa: E402
 
 O.build()
 n_act = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+only = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None      # fixtures to run (the others still draw their random numbers)
+from dhts import _lib      # noqa: E402
+# the oracle forms the reward as ItscpEnv._reward does (one float32 chain over lanes and steps): so do the kernels here
+assert _lib.lib().dhts_set_option(_lib.OPT_REWARD_CHAIN, 1) == 0
 cuda = torch.device("cuda:0")
 rng = np.random.default_rng(777)
 bad = 0
@@ -42,6 +46,10 @@ for name in names:
     args = (m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"], m["speed_limit"],
             m["static_speed"], m["vehicle_length"])
     hard = name.startswith("eval")
+    if only is not None and name not in only:
+        for k in range(n_act):
+            rng.uniform(0.05, 0.95, len(g["action"]))
+        continue
     net = StepwiseNetwork(t, routes, cuda, lane_capacity=max(16, default_lane_capacity(t, m["vehicle_length"])), persistent=True, vehicle_params=vp)
     wq = wg = 0.0
     done = skipped = 0
@@ -70,7 +78,12 @@ for name in names:
         done += 1
         if not ok:
             bad += 1
-            print("MISMATCH", name, "schedule", k, "counts", c[:2], (ref["n_spawned"], ref["n_deposits"]), "queues %.1e reward %.1e" % (eq, er))
+            d = np.abs(q - ref["queue"])
+            tt, ll = np.unravel_index(int(np.argmax(d)), d.shape)
+            first = np.argwhere(d > 1e-6 * np.abs(ref["queue"]).max())
+            print("MISMATCH", name, "schedule", k, "counts", c[:2], (ref["n_spawned"], ref["n_deposits"]), "queues %.1e reward %.1e" % (eq, er),
+                  "| largest at step %d lane %d (kernel %.9g, oracle %.9g); first entry above 1e-6: step %s" % (
+                      tt, ll, q[tt, ll], ref["queue"][tt, ll], None if not len(first) else tuple(first[0])))
     print("%-22s %4d lanes %5d cells: %d schedules vs the oracle (%d refused): queues %.1e, gradient %.1e" % (
         name, t.n_lanes, t.n_cells, done, skipped, wq, wg), flush=True)
 print("mismatches:", bad)
