@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""dhts_micro_step_fwd_tensor (itscp `micro` mode's float32 tensor ladder) against the oracle, bit for bit, on 81 920 vehicle-steps whose
+vehicles carry random_micro_vehicle-style attributes (doubles with all their bits) and whose states include tiny gaps, collisions and
+standing vehicles.  GPU box."""
 import os, sys
 ROOT='/root/repo'
 sys.path[:0]=[ROOT, os.path.join(ROOT,'diff-hybrid-traffic-sim_amd'), os.path.join(ROOT,'tests')]
