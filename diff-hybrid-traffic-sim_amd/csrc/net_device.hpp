@@ -8,18 +8,35 @@ namespace dhts {
 
 constexpr float kSigK = 32.f;       // sigmoid constant of the signals (_env.py:928-960, _simulator.py:128)
 
+// The exponential of a sigmoid.  `exact` (a wave-uniform flag): the double exponential rounded once instead of the device library's expf
+// (1 ulp).  The reference evaluates torch.sigmoid on CPU float32 tensors; its exp, glibc's expf (the oracle) and a correctly rounded exp
+// agree on all but a fraction of a per cent of arguments, the device's expf differs from them on many.  One ulp in one value is
+// harmless -- but in itscp `micro` mode (every lane an IDM lane stepped in float32 tensor arithmetic, a hundred vehicles following
+// each other for hundreds of steps) the signals and head-gap scores steer a chaotic system, and a fuzz run over random schedules saw
+// such ulps grow to 1.1-1.8e-5 of the largest queue term in 4 of 2 760 episodes (profiles/r06z_fuzz_oracle.log; 0 of 2 760 with the
+// exact form).  The kernels ask for it exactly there: dhts_hybrid_tables::micro_tensor_ladder networks, signals and head gaps of
+// differentiable episodes (+3-7 % on those episodes; every other network keeps expf and its speed).
+// (Out of line in the persistent stepwise kernels -- inlined, its forty instructions and their registers made a network that never takes
+// it 6 % slower there; inline in the fused kernels (DHTS_SIG_EXACT_INLINE), where a call costs config 4's forward sweep 4 %.)
+#ifdef DHTS_SIG_EXACT_INLINE
+__device__ __forceinline__ float sig_exp_exact(float x) { return (float)exp((double)x); }
+#else
+__device__ __attribute__((noinline)) float sig_exp_exact(float x) { return (float)exp((double)x); }
+#endif
+__device__ __forceinline__ float sig_exp(float x, bool exact) { return exact ? sig_exp_exact(x) : expf(x); }
+
 // dmath/operation.py:3-30
-__device__ __forceinline__ float soft_switch(float value, float constant) {
+__device__ __forceinline__ float soft_switch(float value, float constant, bool exact = false) {
     float z = value * constant;
     z = fminf(fmaxf(z, -16.f), 16.f);
-    return 1.f / (1.f + expf(-z));
+    return 1.f / (1.f + sig_exp(-z, exact));
 }
 // both at once (the reverse sweeps' loss taps): one exponential and one division instead of two of each; the same values
 // (outside the clamp the gradient is 0 and the switch is the clamped one, inside z is not changed by the clamp)
-__device__ __forceinline__ void soft_switch_both(float value, float constant, float &s, float &ds) {
+__device__ __forceinline__ void soft_switch_both(float value, float constant, float &s, float &ds, bool exact = false) {
     const float z = value * constant;
     const float zc = fminf(fmaxf(z, -16.f), 16.f);
-    s = 1.f / (1.f + expf(-zc));
+    s = 1.f / (1.f + sig_exp(-zc, exact));
     ds = (z < -16.f || z > 16.f) ? 0.f : s * (1.f - s) * constant;
 }
 __device__ __forceinline__ float soft_switch_grad(float value, float constant) {
@@ -93,7 +110,8 @@ __device__ __forceinline__ void net_fault(dhts_error *err, int code, int step, i
 // `phase_raw` = t / F and `frame` = t % F are passed in so that rollouts can count them instead of dividing every step.
 // hard = an evaluation episode (differentiable = False): float(a > progress), float(progress > a) (_env.py:928-960).
 __device__ __forceinline__ void phase_signal_at(const float *action, int n_action, int sq, int F, int phase_raw, int frame, int k,
-                                                float &we, float &ns, float &a, float &prog, int &a_index, bool hard = false) {
+                                                float &we, float &ns, float &a, float &prog, int &a_index, bool hard = false,
+                                                bool exact = false) {
     const int last = n_action / sq - 1;
     const int phase = phase_raw > last ? last : phase_raw;
     double pr = (double)frame / (double)F;
@@ -102,8 +120,8 @@ __device__ __forceinline__ void phase_signal_at(const float *action, int n_actio
     a = action[a_index];
     prog = (float)pr;
     if (hard) { we = a > prog ? 1.f : 0.f; ns = prog > a ? 1.f : 0.f; return; }
-    we = soft_switch(a - prog, kSigK);
-    ns = soft_switch(prog - a, kSigK);
+    we = soft_switch(a - prog, kSigK, exact);
+    ns = soft_switch(prog - a, kSigK, exact);
 }
 __device__ __forceinline__ void phase_signal(const float *action, int n_action, int sq, int F, int t, int k,
                                              float &we, float &ns, float &a, float &prog, int &a_index) {

@@ -283,9 +283,9 @@ __device__ __forceinline__ D7 d7_div(D7 a, D7 b) { D7 x; x.v = a.v / b.v;
 #pragma unroll
     for (int i = 0; i < 7; ++i) x.g[i] = a.g[i] * ia + b.g[i] * ib;
     return x; }
-__device__ __forceinline__ D7 d7_soft(D7 a, float k) {          // dmath.operation.sigmoid(value, constant = k)
+__device__ __forceinline__ D7 d7_soft(D7 a, float k, bool exact = false) {          // dmath.operation.sigmoid(value, constant = k)
     float s, ds;
-    soft_switch_both(a.v, k, s, ds);
+    soft_switch_both(a.v, k, s, ds, exact);
     D7 x; x.v = s;
 #pragma unroll
     for (int i = 0; i < 7; ++i) x.g[i] = a.g[i] * ds;
@@ -301,7 +301,7 @@ template <class A> __device__ __forceinline__ void ns_signal_fill(const A &a, co
         if (q >= a.sq) return;
         float we, ns, av, pr; int ai;
         const bool hard = a.hard != 0;
-        phase_signal_at(action, a.n_action, a.sq, a.F, t / a.F, t % a.F, q, we, ns, av, pr, ai, hard);
+        phase_signal_at(action, a.n_action, a.sq, a.F, t / a.F, t % a.F, q, we, ns, av, pr, ai, hard, a.tensor_ladder != 0);
         const float z = (av - pr) * kSigK;
         const bool sat = hard || z < -16.f || z > 16.f;
         const auto s4 = a.sg + ((size_t)(t & 1) * a.sq + q) * 4;
@@ -320,7 +320,7 @@ template <class A> __device__ __forceinline__ float ns_lane_signal(const A &a, c
         return kd == 1 ? s4[0] : s4[1];
     } else {
         float we, ns, av, pr; int ai;
-        phase_signal_at(action, a.n_action, a.sq, a.F, t / a.F, t % a.F, a.inter[lid], we, ns, av, pr, ai, hard);
+        phase_signal_at(action, a.n_action, a.sq, a.F, t / a.F, t % a.F, a.inter[lid], we, ns, av, pr, ai, hard, a.tensor_ladder != 0);
         if (ds_da) {
             const float z = (av - pr) * kSigK;
             const bool sat = hard || z < -16.f || z > 16.f;
@@ -501,6 +501,7 @@ template <class A> __device__ __forceinline__ void ns_micro_fwd(const A &a, int 
                 occ = true;
                 const int l = a.micro_lanes[m];
                 const size_t hs = (size_t)m * cap + n - 1;
+                const bool sig_exact = a.tensor_ladder != 0;      // (net_device.hpp sig_exp: `micro` mode takes the exponential rounded once)
                 const D7 hp = d7_var(P0[hs], 0), hv = d7_var(V0[hs], 1);
                 const int rrow = vroute[hs];
                 const int cursor = vcur[hs];
@@ -527,9 +528,9 @@ template <class A> __device__ __forceinline__ void ns_micro_fwd(const A &a, int 
                 red_dp = d7_pos_or_zero(d7_sub(d7_sub(Lc, hp), d7_c(vlen * 0.5f)));
                 const bool prev_exist = cursor > 0, next_exist = cursor < rlen - 1;
                 D7 prev_s = d7_c(0.f), next_s = d7_c(0.f);
-                if (prev_exist && !hard) prev_s = d7_soft(d7_sub(d7_c(0.f), hp), 16.f);
-                const D7 curr_s = hard ? d7_c(1.f) : d7_mul(d7_soft(hp, 16.f), d7_soft(d7_sub(Lc, hp), 16.f));
-                if (next_exist && !hard) next_s = d7_soft(d7_sub(hp, Lc), 16.f);
+                if (prev_exist && !hard) prev_s = d7_soft(d7_sub(d7_c(0.f), hp), 16.f, sig_exact);
+                const D7 curr_s = hard ? d7_c(1.f) : d7_mul(d7_soft(hp, 16.f, sig_exact), d7_soft(d7_sub(Lc, hp), 16.f, sig_exact));
+                if (next_exist && !hard) next_s = d7_soft(d7_sub(hp, Lc), 16.f, sig_exact);
                 const D7 total = d7_add(d7_add(prev_s, curr_s), next_s);
                 for (int w = 0; w < 3; w++) {
                     if ((w == 0 && !prev_exist) || (w == 2 && !next_exist)) continue;
@@ -558,7 +559,7 @@ template <class A> __device__ __forceinline__ void ns_micro_fwd(const A &a, int 
                 sigS[i] = S;
                 const double mean = (i + 1 > kNsWindow) ? (S - sigS[i - kNsWindow]) / (double)kNsWindow : S / (double)(i + 1);
                 const float k2 = 32.f / fabsf((float)mean);
-                const D7 fs = d7_soft(d7_sub(fin, d7_c(0.5f)), k2);
+                const D7 fs = d7_soft(d7_sub(fin, d7_c(0.5f)), k2, a.tensor_ladder != 0);
                 const D7 one_m = d7_sub(d7_c(1.f), fs);
                 const D7 o_dp = d7_add(d7_mul(green_dp, fs), d7_mul(red_dp, one_m));
                 const D7 o_dv = d7_add(d7_mul(green_dv, fs), d7_mul(d7_c(0.f), one_m));
