@@ -29,7 +29,6 @@
 #include "../../include/dhts.h"
 #include "arz_device.hpp"
 #include "idm_device.hpp"
-#define DHTS_SIG_EXACT_INLINE      // (net_device.hpp: the exact exponential inline in this file's kernels)
 #include "net_device.hpp"
 
 namespace dhts {
@@ -268,10 +267,11 @@ template <unsigned A, unsigned B> __device__ __forceinline__ Du<(A | B)> du_div(
 #pragma unroll
     for (int i = 0; i < kDu; ++i) x.g[i] = (du_has<A>(i) && du_has<B>(i)) ? a.g[i] * ia + b.g[i] * ib : (du_has<A>(i) ? a.g[i] * ia : (du_has<B>(i) ? b.g[i] * ib : 0.f));
     return x; }
-template <unsigned A> __device__ __forceinline__ Du<A> du_soft(Du<A> a, float k, bool exact = false) {          // dmath.operation.sigmoid(value, constant=k)
+// (kInl: net_device.hpp sig_exp -- the exact exponential inline or out of line)
+template <bool kInl = false, unsigned A> __device__ __forceinline__ Du<A> du_soft(Du<A> a, float k, bool exact = false) {          // dmath.operation.sigmoid(value, constant=k)
     const float z = a.v * k;
     const float zc = fminf(fmaxf(z, -16.f), 16.f);
-    const float sgm = 1.f / (1.f + sig_exp(-zc, exact));
+    const float sgm = 1.f / (1.f + sig_exp<kInl>(-zc, exact));
     const float grad = (z < -16.f || z > 16.f) ? 0.f : sgm * (1.f - sgm) * k;
     Du<A> x; x.v = sgm;
 #pragma unroll
@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(kMaxBlock) net_hybrid_fwd_kernel(int R_, int L
     const int sg_base = sq <= 64 ? (((B >> 6) - 2) << 6) : 0;
     const bool is_sg = tid >= sg_base && tid < sg_base + sq;
     const int sg_q = tid - sg_base;
-    if (is_sg) { float we, ns, a, pr; int ai; phase_signal_at(act, n_action, sq, F, 0, 0, sg_q, we, ns, a, pr, ai, kHard, tb.tensor_ladder != 0); sig[2 * sg_q] = we; sig[2 * sg_q + 1] = ns; }
+    if (is_sg) { float we, ns, a, pr; int ai; phase_signal_at<(kMaxBlock <= 768)>(act, n_action, sq, F, 0, 0, sg_q, we, ns, a, pr, ai, kHard, tb.tensor_ladder != 0); sig[2 * sg_q] = we; sig[2 * sg_q + 1] = ns; }
     if (++sig_fr == F) { sig_fr = 0; ++sig_ph; }
 
     // ---- micro wave state

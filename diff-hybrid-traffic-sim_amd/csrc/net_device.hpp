@@ -16,27 +16,29 @@ constexpr float kSigK = 32.f;       // sigmoid constant of the signals (_env.py:
 // such ulps grow to 1.1-1.8e-5 of the largest queue term in 4 of 2 760 episodes (profiles/r06z_fuzz_oracle.log; 0 of 2 760 with the
 // exact form).  The kernels ask for it exactly there: dhts_hybrid_tables::micro_tensor_ladder networks, signals and head gaps of
 // differentiable episodes (+3-7 % on those episodes; every other network keeps expf and its speed).
-// (Out of line in the persistent stepwise kernels -- inlined, its forty instructions and their registers made a network that never takes
-// it 6 % slower there; inline in the fused kernels (DHTS_SIG_EXACT_INLINE), where a call costs config 4's forward sweep 4 %.)
-#ifdef DHTS_SIG_EXACT_INLINE
-__device__ __forceinline__ float sig_exp_exact(float x) { return (float)exp((double)x); }
-#else
-__device__ __attribute__((noinline)) float sig_exp_exact(float x) { return (float)exp((double)x); }
-#endif
-__device__ __forceinline__ float sig_exp(float x, bool exact) { return exact ? sig_exp_exact(x) : expf(x); }
+// Two forms of it.  Out of line (kInl = false, the default): its forty instructions and their registers stay out of the callers' hot
+// paths -- inlined, the persistent stepwise kernel of a network that never takes it ran 6 % slower, and the 128-register instantiation
+// of the fused forward kernel 40 %.  Inline (kInl = true): what the fused kernels' roomier instantiations take -- a call costs config
+// 4's forward sweep 4 %.
+__device__ __forceinline__ float sig_exp_exact_inl(float x) { return (float)exp((double)x); }
+__device__ __attribute__((noinline)) float sig_exp_exact_call(float x) { return (float)exp((double)x); }
+template <bool kInl = false> __device__ __forceinline__ float sig_exp(float x, bool exact) {
+    return exact ? (kInl ? sig_exp_exact_inl(x) : sig_exp_exact_call(x)) : expf(x);
+}
 
 // dmath/operation.py:3-30
-__device__ __forceinline__ float soft_switch(float value, float constant, bool exact = false) {
+template <bool kInl = false> __device__ __forceinline__ float soft_switch(float value, float constant, bool exact = false) {
     float z = value * constant;
     z = fminf(fmaxf(z, -16.f), 16.f);
-    return 1.f / (1.f + sig_exp(-z, exact));
+    return 1.f / (1.f + sig_exp<kInl>(-z, exact));
 }
 // both at once (the reverse sweeps' loss taps): one exponential and one division instead of two of each; the same values
 // (outside the clamp the gradient is 0 and the switch is the clamped one, inside z is not changed by the clamp)
+template <bool kInl = false>
 __device__ __forceinline__ void soft_switch_both(float value, float constant, float &s, float &ds, bool exact = false) {
     const float z = value * constant;
     const float zc = fminf(fmaxf(z, -16.f), 16.f);
-    s = 1.f / (1.f + sig_exp(-zc, exact));
+    s = 1.f / (1.f + sig_exp<kInl>(-zc, exact));
     ds = (z < -16.f || z > 16.f) ? 0.f : s * (1.f - s) * constant;
 }
 __device__ __forceinline__ float soft_switch_grad(float value, float constant) {
@@ -109,6 +111,7 @@ __device__ __forceinline__ void net_fault(dhts_error *err, int code, int step, i
 // phase signals of intersection k at step t: west-east and north-south switches and their inputs (_env.py:885-962).
 // `phase_raw` = t / F and `frame` = t % F are passed in so that rollouts can count them instead of dividing every step.
 // hard = an evaluation episode (differentiable = False): float(a > progress), float(progress > a) (_env.py:928-960).
+template <bool kInl = false>
 __device__ __forceinline__ void phase_signal_at(const float *action, int n_action, int sq, int F, int phase_raw, int frame, int k,
                                                 float &we, float &ns, float &a, float &prog, int &a_index, bool hard = false,
                                                 bool exact = false) {
@@ -120,8 +123,8 @@ __device__ __forceinline__ void phase_signal_at(const float *action, int n_actio
     a = action[a_index];
     prog = (float)pr;
     if (hard) { we = a > prog ? 1.f : 0.f; ns = prog > a ? 1.f : 0.f; return; }
-    we = soft_switch(a - prog, kSigK, exact);
-    ns = soft_switch(prog - a, kSigK, exact);
+    we = soft_switch<kInl>(a - prog, kSigK, exact);
+    ns = soft_switch<kInl>(prog - a, kSigK, exact);
 }
 __device__ __forceinline__ void phase_signal(const float *action, int n_action, int sq, int F, int t, int k,
                                              float &we, float &ns, float &a, float &prog, int &a_index) {
