@@ -9,11 +9,11 @@ namespace dhts {
 constexpr float kSigK = 32.f;       // sigmoid constant of the signals (_env.py:928-960, _simulator.py:128)
 
 // The exponential of a sigmoid.  `exact` (a wave-uniform flag): the double exponential rounded once instead of the device library's expf
-// (1 ulp).  The reference evaluates torch.sigmoid on CPU float32 tensors; its exp, glibc's expf (the oracle) and a correctly rounded exp
+// (1 ulp).  The reference evaluates torch.sigmoid on CPU float32 tensors; its exp, glibc's expf and a correctly rounded exp
 // agree on all but a fraction of a per cent of arguments, the device's expf differs from them on many.  One ulp in one value is
 // harmless -- but in itscp `micro` mode (every lane an IDM lane stepped in float32 tensor arithmetic, a hundred vehicles following
 // each other for hundreds of steps) the signals and head-gap scores steer a chaotic system, and a fuzz run over random schedules saw
-// such ulps grow to 1.1-1.8e-5 of the largest queue term in 4 of 2 760 episodes (profiles/r06z_fuzz_oracle.log; 0 of 2 760 with the
+// such ulps grow to 1.1-1.8e-5 of the largest queue term in 4 of 2 760 episodes (profiles/r06z_fuzz_*.log; 0 of 2 760 with the
 // exact form).  The kernels ask for it exactly there: dhts_hybrid_tables::micro_tensor_ladder networks, signals and head gaps of
 // differentiable episodes (+3-7 % on those episodes; every other network keeps expf and its speed).
 // Two forms of it.  Out of line (kInl = false, the default): its forty instructions and their registers stay out of the callers' hot
