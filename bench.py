@@ -14,8 +14,8 @@ Every rank owns its own shard of independent lanes / replicas (weak scaling: the
 configuration above), there is no data-path collective, and the flat [d loss / d theta_shared || loss] buffer is
 all-reduced over RCCL once per pass.  Rank 0 prints ONE JSON line.
 
-roofline.achieved / frac are priced in the bytes the dominant kernel MOVES (its compact tape, checked against the PMC
-passes under profiles/); the reference's algorithmic tape bytes (48 B per cell-step, 32 B per vehicle-step) divided by
+roofline.achieved / frac are priced in the bytes the dominant kernel MOVES (its compact tape, checked against PMC passes:
+at N = 1 the run takes them itself before it touches the GPU -- live_counters -- and falls back to the ones under profiles/); the reference's algorithmic tape bytes (48 B per cell-step, 32 B per vehicle-step) divided by
 the same time are reported beside them as achieved_algorithmic / frac_algorithmic.
 """
 import argparse
@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the sub-records of the default run (N = 1: configs 3 and 4, the stepwise "
                     "network, the replica sweep, config 2 x 8 lanes; N > 1: config 5)")
+    ap.add_argument("--no-live-counters", action="store_true", help="N = 1: skip the rocprofv3 --pmc child passes taken before the timed region "
+                    "(roofline.traffic / issue_side then quote the committed passes under profiles/, fingerprint permitting)")
     ap.add_argument("--also-replicas", type=int, default=0, help="N > 1: replicas per rank of the config 5 sub-record (default 256); "
                     "giving it forces the sub-record even when the headline's shape is overridden (tests)")
     return ap.parse_args()
@@ -753,12 +755,78 @@ def make_workload(name, dev, rank, lanes=0, cells=0, time_steps=0):
     return ItscpMacroWorkload(dev, rank, lanes or 256, 0, 0)
 
 
+# Counter passes of THIS run (live_counters), keyed like profiles/issue_counters.json / pmc_traffic.json; None = not taken.
+_LIVE = {"issue": None, "traffic": None, "seconds": None}
+# FETCH_SIZE and WRITE_SIZE each alone (MI355X_MICROARCH.md, HBM section); the other two passes are the instruction-issue side
+LIVE_GROUPS = (("FETCH_SIZE",), ("WRITE_SIZE",),
+               ("GRBM_GUI_ACTIVE", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY",
+                "SQ_WAIT_INST_ANY"),
+               ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VMEM_WR",
+                "SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU_CVT"))
+
+
+def under_profiler():
+    env = os.environ
+    return any(k.startswith(("ROCPROF", "ROCP_")) for k in env) or "rocprof" in env.get("LD_PRELOAD", "")
+
+
+def live_counters(key, budget_s=240.0):
+    """HBM bytes and the instruction-issue side of the headline workload's rollout kernels, MEASURED BY THIS RUN: four child
+    processes `rocprofv3 --kernel-trace --pmc <group> -- python3 tools/run_workload.py <key> 3` (FETCH_SIZE alone, WRITE_SIZE alone,
+    two SQ groups; never a trace domain beside --pmc), started before this process touches the GPU and summarised by
+    tools/pmc_workloads_summary.py exactly like the committed passes of tools/pmc_workloads.sh.  Any failure (no rocprofv3, a
+    time-out, a counter the box refuses) leaves _LIVE empty and the record falls back to the committed passes, labelled so."""
+    import shutil
+    import tempfile
+    exe = os.environ.get("DHTS_ROCPROFV3") or shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        print("bench.py: no rocprofv3: counters not taken by this run", file=sys.stderr)
+        return False
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_workloads_summary
+    out = tempfile.mkdtemp(prefix="dhts_pmc_", dir="/tmp")
+    t0 = time.time()
+    try:
+        for i, group in enumerate(LIVE_GROUPS, 1):
+            left = budget_s - (time.time() - t0)
+            if left < 20.0:
+                raise subprocess.TimeoutExpired(exe, budget_s)
+            cmd = [exe, "--kernel-trace", "--pmc", *group, "--output-format", "csv", "-d", os.path.join(out, key, "g%d" % i), "--",
+                   sys.executable, os.path.join(ROOT, "tools", "run_workload.py"), key, "3"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=left, stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT)
+            with open(os.path.join(out, "%s.g%d.log" % (key, i)), "wb") as f:
+                f.write(r.stdout)
+            if r.returncode != 0:
+                print("bench.py: counter pass %d (%s) ended with code %d: %s" % (i, " ".join(group), r.returncode,
+                      r.stdout.decode(errors="replace")[-400:]), file=sys.stderr)
+                return False
+        issue, traffic = pmc_workloads_summary.summarise(out, quiet=True)
+        if issue.get("library_code_sha16") != library_code_sha16():
+            return False
+        for slot, got in (("issue", issue), ("traffic", traffic)):
+            _LIVE[slot] = dict(_LIVE[slot] or {}, **{k: v for k, v in got.items() if isinstance(v, dict)})
+        _LIVE["seconds"] = round((_LIVE["seconds"] or 0.0) + time.time() - t0, 1)
+        return True
+    except (OSError, subprocess.TimeoutExpired, ValueError, KeyError) as e:
+        print("bench.py: counter passes of this run failed (%s): falling back to the committed ones" % e, file=sys.stderr)
+        return False
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def pmc_source(live):
+    return ("measured by this run: rocprofv3 --pmc child passes (FETCH_SIZE and WRITE_SIZE each alone, two SQ groups) over 3 passes of this "
+            "workload before the timed region; %s s for all workloads of this run" % _LIVE["seconds"]) if live else "committed passes under profiles/ (tools/pmc_workloads.sh)"
+
+
 def pmc_traffic(w, kernel, moved=None):
     """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE, gfx950 FETCH correction applied).  Quoted only for the configuration the passes were taken on and only
     while the tape the library allocates still has the size the passes saw (a changed layout needs fresh passes)."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        pmc = _LIVE["traffic"] if _LIVE["traffic"] is not None and w.name in _LIVE["traffic"] else \
+            json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         hbm = pmc[w.name][kernel]["hbm_bytes"]
     except (OSError, ValueError, KeyError):
         return None
@@ -822,6 +890,8 @@ def issue_counters(w, kernel):
     """Instruction-issue side of `kernel` from the counter passes committed as profiles/issue_counters.json (tools/pmc_workloads.sh:
     rocprofv3 --pmc SQ_* passes over each workload at its BASELINE shape).  Not measured by this run; refused when the library's
     kernels are not the ones the passes saw (fingerprint of the device code, not of the kernel names)."""
+    if _LIVE["issue"] is not None and w.name in _LIVE["issue"] and kernel in _LIVE["issue"][w.name]:
+        return dict(_LIVE["issue"][w.name][kernel], source=pmc_source(True))
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "issue_counters.json")))
         side = rec[w.name][kernel]
@@ -877,7 +947,7 @@ def also_record(name, dev, passes=5, lanes=0):
     el = time.perf_counter() - t0
     check_faults(w, "the bench")
     kernels, dom = kernel_records(w)
-    for k in kernels:          # the counters behind each kernel's `limiter` (committed passes of this very shape, fingerprinted)
+    for k in kernels:          # the counters behind each kernel's `limiter` (this run's passes, else the committed ones, fingerprinted)
         side = issue_counters(w, k)
         if side is not None:
             kernels[k]["issue_side"] = side
@@ -985,6 +1055,12 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))        # before any GPU call: the children own the devices
+    if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.workload != "stub" and not args.no_live_counters
+            and not (args.lanes or args.cells or args.time_steps) and not under_profiler() and torch.cuda.device_count() > 0):
+        # child processes; this one has not touched the GPU yet.  The default run takes them for its sub-records' workloads too
+        for key in ((args.workload,) if args.no_also or args.workload != "macro" else ("macro", "micro", "itscp_hybrid", "itscp_stepwise")):
+            if not live_counters(key):
+                break
     from dhts import dist as D
     rank, world, local = D.init()                  # (makes this rank's GPU current, then builds the process group on it)
     if world != args.gpus and rank == 0:
@@ -1094,6 +1170,7 @@ def main():
                                          "d loss / d action || loss" if shared_grad else "loss")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": k["frac_of_peak"], "traffic": pmc_traffic(w, dom, moved), "traffic_unit": "bytes per launch (PMC)",
+                         "traffic_source": pmc_source(_LIVE["traffic"] is not None and w.name in _LIVE["traffic"]),
                          "moved_bytes_per_launch": moved,
                          "algorithmic_bytes_per_launch": w.units * w.unit_bytes,
                          "achieved_algorithmic": k["algorithmic_GBps"], "frac_algorithmic": k["algorithmic_GBps"] / HBM_PEAK_GBS,
