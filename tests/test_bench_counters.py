@@ -3,6 +3,7 @@ rocprofv3 that writes the csv a real pass would (CPU; the real passes run in the
 import json
 import os
 import stat
+import time
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -53,7 +54,7 @@ class _W:
 
 def test_live_counters_summarise_three_passes(tmp_path, monkeypatch):
     _standin(tmp_path, monkeypatch, bench.library_code_sha16())
-    assert bench.live_counters("macro") is True
+    assert bench.live_counters("macro", time.time() + 60.0) is True
     fwd = bench._LIVE["traffic"][_W.name]["rollout_fwd"]
     assert fwd["write_bytes"] == 8.0e6 * 1024 and fwd["fetch_bytes_corrected"] == 4.0e6 * 1024 * 2      # KiB; FETCH doubled on gfx950
     assert bench.pmc_traffic(_W, "rollout_fwd", moved=fwd["hbm_bytes"] * 1.01) == fwd["hbm_bytes"]
@@ -66,7 +67,7 @@ def test_live_counters_summarise_three_passes(tmp_path, monkeypatch):
 
 def test_live_counters_of_another_build_are_refused(tmp_path, monkeypatch):
     _standin(tmp_path, monkeypatch, "0123456789abcdef")
-    assert bench.live_counters("macro") is False and bench._LIVE["traffic"] is None
+    assert bench.live_counters("macro", time.time() + 60.0) is False and bench._LIVE["traffic"] is None
     side = bench.issue_counters(_W, "rollout_fwd")             # falls back to the committed passes (or to nothing), never to a live label
     assert side is None or "not measured by this run" in side["source"]
 
@@ -77,3 +78,8 @@ def test_live_counters_are_skipped_under_a_profiler(monkeypatch):
     monkeypatch.delenv("ROCPROFILER_LIBRARY_CTOR")
     monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
     assert bench.under_profiler()
+
+
+def test_live_counters_give_up_at_the_deadline(tmp_path, monkeypatch):
+    _standin(tmp_path, monkeypatch, bench.library_code_sha16())
+    assert bench.live_counters("macro", time.time() + 5.0) is False and bench._LIVE["issue"] is None
