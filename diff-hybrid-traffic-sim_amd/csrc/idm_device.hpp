@@ -79,9 +79,15 @@ __device__ __forceinline__ void idm_step_ieee(double p, double v, double dp_raw,
 // whose vehicle states become float32 TENSORS with the first head gap, so IDM.compute_acceleration and the Euler step
 // (_idm.py:30-50, _micro_lane.py:166-183) are evaluated by torch: every operation rounds to float32, a Python float operand is cast
 // to float32 first, pow(x, 2.0) is x * x, pow(x, 4.0) is powf (here: the float64 power rounded once).  Values in that ladder;
-// the Jacobian blocks -- what autograd differentiates -- from the analytic formulas at the same operands.
-// dp_raw, dv_raw: gap and speed difference as float32 tensor arithmetic gives them (|p_l - p| - float32((len_l + len) / 2), v - v_l).
-__device__ __forceinline__ void idm_step_f32(float p, float v, float dp_raw, float dv_raw, const IdmParams &m, double dt, IdmStep &o) {
+// the Jacobian blocks -- what autograd differentiates: the forward's OWN operations -- from the analytic formulas at the operands the
+// forward used: after a collision both deltas are the Python ints 0, 0 (_micro_lane.py:151-162) and below POSITION_DELTA_EPS max()
+// picks the Python float (:166) -- constants, nothing flows through them (dIDM's un-clamped deltas, dmicro_lane.py:97, are the hybrid
+// lanes' rule: there a zero gap divides by zero, here it must not -- reference runs of congested 8-second episodes have finite
+// gradients, tests/golden/itscp_micro_jam_*.npz); abs() hands the gap's cotangent on with the sign of (leader - ego).
+// dp_raw, dv_raw: gap and speed difference as float32 tensor arithmetic gives them (|p_l - p| - float32((len_l + len) / 2), v - v_l);
+// lead_sign: sign(p_l - p) of a follower (1 for a head vehicle: its gap is handed in).
+__device__ __forceinline__ void idm_step_f32(float p, float v, float dp_raw, float dv_raw, const IdmParams &m, double dt, IdmStep &o,
+                                             float lead_sign = 1.f) {
     float dp = dp_raw, dv = dv_raw;
     o.collided = dp < 0.f;
     if (o.collided) { dp = 0.f; dv = 0.f; }
@@ -106,15 +112,16 @@ __device__ __forceinline__ void idm_step_f32(float p, float v, float dp_raw, flo
     o.dE[0] = 1.f; o.dE[1] = (float)dt; o.dE[2] = 0.f; o.dE[3] = 0.f;
     o.dLd[0] = o.dLd[1] = o.dLd[2] = o.dLd[3] = 0.f;
     if (!clipped_a) {
-        const double vd = v, sd = s, dpr = dp_raw, dvr = dv_raw;
+        const bool live_dp = !o.collided && !((float)1e-5 > dp);      // the gap is still the tensor
+        const double vd = v, sd = s, dpr = dpc, dvr = o.collided ? -vd : (double)dv_raw;      // (collided: v + dv = 0 below)
         const double dp2 = dpr * dpr;
         const double dp3 = dp2 * dpr;
         const double s2_dp3 = (sd * sd) / dp3;
         const double vt2 = m.v_target * m.v_target;
         const double free_term = -4.0 * ((vd * vd * vd) / (vt2 * vt2));
         const double s_dp2 = sd / dp2;
-        o.dE[2] = (float)(dt * (-2 * m.a_max * s2_dp3));
-        o.dLd[2] = (float)(dt * (2 * m.a_max * s2_dp3));
+        o.dE[2] = live_dp ? (float)(dt * (-2 * m.a_max * s2_dp3)) * lead_sign : 0.f;
+        o.dLd[2] = live_dp ? (float)(dt * (2 * m.a_max * s2_dp3)) * lead_sign : 0.f;
         if (clipped_s) {
             o.dE[3] = (float)(1 + dt * m.a_max * free_term);
             o.dLd[3] = (float)(dt * m.a_max * (-2 * s_dp2));
@@ -122,6 +129,7 @@ __device__ __forceinline__ void idm_step_f32(float p, float v, float dp_raw, flo
             o.dE[3] = (float)(1 + dt * m.a_max * (free_term - 2 * s_dp2 * (m.time_pref + ((vd + dvr) / two_sqrt_ab))));
             o.dLd[3] = (float)(dt * m.a_max * (-2 * s_dp2 * (-vd / two_sqrt_ab)));
         }
+        if (o.collided) o.dLd[3] = 0.f;        // (speed_delta is the int 0: the leader's speed is out of the step)
     }
 }
 

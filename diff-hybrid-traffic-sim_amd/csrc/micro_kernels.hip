@@ -364,7 +364,8 @@ __global__ void micro_step_tensor_fwd_kernel(int L, int V, double dt, const floa
             }
             idm_step_lane(pi, vi, dpd, dvd, i == n - 1, m, dt, o);
         } else {
-            idm_step_f32(pi, vi, dp, dv, m, dt, o);
+            const float sg = i == n - 1 ? 1.f : (p_in[base + i + 1] > pi ? 1.f : (p_in[base + i + 1] < pi ? -1.f : 0.f));
+            idm_step_f32(pi, vi, dp, dv, m, dt, o, sg);
         }
         if (o.collided && fault_index < 0) fault_index = i;
         p_out[base + i] = o.np; v_out[base + i] = o.nv;

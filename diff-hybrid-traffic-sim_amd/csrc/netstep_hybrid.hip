@@ -598,10 +598,14 @@ template <class A> __device__ __forceinline__ void ns_micro_fwd(const A &a, int 
         auto one_step = [&](const IdmParams &pm) {
             if (f32_ladder) {            // `micro` mode, differentiable: the reference steps these lanes in float32 tensor arithmetic (idm_device.hpp)
                 const float p = P0[idx], v = V0[idx];
-                float dp, dv;
+                float dp, dv, sg = 1.f;
                 if (i == n - 1) { dp = hd_s[2 * m]; dv = hd_s[2 * m + 1]; }
-                else { dp = fabsf(P0[idx + 1] - p) - (float)((pm.length + pm.length) * 0.5); dv = v - V0[idx + 1]; }
-                idm_step_f32(p, v, dp, dv, pm, a.dt_d, o);
+                else {
+                    const float pl = P0[idx + 1];
+                    dp = fabsf(pl - p) - (float)((pm.length + pm.length) * 0.5); dv = v - V0[idx + 1];
+                    sg = pl > p ? 1.f : (pl < p ? -1.f : 0.f);
+                }
+                idm_step_f32(p, v, dp, dv, pm, a.dt_d, o, sg);
             } else {
                 const double p = P0[idx], v = V0[idx];
                 double dp, dv;

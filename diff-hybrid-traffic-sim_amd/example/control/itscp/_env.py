@@ -467,42 +467,7 @@ class ItscpEnv:
                 except ValueError:
                     net = self._batched_net = BatchedMacroNetwork(tabs, device)
                 return ("batched", net)
-            tab = HybridNetworkTables.from_env(self)
-            veh_params = getattr(self, "fused_vehicle_params", None)     # [routes][6] beside `fused_routes` (hybrid mode), or None
-            if mode == "micro":
-                # every lane an IDM lane; source lanes admit their waiting vehicles against np.random draws
-                # (_simulator.py:153-174): the waiting routes in admission order (the list is popped from its end) are
-                # the route rows, the draws of the episode are drawn up front (fused_draws replays a recorded stream)
-                rows, vrows = [], []
-                for l in range(tab.n_lanes):
-                    waiting = sim.lane_waiting_micro_vehicle.get(l, [])
-                    for k, r in enumerate(reversed(sim.lane_waiting_micro_route.get(l, []))):
-                        r = list(r.route)[:32]
-                        rows.append(r + [-1] * (32 - len(r)))
-                        v = waiting[len(waiting) - 1 - k] if k < len(waiting) else None
-                        vrows.append(_vehicle_attributes(v, sim))
-                routes = np.asarray(rows if rows else [[-1, -1]], dtype=np.int32)
-                # the waiting vehicles' own IDM attributes ride beside their routes (dhts_hybrid_tables::veh_params) unless every one of
-                # them is the default vehicle the reference's reset() builds (_env.py:205-219)
-                if any(v != _vehicle_attributes(None, sim) for v in vrows):
-                    veh_params = np.asarray(vrows, dtype=np.float64)
-                self._fused_n_draws = T * max(1, int(tab.lane_source.sum()))
-                tab.set_micro_sources(np.full(self._fused_n_draws, 2.0))
-            else:
-                routes = getattr(self, "fused_routes", None)
-                if routes is None:
-                    routes = getattr(self, "_fused_routes_drawn", None)      # (a capacity retry is the same episode: the same routes)
-                if routes is None:
-                    routes = []
-                    for l in range(tab.n_lanes):
-                        if tab.lane_macro[l] == 0 and any(tab.lane_macro[a] for a in tab.prev_lanes[l]):
-                            for _ in range(8):
-                                r = list(sim.create_random_route(l).route)[:32]
-                                routes.append(r + [-1] * (32 - len(r)))
-                    if not routes:
-                        routes = [[-1, -1]]
-                    self._fused_routes_drawn = routes
-                routes = np.asarray(routes, dtype=np.int32)
+            tab, routes, veh_params = self._fused_episode_inputs()
             fits = True
             try:
                 tab.check_kernel_limits()
@@ -518,6 +483,51 @@ class ItscpEnv:
             return ("stepwise", self._stepwise_net(tab, routes, device, lane_cap, veh_params))
         except ValueError:
             return ("none", None)
+
+    def _fused_episode_inputs(self):
+        """(tables, route rows, per-row vehicle attributes or None) of a `hybrid` / `micro` mode episode as the network kernels take
+        them -- host arrays; tools/probes/fuzz_env.py hands the same three to the CPU checker."""
+        from dhts.network import HybridNetworkTables
+        sim = self.simulator
+        mode = self.config["mode"]
+        T = self.num_timestep
+        tab = HybridNetworkTables.from_env(self)
+        veh_params = getattr(self, "fused_vehicle_params", None)     # [routes][6] beside `fused_routes` (hybrid mode), or None
+        if mode == "micro":
+            # every lane an IDM lane; source lanes admit their waiting vehicles against np.random draws
+            # (_simulator.py:153-174): the waiting routes in admission order (the list is popped from its end) are
+            # the route rows, the draws of the episode are drawn up front (fused_draws replays a recorded stream)
+            rows, vrows = [], []
+            for l in range(tab.n_lanes):
+                waiting = sim.lane_waiting_micro_vehicle.get(l, [])
+                for k, r in enumerate(reversed(sim.lane_waiting_micro_route.get(l, []))):
+                    r = list(r.route)[:32]
+                    rows.append(r + [-1] * (32 - len(r)))
+                    v = waiting[len(waiting) - 1 - k] if k < len(waiting) else None
+                    vrows.append(_vehicle_attributes(v, sim))
+            routes = np.asarray(rows if rows else [[-1, -1]], dtype=np.int32)
+            # the waiting vehicles' own IDM attributes ride beside their routes (dhts_hybrid_tables::veh_params) unless every one of
+            # them is the default vehicle the reference's reset() builds (_env.py:205-219)
+            if any(v != _vehicle_attributes(None, sim) for v in vrows):
+                veh_params = np.asarray(vrows, dtype=np.float64)
+            self._fused_n_draws = T * max(1, int(tab.lane_source.sum()))
+            tab.set_micro_sources(np.full(self._fused_n_draws, 2.0))
+        else:
+            routes = getattr(self, "fused_routes", None)
+            if routes is None:
+                routes = getattr(self, "_fused_routes_drawn", None)      # (a capacity retry is the same episode: the same routes)
+            if routes is None:
+                routes = []
+                for l in range(tab.n_lanes):
+                    if tab.lane_macro[l] == 0 and any(tab.lane_macro[a] for a in tab.prev_lanes[l]):
+                        for _ in range(8):
+                            r = list(sim.create_random_route(l).route)[:32]
+                            routes.append(r + [-1] * (32 - len(r)))
+                if not routes:
+                    routes = [[-1, -1]]
+                self._fused_routes_drawn = routes
+            routes = np.asarray(routes, dtype=np.int32)
+        return tab, routes, veh_params
 
     def _stepwise_net(self, tab, routes, device, lane_cap, veh_params=None):
         from dhts.stepwise import StepwiseNetwork

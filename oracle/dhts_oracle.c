@@ -630,9 +630,21 @@ int oracle_micro_step_f32(int V, const float *p, const float *v, const double *p
         if (lim > acc) acc = lim;
         np_[i] = p[i] + dtf * v[i];
         nv_[i] = v[i] + dtf * acc;
-        if (dqs)
-            oracle_idm_jac(pr[0], pr[1], v[i], pr[2], dp_raw, dv_raw, pr[3], pr[4], (double)s, dt, fl,
-                           dqs + (size_t)i * 8, dqs + (size_t)i * 8 + 4);
+        if (dqs) {
+            /* What autograd differentiates here is the forward's own operations: after a collision both deltas are the Python ints 0, 0
+             * (_micro_lane.py:151-162) and below POSITION_DELTA_EPS max() picks the Python float (:166) -- constants, nothing flows
+             * through them -- where dIDM's formulas take the un-clamped deltas (dmicro_lane.py:97: the hybrid lanes).  abs() hands the
+             * gap's cotangent on with the sign of (leader - ego).  With a live gap both are the same blocks. */
+            const int collided = dp_raw < 0;
+            const int live_dp = !collided && !((float)1e-5 > dp);
+            float sg = 1.f;
+            if (i < V - 1) sg = p[i + 1] > p[i] ? 1.f : (p[i + 1] < p[i] ? -1.f : 0.f);
+            float *dE = dqs + (size_t)i * 8, *dLd = dqs + (size_t)i * 8 + 4;
+            oracle_idm_jac(pr[0], pr[1], v[i], pr[2], (double)dpc, collided ? -(double)v[i] : dv_raw, pr[3], pr[4], (double)s, dt, fl, dE, dLd);
+            if (!live_dp) { dE[2] = 0.f; dLd[2] = 0.f; }
+            else { dE[2] *= sg; dLd[2] *= sg; }
+            if (collided) dLd[3] = 0.f;         /* (speed_delta is the int 0: the leader's speed is out of the step; v + dv = 0 above leaves dE[3] its own-speed terms) */
+        }
     }
     return rc;
 }
@@ -838,6 +850,8 @@ int oracle_net_macro_fwd(const oracle_net_desc *d, const int *lane_ncell, const 
     const float um = (float)d->u_max;
     int rc = ORACLE_OK;
     int maxn = 0;
+    /* (a schedule needs one action per intersection at least: the library's DHTS_E_INVALID) */
+    if (d->n_inter_sq <= 0 || d->n_action < d->n_inter_sq || d->frames_per_phase <= 0) return ORACLE_E_INVALID;
     for (int l = 0; l < L; l++) if (lane_ncell[l] > maxn) maxn = lane_ncell[l];
     float *pad = (float *)malloc(sizeof(float) * 8 * (size_t)(maxn + 2));
     float *own_r = (float *)malloc(sizeof(float) * 2 * (size_t)L);      /* stored downstream ghost (r, u) of sink lanes */

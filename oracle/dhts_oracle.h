@@ -30,6 +30,7 @@ extern "C" {
 #define ORACLE_ERR_CFL 1
 #define ORACLE_ERR_COLLISION 2
 #define ORACLE_ERR_ROUTE 3        /* hybrid network: spawn without a matching pre-drawn route / lane over capacity */
+#define ORACLE_E_INVALID 4        /* network episodes: fewer actions than intersections, no frames per phase (the library: DHTS_E_INVALID) */
 
 /* ---- ARZ: one interface -------------------------------------------------------------------- */
 /* L, R: (r, y, u, u_eq) of the left / right cell as doubles holding float32 values.

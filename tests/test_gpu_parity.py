@@ -985,6 +985,36 @@ def test_micro_step_tensor_ladder_vs_oracle(cuda, oracle, V):
     assert V == 1 or differs > 0
 
 
+def test_micro_step_tensor_ladder_at_the_clamps(cuda, oracle):
+    """The float32 tensor ladder where the forward clamps (found by tools/probes/fuzz_env.py, pinned by tests/golden/itscp_micro_jam_*):
+    a collision (both deltas become the ints 0, 0), a gap of exactly 0 and one below POSITION_DELTA_EPS (max() picks the Python float),
+    a leader that has fallen behind (abs() flips the sign).  Autograd differentiates those operations: the blocks are finite, the
+    gap's entries are 0 where the gap is a constant -- device and restatement agree, and dIDM's un-clamped formulas do not apply."""
+    import torch
+    from dhts import ops
+    L, V, dt = 1, 8, 1.0 / 30.0
+    # vehicles tail -> head; lengths 5: gap_i = |p[i+1] - p[i]| - 5
+    p = np.array([[0.0, 4.0, 9.0, 14.000004, 30.0, 22.0, 40.0, 60.0]], dtype=np.float32)     # gaps: -1 (collided), 0, 4e-6, 11, 3 (leader behind), 13, 15
+    v = np.array([[8.0, 6.0, 5.0, 7.0, 9.0, 4.0, 10.0, 12.0]], dtype=np.float32)
+    prm = np.empty((L, V, 6)); prm[:] = [2.0, 1.6, 30.0, 2.0, 1.5, 5.0]
+    head = np.array([[3e-6, 1.0]], dtype=np.float32).astype(np.float64)                        # the head's gap below the epsilon too
+    desc = ops.micro_desc(L, V, dt)
+    tape = torch.empty(ops.micro_step_tape_numel(desc), dtype=torch.float32, device=cuda)
+    params_d = torch.tensor(np.ascontiguousarray(prm.transpose(2, 0, 1)), dtype=torch.float64, device=cuda)
+    np_t, nv_t = ops.micro_step_fwd(desc, torch.tensor(p, device=cuda), torch.tensor(v, device=cuda), params_d, torch.tensor(head, device=cuda),
+                                    tape=tape, tensor_ladder=True)
+    tp = tape.view(L, 2, 64, 4).cpu().numpy()[0, :, :V]
+    o = oracle.micro_step_f32(p[0], v[0], prm[0], head[0, 0], head[0, 1], dt)
+    dq = o["dqs"].reshape(V, 2, 4)
+    assert np.array_equal(np_t[0].cpu().numpy(), o["np"]) and np.array_equal(nv_t[0].cpu().numpy(), o["nv"])
+    assert np.isfinite(tp).all() and np.isfinite(dq).all()
+    assert rel_max(tp[0], dq[:, 0]) <= 1e-6 and rel_max(tp[1], dq[:, 1]) <= 1e-6
+    for i in (0, 1, 2, 7):          # collided, zero gap, below the epsilon, the head below the epsilon: the gap is a constant
+        assert tp[0, i, 2] == 0.0 and tp[1, i, 2] == 0.0, i
+    assert tp[1, 0, 3] == 0.0       # collided: the leader's speed is out of the step too
+    assert tp[1, 3, 2] > 0.0 and tp[1, 4, 2] < 0.0 and tp[0, 4, 2] == -tp[1, 4, 2]       # a leader ahead / behind: the sign of abs()
+
+
 @pytest.mark.gpu
 def test_macro_step_reads_a_source_ghost_in_double(cuda):
     """A boundary cell of plain Python floats -- an itscp source lane's inflow (r, u_eq(r)), _simulator.py:68-71 -- enters the

@@ -439,7 +439,7 @@ def test_hybrid_evaluation_episode_vs_reference(cuda, oracle, golden_dir, name):
     assert torch.equal(reward, reward2) and torch.equal(queue, queue2)
 
 
-@pytest.mark.parametrize("name", ["micro_small", "micro", "micro_p2", "micro_l10"])
+@pytest.mark.parametrize("name", ["micro_small", "micro", "micro_p2", "micro_l10", "micro_jam_a", "micro_jam_b", "micro_jam_c"])
 def test_itscp_micro_mode_through_fused_kernels(cuda, oracle, golden_dir, name):
     """itscp `micro` mode (run_itscp_micro.sh: 40 IDM lanes, no cells, 65 vehicles admitted stochastically by the source lanes,
     _simulator.py:153-174) through dhts_net_hybrid_rollout_fwd / _bwd: the recorded admission draws as data, waiting routes as

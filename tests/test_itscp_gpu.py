@@ -132,7 +132,7 @@ def test_itscp_rollout_matches_reference(cuda, golden_dir, name):
     assert np.abs(total - g["g_action"]).max() <= TOL_GRAD * scale
 
 
-@pytest.mark.parametrize("name", ["micro_small", "micro"])
+@pytest.mark.parametrize("name", ["micro_small", "micro", "micro_jam_a"])
 def test_itscp_micro_mode_matches_reference(cuda, golden_dir, name):
     """itscp `micro` mode (run_itscp_micro.sh: every lane an IDM lane, source lanes admit waiting vehicles stochastically,
     _simulator.py:153-174) through the mirror classes on the kernels, against the reference's run.  The reference uses the
@@ -240,7 +240,7 @@ def test_env_evaluation_step_uses_fused_kernels(cuda, golden_dir, name):
         print("evaluation episode %s: fused %.1f ms (first call, with table upload), lane by lane %.1f s" % (name, 1e3 * t_fused, t_slow))
 
 
-@pytest.mark.parametrize("name", ["micro_small", "micro"])
+@pytest.mark.parametrize("name", ["micro_small", "micro", "micro_jam_a"])
 def test_env_micro_mode_step_uses_fused_kernels(cuda, golden_dir, name):
     """ItscpEnv.step(action, True) in `micro` mode through the fused kernels (two launches instead of 40 lanes x 300 steps of
     operator calls), the reference's recorded admission draws replayed as data (env.fused_draws)."""

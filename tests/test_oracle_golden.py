@@ -337,14 +337,17 @@ def itscp_vehicle_params(g):
     return np.asarray(rows, dtype=np.float64)
 
 
-@pytest.mark.parametrize("name", ["micro_small", "micro", "micro_2x2", "micro_p2", "micro_l10"])
+@pytest.mark.parametrize("name", ["micro_small", "micro", "micro_2x2", "micro_p2", "micro_l10", "micro_jam_a", "micro_jam_b", "micro_jam_c"])
 def test_itscp_micro_mode_network(oracle, golden_dir, name):
     """itscp `micro` mode (run_itscp_micro.sh: 40 IDM lanes, 65 vehicles admitted stochastically over 300 steps; and a 16-lane
     case): source lanes admit waiting vehicles against the host's recorded draws (_simulator.py:153-174), every recorded draw
     is consumed, same vehicle count, queues, reward and d reward / d action as the reference's run.  (The reference steps
     these lanes with the plain autodiff MicroLane in float32 TENSOR arithmetic; since round 5 the restatement follows that ladder
     operation by operation in this mode (oracle_micro_step_f32): queues 6e-8 / 2.2e-6 / 1.7e-7 on the three goldens, where the
-    analytic operator's float64 ladder gave 1.2e-5 / 3.7e-6 / 2.7e-6.)"""
+    analytic operator's float64 ladder gave 1.2e-5 / 3.7e-6 / 2.7e-6.)
+    micro_jam_*: congested 8-second episodes (~110 vehicles on 60 m lanes) whose followers close in below POSITION_DELTA_EPS and collide:
+    autograd differentiates the forward's clamps there (constants), the gradient is finite -- dIDM's formulas at the un-clamped gap
+    (the hybrid lanes' rule) divide by zero on all three."""
     g = load(golden_dir, "itscp_%s.npz" % name)
     t, m, rows = itscp_micro_tables(g)
     from dhts.network import group_routes

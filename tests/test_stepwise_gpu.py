@@ -86,7 +86,7 @@ def test_stepwise_macro_matches_reference(cuda, golden_dir, name):
     assert o["counts"][0] == 0 and o["counts"][2] == 0
 
 
-@pytest.mark.parametrize("name", ["micro_small", "micro", "micro_2x2", "micro_p2", "micro_l10"])
+@pytest.mark.parametrize("name", ["micro_small", "micro", "micro_2x2", "micro_p2", "micro_l10", "micro_jam_a", "micro_jam_b", "micro_jam_c"])
 def test_stepwise_micro_mode_matches_reference(cuda, golden_dir, name):
     """itscp `micro` mode: every lane an IDM lane, source lanes admit waiting vehicles against the host's recorded draws; 16, 40 and
     112 lanes (the last beyond the fused kernels' 64).  The reference steps these lanes with the autodiff MicroLane in float32 tensor
@@ -263,7 +263,7 @@ def test_persistent_form_equals_stepwise_form_and_reference(cuda, golden_dir, na
     assert np.array_equal(oe_p["queue"], oe_s["queue"]) and np.array_equal(oe_p["counts"], oe_s["counts"])     # evaluation episodes too
 
 
-@pytest.mark.parametrize("name", ["micro_small", "micro_2x2", "micro_p2", "micro_l10"])
+@pytest.mark.parametrize("name", ["micro_small", "micro_2x2", "micro_p2", "micro_l10", "micro_jam_a", "micro_jam_b", "micro_jam_c"])
 def test_persistent_form_micro_mode(cuda, golden_dir, name):
     from dhts.stepwise import StepwiseNetwork
     g = np.load(os.path.join(golden_dir, "itscp_%s.npz" % name))

@@ -1071,6 +1071,14 @@ def main():
             gen_itscp("hybrid_rv_n2", "hybrid", 3, 2, 5.0, 8, 2, seed=137, action_kind="rand", problem=1, random_vehicles=0.7)
         if "eval_hybrid_rv" in which:
             gen_itscp("eval_hybrid_rv", "hybrid", 3, 1, 5.0, 16, 4, seed=121, action_kind="rand", problem=2, differentiable=False, random_vehicles=0.7)
+        # congested `micro` mode episodes (8 s, 60 m lanes, ~110 vehicles): followers close in below POSITION_DELTA_EPS and collide
+        # ("Set deltas to 0"), where autograd differentiates the forward's clamps -- constants -- and the gradient stays finite
+        # (found by tools/probes/fuzz_env.py: dIDM's formulas at the un-clamped gap divide by zero there)
+        for nm, sd, pb in (("micro_jam_a", 1, 2), ("micro_jam_b", 14, 3), ("micro_jam_c", 25, 2)):
+            if nm in which:
+                os.environ.pop("DHTS_FINE_CUTS", None)
+                os.environ.pop("DHTS_LANE_LATE", None)
+                gen_itscp(nm, "micro", 1, 3, 60.0, 8, 1, seed=sd, action_kind="rand", problem=pb)
         if "hybrid_short" in which:      # 8 s: enough for the first vehicles to cross the interior intersection
             gen_itscp("hybrid_short", "hybrid", 3, 1, 5.0, 8, 2, seed=9, action_kind="rand")
 
