@@ -652,7 +652,7 @@ class SolverMargins:
 
 
 def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, action_kind, problem=1, differentiable=True,
-              random_vehicles=False, action_override=None, draws_override=None):
+              random_vehicles=False, action_override=None, draws_override=None, speed_limit=60.0):
     """action_override / draws_override (tools/probes/ref_replay_case.py): another action vector, and the admission draws of `micro` mode
     taken from a given stream instead of np.random -- the reference on a case a fuzz run found, to adjudicate between oracle and kernels.
     random_vehicles: every vehicle that enters the network takes the attributes of a MicroVehicle.random_micro_vehicle(speed_limit)
@@ -670,7 +670,7 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
     env.schedule_callback = getattr(problems, "problem_%d" % problem)
     env.render_eval = False
     for k, v in dict(num_intersection=n_int, lane_length=lane_length, num_lane=n_lane, render=False, policy_length=sim_len,
-                     signal_length=sig_len, mode=mode, speed_limit=60.0, random_seed=seed).items():
+                     signal_length=sig_len, mode=mode, speed_limit=float(speed_limit), random_seed=seed).items():
         env.config[k] = v
     env.reset()
     sim = env.simulator
@@ -781,7 +781,7 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
             waiting_routes=np.array(json.dumps(waiting_routes)),
             veh_params=np.array(veh_params, dtype=np.float64).reshape(len(veh_params), 6), waiting_params=np.array(json.dumps(waiting_params)),
             meta=meta(seed=seed, mode=mode, num_intersection=n_int, num_lane=n_lane, lane_length=lane_length,
-                      policy_length=sim_len, signal_length=sig_len, speed_limit=60.0, cell_length=5.0, simulation_frequency=30,
+                      policy_length=sim_len, signal_length=sig_len, speed_limit=float(speed_limit), cell_length=5.0, simulation_frequency=30,
                       static_speed=0.2, vehicle_length=5.0, T=T, n_vehicle_spawned=nveh, problem=problem,
                       action_kind=action_kind, differentiable=False, **margins.as_meta(), ref_seconds_fwd=t1 - t0))
         return
@@ -840,7 +840,7 @@ def gen_itscp(name, mode, n_int, n_lane, lane_length, sim_len, sig_len, seed, ac
         g_lane_late_ids=np.array(sorted(g_lane_late), dtype=np.int32),
         g_lane_late=np.array([g_lane_late[i] for i in sorted(g_lane_late)], dtype=np.float32).reshape(len(g_lane_late), len(a0)),
         meta=meta(seed=seed, mode=mode, num_intersection=n_int, num_lane=n_lane, lane_length=lane_length,
-                  policy_length=sim_len, signal_length=sig_len, speed_limit=60.0, cell_length=5.0, simulation_frequency=30,
+                  policy_length=sim_len, signal_length=sig_len, speed_limit=float(speed_limit), cell_length=5.0, simulation_frequency=30,
                   static_speed=0.2, vehicle_length=5.0, T=T, n_vehicle_spawned=nveh, problem=problem,
                   action_kind=action_kind, **margins.as_meta(),
                   ref_seconds_fwd=t1 - t0, ref_seconds_bwd=t2 - t1))
