@@ -53,19 +53,22 @@ for name in names:
     net = StepwiseNetwork(t, routes, cuda, lane_capacity=max(16, default_lane_capacity(t, m["vehicle_length"])), persistent=True, vehicle_params=vp)
     wq = wg = 0.0
     done = skipped = 0
+    why = {}
     for k in range(n_act):
         act = rng.uniform(0.05, 0.95, len(g["action"])).astype(np.float32)
         ref = O.net_hybrid(t, gr, ptr, act, *args, hard=hard, want_grad=not hard, vehicle_params=gvp)
         if ref["rc"] != 0:
             skipped += 1
+            why["oracle rc %d" % ref["rc"]] = why.get("oracle rc %d" % ref["rc"], 0) + 1
             continue
         a = torch.tensor(act, device=cuda, requires_grad=not hard)
         try:
             cut, reward, queue, counts = net.rollout(a, *args, differentiable=not hard)
             if not hard:
                 cut.backward()
-        except (ops.CapacityError, AssertionError):
+        except (ops.CapacityError, AssertionError) as e:
             skipped += 1
+            why[type(e).__name__] = why.get(type(e).__name__, 0) + 1
             continue
         q = queue.cpu().numpy()
         c = counts.cpu().numpy()
@@ -84,7 +87,7 @@ for name in names:
             print("MISMATCH", name, "schedule", k, "counts", c[:2], (ref["n_spawned"], ref["n_deposits"]), "queues %.1e reward %.1e" % (eq, er),
                   "| largest at step %d lane %d (kernel %.9g, oracle %.9g); first entry above 1e-6: step %s" % (
                       tt, ll, q[tt, ll], ref["queue"][tt, ll], None if not len(first) else tuple(first[0])))
-    print("%-22s %4d lanes %5d cells: %d schedules vs the oracle (%d refused): queues %.1e, gradient %.1e" % (
-        name, t.n_lanes, t.n_cells, done, skipped, wq, wg), flush=True)
+    print("%-22s %4d lanes %5d cells: %d schedules vs the oracle (%d refused%s): queues %.1e, gradient %.1e" % (
+        name, t.n_lanes, t.n_cells, done, skipped, ": %s" % why if why else "", wq, wg), flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
