@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""The REFERENCE against the oracle on random environment shapes the goldens do not hold (build container only, CPU only: the reference
+is imported through tools/gen_goldens.py in a child process -- its packages share names with the mirror's --, the oracle runs on the
+fixture the child wrote under /tmp).  Per episode: queue terms, reward, vehicle count, d reward / d action, and whether either gradient
+is non-finite.  This is how the `micro`-mode Jacobian at the forward's clamps was pinned down (9 of 28 reference runs of congested
+8-second episodes finite where the oracle was not; tests/golden/itscp_micro_jam_*.npz are three of them).
+
+    python tools/probes/ref_sweep.py <worker id> <n episodes> [hybrid]        (several workers side by side: one per core)
+
+`hybrid`: 2x2 / 3x3 grids of short lanes over 12-20 s (episodes in which the flux capacitors spawn vehicles; minutes each).
+A line ending in LOOK is outside 1e-5 / 1e-4; tools/probes/oracle_environment.py's two library switches (numpy's float32 mean tree, this
+torch build's float32 sqrt) say whether it is the reference's own environment (profiles/r06z_reference_sweep.log: the one such line is)."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+if len(sys.argv) > 1 and sys.argv[1] == "--gen":          # child: the reference's run of one episode -> <out>/itscp_<name>.npz
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_goldens as G
+    out, name, mode, n_int, n_lane, ll, pol, sig, seed, pb, hard, sl = sys.argv[2:]
+    G.OUT = out
+    os.environ.pop("DHTS_FINE_CUTS", None)
+    os.environ.pop("DHTS_LANE_LATE", None)
+    G.gen_itscp(name, mode, int(n_int), int(n_lane), float(ll), int(pol), int(sig), seed=int(seed), action_kind="rand", problem=int(pb),
+                differentiable=not int(hard), speed_limit=float(sl))
+    sys.exit(0)
+
+sys.path[:0] = [ROOT, os.path.join(ROOT, "diff-hybrid-traffic-sim_amd"), os.path.join(ROOT, "tests")]
+from test_oracle_golden import itscp_hybrid_tables, itscp_micro_tables, itscp_tables      # noqa: E402
+from dhts.network import group_routes      # noqa: E402
+from oracle import oracle as O      # noqa: E402
+
+O.build()
+w, n = int(sys.argv[1]), int(sys.argv[2])
+hybrid_only = len(sys.argv) > 3 and sys.argv[3] == "hybrid"
+OUT = "/tmp/dhts_ref_sweep/%s%d" % ("h" if hybrid_only else "w", w)
+os.makedirs(OUT, exist_ok=True)
+rng = np.random.default_rng((5000 if hybrid_only else 1000) + w)
+for k in range(n):
+    if hybrid_only:
+        mode = "hybrid"
+        n_int, n_lane = int(rng.choice([2, 3, 3])), int(rng.choice([1, 1, 2]))
+        ll, sl = float(rng.choice([5, 10, 15])), float(rng.choice([45, 60]))
+        pol, sig = int(rng.choice([12, 16, 20])), int(rng.choice([2, 4]))
+    else:
+        mode = ("macro", "hybrid", "micro")[int(rng.integers(3))]
+        n_int, n_lane = int(rng.integers(1, 3)), int(rng.integers(1, 4))
+        ll, sl = float(rng.choice([5, 10, 15, 20, 30, 40, 60])), float(rng.choice([30, 45, 60]))
+        pol = int(rng.choice([4, 6, 8, 10, 12]))
+        sig = min(int(rng.choice([1, 2, 4])), pol)
+    pb, seed, hard = int(rng.integers(1, 4)), int(rng.integers(1 << 16)), bool(rng.integers(5) == 0)
+    name = "sweep_%d_%d" % (w, k)
+    tag = "%s %dx%d x%d %gm %gm/s %ds/%ds p%d seed %d %s" % (mode, n_int, n_int, n_lane, ll, sl, pol, sig, pb, seed, "eval" if hard else "train")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gen", OUT, name, mode, str(n_int), str(n_lane), str(ll), str(pol), str(sig),
+                        str(seed), str(pb), str(int(hard)), str(sl)], capture_output=True, text=True)
+    if r.returncode != 0:
+        print("RESULT", tag, "| reference ends with:", r.stderr.strip().splitlines()[-1][:120] if r.stderr.strip() else r.returncode, flush=True)
+        continue
+    g = np.load(os.path.join(OUT, "itscp_%s.npz" % name))
+    if mode == "macro":
+        t, m = itscp_tables(g)
+    elif mode == "micro":
+        t, m, rows = itscp_micro_tables(g)
+    else:
+        t, m = itscp_hybrid_tables(g)
+        rows = g["spawn_routes"] if g["spawn_routes"].shape[0] else -np.ones((1, 2), np.int32)
+    args = (m["num_intersection"] ** 2, m["simulation_frequency"] * m["signal_length"], 1.0 / m["simulation_frequency"], m["speed_limit"],
+            m["static_speed"], m["vehicle_length"])
+    if mode == "macro":
+        o = O.net_macro(t, g["action"], *args, hard=hard)
+    else:
+        routes, ptr = group_routes(rows, t.n_lanes)
+        o = O.net_hybrid(t, routes, ptr, g["action"], *args, hard=hard, want_grad=not hard)
+    q, gq = o["queue"].T.astype(np.float32), g["queue"].astype(np.float32)
+    eq = np.abs(q - gq).max() / max(np.abs(gq).max(), 1e-30)
+    er = abs(o["reward"] - float(g["reward"])) / max(abs(float(g["reward"])), 1e-30)
+    eg, fin = 0.0, ""
+    if not hard:
+        ga, oa = g["g_action"], o["g_action"]
+        if np.isfinite(ga).all() and np.isfinite(oa).all():
+            eg = np.abs(oa - ga).max() / max(np.abs(ga).max(), 1e-30)
+        else:
+            eg = float("nan")
+            fin = " NON-FINITE: reference %d, oracle %d entries" % ((~np.isfinite(ga)).sum(), (~np.isfinite(oa)).sum())
+    veh = "" if mode == "macro" else " vehicles %s/%s" % (o["n_spawned"], m.get("n_vehicle_spawned"))
+    look = o["rc"] != 0 or eq > 1e-5 or er > 1e-5 or not (eg <= 1e-4) or (mode != "macro" and o["n_spawned"] != m.get("n_vehicle_spawned"))
+    print("RESULT", tag, "| %d lanes rc %d queues %.1e reward %.1e gradient %.1e%s%s (%.0f s)%s" % (
+        len(g["lane_tab"]), o["rc"], eq, er, eg, fin, veh, time.time() - t0, "  <-- LOOK" if look else ""), flush=True)
