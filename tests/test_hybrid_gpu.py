@@ -545,13 +545,13 @@ def _plain_three_lane_tables(N, dx, T):
     return HybridNetworkTables.plain([1, 0, 1], [N, 0, N], [N * dx] * 3, [(0, 1), (1, 2)], T, macro_route=[1, -1, -1])
 
 
-def _fused_three_lane(cuda, r0, u0, bd_r, bd_u, N, T, dx, dt, um):
+def _fused_three_lane(cuda, r0, u0, bd_r, bd_u, N, T, dx, dt, um, lane_capacity=0):
     """The network of example/inverse/hybrid.py through the fused kernels: lane 0 starts from (r0, u0), lane 2 empty, stored
     ghosts bd_*[0..3] = (lane 0 left, lane 0 right, lane 2 left, lane 2 right)."""
     import torch
     from dhts import ops
     tab = _plain_three_lane_tables(N, dx, T)
-    dtab = ops.DeviceHybridTables(tab, np.array([[1, 2]], dtype=np.int32), cuda)
+    dtab = ops.DeviceHybridTables(tab, np.array([[1, 2]], dtype=np.int32), cuda, lane_capacity=lane_capacity)
     r_all = torch.cat([r0, torch.zeros(N, device=cuda)])[None]
     u_all = torch.cat([u0, torch.full((N,), um, device=cuda)])[None]
     ghost0 = torch.tensor([[[bd_r[0], bd_u[0], bd_r[1], bd_u[1]], [0.0, um, 0.0, um], [bd_r[2], bd_u[2], bd_r[3], bd_u[3]]]],
@@ -559,14 +559,16 @@ def _fused_three_lane(cuda, r0, u0, bd_r, bd_u, N, T, dx, dt, um):
     return ops.net_hybrid_state_rollout(r_all, u_all, dtab, dt, um, ghost0=ghost0, plain=True)
 
 
-def test_fused_state_rollout_matches_reference_three_lane_network(cuda, golden_dir):
+@pytest.mark.parametrize("name", ["hybrid3", "hybrid3_b", "hybrid3_c", "hybrid3_d"])
+def test_fused_state_rollout_matches_reference_three_lane_network(cuda, golden_dir, name):
     """example/inverse/hybrid.py's macro -> micro -> macro network (G7, 500 steps of the reference's RoadNetwork.forward) in ONE
     launch each way: the fused hybrid kernels started from the given state of lane 0 with the stored ghosts of the example, taps
     on the final state of all three lanes.  Spawn / deposit steps, vehicle count per step's end, final states <= 1e-5, the loss
-    and d loss / d (r0, u0) <= 1e-4 of the reference's run."""
+    and d loss / d (r0, u0) <= 1e-4 of the reference's run.  hybrid3_b / _c / _d (round 6): 16 / 8 / 12 cells per lane, 400 / 700 / 600
+    steps, u_max 20 in _c, dt 0.02 in _d, other initial states and ghosts (7 / 19 / 22 events)."""
     import json
     import torch
-    g = np.load(os.path.join(golden_dir, "hybrid_hybrid3.npz"))
+    g = np.load(os.path.join(golden_dir, "hybrid_%s.npz" % name))
     m = json.loads(str(g["meta"]))
     N, T, dx, dt, um = m["N"], m["T"], m["dx"], m["dt"], m["u_max"]
     r0 = torch.tensor(g["r0"], device=cuda, requires_grad=True)

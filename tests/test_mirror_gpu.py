@@ -243,14 +243,15 @@ def test_inverse_examples_reduce_the_error(cuda, tmp_path):
     assert np.allclose(logs["h"], logs["hl"], rtol=2e-4, atol=1e-6), (logs["h"], logs["hl"])
 
 
-def test_hybrid_three_lane_network_like_example(cuda, golden_dir):
+@pytest.mark.parametrize("name", ["hybrid3", "hybrid3_b", "hybrid3_c", "hybrid3_d"])
+def test_hybrid_three_lane_network_like_example(cuda, golden_dir, name):
     """example/inverse/hybrid.py's network macro(0) -> micro(1) -> macro(2) through the mirror (G7): flux-capacitor
     spawning, micro -> macro hand-off with the ancillary variable `a`, same event times, states and gradients."""
     import torch
     from road.lane.dmacro_lane import dMacroLane
     from road.lane.dmicro_lane import dMicroLane
     from road.network.road_network import RoadNetwork
-    g = load(golden_dir, "hybrid_hybrid3.npz")
+    g = load(golden_dir, "hybrid_%s.npz" % name)
     m = meta_of(g)
     N, T, dx, dt, um = m["N"], m["T"], m["dx"], m["dt"], m["u_max"]
     np.random.seed(m["seed"])

@@ -891,6 +891,7 @@ def gen_macro_state_of_micro_lane(seed=3):
 
 
 def main():
+    global OUT
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="G1,G3,G4,G5,G6")
     ap.add_argument("--g4", default="c1,sanity,small,bench64,long")
@@ -915,8 +916,25 @@ def main():
         gen_micro_rollouts(set(args.g6.split(",")))
     if "G7" in only:
         gen_hybrid()
+        # other sizes, horizons, speed limits and initial states of the same three-lane network (round 6)
+        gen_hybrid("hybrid3_b", N=16, T=400, seed=5)
+        gen_hybrid("hybrid3_c", N=8, T=700, um=20.0, seed=9)
+        gen_hybrid("hybrid3_d", N=12, T=600, dt=0.02, seed=33)
     if "G9" in only:
         gen_macro_state_of_micro_lane()
+    if "G7x" in only:                # 72 random cases of the three-lane network for tools/probes/three_lane_cases.py: not fixtures -- written to
+        #                              the untracked gpurun_in/ (it travels to the GPU box with the snapshot), a few seconds each
+        OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_in")
+        os.makedirs(OUT, exist_ok=True)
+        for w in range(6):
+            rng = np.random.default_rng(300 + w)
+            for k in range(12):
+                N, T = int(rng.integers(4, 25)), int(rng.integers(200, 1001))
+                um, dx = float(rng.choice([15.0, 20.0, 30.0, 35.0])), float(rng.choice([2.5, 5.0, 10.0]))
+                dt = float(rng.choice([0.005, 0.01, 0.02, 0.04]))
+                if dt * um / dx > 0.3:
+                    dt = 0.01
+                gen_hybrid("case_%d_%d" % (w, k), N=N, T=T, dx=dx, dt=dt, um=um, seed=int(rng.integers(1 << 16)))
     if "G8" in only:                 # run_itscp_macro.sh / run_itscp_hybrid.sh flag sets (+ a small macro case)
         which = set(args.g8.split(","))
         if "macro_small" in which:
