@@ -922,6 +922,27 @@ def main():
         gen_hybrid("hybrid3_d", N=12, T=600, dt=0.02, seed=33)
     if "G9" in only:
         gen_macro_state_of_micro_lane()
+    if "G4x" in only or "G6x" in only:      # random straight lanes for tools/probes/lane_cases.py (untracked gpurun_in/, like G7x)
+        OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_in")
+        os.makedirs(OUT, exist_ok=True)
+        rng = np.random.default_rng(4600)
+        for k in range(48 if "G4x" in only else 0):
+            N, T = int(rng.integers(3, 97)), int(rng.integers(10, 401))
+            dx, um = float(rng.choice([2.5, 5.0, 10.0, 100.0])), float(rng.choice([15.0, 30.0]))
+            dt = float(rng.choice([0.1, 0.2, 0.3]) * dx / um)             # (dt u_max / dx <= 0.3: inside the reference's CFL assert)
+            try:
+                macro_rollout("case_%d" % k, N, T, dx, dt, um, seed=int(rng.integers(1 << 16)), init=str(rng.choice(["uniform", "bench", "sanity"])),
+                              tap=str(rng.choice(["final_sq", "every_sum"])), record_steps=int(min(T, 4)))
+            except AssertionError as e:
+                print("G4x case_%d: the reference asserts: %s" % (k, str(e)[:80]))
+        rng = np.random.default_rng(4601)
+        for k in range(48 if "G6x" in only else 0):
+            V, T = int(rng.integers(1, 49)), int(rng.integers(10, 601))
+            spacing = float(rng.choice([1.3, 2.0, 4.0]))                  # (in vehicle lengths; the jitter keeps add_vehicle's spacing assert)
+            micro_rollout("case_%d" % k, V, T, float(rng.choice([0.01, 1.0 / 30.0, 0.05])), float(rng.choice([13.5, 20.0, 30.0])),
+                          seed=int(rng.integers(1 << 16)), params=str(rng.choice(["default", "random"])), tap=str(rng.choice(["final_sq", "every_sum"])),
+                          record_steps=int(min(T, 4)),
+                          spacing=spacing, jitter=float(rng.choice([0.2, 0.5, 0.9])) * (spacing - 1.0))
     if "G7x" in only:                # 72 random cases of the three-lane network for tools/probes/three_lane_cases.py: not fixtures -- written to
         #                              the untracked gpurun_in/ (it travels to the GPU box with the snapshot), a few seconds each
         OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_in")
