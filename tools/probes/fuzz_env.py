@@ -50,10 +50,23 @@ for trial in range(n_env):
     args = (env.num_intersection ** 2, env.config["signal_length"] * env.config["simulation_frequency"],
             1.0 / env.config["simulation_frequency"], env.simulator.speed_limit, env.config["static_speed"], env.simulator.vehicle_length)
     # the checker's run, on the environment's own host tables
+    # a quarter of the hybrid / micro environments: every vehicle with attributes of its own (micro_vehicle.py:75-121's ranges; hybrid: drawn
+    # for 0.7 x the speed limit, so that a deposited vehicle stays inside the ARZ cells' CFL bound) -- dhts_hybrid_tables::veh_params
+    own = mode != "macro" and bool(rng.integers(4) == 0)
+
+    def attributes(limit):
+        u = rng.random(5)
+        return [limit * (1.5 + 0.5 * u[0]), limit * (1.0 + 0.5 * u[1]), limit * (0.8 + 0.4 * u[2]), 5.0 * (0.2 + 0.2 * u[3]), 0.2 + 0.4 * u[4], 5.0]
+    if own and mode == "micro":
+        for waiting in env.simulator.lane_waiting_micro_vehicle.values():
+            for v in waiting:
+                v.accel_max, v.accel_pref, v.target_speed, v.min_space, v.time_pref, v.length = attributes(env.simulator.speed_limit)
     if mode == "macro":
         tab = MacroNetworkTables.from_env(env)
     else:
         tab, routes, vp = env._fused_episode_inputs()
+        if own and mode == "hybrid":
+            vp = env.fused_vehicle_params = np.array([attributes(0.7 * env.simulator.speed_limit) for _ in range(len(routes))])
         if mode == "micro":
             draws = rng.random(env._fused_n_draws)
             env.fused_draws = draws
@@ -72,8 +85,9 @@ for trial in range(n_env):
         else:
             gr, ptr, gvp = group_routes(routes, tab.n_lanes, vp)
         ref = O.net_hybrid(tab, gr, ptr, act, *args, hard=hard, want_grad=not hard, vehicle_params=gvp)
-    tag = "%-6s %dx%d x%d lanes of %4.0f m, %2.0f m/s, %d s / %d s, %s" % (
-        mode, n_int, n_int, n_lane, cfg["lane_length"], cfg["speed_limit"], cfg["policy_length"], cfg["signal_length"], "eval " if hard else "train")
+    tag = "%-6s %dx%d x%d lanes of %4.0f m, %2.0f m/s, %d s / %d s, %s%s" % (
+        mode, n_int, n_int, n_lane, cfg["lane_length"], cfg["speed_limit"], cfg["policy_length"], cfg["signal_length"], "eval " if hard else "train",
+        ", own attributes" if own else "")
     if ref["rc"] != 0:
         # a CFL violation (rc 1) is the reference's assert: the product must fault as well, not return numbers
         verdict = ""
