@@ -5,7 +5,7 @@ fixture the child wrote under /tmp).  Per episode: queue terms, reward, vehicle 
 is non-finite.  This is how the `micro`-mode Jacobian at the forward's clamps was pinned down (9 of 28 reference runs of congested
 8-second episodes finite where the oracle was not; tests/golden/itscp_micro_jam_*.npz are three of them).
 
-    python tools/probes/ref_sweep.py <worker id> <n episodes> [hybrid]        (several workers side by side: one per core)
+    python tools/probes/ref_sweep.py <worker id> <n episodes> [hybrid | big]        (several workers side by side: one per core)
 
 `hybrid`: 2x2 / 3x3 grids of short lanes over 12-20 s (episodes in which the flux capacitors spawn vehicles; minutes each).
 A line ending in LOOK is outside 1e-5 / 1e-4; tools/probes/oracle_environment.py's two library switches (numpy's float32 mean tree, this
@@ -38,11 +38,17 @@ from oracle import oracle as O      # noqa: E402
 O.build()
 w, n = int(sys.argv[1]), int(sys.argv[2])
 hybrid_only = len(sys.argv) > 3 and sys.argv[3] == "hybrid"
-OUT = "/tmp/dhts_ref_sweep/%s%d" % ("h" if hybrid_only else "w", w)
+big = len(sys.argv) > 3 and sys.argv[3] == "big"          # 3x3 grids in macro / micro mode (144 .. 360 lanes; a few minutes each)
+OUT = "/tmp/dhts_ref_sweep/%s%d" % ("h" if hybrid_only else ("b" if big else "w"), w)
 os.makedirs(OUT, exist_ok=True)
-rng = np.random.default_rng((5000 if hybrid_only else 1000) + w)
+rng = np.random.default_rng((5000 if hybrid_only else (9000 if big else 1000)) + w)
 for k in range(n):
-    if hybrid_only:
+    if big:
+        mode = ("macro", "micro")[int(rng.integers(2))]
+        n_int, n_lane = 3, int(rng.integers(1, 3))
+        ll, sl = float(rng.choice([10, 20, 30])), float(rng.choice([30, 45, 60]))
+        pol, sig = int(rng.choice([4, 6, 8])), int(rng.choice([1, 2, 4]))
+    elif hybrid_only:
         mode = "hybrid"
         n_int, n_lane = int(rng.choice([2, 3, 3])), int(rng.choice([1, 1, 2]))
         ll, sl = float(rng.choice([5, 10, 15])), float(rng.choice([45, 60]))
