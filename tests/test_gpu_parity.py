@@ -193,7 +193,7 @@ def test_macro_step_vs_golden_and_oracle(cuda, oracle, golden_dir, name):
     assert np.allclose(gg[0], [ref_r[0], ref_y[0]], rtol=1e-6, atol=1e-7) and np.allclose(gg[1], [ref_r[-1], ref_y[-1]], rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("name", ["small", "c1", "sanity", "bench64", "long"])
+@pytest.mark.parametrize("name", ["small", "c1", "sanity", "bench64", "long", "x3", "x5", "x10", "x22", "x31", "x40"])   # x<k>: random shapes (gen_goldens --only G4x,Gx_pick)
 def test_macro_rollout_vs_golden(cuda, golden_dir, name):
     """Autograd-level drop-in (dhts.macro_rollout) against the reference's rollouts and gradients (G4)."""
     import torch
@@ -692,7 +692,7 @@ def micro_inputs(g, cuda):
     return params
 
 
-@pytest.mark.parametrize("name", ["inv10", "rand24", "dense16", "long"])
+@pytest.mark.parametrize("name", ["inv10", "rand24", "dense16", "long", "x2", "x9", "x15", "x23", "x37", "x44"])   # x<k>: random shapes (gen_goldens --only G6x,Gx_pick)
 def test_micro_rollout_vs_golden(cuda, golden_dir, name):
     import torch
     import dhts

@@ -559,7 +559,7 @@ def _fused_three_lane(cuda, r0, u0, bd_r, bd_u, N, T, dx, dt, um, lane_capacity=
     return ops.net_hybrid_state_rollout(r_all, u_all, dtab, dt, um, ghost0=ghost0, plain=True)
 
 
-@pytest.mark.parametrize("name", ["hybrid3", "hybrid3_b", "hybrid3_c", "hybrid3_d"])
+@pytest.mark.parametrize("name", ["hybrid3", "hybrid3_b", "hybrid3_c", "hybrid3_d", "x0_1", "x1_4", "x2_11", "x3_1", "x4_0", "x5_9"])
 def test_fused_state_rollout_matches_reference_three_lane_network(cuda, golden_dir, name):
     """example/inverse/hybrid.py's macro -> micro -> macro network (G7, 500 steps of the reference's RoadNetwork.forward) in ONE
     launch each way: the fused hybrid kernels started from the given state of lane 0 with the stored ghosts of the example, taps
@@ -573,7 +573,14 @@ def test_fused_state_rollout_matches_reference_three_lane_network(cuda, golden_d
     N, T, dx, dt, um = m["N"], m["T"], m["dx"], m["dt"], m["u_max"]
     r0 = torch.tensor(g["r0"], device=cuda, requires_grad=True)
     u0 = torch.tensor(g["u0"], device=cuda, requires_grad=True)
-    rT, yT, uT, veh, events, counts = _fused_three_lane(cuda, r0, u0, g["bd_r"], g["bd_u"], N, T, dx, dt, um)
+    # (x<k>: random shapes, tools/gen_goldens.py --only G7x,Gx_pick; x0_1's 230 m lane holds 17 vehicles at the end: beyond the default
+    # 16 slots per lane -- a capacity fault there -- so it runs with dhts_hybrid_tables::lane_capacity = 128)
+    if name == "x0_1":
+        from dhts import ops
+        with pytest.raises(ops.CapacityError):
+            _fused_three_lane(cuda, r0, u0, g["bd_r"], g["bd_u"], N, T, dx, dt, um)
+    rT, yT, uT, veh, events, counts = _fused_three_lane(cuda, r0, u0, g["bd_r"], g["bd_u"], N, T, dx, dt, um,
+                                                        lane_capacity=128 if name == "x0_1" else 0)
     n_ev = int(counts[0, 3])
     ev = events[0, :n_ev].cpu().numpy()
     assert [(int(a), int(b)) for a, b in ev] == [(int(e[0]), int(e[1])) for e in g["events"]]

@@ -243,7 +243,7 @@ def test_inverse_examples_reduce_the_error(cuda, tmp_path):
     assert np.allclose(logs["h"], logs["hl"], rtol=2e-4, atol=1e-6), (logs["h"], logs["hl"])
 
 
-@pytest.mark.parametrize("name", ["hybrid3", "hybrid3_b", "hybrid3_c", "hybrid3_d"])
+@pytest.mark.parametrize("name", ["hybrid3", "hybrid3_b", "hybrid3_c", "hybrid3_d", "x1_4", "x2_11", "x5_9"])
 def test_hybrid_three_lane_network_like_example(cuda, golden_dir, name):
     """example/inverse/hybrid.py's network macro(0) -> micro(1) -> macro(2) through the mirror (G7): flux-capacitor
     spawning, micro -> macro hand-off with the ancillary variable `a`, same event times, states and gradients."""

@@ -53,7 +53,7 @@ def test_macro_step(oracle, golden_dir, name):
 
 
 # ---- G4: macro rollouts ---------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["small", "c1", "sanity", "bench64", "long", "c2slice"])
+@pytest.mark.parametrize("name", ["small", "c1", "sanity", "bench64", "long", "c2slice", "x3", "x5", "x10", "x22", "x31", "x40"])
 def test_macro_rollout(oracle, golden_dir, name):
     g = load(golden_dir, "macro_rollout_%s.npz" % name)
     m = meta_of(g)
@@ -106,7 +106,7 @@ def test_idm_kat_bit_exact(oracle, golden_dir):
 
 
 # ---- G6: micro rollouts: bit-exact state AND gradients ---------------------------------------------------------
-@pytest.mark.parametrize("name", ["inv10", "rand24", "dense16", "long", "c3slice"])
+@pytest.mark.parametrize("name", ["inv10", "rand24", "dense16", "long", "c3slice", "x2", "x9", "x15", "x23", "x37", "x44"])
 def test_micro_rollout_bit_exact(oracle, golden_dir, name):
     g = load(golden_dir, "micro_rollout_%s.npz" % name)
     m = meta_of(g)

@@ -943,6 +943,16 @@ def main():
                           seed=int(rng.integers(1 << 16)), params=str(rng.choice(["default", "random"])), tap=str(rng.choice(["final_sq", "every_sum"])),
                           record_steps=int(min(T, 4)),
                           spacing=spacing, jitter=float(rng.choice([0.2, 0.5, 0.9])) * (spacing - 1.0))
+    if "Gx_pick" in only:            # eighteen of the random cases above become committed fixtures (tests/golden/*_x<k>.npz): run after G4x,G6x,G7x
+        import shutil
+        src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_in")
+        dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+        for k in (3, 5, 10, 22, 31, 40):
+            shutil.copy(os.path.join(src, "macro_rollout_case_%d.npz" % k), os.path.join(dst, "macro_rollout_x%d.npz" % k))
+        for k in (2, 9, 15, 23, 37, 44):
+            shutil.copy(os.path.join(src, "micro_rollout_case_%d.npz" % k), os.path.join(dst, "micro_rollout_x%d.npz" % k))
+        for k in ("0_1", "1_4", "2_11", "3_1", "4_0", "5_9"):
+            shutil.copy(os.path.join(src, "hybrid_case_%s.npz" % k), os.path.join(dst, "hybrid_x%s.npz" % k))
     if "G7x" in only:                # 72 random cases of the three-lane network for tools/probes/three_lane_cases.py: not fixtures -- written to
         #                              the untracked gpurun_in/ (it travels to the GPU box with the snapshot), a few seconds each
         OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_in")
