@@ -156,7 +156,7 @@ def itscp_tables(g):
     return MacroNetworkTables(tab[:, 3].astype(int), tab[:, 2], g["edges"], kinds, inter, g["macro_route"], g["schedule"]), m
 
 
-@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "macro_half", "macro_long", "macro_3x3x3"])
+@pytest.mark.parametrize("name", ["macro_small", "macro", "macro_2x2", "macro_half", "macro_long", "macro_3x3x3", "sweep_b"])      # sweep_*: ref_sweep.py's shapes
 def test_itscp_macro_network(oracle, golden_dir, name):
     g = load(golden_dir, "itscp_%s.npz" % name)
     t, m = itscp_tables(g)
@@ -169,7 +169,7 @@ def test_itscp_macro_network(oracle, golden_dir, name):
     assert grad_report("G8 %s d reward / d action" % name, o["g_action"], g["g_action"]) <= TOL_GRAD
 
 
-@pytest.mark.parametrize("name", ["eval_macro", "eval_macro_2x2", "eval_macro_3x3x3"])
+@pytest.mark.parametrize("name", ["eval_macro", "eval_macro_2x2", "eval_macro_3x3x3", "sweep_a"])
 def test_itscp_macro_network_evaluation_episode(oracle, golden_dir, name):
     """ItscpEnv.step(action, False) of the reference (what Trainer.evaluate runs): hard signals, hard ghost switch, hard
     is_static.  The queue terms are squares of sums of whole cells' vehicle counts, so a cell whose speed crosses
@@ -208,7 +208,7 @@ FULL_HORIZON_600 = ["hybrid_half", "hybrid_s2", "hybrid_s3", "hybrid_p2_600"]   
 # round 5: hybrid_l30 (30 m lanes), hybrid_5x5 (144 IDM lanes) and hybrid_n2l30 (252 lanes + 1 300 cells) pin the oracle where the
 # fused kernels do not reach (or only just): the stepwise device path is judged by it there
 @pytest.mark.parametrize("name", ["hybrid_short", "hybrid_p2", "hybrid_p3", "hybrid_l10", "hybrid_n2", "hybrid_4x4", "hybrid", "hybrid_l30",
-                                  "hybrid_5x5", "hybrid_n2l30"] + FULL_HORIZON_600)
+                                  "hybrid_5x5", "hybrid_n2l30", "sweep_g"] + FULL_HORIZON_600)
 def test_itscp_hybrid_network(oracle, golden_dir, name):
     """G8 hybrid: macro lanes, micro lanes, spawns, lane changes and deposits against the reference's own run.
     FULL_HORIZON_600 = four reference runs of BASELINE config 4's exact episode (3 x 3 intersections, 1 lane, 5 m, 20 s,
@@ -286,7 +286,7 @@ def test_restricted_gradient_lattice_of_the_standing_vehicle(oracle, golden_dir)
     assert np.abs(d570).max() <= 8 * q
 
 
-@pytest.mark.parametrize("name", ["eval_hybrid_short", "eval_hybrid_p2", "eval_hybrid", "eval_hybrid_4x4", "eval_hybrid_n2l30", "eval_hybrid_5x5"])
+@pytest.mark.parametrize("name", ["eval_hybrid_short", "eval_hybrid_p2", "eval_hybrid", "eval_hybrid_4x4", "eval_hybrid_n2l30", "eval_hybrid_5x5", "sweep_f"])
 def test_itscp_hybrid_network_evaluation_episode(oracle, golden_dir, name):
     """Evaluation episodes of the hybrid network (240 steps; 480 steps over problem_2's inflows; BASELINE config 4's 600-step
     episode): hard signals and boundaries, head gap = green iff the lane's own signal >= 0.5, hard is_static for cells and
@@ -337,7 +337,7 @@ def itscp_vehicle_params(g):
     return np.asarray(rows, dtype=np.float64)
 
 
-@pytest.mark.parametrize("name", ["micro_small", "micro", "micro_2x2", "micro_p2", "micro_l10", "micro_jam_a", "micro_jam_b", "micro_jam_c"])
+@pytest.mark.parametrize("name", ["micro_small", "micro", "micro_2x2", "micro_p2", "micro_l10", "micro_jam_a", "micro_jam_b", "micro_jam_c", "sweep_c", "sweep_e"])
 def test_itscp_micro_mode_network(oracle, golden_dir, name):
     """itscp `micro` mode (run_itscp_micro.sh: 40 IDM lanes, 65 vehicles admitted stochastically over 300 steps; and a 16-lane
     case): source lanes admit waiting vehicles against the host's recorded draws (_simulator.py:153-174), every recorded draw
@@ -382,7 +382,7 @@ def test_persistent_form_pays_up_to_a_workgroup_of_lanes(golden_dir):
     assert not persistent_form_pays(big)
 
 
-@pytest.mark.parametrize("name", ["eval_micro_small", "eval_micro", "eval_micro_2x2"])
+@pytest.mark.parametrize("name", ["eval_micro_small", "eval_micro", "eval_micro_2x2", "sweep_d"])
 def test_itscp_micro_mode_evaluation_episode(oracle, golden_dir, name):
     """Evaluation episodes in `micro` mode (round 5 fixtures): without gradients nothing in the reference is a tensor -- Python floats all
     the way --, so the lanes step in the analytic operator's float64 ladder here (not the float32 tensor ladder of the differentiable

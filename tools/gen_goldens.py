@@ -1128,6 +1128,16 @@ def main():
                 os.environ.pop("DHTS_FINE_CUTS", None)
                 os.environ.pop("DHTS_LANE_LATE", None)
                 gen_itscp(nm, "micro", 1, 3, 60.0, 8, 1, seed=sd, action_kind="rand", problem=pb)
+        # seven episodes of tools/probes/ref_sweep.py's random shapes: speed limits other than 60 m/s, episodes with more than 128 vehicles
+        # (beyond the fused kernels: the stepwise path), a 252-lane `micro` grid
+        for nm, a_ in (("sweep_a", ("macro", 2, 2, 20.0, 6, 1, 57327, 2, False, 30.0)), ("sweep_b", ("macro", 1, 3, 10.0, 4, 2, 19269, 1, True, 30.0)),
+                       ("sweep_c", ("micro", 2, 2, 20.0, 8, 4, 24407, 2, True, 30.0)), ("sweep_d", ("micro", 2, 3, 10.0, 10, 2, 13207, 2, False, 30.0)),
+                       ("sweep_e", ("micro", 3, 2, 30.0, 6, 2, 45800, 2, True, 30.0)), ("sweep_f", ("hybrid", 3, 1, 10.0, 16, 2, 43887, 3, False, 45.0)),
+                       ("sweep_g", ("hybrid", 3, 1, 10.0, 16, 4, 1323, 1, True, 45.0))):
+            if nm in which:
+                os.environ.pop("DHTS_FINE_CUTS", None)
+                os.environ.pop("DHTS_LANE_LATE", None)
+                gen_itscp(nm, a_[0], a_[1], a_[2], a_[3], a_[4], a_[5], seed=a_[6], action_kind="rand", problem=a_[7], differentiable=a_[8], speed_limit=a_[9])
         if "hybrid_short" in which:      # 8 s: enough for the first vehicles to cross the interior intersection
             gen_itscp("hybrid_short", "hybrid", 3, 1, 5.0, 8, 2, seed=9, action_kind="rand")
 
